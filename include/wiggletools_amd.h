@@ -1,0 +1,275 @@
+/*
+ * wiggletools_amd.h -- C ABI of the MI355X-native multiplexer / reducer engine.
+ *
+ * Two layers are declared here:
+ *
+ *  (1) DROP-IN LAYER.  The symbols the reference's own callers bind
+ *      (reference src/commandParser.c:500-569,635-651 call them; they are
+ *      declared in reference src/wiggletools.h:80-103 and
+ *      src/multiplexer.h:38-41, src/multiSet.h:32-33).  Same names, same C
+ *      signatures, same struct layouts (reference src/wiggleIterator.h:21-35,
+ *      src/multiplexer.h:21-36, src/multiSet.h:20-30), so that
+ *      libwiggletools_amd.so can be linked in place of multiplexer.o /
+ *      multiSet.o / reducers.o / setComparisons.o.  See INTEGRATION.md.
+ *
+ *  (2) BULK LAYER (wtamd_*).  Plain pointers + sizes.  This is what the
+ *      drop-in layer itself calls once it has drained the child iterators
+ *      into SoA batches, and what a bulk reader (BigWig section decoder)
+ *      or bench.py binds directly when the tracks are already resident
+ *      in HBM.
+ *
+ * No torch / C++ types appear in any signature.
+ */
+#ifndef WIGGLETOOLS_AMD_H_
+#define WIGGLETOOLS_AMD_H_
+
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* (1) DROP-IN LAYER                                                   */
+/* ------------------------------------------------------------------ */
+
+/* The reference spells its booleans `#define bool char`
+ * (reference src/wiggletools.h:18-22).  We cannot #define bool in a header
+ * that C++ also includes, so the ABI type is named explicitly. */
+typedef char wt_bool;
+
+typedef struct wiggleIterator_st WiggleIterator;
+typedef struct multiplexer_st Multiplexer;
+typedef struct multiset_st Multiset;
+
+/* Layout == reference src/wiggleIterator.h:21-35 (88 bytes on LP64). */
+struct wiggleIterator_st {
+    char *chrom;
+    int start;              /* 1-based, inclusive  */
+    int finish;             /* exclusive           */
+    double value;
+    void *valuePtr;
+    wt_bool done;
+    int strand;
+    void *data;
+    void (*pop)(WiggleIterator *);
+    void (*seek)(WiggleIterator *, const char *, int, int);
+    wt_bool overlaps;
+    double default_value;
+    WiggleIterator *append;
+};
+
+/* Layout == reference src/multiplexer.h:21-36.  `starts`/`finishes` are the
+ * reference's FibHeap pointers; this engine has no heaps and keeps them NULL. */
+struct multiplexer_st {
+    char *chrom;
+    int start;
+    int finish;
+    double *values;
+    double *default_values;
+    int count, inplay_count;
+    wt_bool *inplay;
+    WiggleIterator **iters;
+    wt_bool done;
+    wt_bool strict;
+    void (*pop)(Multiplexer *);
+    void (*seek)(Multiplexer *, const char *, int, int);
+    void *starts, *finishes;
+    void *data;
+};
+
+/* Layout == reference src/multiSet.h:20-30. */
+struct multiset_st {
+    char *chrom;
+    int start;
+    int finish;
+    double **values;
+    int count, inplay_count;
+    wt_bool *inplay;
+    Multiplexer **multis;
+    wt_bool done;
+    void *starts, *finishes;
+};
+
+/* Iterator core -- replaces reference src/wiggleIterator.c:20-70.
+ * (Provided so the library is self-contained; when linked into the reference
+ * build the reference's wiggleIterator.o may be kept instead -- the semantics
+ * are identical: ctor primes the first element, pop() guards on done.) */
+WiggleIterator *newWiggleIterator(void *data, void (*pop)(WiggleIterator *),
+                                  void (*seek)(WiggleIterator *, const char *, int, int),
+                                  double default_value, wt_bool overlapping);
+void pop(WiggleIterator *);
+void seek(WiggleIterator *, const char *, int, int);
+void runWiggleIterator(WiggleIterator *);
+void destroyWiggleIterator(WiggleIterator *);
+
+/* Multiplexer -- replaces reference src/multiplexer.c:22-169. */
+Multiplexer *newMultiplexer(WiggleIterator **iters, int count, wt_bool strict);
+Multiplexer *newCoreMultiplexer(void *data, int count, void (*pop)(Multiplexer *),
+                                void (*seek)(Multiplexer *, const char *, int, int));
+void popMultiplexer(Multiplexer *);
+void seekMultiplexer(Multiplexer *, const char *chrom, int start, int finish);
+void runMultiplexer(Multiplexer *);
+
+/* Multiset -- replaces reference src/multiSet.c:80-128. */
+Multiset *newMultiset(Multiplexer **multis, int count);
+void popMultiset(Multiset *);
+void seekMultiset(Multiset *, const char *chrom, int start, int finish);
+
+/* Reducers -- replace reference src/reducers.c (ctor lines in brackets). */
+WiggleIterator *SumReduction(Multiplexer *);      /* reducers.c:294-307 */
+WiggleIterator *ProductReduction(Multiplexer *);  /* reducers.c:348-361 */
+WiggleIterator *MeanReduction(Multiplexer *);     /* reducers.c:404-422 */
+WiggleIterator *VarianceReduction(Multiplexer *); /* reducers.c:481-505 */
+WiggleIterator *StdDevReduction(Multiplexer *);   /* reducers.c:565-590 */
+WiggleIterator *EntropyReduction(Multiplexer *);  /* reducers.c:640-666 */
+WiggleIterator *CVReduction(Multiplexer *);       /* reducers.c:727-751 */
+WiggleIterator *MedianReduction(Multiplexer *);   /* reducers.c:815-834 */
+WiggleIterator *MinReduction(Multiplexer *);      /* reducers.c:237-253 */
+WiggleIterator *MaxReduction(Multiplexer *);      /* reducers.c:170-186 */
+WiggleIterator *SelectReduction(Multiplexer *, int);      /* reducers.c:67-72, host */
+WiggleIterator *FillInReduction(Multiplexer *, wt_bool);  /* reducers.c:108-119, host */
+
+/* Two-sample tests -- replace reference src/setComparisons.c. */
+WiggleIterator *TTestReduction(Multiset *);  /* setComparisons.c:123-131 */
+WiggleIterator *MWUReduction(Multiset *);    /* setComparisons.c:372-390 */
+
+/* ------------------------------------------------------------------ */
+/* (2) BULK LAYER                                                      */
+/* ------------------------------------------------------------------ */
+
+/* Reducer selector.  One code per reference ...ReductionPop. */
+enum wtamd_op {
+    WTAMD_OP_SUM = 0,      /* SumReductionPop       reducers.c:259-292 */
+    WTAMD_OP_PRODUCT = 1,  /* ProductReductionPop   reducers.c:313-346 */
+    WTAMD_OP_MEAN = 2,     /* MeanReductionPop      reducers.c:367-402 */
+    WTAMD_OP_VAR = 3,      /* VarianceReductionPop  reducers.c:428-479 */
+    WTAMD_OP_STDDEV = 4,   /* StdDevReductionPop    reducers.c:511-563 */
+    WTAMD_OP_ENTROPY = 5,  /* == STDDEV pop (reducers.c:665 installs StdDevReductionPop) */
+    WTAMD_OP_CV = 6,       /* CVReductionPop        reducers.c:672-725 */
+    WTAMD_OP_MIN = 7,      /* MinReductionPop       reducers.c:192-235 */
+    WTAMD_OP_MAX = 8,      /* MaxReductionPop       reducers.c:125-168 */
+    WTAMD_OP_MEDIAN = 9,   /* MedianReductionPop    reducers.c:780-813 */
+    WTAMD_OP_TTEST = 10,   /* TTestReductionPop     setComparisons.c:35-121 */
+    WTAMD_OP_MWU = 11,     /* MWUReductionPop       setComparisons.c:269-370 */
+    WTAMD_OP_COUNT_ = 12
+};
+
+/* Flags for wtamd_reduce_desc.flags */
+#define WTAMD_STRICT_SET0 1u   /* Multiplexer `strict` (set 0, or the only set) */
+#define WTAMD_STRICT_SET1 2u   /* `strict` of the second Multiplexer (two-sample ops) */
+
+/* Status codes (every wtamd_* function returning int). */
+#define WTAMD_OK 0
+#define WTAMD_ERR_ARG 1        /* bad argument                         */
+#define WTAMD_ERR_HIP 2        /* HIP runtime error (see wtamd_last_error) */
+#define WTAMD_ERR_CAPACITY 3   /* output buffers too small             */
+#define WTAMD_ERR_NODEVICE 4   /* no gfx950 device visible             */
+#define WTAMD_ERR_INTERNAL 5   /* kernel reported an internal fault    */
+
+typedef struct wtamd_trackset wtamd_trackset; /* opaque: N tracks resident in HBM */
+
+/*
+ * Track storage ("run lists"): for chromosome c (0..n_chrom-1, already in
+ * strcmp order, cf. reference multiplexer.c:56) and track i (0..n_tracks-1)
+ * the intervals of that track on that chromosome are the slice
+ *     [seg_off[c*n_tracks+i], seg_off[c*n_tracks+i+1])
+ * of the three parallel arrays start[] (1-based inclusive), finish[]
+ * (exclusive) and value[].  Within a slice intervals are sorted and
+ * non-overlapping (the Multiplexer's precondition, multiplexer.c:163).
+ * value[] is float32 (BigWig payload type) or float64.
+ */
+typedef struct {
+    int32_t n_chrom;
+    int32_t n_tracks;
+    const int64_t *seg_off;   /* HOST pointer, n_chrom*n_tracks+1 entries */
+    const int32_t *start;     /* host or device, see create function */
+    const int32_t *finish;
+    const void *value;        /* float* or double* */
+    int32_t value_is_f64;     /* 0: float32, 1: float64 */
+    const double *defaults;   /* HOST pointer, n_tracks default_values */
+} wtamd_tracks;
+
+typedef struct {
+    int32_t op;        /* enum wtamd_op */
+    uint32_t flags;    /* WTAMD_STRICT_* */
+    int32_t n_set0;    /* two-sample ops: tracks [0,n_set0) = set 0, rest = set 1; else 0 */
+    int32_t reserved;
+} wtamd_reduce_desc;
+
+/* Output of one reduction: R runs in (chrom, start) order. All DEVICE pointers
+ * unless the _host entry point is used. */
+typedef struct {
+    int64_t capacity;        /* in: entries available in the arrays below */
+    int32_t *start;          /* out: run start  (1-based inclusive)  */
+    int32_t *finish;         /* out: run finish (exclusive)          */
+    double *value;           /* out: reducer value                   */
+    int64_t *chrom_run_off;  /* out: n_chrom+1 entries, runs of chrom c = [off[c],off[c+1]) */
+} wtamd_runs;
+
+/* Aggregate statistics of the last reduce on a trackset (for metrics). */
+typedef struct {
+    int64_t n_runs;          /* emitted runs                                   */
+    int64_t covered_bp;      /* sum(finish-start) of emitted runs              */
+    int64_t n_intervals;     /* input intervals examined                       */
+    int64_t n_windows;       /* alignment windows processed                    */
+    int32_t window_bp;       /* window width used                              */
+    int32_t lds_bytes;       /* LDS per workgroup                              */
+    float index_ms;          /* last window-index kernel time (HIP events)     */
+    float reduce_ms;         /* last multiplex+reduce kernel time (HIP events) */
+} wtamd_stats;
+
+int wtamd_device_count(void);
+int wtamd_set_device(int ordinal);
+const char *wtamd_last_error(void);
+const char *wtamd_version(void);
+
+/* Copies the SoA arrays from HOST memory into HBM. */
+int wtamd_trackset_create_host(const wtamd_tracks *tracks, wtamd_trackset **out);
+/* Zero-copy: start/finish/value are DEVICE pointers owned by the caller and
+ * must stay valid until wtamd_trackset_destroy. */
+int wtamd_trackset_create_device(const wtamd_tracks *tracks, wtamd_trackset **out);
+void wtamd_trackset_destroy(wtamd_trackset *);
+
+/* Upper bound on the number of runs any reduction over `ts` can emit. */
+int64_t wtamd_trackset_max_runs(const wtamd_trackset *ts);
+
+/* Build (or rebuild) the window index of `ts` on `stream` (hipStream_t as void*).
+ * wtamd_reduce() calls this itself when the index is missing; it is exposed so
+ * callers can time / amortise it separately. */
+int wtamd_trackset_index(wtamd_trackset *ts, void *stream);
+
+/* Multiplex + reduce, everything on device. `runs` arrays are DEVICE memory.
+ * *n_runs is written on the host after the stream has been synchronised iff
+ * n_runs != NULL (otherwise the call is fully asynchronous and the count can be
+ * read from chrom_run_off[n_chrom]). */
+int wtamd_reduce(wtamd_trackset *ts, const wtamd_reduce_desc *desc, wtamd_runs *runs,
+                 int64_t *n_runs, void *stream);
+
+/* Convenience: same, but `runs` arrays are HOST memory (internally staged). */
+int wtamd_reduce_host(wtamd_trackset *ts, const wtamd_reduce_desc *desc, wtamd_runs *runs,
+                      int64_t *n_runs);
+
+/* Multiplexer "materialise": emits the aligned tile the reference exposes per
+ * popMultiplexer (multiplexer.h:21-36): for each run r, values[r*n_tracks+i]
+ * and inplay[r*n_tracks+i].  HOST output.  Used by the drop-in layer when a
+ * Multiplexer* escapes to code that reads its fields. */
+int wtamd_multiplex_host(wtamd_trackset *ts, uint32_t flags, wtamd_runs *runs,
+                         double *values, uint8_t *inplay, int64_t *n_runs);
+
+/* Genome-wide scalar over the output of a reduction, computed on device:
+ * AUC = sum over runs of (finish-start)*value skipping NaN
+ * (reference statistics.c:103-120).  Result written to *auc (host). */
+int wtamd_runs_auc(const wtamd_runs *runs, int64_t n_runs, double *auc, void *stream);
+
+int wtamd_get_stats(const wtamd_trackset *ts, wtamd_stats *out);
+
+/* Default value a reducer iterator advertises to its parent
+ * (reference reducers.c ctor of each op, incl. float truncations). HOST only. */
+double wtamd_reducer_default(int op, int n_tracks, const double *defaults);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WIGGLETOOLS_AMD_H_ */

@@ -1,0 +1,288 @@
+"""ctypes front-end of the checker libraries (TEST INFRASTRUCTURE ONLY).
+
+* ``libwt_oracle.so``   -- our plain-C restatement (oracle/wt_oracle.c)
+* ``libref_harness.so`` -- driver of the compiled reference (oracle/_ref/...)
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg may
+import this module.  The product package (wiggletools_amd/) never does.
+
+Tracks are passed as a plain dict (see wiggletools_amd.runlists.RunLists.as_dict):
+    n_chrom, n_tracks, seg_off[int64], start[int32], finish[int32],
+    value[float64], defaults[float64]
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+OPS = {"sum": 0, "product": 1, "mean": 2, "var": 3, "stddev": 4, "entropy": 5, "cv": 6,
+       "min": 7, "max": 8, "median": 9, "ttest": 10, "mwu": 11}
+STRICT_SET0, STRICT_SET1 = 1, 2
+
+
+class _Tracks(C.Structure):
+    _fields_ = [("n_chrom", C.c_int32), ("n_tracks", C.c_int32),
+                ("seg_off", C.c_void_p), ("start", C.c_void_p), ("finish", C.c_void_p),
+                ("value", C.c_void_p), ("defaults", C.c_void_p)]
+
+
+def build(force=False):
+    """(Re)build the checker libraries with oracle/Makefile."""
+    need = force or not (os.path.exists(os.path.join(_HERE, "libwt_oracle.so"))
+                         and os.path.exists(os.path.join(_HERE, "libref_harness.so")))
+    ref_missing = not os.path.exists(os.path.join(_HERE, "_ref", "libwiggletools_ref.so"))
+    if need or (ref_missing and os.path.isdir("/root/reference/src")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+
+
+_oracle = None
+_ref = None
+
+
+def _pack(t):
+    keep = {
+        "seg_off": np.ascontiguousarray(t["seg_off"], dtype=np.int64),
+        "start": np.ascontiguousarray(t["start"], dtype=np.int32),
+        "finish": np.ascontiguousarray(t["finish"], dtype=np.int32),
+        "value": np.ascontiguousarray(t["value"], dtype=np.float64),
+        "defaults": np.ascontiguousarray(t["defaults"], dtype=np.float64),
+    }
+    s = _Tracks(int(t["n_chrom"]), int(t["n_tracks"]),
+                keep["seg_off"].ctypes.data, keep["start"].ctypes.data, keep["finish"].ctypes.data,
+                keep["value"].ctypes.data, keep["defaults"].ctypes.data)
+    return s, keep
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "libwt_oracle.so"))
+        L.wto_reduce.restype = C.c_int64
+        L.wto_reduce.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int, C.c_int64,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wto_multiplex.restype = C.c_int64
+        L.wto_multiplex.argtypes = [C.POINTER(_Tracks), C.c_uint, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wto_reducer_default.restype = C.c_double
+        L.wto_reducer_default.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.wto_auc.restype = C.c_double
+        L.wto_auc.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wto_compress.restype = C.c_int64
+        L.wto_compress.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.wto_tdist_Q.restype = C.c_double
+        L.wto_tdist_Q.argtypes = [C.c_double, C.c_double]
+        L.wto_ttest_stat.restype = None
+        L.wto_ttest_stat.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _oracle = L
+    return _oracle
+
+
+def have_ref():
+    build()
+    return os.path.exists(os.path.join(_HERE, "_ref", "libwiggletools_ref.so"))
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        build()
+        path = os.path.join(_HERE, "_ref", "libwiggletools_ref.so")
+        if not os.path.exists(path):
+            raise RuntimeError("compiled reference not available (oracle/_ref missing)")
+        L = C.CDLL(os.path.join(_HERE, "libref_harness.so"))
+        L.ref_open.argtypes = [C.c_char_p]
+        if L.ref_open(path.encode()) != 0:
+            raise RuntimeError("ref_open failed")
+        sig = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_reduce.restype = C.c_int64
+        L.ref_reduce.argtypes = sig
+        L.ref_reduce_compressed.restype = C.c_int64
+        L.ref_reduce_compressed.argtypes = sig
+        L.ref_reduce_seek.restype = C.c_int64
+        L.ref_reduce_seek.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_multiplex.restype = C.c_int64
+        L.ref_multiplex.argtypes = [C.POINTER(_Tracks), C.c_uint, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_multiset.restype = C.c_int64
+        L.ref_multiset.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int64,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_reducer_default.restype = C.c_double
+        L.ref_reducer_default.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.ref_auc_of_reduce.restype = C.c_double
+        L.ref_auc_of_reduce.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint]
+        L.ref_pearson.restype = C.c_double
+        L.ref_pearson.argtypes = [C.POINTER(_Tracks)]
+        L.ref_time_reduce.restype = C.c_double
+        L.ref_time_reduce.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_void_p, C.c_void_p]
+        L.ref_reduce_files.restype = C.c_int64
+        L.ref_reduce_files.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_uint, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        _ref = L
+    return _ref
+
+
+def _bound(t):
+    # every run starts at an interval start or finish
+    return 2 * int(len(t["start"])) + 8
+
+
+def _alloc(cap):
+    return (np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float64))
+
+
+def _trim(n, arrs):
+    if n < 0:
+        raise RuntimeError("checker returned %d" % n)
+    return tuple(a[:n].copy() for a in arrs)
+
+
+def _opcode(op):
+    return OPS[op] if isinstance(op, str) else int(op)
+
+
+def reduce(t, op, flags=0, n_set0=0):
+    """Oracle restatement: returns (chrom, start, finish, value) numpy arrays."""
+    L = oracle_lib()
+    s, keep = _pack(t)
+    cap = _bound(t)
+    oc, os_, of, ov = _alloc(cap)
+    n = L.wto_reduce(C.byref(s), _opcode(op), flags, n_set0, cap,
+                     oc.ctypes.data, os_.ctypes.data, of.ctypes.data, ov.ctypes.data)
+    return _trim(n, (oc, os_, of, ov))
+
+
+def multiplex(t, flags=0):
+    """Oracle restatement of the Multiplexer tile: (chrom,start,finish,values[R,N],inplay[R,N])."""
+    L = oracle_lib()
+    s, keep = _pack(t)
+    cap = _bound(t)
+    N = int(t["n_tracks"])
+    oc, os_, of, _ = _alloc(cap)
+    tile = np.empty((cap, N), np.float64)
+    ip = np.empty((cap, N), np.uint8)
+    n = L.wto_multiplex(C.byref(s), flags, cap, oc.ctypes.data, os_.ctypes.data, of.ctypes.data,
+                        tile.ctypes.data, ip.ctypes.data)
+    return _trim(n, (oc, os_, of, tile, ip))
+
+
+def reducer_default(op, defaults):
+    d = np.ascontiguousarray(defaults, np.float64)
+    return oracle_lib().wto_reducer_default(_opcode(op), len(d), d.ctypes.data)
+
+
+def auc(start, finish, value):
+    s = np.ascontiguousarray(start, np.int32)
+    f = np.ascontiguousarray(finish, np.int32)
+    v = np.ascontiguousarray(value, np.float64)
+    return oracle_lib().wto_auc(len(s), s.ctypes.data, f.ctypes.data, v.ctypes.data)
+
+
+def compress(chrom, start, finish, value):
+    c = np.array(chrom, np.int32)
+    s = np.array(start, np.int32)
+    f = np.array(finish, np.int32)
+    v = np.array(value, np.float64)
+    n = oracle_lib().wto_compress(len(s), c.ctypes.data, s.ctypes.data, f.ctypes.data, v.ctypes.data)
+    return c[:n], s[:n], f[:n], v[:n]
+
+
+def tdist_Q(t, nu):
+    return oracle_lib().wto_tdist_Q(float(t), float(nu))
+
+
+def ttest_stat(n1, n2, values, inplay):
+    v = np.ascontiguousarray(values, np.float64)
+    ip = np.ascontiguousarray(inplay, np.uint8)
+    t = C.c_double()
+    nu = C.c_double()
+    oracle_lib().wto_ttest_stat(n1, n2, v.ctypes.data, ip.ctypes.data, C.byref(t), C.byref(nu))
+    return t.value, nu.value
+
+
+# ---------------- compiled reference ----------------
+
+def ref_reduce(t, op, flags=0, compressed=False):
+    L = ref_lib()
+    s, keep = _pack(t)
+    cap = _bound(t)
+    oc, os_, of, ov = _alloc(cap)
+    fn = L.ref_reduce_compressed if compressed else L.ref_reduce
+    n = fn(C.byref(s), _opcode(op), flags, cap, oc.ctypes.data, os_.ctypes.data, of.ctypes.data, ov.ctypes.data)
+    return _trim(n, (oc, os_, of, ov))
+
+
+def ref_reduce_seek(t, op, chrom, start, finish, flags=0):
+    L = ref_lib()
+    s, keep = _pack(t)
+    cap = _bound(t)
+    oc, os_, of, ov = _alloc(cap)
+    n = L.ref_reduce_seek(C.byref(s), _opcode(op), flags, chrom, start, finish, cap,
+                          oc.ctypes.data, os_.ctypes.data, of.ctypes.data, ov.ctypes.data)
+    return _trim(n, (oc, os_, of, ov))
+
+
+def ref_multiplex(t, flags=0):
+    L = ref_lib()
+    s, keep = _pack(t)
+    cap = _bound(t)
+    N = int(t["n_tracks"])
+    oc, os_, of, _ = _alloc(cap)
+    tile = np.empty((cap, N), np.float64)
+    ip = np.empty((cap, N), np.uint8)
+    n = L.ref_multiplex(C.byref(s), flags, cap, oc.ctypes.data, os_.ctypes.data, of.ctypes.data,
+                        tile.ctypes.data, ip.ctypes.data)
+    return _trim(n, (oc, os_, of, tile, ip))
+
+
+def ref_multiset(t, n_set0, flags=0):
+    L = ref_lib()
+    s, keep = _pack(t)
+    cap = _bound(t)
+    N = int(t["n_tracks"])
+    oc, os_, of, _ = _alloc(cap)
+    tile = np.zeros((cap, N), np.float64)
+    ip = np.zeros((cap, N), np.uint8)
+    n = L.ref_multiset(C.byref(s), n_set0, flags, cap, oc.ctypes.data, os_.ctypes.data, of.ctypes.data,
+                       tile.ctypes.data, ip.ctypes.data)
+    return _trim(n, (oc, os_, of, tile, ip))
+
+
+def ref_reducer_default(op, defaults):
+    d = np.ascontiguousarray(defaults, np.float64)
+    return ref_lib().ref_reducer_default(_opcode(op), len(d), d.ctypes.data)
+
+
+def ref_auc_of_reduce(t, op, flags=0):
+    s, keep = _pack(t)
+    return ref_lib().ref_auc_of_reduce(C.byref(s), _opcode(op), flags)
+
+
+def ref_pearson(t):
+    s, keep = _pack(t)
+    return ref_lib().ref_pearson(C.byref(s))
+
+
+def ref_time_reduce(t, op, flags=0):
+    """Times the compiled reference: returns (seconds, runs, covered_bp)."""
+    s, keep = _pack(t)
+    runs = C.c_int64()
+    bp = C.c_int64()
+    sec = ref_lib().ref_time_reduce(C.byref(s), _opcode(op), flags, C.byref(runs), C.byref(bp))
+    return sec, runs.value, bp.value
+
+
+def ref_reduce_files(paths, op, flags=0, cap=1 << 20):
+    """Reference reducer over text files read by the reference's own readers."""
+    L = ref_lib()
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    oc, os_, of, ov = _alloc(cap)
+    names = C.create_string_buffer(1 << 16)
+    n = L.ref_reduce_files(len(paths), arr, _opcode(op), flags, cap,
+                           oc.ctypes.data, os_.ctypes.data, of.ctypes.data, ov.ctypes.data, names, 1 << 16)
+    out = _trim(n, (oc, os_, of, ov))
+    return out + (names.value.decode().split("\n") if n > 0 else [],)

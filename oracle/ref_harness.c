@@ -1,0 +1,346 @@
+/*
+ * ref_harness.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Driver for the *compiled reference* (oracle/_ref/libwiggletools_ref.so, built
+ * by oracle/Makefile straight from /root/reference/src without modification).
+ * It feeds the reference's own newMultiplexer / ...Reduction / newMultiset with
+ * array-backed WiggleIterators and records what the reference emits, so that
+ *   (a) oracle/wt_oracle.c can be validated against the real thing, and
+ *   (b) bench.py can time the real reference as cpu_baseline.kind="reference".
+ *
+ * The reference library is opened with dlopen(RTLD_LAZY): reference unaryOps.c
+ * refers to BigWiggleReader/BamReader/... whose sources need libBigWig/htslib
+ * (absent here); those symbols stay unresolved and are never called.
+ *
+ * Everything in this file is our own code; the only thing taken from the
+ * reference is its ABI (struct layouts in include/wiggletools_amd.h).
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../include/wiggletools_amd.h"
+
+typedef struct {
+    int32_t n_chrom, n_tracks;
+    const int64_t *seg_off;
+    const int32_t *start, *finish;
+    const double *value;
+    const double *defaults;
+} wto_tracks;
+
+/* function pointers into the reference library */
+static void *g_lib;
+static WiggleIterator *(*r_newWiggleIterator)(void *, void (*)(WiggleIterator *),
+                                              void (*)(WiggleIterator *, const char *, int, int), double, wt_bool);
+static Multiplexer *(*r_newMultiplexer)(WiggleIterator **, int, wt_bool);
+static Multiset *(*r_newMultiset)(Multiplexer **, int);
+static void (*r_popMultiplexer)(Multiplexer *);
+static void (*r_popMultiset)(Multiset *);
+static void (*r_pop)(WiggleIterator *);
+static void (*r_seek)(WiggleIterator *, const char *, int, int);
+static WiggleIterator *(*r_SmartReader)(char *, wt_bool);
+static WiggleIterator *(*r_AUCIntegrator)(WiggleIterator *);
+static WiggleIterator *(*r_PearsonIntegrator)(Multiplexer *);
+static WiggleIterator *(*r_CompressionWiggleIterator)(WiggleIterator *);
+static WiggleIterator *(*r_reduction[10])(Multiplexer *);
+
+static const char *k_red_names[10] = {
+    "SumReduction", "ProductReduction", "MeanReduction", "VarianceReduction", "StdDevReduction",
+    "EntropyReduction", "CVReduction", "MinReduction", "MaxReduction", "MedianReduction"
+};
+
+int ref_open(const char *path) {
+    if (g_lib) return 0;
+    g_lib = dlopen(path, RTLD_LAZY | RTLD_LOCAL);
+    if (!g_lib) { fprintf(stderr, "ref_open: %s\n", dlerror()); return -1; }
+#define BIND(var, name) do { *(void **) (&var) = dlsym(g_lib, name); \
+        if (!var) { fprintf(stderr, "ref_open: missing %s\n", name); return -2; } } while (0)
+    BIND(r_newWiggleIterator, "newWiggleIterator");
+    BIND(r_newMultiplexer, "newMultiplexer");
+    BIND(r_newMultiset, "newMultiset");
+    BIND(r_popMultiplexer, "popMultiplexer");
+    BIND(r_popMultiset, "popMultiset");
+    BIND(r_pop, "pop");
+    BIND(r_seek, "seek");
+    BIND(r_SmartReader, "SmartReader");
+    BIND(r_AUCIntegrator, "AUCIntegrator");
+    BIND(r_PearsonIntegrator, "PearsonIntegrator");
+    BIND(r_CompressionWiggleIterator, "CompressionWiggleIterator");
+    for (int i = 0; i < 10; i++) BIND(r_reduction[i], k_red_names[i]);
+#undef BIND
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Array-backed child iterator                                         */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    const wto_tracks *t;
+    char **names;      /* stable char* per chromosome (reference compares pointers, unaryOps.c:76) */
+    int track;
+    int c;             /* current chromosome */
+    int64_t j;         /* next interval index inside (c, track) */
+    /* optional seek window */
+    int have_win; int win_c; int win_start, win_finish;
+} arr_iter;
+
+static void arr_pop(WiggleIterator *wi) {
+    arr_iter *a = (arr_iter *) wi->data;
+    const wto_tracks *t = a->t;
+    for (;;) {
+        if (a->c >= t->n_chrom) { wi->done = 1; return; }
+        int64_t seg = (int64_t) a->c * t->n_tracks + a->track;
+        int64_t lo = t->seg_off[seg], hi = t->seg_off[seg + 1];
+        if (a->j < lo) a->j = lo;
+        if (a->j >= hi) { a->c++; a->j = -1; if (a->have_win) { wi->done = 1; return; } continue; }
+        int32_t s = t->start[a->j], f = t->finish[a->j];
+        if (a->have_win) {
+            if (f <= a->win_start) { a->j++; continue; }
+            if (s >= a->win_finish) { wi->done = 1; return; }
+            if (s < a->win_start) s = a->win_start;
+            if (f > a->win_finish) f = a->win_finish;
+        }
+        wi->chrom = a->names[a->c];
+        wi->start = s; wi->finish = f;
+        wi->value = t->value[a->j];
+        a->j++;
+        return;
+    }
+}
+
+static void arr_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
+    arr_iter *a = (arr_iter *) wi->data;
+    a->have_win = 1; a->win_start = start; a->win_finish = finish;
+    a->c = a->t->n_chrom; a->j = -1;
+    for (int c = 0; c < a->t->n_chrom; c++)
+        if (!strcmp(a->names[c], chrom)) { a->c = c; break; }
+    wi->done = 0;
+    arr_pop(wi);
+}
+
+static WiggleIterator *make_child(const wto_tracks *t, char **names, int track) {
+    arr_iter *a = (arr_iter *) calloc(1, sizeof(arr_iter));
+    a->t = t; a->names = names; a->track = track; a->c = 0; a->j = -1;
+    return r_newWiggleIterator(a, arr_pop, arr_seek, t->defaults[track], 0);
+}
+
+static char **make_names(int n_chrom) {
+    char **names = (char **) calloc((size_t) n_chrom, sizeof(char *));
+    for (int c = 0; c < n_chrom; c++) {
+        names[c] = (char *) malloc(16);
+        snprintf(names[c], 16, "c%05d", c);    /* strcmp order == index order */
+    }
+    return names;
+}
+
+static int name_to_index(const char *name) { return atoi(name + 1); }
+
+static Multiplexer *make_multiplexer(const wto_tracks *t, char **names, int lo, int hi, int strict) {
+    int n = hi - lo;
+    WiggleIterator **iters = (WiggleIterator **) calloc((size_t) n, sizeof(WiggleIterator *));
+    for (int i = 0; i < n; i++) iters[i] = make_child(t, names, lo + i);
+    Multiplexer *m = r_newMultiplexer(iters, n, (wt_bool) (strict != 0));
+    free(iters);   /* newMultiplexer copies the array (multiplexer.c:160-166) */
+    return m;
+}
+
+/* Runs the reference reducer `op` (0..9) and records every run it emits. */
+int64_t ref_reduce(const wto_tracks *t, int op, unsigned flags, int64_t cap,
+                   int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value) {
+    if (!g_lib || op < 0 || op > 9) return -2;
+    char **names = make_names(t->n_chrom);
+    Multiplexer *m = make_multiplexer(t, names, 0, t->n_tracks, flags & 1u);
+    WiggleIterator *r = r_reduction[op](m);
+    int64_t n = 0;
+    while (!r->done) {
+        if (n >= cap) return -1;
+        o_chrom[n] = name_to_index(r->chrom);
+        o_start[n] = r->start; o_finish[n] = r->finish; o_value[n] = r->value;
+        n++;
+        r_pop(r);
+    }
+    return n;   /* everything is leaked by design, like the reference */
+}
+
+/* Same after seek(chrom_index, start, finish) on the reducer (reducers.c:25-29). */
+int64_t ref_reduce_seek(const wto_tracks *t, int op, unsigned flags, int chrom, int start, int finish,
+                        int64_t cap, int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value) {
+    if (!g_lib || op < 0 || op > 9) return -2;
+    char **names = make_names(t->n_chrom);
+    Multiplexer *m = make_multiplexer(t, names, 0, t->n_tracks, flags & 1u);
+    WiggleIterator *r = r_reduction[op](m);
+    r_seek(r, names[chrom], start, finish);
+    int64_t n = 0;
+    while (!r->done) {
+        if (n >= cap) return -1;
+        o_chrom[n] = name_to_index(r->chrom);
+        o_start[n] = r->start; o_finish[n] = r->finish; o_value[n] = r->value;
+        n++;
+        r_pop(r);
+    }
+    return n;
+}
+
+/* Steps the reference Multiplexer and dumps values[]/inplay[] per run. */
+int64_t ref_multiplex(const wto_tracks *t, unsigned flags, int64_t cap,
+                      int32_t *o_chrom, int32_t *o_start, int32_t *o_finish,
+                      double *o_tile, uint8_t *o_inplay) {
+    if (!g_lib) return -2;
+    char **names = make_names(t->n_chrom);
+    Multiplexer *m = make_multiplexer(t, names, 0, t->n_tracks, flags & 1u);
+    int N = t->n_tracks;
+    int64_t n = 0;
+    while (!m->done) {
+        if (n >= cap) return -1;
+        o_chrom[n] = name_to_index(m->chrom);
+        o_start[n] = m->start; o_finish[n] = m->finish;
+        for (int i = 0; i < N; i++) {
+            o_tile[n * N + i] = m->values[i];
+            o_inplay[n * N + i] = (uint8_t) m->inplay[i];
+        }
+        n++;
+        r_popMultiplexer(m);
+    }
+    return n;
+}
+
+/* Steps the reference Multiset over two Multiplexers (tracks [0,n_set0) and the
+ * rest); records the runs where both are in play (setComparisons.c:48-54) with
+ * the per-track values/inplay the two-sample reducers would read. */
+int64_t ref_multiset(const wto_tracks *t, int n_set0, unsigned flags, int64_t cap,
+                     int32_t *o_chrom, int32_t *o_start, int32_t *o_finish,
+                     double *o_tile, uint8_t *o_inplay) {
+    if (!g_lib) return -2;
+    char **names = make_names(t->n_chrom);
+    Multiplexer **ms = (Multiplexer **) calloc(2, sizeof(Multiplexer *));
+    ms[0] = make_multiplexer(t, names, 0, n_set0, flags & 1u);
+    ms[1] = make_multiplexer(t, names, n_set0, t->n_tracks, flags & 2u);
+    Multiset *S = r_newMultiset(ms, 2);
+    int N = t->n_tracks;
+    int64_t n = 0;
+    while (!S->done) {
+        if (S->inplay[0] && S->inplay[1]) {
+            if (n >= cap) return -1;
+            o_chrom[n] = name_to_index(S->chrom);
+            o_start[n] = S->start; o_finish[n] = S->finish;
+            for (int k = 0; k < 2; k++) {
+                int base = k ? n_set0 : 0;
+                for (int i = 0; i < ms[k]->count; i++) {
+                    o_tile[n * N + base + i] = S->values[k][i];
+                    o_inplay[n * N + base + i] = (uint8_t) ms[k]->inplay[i];
+                }
+            }
+            n++;
+        }
+        r_popMultiset(S);
+    }
+    return n;
+}
+
+/* Default value the reference reducer ctor computes. */
+double ref_reducer_default(int op, int n, const double *defaults) {
+    if (!g_lib || op < 0 || op > 9) return NAN;
+    int64_t *off = (int64_t *) calloc((size_t) n + 1, sizeof(int64_t));
+    wto_tracks t = { 1, n, off, NULL, NULL, NULL, defaults };
+    char **names = make_names(1);
+    Multiplexer *m = make_multiplexer(&t, names, 0, n, 0);
+    WiggleIterator *r = r_reduction[op](m);
+    return r->default_value;
+}
+
+/* AUC of the reference reducer output (statistics.c:103-120). */
+double ref_auc_of_reduce(const wto_tracks *t, int op, unsigned flags) {
+    if (!g_lib || op < 0 || op > 9) return NAN;
+    char **names = make_names(t->n_chrom);
+    Multiplexer *m = make_multiplexer(t, names, 0, t->n_tracks, flags & 1u);
+    WiggleIterator *a = r_AUCIntegrator(r_reduction[op](m));
+    while (!a->done) r_pop(a);
+    return *(double *) a->data;
+}
+
+/* Pearson of tracks 0 and 1 (statistics.c:414-465). */
+double ref_pearson(const wto_tracks *t) {
+    if (!g_lib || t->n_tracks != 2) return NAN;
+    char **names = make_names(t->n_chrom);
+    Multiplexer *m = make_multiplexer(t, names, 0, 2, 0);
+    WiggleIterator *p = r_PearsonIntegrator(m);
+    while (!p->done) r_pop(p);
+    return *(double *) p->data;
+}
+
+/* Compression (unaryOps.c:235-263) of the reference reducer output. */
+int64_t ref_reduce_compressed(const wto_tracks *t, int op, unsigned flags, int64_t cap,
+                              int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value) {
+    if (!g_lib || op < 0 || op > 9) return -2;
+    char **names = make_names(t->n_chrom);
+    Multiplexer *m = make_multiplexer(t, names, 0, t->n_tracks, flags & 1u);
+    WiggleIterator *r = r_CompressionWiggleIterator(r_reduction[op](m));
+    int64_t n = 0;
+    while (!r->done) {
+        if (n >= cap) return -1;
+        o_chrom[n] = name_to_index(r->chrom);
+        o_start[n] = r->start; o_finish[n] = r->finish; o_value[n] = r->value;
+        n++;
+        r_pop(r);
+    }
+    return n;
+}
+
+/* Runs `op` over text files through the reference's own readers
+ * (SmartReader, unaryOps.c:1168-1204: .wig/.bg/.bed only here).
+ * Chromosome names are returned as one '\n'-joined buffer of unique names in
+ * order of first appearance; o_chrom indexes into it. */
+int64_t ref_reduce_files(int n_files, char **paths, int op, unsigned flags, int64_t cap,
+                         int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value,
+                         char *names_buf, int names_cap) {
+    if (!g_lib || op < 0 || op > 9) return -2;
+    WiggleIterator **iters = (WiggleIterator **) calloc((size_t) n_files, sizeof(WiggleIterator *));
+    for (int i = 0; i < n_files; i++) iters[i] = r_SmartReader(paths[i], 0);
+    Multiplexer *m = r_newMultiplexer(iters, n_files, (wt_bool) (flags & 1u));
+    WiggleIterator *r = r_reduction[op](m);
+    int64_t n = 0;
+    int n_names = 0;
+    char *last = NULL;
+    names_buf[0] = 0;
+    while (!r->done) {
+        if (n >= cap) return -1;
+        if (!last || strcmp(last, r->chrom)) {
+            if ((int) (strlen(names_buf) + strlen(r->chrom) + 2) > names_cap) return -3;
+            if (n_names) strcat(names_buf, "\n");
+            strcat(names_buf, r->chrom);
+            n_names++;
+            last = r->chrom;
+        }
+        o_chrom[n] = n_names - 1;
+        o_start[n] = r->start; o_finish[n] = r->finish; o_value[n] = r->value;
+        n++;
+        r_pop(r);
+    }
+    return n;
+}
+
+/* Wall-clock of the reference path, sink = none (the reference's `do`):
+ * returns seconds; *o_runs / *o_bp receive runs emitted and bp covered. */
+double ref_time_reduce(const wto_tracks *t, int op, unsigned flags, int64_t *o_runs, int64_t *o_bp) {
+    if (!g_lib || op < 0 || op > 9) return -1;
+    char **names = make_names(t->n_chrom);
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    Multiplexer *m = make_multiplexer(t, names, 0, t->n_tracks, flags & 1u);
+    WiggleIterator *r = r_reduction[op](m);
+    int64_t n = 0, bp = 0;
+    volatile double sinkv = 0;
+    while (!r->done) {
+        n++; bp += r->finish - r->start; sinkv += r->value;
+        r->pop(r);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    *o_runs = n; *o_bp = bp;
+    return (double) (b.tv_sec - a.tv_sec) + 1e-9 * (double) (b.tv_nsec - a.tv_nsec);
+}
