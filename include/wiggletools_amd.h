@@ -235,10 +235,10 @@ void wtamd_trackset_destroy(wtamd_trackset *);
 /* Upper bound on the number of runs any reduction over `ts` can emit. */
 int64_t wtamd_trackset_max_runs(const wtamd_trackset *ts);
 
-/* Build (or rebuild) the window index of `ts` on `stream` (hipStream_t as void*).
- * wtamd_reduce() calls this itself when the index is missing; it is exposed so
- * callers can time / amortise it separately. */
-int wtamd_trackset_index(wtamd_trackset *ts, void *stream);
+/* Build (or rebuild) the window index `op` (enum wtamd_op) would use, on `stream`
+ * (hipStream_t as void*).  wtamd_reduce() calls this itself when the index is
+ * missing; it is exposed so callers can time / amortise it separately. */
+int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream);
 
 /* Multiplex + reduce, everything on device. `runs` arrays are DEVICE memory.
  * *n_runs is written on the host after the stream has been synchronised iff

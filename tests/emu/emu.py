@@ -1,0 +1,63 @@
+"""ctypes wrapper of the CPU emulator of the HIP kernels (test-only)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(_build.build())
+        L.wtemu_reduce.restype = C.c_longlong
+        L.wtemu_reduce.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_longlong,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def reduce(t, op, flags=0, n_set0=0, W=None, T=None, multiplex=False):
+    """t: RunLists.  Returns (chrom, start, finish, value) [+ (tile, inplay) if multiplex], info."""
+    from oracle.oracle import OPS
+    opcode = 12 if multiplex else (OPS[op] if isinstance(op, str) else int(op))
+    old = {k: os.environ.get(k) for k in ("WTAMD_W", "WTAMD_T")}
+    try:
+        for k, v in (("WTAMD_W", W), ("WTAMD_T", T)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        cap = 2 * t.n_intervals + 8
+        N = t.n_tracks
+        os_, of, ov = np.empty(cap, np.int32), np.empty(cap, np.int32), np.full(cap, -7.0, np.float64)
+        cro = np.zeros(t.n_chrom + 1, np.int64)
+        tile = np.zeros((cap, N), np.float64) if multiplex else None
+        ip = np.zeros((cap, N), np.uint8) if multiplex else None
+        info = np.zeros(8, np.int64)
+        value = np.ascontiguousarray(t.value)
+        n = lib().wtemu_reduce(t.n_chrom, N, t.seg_off.ctypes.data, t.start.ctypes.data, t.finish.ctypes.data,
+                               value.ctypes.data, int(value.dtype == np.float64), t.defaults.ctypes.data,
+                               opcode, flags, n_set0, cap, os_.ctypes.data, of.ctypes.data, ov.ctypes.data,
+                               cro.ctypes.data, tile.ctypes.data if multiplex else None,
+                               ip.ctypes.data if multiplex else None, info.ctypes.data)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if n < 0:
+        raise RuntimeError("emulator returned %d" % n)
+    assert cro[-1] == n
+    chrom = np.repeat(np.arange(t.n_chrom, dtype=np.int32), np.diff(cro))
+    out = (chrom, os_[:n].copy(), of[:n].copy(), ov[:n].copy())
+    if multiplex:
+        out = (chrom, os_[:n].copy(), of[:n].copy(), tile[:n].copy(), ip[:n].copy())
+    return out, dict(W=int(info[0]), T=int(info[1]), lds=int(info[2]), n_windows=int(info[3]),
+                     covered_bp=int(info[4]), n_intervals=int(info[5]))

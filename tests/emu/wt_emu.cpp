@@ -1,0 +1,97 @@
+// wt_emu.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Phase-by-phase CPU emulation of the HIP kernels in
+// wiggletools_amd/csrc/wt_core.h: every __syncthreads()-delimited phase is run
+// for tid = 0..T-1 in turn, windows are executed in ticket order.  It exists so
+// that the alignment / reducer / look-back logic can be checked against the
+// oracle in the build container, which has no GPU.  Built by tests/emu/build.py
+// into tests/emu/libwt_emu.so.
+#define WT_EMU 1
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../wiggletools_amd/csrc/wt_core.h"
+#include "../../wiggletools_amd/csrc/wt_plan.h"
+
+namespace {
+
+struct EmuRun {
+    WtParams P;
+    WtPlan plan;
+    std::vector<char> lds;
+    std::vector<WtLane> lanes;
+
+    template <int OP, class ValT, class ScrT>
+    void run() {
+        WtCtx c;
+        wt_ctx_init(c, P, lds.data());
+        const int T = plan.T;
+        for (;;) {
+            const long long k = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+            if (k >= P.n_windows) break;
+            wt_phase_header(P, c, k);
+            for (int t = 0; t < T; t++) wt_phase_zero(P, c, t, T);
+            for (int t = 0; t < T; t++) wt_phase_load(P, c, t, T);
+            for (int t = 0; t < T; t++) wt_phase_count(P, c, t, T);
+            for (int t = 0; t < T; t++) wt_phase_eval<OP, ValT, ScrT>(P, c, lanes[t], t, T);
+            for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
+            wt_phase_lookback(P, c, k);
+            for (int t = 0; t < T; t++) wt_phase_write<OP, ValT>(P, c, lanes[t], t, T);
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+// Returns number of runs (>= 0) or a negative error.  All pointers are host.
+// info[0..3] receive W, T, lds_bytes, n_windows.
+long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const int32_t *start,
+                       const int32_t *finish, const void *value, int value_is_f64, const double *defaults,
+                       int op, unsigned flags, int n_set0, long long capacity,
+                       int32_t *o_start, int32_t *o_finish, double *o_value, int64_t *chrom_run_off,
+                       double *o_tile, uint8_t *o_inplay, long long *info) {
+    EmuRun R;
+    std::string err;
+    const bool s32 = !value_is_f64 && wt_defaults_fit_f32(defaults, n_tracks);
+    if (!wt_make_plan(n_tracks, op, s32, R.plan, err)) { fprintf(stderr, "wtemu: %s\n", err.c_str()); return -10; }
+    const int64_t n_seg = (int64_t) n_chrom * n_tracks;
+    std::vector<int32_t> fs(n_seg, 0), lf(n_seg, 0);
+    for (int64_t s = 0; s < n_seg; s++)
+        if (seg_off[s + 1] > seg_off[s]) { fs[s] = start[seg_off[s]]; lf[s] = finish[seg_off[s + 1] - 1]; }
+    WtWindowTables tab;
+    wt_make_windows(n_chrom, n_tracks, seg_off, fs.data(), lf.data(), R.plan.W, tab);
+
+    std::vector<uint32_t> widx((size_t) tab.n_rows * n_tracks, 0);
+    std::vector<unsigned long long> status(tab.n_windows, 0), counters(WT_CTR_N, 0);
+
+    WtParams &P = R.P;
+    memset(&P, 0, sizeof(P));
+    P.start = start; P.finish = finish; P.value = value; P.seg_off = seg_off; P.defaults = defaults;
+    P.n_chrom = n_chrom; P.n_tracks = n_tracks;
+    P.cbase = tab.cbase.data(); P.c_nwin = tab.c_nwin.data(); P.c_first_win = tab.c_first_win.data();
+    P.n_windows = tab.n_windows; P.win_chrom = tab.win_chrom.data(); P.widx = widx.data();
+    P.op = op; P.flags = flags; P.n_set0 = n_set0;
+    P.status = status.data(); P.counters = counters.data();
+    P.capacity = capacity; P.o_start = o_start; P.o_finish = o_finish; P.o_value = o_value;
+    P.chrom_run_off = chrom_run_off; P.o_tile = o_tile; P.o_inplay = o_inplay;
+    wt_plan_to_params(R.plan, P);
+
+    // window index "kernel"
+    const int64_t total = seg_off[n_seg];
+    for (int64_t g = 0; g < total; g++) wt_index_interval(P, g);
+
+    R.lds.assign((size_t) R.plan.lds_bytes + 64, 0);
+    R.lanes.resize(R.plan.T);
+    if (!wt_dispatch(op, value_is_f64 != 0, s32, R)) return -11;
+    if (info) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows;
+                info[4] = (long long) counters[WT_CTR_BP]; info[5] = (long long) counters[WT_CTR_INTERVALS]; }
+    if (counters[WT_CTR_ERROR] & WT_ERR_CAPACITY) return -1;
+    if (counters[WT_CTR_ERROR]) return -2;
+    return (long long) counters[WT_CTR_RUNS];
+}
+
+}  // extern "C"

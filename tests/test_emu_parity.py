@@ -1,0 +1,79 @@
+"""Kernel LOGIC vs oracle on CPU: the HIP kernel source (wt_core.h) compiled for the
+host and executed phase by phase (tests/emu).  The same cases run on the real GPU
+in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from helpers import ALL_MULTIPLEX_OPS, assert_runs_equal, random_case
+from emu import emu
+
+# values: sum/mean/min/max/median are bit-exact by construction (same op order);
+# var/stddev/cv go through sqrt/div in the same order as well -> bit-exact on CPU.
+GEOMS = [(None, None), (64, 64), (128, 64), (256, 64), (256, 128)]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_emu_one_sample_ops(oracle, seed):
+    t = random_case(seed, dtype=np.float64 if seed % 2 else np.float32)
+    d = t.as_dict()
+    W, T = GEOMS[seed % len(GEOMS)]
+    for strict in (0, 1):
+        for op in ALL_MULTIPLEX_OPS:
+            exp = oracle.reduce(d, op, flags=strict)
+            got, info = emu.reduce(t, op, flags=strict, W=W, T=T)
+            assert_runs_equal(got, exp, 0.0, "seed %d op %s strict %d %s" % (seed, op, strict, info))
+            assert info["covered_bp"] == int((exp[2] - exp[1]).sum())
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_emu_two_sample_ops(oracle, seed):
+    rng = np.random.default_rng(seed)
+    t = random_case(500 + seed, n_tracks=int(rng.integers(6, 12)), dtype=np.float64 if seed % 2 else np.float32)
+    d = t.as_dict()
+    n1 = int(rng.integers(3, t.n_tracks - 2))
+    W, T = GEOMS[seed % len(GEOMS)]
+    for flags in (0, 1, 2, 3):
+        for op in ("ttest", "mwu"):
+            exp = oracle.reduce(d, op, flags=flags, n_set0=n1)
+            got, info = emu.reduce(t, op, flags=flags, n_set0=n1, W=W, T=T)
+            assert_runs_equal(got, exp, 1e-12 if op == "ttest" else 0.0,
+                              "seed %d op %s flags %d %s" % (seed, op, flags, info))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_emu_multiplex_tile(oracle, seed):
+    t = random_case(900 + seed)
+    d = t.as_dict()
+    W, T = GEOMS[seed % len(GEOMS)]
+    for strict in (0, 1):
+        exp = oracle.multiplex(d, flags=strict)
+        got, info = emu.reduce(t, "sum", flags=strict, W=W, T=T, multiplex=True)
+        assert len(got[0]) == len(exp[0])
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_emu_long_intervals_span_many_windows(oracle):
+    """One interval much longer than the window; breakpoints exactly on window edges."""
+    from wiggletools_amd.runlists import RunLists
+    tracks = [
+        [[(1, 1000, 2.0)]],
+        [[(65, 129, 1.0), (129, 500, 3.0), (900, 1200, 4.0)]],
+        [[(64, 65, 5.0), (128, 129, 6.0), (193, 257, 7.0)]],
+    ]
+    t = RunLists.from_lists(tracks)
+    for W in (64, 128, 256):
+        for op in ("sum", "mean", "max", "median"):
+            exp = oracle.reduce(t.as_dict(), op)
+            got, info = emu.reduce(t, op, W=W, T=64)
+            assert_runs_equal(got, exp, 0.0, "W %d op %s" % (W, op))
+
+
+def test_emu_empty_and_single(oracle):
+    from wiggletools_amd.runlists import RunLists
+    t = RunLists.from_lists([[[], []], [[], []]])
+    got, info = emu.reduce(t, "mean")
+    assert len(got[0]) == 0
+    t = RunLists.from_lists([[[(5, 6, 1.5)], []]])
+    got, info = emu.reduce(t, "mean")
+    assert got[1].tolist() == [5] and got[2].tolist() == [6] and got[3].tolist() == [1.5]

@@ -1,0 +1,171 @@
+"""Parity of the HIP path (through the C ABI) with the oracle, on a real MI355X.
+
+Coordinates: bit-exact.  Values: the north-star tolerance is 1e-6 relative; the
+kernels visit tracks in the reference's order in f64, so sums/means/min/max/
+median are expected bit-exact and are asserted so; var/stddev/CV/ttest/MWU go
+through device sqrt/div/erf/lgamma and are held to 1e-12 / 1e-9.
+"""
+import numpy as np
+import pytest
+
+from helpers import ALL_MULTIPLEX_OPS, assert_runs_equal, random_case
+
+pytestmark = pytest.mark.gpu
+
+EXACT = {"sum", "product", "mean", "min", "max", "median"}
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import torch
+    assert torch.cuda.is_available()
+    from wiggletools_amd import engine as E
+    return E
+
+
+def _tol(op):
+    if op in EXACT:
+        return 0.0
+    return 1e-9 if op in ("ttest", "mwu") else 1e-12
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_gpu_one_sample_ops_fuzz(oracle, engine, seed):
+    t = random_case(seed, dtype=np.float64 if seed % 2 else np.float32)
+    d = t.as_dict()
+    ts = engine.TrackSet.from_runlists(t)
+    for strict in (0, 1):
+        for op in ALL_MULTIPLEX_OPS:
+            exp = oracle.reduce(d, op, flags=strict)
+            got = ts.reduce_host(op, flags=strict)
+            assert_runs_equal(got, exp, _tol(op), "seed %d op %s strict %d" % (seed, op, strict))
+    ts.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_gpu_two_sample_ops_fuzz(oracle, engine, seed):
+    rng = np.random.default_rng(seed)
+    t = random_case(500 + seed, n_tracks=int(rng.integers(6, 12)), dtype=np.float64 if seed % 2 else np.float32)
+    d = t.as_dict()
+    n1 = int(rng.integers(3, t.n_tracks - 2))
+    ts = engine.TrackSet.from_runlists(t)
+    for flags in (0, 1, 2, 3):
+        for op in ("ttest", "mwu"):
+            exp = oracle.reduce(d, op, flags=flags, n_set0=n1)
+            got = ts.reduce_host(op, flags=flags, n_set0=n1)
+            assert_runs_equal(got, exp, _tol(op), "seed %d op %s flags %d" % (seed, op, flags))
+    ts.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_gpu_multiplexer_tile(oracle, engine, seed):
+    t = random_case(900 + seed)
+    ts = engine.TrackSet.from_runlists(t)
+    for strict in (0, 1):
+        exp = oracle.multiplex(t.as_dict(), flags=strict)
+        got = ts.multiplex_host(flags=strict)
+        assert len(got[0]) == len(exp[0])
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b, equal_nan=True)
+    ts.close()
+
+
+@pytest.mark.parametrize("n_tracks,ops", [(100, ["mean", "sum", "max", "median"]), (500, ["var", "stddev"]),
+                                          (100, ["cv", "min", "product"])])
+def test_gpu_config_sized_tracks(oracle, engine, n_tracks, ops):
+    """BASELINE configs C2/C3/C4 track counts on a window-crossing multi-chromosome batch."""
+    from wiggletools_amd.runlists import synth
+    t = synth(n_tracks, [60000, 20000, 7], mean_run=16, seed=n_tracks)
+    ts = engine.TrackSet.from_runlists(t)
+    for op in ops:
+        exp = oracle.reduce(t.as_dict(), op)
+        got = ts.reduce_host(op)
+        assert_runs_equal(got, exp, _tol(op), "N %d op %s" % (n_tracks, op))
+    st = ts.stats()
+    assert st["covered_bp"] == int((exp[2] - exp[1]).sum())
+    ts.close()
+
+
+def test_gpu_wilcoxon_50_vs_50(oracle, engine):
+    """BASELINE config C5 shape (n1 = n2 = 50: mu = 1250, sigma = sqrt(21041))."""
+    from wiggletools_amd.runlists import synth
+    t = synth(100, [30000, 5000], mean_run=16, seed=50)
+    ts = engine.TrackSet.from_runlists(t)
+    for op in ("mwu", "ttest"):
+        exp = oracle.reduce(t.as_dict(), op, n_set0=50)
+        got = ts.reduce_host(op, n_set0=50)
+        assert_runs_equal(got, exp, _tol(op), op)
+    ts.close()
+
+
+def test_gpu_golden_reference_fixtures(engine):
+    """The reference's own fixtures through the HIP path == outputs of the compiled reference."""
+    import json
+    import os
+    from wiggletools_amd.textio import load_runlists
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cases = json.load(open(os.path.join(G, "reference_fixtures.json")))["cases"]
+    cache = {}
+    for case in cases:
+        key = tuple(case["files"])
+        if key not in cache:
+            rl = load_runlists([os.path.join(G, f) for f in case["files"]])
+            cache[key] = (rl, engine.TrackSet.from_runlists(rl))
+        rl, ts = cache[key]
+        got = ts.reduce_host(case["op"], flags=case["strict"])
+        names_got = [rl.chrom_names[c] for c in got[0]]
+        assert names_got == [case["chrom_names"][c] for c in case["chrom"]]
+        exp_v = np.array([np.nan if v is None else v for v in case["value"]], np.float64)
+        z = np.zeros(len(exp_v))
+        assert_runs_equal((z, got[1], got[2], got[3]),
+                          (z, np.array(case["start"]), np.array(case["finish"]), exp_v), _tol(case["op"]),
+                          "%s %s" % (case["set"], case["op"]))
+
+
+def test_gpu_device_resident_path_and_auc(oracle, engine):
+    """Zero-copy device tensors in, device run list out, AUC on device."""
+    import torch
+    from wiggletools_amd.runlists import synth
+    t = synth(20, [40000, 3000], mean_run=8, seed=77)
+    dev = torch.device("cuda", 0)
+    ts = engine.TrackSet.from_device(t.n_chrom, t.n_tracks, t.seg_off, torch.from_numpy(t.start).to(dev),
+                                     torch.from_numpy(t.finish).to(dev), torch.from_numpy(t.value).to(dev),
+                                     t.defaults)
+    out = ts.alloc_runs()
+    stream = torch.cuda.current_stream().cuda_stream
+    n = ts.reduce("mean", out, stream=stream, sync=True)
+    exp = oracle.reduce(t.as_dict(), "mean")
+    assert n == len(exp[0])
+    assert_runs_equal(out.to_host(), exp, 0.0, "device path")
+    auc = out.auc()
+    ref = oracle.auc(exp[1], exp[2], exp[3])
+    assert abs(auc - ref) <= 1e-9 * abs(ref)
+    # idempotence: a second pass over the same resident tracks gives the same run list
+    n2 = ts.reduce("mean", out, stream=stream, sync=True)
+    assert n2 == n
+    assert_runs_equal(out.to_host(), exp, 0.0, "second pass")
+    ts.close()
+
+
+def test_gpu_capacity_error_is_reported(engine):
+    from wiggletools_amd import _lib
+    from wiggletools_amd.runlists import synth
+    t = synth(4, [5000], mean_run=4, seed=5)
+    ts = engine.TrackSet.from_runlists(t)
+    out = ts.alloc_runs(capacity=10)
+    with pytest.raises(_lib.WtamdError):
+        ts.reduce("sum", out, sync=True)
+    ts.close()
+
+
+def test_gpu_precondition_messages(engine):
+    """Error text of the reference ctors (setComparisons.c:123-128, 374-377)."""
+    from wiggletools_amd import _lib
+    from wiggletools_amd.runlists import synth
+    t = synth(4, [500], mean_run=4, seed=5)
+    ts = engine.TrackSet.from_runlists(t)
+    with pytest.raises(_lib.WtamdError, match="t-test function only works"):
+        ts.reduce_host("ttest", n_set0=2)
+    with pytest.raises(_lib.WtamdError, match="Mann-Whitney U function only works"):
+        ts.reduce_host("mwu", n_set0=0)
+    ts.close()

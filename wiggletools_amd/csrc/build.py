@@ -1,0 +1,28 @@
+"""Builds wiggletools_amd/csrc/libwiggletools_amd.so for gfx950 (hipcc cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libwiggletools_amd.so")
+SRCS = ["wt_engine.hip", "wt_defaults.cpp", "wt_iter_abi.cpp"]
+DEPS = ["wt_core.h", "wt_plan.h", os.path.join("..", "..", "include", "wiggletools_amd.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wall", "-Wno-unused-function"]
+
+
+def build(force=False, verbose=False):
+    srcs = [os.path.join(HERE, s) for s in SRCS if os.path.exists(os.path.join(HERE, s))]
+    deps = srcs + [os.path.join(HERE, d) for d in DEPS]
+    if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
+        return SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + srcs + ["-o", SO]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

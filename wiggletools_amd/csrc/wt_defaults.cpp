@@ -1,0 +1,85 @@
+// wt_defaults.cpp -- default_value a reducer iterator advertises to its parent
+// (what the reference computes once in each reducer's constructor).  Host only.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/wiggletools_amd.h"
+
+namespace {
+inline bool any_nan(const double *d, int n) {
+    for (int i = 0; i < n; i++)
+        if (std::isnan(d[i])) return true;
+    return false;
+}
+inline double plain_sum(const double *d, int n) {
+    double s = 0;
+    for (int i = 0; i < n; i++) s += d[i];
+    return s;
+}
+inline double sq_error(const double *d, int n, double mean) {
+    double e = 0;
+    for (int i = 0; i < n; i++) e += (d[i] - mean) * (d[i] - mean);
+    return e;
+}
+}  // namespace
+
+extern "C" double wtamd_reducer_default(int op, int n, const double *d) {
+    if (n <= 0 || !d) return NAN;
+    const bool nan = any_nan(d, n);
+    switch (op) {
+    case WTAMD_OP_SUM:           // reducers.c:294-307
+        return nan ? NAN : plain_sum(d, n);
+    case WTAMD_OP_PRODUCT: {     // reducers.c:348-361
+        if (nan) return NAN;
+        double p = 1;
+        for (int i = 0; i < n; i++) p *= d[i];
+        return p;
+    }
+    case WTAMD_OP_MEAN: {        // reducers.c:404-422, stored through `float`
+        if (nan) return NAN;
+        const float f = (float) (plain_sum(d, n) / n);
+        return f;
+    }
+    case WTAMD_OP_VAR: {         // reducers.c:481-505
+        if (nan) return NAN;
+        const double mean = plain_sum(d, n) / n;
+        return sq_error(d, n, mean) / n;
+    }
+    case WTAMD_OP_STDDEV: {      // reducers.c:565-590
+        if (nan) return NAN;
+        const double mean = plain_sum(d, n) / n;
+        return std::sqrt(sq_error(d, n, mean) / n);
+    }
+    case WTAMD_OP_ENTROPY: {     // reducers.c:640-663: `count / multi->count` is an int division
+        if (nan) return NAN;
+        int count = 0;
+        for (int i = 0; i < n; i++) count += (d[i] != 0);
+        const double p = count / n;
+        return p ? -p * std::log(p) - (1 - p) * std::log(1 - p) : 0.0;
+    }
+    case WTAMD_OP_CV: {          // reducers.c:727-751, stored through `float`
+        if (nan) return NAN;
+        const double mean = plain_sum(d, n) / n;
+        double e = 0;
+        for (int i = 0; i < n; i++) e += (mean - d[i]) * (mean - d[i]);
+        const float f = (float) (std::sqrt(e / n) / mean);
+        return f;
+    }
+    case WTAMD_OP_MIN:           // reducers.c:237-253 (first element NaN is returned as is)
+    case WTAMD_OP_MAX: {         // reducers.c:170-186
+        if (std::isnan(d[0])) return d[0];
+        if (nan) return NAN;
+        return op == WTAMD_OP_MAX ? *std::max_element(d, d + n) : *std::min_element(d, d + n);
+    }
+    case WTAMD_OP_MEDIAN: {      // reducers.c:815-834, stored through `float`
+        if (nan) return NAN;
+        std::vector<double> tmp(d, d + n);
+        std::sort(tmp.begin(), tmp.end());
+        const float f = (float) tmp[n / 2];
+        return f;
+    }
+    default:                     // ttest / MWU: NAN (setComparisons.c:130, 389)
+        return NAN;
+    }
+}

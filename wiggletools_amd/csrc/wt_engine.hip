@@ -1,0 +1,545 @@
+// wt_engine.hip -- gfx950 kernels + the bulk C ABI (wtamd_*) of
+// include/wiggletools_amd.h.  Compiled only by hipcc --offload-arch=gfx950.
+//
+// Kernels
+//   wt_index_kernel     one lane per input interval: window index (widx)
+//   wt_reduce_kernel    persistent workgroups, one alignment window per ticket:
+//                       bitmap multiplexer + per-run reducer + ordered output
+//                       (logic in wt_core.h)
+//   wt_extents_kernel   first start / last finish per (chrom, track) segment
+//   wt_auc_kernel       sum (finish-start)*value over a run list (AUC)
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/wiggletools_amd.h"
+#include "wt_core.h"
+#include "wt_plan.h"
+
+#define WT_MAX_BLOCK 512
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+template <int OP, class ValT, class ScrT>
+__global__ void __launch_bounds__(WT_MAX_BLOCK) wt_reduce_kernel(const WtParams P) {
+    extern __shared__ __attribute__((aligned(16))) char wt_lds[];
+    WtCtx c;
+    wt_ctx_init(c, P, wt_lds);
+    WtLane L;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (;;) {
+        if (tid == 0) c.sh->ticket = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+        __syncthreads();
+        const long long k = c.sh->ticket;
+        if (k >= P.n_windows) break;
+        if (tid == 0) wt_phase_header(P, c, k);
+        wt_phase_zero(P, c, tid, nt);
+        __syncthreads();
+        wt_phase_load(P, c, tid, nt);
+        __syncthreads();
+        wt_phase_count(P, c, tid, nt);
+        __syncthreads();
+        wt_phase_eval<OP, ValT, ScrT>(P, c, L, tid, nt);
+        __syncthreads();
+        wt_phase_escan(P, c, tid, nt);
+        __syncthreads();
+        if (tid == 0) wt_phase_lookback(P, c, k);
+        __syncthreads();
+        wt_phase_write<OP, ValT>(P, c, L, tid, nt);
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) wt_index_kernel(const WtParams P, long long total) {
+    const long long stride = (long long) gridDim.x * blockDim.x;
+    for (long long g = (long long) blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride)
+        wt_index_interval(P, g);
+}
+
+__global__ void __launch_bounds__(256) wt_extents_kernel(const int64_t *seg_off, const int32_t *start,
+                                                          const int32_t *finish, long long n_seg,
+                                                          int32_t *first_start, int32_t *last_finish) {
+    const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    const long long lo = seg_off[s], hi = seg_off[s + 1];
+    first_start[s] = hi > lo ? start[lo] : 0;
+    last_finish[s] = hi > lo ? finish[hi - 1] : 0;
+}
+
+// AUC: statistics.c:103-120.  Deterministic two-level sum.
+__global__ void __launch_bounds__(256) wt_auc_kernel(const int32_t *start, const int32_t *finish, const double *value,
+                                                      long long n, double *partial) {
+    __shared__ double red[256];
+    double acc = 0;
+    const long long stride = (long long) gridDim.x * blockDim.x;
+    for (long long r = (long long) blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const double v = value[r];
+        if (v == v) acc += (double) (finish[r] - start[r]) * v;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int) threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void wt_auc_final_kernel(const double *partial, int n, double *out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double acc = 0;
+        for (int i = 0; i < n; i++) acc += partial[i];
+        *out = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int wt_fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define WT_HIP(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return wt_fail(WTAMD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+struct WtWindows {
+    WtPlan plan_geom;        // only W matters for the tables
+    WtWindowTables tab;
+    int32_t *d_cbase = nullptr, *d_cnwin = nullptr, *d_win_chrom = nullptr;
+    int64_t *d_cfirst = nullptr;
+    uint32_t *d_widx = nullptr;
+    unsigned long long *d_status = nullptr;
+    bool indexed = false;
+};
+
+struct wtamd_trackset {
+    int n_chrom = 0, n_tracks = 0;
+    bool value_f64 = false;
+    bool owns = false;
+    int64_t n_intervals = 0;
+    std::vector<int64_t> seg_off;
+    std::vector<double> defaults;
+    std::vector<int32_t> first_start, last_finish;
+    int32_t *d_start = nullptr, *d_finish = nullptr;
+    void *d_value = nullptr;
+    int64_t *d_seg_off = nullptr;
+    double *d_defaults = nullptr;
+    unsigned long long *d_counters = nullptr;
+    unsigned long long *h_counters = nullptr;   // pinned
+    int64_t *d_chrom_run_off = nullptr;         // scratch when the caller passes none
+    std::map<int, WtWindows> windows;           // keyed by W
+    hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
+    bool have_index_time = false, have_reduce_time = false;
+    wtamd_stats stats{};
+    int device = 0;
+    int num_cu = 256;
+    bool scratch_f32 = false;
+};
+
+static void wt_free_windows(WtWindows &w) {
+    (void) hipFree(w.d_cbase); (void) hipFree(w.d_cnwin); (void) hipFree(w.d_win_chrom); (void) hipFree(w.d_cfirst);
+    (void) hipFree(w.d_widx); (void) hipFree(w.d_status);
+}
+
+extern "C" {
+
+const char *wtamd_last_error(void) { return g_last_error.c_str(); }
+const char *wtamd_version(void) { return "wiggletools_amd 0.1 (gfx950)"; }
+
+int wtamd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int wtamd_set_device(int ordinal) {
+    WT_HIP(hipSetDevice(ordinal));
+    return WTAMD_OK;
+}
+
+static int wt_trackset_common(const wtamd_tracks *t, wtamd_trackset *ts) {
+    if (!t || t->n_chrom < 0 || t->n_tracks <= 0 || !t->seg_off || !t->defaults)
+        return wt_fail(WTAMD_ERR_ARG, "wtamd_trackset_create: bad tracks descriptor");
+    if (wtamd_device_count() <= 0) return wt_fail(WTAMD_ERR_NODEVICE, "no HIP device visible");
+    ts->n_chrom = t->n_chrom;
+    ts->n_tracks = t->n_tracks;
+    ts->value_f64 = t->value_is_f64 != 0;
+    const int64_t n_seg = (int64_t) t->n_chrom * t->n_tracks;
+    ts->seg_off.assign(t->seg_off, t->seg_off + n_seg + 1);
+    for (int64_t s = 0; s < n_seg; s++)
+        if (ts->seg_off[s + 1] < ts->seg_off[s]) return wt_fail(WTAMD_ERR_ARG, "seg_off not monotone");
+    ts->n_intervals = ts->seg_off[n_seg] - ts->seg_off[0];
+    if (ts->seg_off[0] != 0) return wt_fail(WTAMD_ERR_ARG, "seg_off[0] must be 0");
+    ts->defaults.assign(t->defaults, t->defaults + t->n_tracks);
+    ts->scratch_f32 = !ts->value_f64 && wt_defaults_fit_f32(ts->defaults.data(), ts->n_tracks);
+    WT_HIP(hipGetDevice(&ts->device));
+    hipDeviceProp_t prop;
+    WT_HIP(hipGetDeviceProperties(&prop, ts->device));
+    ts->num_cu = prop.multiProcessorCount;
+    WT_HIP(hipMalloc(&ts->d_seg_off, sizeof(int64_t) * (n_seg + 1)));
+    WT_HIP(hipMemcpy(ts->d_seg_off, ts->seg_off.data(), sizeof(int64_t) * (n_seg + 1), hipMemcpyHostToDevice));
+    WT_HIP(hipMalloc(&ts->d_defaults, sizeof(double) * t->n_tracks));
+    WT_HIP(hipMemcpy(ts->d_defaults, ts->defaults.data(), sizeof(double) * t->n_tracks, hipMemcpyHostToDevice));
+    WT_HIP(hipMalloc(&ts->d_counters, sizeof(unsigned long long) * WT_CTR_N));
+    WT_HIP(hipHostMalloc(&ts->h_counters, sizeof(unsigned long long) * WT_CTR_N));
+    WT_HIP(hipMalloc(&ts->d_chrom_run_off, sizeof(int64_t) * (t->n_chrom + 1)));
+    WT_HIP(hipEventCreate(&ts->ev_i0));
+    WT_HIP(hipEventCreate(&ts->ev_i1));
+    WT_HIP(hipEventCreate(&ts->ev_r0));
+    WT_HIP(hipEventCreate(&ts->ev_r1));
+    return WTAMD_OK;
+}
+
+int wtamd_trackset_create_host(const wtamd_tracks *t, wtamd_trackset **out) {
+    if (!out) return wt_fail(WTAMD_ERR_ARG, "out == NULL");
+    wtamd_trackset *ts = new wtamd_trackset();
+    int rc = wt_trackset_common(t, ts);
+    if (rc != WTAMD_OK) { wtamd_trackset_destroy(ts); return rc; }
+    ts->owns = true;
+    const int64_t n = ts->n_intervals;
+    const size_t vsz = ts->value_f64 ? 8 : 4;
+    const int64_t n_alloc = n > 0 ? n : 1;
+    WT_HIP(hipMalloc(&ts->d_start, sizeof(int32_t) * n_alloc));
+    WT_HIP(hipMalloc(&ts->d_finish, sizeof(int32_t) * n_alloc));
+    WT_HIP(hipMalloc(&ts->d_value, vsz * n_alloc));
+    if (n > 0) {
+        if (!t->start || !t->finish || !t->value) { wtamd_trackset_destroy(ts); return wt_fail(WTAMD_ERR_ARG, "NULL arrays"); }
+        WT_HIP(hipMemcpy(ts->d_start, t->start, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        WT_HIP(hipMemcpy(ts->d_finish, t->finish, sizeof(int32_t) * n, hipMemcpyHostToDevice));
+        WT_HIP(hipMemcpy(ts->d_value, t->value, vsz * n, hipMemcpyHostToDevice));
+    }
+    const int64_t n_seg = (int64_t) ts->n_chrom * ts->n_tracks;
+    ts->first_start.assign(n_seg, 0);
+    ts->last_finish.assign(n_seg, 0);
+    for (int64_t s = 0; s < n_seg; s++)
+        if (ts->seg_off[s + 1] > ts->seg_off[s]) {
+            ts->first_start[s] = t->start[ts->seg_off[s]];
+            ts->last_finish[s] = t->finish[ts->seg_off[s + 1] - 1];
+        }
+    *out = ts;
+    return WTAMD_OK;
+}
+
+int wtamd_trackset_create_device(const wtamd_tracks *t, wtamd_trackset **out) {
+    if (!out) return wt_fail(WTAMD_ERR_ARG, "out == NULL");
+    wtamd_trackset *ts = new wtamd_trackset();
+    int rc = wt_trackset_common(t, ts);
+    if (rc != WTAMD_OK) { wtamd_trackset_destroy(ts); return rc; }
+    ts->owns = false;
+    ts->d_start = const_cast<int32_t *>(t->start);
+    ts->d_finish = const_cast<int32_t *>(t->finish);
+    ts->d_value = const_cast<void *>(t->value);
+    const int64_t n_seg = (int64_t) ts->n_chrom * ts->n_tracks;
+    ts->first_start.assign(n_seg, 0);
+    ts->last_finish.assign(n_seg, 0);
+    if (n_seg > 0 && ts->n_intervals > 0) {
+        int32_t *d_fs = nullptr, *d_lf = nullptr;
+        WT_HIP(hipMalloc(&d_fs, sizeof(int32_t) * n_seg));
+        WT_HIP(hipMalloc(&d_lf, sizeof(int32_t) * n_seg));
+        hipLaunchKernelGGL(wt_extents_kernel, dim3((unsigned) ((n_seg + 255) / 256)), dim3(256), 0, 0,
+                           ts->d_seg_off, ts->d_start, ts->d_finish, (long long) n_seg, d_fs, d_lf);
+        WT_HIP(hipGetLastError());
+        WT_HIP(hipMemcpy(ts->first_start.data(), d_fs, sizeof(int32_t) * n_seg, hipMemcpyDeviceToHost));
+        WT_HIP(hipMemcpy(ts->last_finish.data(), d_lf, sizeof(int32_t) * n_seg, hipMemcpyDeviceToHost));
+        (void) hipFree(d_fs); (void) hipFree(d_lf);
+    }
+    *out = ts;
+    return WTAMD_OK;
+}
+
+void wtamd_trackset_destroy(wtamd_trackset *ts) {
+    if (!ts) return;
+    if (ts->owns) { (void) hipFree(ts->d_start); (void) hipFree(ts->d_finish); (void) hipFree(ts->d_value); }
+    (void) hipFree(ts->d_seg_off); (void) hipFree(ts->d_defaults); (void) hipFree(ts->d_counters); (void) hipFree(ts->d_chrom_run_off);
+    if (ts->h_counters) (void) hipHostFree(ts->h_counters);
+    for (auto &kv : ts->windows) wt_free_windows(kv.second);
+    if (ts->ev_i0) (void) hipEventDestroy(ts->ev_i0);
+    if (ts->ev_i1) (void) hipEventDestroy(ts->ev_i1);
+    if (ts->ev_r0) (void) hipEventDestroy(ts->ev_r0);
+    if (ts->ev_r1) (void) hipEventDestroy(ts->ev_r1);
+    delete ts;
+}
+
+static int64_t wt_span(const wtamd_trackset *ts) {
+    // sum over chromosomes of (max finish - min start)
+    int64_t span = 0;
+    for (int c = 0; c < ts->n_chrom; c++) {
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (int i = 0; i < ts->n_tracks; i++) {
+            const int64_t s = (int64_t) c * ts->n_tracks + i;
+            if (ts->seg_off[s + 1] > ts->seg_off[s]) {
+                lo = std::min<int64_t>(lo, ts->first_start[s]);
+                hi = std::max<int64_t>(hi, ts->last_finish[s]);
+            }
+        }
+        if (lo <= hi) span += hi - lo;
+    }
+    return span;
+}
+
+int64_t wtamd_trackset_max_runs(const wtamd_trackset *ts) {
+    if (!ts) return 0;
+    // every run starts at an interval start or finish, and no two runs start at the same position
+    return std::min<int64_t>(2 * ts->n_intervals, wt_span(ts));
+}
+
+static int wt_get_windows(wtamd_trackset *ts, int W, WtWindows **out) {
+    auto it = ts->windows.find(W);
+    if (it != ts->windows.end()) { *out = &it->second; return WTAMD_OK; }
+    WtWindows w;
+    wt_make_windows(ts->n_chrom, ts->n_tracks, ts->seg_off.data(), ts->first_start.data(), ts->last_finish.data(), W, w.tab);
+    const int nc = ts->n_chrom > 0 ? ts->n_chrom : 1;
+    const int64_t nwin = w.tab.n_windows > 0 ? w.tab.n_windows : 1;
+    WT_HIP(hipMalloc(&w.d_cbase, sizeof(int32_t) * nc));
+    WT_HIP(hipMalloc(&w.d_cnwin, sizeof(int32_t) * nc));
+    WT_HIP(hipMalloc(&w.d_cfirst, sizeof(int64_t) * (nc + 1)));
+    WT_HIP(hipMalloc(&w.d_win_chrom, sizeof(int32_t) * nwin));
+    WT_HIP(hipMalloc(&w.d_widx, sizeof(uint32_t) * (size_t) (w.tab.n_rows > 0 ? w.tab.n_rows : 1) * ts->n_tracks));
+    WT_HIP(hipMalloc(&w.d_status, sizeof(unsigned long long) * nwin));
+    if (ts->n_chrom > 0) {
+        WT_HIP(hipMemcpy(w.d_cbase, w.tab.cbase.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
+        WT_HIP(hipMemcpy(w.d_cnwin, w.tab.c_nwin.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
+        WT_HIP(hipMemcpy(w.d_cfirst, w.tab.c_first_win.data(), sizeof(int64_t) * (ts->n_chrom + 1), hipMemcpyHostToDevice));
+        WT_HIP(hipMemcpy(w.d_win_chrom, w.tab.win_chrom.data(), sizeof(int32_t) * w.tab.n_windows, hipMemcpyHostToDevice));
+    }
+    ts->windows[W] = w;
+    *out = &ts->windows[W];
+    return WTAMD_OK;
+}
+
+static void wt_fill_params(const wtamd_trackset *ts, const WtWindows *w, const WtPlan &plan, WtParams &P) {
+    memset(&P, 0, sizeof(P));
+    P.start = ts->d_start; P.finish = ts->d_finish; P.value = ts->d_value;
+    P.seg_off = ts->d_seg_off; P.defaults = ts->d_defaults;
+    P.n_chrom = ts->n_chrom; P.n_tracks = ts->n_tracks;
+    P.cbase = w->d_cbase; P.c_nwin = w->d_cnwin; P.c_first_win = w->d_cfirst;
+    P.n_windows = w->tab.n_windows; P.win_chrom = w->d_win_chrom; P.widx = w->d_widx;
+    P.status = w->d_status; P.counters = ts->d_counters;
+    wt_plan_to_params(plan, P);
+}
+
+static int wt_build_index(wtamd_trackset *ts, WtWindows *w, const WtPlan &plan, hipStream_t s) {
+    WtParams P;
+    wt_fill_params(ts, w, plan, P);
+    WT_HIP(hipEventRecord(ts->ev_i0, s));
+    WT_HIP(hipMemsetAsync(w->d_widx, 0, sizeof(uint32_t) * (size_t) w->tab.n_rows * ts->n_tracks, s));
+    if (ts->n_intervals > 0) {
+        const long long total = ts->n_intervals;
+        long long blocks = (total + 255) / 256;
+        const long long cap = (long long) ts->num_cu * 16;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(wt_index_kernel, dim3((unsigned) blocks), dim3(256), 0, s, P, total);
+        WT_HIP(hipGetLastError());
+    }
+    WT_HIP(hipEventRecord(ts->ev_i1, s));
+    ts->have_index_time = true;
+    w->indexed = true;
+    return WTAMD_OK;
+}
+
+int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
+    if (!ts) return wt_fail(WTAMD_ERR_ARG, "ts == NULL");
+    WtPlan plan;
+    std::string err;
+    if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
+    WtWindows *w = nullptr;
+    int rc = wt_get_windows(ts, plan.W, &w);
+    if (rc != WTAMD_OK) return rc;
+    return wt_build_index(ts, w, plan, (hipStream_t) stream);
+}
+
+}  // extern "C"
+
+// Launch functor for wt_dispatch
+struct WtLaunch {
+    WtParams P;
+    int T = 0, lds = 0, grid = 0;
+    hipStream_t stream = nullptr;
+    int num_cu = 256;
+    hipError_t err = hipSuccess;
+
+    template <int OP, class ValT, class ScrT>
+    void run() {
+        auto kern = wt_reduce_kernel<OP, ValT, ScrT>;
+        if (lds > 48 * 1024) {
+            err = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (err != hipSuccess) return;
+        }
+        int per_cu = 0;
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, T, (size_t) lds);
+        if (err != hipSuccess) return;
+        if (per_cu < 1) per_cu = 1;
+        long long g = (long long) num_cu * per_cu;
+        if (g > P.n_windows) g = P.n_windows;
+        if (g < 1) g = 1;
+        grid = (int) g;
+        hipLaunchKernelGGL(kern, dim3((unsigned) grid), dim3((unsigned) T), (size_t) lds, stream, P);
+        err = hipGetLastError();
+    }
+};
+
+extern "C" {
+
+static int wt_check_desc(const wtamd_trackset *ts, const wtamd_reduce_desc *d) {
+    if (!ts || !d) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    if (d->op < 0 || d->op >= WTAMD_OP_COUNT_) return wt_fail(WTAMD_ERR_ARG, "unknown op");
+    if (d->op == WTAMD_OP_TTEST) {
+        // message + precondition of reference setComparisons.c:123-128
+        if (d->n_set0 < 3 || ts->n_tracks - d->n_set0 < 3)
+            return wt_fail(WTAMD_ERR_ARG, "The t-test function only works for two sets with enough elements to compute variance");
+    } else if (d->op == WTAMD_OP_MWU) {
+        // reference setComparisons.c:374-377
+        if (d->n_set0 < 1 || ts->n_tracks - d->n_set0 < 1)
+            return wt_fail(WTAMD_ERR_ARG, "The Mann-Whitney U function only works for two non-empty sets");
+    }
+    return WTAMD_OK;
+}
+
+static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0, wtamd_runs *runs,
+                          double *d_tile, uint8_t *d_inplay, int64_t *n_runs, hipStream_t s) {
+    if (!runs || !runs->start || !runs->finish || (op != WT_OP_MULTIPLEX && !runs->value))
+        return wt_fail(WTAMD_ERR_ARG, "wtamd_reduce: output arrays missing");
+    WtPlan plan;
+    std::string err;
+    if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
+    if (plan.T > WT_MAX_BLOCK) return wt_fail(WTAMD_ERR_ARG, "workgroup size above 512");
+    WtWindows *w = nullptr;
+    int rc = wt_get_windows(ts, plan.W, &w);
+    if (rc != WTAMD_OK) return rc;
+    if (!w->indexed) {
+        rc = wt_build_index(ts, w, plan, s);
+        if (rc != WTAMD_OK) return rc;
+    }
+    WtLaunch L;
+    wt_fill_params(ts, w, plan, L.P);
+    L.P.op = op; L.P.flags = flags; L.P.n_set0 = n_set0;
+    L.P.capacity = runs->capacity;
+    L.P.o_start = runs->start; L.P.o_finish = runs->finish; L.P.o_value = runs->value;
+    L.P.chrom_run_off = runs->chrom_run_off ? runs->chrom_run_off : ts->d_chrom_run_off;
+    L.P.o_tile = d_tile; L.P.o_inplay = d_inplay;
+    L.T = plan.T; L.lds = plan.lds_bytes; L.stream = s; L.num_cu = ts->num_cu;
+
+    WT_HIP(hipMemsetAsync(ts->d_counters, 0, sizeof(unsigned long long) * WT_CTR_N, s));
+    WT_HIP(hipMemsetAsync(L.P.chrom_run_off, 0, sizeof(int64_t) * (ts->n_chrom + 1), s));
+    if (w->tab.n_windows > 0) {
+        WT_HIP(hipMemsetAsync(w->d_status, 0, sizeof(unsigned long long) * w->tab.n_windows, s));
+        WT_HIP(hipEventRecord(ts->ev_r0, s));
+        if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, L)) return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
+        if (L.err != hipSuccess) return wt_fail(WTAMD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(L.err));
+        WT_HIP(hipEventRecord(ts->ev_r1, s));
+        ts->have_reduce_time = true;
+    }
+    ts->stats.n_windows = w->tab.n_windows;
+    ts->stats.window_bp = plan.W;
+    ts->stats.lds_bytes = plan.lds_bytes;
+    if (n_runs) {
+        WT_HIP(hipMemcpyAsync(ts->h_counters, ts->d_counters, sizeof(unsigned long long) * WT_CTR_N, hipMemcpyDeviceToHost, s));
+        WT_HIP(hipStreamSynchronize(s));
+        ts->stats.n_runs = (int64_t) ts->h_counters[WT_CTR_RUNS];
+        ts->stats.covered_bp = (int64_t) ts->h_counters[WT_CTR_BP];
+        ts->stats.n_intervals = (int64_t) ts->h_counters[WT_CTR_INTERVALS];
+        *n_runs = ts->stats.n_runs;
+        if (ts->h_counters[WT_CTR_ERROR] & WT_ERR_LOOKBACK) return wt_fail(WTAMD_ERR_INTERNAL, "look-back timed out");
+        if (ts->h_counters[WT_CTR_ERROR] & WT_ERR_CAPACITY) return wt_fail(WTAMD_ERR_CAPACITY, "output capacity too small");
+    }
+    return WTAMD_OK;
+}
+
+int wtamd_reduce(wtamd_trackset *ts, const wtamd_reduce_desc *desc, wtamd_runs *runs, int64_t *n_runs, void *stream) {
+    int rc = wt_check_desc(ts, desc);
+    if (rc != WTAMD_OK) return rc;
+    return wt_reduce_impl(ts, desc->op, desc->flags, desc->n_set0, runs, nullptr, nullptr, n_runs, (hipStream_t) stream);
+}
+
+static int wt_reduce_host_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0, wtamd_runs *runs,
+                               double *h_tile, uint8_t *h_inplay, int64_t *n_runs) {
+    if (!runs) return wt_fail(WTAMD_ERR_ARG, "runs == NULL");
+    int64_t cap = wtamd_trackset_max_runs(ts);
+    if (cap > runs->capacity) cap = runs->capacity;     // never write past the caller's arrays
+    const int64_t alloc = cap > 0 ? cap : 1;
+    const int N = ts->n_tracks;
+    wtamd_runs d{};
+    d.capacity = cap;
+    double *d_tile = nullptr;
+    uint8_t *d_inplay = nullptr;
+    WT_HIP(hipMalloc(&d.start, sizeof(int32_t) * alloc));
+    WT_HIP(hipMalloc(&d.finish, sizeof(int32_t) * alloc));
+    WT_HIP(hipMalloc(&d.value, sizeof(double) * alloc));
+    WT_HIP(hipMalloc(&d.chrom_run_off, sizeof(int64_t) * (ts->n_chrom + 1)));
+    if (op == WT_OP_MULTIPLEX) {
+        WT_HIP(hipMalloc(&d_tile, sizeof(double) * alloc * N));
+        WT_HIP(hipMalloc(&d_inplay, sizeof(uint8_t) * alloc * N));
+    }
+    int64_t n = 0;
+    int rc = wt_reduce_impl(ts, op, flags, n_set0, &d, d_tile, d_inplay, &n, nullptr);
+    if (rc == WTAMD_OK) {
+        if (n > 0) {
+            WT_HIP(hipMemcpy(runs->start, d.start, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+            WT_HIP(hipMemcpy(runs->finish, d.finish, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+            if (runs->value) WT_HIP(hipMemcpy(runs->value, d.value, sizeof(double) * n, hipMemcpyDeviceToHost));
+            if (h_tile) WT_HIP(hipMemcpy(h_tile, d_tile, sizeof(double) * n * N, hipMemcpyDeviceToHost));
+            if (h_inplay) WT_HIP(hipMemcpy(h_inplay, d_inplay, sizeof(uint8_t) * n * N, hipMemcpyDeviceToHost));
+        }
+        if (runs->chrom_run_off)
+            WT_HIP(hipMemcpy(runs->chrom_run_off, d.chrom_run_off, sizeof(int64_t) * (ts->n_chrom + 1), hipMemcpyDeviceToHost));
+        if (n_runs) *n_runs = n;
+    }
+    (void) hipFree(d.start); (void) hipFree(d.finish); (void) hipFree(d.value); (void) hipFree(d.chrom_run_off);
+    (void) hipFree(d_tile); (void) hipFree(d_inplay);
+    return rc;
+}
+
+int wtamd_reduce_host(wtamd_trackset *ts, const wtamd_reduce_desc *desc, wtamd_runs *runs, int64_t *n_runs) {
+    int rc = wt_check_desc(ts, desc);
+    if (rc != WTAMD_OK) return rc;
+    return wt_reduce_host_impl(ts, desc->op, desc->flags, desc->n_set0, runs, nullptr, nullptr, n_runs);
+}
+
+int wtamd_multiplex_host(wtamd_trackset *ts, uint32_t flags, wtamd_runs *runs, double *values, uint8_t *inplay,
+                         int64_t *n_runs) {
+    if (!ts || !values || !inplay) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    return wt_reduce_host_impl(ts, WT_OP_MULTIPLEX, flags, 0, runs, values, inplay, n_runs);
+}
+
+int wtamd_runs_auc(const wtamd_runs *runs, int64_t n_runs, double *auc, void *stream) {
+    if (!runs || !auc) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    hipStream_t s = (hipStream_t) stream;
+    const int blocks = 512;
+    double *d_partial = nullptr;
+    WT_HIP(hipMalloc(&d_partial, sizeof(double) * (blocks + 1)));
+    hipLaunchKernelGGL(wt_auc_kernel, dim3(blocks), dim3(256), 0, s, runs->start, runs->finish, runs->value,
+                       (long long) n_runs, d_partial);
+    hipLaunchKernelGGL(wt_auc_final_kernel, dim3(1), dim3(64), 0, s, d_partial, blocks, d_partial + blocks);
+    WT_HIP(hipGetLastError());
+    WT_HIP(hipMemcpyAsync(auc, d_partial + blocks, sizeof(double), hipMemcpyDeviceToHost, s));
+    WT_HIP(hipStreamSynchronize(s));
+    (void) hipFree(d_partial);
+    return WTAMD_OK;
+}
+
+int wtamd_get_stats(const wtamd_trackset *ts_c, wtamd_stats *out) {
+    if (!ts_c || !out) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    wtamd_trackset *ts = const_cast<wtamd_trackset *>(ts_c);
+    if (ts->have_index_time && hipEventSynchronize(ts->ev_i1) == hipSuccess)
+        (void) hipEventElapsedTime(&ts->stats.index_ms, ts->ev_i0, ts->ev_i1);
+    if (ts->have_reduce_time && hipEventSynchronize(ts->ev_r1) == hipSuccess)
+        (void) hipEventElapsedTime(&ts->stats.reduce_ms, ts->ev_r0, ts->ev_r1);
+    *out = ts->stats;
+    return WTAMD_OK;
+}
+
+}  // extern "C"

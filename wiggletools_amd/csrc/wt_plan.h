@@ -1,0 +1,168 @@
+// wt_plan.h -- host-side planning shared by the HIP engine (wt_engine.hip) and
+// the CPU emulator used by the no-GPU tests: window width / workgroup size /
+// LDS carve for a given track count and reducer, and the per-chromosome window
+// tables.  Pure C++, no HIP.
+#ifndef WT_PLAN_H_
+#define WT_PLAN_H_
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "wt_core.h"
+
+struct WtPlan {
+    int W = 0;          // window width (bp), multiple of 64
+    int T = 0;          // workgroup size (lanes), multiple of 64
+    int n_words = 0;
+    int spitch = 0, cpitch = 0;
+    int off_S = 0, off_cnt = 0, off_U = 0, off_E = 0, off_epfx = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
+    int lds_bytes = 0;
+    int scratch_elem = 0;   // bytes per scratch element (0: op needs no scratch)
+};
+
+static inline int wt_align16(int x) { return (x + 15) & ~15; }
+
+static inline bool wt_op_needs_scratch(int op) { return op == WT_OP_MEDIAN || op == WT_OP_MWU; }
+
+// LDS bytes for a candidate (W, T)
+static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem, WtPlan &p) {
+    p.W = W; p.T = T; p.n_words = W / 64;
+    p.spitch = p.n_words + 1;                 // +1 word: rows start on different banks
+    p.cpitch = (p.n_words + 1) & ~1;          // even number of u16
+    p.scratch_elem = scratch_elem;
+    int o = 0;
+    p.off_S = o;       o = wt_align16(o + n_tracks * p.spitch * 8);
+    p.off_cnt = o;     o = wt_align16(o + n_tracks * p.cpitch * 2);
+    p.off_U = o;       o = wt_align16(o + p.n_words * 8);
+    p.off_E = o;       o = wt_align16(o + p.n_words * 8);
+    p.off_epfx = o;    o = wt_align16(o + (p.n_words + 1) * 4);
+    p.off_gbase = o;   o = wt_align16(o + n_tracks * 8);
+    p.off_scratch = o;
+    if (op == WT_OP_MEDIAN) o = wt_align16(o + n_tracks * T * scratch_elem);
+    else if (op == WT_OP_MWU) o = wt_align16(o + n_tracks * T * (scratch_elem + 1));
+    p.off_shared = o;  o = wt_align16(o + (int) sizeof(WtShared));
+    p.lds_bytes = o;
+}
+
+// Chooses (W, T).  Environment overrides (experiments): WTAMD_W, WTAMD_T.
+// soft_limit: preferred LDS per workgroup (several workgroups per CU);
+// hard_limit: the most one workgroup may take (gfx950: 160 KiB).
+static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &out, std::string &err,
+                                int soft_limit = 64 * 1024, int hard_limit = 160 * 1024) {
+    const char *eW = getenv("WTAMD_W");
+    const char *eT = getenv("WTAMD_T");
+    const int scratch_elem = wt_op_needs_scratch(op) ? (scratch_f32 ? 4 : 8) : 0;
+    std::vector<int> Ts;
+    if (eT) Ts.push_back(atoi(eT));
+    else if (wt_op_needs_scratch(op)) Ts = {256, 128, 64};
+    else Ts = {512, 256};
+    for (int pass = 0; pass < 2; pass++) {
+        const int limit = pass == 0 ? soft_limit : hard_limit;
+        for (int T : Ts) {
+            if (T <= 0 || (T & 63) || T > 1024) continue;
+            for (int W = eW ? atoi(eW) : WT_MAX_ITERS * T; W >= 64; W >>= 1) {
+                if ((W & 63) || W > WT_MAX_ITERS * T || W > 32768) { if (eW) break; continue; }
+                WtPlan p;
+                wt_carve(n_tracks, op, W, T, scratch_elem, p);
+                // scratch ops: do not accept tiny windows while a smaller T is still to be tried
+                if (p.lds_bytes <= limit && !(pass == 0 && W < 256 && !eW)) { out = p; return true; }
+                if (eW) break;
+            }
+        }
+    }
+    err = "no LDS plan fits " + std::to_string(n_tracks) + " tracks (op " + std::to_string(op) + ")";
+    return false;
+}
+
+static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
+    P.W = p.W; P.n_words = p.n_words; P.spitch = p.spitch; P.cpitch = p.cpitch;
+    P.off_S = p.off_S; P.off_cnt = p.off_cnt; P.off_U = p.off_U; P.off_E = p.off_E;
+    P.off_epfx = p.off_epfx; P.off_gbase = p.off_gbase; P.off_scratch = p.off_scratch;
+    P.off_shared = p.off_shared; P.lds_bytes = p.lds_bytes;
+}
+
+struct WtWindowTables {
+    std::vector<int32_t> cbase, c_nwin, win_chrom;
+    std::vector<int64_t> c_first_win;   // n_chrom + 1
+    int64_t n_windows = 0;
+    int64_t n_rows = 0;                 // n_windows + n_chrom
+    int64_t span_bp = 0;                // sum over chromosomes of (last finish - first start)
+};
+
+// first_start / last_finish: per (chrom, track) segment, only meaningful when the
+// segment is non-empty (seg_off[s+1] > seg_off[s]).
+static inline void wt_make_windows(int n_chrom, int n_tracks, const int64_t *seg_off,
+                                   const int32_t *first_start, const int32_t *last_finish, int W,
+                                   WtWindowTables &t) {
+    t.cbase.assign(n_chrom, 0);
+    t.c_nwin.assign(n_chrom, 1);
+    t.c_first_win.assign(n_chrom + 1, 0);
+    t.win_chrom.clear();
+    t.span_bp = 0;
+    for (int c = 0; c < n_chrom; c++) {
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (int i = 0; i < n_tracks; i++) {
+            const int64_t s = (int64_t) c * n_tracks + i;
+            if (seg_off[s + 1] > seg_off[s]) {
+                lo = std::min<int64_t>(lo, first_start[s]);
+                hi = std::max<int64_t>(hi, last_finish[s]);
+            }
+        }
+        int64_t nw = 1;
+        if (lo <= hi) {
+            t.cbase[c] = (int32_t) lo;
+            nw = std::max<int64_t>(1, (hi - lo + W - 1) / W);
+            t.span_bp += hi - lo;
+        }
+        t.c_nwin[c] = (int32_t) nw;
+        t.c_first_win[c + 1] = t.c_first_win[c] + nw;
+        for (int64_t m = 0; m < nw; m++) t.win_chrom.push_back(c);
+    }
+    t.n_windows = t.c_first_win[n_chrom];
+    t.n_rows = t.n_windows + n_chrom;
+}
+
+// Template dispatch over (op, value type, scratch type).  F must provide
+//   template <int OP, class ValT, class ScrT> void run();
+// Streaming ops ignore ScrT (ScrT = ValT keeps the instantiation count down).
+template <int OP, class F>
+static inline void wt_dispatch_types(bool value_f64, bool scratch_f32, F &f) {
+    if (value_f64) f.template run<OP, double, double>();
+    else if (!wt_op_needs_scratch(OP) || scratch_f32) f.template run<OP, float, float>();
+    else f.template run<OP, float, double>();
+}
+
+template <class F>
+static inline bool wt_dispatch(int op, bool value_f64, bool scratch_f32, F &f) {
+    switch (op) {
+    case WT_OP_SUM: wt_dispatch_types<WT_OP_SUM>(value_f64, scratch_f32, f); return true;
+    case WT_OP_PRODUCT: wt_dispatch_types<WT_OP_PRODUCT>(value_f64, scratch_f32, f); return true;
+    case WT_OP_MEAN: wt_dispatch_types<WT_OP_MEAN>(value_f64, scratch_f32, f); return true;
+    case WT_OP_VAR: wt_dispatch_types<WT_OP_VAR>(value_f64, scratch_f32, f); return true;
+    case WT_OP_STDDEV: case WT_OP_ENTROPY:   // reference reducers.c:665: entropy runs the stddev pop
+        wt_dispatch_types<WT_OP_STDDEV>(value_f64, scratch_f32, f); return true;
+    case WT_OP_CV: wt_dispatch_types<WT_OP_CV>(value_f64, scratch_f32, f); return true;
+    case WT_OP_MIN: wt_dispatch_types<WT_OP_MIN>(value_f64, scratch_f32, f); return true;
+    case WT_OP_MAX: wt_dispatch_types<WT_OP_MAX>(value_f64, scratch_f32, f); return true;
+    case WT_OP_MEDIAN: wt_dispatch_types<WT_OP_MEDIAN>(value_f64, scratch_f32, f); return true;
+    case WT_OP_TTEST: wt_dispatch_types<WT_OP_TTEST>(value_f64, scratch_f32, f); return true;
+    case WT_OP_MWU: wt_dispatch_types<WT_OP_MWU>(value_f64, scratch_f32, f); return true;
+    case WT_OP_MULTIPLEX: wt_dispatch_types<WT_OP_MULTIPLEX>(value_f64, scratch_f32, f); return true;
+    default: return false;
+    }
+}
+
+// True iff every default survives a round trip through float (then float
+// tracks may keep their median / MWU scratch column in 4-byte elements).
+static inline bool wt_defaults_fit_f32(const double *d, int n) {
+    for (int i = 0; i < n; i++) {
+        if (d[i] != d[i]) continue;
+        if ((double) (float) d[i] != d[i]) return false;
+    }
+    return true;
+}
+
+#endif  // WT_PLAN_H_
