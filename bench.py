@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--mean-run", type=float, default=16.0)
     ap.add_argument("--scale", type=float, default=0.125, help="fraction of the GRCh38 lengths per step")
     ap.add_argument("--op", default="mean")
+    ap.add_argument("--n-set0", type=int, default=-1, help="two-sample ops: tracks in the first set (default N/2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -152,9 +153,12 @@ def main():
     out = ts.alloc_runs()
     stream = torch.cuda.current_stream().cuda_stream
 
+    two = engine.opcode(args.op) in (10, 11)
+    n_set0 = (args.n_set0 if args.n_set0 >= 0 else args.tracks // 2) if two else 0
+
     def step(sync=False):
         ts.index(args.op, stream)
-        return ts.reduce(args.op, out, stream=stream, sync=sync)
+        return ts.reduce(args.op, out, n_set0=n_set0, stream=stream, sync=sync)
 
     for _ in range(max(args.warmup, 0)):
         step(sync=True)
@@ -172,7 +176,7 @@ def main():
         ev[k][0].record()
         ts.index(args.op, stream)
         ev[k][1].record()
-        ts.reduce(args.op, out, stream=stream, sync=False)
+        ts.reduce(args.op, out, n_set0=n_set0, stream=stream, sync=False)
         ev[k][2].record()
     torch.cuda.synchronize()
     if world > 1:
@@ -182,7 +186,7 @@ def main():
     reduce_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
 
     # post-timing verification + scalar gather (RCCL over xGMI when world > 1)
-    n_runs = ts.reduce(args.op, out, stream=stream, sync=True)
+    n_runs = ts.reduce(args.op, out, n_set0=n_set0, stream=stream, sync=True)
     st = ts.stats()
     covered_bp = st["covered_bp"]
     auc = out.auc()

@@ -22,13 +22,13 @@ def lib():
     return _lib
 
 
-def reduce(t, op, flags=0, n_set0=0, W=None, T=None, multiplex=False):
+def reduce(t, op, flags=0, n_set0=0, ppt=None, T=None, multiplex=False):
     """t: RunLists.  Returns (chrom, start, finish, value) [+ (tile, inplay) if multiplex], info."""
     from oracle.oracle import OPS
     opcode = 12 if multiplex else (OPS[op] if isinstance(op, str) else int(op))
-    old = {k: os.environ.get(k) for k in ("WTAMD_W", "WTAMD_T")}
+    old = {k: os.environ.get(k) for k in ("WTAMD_PPT", "WTAMD_T")}
     try:
-        for k, v in (("WTAMD_W", W), ("WTAMD_T", T)):
+        for k, v in (("WTAMD_PPT", ppt), ("WTAMD_T", T)):
             if v is None:
                 os.environ.pop(k, None)
             else:

@@ -21,24 +21,26 @@ struct EmuRun {
     WtParams P;
     WtPlan plan;
     std::vector<char> lds;
-    std::vector<WtLane> lanes;
+    int T_lanes = 0;
 
-    template <int OP, class ValT, class ScrT>
+    template <int OP, class ValT, class ScrT, int K>
     void run() {
         WtCtx c;
         wt_ctx_init(c, P, lds.data());
         const int T = plan.T;
+        std::vector<WtLane<K>> lanes(T);
         for (;;) {
             const long long k = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
             if (k >= P.n_windows) break;
             wt_phase_header(P, c, k);
             for (int t = 0; t < T; t++) wt_phase_zero(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_load(P, c, t, T);
-            for (int t = 0; t < T; t++) wt_phase_count(P, c, t, T);
-            for (int t = 0; t < T; t++) wt_phase_eval<OP, ValT, ScrT>(P, c, lanes[t], t, T);
+            for (int t = 0; t < T; t++) wt_phase_count_a(P, c, t, T);
+            for (int t = 0; t < T; t++) wt_phase_count_b(P, c, t, T);
+            for (int t = 0; t < T; t++) wt_phase_eval<OP, ValT, ScrT, K>(P, c, lanes[t], t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
             wt_phase_lookback(P, c, k);
-            for (int t = 0; t < T; t++) wt_phase_write<OP, ValT>(P, c, lanes[t], t, T);
+            for (int t = 0; t < T; t++) wt_phase_write<OP, ValT, K>(P, c, lanes[t], t, T);
         }
     }
 };
@@ -82,11 +84,11 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
 
     // window index "kernel"
     const int64_t total = seg_off[n_seg];
-    for (int64_t g = 0; g < total; g++) wt_index_interval(P, g);
+    P.n_total = total;
+    { long long seg = 0; for (int64_t g = 0; g < total; g++) wt_index_interval(P, g, seg); }
 
     R.lds.assign((size_t) R.plan.lds_bytes + 64, 0);
-    R.lanes.resize(R.plan.T);
-    if (!wt_dispatch(op, value_is_f64 != 0, s32, R)) return -11;
+    if (total > 0 && !wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R)) return -11;
     if (info) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows;
                 info[4] = (long long) counters[WT_CTR_BP]; info[5] = (long long) counters[WT_CTR_INTERVALS]; }
     if (counters[WT_CTR_ERROR] & WT_ERR_CAPACITY) return -1;

@@ -9,18 +9,18 @@ from emu import emu
 
 # values: sum/mean/min/max/median are bit-exact by construction (same op order);
 # var/stddev/cv go through sqrt/div in the same order as well -> bit-exact on CPU.
-GEOMS = [(None, None), (64, 64), (128, 64), (256, 64), (256, 128)]
+GEOMS = [(None, None), (4, 64), (1, 64), (4, 128), (1, 128)]   # (positions per lane, workgroup size)
 
 
 @pytest.mark.parametrize("seed", range(40))
 def test_emu_one_sample_ops(oracle, seed):
     t = random_case(seed, dtype=np.float64 if seed % 2 else np.float32)
     d = t.as_dict()
-    W, T = GEOMS[seed % len(GEOMS)]
+    ppt, T = GEOMS[seed % len(GEOMS)]
     for strict in (0, 1):
         for op in ALL_MULTIPLEX_OPS:
             exp = oracle.reduce(d, op, flags=strict)
-            got, info = emu.reduce(t, op, flags=strict, W=W, T=T)
+            got, info = emu.reduce(t, op, flags=strict, ppt=ppt, T=T)
             assert_runs_equal(got, exp, 0.0, "seed %d op %s strict %d %s" % (seed, op, strict, info))
             assert info["covered_bp"] == int((exp[2] - exp[1]).sum())
 
@@ -31,11 +31,11 @@ def test_emu_two_sample_ops(oracle, seed):
     t = random_case(500 + seed, n_tracks=int(rng.integers(6, 12)), dtype=np.float64 if seed % 2 else np.float32)
     d = t.as_dict()
     n1 = int(rng.integers(3, t.n_tracks - 2))
-    W, T = GEOMS[seed % len(GEOMS)]
+    ppt, T = GEOMS[seed % len(GEOMS)]
     for flags in (0, 1, 2, 3):
         for op in ("ttest", "mwu"):
             exp = oracle.reduce(d, op, flags=flags, n_set0=n1)
-            got, info = emu.reduce(t, op, flags=flags, n_set0=n1, W=W, T=T)
+            got, info = emu.reduce(t, op, flags=flags, n_set0=n1, ppt=ppt, T=T)
             assert_runs_equal(got, exp, 1e-12 if op == "ttest" else 0.0,
                               "seed %d op %s flags %d %s" % (seed, op, flags, info))
 
@@ -44,10 +44,10 @@ def test_emu_two_sample_ops(oracle, seed):
 def test_emu_multiplex_tile(oracle, seed):
     t = random_case(900 + seed)
     d = t.as_dict()
-    W, T = GEOMS[seed % len(GEOMS)]
+    ppt, T = GEOMS[seed % len(GEOMS)]
     for strict in (0, 1):
         exp = oracle.multiplex(d, flags=strict)
-        got, info = emu.reduce(t, "sum", flags=strict, W=W, T=T, multiplex=True)
+        got, info = emu.reduce(t, "sum", flags=strict, ppt=ppt, T=T, multiplex=True)
         assert len(got[0]) == len(exp[0])
         for a, b in zip(got, exp):
             assert np.array_equal(a, b, equal_nan=True)
@@ -62,11 +62,11 @@ def test_emu_long_intervals_span_many_windows(oracle):
         [[(64, 65, 5.0), (128, 129, 6.0), (193, 257, 7.0)]],
     ]
     t = RunLists.from_lists(tracks)
-    for W in (64, 128, 256):
+    for ppt, T in ((1, 64), (4, 64), (1, 128)):
         for op in ("sum", "mean", "max", "median"):
             exp = oracle.reduce(t.as_dict(), op)
-            got, info = emu.reduce(t, op, W=W, T=64)
-            assert_runs_equal(got, exp, 0.0, "W %d op %s" % (W, op))
+            got, info = emu.reduce(t, op, ppt=ppt, T=T)
+            assert_runs_equal(got, exp, 0.0, "ppt %d T %d op %s" % (ppt, T, op))
 
 
 def test_emu_empty_and_single(oracle):

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwiggletools_amd.so")
+LIB_PATH = os.environ.get("WTAMD_LIB") or os.path.join(_HERE, "csrc", "libwiggletools_amd.so")
 
 
 class Tracks(C.Structure):

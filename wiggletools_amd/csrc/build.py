@@ -8,7 +8,17 @@ SO = os.path.join(HERE, "libwiggletools_amd.so")
 SRCS = ["wt_engine.hip", "wt_defaults.cpp", "wt_iter_abi.cpp"]
 DEPS = ["wt_core.h", "wt_plan.h", os.path.join("..", "..", "include", "wiggletools_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
+
+
+def build_variant(name, extra_flags):
+    """Experiment helper: builds libwiggletools_amd_<name>.so with extra compiler flags
+    (select it at run time with WTAMD_LIB=<path>)."""
+    srcs = [os.path.join(HERE, s) for s in SRCS if os.path.exists(os.path.join(HERE, s))]
+    out = os.path.join(HERE, "libwiggletools_amd_%s.so" % name)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc] + FLAGS + list(extra_flags) + srcs + ["-o", out])
+    return out
 
 
 def build(force=False, verbose=False):

@@ -48,13 +48,14 @@ enum {
 #define WT_STRICT_SET0 1u
 #define WT_STRICT_SET1 2u
 
-#define WT_MAX_ITERS 4           // positions per lane per window: W <= WT_MAX_ITERS * blockDim
+// consecutive window positions evaluated by one lane (template parameter K): 4 or 1; W == K * blockDim
 #define WT_FLAG_AGG  (1ull << 62)
 #define WT_FLAG_PFX  (2ull << 62)
 #define WT_VAL_MASK  ((1ull << 62) - 1)
 
 // counters[] slots (device, 64-bit each)
-enum { WT_CTR_TICKET = 0, WT_CTR_RUNS = 1, WT_CTR_BP = 2, WT_CTR_INTERVALS = 3, WT_CTR_ERROR = 4, WT_CTR_N = 8 };
+enum { WT_CTR_TICKET = 0, WT_CTR_RUNS = 1, WT_CTR_BP = 2, WT_CTR_INTERVALS = 3, WT_CTR_ERROR = 4,
+       WT_CTR_PROF = 8 /* 8 phase cycle counters, -DWT_PROFILE builds only */, WT_CTR_N = 16 };
 // error bits
 #define WT_ERR_CAPACITY 1ull
 #define WT_ERR_LOOKBACK 2ull
@@ -67,13 +68,15 @@ struct WtParams {
     const int64_t *seg_off;       // [n_chrom*n_tracks+1]
     const double *defaults;       // [n_tracks]
     int32_t n_chrom, n_tracks;
+    long long n_total;            // total number of intervals (>= 1 when a kernel is launched)
     // ---- chromosome tables ----
     const int32_t *cbase;         // [n_chrom] position of window 0 of the chromosome
     const int32_t *c_nwin;        // [n_chrom] number of windows (>= 1)
     const int64_t *c_first_win;   // [n_chrom+1] first global window index
     // ---- windows ----
-    int32_t W;                    // window width in bp, multiple of 64
-    int32_t n_words;              // W / 64
+    int32_t W;                    // window width in bp, power of two >= 64
+    int32_t logW;                 // log2(W)
+    int32_t n_words;              // W / 64 (64-bit words of U / E)
     int64_t n_windows;
     const int32_t *win_chrom;     // [n_windows]
     uint32_t *widx;               // [(n_windows + n_chrom) * n_tracks] first interval with finish >= boundary
@@ -94,9 +97,9 @@ struct WtParams {
     double *o_tile;               // WT_OP_MULTIPLEX only: [capacity * n_tracks]
     uint8_t *o_inplay;            // WT_OP_MULTIPLEX only
     // ---- LDS carve (bytes from the dynamic LDS base; all multiples of 16) ----
-    int32_t spitch;               // u64 words per S_i row (n_words + 1: bank spread)
-    int32_t cpitch;               // u16 entries per cnt_i row
-    int32_t off_S, off_cnt, off_U, off_E, off_epfx, off_gbase, off_scratch, off_shared;
+    int32_t spitch;               // u64 {S,C} pairs per track row (W/32 + 1: bank spread)
+    int32_t cpitch;               // u16 entries per cnt_i row (W/32, even)
+    int32_t off_S, off_cnt, off_segtot, off_U, off_E, off_epfx, off_gbase, off_scratch, off_shared;
     int32_t lds_bytes;
 };
 
@@ -113,16 +116,18 @@ struct WtShared {
 };
 
 // Per-lane state that lives across phases (registers on the GPU)
+template <int K>
 struct WtLane {
-    double res[WT_MAX_ITERS];
-    int32_t fin[WT_MAX_ITERS];
-    uint32_t emit;                // bit `it` set <=> position it*T+tid starts an emitted run
+    double res[K];
+    int32_t fin[K];
+    uint32_t emit;                // bit k set <=> position tid*K+k starts an emitted run
 };
 
 // LDS views
 struct WtCtx {
-    uint64_t *S;        // [n_tracks * spitch]
-    uint16_t *cnt;      // [n_tracks * cpitch]
+    uint64_t *SC;       // [n_tracks * spitch] low half: start bits S, high half: toggles -> coverage C
+    uint16_t *cnt;      // [n_tracks * cpitch] start-bit rank prefix per 32-bit word
+    uint32_t *segtot;   // [n_tracks * WT_COUNT_SEGS] count-phase segment totals
     uint64_t *U;        // [n_words] true breakpoints
     uint64_t *E;        // [n_words] emitted run starts
     uint32_t *epfx;     // [n_words + 1]
@@ -132,8 +137,9 @@ struct WtCtx {
 };
 
 WT_DEV void wt_ctx_init(WtCtx &c, const WtParams &P, char *lds) {
-    c.S = (uint64_t *) (lds + P.off_S);
+    c.SC = (uint64_t *) (lds + P.off_S);
     c.cnt = (uint16_t *) (lds + P.off_cnt);
+    c.segtot = (uint32_t *) (lds + P.off_segtot);
     c.U = (uint64_t *) (lds + P.off_U);
     c.E = (uint64_t *) (lds + P.off_E);
     c.epfx = (uint32_t *) (lds + P.off_epfx);
@@ -147,8 +153,11 @@ WT_DEV void wt_ctx_init(WtCtx &c, const WtParams &P, char *lds) {
 // ---------------------------------------------------------------------------
 #ifdef WT_EMU
 WT_DEV int wt_popc64(uint64_t x) { return __builtin_popcountll(x); }
+WT_DEV int wt_popc32(uint32_t x) { return __builtin_popcount(x); }
 WT_DEV int wt_ctz64(uint64_t x) { return __builtin_ctzll(x); }
+WT_DEV long long wt_uniform64(long long x) { return x; }
 WT_DEV void wt_lds_or64(uint64_t *p, uint64_t v) { *p |= v; }
+WT_DEV void wt_lds_xor64(uint64_t *p, uint64_t v) { *p ^= v; }
 WT_DEV void wt_lds_min32(int32_t *p, int32_t v) { if (v < *p) *p = v; }
 WT_DEV void wt_lds_add64(unsigned long long *p, unsigned long long v) { *p += v; }
 WT_DEV unsigned long long wt_glb_add64(unsigned long long *p, unsigned long long v) {
@@ -160,8 +169,16 @@ WT_DEV void wt_status_store(unsigned long long *p, unsigned long long v) { *p = 
 WT_DEV void wt_backoff() {}
 #else
 WT_DEV int wt_popc64(uint64_t x) { return __popcll(x); }
+WT_DEV int wt_popc32(uint32_t x) { return __popc(x); }
 WT_DEV int wt_ctz64(uint64_t x) { return __ffsll((unsigned long long) x) - 1; }
+// value known to be identical in every lane of the wave -> keep it in SGPRs
+WT_DEV long long wt_uniform64(long long x) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) (unsigned long long) x);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned) ((unsigned long long) x >> 32));
+    return (long long) (((unsigned long long) hi << 32) | lo);
+}
 WT_DEV void wt_lds_or64(uint64_t *p, uint64_t v) { atomicOr((unsigned long long *) p, (unsigned long long) v); }
+WT_DEV void wt_lds_xor64(uint64_t *p, uint64_t v) { atomicXor((unsigned long long *) p, (unsigned long long) v); }
 WT_DEV void wt_lds_min32(int32_t *p, int32_t v) { atomicMin(p, v); }
 WT_DEV void wt_lds_add64(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
 WT_DEV unsigned long long wt_glb_add64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
@@ -253,78 +270,213 @@ WT_DEV void wt_phase_header(const WtParams &P, WtCtx &c, long long k) {
 // ---------------------------------------------------------------------------
 WT_DEV void wt_phase_zero(const WtParams &P, WtCtx &c, int tid, int nt) {
     const int nS = P.n_tracks * P.spitch;
-    for (int x = tid; x < nS; x += nt) c.S[x] = 0;
+    for (int x = tid; x < nS; x += nt) c.SC[x] = 0;
     for (int x = tid; x < P.n_words; x += nt) { c.U[x] = 0; c.E[x] = 0; }
 }
 
 // ---------------------------------------------------------------------------
-// Phase 2: stream the window's intervals, build S_i and U.
-// One 64-lane group per track (coalesced reads of start[]/finish[]).
+// Phase 2: stream the window's intervals; build, per track i, the paired
+// 32-bit bitmaps SC_i[w] = {S (low half): clipped interval starts,
+//                           C (high half): coverage TOGGLES (start ^ finish)}
+// and the shared union bitmap U of true breakpoints.
+// One WT_LOAD_GROUP-lane group per track (coalesced reads of start[]/finish[]); the loads
+// of the group's NEXT track are issued before the LDS atomics of the current
+// one so that one global round trip is hidden per track.
 // Interval classes relative to the window [w0,w1):
-//   f == w0           : true breakpoint at w0, covers nothing here
-//   s >= w1           : first interval beyond the window: candidate for next_bp
-//   otherwise         : covers part of the window; clipped start bit in S_i;
-//                       true start/finish bits in U; f >= w1 -> candidate next_bp
+//   f == w0   : true breakpoint at w0, covers nothing here
+//   s >= w1   : first interval beyond the window: candidate for next_bp
+//   otherwise : covers part of the window: start bit + toggle at the clipped
+//               start, toggle at f if f < w1, true start/finish bits in U,
+//               f >= w1 -> candidate for next_bp
+// A start bit is set exactly once, so S can share one 64-bit XOR with the toggle.
 // ---------------------------------------------------------------------------
-WT_DEV void wt_phase_load(const WtParams &P, WtCtx &c, int tid, int nt) {
-    const WtShared *sh = c.sh;
+#define WT_LOAD_GROUP 32         // lanes per track in the load phase
+#define WT_LOAD_UNROLL 4        // intervals per lane fetched ahead
+struct WtLoadBatch {
+    long long off, lo, hi;
+    int32_t s[WT_LOAD_UNROLL], f[WT_LOAD_UNROLL];
+};
+
+WT_DEV void wt_load_fetch(const WtParams &P, const WtCtx &c, int i, int lane, WtLoadBatch &b) {
     const int N = P.n_tracks;
-    const int32_t w0 = sh->w0, w1 = sh->w1;
-    const int group = tid >> 6, lane = tid & 63, ngroups = nt >> 6;
-    const uint32_t *row0 = P.widx + (size_t) sh->row * N;
-    const uint32_t *row1 = row0 + N;
+    const uint32_t *row0 = P.widx + (size_t) c.sh->row * N;
+    const long long seg = (long long) c.sh->chrom * N + i;
+    b.off = P.seg_off[seg];
+    const long long n = P.seg_off[seg + 1] - b.off;
+    b.lo = row0[i];
+    b.hi = row0[N + i];
+    if (b.hi >= n) b.hi = n - 1;
+#pragma unroll
+    for (int u = 0; u < WT_LOAD_UNROLL; u++) {
+        const long long jr = b.lo + lane + WT_LOAD_GROUP * u;
+        const bool ok = jr <= b.hi;
+        b.s[u] = ok ? P.start[b.off + jr] : 0;
+        b.f[u] = ok ? P.finish[b.off + jr] : 0;
+    }
+}
+
+WT_DEV void wt_load_apply(const WtParams &P, WtCtx &c, uint64_t *SCi, int32_t s, int32_t f) {
+    const int32_t w0 = c.sh->w0, w1 = c.sh->w1;
+    if (f == w0) { wt_lds_or64(&c.U[0], 1ull); return; }
+    if (s >= w1) { wt_lds_min32(&c.sh->next_bp, s); return; }
+    const int cs = s > w0 ? s - w0 : 0;
+    const uint64_t sbit = 1ull << (cs & 31);
+    wt_lds_xor64(&SCi[cs >> 5], sbit | (sbit << 32));
+    if (s >= w0) wt_lds_or64(&c.U[cs >> 6], 1ull << (cs & 63));
+    if (f < w1) {
+        const int cf = f - w0;
+        wt_lds_xor64(&SCi[cf >> 5], (1ull << (cf & 31)) << 32);
+        wt_lds_or64(&c.U[cf >> 6], 1ull << (cf & 63));
+    } else {
+        wt_lds_min32(&c.sh->next_bp, f);
+    }
+}
+
+WT_DEV void wt_phase_load(const WtParams &P, WtCtx &c, int tid, int nt) {
+    const int N = P.n_tracks;
+    const int group = tid / WT_LOAD_GROUP, lane = tid % WT_LOAD_GROUP, ngroups = nt / WT_LOAD_GROUP;
+    if (group >= N) return;
+    WtLoadBatch cur;
+    wt_load_fetch(P, c, group, lane, cur);
     for (int i = group; i < N; i += ngroups) {
-        const long long seg = (long long) sh->chrom * N + i;
-        const long long off = P.seg_off[seg];
-        const long long n = P.seg_off[seg + 1] - off;
-        long long lo = row0[i], hi = row1[i];
-        if (hi >= n) hi = n - 1;
-        uint64_t *Si = c.S + (size_t) i * P.spitch;
-        if (lane == 0 && hi >= lo) wt_lds_add64(&c.sh->n_intervals, (unsigned long long) (hi - lo + 1));
-        for (long long jr = lo + lane; jr <= hi; jr += 64) {
-            const int32_t s = P.start[off + jr];
-            const int32_t f = P.finish[off + jr];
-            if (jr == lo) c.gbase[i] = off + lo - 1 + (f == w0 ? 1 : 0);
-            if (f == w0) { wt_lds_or64(&c.U[0], 1ull); continue; }
-            if (s >= w1) { wt_lds_min32(&c.sh->next_bp, s); continue; }
-            const int cs = s > w0 ? s - w0 : 0;
-            wt_lds_or64(&Si[cs >> 6], 1ull << (cs & 63));
-            if (s >= w0) wt_lds_or64(&c.U[cs >> 6], 1ull << (cs & 63));
-            if (f < w1) {
-                const int cf = f - w0;
-                wt_lds_or64(&c.U[cf >> 6], 1ull << (cf & 63));
-            } else {
-                wt_lds_min32(&c.sh->next_bp, f);
+        WtLoadBatch nxt;
+        const int inext = i + ngroups;
+        if (inext < N) wt_load_fetch(P, c, inext, lane, nxt);
+        uint64_t *SCi = c.SC + (size_t) i * P.spitch;
+        if (lane == 0) {
+            // gbase + r = global index of the r-th interval that has a start bit in S_i;
+            // clamped so that gbase + 1 is always a valid address (r == 0 lookups load it blindly)
+            long long gb = -1;
+            if (cur.hi >= cur.lo) {
+                gb = cur.off + cur.lo - 1 + (cur.f[0] == c.sh->w0 ? 1 : 0);
+                wt_lds_add64(&c.sh->n_intervals, (unsigned long long) (cur.hi - cur.lo + 1));
             }
+            if (gb > P.n_total - 2) gb = P.n_total - 2;
+            c.gbase[i] = gb;
         }
+#pragma unroll
+        for (int u = 0; u < WT_LOAD_UNROLL; u++)
+            if (cur.lo + lane + WT_LOAD_GROUP * u <= cur.hi) wt_load_apply(P, c, SCi, cur.s[u], cur.f[u]);
+        for (long long jr = cur.lo + lane + WT_LOAD_GROUP * WT_LOAD_UNROLL; jr <= cur.hi; jr += WT_LOAD_GROUP)
+            wt_load_apply(P, c, SCi, P.start[cur.off + jr], P.finish[cur.off + jr]);
+        cur = nxt;
     }
 }
 
 // ---------------------------------------------------------------------------
-// Phase 3: per-track exclusive popcount prefix over the words of S_i
+// Phase 3: per track, over the 32-bit words of the window:
+//   cnt_i[w]  = number of start bits in words < w       (rank prefix)
+//   C_i[w]    = coverage bits = running XOR of the toggles (prefix-xor inside
+//               the word by shifts, carry = last bit of the previous word)
 // ---------------------------------------------------------------------------
-WT_DEV void wt_phase_count(const WtParams &P, WtCtx &c, int tid, int nt) {
-    for (int i = tid; i < P.n_tracks; i += nt) {
-        const uint64_t *Si = c.S + (size_t) i * P.spitch;
+// Two sub-phases (a barrier in between) so that WT_COUNT_SEGS lanes share a track:
+//   3a  every lane totals its own segment of words (start bits, toggle parity)
+//   3b  every lane prefixes the totals of the segments before it, then rewrites
+//       its own words in place (toggles -> coverage) and fills cnt.
+#define WT_COUNT_SEGS 8
+WT_DEV void wt_phase_count_a(const WtParams &P, WtCtx &c, int tid, int nt) {
+    const int nw32 = P.n_words * 2;
+    const int seg_words = (nw32 + WT_COUNT_SEGS - 1) / WT_COUNT_SEGS;
+    const int items = P.n_tracks * WT_COUNT_SEGS;
+    for (int it = tid; it < items; it += nt) {
+        const int i = it / WT_COUNT_SEGS, q = it % WT_COUNT_SEGS;
+        const uint64_t *SCi = c.SC + (size_t) i * P.spitch;
+        const int w_lo = q * seg_words;
+        int w_hi = w_lo + seg_words;
+        if (w_hi > nw32) w_hi = nw32;
+        unsigned run = 0, par = 0;
+        for (int w = w_lo; w < w_hi; w++) {
+            const uint64_t sc = SCi[w];
+            run += (unsigned) wt_popc32((uint32_t) sc);
+            par ^= (unsigned) wt_popc32((uint32_t) (sc >> 32));
+        }
+        c.segtot[it] = (run & 0xffffu) | ((par & 1u) << 31);
+    }
+}
+
+WT_DEV void wt_phase_count_b(const WtParams &P, WtCtx &c, int tid, int nt) {
+    const int nw32 = P.n_words * 2;
+    const int seg_words = (nw32 + WT_COUNT_SEGS - 1) / WT_COUNT_SEGS;
+    const int items = P.n_tracks * WT_COUNT_SEGS;
+    for (int it = tid; it < items; it += nt) {
+        const int i = it / WT_COUNT_SEGS, q = it % WT_COUNT_SEGS;
+        uint64_t *SCi = c.SC + (size_t) i * P.spitch;
         uint16_t *ci = c.cnt + (size_t) i * P.cpitch;
-        unsigned run = 0;
-        for (int w = 0; w < P.n_words; w++) {
+        const int w_lo = q * seg_words;
+        int w_hi = w_lo + seg_words;
+        if (w_hi > nw32) w_hi = nw32;
+        unsigned run = 0, par = 0;
+        for (int x = 0; x < q; x++) {
+            const uint32_t st = c.segtot[i * WT_COUNT_SEGS + x];
+            run += st & 0xffffu;
+            par ^= st >> 31;
+        }
+        uint32_t carry = par ? 0xffffffffu : 0u;
+        for (int w = w_lo; w < w_hi; w++) {
+            const uint64_t sc = SCi[w];
+            const uint32_t sbits = (uint32_t) sc;
+            uint32_t t = (uint32_t) (sc >> 32);
             ci[w] = (uint16_t) run;
-            run += (unsigned) wt_popc64(Si[w]);
+            run += (unsigned) wt_popc32(sbits);
+            t ^= t << 1; t ^= t << 2; t ^= t << 4; t ^= t << 8; t ^= t << 16;
+            t ^= carry;
+            carry = (t >> 31) ? 0xffffffffu : 0u;
+            SCi[w] = ((uint64_t) t << 32) | sbits;
         }
     }
 }
 
-// Does an interval of track i cover window position p?  If so return its value.
-template <class ValT>
-WT_DEV bool wt_fetch(const WtParams &P, const WtCtx &c, int i, int word, uint64_t mask, int32_t p_abs, double &v) {
-    const uint64_t sw = c.S[(size_t) i * P.spitch + word];
-    const unsigned r = (unsigned) c.cnt[(size_t) i * P.cpitch + word] + (unsigned) wt_popc64(sw & mask);
-    if (r == 0) return false;
-    const long long g = c.gbase[i] + r;
-    if (p_abs >= P.finish[g]) return false;
-    v = (double) ((const ValT *) P.value)[g];
-    return true;
+// ---------------------------------------------------------------------------
+// Track lookup for a GROUP of K consecutive window positions p0..p0+K-1 that
+// share one 32-bit bitmap word (K divides 32, p0 % K == 0).  Branch-free:
+//   rank_k = cnt_i[w] + popc(S & mask_k)     -> interval index gbase_i + rank_k
+//   cov_k  = bit (p0+k) of C_i[w]
+// The value gather is issued unconditionally (index clamped to >= 1, which is
+// always a valid address) so K independent loads are in flight per lane; the
+// interval's finish is never read here.
+// ---------------------------------------------------------------------------
+// Track-loop unrolling of the streaming reducers: gathers of WT_TRACK_UNROLL
+// consecutive tracks are in flight at once (the adds still happen in index order).
+#ifndef WT_TRACK_UNROLL
+#define WT_TRACK_UNROLL 2
+#endif
+#define WT_PRAGMA(x) _Pragma(#x)
+#define WT_UNROLL_TRACKS WT_PRAGMA(unroll WT_TRACK_UNROLL)
+
+template <int K>
+struct WtFetchK {
+    bool cov[K];
+    double x[K];      // default-substituted value
+    uint32_t cbits;   // coverage word of the track (bit b0+k <=> cov[k])
+};
+
+template <class ValT, class ScrT, int K>
+WT_DEV void wt_fetch_group(const WtParams &P, const WtCtx &c, int i, int w32, int b0, const uint32_t (&mask)[K],
+                           double dflt, WtFetchK<K> &out) {
+    const uint64_t sc = c.SC[(size_t) i * P.spitch + w32];
+    const uint32_t sbits = (uint32_t) sc, cbits = (uint32_t) (sc >> 32);
+    const unsigned cn = (unsigned) c.cnt[(size_t) i * P.cpitch + w32];
+    out.cbits = cbits;
+    const char *vp = (const char *) ((const ValT *) P.value + wt_uniform64(c.gbase[i]));
+    ValT v[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        unsigned r = cn + (unsigned) wt_popc32(sbits & mask[k]);
+        r = r ? r : 1u;
+        v[k] = *(const ValT *) (vp + (uint32_t) (r * (unsigned) sizeof(ValT)));
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const bool cov = (cbits >> (b0 + k)) & 1u;
+        out.cov[k] = cov;
+        if (sizeof(ValT) == 4 && sizeof(ScrT) == 4) {
+            // float tracks whose defaults are float-exact: select in f32, widen once
+            const float xf = cov ? (float) v[k] : (float) dflt;
+            out.x[k] = (double) xf;
+        } else {
+            out.x[k] = cov ? (double) v[k] : dflt;
+        }
+    }
 }
 
 // order-preserving integer keys for selection
@@ -345,117 +497,166 @@ WT_DEV double wt_unkey64(uint64_t k) {
     return __builtin_bit_cast(double, u);
 }
 
-// ---------------------------------------------------------------------------
-// Per-run reducers.  One lane evaluates one run start p (window-relative).
-// Tracks are visited in index order in f64 exactly like the reference loops.
-// Returns the reducer value; n0/n1 receive the in-play counts of set 0 / set 1
-// (one-sample ops: everything is "set 0").
-// `col`/`colstride`: this lane's scratch column in LDS (median, MWU only).
-// ---------------------------------------------------------------------------
-template <int OP, class ValT, class ScrT>
-WT_DEV double wt_eval_position(const WtParams &P, const WtCtx &c, int p, int &n0, int &n1,
-                               char *scratch, int lane_col, int colstride) {
-    const int N = P.n_tracks;
-    const int word = p >> 6;
-    const uint64_t mask = wt_mask_incl(p & 63);
-    const int32_t p_abs = c.sh->w0 + p;
+// Coverage summary of a group of tracks over the 32 positions of one word:
+// any = OR of the tracks' coverage words, all = AND.  Bit b0+k answers the
+// Multiplexer's emission predicate for position p0+k (multiplexer.c:120,125 and
+// setComparisons.c:48-54) without counting tracks per position.
+struct WtCover {
+    uint32_t any, all;
+};
+
+// Visits tracks lo..hi-1 in index order, two tracks' gathers in flight at a time.
+// body(i, F) is called in increasing i.
+template <class ValT, class ScrT, int K, class Body>
+WT_DEV void wt_for_tracks(const WtParams &P, const WtCtx &c, int lo, int hi, int w32, int b0,
+                          const uint32_t (&mask)[K], bool use_defaults, WtCover &cv, Body body) {
     const double *dflt = P.defaults;
-    n0 = 0; n1 = 0;
+    int i = lo;
+    for (; i + 1 < hi; i += 2) {
+        WtFetchK<K> F0, F1;
+        wt_fetch_group<ValT, ScrT, K>(P, c, i, w32, b0, mask, use_defaults ? dflt[i] : 0.0, F0);
+        wt_fetch_group<ValT, ScrT, K>(P, c, i + 1, w32, b0, mask, use_defaults ? dflt[i + 1] : 0.0, F1);
+        cv.any |= F0.cbits | F1.cbits;
+        cv.all &= F0.cbits & F1.cbits;
+        body(i, F0);
+        body(i + 1, F1);
+    }
+    if (i < hi) {
+        WtFetchK<K> F0;
+        wt_fetch_group<ValT, ScrT, K>(P, c, i, w32, b0, mask, use_defaults ? dflt[i] : 0.0, F0);
+        cv.any |= F0.cbits;
+        cv.all &= F0.cbits;
+        body(i, F0);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Per-run reducers.  One lane evaluates K consecutive window positions; for
+// every position the tracks are visited in index order i = 0..N-1 in f64,
+// exactly the reference's summation order (bit-identical sums).
+// res[k] = reducer value; cv0 / cv1 = coverage summaries of set 0 / set 1
+// (one-sample ops: everything is "set 0").  Positions that are not breakpoints
+// are computed too (cheaper than diverging) and discarded by the caller.
+// NaN: the reference tests isnan() per value and yields NaN; for sum / product /
+// mean / var / stddev / CV IEEE propagation through the accumulator gives the
+// same answer (NaN in -> NaN out), so no flag is carried; min / max / median /
+// MWU carry an explicit flag because comparisons swallow NaN.
+// Median / MWU use K == 1 and this lane's LDS scratch column.
+// ---------------------------------------------------------------------------
+template <int OP, class ValT, class ScrT, int K>
+WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&res)[K], WtCover &cv0, WtCover &cv1,
+                          char *scratch, int lane_col, int colstride) {
+    const int N = P.n_tracks;
+    const int w32 = p0 >> 5, b0 = p0 & 31;
+    uint32_t mask[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) mask[k] = (2u << (b0 + k)) - 1u;
+    cv0.any = 0; cv0.all = 0xffffffffu; cv1.any = 0; cv1.all = 0xffffffffu;
 
     if (OP == WT_OP_SUM || OP == WT_OP_PRODUCT || OP == WT_OP_MEAN) {
         // reducers.c:259-292, 313-346, 367-402
-        double acc = (OP == WT_OP_PRODUCT) ? 1.0 : 0.0;
-        bool nan = false;
-        for (int i = 0; i < N; i++) {
-            double x;
-            const bool cov = wt_fetch<ValT>(P, c, i, word, mask, p_abs, x);
-            if (!cov) x = dflt[i];
-            n0 += cov;
-            if (wt_isnan(x)) nan = true;
-            if (OP == WT_OP_PRODUCT) acc *= x; else acc += x;
-        }
-        if (nan) return wt_nan();
-        if (OP == WT_OP_MEAN) acc /= N;
-        return acc;
+        double acc[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) acc[k] = (OP == WT_OP_PRODUCT) ? 1.0 : 0.0;
+        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, cv0, [&](int, const WtFetchK<K> &F) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if (OP == WT_OP_PRODUCT) acc[k] *= F.x[k]; else acc[k] += F.x[k];
+            }
+        });
+#pragma unroll
+        for (int k = 0; k < K; k++) res[k] = (OP == WT_OP_MEAN) ? acc[k] / N : acc[k];
+        return;
     }
     if (OP == WT_OP_MIN || OP == WT_OP_MAX) {
         // reducers.c:125-168, 192-235: seed is 0 (not the default) when track 0 is absent
-        double best;
-        bool nan = false;
+        double best[K];
+        bool nan[K];
         {
-            double x;
-            const bool cov = wt_fetch<ValT>(P, c, 0, word, mask, p_abs, x);
-            best = cov ? x : 0.0;
-            n0 += cov;
-            if (wt_isnan(best)) nan = true;
+            WtFetchK<K> F;
+            wt_fetch_group<ValT, ScrT, K>(P, c, 0, w32, b0, mask, 0.0, F);
+            cv0.any |= F.cbits; cv0.all &= F.cbits;
+#pragma unroll
+            for (int k = 0; k < K; k++) { best[k] = F.x[k]; nan[k] = wt_isnan(best[k]); }
         }
-        for (int i = 1; i < N; i++) {
-            double x;
-            const bool cov = wt_fetch<ValT>(P, c, i, word, mask, p_abs, x);
-            if (!cov) x = dflt[i];
-            n0 += cov;
-            if (wt_isnan(x)) nan = true;
-            if (OP == WT_OP_MAX) { if (best < x) best = x; } else { if (best > x) best = x; }
-        }
-        return nan ? wt_nan() : best;
+        wt_for_tracks<ValT, ScrT, K>(P, c, 1, N, w32, b0, mask, true, cv0, [&](int, const WtFetchK<K> &F) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const double x = F.x[k];
+                nan[k] |= wt_isnan(x);
+                if (OP == WT_OP_MAX) { if (best[k] < x) best[k] = x; } else { if (best[k] > x) best[k] = x; }
+            }
+        });
+#pragma unroll
+        for (int k = 0; k < K; k++) res[k] = nan[k] ? wt_nan() : best[k];
+        return;
     }
     if (OP == WT_OP_VAR || OP == WT_OP_STDDEV || OP == WT_OP_ENTROPY || OP == WT_OP_CV) {
         // reducers.c:428-479 (var), 511-563 (stddev; entropy installs the same pop, :665),
         // 672-725 (CV).  Pass 1 rounds every value through `float`.
-        double mean = 0;
-        bool nan = false;
-        for (int i = 0; i < N; i++) {
-            double x;
-            const bool cov = wt_fetch<ValT>(P, c, i, word, mask, p_abs, x);
-            if (!cov) x = dflt[i];
-            n0 += cov;
-            const float fx = (float) x;
-            if (wt_isnanf(fx)) nan = true;
-            mean += (double) fx;
+        double mean[K], acc[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { mean[k] = 0; acc[k] = 0; }
+        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, cv0, [&](int, const WtFetchK<K> &F) {
+#pragma unroll
+            for (int k = 0; k < K; k++) mean[k] += (double) (float) F.x[k];
+        });
+#pragma unroll
+        for (int k = 0; k < K; k++) mean[k] /= N;
+        WtCover dummy = {0, 0};
+        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, dummy, [&](int, const WtFetchK<K> &F) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                // var ignores absent tracks in pass 2 (:470-475); stddev / CV use their default
+                double diff = mean[k] - F.x[k];
+                if (OP == WT_OP_VAR) diff = F.cov[k] ? diff : 0.0;
+                acc[k] += diff * diff;
+            }
+        });
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            double a = acc[k] / N;
+            bool bad = wt_isnan(mean[k]);
+            if (OP == WT_OP_VAR) { if (N < 2) bad = true; }
+            else {
+                a = sqrt(a);
+                if (OP == WT_OP_CV) { if (mean[k] == 0) bad = true; a /= mean[k]; }
+            }
+            res[k] = bad ? wt_nan() : a;
         }
-        if (nan || wt_isnan(mean)) return wt_nan();
-        if (OP == WT_OP_VAR && N < 2) return wt_nan();
-        mean /= N;
-        if (OP == WT_OP_CV && mean == 0) return wt_nan();
-        double acc = 0;
-        for (int i = 0; i < N; i++) {
-            double x;
-            const bool cov = wt_fetch<ValT>(P, c, i, word, mask, p_abs, x);
-            if (OP == WT_OP_VAR) {
-                if (!cov) continue;          // :470-475 ignores absent tracks
-            } else if (!cov) x = dflt[i];
-            const double diff = mean - x;
-            acc += diff * diff;
-        }
-        acc /= N;
-        if (OP == WT_OP_VAR) return acc;
-        acc = sqrt(acc);
-        if (OP == WT_OP_CV) acc /= mean;
-        return acc;
+        return;
     }
     if (OP == WT_OP_TTEST) {
         // setComparisons.c:60-117: sums over in-play tracks, counts over all tracks
         const int na = P.n_set0, nb = N - P.n_set0;
-        double s1 = 0, q1 = 0, s2 = 0, q2 = 0;
-        for (int i = 0; i < na; i++) {
-            double x;
-            if (wt_fetch<ValT>(P, c, i, word, mask, p_abs, x)) { n0++; s1 += x; q1 += x * x; }
+        double s1[K], q1[K], s2[K], q2[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { s1[k] = q1[k] = s2[k] = q2[k] = 0; }
+        wt_for_tracks<ValT, ScrT, K>(P, c, 0, na, w32, b0, mask, false, cv0, [&](int, const WtFetchK<K> &F) {
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (F.cov[k]) { s1[k] += F.x[k]; q1[k] += F.x[k] * F.x[k]; }
+        });
+        wt_for_tracks<ValT, ScrT, K>(P, c, na, N, w32, b0, mask, false, cv1, [&](int, const WtFetchK<K> &F) {
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (F.cov[k]) { s2[k] += F.x[k]; q2[k] += F.x[k] * F.x[k]; }
+        });
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const double m1 = s1[k] / na, m2 = s2[k] / nb;
+            const double msq1 = q1[k] / na, msq2 = q2[k] / nb;
+            const double var1 = msq1 - m1 * m1, var2 = msq2 - m2 * m2;
+            if (var1 + var2 == 0) { res[k] = wt_nan(); continue; }
+            double t = (m1 - m2) / sqrt(var1 / na + var2 / nb);
+            if (t < 0) t = -t;
+            const double den = var1 / na + var2 / nb;
+            const double c1 = (double) ((long long) na * na * (na - 1));
+            const double c2 = (double) ((long long) nb * nb * (nb - 1));
+            const double nu = den * den / ((var1 * var1) / c1 + (var2 * var2) / c2);
+            res[k] = 2 * wt_tdist_Q(t, nu);
         }
-        for (int i = na; i < N; i++) {
-            double x;
-            if (wt_fetch<ValT>(P, c, i, word, mask, p_abs, x)) { n1++; s2 += x; q2 += x * x; }
-        }
-        const double m1 = s1 / na, m2 = s2 / nb;
-        const double msq1 = q1 / na, msq2 = q2 / nb;
-        const double var1 = msq1 - m1 * m1, var2 = msq2 - m2 * m2;
-        if (var1 + var2 == 0) return wt_nan();
-        double t = (m1 - m2) / sqrt(var1 / na + var2 / nb);
-        if (t < 0) t = -t;
-        const double den = var1 / na + var2 / nb;
-        const double c1 = (double) ((long long) na * na * (na - 1));
-        const double c2 = (double) ((long long) nb * nb * (nb - 1));
-        const double nu = den * den / ((var1 * var1) / c1 + (var2 * var2) / c2);
-        return 2 * wt_tdist_Q(t, nu);
+        return;
     }
     if (OP == WT_OP_MEDIAN) {
         // reducers.c:780-813: upper median of the default-substituted values.
@@ -464,26 +665,24 @@ WT_DEV double wt_eval_position(const WtParams &P, const WtCtx &c, int p, int &n0
         typedef typename std::conditional<sizeof(ScrT) == 4, uint32_t, uint64_t>::type KeyT;
         KeyT *col = (KeyT *) scratch + lane_col;
         bool nan = false;
-        for (int i = 0; i < N; i++) {
-            double x;
-            const bool cov = wt_fetch<ValT>(P, c, i, word, mask, p_abs, x);
-            if (!cov) x = dflt[i];
-            n0 += cov;
-            if (wt_isnan(x)) nan = true;
+        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, cv0, [&](int i, const WtFetchK<K> &F) {
+            const double x = F.x[0];
+            nan |= wt_isnan(x);
             if (sizeof(ScrT) == 4) col[(size_t) i * colstride] = (KeyT) wt_key32((float) x);
             else col[(size_t) i * colstride] = (KeyT) wt_key64(x);
-        }
-        if (nan) return wt_nan();
+        });
         const int kth = N / 2;       // 0-based rank of vals[N/2]
-        // largest key K such that count(keys < K) <= kth  ==  the kth smallest key
-        KeyT K = 0;
+        // largest key Kk such that count(keys < Kk) <= kth  ==  the kth smallest key
+        KeyT Kk = 0;
         for (int b = (int) sizeof(KeyT) * 8 - 1; b >= 0; b--) {
-            const KeyT trial = K | ((KeyT) 1 << b);
+            const KeyT trial = Kk | ((KeyT) 1 << b);
             int below = 0;
             for (int i = 0; i < N; i++) below += (col[(size_t) i * colstride] < trial);
-            if (below <= kth) K = trial;
+            if (below <= kth) Kk = trial;
         }
-        return (sizeof(ScrT) == 4) ? (double) wt_unkey32((uint32_t) K) : wt_unkey64((uint64_t) K);
+        const double m = (sizeof(ScrT) == 4) ? (double) wt_unkey32((uint32_t) Kk) : wt_unkey64((uint64_t) Kk);
+        res[0] = nan ? wt_nan() : m;
+        return;
     }
     if (OP == WT_OP_MWU) {
         // setComparisons.c:293-366.  The lane's LDS column holds (value,set)
@@ -494,12 +693,9 @@ WT_DEV double wt_eval_position(const WtParams &P, const WtCtx &c, int p, int &n0
         ScrT *val = (ScrT *) scratch + lane_col;                   // [N][colstride]
         uint8_t *set = (uint8_t *) ((ScrT *) scratch + (size_t) N * colstride) + lane_col;
         bool nan = false;
-        for (int i = 0; i < N; i++) {
-            double x;
-            const bool cov = wt_fetch<ValT>(P, c, i, word, mask, p_abs, x);
-            if (!cov) x = dflt[i];
-            if (i < na) n0 += cov; else n1 += cov;
-            if (wt_isnan(x)) nan = true;
+        auto insert = [&](int i, const WtFetchK<K> &F) {
+            const double x = F.x[0];
+            nan |= wt_isnan(x);
             // stable insertion: shift strictly greater elements up
             int j = i;
             while (j > 0 && (double) val[(size_t) (j - 1) * colstride] > x) {
@@ -509,8 +705,10 @@ WT_DEV double wt_eval_position(const WtParams &P, const WtCtx &c, int p, int &n0
             }
             val[(size_t) j * colstride] = (ScrT) x;
             set[(size_t) j * colstride] = (uint8_t) (i >= na);
-        }
-        if (nan) return wt_nan();
+        };
+        wt_for_tracks<ValT, ScrT, K>(P, c, 0, na, w32, b0, mask, true, cv0, insert);
+        wt_for_tracks<ValT, ScrT, K>(P, c, na, N, w32, b0, mask, true, cv1, insert);
+        if (nan) { res[0] = wt_nan(); return; }
         const double mu = (double) (na * nb / 2);                               // :386 int division
         const double sigma = sqrt((double) (na * nb * (na + nb + 1) / 12));     // :387 int division
         double U1 = 0;
@@ -533,17 +731,19 @@ WT_DEV double wt_eval_position(const WtParams &P, const WtCtx &c, int p, int &n0
                 prev++;
             }
         }
-        if (U1 > mu) return 2 * erf((mu - U1) / sigma);
-        return 2 * erf((U1 - mu) / sigma);
+        res[0] = (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
+        return;
     }
     if (OP == WT_OP_MULTIPLEX) {
+        // only the coverage summary is needed: OR / AND of the tracks' coverage words
         for (int i = 0; i < N; i++) {
-            double x;
-            n0 += wt_fetch<ValT>(P, c, i, word, mask, p_abs, x);
+            const uint32_t cb = (uint32_t) (c.SC[(size_t) i * P.spitch + w32] >> 32);
+            cv0.any |= cb; cv0.all &= cb;
         }
-        return 0.0;
+#pragma unroll
+        for (int k = 0; k < K; k++) res[k] = 0.0;
+        return;
     }
-    return wt_nan();
 }
 
 // First true breakpoint after window position p (absolute coordinate).
@@ -558,43 +758,45 @@ WT_DEV int32_t wt_next_breakpoint(const WtParams &P, const WtCtx &c, int p) {
 }
 
 // ---------------------------------------------------------------------------
-// Phase 4: evaluate every breakpoint owned by the window
+// Phase 4: evaluate every breakpoint owned by the window.  Lane `tid` owns the
+// K consecutive positions [tid*K, tid*K+K).
 // ---------------------------------------------------------------------------
-template <int OP, class ValT, class ScrT>
-WT_DEV void wt_phase_eval(const WtParams &P, WtCtx &c, WtLane &L, int tid, int nt) {
+template <int OP, class ValT, class ScrT, int K>
+WT_DEV void wt_phase_eval(const WtParams &P, WtCtx &c, WtLane<K> &L, int tid, int nt) {
     const bool two = (OP == WT_OP_TTEST || OP == WT_OP_MWU);
-    const int N = P.n_tracks;
-    const int na = two ? P.n_set0 : N, nb = N - na;
     L.emit = 0;
+    const int p0 = tid * K;
+    if (p0 >= P.W) return;
+    const unsigned bp_bits = (unsigned) ((c.U[p0 >> 6] >> (p0 & 63)) & ((1ull << K) - 1ull));
+    if (!bp_bits) return;
+    double res[K];
+    WtCover cv0, cv1;
+    wt_eval_group<OP, ValT, ScrT, K>(P, c, p0, res, cv0, cv1, c.scratch, tid, nt);
+    // emission predicate as a word: one-sample any/all (multiplexer.c:120,125); two-sample: both
+    // Multiplexers in play (setComparisons.c:48-54 / 282-288)
+    uint32_t emit_word = (P.flags & WT_STRICT_SET0) ? cv0.all : cv0.any;
+    if (two) emit_word &= (P.flags & WT_STRICT_SET1) ? cv1.all : cv1.any;
+    const unsigned emit_k = (emit_word >> (p0 & 31)) & ((1u << K) - 1u);
     unsigned long long bp = 0;
-    int n_emit = 0;
+    unsigned emit_bits = 0;
 #pragma unroll
-    for (int it = 0; it < WT_MAX_ITERS; it++) {
-        const int p = it * nt + tid;
-        if (p >= P.W) continue;
-        if (!((c.U[p >> 6] >> (p & 63)) & 1ull)) continue;
-        int n0, n1;
-        const double r = wt_eval_position<OP, ValT, ScrT>(P, c, p, n0, n1, c.scratch, tid, nt);
-        bool emit;
-        if (two) {
-            // setComparisons.c:48-54 / 282-288: both Multiplexers in play
-            const bool a = (P.flags & WT_STRICT_SET0) ? (n0 == na) : (n0 > 0);
-            const bool b = (P.flags & WT_STRICT_SET1) ? (n1 == nb) : (n1 > 0);
-            emit = a && b;
-        } else {
-            // multiplexer.c:120,125
-            emit = (P.flags & WT_STRICT_SET0) ? (n0 == N) : (n0 > 0);
+    for (int k = 0; k < K; k++) {
+        bool emit = (emit_k >> k) & 1u;
+        emit = emit && ((bp_bits >> k) & 1u);
+        L.res[k] = res[k];
+        L.fin[k] = 0;
+        if (emit) {
+            const int32_t fin = wt_next_breakpoint(P, c, p0 + k);
+            L.fin[k] = fin;
+            emit_bits |= 1u << k;
+            bp += (unsigned long long) (fin - (c.sh->w0 + p0 + k));
         }
-        if (!emit) continue;
-        const int32_t fin = wt_next_breakpoint(P, c, p);
-        L.res[it] = r;
-        L.fin[it] = fin;
-        L.emit |= 1u << it;
-        wt_lds_or64(&c.E[p >> 6], 1ull << (p & 63));
-        bp += (unsigned long long) (fin - (c.sh->w0 + p));
-        n_emit++;
     }
-    if (n_emit) wt_lds_add64(&c.sh->bp_sum, bp);
+    L.emit = emit_bits;
+    if (emit_bits) {
+        wt_lds_or64(&c.E[p0 >> 6], (uint64_t) emit_bits << (p0 & 63));
+        wt_lds_add64(&c.sh->bp_sum, bp);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -615,10 +817,28 @@ WT_DEV void wt_phase_escan(const WtParams &P, WtCtx &c, int tid, int nt) {
 // Windows are handed out in order by the ticket, so every predecessor has
 // started; the spin is bounded and reports WT_ERR_LOOKBACK instead of hanging.
 // ---------------------------------------------------------------------------
-WT_DEV void wt_phase_lookback(const WtParams &P, WtCtx &c, long long k) {
+// Bookkeeping shared by both look-back flavours once `excl` is known (one lane).
+WT_DEV void wt_lookback_finish(const WtParams &P, WtCtx &c, long long k, unsigned long long excl,
+                               unsigned long long mine) {
     WtShared *sh = c.sh;
+    wt_status_store(&P.status[k], WT_FLAG_PFX | (excl + mine));
+    sh->goffset = (long long) excl;
+    const int ch = sh->chrom;
+    if (k == P.c_first_win[ch]) P.chrom_run_off[ch] = (long long) excl;
+    if (k == P.n_windows - 1) {
+        P.chrom_run_off[P.n_chrom] = (long long) (excl + mine);
+        P.counters[WT_CTR_RUNS] = excl + mine;
+    }
+    if (sh->bp_sum) wt_glb_add64(&P.counters[WT_CTR_BP], sh->bp_sum);
+    if (sh->n_intervals) wt_glb_add64(&P.counters[WT_CTR_INTERVALS], sh->n_intervals);
+    if ((long long) (excl + mine) > P.capacity) wt_glb_or64(&P.counters[WT_CTR_ERROR], WT_ERR_CAPACITY);
+}
+
+// Sequential flavour (one lane): used by the CPU emulator, kept as the plain statement
+// of the protocol.
+WT_DEV void wt_phase_lookback(const WtParams &P, WtCtx &c, long long k) {
     const unsigned long long mine = c.epfx[P.n_words];
-    sh->n_emit = (int32_t) mine;
+    c.sh->n_emit = (int32_t) mine;
     unsigned long long excl = 0;
     if (k > 0) {
         wt_status_store(&P.status[k], WT_FLAG_AGG | mine);
@@ -639,49 +859,82 @@ WT_DEV void wt_phase_lookback(const WtParams &P, WtCtx &c, long long k) {
             j--;
         }
     }
-    wt_status_store(&P.status[k], WT_FLAG_PFX | (excl + mine));
-    sh->goffset = (long long) excl;
-    // chromosome run offsets + totals
-    const int ch = sh->chrom;
-    if (k == P.c_first_win[ch]) P.chrom_run_off[ch] = (long long) excl;
-    if (k == P.n_windows - 1) {
-        P.chrom_run_off[P.n_chrom] = (long long) (excl + mine);
-        P.counters[WT_CTR_RUNS] = excl + mine;
-    }
-    if (sh->bp_sum) wt_glb_add64(&P.counters[WT_CTR_BP], sh->bp_sum);
-    if (sh->n_intervals) wt_glb_add64(&P.counters[WT_CTR_INTERVALS], sh->n_intervals);
-    if ((long long) (excl + mine) > P.capacity) wt_glb_or64(&P.counters[WT_CTR_ERROR], WT_ERR_CAPACITY);
+    wt_lookback_finish(P, c, k, excl, mine);
 }
 
+#ifndef WT_EMU
+// Wave flavour (the 64 lanes of wave 0): lane L inspects window base-L, so one
+// global round trip covers 64 predecessors instead of one.
+WT_DEV void wt_phase_lookback_wave(const WtParams &P, WtCtx &c, long long k, int lane) {
+    const unsigned long long mine = c.epfx[P.n_words];
+    if (lane == 0) {
+        c.sh->n_emit = (int32_t) mine;
+        if (k > 0) wt_status_store(&P.status[k], WT_FLAG_AGG | mine);
+    }
+    unsigned long long excl = 0;
+    long long base = k - 1;
+    while (base >= 0) {
+        const long long j = base - lane;
+        // windows before the first one behave like a published prefix of 0
+        unsigned long long v = (j >= 0) ? wt_status_load(&P.status[j]) : WT_FLAG_PFX;
+        unsigned long long pfx;
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned long long ready = __ballot(v != 0);
+            pfx = __ballot((v & WT_FLAG_PFX) != 0);
+            // lanes 0..p must be ready, p = nearest lane holding a prefix (all 64 if none)
+            const unsigned long long need = pfx ? (((pfx & (0ull - pfx)) << 1) - 1ull) : ~0ull;
+            if ((ready & need) == need) break;
+            if (++spins > (1u << 22)) {
+                if (lane == 0) wt_glb_or64(&P.counters[WT_CTR_ERROR], WT_ERR_LOOKBACK);
+                pfx = 1ull;         // give up: offsets are garbage, error is reported
+                break;
+            }
+            if (v == 0) { wt_backoff(); v = wt_status_load(&P.status[j]); }
+        }
+        const int p = pfx ? (int) wt_ctz64(pfx) : 63;
+        unsigned long long part = (lane <= p) ? (v & WT_VAL_MASK) : 0ull;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += (unsigned long long) __shfl_xor((long long) part, d);
+        excl += part;
+        if (pfx) break;
+        base -= 64;
+    }
+    if (lane == 0) wt_lookback_finish(P, c, k, excl, mine);
+}
+#endif
+
 // ---------------------------------------------------------------------------
-// Phase 7: write the emitted runs at their global positions (coalesced: lanes
-// hold consecutive positions)
+// Phase 7: write the emitted runs at their global positions
 // ---------------------------------------------------------------------------
-template <int OP, class ValT>
-WT_DEV void wt_phase_write(const WtParams &P, WtCtx &c, const WtLane &L, int tid, int nt) {
+template <int OP, class ValT, int K>
+WT_DEV void wt_phase_write(const WtParams &P, WtCtx &c, const WtLane<K> &L, int tid, int nt) {
+    if (!L.emit) return;
     const long long goff = c.sh->goffset;
     const int32_t w0 = c.sh->w0;
+    const int p0 = tid * K;
+    const int w = p0 >> 6, b0 = p0 & 63;
+    const uint64_t below0 = b0 ? wt_mask_incl(b0 - 1) : 0ull;
+    long long idx = goff + c.epfx[w] + wt_popc64(c.E[w] & below0);
 #pragma unroll
-    for (int it = 0; it < WT_MAX_ITERS; it++) {
-        if (!((L.emit >> it) & 1u)) continue;
-        const int p = it * nt + tid;
-        const int w = p >> 6, b = p & 63;
-        const uint64_t below = b ? wt_mask_incl(b - 1) : 0ull;
-        const long long idx = goff + c.epfx[w] + wt_popc64(c.E[w] & below);
-        if (idx >= P.capacity) continue;
-        P.o_start[idx] = w0 + p;
-        P.o_finish[idx] = L.fin[it];
+    for (int k = 0; k < K; k++) {
+        if (!((L.emit >> k) & 1u)) continue;
+        const long long o = idx++;
+        if (o >= P.capacity) continue;
+        const int p = p0 + k;
+        P.o_start[o] = w0 + p;
+        P.o_finish[o] = L.fin[k];
         if (OP == WT_OP_MULTIPLEX) {
             const int N = P.n_tracks;
-            const uint64_t mask = wt_mask_incl(b);
+            const uint32_t mask1[1] = { (2u << (p & 31)) - 1u };
+            WtFetchK<1> F;
             for (int i = 0; i < N; i++) {
-                double x;
-                const bool cov = wt_fetch<ValT>(P, c, i, w, mask, w0 + p, x);
-                P.o_tile[idx * N + i] = cov ? x : P.defaults[i];
-                P.o_inplay[idx * N + i] = (uint8_t) cov;
+                wt_fetch_group<ValT, double, 1>(P, c, i, p >> 5, p & 31, mask1, P.defaults[i], F);
+                P.o_tile[o * N + i] = F.x[0];
+                P.o_inplay[o * N + i] = (uint8_t) F.cov[0];
             }
         } else {
-            P.o_value[idx] = L.res[it];
+            P.o_value[o] = L.res[k];
         }
     }
 }
@@ -692,30 +945,37 @@ WT_DEV void wt_phase_write(const WtParams &P, WtCtx &c, const WtLane &L, int tid
 //   widx[row(b)][track] = jr  == first interval with finish >= b.
 // Rows past the last interval get n (= none).  Empty (chrom,track) segments
 // rely on the rows having been zeroed (0 == n).
+// `seg` is an in/out hint: the segment of the previous interval handled by
+// this lane (intervals are visited in increasing g, so it only moves forward).
 // ---------------------------------------------------------------------------
-WT_DEV void wt_index_interval(const WtParams &P, long long g) {
-    const int N = P.n_tracks;
-    // segment of g: last seg with seg_off[seg] <= g
-    long long lo = 0, hi = (long long) P.n_chrom * N;     // invariant: seg_off[lo] <= g < seg_off[hi]
+WT_DEV long long wt_index_find_segment(const WtParams &P, long long g) {
+    long long lo = 0, hi = (long long) P.n_chrom * P.n_tracks;   // seg_off[lo] <= g < seg_off[hi]
     while (hi - lo > 1) {
         const long long mid = (lo + hi) >> 1;
         if (P.seg_off[mid] <= g) lo = mid; else hi = mid;
     }
-    const long long seg = lo;
-    const int ch = (int) (seg / N), i = (int) (seg % N);
-    const long long jr = g - P.seg_off[seg];
-    const long long n = P.seg_off[seg + 1] - P.seg_off[seg];
-    const long long cb = P.cbase[ch];
+    return lo;
+}
+
+WT_DEV void wt_index_interval(const WtParams &P, long long g, long long &seg) {
+    const int N = P.n_tracks;
+    while (g >= P.seg_off[seg + 1]) seg++;
+    const long long s0 = P.seg_off[seg];
+    const int ch = (int) (seg / N), i = (int) (seg - (long long) ch * N);
+    const long long jr = g - s0;
+    const int32_t cb = P.cbase[ch];
+    const int32_t f = P.finish[g];
+    long long m_lo = 0;
+    if (jr > 0) m_lo = (long long) ((uint32_t) (P.finish[g - 1] - cb) >> P.logW) + 1;   // finish[g-1] > cbase
+    long long m_hi = (long long) ((uint32_t) (f - cb) >> P.logW);
+    const bool last = (g + 1 == P.seg_off[seg + 1]);
+    if (m_lo > m_hi && !last) return;                    // common case: no boundary inside this interval
     const long long nw = P.c_nwin[ch];
     const long long rowbase = P.c_first_win[ch] + ch;
-    const long long f = P.finish[g];
-    long long m_lo = 0;
-    if (jr > 0) m_lo = (P.finish[g - 1] - cb) / P.W + 1;     // finish[g-1] > cbase always
-    long long m_hi = (f - cb) / P.W;
     if (m_hi > nw) m_hi = nw;
     for (long long m = m_lo; m <= m_hi; m++) P.widx[(size_t) (rowbase + m) * N + i] = (uint32_t) jr;
-    if (jr == n - 1)
-        for (long long m = m_hi + 1; m <= nw; m++) P.widx[(size_t) (rowbase + m) * N + i] = (uint32_t) n;
+    if (last)
+        for (long long m = m_hi + 1; m <= nw; m++) P.widx[(size_t) (rowbase + m) * N + i] = (uint32_t) (jr + 1);
 }
 
 #endif  // WT_CORE_H_

@@ -26,13 +26,21 @@
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-template <int OP, class ValT, class ScrT>
+template <int OP, class ValT, class ScrT, int K>
 __global__ void __launch_bounds__(WT_MAX_BLOCK) wt_reduce_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
     wt_ctx_init(c, P, wt_lds);
-    WtLane L;
+    WtLane<K> L;
     const int tid = threadIdx.x, nt = blockDim.x;
+#ifdef WT_PROFILE
+#define WT_TICK(slot) do { if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+        prof[slot] += t_ - t_last; t_last = t_; } } while (0)
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_readcyclecounter();
+#else
+#define WT_TICK(slot) do { } while (0)
+#endif
     for (;;) {
         if (tid == 0) c.sh->ticket = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
         __syncthreads();
@@ -41,25 +49,51 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK) wt_reduce_kernel(const WtParams 
         if (tid == 0) wt_phase_header(P, c, k);
         wt_phase_zero(P, c, tid, nt);
         __syncthreads();
+        WT_TICK(0);
         wt_phase_load(P, c, tid, nt);
         __syncthreads();
-        wt_phase_count(P, c, tid, nt);
+        WT_TICK(1);
+        wt_phase_count_a(P, c, tid, nt);
         __syncthreads();
-        wt_phase_eval<OP, ValT, ScrT>(P, c, L, tid, nt);
+        wt_phase_count_b(P, c, tid, nt);
         __syncthreads();
+        WT_TICK(2);
+        wt_phase_eval<OP, ValT, ScrT, K>(P, c, L, tid, nt);
+        __syncthreads();
+        WT_TICK(3);
         wt_phase_escan(P, c, tid, nt);
         __syncthreads();
-        if (tid == 0) wt_phase_lookback(P, c, k);
+        WT_TICK(4);
+        if (tid < 64) wt_phase_lookback_wave(P, c, k, tid);
         __syncthreads();
-        wt_phase_write<OP, ValT>(P, c, L, tid, nt);
+        WT_TICK(5);
+        wt_phase_write<OP, ValT, K>(P, c, L, tid, nt);
         __syncthreads();
+        WT_TICK(6);
     }
+#ifdef WT_PROFILE
+    if (tid == 0)
+        for (int q = 0; q < 8; q++) wt_glb_add64(&P.counters[WT_CTR_PROF + q], prof[q]);
+#endif
 }
 
+// Each block owns chunks of WT_INDEX_CHUNK consecutive intervals; one binary
+// search per chunk finds the (chrom,track) segment of its first interval, every
+// lane then walks forward from there.
+#define WT_INDEX_CHUNK 4096
 __global__ void __launch_bounds__(256) wt_index_kernel(const WtParams P, long long total) {
-    const long long stride = (long long) gridDim.x * blockDim.x;
-    for (long long g = (long long) blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride)
-        wt_index_interval(P, g);
+    __shared__ long long seg0;
+    const long long n_chunks = (total + WT_INDEX_CHUNK - 1) / WT_INDEX_CHUNK;
+    for (long long ck = blockIdx.x; ck < n_chunks; ck += gridDim.x) {
+        const long long begin = ck * WT_INDEX_CHUNK;
+        long long end = begin + WT_INDEX_CHUNK;
+        if (end > total) end = total;
+        __syncthreads();
+        if (threadIdx.x == 0) seg0 = wt_index_find_segment(P, begin);
+        __syncthreads();
+        long long seg = seg0;
+        for (long long g = begin + threadIdx.x; g < end; g += blockDim.x) wt_index_interval(P, g, seg);
+    }
 }
 
 __global__ void __launch_bounds__(256) wt_extents_kernel(const int64_t *seg_off, const int32_t *start,
@@ -325,7 +359,7 @@ static void wt_fill_params(const wtamd_trackset *ts, const WtWindows *w, const W
     memset(&P, 0, sizeof(P));
     P.start = ts->d_start; P.finish = ts->d_finish; P.value = ts->d_value;
     P.seg_off = ts->d_seg_off; P.defaults = ts->d_defaults;
-    P.n_chrom = ts->n_chrom; P.n_tracks = ts->n_tracks;
+    P.n_chrom = ts->n_chrom; P.n_tracks = ts->n_tracks; P.n_total = ts->n_intervals;
     P.cbase = w->d_cbase; P.c_nwin = w->d_cnwin; P.c_first_win = w->d_cfirst;
     P.n_windows = w->tab.n_windows; P.win_chrom = w->d_win_chrom; P.widx = w->d_widx;
     P.status = w->d_status; P.counters = ts->d_counters;
@@ -339,7 +373,7 @@ static int wt_build_index(wtamd_trackset *ts, WtWindows *w, const WtPlan &plan, 
     WT_HIP(hipMemsetAsync(w->d_widx, 0, sizeof(uint32_t) * (size_t) w->tab.n_rows * ts->n_tracks, s));
     if (ts->n_intervals > 0) {
         const long long total = ts->n_intervals;
-        long long blocks = (total + 255) / 256;
+        long long blocks = (total + WT_INDEX_CHUNK - 1) / WT_INDEX_CHUNK;
         const long long cap = (long long) ts->num_cu * 16;
         if (blocks > cap) blocks = cap;
         hipLaunchKernelGGL(wt_index_kernel, dim3((unsigned) blocks), dim3(256), 0, s, P, total);
@@ -372,9 +406,9 @@ struct WtLaunch {
     int num_cu = 256;
     hipError_t err = hipSuccess;
 
-    template <int OP, class ValT, class ScrT>
+    template <int OP, class ValT, class ScrT, int K>
     void run() {
-        auto kern = wt_reduce_kernel<OP, ValT, ScrT>;
+        auto kern = wt_reduce_kernel<OP, ValT, ScrT, K>;
         if (lds > 48 * 1024) {
             err = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;
@@ -435,10 +469,10 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
 
     WT_HIP(hipMemsetAsync(ts->d_counters, 0, sizeof(unsigned long long) * WT_CTR_N, s));
     WT_HIP(hipMemsetAsync(L.P.chrom_run_off, 0, sizeof(int64_t) * (ts->n_chrom + 1), s));
-    if (w->tab.n_windows > 0) {
+    if (w->tab.n_windows > 0 && ts->n_intervals > 0) {
         WT_HIP(hipMemsetAsync(w->d_status, 0, sizeof(unsigned long long) * w->tab.n_windows, s));
         WT_HIP(hipEventRecord(ts->ev_r0, s));
-        if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, L)) return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
+        if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, L)) return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
         if (L.err != hipSuccess) return wt_fail(WTAMD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(L.err));
         WT_HIP(hipEventRecord(ts->ev_r1, s));
         ts->have_reduce_time = true;
@@ -453,6 +487,17 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
         ts->stats.covered_bp = (int64_t) ts->h_counters[WT_CTR_BP];
         ts->stats.n_intervals = (int64_t) ts->h_counters[WT_CTR_INTERVALS];
         *n_runs = ts->stats.n_runs;
+#ifdef WT_PROFILE
+        {
+            static const char *names[8] = {"zero", "load", "count", "eval", "escan", "lookback", "write", "-"};
+            unsigned long long tot = 0;
+            for (int q = 0; q < 8; q++) tot += ts->h_counters[WT_CTR_PROF + q];
+            fprintf(stderr, "[wt_profile] op %d:", op);
+            for (int q = 0; q < 7; q++)
+                fprintf(stderr, " %s %.1f%%", names[q], tot ? 100.0 * ts->h_counters[WT_CTR_PROF + q] / tot : 0.0);
+            fprintf(stderr, " (total %.3g cycles over all workgroups)\n", (double) tot);
+        }
+#endif
         if (ts->h_counters[WT_CTR_ERROR] & WT_ERR_LOOKBACK) return wt_fail(WTAMD_ERR_INTERNAL, "look-back timed out");
         if (ts->h_counters[WT_CTR_ERROR] & WT_ERR_CAPACITY) return wt_fail(WTAMD_ERR_CAPACITY, "output capacity too small");
     }

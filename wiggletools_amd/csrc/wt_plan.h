@@ -18,9 +18,10 @@ struct WtPlan {
     int T = 0;          // workgroup size (lanes), multiple of 64
     int n_words = 0;
     int spitch = 0, cpitch = 0;
-    int off_S = 0, off_cnt = 0, off_U = 0, off_E = 0, off_epfx = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
+    int off_S = 0, off_cnt = 0, off_segtot = 0, off_U = 0, off_E = 0, off_epfx = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
     int lds_bytes = 0;
     int scratch_elem = 0;   // bytes per scratch element (0: op needs no scratch)
+    int ppt = 1;            // consecutive window positions per lane (1 or 4)
 };
 
 static inline int wt_align16(int x) { return (x + 15) & ~15; }
@@ -30,12 +31,13 @@ static inline bool wt_op_needs_scratch(int op) { return op == WT_OP_MEDIAN || op
 // LDS bytes for a candidate (W, T)
 static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem, WtPlan &p) {
     p.W = W; p.T = T; p.n_words = W / 64;
-    p.spitch = p.n_words + 1;                 // +1 word: rows start on different banks
-    p.cpitch = (p.n_words + 1) & ~1;          // even number of u16
+    p.spitch = W / 32 + 1;                    // {S,C} pairs per track, +1: rows start on different banks
+    p.cpitch = (W / 32 + 1) & ~1;             // u16 rank prefix per 32-bit word, even count
     p.scratch_elem = scratch_elem;
     int o = 0;
     p.off_S = o;       o = wt_align16(o + n_tracks * p.spitch * 8);
     p.off_cnt = o;     o = wt_align16(o + n_tracks * p.cpitch * 2);
+    p.off_segtot = o;  o = wt_align16(o + n_tracks * 8 * 4);      // WT_COUNT_SEGS == 8
     p.off_U = o;       o = wt_align16(o + p.n_words * 8);
     p.off_E = o;       o = wt_align16(o + p.n_words * 8);
     p.off_epfx = o;    o = wt_align16(o + (p.n_words + 1) * 4);
@@ -47,30 +49,35 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
     p.lds_bytes = o;
 }
 
-// Chooses (W, T).  Environment overrides (experiments): WTAMD_W, WTAMD_T.
-// soft_limit: preferred LDS per workgroup (several workgroups per CU);
-// hard_limit: the most one workgroup may take (gfx950: 160 KiB).
+// Chooses (positions per lane, T, W = ppt*T).  Preference: wide windows with 4
+// positions per lane (instruction-level parallelism, shared bitmap reads) while
+// two workgroups still fit one CU; many tracks fall back to 1 position per lane so
+// that the CU keeps enough waves.  Environment overrides (experiments only):
+// WTAMD_PPT, WTAMD_T.
 static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &out, std::string &err,
-                                int soft_limit = 64 * 1024, int hard_limit = 160 * 1024) {
-    const char *eW = getenv("WTAMD_W");
+                                int soft_limit = 80 * 1024, int hard_limit = 160 * 1024) {
+    const char *eP = getenv("WTAMD_PPT");
     const char *eT = getenv("WTAMD_T");
-    const int scratch_elem = wt_op_needs_scratch(op) ? (scratch_f32 ? 4 : 8) : 0;
-    std::vector<int> Ts;
-    if (eT) Ts.push_back(atoi(eT));
-    else if (wt_op_needs_scratch(op)) Ts = {256, 128, 64};
-    else Ts = {512, 256};
+    const bool scr = wt_op_needs_scratch(op);
+    const int scratch_elem = scr ? (scratch_f32 ? 4 : 8) : 0;
+    struct Cand { int ppt, T; };
+    std::vector<Cand> cands;
+    if (eP || eT) {
+        const int ppt = scr ? 1 : (eP ? atoi(eP) : 4);
+        const int T = eT ? atoi(eT) : 256;
+        if ((ppt == 1 || ppt == 4) && T >= 64 && T <= 512 && !(T & (T - 1))) cands.push_back({ppt, T});
+    }
+    if (cands.empty()) {
+        if (scr) cands = {{1, 256}, {1, 128}, {1, 64}};
+        else cands = {{4, 512}, {4, 256}, {1, 512}, {1, 256}, {1, 128}, {1, 64}};
+    }
     for (int pass = 0; pass < 2; pass++) {
         const int limit = pass == 0 ? soft_limit : hard_limit;
-        for (int T : Ts) {
-            if (T <= 0 || (T & 63) || T > 1024) continue;
-            for (int W = eW ? atoi(eW) : WT_MAX_ITERS * T; W >= 64; W >>= 1) {
-                if ((W & 63) || W > WT_MAX_ITERS * T || W > 32768) { if (eW) break; continue; }
-                WtPlan p;
-                wt_carve(n_tracks, op, W, T, scratch_elem, p);
-                // scratch ops: do not accept tiny windows while a smaller T is still to be tried
-                if (p.lds_bytes <= limit && !(pass == 0 && W < 256 && !eW)) { out = p; return true; }
-                if (eW) break;
-            }
+        for (const Cand &cd : cands) {
+            WtPlan p;
+            wt_carve(n_tracks, op, cd.ppt * cd.T, cd.T, scratch_elem, p);
+            p.ppt = cd.ppt;
+            if (p.lds_bytes <= limit) { out = p; return true; }
         }
     }
     err = "no LDS plan fits " + std::to_string(n_tracks) + " tracks (op " + std::to_string(op) + ")";
@@ -79,7 +86,9 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
 
 static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.W = p.W; P.n_words = p.n_words; P.spitch = p.spitch; P.cpitch = p.cpitch;
-    P.off_S = p.off_S; P.off_cnt = p.off_cnt; P.off_U = p.off_U; P.off_E = p.off_E;
+    P.logW = 0;
+    while ((1 << P.logW) < p.W) P.logW++;
+    P.off_S = p.off_S; P.off_cnt = p.off_cnt; P.off_segtot = p.off_segtot; P.off_U = p.off_U; P.off_E = p.off_E;
     P.off_epfx = p.off_epfx; P.off_gbase = p.off_gbase; P.off_scratch = p.off_scratch;
     P.off_shared = p.off_shared; P.lds_bytes = p.lds_bytes;
 }
@@ -128,29 +137,36 @@ static inline void wt_make_windows(int n_chrom, int n_tracks, const int64_t *seg
 // Template dispatch over (op, value type, scratch type).  F must provide
 //   template <int OP, class ValT, class ScrT> void run();
 // Streaming ops ignore ScrT (ScrT = ValT keeps the instantiation count down).
+template <int OP, int K, class F>
+static inline void wt_dispatch_types2(bool value_f64, bool scratch_f32, F &f) {
+    // ScrT == float <=> float tracks whose defaults are float-exact (f32 select / f32 scratch)
+    if (value_f64) f.template run<OP, double, double, K>();
+    else if (scratch_f32) f.template run<OP, float, float, K>();
+    else f.template run<OP, float, double, K>();
+}
+
 template <int OP, class F>
-static inline void wt_dispatch_types(bool value_f64, bool scratch_f32, F &f) {
-    if (value_f64) f.template run<OP, double, double>();
-    else if (!wt_op_needs_scratch(OP) || scratch_f32) f.template run<OP, float, float>();
-    else f.template run<OP, float, double>();
+static inline void wt_dispatch_types(bool value_f64, bool scratch_f32, int ppt, F &f) {
+    if (wt_op_needs_scratch(OP) || ppt == 1) wt_dispatch_types2<OP, 1>(value_f64, scratch_f32, f);
+    else wt_dispatch_types2<OP, 4>(value_f64, scratch_f32, f);
 }
 
 template <class F>
-static inline bool wt_dispatch(int op, bool value_f64, bool scratch_f32, F &f) {
+static inline bool wt_dispatch(int op, bool value_f64, bool scratch_f32, int ppt, F &f) {
     switch (op) {
-    case WT_OP_SUM: wt_dispatch_types<WT_OP_SUM>(value_f64, scratch_f32, f); return true;
-    case WT_OP_PRODUCT: wt_dispatch_types<WT_OP_PRODUCT>(value_f64, scratch_f32, f); return true;
-    case WT_OP_MEAN: wt_dispatch_types<WT_OP_MEAN>(value_f64, scratch_f32, f); return true;
-    case WT_OP_VAR: wt_dispatch_types<WT_OP_VAR>(value_f64, scratch_f32, f); return true;
+    case WT_OP_SUM: wt_dispatch_types<WT_OP_SUM>(value_f64, scratch_f32, ppt, f); return true;
+    case WT_OP_PRODUCT: wt_dispatch_types<WT_OP_PRODUCT>(value_f64, scratch_f32, ppt, f); return true;
+    case WT_OP_MEAN: wt_dispatch_types<WT_OP_MEAN>(value_f64, scratch_f32, ppt, f); return true;
+    case WT_OP_VAR: wt_dispatch_types<WT_OP_VAR>(value_f64, scratch_f32, ppt, f); return true;
     case WT_OP_STDDEV: case WT_OP_ENTROPY:   // reference reducers.c:665: entropy runs the stddev pop
-        wt_dispatch_types<WT_OP_STDDEV>(value_f64, scratch_f32, f); return true;
-    case WT_OP_CV: wt_dispatch_types<WT_OP_CV>(value_f64, scratch_f32, f); return true;
-    case WT_OP_MIN: wt_dispatch_types<WT_OP_MIN>(value_f64, scratch_f32, f); return true;
-    case WT_OP_MAX: wt_dispatch_types<WT_OP_MAX>(value_f64, scratch_f32, f); return true;
-    case WT_OP_MEDIAN: wt_dispatch_types<WT_OP_MEDIAN>(value_f64, scratch_f32, f); return true;
-    case WT_OP_TTEST: wt_dispatch_types<WT_OP_TTEST>(value_f64, scratch_f32, f); return true;
-    case WT_OP_MWU: wt_dispatch_types<WT_OP_MWU>(value_f64, scratch_f32, f); return true;
-    case WT_OP_MULTIPLEX: wt_dispatch_types<WT_OP_MULTIPLEX>(value_f64, scratch_f32, f); return true;
+        wt_dispatch_types<WT_OP_STDDEV>(value_f64, scratch_f32, ppt, f); return true;
+    case WT_OP_CV: wt_dispatch_types<WT_OP_CV>(value_f64, scratch_f32, ppt, f); return true;
+    case WT_OP_MIN: wt_dispatch_types<WT_OP_MIN>(value_f64, scratch_f32, ppt, f); return true;
+    case WT_OP_MAX: wt_dispatch_types<WT_OP_MAX>(value_f64, scratch_f32, ppt, f); return true;
+    case WT_OP_MEDIAN: wt_dispatch_types<WT_OP_MEDIAN>(value_f64, scratch_f32, ppt, f); return true;
+    case WT_OP_TTEST: wt_dispatch_types<WT_OP_TTEST>(value_f64, scratch_f32, ppt, f); return true;
+    case WT_OP_MWU: wt_dispatch_types<WT_OP_MWU>(value_f64, scratch_f32, ppt, f); return true;
+    case WT_OP_MULTIPLEX: wt_dispatch_types<WT_OP_MULTIPLEX>(value_f64, scratch_f32, ppt, f); return true;
     default: return false;
     }
 }
