@@ -189,6 +189,13 @@ typedef struct {
     const void *value;        /* float* or double* */
     int32_t value_is_f64;     /* 0: float32, 1: float64 */
     const double *defaults;   /* HOST pointer, n_tracks default_values */
+    /* Optional (NULL = whole chromosome): per chromosome, only runs whose START lies in
+     * [range_lo[c], range_hi[c]) are produced.  This is how one chromosome is cut into
+     * batches (drop-in layer) or shards (multi-GPU): a run spanning a cut belongs to the
+     * piece that holds its start and keeps its true finish, so pieces concatenate to the
+     * unsharded output.  INT32_MAX as range_hi = "to the end".  HOST pointers, n_chrom entries. */
+    const int32_t *range_lo;
+    const int32_t *range_hi;
 } wtamd_tracks;
 
 typedef struct {

@@ -81,6 +81,88 @@ def oracle_lib():
     return _oracle
 
 
+class Harness:
+    """A private copy of libref_harness.so bound to ONE library that exports the reference's
+    C API (the compiled reference, or wiggletools_amd's drop-in library)."""
+
+    def __init__(self, lib_path, tag):
+        import shutil
+        build()
+        src = os.path.join(_HERE, "libref_harness.so")
+        dst = os.path.join(_HERE, "libref_harness_%s.so" % tag)
+        if not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
+            shutil.copyfile(src, dst)
+        L = C.CDLL(dst)
+        L.ref_open.argtypes = [C.c_char_p]
+        if L.ref_open(lib_path.encode()) != 0:
+            raise RuntimeError("ref_open(%s) failed" % lib_path)
+        sig = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_reduce.restype = C.c_int64
+        L.ref_reduce.argtypes = sig
+        L.ref_reduce2.restype = C.c_int64
+        L.ref_reduce2.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_int, C.c_uint, C.c_int64,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_reduce_seek.restype = C.c_int64
+        L.ref_reduce_seek.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_multiplex.restype = C.c_int64
+        L.ref_multiplex.argtypes = [C.POINTER(_Tracks), C.c_uint, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_multiset.restype = C.c_int64
+        L.ref_multiset.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int64,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_reducer_default.restype = C.c_double
+        L.ref_reducer_default.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        self.L = L
+
+    def reduce(self, t, op, flags=0, n_set0=0):
+        s, keep = _pack(t)
+        cap = _bound(t)
+        oc, os_, of, ov = _alloc(cap)
+        code = _opcode(op)
+        if code >= 10:
+            n = self.L.ref_reduce2(C.byref(s), code, n_set0, flags, cap,
+                                   oc.ctypes.data, os_.ctypes.data, of.ctypes.data, ov.ctypes.data)
+        else:
+            n = self.L.ref_reduce(C.byref(s), code, flags, cap,
+                                  oc.ctypes.data, os_.ctypes.data, of.ctypes.data, ov.ctypes.data)
+        return _trim(n, (oc, os_, of, ov))
+
+    def reduce_seek(self, t, op, chrom, start, finish, flags=0):
+        s, keep = _pack(t)
+        cap = _bound(t)
+        oc, os_, of, ov = _alloc(cap)
+        n = self.L.ref_reduce_seek(C.byref(s), _opcode(op), flags, chrom, start, finish, cap,
+                                   oc.ctypes.data, os_.ctypes.data, of.ctypes.data, ov.ctypes.data)
+        return _trim(n, (oc, os_, of, ov))
+
+    def multiplex(self, t, flags=0):
+        s, keep = _pack(t)
+        cap = _bound(t)
+        N = int(t["n_tracks"])
+        oc, os_, of, _ = _alloc(cap)
+        tile = np.empty((cap, N), np.float64)
+        ip = np.empty((cap, N), np.uint8)
+        n = self.L.ref_multiplex(C.byref(s), flags, cap, oc.ctypes.data, os_.ctypes.data, of.ctypes.data,
+                                 tile.ctypes.data, ip.ctypes.data)
+        return _trim(n, (oc, os_, of, tile, ip))
+
+    def multiset(self, t, n_set0, flags=0):
+        s, keep = _pack(t)
+        cap = _bound(t)
+        N = int(t["n_tracks"])
+        oc, os_, of, _ = _alloc(cap)
+        tile = np.zeros((cap, N), np.float64)
+        ip = np.zeros((cap, N), np.uint8)
+        n = self.L.ref_multiset(C.byref(s), n_set0, flags, cap, oc.ctypes.data, os_.ctypes.data, of.ctypes.data,
+                                tile.ctypes.data, ip.ctypes.data)
+        return _trim(n, (oc, os_, of, tile, ip))
+
+    def reducer_default(self, op, defaults):
+        d = np.ascontiguousarray(defaults, np.float64)
+        return self.L.ref_reducer_default(_opcode(op), len(d), d.ctypes.data)
+
+
 def have_ref():
     build()
     return os.path.exists(os.path.join(_HERE, "_ref", "libwiggletools_ref.so"))

@@ -8,6 +8,10 @@
  *   (a) oracle/wt_oracle.c can be validated against the real thing, and
  *   (b) bench.py can time the real reference as cpu_baseline.kind="reference".
  *
+ * The same harness also drives OUR drop-in library (it exports the same C API),
+ * which is how the GPU parity tests of the drop-in layer read like calls into
+ * the reference.
+ *
  * The reference library is opened with dlopen(RTLD_LAZY): reference unaryOps.c
  * refers to BigWiggleReader/BamReader/... whose sources need libBigWig/htslib
  * (absent here); those symbols stay unresolved and are never called.
@@ -49,6 +53,7 @@ static WiggleIterator *(*r_AUCIntegrator)(WiggleIterator *);
 static WiggleIterator *(*r_PearsonIntegrator)(Multiplexer *);
 static WiggleIterator *(*r_CompressionWiggleIterator)(WiggleIterator *);
 static WiggleIterator *(*r_reduction[10])(Multiplexer *);
+static WiggleIterator *(*r_set_reduction[2])(Multiset *);      /* TTestReduction, MWUReduction (optional) */
 
 static const char *k_red_names[10] = {
     "SumReduction", "ProductReduction", "MeanReduction", "VarianceReduction", "StdDevReduction",
@@ -68,12 +73,18 @@ int ref_open(const char *path) {
     BIND(r_popMultiset, "popMultiset");
     BIND(r_pop, "pop");
     BIND(r_seek, "seek");
-    BIND(r_SmartReader, "SmartReader");
-    BIND(r_AUCIntegrator, "AUCIntegrator");
-    BIND(r_PearsonIntegrator, "PearsonIntegrator");
-    BIND(r_CompressionWiggleIterator, "CompressionWiggleIterator");
     for (int i = 0; i < 10; i++) BIND(r_reduction[i], k_red_names[i]);
 #undef BIND
+    /* optional symbols: the compiled reference lacks the set comparisons (GSL), the
+     * drop-in library lacks readers / integrators it does not replace */
+#define OPT(var, name) *(void **) (&var) = dlsym(g_lib, name)
+    OPT(r_SmartReader, "SmartReader");
+    OPT(r_AUCIntegrator, "AUCIntegrator");
+    OPT(r_PearsonIntegrator, "PearsonIntegrator");
+    OPT(r_CompressionWiggleIterator, "CompressionWiggleIterator");
+    OPT(r_set_reduction[0], "TTestReduction");
+    OPT(r_set_reduction[1], "MWUReduction");
+#undef OPT
     return 0;
 }
 
@@ -243,6 +254,28 @@ int64_t ref_multiset(const wto_tracks *t, int n_set0, unsigned flags, int64_t ca
     return n;
 }
 
+/* Two-sample reducer (op 10 = ttest, 11 = MWU) through newMultiset; only for libraries
+ * that export TTestReduction / MWUReduction. */
+int64_t ref_reduce2(const wto_tracks *t, int op, int n_set0, unsigned flags, int64_t cap,
+                    int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value) {
+    if (!g_lib || op < 10 || op > 11 || !r_set_reduction[op - 10]) return -2;
+    char **names = make_names(t->n_chrom);
+    Multiplexer **ms = (Multiplexer **) calloc(2, sizeof(Multiplexer *));
+    ms[0] = make_multiplexer(t, names, 0, n_set0, flags & 1u);
+    ms[1] = make_multiplexer(t, names, n_set0, t->n_tracks, flags & 2u);
+    Multiset *S = r_newMultiset(ms, 2);
+    WiggleIterator *r = r_set_reduction[op - 10](S);
+    int64_t n = 0;
+    while (!r->done) {
+        if (n >= cap) return -1;
+        o_chrom[n] = name_to_index(r->chrom);
+        o_start[n] = r->start; o_finish[n] = r->finish; o_value[n] = r->value;
+        n++;
+        r_pop(r);
+    }
+    return n;
+}
+
 /* Default value the reference reducer ctor computes. */
 double ref_reducer_default(int op, int n, const double *defaults) {
     if (!g_lib || op < 0 || op > 9) return NAN;
@@ -256,7 +289,7 @@ double ref_reducer_default(int op, int n, const double *defaults) {
 
 /* AUC of the reference reducer output (statistics.c:103-120). */
 double ref_auc_of_reduce(const wto_tracks *t, int op, unsigned flags) {
-    if (!g_lib || op < 0 || op > 9) return NAN;
+    if (!g_lib || op < 0 || op > 9 || !r_AUCIntegrator) return NAN;
     char **names = make_names(t->n_chrom);
     Multiplexer *m = make_multiplexer(t, names, 0, t->n_tracks, flags & 1u);
     WiggleIterator *a = r_AUCIntegrator(r_reduction[op](m));
@@ -266,7 +299,7 @@ double ref_auc_of_reduce(const wto_tracks *t, int op, unsigned flags) {
 
 /* Pearson of tracks 0 and 1 (statistics.c:414-465). */
 double ref_pearson(const wto_tracks *t) {
-    if (!g_lib || t->n_tracks != 2) return NAN;
+    if (!g_lib || t->n_tracks != 2 || !r_PearsonIntegrator) return NAN;
     char **names = make_names(t->n_chrom);
     Multiplexer *m = make_multiplexer(t, names, 0, 2, 0);
     WiggleIterator *p = r_PearsonIntegrator(m);
@@ -277,7 +310,7 @@ double ref_pearson(const wto_tracks *t) {
 /* Compression (unaryOps.c:235-263) of the reference reducer output. */
 int64_t ref_reduce_compressed(const wto_tracks *t, int op, unsigned flags, int64_t cap,
                               int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value) {
-    if (!g_lib || op < 0 || op > 9) return -2;
+    if (!g_lib || op < 0 || op > 9 || !r_CompressionWiggleIterator) return -2;
     char **names = make_names(t->n_chrom);
     Multiplexer *m = make_multiplexer(t, names, 0, t->n_tracks, flags & 1u);
     WiggleIterator *r = r_CompressionWiggleIterator(r_reduction[op](m));
@@ -299,7 +332,7 @@ int64_t ref_reduce_compressed(const wto_tracks *t, int op, unsigned flags, int64
 int64_t ref_reduce_files(int n_files, char **paths, int op, unsigned flags, int64_t cap,
                          int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value,
                          char *names_buf, int names_cap) {
-    if (!g_lib || op < 0 || op > 9) return -2;
+    if (!g_lib || op < 0 || op > 9 || !r_SmartReader) return -2;
     WiggleIterator **iters = (WiggleIterator **) calloc((size_t) n_files, sizeof(WiggleIterator *));
     for (int i = 0; i < n_files; i++) iters[i] = r_SmartReader(paths[i], 0);
     Multiplexer *m = r_newMultiplexer(iters, n_files, (wt_bool) (flags & 1u));

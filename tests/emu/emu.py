@@ -17,12 +17,12 @@ def lib():
         L.wtemu_reduce.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_longlong,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p]
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
 
-def reduce(t, op, flags=0, n_set0=0, ppt=None, T=None, multiplex=False):
+def reduce(t, op, flags=0, n_set0=0, ppt=None, T=None, multiplex=False, ranges=None):
     """t: RunLists.  Returns (chrom, start, finish, value) [+ (tile, inplay) if multiplex], info."""
     from oracle.oracle import OPS
     opcode = 12 if multiplex else (OPS[op] if isinstance(op, str) else int(op))
@@ -40,12 +40,17 @@ def reduce(t, op, flags=0, n_set0=0, ppt=None, T=None, multiplex=False):
         tile = np.zeros((cap, N), np.float64) if multiplex else None
         ip = np.zeros((cap, N), np.uint8) if multiplex else None
         info = np.zeros(8, np.int64)
+        if ranges is not None:
+            rlo = np.ascontiguousarray([r[0] for r in ranges], np.int32)
+            rhi = np.ascontiguousarray([r[1] for r in ranges], np.int32)
         value = np.ascontiguousarray(t.value)
         n = lib().wtemu_reduce(t.n_chrom, N, t.seg_off.ctypes.data, t.start.ctypes.data, t.finish.ctypes.data,
                                value.ctypes.data, int(value.dtype == np.float64), t.defaults.ctypes.data,
                                opcode, flags, n_set0, cap, os_.ctypes.data, of.ctypes.data, ov.ctypes.data,
                                cro.ctypes.data, tile.ctypes.data if multiplex else None,
-                               ip.ctypes.data if multiplex else None, info.ctypes.data)
+                               ip.ctypes.data if multiplex else None, info.ctypes.data,
+                               rlo.ctypes.data if ranges is not None else None,
+                               rhi.ctypes.data if ranges is not None else None)
     finally:
         for k, v in old.items():
             if v is None:

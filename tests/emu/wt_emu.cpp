@@ -55,7 +55,8 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
                        const int32_t *finish, const void *value, int value_is_f64, const double *defaults,
                        int op, unsigned flags, int n_set0, long long capacity,
                        int32_t *o_start, int32_t *o_finish, double *o_value, int64_t *chrom_run_off,
-                       double *o_tile, uint8_t *o_inplay, long long *info) {
+                       double *o_tile, uint8_t *o_inplay, long long *info,
+                       const int32_t *range_lo, const int32_t *range_hi) {
     EmuRun R;
     std::string err;
     const bool s32 = !value_is_f64 && wt_defaults_fit_f32(defaults, n_tracks);
@@ -65,7 +66,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
     for (int64_t s = 0; s < n_seg; s++)
         if (seg_off[s + 1] > seg_off[s]) { fs[s] = start[seg_off[s]]; lf[s] = finish[seg_off[s + 1] - 1]; }
     WtWindowTables tab;
-    wt_make_windows(n_chrom, n_tracks, seg_off, fs.data(), lf.data(), R.plan.W, tab);
+    wt_make_windows(n_chrom, n_tracks, seg_off, fs.data(), lf.data(), R.plan.W, tab, range_lo, range_hi);
 
     std::vector<uint32_t> widx((size_t) tab.n_rows * n_tracks, 0);
     std::vector<unsigned long long> status(tab.n_windows, 0), counters(WT_CTR_N, 0);
@@ -74,7 +75,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
     memset(&P, 0, sizeof(P));
     P.start = start; P.finish = finish; P.value = value; P.seg_off = seg_off; P.defaults = defaults;
     P.n_chrom = n_chrom; P.n_tracks = n_tracks;
-    P.cbase = tab.cbase.data(); P.c_nwin = tab.c_nwin.data(); P.c_first_win = tab.c_first_win.data();
+    P.cbase = tab.cbase.data(); P.c_nwin = tab.c_nwin.data(); P.c_hi = tab.c_hi.data(); P.c_first_win = tab.c_first_win.data();
     P.n_windows = tab.n_windows; P.win_chrom = tab.win_chrom.data(); P.widx = widx.data();
     P.op = op; P.flags = flags; P.n_set0 = n_set0;
     P.status = status.data(); P.counters = counters.data();

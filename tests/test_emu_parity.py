@@ -77,3 +77,37 @@ def test_emu_empty_and_single(oracle):
     t = RunLists.from_lists([[[(5, 6, 1.5)], []]])
     got, info = emu.reduce(t, "mean")
     assert got[1].tolist() == [5] and got[2].tolist() == [6] and got[3].tolist() == [1.5]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_emu_run_start_ranges_concatenate(oracle, seed):
+    """Cutting every chromosome into run-start ranges (batches / shards) and concatenating
+    the pieces reproduces the unsharded output: a run spanning a cut belongs to the piece
+    holding its start and keeps its true finish."""
+    rng = np.random.default_rng(seed)
+    t = random_case(4000 + seed, max_len=9000)
+    d = t.as_dict()
+    INT_MAX = 2 ** 31 - 1
+    for op in ("mean", "median", "max"):
+        exp = oracle.reduce(d, op)
+        # arbitrary cut points per chromosome
+        origin = [int(rng.integers(1, 3000)) for _ in range(t.n_chrom)]
+        step = int(rng.integers(500, 3000))
+        pieces = []
+        for part in range(4):
+            ranges = []
+            for c in range(t.n_chrom):
+                lo = origin[c] + step * (part - 1) if part > 0 else -INT_MAX
+                hi = origin[c] + step * part if part < 3 else INT_MAX
+                ranges.append((max(lo, -INT_MAX), hi))
+            got, info = emu.reduce(t, op, ranges=ranges, ppt=[None, 4, 1][seed % 3], T=[None, 64, 128][seed % 3])
+            pieces.append(got)
+        # interleave per chromosome
+        cat = [[], [], [], []]
+        for c in range(t.n_chrom):
+            for g in pieces:
+                m = g[0] == c
+                for k in range(4):
+                    cat[k].append(g[k][m])
+        cat = tuple(np.concatenate(x) for x in cat)
+        assert_runs_equal(cat, exp, 0.0, "seed %d op %s" % (seed, op))

@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("WTAMD_LIB") or os.path.join(_HERE, "csrc", "libwiggle
 class Tracks(C.Structure):
     _fields_ = [("n_chrom", C.c_int32), ("n_tracks", C.c_int32), ("seg_off", C.c_void_p),
                 ("start", C.c_void_p), ("finish", C.c_void_p), ("value", C.c_void_p),
-                ("value_is_f64", C.c_int32), ("defaults", C.c_void_p)]
+                ("value_is_f64", C.c_int32), ("defaults", C.c_void_p),
+                ("range_lo", C.c_void_p), ("range_hi", C.c_void_p)]
 
 
 class ReduceDesc(C.Structure):

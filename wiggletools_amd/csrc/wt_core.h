@@ -72,6 +72,7 @@ struct WtParams {
     // ---- chromosome tables ----
     const int32_t *cbase;         // [n_chrom] position of window 0 of the chromosome
     const int32_t *c_nwin;        // [n_chrom] number of windows (>= 1)
+    const int32_t *c_hi;          // [n_chrom] runs starting at or beyond this position are not produced
     const int64_t *c_first_win;   // [n_chrom+1] first global window index
     // ---- windows ----
     int32_t W;                    // window width in bp, power of two >= 64
@@ -107,7 +108,7 @@ struct WtParams {
 struct WtShared {
     long long ticket;
     long long goffset;            // global index of this window's first emitted run
-    int32_t chrom, w0, w1, nbits; // nbits = w1 - w0
+    int32_t chrom, w0, w1, emit_hi; // emit_hi: first run start NOT produced (range end)
     long long row;                // widx row of w0
     int32_t next_bp;              // first breakpoint >= w1 (INT32_MAX if none)
     int32_t n_emit;               // runs emitted by this window
@@ -256,7 +257,7 @@ WT_DEV void wt_phase_header(const WtParams &P, WtCtx &c, long long k) {
     sh->chrom = ch;
     sh->w0 = P.cbase[ch] + (int32_t) m * P.W;
     sh->w1 = sh->w0 + P.W;
-    sh->nbits = P.W;
+    sh->emit_hi = P.c_hi[ch];
     sh->row = k + ch;                 // one extra boundary row per chromosome
     sh->next_bp = 0x7fffffff;
     sh->n_emit = 0;
@@ -767,7 +768,11 @@ WT_DEV void wt_phase_eval(const WtParams &P, WtCtx &c, WtLane<K> &L, int tid, in
     L.emit = 0;
     const int p0 = tid * K;
     if (p0 >= P.W) return;
-    const unsigned bp_bits = (unsigned) ((c.U[p0 >> 6] >> (p0 & 63)) & ((1ull << K) - 1ull));
+    unsigned bp_bits = (unsigned) ((c.U[p0 >> 6] >> (p0 & 63)) & ((1ull << K) - 1ull));
+    {   // run starts at or beyond the range end belong to the next batch / shard
+        const long long room = (long long) c.sh->emit_hi - ((long long) c.sh->w0 + p0);
+        if (room < K) bp_bits &= (room <= 0) ? 0u : ((1u << room) - 1u);
+    }
     if (!bp_bits) return;
     double res[K];
     WtCover cv0, cv1;
@@ -965,9 +970,13 @@ WT_DEV void wt_index_interval(const WtParams &P, long long g, long long &seg) {
     const long long jr = g - s0;
     const int32_t cb = P.cbase[ch];
     const int32_t f = P.finish[g];
+    // cbase may be a range start above the data start: intervals ending before it claim nothing
     long long m_lo = 0;
-    if (jr > 0) m_lo = (long long) ((uint32_t) (P.finish[g - 1] - cb) >> P.logW) + 1;   // finish[g-1] > cbase
-    long long m_hi = (long long) ((uint32_t) (f - cb) >> P.logW);
+    if (jr > 0) {
+        const int32_t pf = P.finish[g - 1];
+        if (pf >= cb) m_lo = (long long) ((uint32_t) (pf - cb) >> P.logW) + 1;
+    }
+    long long m_hi = (f >= cb) ? (long long) ((uint32_t) (f - cb) >> P.logW) : -1;
     const bool last = (g + 1 == P.seg_off[seg + 1]);
     if (m_lo > m_hi && !last) return;                    // common case: no boundary inside this interval
     const long long nw = P.c_nwin[ch];

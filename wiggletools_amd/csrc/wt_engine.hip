@@ -153,7 +153,7 @@ static int wt_fail(int code, const std::string &msg) {
 struct WtWindows {
     WtPlan plan_geom;        // only W matters for the tables
     WtWindowTables tab;
-    int32_t *d_cbase = nullptr, *d_cnwin = nullptr, *d_win_chrom = nullptr;
+    int32_t *d_cbase = nullptr, *d_cnwin = nullptr, *d_chi = nullptr, *d_win_chrom = nullptr;
     int64_t *d_cfirst = nullptr;
     uint32_t *d_widx = nullptr;
     unsigned long long *d_status = nullptr;
@@ -168,6 +168,7 @@ struct wtamd_trackset {
     std::vector<int64_t> seg_off;
     std::vector<double> defaults;
     std::vector<int32_t> first_start, last_finish;
+    std::vector<int32_t> range_lo, range_hi;     // optional run-start ranges (empty = none)
     int32_t *d_start = nullptr, *d_finish = nullptr;
     void *d_value = nullptr;
     int64_t *d_seg_off = nullptr;
@@ -185,7 +186,7 @@ struct wtamd_trackset {
 };
 
 static void wt_free_windows(WtWindows &w) {
-    (void) hipFree(w.d_cbase); (void) hipFree(w.d_cnwin); (void) hipFree(w.d_win_chrom); (void) hipFree(w.d_cfirst);
+    (void) hipFree(w.d_cbase); (void) hipFree(w.d_cnwin); (void) hipFree(w.d_chi); (void) hipFree(w.d_win_chrom); (void) hipFree(w.d_cfirst);
     (void) hipFree(w.d_widx); (void) hipFree(w.d_status);
 }
 
@@ -219,6 +220,10 @@ static int wt_trackset_common(const wtamd_tracks *t, wtamd_trackset *ts) {
     ts->n_intervals = ts->seg_off[n_seg] - ts->seg_off[0];
     if (ts->seg_off[0] != 0) return wt_fail(WTAMD_ERR_ARG, "seg_off[0] must be 0");
     ts->defaults.assign(t->defaults, t->defaults + t->n_tracks);
+    if (t->range_lo && t->range_hi) {
+        ts->range_lo.assign(t->range_lo, t->range_lo + t->n_chrom);
+        ts->range_hi.assign(t->range_hi, t->range_hi + t->n_chrom);
+    }
     ts->scratch_f32 = !ts->value_f64 && wt_defaults_fit_f32(ts->defaults.data(), ts->n_tracks);
     WT_HIP(hipGetDevice(&ts->device));
     hipDeviceProp_t prop;
@@ -335,11 +340,14 @@ static int wt_get_windows(wtamd_trackset *ts, int W, WtWindows **out) {
     auto it = ts->windows.find(W);
     if (it != ts->windows.end()) { *out = &it->second; return WTAMD_OK; }
     WtWindows w;
-    wt_make_windows(ts->n_chrom, ts->n_tracks, ts->seg_off.data(), ts->first_start.data(), ts->last_finish.data(), W, w.tab);
+    wt_make_windows(ts->n_chrom, ts->n_tracks, ts->seg_off.data(), ts->first_start.data(), ts->last_finish.data(), W, w.tab,
+                    ts->range_lo.empty() ? nullptr : ts->range_lo.data(),
+                    ts->range_hi.empty() ? nullptr : ts->range_hi.data());
     const int nc = ts->n_chrom > 0 ? ts->n_chrom : 1;
     const int64_t nwin = w.tab.n_windows > 0 ? w.tab.n_windows : 1;
     WT_HIP(hipMalloc(&w.d_cbase, sizeof(int32_t) * nc));
     WT_HIP(hipMalloc(&w.d_cnwin, sizeof(int32_t) * nc));
+    WT_HIP(hipMalloc(&w.d_chi, sizeof(int32_t) * nc));
     WT_HIP(hipMalloc(&w.d_cfirst, sizeof(int64_t) * (nc + 1)));
     WT_HIP(hipMalloc(&w.d_win_chrom, sizeof(int32_t) * nwin));
     WT_HIP(hipMalloc(&w.d_widx, sizeof(uint32_t) * (size_t) (w.tab.n_rows > 0 ? w.tab.n_rows : 1) * ts->n_tracks));
@@ -347,6 +355,7 @@ static int wt_get_windows(wtamd_trackset *ts, int W, WtWindows **out) {
     if (ts->n_chrom > 0) {
         WT_HIP(hipMemcpy(w.d_cbase, w.tab.cbase.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
         WT_HIP(hipMemcpy(w.d_cnwin, w.tab.c_nwin.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
+        WT_HIP(hipMemcpy(w.d_chi, w.tab.c_hi.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
         WT_HIP(hipMemcpy(w.d_cfirst, w.tab.c_first_win.data(), sizeof(int64_t) * (ts->n_chrom + 1), hipMemcpyHostToDevice));
         WT_HIP(hipMemcpy(w.d_win_chrom, w.tab.win_chrom.data(), sizeof(int32_t) * w.tab.n_windows, hipMemcpyHostToDevice));
     }
@@ -360,7 +369,7 @@ static void wt_fill_params(const wtamd_trackset *ts, const WtWindows *w, const W
     P.start = ts->d_start; P.finish = ts->d_finish; P.value = ts->d_value;
     P.seg_off = ts->d_seg_off; P.defaults = ts->d_defaults;
     P.n_chrom = ts->n_chrom; P.n_tracks = ts->n_tracks; P.n_total = ts->n_intervals;
-    P.cbase = w->d_cbase; P.c_nwin = w->d_cnwin; P.c_first_win = w->d_cfirst;
+    P.cbase = w->d_cbase; P.c_nwin = w->d_cnwin; P.c_hi = w->d_chi; P.c_first_win = w->d_cfirst;
     P.n_windows = w->tab.n_windows; P.win_chrom = w->d_win_chrom; P.widx = w->d_widx;
     P.status = w->d_status; P.counters = ts->d_counters;
     wt_plan_to_params(plan, P);

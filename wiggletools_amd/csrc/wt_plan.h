@@ -94,8 +94,9 @@ static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
 }
 
 struct WtWindowTables {
-    std::vector<int32_t> cbase, c_nwin, win_chrom;
+    std::vector<int32_t> cbase, c_nwin, c_hi, win_chrom;
     std::vector<int64_t> c_first_win;   // n_chrom + 1
+    std::vector<int> empty_chrom;       // chromosomes whose range excludes all data
     int64_t n_windows = 0;
     int64_t n_rows = 0;                 // n_windows + n_chrom
     int64_t span_bp = 0;                // sum over chromosomes of (last finish - first start)
@@ -105,11 +106,14 @@ struct WtWindowTables {
 // segment is non-empty (seg_off[s+1] > seg_off[s]).
 static inline void wt_make_windows(int n_chrom, int n_tracks, const int64_t *seg_off,
                                    const int32_t *first_start, const int32_t *last_finish, int W,
-                                   WtWindowTables &t) {
+                                   WtWindowTables &t, const int32_t *range_lo = nullptr,
+                                   const int32_t *range_hi = nullptr) {
     t.cbase.assign(n_chrom, 0);
     t.c_nwin.assign(n_chrom, 1);
+    t.c_hi.assign(n_chrom, INT32_MAX);
     t.c_first_win.assign(n_chrom + 1, 0);
     t.win_chrom.clear();
+    t.empty_chrom.clear();
     t.span_bp = 0;
     for (int c = 0; c < n_chrom; c++) {
         int64_t lo = INT64_MAX, hi = INT64_MIN;
@@ -122,11 +126,23 @@ static inline void wt_make_windows(int n_chrom, int n_tracks, const int64_t *seg
         }
         int64_t nw = 1;
         if (lo <= hi) {
-            t.cbase[c] = (int32_t) lo;
-            nw = std::max<int64_t>(1, (hi - lo + W - 1) / W);
-            t.span_bp += hi - lo;
+            // optional run-start range [range_lo, range_hi): the window grid starts at range_lo
+            // and stops at range_hi (a multiple of every window width away, see the header)
+            const int64_t data_hi = hi;
+            if (range_lo && range_lo[c] > lo) lo = range_lo[c];
+            if (range_hi && range_hi[c] != INT32_MAX && range_hi[c] < hi) hi = range_hi[c];
+            if (lo < hi) {
+                t.cbase[c] = (int32_t) lo;
+                nw = std::max<int64_t>(1, (hi - lo + W - 1) / W);
+                t.span_bp += hi - lo;
+            } else {
+                // the range excludes every run start: park one window past the data (emits nothing)
+                t.cbase[c] = (int32_t) std::min<int64_t>(data_hi, INT32_MAX - 65536);
+                t.empty_chrom.push_back(c);
+            }
         }
         t.c_nwin[c] = (int32_t) nw;
+        if (range_hi) t.c_hi[c] = range_hi[c];
         t.c_first_win[c + 1] = t.c_first_win[c] + nw;
         for (int64_t m = 0; m < nw; m++) t.win_chrom.push_back(c);
     }

@@ -38,19 +38,31 @@ class TrackSet:
         self.n_tracks = n_tracks
         self._keep = keep
 
+    @staticmethod
+    def _ranges(ranges, n_chrom):
+        """ranges: None or per-chromosome (lo, hi) run-start bounds -> two int32 arrays (or None, None)."""
+        if ranges is None:
+            return None, None
+        assert len(ranges) == n_chrom
+        lo = np.ascontiguousarray([r[0] for r in ranges], np.int32)
+        hi = np.ascontiguousarray([r[1] for r in ranges], np.int32)
+        return lo, hi
+
     @classmethod
-    def from_runlists(cls, rl: RunLists):
+    def from_runlists(cls, rl: RunLists, ranges=None):
         L = _lib.lib()
         value = np.ascontiguousarray(rl.value)
+        rlo, rhi = cls._ranges(ranges, rl.n_chrom)
         t = _lib.Tracks(rl.n_chrom, rl.n_tracks, rl.seg_off.ctypes.data, rl.start.ctypes.data,
                         rl.finish.ctypes.data, value.ctypes.data, int(value.dtype == np.float64),
-                        rl.defaults.ctypes.data)
+                        rl.defaults.ctypes.data, rlo.ctypes.data if rlo is not None else None,
+                        rhi.ctypes.data if rhi is not None else None)
         h = C.c_void_p()
         _lib.check(L.wtamd_trackset_create_host(C.byref(t), C.byref(h)))
         return cls(h, rl.n_chrom, rl.n_tracks)
 
     @classmethod
-    def from_device(cls, n_chrom, n_tracks, seg_off, start, finish, value, defaults):
+    def from_device(cls, n_chrom, n_tracks, seg_off, start, finish, value, defaults, ranges=None):
         """start/finish/value: torch CUDA tensors (int32,int32,float32|float64), kept alive by this object.
         seg_off / defaults: host numpy arrays."""
         import torch
@@ -60,8 +72,10 @@ class TrackSet:
         assert value.dtype in (torch.float32, torch.float64)
         seg_off = np.ascontiguousarray(seg_off, np.int64)
         defaults = np.ascontiguousarray(defaults, np.float64)
+        rlo, rhi = cls._ranges(ranges, n_chrom)
         t = _lib.Tracks(n_chrom, n_tracks, seg_off.ctypes.data, start.data_ptr(), finish.data_ptr(),
-                        value.data_ptr(), int(value.dtype == torch.float64), defaults.ctypes.data)
+                        value.data_ptr(), int(value.dtype == torch.float64), defaults.ctypes.data,
+                        rlo.ctypes.data if rlo is not None else None, rhi.ctypes.data if rhi is not None else None)
         h = C.c_void_p()
         _lib.check(L.wtamd_trackset_create_device(C.byref(t), C.byref(h)))
         return cls(h, n_chrom, n_tracks, keep=(start, finish, value))
