@@ -206,11 +206,14 @@ def main():
         alg_bytes = 12.0 * n_intervals + 8.0 * N * st["n_windows"] + 16.0 * n_runs
         achieved = alg_bytes / (reduce_ms * 1e-3) / 1e9
         tile_equiv = n_runs * (4.0 * N + N / 8.0 + 24.0) / (reduce_ms * 1e-3) / 1e9   # SURVEY 8d tile figure
+        # HBM bytes per launch from the PMC passes (profiles/traffic.json, measured with
+        # tools_prof.sh): stored as a ratio to the algorithmic bytes of the profiled launch and
+        # scaled to this launch; None when no profile has been taken for this kernel.
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.op == "mean":
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath))["hbm_bytes_per_algorithmic_byte"] * alg_bytes
             except Exception:
                 traffic = None
         res = {

@@ -86,7 +86,11 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
     // window index "kernel"
     const int64_t total = seg_off[n_seg];
     P.n_total = total;
-    { long long seg = 0; for (int64_t g = 0; g < total; g++) wt_index_interval(P, g, seg); }
+    if (total > 0) {
+        WtIndexCursor cur;
+        wt_index_cursor_set(P, cur, wt_index_find_segment(P, 0));
+        for (int64_t g = 0; g < total; g++) wt_index_apply(P, cur, g, finish[g], g > 0 ? finish[g - 1] : 0);
+    }
 
     R.lds.assign((size_t) R.plan.lds_bytes + 64, 0);
     if (total > 0 && !wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R)) return -11;

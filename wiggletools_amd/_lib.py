@@ -44,7 +44,7 @@ def lib():
         raise ImportError(
             "wiggletools_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
-    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(LIB_PATH)   # RTLD_LOCAL: the library exports the reference's symbol names (pop, seek, ...)
     L.wtamd_last_error.restype = C.c_char_p
     L.wtamd_version.restype = C.c_char_p
     L.wtamd_device_count.restype = C.c_int

@@ -962,29 +962,42 @@ WT_DEV long long wt_index_find_segment(const WtParams &P, long long g) {
     return lo;
 }
 
-WT_DEV void wt_index_interval(const WtParams &P, long long g, long long &seg) {
+// Per-lane cursor: the (chrom, track) segment the lane is in and its constants.
+struct WtIndexCursor {
+    long long seg, s0, s1;      // segment index, its first interval, one past its last
+    long long nw, rowbase;
+    int32_t cb;
+    int i;
+};
+
+WT_DEV void wt_index_cursor_set(const WtParams &P, WtIndexCursor &c, long long seg) {
     const int N = P.n_tracks;
-    while (g >= P.seg_off[seg + 1]) seg++;
-    const long long s0 = P.seg_off[seg];
-    const int ch = (int) (seg / N), i = (int) (seg - (long long) ch * N);
-    const long long jr = g - s0;
-    const int32_t cb = P.cbase[ch];
-    const int32_t f = P.finish[g];
+    c.seg = seg;
+    c.s0 = P.seg_off[seg];
+    c.s1 = P.seg_off[seg + 1];
+    const int ch = (int) (seg / N);
+    c.i = (int) (seg - (long long) ch * N);
+    c.cb = P.cbase[ch];
+    c.nw = P.c_nwin[ch];
+    c.rowbase = P.c_first_win[ch] + ch;
+}
+
+// f = finish[g], pf = finish[g-1] (ignored for the first interval of a segment)
+WT_DEV void wt_index_apply(const WtParams &P, WtIndexCursor &c, long long g, int32_t f, int32_t pf) {
+    while (g >= c.s1) wt_index_cursor_set(P, c, c.seg + 1);      // empty segments are skipped too
+    const long long jr = g - c.s0;
+    const int32_t cb = c.cb;
     // cbase may be a range start above the data start: intervals ending before it claim nothing
     long long m_lo = 0;
-    if (jr > 0) {
-        const int32_t pf = P.finish[g - 1];
-        if (pf >= cb) m_lo = (long long) ((uint32_t) (pf - cb) >> P.logW) + 1;
-    }
+    if (jr > 0 && pf >= cb) m_lo = (long long) ((uint32_t) (pf - cb) >> P.logW) + 1;
     long long m_hi = (f >= cb) ? (long long) ((uint32_t) (f - cb) >> P.logW) : -1;
-    const bool last = (g + 1 == P.seg_off[seg + 1]);
+    const bool last = (g + 1 == c.s1);
     if (m_lo > m_hi && !last) return;                    // common case: no boundary inside this interval
-    const long long nw = P.c_nwin[ch];
-    const long long rowbase = P.c_first_win[ch] + ch;
-    if (m_hi > nw) m_hi = nw;
-    for (long long m = m_lo; m <= m_hi; m++) P.widx[(size_t) (rowbase + m) * N + i] = (uint32_t) jr;
+    const int N = P.n_tracks;
+    if (m_hi > c.nw) m_hi = c.nw;
+    for (long long m = m_lo; m <= m_hi; m++) P.widx[(size_t) (c.rowbase + m) * N + c.i] = (uint32_t) jr;
     if (last)
-        for (long long m = m_hi + 1; m <= nw; m++) P.widx[(size_t) (rowbase + m) * N + i] = (uint32_t) (jr + 1);
+        for (long long m = m_hi + 1; m <= c.nw; m++) P.widx[(size_t) (c.rowbase + m) * N + c.i] = (uint32_t) (jr + 1);
 }
 
 #endif  // WT_CORE_H_

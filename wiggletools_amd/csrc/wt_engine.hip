@@ -79,20 +79,32 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK) wt_reduce_kernel(const WtParams 
 
 // Each block owns chunks of WT_INDEX_CHUNK consecutive intervals; one binary
 // search per chunk finds the (chrom,track) segment of its first interval, every
-// lane then walks forward from there.
-#define WT_INDEX_CHUNK 4096
+// lane then walks forward from there.  The finish[] reads of a lane's
+// WT_INDEX_UNROLL intervals are issued before any of them is consumed.
+#define WT_INDEX_UNROLL 8
+#define WT_INDEX_CHUNK (256 * WT_INDEX_UNROLL)
 __global__ void __launch_bounds__(256) wt_index_kernel(const WtParams P, long long total) {
     __shared__ long long seg0;
     const long long n_chunks = (total + WT_INDEX_CHUNK - 1) / WT_INDEX_CHUNK;
     for (long long ck = blockIdx.x; ck < n_chunks; ck += gridDim.x) {
         const long long begin = ck * WT_INDEX_CHUNK;
-        long long end = begin + WT_INDEX_CHUNK;
-        if (end > total) end = total;
         __syncthreads();
         if (threadIdx.x == 0) seg0 = wt_index_find_segment(P, begin);
+        int32_t f[WT_INDEX_UNROLL], pf[WT_INDEX_UNROLL];
+#pragma unroll
+        for (int u = 0; u < WT_INDEX_UNROLL; u++) {
+            const long long g = begin + threadIdx.x + 256 * u;
+            f[u] = (g < total) ? P.finish[g] : 0;
+            pf[u] = (g < total && g > 0) ? P.finish[g - 1] : 0;
+        }
         __syncthreads();
-        long long seg = seg0;
-        for (long long g = begin + threadIdx.x; g < end; g += blockDim.x) wt_index_interval(P, g, seg);
+        WtIndexCursor cur;
+        wt_index_cursor_set(P, cur, seg0);
+#pragma unroll
+        for (int u = 0; u < WT_INDEX_UNROLL; u++) {
+            const long long g = begin + threadIdx.x + 256 * u;
+            if (g < total) wt_index_apply(P, cur, g, f[u], pf[u]);
+        }
     }
 }
 
