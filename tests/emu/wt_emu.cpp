@@ -34,7 +34,7 @@ struct EmuRun {
             if (k >= P.n_windows) break;
             wt_phase_header(P, c, k);
             for (int t = 0; t < T; t++) wt_phase_zero(P, c, t, T);
-            for (int t = 0; t < T; t++) wt_phase_load(P, c, t, T);
+            for (int t = 0; t < T; t++) wt_phase_load<ValT>(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_count_a(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_count_b(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_eval<OP, ValT, ScrT, K>(P, c, lanes[t], t, T);

@@ -159,6 +159,7 @@ WT_DEV int wt_ctz64(uint64_t x) { return __builtin_ctzll(x); }
 WT_DEV long long wt_uniform64(long long x) { return x; }
 WT_DEV void wt_lds_or64(uint64_t *p, uint64_t v) { *p |= v; }
 WT_DEV void wt_lds_xor64(uint64_t *p, uint64_t v) { *p ^= v; }
+WT_DEV void wt_lds_or32(uint32_t *p, uint32_t v) { *p |= v; }
 WT_DEV void wt_lds_min32(int32_t *p, int32_t v) { if (v < *p) *p = v; }
 WT_DEV void wt_lds_add64(unsigned long long *p, unsigned long long v) { *p += v; }
 WT_DEV unsigned long long wt_glb_add64(unsigned long long *p, unsigned long long v) {
@@ -168,6 +169,7 @@ WT_DEV void wt_glb_or64(unsigned long long *p, unsigned long long v) { *p |= v; 
 WT_DEV unsigned long long wt_status_load(unsigned long long *p) { return *p; }
 WT_DEV void wt_status_store(unsigned long long *p, unsigned long long v) { *p = v; }
 WT_DEV void wt_backoff() {}
+template <class T> WT_DEV void wt_keep_alive(T) {}
 #else
 WT_DEV int wt_popc64(uint64_t x) { return __popcll(x); }
 WT_DEV int wt_popc32(uint32_t x) { return __popc(x); }
@@ -180,6 +182,7 @@ WT_DEV long long wt_uniform64(long long x) {
 }
 WT_DEV void wt_lds_or64(uint64_t *p, uint64_t v) { atomicOr((unsigned long long *) p, (unsigned long long) v); }
 WT_DEV void wt_lds_xor64(uint64_t *p, uint64_t v) { atomicXor((unsigned long long *) p, (unsigned long long) v); }
+WT_DEV void wt_lds_or32(uint32_t *p, uint32_t v) { atomicOr((unsigned int *) p, (unsigned int) v); }
 WT_DEV void wt_lds_min32(int32_t *p, int32_t v) { atomicMin(p, v); }
 WT_DEV void wt_lds_add64(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
 WT_DEV unsigned long long wt_glb_add64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
@@ -193,6 +196,9 @@ WT_DEV void wt_status_store(unsigned long long *p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 WT_DEV void wt_backoff() { __builtin_amdgcn_s_sleep(8); }
+// forces a loaded value to materialise (used to warm L2 with data a later phase gathers)
+WT_DEV void wt_keep_alive(float v) { asm volatile("" :: "v"(v)); }
+WT_DEV void wt_keep_alive(double v) { asm volatile("" :: "v"(v)); }
 #endif
 
 WT_DEV bool wt_isnan(double x) { return x != x; }
@@ -273,6 +279,9 @@ WT_DEV void wt_phase_zero(const WtParams &P, WtCtx &c, int tid, int nt) {
     const int nS = P.n_tracks * P.spitch;
     for (int x = tid; x < nS; x += nt) c.SC[x] = 0;
     for (int x = tid; x < P.n_words; x += nt) { c.U[x] = 0; c.E[x] = 0; }
+    // spare cnt entry of every track: "an interval of this track spans w0" (its start bit at
+    // position 0 is a clipping artefact, not a breakpoint)
+    for (int i = tid; i < P.n_tracks; i += nt) c.cnt[(size_t) i * P.cpitch + P.n_words * 2] = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -293,12 +302,15 @@ WT_DEV void wt_phase_zero(const WtParams &P, WtCtx &c, int tid, int nt) {
 // ---------------------------------------------------------------------------
 #define WT_LOAD_GROUP 32         // lanes per track in the load phase
 #define WT_LOAD_UNROLL 4        // intervals per lane fetched ahead
+template <class ValT>
 struct WtLoadBatch {
     long long off, lo, hi;
     int32_t s[WT_LOAD_UNROLL], f[WT_LOAD_UNROLL];
+    ValT v[WT_LOAD_UNROLL];
 };
 
-WT_DEV void wt_load_fetch(const WtParams &P, const WtCtx &c, int i, int lane, WtLoadBatch &b) {
+template <class ValT>
+WT_DEV void wt_load_fetch(const WtParams &P, const WtCtx &c, int i, int lane, WtLoadBatch<ValT> &b) {
     const int N = P.n_tracks;
     const uint32_t *row0 = P.widx + (size_t) c.sh->row * N;
     const long long seg = (long long) c.sh->chrom * N + i;
@@ -313,37 +325,45 @@ WT_DEV void wt_load_fetch(const WtParams &P, const WtCtx &c, int i, int lane, Wt
         const bool ok = jr <= b.hi;
         b.s[u] = ok ? P.start[b.off + jr] : 0;
         b.f[u] = ok ? P.finish[b.off + jr] : 0;
+        // the value is not needed here: the load (coalesced, many in flight) warms L2 with the
+        // very cache lines the eval phase gathers from, so those gathers stop paying HBM latency
+        b.v[u] = ok ? ((const ValT *) P.value)[b.off + jr] : (ValT) 0;
     }
 }
 
-WT_DEV void wt_load_apply(const WtParams &P, WtCtx &c, uint64_t *SCi, int32_t s, int32_t f) {
+WT_DEV void wt_load_apply(const WtParams &P, WtCtx &c, uint64_t *SCi, uint16_t *pseudo, int32_t s, int32_t f) {
     const int32_t w0 = c.sh->w0, w1 = c.sh->w1;
     if (f == w0) { wt_lds_or64(&c.U[0], 1ull); return; }
     if (s >= w1) { wt_lds_min32(&c.sh->next_bp, s); return; }
     const int cs = s > w0 ? s - w0 : 0;
+    if (s < w0) *pseudo = 1;                  // at most one such interval per track and window
     const uint64_t sbit = 1ull << (cs & 31);
-    wt_lds_xor64(&SCi[cs >> 5], sbit | (sbit << 32));
-    if (s >= w0) wt_lds_or64(&c.U[cs >> 6], 1ull << (cs & 63));
+    uint64_t x = sbit | (sbit << 32);         // start bit (low half) + coverage toggle (high half)
     if (f < w1) {
         const int cf = f - w0;
-        wt_lds_xor64(&SCi[cf >> 5], (1ull << (cf & 31)) << 32);
-        wt_lds_or64(&c.U[cf >> 6], 1ull << (cf & 63));
+        const uint64_t fbit = (1ull << (cf & 31)) << 32;
+        if ((cf >> 5) == (cs >> 5)) x ^= fbit;            // same word: one atomic for both
+        else wt_lds_xor64(&SCi[cf >> 5], fbit);
     } else {
         wt_lds_min32(&c.sh->next_bp, f);
     }
+    wt_lds_xor64(&SCi[cs >> 5], x);
+    // true breakpoints (U) are derived from S | toggles in the count phase: no atomics here
 }
 
+template <class ValT>
 WT_DEV void wt_phase_load(const WtParams &P, WtCtx &c, int tid, int nt) {
     const int N = P.n_tracks;
     const int group = tid / WT_LOAD_GROUP, lane = tid % WT_LOAD_GROUP, ngroups = nt / WT_LOAD_GROUP;
     if (group >= N) return;
-    WtLoadBatch cur;
-    wt_load_fetch(P, c, group, lane, cur);
+    WtLoadBatch<ValT> cur;
+    wt_load_fetch<ValT>(P, c, group, lane, cur);
     for (int i = group; i < N; i += ngroups) {
-        WtLoadBatch nxt;
+        WtLoadBatch<ValT> nxt;
         const int inext = i + ngroups;
-        if (inext < N) wt_load_fetch(P, c, inext, lane, nxt);
+        if (inext < N) wt_load_fetch<ValT>(P, c, inext, lane, nxt);
         uint64_t *SCi = c.SC + (size_t) i * P.spitch;
+        uint16_t *pseudo = c.cnt + (size_t) i * P.cpitch + P.n_words * 2;
         if (lane == 0) {
             // gbase + r = global index of the r-th interval that has a start bit in S_i;
             // clamped so that gbase + 1 is always a valid address (r == 0 lookups load it blindly)
@@ -357,9 +377,12 @@ WT_DEV void wt_phase_load(const WtParams &P, WtCtx &c, int tid, int nt) {
         }
 #pragma unroll
         for (int u = 0; u < WT_LOAD_UNROLL; u++)
-            if (cur.lo + lane + WT_LOAD_GROUP * u <= cur.hi) wt_load_apply(P, c, SCi, cur.s[u], cur.f[u]);
+            if (cur.lo + lane + WT_LOAD_GROUP * u <= cur.hi) {
+                wt_load_apply(P, c, SCi, pseudo, cur.s[u], cur.f[u]);
+                wt_keep_alive(cur.v[u]);
+            }
         for (long long jr = cur.lo + lane + WT_LOAD_GROUP * WT_LOAD_UNROLL; jr <= cur.hi; jr += WT_LOAD_GROUP)
-            wt_load_apply(P, c, SCi, P.start[cur.off + jr], P.finish[cur.off + jr]);
+            wt_load_apply(P, c, SCi, pseudo, P.start[cur.off + jr], P.finish[cur.off + jr]);
         cur = nxt;
     }
 }
@@ -413,10 +436,18 @@ WT_DEV void wt_phase_count_b(const WtParams &P, WtCtx &c, int tid, int nt) {
             par ^= st >> 31;
         }
         uint32_t carry = par ? 0xffffffffu : 0u;
+        uint32_t *U32 = (uint32_t *) c.U;
+        const bool pseudo = ci[nw32] != 0;
         for (int w = w_lo; w < w_hi; w++) {
             const uint64_t sc = SCi[w];
             const uint32_t sbits = (uint32_t) sc;
             uint32_t t = (uint32_t) (sc >> 32);
+            // true breakpoints of this track: starts | finishes, and finishes == toggles ^ starts
+            // (a finish meeting the next start cancels in the toggles but shows in the starts);
+            // the clipped start of an interval spanning w0 is not a breakpoint
+            uint32_t u = sbits | t;
+            if (w == 0 && pseudo) u &= ~1u;
+            if (u) wt_lds_or32(&U32[w], u);
             ci[w] = (uint16_t) run;
             run += (unsigned) wt_popc32(sbits);
             t ^= t << 1; t ^= t << 2; t ^= t << 4; t ^= t << 8; t ^= t << 16;

@@ -22,12 +22,19 @@
 #include "wt_plan.h"
 
 #define WT_MAX_BLOCK 512
+// minimum waves per SIMD the register allocator must leave room for (MI355X_MICROARCH:
+// w = k*T/256).  The kernels fit 128 VGPRs on their own (two 512-lane workgroups per CU);
+// asking for 4 changes nothing in the register count but measurably worsens the schedule
+// (2.58 vs 2.39 ms on the bench kernel), so the bound stays at 3.
+#ifndef WT_MIN_WAVES
+#define WT_MIN_WAVES 3
+#endif
 
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
 template <int OP, class ValT, class ScrT, int K>
-__global__ void __launch_bounds__(WT_MAX_BLOCK) wt_reduce_kernel(const WtParams P) {
+__global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES) wt_reduce_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
     wt_ctx_init(c, P, wt_lds);
@@ -50,7 +57,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK) wt_reduce_kernel(const WtParams 
         wt_phase_zero(P, c, tid, nt);
         __syncthreads();
         WT_TICK(0);
-        wt_phase_load(P, c, tid, nt);
+        wt_phase_load<ValT>(P, c, tid, nt);
         __syncthreads();
         WT_TICK(1);
         wt_phase_count_a(P, c, tid, nt);
@@ -77,34 +84,40 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK) wt_reduce_kernel(const WtParams 
 #endif
 }
 
-// Each block owns chunks of WT_INDEX_CHUNK consecutive intervals; one binary
-// search per chunk finds the (chrom,track) segment of its first interval, every
-// lane then walks forward from there.  The finish[] reads of a lane's
-// WT_INDEX_UNROLL intervals are issued before any of them is consumed.
+// Each block owns ONE contiguous span of intervals: a single binary search finds the
+// (chrom,track) segment of its first interval, every lane then walks its cursor forward.  The
+// finish[] reads of the next sub-chunk are in flight while the current one is applied.
 #define WT_INDEX_UNROLL 8
 #define WT_INDEX_CHUNK (256 * WT_INDEX_UNROLL)
-__global__ void __launch_bounds__(256) wt_index_kernel(const WtParams P, long long total) {
-    __shared__ long long seg0;
-    const long long n_chunks = (total + WT_INDEX_CHUNK - 1) / WT_INDEX_CHUNK;
-    for (long long ck = blockIdx.x; ck < n_chunks; ck += gridDim.x) {
-        const long long begin = ck * WT_INDEX_CHUNK;
-        __syncthreads();
-        if (threadIdx.x == 0) seg0 = wt_index_find_segment(P, begin);
-        int32_t f[WT_INDEX_UNROLL], pf[WT_INDEX_UNROLL];
+__global__ void __launch_bounds__(256) wt_index_kernel(const WtParams P, long long total, long long span) {
+    const long long begin0 = (long long) blockIdx.x * span;
+    long long end0 = begin0 + span;
+    if (end0 > total) end0 = total;
+    if (begin0 >= end0) return;
+    WtIndexCursor cur;
+    wt_index_cursor_set(P, cur, wt_index_find_segment(P, begin0));
+    int32_t f[WT_INDEX_UNROLL], pf[WT_INDEX_UNROLL], nf[WT_INDEX_UNROLL], npf[WT_INDEX_UNROLL];
+#pragma unroll
+    for (int u = 0; u < WT_INDEX_UNROLL; u++) {
+        const long long g = begin0 + threadIdx.x + 256 * u;
+        f[u] = (g < end0) ? P.finish[g] : 0;
+        pf[u] = (g < end0 && g > 0) ? P.finish[g - 1] : 0;
+    }
+    for (long long begin = begin0; begin < end0; begin += WT_INDEX_CHUNK) {
+        const long long nb = begin + WT_INDEX_CHUNK;
+#pragma unroll
+        for (int u = 0; u < WT_INDEX_UNROLL; u++) {
+            const long long g = nb + threadIdx.x + 256 * u;
+            nf[u] = (g < end0) ? P.finish[g] : 0;
+            npf[u] = (g < end0) ? P.finish[g - 1] : 0;
+        }
 #pragma unroll
         for (int u = 0; u < WT_INDEX_UNROLL; u++) {
             const long long g = begin + threadIdx.x + 256 * u;
-            f[u] = (g < total) ? P.finish[g] : 0;
-            pf[u] = (g < total && g > 0) ? P.finish[g - 1] : 0;
+            if (g < end0) wt_index_apply(P, cur, g, f[u], pf[u]);
         }
-        __syncthreads();
-        WtIndexCursor cur;
-        wt_index_cursor_set(P, cur, seg0);
 #pragma unroll
-        for (int u = 0; u < WT_INDEX_UNROLL; u++) {
-            const long long g = begin + threadIdx.x + 256 * u;
-            if (g < total) wt_index_apply(P, cur, g, f[u], pf[u]);
-        }
+        for (int u = 0; u < WT_INDEX_UNROLL; u++) { f[u] = nf[u]; pf[u] = npf[u]; }
     }
 }
 
@@ -395,9 +408,13 @@ static int wt_build_index(wtamd_trackset *ts, WtWindows *w, const WtPlan &plan, 
     if (ts->n_intervals > 0) {
         const long long total = ts->n_intervals;
         long long blocks = (total + WT_INDEX_CHUNK - 1) / WT_INDEX_CHUNK;
-        const long long cap = (long long) ts->num_cu * 16;
+        const long long cap = (long long) ts->num_cu * 8;      // 8 x 256 lanes = a full CU
         if (blocks > cap) blocks = cap;
-        hipLaunchKernelGGL(wt_index_kernel, dim3((unsigned) blocks), dim3(256), 0, s, P, total);
+        // contiguous span per block, a whole number of sub-chunks
+        long long span = (total + blocks - 1) / blocks;
+        span = (span + WT_INDEX_CHUNK - 1) / WT_INDEX_CHUNK * WT_INDEX_CHUNK;
+        blocks = (total + span - 1) / span;
+        hipLaunchKernelGGL(wt_index_kernel, dim3((unsigned) blocks), dim3(256), 0, s, P, total, span);
         WT_HIP(hipGetLastError());
     }
     WT_HIP(hipEventRecord(ts->ev_i1, s));

@@ -32,7 +32,7 @@ static inline bool wt_op_needs_scratch(int op) { return op == WT_OP_MEDIAN || op
 static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem, WtPlan &p) {
     p.W = W; p.T = T; p.n_words = W / 64;
     p.spitch = W / 32 + 1;                    // {S,C} pairs per track, +1: rows start on different banks
-    p.cpitch = (W / 32 + 1) & ~1;             // u16 rank prefix per 32-bit word, even count
+    p.cpitch = (W / 32 + 2) & ~1;             // u16 rank prefix per 32-bit word + 1 spare flag entry, even count
     p.scratch_elem = scratch_elem;
     int o = 0;
     p.off_S = o;       o = wt_align16(o + n_tracks * p.spitch * 8);
