@@ -260,8 +260,8 @@ int wtamd_reduce_host(wtamd_trackset *ts, const wtamd_reduce_desc *desc, wtamd_r
 
 /* Multiplexer "materialise": emits the aligned tile the reference exposes per
  * popMultiplexer (multiplexer.h:21-36): for each run r, values[r*n_tracks+i]
- * and inplay[r*n_tracks+i].  HOST output.  Used by the drop-in layer when a
- * Multiplexer* escapes to code that reads its fields. */
+ * and inplay[r*n_tracks+i]; runs->value[r] receives the run's inplay_count.  HOST output.
+ * Used by the drop-in layer when a Multiplexer* escapes to code that reads its fields. */
 int wtamd_multiplex_host(wtamd_trackset *ts, uint32_t flags, wtamd_runs *runs,
                          double *values, uint8_t *inplay, int64_t *n_runs);
 

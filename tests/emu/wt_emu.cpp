@@ -37,10 +37,13 @@ struct EmuRun {
             for (int t = 0; t < T; t++) wt_phase_load<ValT>(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_count_a(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_count_b(P, c, t, T);
-            for (int t = 0; t < T; t++) wt_phase_eval<OP, ValT, ScrT, K>(P, c, lanes[t], t, T);
+            constexpr bool two = (OP == WT_OP_TTEST || OP == WT_OP_MWU);
+            for (int t = 0; t < T; t++) wt_phase_emask(P, c, two, t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
+            for (int t = 0; t < T; t++) wt_phase_eval<OP, ValT, ScrT, K>(P, c, lanes[t], t, T);
             wt_phase_lookback(P, c, k);
             for (int t = 0; t < T; t++) wt_phase_write<OP, ValT, K>(P, c, lanes[t], t, T);
+            wt_window_stats(P, c);
         }
     }
 };

@@ -89,6 +89,7 @@ struct WtParams {
     // ---- ordering / bookkeeping ----
     unsigned long long *status;   // [n_windows] look-back words, zeroed before each launch
     unsigned long long *counters; // [WT_CTR_N], zeroed before each launch
+    unsigned long long *debug;    // host-visible progress markers (-DWT_DEBUG_MARK builds only)
     // ---- output ----
     int64_t capacity;
     int32_t *o_start;
@@ -100,7 +101,7 @@ struct WtParams {
     // ---- LDS carve (bytes from the dynamic LDS base; all multiples of 16) ----
     int32_t spitch;               // u64 {S,C} pairs per track row (W/32 + 1: bank spread)
     int32_t cpitch;               // u16 entries per cnt_i row (W/32, even)
-    int32_t off_S, off_cnt, off_segtot, off_U, off_E, off_epfx, off_gbase, off_scratch, off_shared;
+    int32_t off_S, off_cnt, off_segtot, off_U, off_cover, off_E, off_epfx, off_nextw, off_gbase, off_scratch, off_shared;
     int32_t lds_bytes;
 };
 
@@ -119,9 +120,7 @@ struct WtShared {
 // Per-lane state that lives across phases (registers on the GPU)
 template <int K>
 struct WtLane {
-    double res[K];
-    int32_t fin[K];
-    uint32_t emit;                // bit k set <=> position tid*K+k starts an emitted run
+    double res[K];                // reducer values of the lane's K positions (registers across the barrier)
 };
 
 // LDS views
@@ -130,8 +129,10 @@ struct WtCtx {
     uint16_t *cnt;      // [n_tracks * cpitch] start-bit rank prefix per 32-bit word
     uint32_t *segtot;   // [n_tracks * WT_COUNT_SEGS] count-phase segment totals
     uint64_t *U;        // [n_words] true breakpoints
+    uint32_t *cover;    // [4][2*n_words] coverage summaries over tracks: any(set0), all(set0), any(set1), all(set1)
     uint64_t *E;        // [n_words] emitted run starts
     uint32_t *epfx;     // [n_words + 1]
+    int16_t *nextw;     // [n_words] index of the next non-empty word of U after w, or -1
     long long *gbase;   // [n_tracks] global index of (first covering interval) - 1
     char *scratch;      // per-lane column scratch for median / MWU
     WtShared *sh;
@@ -142,8 +143,10 @@ WT_DEV void wt_ctx_init(WtCtx &c, const WtParams &P, char *lds) {
     c.cnt = (uint16_t *) (lds + P.off_cnt);
     c.segtot = (uint32_t *) (lds + P.off_segtot);
     c.U = (uint64_t *) (lds + P.off_U);
+    c.cover = (uint32_t *) (lds + P.off_cover);
     c.E = (uint64_t *) (lds + P.off_E);
     c.epfx = (uint32_t *) (lds + P.off_epfx);
+    c.nextw = (int16_t *) (lds + P.off_nextw);
     c.gbase = (long long *) (lds + P.off_gbase);
     c.scratch = lds + P.off_scratch;
     c.sh = (WtShared *) (lds + P.off_shared);
@@ -160,6 +163,7 @@ WT_DEV long long wt_uniform64(long long x) { return x; }
 WT_DEV void wt_lds_or64(uint64_t *p, uint64_t v) { *p |= v; }
 WT_DEV void wt_lds_xor64(uint64_t *p, uint64_t v) { *p ^= v; }
 WT_DEV void wt_lds_or32(uint32_t *p, uint32_t v) { *p |= v; }
+WT_DEV void wt_lds_and32(uint32_t *p, uint32_t v) { *p &= v; }
 WT_DEV void wt_lds_min32(int32_t *p, int32_t v) { if (v < *p) *p = v; }
 WT_DEV void wt_lds_add64(unsigned long long *p, unsigned long long v) { *p += v; }
 WT_DEV unsigned long long wt_glb_add64(unsigned long long *p, unsigned long long v) {
@@ -183,6 +187,7 @@ WT_DEV long long wt_uniform64(long long x) {
 WT_DEV void wt_lds_or64(uint64_t *p, uint64_t v) { atomicOr((unsigned long long *) p, (unsigned long long) v); }
 WT_DEV void wt_lds_xor64(uint64_t *p, uint64_t v) { atomicXor((unsigned long long *) p, (unsigned long long) v); }
 WT_DEV void wt_lds_or32(uint32_t *p, uint32_t v) { atomicOr((unsigned int *) p, (unsigned int) v); }
+WT_DEV void wt_lds_and32(uint32_t *p, uint32_t v) { atomicAnd((unsigned int *) p, (unsigned int) v); }
 WT_DEV void wt_lds_min32(int32_t *p, int32_t v) { atomicMin(p, v); }
 WT_DEV void wt_lds_add64(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
 WT_DEV unsigned long long wt_glb_add64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
@@ -279,6 +284,13 @@ WT_DEV void wt_phase_zero(const WtParams &P, WtCtx &c, int tid, int nt) {
     const int nS = P.n_tracks * P.spitch;
     for (int x = tid; x < nS; x += nt) c.SC[x] = 0;
     for (int x = tid; x < P.n_words; x += nt) { c.U[x] = 0; c.E[x] = 0; }
+    const int nw32z = P.n_words * 2;
+    for (int x = tid; x < nw32z; x += nt) {
+        c.cover[x] = 0;                      // any(set 0)
+        c.cover[nw32z + x] = 0xffffffffu;    // all(set 0)
+        c.cover[2 * nw32z + x] = 0;          // any(set 1)
+        c.cover[3 * nw32z + x] = 0xffffffffu;// all(set 1)
+    }
     // spare cnt entry of every track: "an interval of this track spans w0" (its start bit at
     // position 0 is a clipping artefact, not a breakpoint)
     for (int i = tid; i < P.n_tracks; i += nt) c.cnt[(size_t) i * P.cpitch + P.n_words * 2] = 0;
@@ -438,6 +450,10 @@ WT_DEV void wt_phase_count_b(const WtParams &P, WtCtx &c, int tid, int nt) {
         uint32_t carry = par ? 0xffffffffu : 0u;
         uint32_t *U32 = (uint32_t *) c.U;
         const bool pseudo = ci[nw32] != 0;
+        const int set1 = (P.n_set0 > 0 && i >= P.n_set0) ? 1 : 0;
+        uint32_t *cov_any = c.cover + (size_t) (2 * set1) * nw32;
+        uint32_t *cov_all = cov_any + nw32;
+        const bool strict_set = (P.flags & (set1 ? WT_STRICT_SET1 : WT_STRICT_SET0)) != 0;
         for (int w = w_lo; w < w_hi; w++) {
             const uint64_t sc = SCi[w];
             const uint32_t sbits = (uint32_t) sc;
@@ -454,6 +470,10 @@ WT_DEV void wt_phase_count_b(const WtParams &P, WtCtx &c, int tid, int nt) {
             t ^= carry;
             carry = (t >> 31) ? 0xffffffffu : 0u;
             SCi[w] = ((uint64_t) t << 32) | sbits;
+            // coverage summaries for the emission predicate (multiplexer.c:120,125;
+            // setComparisons.c:48-54): any = OR over the set's tracks, all = AND (strict only)
+            if (t) wt_lds_or32(&cov_any[w], t);
+            if (strict_set && t != 0xffffffffu) wt_lds_and32(&cov_all[w], t);
         }
     }
 }
@@ -529,35 +549,23 @@ WT_DEV double wt_unkey64(uint64_t k) {
     return __builtin_bit_cast(double, u);
 }
 
-// Coverage summary of a group of tracks over the 32 positions of one word:
-// any = OR of the tracks' coverage words, all = AND.  Bit b0+k answers the
-// Multiplexer's emission predicate for position p0+k (multiplexer.c:120,125 and
-// setComparisons.c:48-54) without counting tracks per position.
-struct WtCover {
-    uint32_t any, all;
-};
-
 // Visits tracks lo..hi-1 in index order, two tracks' gathers in flight at a time.
 // body(i, F) is called in increasing i.
 template <class ValT, class ScrT, int K, class Body>
 WT_DEV void wt_for_tracks(const WtParams &P, const WtCtx &c, int lo, int hi, int w32, int b0,
-                          const uint32_t (&mask)[K], bool use_defaults, WtCover &cv, Body body) {
+                          const uint32_t (&mask)[K], bool use_defaults, Body body) {
     const double *dflt = P.defaults;
     int i = lo;
     for (; i + 1 < hi; i += 2) {
         WtFetchK<K> F0, F1;
         wt_fetch_group<ValT, ScrT, K>(P, c, i, w32, b0, mask, use_defaults ? dflt[i] : 0.0, F0);
         wt_fetch_group<ValT, ScrT, K>(P, c, i + 1, w32, b0, mask, use_defaults ? dflt[i + 1] : 0.0, F1);
-        cv.any |= F0.cbits | F1.cbits;
-        cv.all &= F0.cbits & F1.cbits;
         body(i, F0);
         body(i + 1, F1);
     }
     if (i < hi) {
         WtFetchK<K> F0;
         wt_fetch_group<ValT, ScrT, K>(P, c, i, w32, b0, mask, use_defaults ? dflt[i] : 0.0, F0);
-        cv.any |= F0.cbits;
-        cv.all &= F0.cbits;
         body(i, F0);
     }
 }
@@ -566,9 +574,8 @@ WT_DEV void wt_for_tracks(const WtParams &P, const WtCtx &c, int lo, int hi, int
 // Per-run reducers.  One lane evaluates K consecutive window positions; for
 // every position the tracks are visited in index order i = 0..N-1 in f64,
 // exactly the reference's summation order (bit-identical sums).
-// res[k] = reducer value; cv0 / cv1 = coverage summaries of set 0 / set 1
-// (one-sample ops: everything is "set 0").  Positions that are not breakpoints
-// are computed too (cheaper than diverging) and discarded by the caller.
+// res[k] = reducer value.  Positions of the group that do not start an emitted run are
+// computed too (cheaper than diverging) and discarded by the caller.
 // NaN: the reference tests isnan() per value and yields NaN; for sum / product /
 // mean / var / stddev / CV IEEE propagation through the accumulator gives the
 // same answer (NaN in -> NaN out), so no flag is carried; min / max / median /
@@ -576,21 +583,20 @@ WT_DEV void wt_for_tracks(const WtParams &P, const WtCtx &c, int lo, int hi, int
 // Median / MWU use K == 1 and this lane's LDS scratch column.
 // ---------------------------------------------------------------------------
 template <int OP, class ValT, class ScrT, int K>
-WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&res)[K], WtCover &cv0, WtCover &cv1,
+WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&res)[K],
                           char *scratch, int lane_col, int colstride) {
     const int N = P.n_tracks;
     const int w32 = p0 >> 5, b0 = p0 & 31;
     uint32_t mask[K];
 #pragma unroll
     for (int k = 0; k < K; k++) mask[k] = (2u << (b0 + k)) - 1u;
-    cv0.any = 0; cv0.all = 0xffffffffu; cv1.any = 0; cv1.all = 0xffffffffu;
 
     if (OP == WT_OP_SUM || OP == WT_OP_PRODUCT || OP == WT_OP_MEAN) {
         // reducers.c:259-292, 313-346, 367-402
         double acc[K];
 #pragma unroll
         for (int k = 0; k < K; k++) acc[k] = (OP == WT_OP_PRODUCT) ? 1.0 : 0.0;
-        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, cv0, [&](int, const WtFetchK<K> &F) {
+        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, [&](int, const WtFetchK<K> &F) {
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 if (OP == WT_OP_PRODUCT) acc[k] *= F.x[k]; else acc[k] += F.x[k];
@@ -607,11 +613,10 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
         {
             WtFetchK<K> F;
             wt_fetch_group<ValT, ScrT, K>(P, c, 0, w32, b0, mask, 0.0, F);
-            cv0.any |= F.cbits; cv0.all &= F.cbits;
 #pragma unroll
             for (int k = 0; k < K; k++) { best[k] = F.x[k]; nan[k] = wt_isnan(best[k]); }
         }
-        wt_for_tracks<ValT, ScrT, K>(P, c, 1, N, w32, b0, mask, true, cv0, [&](int, const WtFetchK<K> &F) {
+        wt_for_tracks<ValT, ScrT, K>(P, c, 1, N, w32, b0, mask, true, [&](int, const WtFetchK<K> &F) {
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const double x = F.x[k];
@@ -629,14 +634,13 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
         double mean[K], acc[K];
 #pragma unroll
         for (int k = 0; k < K; k++) { mean[k] = 0; acc[k] = 0; }
-        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, cv0, [&](int, const WtFetchK<K> &F) {
+        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, [&](int, const WtFetchK<K> &F) {
 #pragma unroll
             for (int k = 0; k < K; k++) mean[k] += (double) (float) F.x[k];
         });
 #pragma unroll
         for (int k = 0; k < K; k++) mean[k] /= N;
-        WtCover dummy = {0, 0};
-        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, dummy, [&](int, const WtFetchK<K> &F) {
+        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, [&](int, const WtFetchK<K> &F) {
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 // var ignores absent tracks in pass 2 (:470-475); stddev / CV use their default
@@ -664,12 +668,12 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
         double s1[K], q1[K], s2[K], q2[K];
 #pragma unroll
         for (int k = 0; k < K; k++) { s1[k] = q1[k] = s2[k] = q2[k] = 0; }
-        wt_for_tracks<ValT, ScrT, K>(P, c, 0, na, w32, b0, mask, false, cv0, [&](int, const WtFetchK<K> &F) {
+        wt_for_tracks<ValT, ScrT, K>(P, c, 0, na, w32, b0, mask, false, [&](int, const WtFetchK<K> &F) {
 #pragma unroll
             for (int k = 0; k < K; k++)
                 if (F.cov[k]) { s1[k] += F.x[k]; q1[k] += F.x[k] * F.x[k]; }
         });
-        wt_for_tracks<ValT, ScrT, K>(P, c, na, N, w32, b0, mask, false, cv1, [&](int, const WtFetchK<K> &F) {
+        wt_for_tracks<ValT, ScrT, K>(P, c, na, N, w32, b0, mask, false, [&](int, const WtFetchK<K> &F) {
 #pragma unroll
             for (int k = 0; k < K; k++)
                 if (F.cov[k]) { s2[k] += F.x[k]; q2[k] += F.x[k] * F.x[k]; }
@@ -697,7 +701,7 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
         typedef typename std::conditional<sizeof(ScrT) == 4, uint32_t, uint64_t>::type KeyT;
         KeyT *col = (KeyT *) scratch + lane_col;
         bool nan = false;
-        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, cv0, [&](int i, const WtFetchK<K> &F) {
+        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, [&](int i, const WtFetchK<K> &F) {
             const double x = F.x[0];
             nan |= wt_isnan(x);
             if (sizeof(ScrT) == 4) col[(size_t) i * colstride] = (KeyT) wt_key32((float) x);
@@ -738,8 +742,8 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
             val[(size_t) j * colstride] = (ScrT) x;
             set[(size_t) j * colstride] = (uint8_t) (i >= na);
         };
-        wt_for_tracks<ValT, ScrT, K>(P, c, 0, na, w32, b0, mask, true, cv0, insert);
-        wt_for_tracks<ValT, ScrT, K>(P, c, na, N, w32, b0, mask, true, cv1, insert);
+        wt_for_tracks<ValT, ScrT, K>(P, c, 0, na, w32, b0, mask, true, insert);
+        wt_for_tracks<ValT, ScrT, K>(P, c, na, N, w32, b0, mask, true, insert);
         if (nan) { res[0] = wt_nan(); return; }
         const double mu = (double) (na * nb / 2);                               // :386 int division
         const double sigma = sqrt((double) (na * nb * (na + nb + 1) / 12));     // :387 int division
@@ -767,71 +771,59 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
         return;
     }
     if (OP == WT_OP_MULTIPLEX) {
-        // only the coverage summary is needed: OR / AND of the tracks' coverage words
+        // the per-run value of the materialised Multiplexer is its inplay_count
+        // (multiplexer.h:27); the values[] / inplay[] tile is gathered in the write phase
+        int cnt[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) cnt[k] = 0;
         for (int i = 0; i < N; i++) {
             const uint32_t cb = (uint32_t) (c.SC[(size_t) i * P.spitch + w32] >> 32);
-            cv0.any |= cb; cv0.all &= cb;
+#pragma unroll
+            for (int k = 0; k < K; k++) cnt[k] += (int) ((cb >> (b0 + k)) & 1u);
         }
 #pragma unroll
-        for (int k = 0; k < K; k++) res[k] = 0.0;
+        for (int k = 0; k < K; k++) res[k] = (double) cnt[k];
         return;
     }
 }
 
-// First true breakpoint after window position p (absolute coordinate).
+// First true breakpoint after window position p (absolute coordinate).  Loop-free: the
+// emask phase records for every word of U the next non-empty word (nextw).
 WT_DEV int32_t wt_next_breakpoint(const WtParams &P, const WtCtx &c, int p) {
-    int w = p >> 6;
-    uint64_t bits = c.U[w] & ~wt_mask_incl(p & 63);
-    while (!bits) {
-        if (++w >= P.n_words) return c.sh->next_bp;
-        bits = c.U[w];
-    }
-    return c.sh->w0 + w * 64 + wt_ctz64(bits);
+    const int w = p >> 6;
+    const uint64_t here = c.U[w] & ~wt_mask_incl(p & 63);
+    const int w2 = here ? w : (int) c.nextw[w];
+    if (w2 < 0) return c.sh->next_bp;
+    const uint64_t bits = here ? here : c.U[w2];
+    return c.sh->w0 + w2 * 64 + wt_ctz64(bits);
 }
 
 // ---------------------------------------------------------------------------
-// Phase 4: evaluate every breakpoint owned by the window.  Lane `tid` owns the
-// K consecutive positions [tid*K, tid*K+K).
+// Phase 4: emitted-run bitmap E = true breakpoints & emission predicate & range.
+// The predicate comes from the coverage summaries of the count phase, so the run
+// count of the window is known BEFORE the reducers run: the look-back can overlap
+// the evaluation instead of following it.
 // ---------------------------------------------------------------------------
-template <int OP, class ValT, class ScrT, int K>
-WT_DEV void wt_phase_eval(const WtParams &P, WtCtx &c, WtLane<K> &L, int tid, int nt) {
-    const bool two = (OP == WT_OP_TTEST || OP == WT_OP_MWU);
-    L.emit = 0;
-    const int p0 = tid * K;
-    if (p0 >= P.W) return;
-    unsigned bp_bits = (unsigned) ((c.U[p0 >> 6] >> (p0 & 63)) & ((1ull << K) - 1ull));
-    {   // run starts at or beyond the range end belong to the next batch / shard
-        const long long room = (long long) c.sh->emit_hi - ((long long) c.sh->w0 + p0);
-        if (room < K) bp_bits &= (room <= 0) ? 0u : ((1u << room) - 1u);
+WT_DEV void wt_phase_emask(const WtParams &P, WtCtx &c, bool two, int tid, int nt) {
+    const int nw32 = P.n_words * 2;
+    const uint64_t *any0 = (const uint64_t *) c.cover;
+    const uint64_t *all0 = (const uint64_t *) (c.cover + nw32);
+    const uint64_t *any1 = (const uint64_t *) (c.cover + 2 * nw32);
+    const uint64_t *all1 = (const uint64_t *) (c.cover + 3 * nw32);
+    for (int w = tid; w < P.n_words; w += nt) {
+        uint64_t emit = (P.flags & WT_STRICT_SET0) ? all0[w] : any0[w];     // multiplexer.c:120,125
+        if (two) emit &= (P.flags & WT_STRICT_SET1) ? all1[w] : any1[w];    // setComparisons.c:48-54
+        // run starts at or beyond the range end belong to the next batch / shard
+        const long long room = (long long) c.sh->emit_hi - ((long long) c.sh->w0 + (long long) w * 64);
+        if (room < 64) emit &= (room <= 0) ? 0ull : ((1ull << room) - 1ull);
+        c.E[w] = c.U[w] & emit;
     }
-    if (!bp_bits) return;
-    double res[K];
-    WtCover cv0, cv1;
-    wt_eval_group<OP, ValT, ScrT, K>(P, c, p0, res, cv0, cv1, c.scratch, tid, nt);
-    // emission predicate as a word: one-sample any/all (multiplexer.c:120,125); two-sample: both
-    // Multiplexers in play (setComparisons.c:48-54 / 282-288)
-    uint32_t emit_word = (P.flags & WT_STRICT_SET0) ? cv0.all : cv0.any;
-    if (two) emit_word &= (P.flags & WT_STRICT_SET1) ? cv1.all : cv1.any;
-    const unsigned emit_k = (emit_word >> (p0 & 31)) & ((1u << K) - 1u);
-    unsigned long long bp = 0;
-    unsigned emit_bits = 0;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        bool emit = (emit_k >> k) & 1u;
-        emit = emit && ((bp_bits >> k) & 1u);
-        L.res[k] = res[k];
-        L.fin[k] = 0;
-        if (emit) {
-            const int32_t fin = wt_next_breakpoint(P, c, p0 + k);
-            L.fin[k] = fin;
-            emit_bits |= 1u << k;
-            bp += (unsigned long long) (fin - (c.sh->w0 + p0 + k));
+    if (tid == nt - 1) {            // tiny backward scan (n_words <= 512)
+        int last = -1;
+        for (int w = P.n_words - 1; w >= 0; w--) {
+            c.nextw[w] = (int16_t) last;
+            if (c.U[w]) last = w;
         }
-    }
-    L.emit = emit_bits;
-    if (emit_bits) {
-        wt_lds_or64(&c.E[p0 >> 6], (uint64_t) emit_bits << (p0 & 63));
-        wt_lds_add64(&c.sh->bp_sum, bp);
     }
 }
 
@@ -847,9 +839,23 @@ WT_DEV void wt_phase_escan(const WtParams &P, WtCtx &c, int tid, int nt) {
 }
 
 // ---------------------------------------------------------------------------
-// Phase 6 (one lane): decoupled look-back for the global run offset.
-// status[k] = AGG|count once window k knows its own count,
-//             PFX|inclusive_prefix once it also knows everything before it.
+// Phase 6: evaluate the reducer at every emitted run start.  Lane `tid` owns the
+// K consecutive positions [tid*K, tid*K+K).
+// ---------------------------------------------------------------------------
+template <int OP, class ValT, class ScrT, int K>
+WT_DEV void wt_phase_eval(const WtParams &P, WtCtx &c, WtLane<K> &L, int tid, int nt) {
+    const int p0 = tid * K;
+    if (p0 >= P.W) return;
+    const unsigned emit_bits = (unsigned) ((c.E[p0 >> 6] >> (p0 & 63)) & ((1ull << K) - 1ull));
+    if (!emit_bits) return;
+    wt_eval_group<OP, ValT, ScrT, K>(P, c, p0, L.res, c.scratch, tid, nt);
+}
+
+// ---------------------------------------------------------------------------
+// Look-back: global offset of the window's first run.  Decoupled look-back over
+// 64-bit {flag,count} status words:
+//   status[k] = AGG|count once window k knows its own count,
+//               PFX|inclusive_prefix once it also knows everything before it.
 // Windows are handed out in order by the ticket, so every predecessor has
 // started; the spin is bounded and reports WT_ERR_LOOKBACK instead of hanging.
 // ---------------------------------------------------------------------------
@@ -865,8 +871,6 @@ WT_DEV void wt_lookback_finish(const WtParams &P, WtCtx &c, long long k, unsigne
         P.chrom_run_off[P.n_chrom] = (long long) (excl + mine);
         P.counters[WT_CTR_RUNS] = excl + mine;
     }
-    if (sh->bp_sum) wt_glb_add64(&P.counters[WT_CTR_BP], sh->bp_sum);
-    if (sh->n_intervals) wt_glb_add64(&P.counters[WT_CTR_INTERVALS], sh->n_intervals);
     if ((long long) (excl + mine) > P.capacity) wt_glb_or64(&P.counters[WT_CTR_ERROR], WT_ERR_CAPACITY);
 }
 
@@ -899,14 +903,18 @@ WT_DEV void wt_phase_lookback(const WtParams &P, WtCtx &c, long long k) {
 }
 
 #ifndef WT_EMU
-// Wave flavour (the 64 lanes of wave 0): lane L inspects window base-L, so one
-// global round trip covers 64 predecessors instead of one.
-WT_DEV void wt_phase_lookback_wave(const WtParams &P, WtCtx &c, long long k, int lane) {
+// Wave flavour (the 64 lanes of wave 0), split in two around the evaluation phase:
+//   publish  (before eval)  AGG|count of this window -- successors never wait for our reducers
+//   complete (after eval)   lane L inspects window base-L: 64 predecessors per round trip; by
+//                           now they have almost always published, so there is no spinning.
+WT_DEV void wt_lookback_publish(const WtParams &P, WtCtx &c, long long k) {
     const unsigned long long mine = c.epfx[P.n_words];
-    if (lane == 0) {
-        c.sh->n_emit = (int32_t) mine;
-        if (k > 0) wt_status_store(&P.status[k], WT_FLAG_AGG | mine);
-    }
+    c.sh->n_emit = (int32_t) mine;
+    if (k > 0) wt_status_store(&P.status[k], WT_FLAG_AGG | mine);
+}
+
+WT_DEV void wt_lookback_complete(const WtParams &P, WtCtx &c, long long k, int lane) {
+    const unsigned long long mine = c.epfx[P.n_words];
     unsigned long long excl = 0;
     long long base = k - 1;
     while (base >= 0) {
@@ -945,34 +953,46 @@ WT_DEV void wt_phase_lookback_wave(const WtParams &P, WtCtx &c, long long k, int
 // ---------------------------------------------------------------------------
 template <int OP, class ValT, int K>
 WT_DEV void wt_phase_write(const WtParams &P, WtCtx &c, const WtLane<K> &L, int tid, int nt) {
-    if (!L.emit) return;
-    const long long goff = c.sh->goffset;
-    const int32_t w0 = c.sh->w0;
     const int p0 = tid * K;
-    const int w = p0 >> 6, b0 = p0 & 63;
-    const uint64_t below0 = b0 ? wt_mask_incl(b0 - 1) : 0ull;
-    long long idx = goff + c.epfx[w] + wt_popc64(c.E[w] & below0);
+    unsigned emit_bits = 0;
+    if (p0 < P.W) emit_bits = (unsigned) ((c.E[p0 >> 6] >> (p0 & 63)) & ((1ull << K) - 1ull));
+    unsigned long long bp = 0;
+    if (emit_bits) {
+        const long long goff = c.sh->goffset;
+        const int32_t w0 = c.sh->w0;
+        const int w = p0 >> 6, b0 = p0 & 63;
+        const uint64_t below0 = b0 ? wt_mask_incl(b0 - 1) : 0ull;
+        long long idx = goff + c.epfx[w] + wt_popc64(c.E[w] & below0);
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        if (!((L.emit >> k) & 1u)) continue;
-        const long long o = idx++;
-        if (o >= P.capacity) continue;
-        const int p = p0 + k;
-        P.o_start[o] = w0 + p;
-        P.o_finish[o] = L.fin[k];
-        if (OP == WT_OP_MULTIPLEX) {
-            const int N = P.n_tracks;
-            const uint32_t mask1[1] = { (2u << (p & 31)) - 1u };
-            WtFetchK<1> F;
-            for (int i = 0; i < N; i++) {
-                wt_fetch_group<ValT, double, 1>(P, c, i, p >> 5, p & 31, mask1, P.defaults[i], F);
-                P.o_tile[o * N + i] = F.x[0];
-                P.o_inplay[o * N + i] = (uint8_t) F.cov[0];
+        for (int k = 0; k < K; k++) {
+            if (!((emit_bits >> k) & 1u)) continue;
+            const long long o = idx++;
+            const int p = p0 + k;
+            const int32_t fin = wt_next_breakpoint(P, c, p);
+            bp += (unsigned long long) (fin - (w0 + p));
+            if (o >= P.capacity) continue;
+            P.o_start[o] = w0 + p;
+            P.o_finish[o] = fin;
+            if (OP == WT_OP_MULTIPLEX) {
+                const int N = P.n_tracks;
+                const uint32_t mask1[1] = { (2u << (p & 31)) - 1u };
+                WtFetchK<1> F;
+                for (int i = 0; i < N; i++) {
+                    wt_fetch_group<ValT, double, 1>(P, c, i, p >> 5, p & 31, mask1, P.defaults[i], F);
+                    P.o_tile[o * N + i] = F.x[0];
+                    P.o_inplay[o * N + i] = (uint8_t) F.cov[0];
+                }
             }
-        } else {
             P.o_value[o] = L.res[k];
         }
+        wt_lds_add64(&c.sh->bp_sum, bp);
     }
+}
+
+// Per-window statistics -> global counters (one lane, after every lane's contribution is in).
+WT_DEV void wt_window_stats(const WtParams &P, WtCtx &c) {
+    if (c.sh->bp_sum) wt_glb_add64(&P.counters[WT_CTR_BP], c.sh->bp_sum);
+    if (c.sh->n_intervals) wt_glb_add64(&P.counters[WT_CTR_INTERVALS], c.sh->n_intervals);
 }
 
 // ---------------------------------------------------------------------------

@@ -10,7 +10,10 @@
 //   wt_auc_kernel       sum (finish-start)*value over a run list (AUC)
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
+#include <thread>
+#include <unistd.h>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -23,23 +26,18 @@
 
 #define WT_MAX_BLOCK 512
 // minimum waves per SIMD the register allocator must leave room for (MI355X_MICROARCH:
-// w = k*T/256).  The kernels fit 128 VGPRs on their own (two 512-lane workgroups per CU);
-// asking for 4 changes nothing in the register count but measurably worsens the schedule
-// (2.58 vs 2.39 ms on the bench kernel), so the bound stays at 3.
+// w = k*T/256).  Measured on MI355X: the K=4 kernels sit at 129 VGPRs unconstrained -- one
+// register over the limit for two 512-lane workgroups per CU -- so they are held to 128
+// (w = 4: 2.35 vs 3.14 ms on the bench kernel); the K=1 kernels fit anyway and schedule
+// better unconstrained (var/500 tracks: 71 vs 93 ms).
 #ifndef WT_MIN_WAVES
-#define WT_MIN_WAVES 3
+#define WT_MIN_WAVES(K) ((K) == 4 ? 4 : 3)
 #endif
-
-// ---------------------------------------------------------------------------
-// kernels
-// ---------------------------------------------------------------------------
-template <int OP, class ValT, class ScrT, int K>
-__global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES) wt_reduce_kernel(const WtParams P) {
-    extern __shared__ __attribute__((aligned(16))) char wt_lds[];
-    WtCtx c;
-    wt_ctx_init(c, P, wt_lds);
-    WtLane<K> L;
-    const int tid = threadIdx.x, nt = blockDim.x;
+#ifdef WT_DEBUG_MARK
+#define WT_MARK(x) do { if (tid == 0) { P.debug[0] = (unsigned long long) (x); P.debug[1] = (unsigned long long) k_dbg; __threadfence_system(); } } while (0)
+#else
+#define WT_MARK(x) do { } while (0)
+#endif
 #ifdef WT_PROFILE
 #define WT_TICK(slot) do { if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
         prof[slot] += t_ - t_last; t_last = t_; } } while (0)
@@ -48,34 +46,54 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES) wt_reduce_kernel(c
 #else
 #define WT_TICK(slot) do { } while (0)
 #endif
+    long long k_dbg = -1;
+    (void) k_dbg;
     for (;;) {
+        WT_MARK(1);
         if (tid == 0) c.sh->ticket = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
         __syncthreads();
         const long long k = c.sh->ticket;
+        k_dbg = k;
+        WT_MARK(2);
         if (k >= P.n_windows) break;
         if (tid == 0) wt_phase_header(P, c, k);
         wt_phase_zero(P, c, tid, nt);
         __syncthreads();
         WT_TICK(0);
+        WT_MARK(3);
         wt_phase_load<ValT>(P, c, tid, nt);
         __syncthreads();
         WT_TICK(1);
+        WT_MARK(4);
         wt_phase_count_a(P, c, tid, nt);
         __syncthreads();
+        WT_MARK(5);
         wt_phase_count_b(P, c, tid, nt);
         __syncthreads();
         WT_TICK(2);
-        wt_phase_eval<OP, ValT, ScrT, K>(P, c, L, tid, nt);
+        WT_MARK(6);
+        wt_phase_emask(P, c, OP == WT_OP_TTEST || OP == WT_OP_MWU, tid, nt);
         __syncthreads();
-        WT_TICK(3);
+        WT_MARK(7);
         wt_phase_escan(P, c, tid, nt);
         __syncthreads();
+        WT_TICK(3);
+        // the window's run count is known before the reducers run: publish it now, so that no
+        // successor ever waits for our evaluation
+        WT_MARK(8);
+        if (tid == 0) wt_lookback_publish(P, c, k);
+        WT_MARK(9);
+        wt_phase_eval<OP, ValT, ScrT, K>(P, c, L, tid, nt);
         WT_TICK(4);
-        if (tid < 64) wt_phase_lookback_wave(P, c, k, tid);
+        WT_MARK(10);
+        if (tid < 64) wt_lookback_complete(P, c, k, tid);
         __syncthreads();
         WT_TICK(5);
+        WT_MARK(11);
         wt_phase_write<OP, ValT, K>(P, c, L, tid, nt);
         __syncthreads();
+        WT_MARK(12);
+        if (tid == 0) wt_window_stats(P, c);     // the next window's header runs after the ticket barrier
         WT_TICK(6);
     }
 #ifdef WT_PROFILE
@@ -200,6 +218,7 @@ struct wtamd_trackset {
     double *d_defaults = nullptr;
     unsigned long long *d_counters = nullptr;
     unsigned long long *h_counters = nullptr;   // pinned
+    unsigned long long *h_debug = nullptr;      // pinned, device-visible (debug builds)
     int64_t *d_chrom_run_off = nullptr;         // scratch when the caller passes none
     std::map<int, WtWindows> windows;           // keyed by W
     hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
@@ -260,6 +279,8 @@ static int wt_trackset_common(const wtamd_tracks *t, wtamd_trackset *ts) {
     WT_HIP(hipMemcpy(ts->d_defaults, ts->defaults.data(), sizeof(double) * t->n_tracks, hipMemcpyHostToDevice));
     WT_HIP(hipMalloc(&ts->d_counters, sizeof(unsigned long long) * WT_CTR_N));
     WT_HIP(hipHostMalloc(&ts->h_counters, sizeof(unsigned long long) * WT_CTR_N));
+    WT_HIP(hipHostMalloc(&ts->h_debug, sizeof(unsigned long long) * 8));
+    memset(ts->h_debug, 0, sizeof(unsigned long long) * 8);
     WT_HIP(hipMalloc(&ts->d_chrom_run_off, sizeof(int64_t) * (t->n_chrom + 1)));
     WT_HIP(hipEventCreate(&ts->ev_i0));
     WT_HIP(hipEventCreate(&ts->ev_i1));
@@ -330,6 +351,7 @@ void wtamd_trackset_destroy(wtamd_trackset *ts) {
     if (ts->owns) { (void) hipFree(ts->d_start); (void) hipFree(ts->d_finish); (void) hipFree(ts->d_value); }
     (void) hipFree(ts->d_seg_off); (void) hipFree(ts->d_defaults); (void) hipFree(ts->d_counters); (void) hipFree(ts->d_chrom_run_off);
     if (ts->h_counters) (void) hipHostFree(ts->h_counters);
+    if (ts->h_debug) (void) hipHostFree(ts->h_debug);
     for (auto &kv : ts->windows) wt_free_windows(kv.second);
     if (ts->ev_i0) (void) hipEventDestroy(ts->ev_i0);
     if (ts->ev_i1) (void) hipEventDestroy(ts->ev_i1);
@@ -396,7 +418,7 @@ static void wt_fill_params(const wtamd_trackset *ts, const WtWindows *w, const W
     P.n_chrom = ts->n_chrom; P.n_tracks = ts->n_tracks; P.n_total = ts->n_intervals;
     P.cbase = w->d_cbase; P.c_nwin = w->d_cnwin; P.c_hi = w->d_chi; P.c_first_win = w->d_cfirst;
     P.n_windows = w->tab.n_windows; P.win_chrom = w->d_win_chrom; P.widx = w->d_widx;
-    P.status = w->d_status; P.counters = ts->d_counters;
+    P.status = w->d_status; P.counters = ts->d_counters; P.debug = ts->h_debug;
     wt_plan_to_params(plan, P);
 }
 
@@ -483,7 +505,7 @@ static int wt_check_desc(const wtamd_trackset *ts, const wtamd_reduce_desc *d) {
 
 static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0, wtamd_runs *runs,
                           double *d_tile, uint8_t *d_inplay, int64_t *n_runs, hipStream_t s) {
-    if (!runs || !runs->start || !runs->finish || (op != WT_OP_MULTIPLEX && !runs->value))
+    if (!runs || !runs->start || !runs->finish || !runs->value)
         return wt_fail(WTAMD_ERR_ARG, "wtamd_reduce: output arrays missing");
     WtPlan plan;
     std::string err;
@@ -520,14 +542,35 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
     ts->stats.lds_bytes = plan.lds_bytes;
     if (n_runs) {
         WT_HIP(hipMemcpyAsync(ts->h_counters, ts->d_counters, sizeof(unsigned long long) * WT_CTR_N, hipMemcpyDeviceToHost, s));
-        WT_HIP(hipStreamSynchronize(s));
+        {
+            // bounded wait: a kernel that does not finish is reported, never waited for forever
+            const double limit_s = getenv("WTAMD_TIMEOUT_S") ? atof(getenv("WTAMD_TIMEOUT_S")) : 120.0;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (;;) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return wt_fail(WTAMD_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (el > limit_s) {
+                    char buf[160];
+                    snprintf(buf, sizeof buf, "kernel did not finish within %.0f s (debug marker %llu, window %lld)",
+                             limit_s, ts->h_debug[0], (long long) ts->h_debug[1]);
+                    // a kernel that never finishes cannot be cancelled and every later HIP call of this
+                    // process (even hipFree) would block behind it: report and terminate the process
+                    fprintf(stderr, "wiggletools_amd: FATAL: %s\n", buf);
+                    fflush(stderr);
+                    _exit(70);
+                }
+                if (el > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        }
         ts->stats.n_runs = (int64_t) ts->h_counters[WT_CTR_RUNS];
         ts->stats.covered_bp = (int64_t) ts->h_counters[WT_CTR_BP];
         ts->stats.n_intervals = (int64_t) ts->h_counters[WT_CTR_INTERVALS];
         *n_runs = ts->stats.n_runs;
 #ifdef WT_PROFILE
         {
-            static const char *names[8] = {"zero", "load", "count", "eval", "escan", "lookback", "write", "-"};
+            static const char *names[8] = {"zero", "load", "count", "emask+escan", "eval", "lookback", "write", "-"};
             unsigned long long tot = 0;
             for (int q = 0; q < 8; q++) tot += ts->h_counters[WT_CTR_PROF + q];
             fprintf(stderr, "[wt_profile] op %d:", op);

@@ -202,6 +202,7 @@ struct Drainer {
 struct MuxState {
     Drainer dr;
     std::vector<int32_t> rs, rf;
+    std::vector<double> rcount;     // per-run inplay_count
     std::vector<double> tile;
     std::vector<uint8_t> ip;
     int64_t n = 0, cur = 0;
@@ -217,11 +218,11 @@ void mux_materialise(Multiplexer *m) {
     int64_t cap = wtamd_trackset_max_runs(ts);
     if (cap < 1) cap = 1;
     const int N = m->count;
-    S->rs.resize(cap); S->rf.resize(cap);
+    S->rs.resize(cap); S->rf.resize(cap); S->rcount.resize(cap);
     S->tile.resize((size_t) cap * N); S->ip.resize((size_t) cap * N);
     wtamd_runs r;
     memset(&r, 0, sizeof(r));
-    r.capacity = cap; r.start = S->rs.data(); r.finish = S->rf.data();
+    r.capacity = cap; r.start = S->rs.data(); r.finish = S->rf.data(); r.value = S->rcount.data();
     int64_t n = 0;
     if (wtamd_multiplex_host(ts, m->strict ? WTAMD_STRICT_SET0 : 0, &r, S->tile.data(), S->ip.data(), &n) != WTAMD_OK)
         die("wtamd_multiplex_host");
@@ -244,13 +245,11 @@ void mux_pop(Multiplexer *m) {
             m->chrom = S->dr.chrom;
             m->start = S->rs[r];
             m->finish = S->rf[r];
-            int inplay = 0;
             for (int i = 0; i < N; i++) {
                 m->values[i] = S->tile[(size_t) r * N + i];
                 m->inplay[i] = (wt_bool) S->ip[(size_t) r * N + i];
-                inplay += m->inplay[i] != 0;
             }
-            m->inplay_count = inplay;
+            m->inplay_count = (int) S->rcount[r];
             return;
         }
         S->dr.have = false;     // batch exhausted

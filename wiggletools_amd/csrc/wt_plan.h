@@ -18,7 +18,7 @@ struct WtPlan {
     int T = 0;          // workgroup size (lanes), multiple of 64
     int n_words = 0;
     int spitch = 0, cpitch = 0;
-    int off_S = 0, off_cnt = 0, off_segtot = 0, off_U = 0, off_E = 0, off_epfx = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
+    int off_S = 0, off_cnt = 0, off_segtot = 0, off_U = 0, off_cover = 0, off_E = 0, off_epfx = 0, off_nextw = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
     int lds_bytes = 0;
     int scratch_elem = 0;   // bytes per scratch element (0: op needs no scratch)
     int ppt = 1;            // consecutive window positions per lane (1 or 4)
@@ -39,8 +39,10 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
     p.off_cnt = o;     o = wt_align16(o + n_tracks * p.cpitch * 2);
     p.off_segtot = o;  o = wt_align16(o + n_tracks * 8 * 4);      // WT_COUNT_SEGS == 8
     p.off_U = o;       o = wt_align16(o + p.n_words * 8);
+    p.off_cover = o;   o = wt_align16(o + 4 * p.n_words * 8);
     p.off_E = o;       o = wt_align16(o + p.n_words * 8);
     p.off_epfx = o;    o = wt_align16(o + (p.n_words + 1) * 4);
+    p.off_nextw = o;   o = wt_align16(o + p.n_words * 2);
     p.off_gbase = o;   o = wt_align16(o + n_tracks * 8);
     p.off_scratch = o;
     if (op == WT_OP_MEDIAN) o = wt_align16(o + n_tracks * T * scratch_elem);
@@ -88,8 +90,8 @@ static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.W = p.W; P.n_words = p.n_words; P.spitch = p.spitch; P.cpitch = p.cpitch;
     P.logW = 0;
     while ((1 << P.logW) < p.W) P.logW++;
-    P.off_S = p.off_S; P.off_cnt = p.off_cnt; P.off_segtot = p.off_segtot; P.off_U = p.off_U; P.off_E = p.off_E;
-    P.off_epfx = p.off_epfx; P.off_gbase = p.off_gbase; P.off_scratch = p.off_scratch;
+    P.off_S = p.off_S; P.off_cnt = p.off_cnt; P.off_segtot = p.off_segtot; P.off_U = p.off_U; P.off_cover = p.off_cover; P.off_E = p.off_E;
+    P.off_epfx = p.off_epfx; P.off_nextw = p.off_nextw; P.off_gbase = p.off_gbase; P.off_scratch = p.off_scratch;
     P.off_shared = p.off_shared; P.lds_bytes = p.lds_bytes;
 }
 

@@ -122,10 +122,11 @@ class TrackSet:
         cap = max(self.max_runs(), 1)
         N = self.n_tracks
         s, f = np.empty(cap, np.int32), np.empty(cap, np.int32)
+        cnt = np.empty(cap, np.float64)      # per-run inplay_count (multiplexer.h:27)
         cro = np.zeros(self.n_chrom + 1, np.int64)
         tile = np.empty((cap, N), np.float64)
         ip = np.empty((cap, N), np.uint8)
-        runs = _lib.Runs(cap, s.ctypes.data, f.ctypes.data, None, cro.ctypes.data)
+        runs = _lib.Runs(cap, s.ctypes.data, f.ctypes.data, cnt.ctypes.data, cro.ctypes.data)
         n = C.c_int64()
         _lib.check(_lib.lib().wtamd_multiplex_host(self._h, flags, C.byref(runs), tile.ctypes.data, ip.ctypes.data,
                                                    C.byref(n)))
