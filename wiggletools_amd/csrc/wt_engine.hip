@@ -33,6 +33,17 @@
 #ifndef WT_MIN_WAVES
 #define WT_MIN_WAVES(K) ((K) == 4 ? 4 : 3)
 #endif
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+template <int OP, class ValT, class ScrT, int K>
+__global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kernel(const WtParams P) {
+    extern __shared__ __attribute__((aligned(16))) char wt_lds[];
+    WtCtx c;
+    wt_ctx_init(c, P, wt_lds);
+    WtLane<K> L;
+    const int tid = threadIdx.x, nt = blockDim.x;
 #ifdef WT_DEBUG_MARK
 #define WT_MARK(x) do { if (tid == 0) { P.debug[0] = (unsigned long long) (x); P.debug[1] = (unsigned long long) k_dbg; __threadfence_system(); } } while (0)
 #else
