@@ -23,7 +23,7 @@ struct EmuRun {
     std::vector<char> lds;
     int T_lanes = 0;
 
-    template <int OP, class ValT, class ScrT, int K>
+    template <int OP, class ValT, class ScrT, int K, int NREG>
     void run() {
         WtCtx c;
         wt_ctx_init(c, P, lds.data());
@@ -40,7 +40,7 @@ struct EmuRun {
             constexpr bool two = (OP == WT_OP_TTEST || OP == WT_OP_MWU);
             for (int t = 0; t < T; t++) wt_phase_emask(P, c, two, t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
-            for (int t = 0; t < T; t++) wt_phase_eval<OP, ValT, ScrT, K>(P, c, lanes[t], t, T);
+            for (int t = 0; t < T; t++) wt_phase_eval<OP, ValT, ScrT, K, NREG>(P, c, lanes[t], t, T);
             wt_phase_lookback(P, c, k);
             for (int t = 0; t < T; t++) wt_phase_write<OP, ValT, K>(P, c, lanes[t], t, T);
             wt_window_stats(P, c);
@@ -96,7 +96,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
     }
 
     R.lds.assign((size_t) R.plan.lds_bytes + 64, 0);
-    if (total > 0 && !wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R)) return -11;
+    if (total > 0 && !wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R.plan.nreg, R)) return -11;
     if (info) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows;
                 info[4] = (long long) counters[WT_CTR_BP]; info[5] = (long long) counters[WT_CTR_INTERVALS]; }
     if (counters[WT_CTR_ERROR] & WT_ERR_CAPACITY) return -1;

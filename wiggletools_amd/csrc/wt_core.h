@@ -502,33 +502,55 @@ struct WtFetchK {
     uint32_t cbits;   // coverage word of the track (bit b0+k <=> cov[k])
 };
 
-template <class ValT, class ScrT, int K>
-WT_DEV void wt_fetch_group(const WtParams &P, const WtCtx &c, int i, int w32, int b0, const uint32_t (&mask)[K],
-                           double dflt, WtFetchK<K> &out) {
-    const uint64_t sc = c.SC[(size_t) i * P.spitch + w32];
-    const uint32_t sbits = (uint32_t) sc, cbits = (uint32_t) (sc >> 32);
-    const unsigned cn = (unsigned) c.cnt[(size_t) i * P.cpitch + w32];
-    out.cbits = cbits;
-    const char *vp = (const char *) ((const ValT *) P.value + wt_uniform64(c.gbase[i]));
+// Raw result of the gathers of one track (issued, not yet consumed): keeping several of these
+// alive is what keeps many global loads in flight per lane.
+template <class ValT, int K>
+struct WtRawK {
     ValT v[K];
+    uint32_t cbits;
+    double dflt;
+};
+
+template <class ValT, int K>
+WT_DEV void wt_fetch_issue(const WtParams &P, const WtCtx &c, int i, int w32, const uint32_t (&mask)[K],
+                           double dflt, WtRawK<ValT, K> &raw) {
+    const uint64_t sc = c.SC[(size_t) i * P.spitch + w32];
+    const uint32_t sbits = (uint32_t) sc;
+    const unsigned cn = (unsigned) c.cnt[(size_t) i * P.cpitch + w32];
+    raw.cbits = (uint32_t) (sc >> 32);
+    raw.dflt = dflt;
+    const char *vp = (const char *) ((const ValT *) P.value + wt_uniform64(c.gbase[i]));
 #pragma unroll
     for (int k = 0; k < K; k++) {
         unsigned r = cn + (unsigned) wt_popc32(sbits & mask[k]);
         r = r ? r : 1u;
-        v[k] = *(const ValT *) (vp + (uint32_t) (r * (unsigned) sizeof(ValT)));
+        raw.v[k] = *(const ValT *) (vp + (uint32_t) (r * (unsigned) sizeof(ValT)));
     }
+}
+
+template <class ValT, class ScrT, int K>
+WT_DEV void wt_fetch_finish(const WtRawK<ValT, K> &raw, int b0, WtFetchK<K> &out) {
+    out.cbits = raw.cbits;
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        const bool cov = (cbits >> (b0 + k)) & 1u;
+        const bool cov = (raw.cbits >> (b0 + k)) & 1u;
         out.cov[k] = cov;
         if (sizeof(ValT) == 4 && sizeof(ScrT) == 4) {
             // float tracks whose defaults are float-exact: select in f32, widen once
-            const float xf = cov ? (float) v[k] : (float) dflt;
+            const float xf = cov ? (float) raw.v[k] : (float) raw.dflt;
             out.x[k] = (double) xf;
         } else {
-            out.x[k] = cov ? (double) v[k] : dflt;
+            out.x[k] = cov ? (double) raw.v[k] : raw.dflt;
         }
     }
+}
+
+template <class ValT, class ScrT, int K>
+WT_DEV void wt_fetch_group(const WtParams &P, const WtCtx &c, int i, int w32, int b0, const uint32_t (&mask)[K],
+                           double dflt, WtFetchK<K> &out) {
+    WtRawK<ValT, K> raw;
+    wt_fetch_issue<ValT, K>(P, c, i, w32, mask, dflt, raw);
+    wt_fetch_finish<ValT, ScrT, K>(raw, b0, out);
 }
 
 // order-preserving integer keys for selection
@@ -570,6 +592,36 @@ WT_DEV void wt_for_tracks(const WtParams &P, const WtCtx &c, int lo, int hi, int
     }
 }
 
+// Same contract as wt_for_tracks, but WT_DEEP tracks' gathers are in flight per lane.  Used by
+// median / MWU (one position per lane, no accumulators in registers): their gather phase is pure
+// memory latency, and with only a few waves per CU (the LDS scratch columns limit the workgroup
+// size) depth is what keeps enough loads outstanding.
+#ifndef WT_DEEP
+#define WT_DEEP 8
+#endif
+template <class ValT, class ScrT, int K, class Body>
+WT_DEV void wt_for_tracks_deep(const WtParams &P, const WtCtx &c, int lo, int hi, int w32, int b0,
+                               const uint32_t (&mask)[K], Body body) {
+    const double *dflt = P.defaults;
+    constexpr int D = WT_DEEP;
+    WtRawK<ValT, K> R[D];
+#pragma unroll
+    for (int u = 0; u < D; u++)
+        if (lo + u < hi) wt_fetch_issue<ValT, K>(P, c, lo + u, w32, mask, dflt[lo + u], R[u]);
+    for (int j = lo; j < hi; j += D) {
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            const int t = j + u;
+            if (t < hi) {                       // wave-uniform
+                WtFetchK<K> F;
+                wt_fetch_finish<ValT, ScrT, K>(R[u], b0, F);
+                body(t, F);
+                if (t + D < hi) wt_fetch_issue<ValT, K>(P, c, t + D, w32, mask, dflt[t + D], R[u]);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Per-run reducers.  One lane evaluates K consecutive window positions; for
 // every position the tracks are visited in index order i = 0..N-1 in f64,
@@ -582,7 +634,7 @@ WT_DEV void wt_for_tracks(const WtParams &P, const WtCtx &c, int lo, int hi, int
 // MWU carry an explicit flag because comparisons swallow NaN.
 // Median / MWU use K == 1 and this lane's LDS scratch column.
 // ---------------------------------------------------------------------------
-template <int OP, class ValT, class ScrT, int K>
+template <int OP, class ValT, class ScrT, int K, int NREG>
 WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&res)[K],
                           char *scratch, int lane_col, int colstride) {
     const int N = P.n_tracks;
@@ -701,7 +753,7 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
         typedef typename std::conditional<sizeof(ScrT) == 4, uint32_t, uint64_t>::type KeyT;
         KeyT *col = (KeyT *) scratch + lane_col;
         bool nan = false;
-        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, [&](int i, const WtFetchK<K> &F) {
+        wt_for_tracks_deep<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, [&](int i, const WtFetchK<K> &F) {
             const double x = F.x[0];
             nan |= wt_isnan(x);
             if (sizeof(ScrT) == 4) col[(size_t) i * colstride] = (KeyT) wt_key32((float) x);
@@ -713,6 +765,8 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
         for (int b = (int) sizeof(KeyT) * 8 - 1; b >= 0; b--) {
             const KeyT trial = Kk | ((KeyT) 1 << b);
             int below = 0;
+            // independent LDS reads: unrolled so that several are in flight (few waves per CU here)
+#pragma unroll 10
             for (int i = 0; i < N; i++) below += (col[(size_t) i * colstride] < trial);
             if (below <= kth) Kk = trial;
         }
@@ -721,50 +775,61 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
         return;
     }
     if (OP == WT_OP_MWU) {
-        // setComparisons.c:293-366.  The lane's LDS column holds (value,set)
-        // pairs, insertion-sorted stably by value (set-0 entries are inserted
-        // first, so inside a tie group they precede set-1 entries exactly as
-        // after glibc's stable merge-sort qsort).  Then the reference's scan.
+        // setComparisons.c:293-366 without sorting.  The reference sorts the n1+n2 (value,set)
+        // pairs stably (set-0 entries first inside a tie group) and scans them; every quantity the
+        // scan uses for a set-0 element e is a COUNT:
+        //   index - prev            = L_e  = #set-1 values <  x_e
+        //   set-1 entries tied to e = t_e  = #set-1 values == x_e, all of them after e in the table
+        //   "contiguous set-1 successors" (:338-341) = t_e if e is the last set-0 entry of its tie
+        //                             group, else 0 (the next entry is another set-0 one)
+        // and the scan visits the set-0 elements in (value, index) order, i.e. at rank
+        //   r_e = #set-0 values < x_e + #set-0 values == x_e with a smaller index.
+        // All counts come from two branch-free n1*n2 / n1*n1 loops over this lane's LDS column
+        // (independent reads: no data-dependent trip counts, no divergence); (L,t,last) are
+        // scattered to rank r_e and the reference's tie state machine then runs over n1 entries,
+        // performing the same double additions in the same order.
         const int na = P.n_set0, nb = N - P.n_set0;
-        ScrT *val = (ScrT *) scratch + lane_col;                   // [N][colstride]
-        uint8_t *set = (uint8_t *) ((ScrT *) scratch + (size_t) N * colstride) + lane_col;
+        ScrT *val = (ScrT *) scratch + lane_col;                                   // [N][colstride]
+        uint32_t *attr = (uint32_t *) ((ScrT *) scratch + (size_t) N * colstride) + lane_col;   // [na][colstride]
         bool nan = false;
-        auto insert = [&](int i, const WtFetchK<K> &F) {
-            const double x = F.x[0];
-            nan |= wt_isnan(x);
-            // stable insertion: shift strictly greater elements up
-            int j = i;
-            while (j > 0 && (double) val[(size_t) (j - 1) * colstride] > x) {
-                val[(size_t) j * colstride] = val[(size_t) (j - 1) * colstride];
-                set[(size_t) j * colstride] = set[(size_t) (j - 1) * colstride];
-                j--;
-            }
-            val[(size_t) j * colstride] = (ScrT) x;
-            set[(size_t) j * colstride] = (uint8_t) (i >= na);
-        };
-        wt_for_tracks<ValT, ScrT, K>(P, c, 0, na, w32, b0, mask, true, insert);
-        wt_for_tracks<ValT, ScrT, K>(P, c, na, N, w32, b0, mask, true, insert);
+        wt_for_tracks_deep<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, [&](int i, const WtFetchK<K> &F) {
+            nan |= wt_isnan(F.x[0]);
+            val[(size_t) i * colstride] = (ScrT) F.x[0];
+        });
         if (nan) { res[0] = wt_nan(); return; }
+        for (int e = 0; e < na; e++) {
+            const ScrT x = val[(size_t) e * colstride];
+            int L = 0, t = 0, r = 0, later_equal = 0;
+#pragma unroll 8
+            for (int j = na; j < N; j++) {
+                const ScrT y = val[(size_t) j * colstride];
+                L += (y < x);
+                t += (y == x);
+            }
+#pragma unroll 8
+            for (int j = 0; j < na; j++) {
+                const ScrT y = val[(size_t) j * colstride];
+                r += (y < x) | ((y == x) & (j < e));
+                later_equal += (y == x) & (j > e);
+            }
+            attr[(size_t) r * colstride] = ((uint32_t) L << 17) | ((uint32_t) t << 1) | (later_equal == 0 ? 1u : 0u);
+        }
         const double mu = (double) (na * nb / 2);                               // :386 int division
         const double sigma = sqrt((double) (na * nb * (na + nb + 1) / 12));     // :387 int division
         double U1 = 0;
-        int prev = 0, ties = 0, prevTies = 0;
-        for (int idx = 0; idx < N && prev < na; idx++) {
-            if (!set[(size_t) idx * colstride]) {
-                const ScrT x = val[(size_t) idx * colstride];
-                U1 += idx - prev;
-                if (ties) {
-                    for (int j = idx + 1; j < N && val[(size_t) j * colstride] == x && set[(size_t) j * colstride]; j++)
-                        prevTies++;
-                    U1 -= prevTies / 2.0;
-                    U1 += (ties - prevTies) / 2.0;
-                    if (prevTies == ties) prevTies = ties = 0;
-                } else {
-                    for (int j = idx + 1; j < N && val[(size_t) j * colstride] == x; j++)
-                        if (set[(size_t) j * colstride]) ties++;
-                    if (ties) U1 += ties / 2.0;
-                }
-                prev++;
+        int ties = 0, prevTies = 0;
+        for (int q = 0; q < na; q++) {
+            const uint32_t a = attr[(size_t) q * colstride];
+            const int L = (int) (a >> 17), t = (int) ((a >> 1) & 0xffffu);
+            U1 += L;                                      // :336  U1 += index - prev
+            if (ties) {                                   // :337-346
+                if (a & 1u) prevTies += t;
+                U1 -= prevTies / 2.0;
+                U1 += (ties - prevTies) / 2.0;
+                if (prevTies == ties) prevTies = ties = 0;
+            } else {                                      // :347-354
+                ties += t;
+                if (ties) U1 += ties / 2.0;
             }
         }
         res[0] = (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
@@ -842,13 +907,13 @@ WT_DEV void wt_phase_escan(const WtParams &P, WtCtx &c, int tid, int nt) {
 // Phase 6: evaluate the reducer at every emitted run start.  Lane `tid` owns the
 // K consecutive positions [tid*K, tid*K+K).
 // ---------------------------------------------------------------------------
-template <int OP, class ValT, class ScrT, int K>
+template <int OP, class ValT, class ScrT, int K, int NREG>
 WT_DEV void wt_phase_eval(const WtParams &P, WtCtx &c, WtLane<K> &L, int tid, int nt) {
     const int p0 = tid * K;
     if (p0 >= P.W) return;
     const unsigned emit_bits = (unsigned) ((c.E[p0 >> 6] >> (p0 & 63)) & ((1ull << K) - 1ull));
     if (!emit_bits) return;
-    wt_eval_group<OP, ValT, ScrT, K>(P, c, p0, L.res, c.scratch, tid, nt);
+    wt_eval_group<OP, ValT, ScrT, K, NREG>(P, c, p0, L.res, c.scratch, tid, nt);
 }
 
 // ---------------------------------------------------------------------------

@@ -37,7 +37,7 @@
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-template <int OP, class ValT, class ScrT, int K>
+template <int OP, class ValT, class ScrT, int K, int NREG>
 __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
         WT_MARK(8);
         if (tid == 0) wt_lookback_publish(P, c, k);
         WT_MARK(9);
-        wt_phase_eval<OP, ValT, ScrT, K>(P, c, L, tid, nt);
+        wt_phase_eval<OP, ValT, ScrT, K, NREG>(P, c, L, tid, nt);
         WT_TICK(4);
         WT_MARK(10);
         if (tid < 64) wt_lookback_complete(P, c, k, tid);
@@ -477,9 +477,9 @@ struct WtLaunch {
     int num_cu = 256;
     hipError_t err = hipSuccess;
 
-    template <int OP, class ValT, class ScrT, int K>
+    template <int OP, class ValT, class ScrT, int K, int NREG>
     void run() {
-        auto kern = wt_reduce_kernel<OP, ValT, ScrT, K>;
+        auto kern = wt_reduce_kernel<OP, ValT, ScrT, K, NREG>;
         if (lds > 48 * 1024) {
             err = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;
@@ -543,7 +543,7 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
     if (w->tab.n_windows > 0 && ts->n_intervals > 0) {
         WT_HIP(hipMemsetAsync(w->d_status, 0, sizeof(unsigned long long) * w->tab.n_windows, s));
         WT_HIP(hipEventRecord(ts->ev_r0, s));
-        if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, L)) return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
+        if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, plan.nreg, L)) return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
         if (L.err != hipSuccess) return wt_fail(WTAMD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(L.err));
         WT_HIP(hipEventRecord(ts->ev_r1, s));
         ts->have_reduce_time = true;

@@ -22,6 +22,7 @@ struct WtPlan {
     int lds_bytes = 0;
     int scratch_elem = 0;   // bytes per scratch element (0: op needs no scratch)
     int ppt = 1;            // consecutive window positions per lane (1 or 4)
+    int nreg = 0;           // median: values kept in this many registers per lane (0: LDS scratch column)
 };
 
 static inline int wt_align16(int x) { return (x + 15) & ~15; }
@@ -46,7 +47,7 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
     p.off_gbase = o;   o = wt_align16(o + n_tracks * 8);
     p.off_scratch = o;
     if (op == WT_OP_MEDIAN) o = wt_align16(o + n_tracks * T * scratch_elem);
-    else if (op == WT_OP_MWU) o = wt_align16(o + n_tracks * T * (scratch_elem + 1));
+    else if (op == WT_OP_MWU) o = wt_align16(o + n_tracks * T * (scratch_elem + 4));   // values + per-rank attributes
     p.off_shared = o;  o = wt_align16(o + (int) sizeof(WtShared));
     p.lds_bytes = o;
 }
@@ -60,25 +61,32 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
                                 int soft_limit = 80 * 1024, int hard_limit = 160 * 1024) {
     const char *eP = getenv("WTAMD_PPT");
     const char *eT = getenv("WTAMD_T");
-    const bool scr = wt_op_needs_scratch(op);
+    // median of float tracks with few enough tracks sorts in registers: no LDS scratch column
+    int nreg = 0;
+    // (disabled: a fully unrolled 128-key bitonic network makes hipcc take > 20 min on this
+    //  kernel; the template parameter is kept for a later, partially rolled variant)
+    if (op == WT_OP_MEDIAN && scratch_f32 && n_tracks <= 128 && getenv("WTAMD_MEDIAN_REGS") && false)
+        nreg = n_tracks <= 32 ? 32 : n_tracks <= 64 ? 64 : 128;
+    const bool scr = wt_op_needs_scratch(op) && nreg == 0;
     const int scratch_elem = scr ? (scratch_f32 ? 4 : 8) : 0;
     struct Cand { int ppt, T; };
     std::vector<Cand> cands;
     if (eP || eT) {
-        const int ppt = scr ? 1 : (eP ? atoi(eP) : 4);
+        const int ppt = (scr || nreg) ? 1 : (eP ? atoi(eP) : 4);
         const int T = eT ? atoi(eT) : 256;
         if ((ppt == 1 || ppt == 4) && T >= 64 && T <= 512 && !(T & (T - 1))) cands.push_back({ppt, T});
     }
     if (cands.empty()) {
-        if (scr) cands = {{1, 256}, {1, 128}, {1, 64}};
+        if (scr || nreg) cands = {{1, 256}, {1, 128}, {1, 64}};
         else cands = {{4, 512}, {4, 256}, {1, 512}, {1, 256}, {1, 128}, {1, 64}};
     }
     for (int pass = 0; pass < 2; pass++) {
         const int limit = pass == 0 ? soft_limit : hard_limit;
         for (const Cand &cd : cands) {
             WtPlan p;
-            wt_carve(n_tracks, op, cd.ppt * cd.T, cd.T, scratch_elem, p);
+            wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p);
             p.ppt = cd.ppt;
+            p.nreg = nreg;
             if (p.lds_bytes <= limit) { out = p; return true; }
         }
     }
@@ -156,35 +164,35 @@ static inline void wt_make_windows(int n_chrom, int n_tracks, const int64_t *seg
 //   template <int OP, class ValT, class ScrT> void run();
 // Streaming ops ignore ScrT (ScrT = ValT keeps the instantiation count down).
 template <int OP, int K, class F>
-static inline void wt_dispatch_types2(bool value_f64, bool scratch_f32, F &f) {
+static inline void wt_dispatch_types2(bool value_f64, bool scratch_f32, int nreg, F &f) {
     // ScrT == float <=> float tracks whose defaults are float-exact (f32 select / f32 scratch)
-    if (value_f64) f.template run<OP, double, double, K>();
-    else if (scratch_f32) f.template run<OP, float, float, K>();
-    else f.template run<OP, float, double, K>();
+    if (value_f64) f.template run<OP, double, double, K, 0>();
+    else if (!scratch_f32) f.template run<OP, float, double, K, 0>();
+    else f.template run<OP, float, float, K, 0>();
 }
 
 template <int OP, class F>
-static inline void wt_dispatch_types(bool value_f64, bool scratch_f32, int ppt, F &f) {
-    if (wt_op_needs_scratch(OP) || ppt == 1) wt_dispatch_types2<OP, 1>(value_f64, scratch_f32, f);
-    else wt_dispatch_types2<OP, 4>(value_f64, scratch_f32, f);
+static inline void wt_dispatch_types(bool value_f64, bool scratch_f32, int ppt, int nreg, F &f) {
+    if (wt_op_needs_scratch(OP) || ppt == 1) wt_dispatch_types2<OP, 1>(value_f64, scratch_f32, nreg, f);
+    else wt_dispatch_types2<OP, 4>(value_f64, scratch_f32, nreg, f);
 }
 
 template <class F>
-static inline bool wt_dispatch(int op, bool value_f64, bool scratch_f32, int ppt, F &f) {
+static inline bool wt_dispatch(int op, bool value_f64, bool scratch_f32, int ppt, int nreg, F &f) {
     switch (op) {
-    case WT_OP_SUM: wt_dispatch_types<WT_OP_SUM>(value_f64, scratch_f32, ppt, f); return true;
-    case WT_OP_PRODUCT: wt_dispatch_types<WT_OP_PRODUCT>(value_f64, scratch_f32, ppt, f); return true;
-    case WT_OP_MEAN: wt_dispatch_types<WT_OP_MEAN>(value_f64, scratch_f32, ppt, f); return true;
-    case WT_OP_VAR: wt_dispatch_types<WT_OP_VAR>(value_f64, scratch_f32, ppt, f); return true;
+    case WT_OP_SUM: wt_dispatch_types<WT_OP_SUM>(value_f64, scratch_f32, ppt, nreg, f); return true;
+    case WT_OP_PRODUCT: wt_dispatch_types<WT_OP_PRODUCT>(value_f64, scratch_f32, ppt, nreg, f); return true;
+    case WT_OP_MEAN: wt_dispatch_types<WT_OP_MEAN>(value_f64, scratch_f32, ppt, nreg, f); return true;
+    case WT_OP_VAR: wt_dispatch_types<WT_OP_VAR>(value_f64, scratch_f32, ppt, nreg, f); return true;
     case WT_OP_STDDEV: case WT_OP_ENTROPY:   // reference reducers.c:665: entropy runs the stddev pop
-        wt_dispatch_types<WT_OP_STDDEV>(value_f64, scratch_f32, ppt, f); return true;
-    case WT_OP_CV: wt_dispatch_types<WT_OP_CV>(value_f64, scratch_f32, ppt, f); return true;
-    case WT_OP_MIN: wt_dispatch_types<WT_OP_MIN>(value_f64, scratch_f32, ppt, f); return true;
-    case WT_OP_MAX: wt_dispatch_types<WT_OP_MAX>(value_f64, scratch_f32, ppt, f); return true;
-    case WT_OP_MEDIAN: wt_dispatch_types<WT_OP_MEDIAN>(value_f64, scratch_f32, ppt, f); return true;
-    case WT_OP_TTEST: wt_dispatch_types<WT_OP_TTEST>(value_f64, scratch_f32, ppt, f); return true;
-    case WT_OP_MWU: wt_dispatch_types<WT_OP_MWU>(value_f64, scratch_f32, ppt, f); return true;
-    case WT_OP_MULTIPLEX: wt_dispatch_types<WT_OP_MULTIPLEX>(value_f64, scratch_f32, ppt, f); return true;
+        wt_dispatch_types<WT_OP_STDDEV>(value_f64, scratch_f32, ppt, nreg, f); return true;
+    case WT_OP_CV: wt_dispatch_types<WT_OP_CV>(value_f64, scratch_f32, ppt, nreg, f); return true;
+    case WT_OP_MIN: wt_dispatch_types<WT_OP_MIN>(value_f64, scratch_f32, ppt, nreg, f); return true;
+    case WT_OP_MAX: wt_dispatch_types<WT_OP_MAX>(value_f64, scratch_f32, ppt, nreg, f); return true;
+    case WT_OP_MEDIAN: wt_dispatch_types<WT_OP_MEDIAN>(value_f64, scratch_f32, ppt, nreg, f); return true;
+    case WT_OP_TTEST: wt_dispatch_types<WT_OP_TTEST>(value_f64, scratch_f32, ppt, nreg, f); return true;
+    case WT_OP_MWU: wt_dispatch_types<WT_OP_MWU>(value_f64, scratch_f32, ppt, nreg, f); return true;
+    case WT_OP_MULTIPLEX: wt_dispatch_types<WT_OP_MULTIPLEX>(value_f64, scratch_f32, ppt, nreg, f); return true;
     default: return false;
     }
 }
