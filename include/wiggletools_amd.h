@@ -270,7 +270,28 @@ int wtamd_multiplex_host(wtamd_trackset *ts, uint32_t flags, wtamd_runs *runs,
  * (reference statistics.c:103-120).  Result written to *auc (host). */
 int wtamd_runs_auc(const wtamd_runs *runs, int64_t n_runs, double *auc, void *stream);
 
+/* Run compression on device (reference CompressionWiggleIterator, unaryOps.c:235-253, which the
+ * default writer applies, wigWriter.c:263-267): adjacent runs of one chromosome merge while
+ * start == previous finish and (both NaN or |value - value of the group's first run| < 1e-6).
+ * `in` / `out` are DEVICE run lists (in->chrom_run_off required); *n_out is written on the host. */
+int wtamd_runs_compress(const wtamd_runs *in, int64_t n_runs, int32_t n_chrom, wtamd_runs *out,
+                        int64_t *n_out, void *stream);
+
 int wtamd_get_stats(const wtamd_trackset *ts, wtamd_stats *out);
+
+/* ---- BigWig section decoder (bulk side door; replaces what the reference gets from libBigWig
+ * through src/bigWiggleReader.c:52-83).  HOST only. ---- */
+typedef struct wtamd_bw wtamd_bw;
+int wtamd_bw_open(const char *path, wtamd_bw **out);    /* prints the reference's message on a non-BigWig file */
+void wtamd_bw_close(wtamd_bw *);
+int wtamd_bw_n_chrom(const wtamd_bw *);
+const char *wtamd_bw_chrom_name(const wtamd_bw *, int i);
+uint32_t wtamd_bw_chrom_length(const wtamd_bw *, int i);
+/* All runs of one chromosome, 1-based start / exclusive finish, sorted.  box != 0 cuts runs at the
+ * reference reader's 10 000-bp stretch edges (bigWiggleReader.c:42-44,73-83).  Returns the number
+ * of runs; when that exceeds `capacity` nothing was written (call again with more room). */
+int64_t wtamd_bw_read_chrom(wtamd_bw *, const char *chrom, int box, int64_t capacity,
+                            int32_t *start, int32_t *finish, float *value);
 
 /* Default value a reducer iterator advertises to its parent
  * (reference reducers.c ctor of each op, incl. float truncations). HOST only. */

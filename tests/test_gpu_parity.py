@@ -169,3 +169,64 @@ def test_gpu_precondition_messages(engine):
     with pytest.raises(_lib.WtamdError, match="Mann-Whitney U function only works"):
         ts.reduce_host("mwu", n_set0=0)
     ts.close()
+
+
+def _device_runs(engine, c, s, f, v, n_chrom):
+    import torch
+    dev = torch.device("cuda", 0)
+    cro = np.zeros(n_chrom + 1, np.int64)
+    np.cumsum(np.bincount(c, minlength=n_chrom), out=cro[1:])
+    r = engine.DeviceRuns(torch.from_numpy(np.ascontiguousarray(s, np.int32)).to(dev),
+                          torch.from_numpy(np.ascontiguousarray(f, np.int32)).to(dev),
+                          torch.from_numpy(np.ascontiguousarray(v, np.float64)).to(dev),
+                          torch.from_numpy(cro).to(dev))
+    r.n = len(s)
+    return r
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_gpu_run_compression_matches_reference_rule(oracle, engine, seed):
+    """Device CompressionWiggleIterator (unaryOps.c:235-253) on reducer outputs and on adversarial
+    slowly drifting values (|dv| < 1e-6 per run but > 1e-6 from the group leader)."""
+    rng = np.random.default_rng(seed)
+    t = random_case(5000 + seed, max_len=3000)
+    c, s, f, v = oracle.reduce(t.as_dict(), ["mean", "max", "stddev", "min"][seed % 4])
+    if seed % 2 and len(v):
+        # drift: consecutive differences of 0.4e-6 .. 0.9e-6, plus exact repeats and NaN runs
+        drift = np.cumsum(rng.choice([0.0, 4e-7, 7e-7, 9e-7, -6e-7], len(v)))
+        v = np.where(rng.random(len(v)) < 0.05, np.nan, np.round(v) + drift)
+    exp = oracle.compress(c, s, f, v)
+    r = _device_runs(engine, c, s, f, v, t.n_chrom)
+    out = r.compress()
+    got = out.to_host()
+    assert_runs_equal(got, exp, 0.0, "compress seed %d" % seed)
+
+
+def test_gpu_compress_long_constant_stretch(oracle, engine):
+    n = 300000
+    s = np.arange(1, n + 1, dtype=np.int32)
+    f = s + 1
+    v = np.zeros(n)
+    v[100000:100010] = 1.0
+    v[200000] = np.nan
+    c = np.zeros(n, np.int32)
+    exp = oracle.compress(c, s, f, v)
+    got = _device_runs(engine, c, s, f, v, 1).compress().to_host()
+    assert_runs_equal(got, exp, 0.0, "long stretch")
+    assert len(got[0]) == 5
+
+
+def test_gpu_bigwig_config_c1(oracle, engine):
+    """BASELINE config C1: `mean test/fixedStep.bw test/variableStep.bw` -- the two reference
+    fixtures decoded by the library's BigWig section decoder, reduced on the GPU; expected
+    values are the ones of SURVEY 8c (the reference prints them as fixedStep chr1 start=1)."""
+    import os
+    from wiggletools_amd import bigwig
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    t = bigwig.load_runlists([os.path.join(G, "fixedStep.bw"), os.path.join(G, "variableStep.bw")])
+    ts = engine.TrackSet.from_runlists(t)
+    c, s, f, v = ts.reduce_host("mean")
+    assert [t.chrom_names[x] for x in c] == ["chr1"] * 10
+    assert s.tolist() == list(range(1, 11)) and f.tolist() == list(range(2, 12))
+    assert v.tolist() == [0.5, 1.5, 1, 3, 2, 4.5, 3, 6, 4, 4.5]
+    ts.close()

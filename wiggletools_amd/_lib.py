@@ -61,7 +61,18 @@ def lib():
     L.wtamd_multiplex_host.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Runs), C.c_void_p, C.c_void_p,
                                        C.POINTER(C.c_int64)]
     L.wtamd_runs_auc.argtypes = [C.POINTER(Runs), C.c_int64, C.POINTER(C.c_double), C.c_void_p]
+    L.wtamd_runs_compress.argtypes = [C.POINTER(Runs), C.c_int64, C.c_int32, C.POINTER(Runs), C.POINTER(C.c_int64), C.c_void_p]
     L.wtamd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.wtamd_bw_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.wtamd_bw_close.argtypes = [C.c_void_p]
+    L.wtamd_bw_close.restype = None
+    L.wtamd_bw_n_chrom.argtypes = [C.c_void_p]
+    L.wtamd_bw_chrom_name.argtypes = [C.c_void_p, C.c_int]
+    L.wtamd_bw_chrom_name.restype = C.c_char_p
+    L.wtamd_bw_chrom_length.argtypes = [C.c_void_p, C.c_int]
+    L.wtamd_bw_chrom_length.restype = C.c_uint32
+    L.wtamd_bw_read_chrom.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.wtamd_bw_read_chrom.restype = C.c_int64
     L.wtamd_reducer_default.argtypes = [C.c_int, C.c_int, C.c_void_p]
     L.wtamd_reducer_default.restype = C.c_double
     _lib = L

@@ -5,7 +5,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libwiggletools_amd.so")
-SRCS = ["wt_engine.hip", "wt_defaults.cpp", "wt_iter_abi.cpp"]
+SRCS = ["wt_engine.hip", "wt_compress.hip", "wt_defaults.cpp", "wt_iter_abi.cpp", "wt_bigwig.cpp"]
+LIBS = ["-lz"]
 DEPS = ["wt_core.h", "wt_plan.h", os.path.join("..", "..", "include", "wiggletools_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
@@ -17,7 +18,7 @@ def build_variant(name, extra_flags):
     srcs = [os.path.join(HERE, s) for s in SRCS if os.path.exists(os.path.join(HERE, s))]
     out = os.path.join(HERE, "libwiggletools_amd_%s.so" % name)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    subprocess.check_call([hipcc] + FLAGS + list(extra_flags) + srcs + ["-o", out])
+    subprocess.check_call([hipcc] + FLAGS + list(extra_flags) + srcs + LIBS + ["-o", out])
     return out
 
 
@@ -27,7 +28,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + srcs + ["-o", SO]
+    cmd = [hipcc] + FLAGS + srcs + LIBS + ["-o", SO]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,0 +1,244 @@
+// wt_bigwig.cpp -- BigWig section decoder: file -> run lists (start, finish, float value),
+// the bulk side door in front of the engine.  Host C++ + zlib.
+//
+// The reference reads BigWig through libBigWig (bwOverlappingIntervalsIterator, reference
+// src/bigWiggleReader.c:52-83), which is not available here; this is an independent decoder of
+// the published BigWig layout (Kent et al. 2010: 64-byte header, chromosome B+ tree, R-tree
+// index over zlib-compressed sections of type 1 bedGraph / 2 variableStep / 3 fixedStep,
+// float32 payload).  What it reproduces from the reference reader, because it changes what the
+// Multiplexer sees:
+//   * 0-based half-open -> 1-based start, exclusive finish        bigWiggleReader.c:39-40
+//   * chromosomes in strcmp order (done by the caller)            bigWiggleReader.c:91-101
+//   * intervals boxed into 10 000-bp stretches [1+10000k, 1+10000(k+1))  :42-44, :73-83
+//     (optional; a run crossing a stretch edge is cut there, as the reference does)
+//   * the stretch loop `for (start = 1; start < length; ...)` (:76) never visits a stretch that
+//     would start at position `length`, so the last base of a chromosome whose length is
+//     1 (mod 10000) is dropped -- reproduced when boxing is on.
+// Pinned by the reference's own fixtures test/fixedStep.bw == fixedStep.wig and
+// variableStep.bw == variableStep.wig (reference test/test.py:28,52).
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wiggletools_amd.h"
+
+namespace {
+
+struct BwBlock {
+    uint32_t start_chrom, start_base, end_chrom, end_base;
+    uint64_t offset, size;
+};
+
+struct BwChrom {
+    std::string name;
+    uint32_t id, length;
+};
+
+}  // namespace
+
+struct wtamd_bw {
+    FILE *fp = nullptr;
+    uint32_t uncompress_buf = 0;
+    std::vector<BwChrom> chroms;
+    std::vector<BwBlock> blocks;
+    std::string error;
+};
+
+namespace {
+
+bool rd(FILE *fp, uint64_t off, void *dst, size_t n) {
+    if (fseeko(fp, (off_t) off, SEEK_SET) != 0) return false;
+    return fread(dst, 1, n, fp) == n;
+}
+
+template <class T>
+T get(const unsigned char *p) {
+    T v;
+    memcpy(&v, p, sizeof(T));
+    return v;
+}
+
+bool walk_chrom_tree(wtamd_bw *bw, uint64_t node_off, uint32_t key_size, uint32_t val_size) {
+    unsigned char hdr[4];
+    if (!rd(bw->fp, node_off, hdr, 4)) return false;
+    const bool leaf = hdr[0] != 0;
+    const uint16_t count = get<uint16_t>(hdr + 2);
+    const size_t item = key_size + (leaf ? val_size : 8);
+    std::vector<unsigned char> buf(item * count);
+    if (count && !rd(bw->fp, node_off + 4, buf.data(), buf.size())) return false;
+    for (uint16_t k = 0; k < count; k++) {
+        const unsigned char *p = buf.data() + item * k;
+        if (leaf) {
+            BwChrom c;
+            c.name.assign((const char *) p, strnlen((const char *) p, key_size));
+            c.id = get<uint32_t>(p + key_size);
+            c.length = get<uint32_t>(p + key_size + 4);
+            bw->chroms.push_back(c);
+        } else if (!walk_chrom_tree(bw, get<uint64_t>(p + key_size), key_size, val_size)) {
+            return false;
+        }
+    }
+    return true;
+}
+
+bool walk_rtree(wtamd_bw *bw, uint64_t node_off) {
+    unsigned char hdr[4];
+    if (!rd(bw->fp, node_off, hdr, 4)) return false;
+    const bool leaf = hdr[0] != 0;
+    const uint16_t count = get<uint16_t>(hdr + 2);
+    const size_t item = leaf ? 32 : 24;
+    std::vector<unsigned char> buf(item * count);
+    if (count && !rd(bw->fp, node_off + 4, buf.data(), buf.size())) return false;
+    for (uint16_t k = 0; k < count; k++) {
+        const unsigned char *p = buf.data() + item * k;
+        if (leaf) {
+            BwBlock b = { get<uint32_t>(p), get<uint32_t>(p + 4), get<uint32_t>(p + 8), get<uint32_t>(p + 12),
+                          get<uint64_t>(p + 16), get<uint64_t>(p + 24) };
+            bw->blocks.push_back(b);
+        } else if (!walk_rtree(bw, get<uint64_t>(p + 16))) {
+            return false;
+        }
+    }
+    return true;
+}
+
+struct Triple {
+    uint32_t start, end;   // 0-based half-open
+    float value;
+};
+
+bool decode_block(wtamd_bw *bw, const BwBlock &b, uint32_t chrom_id, std::vector<Triple> &out) {
+    std::vector<unsigned char> raw(b.size);
+    if (!rd(bw->fp, b.offset, raw.data(), raw.size())) { bw->error = "short read of a data block"; return false; }
+    std::vector<unsigned char> plain;
+    const unsigned char *d = raw.data();
+    size_t dn = raw.size();
+    if (bw->uncompress_buf) {
+        plain.resize(bw->uncompress_buf);
+        uLongf n = plain.size();
+        if (uncompress(plain.data(), &n, raw.data(), raw.size()) != Z_OK) { bw->error = "zlib: bad data block"; return false; }
+        d = plain.data();
+        dn = n;
+    }
+    if (dn < 24) { bw->error = "data block too short"; return false; }
+    const uint32_t cid = get<uint32_t>(d), cstart = get<uint32_t>(d + 4);
+    const uint32_t step = get<uint32_t>(d + 12), span = get<uint32_t>(d + 16);
+    const uint8_t type = d[20];
+    const uint16_t n_items = get<uint16_t>(d + 22);
+    if (cid != chrom_id) return true;       // block of another chromosome sharing the index leaf
+    const unsigned char *p = d + 24;
+    const size_t item = type == 1 ? 12 : type == 2 ? 8 : 4;
+    if (24 + item * n_items > dn) { bw->error = "data block item count exceeds its size"; return false; }
+    for (uint16_t k = 0; k < n_items; k++, p += item) {
+        Triple t;
+        if (type == 1) { t.start = get<uint32_t>(p); t.end = get<uint32_t>(p + 4); t.value = get<float>(p + 8); }
+        else if (type == 2) { t.start = get<uint32_t>(p); t.end = t.start + span; t.value = get<float>(p + 4); }
+        else if (type == 3) { t.start = cstart + k * step; t.end = t.start + span; t.value = get<float>(p); }
+        else { bw->error = "unknown BigWig section type"; return false; }
+        out.push_back(t);
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wtamd_bw_open(const char *path, wtamd_bw **out) {
+    if (!path || !out) return WTAMD_ERR_ARG;
+    wtamd_bw *bw = new wtamd_bw();
+    bw->fp = fopen(path, "rb");
+    unsigned char h[64];
+    if (!bw->fp || !rd(bw->fp, 0, h, 64) || get<uint32_t>(h) != 0x888FFC26u) {
+        // message of the reference (bigWiggleReader.c:116-118) for a non-BigWig file
+        fprintf(stderr, "File %s is not in BigWig format\n", path);
+        if (bw->fp) fclose(bw->fp);
+        delete bw;
+        return WTAMD_ERR_ARG;
+    }
+    const uint64_t chrom_tree = get<uint64_t>(h + 8), full_index = get<uint64_t>(h + 24);
+    bw->uncompress_buf = get<uint32_t>(h + 52);
+    unsigned char t[32];
+    bool ok = rd(bw->fp, chrom_tree, t, 32) && get<uint32_t>(t) == 0x78CA8C91u;
+    if (ok) ok = walk_chrom_tree(bw, chrom_tree + 32, get<uint32_t>(t + 8), get<uint32_t>(t + 12));
+    unsigned char r[48];
+    if (ok) ok = rd(bw->fp, full_index, r, 48) && get<uint32_t>(r) == 0x2468ACE0u;
+    if (ok) ok = walk_rtree(bw, full_index + 48);
+    if (!ok) {
+        fprintf(stderr, "File %s: corrupt BigWig index\n", path);
+        fclose(bw->fp);
+        delete bw;
+        return WTAMD_ERR_ARG;
+    }
+    *out = bw;
+    return WTAMD_OK;
+}
+
+void wtamd_bw_close(wtamd_bw *bw) {
+    if (!bw) return;
+    if (bw->fp) fclose(bw->fp);
+    delete bw;
+}
+
+int wtamd_bw_n_chrom(const wtamd_bw *bw) { return bw ? (int) bw->chroms.size() : 0; }
+
+const char *wtamd_bw_chrom_name(const wtamd_bw *bw, int i) {
+    return (bw && i >= 0 && i < (int) bw->chroms.size()) ? bw->chroms[i].name.c_str() : nullptr;
+}
+
+uint32_t wtamd_bw_chrom_length(const wtamd_bw *bw, int i) {
+    return (bw && i >= 0 && i < (int) bw->chroms.size()) ? bw->chroms[i].length : 0;
+}
+
+// Decodes every interval of chromosome `chrom` into start[]/finish[]/value[] (1-based start,
+// exclusive finish, sorted).  box != 0: cut at the reference reader's 10 000-bp stretch edges.
+// Returns the number of runs; if it exceeds `capacity` nothing is written and the caller
+// retries with a bigger buffer; < 0 on error.
+int64_t wtamd_bw_read_chrom(wtamd_bw *bw, const char *chrom, int box, int64_t capacity,
+                            int32_t *start, int32_t *finish, float *value) {
+    if (!bw || !chrom) return -1;
+    const BwChrom *c = nullptr;
+    for (const BwChrom &x : bw->chroms)
+        if (x.name == chrom) c = &x;
+    if (!c) return 0;
+    std::vector<Triple> t;
+    for (const BwBlock &b : bw->blocks)
+        if (b.start_chrom <= c->id && c->id <= b.end_chrom)
+            if (!decode_block(bw, b, c->id, t)) { fprintf(stderr, "wiggletools_amd: %s\n", bw->error.c_str()); return -2; }
+    if (!std::is_sorted(t.begin(), t.end(), [](const Triple &a, const Triple &b) { return a.start < b.start; }))
+        std::stable_sort(t.begin(), t.end(), [](const Triple &a, const Triple &b) { return a.start < b.start; });
+    // first pass counts, second pass writes (boxing can split runs)
+    const int64_t stretch = 10000;
+    const int64_t length = c->length;
+    for (int pass = 0; pass < 2; pass++) {
+        int64_t n = 0;
+        for (const Triple &x : t) {
+            int64_t s = (int64_t) x.start + 1, f = (int64_t) x.end + 1;      // bigWiggleReader.c:39-40
+            if (!box) {
+                if (pass) { start[n] = (int32_t) s; finish[n] = (int32_t) f; value[n] = x.value; }
+                n++;
+                continue;
+            }
+            // stretches [1+10000k, 1+10000(k+1)) for 1+10000k < length  (bigWiggleReader.c:73-83)
+            for (int64_t k = (s - 1) / stretch; ; k++) {
+                const int64_t a = 1 + k * stretch, b = a + stretch;
+                if (a >= length || a >= f) break;
+                const int64_t bs = std::max(s, a), bf = std::min(f, b);          // :42-44
+                if (bs < bf) {
+                    if (pass) { start[n] = (int32_t) bs; finish[n] = (int32_t) bf; value[n] = x.value; }
+                    n++;
+                }
+            }
+        }
+        if (pass == 0 && n > capacity) return n;
+        if (pass == 1) return n;
+    }
+    return 0;
+}
+
+}  // extern "C"

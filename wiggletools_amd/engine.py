@@ -172,6 +172,22 @@ class DeviceRuns:
         _lib.check(_lib.lib().wtamd_runs_auc(C.byref(r), int(self.n if n is None else n), C.byref(out), stream))
         return out.value
 
+    def compress(self, out=None, n=None, stream=None):
+        """Merged run list (reference CompressionWiggleIterator) as a new DeviceRuns."""
+        import torch
+        n = int(self.n if n is None else n)
+        if out is None:
+            cap = max(n, 1)
+            dev = self.start.device
+            out = DeviceRuns(torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev),
+                             torch.empty(cap, dtype=torch.float64, device=dev), torch.zeros_like(self.chrom_run_off))
+        a, b = self.as_struct(), out.as_struct()
+        m = C.c_int64()
+        _lib.check(_lib.lib().wtamd_runs_compress(C.byref(a), n, self.chrom_run_off.numel() - 1, C.byref(b), C.byref(m),
+                                                  stream))
+        out.n = m.value
+        return out
+
     def to_host(self):
         n = self.n
         cro = self.chrom_run_off.cpu().numpy()
