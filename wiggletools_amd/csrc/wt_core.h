@@ -99,6 +99,7 @@ struct WtParams {
     double *o_tile;               // WT_OP_MULTIPLEX only: [capacity * n_tracks]
     uint8_t *o_inplay;            // WT_OP_MULTIPLEX only
     // ---- LDS carve (bytes from the dynamic LDS base; all multiples of 16) ----
+    int32_t count_segs;           // lanes per track in the count phase (1, 2, 4 or 8; >= 4 words each)
     int32_t spitch;               // u64 {S,C} pairs per track row (W/32 + 1: bank spread)
     int32_t cpitch;               // u16 entries per cnt_i row (W/32, even)
     int32_t off_S, off_cnt, off_segtot, off_U, off_cover, off_E, off_epfx, off_nextw, off_gbase, off_scratch, off_shared;
@@ -127,7 +128,7 @@ struct WtLane {
 struct WtCtx {
     uint64_t *SC;       // [n_tracks * spitch] low half: start bits S, high half: toggles -> coverage C
     uint16_t *cnt;      // [n_tracks * cpitch] start-bit rank prefix per 32-bit word
-    uint32_t *segtot;   // [n_tracks * WT_COUNT_SEGS] count-phase segment totals
+    uint32_t *segtot;   // [n_tracks * count_segs] count-phase segment totals
     uint64_t *U;        // [n_words] true breakpoints
     uint32_t *cover;    // [4][2*n_words] coverage summaries over tracks: any(set0), all(set0), any(set1), all(set1)
     uint64_t *E;        // [n_words] emitted run starts
@@ -405,17 +406,16 @@ WT_DEV void wt_phase_load(const WtParams &P, WtCtx &c, int tid, int nt) {
 //   C_i[w]    = coverage bits = running XOR of the toggles (prefix-xor inside
 //               the word by shifts, carry = last bit of the previous word)
 // ---------------------------------------------------------------------------
-// Two sub-phases (a barrier in between) so that WT_COUNT_SEGS lanes share a track:
+// Two sub-phases (a barrier in between) so that count_segs lanes share a track:
 //   3a  every lane totals its own segment of words (start bits, toggle parity)
 //   3b  every lane prefixes the totals of the segments before it, then rewrites
 //       its own words in place (toggles -> coverage) and fills cnt.
-#define WT_COUNT_SEGS 8
 WT_DEV void wt_phase_count_a(const WtParams &P, WtCtx &c, int tid, int nt) {
     const int nw32 = P.n_words * 2;
-    const int seg_words = (nw32 + WT_COUNT_SEGS - 1) / WT_COUNT_SEGS;
-    const int items = P.n_tracks * WT_COUNT_SEGS;
+    const int seg_words = (nw32 + P.count_segs - 1) / P.count_segs;
+    const int items = P.n_tracks * P.count_segs;
     for (int it = tid; it < items; it += nt) {
-        const int i = it / WT_COUNT_SEGS, q = it % WT_COUNT_SEGS;
+        const int i = it / P.count_segs, q = it % P.count_segs;
         const uint64_t *SCi = c.SC + (size_t) i * P.spitch;
         const int w_lo = q * seg_words;
         int w_hi = w_lo + seg_words;
@@ -432,10 +432,10 @@ WT_DEV void wt_phase_count_a(const WtParams &P, WtCtx &c, int tid, int nt) {
 
 WT_DEV void wt_phase_count_b(const WtParams &P, WtCtx &c, int tid, int nt) {
     const int nw32 = P.n_words * 2;
-    const int seg_words = (nw32 + WT_COUNT_SEGS - 1) / WT_COUNT_SEGS;
-    const int items = P.n_tracks * WT_COUNT_SEGS;
+    const int seg_words = (nw32 + P.count_segs - 1) / P.count_segs;
+    const int items = P.n_tracks * P.count_segs;
     for (int it = tid; it < items; it += nt) {
-        const int i = it / WT_COUNT_SEGS, q = it % WT_COUNT_SEGS;
+        const int i = it / P.count_segs, q = it % P.count_segs;
         uint64_t *SCi = c.SC + (size_t) i * P.spitch;
         uint16_t *ci = c.cnt + (size_t) i * P.cpitch;
         const int w_lo = q * seg_words;
@@ -443,7 +443,7 @@ WT_DEV void wt_phase_count_b(const WtParams &P, WtCtx &c, int tid, int nt) {
         if (w_hi > nw32) w_hi = nw32;
         unsigned run = 0, par = 0;
         for (int x = 0; x < q; x++) {
-            const uint32_t st = c.segtot[i * WT_COUNT_SEGS + x];
+            const uint32_t st = c.segtot[i * P.count_segs + x];
             run += st & 0xffffu;
             par ^= st >> 31;
         }

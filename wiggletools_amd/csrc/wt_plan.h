@@ -17,7 +17,7 @@ struct WtPlan {
     int W = 0;          // window width (bp), multiple of 64
     int T = 0;          // workgroup size (lanes), multiple of 64
     int n_words = 0;
-    int spitch = 0, cpitch = 0;
+    int spitch = 0, cpitch = 0, count_segs = 8;
     int off_S = 0, off_cnt = 0, off_segtot = 0, off_U = 0, off_cover = 0, off_E = 0, off_epfx = 0, off_nextw = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
     int lds_bytes = 0;
     int scratch_elem = 0;   // bytes per scratch element (0: op needs no scratch)
@@ -38,7 +38,9 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
     int o = 0;
     p.off_S = o;       o = wt_align16(o + n_tracks * p.spitch * 8);
     p.off_cnt = o;     o = wt_align16(o + n_tracks * p.cpitch * 2);
-    p.off_segtot = o;  o = wt_align16(o + n_tracks * 8 * 4);      // WT_COUNT_SEGS == 8
+    p.count_segs = 8;                         // lanes per track in the count phase, >= 4 words each
+    while (p.count_segs > 1 && (W / 32) / p.count_segs < 4) p.count_segs >>= 1;
+    p.off_segtot = o;  o = wt_align16(o + n_tracks * p.count_segs * 4);
     p.off_U = o;       o = wt_align16(o + p.n_words * 8);
     p.off_cover = o;   o = wt_align16(o + 4 * p.n_words * 8);
     p.off_E = o;       o = wt_align16(o + p.n_words * 8);
@@ -52,11 +54,9 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
     p.lds_bytes = o;
 }
 
-// Chooses (positions per lane, T, W = ppt*T).  Preference: wide windows with 4
-// positions per lane (instruction-level parallelism, shared bitmap reads) while
-// two workgroups still fit one CU; many tracks fall back to 1 position per lane so
-// that the CU keeps enough waves.  Environment overrides (experiments only):
-// WTAMD_PPT, WTAMD_T.
+// Chooses (positions per lane, T, W = ppt*T): the widest window whose bitmaps (and scratch
+// columns) fit one workgroup's LDS, 4 positions per lane when possible (instruction-level
+// parallelism, shared bitmap reads).  Environment overrides (experiments only): WTAMD_PPT, WTAMD_T.
 static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &out, std::string &err,
                                 int soft_limit = 80 * 1024, int hard_limit = 160 * 1024) {
     const char *eP = getenv("WTAMD_PPT");
@@ -80,22 +80,23 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
         if (scr || nreg) cands = {{1, 256}, {1, 128}, {1, 64}};
         else cands = {{4, 512}, {4, 256}, {1, 512}, {1, 256}, {1, 128}, {1, 64}};
     }
-    for (int pass = 0; pass < 2; pass++) {
-        const int limit = pass == 0 ? soft_limit : hard_limit;
-        for (const Cand &cd : cands) {
-            WtPlan p;
-            wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p);
-            p.ppt = cd.ppt;
-            p.nreg = nreg;
-            if (p.lds_bytes <= limit) { out = p; return true; }
-        }
+    // Measured on MI355X (round 1): the widest window that fits ONE workgroup's LDS wins, even
+    // when that leaves a single workgroup per CU (mean/200 tracks: 7.4 vs 8.5 ms, var/500: 47 vs
+    // 71 ms, median/100: 51 vs 59 ms) -- per-window fixed costs outweigh inter-workgroup overlap.
+    (void) soft_limit;
+    for (const Cand &cd : cands) {
+        WtPlan p;
+        wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p);
+        p.ppt = cd.ppt;
+        p.nreg = nreg;
+        if (p.lds_bytes <= hard_limit - 1024) { out = p; return true; }
     }
     err = "no LDS plan fits " + std::to_string(n_tracks) + " tracks (op " + std::to_string(op) + ")";
     return false;
 }
 
 static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
-    P.W = p.W; P.n_words = p.n_words; P.spitch = p.spitch; P.cpitch = p.cpitch;
+    P.W = p.W; P.n_words = p.n_words; P.spitch = p.spitch; P.cpitch = p.cpitch; P.count_segs = p.count_segs;
     P.logW = 0;
     while ((1 << P.logW) < p.W) P.logW++;
     P.off_S = p.off_S; P.off_cnt = p.off_cnt; P.off_segtot = p.off_segtot; P.off_U = p.off_U; P.off_cover = p.off_cover; P.off_E = p.off_E;
