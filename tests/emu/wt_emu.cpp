@@ -7,6 +7,7 @@
 // oracle in the build container, which has no GPU.  Built by tests/emu/build.py
 // into tests/emu/libwt_emu.so.
 #define WT_EMU 1
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -23,7 +24,7 @@ struct EmuRun {
     std::vector<char> lds;
     int T_lanes = 0;
 
-    template <int OP, class ValT, class ScrT, int K, int NREG>
+    template <int OP, class ValT, class ScrT, int K, bool MULTI>
     void run() {
         WtCtx c;
         wt_ctx_init(c, P, lds.data());
@@ -32,16 +33,38 @@ struct EmuRun {
         for (;;) {
             const long long k = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
             if (k >= P.n_windows) break;
-            wt_phase_header(P, c, k);
-            for (int t = 0; t < T; t++) wt_phase_zero(P, c, t, T);
-            for (int t = 0; t < T; t++) wt_phase_load<ValT>(P, c, t, T);
-            for (int t = 0; t < T; t++) wt_phase_count_a(P, c, t, T);
-            for (int t = 0; t < T; t++) wt_phase_count_b(P, c, t, T);
             constexpr bool two = (OP == WT_OP_TTEST || OP == WT_OP_MWU);
+            constexpr int npass = wt_eval_passes(OP);
+            const int N = P.n_tracks, NC = P.chunk_tracks;
+            constexpr bool multi = MULTI;
+            std::vector<WtAcc<K>> acc(T);
+            wt_phase_header(P, c, k);
+            for (int t = 0; t < T; t++) wt_phase_zero(P, c, true, t, T);
+            for (int ch = 0; ch < P.n_chunks; ch++) {
+                const int t_lo = ch * NC, t_hi = std::min(N, t_lo + NC);
+                if (ch > 0) for (int t = 0; t < T; t++) wt_phase_zero(P, c, false, t, T);
+                for (int t = 0; t < T; t++) wt_phase_load<ValT>(P, c, t_lo, t_hi, true, t, T);
+                for (int t = 0; t < T; t++) wt_phase_count_a(P, c, t_lo, t_hi, t, T);
+                for (int t = 0; t < T; t++) wt_phase_count_b(P, c, t_lo, t_hi, t, T);
+            }
             for (int t = 0; t < T; t++) wt_phase_emask(P, c, two, t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
-            for (int t = 0; t < T; t++) wt_phase_eval<OP, ValT, ScrT, K, NREG>(P, c, lanes[t], t, T);
-            wt_phase_lookback(P, c, k);
+            wt_phase_lookback(P, c, k);     // sequential emulation: the offset is known at once
+            for (int t = 0; t < T; t++) wt_eval_init<OP, K>(acc[t]);
+            for (int pass = 0; pass < npass; pass++) {
+                for (int ch = 0; ch < P.n_chunks; ch++) {
+                    const int t_lo = ch * NC, t_hi = std::min(N, t_lo + NC);
+                    if (multi) {
+                        for (int t = 0; t < T; t++) wt_phase_zero(P, c, false, t, T);
+                        for (int t = 0; t < T; t++) wt_phase_load<ValT>(P, c, t_lo, t_hi, false, t, T);
+                        for (int t = 0; t < T; t++) wt_phase_count_a(P, c, t_lo, t_hi, t, T);
+                        for (int t = 0; t < T; t++) wt_phase_count_b(P, c, t_lo, t_hi, t, T);
+                    }
+                    for (int t = 0; t < T; t++) wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, acc[t], pass, t_lo, t_hi, t, T);
+                }
+                if (pass == 0 && npass == 2) for (int t = 0; t < T; t++) wt_eval_mid<OP, K>(P, acc[t]);
+            }
+            for (int t = 0; t < T; t++) wt_phase_eval_finish<OP, ValT, ScrT, K>(P, c, acc[t], lanes[t], t, T);
             for (int t = 0; t < T; t++) wt_phase_write<OP, ValT, K>(P, c, lanes[t], t, T);
             wt_window_stats(P, c);
         }
@@ -96,8 +119,8 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
     }
 
     R.lds.assign((size_t) R.plan.lds_bytes + 64, 0);
-    if (total > 0 && !wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R.plan.nreg, R)) return -11;
-    if (info) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows;
+    if (total > 0 && !wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R.plan.n_chunks > 1, R)) return -11;
+    if (info) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows; info[6] = R.plan.n_chunks;
                 info[4] = (long long) counters[WT_CTR_BP]; info[5] = (long long) counters[WT_CTR_INTERVALS]; }
     if (counters[WT_CTR_ERROR] & WT_ERR_CAPACITY) return -1;
     if (counters[WT_CTR_ERROR]) return -2;

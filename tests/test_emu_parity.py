@@ -111,3 +111,31 @@ def test_emu_run_start_ranges_concatenate(oracle, seed):
                     cat[k].append(g[k][m])
         cat = tuple(np.concatenate(x) for x in cat)
         assert_runs_equal(cat, exp, 0.0, "seed %d op %s" % (seed, op))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_emu_chunked_tracks(oracle, seed):
+    """Tracks visited in chunks (bitmaps rebuilt per chunk and pass): same results as all-resident."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(5, 14))
+    t = random_case(1300 + seed, n_tracks=n, dtype=np.float64 if seed % 2 else np.float32)
+    d = t.as_dict()
+    chunk = int(rng.integers(1, n))
+    ppt, T = GEOMS[seed % len(GEOMS)]
+    n1 = int(rng.integers(2, n - 1))
+    for flags in (0, 1):
+        for op in ALL_MULTIPLEX_OPS:
+            exp = oracle.reduce(d, op, flags=flags)
+            got, info = emu.reduce(t, op, flags=flags, ppt=ppt, T=T, chunk=chunk)
+            assert info["n_chunks"] == -(-n // chunk)
+            assert_runs_equal(got, exp, 0.0, "seed %d op %s flags %d %s" % (seed, op, flags, info))
+        exp = oracle.multiplex(d, flags=flags)
+        got, info = emu.reduce(t, "sum", flags=flags, ppt=ppt, T=T, multiplex=True, chunk=chunk)
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b, equal_nan=True)
+    for flags in (0, 1, 2, 3):
+        for op in ("ttest", "mwu"):
+            exp = oracle.reduce(d, op, flags=flags, n_set0=n1)
+            got, info = emu.reduce(t, op, flags=flags, n_set0=n1, ppt=ppt, T=T, chunk=chunk)
+            assert_runs_equal(got, exp, 1e-12 if op == "ttest" else 0.0,
+                              "seed %d op %s flags %d %s" % (seed, op, flags, info))

@@ -99,6 +99,8 @@ struct WtParams {
     double *o_tile;               // WT_OP_MULTIPLEX only: [capacity * n_tracks]
     uint8_t *o_inplay;            // WT_OP_MULTIPLEX only
     // ---- LDS carve (bytes from the dynamic LDS base; all multiples of 16) ----
+    int32_t chunk_tracks;         // tracks whose bitmaps are resident in LDS at a time (== n_tracks: one chunk)
+    int32_t n_chunks;             // ceil(n_tracks / chunk_tracks)
     int32_t count_segs;           // lanes per track in the count phase (1, 2, 4 or 8; >= 4 words each)
     int32_t spitch;               // u64 {S,C} pairs per track row (W/32 + 1: bank spread)
     int32_t cpitch;               // u16 entries per cnt_i row (W/32, even)
@@ -281,9 +283,15 @@ WT_DEV void wt_phase_header(const WtParams &P, WtCtx &c, long long k) {
 // ---------------------------------------------------------------------------
 // Phase 1: clear the bitmaps
 // ---------------------------------------------------------------------------
-WT_DEV void wt_phase_zero(const WtParams &P, WtCtx &c, int tid, int nt) {
-    const int nS = P.n_tracks * P.spitch;
+// `first`: also clear the window-wide bitmaps (once per window); the per-track bitmaps are cleared
+// for every chunk of tracks.
+WT_DEV void wt_phase_zero(const WtParams &P, WtCtx &c, bool first, int tid, int nt) {
+    const int nS = P.chunk_tracks * P.spitch;
     for (int x = tid; x < nS; x += nt) c.SC[x] = 0;
+    // spare cnt entry of every track: "an interval of this track spans w0" (its start bit at
+    // position 0 is a clipping artefact, not a breakpoint)
+    for (int i = tid; i < P.chunk_tracks; i += nt) c.cnt[(size_t) i * P.cpitch + P.n_words * 2] = 0;
+    if (!first) return;
     for (int x = tid; x < P.n_words; x += nt) { c.U[x] = 0; c.E[x] = 0; }
     const int nw32z = P.n_words * 2;
     for (int x = tid; x < nw32z; x += nt) {
@@ -292,9 +300,6 @@ WT_DEV void wt_phase_zero(const WtParams &P, WtCtx &c, int tid, int nt) {
         c.cover[2 * nw32z + x] = 0;          // any(set 1)
         c.cover[3 * nw32z + x] = 0xffffffffu;// all(set 1)
     }
-    // spare cnt entry of every track: "an interval of this track spans w0" (its start bit at
-    // position 0 is a clipping artefact, not a breakpoint)
-    for (int i = tid; i < P.n_tracks; i += nt) c.cnt[(size_t) i * P.cpitch + P.n_words * 2] = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -364,17 +369,19 @@ WT_DEV void wt_load_apply(const WtParams &P, WtCtx &c, uint64_t *SCi, uint16_t *
     // true breakpoints (U) are derived from S | toggles in the count phase: no atomics here
 }
 
+// Tracks [t_lo, t_hi) are loaded into the LDS rows 0 .. t_hi-t_lo-1.  `stats`: count the
+// examined intervals (first pass over the chunks only).
 template <class ValT>
-WT_DEV void wt_phase_load(const WtParams &P, WtCtx &c, int tid, int nt) {
-    const int N = P.n_tracks;
+WT_DEV void wt_phase_load(const WtParams &P, WtCtx &c, int t_lo, int t_hi, bool stats, int tid, int nt) {
     const int group = tid / WT_LOAD_GROUP, lane = tid % WT_LOAD_GROUP, ngroups = nt / WT_LOAD_GROUP;
-    if (group >= N) return;
+    if (t_lo + group >= t_hi) return;
     WtLoadBatch<ValT> cur;
-    wt_load_fetch<ValT>(P, c, group, lane, cur);
-    for (int i = group; i < N; i += ngroups) {
+    wt_load_fetch<ValT>(P, c, t_lo + group, lane, cur);
+    for (int g = t_lo + group; g < t_hi; g += ngroups) {
         WtLoadBatch<ValT> nxt;
-        const int inext = i + ngroups;
-        if (inext < N) wt_load_fetch<ValT>(P, c, inext, lane, nxt);
+        const int gnext = g + ngroups;
+        if (gnext < t_hi) wt_load_fetch<ValT>(P, c, gnext, lane, nxt);
+        const int i = g - t_lo;
         uint64_t *SCi = c.SC + (size_t) i * P.spitch;
         uint16_t *pseudo = c.cnt + (size_t) i * P.cpitch + P.n_words * 2;
         if (lane == 0) {
@@ -383,7 +390,7 @@ WT_DEV void wt_phase_load(const WtParams &P, WtCtx &c, int tid, int nt) {
             long long gb = -1;
             if (cur.hi >= cur.lo) {
                 gb = cur.off + cur.lo - 1 + (cur.f[0] == c.sh->w0 ? 1 : 0);
-                wt_lds_add64(&c.sh->n_intervals, (unsigned long long) (cur.hi - cur.lo + 1));
+                if (stats) wt_lds_add64(&c.sh->n_intervals, (unsigned long long) (cur.hi - cur.lo + 1));
             }
             if (gb > P.n_total - 2) gb = P.n_total - 2;
             c.gbase[i] = gb;
@@ -410,10 +417,10 @@ WT_DEV void wt_phase_load(const WtParams &P, WtCtx &c, int tid, int nt) {
 //   3a  every lane totals its own segment of words (start bits, toggle parity)
 //   3b  every lane prefixes the totals of the segments before it, then rewrites
 //       its own words in place (toggles -> coverage) and fills cnt.
-WT_DEV void wt_phase_count_a(const WtParams &P, WtCtx &c, int tid, int nt) {
+WT_DEV void wt_phase_count_a(const WtParams &P, WtCtx &c, int t_lo, int t_hi, int tid, int nt) {
     const int nw32 = P.n_words * 2;
     const int seg_words = (nw32 + P.count_segs - 1) / P.count_segs;
-    const int items = P.n_tracks * P.count_segs;
+    const int items = (t_hi - t_lo) * P.count_segs;
     for (int it = tid; it < items; it += nt) {
         const int i = it / P.count_segs, q = it % P.count_segs;
         const uint64_t *SCi = c.SC + (size_t) i * P.spitch;
@@ -430,10 +437,10 @@ WT_DEV void wt_phase_count_a(const WtParams &P, WtCtx &c, int tid, int nt) {
     }
 }
 
-WT_DEV void wt_phase_count_b(const WtParams &P, WtCtx &c, int tid, int nt) {
+WT_DEV void wt_phase_count_b(const WtParams &P, WtCtx &c, int t_lo, int t_hi, int tid, int nt) {
     const int nw32 = P.n_words * 2;
     const int seg_words = (nw32 + P.count_segs - 1) / P.count_segs;
-    const int items = P.n_tracks * P.count_segs;
+    const int items = (t_hi - t_lo) * P.count_segs;
     for (int it = tid; it < items; it += nt) {
         const int i = it / P.count_segs, q = it % P.count_segs;
         uint64_t *SCi = c.SC + (size_t) i * P.spitch;
@@ -450,7 +457,7 @@ WT_DEV void wt_phase_count_b(const WtParams &P, WtCtx &c, int tid, int nt) {
         uint32_t carry = par ? 0xffffffffu : 0u;
         uint32_t *U32 = (uint32_t *) c.U;
         const bool pseudo = ci[nw32] != 0;
-        const int set1 = (P.n_set0 > 0 && i >= P.n_set0) ? 1 : 0;
+        const int set1 = (P.n_set0 > 0 && t_lo + i >= P.n_set0) ? 1 : 0;
         uint32_t *cov_any = c.cover + (size_t) (2 * set1) * nw32;
         uint32_t *cov_all = cov_any + nw32;
         const bool strict_set = (P.flags & (set1 ? WT_STRICT_SET1 : WT_STRICT_SET0)) != 0;
@@ -571,43 +578,44 @@ WT_DEV double wt_unkey64(uint64_t k) {
     return __builtin_bit_cast(double, u);
 }
 
-// Visits tracks lo..hi-1 in index order, two tracks' gathers in flight at a time.
-// body(i, F) is called in increasing i.
+// Visits the (global) tracks lo..hi-1 in index order, two tracks' gathers in flight at a time.
+// The tracks' bitmaps are the LDS rows (track - base) of the resident chunk.
+// body(track, F) is called in increasing track order (the reference's summation order).
 template <class ValT, class ScrT, int K, class Body>
-WT_DEV void wt_for_tracks(const WtParams &P, const WtCtx &c, int lo, int hi, int w32, int b0,
+WT_DEV void wt_for_tracks(const WtParams &P, const WtCtx &c, int base, int lo, int hi, int w32, int b0,
                           const uint32_t (&mask)[K], bool use_defaults, Body body) {
     const double *dflt = P.defaults;
-    int i = lo;
-    for (; i + 1 < hi; i += 2) {
+    int g = lo;
+    for (; g + 1 < hi; g += 2) {
         WtFetchK<K> F0, F1;
-        wt_fetch_group<ValT, ScrT, K>(P, c, i, w32, b0, mask, use_defaults ? dflt[i] : 0.0, F0);
-        wt_fetch_group<ValT, ScrT, K>(P, c, i + 1, w32, b0, mask, use_defaults ? dflt[i + 1] : 0.0, F1);
-        body(i, F0);
-        body(i + 1, F1);
+        wt_fetch_group<ValT, ScrT, K>(P, c, g - base, w32, b0, mask, use_defaults ? dflt[g] : 0.0, F0);
+        wt_fetch_group<ValT, ScrT, K>(P, c, g + 1 - base, w32, b0, mask, use_defaults ? dflt[g + 1] : 0.0, F1);
+        body(g, F0);
+        body(g + 1, F1);
     }
-    if (i < hi) {
+    if (g < hi) {
         WtFetchK<K> F0;
-        wt_fetch_group<ValT, ScrT, K>(P, c, i, w32, b0, mask, use_defaults ? dflt[i] : 0.0, F0);
-        body(i, F0);
+        wt_fetch_group<ValT, ScrT, K>(P, c, g - base, w32, b0, mask, use_defaults ? dflt[g] : 0.0, F0);
+        body(g, F0);
     }
 }
 
-// Same contract as wt_for_tracks, but WT_DEEP tracks' gathers are in flight per lane.  Used by
-// median / MWU (one position per lane, no accumulators in registers): their gather phase is pure
-// memory latency, and with only a few waves per CU (the LDS scratch columns limit the workgroup
-// size) depth is what keeps enough loads outstanding.
+// Same contract, but WT_DEEP tracks' gathers are in flight per lane.  Used by median / MWU (one
+// position per lane, no accumulators in registers): their gather phase is pure memory latency,
+// and with only a few waves per CU (the LDS scratch columns limit the workgroup size) depth is
+// what keeps enough loads outstanding.
 #ifndef WT_DEEP
 #define WT_DEEP 8
 #endif
 template <class ValT, class ScrT, int K, class Body>
-WT_DEV void wt_for_tracks_deep(const WtParams &P, const WtCtx &c, int lo, int hi, int w32, int b0,
+WT_DEV void wt_for_tracks_deep(const WtParams &P, const WtCtx &c, int base, int lo, int hi, int w32, int b0,
                                const uint32_t (&mask)[K], Body body) {
     const double *dflt = P.defaults;
     constexpr int D = WT_DEEP;
     WtRawK<ValT, K> R[D];
 #pragma unroll
     for (int u = 0; u < D; u++)
-        if (lo + u < hi) wt_fetch_issue<ValT, K>(P, c, lo + u, w32, mask, dflt[lo + u], R[u]);
+        if (lo + u < hi) wt_fetch_issue<ValT, K>(P, c, lo + u - base, w32, mask, dflt[lo + u], R[u]);
     for (int j = lo; j < hi; j += D) {
 #pragma unroll
         for (int u = 0; u < D; u++) {
@@ -616,28 +624,52 @@ WT_DEV void wt_for_tracks_deep(const WtParams &P, const WtCtx &c, int lo, int hi
                 WtFetchK<K> F;
                 wt_fetch_finish<ValT, ScrT, K>(R[u], b0, F);
                 body(t, F);
-                if (t + D < hi) wt_fetch_issue<ValT, K>(P, c, t + D, w32, mask, dflt[t + D], R[u]);
+                if (t + D < hi) wt_fetch_issue<ValT, K>(P, c, t + D - base, w32, mask, dflt[t + D], R[u]);
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-// Per-run reducers.  One lane evaluates K consecutive window positions; for
-// every position the tracks are visited in index order i = 0..N-1 in f64,
-// exactly the reference's summation order (bit-identical sums).
-// res[k] = reducer value.  Positions of the group that do not start an emitted run are
-// computed too (cheaper than diverging) and discarded by the caller.
-// NaN: the reference tests isnan() per value and yields NaN; for sum / product /
-// mean / var / stddev / CV IEEE propagation through the accumulator gives the
-// same answer (NaN in -> NaN out), so no flag is carried; min / max / median /
-// MWU carry an explicit flag because comparisons swallow NaN.
-// Median / MWU use K == 1 and this lane's LDS scratch column.
+// Per-run reducers.  One lane evaluates K consecutive window positions; for every position the
+// tracks are visited in index order i = 0..N-1 in f64, exactly the reference's summation order
+// (bit-identical sums).  The tracks arrive in CHUNKS (the ones whose bitmaps are resident in
+// LDS), so a reducer is init / add(chunk) [/ second pass for var, stddev, CV] / finish, with its
+// accumulators living in registers across the chunk loop.  With few enough tracks there is one
+// chunk and this degenerates to one loop over all tracks.
+// Positions of the group that do not start an emitted run are computed too (cheaper than
+// diverging) and discarded by the caller.
+// NaN: the reference tests isnan() per value and yields NaN; for sum / product / mean / var /
+// stddev / CV IEEE propagation through the accumulator gives the same answer (NaN in -> NaN
+// out), so no flag is carried; min / max / median / MWU carry an explicit flag because
+// comparisons swallow NaN.  Median / MWU use K == 1 and this lane's LDS scratch column.
 // ---------------------------------------------------------------------------
-template <int OP, class ValT, class ScrT, int K, int NREG>
-WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&res)[K],
-                          char *scratch, int lane_col, int colstride) {
-    const int N = P.n_tracks;
+template <int K>
+struct WtAcc {
+    double a[K], b[K];        // sum|product|best|mean|s1 , squares|q1
+    double c2[K], d[K];       // t-test: s2, q2
+    bool nan[K];
+};
+
+WT_DEV constexpr int wt_eval_passes(int op) {
+    return (op == WT_OP_VAR || op == WT_OP_STDDEV || op == WT_OP_ENTROPY || op == WT_OP_CV) ? 2 : 1;
+}
+
+template <int OP, int K>
+WT_DEV void wt_eval_init(WtAcc<K> &A) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        A.a[k] = (OP == WT_OP_PRODUCT) ? 1.0 : 0.0;
+        A.b[k] = 0; A.c2[k] = 0; A.d[k] = 0;
+        A.nan[k] = false;
+    }
+}
+
+// Adds the tracks [t_lo, t_hi) (resident chunk, LDS rows relative to t_lo) in pass `pass`.
+// goff_run0: MULTIPLEX only -- global index of the run at the lane's first emitted position.
+template <int OP, class ValT, class ScrT, int K>
+WT_DEV void wt_eval_chunk(const WtParams &P, const WtCtx &c, int p0, WtAcc<K> &A, int pass, int t_lo, int t_hi,
+                          char *scratch, int lane_col, int colstride, unsigned emit_bits, long long run0) {
     const int w32 = p0 >> 5, b0 = p0 & 31;
     uint32_t mask[K];
 #pragma unroll
@@ -645,95 +677,161 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
 
     if (OP == WT_OP_SUM || OP == WT_OP_PRODUCT || OP == WT_OP_MEAN) {
         // reducers.c:259-292, 313-346, 367-402
-        double acc[K];
-#pragma unroll
-        for (int k = 0; k < K; k++) acc[k] = (OP == WT_OP_PRODUCT) ? 1.0 : 0.0;
-        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, [&](int, const WtFetchK<K> &F) {
+        wt_for_tracks<ValT, ScrT, K>(P, c, t_lo, t_lo, t_hi, w32, b0, mask, true, [&](int, const WtFetchK<K> &F) {
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                if (OP == WT_OP_PRODUCT) acc[k] *= F.x[k]; else acc[k] += F.x[k];
+                if (OP == WT_OP_PRODUCT) A.a[k] *= F.x[k]; else A.a[k] += F.x[k];
             }
         });
-#pragma unroll
-        for (int k = 0; k < K; k++) res[k] = (OP == WT_OP_MEAN) ? acc[k] / N : acc[k];
         return;
     }
     if (OP == WT_OP_MIN || OP == WT_OP_MAX) {
         // reducers.c:125-168, 192-235: seed is 0 (not the default) when track 0 is absent
-        double best[K];
-        bool nan[K];
-        {
+        int lo = t_lo;
+        if (t_lo == 0) {
             WtFetchK<K> F;
             wt_fetch_group<ValT, ScrT, K>(P, c, 0, w32, b0, mask, 0.0, F);
 #pragma unroll
-            for (int k = 0; k < K; k++) { best[k] = F.x[k]; nan[k] = wt_isnan(best[k]); }
+            for (int k = 0; k < K; k++) { A.a[k] = F.x[k]; A.nan[k] = wt_isnan(F.x[k]); }
+            lo = 1;
         }
-        wt_for_tracks<ValT, ScrT, K>(P, c, 1, N, w32, b0, mask, true, [&](int, const WtFetchK<K> &F) {
+        wt_for_tracks<ValT, ScrT, K>(P, c, t_lo, lo, t_hi, w32, b0, mask, true, [&](int, const WtFetchK<K> &F) {
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 const double x = F.x[k];
-                nan[k] |= wt_isnan(x);
-                if (OP == WT_OP_MAX) { if (best[k] < x) best[k] = x; } else { if (best[k] > x) best[k] = x; }
+                A.nan[k] |= wt_isnan(x);
+                if (OP == WT_OP_MAX) { if (A.a[k] < x) A.a[k] = x; } else { if (A.a[k] > x) A.a[k] = x; }
             }
         });
-#pragma unroll
-        for (int k = 0; k < K; k++) res[k] = nan[k] ? wt_nan() : best[k];
         return;
     }
     if (OP == WT_OP_VAR || OP == WT_OP_STDDEV || OP == WT_OP_ENTROPY || OP == WT_OP_CV) {
         // reducers.c:428-479 (var), 511-563 (stddev; entropy installs the same pop, :665),
-        // 672-725 (CV).  Pass 1 rounds every value through `float`.
-        double mean[K], acc[K];
+        // 672-725 (CV).  Pass 0 (mean) rounds every value through `float`; pass 1 sums squares.
+        if (pass == 0) {
+            wt_for_tracks<ValT, ScrT, K>(P, c, t_lo, t_lo, t_hi, w32, b0, mask, true, [&](int, const WtFetchK<K> &F) {
 #pragma unroll
-        for (int k = 0; k < K; k++) { mean[k] = 0; acc[k] = 0; }
-        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, [&](int, const WtFetchK<K> &F) {
+                for (int k = 0; k < K; k++) A.a[k] += (double) (float) F.x[k];
+            });
+        } else {
+            wt_for_tracks<ValT, ScrT, K>(P, c, t_lo, t_lo, t_hi, w32, b0, mask, true, [&](int, const WtFetchK<K> &F) {
 #pragma unroll
-            for (int k = 0; k < K; k++) mean[k] += (double) (float) F.x[k];
+                for (int k = 0; k < K; k++) {
+                    // var ignores absent tracks in pass 2 (:470-475); stddev / CV use their default
+                    double diff = A.a[k] - F.x[k];
+                    if (OP == WT_OP_VAR) diff = F.cov[k] ? diff : 0.0;
+                    A.b[k] += diff * diff;
+                }
+            });
+        }
+        return;
+    }
+    if (OP == WT_OP_TTEST) {
+        // setComparisons.c:60-117: sums over in-play tracks, counts over all tracks
+        const int na = P.n_set0;
+        const int mid = na < t_lo ? t_lo : (na > t_hi ? t_hi : na);
+        wt_for_tracks<ValT, ScrT, K>(P, c, t_lo, t_lo, mid, w32, b0, mask, false, [&](int, const WtFetchK<K> &F) {
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (F.cov[k]) { A.a[k] += F.x[k]; A.b[k] += F.x[k] * F.x[k]; }
         });
+        wt_for_tracks<ValT, ScrT, K>(P, c, t_lo, mid, t_hi, w32, b0, mask, false, [&](int, const WtFetchK<K> &F) {
 #pragma unroll
-        for (int k = 0; k < K; k++) mean[k] /= N;
-        wt_for_tracks<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, true, [&](int, const WtFetchK<K> &F) {
+            for (int k = 0; k < K; k++)
+                if (F.cov[k]) { A.c2[k] += F.x[k]; A.d[k] += F.x[k] * F.x[k]; }
+        });
+        return;
+    }
+    if (OP == WT_OP_MEDIAN) {
+        // gather: default-substituted values -> order-preserving keys in this lane's LDS column
+        typedef typename std::conditional<sizeof(ScrT) == 4, uint32_t, uint64_t>::type KeyT;
+        KeyT *col = (KeyT *) scratch + lane_col;
+        bool nan = A.nan[0];
+        wt_for_tracks_deep<ValT, ScrT, K>(P, c, t_lo, t_lo, t_hi, w32, b0, mask, [&](int i, const WtFetchK<K> &F) {
+            const double x = F.x[0];
+            nan |= wt_isnan(x);
+            if (sizeof(ScrT) == 4) col[(size_t) i * colstride] = (KeyT) wt_key32((float) x);
+            else col[(size_t) i * colstride] = (KeyT) wt_key64(x);
+        });
+        A.nan[0] = nan;
+        return;
+    }
+    if (OP == WT_OP_MWU) {
+        ScrT *val = (ScrT *) scratch + lane_col;                                   // [N][colstride]
+        bool nan = A.nan[0];
+        wt_for_tracks_deep<ValT, ScrT, K>(P, c, t_lo, t_lo, t_hi, w32, b0, mask, [&](int i, const WtFetchK<K> &F) {
+            nan |= wt_isnan(F.x[0]);
+            val[(size_t) i * colstride] = (ScrT) F.x[0];
+        });
+        A.nan[0] = nan;
+        return;
+    }
+    if (OP == WT_OP_MULTIPLEX) {
+        // the per-run value of the materialised Multiplexer is its inplay_count (multiplexer.h:27);
+        // the values[] / inplay[] columns of this chunk's tracks go straight to the tile
+        const int N = P.n_tracks;
+        for (int g = t_lo; g < t_hi; g++) {
+            WtFetchK<K> F;
+            wt_fetch_group<ValT, double, K>(P, c, g - t_lo, w32, b0, mask, P.defaults[g], F);
+            long long o = run0;
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                // var ignores absent tracks in pass 2 (:470-475); stddev / CV use their default
-                double diff = mean[k] - F.x[k];
-                if (OP == WT_OP_VAR) diff = F.cov[k] ? diff : 0.0;
-                acc[k] += diff * diff;
+                A.a[k] += F.cov[k] ? 1.0 : 0.0;
+                if ((emit_bits >> k) & 1u) {
+                    if (o < P.capacity) {
+                        P.o_tile[o * N + g] = F.x[k];
+                        P.o_inplay[o * N + g] = (uint8_t) F.cov[k];
+                    }
+                    o++;
+                }
             }
-        });
+        }
+        return;
+    }
+}
+
+// Between the two passes of var / stddev / CV: the mean is final.
+template <int OP, int K>
+WT_DEV void wt_eval_mid(const WtParams &P, WtAcc<K> &A) {
+#pragma unroll
+    for (int k = 0; k < K; k++) A.a[k] /= P.n_tracks;
+}
+
+template <int OP, class ValT, class ScrT, int K>
+WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K], char *scratch, int lane_col,
+                           int colstride) {
+    const int N = P.n_tracks;
+    if (OP == WT_OP_SUM || OP == WT_OP_PRODUCT || OP == WT_OP_MEAN) {
+#pragma unroll
+        for (int k = 0; k < K; k++) res[k] = (OP == WT_OP_MEAN) ? A.a[k] / N : A.a[k];
+        return;
+    }
+    if (OP == WT_OP_MIN || OP == WT_OP_MAX) {
+#pragma unroll
+        for (int k = 0; k < K; k++) res[k] = A.nan[k] ? wt_nan() : A.a[k];
+        return;
+    }
+    if (OP == WT_OP_VAR || OP == WT_OP_STDDEV || OP == WT_OP_ENTROPY || OP == WT_OP_CV) {
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            double a = acc[k] / N;
-            bool bad = wt_isnan(mean[k]);
+            const double mean = A.a[k];
+            double a = A.b[k] / N;
+            bool bad = wt_isnan(mean);
             if (OP == WT_OP_VAR) { if (N < 2) bad = true; }
             else {
                 a = sqrt(a);
-                if (OP == WT_OP_CV) { if (mean[k] == 0) bad = true; a /= mean[k]; }
+                if (OP == WT_OP_CV) { if (mean == 0) bad = true; a /= mean; }
             }
             res[k] = bad ? wt_nan() : a;
         }
         return;
     }
     if (OP == WT_OP_TTEST) {
-        // setComparisons.c:60-117: sums over in-play tracks, counts over all tracks
         const int na = P.n_set0, nb = N - P.n_set0;
-        double s1[K], q1[K], s2[K], q2[K];
-#pragma unroll
-        for (int k = 0; k < K; k++) { s1[k] = q1[k] = s2[k] = q2[k] = 0; }
-        wt_for_tracks<ValT, ScrT, K>(P, c, 0, na, w32, b0, mask, false, [&](int, const WtFetchK<K> &F) {
-#pragma unroll
-            for (int k = 0; k < K; k++)
-                if (F.cov[k]) { s1[k] += F.x[k]; q1[k] += F.x[k] * F.x[k]; }
-        });
-        wt_for_tracks<ValT, ScrT, K>(P, c, na, N, w32, b0, mask, false, [&](int, const WtFetchK<K> &F) {
-#pragma unroll
-            for (int k = 0; k < K; k++)
-                if (F.cov[k]) { s2[k] += F.x[k]; q2[k] += F.x[k] * F.x[k]; }
-        });
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const double m1 = s1[k] / na, m2 = s2[k] / nb;
-            const double msq1 = q1[k] / na, msq2 = q2[k] / nb;
+            const double m1 = A.a[k] / na, m2 = A.c2[k] / nb;
+            const double msq1 = A.b[k] / na, msq2 = A.d[k] / nb;
             const double var1 = msq1 - m1 * m1, var2 = msq2 - m2 * m2;
             if (var1 + var2 == 0) { res[k] = wt_nan(); continue; }
             double t = (m1 - m2) / sqrt(var1 / na + var2 / nb);
@@ -747,18 +845,10 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
         return;
     }
     if (OP == WT_OP_MEDIAN) {
-        // reducers.c:780-813: upper median of the default-substituted values.
-        // Selection by bitwise binary search over order-preserving keys kept in
-        // this lane's LDS column (no divergence, no writes after the gather).
+        // reducers.c:780-813: upper median.  Selection by bitwise binary search over the keys of
+        // this lane's LDS column (no divergence, no writes).
         typedef typename std::conditional<sizeof(ScrT) == 4, uint32_t, uint64_t>::type KeyT;
-        KeyT *col = (KeyT *) scratch + lane_col;
-        bool nan = false;
-        wt_for_tracks_deep<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, [&](int i, const WtFetchK<K> &F) {
-            const double x = F.x[0];
-            nan |= wt_isnan(x);
-            if (sizeof(ScrT) == 4) col[(size_t) i * colstride] = (KeyT) wt_key32((float) x);
-            else col[(size_t) i * colstride] = (KeyT) wt_key64(x);
-        });
+        const KeyT *col = (const KeyT *) scratch + lane_col;
         const int kth = N / 2;       // 0-based rank of vals[N/2]
         // largest key Kk such that count(keys < Kk) <= kth  ==  the kth smallest key
         KeyT Kk = 0;
@@ -771,7 +861,7 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
             if (below <= kth) Kk = trial;
         }
         const double m = (sizeof(ScrT) == 4) ? (double) wt_unkey32((uint32_t) Kk) : wt_unkey64((uint64_t) Kk);
-        res[0] = nan ? wt_nan() : m;
+        res[0] = A.nan[0] ? wt_nan() : m;
         return;
     }
     if (OP == WT_OP_MWU) {
@@ -789,14 +879,9 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
         // scattered to rank r_e and the reference's tie state machine then runs over n1 entries,
         // performing the same double additions in the same order.
         const int na = P.n_set0, nb = N - P.n_set0;
-        ScrT *val = (ScrT *) scratch + lane_col;                                   // [N][colstride]
+        const ScrT *val = (const ScrT *) scratch + lane_col;                       // [N][colstride]
         uint32_t *attr = (uint32_t *) ((ScrT *) scratch + (size_t) N * colstride) + lane_col;   // [na][colstride]
-        bool nan = false;
-        wt_for_tracks_deep<ValT, ScrT, K>(P, c, 0, N, w32, b0, mask, [&](int i, const WtFetchK<K> &F) {
-            nan |= wt_isnan(F.x[0]);
-            val[(size_t) i * colstride] = (ScrT) F.x[0];
-        });
-        if (nan) { res[0] = wt_nan(); return; }
+        if (A.nan[0]) { res[0] = wt_nan(); return; }
         for (int e = 0; e < na; e++) {
             const ScrT x = val[(size_t) e * colstride];
             int L = 0, t = 0, r = 0, later_equal = 0;
@@ -836,18 +921,8 @@ WT_DEV void wt_eval_group(const WtParams &P, const WtCtx &c, int p0, double (&re
         return;
     }
     if (OP == WT_OP_MULTIPLEX) {
-        // the per-run value of the materialised Multiplexer is its inplay_count
-        // (multiplexer.h:27); the values[] / inplay[] tile is gathered in the write phase
-        int cnt[K];
 #pragma unroll
-        for (int k = 0; k < K; k++) cnt[k] = 0;
-        for (int i = 0; i < N; i++) {
-            const uint32_t cb = (uint32_t) (c.SC[(size_t) i * P.spitch + w32] >> 32);
-#pragma unroll
-            for (int k = 0; k < K; k++) cnt[k] += (int) ((cb >> (b0 + k)) & 1u);
-        }
-#pragma unroll
-        for (int k = 0; k < K; k++) res[k] = (double) cnt[k];
+        for (int k = 0; k < K; k++) res[k] = A.a[k];
         return;
     }
 }
@@ -904,16 +979,34 @@ WT_DEV void wt_phase_escan(const WtParams &P, WtCtx &c, int tid, int nt) {
 }
 
 // ---------------------------------------------------------------------------
-// Phase 6: evaluate the reducer at every emitted run start.  Lane `tid` owns the
-// K consecutive positions [tid*K, tid*K+K).
+// Phase 6: evaluate the reducer at every emitted run start.  Lane `tid` owns the K consecutive
+// positions [tid*K, tid*K+K); its accumulators (WtAcc) live in registers across the chunk loop.
 // ---------------------------------------------------------------------------
-template <int OP, class ValT, class ScrT, int K, int NREG>
-WT_DEV void wt_phase_eval(const WtParams &P, WtCtx &c, WtLane<K> &L, int tid, int nt) {
+template <int K>
+WT_DEV unsigned wt_lane_emit_bits(const WtParams &P, const WtCtx &c, int tid) {
     const int p0 = tid * K;
-    if (p0 >= P.W) return;
-    const unsigned emit_bits = (unsigned) ((c.E[p0 >> 6] >> (p0 & 63)) & ((1ull << K) - 1ull));
+    if (p0 >= P.W) return 0u;
+    return (unsigned) ((c.E[p0 >> 6] >> (p0 & 63)) & ((1ull << K) - 1ull));
+}
+
+template <int OP, class ValT, class ScrT, int K>
+WT_DEV void wt_phase_eval_chunk(const WtParams &P, WtCtx &c, WtAcc<K> &A, int pass, int t_lo, int t_hi, int tid, int nt) {
+    const unsigned emit_bits = wt_lane_emit_bits<K>(P, c, tid);
     if (!emit_bits) return;
-    wt_eval_group<OP, ValT, ScrT, K, NREG>(P, c, p0, L.res, c.scratch, tid, nt);
+    const int p0 = tid * K;
+    long long run0 = 0;
+    if (OP == WT_OP_MULTIPLEX) {    // global index of the lane's first emitted run (look-back already done)
+        const int w = p0 >> 6, b0 = p0 & 63;
+        const uint64_t below0 = b0 ? wt_mask_incl(b0 - 1) : 0ull;
+        run0 = c.sh->goffset + c.epfx[w] + wt_popc64(c.E[w] & below0);
+    }
+    wt_eval_chunk<OP, ValT, ScrT, K>(P, c, p0, A, pass, t_lo, t_hi, c.scratch, tid, nt, emit_bits, run0);
+}
+
+template <int OP, class ValT, class ScrT, int K>
+WT_DEV void wt_phase_eval_finish(const WtParams &P, WtCtx &c, const WtAcc<K> &A, WtLane<K> &L, int tid, int nt) {
+    if (!wt_lane_emit_bits<K>(P, c, tid)) return;
+    wt_eval_finish<OP, ValT, ScrT, K>(P, A, L.res, c.scratch, tid, nt);
 }
 
 // ---------------------------------------------------------------------------
@@ -1038,16 +1131,6 @@ WT_DEV void wt_phase_write(const WtParams &P, WtCtx &c, const WtLane<K> &L, int 
             if (o >= P.capacity) continue;
             P.o_start[o] = w0 + p;
             P.o_finish[o] = fin;
-            if (OP == WT_OP_MULTIPLEX) {
-                const int N = P.n_tracks;
-                const uint32_t mask1[1] = { (2u << (p & 31)) - 1u };
-                WtFetchK<1> F;
-                for (int i = 0; i < N; i++) {
-                    wt_fetch_group<ValT, double, 1>(P, c, i, p >> 5, p & 31, mask1, P.defaults[i], F);
-                    P.o_tile[o * N + i] = F.x[0];
-                    P.o_inplay[o * N + i] = (uint8_t) F.cov[0];
-                }
-            }
             P.o_value[o] = L.res[k];
         }
         wt_lds_add64(&c.sh->bp_sum, bp);

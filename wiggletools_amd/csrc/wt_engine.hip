@@ -37,7 +37,7 @@
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-template <int OP, class ValT, class ScrT, int K, int NREG>
+template <int OP, class ValT, class ScrT, int K, bool MULTI>
 __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
@@ -68,20 +68,30 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
         WT_MARK(2);
         if (k >= P.n_windows) break;
         if (tid == 0) wt_phase_header(P, c, k);
-        wt_phase_zero(P, c, tid, nt);
+        wt_phase_zero(P, c, true, tid, nt);
         __syncthreads();
         WT_TICK(0);
-        WT_MARK(3);
-        wt_phase_load<ValT>(P, c, tid, nt);
-        __syncthreads();
-        WT_TICK(1);
-        WT_MARK(4);
-        wt_phase_count_a(P, c, tid, nt);
-        __syncthreads();
-        WT_MARK(5);
-        wt_phase_count_b(P, c, tid, nt);
-        __syncthreads();
-        WT_TICK(2);
+        // pass A: every track's breakpoints and coverage enter U / cover[]; with one chunk the
+        // per-track bitmaps stay resident for the evaluation
+        const int N = P.n_tracks, NC = MULTI ? P.chunk_tracks : N, n_chunks = MULTI ? P.n_chunks : 1;
+        for (int ch = 0; ch < n_chunks; ch++) {
+            const int t_lo = ch * NC, t_hi = (t_lo + NC < N) ? t_lo + NC : N;
+            if (MULTI && ch > 0) {
+                wt_phase_zero(P, c, false, tid, nt);
+                __syncthreads();
+            }
+            WT_MARK(3);
+            wt_phase_load<ValT>(P, c, t_lo, t_hi, true, tid, nt);
+            __syncthreads();
+            WT_TICK(1);
+            WT_MARK(4);
+            wt_phase_count_a(P, c, t_lo, t_hi, tid, nt);
+            __syncthreads();
+            WT_MARK(5);
+            wt_phase_count_b(P, c, t_lo, t_hi, tid, nt);
+            __syncthreads();
+            WT_TICK(2);
+        }
         WT_MARK(6);
         wt_phase_emask(P, c, OP == WT_OP_TTEST || OP == WT_OP_MWU, tid, nt);
         __syncthreads();
@@ -93,11 +103,37 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
         // successor ever waits for our evaluation
         WT_MARK(8);
         if (tid == 0) wt_lookback_publish(P, c, k);
+        if (OP == WT_OP_MULTIPLEX) {     // the tile rows are written by the evaluation: offset first
+            if (tid < 64) wt_lookback_complete(P, c, k, tid);
+            __syncthreads();
+        }
         WT_MARK(9);
-        wt_phase_eval<OP, ValT, ScrT, K, NREG>(P, c, L, tid, nt);
+        WtAcc<K> A;
+        wt_eval_init<OP, K>(A);
+        constexpr int npass = wt_eval_passes(OP);
+#pragma unroll
+        for (int pass = 0; pass < npass; pass++) {
+            for (int ch = 0; ch < n_chunks; ch++) {
+                const int t_lo = ch * NC, t_hi = (t_lo + NC < N) ? t_lo + NC : N;
+                if (MULTI) {
+                    wt_phase_zero(P, c, false, tid, nt);
+                    __syncthreads();
+                    wt_phase_load<ValT>(P, c, t_lo, t_hi, false, tid, nt);
+                    __syncthreads();
+                    wt_phase_count_a(P, c, t_lo, t_hi, tid, nt);
+                    __syncthreads();
+                    wt_phase_count_b(P, c, t_lo, t_hi, tid, nt);
+                    __syncthreads();
+                }
+                wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, A, pass, t_lo, t_hi, tid, nt);
+                if (MULTI) __syncthreads();     // the next chunk overwrites the bitmaps
+            }
+            if (pass == 0 && npass == 2) wt_eval_mid<OP, K>(P, A);
+        }
+        wt_phase_eval_finish<OP, ValT, ScrT, K>(P, c, A, L, tid, nt);
         WT_TICK(4);
         WT_MARK(10);
-        if (tid < 64) wt_lookback_complete(P, c, k, tid);
+        if (OP != WT_OP_MULTIPLEX && tid < 64) wt_lookback_complete(P, c, k, tid);
         __syncthreads();
         WT_TICK(5);
         WT_MARK(11);
@@ -477,9 +513,9 @@ struct WtLaunch {
     int num_cu = 256;
     hipError_t err = hipSuccess;
 
-    template <int OP, class ValT, class ScrT, int K, int NREG>
+    template <int OP, class ValT, class ScrT, int K, bool MULTI>
     void run() {
-        auto kern = wt_reduce_kernel<OP, ValT, ScrT, K, NREG>;
+        auto kern = wt_reduce_kernel<OP, ValT, ScrT, K, MULTI>;
         if (lds > 48 * 1024) {
             err = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;
@@ -543,7 +579,7 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
     if (w->tab.n_windows > 0 && ts->n_intervals > 0) {
         WT_HIP(hipMemsetAsync(w->d_status, 0, sizeof(unsigned long long) * w->tab.n_windows, s));
         WT_HIP(hipEventRecord(ts->ev_r0, s));
-        if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, plan.nreg, L)) return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
+        if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, plan.n_chunks > 1, L)) return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
         if (L.err != hipSuccess) return wt_fail(WTAMD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(L.err));
         WT_HIP(hipEventRecord(ts->ev_r1, s));
         ts->have_reduce_time = true;

@@ -18,11 +18,11 @@ struct WtPlan {
     int T = 0;          // workgroup size (lanes), multiple of 64
     int n_words = 0;
     int spitch = 0, cpitch = 0, count_segs = 8;
+    int chunk_tracks = 0, n_chunks = 1;   // tracks resident in LDS at a time / number of chunks
     int off_S = 0, off_cnt = 0, off_segtot = 0, off_U = 0, off_cover = 0, off_E = 0, off_epfx = 0, off_nextw = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
     int lds_bytes = 0;
     int scratch_elem = 0;   // bytes per scratch element (0: op needs no scratch)
     int ppt = 1;            // consecutive window positions per lane (1 or 4)
-    int nreg = 0;           // median: values kept in this many registers per lane (0: LDS scratch column)
 };
 
 static inline int wt_align16(int x) { return (x + 15) & ~15; }
@@ -30,23 +30,27 @@ static inline int wt_align16(int x) { return (x + 15) & ~15; }
 static inline bool wt_op_needs_scratch(int op) { return op == WT_OP_MEDIAN || op == WT_OP_MWU; }
 
 // LDS bytes for a candidate (W, T)
-static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem, WtPlan &p) {
+// n_tracks: all tracks (scratch columns); chunk: tracks whose bitmaps are resident at a time
+static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem, WtPlan &p, int chunk = 0) {
+    if (chunk <= 0 || chunk > n_tracks) chunk = n_tracks;
+    p.chunk_tracks = chunk;
+    p.n_chunks = (n_tracks + chunk - 1) / chunk;
     p.W = W; p.T = T; p.n_words = W / 64;
     p.spitch = W / 32 + 1;                    // {S,C} pairs per track, +1: rows start on different banks
     p.cpitch = (W / 32 + 2) & ~1;             // u16 rank prefix per 32-bit word + 1 spare flag entry, even count
     p.scratch_elem = scratch_elem;
     int o = 0;
-    p.off_S = o;       o = wt_align16(o + n_tracks * p.spitch * 8);
-    p.off_cnt = o;     o = wt_align16(o + n_tracks * p.cpitch * 2);
+    p.off_S = o;       o = wt_align16(o + chunk * p.spitch * 8);
+    p.off_cnt = o;     o = wt_align16(o + chunk * p.cpitch * 2);
     p.count_segs = 8;                         // lanes per track in the count phase, >= 4 words each
     while (p.count_segs > 1 && (W / 32) / p.count_segs < 4) p.count_segs >>= 1;
-    p.off_segtot = o;  o = wt_align16(o + n_tracks * p.count_segs * 4);
+    p.off_segtot = o;  o = wt_align16(o + chunk * p.count_segs * 4);
     p.off_U = o;       o = wt_align16(o + p.n_words * 8);
     p.off_cover = o;   o = wt_align16(o + 4 * p.n_words * 8);
     p.off_E = o;       o = wt_align16(o + p.n_words * 8);
     p.off_epfx = o;    o = wt_align16(o + (p.n_words + 1) * 4);
     p.off_nextw = o;   o = wt_align16(o + p.n_words * 2);
-    p.off_gbase = o;   o = wt_align16(o + n_tracks * 8);
+    p.off_gbase = o;   o = wt_align16(o + chunk * 8);
     p.off_scratch = o;
     if (op == WT_OP_MEDIAN) o = wt_align16(o + n_tracks * T * scratch_elem);
     else if (op == WT_OP_MWU) o = wt_align16(o + n_tracks * T * (scratch_elem + 4));   // values + per-rank attributes
@@ -61,35 +65,51 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
                                 int soft_limit = 80 * 1024, int hard_limit = 160 * 1024) {
     const char *eP = getenv("WTAMD_PPT");
     const char *eT = getenv("WTAMD_T");
-    // median of float tracks with few enough tracks sorts in registers: no LDS scratch column
-    int nreg = 0;
-    // (disabled: a fully unrolled 128-key bitonic network makes hipcc take > 20 min on this
-    //  kernel; the template parameter is kept for a later, partially rolled variant)
-    if (op == WT_OP_MEDIAN && scratch_f32 && n_tracks <= 128 && getenv("WTAMD_MEDIAN_REGS") && false)
-        nreg = n_tracks <= 32 ? 32 : n_tracks <= 64 ? 64 : 128;
-    const bool scr = wt_op_needs_scratch(op) && nreg == 0;
+    const bool scr = wt_op_needs_scratch(op);
     const int scratch_elem = scr ? (scratch_f32 ? 4 : 8) : 0;
     struct Cand { int ppt, T; };
     std::vector<Cand> cands;
     if (eP || eT) {
-        const int ppt = (scr || nreg) ? 1 : (eP ? atoi(eP) : 4);
+        const int ppt = scr ? 1 : (eP ? atoi(eP) : 4);
         const int T = eT ? atoi(eT) : 256;
         if ((ppt == 1 || ppt == 4) && T >= 64 && T <= 512 && !(T & (T - 1))) cands.push_back({ppt, T});
     }
     if (cands.empty()) {
-        if (scr || nreg) cands = {{1, 256}, {1, 128}, {1, 64}};
+        if (scr) cands = {{1, 256}, {1, 128}, {1, 64}};
         else cands = {{4, 512}, {4, 256}, {1, 512}, {1, 256}, {1, 128}, {1, 64}};
     }
     // Measured on MI355X (round 1): the widest window that fits ONE workgroup's LDS wins, even
     // when that leaves a single workgroup per CU (mean/200 tracks: 7.4 vs 8.5 ms, var/500: 47 vs
     // 71 ms, median/100: 51 vs 59 ms) -- per-window fixed costs outweigh inter-workgroup overlap.
     (void) soft_limit;
+    const char *eC = getenv("WTAMD_CHUNK");     // experiments / tests: force a chunk size
     for (const Cand &cd : cands) {
         WtPlan p;
-        wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p);
+        wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p, eC ? atoi(eC) : 0);
         p.ppt = cd.ppt;
-        p.nreg = nreg;
-        if (p.lds_bytes <= hard_limit - 1024) { out = p; return true; }
+        if (p.lds_bytes <= hard_limit - 1024) {
+            // many tracks: a narrow window with every track resident loses to the widest window
+            // with the tracks visited in chunks (their bitmaps rebuilt per chunk and pass)
+            if (!eC && !scr && cd.ppt * cd.T < 1024 && p.n_chunks == 1) break;
+            out = p;
+            return true;
+        }
+    }
+    // chunked: widest geometry, as many tracks per chunk as fit
+    for (const Cand &cd : cands) {
+        int best = 0;
+        for (int chunk = std::min(n_tracks, 4096); chunk >= 1; chunk = chunk > 64 ? chunk - 8 : chunk - 1) {
+            WtPlan p;
+            wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p, chunk);
+            if (p.lds_bytes <= hard_limit - 1024) { best = chunk; break; }
+        }
+        if (best < 16 && best < n_tracks) continue;
+        const int n_chunks = (n_tracks + best - 1) / best;
+        WtPlan p;
+        wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p, (n_tracks + n_chunks - 1) / n_chunks);
+        p.ppt = cd.ppt;
+        out = p;
+        return true;
     }
     err = "no LDS plan fits " + std::to_string(n_tracks) + " tracks (op " + std::to_string(op) + ")";
     return false;
@@ -97,6 +117,7 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
 
 static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.W = p.W; P.n_words = p.n_words; P.spitch = p.spitch; P.cpitch = p.cpitch; P.count_segs = p.count_segs;
+    P.chunk_tracks = p.chunk_tracks; P.n_chunks = p.n_chunks;
     P.logW = 0;
     while ((1 << P.logW) < p.W) P.logW++;
     P.off_S = p.off_S; P.off_cnt = p.off_cnt; P.off_segtot = p.off_segtot; P.off_U = p.off_U; P.off_cover = p.off_cover; P.off_E = p.off_E;
@@ -162,38 +183,45 @@ static inline void wt_make_windows(int n_chrom, int n_tracks, const int64_t *seg
 }
 
 // Template dispatch over (op, value type, scratch type).  F must provide
-//   template <int OP, class ValT, class ScrT> void run();
+//   template <int OP, class ValT, class ScrT, int K, bool MULTI> void run();
+// MULTI: the tracks are visited in more than one chunk (bitmaps rebuilt per chunk and pass).
 // Streaming ops ignore ScrT (ScrT = ValT keeps the instantiation count down).
 template <int OP, int K, class F>
-static inline void wt_dispatch_types2(bool value_f64, bool scratch_f32, int nreg, F &f) {
+static inline void wt_dispatch_types2(bool value_f64, bool scratch_f32, bool multi, F &f) {
     // ScrT == float <=> float tracks whose defaults are float-exact (f32 select / f32 scratch)
-    if (value_f64) f.template run<OP, double, double, K, 0>();
-    else if (!scratch_f32) f.template run<OP, float, double, K, 0>();
-    else f.template run<OP, float, float, K, 0>();
+    if (multi) {
+        if (value_f64) f.template run<OP, double, double, K, true>();
+        else if (!scratch_f32) f.template run<OP, float, double, K, true>();
+        else f.template run<OP, float, float, K, true>();
+    } else {
+        if (value_f64) f.template run<OP, double, double, K, false>();
+        else if (!scratch_f32) f.template run<OP, float, double, K, false>();
+        else f.template run<OP, float, float, K, false>();
+    }
 }
 
 template <int OP, class F>
-static inline void wt_dispatch_types(bool value_f64, bool scratch_f32, int ppt, int nreg, F &f) {
-    if (wt_op_needs_scratch(OP) || ppt == 1) wt_dispatch_types2<OP, 1>(value_f64, scratch_f32, nreg, f);
-    else wt_dispatch_types2<OP, 4>(value_f64, scratch_f32, nreg, f);
+static inline void wt_dispatch_types(bool value_f64, bool scratch_f32, int ppt, bool multi, F &f) {
+    if (wt_op_needs_scratch(OP) || ppt == 1) wt_dispatch_types2<OP, 1>(value_f64, scratch_f32, multi, f);
+    else wt_dispatch_types2<OP, 4>(value_f64, scratch_f32, multi, f);
 }
 
 template <class F>
-static inline bool wt_dispatch(int op, bool value_f64, bool scratch_f32, int ppt, int nreg, F &f) {
+static inline bool wt_dispatch(int op, bool value_f64, bool scratch_f32, int ppt, bool multi, F &f) {
     switch (op) {
-    case WT_OP_SUM: wt_dispatch_types<WT_OP_SUM>(value_f64, scratch_f32, ppt, nreg, f); return true;
-    case WT_OP_PRODUCT: wt_dispatch_types<WT_OP_PRODUCT>(value_f64, scratch_f32, ppt, nreg, f); return true;
-    case WT_OP_MEAN: wt_dispatch_types<WT_OP_MEAN>(value_f64, scratch_f32, ppt, nreg, f); return true;
-    case WT_OP_VAR: wt_dispatch_types<WT_OP_VAR>(value_f64, scratch_f32, ppt, nreg, f); return true;
+    case WT_OP_SUM: wt_dispatch_types<WT_OP_SUM>(value_f64, scratch_f32, ppt, multi, f); return true;
+    case WT_OP_PRODUCT: wt_dispatch_types<WT_OP_PRODUCT>(value_f64, scratch_f32, ppt, multi, f); return true;
+    case WT_OP_MEAN: wt_dispatch_types<WT_OP_MEAN>(value_f64, scratch_f32, ppt, multi, f); return true;
+    case WT_OP_VAR: wt_dispatch_types<WT_OP_VAR>(value_f64, scratch_f32, ppt, multi, f); return true;
     case WT_OP_STDDEV: case WT_OP_ENTROPY:   // reference reducers.c:665: entropy runs the stddev pop
-        wt_dispatch_types<WT_OP_STDDEV>(value_f64, scratch_f32, ppt, nreg, f); return true;
-    case WT_OP_CV: wt_dispatch_types<WT_OP_CV>(value_f64, scratch_f32, ppt, nreg, f); return true;
-    case WT_OP_MIN: wt_dispatch_types<WT_OP_MIN>(value_f64, scratch_f32, ppt, nreg, f); return true;
-    case WT_OP_MAX: wt_dispatch_types<WT_OP_MAX>(value_f64, scratch_f32, ppt, nreg, f); return true;
-    case WT_OP_MEDIAN: wt_dispatch_types<WT_OP_MEDIAN>(value_f64, scratch_f32, ppt, nreg, f); return true;
-    case WT_OP_TTEST: wt_dispatch_types<WT_OP_TTEST>(value_f64, scratch_f32, ppt, nreg, f); return true;
-    case WT_OP_MWU: wt_dispatch_types<WT_OP_MWU>(value_f64, scratch_f32, ppt, nreg, f); return true;
-    case WT_OP_MULTIPLEX: wt_dispatch_types<WT_OP_MULTIPLEX>(value_f64, scratch_f32, ppt, nreg, f); return true;
+        wt_dispatch_types<WT_OP_STDDEV>(value_f64, scratch_f32, ppt, multi, f); return true;
+    case WT_OP_CV: wt_dispatch_types<WT_OP_CV>(value_f64, scratch_f32, ppt, multi, f); return true;
+    case WT_OP_MIN: wt_dispatch_types<WT_OP_MIN>(value_f64, scratch_f32, ppt, multi, f); return true;
+    case WT_OP_MAX: wt_dispatch_types<WT_OP_MAX>(value_f64, scratch_f32, ppt, multi, f); return true;
+    case WT_OP_MEDIAN: wt_dispatch_types<WT_OP_MEDIAN>(value_f64, scratch_f32, ppt, multi, f); return true;
+    case WT_OP_TTEST: wt_dispatch_types<WT_OP_TTEST>(value_f64, scratch_f32, ppt, multi, f); return true;
+    case WT_OP_MWU: wt_dispatch_types<WT_OP_MWU>(value_f64, scratch_f32, ppt, multi, f); return true;
+    case WT_OP_MULTIPLEX: wt_dispatch_types<WT_OP_MULTIPLEX>(value_f64, scratch_f32, ppt, multi, f); return true;
     default: return false;
     }
 }
