@@ -22,13 +22,13 @@ def lib():
     return _lib
 
 
-def reduce(t, op, flags=0, n_set0=0, ppt=None, T=None, multiplex=False, ranges=None, chunk=None):
+def reduce(t, op, flags=0, n_set0=0, ppt=None, T=None, multiplex=False, ranges=None, chunk=None, global_scratch=None):
     """t: RunLists.  Returns (chrom, start, finish, value) [+ (tile, inplay) if multiplex], info."""
     from oracle.oracle import OPS
     opcode = 12 if multiplex else (OPS[op] if isinstance(op, str) else int(op))
-    old = {k: os.environ.get(k) for k in ("WTAMD_PPT", "WTAMD_T", "WTAMD_CHUNK")}
+    old = {k: os.environ.get(k) for k in ("WTAMD_PPT", "WTAMD_T", "WTAMD_CHUNK", "WTAMD_GLOBAL_SCRATCH")}
     try:
-        for k, v in (("WTAMD_PPT", ppt), ("WTAMD_T", T), ("WTAMD_CHUNK", chunk)):
+        for k, v in (("WTAMD_PPT", ppt), ("WTAMD_T", T), ("WTAMD_CHUNK", chunk), ("WTAMD_GLOBAL_SCRATCH", global_scratch)):
             if v is None:
                 os.environ.pop(k, None)
             else:
@@ -64,5 +64,5 @@ def reduce(t, op, flags=0, n_set0=0, ppt=None, T=None, multiplex=False, ranges=N
     out = (chrom, os_[:n].copy(), of[:n].copy(), ov[:n].copy())
     if multiplex:
         out = (chrom, os_[:n].copy(), of[:n].copy(), tile[:n].copy(), ip[:n].copy())
-    return out, dict(W=int(info[0]), T=int(info[1]), lds=int(info[2]), n_windows=int(info[3]), n_chunks=int(info[6]),
+    return out, dict(W=int(info[0]), T=int(info[1]), lds=int(info[2]), n_windows=int(info[3]), n_chunks=int(info[6]), scratch_slab=int(info[7]),
                      covered_bp=int(info[4]), n_intervals=int(info[5]))

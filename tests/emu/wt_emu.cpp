@@ -28,6 +28,8 @@ struct EmuRun {
     void run() {
         WtCtx c;
         wt_ctx_init(c, P, lds.data());
+        std::vector<char> slab((size_t) P.g_scratch_slab);
+        if (P.g_scratch_slab) c.scratch = slab.data();      // one emulated workgroup: one slab
         const int T = plan.T;
         std::vector<WtLane<K>> lanes(T);
         for (;;) {
@@ -119,8 +121,8 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
     }
 
     R.lds.assign((size_t) R.plan.lds_bytes + 64, 0);
-    if (total > 0 && !wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R.plan.n_chunks > 1, R)) return -11;
-    if (info) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows; info[6] = R.plan.n_chunks;
+    if (total > 0 && !wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R.plan.n_chunks > 1 || R.plan.scratch_slab > 0, R)) return -11;
+    if (info) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows; info[6] = R.plan.n_chunks; info[7] = R.plan.scratch_slab;
                 info[4] = (long long) counters[WT_CTR_BP]; info[5] = (long long) counters[WT_CTR_INTERVALS]; }
     if (counters[WT_CTR_ERROR] & WT_ERR_CAPACITY) return -1;
     if (counters[WT_CTR_ERROR]) return -2;

@@ -139,3 +139,38 @@ def test_emu_chunked_tracks(oracle, seed):
             got, info = emu.reduce(t, op, flags=flags, n_set0=n1, ppt=ppt, T=T, chunk=chunk)
             assert_runs_equal(got, exp, 1e-12 if op == "ttest" else 0.0,
                               "seed %d op %s flags %d %s" % (seed, op, flags, info))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_emu_global_scratch_columns(oracle, seed):
+    """median / MWU with the per-lane columns in a global slab (very many tracks), chunked bitmaps."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(5, 14))
+    t = random_case(1700 + seed, n_tracks=n, dtype=np.float64 if seed % 2 else np.float32)
+    d = t.as_dict()
+    chunk = int(rng.integers(1, n + 1)) if seed % 3 else None
+    n1 = int(rng.integers(2, n - 1))
+    for flags in (0, 1):
+        exp = oracle.reduce(d, "median", flags=flags)
+        got, info = emu.reduce(t, "median", flags=flags, chunk=chunk, global_scratch=1)
+        assert info["scratch_slab"] > 0
+        assert_runs_equal(got, exp, 0.0, "seed %d median flags %d %s" % (seed, flags, info))
+    for flags in (0, 1, 2, 3):
+        exp = oracle.reduce(d, "mwu", flags=flags, n_set0=n1)
+        got, info = emu.reduce(t, "mwu", flags=flags, n_set0=n1, chunk=chunk, global_scratch=1)
+        assert info["scratch_slab"] > 0
+        assert_runs_equal(got, exp, 0.0, "seed %d mwu flags %d %s" % (seed, flags, info))
+
+
+def test_emu_many_tracks_plans(oracle):
+    """Track counts beyond one workgroup's LDS: chunked bitmaps / global columns chosen automatically."""
+    t = random_case(77, n_tracks=700)
+    d = t.as_dict()
+    for op, kw in (("mean", {}), ("var", {}), ("median", {}), ("mwu", dict(n_set0=300)), ("ttest", dict(n_set0=300))):
+        exp = oracle.reduce(d, op, **kw)
+        got, info = emu.reduce(t, op, **kw)
+        if op in ("median", "mwu"):
+            assert info["scratch_slab"] > 0
+        else:
+            assert info["n_chunks"] > 1
+        assert_runs_equal(got, exp, 1e-12 if op == "ttest" else 0.0, "%s %s" % (op, info))

@@ -86,6 +86,25 @@ def test_gpu_config_sized_tracks(oracle, engine, n_tracks, ops):
     ts.close()
 
 
+def test_gpu_many_tracks_chunked(oracle, engine):
+    """More tracks than one workgroup's LDS holds: bitmaps rebuilt per chunk and pass (streaming ops,
+    Multiplexer tile), median / MWU columns in a global slab per workgroup."""
+    from wiggletools_amd.runlists import synth
+    t = synth(700, [9000, 2500, 7], mean_run=16, seed=700)
+    d = t.as_dict()
+    ts = engine.TrackSet.from_runlists(t)
+    for op, kw in (("mean", {}), ("var", {}), ("max", {}), ("median", {}),
+                   ("mwu", dict(n_set0=300)), ("ttest", dict(n_set0=300))):
+        exp = oracle.reduce(d, op, **kw)
+        got = ts.reduce_host(op, **kw)
+        assert_runs_equal(got, exp, _tol(op), "N 700 op %s" % op)
+    exp = oracle.multiplex(d)
+    got = ts.multiplex_host()
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b, equal_nan=True)
+    ts.close()
+
+
 def test_gpu_wilcoxon_50_vs_50(oracle, engine):
     """BASELINE config C5 shape (n1 = n2 = 50: mu = 1250, sigma = sqrt(21041))."""
     from wiggletools_amd.runlists import synth

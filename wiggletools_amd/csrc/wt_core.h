@@ -98,6 +98,8 @@ struct WtParams {
     int64_t *chrom_run_off;       // [n_chrom+1]
     double *o_tile;               // WT_OP_MULTIPLEX only: [capacity * n_tracks]
     uint8_t *o_inplay;            // WT_OP_MULTIPLEX only
+    char *g_scratch;              // median / MWU with more tracks than LDS columns hold: one slab per workgroup
+    long long g_scratch_slab;     // bytes per workgroup (0: the columns live in LDS)
     // ---- LDS carve (bytes from the dynamic LDS base; all multiples of 16) ----
     int32_t chunk_tracks;         // tracks whose bitmaps are resident in LDS at a time (== n_tracks: one chunk)
     int32_t n_chunks;             // ceil(n_tracks / chunk_tracks)

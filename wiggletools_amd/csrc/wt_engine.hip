@@ -42,6 +42,8 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
     wt_ctx_init(c, P, wt_lds);
+    if (MULTI && (OP == WT_OP_MEDIAN || OP == WT_OP_MWU) && P.g_scratch_slab)
+        c.scratch = P.g_scratch + (size_t) blockIdx.x * (size_t) P.g_scratch_slab;
     WtLane<K> L;
     const int tid = threadIdx.x, nt = blockDim.x;
 #ifdef WT_DEBUG_MARK
@@ -267,6 +269,8 @@ struct wtamd_trackset {
     unsigned long long *h_counters = nullptr;   // pinned
     unsigned long long *h_debug = nullptr;      // pinned, device-visible (debug builds)
     int64_t *d_chrom_run_off = nullptr;         // scratch when the caller passes none
+    char *d_gscratch = nullptr;                 // median / MWU columns of very many tracks (grown on demand)
+    size_t gscratch_bytes = 0;
     std::map<int, WtWindows> windows;           // keyed by W
     hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
     bool have_index_time = false, have_reduce_time = false;
@@ -396,7 +400,7 @@ int wtamd_trackset_create_device(const wtamd_tracks *t, wtamd_trackset **out) {
 void wtamd_trackset_destroy(wtamd_trackset *ts) {
     if (!ts) return;
     if (ts->owns) { (void) hipFree(ts->d_start); (void) hipFree(ts->d_finish); (void) hipFree(ts->d_value); }
-    (void) hipFree(ts->d_seg_off); (void) hipFree(ts->d_defaults); (void) hipFree(ts->d_counters); (void) hipFree(ts->d_chrom_run_off);
+    (void) hipFree(ts->d_seg_off); (void) hipFree(ts->d_defaults); (void) hipFree(ts->d_counters); (void) hipFree(ts->d_chrom_run_off); (void) hipFree(ts->d_gscratch);
     if (ts->h_counters) (void) hipHostFree(ts->h_counters);
     if (ts->h_debug) (void) hipHostFree(ts->h_debug);
     for (auto &kv : ts->windows) wt_free_windows(kv.second);
@@ -511,6 +515,8 @@ struct WtLaunch {
     int T = 0, lds = 0, grid = 0;
     hipStream_t stream = nullptr;
     int num_cu = 256;
+    char **gscratch = nullptr;
+    size_t *gscratch_bytes = nullptr;
     hipError_t err = hipSuccess;
 
     template <int OP, class ValT, class ScrT, int K, bool MULTI>
@@ -527,6 +533,18 @@ struct WtLaunch {
         long long g = (long long) num_cu * per_cu;
         if (g > P.n_windows) g = P.n_windows;
         if (g < 1) g = 1;
+        if (P.g_scratch_slab) {     // global scratch columns: one slab per resident workgroup
+            if (g > 2ll * num_cu) g = 2ll * num_cu;
+            const size_t need = (size_t) g * (size_t) P.g_scratch_slab;
+            if (*gscratch_bytes < need) {
+                (void) hipFree(*gscratch);      // synchronises with earlier launches
+                *gscratch = nullptr; *gscratch_bytes = 0;
+                err = hipMalloc((void **) gscratch, need);
+                if (err != hipSuccess) return;
+                *gscratch_bytes = need;
+            }
+            P.g_scratch = *gscratch;
+        }
         grid = (int) g;
         hipLaunchKernelGGL(kern, dim3((unsigned) grid), dim3((unsigned) T), (size_t) lds, stream, P);
         err = hipGetLastError();
@@ -573,13 +591,14 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
     L.P.chrom_run_off = runs->chrom_run_off ? runs->chrom_run_off : ts->d_chrom_run_off;
     L.P.o_tile = d_tile; L.P.o_inplay = d_inplay;
     L.T = plan.T; L.lds = plan.lds_bytes; L.stream = s; L.num_cu = ts->num_cu;
+    L.gscratch = &ts->d_gscratch; L.gscratch_bytes = &ts->gscratch_bytes;
 
     WT_HIP(hipMemsetAsync(ts->d_counters, 0, sizeof(unsigned long long) * WT_CTR_N, s));
     WT_HIP(hipMemsetAsync(L.P.chrom_run_off, 0, sizeof(int64_t) * (ts->n_chrom + 1), s));
     if (w->tab.n_windows > 0 && ts->n_intervals > 0) {
         WT_HIP(hipMemsetAsync(w->d_status, 0, sizeof(unsigned long long) * w->tab.n_windows, s));
         WT_HIP(hipEventRecord(ts->ev_r0, s));
-        if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, plan.n_chunks > 1, L)) return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
+        if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, plan.n_chunks > 1 || plan.scratch_slab > 0, L)) return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
         if (L.err != hipSuccess) return wt_fail(WTAMD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(L.err));
         WT_HIP(hipEventRecord(ts->ev_r1, s));
         ts->have_reduce_time = true;

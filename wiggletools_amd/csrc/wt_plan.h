@@ -22,6 +22,7 @@ struct WtPlan {
     int off_S = 0, off_cnt = 0, off_segtot = 0, off_U = 0, off_cover = 0, off_E = 0, off_epfx = 0, off_nextw = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
     int lds_bytes = 0;
     int scratch_elem = 0;   // bytes per scratch element (0: op needs no scratch)
+    long long scratch_slab = 0;   // > 0: scratch columns in global memory, this many bytes per workgroup
     int ppt = 1;            // consecutive window positions per lane (1 or 4)
 };
 
@@ -31,7 +32,8 @@ static inline bool wt_op_needs_scratch(int op) { return op == WT_OP_MEDIAN || op
 
 // LDS bytes for a candidate (W, T)
 // n_tracks: all tracks (scratch columns); chunk: tracks whose bitmaps are resident at a time
-static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem, WtPlan &p, int chunk = 0) {
+static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem, WtPlan &p, int chunk = 0,
+                            bool scratch_global = false) {
     if (chunk <= 0 || chunk > n_tracks) chunk = n_tracks;
     p.chunk_tracks = chunk;
     p.n_chunks = (n_tracks + chunk - 1) / chunk;
@@ -52,8 +54,12 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
     p.off_nextw = o;   o = wt_align16(o + p.n_words * 2);
     p.off_gbase = o;   o = wt_align16(o + chunk * 8);
     p.off_scratch = o;
-    if (op == WT_OP_MEDIAN) o = wt_align16(o + n_tracks * T * scratch_elem);
-    else if (op == WT_OP_MWU) o = wt_align16(o + n_tracks * T * (scratch_elem + 4));   // values + per-rank attributes
+    long long scr_bytes = 0;
+    if (op == WT_OP_MEDIAN) scr_bytes = (long long) n_tracks * T * scratch_elem;
+    else if (op == WT_OP_MWU) scr_bytes = (long long) n_tracks * T * (scratch_elem + 4);   // values + per-rank attributes
+    scr_bytes = (scr_bytes + 255) & ~255ll;
+    p.scratch_slab = scratch_global ? scr_bytes : 0;
+    if (!scratch_global) o = (int) std::min<long long>(o + scr_bytes, 1 << 30);
     p.off_shared = o;  o = wt_align16(o + (int) sizeof(WtShared));
     p.lds_bytes = o;
 }
@@ -78,38 +84,61 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
         if (scr) cands = {{1, 256}, {1, 128}, {1, 64}};
         else cands = {{4, 512}, {4, 256}, {1, 512}, {1, 256}, {1, 128}, {1, 64}};
     }
-    // Measured on MI355X (round 1): the widest window that fits ONE workgroup's LDS wins, even
-    // when that leaves a single workgroup per CU (mean/200 tracks: 7.4 vs 8.5 ms, var/500: 47 vs
-    // 71 ms, median/100: 51 vs 59 ms) -- per-window fixed costs outweigh inter-workgroup overlap.
+    // Measured on MI355X (round 1):
+    //  * the widest window wins: per-window fixed costs (header, scans, look-back, barriers)
+    //    outweigh everything else (mean/200 tracks: W=2048 7.4 ms vs W=1024 8.5 ms);
+    //  * two workgroups per CU beat one: with more tracks than fit in HALF the CU's LDS the
+    //    tracks are visited in chunks whose bitmaps are rebuilt per chunk and pass
+    //    (sum/1000: 28 ms chunked at 79 KB vs 48 ms at 140 KB; var/500: 25 vs 40; mean/200: 5.8 vs 7.4);
+    //  * scratch-column ops (median, MWU) keep every track resident in the widest window that
+    //    fits (median/100: 51 vs 59 ms), chunking only when nothing else fits.
+    const int limit = hard_limit - 1024;
+    const int half = hard_limit / 2 - 512;
     (void) soft_limit;
     const char *eC = getenv("WTAMD_CHUNK");     // experiments / tests: force a chunk size
-    for (const Cand &cd : cands) {
+    auto try_plan = [&](const Cand &cd, int chunk, int lim, bool glob = false) -> bool {
         WtPlan p;
-        wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p, eC ? atoi(eC) : 0);
+        wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p, chunk, glob);
         p.ppt = cd.ppt;
-        if (p.lds_bytes <= hard_limit - 1024) {
-            // many tracks: a narrow window with every track resident loses to the widest window
-            // with the tracks visited in chunks (their bitmaps rebuilt per chunk and pass)
-            if (!eC && !scr && cd.ppt * cd.T < 1024 && p.n_chunks == 1) break;
-            out = p;
-            return true;
-        }
-    }
-    // chunked: widest geometry, as many tracks per chunk as fit
-    for (const Cand &cd : cands) {
-        int best = 0;
-        for (int chunk = std::min(n_tracks, 4096); chunk >= 1; chunk = chunk > 64 ? chunk - 8 : chunk - 1) {
-            WtPlan p;
-            wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p, chunk);
-            if (p.lds_bytes <= hard_limit - 1024) { best = chunk; break; }
-        }
-        if (best < 16 && best < n_tracks) continue;
-        const int n_chunks = (n_tracks + best - 1) / best;
-        WtPlan p;
-        wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p, (n_tracks + n_chunks - 1) / n_chunks);
-        p.ppt = cd.ppt;
+        if (p.lds_bytes > lim) return false;
         out = p;
         return true;
+    };
+    auto max_chunk = [&](const Cand &cd, int lim, bool glob = false) -> int {
+        int lo = 0, hi = n_tracks;          // largest chunk whose plan fits `lim` (lds grows with chunk)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) / 2;
+            WtPlan p;
+            wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p, mid, glob);
+            if (p.lds_bytes <= lim) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    };
+    const bool eG = scr && getenv("WTAMD_GLOBAL_SCRATCH");   // experiments / tests: force global columns
+    if (eC || eG) {
+        for (const Cand &cd : cands)
+            if (try_plan(cd, eC ? atoi(eC) : 0, limit, eG)) return true;
+    } else if (!scr) {
+        const Cand &cd = cands[0];
+        if (try_plan(cd, 0, half)) return true;
+        const int best = max_chunk(cd, half);
+        if (best >= 16) {
+            const int n_chunks = (n_tracks + best - 1) / best;
+            if (try_plan(cd, (n_tracks + n_chunks - 1) / n_chunks, half)) return true;
+        }
+        for (const Cand &c2 : cands)
+            if (try_plan(c2, 0, limit)) return true;
+    } else {
+        for (const Cand &cd : cands)
+            if (try_plan(cd, 0, limit)) return true;
+        // more tracks than LDS columns hold: the columns move to a global slab per workgroup
+        // (coalesced: element i of lane l at [i][l]); the bitmaps are chunked to half the LDS
+        for (const Cand &cd : cands) {
+            const int best = max_chunk(cd, half, true);
+            if (best < 1) continue;
+            const int n_chunks = (n_tracks + best - 1) / best;
+            if (try_plan(cd, (n_tracks + n_chunks - 1) / n_chunks, half, true)) return true;
+        }
     }
     err = "no LDS plan fits " + std::to_string(n_tracks) + " tracks (op " + std::to_string(op) + ")";
     return false;
@@ -118,6 +147,7 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
 static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.W = p.W; P.n_words = p.n_words; P.spitch = p.spitch; P.cpitch = p.cpitch; P.count_segs = p.count_segs;
     P.chunk_tracks = p.chunk_tracks; P.n_chunks = p.n_chunks;
+    P.g_scratch = nullptr; P.g_scratch_slab = p.scratch_slab;
     P.logW = 0;
     while ((1 << P.logW) < p.W) P.logW++;
     P.off_S = p.off_S; P.off_cnt = p.off_cnt; P.off_segtot = p.off_segtot; P.off_U = p.off_U; P.off_cover = p.off_cover; P.off_E = p.off_E;
