@@ -71,6 +71,44 @@ struct EmuRun {
             wt_window_stats(P, c);
         }
     }
+
+    template <int OP>
+    void run_delta() {
+        WtCtx c;
+        wt_ctx_init(c, P, lds.data());
+        WtDeltaCtx d;
+        wt_delta_ctx_init(d, P, lds.data());
+        const int T = plan.T;
+        std::vector<WtDeltaLane> dl(T);
+        std::vector<WtLane<WT_DELTA_K>> lanes(T);
+        for (;;) {
+            const long long k = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+            if (k >= P.n_windows) break;
+            wt_phase_header(P, c, k);
+            for (int t = 0; t < T; t++) wt_delta_zero(P, c, d, t, T);
+            const int nchunks = (P.n_tracks + T - 1) / T;
+            for (int pass = 1; pass <= 2; pass++) {
+                for (int ch = 0; ch < nchunks; ch++) {
+                    if (pass == 1 || nchunks > 1) {     // one chunk: pass 2 reuses pass 1's ranges
+                        for (int t = 0; t < T; t++) wt_delta_ranges1(P, c, d, ch * T, t, T);
+                        for (int t = 0; t < T; t++) wt_delta_ranges2(P, c, d, t, T);
+                        for (int t = 0; t < T; t++) wt_delta_ranges3(P, c, d, t, T);
+                    }
+                    if (pass == 1) for (int t = 0; t < T; t++) wt_delta_pass1(P, c, d, t, T);
+                    else for (int t = 0; t < T; t++) wt_delta_pass2(P, c, d, t, T);
+                }
+                if (pass == 1) wt_delta_decide(P, c, d);
+            }
+            for (int t = 0; t < T; t++) wt_delta_scan1(P, c, d, dl[t], t, T);
+            for (int t = 0; t < T; t++) wt_delta_scan2(P, c, d, t, T);
+            for (int t = 0; t < T; t++) wt_delta_scan3<OP>(P, c, d, dl[t], lanes[t], t, T);
+            for (int t = 0; t < T; t++) wt_delta_nextw(P, c, t, T);
+            for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
+            wt_phase_lookback(P, c, k);
+            for (int t = 0; t < T; t++) wt_phase_write<OP, float, WT_DELTA_K>(P, c, lanes[t], t, T);
+            wt_window_stats(P, c);
+        }
+    }
 };
 
 }  // namespace
@@ -85,45 +123,66 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
                        int32_t *o_start, int32_t *o_finish, double *o_value, int64_t *chrom_run_off,
                        double *o_tile, uint8_t *o_inplay, long long *info,
                        const int32_t *range_lo, const int32_t *range_hi) {
-    EmuRun R;
-    std::string err;
     const bool s32 = !value_is_f64 && wt_defaults_fit_f32(defaults, n_tracks);
-    if (!wt_make_plan(n_tracks, op, s32, R.plan, err)) { fprintf(stderr, "wtemu: %s\n", err.c_str()); return -10; }
     const int64_t n_seg = (int64_t) n_chrom * n_tracks;
     std::vector<int32_t> fs(n_seg, 0), lf(n_seg, 0);
     for (int64_t s = 0; s < n_seg; s++)
         if (seg_off[s + 1] > seg_off[s]) { fs[s] = start[seg_off[s]]; lf[s] = finish[seg_off[s + 1] - 1]; }
-    WtWindowTables tab;
-    wt_make_windows(n_chrom, n_tracks, seg_off, fs.data(), lf.data(), R.plan.W, tab, range_lo, range_hi);
-
-    std::vector<uint32_t> widx((size_t) tab.n_rows * n_tracks, 0);
-    std::vector<unsigned long long> status(tab.n_windows, 0), counters(WT_CTR_N, 0);
-
-    WtParams &P = R.P;
-    memset(&P, 0, sizeof(P));
-    P.start = start; P.finish = finish; P.value = value; P.seg_off = seg_off; P.defaults = defaults;
-    P.n_chrom = n_chrom; P.n_tracks = n_tracks;
-    P.cbase = tab.cbase.data(); P.c_nwin = tab.c_nwin.data(); P.c_hi = tab.c_hi.data(); P.c_first_win = tab.c_first_win.data();
-    P.n_windows = tab.n_windows; P.win_chrom = tab.win_chrom.data(); P.widx = widx.data();
-    P.op = op; P.flags = flags; P.n_set0 = n_set0;
-    P.status = status.data(); P.counters = counters.data();
-    P.capacity = capacity; P.o_start = o_start; P.o_finish = o_finish; P.o_value = o_value;
-    P.chrom_run_off = chrom_run_off; P.o_tile = o_tile; P.o_inplay = o_inplay;
-    wt_plan_to_params(R.plan, P);
-
-    // window index "kernel"
     const int64_t total = seg_off[n_seg];
-    P.n_total = total;
-    if (total > 0) {
-        WtIndexCursor cur;
-        wt_index_cursor_set(P, cur, wt_index_find_segment(P, 0));
-        for (int64_t g = 0; g < total; g++) wt_index_apply(P, cur, g, finish[g], g > 0 ? finish[g - 1] : 0);
-    }
+    std::vector<unsigned long long> counters(WT_CTR_N, 0);
+    long long used_delta = 0, delta_bad = 0;
+    // the engine's policy: exact difference-array path first when eligible, the general kernel
+    // if any window had to give up
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const bool delta = attempt == 0 && o_tile == nullptr && wt_delta_eligible(op, value_is_f64 != 0, n_tracks, defaults);
+        if (attempt == 0 && !delta) continue;
+        EmuRun R;
+        std::string err;
+        if (delta) wt_make_delta_plan(R.plan, n_tracks);
+        else if (!wt_make_plan(n_tracks, op, s32, R.plan, err)) { fprintf(stderr, "wtemu: %s\n", err.c_str()); return -10; }
+        WtWindowTables tab;
+        wt_make_windows(n_chrom, n_tracks, seg_off, fs.data(), lf.data(), R.plan.W, tab, range_lo, range_hi);
+        std::vector<uint32_t> widx((size_t) tab.n_rows * n_tracks, 0);
+        std::vector<unsigned long long> status(tab.n_windows, 0);
+        counters.assign(WT_CTR_N, 0);
 
-    R.lds.assign((size_t) R.plan.lds_bytes + 64, 0);
-    if (total > 0 && !wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R.plan.n_chunks > 1 || R.plan.scratch_slab > 0, R)) return -11;
-    if (info) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows; info[6] = R.plan.n_chunks; info[7] = R.plan.scratch_slab;
-                info[4] = (long long) counters[WT_CTR_BP]; info[5] = (long long) counters[WT_CTR_INTERVALS]; }
+        WtParams &P = R.P;
+        memset(&P, 0, sizeof(P));
+        P.start = start; P.finish = finish; P.value = value; P.seg_off = seg_off; P.defaults = defaults;
+        P.n_chrom = n_chrom; P.n_tracks = n_tracks;
+        P.cbase = tab.cbase.data(); P.c_nwin = tab.c_nwin.data(); P.c_hi = tab.c_hi.data(); P.c_first_win = tab.c_first_win.data();
+        P.n_windows = tab.n_windows; P.win_chrom = tab.win_chrom.data(); P.widx = widx.data();
+        P.op = op; P.flags = flags; P.n_set0 = n_set0;
+        P.status = status.data(); P.counters = counters.data();
+        P.capacity = capacity; P.o_start = o_start; P.o_finish = o_finish; P.o_value = o_value;
+        P.chrom_run_off = chrom_run_off; P.o_tile = o_tile; P.o_inplay = o_inplay;
+        wt_plan_to_params(R.plan, P);
+
+        // window index "kernel"
+        P.n_total = total;
+        if (total > 0) {
+            WtIndexCursor cur;
+            wt_index_cursor_set(P, cur, wt_index_find_segment(P, 0));
+            for (int64_t g = 0; g < total; g++) wt_index_apply(P, cur, g, finish[g], g > 0 ? finish[g - 1] : 0);
+        }
+
+        R.lds.assign((size_t) R.plan.lds_bytes + 64, 0);
+        if (total > 0) {
+            if (delta) {
+                if (op == WT_OP_SUM) R.run_delta<WT_OP_SUM>(); else R.run_delta<WT_OP_MEAN>();
+            } else if (!wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R.plan.n_chunks > 1 || R.plan.scratch_slab > 0, R)) {
+                return -11;
+            }
+        }
+        if (info) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows; info[6] = R.plan.n_chunks; info[7] = R.plan.scratch_slab;
+                    info[4] = (long long) counters[WT_CTR_BP]; info[5] = (long long) counters[WT_CTR_INTERVALS]; }
+        if (delta) {
+            delta_bad = (long long) counters[WT_CTR_DELTA_BAD];
+            used_delta = delta_bad == 0;
+            if (used_delta) break;
+        }
+    }
+    if (info) { info[8] = used_delta; info[9] = delta_bad; }
     if (counters[WT_CTR_ERROR] & WT_ERR_CAPACITY) return -1;
     if (counters[WT_CTR_ERROR]) return -2;
     return (long long) counters[WT_CTR_RUNS];

@@ -174,3 +174,116 @@ def test_emu_many_tracks_plans(oracle):
         else:
             assert info["n_chunks"] > 1
         assert_runs_equal(got, exp, 1e-12 if op == "ttest" else 0.0, "%s %s" % (op, info))
+
+
+# ---- exact difference-array path (wt_delta.h) ----
+def _delta_case(seed, n_tracks, clens, mean_run, value_fn, gap=0.1, first_start=1):
+    from wiggletools_amd.runlists import synth
+    t = synth(n_tracks, clens, mean_run=mean_run, gap_prob=gap, seed=seed, dtype=np.float32, first_start=first_start)
+    rng = np.random.default_rng(seed + 1)
+    t.value[:] = value_fn(rng, len(t.value)).astype(np.float32)
+    return t
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_emu_delta_sum_mean_exact(oracle, seed):
+    """Sum / Mean of float tracks with zero defaults through the difference-array path: bit-identical."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 12))
+    clens = [int(rng.integers(1, 3000)) for _ in range(int(rng.integers(1, 4)))]
+    kinds = [
+        lambda r, k: r.integers(-800, 800, k) / 8.0,                      # signed, ties, zeros
+        lambda r, k: r.random(k) * 1000.0,                                # full 24-bit mantissas
+        lambda r, k: np.ldexp(r.integers(1, 1 << 24, k).astype(np.float64), r.integers(-30, -10, k)),  # span < 29 - lg n
+        lambda r, k: np.where(r.random(k) < 0.3, 0.0, -r.random(k)),      # many zeros, negatives
+    ]
+    t = _delta_case(seed, n, clens, float(rng.choice([1, 3, 16, 200])), kinds[seed % 4],
+                    gap=float(rng.choice([0.0, 0.1, 0.6])), first_start=int(rng.choice([1, 5, 4097])))
+    d = t.as_dict()
+    for T in (64, 128):
+        for strict in (0, 1):
+            for op in ("sum", "mean"):
+                exp = oracle.reduce(d, op, flags=strict)
+                got, info = emu.reduce(t, op, flags=strict, delta_T=T)
+                assert info["delta"] == 1 and info["delta_bad"] == 0, info
+                assert info["W"] == 8 * T
+                assert_runs_equal(got, exp, 0.0, "seed %d op %s strict %d %s" % (seed, op, strict, info))
+                assert info["covered_bp"] == int((exp[2] - exp[1]).sum())
+
+
+def test_emu_delta_more_tracks_than_lanes(oracle):
+    """Track ranges are scanned in chunks of T tracks: 150 tracks on a 64-lane workgroup."""
+    t = _delta_case(3, 150, [1200, 90], 5, lambda r, k: r.integers(0, 2000, k) / 16.0, gap=0.2)
+    for strict in (0, 1):
+        for op in ("sum", "mean"):
+            exp = oracle.reduce(t.as_dict(), op, flags=strict)
+            got, info = emu.reduce(t, op, flags=strict, delta_T=64)
+            assert info["delta"] == 1 and info["T"] == 64
+            assert_runs_equal(got, exp, 0.0, "%s strict %d %s" % (op, strict, info))
+
+
+def test_emu_delta_dense_window_beyond_tile_table(oracle):
+    """A window holding more intervals than the tile table covers (binary-search fallback)."""
+    t = _delta_case(8, 150, [5000], 1, lambda r, k: r.integers(0, 64, k) / 4.0, gap=0.05)
+    exp = oracle.reduce(t.as_dict(), "mean")
+    got, info = emu.reduce(t, "mean", delta_T=512)
+    assert info["delta"] == 1 and info["T"] == 512 and info["n_intervals"] > 2048 * 256
+    assert_runs_equal(got, exp, 0.0, "dense %s" % info)
+
+
+def test_emu_delta_falls_back_on_wide_range_and_nonfinite(oracle):
+    """Windows whose values span too many binades, or hold NaN / Inf, are re-run by the general kernel."""
+    for kind in ("wide", "nan", "inf", "denormal"):
+        t = _delta_case(5, 6, [2000, 300], 8, lambda r, k: r.random(k) + 0.5)
+        if kind == "wide":
+            t.value[3] = np.float32(1e-30)
+        elif kind == "nan":
+            t.value[7] = np.nan
+        elif kind == "inf":
+            t.value[7] = np.inf
+        else:
+            t.value[:] = (t.value * np.float32(1e-42)).astype(np.float32)     # all denormal: still exact
+        for op in ("sum", "mean"):
+            exp = oracle.reduce(t.as_dict(), op)
+            got, info = emu.reduce(t, op, delta_T=64)
+            if kind == "denormal":
+                assert info["delta"] == 1
+            else:
+                assert info["delta"] == 0 and info["delta_bad"] > 0, info
+            assert_runs_equal(got, exp, 0.0, "%s %s %s" % (kind, op, info))
+
+
+def test_emu_delta_not_used_when_ineligible(oracle):
+    t = _delta_case(9, 5, [700], 8, lambda r, k: r.random(k))
+    t.defaults[2] = 1.5                                    # a non-zero default value
+    got, info = emu.reduce(t, "sum")
+    assert info["delta"] == 0 and info["delta_bad"] == 0
+    assert_runs_equal(got, oracle.reduce(t.as_dict(), "sum"), 0.0, "defaults")
+    from wiggletools_amd.runlists import synth
+    t64 = synth(4, [700], mean_run=8, seed=3, dtype=np.float64)
+    got, info = emu.reduce(t64, "mean")
+    assert info["delta"] == 0
+    assert_runs_equal(got, oracle.reduce(t64.as_dict(), "mean"), 0.0, "f64 tracks")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_emu_delta_ranges_concatenate(oracle, seed):
+    """Run-start ranges (batches / shards) through the difference-array path tile the full result."""
+    rng = np.random.default_rng(seed)
+    t = _delta_case(40 + seed, 5, [1500, 900], 6, lambda r, k: r.integers(0, 64, k) / 4.0, first_start=int(rng.choice([1, 300])))
+    full = oracle.reduce(t.as_dict(), "mean")
+    cuts = sorted(int(x) for x in rng.integers(1, 1900, 3))
+    edges = [-(2 ** 31 - 1)] + cuts + [2 ** 31 - 1]
+    parts = []
+    for a, b in zip(edges[:-1], edges[1:]):
+        got, info = emu.reduce(t, "mean", delta_T=64, ranges=[(a, b)] * t.n_chrom)
+        assert info["delta"] == 1
+        parts.append(got)
+    cat = [[], [], [], []]
+    for c in range(t.n_chrom):
+        for g in parts:
+            m = g[0] == c
+            for k in range(4):
+                cat[k].append(g[k][m])
+    cat = tuple(np.concatenate(x) for x in cat)
+    assert_runs_equal(cat, full, 0.0, "ranges")

@@ -105,6 +105,43 @@ def test_gpu_many_tracks_chunked(oracle, engine):
     ts.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_gpu_exact_difference_array_path(oracle, engine, seed, monkeypatch):
+    """Sum / Mean over float tracks with zero defaults run through the O(intervals) difference-array
+    kernel (8 positions per lane: W = 4096) and stay bit-identical; data it cannot prove exact
+    (wide dynamic range, NaN) is redone by the general kernel."""
+    from wiggletools_amd.runlists import synth
+    monkeypatch.setenv("WTAMD_DELTA_MIN_TRACKS", "1")
+    monkeypatch.setenv("WTAMD_DELTA_T", "512" if seed % 3 else "256")
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(1, 40))
+    t = synth(n, [int(rng.integers(1, 60000)), 9000, 3], mean_run=float(rng.choice([1, 4, 16, 300])),
+              gap_prob=float(rng.choice([0.0, 0.1, 0.5])), seed=seed, first_start=int(rng.choice([1, 77, 5000])))
+    if seed % 2:
+        t.value[:] = ((rng.random(len(t.value)) - 0.3) * 1000).astype(np.float32)     # full mantissas, signs
+    d = t.as_dict()
+    ts = engine.TrackSet.from_runlists(t)
+    for strict in (0, 1):
+        for op in ("sum", "mean"):
+            exp = oracle.reduce(d, op, flags=strict)
+            got = ts.reduce_host(op, flags=strict)
+            if seed % 2 == 0:       # k/8 values: every window is provably exact
+                assert ts.stats()["window_bp"] == (4096 if seed % 3 else 2048) and ts.stats()["lds_bytes"] < 70000, \
+                    "difference-array path not taken"
+            assert_runs_equal(got, exp, 0.0, "seed %d op %s strict %d" % (seed, op, strict))
+    lds_delta = ts.stats()["lds_bytes"] if seed % 2 == 0 else -1
+    ts.close()
+    # not provably exact -> general kernel, same answer
+    t.value[len(t.value) // 2] = np.nan if seed % 2 else np.float32(1e-35)
+    ts = engine.TrackSet.from_runlists(t)
+    for op in ("sum", "mean"):
+        exp = oracle.reduce(t.as_dict(), op)
+        got = ts.reduce_host(op)
+        assert ts.stats()["lds_bytes"] != lds_delta
+        assert_runs_equal(got, exp, 0.0, "fallback seed %d op %s" % (seed, op))
+    ts.close()
+
+
 def test_gpu_wilcoxon_50_vs_50(oracle, engine):
     """BASELINE config C5 shape (n1 = n2 = 50: mu = 1250, sigma = sqrt(21041))."""
     from wiggletools_amd.runlists import synth

@@ -55,6 +55,7 @@ enum {
 
 // counters[] slots (device, 64-bit each)
 enum { WT_CTR_TICKET = 0, WT_CTR_RUNS = 1, WT_CTR_BP = 2, WT_CTR_INTERVALS = 3, WT_CTR_ERROR = 4,
+       WT_CTR_DELTA_BAD = 5 /* windows the exact difference-array path had to give up on */,
        WT_CTR_PROF = 8 /* 8 phase cycle counters, -DWT_PROFILE builds only */, WT_CTR_N = 16 };
 // error bits
 #define WT_ERR_CAPACITY 1ull
@@ -107,6 +108,7 @@ struct WtParams {
     int32_t spitch;               // u64 {S,C} pairs per track row (W/32 + 1: bank spread)
     int32_t cpitch;               // u16 entries per cnt_i row (W/32, even)
     int32_t off_S, off_cnt, off_segtot, off_U, off_cover, off_E, off_epfx, off_nextw, off_gbase, off_scratch, off_shared;
+    int32_t off_acc, off_ev, off_ltv, off_ltc, off_gtv, off_gtc, off_tbase, off_tpfx, off_tfirst, off_dsh;   // difference-array path (wt_delta.h)
     int32_t lds_bytes;
 };
 
@@ -501,6 +503,9 @@ WT_DEV void wt_phase_count_b(const WtParams &P, WtCtx &c, int t_lo, int t_hi, in
 #ifndef WT_TRACK_UNROLL
 #define WT_TRACK_UNROLL 2
 #endif
+#ifndef WT_PIPE
+#define WT_PIPE 3
+#endif
 #define WT_PRAGMA(x) _Pragma(#x)
 #define WT_UNROLL_TRACKS WT_PRAGMA(unroll WT_TRACK_UNROLL)
 
@@ -520,14 +525,61 @@ struct WtRawK {
     double dflt;
 };
 
+// compile-time loop: f(std::integral_constant<int, k>) for k = B..E-1
+template <int B, int E, class F>
+WT_DEV void wt_static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        wt_static_for<B + 1, E>(f);
+    }
+}
+
+// Three VALU idioms the optimiser undoes when they are written in C (it turns the masks back
+// into compare + select pairs and the bit add into shift/and/add); spelled out so the
+// evaluation loop stays at its minimum instruction count.
+//   wt_bit_mask<k>(x)        all-ones if bit k of x is set, else 0          v_bfe_i32
+//   wt_bfi(m, a, b)          (a & m) | (b & ~m)                             v_bfi_b32
+//   wt_add_bit_shl<k,SH>(o,x)  o + (bit k of x << SH)                       v_bfe_u32 + v_lshl_add_u32
+template <int k>
+WT_DEV uint32_t wt_bit_mask(uint32_t x) {
+#if defined(WT_EMU) || defined(WT_NO_ASM)
+    return 0u - ((x >> k) & 1u);
+#else
+    uint32_t m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(x), "n"(k));
+    return m;
+#endif
+}
+WT_DEV uint32_t wt_bfi(uint32_t m, uint32_t a, uint32_t b) {
+#if defined(WT_EMU) || defined(WT_NO_ASM)
+    return (a & m) | (b & ~m);
+#else
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+#endif
+}
+template <int k, unsigned SH>
+WT_DEV unsigned wt_add_bit_shl(unsigned o, uint32_t x) {
+#if defined(WT_EMU) || defined(WT_NO_ASM)
+    return o + (((x >> k) & 1u) << SH);
+#else
+    uint32_t t, r;
+    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(t) : "v"(x), "n"(k));
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(t), "n"(SH), "v"(o));
+    return r;
+#endif
+}
+
 template <class ValT, int K>
-WT_DEV void wt_fetch_issue(const WtParams &P, const WtCtx &c, int i, int w32, const uint32_t (&mask)[K],
+WT_DEV void wt_fetch_issue(const WtParams &P, const WtCtx &c, int i, int w32, int b0, const uint32_t (&mask)[K],
                            double dflt, WtRawK<ValT, K> &raw) {
     const uint64_t sc = c.SC[(size_t) i * P.spitch + w32];
     const uint32_t sbits = (uint32_t) sc;
     const unsigned cn = (unsigned) c.cnt[(size_t) i * P.cpitch + w32];
     raw.cbits = (uint32_t) (sc >> 32);
     raw.dflt = dflt;
+#ifdef WT_EMU
     const char *vp = (const char *) ((const ValT *) P.value + wt_uniform64(c.gbase[i]));
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -535,30 +587,55 @@ WT_DEV void wt_fetch_issue(const WtParams &P, const WtCtx &c, int i, int w32, co
         r = r ? r : 1u;
         raw.v[k] = *(const ValT *) (vp + (uint32_t) (r * (unsigned) sizeof(ValT)));
     }
+#else
+    // The eval phase is VALU-bound (measured), so the index arithmetic is kept minimal: a buffer
+    // descriptor per track (scalar), byte offset of position 0 from one popcount, the following
+    // positions add their own start bit.  rank 0 (nothing started yet: the position is not
+    // covered, the value unused) gives offset -sizeof(ValT), which the descriptor's range check
+    // turns into a zero result instead of an access.
+    constexpr unsigned SH = sizeof(ValT) == 4 ? 2u : 3u;
+    const ValT *tb = (const ValT *) P.value + (wt_uniform64(c.gbase[i]) + 1);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) tb, 0, 1 << 30, 0x00020000);
+    unsigned off = ((unsigned) wt_popc32(sbits & mask[0]) << SH) + ((cn << SH) - (unsigned) sizeof(ValT));
+    const unsigned sk = sbits >> b0;
+    wt_static_for<0, K>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k > 0) off = wt_add_bit_shl<k, SH>(off, sk);
+        if constexpr (sizeof(ValT) == 4) raw.v[k] = __builtin_bit_cast(ValT, (uint32_t) __builtin_amdgcn_raw_buffer_load_b32(rs, (int) off, 0, 0));
+        else raw.v[k] = __builtin_bit_cast(ValT, __builtin_amdgcn_raw_buffer_load_b64(rs, (int) off, 0, 0));
+    });
+#endif
 }
 
 template <class ValT, class ScrT, int K>
 WT_DEV void wt_fetch_finish(const WtRawK<ValT, K> &raw, int b0, WtFetchK<K> &out) {
     out.cbits = raw.cbits;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const bool cov = (raw.cbits >> (b0 + k)) & 1u;
-        out.cov[k] = cov;
+    const uint32_t ck = raw.cbits >> b0;
+    wt_static_for<0, K>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        out.cov[k] = ((ck >> k) & 1u) != 0;
+        // branch-free select through a sign mask: one bit-field insert per 32 bits
+        const uint32_t m = wt_bit_mask<k>(ck);
         if (sizeof(ValT) == 4 && sizeof(ScrT) == 4) {
             // float tracks whose defaults are float-exact: select in f32, widen once
-            const float xf = cov ? (float) raw.v[k] : (float) raw.dflt;
-            out.x[k] = (double) xf;
+            const uint32_t vb = __builtin_bit_cast(uint32_t, (float) raw.v[k]);
+            const uint32_t db = __builtin_bit_cast(uint32_t, (float) raw.dflt);
+            out.x[k] = (double) __builtin_bit_cast(float, wt_bfi(m, vb, db));
         } else {
-            out.x[k] = cov ? (double) raw.v[k] : raw.dflt;
+            const uint64_t vb = __builtin_bit_cast(uint64_t, (double) raw.v[k]);
+            const uint64_t db = __builtin_bit_cast(uint64_t, raw.dflt);
+            const uint32_t lo = wt_bfi(m, (uint32_t) vb, (uint32_t) db);
+            const uint32_t hi = wt_bfi(m, (uint32_t) (vb >> 32), (uint32_t) (db >> 32));
+            out.x[k] = __builtin_bit_cast(double, ((uint64_t) hi << 32) | lo);
         }
-    }
+    });
 }
 
 template <class ValT, class ScrT, int K>
 WT_DEV void wt_fetch_group(const WtParams &P, const WtCtx &c, int i, int w32, int b0, const uint32_t (&mask)[K],
                            double dflt, WtFetchK<K> &out) {
     WtRawK<ValT, K> raw;
-    wt_fetch_issue<ValT, K>(P, c, i, w32, mask, dflt, raw);
+    wt_fetch_issue<ValT, K>(P, c, i, w32, b0, mask, dflt, raw);
     wt_fetch_finish<ValT, ScrT, K>(raw, b0, out);
 }
 
@@ -587,18 +664,25 @@ template <class ValT, class ScrT, int K, class Body>
 WT_DEV void wt_for_tracks(const WtParams &P, const WtCtx &c, int base, int lo, int hi, int w32, int b0,
                           const uint32_t (&mask)[K], bool use_defaults, Body body) {
     const double *dflt = P.defaults;
-    int g = lo;
-    for (; g + 1 < hi; g += 2) {
-        WtFetchK<K> F0, F1;
-        wt_fetch_group<ValT, ScrT, K>(P, c, g - base, w32, b0, mask, use_defaults ? dflt[g] : 0.0, F0);
-        wt_fetch_group<ValT, ScrT, K>(P, c, g + 1 - base, w32, b0, mask, use_defaults ? dflt[g + 1] : 0.0, F1);
-        body(g, F0);
-        body(g + 1, F1);
-    }
-    if (g < hi) {
-        WtFetchK<K> F0;
-        wt_fetch_group<ValT, ScrT, K>(P, c, g - base, w32, b0, mask, use_defaults ? dflt[g] : 0.0, F0);
-        body(g, F0);
+    // The loop is bound by the gather round trip (LDS word -> global value), not by VALU work
+    // (measured: 40 % fewer VALU instructions changed nothing), so WT_PIPE tracks' gathers are
+    // kept in flight: track t + WT_PIPE is issued right after track t is consumed.
+    constexpr int D = WT_PIPE;
+    WtRawK<ValT, K> R[D];
+#pragma unroll
+    for (int u = 0; u < D; u++)
+        if (lo + u < hi) wt_fetch_issue<ValT, K>(P, c, lo + u - base, w32, b0, mask, use_defaults ? dflt[lo + u] : 0.0, R[u]);
+    for (int j = lo; j < hi; j += D) {
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            const int t = j + u;
+            if (t < hi) {                       // wave-uniform
+                WtFetchK<K> F;
+                wt_fetch_finish<ValT, ScrT, K>(R[u], b0, F);
+                body(t, F);
+                if (t + D < hi) wt_fetch_issue<ValT, K>(P, c, t + D - base, w32, b0, mask, use_defaults ? dflt[t + D] : 0.0, R[u]);
+            }
+        }
     }
 }
 
@@ -617,7 +701,7 @@ WT_DEV void wt_for_tracks_deep(const WtParams &P, const WtCtx &c, int base, int 
     WtRawK<ValT, K> R[D];
 #pragma unroll
     for (int u = 0; u < D; u++)
-        if (lo + u < hi) wt_fetch_issue<ValT, K>(P, c, lo + u - base, w32, mask, dflt[lo + u], R[u]);
+        if (lo + u < hi) wt_fetch_issue<ValT, K>(P, c, lo + u - base, w32, b0, mask, dflt[lo + u], R[u]);
     for (int j = lo; j < hi; j += D) {
 #pragma unroll
         for (int u = 0; u < D; u++) {
@@ -626,7 +710,7 @@ WT_DEV void wt_for_tracks_deep(const WtParams &P, const WtCtx &c, int base, int 
                 WtFetchK<K> F;
                 wt_fetch_finish<ValT, ScrT, K>(R[u], b0, F);
                 body(t, F);
-                if (t + D < hi) wt_fetch_issue<ValT, K>(P, c, t + D - base, w32, mask, dflt[t + D], R[u]);
+                if (t + D < hi) wt_fetch_issue<ValT, K>(P, c, t + D - base, w32, b0, mask, dflt[t + D], R[u]);
             }
         }
     }
@@ -1135,7 +1219,9 @@ WT_DEV void wt_phase_write(const WtParams &P, WtCtx &c, const WtLane<K> &L, int 
             P.o_finish[o] = fin;
             P.o_value[o] = L.res[k];
         }
+#ifndef WT_NO_BPSUM
         wt_lds_add64(&c.sh->bp_sum, bp);
+#endif
     }
 }
 
@@ -1200,5 +1286,7 @@ WT_DEV void wt_index_apply(const WtParams &P, WtIndexCursor &c, long long g, int
     if (last)
         for (long long m = m_hi + 1; m <= c.nw; m++) P.widx[(size_t) (c.rowbase + m) * N + c.i] = (uint32_t) (jr + 1);
 }
+
+#include "wt_delta.h"
 
 #endif  // WT_CORE_H_

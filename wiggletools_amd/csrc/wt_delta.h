@@ -1,0 +1,366 @@
+// wt_delta.h -- exact difference-array path for Sum / Mean over float tracks (device + -DWT_EMU).
+//
+// The general kernel (wt_core.h) visits every track at every run start: O(tracks x runs) f64
+// adds, VALU-bound on MI355X (measured: VALUBusy 64 %, 12 % of the HBM roofline).  For
+// SumReduction / MeanReduction (reference reducers.c:294-307, 375-401) the work can drop to
+// O(intervals): add +v at an interval's start and -v at its finish, prefix-sum over the window.
+// Floating-point prefix sums would not reproduce the reference's track-order f64 summation --
+// unless NO addition rounds.  That is decidable per window:
+//   * every value is a float, v = m * 2^(e-150) with |m| < 2^24 (e = biased exponent, 1..254;
+//     denormals: e = 1 without the hidden bit);
+//   * with emin / emax the smallest / largest exponent of the non-zero values the window touches,
+//     every value is an integer multiple of q = 2^(emin-150) and every partial sum of at most N
+//     of them is below N * 2^(emax-emin+24) * q;
+//   * if N * 2^(emax-emin+24) <= 2^53 every partial sum -- in ANY order -- is exactly
+//     representable in f64, so the reference's sequential sum is exact and equals the integer sum
+//     of the scaled mantissas times q.  Bit-identical, not approximately equal.
+// Windows that fail the test (wide dynamic range, NaN / Inf) are counted in WT_CTR_DELTA_BAD and
+// the host re-runs the launch through the general kernel.  Preconditions checked by the host:
+// float tracks, all default values == 0 (absent tracks then add +0.0, which never changes a
+// sum), op in {SUM, MEAN}.
+//
+// Per window (W = 8 * workgroup size positions):
+//   ranges   per chunk of T tracks: interval range of every track, scanned into one flat space
+//   pass 1   exponent range of the window's values                        (4 B / interval)
+//   pass 2   acc[p] += +-scaled mantissa, ev[p] += start | finish<<16    (12 B / interval)
+//            intervals spanning w0 go to the window base instead (not a breakpoint)
+//   scan     one lane per 8 positions: running sum, running coverage, breakpoint byte,
+//            emitted byte (breakpoint & coverage predicate & range), value of the run
+//   then the general kernel's tail: run-count scan, look-back, write.
+#ifndef WT_DELTA_H_
+#define WT_DELTA_H_
+
+#define WT_DELTA_K 8            // positions per lane: one byte of the U / E bitmaps
+#define WT_DELTA_GROUP 16       // lanes per group in the hierarchical scan
+#define WT_DELTA_U 4            // flat interval indices per lane and tile
+#define WT_DELTA_TILE (64 * WT_DELTA_U)
+#define WT_DELTA_TF 2048        // tiles whose first track is tabulated (beyond: binary search)
+
+struct WtDeltaShared {
+    long long base_v;           // scaled sum of the intervals spanning w0
+    int32_t base_c;             // their number
+    int32_t emin, emax, bad;    // exponent range of the window's non-zero values, NaN/Inf seen
+    int32_t shift_ok;           // 1: the window is exact
+};
+
+struct WtDeltaCtx {
+    long long *acc;             // [W] scaled value deltas
+    uint32_t *ev;               // [W] starts (low half) | finishes (high half)
+    long long *ltv;             // [T] lane totals (value)
+    int32_t *ltc;               // [T] lane totals (coverage)
+    long long *gtv;             // [T / 16] group totals
+    int32_t *gtc;
+    long long *tbase;           // [T] global index of the first interval of the chunk's track t in this window
+    uint32_t *tpfx;             // [T + 1] exclusive prefix of the tracks' interval counts (flat index space)
+    uint16_t *tfirst;           // [WT_DELTA_TF] first track of every tile of the flat space
+    WtDeltaShared *dsh;
+};
+
+// per-lane registers across the scan's barriers
+struct WtDeltaLane {
+    long long pv[WT_DELTA_K];   // inclusive prefix of the lane's value deltas
+    int32_t pc[WT_DELTA_K];     // inclusive prefix of the lane's coverage deltas
+    uint32_t evmask;            // bit k: position k is a true breakpoint
+};
+
+WT_DEV void wt_delta_ctx_init(WtDeltaCtx &d, const WtParams &P, char *lds) {
+    d.acc = (long long *) (lds + P.off_acc);
+    d.ev = (uint32_t *) (lds + P.off_ev);
+    d.ltv = (long long *) (lds + P.off_ltv);
+    d.ltc = (int32_t *) (lds + P.off_ltc);
+    d.gtv = (long long *) (lds + P.off_gtv);
+    d.gtc = (int32_t *) (lds + P.off_gtc);
+    d.tbase = (long long *) (lds + P.off_tbase);
+    d.tpfx = (uint32_t *) (lds + P.off_tpfx);
+    d.tfirst = (uint16_t *) (lds + P.off_tfirst);
+    d.dsh = (WtDeltaShared *) (lds + P.off_dsh);
+}
+
+#ifdef WT_EMU
+WT_DEV void wt_lds_add32(uint32_t *p, uint32_t v) { *p += v; }
+WT_DEV void wt_lds_addi32(int32_t *p, int32_t v) { *p += v; }
+WT_DEV void wt_lds_max32(int32_t *p, int32_t v) { if (v > *p) *p = v; }
+#else
+WT_DEV void wt_lds_add32(uint32_t *p, uint32_t v) { atomicAdd((unsigned int *) p, (unsigned int) v); }
+WT_DEV void wt_lds_addi32(int32_t *p, int32_t v) { atomicAdd(p, v); }
+WT_DEV void wt_lds_max32(int32_t *p, int32_t v) { atomicMax(p, v); }
+#endif
+
+// largest exponent span a window of N tracks may have: N * 2^(span+24) <= 2^53
+WT_DEV int wt_delta_max_span(int n_tracks) {
+    int lg = 0;
+    while ((1ll << lg) < (long long) n_tracks) lg++;
+    return 29 - lg;
+}
+
+WT_DEV void wt_delta_zero(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+    for (int x = tid; x < P.W; x += nt) { d.acc[x] = 0; d.ev[x] = 0; }
+    if (tid == 0) {
+        d.dsh->base_v = 0; d.dsh->base_c = 0;
+        d.dsh->emin = 255; d.dsh->emax = 0; d.dsh->bad = 0; d.dsh->shift_ok = 0;
+    }
+}
+
+// ---- the window's intervals as ONE flat index space ----
+// A chunk of up to T tracks (T = workgroup size): lane t looks up track c0 + t's interval range
+// (first interval with finish >= w0 .. last one that can start before w1, from the window index),
+// an exclusive scan of the counts gives every track its slice [tpfx[t], tpfx[t+1]) of the flat
+// space.  The passes then stride over flat indices: 64-lane tiles of 4 x 64 consecutive indices,
+// so loads are coalesced inside a track and every lane is busy whatever the tracks' densities.
+WT_DEV void wt_delta_ranges1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0, int tid, int nt) {
+    const int N = P.n_tracks;
+    const int g = c0 + tid;
+    long long n = 0;
+    if (g < N) {
+        const uint32_t *row0 = P.widx + (size_t) c.sh->row * N;
+        const long long seg = (long long) c.sh->chrom * N + g;
+        const long long off = P.seg_off[seg];
+        const long long cnt = P.seg_off[seg + 1] - off;
+        const long long lo = row0[g];
+        long long hi = row0[N + g];
+        if (hi >= cnt) hi = cnt - 1;
+        n = hi >= lo ? hi - lo + 1 : 0;
+        d.tbase[tid] = off + lo;
+    }
+    d.ltc[tid] = (int32_t) n;
+}
+
+WT_DEV void wt_delta_ranges2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+    const int ngroups = nt / WT_DELTA_GROUP;
+    if (tid >= ngroups) return;
+    int32_t sc = 0;
+    for (int x = 0; x < WT_DELTA_GROUP; x++) sc += d.ltc[tid * WT_DELTA_GROUP + x];
+    d.gtc[tid] = sc;
+}
+
+WT_DEV void wt_delta_ranges3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+    const int grp = tid / WT_DELTA_GROUP;
+    uint32_t pfx = 0;
+    for (int x = 0; x < grp; x++) pfx += (uint32_t) d.gtc[x];
+    for (int x = grp * WT_DELTA_GROUP; x < tid; x++) pfx += (uint32_t) d.ltc[x];
+    const uint32_t n = (uint32_t) d.ltc[tid];
+    d.tpfx[tid] = pfx;
+    if (tid == nt - 1) d.tpfx[nt] = pfx + n;
+    // first track of every tile of WT_DELTA_TILE flat indices (the slices partition the flat
+    // space, so every tile start lies in exactly one non-empty slice)
+    for (uint32_t b = (pfx + WT_DELTA_TILE - 1) / WT_DELTA_TILE; b * WT_DELTA_TILE < pfx + n && b < WT_DELTA_TF; b++)
+        d.tfirst[b] = (uint16_t) tid;
+}
+
+// smallest track slot i' >= i whose slice holds flat index jj (jj < tpfx[nt])
+WT_DEV int wt_delta_find(const uint32_t *tpfx, int nt, uint32_t jj, int i) {
+    int lo = i, hi = nt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (jj >= tpfx[mid + 1]) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// global interval indices of the lane's WT_DELTA_U flat indices of tile `tb` (-1: past the end)
+WT_DEV void wt_delta_tile(const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, long long (&g)[WT_DELTA_U]) {
+    const uint32_t tile = tb / WT_DELTA_TILE;
+    int i = tile < WT_DELTA_TF ? (int) d.tfirst[tile] : wt_delta_find(d.tpfx, nt, tb, 0);
+#pragma unroll
+    for (int u = 0; u < WT_DELTA_U; u++) {
+        const uint32_t jj = tb + (uint32_t) lane + 64u * (uint32_t) u;
+        g[u] = -1;
+        if (jj < M) {
+            while (jj >= d.tpfx[i + 1]) i++;
+            g[u] = d.tbase[i] + (long long) (jj - d.tpfx[i]);
+        }
+    }
+}
+
+// pass 1: exponent range of every value the window may use.  The loads of the wave's next tile
+// are issued before the current one is consumed (the passes are latency-, not bandwidth-bound).
+WT_DEV void wt_delta_pass1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+    const int wave = tid >> 6, lane = tid & 63, nwaves = nt >> 6;
+    const uint32_t *val = (const uint32_t *) P.value;
+    const uint32_t M = d.tpfx[nt];
+    const uint32_t step = (uint32_t) nwaves * WT_DELTA_TILE;
+    int emin = 255, emax = 0, bad = 0;
+    uint32_t cur[WT_DELTA_U], nxt[WT_DELTA_U];
+    uint32_t tb = (uint32_t) wave * WT_DELTA_TILE;
+    if (tb < M) {
+        long long g[WT_DELTA_U];
+        wt_delta_tile(d, nt, M, tb, lane, g);
+#pragma unroll
+        for (int u = 0; u < WT_DELTA_U; u++) cur[u] = g[u] >= 0 ? val[g[u]] : 0u;
+    }
+    for (; tb < M; tb += step) {
+        if (tb + step < M) {
+            long long g[WT_DELTA_U];
+            wt_delta_tile(d, nt, M, tb + step, lane, g);
+#pragma unroll
+            for (int u = 0; u < WT_DELTA_U; u++) nxt[u] = g[u] >= 0 ? val[g[u]] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < WT_DELTA_U; u++) {
+            const int e = (int) ((cur[u] >> 23) & 0xffu);
+            if (e == 0xff) bad = 1;
+            if ((cur[u] & 0x7fffffffu) != 0u) {
+                const int ee = e ? e : 1;
+                emin = ee < emin ? ee : emin;
+                emax = ee > emax ? ee : emax;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WT_DELTA_U; u++) cur[u] = nxt[u];
+    }
+    if (emin <= emax) { wt_lds_min32(&d.dsh->emin, emin); wt_lds_max32(&d.dsh->emax, emax); }
+    if (bad) wt_lds_max32(&d.dsh->bad, 1);
+}
+
+// one lane, between the passes: is the window exact?
+WT_DEV void wt_delta_decide(const WtParams &P, WtCtx &c, WtDeltaCtx &d) {
+    WtDeltaShared *s = d.dsh;
+    if (s->emin > s->emax) { s->emin = 1; s->emax = 1; }        // no non-zero value at all
+    const bool ok = !s->bad && (s->emax - s->emin) <= wt_delta_max_span(P.n_tracks);
+    s->shift_ok = ok ? 1 : 0;
+    if (!ok) wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
+}
+
+WT_DEV void wt_delta_apply(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t s, int32_t f, uint32_t vb,
+                           int emin, bool ok, int32_t &my_next) {
+    const int32_t w0 = c.sh->w0, w1 = c.sh->w1;
+    if (f == w0) { wt_lds_add32(&d.ev[0], 0x00010001u); return; }    // true breakpoint at w0, covers nothing here
+    if (s >= w1) { my_next = s < my_next ? s : my_next; return; }
+    const int e = (int) ((vb >> 23) & 0xffu);
+    const uint32_t frac = vb & 0x7fffffu;
+    const uint32_t m = e ? (frac | 0x800000u) : frac;
+    long long vi = 0;
+    if (ok && m) vi = (long long) ((unsigned long long) m << ((e ? e : 1) - emin));
+    if (vb >> 31) vi = -vi;
+    if (s < w0) {                               // spans w0: part of the window's base, not a breakpoint
+        wt_lds_add64((unsigned long long *) &d.dsh->base_v, (unsigned long long) vi);
+        wt_lds_addi32(&d.dsh->base_c, 1);
+    } else {
+        const int cs = s - w0;
+        if (vi) wt_lds_add64((unsigned long long *) &d.acc[cs], (unsigned long long) vi);
+        wt_lds_add32(&d.ev[cs], 1u);
+    }
+    if (f < w1) {
+        const int cf = f - w0;
+        if (vi) wt_lds_add64((unsigned long long *) &d.acc[cf], (unsigned long long) (-vi));
+        wt_lds_add32(&d.ev[cf], 0x10000u);
+    } else {
+        my_next = f < my_next ? f : my_next;
+    }
+}
+
+// pass 2: the deltas (same software pipeline as pass 1)
+struct WtDeltaBatch {
+    int32_t s[WT_DELTA_U], f[WT_DELTA_U];
+    uint32_t b[WT_DELTA_U];
+    bool in[WT_DELTA_U];
+};
+
+WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, WtDeltaBatch &B) {
+    const uint32_t *val = (const uint32_t *) P.value;
+    long long g[WT_DELTA_U];
+    wt_delta_tile(d, nt, M, tb, lane, g);
+#pragma unroll
+    for (int u = 0; u < WT_DELTA_U; u++) {
+        B.in[u] = g[u] >= 0;
+        B.s[u] = B.in[u] ? P.start[g[u]] : 0;
+        B.f[u] = B.in[u] ? P.finish[g[u]] : 0;
+        B.b[u] = B.in[u] ? val[g[u]] : 0u;
+    }
+}
+
+WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+    const int wave = tid >> 6, lane = tid & 63, nwaves = nt >> 6;
+    const uint32_t M = d.tpfx[nt];
+    const uint32_t step = (uint32_t) nwaves * WT_DELTA_TILE;
+    const int emin = d.dsh->emin;
+    const bool ok = d.dsh->shift_ok != 0;
+    int32_t my_next = 0x7fffffff;
+    WtDeltaBatch cur, nxt;
+    uint32_t tb = (uint32_t) wave * WT_DELTA_TILE;
+    if (tb < M) wt_delta_fetch(P, d, nt, M, tb, lane, cur);
+    for (; tb < M; tb += step) {
+        if (tb + step < M) wt_delta_fetch(P, d, nt, M, tb + step, lane, nxt);
+#pragma unroll
+        for (int u = 0; u < WT_DELTA_U; u++)
+            if (cur.in[u]) wt_delta_apply(P, c, d, cur.s[u], cur.f[u], cur.b[u], emin, ok, my_next);
+        cur = nxt;
+    }
+    if (my_next != 0x7fffffff) wt_lds_min32(&c.sh->next_bp, my_next);
+    if (tid == 0 && M) wt_lds_add64(&c.sh->n_intervals, (unsigned long long) M);
+}
+
+// scan step 1: the lane's 8 positions
+WT_DEV void wt_delta_scan1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLane &L, int tid, int nt) {
+    const int p0 = tid * WT_DELTA_K;
+    long long rv = 0;
+    int32_t rc = 0;
+    uint32_t evm = 0;
+#pragma unroll
+    for (int k = 0; k < WT_DELTA_K; k++) {
+        const uint32_t e = d.ev[p0 + k];
+        rv += d.acc[p0 + k];
+        rc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
+        L.pv[k] = rv;
+        L.pc[k] = rc;
+        evm |= (e != 0u ? 1u : 0u) << k;
+    }
+    L.evmask = evm;
+    d.ltv[tid] = rv;
+    d.ltc[tid] = rc;
+}
+
+// scan step 2: group totals (one lane per group of 16)
+WT_DEV void wt_delta_scan2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+    const int ngroups = nt / WT_DELTA_GROUP;
+    if (tid >= ngroups) return;
+    long long sv = 0;
+    int32_t sc = 0;
+    for (int x = 0; x < WT_DELTA_GROUP; x++) {
+        sv += d.ltv[tid * WT_DELTA_GROUP + x];
+        sc += d.ltc[tid * WT_DELTA_GROUP + x];
+    }
+    d.gtv[tid] = sv;
+    d.gtc[tid] = sc;
+}
+
+// scan step 3: running sum / coverage of every position, breakpoint and emitted bytes, run values
+template <int OP>
+WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtDeltaLane &L,
+                           WtLane<WT_DELTA_K> &out, int tid, int nt) {
+    const int grp = tid / WT_DELTA_GROUP;
+    long long bv = d.dsh->base_v;
+    int32_t bc = d.dsh->base_c;
+    for (int x = 0; x < grp; x++) { bv += d.gtv[x]; bc += d.gtc[x]; }
+    for (int x = grp * WT_DELTA_GROUP; x < tid; x++) { bv += d.ltv[x]; bc += d.ltc[x]; }
+    const int N = P.n_tracks;
+    const bool strict = (P.flags & WT_STRICT_SET0) != 0;
+    const int p0 = tid * WT_DELTA_K;
+    // 2^(emin - 150): the weight of one unit of the scaled mantissas
+    const double q = __builtin_bit_cast(double, (uint64_t) (d.dsh->emin - 150 + 1023) << 52);
+    const long long room = (long long) c.sh->emit_hi - ((long long) c.sh->w0 + p0);
+    uint32_t em = 0;
+#pragma unroll
+    for (int k = 0; k < WT_DELTA_K; k++) {
+        const int32_t cov = bc + L.pc[k];
+        const bool pred = strict ? (cov == N) : (cov > 0);       // multiplexer.c:120,125
+        if (((L.evmask >> k) & 1u) && pred && k < room) em |= 1u << k;
+        const double s = (double) (bv + L.pv[k]) * q;
+        out.res[k] = (OP == WT_OP_MEAN) ? s / N : s;
+    }
+    ((uint8_t *) c.U)[tid] = (uint8_t) L.evmask;
+    ((uint8_t *) c.E)[tid] = (uint8_t) em;
+}
+
+// the tail of the general kernel's emask phase: next non-empty word of U
+WT_DEV void wt_delta_nextw(const WtParams &P, WtCtx &c, int tid, int nt) {
+    if (tid == nt - 1) {
+        int last = -1;
+        for (int w = P.n_words - 1; w >= 0; w--) {
+            c.nextw[w] = (int16_t) last;
+            if (c.U[w]) last = w;
+        }
+    }
+}
+
+#endif  // WT_DELTA_H_

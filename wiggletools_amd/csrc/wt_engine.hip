@@ -46,8 +46,10 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
         c.scratch = P.g_scratch + (size_t) blockIdx.x * (size_t) P.g_scratch_slab;
     WtLane<K> L;
     const int tid = threadIdx.x, nt = blockDim.x;
-#ifdef WT_DEBUG_MARK
-#define WT_MARK(x) do { if (tid == 0) { P.debug[0] = (unsigned long long) (x); P.debug[1] = (unsigned long long) k_dbg; __threadfence_system(); } } while (0)
+#ifdef WT_MARK_ONLY
+#define WT_MARK(x) do { if ((x) == WT_MARK_ONLY && (tid & 63) == 0) { P.debug[2 + (tid >> 6)] = (unsigned long long) (x); __threadfence_system(); } } while (0)
+#elif defined(WT_DEBUG_MARK)
+#define WT_MARK(x) do { if ((tid & 63) == 0) { if (tid == 0) { P.debug[0] = (unsigned long long) (x); P.debug[1] = (unsigned long long) k_dbg; } P.debug[2 + (tid >> 6)] = (unsigned long long) (x); __threadfence_system(); } } while (0)
 #else
 #define WT_MARK(x) do { } while (0)
 #endif
@@ -61,10 +63,17 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
 #endif
     long long k_dbg = -1;
     (void) k_dbg;
+    // Window tickets.  The lane-0 work at the end of one iteration (statistics) and at the start of
+    // the next (ticket) must NOT be left adjacent across the loop back-edge: hipcc (ROCm 7.2) merges
+    // the two `tid == 0` regions into a divergent exit of an inner loop, whose header -- including
+    // its s_barrier -- the other 63 lanes of wave 0 then re-enter before lane 0 has fetched the next
+    // ticket: every wave re-reads the stale ticket and the workgroup never terminates (observed on
+    // MI355X; any instruction between the two regions hides it).  So the next ticket is taken in the
+    // same lane-0 block as the statistics, followed by the barrier that publishes it.
+    if (tid == 0) c.sh->ticket = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+    __syncthreads();
     for (;;) {
         WT_MARK(1);
-        if (tid == 0) c.sh->ticket = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
-        __syncthreads();
         const long long k = c.sh->ticket;
         k_dbg = k;
         WT_MARK(2);
@@ -142,8 +151,105 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
         wt_phase_write<OP, ValT, K>(P, c, L, tid, nt);
         __syncthreads();
         WT_MARK(12);
-        if (tid == 0) wt_window_stats(P, c);     // the next window's header runs after the ticket barrier
+        if (tid == 0) {
+            wt_window_stats(P, c);
+            c.sh->ticket = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+        }
+        __syncthreads();
         WT_TICK(6);
+    }
+#ifdef WT_PROFILE
+    if (tid == 0)
+        for (int q = 0; q < 8; q++) wt_glb_add64(&P.counters[WT_CTR_PROF + q], prof[q]);
+#endif
+}
+
+// Exact difference-array path for Sum / Mean over float tracks (wt_delta.h): O(intervals) work
+// instead of O(tracks x runs); LDS independent of the track count.
+template <int OP>
+__global__ void __launch_bounds__(WT_MAX_BLOCK) wt_delta_kernel(const WtParams P) {
+    extern __shared__ __attribute__((aligned(16))) char wt_lds[];
+    WtCtx c;
+    wt_ctx_init(c, P, wt_lds);
+    WtDeltaCtx d;
+    wt_delta_ctx_init(d, P, wt_lds);
+    WtDeltaLane DL;
+    WtLane<WT_DELTA_K> L;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    long long k_dbg = -1;
+    (void) k_dbg;
+#ifdef WT_PROFILE
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
+    if (tid == 0) c.sh->ticket = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+    __syncthreads();
+    for (;;) {      // ticket handling: see wt_reduce_kernel
+        WT_MARK(101);
+        const long long k = c.sh->ticket;
+        k_dbg = k;
+        if (k >= P.n_windows) break;
+        if (tid == 0) wt_phase_header(P, c, k);
+        wt_delta_zero(P, c, d, tid, nt);
+        __syncthreads();
+        WT_TICK(0);
+        WT_MARK(102);
+        const int nchunks = (P.n_tracks + nt - 1) / nt;
+        for (int pass = 1; pass <= 2; pass++) {
+            for (int ch = 0; ch < nchunks; ch++) {
+                if (pass == 1 || nchunks > 1) {         // one chunk: pass 2 reuses pass 1's ranges
+                    wt_delta_ranges1(P, c, d, ch * nt, tid, nt);
+                    __syncthreads();
+                    wt_delta_ranges2(P, c, d, tid, nt);
+                    __syncthreads();
+                    wt_delta_ranges3(P, c, d, tid, nt);
+                    __syncthreads();
+                }
+                WT_TICK(1);
+                if (pass == 1) wt_delta_pass1(P, c, d, tid, nt);
+                else wt_delta_pass2(P, c, d, tid, nt);
+                __syncthreads();
+                if (pass == 1) WT_TICK(2); else WT_TICK(3);
+            }
+            if (pass == 1) {
+                if (tid == 0) wt_delta_decide(P, c, d);
+                __syncthreads();
+            }
+        }
+        WT_MARK(105);
+        wt_delta_scan1(P, c, d, DL, tid, nt);
+        __syncthreads();
+        WT_MARK(106);
+        wt_delta_scan2(P, c, d, tid, nt);
+        __syncthreads();
+        WT_MARK(107);
+        wt_delta_scan3<OP>(P, c, d, DL, L, tid, nt);
+        __syncthreads();
+        WT_TICK(4);
+        WT_MARK(108);
+        wt_delta_nextw(P, c, tid, nt);
+        wt_phase_escan(P, c, tid, nt);
+        __syncthreads();
+        WT_TICK(5);
+        WT_MARK(109);
+#ifdef WT_SEQ_LOOKBACK
+        if (tid == 0) wt_phase_lookback(P, c, k);
+#else
+        if (tid == 0) wt_lookback_publish(P, c, k);
+        if (tid < 64) wt_lookback_complete(P, c, k, tid);
+#endif
+        __syncthreads();
+        WT_TICK(6);
+        WT_MARK(110);
+        wt_phase_write<OP, float, WT_DELTA_K>(P, c, L, tid, nt);
+        __syncthreads();
+        WT_MARK(111);
+        if (tid == 0) {
+            wt_window_stats(P, c);
+            c.sh->ticket = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+        }
+        __syncthreads();
+        WT_TICK(7);
     }
 #ifdef WT_PROFILE
     if (tid == 0)
@@ -278,6 +384,8 @@ struct wtamd_trackset {
     int device = 0;
     int num_cu = 256;
     bool scratch_f32 = false;
+    bool delta_failed = false;                  // a window of this data was not exact: Sum / Mean use the general kernel
+    bool delta_verified = false;                // every window of this data is exact (checked by a completed launch)
 };
 
 static void wt_free_windows(WtWindows &w) {
@@ -330,8 +438,8 @@ static int wt_trackset_common(const wtamd_tracks *t, wtamd_trackset *ts) {
     WT_HIP(hipMemcpy(ts->d_defaults, ts->defaults.data(), sizeof(double) * t->n_tracks, hipMemcpyHostToDevice));
     WT_HIP(hipMalloc(&ts->d_counters, sizeof(unsigned long long) * WT_CTR_N));
     WT_HIP(hipHostMalloc(&ts->h_counters, sizeof(unsigned long long) * WT_CTR_N));
-    WT_HIP(hipHostMalloc(&ts->h_debug, sizeof(unsigned long long) * 8));
-    memset(ts->h_debug, 0, sizeof(unsigned long long) * 8);
+    WT_HIP(hipHostMalloc(&ts->h_debug, sizeof(unsigned long long) * 16));
+    memset(ts->h_debug, 0, sizeof(unsigned long long) * 16);
     WT_HIP(hipMalloc(&ts->d_chrom_run_off, sizeof(int64_t) * (t->n_chrom + 1)));
     WT_HIP(hipEventCreate(&ts->ev_i0));
     WT_HIP(hipEventCreate(&ts->ev_i1));
@@ -496,11 +604,19 @@ static int wt_build_index(wtamd_trackset *ts, WtWindows *w, const WtPlan &plan, 
     return WTAMD_OK;
 }
 
+// The plan a reduction of `op` will run with first: the exact difference-array plan for Sum /
+// Mean over float tracks with zero defaults (until a window of this data proved inexact), else the
+// general bitmap plan.
+static bool wt_wants_delta(const wtamd_trackset *ts, int op) {
+    return !ts->delta_failed && wt_delta_eligible(op, ts->value_f64, ts->n_tracks, ts->defaults.data());
+}
+
 int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
     if (!ts) return wt_fail(WTAMD_ERR_ARG, "ts == NULL");
     WtPlan plan;
     std::string err;
-    if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
+    if (wt_wants_delta(ts, op)) wt_make_delta_plan(plan, ts->n_tracks);
+    else if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
     WtWindows *w = nullptr;
     int rc = wt_get_windows(ts, plan.W, &w);
     if (rc != WTAMD_OK) return rc;
@@ -551,6 +667,25 @@ struct WtLaunch {
     }
 };
 
+template <int OP>
+static void wt_launch_delta(WtLaunch &L) {
+    auto kern = wt_delta_kernel<OP>;
+    if (L.lds > 48 * 1024) {
+        L.err = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds);
+        if (L.err != hipSuccess) return;
+    }
+    int per_cu = 0;
+    L.err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, L.T, (size_t) L.lds);
+    if (L.err != hipSuccess) return;
+    if (per_cu < 1) per_cu = 1;
+    long long g = (long long) L.num_cu * per_cu;
+    if (g > L.P.n_windows) g = L.P.n_windows;
+    if (g < 1) g = 1;
+    L.grid = (int) g;
+    hipLaunchKernelGGL(kern, dim3((unsigned) L.grid), dim3((unsigned) L.T), (size_t) L.lds, L.stream, L.P);
+    L.err = hipGetLastError();
+}
+
 extern "C" {
 
 static int wt_check_desc(const wtamd_trackset *ts, const wtamd_reduce_desc *d) {
@@ -568,13 +703,37 @@ static int wt_check_desc(const wtamd_trackset *ts, const wtamd_reduce_desc *d) {
     return WTAMD_OK;
 }
 
+static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32_t flags, int n_set0, wtamd_runs *runs,
+                          double *d_tile, uint8_t *d_inplay, int64_t *n_runs, hipStream_t s);
+
 static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0, wtamd_runs *runs,
                           double *d_tile, uint8_t *d_inplay, int64_t *n_runs, hipStream_t s) {
     if (!runs || !runs->start || !runs->finish || !runs->value)
         return wt_fail(WTAMD_ERR_ARG, "wtamd_reduce: output arrays missing");
     WtPlan plan;
     std::string err;
+    // Sum / Mean: exact difference-array kernel first.  It verifies every window; if one was not
+    // exact the whole launch is redone by the general kernel and this data stays on it.  The
+    // verdict depends on the data and the windows only (not on the op or its flags), so it is
+    // established once per track set -- that first launch is waited for even when the caller asked
+    // for an asynchronous one -- and later launches skip the check.
+    if (!d_tile && wt_wants_delta(ts, op)) {
+        wt_make_delta_plan(plan, ts->n_tracks);
+        int64_t n_probe = 0;
+        const bool probe = !ts->delta_verified;
+        const int rc = wt_reduce_plan(ts, plan, op, flags, n_set0, runs, d_tile, d_inplay,
+                                      (probe && !n_runs) ? &n_probe : n_runs, s);
+        if (!probe) return rc;
+        if (rc != WTAMD_OK && rc != WTAMD_ERR_CAPACITY) return rc;
+        if (ts->h_counters[WT_CTR_DELTA_BAD] == 0) { ts->delta_verified = true; return rc; }
+        ts->delta_failed = true;
+    }
     if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
+    return wt_reduce_plan(ts, plan, op, flags, n_set0, runs, d_tile, d_inplay, n_runs, s);
+}
+
+static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32_t flags, int n_set0, wtamd_runs *runs,
+                          double *d_tile, uint8_t *d_inplay, int64_t *n_runs, hipStream_t s) {
     if (plan.T > WT_MAX_BLOCK) return wt_fail(WTAMD_ERR_ARG, "workgroup size above 512");
     WtWindows *w = nullptr;
     int rc = wt_get_windows(ts, plan.W, &w);
@@ -598,7 +757,11 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
     if (w->tab.n_windows > 0 && ts->n_intervals > 0) {
         WT_HIP(hipMemsetAsync(w->d_status, 0, sizeof(unsigned long long) * w->tab.n_windows, s));
         WT_HIP(hipEventRecord(ts->ev_r0, s));
-        if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, plan.n_chunks > 1 || plan.scratch_slab > 0, L)) return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
+        if (plan.delta) {
+            if (op == WT_OP_SUM) wt_launch_delta<WT_OP_SUM>(L); else wt_launch_delta<WT_OP_MEAN>(L);
+        } else if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, plan.n_chunks > 1 || plan.scratch_slab > 0, L)) {
+            return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
+        }
         if (L.err != hipSuccess) return wt_fail(WTAMD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(L.err));
         WT_HIP(hipEventRecord(ts->ev_r1, s));
         ts->have_reduce_time = true;
@@ -618,9 +781,10 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
                 if (q != hipErrorNotReady) return wt_fail(WTAMD_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
                 const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (el > limit_s) {
-                    char buf[160];
-                    snprintf(buf, sizeof buf, "kernel did not finish within %.0f s (debug marker %llu, window %lld)",
-                             limit_s, ts->h_debug[0], (long long) ts->h_debug[1]);
+                    char buf[320];
+                    snprintf(buf, sizeof buf, "kernel did not finish within %.0f s (debug marker %llu, window %lld; per wave %llu %llu %llu %llu %llu %llu %llu %llu)",
+                             limit_s, ts->h_debug[0], (long long) ts->h_debug[1], ts->h_debug[2], ts->h_debug[3], ts->h_debug[4],
+                             ts->h_debug[5], ts->h_debug[6], ts->h_debug[7], ts->h_debug[8], ts->h_debug[9]);
                     // a kernel that never finishes cannot be cancelled and every later HIP call of this
                     // process (even hipFree) would block behind it: report and terminate the process
                     fprintf(stderr, "wiggletools_amd: FATAL: %s\n", buf);
@@ -636,11 +800,13 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
         *n_runs = ts->stats.n_runs;
 #ifdef WT_PROFILE
         {
-            static const char *names[8] = {"zero", "load", "count", "emask+escan", "eval", "lookback", "write", "-"};
+            static const char *names_g[8] = {"zero", "load", "count", "emask+escan", "eval", "lookback", "write", "-"};
+            static const char *names_d[8] = {"zero", "ranges", "pass1", "pass2", "scan", "escan", "lookback", "write"};
+            const char **names = plan.delta ? names_d : names_g;
             unsigned long long tot = 0;
             for (int q = 0; q < 8; q++) tot += ts->h_counters[WT_CTR_PROF + q];
             fprintf(stderr, "[wt_profile] op %d:", op);
-            for (int q = 0; q < 7; q++)
+            for (int q = 0; q < 8; q++)
                 fprintf(stderr, " %s %.1f%%", names[q], tot ? 100.0 * ts->h_counters[WT_CTR_PROF + q] / tot : 0.0);
             fprintf(stderr, " (total %.3g cycles over all workgroups)\n", (double) tot);
         }
