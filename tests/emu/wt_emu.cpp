@@ -95,9 +95,8 @@ struct EmuRun {
                         for (int t = 0; t < T; t++) wt_delta_ranges3(P, c, d, t, T);
                     }
                     if (pass == 1) for (int t = 0; t < T; t++) wt_delta_pass1(P, c, d, t, T);
-                    else for (int t = 0; t < T; t++) wt_delta_pass2(P, c, d, t, T);
+                    else for (int t = 0; t < T; t++) wt_delta_pass2(P, c, d, ch == 0, t, T);
                 }
-                if (pass == 1) wt_delta_decide(P, c, d);
             }
             for (int t = 0; t < T; t++) wt_delta_scan1(P, c, d, dl[t], t, T);
             for (int t = 0; t < T; t++) wt_delta_scan2(P, c, d, t, T);

@@ -1151,14 +1151,19 @@ WT_DEV void wt_phase_lookback(const WtParams &P, WtCtx &c, long long k) {
 //   publish  (before eval)  AGG|count of this window -- successors never wait for our reducers
 //   complete (after eval)   lane L inspects window base-L: 64 predecessors per round trip; by
 //                           now they have almost always published, so there is no spinning.
-WT_DEV void wt_lookback_publish(const WtParams &P, WtCtx &c, long long k) {
-    const unsigned long long mine = c.epfx[P.n_words];
+WT_DEV void wt_lookback_publish(const WtParams &P, WtCtx &c, long long k, unsigned long long mine) {
     c.sh->n_emit = (int32_t) mine;
     if (k > 0) wt_status_store(&P.status[k], WT_FLAG_AGG | mine);
 }
+WT_DEV void wt_lookback_publish(const WtParams &P, WtCtx &c, long long k) {
+    wt_lookback_publish(P, c, k, (unsigned long long) c.epfx[P.n_words]);
+}
 
+WT_DEV void wt_lookback_complete(const WtParams &P, WtCtx &c, long long k, int lane, unsigned long long mine);
 WT_DEV void wt_lookback_complete(const WtParams &P, WtCtx &c, long long k, int lane) {
-    const unsigned long long mine = c.epfx[P.n_words];
+    wt_lookback_complete(P, c, k, lane, (unsigned long long) c.epfx[P.n_words]);
+}
+WT_DEV void wt_lookback_complete(const WtParams &P, WtCtx &c, long long k, int lane, unsigned long long mine) {
     unsigned long long excl = 0;
     long long base = k - 1;
     while (base >= 0) {

@@ -32,7 +32,9 @@
 
 #define WT_DELTA_K 8            // positions per lane: one byte of the U / E bitmaps
 #define WT_DELTA_GROUP 16       // lanes per group in the hierarchical scan
-#define WT_DELTA_U 4            // flat interval indices per lane and tile
+#ifndef WT_DELTA_U
+#define WT_DELTA_U 8            // flat interval indices per lane and tile (measured: 8 beats 4 and 2 on many / dense tracks)
+#endif
 #define WT_DELTA_TILE (64 * WT_DELTA_U)
 #define WT_DELTA_TF 2048        // tiles whose first track is tabulated (beyond: binary search)
 
@@ -40,7 +42,6 @@ struct WtDeltaShared {
     long long base_v;           // scaled sum of the intervals spanning w0
     int32_t base_c;             // their number
     int32_t emin, emax, bad;    // exponent range of the window's non-zero values, NaN/Inf seen
-    int32_t shift_ok;           // 1: the window is exact
 };
 
 struct WtDeltaCtx {
@@ -61,6 +62,8 @@ struct WtDeltaLane {
     long long pv[WT_DELTA_K];   // inclusive prefix of the lane's value deltas
     int32_t pc[WT_DELTA_K];     // inclusive prefix of the lane's coverage deltas
     uint32_t evmask;            // bit k: position k is a true breakpoint
+    long long wv;               // device: sum of the value deltas of the wave's lanes before this one
+    int32_t wc;                 // device: same for the coverage deltas
 };
 
 WT_DEV void wt_delta_ctx_init(WtDeltaCtx &d, const WtParams &P, char *lds) {
@@ -97,7 +100,7 @@ WT_DEV void wt_delta_zero(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, i
     for (int x = tid; x < P.W; x += nt) { d.acc[x] = 0; d.ev[x] = 0; }
     if (tid == 0) {
         d.dsh->base_v = 0; d.dsh->base_c = 0;
-        d.dsh->emin = 255; d.dsh->emax = 0; d.dsh->bad = 0; d.dsh->shift_ok = 0;
+        d.dsh->emin = 255; d.dsh->emax = 0; d.dsh->bad = 0;
     }
 }
 
@@ -212,13 +215,13 @@ WT_DEV void wt_delta_pass1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, 
     if (bad) wt_lds_max32(&d.dsh->bad, 1);
 }
 
-// one lane, between the passes: is the window exact?
-WT_DEV void wt_delta_decide(const WtParams &P, WtCtx &c, WtDeltaCtx &d) {
-    WtDeltaShared *s = d.dsh;
-    if (s->emin > s->emax) { s->emin = 1; s->emax = 1; }        // no non-zero value at all
-    const bool ok = !s->bad && (s->emax - s->emin) <= wt_delta_max_span(P.n_tracks);
-    s->shift_ok = ok ? 1 : 0;
-    if (!ok) wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
+// After pass 1 (and a barrier): is the window exact, and what is the unit exponent?  Pure function
+// of the LDS verdict fields, evaluated by every lane that needs it.
+WT_DEV bool wt_delta_verdict(const WtParams &P, const WtDeltaCtx &d, int &emin) {
+    int lo = d.dsh->emin, hi = d.dsh->emax;
+    if (lo > hi) { lo = 1; hi = 1; }            // no non-zero value at all
+    emin = lo;
+    return !d.dsh->bad && (hi - lo) <= wt_delta_max_span(P.n_tracks);
 }
 
 WT_DEV void wt_delta_apply(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t s, int32_t f, uint32_t vb,
@@ -269,12 +272,13 @@ WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint3
     }
 }
 
-WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, bool first_chunk, int tid, int nt) {
     const int wave = tid >> 6, lane = tid & 63, nwaves = nt >> 6;
     const uint32_t M = d.tpfx[nt];
     const uint32_t step = (uint32_t) nwaves * WT_DELTA_TILE;
-    const int emin = d.dsh->emin;
-    const bool ok = d.dsh->shift_ok != 0;
+    int emin;
+    const bool ok = wt_delta_verdict(P, d, emin);
+    if (tid == 0 && first_chunk && !ok) wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
     int32_t my_next = 0x7fffffff;
     WtDeltaBatch cur, nxt;
     uint32_t tb = (uint32_t) wave * WT_DELTA_TILE;
@@ -328,16 +332,24 @@ WT_DEV void wt_delta_scan2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, 
 template <int OP>
 WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtDeltaLane &L,
                            WtLane<WT_DELTA_K> &out, int tid, int nt) {
-    const int grp = tid / WT_DELTA_GROUP;
     long long bv = d.dsh->base_v;
     int32_t bc = d.dsh->base_c;
+#ifdef WT_EMU
+    const int grp = tid / WT_DELTA_GROUP;
     for (int x = 0; x < grp; x++) { bv += d.gtv[x]; bc += d.gtc[x]; }
     for (int x = grp * WT_DELTA_GROUP; x < tid; x++) { bv += d.ltv[x]; bc += d.ltc[x]; }
+#else
+    for (int x = 0; x < (tid >> 6); x++) { bv += d.gtv[x]; bc += d.gtc[x]; }   // waves before this one (wt_delta_scan_w1)
+    bv += L.wv;
+    bc += L.wc;
+#endif
     const int N = P.n_tracks;
     const bool strict = (P.flags & WT_STRICT_SET0) != 0;
     const int p0 = tid * WT_DELTA_K;
     // 2^(emin - 150): the weight of one unit of the scaled mantissas
-    const double q = __builtin_bit_cast(double, (uint64_t) (d.dsh->emin - 150 + 1023) << 52);
+    int emin;
+    (void) wt_delta_verdict(P, d, emin);
+    const double q = __builtin_bit_cast(double, (uint64_t) (emin - 150 + 1023) << 52);
     const long long room = (long long) c.sh->emit_hi - ((long long) c.sh->w0 + p0);
     uint32_t em = 0;
 #pragma unroll
@@ -352,15 +364,84 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
     ((uint8_t *) c.E)[tid] = (uint8_t) em;
 }
 
-// the tail of the general kernel's emask phase: next non-empty word of U
+// next non-empty word of U after every word (wt_next_breakpoint's jump table); one lane per word,
+// each looks ahead until it finds one -- one step where breakpoints are dense
 WT_DEV void wt_delta_nextw(const WtParams &P, WtCtx &c, int tid, int nt) {
-    if (tid == nt - 1) {
-        int last = -1;
-        for (int w = P.n_words - 1; w >= 0; w--) {
-            c.nextw[w] = (int16_t) last;
-            if (c.U[w]) last = w;
-        }
+    for (int w = nt - 1 - tid; w < P.n_words; w += nt) {      // the LAST lanes: wave 0 is busy with the look-back
+        int x = w + 1;
+        while (x < P.n_words && c.U[x] == 0) x++;
+        c.nextw[w] = (int16_t) (x < P.n_words ? x : -1);
     }
 }
+
+
+#ifndef WT_EMU
+// ---------------------------------------------------------------------------
+// Device flavours of the per-window scans: the wave-level part runs on lane shuffles, so every
+// scan is "local + wave scan | barrier | add the totals of the waves before" -- one barrier and
+// no serial loop over lanes.  Measured on MI355X: barriers and single-lane chains, not bandwidth,
+// bound this kernel (dropping ONE barrier took the 100-track mean from 1.69 to 1.48 ms).  The
+// LDS-only versions above are what the CPU emulator executes (it has no lane shuffles).
+// ---------------------------------------------------------------------------
+WT_DEV unsigned wt_wave_scan_u32(unsigned v, int lane) {
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const unsigned o = (unsigned) __shfl_up((int) v, dd);
+        if (lane >= dd) v += o;
+    }
+    return v;
+}
+WT_DEV long long wt_wave_scan_i64(long long v, int lane) {
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const long long o = __shfl_up(v, dd);
+        if (lane >= dd) v += o;
+    }
+    return v;
+}
+
+// ranges: lookup + wave-local exclusive prefix; the wave totals go to gtc[wave]
+WT_DEV void wt_delta_ranges_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0, int tid, int nt) {
+    wt_delta_ranges1(P, c, d, c0, tid, nt);
+    const int lane = tid & 63;
+    const unsigned n = (unsigned) d.ltc[tid];
+    const unsigned incl = wt_wave_scan_u32(n, lane);
+    d.tpfx[tid] = incl - n;
+    if (lane == 63) d.gtc[tid >> 6] = (int32_t) incl;
+}
+
+WT_DEV void wt_delta_ranges_w2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+    const int wave = tid >> 6;
+    uint32_t pfx = d.tpfx[tid];
+    for (int x = 0; x < wave; x++) pfx += (uint32_t) d.gtc[x];
+    const uint32_t n = (uint32_t) d.ltc[tid];
+    d.tpfx[tid] = pfx;
+    if (tid == nt - 1) d.tpfx[nt] = pfx + n;
+    for (uint32_t b = (pfx + WT_DELTA_TILE - 1) / WT_DELTA_TILE; b * WT_DELTA_TILE < pfx + n && b < WT_DELTA_TF; b++)
+        d.tfirst[b] = (uint16_t) tid;
+}
+
+// value / coverage scan, step 1: the lane's 8 positions + the wave-level prefix
+WT_DEV void wt_delta_scan_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLane &L, int tid, int nt) {
+    wt_delta_scan1(P, c, d, L, tid, nt);
+    const int lane = tid & 63;
+    const long long rv = L.pv[WT_DELTA_K - 1];
+    const int32_t rc = L.pc[WT_DELTA_K - 1];
+    const long long iv = wt_wave_scan_i64(rv, lane);
+    const int32_t ic = (int32_t) wt_wave_scan_u32((unsigned) rc, lane);
+    L.wv = iv - rv;
+    L.wc = ic - rc;
+    if (lane == 63) { d.gtv[tid >> 6] = iv; d.gtc[tid >> 6] = ic; }
+}
+
+// escan on wave 0: run-count prefix of the emitted bitmap; returns the window's run count
+WT_DEV unsigned wt_delta_escan_wave(const WtParams &P, WtCtx &c, int lane) {
+    const unsigned v = lane < P.n_words ? (unsigned) wt_popc64(c.E[lane]) : 0u;
+    const unsigned incl = wt_wave_scan_u32(v, lane);
+    if (lane < P.n_words) c.epfx[lane + 1] = incl;
+    if (lane == 0) c.epfx[0] = 0;
+    return (unsigned) __shfl((int) incl, 63);
+}
+#endif
 
 #endif  // WT_DELTA_H_

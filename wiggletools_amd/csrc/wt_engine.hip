@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
 // Exact difference-array path for Sum / Mean over float tracks (wt_delta.h): O(intervals) work
 // instead of O(tracks x runs); LDS independent of the track count.
 template <int OP>
-__global__ void __launch_bounds__(WT_MAX_BLOCK) wt_delta_kernel(const WtParams P) {
+__global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
     wt_ctx_init(c, P, wt_lds);
@@ -182,62 +182,55 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK) wt_delta_kernel(const WtParams P
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_last = __builtin_readcyclecounter();
 #endif
-    if (tid == 0) c.sh->ticket = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+    // ticket handling: see wt_reduce_kernel; lane 0 also prepares the next window's header there,
+    // so that the first phase of a window needs no barrier of its own
+    if (tid == 0) {
+        const long long k0 = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+        c.sh->ticket = k0;
+        if (k0 < P.n_windows) wt_phase_header(P, c, k0);
+    }
     __syncthreads();
-    for (;;) {      // ticket handling: see wt_reduce_kernel
+    for (;;) {
         WT_MARK(101);
         const long long k = c.sh->ticket;
         k_dbg = k;
         if (k >= P.n_windows) break;
-        if (tid == 0) wt_phase_header(P, c, k);
+        const int nchunks = (P.n_tracks + nt - 1) / nt;
         wt_delta_zero(P, c, d, tid, nt);
-        __syncthreads();
         WT_TICK(0);
         WT_MARK(102);
-        const int nchunks = (P.n_tracks + nt - 1) / nt;
         for (int pass = 1; pass <= 2; pass++) {
             for (int ch = 0; ch < nchunks; ch++) {
                 if (pass == 1 || nchunks > 1) {         // one chunk: pass 2 reuses pass 1's ranges
-                    wt_delta_ranges1(P, c, d, ch * nt, tid, nt);
+                    wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
                     __syncthreads();
-                    wt_delta_ranges2(P, c, d, tid, nt);
-                    __syncthreads();
-                    wt_delta_ranges3(P, c, d, tid, nt);
+                    wt_delta_ranges_w2(P, c, d, tid, nt);
                     __syncthreads();
                 }
                 WT_TICK(1);
                 if (pass == 1) wt_delta_pass1(P, c, d, tid, nt);
-                else wt_delta_pass2(P, c, d, tid, nt);
+                else wt_delta_pass2(P, c, d, ch == 0, tid, nt);
                 __syncthreads();
                 if (pass == 1) WT_TICK(2); else WT_TICK(3);
             }
-            if (pass == 1) {
-                if (tid == 0) wt_delta_decide(P, c, d);
-                __syncthreads();
-            }
         }
         WT_MARK(105);
-        wt_delta_scan1(P, c, d, DL, tid, nt);
-        __syncthreads();
-        WT_MARK(106);
-        wt_delta_scan2(P, c, d, tid, nt);
+        wt_delta_scan_w1(P, c, d, DL, tid, nt);
         __syncthreads();
         WT_MARK(107);
         wt_delta_scan3<OP>(P, c, d, DL, L, tid, nt);
         __syncthreads();
         WT_TICK(4);
         WT_MARK(108);
+        // wave 0: run-count scan and look-back back to back (it owns the counts); the last lanes
+        // build the breakpoint jump table meanwhile
+        if (tid < 64) {
+            const unsigned long long mine = wt_delta_escan_wave(P, c, tid);
+            WT_TICK(5);
+            if (tid == 0) wt_lookback_publish(P, c, k, mine);
+            wt_lookback_complete(P, c, k, tid, mine);
+        }
         wt_delta_nextw(P, c, tid, nt);
-        wt_phase_escan(P, c, tid, nt);
-        __syncthreads();
-        WT_TICK(5);
-        WT_MARK(109);
-#ifdef WT_SEQ_LOOKBACK
-        if (tid == 0) wt_phase_lookback(P, c, k);
-#else
-        if (tid == 0) wt_lookback_publish(P, c, k);
-        if (tid < 64) wt_lookback_complete(P, c, k, tid);
-#endif
         __syncthreads();
         WT_TICK(6);
         WT_MARK(110);
@@ -246,7 +239,9 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK) wt_delta_kernel(const WtParams P
         WT_MARK(111);
         if (tid == 0) {
             wt_window_stats(P, c);
-            c.sh->ticket = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+            const long long kn = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+            c.sh->ticket = kn;
+            if (kn < P.n_windows) wt_phase_header(P, c, kn);
         }
         __syncthreads();
         WT_TICK(7);

@@ -68,13 +68,13 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
 
 // Difference-array plan (Sum / Mean over float tracks, wt_delta.h): 8 positions per lane; LDS
 // does not depend on the track count.  WTAMD_DELTA_T overrides the workgroup size (tests).
-// Measured on MI355X (scale 0.01 probes, kernel ms at T = 256 / 512): mean of 100 tracks 1.69 / 2.15,
-// sum of 1000 tracks 9.3 / 8.5 -- the per-window fixed costs favour more, smaller workgroups until
-// the interval stream per window is long enough to amortise them.
+// Measured on MI355X (scale 0.01 probes, kernel + index ms at T = 256 / 512): mean of 100 tracks
+// 1.43+0.37 / 1.35+0.31, sum of 1000 tracks 9.2+3.5 / 8.4+2.8: the widest window wins here too.
 static inline void wt_make_delta_plan(WtPlan &p, int n_tracks) {
     const char *eT = getenv("WTAMD_DELTA_T");
-    int T = eT ? atoi(eT) : (n_tracks >= 400 ? 512 : 256);
-    if (T < 64 || T > 512 || (T & (T - 1))) T = 256;
+    int T = eT ? atoi(eT) : 512;
+    (void) n_tracks;
+    if (T < 64 || T > 512 || (T & (T - 1))) T = 512;
     p = WtPlan();
     p.delta = true;
     p.T = T; p.ppt = WT_DELTA_K; p.W = WT_DELTA_K * T; p.n_words = p.W / 64;
