@@ -211,9 +211,12 @@ def main():
         # scaled to this launch; None when no profile has been taken for this kernel.
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        kernel = ("wt_delta_kernel<%s>" % args.op) if st.get("kernel") == 1 else ("wt_reduce_kernel<%s,f32>" % args.op)
         if os.path.exists(tpath) and args.op == "mean":
             try:
-                traffic = json.load(open(tpath))["hbm_bytes_per_algorithmic_byte"] * alg_bytes
+                tj = json.load(open(tpath))
+                if tj.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
+                    traffic = tj["hbm_bytes_per_algorithmic_byte"] * alg_bytes
             except Exception:
                 traffic = None
         res = {
@@ -223,7 +226,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "int64" if st.get("kernel") == 1 else "f64", "data": "synthetic",
             "config": {"workload": "%s over %d synthetic float32 run-list tracks, 24 chromosomes = GRCh38 x %g "
                                    "(%.0f Mbp per GPU per step), mean run %g bp, 2%% gaps, tracks resident in HBM"
                                    % (args.op, N, args.scale, total_bp / 1e6, args.mean_run),
@@ -231,7 +234,7 @@ def main():
                        "input_runs_per_gpu": n_intervals, "output_runs_per_gpu": n_runs,
                        "window_bp": st["window_bp"], "lds_bytes_per_workgroup": st["lds_bytes"],
                        "sharding": "one independent chromosome batch per GPU, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "wt_reduce_kernel<mean,f32>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms": reduce_ms, "index_kernel_ms": index_ms,

@@ -225,6 +225,9 @@ typedef struct {
     int32_t lds_bytes;       /* LDS per workgroup                              */
     float index_ms;          /* last window-index kernel time (HIP events)     */
     float reduce_ms;         /* last multiplex+reduce kernel time (HIP events) */
+    int32_t kernel;          /* kernel of the last reduction: 0 general bitmap multiplexer (wt_reduce_kernel),
+                                1 exact difference array for Sum / Mean (wt_delta_kernel)             */
+    int32_t reserved_;
 } wtamd_stats;
 
 int wtamd_device_count(void);
