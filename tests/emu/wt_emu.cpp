@@ -104,7 +104,8 @@ struct EmuRun {
             for (int t = 0; t < T; t++) wt_delta_nextw(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
             wt_phase_lookback(P, c, k);
-            for (int t = 0; t < T; t++) wt_phase_write<OP, float, WT_DELTA_K>(P, c, lanes[t], t, T);
+            for (int t = 0; t < T; t++) wt_delta_stage<OP>(P, c, d, lanes[t], t, T);
+            for (int t = 0; t < T; t++) wt_delta_copy_out(P, c, d, t, T);
             wt_window_stats(P, c);
         }
     }

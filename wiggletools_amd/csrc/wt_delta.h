@@ -227,6 +227,20 @@ WT_DEV bool wt_delta_verdict(const WtParams &P, const WtDeltaCtx &d, int &emin) 
 WT_DEV void wt_delta_apply(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t s, int32_t f, uint32_t vb,
                            int emin, bool ok, int32_t &my_next) {
     const int32_t w0 = c.sh->w0, w1 = c.sh->w1;
+#ifndef WT_DELTA_SLOW_APPLY
+    if (s >= w0 && f < w1) {                    // the common case: the run lies inside the window -- no branches
+        const int e = (int) ((vb >> 23) & 0xffu);
+        const uint32_t frac = vb & 0x7fffffu;
+        const uint32_t m = (ok && e) ? (frac | 0x800000u) : (ok ? frac : 0u);
+        long long vi = (long long) ((unsigned long long) m << (ok ? (e ? e : 1) - emin : 0));
+        if (vb >> 31) vi = -vi;
+        wt_lds_add64((unsigned long long *) &d.acc[s - w0], (unsigned long long) vi);
+        wt_lds_add32(&d.ev[s - w0], 1u);
+        wt_lds_add64((unsigned long long *) &d.acc[f - w0], (unsigned long long) (-vi));
+        wt_lds_add32(&d.ev[f - w0], 0x10000u);
+        return;
+    }
+#endif
     if (f == w0) { wt_lds_add32(&d.ev[0], 0x00010001u); return; }    // true breakpoint at w0, covers nothing here
     if (s >= w1) { my_next = s < my_next ? s : my_next; return; }
     const int e = (int) ((vb >> 23) & 0xffu);
@@ -362,6 +376,52 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
     }
     ((uint8_t *) c.U)[tid] = (uint8_t) L.evmask;
     ((uint8_t *) c.E)[tid] = (uint8_t) em;
+}
+
+// Output staging.  A lane owns 8 consecutive positions, so writing its runs straight to HBM makes
+// every store instruction touch 64 scattered 4/8-byte pieces.  Instead the runs are first placed
+// in LDS at their rank inside the window (acc[] / ev[] are dead after the scan and are exactly big
+// enough: one f64 and one u32 per position), then copied out with consecutive lanes writing
+// consecutive runs; the finish (next breakpoint) is looked up by the copying lane.
+template <int OP>
+WT_DEV void wt_delta_stage(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtLane<WT_DELTA_K> &L, int tid, int nt) {
+    const unsigned em = ((const uint8_t *) c.E)[tid];
+    if (!em) return;
+    const int p0 = tid * WT_DELTA_K;
+    const int w = p0 >> 6, b0 = p0 & 63;
+    const uint64_t below0 = b0 ? wt_mask_incl(b0 - 1) : 0ull;
+    unsigned idx = c.epfx[w] + (unsigned) wt_popc64(c.E[w] & below0);
+    double *sv = (double *) d.acc;
+    uint32_t *sp = d.ev;
+#pragma unroll
+    for (int k = 0; k < WT_DELTA_K; k++) {
+        if (!((em >> k) & 1u)) continue;
+        sv[idx] = L.res[k];
+        sp[idx] = (uint32_t) (p0 + k);
+        idx++;
+    }
+}
+
+WT_DEV void wt_delta_copy_out(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+    const int n = c.sh->n_emit;
+    const long long goff = c.sh->goffset;
+    const int32_t w0 = c.sh->w0;
+    const double *sv = (const double *) d.acc;
+    const uint32_t *sp = d.ev;
+    unsigned long long bp = 0;
+    for (int i = tid; i < n; i += nt) {
+        const int p = (int) sp[i];
+        const int32_t fin = wt_next_breakpoint(P, c, p);
+        bp += (unsigned long long) (fin - (w0 + p));
+        const long long o = goff + i;
+        if (o >= P.capacity) continue;
+        P.o_start[o] = w0 + p;
+        P.o_finish[o] = fin;
+        P.o_value[o] = sv[i];
+    }
+#ifndef WT_NO_BPSUM
+    if (bp) wt_lds_add64(&c.sh->bp_sum, bp);
+#endif
 }
 
 // next non-empty word of U after every word (wt_next_breakpoint's jump table); one lane per word,

@@ -234,7 +234,13 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
         __syncthreads();
         WT_TICK(6);
         WT_MARK(110);
+#ifdef WT_DELTA_NO_STAGE
         wt_phase_write<OP, float, WT_DELTA_K>(P, c, L, tid, nt);
+#else
+        wt_delta_stage<OP>(P, c, d, L, tid, nt);
+        __syncthreads();
+        wt_delta_copy_out(P, c, d, tid, nt);
+#endif
         __syncthreads();
         WT_MARK(111);
         if (tid == 0) {
