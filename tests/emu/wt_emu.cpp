@@ -23,6 +23,7 @@ struct EmuRun {
     WtPlan plan;
     std::vector<char> lds;
     int T_lanes = 0;
+    long long n_redo = 0;
 
     template <int OP, class ValT, class ScrT, int K, bool MULTI>
     void run() {
@@ -80,6 +81,7 @@ struct EmuRun {
         wt_delta_ctx_init(d, P, lds.data());
         const int T = plan.T;
         std::vector<WtDeltaLane> dl(T);
+        int guess = 0;      // the workgroup's unit exponent (0: none yet)
         std::vector<WtLane<WT_DELTA_K>> lanes(T);
         for (;;) {
             const long long k = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
@@ -87,20 +89,47 @@ struct EmuRun {
             wt_phase_header(P, c, k);
             for (int t = 0; t < T; t++) wt_delta_zero(P, c, d, t, T);
             const int nchunks = (P.n_tracks + T - 1) / T;
-            for (int pass = 1; pass <= 2; pass++) {
+            auto ranges = [&](int ch) {
+                for (int t = 0; t < T; t++) wt_delta_ranges1(P, c, d, ch * T, t, T);
+                for (int t = 0; t < T; t++) wt_delta_ranges2(P, c, d, t, T);
+                for (int t = 0; t < T; t++) wt_delta_ranges3(P, c, d, t, T);
+            };
+            int scale = 1;
+            if (guess == 0) {       // no unit exponent known yet: range pass, then the delta pass
                 for (int ch = 0; ch < nchunks; ch++) {
-                    if (pass == 1 || nchunks > 1) {     // one chunk: pass 2 reuses pass 1's ranges
-                        for (int t = 0; t < T; t++) wt_delta_ranges1(P, c, d, ch * T, t, T);
-                        for (int t = 0; t < T; t++) wt_delta_ranges2(P, c, d, t, T);
-                        for (int t = 0; t < T; t++) wt_delta_ranges3(P, c, d, t, T);
+                    ranges(ch);
+                    for (int t = 0; t < T; t++) wt_delta_pass1(P, c, d, t, T);
+                }
+                const bool any = d.dsh->emin <= d.dsh->emax;
+                const bool ok = wt_delta_verdict(P, d, scale);
+                if (!ok) wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
+                for (int ch = 0; ch < nchunks; ch++) {
+                    if (nchunks > 1) ranges(ch);
+                    for (int t = 0; t < T; t++) wt_delta_pass2(P, c, d, scale, ok, false, true, t, T);
+                }
+                if (any && ok) guess = scale;
+            } else {                // speculative single pass with the workgroup's unit
+                for (int ch = 0; ch < nchunks; ch++) {
+                    ranges(ch);
+                    for (int t = 0; t < T; t++) wt_delta_pass2(P, c, d, guess, true, true, true, t, T);
+                }
+                int lo; bool ok;
+                scale = guess;
+                if (!wt_delta_window_verdict(P, d, guess, lo, ok)) {
+                    n_redo++;
+                    for (int t = 0; t < T; t++) wt_delta_rezero(P, c, d, t, T);
+                    if (!ok) wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
+                    for (int ch = 0; ch < nchunks; ch++) {
+                        if (nchunks > 1) ranges(ch);
+                        for (int t = 0; t < T; t++) wt_delta_pass2(P, c, d, lo, ok, false, false, t, T);
                     }
-                    if (pass == 1) for (int t = 0; t < T; t++) wt_delta_pass1(P, c, d, t, T);
-                    else for (int t = 0; t < T; t++) wt_delta_pass2(P, c, d, ch == 0, t, T);
+                    scale = lo;
+                    if (ok) guess = lo;
                 }
             }
             for (int t = 0; t < T; t++) wt_delta_scan1(P, c, d, dl[t], t, T);
             for (int t = 0; t < T; t++) wt_delta_scan2(P, c, d, t, T);
-            for (int t = 0; t < T; t++) wt_delta_scan3<OP>(P, c, d, dl[t], lanes[t], t, T);
+            for (int t = 0; t < T; t++) wt_delta_scan3<OP>(P, c, d, dl[t], lanes[t], scale, t, T);
             for (int t = 0; t < T; t++) wt_delta_nextw(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
             wt_phase_lookback(P, c, k);
@@ -130,7 +159,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         if (seg_off[s + 1] > seg_off[s]) { fs[s] = start[seg_off[s]]; lf[s] = finish[seg_off[s + 1] - 1]; }
     const int64_t total = seg_off[n_seg];
     std::vector<unsigned long long> counters(WT_CTR_N, 0);
-    long long used_delta = 0, delta_bad = 0;
+    long long used_delta = 0, delta_bad = 0, n_redo_total = 0;
     // the engine's policy: exact difference-array path first when eligible, the general kernel
     // if any window had to give up
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -177,12 +206,13 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         if (info) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows; info[6] = R.plan.n_chunks; info[7] = R.plan.scratch_slab;
                     info[4] = (long long) counters[WT_CTR_BP]; info[5] = (long long) counters[WT_CTR_INTERVALS]; }
         if (delta) {
+            n_redo_total = R.n_redo;
             delta_bad = (long long) counters[WT_CTR_DELTA_BAD];
             used_delta = delta_bad == 0;
             if (used_delta) break;
         }
     }
-    if (info) { info[8] = used_delta; info[9] = delta_bad; }
+    if (info) { info[8] = used_delta; info[9] = delta_bad; info[10] = n_redo_total; }
     if (counters[WT_CTR_ERROR] & WT_ERR_CAPACITY) return -1;
     if (counters[WT_CTR_ERROR]) return -2;
     return (long long) counters[WT_CTR_RUNS];

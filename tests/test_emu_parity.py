@@ -231,6 +231,22 @@ def test_emu_delta_dense_window_beyond_tile_table(oracle):
     assert_runs_equal(got, exp, 0.0, "dense %s" % info)
 
 
+@pytest.mark.parametrize("direction", ["falling", "rising"])
+def test_emu_delta_speculative_unit_is_redone(oracle, direction):
+    """The single-pass flavour scales with the smallest exponent the workgroup has met so far; a
+    window holding a smaller one (falling magnitudes), or too wide a span relative to that guess
+    although narrow in itself (rising magnitudes), is redone with its own unit -- same bits."""
+    t = _delta_case(21, 7, [12000], 6, lambda r, k: r.random(k) + 1.0, gap=0.1)
+    pos = t.start.astype(np.int64)
+    step = 3 if direction == "rising" else -3
+    t.value[:] = np.ldexp(t.value.astype(np.float64), step * (pos // 512)).astype(np.float32)   # 2^(+-3) per window
+    for op in ("sum", "mean"):
+        exp = oracle.reduce(t.as_dict(), op)
+        got, info = emu.reduce(t, op, delta_T=64)
+        assert info["delta"] == 1 and info["delta_bad"] == 0 and info["delta_redo"] > 0, info
+        assert_runs_equal(got, exp, 0.0, "%s %s %s" % (direction, op, info))
+
+
 def test_emu_delta_falls_back_on_wide_range_and_nonfinite(oracle):
     """Windows whose values span too many binades, or hold NaN / Inf, are re-run by the general kernel."""
     for kind in ("wide", "nan", "inf", "denormal"):

@@ -141,6 +141,29 @@ def test_gpu_exact_difference_array_path(oracle, engine, seed, monkeypatch):
     ts.close()
 
 
+@pytest.mark.parametrize("direction", ["falling", "rising", "mixed"])
+def test_gpu_difference_array_speculative_unit(oracle, engine, direction):
+    """Magnitudes drifting along the genome: windows whose exponents leave the workgroup's guessed
+    unit are redone with their own; whichever workgroup got which window, same bits."""
+    from wiggletools_amd.runlists import synth
+    t = synth(30, [300000, 50000], mean_run=16, gap_prob=0.1, seed=11)
+    rng = np.random.default_rng(5)
+    v = rng.random(len(t.value)) + 1.0
+    pos = t.start.astype(np.int64)
+    if direction == "mixed":
+        shift = rng.integers(-8, 9, size=80)[(pos // 4096) % 80]
+    else:
+        shift = (1 if direction == "rising" else -1) * (pos // 8192)
+    t.value[:] = np.ldexp(v, shift).astype(np.float32)
+    ts = engine.TrackSet.from_runlists(t)
+    for op in ("sum", "mean"):
+        exp = oracle.reduce(t.as_dict(), op)
+        got = ts.reduce_host(op)
+        assert ts.stats()["kernel"] == 1
+        assert_runs_equal(got, exp, 0.0, "%s %s" % (direction, op))
+    ts.close()
+
+
 def test_gpu_wilcoxon_50_vs_50(oracle, engine):
     """BASELINE config C5 shape (n1 = n2 = 50: mu = 1250, sigma = sqrt(21041))."""
     from wiggletools_amd.runlists import synth

@@ -286,14 +286,16 @@ WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint3
     }
 }
 
-WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, bool first_chunk, int tid, int nt) {
+// `scale`: exponent of one unit of the scaled mantissas; `ok`: false -> the window is known not to be
+// exact (only coordinates matter); `collect`: also gather the exponent range of the values (the
+// speculative single-pass flavour, see wt_delta_window_verdict); `stats`: count the intervals.
+WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale, bool ok, bool collect, bool stats,
+                           int tid, int nt) {
     const int wave = tid >> 6, lane = tid & 63, nwaves = nt >> 6;
     const uint32_t M = d.tpfx[nt];
     const uint32_t step = (uint32_t) nwaves * WT_DELTA_TILE;
-    int emin;
-    const bool ok = wt_delta_verdict(P, d, emin);
-    if (tid == 0 && first_chunk && !ok) wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
     int32_t my_next = 0x7fffffff;
+    int emin = 255, emax = 0, bad = 0;
     WtDeltaBatch cur, nxt;
     uint32_t tb = (uint32_t) wave * WT_DELTA_TILE;
     if (tb < M) wt_delta_fetch(P, d, nt, M, tb, lane, cur);
@@ -301,11 +303,51 @@ WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, bool firs
         if (tb + step < M) wt_delta_fetch(P, d, nt, M, tb + step, lane, nxt);
 #pragma unroll
         for (int u = 0; u < WT_DELTA_U; u++)
-            if (cur.in[u]) wt_delta_apply(P, c, d, cur.s[u], cur.f[u], cur.b[u], emin, ok, my_next);
+            if (cur.in[u]) {
+                const uint32_t vb = cur.b[u];
+                int e = (int) ((vb >> 23) & 0xffu);
+                if (e == 0xff) bad = 1;
+                e = e ? e : 1;
+                const bool nz = (vb & 0x7fffffffu) != 0u;
+                emin = (nz && e < emin) ? e : emin;
+                emax = (nz && e > emax) ? e : emax;
+                // speculative pass: a value below the guessed unit would lose bits -- it is added as 0
+                // here and the window is redone (wt_delta_window_verdict)
+                wt_delta_apply(P, c, d, cur.s[u], cur.f[u], vb, scale, ok && e >= scale, my_next);
+            }
         cur = nxt;
     }
     if (my_next != 0x7fffffff) wt_lds_min32(&c.sh->next_bp, my_next);
-    if (tid == 0 && M) wt_lds_add64(&c.sh->n_intervals, (unsigned long long) M);
+    if (collect) {
+        if (emin <= emax) { wt_lds_min32(&d.dsh->emin, emin); wt_lds_max32(&d.dsh->emax, emax); }
+        if (bad) wt_lds_max32(&d.dsh->bad, 1);
+    }
+    if (stats && tid == 0 && M) wt_lds_add64(&c.sh->n_intervals, (unsigned long long) M);
+}
+
+// Single-pass speculation.  Reading value[] twice costs a third more HBM traffic, and the passes
+// are bandwidth-bound, so a workgroup that already knows a unit exponent (`guess`: the smallest
+// exponent it has met so far) scales with it right away and gathers the window's true exponent
+// range on the side.  Any unit <= the window's smallest exponent is as exact as the smallest
+// itself provided the span test holds for it, so the result does not depend on the guess (nor on
+// which workgroup got which window).  After the pass:
+//   returns 1  the guess was fine: go on
+//   returns 0  a value lay below the guess, or the span test fails for the guess: the window is
+//              redone with its own smallest exponent `lo` (verdict `ok`)
+WT_DEV int wt_delta_window_verdict(const WtParams &P, const WtDeltaCtx &d, int guess, int &lo, bool &ok) {
+    int a = d.dsh->emin, b = d.dsh->emax;
+    const bool bad = d.dsh->bad != 0;
+    const int R = wt_delta_max_span(P.n_tracks);
+    if (a > b) { lo = guess; ok = !bad; return bad ? 0 : 1; }      // no non-zero value: any unit will do
+    lo = a;
+    ok = !bad && (b - a) <= R;
+    return (!bad && a >= guess && (b - guess) <= R) ? 1 : 0;
+}
+
+// redo of a window: clear the accumulators only (the exponent range is kept)
+WT_DEV void wt_delta_rezero(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+    for (int x = tid; x < P.W; x += nt) { d.acc[x] = 0; d.ev[x] = 0; }
+    if (tid == 0) { d.dsh->base_v = 0; d.dsh->base_c = 0; }
 }
 
 // scan step 1: the lane's 8 positions
@@ -345,7 +387,7 @@ WT_DEV void wt_delta_scan2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, 
 // scan step 3: running sum / coverage of every position, breakpoint and emitted bytes, run values
 template <int OP>
 WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtDeltaLane &L,
-                           WtLane<WT_DELTA_K> &out, int tid, int nt) {
+                           WtLane<WT_DELTA_K> &out, int emin, int tid, int nt) {
     long long bv = d.dsh->base_v;
     int32_t bc = d.dsh->base_c;
 #ifdef WT_EMU
@@ -361,8 +403,6 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
     const bool strict = (P.flags & WT_STRICT_SET0) != 0;
     const int p0 = tid * WT_DELTA_K;
     // 2^(emin - 150): the weight of one unit of the scaled mantissas
-    int emin;
-    (void) wt_delta_verdict(P, d, emin);
     const double q = __builtin_bit_cast(double, (uint64_t) (emin - 150 + 1023) << 52);
     const long long room = (long long) c.sh->emit_hi - ((long long) c.sh->w0 + p0);
     uint32_t em = 0;

@@ -176,6 +176,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
     WtDeltaLane DL;
     WtLane<WT_DELTA_K> L;
     const int tid = threadIdx.x, nt = blockDim.x;
+    int guess = 0;              // the workgroup's unit exponent (0: none yet); uniform across the lanes
     long long k_dbg = -1;
     (void) k_dbg;
 #ifdef WT_PROFILE
@@ -199,26 +200,73 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
         wt_delta_zero(P, c, d, tid, nt);
         WT_TICK(0);
         WT_MARK(102);
-        for (int pass = 1; pass <= 2; pass++) {
+        int scale = 1;
+        if (guess == 0) {
+            // no unit exponent known to this workgroup yet: exponent-range pass, then the delta pass
             for (int ch = 0; ch < nchunks; ch++) {
-                if (pass == 1 || nchunks > 1) {         // one chunk: pass 2 reuses pass 1's ranges
+                wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
+                __syncthreads();
+                wt_delta_ranges_w2(P, c, d, tid, nt);
+                __syncthreads();
+                WT_TICK(1);
+                wt_delta_pass1(P, c, d, tid, nt);
+                __syncthreads();
+                WT_TICK(2);
+            }
+            const bool any = d.dsh->emin <= d.dsh->emax;
+            const bool ok = wt_delta_verdict(P, d, scale);
+            if (!ok && tid == 0) wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
+            for (int ch = 0; ch < nchunks; ch++) {
+                if (nchunks > 1) {
                     wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
                     __syncthreads();
                     wt_delta_ranges_w2(P, c, d, tid, nt);
                     __syncthreads();
                 }
-                WT_TICK(1);
-                if (pass == 1) wt_delta_pass1(P, c, d, tid, nt);
-                else wt_delta_pass2(P, c, d, ch == 0, tid, nt);
+                wt_delta_pass2(P, c, d, scale, ok, false, true, tid, nt);
                 __syncthreads();
-                if (pass == 1) WT_TICK(2); else WT_TICK(3);
+                WT_TICK(3);
+            }
+            if (any && ok) guess = scale;
+        } else {
+            // speculative single pass with the workgroup's unit (wt_delta_window_verdict)
+            for (int ch = 0; ch < nchunks; ch++) {
+                wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
+                __syncthreads();
+                wt_delta_ranges_w2(P, c, d, tid, nt);
+                __syncthreads();
+                WT_TICK(1);
+                wt_delta_pass2(P, c, d, guess, true, true, true, tid, nt);
+                __syncthreads();
+                WT_TICK(3);
+            }
+            int lo;
+            bool ok;
+            scale = guess;
+            if (!wt_delta_window_verdict(P, d, guess, lo, ok)) {      // workgroup-uniform
+                __syncthreads();            // every lane has read the verdict fields
+                wt_delta_rezero(P, c, d, tid, nt);
+                if (!ok && tid == 0) wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
+                __syncthreads();
+                for (int ch = 0; ch < nchunks; ch++) {
+                    if (nchunks > 1) {
+                        wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
+                        __syncthreads();
+                        wt_delta_ranges_w2(P, c, d, tid, nt);
+                        __syncthreads();
+                    }
+                    wt_delta_pass2(P, c, d, lo, ok, false, false, tid, nt);
+                    __syncthreads();
+                }
+                scale = lo;
+                if (ok) guess = lo;
             }
         }
         WT_MARK(105);
         wt_delta_scan_w1(P, c, d, DL, tid, nt);
         __syncthreads();
         WT_MARK(107);
-        wt_delta_scan3<OP>(P, c, d, DL, L, tid, nt);
+        wt_delta_scan3<OP>(P, c, d, DL, L, scale, tid, nt);
         __syncthreads();
         WT_TICK(4);
         WT_MARK(108);
