@@ -1277,6 +1277,10 @@ WT_DEV void wt_index_cursor_set(const WtParams &P, WtIndexCursor &c, long long s
 // f = finish[g], pf = finish[g-1] (ignored for the first interval of a segment)
 WT_DEV void wt_index_apply(const WtParams &P, WtIndexCursor &c, long long g, int32_t f, int32_t pf) {
     while (g >= c.s1) wt_index_cursor_set(P, c, c.seg + 1);      // empty segments are skipped too
+    // by far the most common case, tested first in 32-bit arithmetic: an interior interval of its
+    // segment whose finish lies in the same window as its predecessor's claims nothing
+    if (g > c.s0 && g + 1 < c.s1 && pf >= c.cb &&
+        ((uint32_t) (pf - c.cb) >> P.logW) == ((uint32_t) (f - c.cb) >> P.logW)) return;
     const long long jr = g - c.s0;
     const int32_t cb = c.cb;
     // cbase may be a range start above the data start: intervals ending before it claim nothing

@@ -309,8 +309,8 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
 // Each block owns ONE contiguous span of intervals: a single binary search finds the
 // (chrom,track) segment of its first interval, every lane then walks its cursor forward.  The
 // finish[] reads of the next sub-chunk are in flight while the current one is applied.
-#define WT_INDEX_UNROLL 8
-#define WT_INDEX_CHUNK (256 * WT_INDEX_UNROLL)
+#define WT_INDEX_UNROLL 2
+#define WT_INDEX_CHUNK (256 * 4 * WT_INDEX_UNROLL)
 __global__ void __launch_bounds__(256) wt_index_kernel(const WtParams P, long long total, long long span) {
     const long long begin0 = (long long) blockIdx.x * span;
     long long end0 = begin0 + span;
@@ -318,25 +318,37 @@ __global__ void __launch_bounds__(256) wt_index_kernel(const WtParams P, long lo
     if (begin0 >= end0) return;
     WtIndexCursor cur;
     wt_index_cursor_set(P, cur, wt_index_find_segment(P, begin0));
-    int32_t f[WT_INDEX_UNROLL], pf[WT_INDEX_UNROLL], nf[WT_INDEX_UNROLL], npf[WT_INDEX_UNROLL];
-#pragma unroll
-    for (int u = 0; u < WT_INDEX_UNROLL; u++) {
-        const long long g = begin0 + threadIdx.x + 256 * u;
-        f[u] = (g < end0) ? P.finish[g] : 0;
-        pf[u] = (g < end0 && g > 0) ? P.finish[g - 1] : 0;
-    }
-    for (long long begin = begin0; begin < end0; begin += WT_INDEX_CHUNK) {
-        const long long nb = begin + WT_INDEX_CHUNK;
+    // Every lane takes 4 CONSECUTIVE runs per sub-chunk: one 16-byte load of finish[] plus the
+    // predecessor's finish (the kernel was instruction-bound on per-element 64-bit addressing).
+    // begin0 is a multiple of WT_INDEX_CHUNK, so the vectors never straddle `total` unguarded.
+    struct __attribute__((packed, aligned(4))) V4 { int32_t x[4]; };
+    V4 f[WT_INDEX_UNROLL], nf[WT_INDEX_UNROLL];
+    int32_t pf[WT_INDEX_UNROLL], npf[WT_INDEX_UNROLL];
+    auto fetch = [&](long long base, V4 (&v)[WT_INDEX_UNROLL], int32_t (&p)[WT_INDEX_UNROLL]) {
 #pragma unroll
         for (int u = 0; u < WT_INDEX_UNROLL; u++) {
-            const long long g = nb + threadIdx.x + 256 * u;
-            nf[u] = (g < end0) ? P.finish[g] : 0;
-            npf[u] = (g < end0) ? P.finish[g - 1] : 0;
+            const long long g = base + 4ll * (threadIdx.x + 256 * u);
+            if (g + 3 < end0) {
+                v[u] = *(const V4 *) (P.finish + g);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[u].x[q] = (g + q < end0) ? P.finish[g + q] : 0;
+            }
+            p[u] = (g < end0 && g > 0) ? P.finish[g - 1] : 0;
         }
+    };
+    fetch(begin0, f, pf);
+    for (long long begin = begin0; begin < end0; begin += WT_INDEX_CHUNK) {
+        if (begin + WT_INDEX_CHUNK < end0) fetch(begin + WT_INDEX_CHUNK, nf, npf);
 #pragma unroll
         for (int u = 0; u < WT_INDEX_UNROLL; u++) {
-            const long long g = begin + threadIdx.x + 256 * u;
-            if (g < end0) wt_index_apply(P, cur, g, f[u], pf[u]);
+            const long long g = begin + 4ll * (threadIdx.x + 256 * u);
+            int32_t prev = pf[u];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (g + q < end0) wt_index_apply(P, cur, g + q, f[u].x[q], prev);
+                prev = f[u].x[q];
+            }
         }
 #pragma unroll
         for (int u = 0; u < WT_INDEX_UNROLL; u++) { f[u] = nf[u]; pf[u] = npf[u]; }
