@@ -273,6 +273,13 @@ int wtamd_multiplex_host(wtamd_trackset *ts, uint32_t flags, wtamd_runs *runs,
  * (reference statistics.c:103-120).  Result written to *auc (host). */
 int wtamd_runs_auc(const wtamd_runs *runs, int64_t n_runs, double *auc, void *stream);
 
+/* Pearson correlation of the two tracks of `ts` over their Multiplexer tile, on device
+ * (reference PearsonIntegrator over a 2-track Multiplexer: statistics.c:414-465,
+ * commandParser.c:683-694).  Non-strict Multiplexer, absent tracks read as their defaults.
+ * NaN when T_XX*T_YY == 0 (statistics.c:421-423).  Slices of runs are merged with the reference's
+ * own update formula, so the result agrees to rounding (not bit-for-bit). */
+int wtamd_pearson(wtamd_trackset *ts, double *result);
+
 /* Run compression on device (reference CompressionWiggleIterator, unaryOps.c:235-253, which the
  * default writer applies, wigWriter.c:263-267): adjacent runs of one chromosome merge while
  * start == previous finish and (both NaN or |value - value of the group's first run| < 1e-6).

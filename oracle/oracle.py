@@ -264,6 +264,20 @@ def auc(start, finish, value):
     return oracle_lib().wto_auc(len(s), s.ctypes.data, f.ctypes.data, v.ctypes.data)
 
 
+def pearson(t):
+    """Pearson correlation of tracks 0 and 1 (reference PearsonIntegrator over a 2-track Multiplexer)."""
+    c, s, f, vals, ip = multiplex(t)
+    d = np.asarray(t["defaults"], np.float64)
+    x = np.ascontiguousarray(np.where(ip[:, 0] != 0, vals[:, 0], d[0]), np.float64)
+    y = np.ascontiguousarray(np.where(ip[:, 1] != 0, vals[:, 1], d[1]), np.float64)
+    s = np.ascontiguousarray(s, np.int32)
+    f = np.ascontiguousarray(f, np.int32)
+    L = oracle_lib()
+    L.wto_pearson.restype = C.c_double
+    L.wto_pearson.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return L.wto_pearson(len(s), s.ctypes.data, f.ctypes.data, x.ctypes.data, y.ctypes.data)
+
+
 def compress(chrom, start, finish, value):
     c = np.array(chrom, np.int32)
     s = np.array(start, np.int32)

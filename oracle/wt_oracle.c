@@ -512,6 +512,34 @@ double wto_auc(int64_t n, const int32_t *start, const int32_t *finish, const dou
     return res;
 }
 
+/* statistics.c:414-458 PearsonPop over the Multiplexer tile of tracks {0,1}: x[r], y[r] are the
+ * default-substituted values of run r.  The reference's online update, statement for statement;
+ * `count` is a C int there (overflows past 2^31 covered bp -- not reproduced: int64 here).
+ * Result NaN unless T_XX*T_YY != 0 (:421-423). */
+double wto_pearson(int64_t n, const int32_t *start, const int32_t *finish, const double *x, const double *y) {
+    int64_t count = 0;
+    double sum_X = 0, sum_Y = 0, T_XX = 0, T_XY = 0, T_YY = 0;
+    for (int64_t r = 0; r < n; r++) {
+        const double X = x[r], Y = y[r];
+        const int length = finish[r] - start[r];
+        if (count) {
+            double old_mean_X = sum_X / count;
+            double new_mean_X = sum_X / (count + length);
+            double old_mean_Y = sum_Y / count;
+            double new_mean_Y = sum_Y / (count + length);
+            double scaling_ratio = (double) count / (count + length);
+            T_XY += (new_mean_X * old_mean_Y + scaling_ratio * X * Y - new_mean_X * Y - new_mean_Y * X) * length;
+            T_XX += (new_mean_X * (old_mean_X - 2 * X) + scaling_ratio * X * X) * length;
+            T_YY += (new_mean_Y * (old_mean_Y - 2 * Y) + scaling_ratio * Y * Y) * length;
+        }
+        count += length;
+        sum_X += X * length;
+        sum_Y += Y * length;
+    }
+    if (T_XX * T_YY) return T_XY / sqrt(T_XX * T_YY);
+    return NAN;
+}
+
 /* unaryOps.c:235-253 : in-place merge of adjacent runs |dv| < 1e-6 (or both NaN). Returns new count. */
 int64_t wto_compress(int64_t n, int32_t *chrom, int32_t *start, int32_t *finish, double *value) {
     int64_t w = 0;

@@ -308,3 +308,36 @@ def test_gpu_bigwig_config_c1(oracle, engine):
     assert s.tolist() == list(range(1, 11)) and f.tolist() == list(range(2, 12))
     assert v.tolist() == [0.5, 1.5, 1, 3, 2, 4.5, 3, 6, 4, 4.5]
     ts.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_gpu_pearson_integrator(oracle, engine, seed):
+    """PearsonIntegrator over a 2-track Multiplexer (statistics.c:414-465) on device: slices of runs
+    merged with the reference's own update formula -- agreement to rounding with the oracle's
+    sequential restatement (which equals the compiled reference bit for bit, tests/test_oracle_vs_ref.py)."""
+    from wiggletools_amd.runlists import synth
+    rng = np.random.default_rng(seed)
+    t = synth(2, [int(rng.integers(50, 400000)), 3000], mean_run=float(rng.choice([1, 16, 200])),
+              gap_prob=float(rng.choice([0.0, 0.2])), seed=100 + seed)
+    if seed % 2:
+        t.defaults[:] = [0.5, -2.0]
+    exp = oracle.pearson(t.as_dict())
+    ts = engine.TrackSet.from_runlists(t)
+    got = ts.pearson()
+    ts.close()
+    assert abs(got - exp) <= 1e-9 * max(1.0, abs(exp)), (got, exp)
+
+
+def test_gpu_pearson_golden_and_degenerate(oracle, engine):
+    import os
+    from wiggletools_amd.textio import load_runlists
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    t = load_runlists([os.path.join(G, "fixedStep.wig"), os.path.join(G, "variableStep.wig")])
+    ts = engine.TrackSet.from_runlists(t)
+    assert abs(ts.pearson() - (-0.028968)) < 5e-7          # reference test/expected/pearson.txt
+    ts.close()
+    from wiggletools_amd.runlists import RunLists
+    t = RunLists.from_lists([[[(1, 10, 2.0)]], [[(1, 10, 3.0)]]])       # constant tracks: T_XX * T_YY == 0 -> NaN
+    ts = engine.TrackSet.from_runlists(t)
+    assert np.isnan(ts.pearson())
+    ts.close()

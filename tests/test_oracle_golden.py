@@ -85,12 +85,12 @@ def test_oracle_auc_mean_survey_vector(oracle):
 
 
 def test_oracle_pearson_reference_expected(oracle):
-    """reference test/expected/pearson.txt == -0.028968 (test/test.py:104); checked through
-    the compiled reference when available (PearsonIntegrator is a 'next' row)."""
-    if not oracle.have_ref():
-        pytest.skip("compiled reference not available")
+    """reference test/expected/pearson.txt == -0.028968 (test/test.py:104): the oracle's restatement
+    of PearsonPop, and the compiled reference when available."""
     t = load_runlists([os.path.join(G, "fixedStep.wig"), os.path.join(G, "variableStep.wig")])
-    assert abs(oracle.ref_pearson(t.as_dict()) - (-0.028968)) < 5e-7
+    assert abs(oracle.pearson(t.as_dict()) - (-0.028968)) < 5e-7
+    if oracle.have_ref():
+        assert oracle.ref_pearson(t.as_dict()) == oracle.pearson(t.as_dict())
 
 
 def test_tdist_tail_against_scipy(oracle):

@@ -75,3 +75,17 @@ def test_auc_and_compression_match_reference(O, seed):
         a = O.compress(c, s, f, v)
         b = O.ref_reduce(d, op, compressed=True)
         assert_runs_equal(a, b, 0.0, "compress %s" % op)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_oracle_pearson_matches_compiled_reference(oracle, seed):
+    """statistics.c:414-465 restated (oracle/wt_oracle.c:wto_pearson) vs the compiled reference."""
+    rng = np.random.default_rng(seed)
+    t = random_case(7000 + seed, n_tracks=2, dtype=np.float64 if seed % 2 else np.float32)
+    if np.isnan(t.value).any() or np.isnan(t.defaults).any():
+        t.value[np.isnan(t.value)] = 1.5
+        t.defaults[np.isnan(t.defaults)] = 0.0
+    d = t.as_dict()
+    exp = oracle.ref_pearson(d)
+    got = oracle.pearson(d)
+    assert (np.isnan(exp) and np.isnan(got)) or got == exp, (got, exp)

@@ -392,6 +392,83 @@ __global__ void wt_auc_final_kernel(const double *partial, int n, double *out) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Pearson correlation of two tracks over the Multiplexer tile (reference PearsonIntegrator,
+// statistics.c:414-465).  The reference updates {count, sum, T_XX, T_XY, T_YY} run by run with the
+// weighted Welford / Chan step (its `new_mean` is old sum / new count; expanding
+// n*L/(n+L) * (X - mean)^2 gives exactly its expression).  Here every lane applies that very step
+// to a contiguous slice of runs, and slices are merged pairwise in genome order with the same
+// formula for two aggregates -- mathematically identical, rounding differs in the last bits
+// (tests: 1e-9 relative against the oracle; the reference prints 6 decimals).
+// ---------------------------------------------------------------------------
+struct WtMoments {
+    double n, sx, sy, txx, txy, tyy;
+};
+
+__device__ inline void wt_moments_add_run(WtMoments &m, double X, double Y, double L) {
+    if (m.n > 0) {
+        const double nn = m.n + L;
+        const double old_mx = m.sx / m.n, new_mx = m.sx / nn;
+        const double old_my = m.sy / m.n, new_my = m.sy / nn;
+        const double ratio = m.n / nn;
+        m.txy += (new_mx * old_my + ratio * X * Y - new_mx * Y - new_my * X) * L;
+        m.txx += (new_mx * (old_mx - 2 * X) + ratio * X * X) * L;
+        m.tyy += (new_my * (old_my - 2 * Y) + ratio * Y * Y) * L;
+    }
+    m.n += L;
+    m.sx += X * L;
+    m.sy += Y * L;
+}
+
+// a := a (+) b, b following a in genome order
+__device__ inline void wt_moments_merge(WtMoments &a, const WtMoments &b) {
+    if (b.n == 0) return;
+    if (a.n == 0) { a = b; return; }
+    const double n = a.n + b.n;
+    const double dx = b.sx / b.n - a.sx / a.n, dy = b.sy / b.n - a.sy / a.n;
+    const double w = a.n * b.n / n;
+    a.txx += b.txx + dx * dx * w;
+    a.txy += b.txy + dx * dy * w;
+    a.tyy += b.tyy + dy * dy * w;
+    a.n = n;
+    a.sx += b.sx;
+    a.sy += b.sy;
+}
+
+__global__ void __launch_bounds__(256) wt_pearson_kernel(const int32_t *start, const int32_t *finish, const double *tile,
+                                                          const uint8_t *inplay, double dx, double dy, long long n,
+                                                          WtMoments *partial) {
+    __shared__ WtMoments red[256];
+    const long long total_lanes = (long long) gridDim.x * blockDim.x;
+    const long long per = (n + total_lanes - 1) / total_lanes;          // contiguous slice per lane
+    const long long lane_id = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    long long lo = lane_id * per, hi = lo + per;
+    if (hi > n) hi = n;
+    WtMoments m = {0, 0, 0, 0, 0, 0};
+    for (long long r = lo; r < hi; r++) {
+        const double X = inplay[2 * r] ? tile[2 * r] : dx;
+        const double Y = inplay[2 * r + 1] ? tile[2 * r + 1] : dy;
+        wt_moments_add_run(m, X, Y, (double) (finish[r] - start[r]));
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 1; s < 256; s <<= 1) {                                 // ordered pairwise merge
+        if ((threadIdx.x & (2 * s - 1)) == 0) wt_moments_merge(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void wt_pearson_final_kernel(const WtMoments *partial, int n, double *out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        WtMoments m = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < n; i++) wt_moments_merge(m, partial[i]);
+        const double den = m.txx * m.tyy;
+        *out = den ? m.txy / sqrt(den) : __builtin_nan("");            // statistics.c:421-423
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -949,6 +1026,40 @@ int wtamd_runs_auc(const wtamd_runs *runs, int64_t n_runs, double *auc, void *st
     WT_HIP(hipStreamSynchronize(s));
     (void) hipFree(d_partial);
     return WTAMD_OK;
+}
+
+int wtamd_pearson(wtamd_trackset *ts, double *result) {
+    if (!ts || !result) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    if (ts->n_tracks != 2) return wt_fail(WTAMD_ERR_ARG, "wtamd_pearson: the track set must hold exactly two tracks");
+    int64_t cap = wtamd_trackset_max_runs(ts);
+    const int64_t alloc = cap > 0 ? cap : 1;
+    wtamd_runs d{};
+    d.capacity = cap;
+    double *d_tile = nullptr;
+    uint8_t *d_inplay = nullptr;
+    WtMoments *d_partial = nullptr;
+    double *d_out = nullptr;
+    const int blocks = 256;
+    WT_HIP(hipMalloc(&d.start, sizeof(int32_t) * alloc));
+    WT_HIP(hipMalloc(&d.finish, sizeof(int32_t) * alloc));
+    WT_HIP(hipMalloc(&d.value, sizeof(double) * alloc));
+    WT_HIP(hipMalloc(&d.chrom_run_off, sizeof(int64_t) * (ts->n_chrom + 1)));
+    WT_HIP(hipMalloc(&d_tile, sizeof(double) * alloc * 2));
+    WT_HIP(hipMalloc(&d_inplay, sizeof(uint8_t) * alloc * 2));
+    WT_HIP(hipMalloc(&d_partial, sizeof(WtMoments) * blocks));
+    WT_HIP(hipMalloc(&d_out, sizeof(double)));
+    int64_t n = 0;
+    int rc = wt_reduce_impl(ts, WT_OP_MULTIPLEX, 0, 0, &d, d_tile, d_inplay, &n, nullptr);
+    if (rc == WTAMD_OK) {
+        hipLaunchKernelGGL(wt_pearson_kernel, dim3(blocks), dim3(256), 0, nullptr, d.start, d.finish, d_tile, d_inplay,
+                           ts->defaults[0], ts->defaults[1], (long long) n, d_partial);
+        hipLaunchKernelGGL(wt_pearson_final_kernel, dim3(1), dim3(64), 0, nullptr, d_partial, blocks, d_out);
+        if (hipGetLastError() != hipSuccess || hipMemcpy(result, d_out, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = wt_fail(WTAMD_ERR_HIP, "wtamd_pearson: kernel launch / copy failed");
+    }
+    (void) hipFree(d.start); (void) hipFree(d.finish); (void) hipFree(d.value); (void) hipFree(d.chrom_run_off);
+    (void) hipFree(d_tile); (void) hipFree(d_inplay); (void) hipFree(d_partial); (void) hipFree(d_out);
+    return rc;
 }
 
 int wtamd_get_stats(const wtamd_trackset *ts_c, wtamd_stats *out) {

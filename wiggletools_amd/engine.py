@@ -102,6 +102,12 @@ class TrackSet:
         _lib.check(_lib.lib().wtamd_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in _lib.Stats._fields_}
 
+    def pearson(self):
+        """Pearson correlation of the set's two tracks (reference `pearson a b`), computed on device."""
+        out = C.c_double()
+        _lib.check(_lib.lib().wtamd_pearson(self._h, C.byref(out)))
+        return out.value
+
     # ---- host-output convenience (tests, drop-in layer) ----
     def reduce_host(self, op, flags=0, n_set0=0):
         """Returns (chrom, start, finish, value) numpy arrays."""
