@@ -29,8 +29,9 @@ struct EmuRun {
     void run() {
         WtCtx c;
         wt_ctx_init(c, P, lds.data());
-        std::vector<char> slab((size_t) P.g_scratch_slab);
+        std::vector<char> slab((size_t) (P.g_scratch_slab + P.g_attr_slab));
         if (P.g_scratch_slab) c.scratch = slab.data();      // one emulated workgroup: one slab
+        if (P.g_attr_slab) c.attr = slab.data() + P.g_scratch_slab;
         const int T = plan.T;
         std::vector<WtLane<K>> lanes(T);
         for (;;) {

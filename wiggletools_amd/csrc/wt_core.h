@@ -101,6 +101,7 @@ struct WtParams {
     uint8_t *o_inplay;            // WT_OP_MULTIPLEX only
     char *g_scratch;              // median / MWU with more tracks than LDS columns hold: one slab per workgroup
     long long g_scratch_slab;     // bytes per workgroup (0: the columns live in LDS)
+    long long g_attr_slab;        // MWU: bytes of per-rank attributes per workgroup, after the columns' slab
     // ---- LDS carve (bytes from the dynamic LDS base; all multiples of 16) ----
     int32_t chunk_tracks;         // tracks whose bitmaps are resident in LDS at a time (== n_tracks: one chunk)
     int32_t n_chunks;             // ceil(n_tracks / chunk_tracks)
@@ -142,6 +143,7 @@ struct WtCtx {
     int16_t *nextw;     // [n_words] index of the next non-empty word of U after w, or -1
     long long *gbase;   // [n_tracks] global index of (first covering interval) - 1
     char *scratch;      // per-lane column scratch for median / MWU
+    char *attr;         // MWU: per-rank attribute words [n_set0][lanes] (global slab of this workgroup)
     WtShared *sh;
 };
 
@@ -156,6 +158,7 @@ WT_DEV void wt_ctx_init(WtCtx &c, const WtParams &P, char *lds) {
     c.nextw = (int16_t *) (lds + P.off_nextw);
     c.gbase = (long long *) (lds + P.off_gbase);
     c.scratch = lds + P.off_scratch;
+    c.attr = nullptr;
     c.sh = (WtShared *) (lds + P.off_shared);
 }
 
@@ -505,6 +508,12 @@ WT_DEV void wt_phase_count_b(const WtParams &P, WtCtx &c, int t_lo, int t_hi, in
 #endif
 #ifndef WT_PIPE
 #define WT_PIPE 3
+#endif
+#ifndef WT_MEDIAN_BITS
+#define WT_MEDIAN_BITS 2  // key bits decided per sweep of the median's bitwise selection
+#endif
+#ifndef WT_MWU_EB
+#define WT_MWU_EB 4      // set-0 elements ranked per sweep over a lane's value column
 #endif
 #define WT_PRAGMA(x) _Pragma(#x)
 #define WT_UNROLL_TRACKS WT_PRAGMA(unroll WT_TRACK_UNROLL)
@@ -884,8 +893,8 @@ WT_DEV void wt_eval_mid(const WtParams &P, WtAcc<K> &A) {
 }
 
 template <int OP, class ValT, class ScrT, int K>
-WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K], char *scratch, int lane_col,
-                           int colstride) {
+WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K], char *scratch, char *attr_base,
+                           int lane_col, int colstride) {
     const int N = P.n_tracks;
     if (OP == WT_OP_SUM || OP == WT_OP_PRODUCT || OP == WT_OP_MEAN) {
 #pragma unroll
@@ -937,14 +946,26 @@ WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K
         const KeyT *col = (const KeyT *) scratch + lane_col;
         const int kth = N / 2;       // 0-based rank of vals[N/2]
         // largest key Kk such that count(keys < Kk) <= kth  ==  the kth smallest key
+        // WT_MEDIAN_BITS key bits are decided per sweep over the column (2^B - 1 trial keys counted
+        // at once): fewer sweeps, each LDS read serves several comparisons (the loop is bound by
+        // LDS latency at the few waves per CU the columns leave room for).
         KeyT Kk = 0;
-        for (int b = (int) sizeof(KeyT) * 8 - 1; b >= 0; b--) {
-            const KeyT trial = Kk | ((KeyT) 1 << b);
-            int below = 0;
-            // independent LDS reads: unrolled so that several are in flight (few waves per CU here)
-#pragma unroll 10
-            for (int i = 0; i < N; i++) below += (col[(size_t) i * colstride] < trial);
-            if (below <= kth) Kk = trial;
+        constexpr int B = WT_MEDIAN_BITS, NT = (1 << B) - 1, KB = (int) sizeof(KeyT) * 8;
+        static_assert(KB % B == 0, "WT_MEDIAN_BITS must divide the key width");
+        for (int b = KB - B; b >= 0; b -= B) {
+            KeyT trial[NT];
+            int below[NT];
+#pragma unroll
+            for (int q = 0; q < NT; q++) { trial[q] = Kk | ((KeyT) (q + 1) << b); below[q] = 0; }
+#pragma unroll 8
+            for (int i = 0; i < N; i++) {
+                const KeyT key = col[(size_t) i * colstride];
+#pragma unroll
+                for (int q = 0; q < NT; q++) below[q] += (key < trial[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < NT; q++)
+                if (below[q] <= kth) Kk = trial[q];      // below[] is non-decreasing in q: the last hit wins
         }
         const double m = (sizeof(ScrT) == 4) ? (double) wt_unkey32((uint32_t) Kk) : wt_unkey64((uint64_t) Kk);
         res[0] = A.nan[0] ? wt_nan() : m;
@@ -966,24 +987,52 @@ WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K
         // performing the same double additions in the same order.
         const int na = P.n_set0, nb = N - P.n_set0;
         const ScrT *val = (const ScrT *) scratch + lane_col;                       // [N][colstride]
-        uint32_t *attr = (uint32_t *) ((ScrT *) scratch + (size_t) N * colstride) + lane_col;   // [na][colstride]
+        uint32_t *attr = (uint32_t *) attr_base + lane_col;                        // [na][colstride]
         if (A.nan[0]) { res[0] = wt_nan(); return; }
-        for (int e = 0; e < na; e++) {
-            const ScrT x = val[(size_t) e * colstride];
-            int L = 0, t = 0, r = 0, later_equal = 0;
-#pragma unroll 8
+        // WT_MWU_EB set-0 elements per sweep over the column: every LDS read serves EB comparisons
+        // (the loop was bound by LDS latency at the 2 waves per CU the columns leave room for)
+        constexpr int EB = WT_MWU_EB;
+        for (int e0 = 0; e0 < na; e0 += EB) {
+            ScrT x[EB];
+            int L[EB], t[EB], r[EB], later[EB];
+#pragma unroll
+            for (int q = 0; q < EB; q++) {
+                x[q] = val[(size_t) (e0 + q < na ? e0 + q : na - 1) * colstride];
+                L[q] = 0; t[q] = 0; r[q] = 0; later[q] = 0;
+            }
+#pragma unroll 4
             for (int j = na; j < N; j++) {
                 const ScrT y = val[(size_t) j * colstride];
-                L += (y < x);
-                t += (y == x);
+#pragma unroll
+                for (int q = 0; q < EB; q++) { L[q] += (y < x[q]); t[q] += (y == x[q]); }
             }
-#pragma unroll 8
-            for (int j = 0; j < na; j++) {
+            // set-0 entries before the block only need (y <= x), the ones after it (y < x) and
+            // (y == x); the index comparisons matter inside the block alone
+#pragma unroll 4
+            for (int j = 0; j < e0; j++) {
                 const ScrT y = val[(size_t) j * colstride];
-                r += (y < x) | ((y == x) & (j < e));
-                later_equal += (y == x) & (j > e);
+#pragma unroll
+                for (int q = 0; q < EB; q++) r[q] += (y <= x[q]);
             }
-            attr[(size_t) r * colstride] = ((uint32_t) L << 17) | ((uint32_t) t << 1) | (later_equal == 0 ? 1u : 0u);
+            const int e1 = e0 + EB < na ? e0 + EB : na;
+            for (int j = e0; j < e1; j++) {
+                const ScrT y = val[(size_t) j * colstride];
+#pragma unroll
+                for (int q = 0; q < EB; q++) {
+                    r[q] += (y < x[q]) | ((y == x[q]) & (j < e0 + q));
+                    later[q] += (y == x[q]) & (j > e0 + q);
+                }
+            }
+#pragma unroll 4
+            for (int j = e1; j < na; j++) {
+                const ScrT y = val[(size_t) j * colstride];
+#pragma unroll
+                for (int q = 0; q < EB; q++) { r[q] += (y < x[q]); later[q] += (y == x[q]); }
+            }
+#pragma unroll
+            for (int q = 0; q < EB; q++)
+                if (e0 + q < na)
+                    attr[(size_t) r[q] * colstride] = ((uint32_t) L[q] << 17) | ((uint32_t) t[q] << 1) | (later[q] == 0 ? 1u : 0u);
         }
         const double mu = (double) (na * nb / 2);                               // :386 int division
         const double sigma = sqrt((double) (na * nb * (na + nb + 1) / 12));     // :387 int division
@@ -1092,7 +1141,7 @@ WT_DEV void wt_phase_eval_chunk(const WtParams &P, WtCtx &c, WtAcc<K> &A, int pa
 template <int OP, class ValT, class ScrT, int K>
 WT_DEV void wt_phase_eval_finish(const WtParams &P, WtCtx &c, const WtAcc<K> &A, WtLane<K> &L, int tid, int nt) {
     if (!wt_lane_emit_bits<K>(P, c, tid)) return;
-    wt_eval_finish<OP, ValT, ScrT, K>(P, A, L.res, c.scratch, tid, nt);
+    wt_eval_finish<OP, ValT, ScrT, K>(P, A, L.res, c.scratch, c.attr, tid, nt);
 }
 
 // ---------------------------------------------------------------------------

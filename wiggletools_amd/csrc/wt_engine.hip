@@ -42,8 +42,11 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
     wt_ctx_init(c, P, wt_lds);
+    // global slab of this workgroup: [value columns, if they do not fit LDS][MWU attributes]
+    const size_t slab = (size_t) P.g_scratch_slab + (size_t) P.g_attr_slab;
     if (MULTI && (OP == WT_OP_MEDIAN || OP == WT_OP_MWU) && P.g_scratch_slab)
-        c.scratch = P.g_scratch + (size_t) blockIdx.x * (size_t) P.g_scratch_slab;
+        c.scratch = P.g_scratch + (size_t) blockIdx.x * slab;
+    if (OP == WT_OP_MWU) c.attr = P.g_scratch + (size_t) blockIdx.x * slab + (size_t) P.g_scratch_slab;
     WtLane<K> L;
     const int tid = threadIdx.x, nt = blockDim.x;
 #ifdef WT_MARK_ONLY
@@ -787,9 +790,9 @@ struct WtLaunch {
         long long g = (long long) num_cu * per_cu;
         if (g > P.n_windows) g = P.n_windows;
         if (g < 1) g = 1;
-        if (P.g_scratch_slab) {     // global scratch columns: one slab per resident workgroup
-            if (g > 2ll * num_cu) g = 2ll * num_cu;
-            const size_t need = (size_t) g * (size_t) P.g_scratch_slab;
+        if (P.g_scratch_slab || P.g_attr_slab) {    // one global slab per resident workgroup
+            if (P.g_scratch_slab && g > 2ll * num_cu) g = 2ll * num_cu;
+            const size_t need = (size_t) g * (size_t) (P.g_scratch_slab + P.g_attr_slab);
             if (*gscratch_bytes < need) {
                 (void) hipFree(*gscratch);      // synchronises with earlier launches
                 *gscratch = nullptr; *gscratch_bytes = 0;

@@ -25,6 +25,7 @@ struct WtPlan {
     int lds_bytes = 0;
     int scratch_elem = 0;   // bytes per scratch element (0: op needs no scratch)
     long long scratch_slab = 0;   // > 0: scratch columns in global memory, this many bytes per workgroup
+    long long attr_slab = 0;      // MWU: bytes of per-rank attributes per workgroup (always global)
     int ppt = 1;            // consecutive window positions per lane (1 or 4)
 };
 
@@ -57,10 +58,13 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
     p.off_gbase = o;   o = wt_align16(o + chunk * 8);
     p.off_scratch = o;
     long long scr_bytes = 0;
-    if (op == WT_OP_MEDIAN) scr_bytes = (long long) n_tracks * T * scratch_elem;
-    else if (op == WT_OP_MWU) scr_bytes = (long long) n_tracks * T * (scratch_elem + 4);   // values + per-rank attributes
+    if (op == WT_OP_MEDIAN || op == WT_OP_MWU) scr_bytes = (long long) n_tracks * T * scratch_elem;
     scr_bytes = (scr_bytes + 255) & ~255ll;
     p.scratch_slab = scratch_global ? scr_bytes : 0;
+    // MWU: the per-rank attribute words (one u32 per set-0 track and lane, written once and read
+    // once per run) always live in a global slab per workgroup: keeping them in LDS halved the lanes
+    // per CU for the part that matters, the N^2 ranking over the value column
+    p.attr_slab = (op == WT_OP_MWU) ? (((long long) n_tracks * T * 4 + 255) & ~255ll) : 0;
     if (!scratch_global) o = (int) std::min<long long>(o + scr_bytes, 1 << 30);
     p.off_shared = o;  o = wt_align16(o + (int) sizeof(WtShared));
     p.lds_bytes = o;
@@ -196,7 +200,7 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
 static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.W = p.W; P.n_words = p.n_words; P.spitch = p.spitch; P.cpitch = p.cpitch; P.count_segs = p.count_segs;
     P.chunk_tracks = p.chunk_tracks; P.n_chunks = p.n_chunks;
-    P.g_scratch = nullptr; P.g_scratch_slab = p.scratch_slab;
+    P.g_scratch = nullptr; P.g_scratch_slab = p.scratch_slab; P.g_attr_slab = p.attr_slab;
     P.logW = 0;
     while ((1 << P.logW) < p.W) P.logW++;
     P.off_S = p.off_S; P.off_cnt = p.off_cnt; P.off_segtot = p.off_segtot; P.off_U = p.off_U; P.off_cover = p.off_cover; P.off_E = p.off_E;
