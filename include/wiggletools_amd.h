@@ -247,7 +247,10 @@ int64_t wtamd_trackset_max_runs(const wtamd_trackset *ts);
 
 /* Build (or rebuild) the window index `op` (enum wtamd_op) would use, on `stream`
  * (hipStream_t as void*).  wtamd_reduce() calls this itself when the index is
- * missing; it is exposed so callers can time / amortise it separately. */
+ * missing; it is exposed so callers can time / amortise it separately, and it is what a caller of
+ * a zero-copy track set must call after rewriting the run lists in place (same segment sizes):
+ * it also voids what earlier reductions learnt about the values -- the next Sum / Mean verifies
+ * again that its exact difference-array kernel applies and therefore waits for its launch. */
 int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream);
 
 /* Multiplex + reduce, everything on device. `runs` arrays are DEVICE memory.

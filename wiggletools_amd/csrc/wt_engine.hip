@@ -754,6 +754,10 @@ static bool wt_wants_delta(const wtamd_trackset *ts, int op) {
 
 int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
     if (!ts) return wt_fail(WTAMD_ERR_ARG, "ts == NULL");
+    // an explicit re-index means the run lists may have been rewritten in place (zero-copy track
+    // sets): what was learnt about their values is void, the next Sum / Mean verifies again
+    ts->delta_verified = false;
+    ts->delta_failed = false;
     WtPlan plan;
     std::string err;
     if (wt_wants_delta(ts, op)) wt_make_delta_plan(plan, ts->n_tracks);
