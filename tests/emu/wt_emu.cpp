@@ -42,20 +42,23 @@ struct EmuRun {
             const int N = P.n_tracks, NC = P.chunk_tracks;
             constexpr bool multi = MULTI;
             std::vector<WtAcc<K>> acc(T);
+            constexpr bool fuse = MULTI && OP != WT_OP_MULTIPLEX;      // as in wt_reduce_kernel
             wt_phase_header(P, c, k);
             for (int t = 0; t < T; t++) wt_phase_zero(P, c, true, t, T);
+            for (int t = 0; t < T; t++) wt_eval_init<OP, K>(acc[t]);
             for (int ch = 0; ch < P.n_chunks; ch++) {
                 const int t_lo = ch * NC, t_hi = std::min(N, t_lo + NC);
                 if (ch > 0) for (int t = 0; t < T; t++) wt_phase_zero(P, c, false, t, T);
                 for (int t = 0; t < T; t++) wt_phase_load<ValT>(P, c, t_lo, t_hi, true, t, T);
                 for (int t = 0; t < T; t++) wt_phase_count_a(P, c, t_lo, t_hi, t, T);
                 for (int t = 0; t < T; t++) wt_phase_count_b(P, c, t_lo, t_hi, t, T);
+                if (fuse) for (int t = 0; t < T; t++) wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, acc[t], 0, t_lo, t_hi, true, t, T);
             }
+            if (fuse && npass == 2) for (int t = 0; t < T; t++) wt_eval_mid<OP, K>(P, acc[t]);
             for (int t = 0; t < T; t++) wt_phase_emask(P, c, two, t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
             wt_phase_lookback(P, c, k);     // sequential emulation: the offset is known at once
-            for (int t = 0; t < T; t++) wt_eval_init<OP, K>(acc[t]);
-            for (int pass = 0; pass < npass; pass++) {
+            for (int pass = fuse ? 1 : 0; pass < npass; pass++) {
                 for (int ch = 0; ch < P.n_chunks; ch++) {
                     const int t_lo = ch * NC, t_hi = std::min(N, t_lo + NC);
                     if (multi) {
@@ -64,7 +67,7 @@ struct EmuRun {
                         for (int t = 0; t < T; t++) wt_phase_count_a(P, c, t_lo, t_hi, t, T);
                         for (int t = 0; t < T; t++) wt_phase_count_b(P, c, t_lo, t_hi, t, T);
                     }
-                    for (int t = 0; t < T; t++) wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, acc[t], pass, t_lo, t_hi, t, T);
+                    for (int t = 0; t < T; t++) wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, acc[t], pass, t_lo, t_hi, false, t, T);
                 }
                 if (pass == 0 && npass == 2) for (int t = 0; t < T; t++) wt_eval_mid<OP, K>(P, acc[t]);
             }

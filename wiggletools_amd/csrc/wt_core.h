@@ -1125,10 +1125,14 @@ WT_DEV unsigned wt_lane_emit_bits(const WtParams &P, const WtCtx &c, int tid) {
 }
 
 template <int OP, class ValT, class ScrT, int K>
-WT_DEV void wt_phase_eval_chunk(const WtParams &P, WtCtx &c, WtAcc<K> &A, int pass, int t_lo, int t_hi, int tid, int nt) {
-    const unsigned emit_bits = wt_lane_emit_bits<K>(P, c, tid);
-    if (!emit_bits) return;
+// `all`: the emitted bitmap is not known yet (first pass fused into the chunk sweep that builds it,
+// see the kernel): evaluate every position of every lane.
+WT_DEV void wt_phase_eval_chunk(const WtParams &P, WtCtx &c, WtAcc<K> &A, int pass, int t_lo, int t_hi, bool all,
+                                int tid, int nt) {
     const int p0 = tid * K;
+    if (p0 >= P.W) return;
+    const unsigned emit_bits = all ? ((1u << K) - 1u) : wt_lane_emit_bits<K>(P, c, tid);
+    if (!emit_bits) return;
     long long run0 = 0;
     if (OP == WT_OP_MULTIPLEX) {    // global index of the lane's first emitted run (look-back already done)
         const int w = p0 >> 6, b0 = p0 & 63;

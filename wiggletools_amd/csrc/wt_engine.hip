@@ -88,6 +88,14 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
         // pass A: every track's breakpoints and coverage enter U / cover[]; with one chunk the
         // per-track bitmaps stay resident for the evaluation
         const int N = P.n_tracks, NC = MULTI ? P.chunk_tracks : N, n_chunks = MULTI ? P.n_chunks : 1;
+        // Chunked tracks: every sweep over the chunks rebuilds their bitmaps, so the first
+        // evaluation pass is fused into the sweep that builds U / the coverage summaries (one
+        // sweep saved: sum-like ops 2 -> 1, var / stddev / CV 3 -> 2).  Not for the Multiplexer
+        // tile, whose rows need the look-back offset first.
+        constexpr bool FUSE = MULTI && OP != WT_OP_MULTIPLEX;
+        constexpr int npass = wt_eval_passes(OP);
+        WtAcc<K> A;
+        wt_eval_init<OP, K>(A);
         for (int ch = 0; ch < n_chunks; ch++) {
             const int t_lo = ch * NC, t_hi = (t_lo + NC < N) ? t_lo + NC : N;
             if (MULTI && ch > 0) {
@@ -105,7 +113,13 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
             wt_phase_count_b(P, c, t_lo, t_hi, tid, nt);
             __syncthreads();
             WT_TICK(2);
+            if (FUSE) {     // first evaluation pass rides on this sweep (every position: E is not known yet)
+                wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, A, 0, t_lo, t_hi, true, tid, nt);
+                __syncthreads();
+                WT_TICK(4);
+            }
         }
+        if (FUSE && npass == 2) wt_eval_mid<OP, K>(P, A);
         WT_MARK(6);
         wt_phase_emask(P, c, OP == WT_OP_TTEST || OP == WT_OP_MWU, tid, nt);
         __syncthreads();
@@ -122,11 +136,8 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
             __syncthreads();
         }
         WT_MARK(9);
-        WtAcc<K> A;
-        wt_eval_init<OP, K>(A);
-        constexpr int npass = wt_eval_passes(OP);
 #pragma unroll
-        for (int pass = 0; pass < npass; pass++) {
+        for (int pass = FUSE ? 1 : 0; pass < npass; pass++) {
             for (int ch = 0; ch < n_chunks; ch++) {
                 const int t_lo = ch * NC, t_hi = (t_lo + NC < N) ? t_lo + NC : N;
                 if (MULTI) {
@@ -139,7 +150,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
                     wt_phase_count_b(P, c, t_lo, t_hi, tid, nt);
                     __syncthreads();
                 }
-                wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, A, pass, t_lo, t_hi, tid, nt);
+                wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, A, pass, t_lo, t_hi, false, tid, nt);
                 if (MULTI) __syncthreads();     // the next chunk overwrites the bitmaps
             }
             if (pass == 0 && npass == 2) wt_eval_mid<OP, K>(P, A);
