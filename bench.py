@@ -45,7 +45,9 @@ def synth_device(n_tracks, chrom_lens, mean_run, gap_prob, seed, device):
     for clen in chrom_lens:
         for _ in range(n_tracks):
             n_est = int(clen / mean_run * 1.1) + 4096
-            lens = torch.empty(n_est, device=device, dtype=torch.float32).geometric_(p, generator=g).to(torch.int64) \
+            # (float32 geometric_ occasionally yields 0: a zero-length run is undefined behaviour for
+            #  the reference's Multiplexer, SURVEY appendix A, and for wtamd_tracks -- hence the clamp)
+            lens = torch.empty(n_est, device=device, dtype=torch.float32).geometric_(p, generator=g).to(torch.int64).clamp_(min=1) \
                 if mean_run > 1 else torch.ones(n_est, device=device, dtype=torch.int64)
             ends = torch.cumsum(lens, 0)
             k = int(torch.searchsorted(ends, torch.tensor([clen], device=device, dtype=torch.int64)).item()) + 1
@@ -150,6 +152,8 @@ def main():
     n_intervals = int(seg_off[-1])
     ts = engine.TrackSet.from_device(len(chrom_lens), args.tracks, seg_off, start, finish, value,
                                      np.zeros(args.tracks))
+    n_bad, first_bad = ts.validate()
+    assert n_bad == 0, "synthetic tracks violate the run-list contract (%d runs, first at %d)" % (n_bad, first_bad)
     out = ts.alloc_runs()
     stream = torch.cuda.current_stream().cuda_stream
 

@@ -242,6 +242,13 @@ int wtamd_trackset_create_host(const wtamd_tracks *tracks, wtamd_trackset **out)
 int wtamd_trackset_create_device(const wtamd_tracks *tracks, wtamd_trackset **out);
 void wtamd_trackset_destroy(wtamd_trackset *);
 
+/* Input contract check, on device: inside every (chrom, track) segment the runs must be sorted,
+ * non-overlapping and of positive length (finish > start).  Anything else is undefined behaviour
+ * here as it is in the reference's Multiplexer (multiplexer.c:76-96; its text readers check it,
+ * bedReader.c:46-49).  *n_bad = number of offending runs, *first_bad (optional) = global index of
+ * the first one or -1.  Not called implicitly: one pass over start[] / finish[]. */
+int wtamd_trackset_validate(wtamd_trackset *ts, int64_t *n_bad, int64_t *first_bad);
+
 /* Upper bound on the number of runs any reduction over `ts` can emit. */
 int64_t wtamd_trackset_max_runs(const wtamd_trackset *ts);
 

@@ -1,0 +1,86 @@
+"""Size-independent properties at the bench's own size (BASELINE config C2: mean / sum over 100
+float tracks, mean run 16 bp, GRCh38 x 1/8 = 386 Mbp, 2.4e9 input runs, 3.9e8 output runs) -- far
+beyond what the oracle can finish, so the checks are properties, not comparisons with it:
+
+ * two independent algorithms agree bit for bit: the exact difference-array kernel and the general
+   bitmap kernel (same run count, same coordinates, same f64 bit patterns);
+ * run-list invariants: start < finish, sorted and non-overlapping inside every chromosome;
+ * a checksum of checksums: AUC(sum over tracks) == sum over tracks of AUC(track).  All values are
+   k/8, so both sides are exact in f64 whatever the summation order, and must be EQUAL;
+ * the covered-bp counter equals the sum of the run lengths.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.mark.parametrize("scale", [0.125])
+def test_gpu_full_size_properties(scale, monkeypatch):
+    import torch
+    import bench
+    from wiggletools_amd import engine
+
+    dev = torch.device("cuda", 0)
+    N = 100
+    chrom_lens = [max(int(x * scale), 1) for x in bench.GRCH38]
+    seg_off, start, finish, value = bench.synth_device(N, chrom_lens, 16.0, 0.02, 7, dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ts0 = engine.TrackSet.from_device(len(chrom_lens), N, seg_off, start, finish, value, np.zeros(N))
+    assert ts0.validate() == (0, -1), "generator produced runs that violate the input contract"
+    ts0.close()
+
+    def run(op, no_delta):
+        if no_delta:
+            monkeypatch.setenv("WTAMD_NO_DELTA", "1")
+        else:
+            monkeypatch.delenv("WTAMD_NO_DELTA", raising=False)
+        ts = engine.TrackSet.from_device(len(chrom_lens), N, seg_off, start, finish, value, np.zeros(N))
+        out = ts.alloc_runs()
+        n = ts.reduce(op, out, stream=stream, sync=True)
+        st = ts.stats()
+        ts.close()
+        return out, n, st
+
+    a, na, sta = run("sum", no_delta=False)
+    assert sta["kernel"] == 1, "difference-array kernel expected for float tracks with zero defaults"
+    b, nb, stb = run("sum", no_delta=True)
+    assert stb["kernel"] == 0
+    assert na == nb and na > 3e8
+    assert torch.equal(a.start[:na], b.start[:nb]) and torch.equal(a.finish[:na], b.finish[:nb])
+    assert torch.equal(a.value[:na].view(torch.int64), b.value[:nb].view(torch.int64)), "kernels disagree bitwise"
+    assert torch.equal(a.chrom_run_off, b.chrom_run_off)
+    del b
+
+    # run-list invariants
+    s, f = a.start[:na], a.finish[:na]
+    assert bool((s < f).all())
+    cro = a.chrom_run_off.cpu().numpy()
+    gap_ok = s[1:] >= f[:-1]
+    first = torch.zeros(na - 1, dtype=torch.bool, device=dev)
+    idx = torch.as_tensor(cro[1:-1], device=dev) - 1          # pairs straddling a chromosome boundary
+    idx = idx[(idx >= 0) & (idx < na - 1)]
+    first[idx] = True
+    assert bool((gap_ok | first).all()), "runs overlap or are out of order inside a chromosome"
+    covered = int((f.to(torch.int64) - s.to(torch.int64)).sum().item())
+    assert covered == sta["covered_bp"]
+
+    # checksum of checksums, exact: AUC(sum over tracks) == sum over tracks of AUC(track)
+    lens = finish.to(torch.int64) - start.to(torch.int64)
+    k8 = (value.to(torch.float64) * 8).to(torch.int64)
+    expect = int((lens * k8).sum().item())                      # in units of 1/8
+    a.n = na
+    auc = a.auc(stream=stream)
+    assert auc * 8 == float(expect) and expect < 2 ** 53, (auc, expect / 8)
+
+    # mean = sum / N, the reference's own expression (reducers.c:399-400)
+    m, nm, stm = run("mean", no_delta=False)
+    assert nm == na and stm["kernel"] == 1
+    # (a tensor divisor: torch turns division by a Python scalar into a multiplication by 1/N)
+    assert torch.equal(m.value[:nm], a.value[:na] / torch.full((na,), float(N), dtype=torch.float64, device=dev))

@@ -341,3 +341,17 @@ def test_gpu_pearson_golden_and_degenerate(oracle, engine):
     ts = engine.TrackSet.from_runlists(t)
     assert np.isnan(ts.pearson())
     ts.close()
+
+
+def test_gpu_input_contract_validation(engine):
+    """wtamd_trackset_validate: zero-length, inverted and overlapping runs are counted; a run list
+    may start a new (chrom, track) segment below the previous segment's last finish."""
+    from wiggletools_amd.runlists import RunLists
+    ok = RunLists.from_lists([[[(5, 9, 1.0), (9, 12, 2.0)], [(1, 3, 1.0)]], [[(2, 4, 1.0)], []]])
+    ts = engine.TrackSet.from_runlists(ok)
+    assert ts.validate() == (0, -1)
+    ts.close()
+    bad = RunLists.from_lists([[[(5, 9, 1.0), (9, 9, 2.0), (9, 12, 3.0), (11, 15, 4.0)]], [[(7, 6, 1.0)]]])
+    ts = engine.TrackSet.from_runlists(bad)
+    assert ts.validate() == (3, 1)          # zero-length, overlapping, inverted
+    ts.close()

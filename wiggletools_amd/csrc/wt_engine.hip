@@ -483,6 +483,29 @@ __global__ void wt_pearson_final_kernel(const WtMoments *partial, int n, double 
     }
 }
 
+
+// Input contract check (sorted, non-overlapping, positive-length runs inside every (chrom, track)
+// segment -- anything else is undefined behaviour in the reference's Multiplexer too,
+// multiplexer.c:76-96, and bedReader.c:46-49 checks it for text input).  One lane per run.
+__global__ void __launch_bounds__(256) wt_validate_kernel(const int32_t *start, const int32_t *finish, const int64_t *seg_off,
+                                                           long long n_seg, long long total, unsigned long long *out) {
+    const long long g = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    bool bad = finish[g] <= start[g];
+    if (!bad && g > 0 && start[g] < finish[g - 1]) {
+        long long lo = 0, hi = n_seg;                   // is g the first run of its segment?
+        while (hi - lo > 1) {
+            const long long mid = (lo + hi) >> 1;
+            if (seg_off[mid] <= g) lo = mid; else hi = mid;
+        }
+        bad = seg_off[lo] != g;
+    }
+    if (bad) {
+        atomicAdd(&out[0], 1ull);
+        atomicMin(&out[1], (unsigned long long) g);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1078,6 +1101,25 @@ int wtamd_pearson(wtamd_trackset *ts, double *result) {
     (void) hipFree(d.start); (void) hipFree(d.finish); (void) hipFree(d.value); (void) hipFree(d.chrom_run_off);
     (void) hipFree(d_tile); (void) hipFree(d_inplay); (void) hipFree(d_partial); (void) hipFree(d_out);
     return rc;
+}
+
+int wtamd_trackset_validate(wtamd_trackset *ts, int64_t *n_bad, int64_t *first_bad) {
+    if (!ts || !n_bad) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    *n_bad = 0;
+    if (first_bad) *first_bad = -1;
+    if (ts->n_intervals <= 0) return WTAMD_OK;
+    unsigned long long h[2] = {0ull, ~0ull}, *d = nullptr;
+    WT_HIP(hipMalloc(&d, sizeof h));
+    WT_HIP(hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice));
+    const long long total = ts->n_intervals;
+    hipLaunchKernelGGL(wt_validate_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, nullptr, ts->d_start,
+                       ts->d_finish, ts->d_seg_off, (long long) ts->n_chrom * ts->n_tracks, total, d);
+    const hipError_t e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void) hipFree(d);
+    if (e != hipSuccess) return wt_fail(WTAMD_ERR_HIP, "wtamd_trackset_validate: kernel / copy failed");
+    *n_bad = (int64_t) h[0];
+    if (first_bad && h[0]) *first_bad = (int64_t) h[1];
+    return WTAMD_OK;
 }
 
 int wtamd_get_stats(const wtamd_trackset *ts_c, wtamd_stats *out) {

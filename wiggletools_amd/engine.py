@@ -102,6 +102,12 @@ class TrackSet:
         _lib.check(_lib.lib().wtamd_get_stats(self._h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in _lib.Stats._fields_}
 
+    def validate(self):
+        """(number of runs violating the input contract, global index of the first or -1)."""
+        n, first = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().wtamd_trackset_validate(self._h, C.byref(n), C.byref(first)))
+        return n.value, first.value
+
     def pearson(self):
         """Pearson correlation of the set's two tracks (reference `pearson a b`), computed on device."""
         out = C.c_double()
