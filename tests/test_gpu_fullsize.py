@@ -84,3 +84,42 @@ def test_gpu_full_size_properties(scale, monkeypatch):
     assert nm == na and stm["kernel"] == 1
     # (a tensor divisor: torch turns division by a Python scalar into a multiplication by 1/N)
     assert torch.equal(m.value[:nm], a.value[:na] / torch.full((na,), float(N), dtype=torch.float64, device=dev))
+
+
+@pytest.mark.parametrize("op,kw", [("max", {}), ("var", {}), ("cv", {}), ("ttest", dict(n_set0=50)),
+                                   ("median", {}), ("mwu", dict(n_set0=50))])
+def test_gpu_plans_agree_bitwise_at_scale(op, kw, monkeypatch):
+    """The same reduction through different execution plans of the general kernel -- 4 positions
+    per lane vs 1, all tracks resident vs chunks of 37 (bitmaps rebuilt per chunk and pass), narrow
+    vs wide workgroups -- must give identical bits: 100 tracks, 62 Mbp (31 Mbp for median / MWU)."""
+    import torch
+    import bench
+    from wiggletools_amd import engine
+
+    dev = torch.device("cuda", 0)
+    N = 100
+    scale = 0.01 if op in ("median", "mwu") else 0.02
+    chrom_lens = [max(int(x * scale), 1) for x in bench.GRCH38]
+    seg_off, start, finish, value = bench.synth_device(N, chrom_lens, 16.0, 0.02, 3, dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    plans = [{}, {"WTAMD_CHUNK": "37"}]
+    plans.append({"WTAMD_T": "64"} if op in ("median", "mwu") else {"WTAMD_PPT": "1", "WTAMD_T": "256"})
+    ref = None
+    for env in plans:
+        for k in ("WTAMD_CHUNK", "WTAMD_PPT", "WTAMD_T"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ts = engine.TrackSet.from_device(len(chrom_lens), N, seg_off, start, finish, value, np.zeros(N))
+        out = ts.alloc_runs()
+        n = ts.reduce(op, out, stream=stream, sync=True, **kw)
+        ts.close()
+        got = (n, out.start[:n].clone(), out.finish[:n].clone(), out.value[:n].view(torch.int64).clone())
+        del out
+        if ref is None:
+            ref = got
+            assert n > 1e7
+        else:
+            assert got[0] == ref[0], (env, got[0], ref[0])
+            assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), env
+            assert torch.equal(got[3], ref[3]), "plan %s changes the value bits of %s" % (env, op)
