@@ -923,20 +923,26 @@ WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K
     }
     if (OP == WT_OP_TTEST) {
         const int na = P.n_set0, nb = N - P.n_set0;
+        // statistic and degrees of freedom of all K positions first (the accumulators die here),
+        // then ONE rolled loop around the Student-t tail: K inlined copies of it (lgamma x3, log,
+        // exp, a continued fraction) made the kernel spill 600+ bytes per lane
+        double tt[K], nn[K];
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const double m1 = A.a[k] / na, m2 = A.c2[k] / nb;
             const double msq1 = A.b[k] / na, msq2 = A.d[k] / nb;
             const double var1 = msq1 - m1 * m1, var2 = msq2 - m2 * m2;
-            if (var1 + var2 == 0) { res[k] = wt_nan(); continue; }
             double t = (m1 - m2) / sqrt(var1 / na + var2 / nb);
             if (t < 0) t = -t;
             const double den = var1 / na + var2 / nb;
             const double c1 = (double) ((long long) na * na * (na - 1));
             const double c2 = (double) ((long long) nb * nb * (nb - 1));
-            const double nu = den * den / ((var1 * var1) / c1 + (var2 * var2) / c2);
-            res[k] = 2 * wt_tdist_Q(t, nu);
+            nn[k] = den * den / ((var1 * var1) / c1 + (var2 * var2) / c2);
+            tt[k] = (var1 + var2 == 0) ? wt_nan() : t;          // setComparisons.c:98 -> NaN
         }
+#pragma unroll 1
+        for (int k = 0; k < K; k++)
+            res[k] = wt_isnan(tt[k]) ? wt_nan() : 2 * wt_tdist_Q(tt[k], nn[k]);
         return;
     }
     if (OP == WT_OP_MEDIAN) {
