@@ -286,23 +286,22 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
         WT_MARK(108);
         // wave 0: run-count scan and look-back back to back (it owns the counts); the last lanes
         // build the breakpoint jump table meanwhile
+        unsigned long long mine = 0;
         if (tid < 64) {
-            const unsigned long long mine = wt_delta_escan_wave(P, c, tid);
+            mine = wt_delta_escan_wave(P, c, tid);
             WT_TICK(5);
             if (tid == 0) wt_lookback_publish(P, c, k, mine);
-            wt_lookback_complete(P, c, k, tid, mine);
         }
         wt_delta_nextw(P, c, tid, nt);
         __syncthreads();
-        WT_TICK(6);
         WT_MARK(110);
-#ifdef WT_DELTA_NO_STAGE
-        wt_phase_write<OP, float, WT_DELTA_K>(P, c, L, tid, nt);
-#else
+        // the look-back's round trips to the status words overlap the staging of the other waves
+        // (and the predecessors get that much longer to publish)
+        if (tid < 64) wt_lookback_complete(P, c, k, tid, mine);
+        WT_TICK(6);
         wt_delta_stage<OP>(P, c, d, L, tid, nt);
         __syncthreads();
         wt_delta_copy_out(P, c, d, tid, nt);
-#endif
         __syncthreads();
         WT_MARK(111);
         if (tid == 0) {
