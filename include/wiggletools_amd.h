@@ -282,6 +282,10 @@ int wtamd_multiplex_host(wtamd_trackset *ts, uint32_t flags, wtamd_runs *runs,
  * AUC = sum over runs of (finish-start)*value skipping NaN
  * (reference statistics.c:103-120).  Result written to *auc (host). */
 int wtamd_runs_auc(const wtamd_runs *runs, int64_t n_runs, double *auc, void *stream);
+/* meanI: sum of (finish-start)*value over the non-NaN runs divided by their span; NaN when that
+ * span is 0 (reference MeanIntegrator, statistics.c:62-100; its NonOverlapping wrapper is the
+ * identity on reducer output, which never overlaps). */
+int wtamd_runs_mean(const wtamd_runs *runs, int64_t n_runs, double *mean, void *stream);
 
 /* Pearson correlation of the two tracks of `ts` over their Multiplexer tile, on device
  * (reference PearsonIntegrator over a 2-track Multiplexer: statistics.c:414-465,
@@ -289,6 +293,31 @@ int wtamd_runs_auc(const wtamd_runs *runs, int64_t n_runs, double *auc, void *st
  * NaN when T_XX*T_YY == 0 (statistics.c:421-423).  Slices of runs are merged with the reference's
  * own update formula, so the result agrees to rounding (not bit-for-bit). */
 int wtamd_pearson(wtamd_trackset *ts, double *result);
+
+/* The reference's `map`-able unary operators (src/unaryOps.c: scale :650-664, offset :722-734,
+ * ln / log :760-813, exp :823-866, pow :873-899, abs :934-949; commandParser.c:115-211) applied to
+ * whole run lists on device before they are multiplexed. */
+enum wtamd_map_op {
+    WTAMD_MAP_SCALE = 0,    /* param * value                                   */
+    WTAMD_MAP_OFFSET = 1,   /* param + value                                   */
+    WTAMD_MAP_LN = 2,       /* log(value); runs with value <= 0 are DROPPED    */
+    WTAMD_MAP_LOG = 3,      /* log(value) / log(param); same                   */
+    WTAMD_MAP_EXP = 4,      /* exp(value)                                      */
+    WTAMD_MAP_EXPB = 5,     /* exp(value * log(param))                         */
+    WTAMD_MAP_POW = 6,      /* pow(value, param); NaN if param < 0 && value <= 0 */
+    WTAMD_MAP_ABS = 7,
+    WTAMD_MAP_COUNT_
+};
+/* start / finish / value and the o_* arrays are DEVICE memory (o_* sized for all input runs),
+ * seg_off / o_seg_off HOST arrays of n_seg + 1 offsets (n_seg = n_chrom * n_tracks).  Output
+ * values are f64.  For the operators that drop nothing o_start / o_finish may be NULL or alias
+ * the inputs.  Synchronous on `stream`. */
+int wtamd_runs_map(int map_op, double param, int64_t n_seg, const int64_t *seg_off, const int32_t *start,
+                   const int32_t *finish, const void *value, int value_is_f64, int32_t *o_start, int32_t *o_finish,
+                   double *o_value, int64_t *o_seg_off, void *stream);
+/* default_value of the operator iterator the reference would build around a track whose default is
+ * `default_value`, including the `float` truncation several constructors apply. */
+double wtamd_map_default(int map_op, double param, double default_value);
 
 /* Run compression on device (reference CompressionWiggleIterator, unaryOps.c:235-253, which the
  * default writer applies, wigWriter.c:263-267): adjacent runs of one chromosome merge while

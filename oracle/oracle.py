@@ -278,6 +278,44 @@ def pearson(t):
     return L.wto_pearson(len(s), s.ctypes.data, f.ctypes.data, x.ctypes.data, y.ctypes.data)
 
 
+MAP_OPS = {"scale": 0, "offset": 1, "ln": 2, "log": 3, "exp": 4, "expb": 5, "pow": 6, "abs": 7}
+
+
+def map_values(op, param, values):
+    """Oracle restatement of the value-wise unary operators: (out f64, keep u8)."""
+    L = oracle_lib()
+    L.wto_map.restype = None
+    L.wto_map.argtypes = [C.c_int, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    v = np.ascontiguousarray(values, np.float64)
+    out = np.empty(len(v), np.float64)
+    keep = np.empty(len(v), np.uint8)
+    L.wto_map(MAP_OPS[op], float(param), len(v), v.ctypes.data, out.ctypes.data, keep.ctypes.data)
+    return out, keep
+
+
+def map_default(op, param, d):
+    L = oracle_lib()
+    L.wto_map_default.restype = C.c_double
+    L.wto_map_default.argtypes = [C.c_int, C.c_double, C.c_double]
+    return L.wto_map_default(MAP_OPS[op], float(param), float(d))
+
+
+def ref_map(t, track, op, param):
+    """The compiled reference's operator iterator over one track: (chrom, start, finish, value, default)."""
+    L = ref_lib()
+    L.ref_map.restype = C.c_int64
+    L.ref_map.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_int, C.c_double, C.c_int64, C.c_void_p, C.c_void_p,
+                          C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    s, keep = _pack(t)
+    cap = int(len(np.asarray(t["start"]))) + 1
+    oc, os_, of, ov = _alloc(cap)
+    dflt = C.c_double()
+    n = L.ref_map(C.byref(s), track, MAP_OPS[op], float(param), cap, oc.ctypes.data, os_.ctypes.data, of.ctypes.data,
+                  ov.ctypes.data, C.byref(dflt))
+    assert n >= 0, n
+    return oc[:n], os_[:n], of[:n], ov[:n], dflt.value
+
+
 def compress(chrom, start, finish, value):
     c = np.array(chrom, np.int32)
     s = np.array(start, np.int32)

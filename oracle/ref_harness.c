@@ -52,6 +52,14 @@ static WiggleIterator *(*r_SmartReader)(char *, wt_bool);
 static WiggleIterator *(*r_AUCIntegrator)(WiggleIterator *);
 static WiggleIterator *(*r_PearsonIntegrator)(Multiplexer *);
 static WiggleIterator *(*r_CompressionWiggleIterator)(WiggleIterator *);
+static WiggleIterator *(*r_ScaleWiggleIterator)(WiggleIterator *, double);
+static WiggleIterator *(*r_ShiftWiggleIterator)(WiggleIterator *, double);
+static WiggleIterator *(*r_NaturalLogWiggleIterator)(WiggleIterator *);
+static WiggleIterator *(*r_LogWiggleIterator)(WiggleIterator *, double);
+static WiggleIterator *(*r_NaturalExpWiggleIterator)(WiggleIterator *);
+static WiggleIterator *(*r_ExpWiggleIterator)(WiggleIterator *, double);
+static WiggleIterator *(*r_PowerWiggleIterator)(WiggleIterator *, double);
+static WiggleIterator *(*r_AbsWiggleIterator)(WiggleIterator *);
 static WiggleIterator *(*r_reduction[10])(Multiplexer *);
 static WiggleIterator *(*r_set_reduction[2])(Multiset *);      /* TTestReduction, MWUReduction (optional) */
 
@@ -82,6 +90,14 @@ int ref_open(const char *path) {
     OPT(r_AUCIntegrator, "AUCIntegrator");
     OPT(r_PearsonIntegrator, "PearsonIntegrator");
     OPT(r_CompressionWiggleIterator, "CompressionWiggleIterator");
+    OPT(r_ScaleWiggleIterator, "ScaleWiggleIterator");
+    OPT(r_ShiftWiggleIterator, "ShiftWiggleIterator");
+    OPT(r_NaturalLogWiggleIterator, "NaturalLogWiggleIterator");
+    OPT(r_LogWiggleIterator, "LogWiggleIterator");
+    OPT(r_NaturalExpWiggleIterator, "NaturalExpWiggleIterator");
+    OPT(r_ExpWiggleIterator, "ExpWiggleIterator");
+    OPT(r_PowerWiggleIterator, "PowerWiggleIterator");
+    OPT(r_AbsWiggleIterator, "AbsWiggleIterator");
     OPT(r_set_reduction[0], "TTestReduction");
     OPT(r_set_reduction[1], "MWUReduction");
 #undef OPT
@@ -305,6 +321,38 @@ double ref_pearson(const wto_tracks *t) {
     WiggleIterator *p = r_PearsonIntegrator(m);
     while (!p->done) r_pop(p);
     return *(double *) p->data;
+}
+
+/* `map`-able unary operators (unaryOps.c:650-949) over ONE track: drains the reference's operator
+ * iterator wrapped around the array-backed child.  map_op: 0 scale, 1 offset, 2 ln, 3 log base
+ * param, 4 exp (natural), 5 exp radix param, 6 pow, 7 abs.  *o_default receives the operator
+ * iterator's default_value.  Returns the number of intervals or < 0. */
+int64_t ref_map(const wto_tracks *t, int track, int map_op, double param, int64_t cap,
+                int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value, double *o_default) {
+    if (!g_lib || !r_ScaleWiggleIterator) return -2;
+    char **names = make_names(t->n_chrom);
+    WiggleIterator *c = make_child(t, names, track), *w = NULL;
+    switch (map_op) {
+    case 0: w = r_ScaleWiggleIterator(c, param); break;
+    case 1: w = r_ShiftWiggleIterator(c, param); break;
+    case 2: w = r_NaturalLogWiggleIterator(c); break;
+    case 3: w = r_LogWiggleIterator(c, param); break;
+    case 4: w = r_NaturalExpWiggleIterator(c); break;
+    case 5: w = r_ExpWiggleIterator(c, param); break;
+    case 6: w = r_PowerWiggleIterator(c, param); break;
+    case 7: w = r_AbsWiggleIterator(c); break;
+    default: return -3;
+    }
+    if (o_default) *o_default = w->default_value;
+    int64_t n = 0;
+    while (!w->done) {
+        if (n >= cap) return -1;
+        o_chrom[n] = name_to_index(w->chrom);
+        o_start[n] = w->start; o_finish[n] = w->finish; o_value[n] = w->value;
+        n++;
+        r_pop(w);
+    }
+    return n;
 }
 
 /* Compression (unaryOps.c:235-263) of the reference reducer output. */

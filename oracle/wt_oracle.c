@@ -540,6 +540,48 @@ double wto_pearson(int64_t n, const int32_t *start, const int32_t *finish, const
     return NAN;
 }
 
+/* `map`-able unary operators, value by value (unaryOps.c: scale :650-664, offset :722-734, ln / log
+ * :760-779 with ctor :786-813, exp :823-835 with ctors :843-866, pow :873-889, abs :934-949).
+ * out[i] = f(in[i]); keep[i] = 0 for intervals the operator skips (ln / log: value <= 0, :764-765).
+ * map_op: 0 scale, 1 offset, 2 ln, 3 log base param, 4 exp, 5 exp radix param, 6 pow, 7 abs. */
+void wto_map(int map_op, double param, int64_t n, const double *in, double *out, unsigned char *keep) {
+    const double lg = (map_op == 3 || map_op == 5) ? log(param) : 1.0;     /* baseLog / radixLog */
+    for (int64_t i = 0; i < n; i++) {
+        const double v = in[i];
+        double r = v;
+        int k = 1;
+        switch (map_op) {
+        case 0: r = isnan(v) ? NAN : param * v; break;
+        case 1: r = param + v; break;
+        case 2: case 3:
+            if (v <= 0) k = 0;                                  /* skipped (NaN <= 0 is false: kept) */
+            r = (isnan(v) || v < 0) ? NAN : log(v) / lg;
+            break;
+        case 4: case 5: r = exp(v * lg); break;
+        case 6: r = ((param < 0 && v <= 0) || isnan(v)) ? NAN : pow(v, param); break;
+        case 7: r = isnan(v) ? NAN : fabs(v); break;
+        default: break;
+        }
+        out[i] = r;
+        if (keep) keep[i] = (unsigned char) k;
+    }
+}
+
+/* default_value of the operator iterator: several ctors store it through `float` */
+double wto_map_default(int map_op, double param, double d) {
+    switch (map_op) {
+    case 0: { float f = isnan(d) ? NAN : d * param; return f; }             /* :675-680 float */
+    case 1: { float f = isnan(d) ? NAN : d + param; return f; }             /* :738-743 float */
+    case 2: return (!isnan(d) && d > 0) ? log(d) / 1.0 : NAN;                /* :792-796 double */
+    case 3: return (!isnan(d) && d > 0) ? log(d) / log(param) : NAN;         /* :807-811 double */
+    case 4: { float f = isnan(d) ? NAN : exp(d * 1.0); return f; }           /* :860-865 float */
+    case 5: { float f = isnan(d) ? NAN : exp(d * log(param)); return f; }    /* :847-852 float */
+    case 6: return (!isnan(d) && (d > 0 || param > 0)) ? pow(d, param) : NAN;/* :895-899 double */
+    case 7: return isnan(d) ? NAN : fabs(d);
+    default: return d;
+    }
+}
+
 /* unaryOps.c:235-253 : in-place merge of adjacent runs |dv| < 1e-6 (or both NaN). Returns new count. */
 int64_t wto_compress(int64_t n, int32_t *chrom, int32_t *start, int32_t *finish, double *value) {
     int64_t w = 0;

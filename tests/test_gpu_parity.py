@@ -218,6 +218,10 @@ def test_gpu_device_resident_path_and_auc(oracle, engine):
     auc = out.auc()
     ref = oracle.auc(exp[1], exp[2], exp[3])
     assert abs(auc - ref) <= 1e-9 * abs(ref)
+    # meanI (statistics.c:62-100): length-weighted mean over the non-NaN runs
+    m = ~np.isnan(exp[3])
+    span = float((exp[2][m] - exp[1][m]).sum())
+    assert abs(out.mean() - ref / span) <= 1e-9 * abs(ref / span)
     # idempotence: a second pass over the same resident tracks gives the same run list
     n2 = ts.reduce("mean", out, stream=stream, sync=True)
     assert n2 == n
@@ -355,3 +359,36 @@ def test_gpu_input_contract_validation(engine):
     ts = engine.TrackSet.from_runlists(bad)
     assert ts.validate() == (3, 1)          # zero-length, overlapping, inverted
     ts.close()
+
+
+@pytest.mark.parametrize("op,param", [("scale", -2.5), ("offset", 3.25), ("ln", 0.0), ("log", 2.0), ("exp", 0.0),
+                                      ("expb", 2.0), ("pow", 2.0), ("pow", -1.0), ("abs", 0.0)])
+def test_gpu_map_ops(oracle, engine, op, param):
+    """`map`-able unary operators on device (wtamd_runs_map) vs the oracle's restatement (itself pinned
+    bit for bit on the compiled reference): dropped runs and segment offsets exact, values to 1e-12
+    (device libm), defaults exact; then `sum map <op>` end to end."""
+    from wiggletools_amd.runlists import RunLists
+    for seed in range(4):
+        t = random_case(8100 + seed, n_tracks=5, max_len=9000, dtype=np.float64 if seed % 2 else np.float32)
+        rng = np.random.default_rng(seed)
+        t.value[:] = (t.value * rng.choice([1.0, -1.0, 0.0], size=len(t.value), p=[0.6, 0.3, 0.1])).astype(t.value.dtype)
+        got = engine.map_runlists(t, op, param)
+        out, keep = oracle.map_values(op, param, t.value)
+        k = keep != 0
+        n_seg = t.n_chrom * t.n_tracks
+        exp_seg = np.concatenate([[0], np.cumsum([int(k[t.seg_off[q]:t.seg_off[q + 1]].sum()) for q in range(n_seg)])])
+        assert np.array_equal(got.seg_off, exp_seg), (op, seed)
+        assert np.array_equal(got.start, t.start[k]) and np.array_equal(got.finish, t.finish[k])
+        a, b = got.value, out[k]
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        m = ~np.isnan(a) & np.isfinite(b)
+        assert np.array_equal(a[~np.isnan(a) & ~np.isfinite(b)], b[~np.isnan(a) & ~np.isfinite(b)])
+        assert np.all(np.abs(a[m] - b[m]) <= 1e-12 * np.maximum(np.abs(b[m]), 1e-300)), (op, seed)
+        expd = np.array([oracle.map_default(op, param, x) for x in t.defaults])
+        assert np.array_equal(got.defaults, expd, equal_nan=True)
+        # end to end: sum over the mapped tracks (oracle over the oracle-mapped run lists)
+        ref_t = RunLists(t.n_chrom, t.n_tracks, exp_seg, t.start[k], t.finish[k], out[k], expd)
+        ts = engine.TrackSet.from_runlists(got)
+        res = ts.reduce_host("sum")
+        ts.close()
+        assert_runs_equal(res, oracle.reduce(ref_t.as_dict(), "sum"), 1e-12, "sum map %s seed %d" % (op, seed))

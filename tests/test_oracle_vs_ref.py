@@ -89,3 +89,30 @@ def test_oracle_pearson_matches_compiled_reference(oracle, seed):
     exp = oracle.ref_pearson(d)
     got = oracle.pearson(d)
     assert (np.isnan(exp) and np.isnan(got)) or got == exp, (got, exp)
+
+
+MAP_CASES = [("scale", -2.5), ("offset", 3.25), ("ln", 0.0), ("log", 2.0), ("log", 10.0), ("exp", 0.0), ("expb", 2.0),
+             ("pow", 2.0), ("pow", -1.0), ("pow", 0.5), ("abs", 0.0)]
+
+
+@pytest.mark.parametrize("op,param", MAP_CASES)
+def test_oracle_map_ops_match_compiled_reference(oracle, op, param):
+    """unaryOps.c:650-949 restated value by value (oracle/wt_oracle.c:wto_map / wto_map_default) vs the
+    compiled reference's operator iterators: values bit for bit (same libm), dropped runs, defaults."""
+    for seed in range(6):
+        t = random_case(8000 + seed, dtype=np.float64 if seed % 2 else np.float32)
+        rng = np.random.default_rng(seed)
+        t.value[:] = (t.value * rng.choice([1.0, -1.0, 0.0], size=len(t.value), p=[0.6, 0.3, 0.1])).astype(t.value.dtype)
+        d = t.as_dict()
+        for i in range(t.n_tracks):
+            rc, rs, rf, rv, rd = oracle.ref_map(d, i, op, param)
+            # the same track through the restatement
+            idx = np.concatenate([np.arange(t.seg_off[c * t.n_tracks + i], t.seg_off[c * t.n_tracks + i + 1])
+                                  for c in range(t.n_chrom)]).astype(np.int64)
+            out, keep = oracle.map_values(op, param, t.value[idx])
+            k = keep != 0
+            assert len(rs) == int(k.sum()), (op, param, seed, i)
+            assert np.array_equal(rs, t.start[idx][k]) and np.array_equal(rf, t.finish[idx][k])
+            assert np.array_equal(rv, out[k], equal_nan=True), (op, param, seed, i)
+            od = oracle.map_default(op, param, t.defaults[i])
+            assert (np.isnan(od) and np.isnan(rd)) or od == rd, (op, param, t.defaults[i], od, rd)

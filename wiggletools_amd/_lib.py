@@ -61,6 +61,11 @@ def lib():
     L.wtamd_multiplex_host.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Runs), C.c_void_p, C.c_void_p,
                                        C.POINTER(C.c_int64)]
     L.wtamd_runs_auc.argtypes = [C.POINTER(Runs), C.c_int64, C.POINTER(C.c_double), C.c_void_p]
+    L.wtamd_runs_map.argtypes = [C.c_int, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.wtamd_map_default.argtypes = [C.c_int, C.c_double, C.c_double]
+    L.wtamd_map_default.restype = C.c_double
+    L.wtamd_runs_mean.argtypes = [C.POINTER(Runs), C.c_int64, C.POINTER(C.c_double), C.c_void_p]
     L.wtamd_runs_compress.argtypes = [C.POINTER(Runs), C.c_int64, C.c_int32, C.POINTER(Runs), C.POINTER(C.c_int64), C.c_void_p]
     L.wtamd_trackset_validate.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.wtamd_pearson.argtypes = [C.c_void_p, C.POINTER(C.c_double)]

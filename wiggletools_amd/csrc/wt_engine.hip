@@ -380,13 +380,17 @@ __global__ void __launch_bounds__(256) wt_extents_kernel(const int64_t *seg_off,
 
 // AUC: statistics.c:103-120.  Deterministic two-level sum.
 __global__ void __launch_bounds__(256) wt_auc_kernel(const int32_t *start, const int32_t *finish, const double *value,
-                                                      long long n, double *partial) {
+                                                      long long n, double *partial, double *partial_span) {
     __shared__ double red[256];
-    double acc = 0;
+    double acc = 0, span = 0;
     const long long stride = (long long) gridDim.x * blockDim.x;
     for (long long r = (long long) blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
         const double v = value[r];
-        if (v == v) acc += (double) (finish[r] - start[r]) * v;
+        if (v == v) {                                   // NaN runs are skipped (statistics.c:78, 110)
+            const double len = (double) (finish[r] - start[r]);
+            acc += len * v;
+            span += len;
+        }
     }
     red[threadIdx.x] = acc;
     __syncthreads();
@@ -395,6 +399,16 @@ __global__ void __launch_bounds__(256) wt_auc_kernel(const int32_t *start, const
         __syncthreads();
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+    if (partial_span) {                                 // MeanIntegrator also needs the non-NaN span
+        __syncthreads();
+        red[threadIdx.x] = span;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int) threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial_span[blockIdx.x] = red[0];
+    }
 }
 
 __global__ void wt_auc_final_kernel(const double *partial, int n, double *out) {
@@ -404,7 +418,6 @@ __global__ void wt_auc_final_kernel(const double *partial, int n, double *out) {
         *out = acc;
     }
 }
-
 
 // ---------------------------------------------------------------------------
 // Pearson correlation of two tracks over the Multiplexer tile (reference PearsonIntegrator,
@@ -514,6 +527,7 @@ static int wt_fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
 }
+int wt_fail_ext(int code, const std::string &msg) { return wt_fail(code, msg); }   // for the other translation units
 
 #define WT_HIP(expr)                                                                           \
     do {                                                                                       \
@@ -1052,19 +1066,35 @@ int wtamd_multiplex_host(wtamd_trackset *ts, uint32_t flags, wtamd_runs *runs, d
     return wt_reduce_host_impl(ts, WT_OP_MULTIPLEX, flags, 0, runs, values, inplay, n_runs);
 }
 
-int wtamd_runs_auc(const wtamd_runs *runs, int64_t n_runs, double *auc, void *stream) {
-    if (!runs || !auc) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+static int wt_runs_auc_span(const wtamd_runs *runs, int64_t n_runs, double *auc, double *span, void *stream) {
     hipStream_t s = (hipStream_t) stream;
     const int blocks = 512;
-    double *d_partial = nullptr;
-    WT_HIP(hipMalloc(&d_partial, sizeof(double) * (blocks + 1)));
+    double *d_partial = nullptr, h[2] = {0, 0};
+    WT_HIP(hipMalloc(&d_partial, sizeof(double) * (2 * blocks + 2)));
     hipLaunchKernelGGL(wt_auc_kernel, dim3(blocks), dim3(256), 0, s, runs->start, runs->finish, runs->value,
-                       (long long) n_runs, d_partial);
-    hipLaunchKernelGGL(wt_auc_final_kernel, dim3(1), dim3(64), 0, s, d_partial, blocks, d_partial + blocks);
+                       (long long) n_runs, d_partial, span ? d_partial + blocks : nullptr);
+    hipLaunchKernelGGL(wt_auc_final_kernel, dim3(1), dim3(64), 0, s, d_partial, blocks, d_partial + 2 * blocks);
+    if (span) hipLaunchKernelGGL(wt_auc_final_kernel, dim3(1), dim3(64), 0, s, d_partial + blocks, blocks, d_partial + 2 * blocks + 1);
     WT_HIP(hipGetLastError());
-    WT_HIP(hipMemcpyAsync(auc, d_partial + blocks, sizeof(double), hipMemcpyDeviceToHost, s));
+    WT_HIP(hipMemcpyAsync(h, d_partial + 2 * blocks, sizeof(double) * (span ? 2 : 1), hipMemcpyDeviceToHost, s));
     WT_HIP(hipStreamSynchronize(s));
     (void) hipFree(d_partial);
+    *auc = h[0];
+    if (span) *span = h[1];
+    return WTAMD_OK;
+}
+
+int wtamd_runs_auc(const wtamd_runs *runs, int64_t n_runs, double *auc, void *stream) {
+    if (!runs || !auc) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    return wt_runs_auc_span(runs, n_runs, auc, nullptr, stream);
+}
+
+int wtamd_runs_mean(const wtamd_runs *runs, int64_t n_runs, double *mean, void *stream) {
+    if (!runs || !mean) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    double sum = 0, span = 0;
+    const int rc = wt_runs_auc_span(runs, n_runs, &sum, &span, stream);
+    if (rc != WTAMD_OK) return rc;
+    *mean = span > 0 ? sum / span : __builtin_nan("");      // statistics.c:66-68, res initialised to NAN :98
     return WTAMD_OK;
 }
 

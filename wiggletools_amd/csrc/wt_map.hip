@@ -1,0 +1,235 @@
+// wt_map.hip -- the reference's `map`-able unary operators applied to whole run lists on device
+// (SURVEY 8f row 3): scale, offset, ln, log, exp, pow, abs (reference src/unaryOps.c:650-949).
+//
+// The reference wraps every track in one lazy operator iterator (one indirect call per interval,
+// commandParser.c:115-211).  Here the operator is an elementwise pass over the track set's value
+// array before it is multiplexed: a run list has one value per input run, so mapping the runs is
+// cheaper than fusing the operator into the reducer's per-(track, position) loop would be.
+// ln / log DROP runs whose value is <= 0 (unaryOps.c:764-765) -- that changes which tracks are in
+// play downstream, so those two also compact the run lists (flag -> block counts -> scan ->
+// scatter) and rewrite the segment offsets.
+// Values become f64 (the reference's operators compute in double); default values are transformed
+// on the host by wtamd_map_default, including the `float` truncation several ctors apply
+// (SURVEY Q14).  Bound: HBM, 12 B read + 16 B written per run.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/wiggletools_amd.h"
+
+#define WM_BLOCK 256
+#define WM_ITEMS 16
+#define WM_TILE (WM_BLOCK * WM_ITEMS)
+
+extern "C" const char *wtamd_last_error(void);
+int wt_fail_ext(int code, const std::string &msg);     // wt_engine.hip
+
+namespace {
+
+__device__ inline double wm_apply(int op, double param, double lg, double v, bool &keep) {
+    keep = true;
+    switch (op) {
+    case WTAMD_MAP_SCALE: return (v != v) ? v : param * v;                       // unaryOps.c:650-664
+    case WTAMD_MAP_OFFSET: return param + v;                                      // :722-734
+    case WTAMD_MAP_LN:
+    case WTAMD_MAP_LOG:                                                           // :760-779
+        if (v <= 0) keep = false;
+        return (v != v || v < 0) ? __builtin_nan("") : log(v) / lg;
+    case WTAMD_MAP_EXP:
+    case WTAMD_MAP_EXPB: return exp(v * lg);                                      // :823-835
+    case WTAMD_MAP_POW: return ((param < 0 && v <= 0) || v != v) ? __builtin_nan("") : pow(v, param);   // :873-889
+    case WTAMD_MAP_ABS: return (v != v) ? v : fabs(v);                            // :934-949
+    default: return v;
+    }
+}
+
+template <class ValT>
+__global__ void __launch_bounds__(WM_BLOCK) wm_map_kernel(int op, double param, double lg, const ValT *in, long long n,
+                                                           double *out, unsigned long long *block_keep) {
+    __shared__ unsigned int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const long long base = (long long) blockIdx.x * WM_TILE;
+    unsigned kept = 0;
+#pragma unroll 4
+    for (int q = 0; q < WM_ITEMS; q++) {
+        const long long g = base + threadIdx.x + (long long) q * WM_BLOCK;
+        if (g < n) {
+            bool keep;
+            const double r = wm_apply(op, param, lg, (double) in[g], keep);
+            // a dropped run keeps a NaN payload nobody reads; the flag is re-derived from the input
+            out[g] = r;
+            kept += keep ? 1u : 0u;
+        }
+    }
+    if (block_keep) {
+        atomicAdd(&cnt, kept);
+        __syncthreads();
+        if (threadIdx.x == 0) block_keep[blockIdx.x] = cnt;
+    }
+}
+
+// exclusive scan of the block counts (one wave; the tile is 4096 runs, so even 2.4e9 runs are
+// only 5.8e5 entries)
+__global__ void wm_scan_blocks(unsigned long long *block_keep, long long n_blocks, unsigned long long *total) {
+    const int lane = threadIdx.x;
+    unsigned long long carry = 0;
+    for (long long b0 = 0; b0 < n_blocks; b0 += 64) {
+        const long long b = b0 + lane;
+        unsigned long long v = b < n_blocks ? block_keep[b] : 0ull, incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = (unsigned long long) __shfl_up((long long) incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (b < n_blocks) block_keep[b] = carry + incl - v;
+        carry += (unsigned long long) __shfl((long long) incl, 63);
+    }
+    if (lane == 0) *total = carry;
+}
+
+template <class ValT>
+__device__ inline bool wm_kept(const ValT *in, long long g) { return !((double) in[g] <= 0); }
+
+// stable scatter of the kept runs of one tile (order inside the tile: by global index)
+template <class ValT>
+__global__ void __launch_bounds__(WM_BLOCK) wm_compact_kernel(const ValT *in, const int32_t *start, const int32_t *finish,
+                                                               const double *mapped, long long n,
+                                                               const unsigned long long *block_off, int32_t *o_start,
+                                                               int32_t *o_finish, double *o_value) {
+    __shared__ unsigned int wave_tot[WM_BLOCK / 64];
+    const long long base = (long long) blockIdx.x * WM_TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long off = block_off[blockIdx.x];
+    // every thread owns WM_ITEMS CONSECUTIVE runs so that the output order is the input order
+    const long long g0 = base + (long long) threadIdx.x * WM_ITEMS;
+    unsigned mask = 0, mine = 0;
+#pragma unroll
+    for (int q = 0; q < WM_ITEMS; q++)
+        if (g0 + q < n && wm_kept(in, g0 + q)) { mask |= 1u << q; mine++; }
+    unsigned incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = (unsigned) __shfl_up((int) incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned before = incl - mine;
+    for (int w = 0; w < wave; w++) before += wave_tot[w];
+    unsigned long long o = off + before;
+#pragma unroll
+    for (int q = 0; q < WM_ITEMS; q++)
+        if ((mask >> q) & 1u) {
+            o_start[o] = start[g0 + q];
+            o_finish[o] = finish[g0 + q];
+            o_value[o] = mapped[g0 + q];
+            o++;
+        }
+}
+
+// new segment offsets: number of kept runs before every old segment boundary
+template <class ValT>
+__global__ void wm_seg_offsets(const ValT *in, const int64_t *seg_off, long long n_seg, long long n,
+                               const unsigned long long *block_off, unsigned long long total, int64_t *o_seg_off) {
+    const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_seg) return;
+    const long long p = seg_off[s];
+    if (p >= n) { o_seg_off[s] = (int64_t) total; return; }
+    const long long b = p / WM_TILE;
+    unsigned long long c = block_off[b];
+    for (long long g = b * WM_TILE; g < p; g++) c += wm_kept(in, g) ? 1ull : 0ull;
+    o_seg_off[s] = (int64_t) c;
+}
+
+}  // namespace
+
+extern "C" {
+
+double wtamd_map_default(int map_op, double param, double d) {
+    const bool nan = d != d;
+    switch (map_op) {
+    case WTAMD_MAP_SCALE: { float f = nan ? NAN : d * param; return f; }                  // unaryOps.c:675-680
+    case WTAMD_MAP_OFFSET: { float f = nan ? NAN : d + param; return f; }                 // :738-743
+    case WTAMD_MAP_LN: return (!nan && d > 0) ? log(d) / 1.0 : NAN;                       // :792-796
+    case WTAMD_MAP_LOG: return (!nan && d > 0) ? log(d) / log(param) : NAN;               // :807-811
+    case WTAMD_MAP_EXP: { float f = nan ? NAN : exp(d * 1.0); return f; }                 // :860-865
+    case WTAMD_MAP_EXPB: { float f = nan ? NAN : exp(d * log(param)); return f; }         // :847-852
+    case WTAMD_MAP_POW: return (!nan && (d > 0 || param > 0)) ? pow(d, param) : NAN;      // :895-899
+    case WTAMD_MAP_ABS: return nan ? NAN : fabs(d);
+    default: return d;
+    }
+}
+
+#define WM_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
+    return wt_fail_ext(WTAMD_ERR_HIP, std::string(#call ": ") + hipGetErrorString(e_)); } while (0)
+
+int wtamd_runs_map(int map_op, double param, int64_t n_seg, const int64_t *seg_off, const int32_t *start,
+                   const int32_t *finish, const void *value, int value_is_f64, int32_t *o_start, int32_t *o_finish,
+                   double *o_value, int64_t *o_seg_off, void *stream) {
+    if (map_op < 0 || map_op >= WTAMD_MAP_COUNT_ || n_seg < 0 || !seg_off || !o_value || !o_seg_off)
+        return wt_fail_ext(WTAMD_ERR_ARG, "wtamd_runs_map: bad argument");
+    if ((map_op == WTAMD_MAP_LOG || map_op == WTAMD_MAP_EXPB) && !(param > 0))
+        return wt_fail_ext(WTAMD_ERR_ARG, "wtamd_runs_map: base / radix must be positive");
+    hipStream_t s = (hipStream_t) stream;
+    const long long n = seg_off[n_seg];
+    const bool drops = map_op == WTAMD_MAP_LN || map_op == WTAMD_MAP_LOG;
+    const double lg = (map_op == WTAMD_MAP_LOG || map_op == WTAMD_MAP_EXPB) ? log(param) : 1.0;
+    if (n == 0) {
+        for (int64_t q = 0; q <= n_seg; q++) o_seg_off[q] = 0;
+        return WTAMD_OK;
+    }
+    const long long n_blocks = (n + WM_TILE - 1) / WM_TILE;
+    unsigned long long *d_blk = nullptr;
+    double *d_mapped = o_value;
+    int64_t *d_seg = nullptr, *d_oseg = nullptr;
+    if (drops) {
+        WM_HIP(hipMalloc(&d_blk, sizeof(unsigned long long) * (n_blocks + 1)));
+        WM_HIP(hipMalloc(&d_mapped, sizeof(double) * n));
+        WM_HIP(hipMalloc(&d_seg, sizeof(int64_t) * (n_seg + 1) * 2));
+        d_oseg = d_seg + (n_seg + 1);
+        WM_HIP(hipMemcpyAsync(d_seg, seg_off, sizeof(int64_t) * (n_seg + 1), hipMemcpyHostToDevice, s));
+    }
+    if (value_is_f64)
+        hipLaunchKernelGGL(wm_map_kernel<double>, dim3((unsigned) n_blocks), dim3(WM_BLOCK), 0, s, map_op, param, lg,
+                           (const double *) value, n, d_mapped, d_blk);
+    else
+        hipLaunchKernelGGL(wm_map_kernel<float>, dim3((unsigned) n_blocks), dim3(WM_BLOCK), 0, s, map_op, param, lg,
+                           (const float *) value, n, d_mapped, d_blk);
+    WM_HIP(hipGetLastError());
+    if (!drops) {
+        // coordinates are unchanged: copy them only if the caller asked for separate arrays
+        if (o_start && o_start != start) WM_HIP(hipMemcpyAsync(o_start, start, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, s));
+        if (o_finish && o_finish != finish) WM_HIP(hipMemcpyAsync(o_finish, finish, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, s));
+        WM_HIP(hipStreamSynchronize(s));
+        for (int64_t q = 0; q <= n_seg; q++) o_seg_off[q] = seg_off[q];
+        return WTAMD_OK;
+    }
+    if (!o_start || !o_finish) return wt_fail_ext(WTAMD_ERR_ARG, "wtamd_runs_map: ln / log need output coordinate arrays");
+    hipLaunchKernelGGL(wm_scan_blocks, dim3(1), dim3(64), 0, s, d_blk, n_blocks, d_blk + n_blocks);
+    unsigned long long total = 0;
+    WM_HIP(hipMemcpyAsync(&total, d_blk + n_blocks, sizeof total, hipMemcpyDeviceToHost, s));
+    WM_HIP(hipStreamSynchronize(s));
+    const unsigned seg_grid = (unsigned) ((n_seg + 1 + 255) / 256);
+    if (value_is_f64) {
+        hipLaunchKernelGGL(wm_compact_kernel<double>, dim3((unsigned) n_blocks), dim3(WM_BLOCK), 0, s, (const double *) value,
+                           start, finish, d_mapped, n, d_blk, o_start, o_finish, o_value);
+        hipLaunchKernelGGL(wm_seg_offsets<double>, dim3(seg_grid), dim3(256), 0, s, (const double *) value, d_seg,
+                           (long long) n_seg, n, d_blk, total, d_oseg);
+    } else {
+        hipLaunchKernelGGL(wm_compact_kernel<float>, dim3((unsigned) n_blocks), dim3(WM_BLOCK), 0, s, (const float *) value,
+                           start, finish, d_mapped, n, d_blk, o_start, o_finish, o_value);
+        hipLaunchKernelGGL(wm_seg_offsets<float>, dim3(seg_grid), dim3(256), 0, s, (const float *) value, d_seg,
+                           (long long) n_seg, n, d_blk, total, d_oseg);
+    }
+    WM_HIP(hipGetLastError());
+    WM_HIP(hipMemcpyAsync(o_seg_off, d_oseg, sizeof(int64_t) * (n_seg + 1), hipMemcpyDeviceToHost, s));
+    WM_HIP(hipStreamSynchronize(s));
+    (void) hipFree(d_blk); (void) hipFree(d_mapped); (void) hipFree(d_seg);
+    return WTAMD_OK;
+}
+
+}  // extern "C"

@@ -29,6 +29,36 @@ def reducer_default(op, defaults):
     return _lib.lib().wtamd_reducer_default(opcode(op), len(d), d.ctypes.data)
 
 
+MAP_OPS = {"scale": 0, "offset": 1, "ln": 2, "log": 3, "exp": 4, "expb": 5, "pow": 6, "abs": 7}
+
+
+def map_default(op, param, default_value):
+    return _lib.lib().wtamd_map_default(MAP_OPS[op], float(param), float(default_value))
+
+
+def map_runlists(rl: RunLists, op, param=0.0):
+    """The reference's `map`-able unary operator `op` over every track of `rl`, on device
+    (wtamd_runs_map): returns a new RunLists with f64 values and transformed defaults."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n = int(rl.seg_off[-1])
+    n_seg = rl.n_chrom * rl.n_tracks
+    seg = np.ascontiguousarray(rl.seg_off, np.int64)
+    s = torch.from_numpy(np.ascontiguousarray(rl.start, np.int32)).to(dev)
+    f = torch.from_numpy(np.ascontiguousarray(rl.finish, np.int32)).to(dev)
+    v = torch.from_numpy(np.ascontiguousarray(rl.value)).to(dev)
+    os_ = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    of = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    ov = torch.empty(max(n, 1), dtype=torch.float64, device=dev)
+    oseg = np.zeros(n_seg + 1, np.int64)
+    _lib.check(_lib.lib().wtamd_runs_map(MAP_OPS[op], float(param), n_seg, seg.ctypes.data, s.data_ptr(), f.data_ptr(),
+                                         v.data_ptr(), 1 if rl.value.dtype == np.float64 else 0, os_.data_ptr(),
+                                         of.data_ptr(), ov.data_ptr(), oseg.ctypes.data, None))
+    m = int(oseg[-1])
+    d = np.array([map_default(op, param, x) for x in rl.defaults], np.float64)
+    return RunLists(rl.n_chrom, rl.n_tracks, oseg, os_[:m].cpu().numpy(), of[:m].cpu().numpy(), ov[:m].cpu().numpy(), d)
+
+
 class TrackSet:
     """N tracks resident in HBM (wtamd_trackset)."""
 
@@ -182,6 +212,13 @@ class DeviceRuns:
         r = self.as_struct()
         out = C.c_double()
         _lib.check(_lib.lib().wtamd_runs_auc(C.byref(r), int(self.n if n is None else n), C.byref(out), stream))
+        return out.value
+
+    def mean(self, n=None, stream=None):
+        """meanI of the run list (reference MeanIntegrator): length-weighted mean of the non-NaN runs."""
+        r = self.as_struct()
+        out = C.c_double()
+        _lib.check(_lib.lib().wtamd_runs_mean(C.byref(r), int(self.n if n is None else n), C.byref(out), stream))
         return out.value
 
     def compress(self, out=None, n=None, stream=None):
