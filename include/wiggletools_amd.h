@@ -227,7 +227,7 @@ typedef struct {
     float reduce_ms;         /* last multiplex+reduce kernel time (HIP events) */
     int32_t kernel;          /* kernel of the last reduction: 0 general bitmap multiplexer (wt_reduce_kernel),
                                 1 exact difference array for Sum / Mean (wt_delta_kernel)             */
-    int32_t reserved_;
+    int32_t patched_windows; /* difference-array windows whose values the general kernel rewrote (NaN, Inf, wide range) */
 } wtamd_stats;
 
 int wtamd_device_count(void);

@@ -64,5 +64,5 @@ def reduce(t, op, flags=0, n_set0=0, ppt=None, T=None, multiplex=False, ranges=N
     out = (chrom, os_[:n].copy(), of[:n].copy(), ov[:n].copy())
     if multiplex:
         out = (chrom, os_[:n].copy(), of[:n].copy(), tile[:n].copy(), ip[:n].copy())
-    return out, dict(W=int(info[0]), T=int(info[1]), lds=int(info[2]), n_windows=int(info[3]), n_chunks=int(info[6]), scratch_slab=int(info[7]), delta=int(info[8]), delta_bad=int(info[9]), delta_redo=int(info[10]),
+    return out, dict(W=int(info[0]), T=int(info[1]), lds=int(info[2]), n_windows=int(info[3]), n_chunks=int(info[6]), scratch_slab=int(info[7]), delta=int(info[8]), delta_bad=int(info[9]), delta_redo=int(info[10]), patched=int(info[11]),
                      covered_bp=int(info[4]), n_intervals=int(info[5]))

@@ -24,6 +24,10 @@ struct EmuRun {
     std::vector<char> lds;
     int T_lanes = 0;
     long long n_redo = 0;
+    // patch mode (wt_patch_kernel): only these windows, run offsets given instead of looked back
+    struct PatchGroup { long long goff; std::vector<long long> wins; };
+    bool patch = false;
+    std::vector<PatchGroup> groups;
 
     template <int OP, class ValT, class ScrT, int K, bool MULTI>
     void run() {
@@ -34,9 +38,19 @@ struct EmuRun {
         if (P.g_attr_slab) c.attr = slab.data() + P.g_scratch_slab;
         const int T = plan.T;
         std::vector<WtLane<K>> lanes(T);
+        size_t gi = 0, wi = 0;
+        long long patch_goff = 0;
         for (;;) {
-            const long long k = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
-            if (k >= P.n_windows) break;
+            long long k;
+            if (patch) {
+                while (gi < groups.size() && wi >= groups[gi].wins.size()) { gi++; wi = 0; }
+                if (gi >= groups.size()) break;
+                if (wi == 0) patch_goff = groups[gi].goff;
+                k = groups[gi].wins[wi++];
+            } else {
+                k = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+                if (k >= P.n_windows) break;
+            }
             constexpr bool two = (OP == WT_OP_TTEST || OP == WT_OP_MWU);
             constexpr int npass = wt_eval_passes(OP);
             const int N = P.n_tracks, NC = P.chunk_tracks;
@@ -57,7 +71,13 @@ struct EmuRun {
             if (fuse && npass == 2) for (int t = 0; t < T; t++) wt_eval_mid<OP, K>(P, acc[t]);
             for (int t = 0; t < T; t++) wt_phase_emask(P, c, two, t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
-            wt_phase_lookback(P, c, k);     // sequential emulation: the offset is known at once
+            if (patch) {                    // the difference-array kernel already placed this window's runs
+                c.sh->n_emit = (int32_t) c.epfx[P.n_words];
+                c.sh->goffset = patch_goff;
+                patch_goff += c.sh->n_emit;
+            } else {
+                wt_phase_lookback(P, c, k);     // sequential emulation: the offset is known at once
+            }
             for (int pass = fuse ? 1 : 0; pass < npass; pass++) {
                 for (int ch = 0; ch < P.n_chunks; ch++) {
                     const int t_lo = ch * NC, t_hi = std::min(N, t_lo + NC);
@@ -73,7 +93,7 @@ struct EmuRun {
             }
             for (int t = 0; t < T; t++) wt_phase_eval_finish<OP, ValT, ScrT, K>(P, c, acc[t], lanes[t], t, T);
             for (int t = 0; t < T; t++) wt_phase_write<OP, ValT, K>(P, c, lanes[t], t, T);
-            wt_window_stats(P, c);
+            if (!patch) wt_window_stats(P, c);
         }
     }
 
@@ -106,7 +126,7 @@ struct EmuRun {
                 }
                 const bool any = d.dsh->emin <= d.dsh->emax;
                 const bool ok = wt_delta_verdict(P, d, scale);
-                if (!ok) wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
+                if (!ok) wt_delta_mark_bad(P, c, k);
                 for (int ch = 0; ch < nchunks; ch++) {
                     if (nchunks > 1) ranges(ch);
                     for (int t = 0; t < T; t++) wt_delta_pass2(P, c, d, scale, ok, false, true, t, T);
@@ -122,7 +142,7 @@ struct EmuRun {
                 if (!wt_delta_window_verdict(P, d, guess, lo, ok)) {
                     n_redo++;
                     for (int t = 0; t < T; t++) wt_delta_rezero(P, c, d, t, T);
-                    if (!ok) wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
+                    if (!ok) wt_delta_mark_bad(P, c, k);
                     for (int ch = 0; ch < nchunks; ch++) {
                         if (nchunks > 1) ranges(ch);
                         for (int t = 0; t < T; t++) wt_delta_pass2(P, c, d, lo, ok, false, false, t, T);
@@ -137,6 +157,7 @@ struct EmuRun {
             for (int t = 0; t < T; t++) wt_delta_nextw(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
             wt_phase_lookback(P, c, k);
+            wt_delta_note_offset(P, c);
             for (int t = 0; t < T; t++) wt_delta_stage<OP>(P, c, d, lanes[t], t, T);
             for (int t = 0; t < T; t++) wt_delta_copy_out(P, c, d, t, T);
             wt_window_stats(P, c);
@@ -163,7 +184,12 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         if (seg_off[s + 1] > seg_off[s]) { fs[s] = start[seg_off[s]]; lf[s] = finish[seg_off[s + 1] - 1]; }
     const int64_t total = seg_off[n_seg];
     std::vector<unsigned long long> counters(WT_CTR_N, 0);
-    long long used_delta = 0, delta_bad = 0, n_redo_total = 0;
+    long long used_delta = 0, delta_bad = 0, n_redo_total = 0, patched = 0;
+    std::vector<int32_t> bad_list;
+    std::vector<long long> bad_goff;
+    WtWindowTables delta_tab;
+    int delta_W = 0;
+    std::vector<unsigned long long> delta_counters;
     // the engine's policy: exact difference-array path first when eligible, the general kernel
     // if any window had to give up
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -178,6 +204,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         std::vector<uint32_t> widx((size_t) tab.n_rows * n_tracks, 0);
         std::vector<unsigned long long> status(tab.n_windows, 0);
         counters.assign(WT_CTR_N, 0);
+        if (delta) { bad_list.assign(tab.n_windows + 1, 0); bad_goff.assign(tab.n_windows + 1, 0); }
 
         WtParams &P = R.P;
         memset(&P, 0, sizeof(P));
@@ -190,6 +217,28 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         P.capacity = capacity; P.o_start = o_start; P.o_finish = o_finish; P.o_value = o_value;
         P.chrom_run_off = chrom_run_off; P.o_tile = o_tile; P.o_inplay = o_inplay;
         wt_plan_to_params(R.plan, P);
+        if (delta) { P.bad_list = bad_list.data(); P.bad_goff = bad_goff.data(); }
+        // few inexact windows: the general kernel rewrites the values of just those (the engine's
+        // wt_patch_kernel); many: it redoes everything
+        const bool patching = !delta && attempt == 1 && delta_bad > 0 && delta_bad * 4 <= (long long) delta_tab.n_windows &&
+                              delta_W >= R.plan.W && delta_W % R.plan.W == 0;
+        if (patching) {
+            const int ratio = delta_W / R.plan.W;
+            R.patch = true;
+            for (long long j = 0; j < delta_bad; j++) {
+                const long long kd = bad_list[j];
+                const int ch = delta_tab.win_chrom[kd];
+                const long long m = kd - delta_tab.c_first_win[ch];
+                EmuRun::PatchGroup g;
+                g.goff = bad_goff[j];
+                for (int h = 0; h < ratio; h++) {
+                    const long long mg = m * ratio + h;
+                    if (mg < tab.c_nwin[ch]) g.wins.push_back(tab.c_first_win[ch] + mg);
+                }
+                R.groups.push_back(g);
+            }
+            patched = delta_bad;
+        }
 
         // window index "kernel"
         P.n_total = total;
@@ -207,16 +256,22 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
                 return -11;
             }
         }
-        if (info) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows; info[6] = R.plan.n_chunks; info[7] = R.plan.scratch_slab;
+        if (info && !patching) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows; info[6] = R.plan.n_chunks; info[7] = R.plan.scratch_slab;
                     info[4] = (long long) counters[WT_CTR_BP]; info[5] = (long long) counters[WT_CTR_INTERVALS]; }
         if (delta) {
             n_redo_total = R.n_redo;
             delta_bad = (long long) counters[WT_CTR_DELTA_BAD];
             used_delta = delta_bad == 0;
             if (used_delta) break;
+            delta_tab = tab;
+            delta_W = R.plan.W;
+            delta_counters = counters;
+        } else if (patching) {
+            counters = delta_counters;          // run count, covered bp, ... are the difference-array launch's
+            used_delta = 1;
         }
     }
-    if (info) { info[8] = used_delta; info[9] = delta_bad; info[10] = n_redo_total; }
+    if (info) { info[8] = used_delta; info[9] = delta_bad; info[10] = n_redo_total; info[11] = patched; }
     if (counters[WT_CTR_ERROR] & WT_ERR_CAPACITY) return -1;
     if (counters[WT_CTR_ERROR]) return -2;
     return (long long) counters[WT_CTR_RUNS];

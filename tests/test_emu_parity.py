@@ -247,26 +247,36 @@ def test_emu_delta_speculative_unit_is_redone(oracle, direction):
         assert_runs_equal(got, exp, 0.0, "%s %s %s" % (direction, op, info))
 
 
-def test_emu_delta_falls_back_on_wide_range_and_nonfinite(oracle):
-    """Windows whose values span too many binades, or hold NaN / Inf, are re-run by the general kernel."""
-    for kind in ("wide", "nan", "inf", "denormal"):
-        t = _delta_case(5, 6, [2000, 300], 8, lambda r, k: r.random(k) + 0.5)
+def test_emu_delta_inexact_windows_are_patched(oracle):
+    """Windows whose values span too many binades, or hold NaN / Inf, keep their coordinates from the
+    difference-array kernel and get their values from the general kernel (few such windows), or
+    the general kernel redoes everything (many)."""
+    for kind in ("wide", "nan", "inf", "denormal", "many"):
+        t = _delta_case(5, 6, [5000, 300], 8, lambda r, k: r.random(k) + 0.5)
         if kind == "wide":
             t.value[3] = np.float32(1e-30)
         elif kind == "nan":
             t.value[7] = np.nan
+            t.value[len(t.value) // 2] = np.nan
         elif kind == "inf":
             t.value[7] = np.inf
+        elif kind == "many":
+            t.value[::40] = np.nan                                             # NaN in every window
         else:
             t.value[:] = (t.value * np.float32(1e-42)).astype(np.float32)     # all denormal: still exact
         for op in ("sum", "mean"):
-            exp = oracle.reduce(t.as_dict(), op)
-            got, info = emu.reduce(t, op, delta_T=64)
-            if kind == "denormal":
-                assert info["delta"] == 1
-            else:
-                assert info["delta"] == 0 and info["delta_bad"] > 0, info
-            assert_runs_equal(got, exp, 0.0, "%s %s %s" % (kind, op, info))
+            for strict in (0, 1):
+                exp = oracle.reduce(t.as_dict(), op, flags=strict)
+                # general plan of 256-bp windows under 512-bp difference-array windows: two per patch
+                got, info = emu.reduce(t, op, flags=strict, delta_T=64, ppt=4, T=64)
+                if kind == "denormal":
+                    assert info["delta"] == 1 and info["delta_bad"] == 0
+                elif kind == "many":
+                    assert info["delta"] == 0 and info["delta_bad"] > 0 and info["patched"] == 0, info
+                else:
+                    assert info["delta"] == 1 and info["delta_bad"] > 0 and info["patched"] == info["delta_bad"], info
+                assert_runs_equal(got, exp, 0.0, "%s %s %s" % (kind, op, info))
+                assert info["covered_bp"] == int((exp[2] - exp[1]).sum())
 
 
 def test_emu_delta_not_used_when_ineligible(oracle):

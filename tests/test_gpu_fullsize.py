@@ -79,6 +79,23 @@ def test_gpu_full_size_properties(scale, monkeypatch):
     auc = a.auc(stream=stream)
     assert auc * 8 == float(expect) and expect < 2 ** 53, (auc, expect / 8)
 
+    # a handful of values the difference-array kernel cannot take (NaN, Inf, a 2^-120 speck): those
+    # windows are patched by the general kernel -- and the whole output still equals the general
+    # kernel's, bit for bit, NaN runs included
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    where = torch.randint(0, value.numel(), (12,), device=dev, generator=g)
+    saved = value[where].clone()
+    value[where] = torch.tensor([float("nan"), float("inf"), 2.0 ** -120] * 4, device=dev, dtype=value.dtype)
+    p, np_, stp = run("sum", no_delta=False)
+    assert stp["kernel"] == 1 and 1 <= stp["patched_windows"] <= 12, stp
+    q, nq, stq = run("sum", no_delta=True)
+    assert np_ == nq == na
+    assert torch.equal(p.start[:np_], q.start[:nq]) and torch.equal(p.finish[:np_], q.finish[:nq])
+    assert torch.equal(p.value[:np_].view(torch.int64), q.value[:nq].view(torch.int64)), "patched windows differ"
+    assert int(torch.isnan(p.value[:np_]).sum().item()) > 0
+    value[where] = saved
+    del p, q
+
     # mean = sum / N, the reference's own expression (reducers.c:399-400)
     m, nm, stm = run("mean", no_delta=False)
     assert nm == na and stm["kernel"] == 1

@@ -30,7 +30,7 @@ class Runs(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_runs", C.c_int64), ("covered_bp", C.c_int64), ("n_intervals", C.c_int64),
                 ("n_windows", C.c_int64), ("window_bp", C.c_int32), ("lds_bytes", C.c_int32),
-                ("index_ms", C.c_float), ("reduce_ms", C.c_float), ("kernel", C.c_int32), ("reserved_", C.c_int32)]
+                ("index_ms", C.c_float), ("reduce_ms", C.c_float), ("kernel", C.c_int32), ("patched_windows", C.c_int32)]
 
 
 _lib = None

@@ -99,6 +99,8 @@ struct WtParams {
     int64_t *chrom_run_off;       // [n_chrom+1]
     double *o_tile;               // WT_OP_MULTIPLEX only: [capacity * n_tracks]
     uint8_t *o_inplay;            // WT_OP_MULTIPLEX only
+    int32_t *bad_list;            // difference-array kernel: windows it could not prove exact (slot order arbitrary)
+    long long *bad_goff;          //   global index of the first run of each of them, same slots
     char *g_scratch;              // median / MWU with more tracks than LDS columns hold: one slab per workgroup
     long long g_scratch_slab;     // bytes per workgroup (0: the columns live in LDS)
     long long g_attr_slab;        // MWU: bytes of per-rank attributes per workgroup, after the columns' slab
@@ -123,6 +125,7 @@ struct WtShared {
     int32_t n_emit;               // runs emitted by this window
     unsigned long long bp_sum;    // covered bp of this window
     unsigned long long n_intervals;
+    int32_t bad_slot;             // difference-array kernel: slot of this window in bad_list, or -1
 };
 
 // Per-lane state that lives across phases (registers on the GPU)
@@ -285,6 +288,7 @@ WT_DEV void wt_phase_header(const WtParams &P, WtCtx &c, long long k) {
     sh->bp_sum = 0;
     sh->n_intervals = 0;
     sh->goffset = 0;
+    sh->bad_slot = -1;
 }
 
 // ---------------------------------------------------------------------------

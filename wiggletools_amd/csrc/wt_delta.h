@@ -14,8 +14,9 @@
 //   * if N * 2^(emax-emin+24) <= 2^53 every partial sum -- in ANY order -- is exactly
 //     representable in f64, so the reference's sequential sum is exact and equals the integer sum
 //     of the scaled mantissas times q.  Bit-identical, not approximately equal.
-// Windows that fail the test (wide dynamic range, NaN / Inf) are counted in WT_CTR_DELTA_BAD and
-// the host re-runs the launch through the general kernel.  Preconditions checked by the host:
+// Windows that fail the test (wide dynamic range, NaN / Inf) still emit their runs and are recorded
+// (WT_CTR_DELTA_BAD, bad_list, bad_goff); the general kernel then rewrites the values of just those
+// windows (wt_patch_kernel), or of everything if they are many.  Preconditions checked by the host:
 // float tracks, all default values == 0 (absent tracks then add +0.0, which never changes a
 // sum), op in {SUM, MEAN}.
 //
@@ -342,6 +343,19 @@ WT_DEV int wt_delta_window_verdict(const WtParams &P, const WtDeltaCtx &d, int g
     lo = a;
     ok = !bad && (b - a) <= R;
     return (!bad && a >= guess && (b - guess) <= R) ? 1 : 0;
+}
+
+// One lane: the window is not provably exact.  It still emits its runs (coordinates, run count,
+// look-back) so that the output stays ordered; it is recorded so that the general kernel can
+// rewrite the values of just these windows afterwards (wt_patch_kernel).
+WT_DEV void wt_delta_mark_bad(const WtParams &P, WtCtx &c, long long k) {
+    const unsigned long long slot = wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
+    c.sh->bad_slot = (int32_t) slot;
+    if (P.bad_list) P.bad_list[slot] = (int32_t) k;
+}
+// after the look-back (same lane): where the window's runs start
+WT_DEV void wt_delta_note_offset(const WtParams &P, WtCtx &c) {
+    if (c.sh->bad_slot >= 0 && P.bad_goff) P.bad_goff[c.sh->bad_slot] = c.sh->goffset;
 }
 
 // redo of a window: clear the accumulators only (the exponent range is kept)

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
             }
             const bool any = d.dsh->emin <= d.dsh->emax;
             const bool ok = wt_delta_verdict(P, d, scale);
-            if (!ok && tid == 0) wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
+            if (!ok && tid == 0) wt_delta_mark_bad(P, c, k);
             for (int ch = 0; ch < nchunks; ch++) {
                 if (nchunks > 1) {
                     wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
             if (!wt_delta_window_verdict(P, d, guess, lo, ok)) {      // workgroup-uniform
                 __syncthreads();            // every lane has read the verdict fields
                 wt_delta_rezero(P, c, d, tid, nt);
-                if (!ok && tid == 0) wt_glb_add64(&P.counters[WT_CTR_DELTA_BAD], 1ull);
+                if (!ok && tid == 0) wt_delta_mark_bad(P, c, k);
                 __syncthreads();
                 for (int ch = 0; ch < nchunks; ch++) {
                     if (nchunks > 1) {
@@ -297,7 +297,10 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
         WT_MARK(110);
         // the look-back's round trips to the status words overlap the staging of the other waves
         // (and the predecessors get that much longer to publish)
-        if (tid < 64) wt_lookback_complete(P, c, k, tid, mine);
+        if (tid < 64) {
+            wt_lookback_complete(P, c, k, tid, mine);
+            if (tid == 0) wt_delta_note_offset(P, c);       // (lane 0 set the offset in the look-back)
+        }
         WT_TICK(6);
         wt_delta_stage<OP>(P, c, d, L, tid, nt);
         __syncthreads();
@@ -317,6 +320,80 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
     if (tid == 0)
         for (int q = 0; q < 8; q++) wt_glb_add64(&P.counters[WT_CTR_PROF + q], prof[q]);
 #endif
+}
+
+// Patch kernel: the general bitmap multiplexer over just the windows the difference-array kernel
+// could not prove exact (a NaN, an Inf, too wide a dynamic range).  That kernel has already emitted
+// those windows' runs -- coordinates, run count, position in the output -- so this one only has
+// to recompute their values in the reference's own summation order and store them at the recorded
+// offsets: no ticket, no look-back, no statistics.  One difference-array window (4096 bp) is
+// `ratio` general windows; they are done in order by one workgroup, the run offset advancing by
+// each one's run count.
+struct WtPatchArgs {
+    const int32_t *bad_list;            // difference-array window ids (slot order)
+    const long long *bad_goff;          // first run of each
+    const unsigned long long *n_bad;    // how many (device counter of the difference-array launch)
+    const int32_t *d_win_chrom;         // the difference-array launch's window tables
+    const int64_t *d_c_first_win;
+    int ratio;                          // its window width / this launch's
+};
+
+template <int OP, int K, bool MULTI>
+__global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_patch_kernel(const WtParams P, const WtPatchArgs Q) {
+    typedef float ValT;
+    typedef float ScrT;
+    extern __shared__ __attribute__((aligned(16))) char wt_lds[];
+    WtCtx c;
+    wt_ctx_init(c, P, wt_lds);
+    WtLane<K> L;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const long long n_bad = (long long) *Q.n_bad;
+    const int N = P.n_tracks, NC = MULTI ? P.chunk_tracks : N, n_chunks = MULTI ? P.n_chunks : 1;
+    for (long long j = blockIdx.x; j < n_bad; j += gridDim.x) {
+        const long long kd = Q.bad_list[j];
+        const int ch = Q.d_win_chrom[kd];
+        const long long m = kd - Q.d_c_first_win[ch];
+        long long goff = Q.bad_goff[j];
+        for (int h = 0; h < Q.ratio; h++) {
+            const long long mg = m * Q.ratio + h;
+            if (mg >= P.c_nwin[ch]) break;                  // workgroup-uniform
+            const long long k = P.c_first_win[ch] + mg;
+            __syncthreads();                                // the previous window is done with the shared block
+            if (tid == 0) wt_phase_header(P, c, k);
+            wt_phase_zero(P, c, true, tid, nt);
+            __syncthreads();
+            WtAcc<K> A;
+            wt_eval_init<OP, K>(A);
+            for (int cc = 0; cc < n_chunks; cc++) {
+                const int t_lo = cc * NC, t_hi = (t_lo + NC < N) ? t_lo + NC : N;
+                if (MULTI && cc > 0) {
+                    wt_phase_zero(P, c, false, tid, nt);
+                    __syncthreads();
+                }
+                wt_phase_load<ValT>(P, c, t_lo, t_hi, false, tid, nt);
+                __syncthreads();
+                wt_phase_count_a(P, c, t_lo, t_hi, tid, nt);
+                __syncthreads();
+                wt_phase_count_b(P, c, t_lo, t_hi, tid, nt);
+                __syncthreads();
+                if (MULTI) {        // Sum / Mean are single-pass: the evaluation rides on the sweep
+                    wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, A, 0, t_lo, t_hi, true, tid, nt);
+                    __syncthreads();
+                }
+            }
+            wt_phase_emask(P, c, false, tid, nt);
+            __syncthreads();
+            wt_phase_escan(P, c, tid, nt);
+            __syncthreads();
+            const long long n_emit = (long long) c.epfx[P.n_words];
+            if (tid == 0) { c.sh->n_emit = (int32_t) n_emit; c.sh->goffset = goff; }
+            if (!MULTI) wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, A, 0, 0, N, false, tid, nt);
+            wt_phase_eval_finish<OP, ValT, ScrT, K>(P, c, A, L, tid, nt);
+            __syncthreads();
+            wt_phase_write<OP, ValT, K>(P, c, L, tid, nt);
+            goff += n_emit;
+        }
+    }
 }
 
 // Each block owns ONE contiguous span of intervals: a single binary search finds the
@@ -543,6 +620,8 @@ struct WtWindows {
     int64_t *d_cfirst = nullptr;
     uint32_t *d_widx = nullptr;
     unsigned long long *d_status = nullptr;
+    int32_t *d_bad_list = nullptr;      // difference-array launches: windows not provably exact ...
+    long long *d_bad_goff = nullptr;    // ... and where their runs start (both [n_windows])
     bool indexed = false;
 };
 
@@ -572,13 +651,15 @@ struct wtamd_trackset {
     int device = 0;
     int num_cu = 256;
     bool scratch_f32 = false;
-    bool delta_failed = false;                  // a window of this data was not exact: Sum / Mean use the general kernel
-    bool delta_verified = false;                // every window of this data is exact (checked by a completed launch)
+    // Sum / Mean over float tracks: what a completed difference-array launch found out about this data
+    bool delta_failed = false;                  // many windows are not provably exact: Sum / Mean use the general kernel
+    bool delta_verified = false;                // verdict known: delta_n_bad windows (few) get patched by the general kernel
+    long long delta_n_bad = 0;
 };
 
 static void wt_free_windows(WtWindows &w) {
     (void) hipFree(w.d_cbase); (void) hipFree(w.d_cnwin); (void) hipFree(w.d_chi); (void) hipFree(w.d_win_chrom); (void) hipFree(w.d_cfirst);
-    (void) hipFree(w.d_widx); (void) hipFree(w.d_status);
+    (void) hipFree(w.d_widx); (void) hipFree(w.d_status); (void) hipFree(w.d_bad_list); (void) hipFree(w.d_bad_goff);
 }
 
 extern "C" {
@@ -805,6 +886,8 @@ int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
     // sets): what was learnt about their values is void, the next Sum / Mean verifies again
     ts->delta_verified = false;
     ts->delta_failed = false;
+    ts->delta_n_bad = 0;
+    for (auto &kv : ts->windows) kv.second.indexed = false;     // every width's index describes the old data
     WtPlan plan;
     std::string err;
     if (wt_wants_delta(ts, op)) wt_make_delta_plan(plan, ts->n_tracks);
@@ -859,6 +942,26 @@ struct WtLaunch {
     }
 };
 
+template <int OP, int K, bool MULTI>
+static hipError_t wt_launch_patch_t(const WtParams &P, const WtPatchArgs &Q, int T, int lds, int num_cu, long long n_bad,
+                                    hipStream_t s) {
+    auto kern = wt_patch_kernel<OP, K, MULTI>;
+    hipError_t e = hipSuccess;
+    if (lds > 48 * 1024) {
+        e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, T, (size_t) lds);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    long long g = (long long) num_cu * per_cu;
+    if (g > n_bad) g = n_bad;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned) g), dim3((unsigned) T), (size_t) lds, s, P, Q);
+    return hipGetLastError();
+}
+
 template <int OP>
 static void wt_launch_delta(WtLaunch &L) {
     auto kern = wt_delta_kernel<OP>;
@@ -898,26 +1001,92 @@ static int wt_check_desc(const wtamd_trackset *ts, const wtamd_reduce_desc *d) {
 static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32_t flags, int n_set0, wtamd_runs *runs,
                           double *d_tile, uint8_t *d_inplay, int64_t *n_runs, hipStream_t s);
 
+// The general kernel over the `n_bad` windows the difference-array launch (window width delta_W,
+// just finished or still running on `s`) recorded as not provably exact.
+static int wt_launch_patch(wtamd_trackset *ts, int delta_W, int op, uint32_t flags, wtamd_runs *runs, long long n_bad,
+                           hipStream_t s) {
+    WtPlan plan;
+    std::string err;
+    if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err)) return wt_fail(WTAMD_ERR_INTERNAL, err);
+    if (plan.scratch_slab > 0 || plan.W > delta_W || delta_W % plan.W != 0 || !ts->scratch_f32 || ts->value_f64)
+        return wt_fail(WTAMD_ERR_INTERNAL, "no general plan compatible with the difference-array windows");
+    WtWindows *dw = nullptr, *w = nullptr;
+    int rc = wt_get_windows(ts, delta_W, &dw);
+    if (rc != WTAMD_OK) return rc;
+    rc = wt_get_windows(ts, plan.W, &w);
+    if (rc != WTAMD_OK) return rc;
+    if (!w->indexed) {
+        rc = wt_build_index(ts, w, plan, s);
+        if (rc != WTAMD_OK) return rc;
+    }
+    WtParams P;
+    wt_fill_params(ts, w, plan, P);
+    P.op = op; P.flags = flags; P.n_set0 = 0;
+    P.capacity = runs->capacity;
+    P.o_start = runs->start; P.o_finish = runs->finish; P.o_value = runs->value;
+    P.chrom_run_off = runs->chrom_run_off ? runs->chrom_run_off : ts->d_chrom_run_off;
+    WtPatchArgs Q;
+    Q.bad_list = dw->d_bad_list; Q.bad_goff = dw->d_bad_goff;
+    Q.n_bad = ts->d_counters + WT_CTR_DELTA_BAD;
+    Q.d_win_chrom = dw->d_win_chrom; Q.d_c_first_win = dw->d_cfirst;
+    Q.ratio = delta_W / plan.W;
+    const bool multi = plan.n_chunks > 1;
+    hipError_t e;
+#define WT_PATCH_GO(OPC, KK, MM) e = wt_launch_patch_t<OPC, KK, MM>(P, Q, plan.T, plan.lds_bytes, ts->num_cu, n_bad, s)
+    if (op == WT_OP_SUM) {
+        if (plan.ppt == 4) { if (multi) WT_PATCH_GO(WT_OP_SUM, 4, true); else WT_PATCH_GO(WT_OP_SUM, 4, false); }
+        else { if (multi) WT_PATCH_GO(WT_OP_SUM, 1, true); else WT_PATCH_GO(WT_OP_SUM, 1, false); }
+    } else {
+        if (plan.ppt == 4) { if (multi) WT_PATCH_GO(WT_OP_MEAN, 4, true); else WT_PATCH_GO(WT_OP_MEAN, 4, false); }
+        else { if (multi) WT_PATCH_GO(WT_OP_MEAN, 1, true); else WT_PATCH_GO(WT_OP_MEAN, 1, false); }
+    }
+#undef WT_PATCH_GO
+    if (e != hipSuccess) return wt_fail(WTAMD_ERR_HIP, std::string("patch kernel launch: ") + hipGetErrorString(e));
+    WT_HIP(hipEventRecord(ts->ev_r1, s));       // the reduction's time includes its patches
+    ts->stats.patched_windows = (int32_t) n_bad;
+    return WTAMD_OK;
+}
+
 static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0, wtamd_runs *runs,
                           double *d_tile, uint8_t *d_inplay, int64_t *n_runs, hipStream_t s) {
     if (!runs || !runs->start || !runs->finish || !runs->value)
         return wt_fail(WTAMD_ERR_ARG, "wtamd_reduce: output arrays missing");
     WtPlan plan;
     std::string err;
-    // Sum / Mean: exact difference-array kernel first.  It verifies every window; if one was not
-    // exact the whole launch is redone by the general kernel and this data stays on it.  The
-    // verdict depends on the data and the windows only (not on the op or its flags), so it is
-    // established once per track set -- that first launch is waited for even when the caller asked
-    // for an asynchronous one -- and later launches skip the check.
+    // Sum / Mean: exact difference-array kernel first.  It verifies every window.  A few windows
+    // it cannot prove exact (NaN, Inf, too wide a dynamic range) keep their coordinates and get
+    // their values from the general kernel restricted to them (wt_patch_kernel); if they are many
+    // the whole launch is redone by the general kernel and this data stays on it.  The verdict
+    // depends on the data and the windows only (not on the op or its flags), so it is established
+    // once per track set -- that first launch is waited for even when the caller asked for an
+    // asynchronous one -- and later launches (patch included) need no host round trip.
     if (!d_tile && wt_wants_delta(ts, op)) {
         wt_make_delta_plan(plan, ts->n_tracks);
         int64_t n_probe = 0;
         const bool probe = !ts->delta_verified;
         const int rc = wt_reduce_plan(ts, plan, op, flags, n_set0, runs, d_tile, d_inplay,
                                       (probe && !n_runs) ? &n_probe : n_runs, s);
-        if (!probe) return rc;
+        if (!probe) {
+            if (ts->delta_n_bad > 0 && (rc == WTAMD_OK || rc == WTAMD_ERR_CAPACITY)) {
+                const int rp = wt_launch_patch(ts, plan.W, op, flags, runs, ts->delta_n_bad, s);
+                if (rp != WTAMD_OK) return rp;
+                if (n_runs) WT_HIP(hipStreamSynchronize(s));
+            }
+            return rc;
+        }
         if (rc != WTAMD_OK && rc != WTAMD_ERR_CAPACITY) return rc;
-        if (ts->h_counters[WT_CTR_DELTA_BAD] == 0) { ts->delta_verified = true; return rc; }
+        const long long n_bad = (long long) ts->h_counters[WT_CTR_DELTA_BAD];
+        if (n_bad == 0) { ts->delta_verified = true; ts->delta_n_bad = 0; return rc; }
+        if (n_bad * 4 <= (long long) ts->stats.n_windows && !getenv("WTAMD_NO_PATCH")) {
+            const int rp = wt_launch_patch(ts, plan.W, op, flags, runs, n_bad, s);
+            if (rp == WTAMD_OK) {
+                WT_HIP(hipStreamSynchronize(s));
+                ts->delta_verified = true;
+                ts->delta_n_bad = n_bad;
+                return rc;
+            }
+            if (rp != WTAMD_ERR_INTERNAL) return rp;        // INTERNAL: no compatible general plan -> full redo
+        }
         ts->delta_failed = true;
     }
     if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
@@ -943,6 +1112,13 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
     L.P.o_tile = d_tile; L.P.o_inplay = d_inplay;
     L.T = plan.T; L.lds = plan.lds_bytes; L.stream = s; L.num_cu = ts->num_cu;
     L.gscratch = &ts->d_gscratch; L.gscratch_bytes = &ts->gscratch_bytes;
+    if (plan.delta) {
+        const size_t nwin = (size_t) (w->tab.n_windows > 0 ? w->tab.n_windows : 1);
+        if (!w->d_bad_list) WT_HIP(hipMalloc(&w->d_bad_list, sizeof(int32_t) * nwin));
+        if (!w->d_bad_goff) WT_HIP(hipMalloc(&w->d_bad_goff, sizeof(long long) * nwin));
+        L.P.bad_list = w->d_bad_list;
+        L.P.bad_goff = w->d_bad_goff;
+    }
 
     WT_HIP(hipMemsetAsync(ts->d_counters, 0, sizeof(unsigned long long) * WT_CTR_N, s));
     WT_HIP(hipMemsetAsync(L.P.chrom_run_off, 0, sizeof(int64_t) * (ts->n_chrom + 1), s));
@@ -962,6 +1138,7 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
     ts->stats.window_bp = plan.W;
     ts->stats.lds_bytes = plan.lds_bytes;
     ts->stats.kernel = plan.delta ? 1 : 0;
+    ts->stats.patched_windows = 0;
     if (n_runs) {
         WT_HIP(hipMemcpyAsync(ts->h_counters, ts->d_counters, sizeof(unsigned long long) * WT_CTR_N, hipMemcpyDeviceToHost, s));
         {
