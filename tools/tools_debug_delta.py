@@ -1,7 +1,7 @@
 """GPU-box debugging aid: one small difference-array launch per process, stderr visible."""
-import sys
+import os, sys
 import numpy as np
-sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests")); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wiggletools_amd.runlists import synth
 from wiggletools_amd import engine as E
 

@@ -1287,9 +1287,7 @@ WT_DEV void wt_phase_write(const WtParams &P, WtCtx &c, const WtLane<K> &L, int 
             P.o_finish[o] = fin;
             P.o_value[o] = L.res[k];
         }
-#ifndef WT_NO_BPSUM
         wt_lds_add64(&c.sh->bp_sum, bp);
-#endif
     }
 }
 

@@ -228,7 +228,6 @@ WT_DEV bool wt_delta_verdict(const WtParams &P, const WtDeltaCtx &d, int &emin) 
 WT_DEV void wt_delta_apply(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t s, int32_t f, uint32_t vb,
                            int emin, bool ok, int32_t &my_next) {
     const int32_t w0 = c.sh->w0, w1 = c.sh->w1;
-#ifndef WT_DELTA_SLOW_APPLY
     if (s >= w0 && f < w1) {                    // the common case: the run lies inside the window -- no branches
         const int e = (int) ((vb >> 23) & 0xffu);
         const uint32_t frac = vb & 0x7fffffu;
@@ -241,7 +240,6 @@ WT_DEV void wt_delta_apply(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t s
         wt_lds_add32(&d.ev[f - w0], 0x10000u);
         return;
     }
-#endif
     if (f == w0) { wt_lds_add32(&d.ev[0], 0x00010001u); return; }    // true breakpoint at w0, covers nothing here
     if (s >= w1) { my_next = s < my_next ? s : my_next; return; }
     const int e = (int) ((vb >> 23) & 0xffu);
@@ -473,9 +471,7 @@ WT_DEV void wt_delta_copy_out(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int ti
         P.o_finish[o] = fin;
         P.o_value[o] = sv[i];
     }
-#ifndef WT_NO_BPSUM
     if (bp) wt_lds_add64(&c.sh->bp_sum, bp);
-#endif
 }
 
 // next non-empty word of U after every word (wt_next_breakpoint's jump table); one lane per word,
