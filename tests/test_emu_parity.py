@@ -313,3 +313,27 @@ def test_emu_delta_ranges_concatenate(oracle, seed):
                 cat[k].append(g[k][m])
     cat = tuple(np.concatenate(x) for x in cat)
     assert_runs_equal(cat, full, 0.0, "ranges")
+
+
+def test_emu_delta_patch_with_run_start_ranges(oracle):
+    """Batches / shards (run-start ranges) whose windows need patching: the pieces still tile the full result."""
+    t = _delta_case(61, 6, [30000, 12000], 6, lambda r, k: r.integers(1, 64, k) / 4.0, first_start=300)
+    t.value[50] = np.nan
+    t.value[len(t.value) // 2] = np.float32(1e-33)
+    full = oracle.reduce(t.as_dict(), "sum")
+    edges = [-(2 ** 31 - 1), 7500, 16100, 2 ** 31 - 1]
+    parts, patched = [], 0
+    for a, b in zip(edges[:-1], edges[1:]):
+        got, info = emu.reduce(t, "sum", delta_T=64, ppt=4, T=64, ranges=[(a, b)] * t.n_chrom)
+        assert info["delta"] == 1, info
+        patched += info["patched"]
+        parts.append(got)
+    assert patched >= 2
+    cat = [[], [], [], []]
+    for c in range(t.n_chrom):
+        for g in parts:
+            m = g[0] == c
+            for k in range(4):
+                cat[k].append(g[k][m])
+    cat = tuple(np.concatenate(x) for x in cat)
+    assert_runs_equal(cat, full, 0.0, "ranges + patches")
