@@ -306,6 +306,10 @@ enum wtamd_map_op {
     WTAMD_MAP_EXPB = 5,     /* exp(value * log(param))                         */
     WTAMD_MAP_POW = 6,      /* pow(value, param); NaN if param < 0 && value <= 0 */
     WTAMD_MAP_ABS = 7,
+    WTAMD_MAP_GT = 8,       /* runs with value > param, value 1; the others and NaN runs are DROPPED */
+    WTAMD_MAP_GTE = 9,      /*   (HighPassFilterWiggleIterator, unaryOps.c:386-419; default 0)      */
+    WTAMD_MAP_LT = 10,      /* value < param (the reference builds it as scale -1, gt -param)       */
+    WTAMD_MAP_LTE = 11,
     WTAMD_MAP_COUNT_
 };
 /* start / finish / value and the o_* arrays are DEVICE memory (o_* sized for all input runs),

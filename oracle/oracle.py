@@ -278,7 +278,8 @@ def pearson(t):
     return L.wto_pearson(len(s), s.ctypes.data, f.ctypes.data, x.ctypes.data, y.ctypes.data)
 
 
-MAP_OPS = {"scale": 0, "offset": 1, "ln": 2, "log": 3, "exp": 4, "expb": 5, "pow": 6, "abs": 7}
+MAP_OPS = {"scale": 0, "offset": 1, "ln": 2, "log": 3, "exp": 4, "expb": 5, "pow": 6, "abs": 7,
+           "gt": 8, "gte": 9, "lt": 10, "lte": 11}
 
 
 def map_values(op, param, values):

@@ -60,6 +60,7 @@ static WiggleIterator *(*r_NaturalExpWiggleIterator)(WiggleIterator *);
 static WiggleIterator *(*r_ExpWiggleIterator)(WiggleIterator *, double);
 static WiggleIterator *(*r_PowerWiggleIterator)(WiggleIterator *, double);
 static WiggleIterator *(*r_AbsWiggleIterator)(WiggleIterator *);
+static WiggleIterator *(*r_HighPassFilterWiggleIterator)(WiggleIterator *, double, wt_bool);
 static WiggleIterator *(*r_reduction[10])(Multiplexer *);
 static WiggleIterator *(*r_set_reduction[2])(Multiset *);      /* TTestReduction, MWUReduction (optional) */
 
@@ -98,6 +99,7 @@ int ref_open(const char *path) {
     OPT(r_ExpWiggleIterator, "ExpWiggleIterator");
     OPT(r_PowerWiggleIterator, "PowerWiggleIterator");
     OPT(r_AbsWiggleIterator, "AbsWiggleIterator");
+    OPT(r_HighPassFilterWiggleIterator, "HighPassFilterWiggleIterator");
     OPT(r_set_reduction[0], "TTestReduction");
     OPT(r_set_reduction[1], "MWUReduction");
 #undef OPT
@@ -325,7 +327,8 @@ double ref_pearson(const wto_tracks *t) {
 
 /* `map`-able unary operators (unaryOps.c:650-949) over ONE track: drains the reference's operator
  * iterator wrapped around the array-backed child.  map_op: 0 scale, 1 offset, 2 ln, 3 log base
- * param, 4 exp (natural), 5 exp radix param, 6 pow, 7 abs.  *o_default receives the operator
+ * param, 4 exp (natural), 5 exp radix param, 6 pow, 7 abs, 8 gt, 9 gte, 10 lt, 11 lte (built as
+ * commandParser.c:180-199 builds them).  *o_default receives the operator
  * iterator's default_value.  Returns the number of intervals or < 0. */
 int64_t ref_map(const wto_tracks *t, int track, int map_op, double param, int64_t cap,
                 int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value, double *o_default) {
@@ -341,6 +344,10 @@ int64_t ref_map(const wto_tracks *t, int track, int map_op, double param, int64_
     case 5: w = r_ExpWiggleIterator(c, param); break;
     case 6: w = r_PowerWiggleIterator(c, param); break;
     case 7: w = r_AbsWiggleIterator(c); break;
+    case 8: w = r_HighPassFilterWiggleIterator(c, param, 0); break;
+    case 9: w = r_HighPassFilterWiggleIterator(c, param, 1); break;
+    case 10: w = r_HighPassFilterWiggleIterator(r_ScaleWiggleIterator(c, -1), -param, 0); break;
+    case 11: w = r_HighPassFilterWiggleIterator(r_ScaleWiggleIterator(c, -1), -param, 1); break;
     default: return -3;
     }
     if (o_default) *o_default = w->default_value;

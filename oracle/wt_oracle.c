@@ -543,7 +543,11 @@ double wto_pearson(int64_t n, const int32_t *start, const int32_t *finish, const
 /* `map`-able unary operators, value by value (unaryOps.c: scale :650-664, offset :722-734, ln / log
  * :760-779 with ctor :786-813, exp :823-835 with ctors :843-866, pow :873-889, abs :934-949).
  * out[i] = f(in[i]); keep[i] = 0 for intervals the operator skips (ln / log: value <= 0, :764-765).
- * map_op: 0 scale, 1 offset, 2 ln, 3 log base param, 4 exp, 5 exp radix param, 6 pow, 7 abs. */
+ * gt / gte / lt / lte (commandParser.c:180-199 -> HighPassFilterWiggleIterator, unaryOps.c:386-419,
+ * lt / lte through ScaleWiggleIterator(-1)): runs failing the comparison and NaN runs are skipped,
+ * the kept ones carry the iterator's initial value 1 (wiggleIterator.c:26).
+ * map_op: 0 scale, 1 offset, 2 ln, 3 log base param, 4 exp, 5 exp radix param, 6 pow, 7 abs,
+ * 8 gt, 9 gte, 10 lt, 11 lte. */
 void wto_map(int map_op, double param, int64_t n, const double *in, double *out, unsigned char *keep) {
     const double lg = (map_op == 3 || map_op == 5) ? log(param) : 1.0;     /* baseLog / radixLog */
     for (int64_t i = 0; i < n; i++) {
@@ -560,6 +564,10 @@ void wto_map(int map_op, double param, int64_t n, const double *in, double *out,
         case 4: case 5: r = exp(v * lg); break;
         case 6: r = ((param < 0 && v <= 0) || isnan(v)) ? NAN : pow(v, param); break;
         case 7: r = isnan(v) ? NAN : fabs(v); break;
+        case 8: k = !(v <= param || isnan(v)); r = 1; break;
+        case 9: k = !(v < param || isnan(v)); r = 1; break;
+        case 10: k = !(-1 * v <= -param || isnan(v)); r = 1; break;     /* scale(-1), then gt -param */
+        case 11: k = !(-1 * v < -param || isnan(v)); r = 1; break;
         default: break;
         }
         out[i] = r;
@@ -578,6 +586,7 @@ double wto_map_default(int map_op, double param, double d) {
     case 5: { float f = isnan(d) ? NAN : exp(d * log(param)); return f; }    /* :847-852 float */
     case 6: return (!isnan(d) && (d > 0 || param > 0)) ? pow(d, param) : NAN;/* :895-899 double */
     case 7: return isnan(d) ? NAN : fabs(d);
+    case 8: case 9: case 10: case 11: return 0;                              /* unaryOps.c:419 */
     default: return d;
     }
 }

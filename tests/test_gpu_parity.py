@@ -407,7 +407,8 @@ def test_gpu_input_contract_validation(engine):
 
 
 @pytest.mark.parametrize("op,param", [("scale", -2.5), ("offset", 3.25), ("ln", 0.0), ("log", 2.0), ("exp", 0.0),
-                                      ("expb", 2.0), ("pow", 2.0), ("pow", -1.0), ("abs", 0.0)])
+                                      ("expb", 2.0), ("pow", 2.0), ("pow", -1.0), ("abs", 0.0),
+                                      ("gt", 12.5), ("gte", 12.5), ("lt", 12.5), ("lte", -3.0)])
 def test_gpu_map_ops(oracle, engine, op, param):
     """`map`-able unary operators on device (wtamd_runs_map) vs the oracle's restatement (itself pinned
     bit for bit on the compiled reference): dropped runs and segment offsets exact, values to 1e-12

@@ -92,7 +92,8 @@ def test_oracle_pearson_matches_compiled_reference(oracle, seed):
 
 
 MAP_CASES = [("scale", -2.5), ("offset", 3.25), ("ln", 0.0), ("log", 2.0), ("log", 10.0), ("exp", 0.0), ("expb", 2.0),
-             ("pow", 2.0), ("pow", -1.0), ("pow", 0.5), ("abs", 0.0)]
+             ("pow", 2.0), ("pow", -1.0), ("pow", 0.5), ("abs", 0.0),
+             ("gt", 0.0), ("gt", 12.5), ("gte", 12.5), ("lt", 12.5), ("lte", 12.5), ("lte", -3.0)]
 
 
 @pytest.mark.parametrize("op,param", MAP_CASES)

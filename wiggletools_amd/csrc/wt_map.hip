@@ -5,8 +5,8 @@
 // commandParser.c:115-211).  Here the operator is an elementwise pass over the track set's value
 // array before it is multiplexed: a run list has one value per input run, so mapping the runs is
 // cheaper than fusing the operator into the reducer's per-(track, position) loop would be.
-// ln / log DROP runs whose value is <= 0 (unaryOps.c:764-765) -- that changes which tracks are in
-// play downstream, so those two also compact the run lists (flag -> block counts -> scan ->
+// ln / log DROP runs whose value is <= 0 (unaryOps.c:764-765), gt / gte / lt / lte the runs failing the
+// comparison (:390-399) -- that changes which tracks are in play downstream, so those also compact the run lists (flag -> block counts -> scan ->
 // scatter) and rewrite the segment offsets.
 // Values become f64 (the reference's operators compute in double); default values are transformed
 // on the host by wtamd_map_default, including the `float` truncation several ctors apply
@@ -42,6 +42,10 @@ __device__ inline double wm_apply(int op, double param, double lg, double v, boo
     case WTAMD_MAP_EXPB: return exp(v * lg);                                      // :823-835
     case WTAMD_MAP_POW: return ((param < 0 && v <= 0) || v != v) ? __builtin_nan("") : pow(v, param);   // :873-889
     case WTAMD_MAP_ABS: return (v != v) ? v : fabs(v);                            // :934-949
+    case WTAMD_MAP_GT: keep = !(v <= param || v != v); return 1.0;                // :386-419, value stays 1
+    case WTAMD_MAP_GTE: keep = !(v < param || v != v); return 1.0;
+    case WTAMD_MAP_LT: keep = !(-1 * v <= -param || v != v); return 1.0;          // commandParser.c:185-189
+    case WTAMD_MAP_LTE: keep = !(-1 * v < -param || v != v); return 1.0;
     default: return v;
     }
 }
@@ -92,12 +96,16 @@ __global__ void wm_scan_blocks(unsigned long long *block_keep, long long n_block
 }
 
 template <class ValT>
-__device__ inline bool wm_kept(const ValT *in, long long g) { return !((double) in[g] <= 0); }
+__device__ inline bool wm_kept(const ValT *in, long long g, int op, double param) {
+    bool keep;
+    (void) wm_apply(op, param, 1.0, (double) in[g], keep);      // the flag does not depend on the log base
+    return keep;
+}
 
 // stable scatter of the kept runs of one tile (order inside the tile: by global index)
 template <class ValT>
-__global__ void __launch_bounds__(WM_BLOCK) wm_compact_kernel(const ValT *in, const int32_t *start, const int32_t *finish,
-                                                               const double *mapped, long long n,
+__global__ void __launch_bounds__(WM_BLOCK) wm_compact_kernel(int op, double param, const ValT *in, const int32_t *start,
+                                                               const int32_t *finish, const double *mapped, long long n,
                                                                const unsigned long long *block_off, int32_t *o_start,
                                                                int32_t *o_finish, double *o_value) {
     __shared__ unsigned int wave_tot[WM_BLOCK / 64];
@@ -109,7 +117,7 @@ __global__ void __launch_bounds__(WM_BLOCK) wm_compact_kernel(const ValT *in, co
     unsigned mask = 0, mine = 0;
 #pragma unroll
     for (int q = 0; q < WM_ITEMS; q++)
-        if (g0 + q < n && wm_kept(in, g0 + q)) { mask |= 1u << q; mine++; }
+        if (g0 + q < n && wm_kept(in, g0 + q, op, param)) { mask |= 1u << q; mine++; }
     unsigned incl = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(WM_BLOCK) wm_compact_kernel(const ValT *in, co
 
 // new segment offsets: number of kept runs before every old segment boundary
 template <class ValT>
-__global__ void wm_seg_offsets(const ValT *in, const int64_t *seg_off, long long n_seg, long long n,
+__global__ void wm_seg_offsets(int op, double param, const ValT *in, const int64_t *seg_off, long long n_seg, long long n,
                                const unsigned long long *block_off, unsigned long long total, int64_t *o_seg_off) {
     const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (s > n_seg) return;
@@ -141,7 +149,7 @@ __global__ void wm_seg_offsets(const ValT *in, const int64_t *seg_off, long long
     if (p >= n) { o_seg_off[s] = (int64_t) total; return; }
     const long long b = p / WM_TILE;
     unsigned long long c = block_off[b];
-    for (long long g = b * WM_TILE; g < p; g++) c += wm_kept(in, g) ? 1ull : 0ull;
+    for (long long g = b * WM_TILE; g < p; g++) c += wm_kept(in, g, op, param) ? 1ull : 0ull;
     o_seg_off[s] = (int64_t) c;
 }
 
@@ -160,6 +168,7 @@ double wtamd_map_default(int map_op, double param, double d) {
     case WTAMD_MAP_EXPB: { float f = nan ? NAN : exp(d * log(param)); return f; }         // :847-852
     case WTAMD_MAP_POW: return (!nan && (d > 0 || param > 0)) ? pow(d, param) : NAN;      // :895-899
     case WTAMD_MAP_ABS: return nan ? NAN : fabs(d);
+    case WTAMD_MAP_GT: case WTAMD_MAP_GTE: case WTAMD_MAP_LT: case WTAMD_MAP_LTE: return 0;   // :419
     default: return d;
     }
 }
@@ -176,7 +185,7 @@ int wtamd_runs_map(int map_op, double param, int64_t n_seg, const int64_t *seg_o
         return wt_fail_ext(WTAMD_ERR_ARG, "wtamd_runs_map: base / radix must be positive");
     hipStream_t s = (hipStream_t) stream;
     const long long n = seg_off[n_seg];
-    const bool drops = map_op == WTAMD_MAP_LN || map_op == WTAMD_MAP_LOG;
+    const bool drops = map_op == WTAMD_MAP_LN || map_op == WTAMD_MAP_LOG || map_op >= WTAMD_MAP_GT;
     const double lg = (map_op == WTAMD_MAP_LOG || map_op == WTAMD_MAP_EXPB) ? log(param) : 1.0;
     if (n == 0) {
         for (int64_t q = 0; q <= n_seg; q++) o_seg_off[q] = 0;
@@ -208,21 +217,21 @@ int wtamd_runs_map(int map_op, double param, int64_t n_seg, const int64_t *seg_o
         for (int64_t q = 0; q <= n_seg; q++) o_seg_off[q] = seg_off[q];
         return WTAMD_OK;
     }
-    if (!o_start || !o_finish) return wt_fail_ext(WTAMD_ERR_ARG, "wtamd_runs_map: ln / log need output coordinate arrays");
+    if (!o_start || !o_finish) return wt_fail_ext(WTAMD_ERR_ARG, "wtamd_runs_map: operators that drop runs need output coordinate arrays");
     hipLaunchKernelGGL(wm_scan_blocks, dim3(1), dim3(64), 0, s, d_blk, n_blocks, d_blk + n_blocks);
     unsigned long long total = 0;
     WM_HIP(hipMemcpyAsync(&total, d_blk + n_blocks, sizeof total, hipMemcpyDeviceToHost, s));
     WM_HIP(hipStreamSynchronize(s));
     const unsigned seg_grid = (unsigned) ((n_seg + 1 + 255) / 256);
     if (value_is_f64) {
-        hipLaunchKernelGGL(wm_compact_kernel<double>, dim3((unsigned) n_blocks), dim3(WM_BLOCK), 0, s, (const double *) value,
-                           start, finish, d_mapped, n, d_blk, o_start, o_finish, o_value);
-        hipLaunchKernelGGL(wm_seg_offsets<double>, dim3(seg_grid), dim3(256), 0, s, (const double *) value, d_seg,
+        hipLaunchKernelGGL(wm_compact_kernel<double>, dim3((unsigned) n_blocks), dim3(WM_BLOCK), 0, s, map_op, param,
+                           (const double *) value, start, finish, d_mapped, n, d_blk, o_start, o_finish, o_value);
+        hipLaunchKernelGGL(wm_seg_offsets<double>, dim3(seg_grid), dim3(256), 0, s, map_op, param, (const double *) value, d_seg,
                            (long long) n_seg, n, d_blk, total, d_oseg);
     } else {
-        hipLaunchKernelGGL(wm_compact_kernel<float>, dim3((unsigned) n_blocks), dim3(WM_BLOCK), 0, s, (const float *) value,
-                           start, finish, d_mapped, n, d_blk, o_start, o_finish, o_value);
-        hipLaunchKernelGGL(wm_seg_offsets<float>, dim3(seg_grid), dim3(256), 0, s, (const float *) value, d_seg,
+        hipLaunchKernelGGL(wm_compact_kernel<float>, dim3((unsigned) n_blocks), dim3(WM_BLOCK), 0, s, map_op, param,
+                           (const float *) value, start, finish, d_mapped, n, d_blk, o_start, o_finish, o_value);
+        hipLaunchKernelGGL(wm_seg_offsets<float>, dim3(seg_grid), dim3(256), 0, s, map_op, param, (const float *) value, d_seg,
                            (long long) n_seg, n, d_blk, total, d_oseg);
     }
     WM_HIP(hipGetLastError());

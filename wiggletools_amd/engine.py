@@ -29,7 +29,8 @@ def reducer_default(op, defaults):
     return _lib.lib().wtamd_reducer_default(opcode(op), len(d), d.ctypes.data)
 
 
-MAP_OPS = {"scale": 0, "offset": 1, "ln": 2, "log": 3, "exp": 4, "expb": 5, "pow": 6, "abs": 7}
+MAP_OPS = {"scale": 0, "offset": 1, "ln": 2, "log": 3, "exp": 4, "expb": 5, "pow": 6, "abs": 7,
+           "gt": 8, "gte": 9, "lt": 10, "lte": 11}
 
 
 def map_default(op, param, default_value):
