@@ -959,10 +959,24 @@ WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K
         // WT_MEDIAN_BITS key bits are decided per sweep over the column (2^B - 1 trial keys counted
         // at once): fewer sweeps, each LDS read serves several comparisons (the loop is bound by
         // LDS latency at the few waves per CU the columns leave room for).
-        KeyT Kk = 0;
         constexpr int B = WT_MEDIAN_BITS, NT = (1 << B) - 1, KB = (int) sizeof(KeyT) * 8;
         static_assert(KB % B == 0, "WT_MEDIAN_BITS must divide the key width");
+        // One sweep first: bits on which ALL keys agree are already decided (they are the median's
+        // bits too), and B-bit groups without a disputed bit need no counting sweep.  Signal
+        // tracks are mostly counts or coarsely rounded values, whose low mantissa bits are all
+        // zero: typically half of the sweeps go away.
+        KeyT all_and = ~(KeyT) 0, all_or = 0;
+#pragma unroll 8
+        for (int i = 0; i < N; i++) {
+            const KeyT key = col[(size_t) i * colstride];
+            all_and &= key;
+            all_or |= key;
+        }
+        const KeyT disputed = all_and ^ all_or;
+        KeyT Kk = 0;
         for (int b = KB - B; b >= 0; b -= B) {
+            const KeyT group = (KeyT) NT << b;
+            if (!(disputed & group)) { Kk |= all_and & group; continue; }
             KeyT trial[NT];
             int below[NT];
 #pragma unroll
