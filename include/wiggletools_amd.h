@@ -235,6 +235,11 @@ int wtamd_set_device(int ordinal);
 const char *wtamd_last_error(void);
 const char *wtamd_version(void);
 
+/* Largest run finish a track set may hold (the 32-bit window arithmetic keeps a margin below
+ * INT32_MAX; creation fails with WTAMD_ERR_ARG above it).  The reference's coordinates are C `int`
+ * as well (wiggleIterator.h:23-24). */
+#define WTAMD_MAX_COORD (2147483647 - 65536)
+
 /* Copies the SoA arrays from HOST memory into HBM. */
 int wtamd_trackset_create_host(const wtamd_tracks *tracks, wtamd_trackset **out);
 /* Zero-copy: start/finish/value are DEVICE pointers owned by the caller and

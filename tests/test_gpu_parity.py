@@ -438,3 +438,27 @@ def test_gpu_map_ops(oracle, engine, op, param):
         res = ts.reduce_host("sum")
         ts.close()
         assert_runs_equal(res, oracle.reduce(ref_t.as_dict(), "sum"), 1e-12, "sum map %s seed %d" % (op, seed))
+
+
+def test_gpu_empty_and_minimal_inputs(oracle, engine, monkeypatch):
+    """No runs at all, one 1-bp run, one run at the top of the coordinate range, through both kernels."""
+    from wiggletools_amd.runlists import RunLists
+    monkeypatch.setenv("WTAMD_DELTA_MIN_TRACKS", "1")
+    cases = [
+        RunLists.from_lists([[[], []], [[], []]]),
+        RunLists.from_lists([[[(5, 6, 1.5)], []]]),
+        RunLists.from_lists([[[(2 ** 31 - 70000, 2 ** 31 - 65600, 2.0)], [(2 ** 31 - 69000, 2 ** 31 - 65537, -1.0)]]]),
+    ]
+    for t in cases:
+        t = RunLists(t.n_chrom, t.n_tracks, t.seg_off, t.start, t.finish, t.value.astype(np.float32), t.defaults)
+        ts = engine.TrackSet.from_runlists(t)
+        for op in ("sum", "mean", "max", "median"):
+            for strict in (0, 1):
+                exp = oracle.reduce(t.as_dict(), op, flags=strict)
+                got = ts.reduce_host(op, flags=strict)
+                assert_runs_equal(got, exp, 0.0, "%s strict %d n=%d" % (op, strict, len(t.start)))
+        ts.close()
+    # above the supported coordinate range: refused at creation, not silently mishandled
+    t = RunLists.from_lists([[[(2 ** 31 - 10, 2 ** 31 - 2, 2.0)]]])
+    with pytest.raises(Exception, match="above the supported maximum"):
+        engine.TrackSet.from_runlists(t)

@@ -717,6 +717,19 @@ static int wt_trackset_common(const wtamd_tracks *t, wtamd_trackset *ts) {
     return WTAMD_OK;
 }
 
+// The window arithmetic (w0 + W, look-ahead sentinels) is 32-bit: keep a margin below INT32_MAX.
+// Loud, at creation -- a run that close to 2^31 would otherwise be silently lost.
+static int wt_check_extents(wtamd_trackset *ts) {
+    for (size_t q = 0; q < ts->last_finish.size(); q++)
+        if (ts->seg_off[q + 1] > ts->seg_off[q] && ts->last_finish[q] > WTAMD_MAX_COORD) {
+            const int64_t bad = ts->last_finish[q];
+            wtamd_trackset_destroy(ts);
+            return wt_fail(WTAMD_ERR_ARG, "run finish " + std::to_string(bad) + " above the supported maximum " +
+                           std::to_string((long long) WTAMD_MAX_COORD) + " (2^31 - 65537)");
+        }
+    return WTAMD_OK;
+}
+
 int wtamd_trackset_create_host(const wtamd_tracks *t, wtamd_trackset **out) {
     if (!out) return wt_fail(WTAMD_ERR_ARG, "out == NULL");
     wtamd_trackset *ts = new wtamd_trackset();
@@ -743,6 +756,8 @@ int wtamd_trackset_create_host(const wtamd_tracks *t, wtamd_trackset **out) {
             ts->first_start[s] = t->start[ts->seg_off[s]];
             ts->last_finish[s] = t->finish[ts->seg_off[s + 1] - 1];
         }
+    rc = wt_check_extents(ts);
+    if (rc != WTAMD_OK) return rc;
     *out = ts;
     return WTAMD_OK;
 }
@@ -770,6 +785,8 @@ int wtamd_trackset_create_device(const wtamd_tracks *t, wtamd_trackset **out) {
         WT_HIP(hipMemcpy(ts->last_finish.data(), d_lf, sizeof(int32_t) * n_seg, hipMemcpyDeviceToHost));
         (void) hipFree(d_fs); (void) hipFree(d_lf);
     }
+    rc = wt_check_extents(ts);
+    if (rc != WTAMD_OK) return rc;
     *out = ts;
     return WTAMD_OK;
 }
