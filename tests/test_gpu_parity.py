@@ -462,3 +462,29 @@ def test_gpu_empty_and_minimal_inputs(oracle, engine, monkeypatch):
     t = RunLists.from_lists([[[(2 ** 31 - 10, 2 ** 31 - 2, 2.0)]]])
     with pytest.raises(Exception, match="above the supported maximum"):
         engine.TrackSet.from_runlists(t)
+
+
+def test_gpu_region_like_tracks_spanning_many_windows(oracle, engine, monkeypatch):
+    """BED-region-like tracks (runs of tens of kbp, each spanning many alignment windows, and one
+    run covering the whole chromosome) multiplexed with dense signal tracks, both kernels."""
+    from helpers import merge_tracks
+    from wiggletools_amd.runlists import RunLists, synth
+    monkeypatch.setenv("WTAMD_DELTA_MIN_TRACKS", "1")
+    clens = [400000, 90000]
+    dense = synth(5, clens, mean_run=8, gap_prob=0.1, seed=5)
+    wide = synth(3, clens, mean_run=40000, gap_prob=0.3, seed=6)
+    whole = RunLists.from_lists([[[(1, clens[0] + 1, 3.0)], [(1, clens[1] + 1, 0.5)]]])
+    whole = RunLists(whole.n_chrom, 1, whole.seg_off, whole.start, whole.finish, whole.value.astype(np.float32), whole.defaults)
+    t = merge_tracks([wide, dense, whole])
+    d = t.as_dict()
+    ts = engine.TrackSet.from_runlists(t)
+    assert ts.validate() == (0, -1)
+    for op, kw in (("sum", {}), ("mean", dict(flags=1)), ("max", {}), ("var", {}), ("median", {}), ("mwu", dict(n_set0=4))):
+        exp = oracle.reduce(d, op, **kw)
+        got = ts.reduce_host(op, **kw)
+        assert_runs_equal(got, exp, _tol(op), "regions op %s" % op)
+    exp = oracle.multiplex(d)
+    got = ts.multiplex_host()
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b, equal_nan=True)
+    ts.close()
