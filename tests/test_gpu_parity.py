@@ -488,3 +488,28 @@ def test_gpu_region_like_tracks_spanning_many_windows(oracle, engine, monkeypatc
     for a, b in zip(got, exp):
         assert np.array_equal(a, b, equal_nan=True)
     ts.close()
+
+
+def test_gpu_many_small_chromosomes(oracle, engine, monkeypatch):
+    """A scaffold-level assembly: hundreds of short chromosomes, several of them empty in some or all
+    tracks (one window each, window tables and the index walk across empty segments)."""
+    from wiggletools_amd.runlists import RunLists, synth
+    monkeypatch.setenv("WTAMD_DELTA_MIN_TRACKS", "1")
+    rng = np.random.default_rng(12)
+    clens = [int(x) for x in rng.integers(1, 3000, 400)]
+    t = synth(6, clens, mean_run=40, gap_prob=0.5, seed=13)
+    # empty every 7th chromosome entirely and every 5th in track 2
+    keep = np.ones(len(t.start), bool)
+    for c in range(t.n_chrom):
+        for i in range(t.n_tracks):
+            if c % 7 == 3 or (c % 5 == 1 and i == 2):
+                keep[t.seg_off[c * t.n_tracks + i]:t.seg_off[c * t.n_tracks + i + 1]] = False
+    seg = np.concatenate([[0], np.cumsum([int(keep[t.seg_off[q]:t.seg_off[q + 1]].sum()) for q in range(t.n_chrom * t.n_tracks)])])
+    t = RunLists(t.n_chrom, t.n_tracks, seg, t.start[keep], t.finish[keep], t.value[keep], t.defaults)
+    d = t.as_dict()
+    ts = engine.TrackSet.from_runlists(t)
+    for op, kw in (("sum", {}), ("mean", dict(flags=1)), ("min", {}), ("stddev", {}), ("median", {}), ("ttest", dict(n_set0=3))):
+        exp = oracle.reduce(d, op, **kw)
+        got = ts.reduce_host(op, **kw)
+        assert_runs_equal(got, exp, _tol(op), "scaffolds op %s" % op)
+    ts.close()
