@@ -258,9 +258,16 @@ WT_DEV double wt_betacf(double a, double b, double x) {
 WT_DEV double wt_inc_beta(double a, double b, double x) {
     if (x <= 0) return 0;
     if (x >= 1) return 1;
-    double lnfront = lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log1p(-x);
-    if (x < (a + 1) / (a + b + 2)) return exp(lnfront) * wt_betacf(a, b, x) / a;
-    return 1 - exp(lnfront) * wt_betacf(b, a, 1 - x) / b;
+    // the t-test always comes with b = 1/2 (or a = 1/2 after the symmetry swap): lgamma(1/2) = ln sqrt(pi)
+    const double lg_half = 0.57236494292470008707;
+    const double lga = (a == 0.5) ? lg_half : lgamma(a), lgb = (b == 0.5) ? lg_half : lgamma(b);
+    double lnfront = lgamma(a + b) - lga - lgb + a * log(x) + b * log1p(-x);
+    // one continued-fraction evaluation with the arguments chosen per lane (a divergent if / else
+    // made every wave run both); same arithmetic per lane as the two-branch form
+    const bool flip = !(x < (a + 1) / (a + b + 2));
+    const double a2 = flip ? b : a, b2 = flip ? a : b, x2 = flip ? 1 - x : x;
+    const double r = exp(lnfront) * wt_betacf(a2, b2, x2) / a2;
+    return flip ? 1 - r : r;
 }
 
 WT_DEV double wt_tdist_Q(double t, double nu) {
@@ -898,7 +905,7 @@ WT_DEV void wt_eval_mid(const WtParams &P, WtAcc<K> &A) {
 
 template <int OP, class ValT, class ScrT, int K>
 WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K], char *scratch, char *attr_base,
-                           int lane_col, int colstride) {
+                           int lane_col, int colstride, unsigned emit_bits) {
     const int N = P.n_tracks;
     if (OP == WT_OP_SUM || OP == WT_OP_PRODUCT || OP == WT_OP_MEAN) {
 #pragma unroll
@@ -944,9 +951,10 @@ WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K
             nn[k] = den * den / ((var1 * var1) / c1 + (var2 * var2) / c2);
             tt[k] = (var1 + var2 == 0) ? wt_nan() : t;          // setComparisons.c:98 -> NaN
         }
+        // (positions that start no emitted run are skipped: the tail is the expensive part)
 #pragma unroll 1
         for (int k = 0; k < K; k++)
-            res[k] = wt_isnan(tt[k]) ? wt_nan() : 2 * wt_tdist_Q(tt[k], nn[k]);
+            res[k] = (wt_isnan(tt[k]) || !((emit_bits >> k) & 1u)) ? wt_nan() : 2 * wt_tdist_Q(tt[k], nn[k]);
         return;
     }
     if (OP == WT_OP_MEDIAN) {
@@ -1168,8 +1176,9 @@ WT_DEV void wt_phase_eval_chunk(const WtParams &P, WtCtx &c, WtAcc<K> &A, int pa
 
 template <int OP, class ValT, class ScrT, int K>
 WT_DEV void wt_phase_eval_finish(const WtParams &P, WtCtx &c, const WtAcc<K> &A, WtLane<K> &L, int tid, int nt) {
-    if (!wt_lane_emit_bits<K>(P, c, tid)) return;
-    wt_eval_finish<OP, ValT, ScrT, K>(P, A, L.res, c.scratch, c.attr, tid, nt);
+    const unsigned emit_bits = wt_lane_emit_bits<K>(P, c, tid);
+    if (!emit_bits) return;
+    wt_eval_finish<OP, ValT, ScrT, K>(P, A, L.res, c.scratch, c.attr, tid, nt, emit_bits);
 }
 
 // ---------------------------------------------------------------------------
