@@ -1,7 +1,7 @@
 // wt_core.h -- the "bitmap multiplexer": window-local breakpoint alignment +
 // per-run reducers.  This header is the single source of the kernel logic.  It
 // is compiled
-//   * by hipcc for gfx950 inside wt_kernels.hip (the product), and
+//   * by hipcc for gfx950 inside wt_engine.hip (the product), and
 //   * by g++ with -DWT_EMU inside tests/emu/wt_emu.cpp, a phase-by-phase CPU
 //     emulator of ONE workgroup used only by the `-m "not gpu"` tests to check
 //     the algorithm against the oracle in a container that has no GPU.
@@ -13,11 +13,13 @@
 //           in [w0, w1).  U = union bitmap of all true breakpoints, S_i = bitmap
 //           of (clipped) interval starts of track i.  For a breakpoint p the
 //           interval of track i covering p is found in O(1):
-//               rank = cnt_i[p/64] + popc(S_i[p/64] & mask(p));  idx = base_i + rank - 1
-//           and `covered` = p < finish[idx].
+//               rank = cnt_i[p/32] + popc(S_i[p/32] & mask(p));  idx = gbase_i + rank
+//           and `covered` = bit p of the coverage bitmap C_i (prefix-XOR of the start / finish
+//           toggles): the run's finish is never read during evaluation.
 //   reducers.c / setComparisons.c ...ReductionPop
-//        -> eval_position<OP>(): one lane per run, tracks visited in index order
-//           i = 0..N-1 in f64, i.e. the reference's own summation order.
+//        -> wt_eval_chunk / wt_eval_finish<OP>: one lane per 4 (or 1) positions, tracks visited in
+//           index order i = 0..N-1 in f64, i.e. the reference's own summation order.
+//           (Sum / Mean over float tracks: wt_delta.h, an exact O(input runs) formulation.)
 //   output ordering (strcmp(chrom), start)
 //        -> windows are handed out by an atomic ticket in genome order and the
 //           global run offset comes from a decoupled look-back over 64-bit

@@ -22,12 +22,14 @@
 //
 // Per window (W = 8 * workgroup size positions):
 //   ranges   per chunk of T tracks: interval range of every track, scanned into one flat space
-//   pass 1   exponent range of the window's values                        (4 B / interval)
-//   pass 2   acc[p] += +-scaled mantissa, ev[p] += start | finish<<16    (12 B / interval)
-//            intervals spanning w0 go to the window base instead (not a breakpoint)
+//   pass 1   exponent range of the window's values (4 B / run) -- only for a workgroup's FIRST
+//            window: afterwards the unit exponent is guessed and checked on the side
+//            (wt_delta_window_verdict), so value[] is read once
+//   pass 2   acc[p] += +-scaled mantissa, ev[p] += start | finish<<16    (12 B / run)
+//            runs spanning w0 go to the window base instead (not a breakpoint)
 //   scan     one lane per 8 positions: running sum, running coverage, breakpoint byte,
 //            emitted byte (breakpoint & coverage predicate & range), value of the run
-//   then the general kernel's tail: run-count scan, look-back, write.
+//   then run-count scan, look-back, staging of the runs in LDS at their rank, coalesced copy-out.
 #ifndef WT_DELTA_H_
 #define WT_DELTA_H_
 

@@ -2,12 +2,18 @@
 // include/wiggletools_amd.h.  Compiled only by hipcc --offload-arch=gfx950.
 //
 // Kernels
-//   wt_index_kernel     one lane per input interval: window index (widx)
+//   wt_index_kernel     window index (widx): contiguous span of input runs per block, 4 per lane
 //   wt_reduce_kernel    persistent workgroups, one alignment window per ticket:
 //                       bitmap multiplexer + per-run reducer + ordered output
-//                       (logic in wt_core.h)
+//                       (logic in wt_core.h) -- every reducer, any track count
+//   wt_delta_kernel     Sum / Mean over float tracks: exact difference array, O(input runs)
+//                       (logic in wt_delta.h)
+//   wt_patch_kernel     the bitmap multiplexer over just the windows wt_delta_kernel could not
+//                       prove exact
 //   wt_extents_kernel   first start / last finish per (chrom, track) segment
-//   wt_auc_kernel       sum (finish-start)*value over a run list (AUC)
+//   wt_validate_kernel  input contract (sorted, non-overlapping, positive length)
+//   wt_auc_kernel       sum (finish-start)*value (+ span) over a run list (AUC, meanI)
+//   wt_pearson_kernel   Pearson of two tracks over their Multiplexer tile
 #include <hip/hip_runtime.h>
 
 #include <chrono>
