@@ -525,6 +525,9 @@ WT_DEV void wt_phase_count_b(const WtParams &P, WtCtx &c, int t_lo, int t_hi, in
 #ifndef WT_MEDIAN_BITS
 #define WT_MEDIAN_BITS 2  // key bits decided per sweep of the median's bitwise selection
 #endif
+#ifndef WT_MWU_RB
+#define WT_MWU_RB 8      // column values read ahead per batch in the MWU ranking sweeps
+#endif
 #ifndef WT_MWU_EB
 #define WT_MWU_EB 4      // set-0 elements ranked per sweep over a lane's value column
 #endif
@@ -976,12 +979,19 @@ WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K
         // tracks are mostly counts or coarsely rounded values, whose low mantissa bits are all
         // zero: typically half of the sweeps go away.
         KeyT all_and = ~(KeyT) 0, all_or = 0;
-#pragma unroll 8
-        for (int i = 0; i < N; i++) {
-            const KeyT key = col[(size_t) i * colstride];
-            all_and &= key;
-            all_or |= key;
-        }
+        // (column sweeps read WT_MWU_RB keys ahead, then consume them: LDS latency overlapped)
+        auto sweep = [&](auto body) {
+            int i = 0;
+            for (; i + WT_MWU_RB <= N; i += WT_MWU_RB) {
+                KeyT k[WT_MWU_RB];
+#pragma unroll
+                for (int u = 0; u < WT_MWU_RB; u++) k[u] = col[(size_t) (i + u) * colstride];
+#pragma unroll
+                for (int u = 0; u < WT_MWU_RB; u++) body(k[u]);
+            }
+            for (; i < N; i++) body(col[(size_t) i * colstride]);
+        };
+        sweep([&](KeyT key) { all_and &= key; all_or |= key; });
         const KeyT disputed = all_and ^ all_or;
         KeyT Kk = 0;
         for (int b = KB - B; b >= 0; b -= B) {
@@ -991,12 +1001,10 @@ WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K
             int below[NT];
 #pragma unroll
             for (int q = 0; q < NT; q++) { trial[q] = Kk | ((KeyT) (q + 1) << b); below[q] = 0; }
-#pragma unroll 8
-            for (int i = 0; i < N; i++) {
-                const KeyT key = col[(size_t) i * colstride];
+            sweep([&](KeyT key) {
 #pragma unroll
                 for (int q = 0; q < NT; q++) below[q] += (key < trial[q]);
-            }
+            });
 #pragma unroll
             for (int q = 0; q < NT; q++)
                 if (below[q] <= kth) Kk = trial[q];      // below[] is non-decreasing in q: the last hit wins
@@ -1034,20 +1042,30 @@ WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K
                 x[q] = val[(size_t) (e0 + q < na ? e0 + q : na - 1) * colstride];
                 L[q] = 0; t[q] = 0; r[q] = 0; later[q] = 0;
             }
-#pragma unroll 4
-            for (int j = na; j < N; j++) {
-                const ScrT y = val[(size_t) j * colstride];
+            // Sweeps over [lo, hi) of the column in batches of WT_MWU_RB values that are read first and
+            // consumed afterwards: the LDS reads of a batch are in flight together (with one wave
+            // per SIMD their latency was fully exposed -- ~60 cycles per value).
+            auto sweep = [&](int lo, int hi, auto body) {
+                int j = lo;
+                for (; j + WT_MWU_RB <= hi; j += WT_MWU_RB) {
+                    ScrT y[WT_MWU_RB];
+#pragma unroll
+                    for (int u = 0; u < WT_MWU_RB; u++) y[u] = val[(size_t) (j + u) * colstride];
+#pragma unroll
+                    for (int u = 0; u < WT_MWU_RB; u++) body(y[u], j + u);
+                }
+                for (; j < hi; j++) body(val[(size_t) j * colstride], j);
+            };
+            sweep(na, N, [&](ScrT y, int) {
 #pragma unroll
                 for (int q = 0; q < EB; q++) { L[q] += (y < x[q]); t[q] += (y == x[q]); }
-            }
+            });
             // set-0 entries before the block only need (y <= x), the ones after it (y < x) and
             // (y == x); the index comparisons matter inside the block alone
-#pragma unroll 4
-            for (int j = 0; j < e0; j++) {
-                const ScrT y = val[(size_t) j * colstride];
+            sweep(0, e0, [&](ScrT y, int) {
 #pragma unroll
                 for (int q = 0; q < EB; q++) r[q] += (y <= x[q]);
-            }
+            });
             const int e1 = e0 + EB < na ? e0 + EB : na;
             for (int j = e0; j < e1; j++) {
                 const ScrT y = val[(size_t) j * colstride];
@@ -1057,12 +1075,10 @@ WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K
                     later[q] += (y == x[q]) & (j > e0 + q);
                 }
             }
-#pragma unroll 4
-            for (int j = e1; j < na; j++) {
-                const ScrT y = val[(size_t) j * colstride];
+            sweep(e1, na, [&](ScrT y, int) {
 #pragma unroll
                 for (int q = 0; q < EB; q++) { r[q] += (y < x[q]); later[q] += (y == x[q]); }
-            }
+            });
 #pragma unroll
             for (int q = 0; q < EB; q++)
                 if (e0 + q < na)
