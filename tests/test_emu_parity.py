@@ -337,3 +337,81 @@ def test_emu_delta_patch_with_run_start_ranges(oracle):
                 cat[k].append(g[k][m])
     cat = tuple(np.concatenate(x) for x in cat)
     assert_runs_equal(cat, full, 0.0, "ranges + patches")
+
+
+# ---- assorted edge cases (both kernels where they apply) ----
+def _f32(t):
+    from wiggletools_amd.runlists import RunLists
+    return RunLists(t.n_chrom, t.n_tracks, t.seg_off, t.start, t.finish, t.value.astype(np.float32), t.defaults)
+
+
+def test_emu_edge_all_nan_track_and_all_nan_data(oracle):
+    t = _delta_case(71, 4, [3000], 6, lambda r, k: r.random(k) + 1)
+    t.value[t.seg_off[1]:t.seg_off[2]] = np.nan          # one track entirely NaN
+    for op in ("sum", "mean", "max", "median"):
+        got, info = emu.reduce(t, op, delta_T=64, ppt=4, T=64)
+        assert_runs_equal(got, oracle.reduce(t.as_dict(), op), 0.0, "%s %s" % (op, info))
+    t.value[:] = np.nan
+    got, info = emu.reduce(t, "sum", delta_T=64, ppt=4, T=64)
+    assert info["delta"] == 0 and info["delta_bad"] > 0
+    assert_runs_equal(got, oracle.reduce(t.as_dict(), "sum"), 0.0, "all NaN")
+
+
+def test_emu_edge_strict_with_an_absent_track(oracle):
+    """strict: a track without runs on a chromosome means no run is ever emitted there."""
+    from wiggletools_amd.runlists import RunLists
+    t = _f32(RunLists.from_lists([[[(1, 50, 1.0), (60, 90, 2.0)], [(5, 20, 1.0)]],
+                                  [[(10, 70, 3.0)], []],
+                                  [[(1, 100, 0.5)], [(1, 30, 4.0)]]]))
+    for op in ("sum", "mean", "min"):
+        for strict in (0, 1):
+            got, info = emu.reduce(t, op, flags=strict, delta_T=64)
+            exp = oracle.reduce(t.as_dict(), op, flags=strict)
+            assert_runs_equal(got, exp, 0.0, "%s strict %d" % (op, strict))
+            if strict:
+                assert not (exp[0] == 1).any()
+
+
+def test_emu_edge_ranges_that_exclude_everything(oracle):
+    t = _delta_case(72, 3, [2000, 500], 6, lambda r, k: r.integers(1, 9, k) / 2.0)
+    for op in ("sum", "max"):
+        got, info = emu.reduce(t, op, delta_T=64, ranges=[(5000, 6000), (-10, 0)])
+        assert len(got[0]) == 0
+        got, info = emu.reduce(t, op, delta_T=64, ranges=[(5000, 6000), (1, 100)])      # only chromosome 1, partly
+        exp = oracle.reduce(t.as_dict(), op)
+        m = (exp[0] == 1) & (exp[1] < 100)
+        assert_runs_equal(got, tuple(x[m] for x in exp), 0.0, op)
+
+
+def test_emu_edge_two_sample_extremes(oracle):
+    t = random_case(9100, n_tracks=9, dtype=np.float32)
+    d = t.as_dict()
+    for n1 in (1, 8):
+        for flags in (0, 3):
+            got, info = emu.reduce(t, "mwu", flags=flags, n_set0=n1)
+            assert_runs_equal(got, oracle.reduce(d, "mwu", flags=flags, n_set0=n1), 0.0, "mwu n1 %d" % n1)
+    for n1 in (3, 6):
+        got, info = emu.reduce(t, "ttest", n_set0=n1)
+        assert_runs_equal(got, oracle.reduce(d, "ttest", n_set0=n1), 1e-12, "ttest n1 %d" % n1)
+
+
+def test_emu_edge_very_many_tracks_small_workgroup(oracle):
+    """2000 tracks: 32 chunks of 64 tracks in the difference-array kernel, chunked bitmaps in the general one."""
+    t = _delta_case(73, 2000, [700], 30, lambda r, k: r.integers(0, 16, k) / 2.0, gap=0.3)
+    d = t.as_dict()
+    got, info = emu.reduce(t, "sum", delta_T=64)
+    assert info["delta"] == 1
+    assert_runs_equal(got, oracle.reduce(d, "sum"), 0.0, "delta 2000 tracks")
+    got, info = emu.reduce(t, "max", ppt=4, T=64)
+    assert info["n_chunks"] > 1
+    assert_runs_equal(got, oracle.reduce(d, "max"), 0.0, "general 2000 tracks")
+
+
+def test_emu_edge_data_only_in_late_tracks_and_late_chromosomes(oracle):
+    from wiggletools_amd.runlists import RunLists
+    t = _f32(RunLists.from_lists([[[], [], []],
+                                  [[], [], [(7, 9, 1.0)]],
+                                  [[], [(1000, 1001, 2.0), (1001, 5000, 3.0)], [(8, 12, 4.0)]]]))
+    for op in ("sum", "mean", "max", "median", "product"):
+        got, info = emu.reduce(t, op, delta_T=64, ppt=4, T=64)
+        assert_runs_equal(got, oracle.reduce(t.as_dict(), op), 0.0, op)
