@@ -92,6 +92,10 @@ struct EmuRun {
                 if (pass == 0 && npass == 2) for (int t = 0; t < T; t++) wt_eval_mid<OP, K>(P, acc[t]);
             }
             for (int t = 0; t < T; t++) wt_phase_eval_finish<OP, ValT, ScrT, K>(P, c, acc[t], lanes[t], t, T);
+            if (OP == WT_OP_MWU) {
+                for (int t = 0; t < T; t++) wt_phase_mwu_rank<ScrT>(P, c, t, T);
+                for (int t = 0; t < T; t++) wt_phase_mwu_tail<K>(P, c, acc[t], lanes[t], t, T);
+            }
             for (int t = 0; t < T; t++) wt_phase_write<OP, ValT, K>(P, c, lanes[t], t, T);
             if (!patch) wt_window_stats(P, c);
         }

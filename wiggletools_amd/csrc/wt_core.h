@@ -908,6 +908,110 @@ WT_DEV void wt_eval_mid(const WtParams &P, WtAcc<K> &A) {
     for (int k = 0; k < K; k++) A.a[k] /= P.n_tracks;
 }
 
+// ---------------------------------------------------------------------------
+// Mann-Whitney U (setComparisons.c:293-366) without sorting, in two steps so that SEVERAL lanes can
+// share one run: the N^2 ranking is split over `nparts` lanes (they all read the run's value
+// column; the set-0 blocks are dealt round robin), the short sequential tie scan is done by one.
+// The value columns cap the lanes a CU can hold (N * 4 B per run), and with one wave per SIMD the
+// ranking was issue-bound: two lanes per run double the waves for the same LDS.
+// The reference sorts the n1+n2 (value,set)
+// pairs stably (set-0 entries first inside a tie group) and scans them; every quantity the
+// scan uses for a set-0 element e is a COUNT:
+//   index - prev            = L_e  = #set-1 values <  x_e
+//   set-1 entries tied to e = t_e  = #set-1 values == x_e, all of them after e in the table
+//   "contiguous set-1 successors" (:338-341) = t_e if e is the last set-0 entry of its tie
+//                             group, else 0 (the next entry is another set-0 one)
+// and the scan visits the set-0 elements in (value, index) order, i.e. at rank
+//   r_e = #set-0 values < x_e + #set-0 values == x_e with a smaller index.
+// All counts come from two branch-free n1*n2 / n1*n1 loops over this lane's LDS column
+// (independent reads: no data-dependent trip counts, no divergence); (L,t,last) are
+// scattered to rank r_e and the reference's tie state machine then runs over n1 entries,
+// performing the same double additions in the same order.
+// ---------------------------------------------------------------------------
+template <class ScrT>
+WT_DEV void wt_mwu_rank(const WtParams &P, char *scratch, char *attr_base, int col, int colstride, int part, int nparts) {
+    const int N = P.n_tracks;
+    const int na = P.n_set0;
+    const ScrT *val = (const ScrT *) scratch + col;                            // [N][colstride]
+    uint32_t *attr = (uint32_t *) attr_base + col;                             // [na][colstride]
+    // WT_MWU_EB set-0 elements per sweep over the column: every LDS read serves EB comparisons
+    constexpr int EB = WT_MWU_EB;
+    for (int e0 = part * EB; e0 < na; e0 += EB * nparts) {
+        ScrT x[EB];
+        int L[EB], t[EB], r[EB], later[EB];
+#pragma unroll
+        for (int q = 0; q < EB; q++) {
+            x[q] = val[(size_t) (e0 + q < na ? e0 + q : na - 1) * colstride];
+            L[q] = 0; t[q] = 0; r[q] = 0; later[q] = 0;
+        }
+        // Sweeps over [lo, hi) of the column in batches of WT_MWU_RB values that are read first and
+        // consumed afterwards: the LDS reads of a batch are in flight together (with one wave
+        // per SIMD their latency was fully exposed -- ~60 cycles per value).
+        auto sweep = [&](int lo, int hi, auto body) {
+            int j = lo;
+            for (; j + WT_MWU_RB <= hi; j += WT_MWU_RB) {
+                ScrT y[WT_MWU_RB];
+#pragma unroll
+                for (int u = 0; u < WT_MWU_RB; u++) y[u] = val[(size_t) (j + u) * colstride];
+#pragma unroll
+                for (int u = 0; u < WT_MWU_RB; u++) body(y[u], j + u);
+            }
+            for (; j < hi; j++) body(val[(size_t) j * colstride], j);
+        };
+        sweep(na, N, [&](ScrT y, int) {
+#pragma unroll
+            for (int q = 0; q < EB; q++) { L[q] += (y < x[q]); t[q] += (y == x[q]); }
+        });
+        // set-0 entries before the block only need (y <= x), the ones after it (y < x) and
+        // (y == x); the index comparisons matter inside the block alone
+        sweep(0, e0, [&](ScrT y, int) {
+#pragma unroll
+            for (int q = 0; q < EB; q++) r[q] += (y <= x[q]);
+        });
+        const int e1 = e0 + EB < na ? e0 + EB : na;
+        for (int j = e0; j < e1; j++) {
+            const ScrT y = val[(size_t) j * colstride];
+#pragma unroll
+            for (int q = 0; q < EB; q++) {
+                r[q] += (y < x[q]) | ((y == x[q]) & (j < e0 + q));
+                later[q] += (y == x[q]) & (j > e0 + q);
+            }
+        }
+        sweep(e1, na, [&](ScrT y, int) {
+#pragma unroll
+            for (int q = 0; q < EB; q++) { r[q] += (y < x[q]); later[q] += (y == x[q]); }
+        });
+#pragma unroll
+        for (int q = 0; q < EB; q++)
+            if (e0 + q < na)
+                attr[(size_t) r[q] * colstride] = ((uint32_t) L[q] << 17) | ((uint32_t) t[q] << 1) | (later[q] == 0 ? 1u : 0u);
+    }
+}
+
+WT_DEV double wt_mwu_tail(const WtParams &P, char *attr_base, int col, int colstride) {
+    const int na = P.n_set0, nb = P.n_tracks - P.n_set0;
+    const uint32_t *attr = (const uint32_t *) attr_base + col;
+    const double mu = (double) (na * nb / 2);                               // :386 int division
+    const double sigma = sqrt((double) (na * nb * (na + nb + 1) / 12));     // :387 int division
+    double U1 = 0;
+    int ties = 0, prevTies = 0;
+    for (int q = 0; q < na; q++) {
+        const uint32_t a = attr[(size_t) q * colstride];
+        const int L = (int) (a >> 17), t = (int) ((a >> 1) & 0xffffu);
+        U1 += L;                                      // :336  U1 += index - prev
+        if (ties) {                                   // :337-346
+            if (a & 1u) prevTies += t;
+            U1 -= prevTies / 2.0;
+            U1 += (ties - prevTies) / 2.0;
+            if (prevTies == ties) prevTies = ties = 0;
+        } else {                                      // :347-354
+            ties += t;
+            if (ties) U1 += ties / 2.0;
+        }
+    }
+    return (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
+}
+
 template <int OP, class ValT, class ScrT, int K>
 WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K], char *scratch, char *attr_base,
                            int lane_col, int colstride, unsigned emit_bits) {
@@ -1013,98 +1117,7 @@ WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K
         res[0] = A.nan[0] ? wt_nan() : m;
         return;
     }
-    if (OP == WT_OP_MWU) {
-        // setComparisons.c:293-366 without sorting.  The reference sorts the n1+n2 (value,set)
-        // pairs stably (set-0 entries first inside a tie group) and scans them; every quantity the
-        // scan uses for a set-0 element e is a COUNT:
-        //   index - prev            = L_e  = #set-1 values <  x_e
-        //   set-1 entries tied to e = t_e  = #set-1 values == x_e, all of them after e in the table
-        //   "contiguous set-1 successors" (:338-341) = t_e if e is the last set-0 entry of its tie
-        //                             group, else 0 (the next entry is another set-0 one)
-        // and the scan visits the set-0 elements in (value, index) order, i.e. at rank
-        //   r_e = #set-0 values < x_e + #set-0 values == x_e with a smaller index.
-        // All counts come from two branch-free n1*n2 / n1*n1 loops over this lane's LDS column
-        // (independent reads: no data-dependent trip counts, no divergence); (L,t,last) are
-        // scattered to rank r_e and the reference's tie state machine then runs over n1 entries,
-        // performing the same double additions in the same order.
-        const int na = P.n_set0, nb = N - P.n_set0;
-        const ScrT *val = (const ScrT *) scratch + lane_col;                       // [N][colstride]
-        uint32_t *attr = (uint32_t *) attr_base + lane_col;                        // [na][colstride]
-        if (A.nan[0]) { res[0] = wt_nan(); return; }
-        // WT_MWU_EB set-0 elements per sweep over the column: every LDS read serves EB comparisons
-        // (the loop was bound by LDS latency at the 2 waves per CU the columns leave room for)
-        constexpr int EB = WT_MWU_EB;
-        for (int e0 = 0; e0 < na; e0 += EB) {
-            ScrT x[EB];
-            int L[EB], t[EB], r[EB], later[EB];
-#pragma unroll
-            for (int q = 0; q < EB; q++) {
-                x[q] = val[(size_t) (e0 + q < na ? e0 + q : na - 1) * colstride];
-                L[q] = 0; t[q] = 0; r[q] = 0; later[q] = 0;
-            }
-            // Sweeps over [lo, hi) of the column in batches of WT_MWU_RB values that are read first and
-            // consumed afterwards: the LDS reads of a batch are in flight together (with one wave
-            // per SIMD their latency was fully exposed -- ~60 cycles per value).
-            auto sweep = [&](int lo, int hi, auto body) {
-                int j = lo;
-                for (; j + WT_MWU_RB <= hi; j += WT_MWU_RB) {
-                    ScrT y[WT_MWU_RB];
-#pragma unroll
-                    for (int u = 0; u < WT_MWU_RB; u++) y[u] = val[(size_t) (j + u) * colstride];
-#pragma unroll
-                    for (int u = 0; u < WT_MWU_RB; u++) body(y[u], j + u);
-                }
-                for (; j < hi; j++) body(val[(size_t) j * colstride], j);
-            };
-            sweep(na, N, [&](ScrT y, int) {
-#pragma unroll
-                for (int q = 0; q < EB; q++) { L[q] += (y < x[q]); t[q] += (y == x[q]); }
-            });
-            // set-0 entries before the block only need (y <= x), the ones after it (y < x) and
-            // (y == x); the index comparisons matter inside the block alone
-            sweep(0, e0, [&](ScrT y, int) {
-#pragma unroll
-                for (int q = 0; q < EB; q++) r[q] += (y <= x[q]);
-            });
-            const int e1 = e0 + EB < na ? e0 + EB : na;
-            for (int j = e0; j < e1; j++) {
-                const ScrT y = val[(size_t) j * colstride];
-#pragma unroll
-                for (int q = 0; q < EB; q++) {
-                    r[q] += (y < x[q]) | ((y == x[q]) & (j < e0 + q));
-                    later[q] += (y == x[q]) & (j > e0 + q);
-                }
-            }
-            sweep(e1, na, [&](ScrT y, int) {
-#pragma unroll
-                for (int q = 0; q < EB; q++) { r[q] += (y < x[q]); later[q] += (y == x[q]); }
-            });
-#pragma unroll
-            for (int q = 0; q < EB; q++)
-                if (e0 + q < na)
-                    attr[(size_t) r[q] * colstride] = ((uint32_t) L[q] << 17) | ((uint32_t) t[q] << 1) | (later[q] == 0 ? 1u : 0u);
-        }
-        const double mu = (double) (na * nb / 2);                               // :386 int division
-        const double sigma = sqrt((double) (na * nb * (na + nb + 1) / 12));     // :387 int division
-        double U1 = 0;
-        int ties = 0, prevTies = 0;
-        for (int q = 0; q < na; q++) {
-            const uint32_t a = attr[(size_t) q * colstride];
-            const int L = (int) (a >> 17), t = (int) ((a >> 1) & 0xffffu);
-            U1 += L;                                      // :336  U1 += index - prev
-            if (ties) {                                   // :337-346
-                if (a & 1u) prevTies += t;
-                U1 -= prevTies / 2.0;
-                U1 += (ties - prevTies) / 2.0;
-                if (prevTies == ties) prevTies = ties = 0;
-            } else {                                      // :347-354
-                ties += t;
-                if (ties) U1 += ties / 2.0;
-            }
-        }
-        res[0] = (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
-        return;
-    }
+    if (OP == WT_OP_MWU) return;    // ranking and tie scan are their own phases (wt_phase_mwu_rank / _tail)
     if (OP == WT_OP_MULTIPLEX) {
 #pragma unroll
         for (int k = 0; k < K; k++) res[k] = A.a[k];
@@ -1189,14 +1202,28 @@ WT_DEV void wt_phase_eval_chunk(const WtParams &P, WtCtx &c, WtAcc<K> &A, int pa
         const uint64_t below0 = b0 ? wt_mask_incl(b0 - 1) : 0ull;
         run0 = c.sh->goffset + c.epfx[w] + wt_popc64(c.E[w] & below0);
     }
-    wt_eval_chunk<OP, ValT, ScrT, K>(P, c, p0, A, pass, t_lo, t_hi, c.scratch, tid, nt, emit_bits, run0);
+    wt_eval_chunk<OP, ValT, ScrT, K>(P, c, p0, A, pass, t_lo, t_hi, c.scratch, tid, P.W, emit_bits, run0);
 }
 
 template <int OP, class ValT, class ScrT, int K>
 WT_DEV void wt_phase_eval_finish(const WtParams &P, WtCtx &c, const WtAcc<K> &A, WtLane<K> &L, int tid, int nt) {
     const unsigned emit_bits = wt_lane_emit_bits<K>(P, c, tid);
     if (!emit_bits) return;
-    wt_eval_finish<OP, ValT, ScrT, K>(P, A, L.res, c.scratch, c.attr, tid, nt, emit_bits);
+    wt_eval_finish<OP, ValT, ScrT, K>(P, A, L.res, c.scratch, c.attr, tid, P.W, emit_bits);
+}
+
+// MWU: lanes tid, tid + W, ... share the run at window position tid % W (K == 1; the plan may give a
+// workgroup lanes_per_pos * W lanes)
+template <class ScrT>
+WT_DEV void wt_phase_mwu_rank(const WtParams &P, WtCtx &c, int tid, int nt) {
+    const int p = tid % P.W, part = tid / P.W, nparts = nt / P.W;
+    if (!((c.E[p >> 6] >> (p & 63)) & 1ull)) return;
+    wt_mwu_rank<ScrT>(P, c.scratch, c.attr, p, P.W, part, nparts);
+}
+template <int K>
+WT_DEV void wt_phase_mwu_tail(const WtParams &P, WtCtx &c, const WtAcc<K> &A, WtLane<K> &L, int tid, int nt) {
+    if (tid >= P.W || !((c.E[tid >> 6] >> (tid & 63)) & 1ull)) return;
+    L.res[0] = A.nan[0] ? wt_nan() : wt_mwu_tail(P, c.attr, tid, P.W);
 }
 
 // ---------------------------------------------------------------------------

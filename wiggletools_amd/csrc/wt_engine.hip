@@ -162,6 +162,12 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
             if (pass == 0 && npass == 2) wt_eval_mid<OP, K>(P, A);
         }
         wt_phase_eval_finish<OP, ValT, ScrT, K>(P, c, A, L, tid, nt);
+        if (OP == WT_OP_MWU) {      // the value columns are complete: rank with every lane, then the tie scan
+            __syncthreads();
+            wt_phase_mwu_rank<ScrT>(P, c, tid, nt);
+            __syncthreads();
+            wt_phase_mwu_tail<K>(P, c, A, L, tid, nt);
+        }
         WT_TICK(4);
         WT_MARK(10);
         if (OP != WT_OP_MULTIPLEX && tid < 64) wt_lookback_complete(P, c, k, tid);

@@ -19,6 +19,7 @@ struct WtPlan {
     int n_words = 0;
     int spitch = 0, cpitch = 0, count_segs = 8;
     int chunk_tracks = 0, n_chunks = 1;   // tracks resident in LDS at a time / number of chunks
+    int lanes_per_pos = 1;  // MWU: lanes of a workgroup sharing one window position (T = lanes_per_pos * W, K = 1)
     int off_acc = 0, off_ev = 0, off_ltv = 0, off_ltc = 0, off_gtv = 0, off_gtc = 0, off_tbase = 0, off_tpfx = 0, off_tfirst = 0, off_dsh = 0;
     bool delta = false;     // difference-array plan (wt_delta.h)
     int off_S = 0, off_cnt = 0, off_segtot = 0, off_U = 0, off_cover = 0, off_E = 0, off_epfx = 0, off_nextw = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
@@ -58,13 +59,13 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
     p.off_gbase = o;   o = wt_align16(o + chunk * 8);
     p.off_scratch = o;
     long long scr_bytes = 0;
-    if (op == WT_OP_MEDIAN || op == WT_OP_MWU) scr_bytes = (long long) n_tracks * T * scratch_elem;
+    if (op == WT_OP_MEDIAN || op == WT_OP_MWU) scr_bytes = (long long) n_tracks * W * scratch_elem;    // one column per position
     scr_bytes = (scr_bytes + 255) & ~255ll;
     p.scratch_slab = scratch_global ? scr_bytes : 0;
     // MWU: the per-rank attribute words (one u32 per set-0 track and lane, written once and read
     // once per run) always live in a global slab per workgroup: keeping them in LDS halved the lanes
     // per CU for the part that matters, the N^2 ranking over the value column
-    p.attr_slab = (op == WT_OP_MWU) ? (((long long) n_tracks * T * 4 + 255) & ~255ll) : 0;
+    p.attr_slab = (op == WT_OP_MWU) ? (((long long) n_tracks * W * 4 + 255) & ~255ll) : 0;
     if (!scratch_global) o = (int) std::min<long long>(o + scr_bytes, 1 << 30);
     p.off_shared = o;  o = wt_align16(o + (int) sizeof(WtShared));
     p.lds_bytes = o;
@@ -126,16 +127,19 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
     const char *eT = getenv("WTAMD_T");
     const bool scr = wt_op_needs_scratch(op);
     const int scratch_elem = scr ? (scratch_f32 ? 4 : 8) : 0;
-    struct Cand { int ppt, T; };
+    struct Cand { int ppt, T, lpp; };
     std::vector<Cand> cands;
     if (eP || eT) {
         const int ppt = scr ? 1 : (eP ? atoi(eP) : 4);
         const int T = eT ? atoi(eT) : 256;
-        if ((ppt == 1 || ppt == 4) && T >= 64 && T <= 512 && !(T & (T - 1))) cands.push_back({ppt, T});
+        if ((ppt == 1 || ppt == 4) && T >= 64 && T <= 512 && !(T & (T - 1))) cands.push_back({ppt, T, 1});
     }
     if (cands.empty()) {
-        if (scr) cands = {{1, 256}, {1, 128}, {1, 64}};
-        else cands = {{4, 512}, {4, 256}, {1, 512}, {1, 256}, {1, 128}, {1, 64}};
+        // MWU first tries two lanes per position (512 lanes on 256 positions): the value columns cap
+        // the positions a CU can hold, the N^2 ranking is what needs the lanes
+        if (op == WT_OP_MWU && !getenv("WTAMD_MWU_LPP1")) cands = {{1, 512, 2}, {1, 256, 2}, {1, 128, 2}, {1, 64, 1}};
+        else if (scr) cands = {{1, 256, 1}, {1, 128, 1}, {1, 64, 1}};
+        else cands = {{4, 512, 1}, {4, 256, 1}, {1, 512, 1}, {1, 256, 1}, {1, 128, 1}, {1, 64, 1}};
     }
     // Measured on MI355X (round 1):
     //  * the widest window wins: per-window fixed costs (header, scans, look-back, barriers)
@@ -151,8 +155,9 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
     const char *eC = getenv("WTAMD_CHUNK");     // experiments / tests: force a chunk size
     auto try_plan = [&](const Cand &cd, int chunk, int lim, bool glob = false) -> bool {
         WtPlan p;
-        wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p, chunk, glob);
+        wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T / cd.lpp, cd.T, scratch_elem, p, chunk, glob);
         p.ppt = cd.ppt;
+        p.lanes_per_pos = cd.lpp;
         if (p.lds_bytes > lim) return false;
         out = p;
         return true;
@@ -162,7 +167,7 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
         while (lo < hi) {
             const int mid = (lo + hi + 1) / 2;
             WtPlan p;
-            wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T, cd.T, scratch_elem, p, mid, glob);
+            wt_carve(n_tracks, scr ? op : WT_OP_SUM, cd.ppt * cd.T / cd.lpp, cd.T, scratch_elem, p, mid, glob);
             if (p.lds_bytes <= lim) lo = mid; else hi = mid - 1;
         }
         return lo;
@@ -182,6 +187,9 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
         for (const Cand &c2 : cands)
             if (try_plan(c2, 0, limit)) return true;
     } else {
+        // MWU with few tracks: the columns of 256 positions fit half the LDS, two workgroups per CU
+        // already fill the SIMDs -- one lane per position (mwu/20 tracks: 4.4 vs 9.1 ms)
+        if (op == WT_OP_MWU && cands.size() > 1 && try_plan({1, 256, 1}, 0, half)) return true;
         for (const Cand &cd : cands)
             if (try_plan(cd, 0, limit)) return true;
         // more tracks than LDS columns hold: the columns move to a global slab per workgroup
