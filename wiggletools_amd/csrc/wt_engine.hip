@@ -29,6 +29,7 @@
 #include "../../include/wiggletools_amd.h"
 #include "wt_core.h"
 #include "wt_plan.h"
+#include "wt_devscope.h"
 
 #define WT_MAX_BLOCK 512
 // minimum waves per SIMD the register allocator must leave room for (MI355X_MICROARCH:
@@ -1229,17 +1230,18 @@ static int wt_reduce_host_impl(wtamd_trackset *ts, int op, uint32_t flags, int n
     if (cap > runs->capacity) cap = runs->capacity;     // never write past the caller's arrays
     const int64_t alloc = cap > 0 ? cap : 1;
     const int N = ts->n_tracks;
+    WtDevScope scope;
     wtamd_runs d{};
     d.capacity = cap;
     double *d_tile = nullptr;
     uint8_t *d_inplay = nullptr;
-    WT_HIP(hipMalloc(&d.start, sizeof(int32_t) * alloc));
-    WT_HIP(hipMalloc(&d.finish, sizeof(int32_t) * alloc));
-    WT_HIP(hipMalloc(&d.value, sizeof(double) * alloc));
-    WT_HIP(hipMalloc(&d.chrom_run_off, sizeof(int64_t) * (ts->n_chrom + 1)));
+    WT_HIP(scope.alloc(&d.start, sizeof(int32_t) * alloc));
+    WT_HIP(scope.alloc(&d.finish, sizeof(int32_t) * alloc));
+    WT_HIP(scope.alloc(&d.value, sizeof(double) * alloc));
+    WT_HIP(scope.alloc(&d.chrom_run_off, sizeof(int64_t) * (ts->n_chrom + 1)));
     if (op == WT_OP_MULTIPLEX) {
-        WT_HIP(hipMalloc(&d_tile, sizeof(double) * alloc * N));
-        WT_HIP(hipMalloc(&d_inplay, sizeof(uint8_t) * alloc * N));
+        WT_HIP(scope.alloc(&d_tile, sizeof(double) * alloc * N));
+        WT_HIP(scope.alloc(&d_inplay, sizeof(uint8_t) * alloc * N));
     }
     int64_t n = 0;
     int rc = wt_reduce_impl(ts, op, flags, n_set0, &d, d_tile, d_inplay, &n, nullptr);
@@ -1255,8 +1257,6 @@ static int wt_reduce_host_impl(wtamd_trackset *ts, int op, uint32_t flags, int n
             WT_HIP(hipMemcpy(runs->chrom_run_off, d.chrom_run_off, sizeof(int64_t) * (ts->n_chrom + 1), hipMemcpyDeviceToHost));
         if (n_runs) *n_runs = n;
     }
-    (void) hipFree(d.start); (void) hipFree(d.finish); (void) hipFree(d.value); (void) hipFree(d.chrom_run_off);
-    (void) hipFree(d_tile); (void) hipFree(d_inplay);
     return rc;
 }
 
@@ -1276,7 +1276,8 @@ static int wt_runs_auc_span(const wtamd_runs *runs, int64_t n_runs, double *auc,
     hipStream_t s = (hipStream_t) stream;
     const int blocks = 512;
     double *d_partial = nullptr, h[2] = {0, 0};
-    WT_HIP(hipMalloc(&d_partial, sizeof(double) * (2 * blocks + 2)));
+    WtDevScope scope;
+    WT_HIP(scope.alloc(&d_partial, sizeof(double) * (2 * blocks + 2)));
     hipLaunchKernelGGL(wt_auc_kernel, dim3(blocks), dim3(256), 0, s, runs->start, runs->finish, runs->value,
                        (long long) n_runs, d_partial, span ? d_partial + blocks : nullptr);
     hipLaunchKernelGGL(wt_auc_final_kernel, dim3(1), dim3(64), 0, s, d_partial, blocks, d_partial + 2 * blocks);
@@ -1284,7 +1285,6 @@ static int wt_runs_auc_span(const wtamd_runs *runs, int64_t n_runs, double *auc,
     WT_HIP(hipGetLastError());
     WT_HIP(hipMemcpyAsync(h, d_partial + 2 * blocks, sizeof(double) * (span ? 2 : 1), hipMemcpyDeviceToHost, s));
     WT_HIP(hipStreamSynchronize(s));
-    (void) hipFree(d_partial);
     *auc = h[0];
     if (span) *span = h[1];
     return WTAMD_OK;
@@ -1316,14 +1316,15 @@ int wtamd_pearson(wtamd_trackset *ts, double *result) {
     WtMoments *d_partial = nullptr;
     double *d_out = nullptr;
     const int blocks = 256;
-    WT_HIP(hipMalloc(&d.start, sizeof(int32_t) * alloc));
-    WT_HIP(hipMalloc(&d.finish, sizeof(int32_t) * alloc));
-    WT_HIP(hipMalloc(&d.value, sizeof(double) * alloc));
-    WT_HIP(hipMalloc(&d.chrom_run_off, sizeof(int64_t) * (ts->n_chrom + 1)));
-    WT_HIP(hipMalloc(&d_tile, sizeof(double) * alloc * 2));
-    WT_HIP(hipMalloc(&d_inplay, sizeof(uint8_t) * alloc * 2));
-    WT_HIP(hipMalloc(&d_partial, sizeof(WtMoments) * blocks));
-    WT_HIP(hipMalloc(&d_out, sizeof(double)));
+    WtDevScope scope;
+    WT_HIP(scope.alloc(&d.start, sizeof(int32_t) * alloc));
+    WT_HIP(scope.alloc(&d.finish, sizeof(int32_t) * alloc));
+    WT_HIP(scope.alloc(&d.value, sizeof(double) * alloc));
+    WT_HIP(scope.alloc(&d.chrom_run_off, sizeof(int64_t) * (ts->n_chrom + 1)));
+    WT_HIP(scope.alloc(&d_tile, sizeof(double) * alloc * 2));
+    WT_HIP(scope.alloc(&d_inplay, sizeof(uint8_t) * alloc * 2));
+    WT_HIP(scope.alloc(&d_partial, sizeof(WtMoments) * blocks));
+    WT_HIP(scope.alloc(&d_out, sizeof(double)));
     int64_t n = 0;
     int rc = wt_reduce_impl(ts, WT_OP_MULTIPLEX, 0, 0, &d, d_tile, d_inplay, &n, nullptr);
     if (rc == WTAMD_OK) {
@@ -1333,8 +1334,6 @@ int wtamd_pearson(wtamd_trackset *ts, double *result) {
         if (hipGetLastError() != hipSuccess || hipMemcpy(result, d_out, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
             rc = wt_fail(WTAMD_ERR_HIP, "wtamd_pearson: kernel launch / copy failed");
     }
-    (void) hipFree(d.start); (void) hipFree(d.finish); (void) hipFree(d.value); (void) hipFree(d.chrom_run_off);
-    (void) hipFree(d_tile); (void) hipFree(d_inplay); (void) hipFree(d_partial); (void) hipFree(d_out);
     return rc;
 }
 
@@ -1344,13 +1343,13 @@ int wtamd_trackset_validate(wtamd_trackset *ts, int64_t *n_bad, int64_t *first_b
     if (first_bad) *first_bad = -1;
     if (ts->n_intervals <= 0) return WTAMD_OK;
     unsigned long long h[2] = {0ull, ~0ull}, *d = nullptr;
-    WT_HIP(hipMalloc(&d, sizeof h));
+    WtDevScope scope;
+    WT_HIP(scope.alloc(&d, sizeof h));
     WT_HIP(hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice));
     const long long total = ts->n_intervals;
     hipLaunchKernelGGL(wt_validate_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, nullptr, ts->d_start,
                        ts->d_finish, ts->d_seg_off, (long long) ts->n_chrom * ts->n_tracks, total, d);
     const hipError_t e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
-    (void) hipFree(d);
     if (e != hipSuccess) return wt_fail(WTAMD_ERR_HIP, "wtamd_trackset_validate: kernel / copy failed");
     *n_bad = (int64_t) h[0];
     if (first_bad && h[0]) *first_bad = (int64_t) h[1];

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/wiggletools_amd.h"
+#include "wt_devscope.h"
 
 #define WM_BLOCK 256
 #define WM_ITEMS 16
@@ -195,10 +196,11 @@ int wtamd_runs_map(int map_op, double param, int64_t n_seg, const int64_t *seg_o
     unsigned long long *d_blk = nullptr;
     double *d_mapped = o_value;
     int64_t *d_seg = nullptr, *d_oseg = nullptr;
+    WtDevScope scope;
     if (drops) {
-        WM_HIP(hipMalloc(&d_blk, sizeof(unsigned long long) * (n_blocks + 1)));
-        WM_HIP(hipMalloc(&d_mapped, sizeof(double) * n));
-        WM_HIP(hipMalloc(&d_seg, sizeof(int64_t) * (n_seg + 1) * 2));
+        WM_HIP(scope.alloc(&d_blk, sizeof(unsigned long long) * (n_blocks + 1)));
+        WM_HIP(scope.alloc(&d_mapped, sizeof(double) * n));
+        WM_HIP(scope.alloc(&d_seg, sizeof(int64_t) * (n_seg + 1) * 2));
         d_oseg = d_seg + (n_seg + 1);
         WM_HIP(hipMemcpyAsync(d_seg, seg_off, sizeof(int64_t) * (n_seg + 1), hipMemcpyHostToDevice, s));
     }
@@ -237,7 +239,6 @@ int wtamd_runs_map(int map_op, double param, int64_t n_seg, const int64_t *seg_o
     WM_HIP(hipGetLastError());
     WM_HIP(hipMemcpyAsync(o_seg_off, d_oseg, sizeof(int64_t) * (n_seg + 1), hipMemcpyDeviceToHost, s));
     WM_HIP(hipStreamSynchronize(s));
-    (void) hipFree(d_blk); (void) hipFree(d_mapped); (void) hipFree(d_seg);
     return WTAMD_OK;
 }
 
