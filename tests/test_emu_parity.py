@@ -415,3 +415,27 @@ def test_emu_edge_data_only_in_late_tracks_and_late_chromosomes(oracle):
     for op in ("sum", "mean", "max", "median", "product"):
         got, info = emu.reduce(t, op, delta_T=64, ppt=4, T=64)
         assert_runs_equal(got, oracle.reduce(t.as_dict(), op), 0.0, op)
+
+
+def test_plan_policy_snapshot():
+    """The execution plans the measurements in DESIGN.md were taken with (MI355X, round 1)."""
+    from wiggletools_amd.runlists import synth
+    def plan(n, op, dtype=np.float32, **kw):
+        t = synth(n, [300], mean_run=8, seed=1, dtype=dtype)
+        return emu.reduce(t, op, **kw)[1]
+    p = plan(100, "mean")
+    assert (p["delta"], p["W"], p["T"]) == (1, 4096, 512)                # difference-array kernel
+    p = plan(100, "max")
+    assert (p["W"], p["T"], p["n_chunks"]) == (2048, 512, 1)             # bitmaps of 100 tracks: half the LDS
+    p = plan(500, "var")
+    assert (p["W"], p["T"]) == (2048, 512) and p["n_chunks"] == 5        # chunks of <= 112 tracks
+    p = plan(100, "median")
+    assert (p["W"], p["T"]) == (256, 256) and p["scratch_slab"] == 0     # one f32 column per lane in LDS
+    p = plan(100, "mwu", n_set0=50)
+    assert (p["W"], p["T"]) == (256, 512)                                # two lanes per run
+    p = plan(20, "mwu", n_set0=10)
+    assert (p["W"], p["T"]) == (256, 256)                                # columns fit half the LDS: one lane per run
+    p = plan(100, "mean", dtype=np.float64)
+    assert p["delta"] == 0 and p["W"] == 2048                            # f64 tracks: general kernel
+    p = plan(1000, "median")
+    assert p["scratch_slab"] > 0                                         # columns in a global slab
