@@ -134,6 +134,16 @@ WiggleIterator *FillInReduction(Multiplexer *, wt_bool);  /* reducers.c:108-119,
 /* Two-sample tests -- replace reference src/setComparisons.c. */
 WiggleIterator *TTestReduction(Multiset *);  /* setComparisons.c:123-131 */
 WiggleIterator *MWUReduction(Multiset *);    /* setComparisons.c:372-390 */
+/* setComparisons.c:232-243.  The reference's F-test pop is broken (its inner loops advance
+ * `index` instead of `index2`, :183,199 -- undefined behaviour) and is out of scope:
+ * exported so that the link change of INTEGRATION.md links (commandParser.c:642-644 calls it);
+ * prints a message and exit(1)s, the reference's own error convention. */
+WiggleIterator *FTestReduction(Multiset *);
+
+/* Behavioural difference at this boundary (documented, loud): the reference accepts any C `int`
+ * coordinate; this engine refuses run finishes above WTAMD_MAX_COORD = 2^31 - 65537 (message +
+ * exit(1) from the drop-in layer, WTAMD_ERR_ARG from the bulk layer) because its 32-bit window
+ * arithmetic keeps a margin below INT32_MAX.  No genome assembly comes near it. */
 
 /* ------------------------------------------------------------------ */
 /* (2) BULK LAYER                                                      */
@@ -336,6 +346,82 @@ int wtamd_runs_compress(const wtamd_runs *in, int64_t n_runs, int32_t n_chrom, w
                         int64_t *n_out, void *stream);
 
 int wtamd_get_stats(const wtamd_trackset *ts, wtamd_stats *out);
+
+/* ---- Streaming pipeline (what the drop-in layer feeds; replaces the producer / consumer
+ * overlap the reference gets from src/bufferedReader.c:41-55,99-109 -- 10 000-entry SoA blocks, a
+ * producer up to 3 blocks ahead -- and the per-run evaluation behind it).
+ *
+ * A pipe owns `n_slots` batch slots.  Each slot has PINNED host staging for one batch of run lists
+ * (one chromosome, run starts in [lo, hi)), device buffers allocated once, and pinned host output.
+ * submit() enqueues  H2D (copy stream) -> window index + multiplex/reduce kernels (compute
+ * stream) -> D2H of exactly the emitted runs (third stream)  and returns at once, so the caller
+ * fills slot k+1 while slot k computes and slot k-1 is being read.  Values stay float32 end to end
+ * when the source's values are float32-exact.  Nothing is allocated or freed per batch.
+ *
+ *   acquire -> fill the staging arrays (grow if needed) -> submit     (repeat, up to n_slots deep)
+ *   collect -> read the result arrays -> release                       (in submission order)      */
+#define WTAMD_OP_MULTIPLEX 12   /* pipe only: the aligned tile values[]/inplay[] per run (multiplexer.h:21-36) */
+#define WTAMD_PIPE_COMPRESS 1u  /* apply CompressionWiggleIterator's merge rule on device before D2H (unaryOps.c:235-253) */
+
+typedef struct wtamd_pipe wtamd_pipe;
+
+typedef struct {
+    int32_t n_tracks;
+    int32_t n_slots;            /* 2..8 batches in flight; 0 = 3 */
+    const double *defaults;     /* HOST, n_tracks default_values */
+    wtamd_reduce_desc desc;     /* op may also be WTAMD_OP_MULTIPLEX */
+    int64_t max_intervals;      /* initial input capacity of a slot (wtamd_pipe_grow enlarges it) */
+    int64_t max_runs;           /* output capacity of a slot, fixed: keep hi - lo <= max_runs (a run is >= 1 bp) */
+    uint32_t flags;             /* WTAMD_PIPE_* */
+    int32_t reserved;
+} wtamd_pipe_config;
+
+typedef struct {                /* pinned staging of the slot being filled */
+    int64_t capacity;           /* intervals the arrays below hold */
+    int64_t *seg_off;           /* n_tracks + 1 offsets into the arrays (seg_off[0] = 0) */
+    int32_t *start, *finish;
+    float *value32;             /* always present */
+    double *value64;            /* NULL until wtamd_pipe_grow(.., want_f64 = 1) */
+} wtamd_pipe_batch;
+
+typedef struct {                /* pinned output of the oldest submitted batch, valid until release */
+    int64_t n_runs;
+    const int32_t *start, *finish;
+    const double *value;        /* reducer value; WTAMD_OP_MULTIPLEX: the run's inplay_count */
+    const double *tile;         /* WTAMD_OP_MULTIPLEX: n_runs * n_tracks values, else NULL */
+    const uint8_t *inplay;      /* WTAMD_OP_MULTIPLEX: n_runs * n_tracks flags, else NULL */
+    int64_t covered_bp;         /* sum (finish - start) of the runs the kernels emitted (before compression) */
+    int64_t n_intervals;        /* input intervals of the batch */
+} wtamd_pipe_result;
+
+typedef struct {
+    int64_t batches, intervals, runs, covered_bp;
+    int64_t h2d_bytes, d2h_bytes;
+    double kernel_ms;           /* sum over batches of index + reduce kernel time (HIP events on the compute stream) */
+    double h2d_ms, d2h_ms;      /* same for the copies (events on their streams) */
+    int32_t delta_batches;      /* batches the exact difference-array kernel evaluated */
+    int32_t n_slots;
+} wtamd_pipe_stats;
+
+int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out);
+void wtamd_pipe_destroy(wtamd_pipe *);
+/* Staging of the next free slot.  WTAMD_ERR_ARG when every slot is in flight or unreleased. */
+int wtamd_pipe_acquire(wtamd_pipe *, wtamd_pipe_batch *out);
+/* Enlarges the acquired slot's staging to >= min_capacity intervals (and adds the float64 value
+ * array if want_f64), preserving the first `used` entries of every array; *out is refreshed. */
+int wtamd_pipe_grow(wtamd_pipe *, int64_t used, int64_t min_capacity, int want_f64, wtamd_pipe_batch *out);
+/* Ships the acquired slot: seg_off[n_tracks] intervals of one chromosome, runs whose start lies in
+ * [range_lo, range_hi) are produced (same meaning as wtamd_tracks.range_lo/hi).  Asynchronous. */
+int wtamd_pipe_submit(wtamd_pipe *, int value_is_f64, int32_t range_lo, int32_t range_hi);
+/* Abandons the acquired slot without shipping it. */
+int wtamd_pipe_cancel(wtamd_pipe *);
+/* Result of the oldest submitted batch (waits for it). */
+int wtamd_pipe_collect(wtamd_pipe *, wtamd_pipe_result *out);
+/* Returns the oldest collected batch's slot to the pipe. */
+int wtamd_pipe_release(wtamd_pipe *);
+/* Submitted batches not yet collected. */
+int wtamd_pipe_in_flight(const wtamd_pipe *);
+int wtamd_pipe_get_stats(const wtamd_pipe *, wtamd_pipe_stats *out);
 
 /* ---- BigWig section decoder (bulk side door; replaces what the reference gets from libBigWig
  * through src/bigWiggleReader.c:52-83).  HOST only. ---- */

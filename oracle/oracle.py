@@ -113,6 +113,12 @@ class Harness:
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_reducer_default.restype = C.c_double
         L.ref_reducer_default.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.ref_reduce_seek_held.restype = C.c_int64
+        L.ref_reduce_seek_held.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int,
+                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_multiset_seek_held.restype = C.c_int64
+        L.ref_multiset_seek_held.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         self.L = L
 
     def reduce(self, t, op, flags=0, n_set0=0):
@@ -135,6 +141,26 @@ class Harness:
         n = self.L.ref_reduce_seek(C.byref(s), _opcode(op), flags, chrom, start, finish, cap,
                                    oc.ctypes.data, os_.ctypes.data, of.ctypes.data, ov.ctypes.data)
         return _trim(n, (oc, os_, of, ov))
+
+    def reduce_seek_held(self, t, op, chrom, start, finish, flags=0, n_set0=0):
+        """`seek chrom start finish <reducer>` the CLI's way: children hold their data until the seek."""
+        s, keep = _pack(t)
+        cap = _bound(t)
+        oc, os_, of, ov = _alloc(cap)
+        n = self.L.ref_reduce_seek_held(C.byref(s), _opcode(op), n_set0, flags, chrom, start, finish, cap,
+                                        oc.ctypes.data, os_.ctypes.data, of.ctypes.data, ov.ctypes.data)
+        return _trim(n, (oc, os_, of, ov))
+
+    def multiset_seek_held(self, t, n_set0, chrom, start, finish, flags=0):
+        s, keep = _pack(t)
+        cap = _bound(t)
+        N = int(t["n_tracks"])
+        oc, os_, of, _ = _alloc(cap)
+        tile = np.zeros((cap, N), np.float64)
+        ip = np.zeros((cap, N), np.uint8)
+        n = self.L.ref_multiset_seek_held(C.byref(s), n_set0, flags, chrom, start, finish, cap, oc.ctypes.data,
+                                          os_.ctypes.data, of.ctypes.data, tile.ctypes.data, ip.ctypes.data)
+        return _trim(n, (oc, os_, of, tile, ip))
 
     def multiplex(self, t, flags=0):
         s, keep = _pack(t)
@@ -206,6 +232,21 @@ def ref_lib():
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
         _ref = L
     return _ref
+
+
+_ref_h = None
+
+
+def ref_harness():
+    """The compiled reference behind the same Harness class that drives the drop-in library."""
+    global _ref_h
+    if _ref_h is None:
+        build()
+        path = os.path.join(_HERE, "_ref", "libwiggletools_ref.so")
+        if not os.path.exists(path):
+            raise RuntimeError("compiled reference not available (oracle/_ref missing)")
+        _ref_h = Harness(path, "ref")
+    return _ref_h
 
 
 def _bound(t):

@@ -46,6 +46,7 @@ static Multiplexer *(*r_newMultiplexer)(WiggleIterator **, int, wt_bool);
 static Multiset *(*r_newMultiset)(Multiplexer **, int);
 static void (*r_popMultiplexer)(Multiplexer *);
 static void (*r_popMultiset)(Multiset *);
+static void (*r_seekMultiset)(Multiset *, const char *, int, int);
 static void (*r_pop)(WiggleIterator *);
 static void (*r_seek)(WiggleIterator *, const char *, int, int);
 static WiggleIterator *(*r_SmartReader)(char *, wt_bool);
@@ -87,6 +88,7 @@ int ref_open(const char *path) {
     /* optional symbols: the compiled reference lacks the set comparisons (GSL), the
      * drop-in library lacks readers / integrators it does not replace */
 #define OPT(var, name) *(void **) (&var) = dlsym(g_lib, name)
+    OPT(r_seekMultiset, "seekMultiset");
     OPT(r_SmartReader, "SmartReader");
     OPT(r_AUCIntegrator, "AUCIntegrator");
     OPT(r_PearsonIntegrator, "PearsonIntegrator");
@@ -117,11 +119,15 @@ typedef struct {
     int64_t j;         /* next interval index inside (c, track) */
     /* optional seek window */
     int have_win; int win_c; int win_start, win_finish;
+    /* held: no data until the first seek -- what the reference's readers do under the CLI's `seek`
+     * (holdFire, commandParser.c:615-624, bufferedReader.c:164-166) */
+    int hold;
 } arr_iter;
 
 static void arr_pop(WiggleIterator *wi) {
     arr_iter *a = (arr_iter *) wi->data;
     const wto_tracks *t = a->t;
+    if (a->hold && !a->have_win) { wi->done = 1; return; }
     for (;;) {
         if (a->c >= t->n_chrom) { wi->done = 1; return; }
         int64_t seg = (int64_t) a->c * t->n_tracks + a->track;
@@ -153,9 +159,12 @@ static void arr_seek(WiggleIterator *wi, const char *chrom, int start, int finis
     arr_pop(wi);
 }
 
+static int g_hold;     /* children made from now on are held until their first seek */
+
 static WiggleIterator *make_child(const wto_tracks *t, char **names, int track) {
     arr_iter *a = (arr_iter *) calloc(1, sizeof(arr_iter));
     a->t = t; a->names = names; a->track = track; a->c = 0; a->j = -1;
+    a->hold = g_hold;
     return r_newWiggleIterator(a, arr_pop, arr_seek, t->defaults[track], 0);
 }
 
@@ -212,6 +221,75 @@ int64_t ref_reduce_seek(const wto_tracks *t, int op, unsigned flags, int chrom, 
         o_start[n] = r->start; o_finish[n] = r->finish; o_value[n] = r->value;
         n++;
         r_pop(r);
+    }
+    return n;
+}
+
+/* The CLI's `seek chr s f <reducer>` (commandParser.c:615-624): children are HELD (no data) while
+ * the Multiplexer(s) and the reducer are constructed, then seek() is called on the reducer
+ * (reducers.c:25-29 / setComparisons.c:25-29).  op 0..9 one-sample, 10/11 two-sample (n_set0). */
+int64_t ref_reduce_seek_held(const wto_tracks *t, int op, int n_set0, unsigned flags, int chrom, int start, int finish,
+                             int64_t cap, int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value) {
+    if (!g_lib || op < 0 || op > 11) return -2;
+    if (op >= 10 && !r_set_reduction[op - 10]) return -2;
+    char **names = make_names(t->n_chrom);
+    WiggleIterator *r;
+    g_hold = 1;
+    if (op < 10) {
+        Multiplexer *m = make_multiplexer(t, names, 0, t->n_tracks, flags & 1u);
+        r = r_reduction[op](m);
+    } else {
+        Multiplexer **ms = (Multiplexer **) calloc(2, sizeof(Multiplexer *));
+        ms[0] = make_multiplexer(t, names, 0, n_set0, flags & 1u);
+        ms[1] = make_multiplexer(t, names, n_set0, t->n_tracks, flags & 2u);
+        r = r_set_reduction[op - 10](r_newMultiset(ms, 2));
+    }
+    g_hold = 0;
+    if (!r->done) return -4;            /* held children: nothing before the seek */
+    r_seek(r, names[chrom], start, finish);
+    int64_t n = 0;
+    while (!r->done) {
+        if (n >= cap) return -1;
+        o_chrom[n] = name_to_index(r->chrom);
+        o_start[n] = r->start; o_finish[n] = r->finish; o_value[n] = r->value;
+        n++;
+        r_pop(r);
+    }
+    return n;
+}
+
+/* seekMultiset (multiSet.c:103-113) over two Multiplexers of held children; records the runs
+ * where both sets are in play, like ref_multiset. */
+int64_t ref_multiset_seek_held(const wto_tracks *t, int n_set0, unsigned flags, int chrom, int start, int finish,
+                               int64_t cap, int32_t *o_chrom, int32_t *o_start, int32_t *o_finish,
+                               double *o_tile, uint8_t *o_inplay) {
+    if (!g_lib || !r_seekMultiset) return -2;
+    char **names = make_names(t->n_chrom);
+    Multiplexer **ms = (Multiplexer **) calloc(2, sizeof(Multiplexer *));
+    g_hold = 1;
+    ms[0] = make_multiplexer(t, names, 0, n_set0, flags & 1u);
+    ms[1] = make_multiplexer(t, names, n_set0, t->n_tracks, flags & 2u);
+    Multiset *S = r_newMultiset(ms, 2);
+    g_hold = 0;
+    if (!S->done) return -4;
+    r_seekMultiset(S, names[chrom], start, finish);
+    int N = t->n_tracks;
+    int64_t n = 0;
+    while (!S->done) {
+        if (S->inplay[0] && S->inplay[1]) {
+            if (n >= cap) return -1;
+            o_chrom[n] = name_to_index(S->chrom);
+            o_start[n] = S->start; o_finish[n] = S->finish;
+            for (int k = 0; k < 2; k++) {
+                int base = k ? n_set0 : 0;
+                for (int i = 0; i < ms[k]->count; i++) {
+                    o_tile[n * N + base + i] = S->values[k][i];
+                    o_inplay[n * N + base + i] = (uint8_t) ms[k]->inplay[i];
+                }
+            }
+            n++;
+        }
+        r_popMultiset(S);
     }
     return n;
 }

@@ -17,5 +17,22 @@ def build(force=False):
     return so
 
 
+def build_dropin(force=False):
+    """tests/emu/libwt_dropin_emu.so: the product's drop-in layer (csrc/wt_iter_abi.cpp,
+    csrc/wt_defaults.cpp) linked against the emulated pipeline (wt_pipe_emu.cpp + wt_emu.cpp)."""
+    so = os.path.join(HERE, "libwt_dropin_emu.so")
+    csrc = os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc")
+    srcs = [os.path.join(HERE, "wt_emu.cpp"), os.path.join(HERE, "wt_pipe_emu.cpp"),
+            os.path.join(csrc, "wt_iter_abi.cpp"), os.path.join(csrc, "wt_defaults.cpp")]
+    deps = srcs + [os.path.join(csrc, "wt_core.h"), os.path.join(csrc, "wt_plan.h"), os.path.join(csrc, "wt_delta.h"),
+                   os.path.join(HERE, "..", "..", "include", "wiggletools_amd.h")]
+    if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in deps):
+        return so
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+                           "-Wno-unused-function", "-o", so] + srcs + ["-lm"])
+    return so
+
+
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_dropin(force=True))

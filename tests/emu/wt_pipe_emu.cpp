@@ -1,0 +1,205 @@
+// wt_pipe_emu.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// The streaming-pipeline entry points of include/wiggletools_amd.h (wtamd_pipe_*) on top of the
+// CPU emulator of the kernels (wt_emu.cpp), synchronously.  Linked with the product's own
+// csrc/wt_iter_abi.cpp + csrc/wt_defaults.cpp into tests/emu/libwt_dropin_emu.so, so that the
+// drop-in layer's host logic -- the Drainer's batch cuts, carried intervals and sentinels, seek,
+// take-over, Multiset stepping, the Feeder's slot bookkeeping -- runs against the oracle and the
+// compiled reference in the GPU-less container.  The product's pipe (csrc/wt_pipe.h: pinned
+// staging, HIP streams, events) is exercised by the -m gpu tests.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wiggletools_amd.h"
+
+extern "C" long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const int32_t *start,
+                                  const int32_t *finish, const void *value, int value_is_f64, const double *defaults,
+                                  int op, unsigned flags, int n_set0, long long capacity,
+                                  int32_t *o_start, int32_t *o_finish, double *o_value, int64_t *chrom_run_off,
+                                  double *o_tile, uint8_t *o_inplay, long long *info,
+                                  const int32_t *range_lo, const int32_t *range_hi);
+
+namespace {
+std::string g_err;
+
+struct Slot {
+    int state = 0;      // 0 free, 1 acquired, 2 submitted, 3 collected
+    std::vector<int64_t> seg_off;
+    std::vector<int32_t> start, finish;
+    std::vector<float> v32;
+    std::vector<double> v64;
+    bool has64 = false;
+    int64_t cap = 0;
+    // result
+    std::vector<int32_t> os, of;
+    std::vector<double> ov, tile;
+    std::vector<uint8_t> ip;
+    int64_t n_runs = 0, covered = 0, n_int = 0;
+};
+}  // namespace
+
+struct wtamd_pipe {
+    wtamd_pipe_config cfg;
+    std::vector<double> defaults;
+    std::vector<Slot> slots;
+    int head = 0;       // next slot to acquire
+    int tail = 0;       // oldest submitted / collected slot
+    int acquired = -1;
+    int in_flight = 0;  // submitted, not collected
+    int held = 0;       // collected, not released
+    wtamd_pipe_stats st{};
+};
+
+extern "C" {
+
+const char *wtamd_last_error(void) { return g_err.c_str(); }
+
+int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
+    if (!cfg || !out || cfg->n_tracks <= 0 || !cfg->defaults || cfg->max_runs <= 0) { g_err = "bad pipe config"; return WTAMD_ERR_ARG; }
+    wtamd_pipe *p = new wtamd_pipe();
+    p->cfg = *cfg;
+    p->defaults.assign(cfg->defaults, cfg->defaults + cfg->n_tracks);
+    p->cfg.defaults = p->defaults.data();
+    int ns = cfg->n_slots ? cfg->n_slots : 3;
+    if (ns < 2) ns = 2;
+    if (ns > 8) ns = 8;
+    p->slots.resize((size_t) ns);
+    // tests: a tiny initial capacity so that wtamd_pipe_grow is exercised
+    const char *e = getenv("WTEMU_PIPE_CAP");
+    const int64_t cap = e ? atoll(e) : (cfg->max_intervals > 0 ? cfg->max_intervals : 1024);
+    for (auto &s : p->slots) {
+        s.cap = cap;
+        s.seg_off.assign((size_t) cfg->n_tracks + 1, 0);
+        s.start.resize((size_t) cap); s.finish.resize((size_t) cap); s.v32.resize((size_t) cap);
+    }
+    p->st.n_slots = ns;
+    *out = p;
+    return WTAMD_OK;
+}
+
+void wtamd_pipe_destroy(wtamd_pipe *p) { delete p; }
+
+static void fill_batch(Slot &s, wtamd_pipe_batch *b) {
+    b->capacity = s.cap;
+    b->seg_off = s.seg_off.data();
+    b->start = s.start.data(); b->finish = s.finish.data();
+    b->value32 = s.v32.data();
+    b->value64 = s.has64 ? s.v64.data() : nullptr;
+}
+
+int wtamd_pipe_acquire(wtamd_pipe *p, wtamd_pipe_batch *out) {
+    if (!p || !out) { g_err = "NULL"; return WTAMD_ERR_ARG; }
+    if (p->acquired >= 0) { g_err = "a slot is already acquired"; return WTAMD_ERR_ARG; }
+    Slot &s = p->slots[(size_t) p->head];
+    if (s.state != 0) { g_err = "every slot is in flight or unreleased"; return WTAMD_ERR_ARG; }
+    s.state = 1;
+    p->acquired = p->head;
+    fill_batch(s, out);
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_grow(wtamd_pipe *p, int64_t used, int64_t min_capacity, int want_f64, wtamd_pipe_batch *out) {
+    if (!p || p->acquired < 0) { g_err = "no acquired slot"; return WTAMD_ERR_ARG; }
+    Slot &s = p->slots[(size_t) p->acquired];
+    if (used > s.cap) { g_err = "used > capacity"; return WTAMD_ERR_ARG; }
+    if (min_capacity > s.cap) {
+        // a fresh allocation on purpose: the caller must not keep stale pointers
+        std::vector<int32_t> a((size_t) min_capacity), b((size_t) min_capacity);
+        std::vector<float> c((size_t) min_capacity);
+        memcpy(a.data(), s.start.data(), sizeof(int32_t) * (size_t) used);
+        memcpy(b.data(), s.finish.data(), sizeof(int32_t) * (size_t) used);
+        memcpy(c.data(), s.v32.data(), sizeof(float) * (size_t) used);
+        s.start.swap(a); s.finish.swap(b); s.v32.swap(c);
+        if (s.has64) {
+            std::vector<double> d((size_t) min_capacity);
+            memcpy(d.data(), s.v64.data(), sizeof(double) * (size_t) used);
+            s.v64.swap(d);
+        }
+        s.cap = min_capacity;
+    }
+    if (want_f64 && !s.has64) { s.v64.assign((size_t) s.cap, 0.0); s.has64 = true; }
+    fill_batch(s, out);
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_cancel(wtamd_pipe *p) {
+    if (!p || p->acquired < 0) { g_err = "no acquired slot"; return WTAMD_ERR_ARG; }
+    p->slots[(size_t) p->acquired].state = 0;
+    p->acquired = -1;
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi) {
+    if (!p || p->acquired < 0) { g_err = "no acquired slot"; return WTAMD_ERR_ARG; }
+    Slot &s = p->slots[(size_t) p->acquired];
+    const int N = p->cfg.n_tracks;
+    const int64_t n = s.seg_off[(size_t) N];
+    if (value_is_f64 && !s.has64) { g_err = "float64 values were never staged"; return WTAMD_ERR_ARG; }
+    if ((int64_t) range_hi - range_lo > p->cfg.max_runs && range_hi != INT32_MAX) { g_err = "hi - lo above max_runs"; return WTAMD_ERR_ARG; }
+    const bool tile = p->cfg.desc.op == WTAMD_OP_MULTIPLEX;
+    int64_t cap = 2 * n + 8;
+    s.os.assign((size_t) cap, 0); s.of.assign((size_t) cap, 0); s.ov.assign((size_t) cap, 0.0);
+    if (tile) { s.tile.assign((size_t) cap * N, 0.0); s.ip.assign((size_t) cap * N, 0); }
+    int64_t cro[2] = {0, 0};
+    long long info[12] = {0};
+    const long long r = wtemu_reduce(1, N, s.seg_off.data(), s.start.data(), s.finish.data(),
+                                     value_is_f64 ? (const void *) s.v64.data() : (const void *) s.v32.data(), value_is_f64,
+                                     p->defaults.data(), p->cfg.desc.op, p->cfg.desc.flags, p->cfg.desc.n_set0, cap,
+                                     s.os.data(), s.of.data(), s.ov.data(), cro, tile ? s.tile.data() : nullptr,
+                                     tile ? s.ip.data() : nullptr, info, &range_lo, &range_hi);
+    if (r < 0) { g_err = "emulator error " + std::to_string(r); return WTAMD_ERR_INTERNAL; }
+    if (r > p->cfg.max_runs) { g_err = "more runs than max_runs"; return WTAMD_ERR_CAPACITY; }
+    s.n_runs = r; s.covered = info[4]; s.n_int = n;
+    s.state = 2;
+    p->acquired = -1;
+    p->head = (p->head + 1) % (int) p->slots.size();
+    p->in_flight++;
+    p->st.batches++; p->st.intervals += n; p->st.runs += r; p->st.covered_bp += info[4];
+    if (info[8]) p->st.delta_batches++;
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
+    if (!p || !out) { g_err = "NULL"; return WTAMD_ERR_ARG; }
+    if (p->in_flight <= 0) { g_err = "nothing in flight"; return WTAMD_ERR_ARG; }
+    if (p->held) { g_err = "the previous result was not released"; return WTAMD_ERR_ARG; }
+    Slot &s = p->slots[(size_t) p->tail];
+    if (s.state != 2) { g_err = "slot order corrupted"; return WTAMD_ERR_INTERNAL; }
+    s.state = 3;
+    p->in_flight--;
+    p->held = 1;
+    const bool tile = p->cfg.desc.op == WTAMD_OP_MULTIPLEX;
+    out->n_runs = s.n_runs;
+    out->start = s.os.data(); out->finish = s.of.data(); out->value = s.ov.data();
+    out->tile = tile ? s.tile.data() : nullptr;
+    out->inplay = tile ? s.ip.data() : nullptr;
+    out->covered_bp = s.covered;
+    out->n_intervals = s.n_int;
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_release(wtamd_pipe *p) {
+    if (!p || !p->held) { g_err = "nothing to release"; return WTAMD_ERR_ARG; }
+    Slot &s = p->slots[(size_t) p->tail];
+    s.state = 0;
+    // poison: a consumer that keeps reading a released result must show up in the tests
+    std::fill(s.os.begin(), s.os.end(), -1);
+    std::fill(s.of.begin(), s.of.end(), -1);
+    p->held = 0;
+    p->tail = (p->tail + 1) % (int) p->slots.size();
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_in_flight(const wtamd_pipe *p) { return p ? p->in_flight : 0; }
+
+int wtamd_pipe_get_stats(const wtamd_pipe *p, wtamd_pipe_stats *out) {
+    if (!p || !out) return WTAMD_ERR_ARG;
+    *out = p->st;
+    return WTAMD_OK;
+}
+
+}  // extern "C"

@@ -28,7 +28,9 @@ def test_library_exports_every_declared_symbol():
             "MedianReduction", "MinReduction", "MaxReduction", "SelectReduction", "FillInReduction",
             "TTestReduction", "MWUReduction", "newWiggleIterator", "pop", "seek", "runWiggleIterator",
             "destroyWiggleIterator", "wtamd_reduce", "wtamd_reduce_host", "wtamd_trackset_create_host",
-            "wtamd_trackset_create_device", "wtamd_multiplex_host", "wtamd_runs_auc", "wtamd_reducer_default", "wtamd_pearson", "wtamd_runs_compress", "wtamd_trackset_validate", "wtamd_runs_mean", "wtamd_runs_map", "wtamd_map_default"}
+            "wtamd_trackset_create_device", "wtamd_multiplex_host", "wtamd_runs_auc", "wtamd_reducer_default", "wtamd_pearson", "wtamd_runs_compress", "wtamd_trackset_validate", "wtamd_runs_mean", "wtamd_runs_map", "wtamd_map_default",
+            "FTestReduction", "wtamd_pipe_create", "wtamd_pipe_acquire", "wtamd_pipe_grow", "wtamd_pipe_submit",
+            "wtamd_pipe_collect", "wtamd_pipe_release", "wtamd_pipe_cancel", "wtamd_pipe_destroy", "wtamd_pipe_get_stats"}
     assert must <= declared, must - declared
     missing = [n for n in sorted(declared) if not hasattr(L, n)]
     assert not missing, missing

@@ -1,0 +1,258 @@
+"""The DROP-IN layer: the reference's own C API (newMultiplexer, MeanReduction, newMultiset,
+MWUReduction, seek, popMultiplexer, seekMultiset ...) exported by the product, driven by the very
+harness that drives the compiled reference (oracle/ref_harness.c) and compared with the oracle and
+with the compiled reference.  Array-backed child WiggleIterators are popped one interval at a
+time, exactly as the reference's readers would be.
+
+Two backends run the same cases:
+  * "amd"  (-m gpu): wiggletools_amd/csrc/libwiggletools_amd.so on a real MI355X -- the parity tests proper;
+  * "emu"  (CPU):    the product's csrc/wt_iter_abi.cpp linked against the emulated pipeline
+                     (tests/emu/wt_pipe_emu.cpp), so the host logic of the layer -- batch cuts,
+                     carried intervals, sentinels, take-over, seek, slot bookkeeping -- is checked
+                     in the GPU-less container too.
+"""
+import numpy as np
+import pytest
+
+from helpers import ALL_MULTIPLEX_OPS, assert_runs_equal, random_case
+
+EXACT = {"sum", "product", "mean", "min", "max", "median"}
+
+
+def _tol(op):
+    return 0.0 if op in EXACT else (1e-9 if op in ("ttest", "mwu") else 1e-12)
+
+
+_harness = {}
+
+
+def _get(oracle, backend):
+    if backend not in _harness:
+        if backend == "amd":
+            import torch
+            assert torch.cuda.is_available()
+            from wiggletools_amd import _lib
+            _harness[backend] = oracle.Harness(_lib.LIB_PATH, "amd")
+        else:
+            from emu import build as emu_build
+            _harness[backend] = oracle.Harness(emu_build.build_dropin(), "emu")
+    return _harness[backend]
+
+
+@pytest.fixture(params=["emu", pytest.param("amd", marks=pytest.mark.gpu)])
+def H(request, oracle):
+    return _get(oracle, request.param)
+
+
+@pytest.fixture
+def tiny_batches(monkeypatch):
+    """Cuts a batch every few bp / intervals and starts the staging at 3 entries: every seam rule
+    (interval reaching the cut, finishing exactly at it, sentinel, empty batch) fires many times."""
+    monkeypatch.setenv("WTAMD_MIN_SPAN", "7")
+    monkeypatch.setenv("WTAMD_BATCH_INTERVALS", "20")
+    monkeypatch.setenv("WTEMU_PIPE_CAP", "3")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_dropin_reducers(oracle, H, seed):
+    t = random_case(7000 + seed, max_len=6000)
+    d = t.as_dict()
+    for strict in (0, 1):
+        for op in ALL_MULTIPLEX_OPS:
+            exp = oracle.reduce(d, op, flags=strict)
+            got = H.reduce(d, op, flags=strict)
+            assert_runs_equal(got, exp, _tol(op), "seed %d op %s strict %d" % (seed, op, strict))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_dropin_multiplexer_fields(oracle, H, seed):
+    """popMultiplexer keeps chrom/start/finish/values[]/inplay[] coherent (multiplexer.h:21-36)."""
+    t = random_case(7100 + seed, max_len=5000)
+    d = t.as_dict()
+    for strict in (0, 1):
+        exp = oracle.multiplex(d, flags=strict)
+        got = H.multiplex(d, flags=strict)
+        assert len(got[0]) == len(exp[0])
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_dropin_two_sample(oracle, H, seed):
+    rng = np.random.default_rng(seed)
+    t = random_case(7200 + seed, n_tracks=int(rng.integers(6, 11)), max_len=4000)
+    d = t.as_dict()
+    n1 = int(rng.integers(3, t.n_tracks - 2))
+    for flags in (0, 1, 2, 3):
+        for op in ("ttest", "mwu"):
+            exp = oracle.reduce(d, op, flags=flags, n_set0=n1)
+            got = H.reduce(d, op, flags=flags, n_set0=n1)
+            assert_runs_equal(got, exp, _tol(op), "seed %d op %s flags %d" % (seed, op, flags))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_dropin_multiset_stepping(oracle, H, seed):
+    """Raw popMultiset over two Multiplexers (fields read by reference callers)."""
+    if not oracle.have_ref():
+        pytest.skip("compiled reference not available")
+    t = random_case(7300 + seed, n_tracks=6, max_len=3000)
+    d = t.as_dict()
+    for flags in (0, 3):
+        exp = oracle.ref_multiset(d, 3, flags)
+        got = H.multiset(d, 3, flags)
+        assert len(got[0]) == len(exp[0])
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
+def clip(t, chrom, start, finish):
+    """Tracks as the reference's readers deliver them after seek(chrom, start, finish)
+    (e.g. bigWiggleReader.c:125-145): only that chromosome, intervals clipped to the region."""
+    from wiggletools_amd.runlists import RunLists
+    tracks = []
+    for i in range(t.n_tracks):
+        per_c = []
+        for c in range(t.n_chrom):
+            lo, hi = t.seg_off[c * t.n_tracks + i], t.seg_off[c * t.n_tracks + i + 1]
+            rows = []
+            if c == chrom:
+                for g in range(lo, hi):
+                    s, f = int(t.start[g]), int(t.finish[g])
+                    if f <= start or s >= finish:
+                        continue
+                    rows.append((max(s, start), min(f, finish), float(t.value[g])))
+            per_c.append(rows)
+        tracks.append(per_c)
+    return RunLists.from_lists(tracks, t.defaults)
+
+
+def _regions(rng, t, k):
+    for _ in range(k):
+        c = int(rng.integers(0, t.n_chrom))
+        s = int(rng.integers(1, 2500))
+        yield c, s, s + int(rng.integers(1, 1500))
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_dropin_seek_vs_reference(oracle, H, seed):
+    """`seek chr s f <reducer>` as the CLI issues it (children held until the seek,
+    commandParser.c:615-624; then reducers.c:25-29 -> multiplexer.c:130-141) against the COMPILED
+    REFERENCE doing the same, and against the oracle over the tracks clipped to the region."""
+    if not oracle.have_ref():
+        pytest.skip("compiled reference not available")
+    R = oracle.ref_harness()
+    rng = np.random.default_rng(seed)
+    t = random_case(7400 + seed, n_tracks=5, n_chrom=2, max_len=3000)
+    d = t.as_dict()
+    for (c, s, f) in _regions(rng, t, 4):
+        for op in ("mean", "median", "max"):
+            for strict in (0, 1):
+                ref = R.reduce_seek_held(d, op, c, s, f, flags=strict)
+                got = H.reduce_seek_held(d, op, c, s, f, flags=strict)
+                assert_runs_equal(got, ref, 0.0, "seek %s %s strict %d vs reference" % ((c, s, f), op, strict))
+                exp = oracle.reduce(clip(t, c, s, f).as_dict(), op, flags=strict)
+                assert_runs_equal(got, exp, 0.0, "seek %s %s strict %d vs oracle" % ((c, s, f), op, strict))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_dropin_seek_multiset_vs_reference(oracle, H, seed):
+    """seekMultiset (multiSet.c:103-113) over two Multiplexers of held children."""
+    if not oracle.have_ref():
+        pytest.skip("compiled reference not available")
+    R = oracle.ref_harness()
+    rng = np.random.default_rng(100 + seed)
+    t = random_case(7450 + seed, n_tracks=6, n_chrom=2, max_len=3000)
+    d = t.as_dict()
+    for (c, s, f) in _regions(rng, t, 4):
+        for flags in (0, 3):
+            exp = R.multiset_seek_held(d, 3, c, s, f, flags)
+            got = H.multiset_seek_held(d, 3, c, s, f, flags)
+            assert len(got[0]) == len(exp[0]), (c, s, f, flags)
+            for a, b in zip(got, exp):
+                assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_dropin_seek_two_sample(oracle, H):
+    """SetComparisonSeek / MWUSeek (setComparisons.c:25-29,253-257): the two-sample reducers after a
+    held seek == the oracle over the clipped tracks (setComparisons.c cannot be compiled here)."""
+    t = random_case(7460, n_tracks=8, n_chrom=2, max_len=3000)
+    d = t.as_dict()
+    rng = np.random.default_rng(3)
+    for (c, s, f) in _regions(rng, t, 3):
+        for op in ("ttest", "mwu"):
+            got = H.reduce_seek_held(d, op, c, s, f, n_set0=4)
+            exp = oracle.reduce(clip(t, c, s, f).as_dict(), op, n_set0=4)
+            assert_runs_equal(got, exp, _tol(op), "seek %s %s" % ((c, s, f), op))
+
+
+def test_dropin_seek_primed(oracle, H):
+    """seek on a reducer whose children already delivered data == the reducer over the clipped
+    tracks.  (The REFERENCE is deliberately not consulted here: seeking a Multiplexer that was
+    already primed leaves stale inplay[]/values[] behind, multiplexer.c:130-141 resets the heaps
+    but not those arrays; the CLI never does that.)"""
+    t = random_case(7400, n_tracks=5, n_chrom=2, max_len=8000)
+    d = t.as_dict()
+    for (c, s, f) in ((0, 100, 3000), (1, 1, 50), (0, 2500, 2600), (1, 10, 4000)):
+        for op in ("mean", "median"):
+            got = H.reduce_seek(d, op, c, s, f)
+            exp = oracle.reduce(clip(t, c, s, f).as_dict(), op)
+            assert_runs_equal(got, exp, 0.0, "seek %s %s" % ((c, s, f), op))
+
+
+def test_dropin_batches_cross_seams(oracle, H):
+    """Long tracks: several batches, intervals crossing every cut."""
+    from wiggletools_amd.runlists import synth
+    t = synth(8, [300000, 5000], mean_run=40, seed=9, gap_prob=0.1)
+    d = t.as_dict()
+    for op in ("mean", "max"):
+        exp = oracle.reduce(d, op)
+        got = H.reduce(d, op)
+        assert_runs_equal(got, exp, 0.0, op)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_dropin_tiny_batches(oracle, H, tiny_batches, seed):
+    """A cut every ~7 bp: gapped tracks whose intervals finish exactly at a cut (the run that starts
+    there must not be lost), cross it, or start right after it."""
+    t = random_case(9000 + seed, max_len=600)
+    d = t.as_dict()
+    for strict in (0, 1):
+        for op in ("mean", "median", "var"):
+            exp = oracle.reduce(d, op, flags=strict)
+            got = H.reduce(d, op, flags=strict)
+            assert_runs_equal(got, exp, _tol(op), "seed %d %s strict %d" % (seed, op, strict))
+    exp = oracle.multiplex(d)
+    got = H.multiplex(d)
+    assert len(got[0]) == len(exp[0])
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_dropin_cut_at_finish_example(oracle, H, monkeypatch):
+    """The advisor's example: A=[1,100), B=[10,50), cut at 50: the run [50,100) starts where B
+    finishes, exactly on the cut."""
+    from wiggletools_amd.runlists import RunLists
+    monkeypatch.setenv("WTAMD_MIN_SPAN", "49")       # first batch = run starts in [1, 50)
+    monkeypatch.setenv("WTAMD_BATCH_INTERVALS", "1")
+    t = RunLists.from_lists([[[(1, 100, 2.0)]], [[(10, 50, 4.0)]]])
+    got = H.reduce(t.as_dict(), "sum")
+    assert got[1].tolist() == [1, 10, 50] and got[2].tolist() == [10, 50, 100]
+    assert got[3].tolist() == [2.0, 6.0, 2.0]
+
+
+def test_dropin_float64_switch(oracle, H, tiny_batches):
+    """Values are staged as float32 until one is not float32-exact; from then on float64."""
+    from wiggletools_amd.runlists import synth
+    t = synth(4, [3000], mean_run=6, seed=5, dtype=np.float64)
+    t.value[len(t.value) // 2] = 0.1            # not float32-exact, in the middle of a track
+    t.value[-3] = 1e-300
+    d = t.as_dict()
+    for op in ("sum", "mean", "median", "stddev"):
+        assert_runs_equal(H.reduce(d, op), oracle.reduce(d, op), _tol(op), op)
+
+
+def test_dropin_ctor_defaults(oracle, H):
+    for dv in (np.zeros(3), np.array([1.0, 2.0, 3.5]), np.array([1.0, np.nan, 2.0])):
+        for op in ALL_MULTIPLEX_OPS:
+            a, b = H.reducer_default(op, dv), oracle.reducer_default(op, dv)
+            assert (np.isnan(a) and np.isnan(b)) or a == b, (op, dv)

@@ -636,6 +636,10 @@ struct WtWindows {
     int32_t *d_bad_list = nullptr;      // difference-array launches: windows not provably exact ...
     long long *d_bad_goff = nullptr;    // ... and where their runs start (both [n_windows])
     bool indexed = false;
+    // capacities of the device tables (entries); the tables are reused and only ever grow
+    int64_t cap_chrom = 0, cap_win = 0, cap_widx = 0, cap_bad = 0;
+    bool tab_valid = false;             // tab / device tables describe the track set's current data
+    int64_t *h_tab = nullptr;           // pinned staging of the per-chromosome tables (pipeline slots: asynchronous upload)
 };
 
 struct wtamd_trackset {
@@ -668,11 +672,29 @@ struct wtamd_trackset {
     bool delta_failed = false;                  // many windows are not provably exact: Sum / Mean use the general kernel
     bool delta_verified = false;                // verdict known: delta_n_bad windows (few) get patched by the general kernel
     long long delta_n_bad = 0;
+    // pipeline slot (wt_pipe.h): the run lists are rebound per batch, device tables are reused,
+    // every upload is asynchronous on the launch stream from pinned staging
+    bool pipe_mode = false;
 };
+
+template <class T>
+static hipError_t wt_grow(T **p, int64_t *cap, int64_t need) {
+    if (*cap >= need && *p) return hipSuccess;
+    int64_t c = *cap * 2;
+    if (c < need) c = need;
+    if (c < 1) c = 1;
+    (void) hipFree(*p);
+    *p = nullptr; *cap = 0;
+    const hipError_t e = hipMalloc((void **) p, sizeof(T) * (size_t) c);
+    if (e == hipSuccess) *cap = c;
+    return e;
+}
 
 static void wt_free_windows(WtWindows &w) {
     (void) hipFree(w.d_cbase); (void) hipFree(w.d_cnwin); (void) hipFree(w.d_chi); (void) hipFree(w.d_win_chrom); (void) hipFree(w.d_cfirst);
     (void) hipFree(w.d_widx); (void) hipFree(w.d_status); (void) hipFree(w.d_bad_list); (void) hipFree(w.d_bad_goff);
+    if (w.h_tab) (void) hipHostFree(w.h_tab);
+    w = WtWindows();
 }
 
 extern "C" {
@@ -736,18 +758,34 @@ static int wt_check_extents(wtamd_trackset *ts) {
     for (size_t q = 0; q < ts->last_finish.size(); q++)
         if (ts->seg_off[q + 1] > ts->seg_off[q] && ts->last_finish[q] > WTAMD_MAX_COORD) {
             const int64_t bad = ts->last_finish[q];
-            wtamd_trackset_destroy(ts);
             return wt_fail(WTAMD_ERR_ARG, "run finish " + std::to_string(bad) + " above the supported maximum " +
                            std::to_string((long long) WTAMD_MAX_COORD) + " (2^31 - 65537)");
         }
     return WTAMD_OK;
 }
 
-int wtamd_trackset_create_host(const wtamd_tracks *t, wtamd_trackset **out) {
-    if (!out) return wt_fail(WTAMD_ERR_ARG, "out == NULL");
-    wtamd_trackset *ts = new wtamd_trackset();
+// Device-side (first start, last finish) of every (chrom, track) segment into the host copies.
+static int wt_refresh_extents_device(wtamd_trackset *ts) {
+    const int64_t n_seg = (int64_t) ts->n_chrom * ts->n_tracks;
+    ts->first_start.assign(n_seg, 0);
+    ts->last_finish.assign(n_seg, 0);
+    if (n_seg > 0 && ts->n_intervals > 0) {
+        int32_t *d_fs = nullptr, *d_lf = nullptr;
+        WtDevScope scope;
+        WT_HIP(scope.alloc(&d_fs, sizeof(int32_t) * n_seg));
+        WT_HIP(scope.alloc(&d_lf, sizeof(int32_t) * n_seg));
+        hipLaunchKernelGGL(wt_extents_kernel, dim3((unsigned) ((n_seg + 255) / 256)), dim3(256), 0, 0,
+                           ts->d_seg_off, ts->d_start, ts->d_finish, (long long) n_seg, d_fs, d_lf);
+        WT_HIP(hipGetLastError());
+        WT_HIP(hipMemcpy(ts->first_start.data(), d_fs, sizeof(int32_t) * n_seg, hipMemcpyDeviceToHost));
+        WT_HIP(hipMemcpy(ts->last_finish.data(), d_lf, sizeof(int32_t) * n_seg, hipMemcpyDeviceToHost));
+    }
+    return WTAMD_OK;
+}
+
+static int wt_create_host_impl(const wtamd_tracks *t, wtamd_trackset *ts) {
     int rc = wt_trackset_common(t, ts);
-    if (rc != WTAMD_OK) { wtamd_trackset_destroy(ts); return rc; }
+    if (rc != WTAMD_OK) return rc;
     ts->owns = true;
     const int64_t n = ts->n_intervals;
     const size_t vsz = ts->value_f64 ? 8 : 4;
@@ -756,7 +794,7 @@ int wtamd_trackset_create_host(const wtamd_tracks *t, wtamd_trackset **out) {
     WT_HIP(hipMalloc(&ts->d_finish, sizeof(int32_t) * n_alloc));
     WT_HIP(hipMalloc(&ts->d_value, vsz * n_alloc));
     if (n > 0) {
-        if (!t->start || !t->finish || !t->value) { wtamd_trackset_destroy(ts); return wt_fail(WTAMD_ERR_ARG, "NULL arrays"); }
+        if (!t->start || !t->finish || !t->value) return wt_fail(WTAMD_ERR_ARG, "NULL arrays");
         WT_HIP(hipMemcpy(ts->d_start, t->start, sizeof(int32_t) * n, hipMemcpyHostToDevice));
         WT_HIP(hipMemcpy(ts->d_finish, t->finish, sizeof(int32_t) * n, hipMemcpyHostToDevice));
         WT_HIP(hipMemcpy(ts->d_value, t->value, vsz * n, hipMemcpyHostToDevice));
@@ -769,37 +807,35 @@ int wtamd_trackset_create_host(const wtamd_tracks *t, wtamd_trackset **out) {
             ts->first_start[s] = t->start[ts->seg_off[s]];
             ts->last_finish[s] = t->finish[ts->seg_off[s + 1] - 1];
         }
-    rc = wt_check_extents(ts);
-    if (rc != WTAMD_OK) return rc;
+    return wt_check_extents(ts);
+}
+
+int wtamd_trackset_create_host(const wtamd_tracks *t, wtamd_trackset **out) {
+    if (!out) return wt_fail(WTAMD_ERR_ARG, "out == NULL");
+    wtamd_trackset *ts = new wtamd_trackset();
+    const int rc = wt_create_host_impl(t, ts);
+    if (rc != WTAMD_OK) { wtamd_trackset_destroy(ts); return rc; }     // every failing path releases what was allocated
     *out = ts;
     return WTAMD_OK;
+}
+
+static int wt_create_device_impl(const wtamd_tracks *t, wtamd_trackset *ts) {
+    int rc = wt_trackset_common(t, ts);
+    if (rc != WTAMD_OK) return rc;
+    ts->owns = false;
+    ts->d_start = const_cast<int32_t *>(t->start);
+    ts->d_finish = const_cast<int32_t *>(t->finish);
+    ts->d_value = const_cast<void *>(t->value);
+    rc = wt_refresh_extents_device(ts);
+    if (rc != WTAMD_OK) return rc;
+    return wt_check_extents(ts);
 }
 
 int wtamd_trackset_create_device(const wtamd_tracks *t, wtamd_trackset **out) {
     if (!out) return wt_fail(WTAMD_ERR_ARG, "out == NULL");
     wtamd_trackset *ts = new wtamd_trackset();
-    int rc = wt_trackset_common(t, ts);
+    const int rc = wt_create_device_impl(t, ts);
     if (rc != WTAMD_OK) { wtamd_trackset_destroy(ts); return rc; }
-    ts->owns = false;
-    ts->d_start = const_cast<int32_t *>(t->start);
-    ts->d_finish = const_cast<int32_t *>(t->finish);
-    ts->d_value = const_cast<void *>(t->value);
-    const int64_t n_seg = (int64_t) ts->n_chrom * ts->n_tracks;
-    ts->first_start.assign(n_seg, 0);
-    ts->last_finish.assign(n_seg, 0);
-    if (n_seg > 0 && ts->n_intervals > 0) {
-        int32_t *d_fs = nullptr, *d_lf = nullptr;
-        WT_HIP(hipMalloc(&d_fs, sizeof(int32_t) * n_seg));
-        WT_HIP(hipMalloc(&d_lf, sizeof(int32_t) * n_seg));
-        hipLaunchKernelGGL(wt_extents_kernel, dim3((unsigned) ((n_seg + 255) / 256)), dim3(256), 0, 0,
-                           ts->d_seg_off, ts->d_start, ts->d_finish, (long long) n_seg, d_fs, d_lf);
-        WT_HIP(hipGetLastError());
-        WT_HIP(hipMemcpy(ts->first_start.data(), d_fs, sizeof(int32_t) * n_seg, hipMemcpyDeviceToHost));
-        WT_HIP(hipMemcpy(ts->last_finish.data(), d_lf, sizeof(int32_t) * n_seg, hipMemcpyDeviceToHost));
-        (void) hipFree(d_fs); (void) hipFree(d_lf);
-    }
-    rc = wt_check_extents(ts);
-    if (rc != WTAMD_OK) return rc;
     *out = ts;
     return WTAMD_OK;
 }
@@ -841,31 +877,57 @@ int64_t wtamd_trackset_max_runs(const wtamd_trackset *ts) {
     return std::min<int64_t>(2 * ts->n_intervals, wt_span(ts));
 }
 
-static int wt_get_windows(wtamd_trackset *ts, int W, WtWindows **out) {
-    auto it = ts->windows.find(W);
-    if (it != ts->windows.end()) { *out = &it->second; return WTAMD_OK; }
-    WtWindows w;
+// Window tables of width W for the track set's current data.  The device tables are kept and
+// reused (they only ever grow); a pipeline slot uploads them asynchronously on `s` from pinned
+// staging (its per-batch data is one chromosome: four scalars and an all-zero win_chrom[]).
+static int wt_get_windows(wtamd_trackset *ts, int W, WtWindows **out, hipStream_t s = nullptr) {
+    WtWindows &w = ts->windows[W];
+    *out = &w;
+    if (w.tab_valid) return WTAMD_OK;
     wt_make_windows(ts->n_chrom, ts->n_tracks, ts->seg_off.data(), ts->first_start.data(), ts->last_finish.data(), W, w.tab,
                     ts->range_lo.empty() ? nullptr : ts->range_lo.data(),
                     ts->range_hi.empty() ? nullptr : ts->range_hi.data());
-    const int nc = ts->n_chrom > 0 ? ts->n_chrom : 1;
+    w.indexed = false;
+    const int64_t nc = ts->n_chrom > 0 ? ts->n_chrom : 1;
     const int64_t nwin = w.tab.n_windows > 0 ? w.tab.n_windows : 1;
-    WT_HIP(hipMalloc(&w.d_cbase, sizeof(int32_t) * nc));
-    WT_HIP(hipMalloc(&w.d_cnwin, sizeof(int32_t) * nc));
-    WT_HIP(hipMalloc(&w.d_chi, sizeof(int32_t) * nc));
-    WT_HIP(hipMalloc(&w.d_cfirst, sizeof(int64_t) * (nc + 1)));
-    WT_HIP(hipMalloc(&w.d_win_chrom, sizeof(int32_t) * nwin));
-    WT_HIP(hipMalloc(&w.d_widx, sizeof(uint32_t) * (size_t) (w.tab.n_rows > 0 ? w.tab.n_rows : 1) * ts->n_tracks));
-    WT_HIP(hipMalloc(&w.d_status, sizeof(unsigned long long) * nwin));
-    if (ts->n_chrom > 0) {
-        WT_HIP(hipMemcpy(w.d_cbase, w.tab.cbase.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
-        WT_HIP(hipMemcpy(w.d_cnwin, w.tab.c_nwin.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
-        WT_HIP(hipMemcpy(w.d_chi, w.tab.c_hi.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
-        WT_HIP(hipMemcpy(w.d_cfirst, w.tab.c_first_win.data(), sizeof(int64_t) * (ts->n_chrom + 1), hipMemcpyHostToDevice));
-        WT_HIP(hipMemcpy(w.d_win_chrom, w.tab.win_chrom.data(), sizeof(int32_t) * w.tab.n_windows, hipMemcpyHostToDevice));
+    const int64_t nwidx = (w.tab.n_rows > 0 ? w.tab.n_rows : 1) * (int64_t) ts->n_tracks;
+    if (w.cap_chrom < nc) {
+        (void) hipFree(w.d_cbase); (void) hipFree(w.d_cnwin); (void) hipFree(w.d_chi); (void) hipFree(w.d_cfirst);
+        w.d_cbase = w.d_cnwin = w.d_chi = nullptr; w.d_cfirst = nullptr; w.cap_chrom = 0;
+        WT_HIP(hipMalloc(&w.d_cbase, sizeof(int32_t) * nc));
+        WT_HIP(hipMalloc(&w.d_cnwin, sizeof(int32_t) * nc));
+        WT_HIP(hipMalloc(&w.d_chi, sizeof(int32_t) * nc));
+        WT_HIP(hipMalloc(&w.d_cfirst, sizeof(int64_t) * (nc + 1)));
+        w.cap_chrom = nc;
     }
-    ts->windows[W] = w;
-    *out = &ts->windows[W];
+    if (w.cap_win < nwin) {
+        int64_t c1 = w.cap_win, c2 = w.cap_win;
+        WT_HIP(wt_grow(&w.d_win_chrom, &c1, nwin));
+        WT_HIP(wt_grow(&w.d_status, &c2, nwin));
+        w.cap_win = c1 < c2 ? c1 : c2;
+    }
+    WT_HIP(wt_grow(&w.d_widx, &w.cap_widx, nwidx));
+    if (ts->n_chrom > 0) {
+        if (ts->pipe_mode) {
+            if (ts->n_chrom != 1) return wt_fail(WTAMD_ERR_INTERNAL, "pipeline slots hold one chromosome");
+            if (!w.h_tab) WT_HIP(hipHostMalloc((void **) &w.h_tab, 64, hipHostMallocDefault));
+            int32_t *h32 = (int32_t *) w.h_tab;
+            h32[0] = w.tab.cbase[0]; h32[1] = w.tab.c_nwin[0]; h32[2] = w.tab.c_hi[0];
+            w.h_tab[2] = w.tab.c_first_win[0]; w.h_tab[3] = w.tab.c_first_win[1];
+            WT_HIP(hipMemcpyAsync(w.d_cbase, h32 + 0, sizeof(int32_t), hipMemcpyHostToDevice, s));
+            WT_HIP(hipMemcpyAsync(w.d_cnwin, h32 + 1, sizeof(int32_t), hipMemcpyHostToDevice, s));
+            WT_HIP(hipMemcpyAsync(w.d_chi, h32 + 2, sizeof(int32_t), hipMemcpyHostToDevice, s));
+            WT_HIP(hipMemcpyAsync(w.d_cfirst, w.h_tab + 2, 2 * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            WT_HIP(hipMemsetAsync(w.d_win_chrom, 0, sizeof(int32_t) * (size_t) nwin, s));
+        } else {
+            WT_HIP(hipMemcpy(w.d_cbase, w.tab.cbase.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
+            WT_HIP(hipMemcpy(w.d_cnwin, w.tab.c_nwin.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
+            WT_HIP(hipMemcpy(w.d_chi, w.tab.c_hi.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
+            WT_HIP(hipMemcpy(w.d_cfirst, w.tab.c_first_win.data(), sizeof(int64_t) * (ts->n_chrom + 1), hipMemcpyHostToDevice));
+            WT_HIP(hipMemcpy(w.d_win_chrom, w.tab.win_chrom.data(), sizeof(int32_t) * w.tab.n_windows, hipMemcpyHostToDevice));
+        }
+    }
+    w.tab_valid = true;
     return WTAMD_OK;
 }
 
@@ -918,12 +980,21 @@ int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
     ts->delta_failed = false;
     ts->delta_n_bad = 0;
     for (auto &kv : ts->windows) kv.second.indexed = false;     // every width's index describes the old data
+    if (!ts->owns && !ts->pipe_mode) {
+        // zero-copy track set rewritten in place: its runs may start earlier / end later than
+        // before, so the extents, their check and every width's window tables are rebuilt too
+        int rce = wt_refresh_extents_device(ts);
+        if (rce != WTAMD_OK) return rce;
+        rce = wt_check_extents(ts);
+        if (rce != WTAMD_OK) return rce;
+        for (auto &kv : ts->windows) kv.second.tab_valid = false;
+    }
     WtPlan plan;
     std::string err;
     if (wt_wants_delta(ts, op)) wt_make_delta_plan(plan, ts->n_tracks);
     else if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
     WtWindows *w = nullptr;
-    int rc = wt_get_windows(ts, plan.W, &w);
+    int rc = wt_get_windows(ts, plan.W, &w, (hipStream_t) stream);
     if (rc != WTAMD_OK) return rc;
     return wt_build_index(ts, w, plan, (hipStream_t) stream);
 }
@@ -1041,9 +1112,9 @@ static int wt_launch_patch(wtamd_trackset *ts, int delta_W, int op, uint32_t fla
     if (plan.scratch_slab > 0 || plan.W > delta_W || delta_W % plan.W != 0 || !ts->scratch_f32 || ts->value_f64)
         return wt_fail(WTAMD_ERR_INTERNAL, "no general plan compatible with the difference-array windows");
     WtWindows *dw = nullptr, *w = nullptr;
-    int rc = wt_get_windows(ts, delta_W, &dw);
+    int rc = wt_get_windows(ts, delta_W, &dw, s);
     if (rc != WTAMD_OK) return rc;
-    rc = wt_get_windows(ts, plan.W, &w);
+    rc = wt_get_windows(ts, plan.W, &w, s);
     if (rc != WTAMD_OK) return rc;
     if (!w->indexed) {
         rc = wt_build_index(ts, w, plan, s);
@@ -1127,7 +1198,7 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
                           double *d_tile, uint8_t *d_inplay, int64_t *n_runs, hipStream_t s) {
     if (plan.T > WT_MAX_BLOCK) return wt_fail(WTAMD_ERR_ARG, "workgroup size above 512");
     WtWindows *w = nullptr;
-    int rc = wt_get_windows(ts, plan.W, &w);
+    int rc = wt_get_windows(ts, plan.W, &w, s);
     if (rc != WTAMD_OK) return rc;
     if (!w->indexed) {
         rc = wt_build_index(ts, w, plan, s);
@@ -1143,9 +1214,13 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
     L.T = plan.T; L.lds = plan.lds_bytes; L.stream = s; L.num_cu = ts->num_cu;
     L.gscratch = &ts->d_gscratch; L.gscratch_bytes = &ts->gscratch_bytes;
     if (plan.delta) {
-        const size_t nwin = (size_t) (w->tab.n_windows > 0 ? w->tab.n_windows : 1);
-        if (!w->d_bad_list) WT_HIP(hipMalloc(&w->d_bad_list, sizeof(int32_t) * nwin));
-        if (!w->d_bad_goff) WT_HIP(hipMalloc(&w->d_bad_goff, sizeof(long long) * nwin));
+        const int64_t nwin = w->tab.n_windows > 0 ? w->tab.n_windows : 1;
+        if (w->cap_bad < nwin) {
+            int64_t c1 = w->cap_bad, c2 = w->cap_bad;
+            WT_HIP(wt_grow(&w->d_bad_list, &c1, nwin));
+            WT_HIP(wt_grow(&w->d_bad_goff, &c2, nwin));
+            w->cap_bad = c1 < c2 ? c1 : c2;
+        }
         L.P.bad_list = w->d_bad_list;
         L.P.bad_goff = w->d_bad_goff;
     }
@@ -1368,3 +1443,5 @@ int wtamd_get_stats(const wtamd_trackset *ts_c, wtamd_stats *out) {
 }
 
 }  // extern "C"
+
+#include "wt_pipe.h"

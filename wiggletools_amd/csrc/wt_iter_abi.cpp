@@ -1,30 +1,37 @@
 // wt_iter_abi.cpp -- DROP-IN LAYER: the reference's own C API for the hot path
 // (reference src/wiggletools.h:80-103, src/multiplexer.h:38-41, src/multiSet.h:32-33),
-// implemented on top of the bulk GPU engine (wtamd_*).  Host-side C++ above the
-// C ABI, mirroring the reference's names, argument meaning and error behaviour
-// (message to stdout/stderr, then exit(1)).
+// implemented on top of the streaming pipeline of the bulk GPU engine (wtamd_pipe_*).
+// Host-side C++ above the C ABI, mirroring the reference's names, argument meaning and
+// error behaviour (message to stdout/stderr, then exit(1)).
 //
 // How a lazy pull API is fed to a bulk engine:
-//   * a Drainer pops the N child iterators (each from ONE thread, as the
-//     reference requires) into a host SoA batch: one chromosome, run starts in
-//     [lo, hi).  An interval that crosses `hi` is carried into the next batch;
-//     one interval beyond `hi` per track is included as a sentinel so the last
-//     run of the batch gets its true finish (no seam artefacts, coordinates stay
-//     bit-exact).  Batches grow geometrically (2 Kbp -> ~4 M intervals).
-//   * popMultiplexer() walks the run tile the GPU materialised for the batch
-//     and keeps every field of struct multiplexer_st coherent (other reference
-//     translation units read them: mWigWriter.c:182-197, statistics.c:432-442).
-//   * a reducer constructor (MeanReduction, ...) takes the Multiplexer over: the
-//     first (tiny, already drained) batch is pushed back and from then on whole
-//     batches go through the FUSED multiplex+reduce kernel; the Multiplexer's
-//     per-run fields are then no longer maintained (allowed when the
-//     reducer owns the multiplexer, which is how commandParser.c builds them).
-//   * TTestReduction / MWUReduction take over both Multiplexers of the Multiset
-//     and run the two-sample kernels over the joint track list.
+//   * a Drainer pops the N child iterators (each from ONE thread, as the reference
+//     requires) straight into the PINNED staging arrays of a pipeline slot: one
+//     chromosome, run starts in [lo, hi).  An interval that reaches `hi` (finish >= hi)
+//     stays the current element of its source and is seen again by the next batch -- so a
+//     track finishing exactly at the cut still marks the breakpoint there; one interval
+//     beyond `hi` per track is included as a sentinel so the last run of the batch gets its
+//     true finish (no seam artefacts, coordinates stay bit-exact).  Values are staged as
+//     float32 until a value that is not float32-exact shows up (then float64, for good).
+//   * a Feeder keeps the pipeline `depth` batches deep: while the consumer walks the runs
+//     of batch k (pinned output), batch k+1 is on the GPU and the Drainer has already
+//     filled and shipped it -- the overlap the reference gets from its producer threads
+//     (bufferedReader.c:41-55,99-109), here across host, PCIe and GPU.
+//   * popMultiplexer() walks the run tile the GPU materialised for the batch and keeps
+//     every field of struct multiplexer_st coherent (other reference translation units
+//     read them: mWigWriter.c:182-197, statistics.c:432-442).  The tile batches are sized
+//     by runs x tracks, so memory stays bounded whatever the track count.
+//   * a reducer constructor (MeanReduction, ...) takes the Multiplexer over: what the
+//     Multiplexer had drained is pushed back and from then on whole batches go through
+//     the FUSED multiplex+reduce kernel; the Multiplexer's per-run fields are then no
+//     longer maintained (allowed when the reducer owns the multiplexer, which
+//     is how commandParser.c builds them).
+//   * TTestReduction / MWUReduction take over both Multiplexers of the Multiset and run
+//     the two-sample kernels over the joint track list.
 //
-// There is no CPU evaluation path here: every run, aligned tile or reduced
-// value comes from the HIP kernels.  If no GPU is present the first engine call
-// fails and the process exits(1) with the engine's message.
+// There is no CPU evaluation path here: every run, aligned tile or reduced value comes
+// from the HIP kernels.  If no GPU is present the first engine call fails and the
+// process exits(1) with the engine's message.
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -44,224 +51,323 @@ namespace {
     exit(1);
 }
 
+int64_t env_i64(const char *name, int64_t dflt) {
+    const char *e = getenv(name);
+    if (!e || !*e) return dflt;
+    const long long v = atoll(e);
+    return v > 0 ? (int64_t) v : dflt;
+}
+
 struct Ivl {
-    char *chrom;
+    const char *chrom;      // interned
     int32_t start, finish;
     double value;
+};
+
+// Chromosome names are interned once per distinct name: child readers only promise a stable
+// `char *` while they stay on a chromosome (bedReader.c:62-68 allocates a fresh string per
+// chromosome, others may reuse a buffer), whereas the pointers this layer hands out are printed
+// later by writer threads (wigWriter.c:175) and compared by identity (unaryOps.c:76).
+struct Interner {
+    std::vector<char *> names;
+    const char *get(const char *raw) {
+        for (char *n : names)
+            if (strcmp(n, raw) == 0) return n;
+        names.push_back(strdup(raw));
+        return names.back();
+    }
 };
 
 // One child iterator plus intervals that were popped from it but pushed back.
 struct TrackSource {
     WiggleIterator *it = nullptr;
-    std::deque<Ivl> pending;
+    std::deque<Ivl> pending;        // pushed back (take-over); precede the iterator's current element
+    std::deque<Ivl> log;            // consumed by batches not yet handed to the consumer (Multiplexer mode)
+    const char *raw = nullptr;      // last chrom pointer seen on `it` ...
+    const char *interned = nullptr; // ... and its interned name
 
+    const char *it_chrom(Interner &in) {
+        if (it->chrom != raw || !interned) { raw = it->chrom; interned = in.get(raw); }
+        return interned;
+    }
     bool empty() const { return pending.empty() && it->done; }
-    Ivl head() const {
-        if (!pending.empty()) return pending.front();
-        Ivl v = { it->chrom, it->start, it->finish, it->value };
-        return v;
-    }
-    void advance() {
-        if (!pending.empty()) pending.pop_front();
-        else pop(it);
-    }
 };
 
-const int64_t kTargetIntervals = 4 << 20;   // intervals per steady-state batch
-const int64_t kFirstSpan = 2048;            // bp of the priming batch
+const int64_t kFirstSpan = 2048;            // bp of a Multiplexer's priming batch
+const int64_t kReducerFirstSpan = 65536;    // bp of a reducer's first batch
 
-struct Drainer {
+// Drains the children into pipeline slots and keeps `depth` batches in flight.
+struct Feeder {
     std::vector<TrackSource> src;
     std::vector<double> defaults;
-    // current batch (one chromosome)
-    char *chrom = nullptr;
-    int32_t lo = 0, hi = 0;
-    std::vector<int64_t> seg_off;
-    std::vector<int32_t> start, finish;
-    std::vector<double> value;
-    std::vector<float> value32;
-    std::vector<char> popped;       // per interval: 0 sentinel (still in the source), 1 consumed,
-                                    // 2 consumed but already requeued because it crosses `hi`
-    bool all_f32 = true;
-    bool have = false;
-    // continuation state
-    bool continuing = false;        // next batch continues `chrom` at `hi`
-    int64_t span = kFirstSpan;
+    Interner names;
+    wtamd_pipe *pipe = nullptr;
+    int64_t max_runs = 0;               // output capacity of a slot = upper bound of hi - lo
+    int64_t target = 0;                 // intervals per steady-state batch
+    int depth = 1;                      // batches kept in flight
+    bool keep_log = false;              // Multiplexer mode: remember what was consumed (take-over pushes it back)
+    bool f64_mode = false;              // a value that is not float32-exact was seen
+    // drain position
+    const char *chrom = nullptr;        // chromosome of the batch being / last drained
+    bool continuing = false;            // next batch continues `chrom` at next_lo
+    int32_t next_lo = 0;
+    int64_t span = kFirstSpan, min_span = kFirstSpan;
+    // batches in flight, oldest first
+    struct Flight { const char *chrom; std::vector<int32_t> consumed; };
+    std::deque<Flight> flights;
+    bool holding = false;               // front flight was collected and is being read
+    wtamd_pipe_result res{};
+    const char *res_chrom = nullptr;
 
     int n_tracks() const { return (int) src.size(); }
 
-    // Pushes the current batch back so that another consumer can start over from it.
-    void rewind() {
-        if (!have) return;
-        for (int i = n_tracks() - 1; i >= 0; i--) {
-            for (int64_t g = seg_off[i + 1] - 1; g >= seg_off[i]; g--) {
-                if (popped[g] != 1) continue;
-                Ivl v = { chrom, start[g], finish[g], value[g] };
-                src[i].pending.push_front(v);
-            }
+    void open(const wtamd_reduce_desc &desc, int64_t max_runs_, int n_slots, int64_t first_span) {
+        wtamd_pipe_config cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.n_tracks = n_tracks();
+        cfg.n_slots = n_slots;
+        cfg.defaults = defaults.data();
+        cfg.desc = desc;
+        cfg.max_intervals = 1 << 16;
+        cfg.max_runs = max_runs_;
+        max_runs = max_runs_;
+        target = env_i64("WTAMD_BATCH_INTERVALS", 4 << 20);
+        min_span = env_i64("WTAMD_MIN_SPAN", kFirstSpan);       // tests cut every few bp to stress the seams
+        if (getenv("WTAMD_MIN_SPAN")) first_span = min_span;
+        span = first_span < max_runs ? first_span : max_runs;
+        if (wtamd_pipe_create(&cfg, &pipe) != WTAMD_OK) die("wtamd_pipe_create");
+    }
+
+    void close() {
+        if (pipe) wtamd_pipe_destroy(pipe);
+        pipe = nullptr;
+    }
+
+    // Throws away everything in flight (results included).
+    void drop_flights() {
+        if (!pipe) return;
+        if (holding) { wtamd_pipe_release(pipe); holding = false; flights.pop_front(); }
+        while (!flights.empty()) {
+            wtamd_pipe_result r;
+            if (wtamd_pipe_collect(pipe, &r) != WTAMD_OK) die("wtamd_pipe_collect");
+            wtamd_pipe_release(pipe);
+            flights.pop_front();
         }
-        have = false;
+    }
+
+    // Take-over: everything drained but not yet consumed by a reducer goes back to the sources.
+    // (A Multiplexer is taken over right after its constructor primed it, commandParser.c:500-569;
+    // the reducer then starts from the Multiplexer's first run, as in the reference.)
+    void rewind() {
+        drop_flights();
+        for (auto &s : src) {
+            while (!s.log.empty()) { s.pending.push_front(s.log.back()); s.log.pop_back(); }
+        }
         continuing = false;
-        span = kFirstSpan;
     }
 
     void reset() {      // after seek: forget everything that was buffered
-        for (auto &s : src) s.pending.clear();
-        have = false;
+        drop_flights();
+        for (auto &s : src) { s.pending.clear(); s.log.clear(); s.raw = nullptr; s.interned = nullptr; }
         continuing = false;
-        span = kFirstSpan;
     }
 
-    bool next_batch() {
+    // Fills one slot with the next batch and ships it.  False: the sources are exhausted.
+    bool drain_and_submit() {
         const int N = n_tracks();
-        have = false;
-        // chromosome and range start
+        int32_t lo;
         if (continuing) {
-            lo = hi;
+            lo = next_lo;
         } else {
             chrom = nullptr;
             for (int i = 0; i < N; i++) {
-                if (src[i].empty()) continue;
-                char *c = src[i].head().chrom;
+                TrackSource &s = src[i];
+                if (s.empty()) continue;
+                const char *c = s.pending.empty() ? s.it_chrom(names) : s.pending.front().chrom;
                 if (!chrom || strcmp(c, chrom) < 0) chrom = c;     // multiplexer.c:56
             }
             if (!chrom) return false;
             int64_t m = INT32_MAX;
             for (int i = 0; i < N; i++) {
-                if (src[i].empty()) continue;
-                Ivl h = src[i].head();
-                if (strcmp(h.chrom, chrom) == 0 && h.start < m) m = h.start;
+                TrackSource &s = src[i];
+                if (s.empty()) continue;
+                const char *c = s.pending.empty() ? s.it_chrom(names) : s.pending.front().chrom;
+                const int32_t st = s.pending.empty() ? s.it->start : s.pending.front().start;
+                if (c == chrom && st < m) m = st;
             }
             lo = (int32_t) m;
         }
         const int64_t hi64 = (int64_t) lo + span;
-        hi = hi64 >= INT32_MAX ? INT32_MAX : (int32_t) hi64;
+        const int32_t hi = hi64 >= INT32_MAX ? INT32_MAX : (int32_t) hi64;
 
-        seg_off.assign(1, 0);
-        start.clear(); finish.clear(); value.clear(); popped.clear();
-        all_f32 = true;
-        bool more = false;
-        for (int i = 0; i < N; i++) {
-            TrackSource &s = src[i];
-            while (!s.empty()) {
-                Ivl h = s.head();
-                if (h.chrom != chrom && strcmp(h.chrom, chrom) != 0) break;
-                const bool inside = h.start < hi;
-                start.push_back(h.start); finish.push_back(h.finish); value.push_back(h.value);
-                popped.push_back(inside ? 1 : 0);
-                if (all_f32 && !(std::isnan(h.value) || (double) (float) h.value == h.value)) all_f32 = false;
-                if (!inside) { more = true; break; }          // sentinel: stays in the source
-                s.advance();
-                if (h.finish > hi) {                          // crosses the cut: needed again next time
-                    popped.back() = 2;
-                    s.pending.push_front(h);
-                    more = true;
-                    // make sure it is not drained twice in this batch
-                    break;
+        wtamd_pipe_batch b;
+        if (wtamd_pipe_acquire(pipe, &b) != WTAMD_OK) die("wtamd_pipe_acquire");
+        if (f64_mode && !b.value64 && wtamd_pipe_grow(pipe, 0, b.capacity, 1, &b) != WTAMD_OK) die("wtamd_pipe_grow");
+        Flight fl;
+        fl.chrom = chrom;
+        if (keep_log) fl.consumed.assign((size_t) N, 0);
+        int64_t n = 0;
+        bool carry = false, more = false;
+        int64_t sentinel_lo = INT32_MAX;
+
+        auto put = [&](int32_t st, int32_t fi, double v) {
+            if (n == b.capacity && wtamd_pipe_grow(pipe, n, 2 * b.capacity, f64_mode, &b) != WTAMD_OK) die("wtamd_pipe_grow");
+            b.start[n] = st;
+            b.finish[n] = fi;
+            if (f64_mode) {
+                b.value64[n] = v;
+            } else {
+                const float f = (float) v;
+                if ((double) f != v && v == v) {        // not float32-exact (NaN is): float64 from here on
+                    if (wtamd_pipe_grow(pipe, n, b.capacity, 1, &b) != WTAMD_OK) die("wtamd_pipe_grow");
+                    for (int64_t k = 0; k < n; k++) b.value64[k] = (double) b.value32[k];
+                    f64_mode = true;
+                    b.value64[n] = v;
+                } else {
+                    b.value32[n] = f;
                 }
             }
-            seg_off.push_back((int64_t) start.size());
+            n++;
+        };
+
+        for (int i = 0; i < N; i++) {
+            TrackSource &s = src[i];
+            b.seg_off[i] = n;
+            bool stop = false;
+            while (!s.pending.empty()) {
+                const Ivl h = s.pending.front();
+                if (h.chrom != chrom) { stop = true; break; }
+                put(h.start, h.finish, h.value);
+                if (h.start >= hi) { more = true; if (h.start < sentinel_lo) sentinel_lo = h.start; stop = true; break; }
+                if (h.finish >= hi) { more = carry = true; stop = true; break; }     // reaches the cut: seen again
+                if (keep_log) { s.log.push_back(h); fl.consumed[i]++; }
+                s.pending.pop_front();
+            }
+            if (stop) continue;
+            WiggleIterator *it = s.it;
+            while (!it->done) {
+                if (s.it_chrom(names) != chrom) break;
+                const int32_t st = it->start, fi = it->finish;
+                put(st, fi, it->value);
+                if (st >= hi) { more = true; if (st < sentinel_lo) sentinel_lo = st; break; }   // sentinel: stays current
+                if (fi >= hi) { more = carry = true; break; }                                    // reaches the cut: stays current
+                if (keep_log) { Ivl h = { chrom, st, fi, it->value }; s.log.push_back(h); fl.consumed[i]++; }
+                it->pop(it);
+            }
         }
-        // a carried interval sits at the front of `pending` with start < hi: next batch must not
-        // stop at it as a "sentinel" -- it is taken because its start < new hi as well.
+        b.seg_off[N] = n;
+        if (wtamd_pipe_submit(pipe, f64_mode ? 1 : 0, lo, hi) != WTAMD_OK) die("wtamd_pipe_submit");
+        flights.push_back(std::move(fl));
+        // where the next batch starts: at the cut if an interval reaches it, else at the first
+        // interval beyond it (no track is in play in between: no run can start there)
         continuing = more;
-        have = true;
-        // grow / shrink towards the interval budget
-        const int64_t n = (int64_t) start.size();
-        if (n < kTargetIntervals / 2 && span < ((int64_t) 1 << 31)) span *= 2;
-        else if (n > kTargetIntervals * 2 && span > kFirstSpan) span /= 2;
-        if (all_f32) {
-            value32.resize(value.size());
-            for (size_t k = 0; k < value.size(); k++) value32[k] = (float) value[k];
+        next_lo = carry ? hi : (int32_t) sentinel_lo;
+        // steer the span towards the interval budget, bounded by the slot's output capacity
+        const int64_t max_span = max_runs < ((int64_t) 1 << 31) ? max_runs : ((int64_t) 1 << 31);
+        int64_t want = span * 2;
+        if (n > 0) {
+            const double per_bp = (double) n / (double) ((int64_t) hi - lo);
+            const double w = (double) target / per_bp;
+            want = w > 4e9 ? (int64_t) 4e9 : (int64_t) w;
+            if (want > span * 8) want = span * 8;
         }
+        if (want < min_span) want = min_span;
+        span = want < max_span ? want : max_span;
         return true;
     }
 
-    wtamd_trackset *upload() {
-        wtamd_tracks t;
-        memset(&t, 0, sizeof(t));
-        t.n_chrom = 1;
-        t.n_tracks = n_tracks();
-        t.seg_off = seg_off.data();
-        t.start = start.data();
-        t.finish = finish.data();
-        t.value = all_f32 ? (const void *) value32.data() : (const void *) value.data();
-        t.value_is_f64 = all_f32 ? 0 : 1;
-        t.defaults = defaults.data();
-        t.range_lo = &lo;
-        t.range_hi = &hi;
-        wtamd_trackset *ts = nullptr;
-        if (wtamd_trackset_create_host(&t, &ts) != WTAMD_OK) die("wtamd_trackset_create_host");
-        return ts;
+    // Next non-empty batch result; false when everything has been delivered.
+    bool next() {
+        if (holding) {
+            wtamd_pipe_release(pipe);
+            holding = false;
+            if (keep_log) {
+                const Flight &f = flights.front();
+                for (size_t i = 0; i < src.size(); i++)
+                    for (int32_t k = 0; k < f.consumed[i]; k++) src[i].log.pop_front();
+            }
+            flights.pop_front();
+        }
+        for (;;) {
+            while ((int) flights.size() < depth && drain_and_submit()) { }
+            if (flights.empty()) return false;
+            if (wtamd_pipe_collect(pipe, &res) != WTAMD_OK) die("wtamd_pipe_collect");
+            res_chrom = flights.front().chrom;
+            holding = true;
+            if (res.n_runs > 0) return true;
+            wtamd_pipe_release(pipe);
+            holding = false;
+            if (keep_log) {
+                const Flight &f = flights.front();
+                for (size_t i = 0; i < src.size(); i++)
+                    for (int32_t k = 0; k < f.consumed[i]; k++) src[i].log.pop_front();
+            }
+            flights.pop_front();
+        }
     }
 };
+
+int pipe_depth() { return (int) env_i64("WTAMD_PIPE_DEPTH", 2); }
 
 // ---------------------------------------------------------------------------
 // Multiplexer
 // ---------------------------------------------------------------------------
 struct MuxState {
-    Drainer dr;
-    std::vector<int32_t> rs, rf;
-    std::vector<double> rcount;     // per-run inplay_count
-    std::vector<double> tile;
-    std::vector<uint8_t> ip;
-    int64_t n = 0, cur = 0;
-    bool materialised = false;
-    bool taken_over = false;        // a reducer owns the drainer now
+    Feeder fd;
+    int64_t cur = 0;
+    bool open = false;
+    bool taken_over = false;        // a reducer owns the sources now
 };
 
 MuxState *mux_state(Multiplexer *m) { return (MuxState *) m->data; }
 
-void mux_materialise(Multiplexer *m) {
-    MuxState *S = mux_state(m);
-    wtamd_trackset *ts = S->dr.upload();
-    int64_t cap = wtamd_trackset_max_runs(ts);
-    if (cap < 1) cap = 1;
-    const int N = m->count;
-    S->rs.resize(cap); S->rf.resize(cap); S->rcount.resize(cap);
-    S->tile.resize((size_t) cap * N); S->ip.resize((size_t) cap * N);
-    wtamd_runs r;
-    memset(&r, 0, sizeof(r));
-    r.capacity = cap; r.start = S->rs.data(); r.finish = S->rf.data(); r.value = S->rcount.data();
-    int64_t n = 0;
-    if (wtamd_multiplex_host(ts, m->strict ? WTAMD_STRICT_SET0 : 0, &r, S->tile.data(), S->ip.data(), &n) != WTAMD_OK)
-        die("wtamd_multiplex_host");
-    wtamd_trackset_destroy(ts);
-    S->n = n; S->cur = 0; S->materialised = true;
+// Tile batches hold runs x tracks values: bound the runs per batch by a byte budget, so a
+// Multiplexer that is popped directly (mWigWriter, Select / FillIn, Pearson through the C API)
+// streams in bounded memory whatever its track count, like the reference does.
+int64_t mux_max_runs(int n_tracks) {
+    const int64_t budget = env_i64("WTAMD_TILE_BYTES", 64 << 20);
+    int64_t r = budget / (9 * (int64_t) n_tracks + 16);
+    if (r < kFirstSpan) r = kFirstSpan;
+    if (r > (2 << 20)) r = 2 << 20;
+    return r;
 }
 
 void mux_pop(Multiplexer *m) {
     MuxState *S = mux_state(m);
     if (S->taken_over) { m->done = 1; return; }
-    for (;;) {
-        if (!S->dr.have) {
-            if (!S->dr.next_batch()) { m->done = 1; return; }
-            S->materialised = false;
-        }
-        if (!S->materialised) mux_materialise(m);
-        if (S->cur < S->n) {
-            const int N = m->count;
-            const int64_t r = S->cur++;
-            m->chrom = S->dr.chrom;
-            m->start = S->rs[r];
-            m->finish = S->rf[r];
-            for (int i = 0; i < N; i++) {
-                m->values[i] = S->tile[(size_t) r * N + i];
-                m->inplay[i] = (wt_bool) S->ip[(size_t) r * N + i];
-            }
-            m->inplay_count = (int) S->rcount[r];
-            return;
-        }
-        S->dr.have = false;     // batch exhausted
+    Feeder &F = S->fd;
+    if (!S->open) {
+        wtamd_reduce_desc d = { WTAMD_OP_MULTIPLEX, m->strict ? WTAMD_STRICT_SET0 : 0u, 0, 0 };
+        F.keep_log = true;
+        F.depth = 1;                // priming batch only; deeper once the consumer keeps popping
+        F.open(d, mux_max_runs(m->count), 3, kFirstSpan);
+        S->open = true;
     }
+    if (!F.holding || S->cur >= F.res.n_runs) {
+        if (F.holding) F.depth = pipe_depth();
+        if (!F.next()) { m->done = 1; return; }
+        S->cur = 0;
+    }
+    const int N = m->count;
+    const int64_t r = S->cur++;
+    m->chrom = (char *) F.res_chrom;
+    m->start = F.res.start[r];
+    m->finish = F.res.finish[r];
+    const double *tv = F.res.tile + (size_t) r * N;
+    const uint8_t *ti = F.res.inplay + (size_t) r * N;
+    for (int i = 0; i < N; i++) {
+        m->values[i] = tv[i];
+        m->inplay[i] = (wt_bool) ti[i];
+    }
+    m->inplay_count = (int) F.res.value[r];
 }
 
 void mux_seek(Multiplexer *m, const char *chrom, int start, int finish) {
     MuxState *S = mux_state(m);
     m->done = 0;
     for (int i = 0; i < m->count; i++) seek(m->iters[i], chrom, start, finish);   // multiplexer.c:133-134
-    S->dr.reset();
-    S->materialised = false;
+    S->fd.reset();
+    S->cur = 0;
     S->taken_over = false;
     m->inplay_count = 0;
     popMultiplexer(m);
@@ -271,13 +377,8 @@ void mux_seek(Multiplexer *m, const char *chrom, int start, int finish) {
 // Reducers (one- and two-sample): iterate over the fused kernel's run list
 // ---------------------------------------------------------------------------
 struct RedState {
-    Drainer dr;
-    int op = 0;
-    uint32_t flags = 0;
-    int n_set0 = 0;
-    std::vector<int32_t> rs, rf;
-    std::vector<double> rv;
-    int64_t n = 0, cur = 0;
+    Feeder fd;
+    int64_t cur = 0;
     Multiplexer *multi = nullptr;       // one-sample
     Multiset *multiset = nullptr;       // two-sample
 };
@@ -291,42 +392,32 @@ RedState *red_state(WiggleIterator *wi) { return ((RedData *) wi->data)->state; 
 void red_pop(WiggleIterator *wi) {
     if (wi->done) return;
     RedState *R = red_state(wi);
-    for (;;) {
-        if (R->cur < R->n) {
-            const int64_t r = R->cur++;
-            wi->chrom = R->dr.chrom;
-            wi->start = R->rs[r];
-            wi->finish = R->rf[r];
-            wi->value = R->rv[r];
-            return;
-        }
-        if (!R->dr.next_batch()) {
+    Feeder &F = R->fd;
+    if (!F.holding || R->cur >= F.res.n_runs) {
+        if (!F.next()) {
             wi->done = 1;
             if (R->multi) R->multi->done = 1;
             if (R->multiset) R->multiset->done = 1;
             return;
         }
-        wtamd_trackset *ts = R->dr.upload();
-        int64_t cap = wtamd_trackset_max_runs(ts);
-        if (cap < 1) cap = 1;
-        R->rs.resize(cap); R->rf.resize(cap); R->rv.resize(cap);
-        wtamd_runs runs;
-        memset(&runs, 0, sizeof(runs));
-        runs.capacity = cap; runs.start = R->rs.data(); runs.finish = R->rf.data(); runs.value = R->rv.data();
-        wtamd_reduce_desc d = { R->op, R->flags, R->n_set0, 0 };
-        int64_t n = 0;
-        if (wtamd_reduce_host(ts, &d, &runs, &n) != WTAMD_OK) die("wtamd_reduce_host");
-        wtamd_trackset_destroy(ts);
-        R->n = n; R->cur = 0;
+        R->cur = 0;
     }
+    const int64_t r = R->cur++;
+    wi->chrom = (char *) F.res_chrom;
+    wi->start = F.res.start[r];
+    wi->finish = F.res.finish[r];
+    wi->value = F.res.value[r];
 }
 
 void red_take_over(RedState *R, Multiplexer *m) {
     MuxState *S = mux_state(m);
-    S->dr.rewind();
-    for (auto &s : S->dr.src) R->dr.src.push_back(std::move(s));
-    for (double d : S->dr.defaults) R->dr.defaults.push_back(d);
-    S->dr.src.clear();
+    S->fd.rewind();
+    for (auto &s : S->fd.src) R->fd.src.push_back(std::move(s));
+    for (double d : S->fd.defaults) R->fd.defaults.push_back(d);
+    for (char *n : S->fd.names.names) R->fd.names.names.push_back(n);   // interned pointers stay valid
+    S->fd.names.names.clear();
+    S->fd.src.clear();
+    S->fd.close();
     S->taken_over = true;
 }
 
@@ -334,21 +425,31 @@ void red_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
     // reference WiggleReducerSeek (reducers.c:25-29) / SetComparisonSeek (setComparisons.c:25-29):
     // seek the children, then pop once.
     RedState *R = red_state(wi);
-    for (auto &s : R->dr.src) seek(s.it, chrom, start, finish);
-    R->dr.reset();
-    R->n = R->cur = 0;
+    for (auto &s : R->fd.src) seek(s.it, chrom, start, finish);
+    R->fd.reset();
+    R->cur = 0;
     if (R->multi) R->multi->done = 0;
     if (R->multiset) R->multiset->done = 0;
     wi->done = 0;
     pop(wi);
 }
 
+void red_open(RedState *R, int op, uint32_t flags, int n_set0) {
+    // pending intervals of two Multiplexers may carry the same name interned twice: re-intern
+    for (auto &s : R->fd.src) {
+        for (auto &h : s.pending) h.chrom = R->fd.names.get(h.chrom);
+        s.raw = nullptr; s.interned = nullptr;
+    }
+    wtamd_reduce_desc d = { op, flags, n_set0, 0 };
+    R->fd.depth = pipe_depth();
+    R->fd.open(d, env_i64("WTAMD_BATCH_RUNS", 2 << 20), R->fd.depth + 1, kReducerFirstSpan);
+}
+
 WiggleIterator *make_reducer(Multiplexer *m, int op) {
     RedState *R = new RedState();
-    R->op = op;
-    R->flags = m->strict ? WTAMD_STRICT_SET0 : 0;
     R->multi = m;
     red_take_over(R, m);
+    red_open(R, op, m->strict ? WTAMD_STRICT_SET0 : 0u, 0);
     RedData *d = (RedData *) calloc(1, sizeof(RedData));
     d->state = R;
     const double dflt = wtamd_reducer_default(op, m->count, m->default_values);
@@ -357,12 +458,12 @@ WiggleIterator *make_reducer(Multiplexer *m, int op) {
 
 WiggleIterator *make_set_reducer(Multiset *ms, int op) {
     RedState *R = new RedState();
-    R->op = op;
     R->multiset = ms;
-    R->n_set0 = ms->multis[0]->count;
-    R->flags = (ms->multis[0]->strict ? WTAMD_STRICT_SET0 : 0) | (ms->multis[1]->strict ? WTAMD_STRICT_SET1 : 0);
+    const int n_set0 = ms->multis[0]->count;
+    const uint32_t flags = (ms->multis[0]->strict ? WTAMD_STRICT_SET0 : 0u) | (ms->multis[1]->strict ? WTAMD_STRICT_SET1 : 0u);
     red_take_over(R, ms->multis[0]);
     red_take_over(R, ms->multis[1]);
+    red_open(R, op, flags, n_set0);
     RedData *d = (RedData *) calloc(1, sizeof(RedData));
     d->state = R;
     return newWiggleIterator(d, &red_pop, &red_seek, NAN, 0);     // setComparisons.c:130,389
@@ -576,13 +677,13 @@ Multiplexer *newMultiplexer(WiggleIterator **iters, int count, wt_bool strict) {
     Multiplexer *m = newCoreMultiplexer(S, count, &mux_pop, &mux_seek);
     m->strict = strict;
     m->iters = (WiggleIterator **) calloc((size_t) count, sizeof(WiggleIterator *));
-    S->dr.src.resize((size_t) count);
+    S->fd.src.resize((size_t) count);
     for (int i = 0; i < count; i++) {
         m->iters[i] = NonOverlappingWiggleIterator(iters[i]);       // multiplexer.c:163
         m->default_values[i] = m->iters[i]->default_value;
         m->values[i] = m->iters[i]->default_value;
-        S->dr.src[i].it = m->iters[i];
-        S->dr.defaults.push_back(m->iters[i]->default_value);
+        S->fd.src[i].it = m->iters[i];
+        S->fd.defaults.push_back(m->iters[i]->default_value);
     }
     popMultiplexer(m);                                              // primed like multiplexer.c:167
     return m;
@@ -651,6 +752,15 @@ WiggleIterator *TTestReduction(Multiset *s) {
         exit(1);
     }
     return make_set_reducer(s, WTAMD_OP_TTEST);
+}
+
+WiggleIterator *FTestReduction(Multiset *s) {
+    // The reference's F-test (setComparisons.c:152-243) is broken -- its inner loops advance
+    // `index` instead of `index2` (:183,199), undefined behaviour -- and is out of
+    // scope here.  Exported so that commandParser.c:642-644 links; fails the reference's way.
+    (void) s;
+    puts("The F-test is not available in the wiggletools_amd engine (the reference implementation is undefined behaviour, setComparisons.c:183,199)");
+    exit(1);
 }
 
 WiggleIterator *MWUReduction(Multiset *s) {

@@ -1,0 +1,479 @@
+// wt_pipe.h -- the streaming pipeline (wtamd_pipe_*, include/wiggletools_amd.h).  Included at the
+// end of wt_engine.hip (it launches that file's kernels and rebinds its track sets).
+//
+// The reference overlaps its readers with the evaluation through producer threads and
+// 10 000-entry SoA blocks, at most 3 blocks ahead (bufferedReader.c:17-28,41-55,99-109).  Here
+// the same role is played across host, PCIe and GPU by `n_slots` batch slots and three HIP streams:
+//
+//      host (Drainer)     fill k+2 | fill k+3 | ...
+//      copy stream        H2D k+1  | H2D k+2  | ...          hipMemcpyAsync from PINNED staging
+//      compute stream     index + multiplex/reduce kernels k | k+1 | ...
+//      result stream      D2H k-1 (exactly the emitted runs) | D2H k | ...   into PINNED output
+//
+// Events order the three streams per slot; nothing is allocated, freed or synchronised per batch
+// (staging, device buffers and window tables only ever grow), the run count travels back with the
+// kernel's counters and the D2H of the runs is issued as soon as that count is known (checked
+// whenever the pipe is entered, waited for only by collect()).  A batch whose difference-array
+// launch reported windows it could not prove exact gets the patch kernel before its D2H.
+#ifndef WT_PIPE_H_
+#define WT_PIPE_H_
+
+struct WtSlot {
+    int state = 0;                  // 0 free, 1 acquired, 2 submitted, 3 collected
+    int stage = 0;                  // submitted: 0 kernels enqueued, 1 D2H enqueued
+    // input staging (pinned) and its device twin
+    int64_t cap = 0;
+    bool has64 = false;
+    int64_t *h_seg = nullptr;
+    int32_t *h_start = nullptr, *h_finish = nullptr;
+    float *h_v32 = nullptr;
+    double *h_v64 = nullptr;
+    int64_t dcap = 0;
+    bool d_has64 = false;
+    int32_t *d_start = nullptr, *d_finish = nullptr;
+    void *d_value = nullptr;
+    // output: device + pinned
+    int64_t ocap = 0;
+    int32_t *d_os = nullptr, *d_of = nullptr;
+    double *d_ov = nullptr, *d_tile = nullptr;
+    uint8_t *d_ip = nullptr;
+    int64_t *d_cro = nullptr;
+    int32_t *h_os = nullptr, *h_of = nullptr;
+    double *h_ov = nullptr, *h_tile = nullptr;
+    uint8_t *h_ip = nullptr;
+    wtamd_trackset *ts = nullptr;
+    hipEvent_t e_h0 = nullptr, e_h1 = nullptr, e_k0 = nullptr, e_cnt = nullptr, e_patch = nullptr, e_d0 = nullptr, e_d1 = nullptr;
+    // the batch in flight
+    int64_t n_int = 0, n_runs = 0, covered = 0;
+    bool f64 = false, used_delta = false, patched = false;
+    int err = WTAMD_OK;
+    std::string err_msg;
+    int delta_W = 0;
+};
+
+struct wtamd_pipe {
+    wtamd_pipe_config cfg;
+    std::vector<double> defaults;
+    std::vector<WtSlot> slots;
+    int head = 0, tail = 0, acquired = -1, in_flight = 0, held = 0;
+    hipStream_t s_copy = nullptr, s_comp = nullptr, s_out = nullptr;
+    bool delta_failed = false;      // a batch had many inexact windows: Sum / Mean stay on the general kernel
+    bool tile = false;
+    wtamd_pipe_stats st{};
+};
+
+static void wt_slot_free(WtSlot &s) {
+    if (s.h_seg) (void) hipHostFree(s.h_seg);
+    if (s.h_start) (void) hipHostFree(s.h_start);
+    if (s.h_finish) (void) hipHostFree(s.h_finish);
+    if (s.h_v32) (void) hipHostFree(s.h_v32);
+    if (s.h_v64) (void) hipHostFree(s.h_v64);
+    (void) hipFree(s.d_start); (void) hipFree(s.d_finish); (void) hipFree(s.d_value);
+    (void) hipFree(s.d_os); (void) hipFree(s.d_of); (void) hipFree(s.d_ov); (void) hipFree(s.d_tile); (void) hipFree(s.d_ip);
+    (void) hipFree(s.d_cro);
+    if (s.h_os) (void) hipHostFree(s.h_os);
+    if (s.h_of) (void) hipHostFree(s.h_of);
+    if (s.h_ov) (void) hipHostFree(s.h_ov);
+    if (s.h_tile) (void) hipHostFree(s.h_tile);
+    if (s.h_ip) (void) hipHostFree(s.h_ip);
+    if (s.ts) {
+        s.ts->d_start = s.ts->d_finish = nullptr; s.ts->d_value = nullptr;      // the slot's, freed above
+        wtamd_trackset_destroy(s.ts);
+    }
+    for (hipEvent_t e : {s.e_h0, s.e_h1, s.e_k0, s.e_cnt, s.e_patch, s.e_d0, s.e_d1})
+        if (e) (void) hipEventDestroy(e);
+    s = WtSlot();
+}
+
+template <class T>
+static hipError_t wt_pinned_grow(T **p, int64_t old_n, int64_t used, int64_t new_n) {
+    T *q = nullptr;
+    const hipError_t e = hipHostMalloc((void **) &q, sizeof(T) * (size_t) (new_n > 0 ? new_n : 1), hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (*p) {
+        if (used > 0) memcpy(q, *p, sizeof(T) * (size_t) (used < old_n ? used : old_n));
+        (void) hipHostFree(*p);
+    }
+    *p = q;
+    return hipSuccess;
+}
+
+static int wt_slot_grow_input(WtSlot &s, int64_t used, int64_t min_cap, bool want64) {
+    if (min_cap > s.cap) {
+        WT_HIP(wt_pinned_grow(&s.h_start, s.cap, used, min_cap));
+        WT_HIP(wt_pinned_grow(&s.h_finish, s.cap, used, min_cap));
+        WT_HIP(wt_pinned_grow(&s.h_v32, s.cap, used, min_cap));
+        if (s.has64) WT_HIP(wt_pinned_grow(&s.h_v64, s.cap, used, min_cap));
+        s.cap = min_cap;
+    }
+    if (want64 && !s.has64) {
+        WT_HIP(wt_pinned_grow(&s.h_v64, 0, 0, s.cap));
+        s.has64 = true;
+    }
+    return WTAMD_OK;
+}
+
+// Bounded wait: a kernel that does not finish is reported, never waited for forever (a hung
+// kernel cannot be cancelled and every later HIP call would block behind it).
+static int wt_wait_event(hipEvent_t ev, const char *what) {
+    const double limit_s = getenv("WTAMD_TIMEOUT_S") ? atof(getenv("WTAMD_TIMEOUT_S")) : 120.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return WTAMD_OK;
+        if (q != hipErrorNotReady) return wt_fail(WTAMD_ERR_HIP, std::string("hipEventQuery (") + what + "): " + hipGetErrorString(q));
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el > limit_s) {
+            fprintf(stderr, "wiggletools_amd: FATAL: pipeline %s did not finish within %.0f s\n", what, limit_s);
+            fflush(stderr);
+            _exit(70);
+        }
+        if (el > 0.0005) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// The run count (and the difference-array verdict) of a submitted batch is on the host: patch
+// the windows that were not provably exact, then ship exactly the emitted runs.
+static int wt_pipe_issue_d2h(wtamd_pipe *p, WtSlot &s) {
+    wtamd_trackset *ts = s.ts;
+    const unsigned long long *hc = ts->h_counters;
+    s.n_runs = (int64_t) hc[WT_CTR_RUNS];
+    s.covered = (int64_t) hc[WT_CTR_BP];
+    s.stage = 1;
+    if (hc[WT_CTR_ERROR] & WT_ERR_LOOKBACK) { s.err = WTAMD_ERR_INTERNAL; s.err_msg = "look-back timed out"; return WTAMD_OK; }
+    if (hc[WT_CTR_ERROR] & WT_ERR_CAPACITY) { s.err = WTAMD_ERR_CAPACITY; s.err_msg = "batch emitted more runs than the slot's output capacity (max_runs)"; return WTAMD_OK; }
+    hipEvent_t after = s.e_cnt;
+    const long long n_bad = (long long) hc[WT_CTR_DELTA_BAD];
+    if (s.used_delta && n_bad > 0) {
+        wtamd_runs runs{};
+        runs.capacity = s.ocap; runs.start = s.d_os; runs.finish = s.d_of; runs.value = s.d_ov; runs.chrom_run_off = s.d_cro;
+        const int rc = wt_launch_patch(ts, s.delta_W, p->cfg.desc.op, p->cfg.desc.flags, &runs, n_bad, p->s_comp);
+        if (rc != WTAMD_OK) { s.err = rc; s.err_msg = g_last_error; return WTAMD_OK; }
+        WT_HIP(hipEventRecord(s.e_patch, p->s_comp));
+        after = s.e_patch;
+        s.patched = true;
+        if (n_bad * 4 > (long long) ts->stats.n_windows) p->delta_failed = true;     // this data: general kernel from now on
+    }
+    WT_HIP(hipStreamWaitEvent(p->s_out, after, 0));
+    WT_HIP(hipEventRecord(s.e_d0, p->s_out));
+    const int64_t n = s.n_runs;
+    if (n > 0) {
+        const int N = p->cfg.n_tracks;
+        WT_HIP(hipMemcpyAsync(s.h_os, s.d_os, sizeof(int32_t) * n, hipMemcpyDeviceToHost, p->s_out));
+        WT_HIP(hipMemcpyAsync(s.h_of, s.d_of, sizeof(int32_t) * n, hipMemcpyDeviceToHost, p->s_out));
+        WT_HIP(hipMemcpyAsync(s.h_ov, s.d_ov, sizeof(double) * n, hipMemcpyDeviceToHost, p->s_out));
+        p->st.d2h_bytes += 16 * n;
+        if (p->tile) {
+            WT_HIP(hipMemcpyAsync(s.h_tile, s.d_tile, sizeof(double) * n * N, hipMemcpyDeviceToHost, p->s_out));
+            WT_HIP(hipMemcpyAsync(s.h_ip, s.d_ip, sizeof(uint8_t) * n * N, hipMemcpyDeviceToHost, p->s_out));
+            p->st.d2h_bytes += 9 * n * N;
+        }
+    }
+    WT_HIP(hipEventRecord(s.e_d1, p->s_out));
+    return WTAMD_OK;
+}
+
+// Non-blocking: issues the D2H of every submitted batch whose counters have arrived.
+static int wt_pipe_progress(wtamd_pipe *p) {
+    const int ns = (int) p->slots.size();
+    for (int k = 0, i = p->tail; k < ns; k++, i = (i + 1) % ns) {
+        WtSlot &s = p->slots[(size_t) i];
+        if (s.state == 3) continue;             // collected, being read
+        if (s.state != 2) break;
+        if (s.stage == 0) {
+            if (hipEventQuery(s.e_cnt) != hipSuccess) break;     // in order: later batches are behind it on the stream
+            const int rc = wt_pipe_issue_d2h(p, s);
+            if (rc != WTAMD_OK) return rc;
+        }
+    }
+    return WTAMD_OK;
+}
+
+extern "C" {
+
+int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
+    if (!cfg || !out || cfg->n_tracks <= 0 || !cfg->defaults || cfg->max_runs <= 0)
+        return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_create: bad configuration");
+    if (cfg->flags & ~0u & ~WTAMD_PIPE_COMPRESS) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_create: unknown flag");
+    if (cfg->flags & WTAMD_PIPE_COMPRESS) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_create: WTAMD_PIPE_COMPRESS is not wired yet");
+    const bool tile = cfg->desc.op == WTAMD_OP_MULTIPLEX;
+    if (wtamd_device_count() <= 0) return wt_fail(WTAMD_ERR_NODEVICE, "no HIP device visible");
+    wtamd_pipe *p = new wtamd_pipe();
+    p->cfg = *cfg;
+    p->defaults.assign(cfg->defaults, cfg->defaults + cfg->n_tracks);
+    p->cfg.defaults = p->defaults.data();
+    p->tile = tile;
+    int ns = cfg->n_slots ? cfg->n_slots : 3;
+    if (ns < 2) ns = 2;
+    if (ns > 8) ns = 8;
+    p->st.n_slots = ns;
+    auto fail = [&](int rc) { wtamd_pipe_destroy(p); return rc; };
+#define WT_PIPE_HIP(expr)                                                                                         \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) return fail(wt_fail(WTAMD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); \
+    } while (0)
+    if (!tile) {
+        wtamd_trackset probe;       // argument check of the descriptor (same messages as wtamd_reduce)
+        probe.n_tracks = cfg->n_tracks;
+        const int rc = wt_check_desc(&probe, &cfg->desc);
+        if (rc != WTAMD_OK) return fail(rc);
+    }
+    WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
+    WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_comp, hipStreamNonBlocking));
+    WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+    p->slots.resize((size_t) ns);
+    const int64_t cap0 = cfg->max_intervals > 0 ? cfg->max_intervals : 4096;
+    const int N = cfg->n_tracks;
+    std::vector<int64_t> seg0((size_t) N + 1, 0);
+    for (auto &s : p->slots) {
+        WT_PIPE_HIP(hipHostMalloc((void **) &s.h_seg, sizeof(int64_t) * ((size_t) N + 1), hipHostMallocDefault));
+        memset(s.h_seg, 0, sizeof(int64_t) * ((size_t) N + 1));
+        int rc = wt_slot_grow_input(s, 0, cap0, false);
+        if (rc != WTAMD_OK) return fail(rc);
+        for (hipEvent_t *e : {&s.e_h0, &s.e_h1, &s.e_k0, &s.e_cnt, &s.e_patch, &s.e_d0, &s.e_d1}) WT_PIPE_HIP(hipEventCreate(e));
+        // the slot's track set: one chromosome, device arrays bound per batch
+        wtamd_tracks t;
+        memset(&t, 0, sizeof(t));
+        t.n_chrom = 1; t.n_tracks = N; t.seg_off = seg0.data(); t.defaults = p->defaults.data();
+        s.ts = new wtamd_trackset();
+        rc = wt_trackset_common(&t, s.ts);
+        if (rc != WTAMD_OK) return fail(rc);
+        s.ts->pipe_mode = true;
+        s.ts->owns = false;
+        s.ts->first_start.assign((size_t) N, 0);
+        s.ts->last_finish.assign((size_t) N, 0);
+        s.ts->range_lo.assign(1, 0);
+        s.ts->range_hi.assign(1, INT32_MAX);
+        WT_PIPE_HIP(hipMalloc(&s.d_cro, sizeof(int64_t) * 2));
+    }
+#undef WT_PIPE_HIP
+    *out = p;
+    return WTAMD_OK;
+}
+
+void wtamd_pipe_destroy(wtamd_pipe *p) {
+    if (!p) return;
+    // everything still in flight must have left the buffers before they are freed
+    if (p->s_copy) (void) hipStreamSynchronize(p->s_copy);
+    if (p->s_comp) (void) hipStreamSynchronize(p->s_comp);
+    if (p->s_out) (void) hipStreamSynchronize(p->s_out);
+    for (auto &s : p->slots) wt_slot_free(s);
+    if (p->s_copy) (void) hipStreamDestroy(p->s_copy);
+    if (p->s_comp) (void) hipStreamDestroy(p->s_comp);
+    if (p->s_out) (void) hipStreamDestroy(p->s_out);
+    delete p;
+}
+
+static void wt_fill_batch(const WtSlot &s, wtamd_pipe_batch *b) {
+    b->capacity = s.cap;
+    b->seg_off = s.h_seg;
+    b->start = s.h_start; b->finish = s.h_finish;
+    b->value32 = s.h_v32;
+    b->value64 = s.has64 ? s.h_v64 : nullptr;
+}
+
+int wtamd_pipe_acquire(wtamd_pipe *p, wtamd_pipe_batch *out) {
+    if (!p || !out) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    if (p->acquired >= 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_acquire: a slot is already acquired");
+    WtSlot &s = p->slots[(size_t) p->head];
+    if (s.state != 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_acquire: every slot is in flight or unreleased");
+    s.state = 1;
+    p->acquired = p->head;
+    wt_fill_batch(s, out);
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_grow(wtamd_pipe *p, int64_t used, int64_t min_capacity, int want_f64, wtamd_pipe_batch *out) {
+    if (!p || !out || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_grow: no acquired slot");
+    WtSlot &s = p->slots[(size_t) p->acquired];
+    if (used > s.cap || used < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_grow: used > capacity");
+    const int rc = wt_slot_grow_input(s, used, min_capacity, want_f64 != 0);
+    if (rc != WTAMD_OK) return rc;
+    wt_fill_batch(s, out);
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_cancel(wtamd_pipe *p) {
+    if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_cancel: no acquired slot");
+    p->slots[(size_t) p->acquired].state = 0;
+    p->acquired = -1;
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi) {
+    if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: no acquired slot");
+    WtSlot &s = p->slots[(size_t) p->acquired];
+    const int N = p->cfg.n_tracks;
+    const int64_t n = s.h_seg[N];
+    if (s.h_seg[0] != 0 || n < 0 || n > s.cap) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: bad seg_off");
+    for (int i = 0; i < N; i++)
+        if (s.h_seg[i + 1] < s.h_seg[i]) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: seg_off not monotone");
+    if (value_is_f64 && !s.has64) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: float64 values were never staged");
+    wtamd_trackset *ts = s.ts;
+    const bool f64 = value_is_f64 != 0;
+    // device twin of the staging (grow-only)
+    const int64_t need_in = n > 0 ? n : 1;
+    if (s.dcap < need_in || (f64 && !s.d_has64)) {
+        (void) hipStreamSynchronize(p->s_comp);         // an earlier batch of this slot has long been collected; be safe anyway
+        int64_t c = s.dcap * 2 > need_in ? s.dcap * 2 : need_in;
+        if (c < s.cap) c = s.cap;
+        (void) hipFree(s.d_start); (void) hipFree(s.d_finish); (void) hipFree(s.d_value);
+        s.d_start = s.d_finish = nullptr; s.d_value = nullptr; s.dcap = 0;
+        const bool w64 = f64 || s.d_has64 || s.has64;
+        WT_HIP(hipMalloc(&s.d_start, sizeof(int32_t) * c));
+        WT_HIP(hipMalloc(&s.d_finish, sizeof(int32_t) * c));
+        WT_HIP(hipMalloc(&s.d_value, (w64 ? 8 : 4) * (size_t) c));
+        s.dcap = c; s.d_has64 = w64;
+    }
+    // output (grow-only, bounded by max_runs): a run is at least 1 bp and starts at an interval edge
+    int64_t need_out = 2 * n;
+    const int64_t span = (int64_t) range_hi - (int64_t) range_lo;
+    if (range_hi != INT32_MAX && span < need_out) need_out = span > 0 ? span : 0;
+    if (need_out > p->cfg.max_runs) need_out = p->cfg.max_runs;
+    if (need_out < 1) need_out = 1;
+    if (s.ocap < need_out) {
+        int64_t c = s.ocap * 2 > need_out ? s.ocap * 2 : need_out;
+        if (c > p->cfg.max_runs) c = p->cfg.max_runs;
+        if (c < need_out) c = need_out;
+        (void) hipFree(s.d_os); (void) hipFree(s.d_of); (void) hipFree(s.d_ov); (void) hipFree(s.d_tile); (void) hipFree(s.d_ip);
+        s.d_os = s.d_of = nullptr; s.d_ov = s.d_tile = nullptr; s.d_ip = nullptr;
+        if (s.h_os) (void) hipHostFree(s.h_os);
+        if (s.h_of) (void) hipHostFree(s.h_of);
+        if (s.h_ov) (void) hipHostFree(s.h_ov);
+        if (s.h_tile) (void) hipHostFree(s.h_tile);
+        if (s.h_ip) (void) hipHostFree(s.h_ip);
+        s.h_os = s.h_of = nullptr; s.h_ov = s.h_tile = nullptr; s.h_ip = nullptr; s.ocap = 0;
+        WT_HIP(hipMalloc(&s.d_os, sizeof(int32_t) * c));
+        WT_HIP(hipMalloc(&s.d_of, sizeof(int32_t) * c));
+        WT_HIP(hipMalloc(&s.d_ov, sizeof(double) * c));
+        WT_HIP(hipHostMalloc((void **) &s.h_os, sizeof(int32_t) * c, hipHostMallocDefault));
+        WT_HIP(hipHostMalloc((void **) &s.h_of, sizeof(int32_t) * c, hipHostMallocDefault));
+        WT_HIP(hipHostMalloc((void **) &s.h_ov, sizeof(double) * c, hipHostMallocDefault));
+        if (p->tile) {
+            WT_HIP(hipMalloc(&s.d_tile, sizeof(double) * c * N));
+            WT_HIP(hipMalloc(&s.d_ip, sizeof(uint8_t) * c * N));
+            WT_HIP(hipHostMalloc((void **) &s.h_tile, sizeof(double) * c * N, hipHostMallocDefault));
+            WT_HIP(hipHostMalloc((void **) &s.h_ip, sizeof(uint8_t) * c * N, hipHostMallocDefault));
+        }
+        s.ocap = c;
+    }
+
+    // rebind the slot's track set to this batch
+    ts->n_intervals = n;
+    ts->seg_off.assign(s.h_seg, s.h_seg + N + 1);
+    for (int i = 0; i < N; i++) {
+        const int64_t a = s.h_seg[i], b = s.h_seg[i + 1];
+        ts->first_start[(size_t) i] = b > a ? s.h_start[a] : 0;
+        ts->last_finish[(size_t) i] = b > a ? s.h_finish[b - 1] : 0;
+    }
+    ts->range_lo[0] = range_lo;
+    ts->range_hi[0] = range_hi;
+    ts->value_f64 = f64;
+    ts->scratch_f32 = !f64 && wt_defaults_fit_f32(ts->defaults.data(), N);
+    ts->d_start = s.d_start; ts->d_finish = s.d_finish; ts->d_value = s.d_value;
+    ts->delta_failed = p->delta_failed;
+    ts->delta_verified = false;
+    ts->delta_n_bad = 0;
+    for (auto &kv : ts->windows) { kv.second.tab_valid = false; kv.second.indexed = false; }
+    int rc = wt_check_extents(ts);
+    if (rc != WTAMD_OK) return rc;
+
+    // copy stream: pinned staging -> HBM
+    WT_HIP(hipEventRecord(s.e_h0, p->s_copy));
+    WT_HIP(hipMemcpyAsync(ts->d_seg_off, s.h_seg, sizeof(int64_t) * ((size_t) N + 1), hipMemcpyHostToDevice, p->s_copy));
+    if (n > 0) {
+        WT_HIP(hipMemcpyAsync(s.d_start, s.h_start, sizeof(int32_t) * n, hipMemcpyHostToDevice, p->s_copy));
+        WT_HIP(hipMemcpyAsync(s.d_finish, s.h_finish, sizeof(int32_t) * n, hipMemcpyHostToDevice, p->s_copy));
+        if (f64) WT_HIP(hipMemcpyAsync(s.d_value, s.h_v64, sizeof(double) * n, hipMemcpyHostToDevice, p->s_copy));
+        else WT_HIP(hipMemcpyAsync(s.d_value, s.h_v32, sizeof(float) * n, hipMemcpyHostToDevice, p->s_copy));
+    }
+    WT_HIP(hipEventRecord(s.e_h1, p->s_copy));
+    p->st.h2d_bytes += (int64_t) sizeof(int64_t) * (N + 1) + n * (f64 ? 16 : 12);
+
+    // compute stream: window index + fused multiplex / reduce, then the counters travel back
+    WT_HIP(hipStreamWaitEvent(p->s_comp, s.e_h1, 0));
+    WT_HIP(hipEventRecord(s.e_k0, p->s_comp));
+    wtamd_runs runs{};
+    runs.capacity = s.ocap; runs.start = s.d_os; runs.finish = s.d_of; runs.value = s.d_ov; runs.chrom_run_off = s.d_cro;
+    const int op = p->cfg.desc.op;
+    WtPlan plan;
+    std::string err;
+    s.used_delta = !p->tile && wt_wants_delta(ts, op);
+    s.patched = false;
+    if (s.used_delta) {
+        wt_make_delta_plan(plan, N);
+        s.delta_W = plan.W;
+    } else if (!wt_make_plan(N, op, ts->scratch_f32, plan, err)) {
+        return wt_fail(WTAMD_ERR_ARG, err);
+    }
+    rc = wt_reduce_plan(ts, plan, op, p->cfg.desc.flags, p->cfg.desc.n_set0, &runs, p->tile ? s.d_tile : nullptr,
+                        p->tile ? s.d_ip : nullptr, nullptr, p->s_comp);
+    if (rc != WTAMD_OK) return rc;
+    WT_HIP(hipMemcpyAsync(ts->h_counters, ts->d_counters, sizeof(unsigned long long) * WT_CTR_N, hipMemcpyDeviceToHost, p->s_comp));
+    WT_HIP(hipEventRecord(s.e_cnt, p->s_comp));
+
+    s.n_int = n; s.f64 = f64; s.err = WTAMD_OK; s.stage = 0; s.state = 2;
+    p->acquired = -1;
+    p->head = (p->head + 1) % (int) p->slots.size();
+    p->in_flight++;
+    p->st.batches++;
+    p->st.intervals += n;
+    if (s.used_delta) p->st.delta_batches++;
+    return wt_pipe_progress(p);
+}
+
+int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
+    if (!p || !out) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    if (p->in_flight <= 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_collect: nothing in flight");
+    if (p->held) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_collect: the previous result was not released");
+    WtSlot &s = p->slots[(size_t) p->tail];
+    if (s.state != 2) return wt_fail(WTAMD_ERR_INTERNAL, "wtamd_pipe_collect: slot order corrupted");
+    int rc = wt_pipe_progress(p);
+    if (rc != WTAMD_OK) return rc;
+    if (s.stage == 0) {
+        rc = wt_wait_event(s.e_cnt, "kernels");
+        if (rc != WTAMD_OK) return rc;
+        rc = wt_pipe_issue_d2h(p, s);
+        if (rc != WTAMD_OK) return rc;
+    }
+    s.state = 3;
+    p->in_flight--;
+    p->held = 1;
+    if (s.err != WTAMD_OK) return wt_fail(s.err, s.err_msg);
+    rc = wt_wait_event(s.e_d1, "result copy");
+    if (rc != WTAMD_OK) return rc;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, s.e_h0, s.e_h1) == hipSuccess) p->st.h2d_ms += ms;
+    if (hipEventElapsedTime(&ms, s.e_k0, s.patched ? s.e_patch : s.e_cnt) == hipSuccess) p->st.kernel_ms += ms;
+    if (hipEventElapsedTime(&ms, s.e_d0, s.e_d1) == hipSuccess) p->st.d2h_ms += ms;
+    p->st.runs += s.n_runs;
+    p->st.covered_bp += s.covered;
+    out->n_runs = s.n_runs;
+    out->start = s.h_os; out->finish = s.h_of; out->value = s.h_ov;
+    out->tile = p->tile ? s.h_tile : nullptr;
+    out->inplay = p->tile ? s.h_ip : nullptr;
+    out->covered_bp = s.covered;
+    out->n_intervals = s.n_int;
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_release(wtamd_pipe *p) {
+    if (!p || !p->held) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_release: nothing to release");
+    p->slots[(size_t) p->tail].state = 0;
+    p->held = 0;
+    p->tail = (p->tail + 1) % (int) p->slots.size();
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_in_flight(const wtamd_pipe *p) { return p ? p->in_flight : 0; }
+
+int wtamd_pipe_get_stats(const wtamd_pipe *p, wtamd_pipe_stats *out) {
+    if (!p || !out) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    *out = p->st;
+    return WTAMD_OK;
+}
+
+}  // extern "C"
+
+#endif  // WT_PIPE_H_
