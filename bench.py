@@ -1,21 +1,30 @@
 #!/usr/bin/env python
-"""bench.py -- throughput of the hot path (Multiplexer -> MeanReduction) on MI355X.
+"""bench.py -- throughput of the hot path (Multiplexer -> reducer) on MI355X.
 
-Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`;
-for N>1 launched by torch.distributed.run, one rank per GPU.  Rank 0 prints ONE
-JSON line.
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1
+launched by torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1]): `mean` over 100 synthetic BigWig-like
-tracks (float32 values k/8, run length ~ Geometric(1/l), 2 % gaps),
-laid out on 24 chromosomes with GRCh38 proportions.  One STEP = one full pass of
-the hot path over the resident batch: window-index kernel + fused
-multiplex/reduce kernel, inputs and outputs in HBM.  The batch is the genome
-scaled by --scale (default 1/8 at l=16 so that generation + K steps finish in
-minutes); bp/s is intensive, a whole genome is 1/scale steps.
+Workload (BASELINE.json configs), `--config`:
+  c2 (default)  mean over 100 synthetic tracks, the WHOLE 3.1 Gbp genome (24 chromosomes, GRCh38 lengths)
+  c3            var + stddev over 500 tracks, chromosome 1 (248 Mbp) -- a step runs both reducers
+  c4            median over 100 tracks, whole genome
+  c5            wilcoxon 50 v 50, whole genome (+ the scalar gathers: AUC and Pearson)
+Tracks: float32 values k/8, run length ~ 1 + Geometric(1/l) (l = --mean-run, default 16), 2 % gaps,
+from the counter-based generator csrc/wt_synth.hip.
 
-Multi-GPU: chromosome batches are independent: every rank owns its
-own batch (weak scaling), no collective on the data path; one RCCL all_reduce of
-the genome-wide AUC / bp scalars after the timed region.
+One STEP = one pass of the hot path over the whole genome of the configuration.  100 tracks x
+3.1 Gbp at l = 16 are 233 GB of run lists -- they do not fit one GPU together with the output -- so a
+pass walks a host-side work queue of chromosomes (largest first): generate the chromosome's
+tracks in HBM (NOT timed), then window-index kernel + fused multiplex/reduce kernel over it with
+inputs and outputs resident (timed: synchronise, clock, launch, synchronise, clock).  ms_per_step
+is the sum of the timed sections of one pass; bp/s = covered bp / that time.
+
+Multi-GPU (--shard genome, default): ONE genome per step, its chromosomes handed out to the
+ranks by a shared work queue (a counter in the torch.distributed store) -- strong scaling, no
+collective on the data path; per-pass time = max over ranks.  Genome-wide scalars travel through
+RCCL after the timed region: AUC / bp / run counts by all_reduce, the Pearson moments of tracks
+0,1 by all_gather + ordered pairwise merge (reference statistics.c:442-456 is sequential).
+--shard replicas: every rank walks its own genome (weak scaling).
 """
 import argparse
 import json
@@ -32,98 +41,132 @@ GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 1593
           138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
           83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+SEED = 20260927
+
+CONFIGS = {
+    "c2": dict(ops=["mean"], tracks=100, chroms=list(range(24)), what="mean over 100 tracks, whole genome"),
+    "c3": dict(ops=["var", "stddev"], tracks=500, chroms=[0], what="var + stddev over 500 tracks, chromosome 1"),
+    "c4": dict(ops=["median"], tracks=100, chroms=list(range(24)), what="median over 100 tracks, whole genome"),
+    "c5": dict(ops=["wilcoxon"], tracks=100, chroms=list(range(24)), what="wilcoxon 50 v 50, whole genome"),
+}
 
 
-def synth_device(n_tracks, chrom_lens, mean_run, gap_prob, seed, device):
-    """Synthetic run lists generated on the GPU with torch (plumbing only)."""
+# ---------------------------------------------------------------------------------------------
+# CPU baselines (the checker's compiled reference, oracle/_ref; else the C restatement)
+# ---------------------------------------------------------------------------------------------
+def _sample_tracks(chrom_id, chrom_len, n_tracks, mean_run, lo, hi):
+    """The bench's own tracks of one chromosome, run starts in [lo, hi), finishes clipped to hi: the
+    counter-based generator's numpy mirror regenerates them on the host (nothing is copied back)."""
+    from wiggletools_amd import synthgen
+    t = synthgen.host_runlists(SEED, [chrom_len], n_tracks, mean_run, 0.02, 800, region=(lo, hi), chrom_ids=[chrom_id])
+    d = t.as_dict()
+    d["finish"] = np.minimum(d["finish"], hi + 1).astype(np.int32)
+    return d
+
+
+def _sample_tracks_device(chrom_id, chrom_len, n_tracks, mean_run, hi):
+    """Same sample (run starts in [0, hi) of one chromosome) taken from the device generator: the
+    single-thread leg's sample is tens of Mbp, which the numpy mirror would take longer to hash than
+    the reference takes to evaluate."""
     import torch
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    S, F, V = [], [], []
-    seg_off = [0]
-    p = 1.0 / mean_run
-    for clen in chrom_lens:
-        for _ in range(n_tracks):
-            n_est = int(clen / mean_run * 1.1) + 4096
-            # (float32 geometric_ occasionally yields 0: a zero-length run is undefined behaviour for
-            #  the reference's Multiplexer, SURVEY appendix A, and for wtamd_tracks -- hence the clamp)
-            lens = torch.empty(n_est, device=device, dtype=torch.float32).geometric_(p, generator=g).to(torch.int64).clamp_(min=1) \
-                if mean_run > 1 else torch.ones(n_est, device=device, dtype=torch.int64)
-            ends = torch.cumsum(lens, 0)
-            k = int(torch.searchsorted(ends, torch.tensor([clen], device=device, dtype=torch.int64)).item()) + 1
-            if k > n_est:      # extremely unlikely: estimate too small
-                k = n_est
-            ends = ends[:k].clone()
-            ends[-1] = clen
-            starts = torch.cat([torch.zeros(1, device=device, dtype=torch.int64), ends[:-1]])
-            keep = torch.rand(k, device=device, generator=g) >= gap_prob
-            vals = torch.randint(0, 800, (k,), device=device, generator=g).to(torch.float32) / 8.0
-            S.append((starts[keep] + 1).to(torch.int32))
-            F.append((ends[keep] + 1).to(torch.int32))
-            V.append(vals[keep])
-            seg_off.append(seg_off[-1] + int(S[-1].numel()))
-            del lens, ends, starts, keep, vals
-    start = torch.cat(S); del S
-    finish = torch.cat(F); del F
-    value = torch.cat(V); del V
-    return np.array(seg_off, np.int64), start, finish, value
+    from wiggletools_amd import synthgen
+    seg, s, f, v = synthgen.device_tracks(SEED, [chrom_len], n_tracks, mean_run, 0.02, 800, chrom_ids=[chrom_id])
+    S, F, V, so = [], [], [], [0]
+    for t in range(n_tracks):
+        a, b = int(seg[t]), int(seg[t + 1])
+        k = int(torch.searchsorted(s[a:b], torch.tensor([hi], device=s.device, dtype=s.dtype), right=True).item())   # 1-based start <= hi
+        S.append(s[a:a + k].cpu().numpy())
+        F.append(np.minimum(f[a:a + k].cpu().numpy(), hi + 1))
+        V.append(v[a:a + k].cpu().numpy().astype(np.float64))
+        so.append(so[-1] + k)
+    del s, f, v
+    return dict(n_chrom=1, n_tracks=n_tracks, seg_off=np.array(so, np.int64), start=np.concatenate(S),
+                finish=np.concatenate(F).astype(np.int32), value=np.concatenate(V), defaults=np.zeros(n_tracks))
 
 
-def cpu_baseline(seg_off, start, finish, value, n_chrom, n_tracks, target_s=15.0):
-    """Times the COMPILED REFERENCE (oracle/_ref, else our C restatement) on a bounded
-    sample: the first `sample_bp` positions of chromosome 0 of this very batch."""
+def _time_cpu(d, op, n_set0):
     from oracle import oracle as O
     O.build()
-    have_ref = O.have_ref()
+    code = O.OPS["mwu" if op == "wilcoxon" else op]
+    if O.have_ref() and code <= 9:
+        sec, runs, bp = O.ref_time_reduce(d, code)
+        return sec, bp, "reference"
+    t0 = time.perf_counter()
+    c, s, f, v = O.reduce(d, code, n_set0=n_set0)
+    return time.perf_counter() - t0, int((f.astype(np.int64) - s).sum()), "port"
 
-    def sample(sample_bp):
-        so = [0]
-        S, F, V = [], [], []
-        for i in range(n_tracks):
-            lo, hi = int(seg_off[i]), int(seg_off[i + 1])
-            s = start[lo:hi]
-            cut = int((s <= sample_bp).sum().item())
-            S.append(start[lo:lo + cut].cpu().numpy())
-            f = finish[lo:lo + cut].cpu().numpy().copy()
-            np.minimum(f, sample_bp + 1, out=f)
-            F.append(f)
-            V.append(value[lo:lo + cut].cpu().numpy().astype(np.float64))
-            so.append(so[-1] + cut)
-        return dict(n_chrom=1, n_tracks=n_tracks, seg_off=np.array(so, np.int64),
-                    start=np.concatenate(S), finish=np.concatenate(F), value=np.concatenate(V),
-                    defaults=np.zeros(n_tracks))
 
-    def run(d):
-        if have_ref:
-            sec, runs, bp = O.ref_time_reduce(d, "mean")
-            return sec, bp
-        t0 = time.perf_counter()
-        c, s, f, v = O.reduce(d, "mean")
-        return time.perf_counter() - t0, int((f - s).sum())
+def _many_core_worker(args):
+    (k, chrom_id, chrom_len, n_tracks, mean_run, lo, hi, op, n_set0, t_go) = args
+    d = _sample_tracks(chrom_id, chrom_len, n_tracks, mean_run, lo, hi)
+    while time.time() < t_go:           # common start: the regions are evaluated side by side
+        time.sleep(0.001)
+    t0 = time.time()
+    sec, bp, kind = _time_cpu(d, op, n_set0)
+    return t0, time.time(), bp, kind
 
-    probe_bp = 200_000
-    sec, bp = run(sample(probe_bp))
+
+def cpu_baseline(chrom_ids, op, n_tracks, mean_run, chrom_lens, many_core=True, target_s=12.0):
+    """(a) as shipped: ONE evaluation thread (the reference never parallelises evaluation);
+    (b) reference-style many-core: one process per 30 Mbp region on every host core
+    (reference python/wiggletools/parallelWiggleTools.py:63,109), each timing a bounded slice of
+    its region.  Both on the bench's own tracks of the largest chromosome, sink = none."""
+    n_set0 = n_tracks // 2 if op == "wilcoxon" else 0
+    k0 = int(np.argmax(chrom_lens))
+    c0, clen = int(chrom_ids[k0]), int(chrom_lens[k0])
+    probe = _sample_tracks(c0, clen, n_tracks, mean_run, 0, min(100_000, clen))
+    sec, bp, kind = _time_cpu(probe, op, n_set0)
     rate = bp / max(sec, 1e-9)
-    sample_bp = int(min(max(rate * target_s, probe_bp), 64_000_000))
-    sec, bp = run(sample(sample_bp))
-    return {"value": bp / sec, "unit": "genomic bp/s", "cores": 1,
-            "kind": "reference" if have_ref else "port",
-            "sample": "mean over the same %d tracks, first %d bp of chromosome 0 of the bench batch, "
-                      "one evaluation thread (the reference never parallelises evaluation), sink=none; %.1f s"
-                      % (n_tracks, sample_bp, sec)}
+    sample_bp = int(min(max(rate * target_s, 100_000), clen, 16_000_000))
+    sec, bp, kind = _time_cpu(_sample_tracks_device(c0, clen, n_tracks, mean_run, sample_bp), op, n_set0)
+    out = {"value": bp / sec, "unit": "genomic bp/s", "cores": 1, "kind": kind,
+           "sample": "%s over the bench's own %d tracks, first %d bp of the largest chromosome, one evaluation thread "
+                     "(the reference never parallelises evaluation), sink=none; %.1f s" % (op, n_tracks, sample_bp, sec)}
+    nproc = os.cpu_count() or 1
+    out["host_cores"] = nproc
+    if many_core and nproc > 1:
+        import multiprocessing as mp
+        region = 30_000_000
+        workers = min(nproc, 256)
+        slice_bp = int(min(max(out["value"] * 4.0, 50_000), 2_000_000))     # ~4 s of evaluation per worker
+        # every worker first regenerates its slice with the generator's numpy mirror (~40 ns per
+        # track position), then all start evaluating at t_go
+        t_go = time.time() + 10.0 + slice_bp * n_tracks * 6e-8
+        jobs = []
+        for k in range(workers):
+            lo = (k * region) % max(clen - slice_bp, 1)
+            jobs.append((k, c0, clen, n_tracks, mean_run, lo, lo + slice_bp, op, n_set0, t_go))
+        try:
+            with mp.get_context("spawn").Pool(workers) as pool:
+                res = pool.map(_many_core_worker, jobs, chunksize=1)
+            t_first = min(r[0] for r in res)
+            t_last = max(r[1] for r in res)
+            late = max(r[0] for r in res) - t_go
+            out["many_core"] = {"value": sum(r[2] for r in res) / (t_last - t_first), "unit": "genomic bp/s",
+                                "cores": nproc, "workers": workers, "kind": res[0][3],
+                                "sample": "one process per 30 Mbp region (parallelWiggleTools.py:63,109), %d regions side by side, "
+                                          "each evaluating the first %d bp of its region; wall %.1f s, latest start %+.2f s after the common go"
+                                          % (workers, slice_bp, t_last - t_first, late)}
+        except Exception as e:      # never lose the bench line to the baseline
+            out["many_core"] = {"error": repr(e)[:200], "cores": nproc}
+    return out
 
 
+# ---------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--tracks", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--op", default=None, help="override the configuration's reducer(s), comma separated")
+    ap.add_argument("--tracks", type=int, default=None)
     ap.add_argument("--mean-run", type=float, default=16.0)
-    ap.add_argument("--scale", type=float, default=0.125, help="fraction of the GRCh38 lengths per step")
-    ap.add_argument("--op", default="mean")
+    ap.add_argument("--scale", type=float, default=1.0, help="fraction of the GRCh38 chromosome lengths (1 = 3.1 Gbp)")
     ap.add_argument("--n-set0", type=int, default=-1, help="two-sample ops: tracks in the first set (default N/2)")
+    ap.add_argument("--shard", default="genome", choices=["genome", "replicas"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-many-core", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -137,117 +180,204 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    store = None
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            store = None
 
-    from wiggletools_amd import engine
+    from wiggletools_amd import engine, synthgen
 
-    chrom_lens = [max(int(x * args.scale), 1) for x in GRCH38]
-    total_bp = sum(chrom_lens)
-    t0 = time.perf_counter()
-    seg_off, start, finish, value = synth_device(args.tracks, chrom_lens, args.mean_run, 0.02,
-                                                 20260927 + rank, device)
-    torch.cuda.synchronize()
-    gen_s = time.perf_counter() - t0
-    n_intervals = int(seg_off[-1])
-    ts = engine.TrackSet.from_device(len(chrom_lens), args.tracks, seg_off, start, finish, value,
-                                     np.zeros(args.tracks))
-    n_bad, first_bad = ts.validate()
-    assert n_bad == 0, "synthetic tracks violate the run-list contract (%d runs, first at %d)" % (n_bad, first_bad)
-    out = ts.alloc_runs()
+    cfg = CONFIGS[args.config]
+    ops = args.op.split(",") if args.op else cfg["ops"]
+    N = args.tracks if args.tracks else cfg["tracks"]
+    chrom_ids = cfg["chroms"]
+    chrom_lens = {c: max(int(GRCH38[c] * args.scale), 1) for c in chrom_ids}
+    queue = sorted(chrom_ids, key=lambda c: -chrom_lens[c])         # host-side work queue: largest first
+    genome_bp = sum(chrom_lens.values())
+    two = any(engine.opcode(o) in (10, 11) for o in ops)
+    n_set0 = (args.n_set0 if args.n_set0 >= 0 else N // 2) if two else 0
     stream = torch.cuda.current_stream().cuda_stream
+    replicas = world > 1 and args.shard == "replicas"
+    seed = SEED + (rank if replicas else 0)
 
-    two = engine.opcode(args.op) in (10, 11)
-    n_set0 = (args.n_set0 if args.n_set0 >= 0 else args.tracks // 2) if two else 0
+    def my_items(pass_no):
+        """Work queue of one pass.  One GPU / replicas: every chromosome.  Sharded genome: tickets
+        from a counter in the rendezvous store (dynamic), else a static largest-first deal."""
+        if world == 1 or replicas:
+            yield from queue
+        elif store is not None:
+            while True:
+                k = store.add("wt_queue_%d" % pass_no, 1) - 1
+                if k >= len(queue):
+                    return
+                yield queue[k]
+        else:
+            load = [0] * world
+            for c in queue:
+                r = int(np.argmin(load))
+                load[r] += chrom_lens[c]
+                if r == rank:
+                    yield c
 
-    def step(sync=False):
-        ts.index(args.op, stream)
-        return ts.reduce(args.op, out, n_set0=n_set0, stream=stream, sync=sync)
+    agg = dict(bp=0.0, auc=0.0, runs=0.0, intervals=0.0, windows=0.0)
+    moments = {}
+    stats_last = {}
+    per_item = {}
+    gen_s = 0.0
 
-    for _ in range(max(args.warmup, 0)):
-        step(sync=True)
-    n_runs = step(sync=True) if args.warmup == 0 else out.n
-    st = ts.stats()
-    covered_bp = st["covered_bp"]
+    def one_pass(pass_no, record):
+        nonlocal gen_s
+        hot_s = 0.0
+        idx_ms = red_ms = 0.0
+        for c in my_items(pass_no):
+            t0 = time.perf_counter()
+            seg, s, f, v = synthgen.device_tracks(seed, [chrom_lens[c]], N, args.mean_run, 0.02, 800, device, chrom_ids=[c])
+            ts = engine.TrackSet.from_device(1, N, seg, s, f, v, np.zeros(N))
+            out = ts.alloc_runs()
+            torch.cuda.synchronize()
+            gen_s += time.perf_counter() - t0
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(1 + 2 * len(ops))]
+            # ---- timed: inputs resident, outputs resident ----
+            t0 = time.perf_counter()
+            ev[0].record()
+            for j, op in enumerate(ops):
+                ts.index(op, stream)
+                ev[1 + 2 * j].record()
+                ts.reduce(op, out, n_set0=n_set0, stream=stream, sync=False)
+                ev[2 + 2 * j].record()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            # ---- untimed bookkeeping ----
+            hot_s += dt
+            for j in range(len(ops)):
+                idx_ms += ev[2 * j].elapsed_time(ev[1 + 2 * j])
+                red_ms += ev[1 + 2 * j].elapsed_time(ev[2 + 2 * j])
+            if record:
+                n_runs = ts.reduce(ops[-1], out, n_set0=n_set0, stream=stream, sync=True)
+                st = ts.stats()
+                agg["bp"] += st["covered_bp"]; agg["runs"] += n_runs; agg["intervals"] += int(seg[-1])
+                agg["windows"] += st["n_windows"] * len(ops)
+                agg["auc"] += out.auc()
+                stats_last.update(st)
+                per_item[c] = dt * 1e3
+                if args.config == "c5" or world > 1:
+                    # Pearson moments of tracks 0 and 1 of this chromosome (scalar gather readiness)
+                    a, b = int(seg[0]), int(seg[2])
+                    ts2 = engine.TrackSet.from_device(1, 2, seg[:3] - seg[0], s[a:b], f[a:b], v[a:b], np.zeros(2))
+                    moments[c] = ts2.pearson_moments()
+                    ts2.close()
+            ts.close()
+            del ts, out, s, f, v
+        return hot_s, idx_ms, red_ms
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    for w in range(max(args.warmup, 0)):
+        one_pass(-1 - w, False)
+
+    pass_s, idx_tot, red_tot = [], 0.0, 0.0
     for k in range(args.steps):
-        ev[k][0].record()
-        ts.index(args.op, stream)
-        ev[k][1].record()
-        ts.reduce(args.op, out, n_set0=n_set0, stream=stream, sync=False)
-        ev[k][2].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    index_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    reduce_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        hs, im, rm = one_pass(k, k == args.steps - 1)
+        t = torch.tensor([hs], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)        # a pass is over when the slowest rank is
+            dist.barrier()
+        pass_s.append(float(t.item()))
+        idx_tot += im; red_tot += rm
+    elapsed = float(sum(pass_s))
 
-    # post-timing verification + scalar gather (RCCL over xGMI when world > 1)
-    n_runs = ts.reduce(args.op, out, n_set0=n_set0, stream=stream, sync=True)
-    st = ts.stats()
-    covered_bp = st["covered_bp"]
-    auc = out.auc()
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    agg = torch.tensor([float(covered_bp), auc, float(n_runs), float(n_intervals)], dtype=torch.float64, device=device)
+    # genome-wide scalars (RCCL over xGMI when world > 1): sums by all_reduce, Pearson by all_gather + ordered merge
+    vec = torch.tensor([agg["bp"], agg["auc"], agg["runs"], agg["intervals"], agg["windows"], idx_tot, red_tot, gen_s],
+                       dtype=torch.float64, device=device)
+    mom = torch.zeros((len(GRCH38), 6), dtype=torch.float64, device=device)
+    for c, m in moments.items():
+        mom[c] = torch.tensor(m, dtype=torch.float64, device=device)
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    tot_bp, tot_auc, tot_runs, tot_intervals = [float(x) for x in agg.tolist()]
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        gathered = [torch.zeros_like(mom) for _ in range(world)]
+        dist.all_gather(gathered, mom)
+        mom = gathered[0] if replicas else torch.stack(gathered).sum(0)   # every row is computed by exactly one rank
+    tot_bp, tot_auc, tot_runs, tot_int, tot_win, idx_all, red_all, gen_all = [float(x) for x in vec.tolist()]
+    pearson = None
+    if moments or world > 1:
+        from wiggletools_amd import shard
+        rows = mom.cpu().numpy()
+        order = sorted(chrom_ids, key=lambda c: ("chr%d" % (c + 1)).encode())       # strcmp order (multiplexer.c:56)
+        pearson = shard.pearson_from_moments([rows[c] for c in order if rows[c][0] > 0])
 
     if rank == 0:
-        N = args.tracks
-        # algorithmic bytes of ONE launch of the dominant (fused multiplex+reduce) kernel on this
-        # rank: every input run read once (start,finish,value = 12 B), the two window-index rows
-        # per window, every output run written once (start,finish,f64 value = 16 B).  DESIGN.md 4.
-        alg_bytes = 12.0 * n_intervals + 8.0 * N * st["n_windows"] + 16.0 * n_runs
-        achieved = alg_bytes / (reduce_ms * 1e-3) / 1e9
-        tile_equiv = n_runs * (4.0 * N + N / 8.0 + 24.0) / (reduce_ms * 1e-3) / 1e9   # SURVEY 8d tile figure
-        # HBM bytes per launch from the PMC passes (profiles/traffic.json, measured with
-        # tools_prof.sh): stored as a ratio to the algorithmic bytes of the profiled launch and
-        # scaled to this launch; None when no profile has been taken for this kernel.
-        traffic = None
+        passes = args.steps
+        bp_per_pass = tot_bp                                # the record pass: every rank's share, summed
+        value = bp_per_pass * passes / elapsed
+        kern = stats_last.get("kernel", 0)
+        kernel = ("wt_delta_kernel<%s>" % ops[-1]) if kern == 1 else ("wt_reduce_kernel<%s,f32>" % ops[-1])
+        # algorithmic bytes of the fused multiplex+reduce launches of ONE pass: every input run read
+        # once per launch (start, finish, value = 12 B), the two window-index rows per window, every
+        # output run written once (start, finish, f64 value = 16 B).  DESIGN.md 4.6.
+        # Launches differ in size (one per chromosome), so the rate is bytes of all launches of a pass /
+        # their summed durations (HIP events on the launch stream, around every launch) -- the
+        # duration-weighted mean of the per-launch rates; with N GPUs: the per-GPU mean.
+        alg_bytes = len(ops) * (12.0 * tot_int + 16.0 * tot_runs) + 8.0 * N * tot_win
+        kernel_ms_sum = red_all / passes                    # per pass, summed over launches (and ranks)
+        achieved = alg_bytes / (kernel_ms_sum * 1e-3) / 1e9
+        tile_equiv = len(ops) * tot_runs * (4.0 * N + N / 8.0 + 24.0) / (kernel_ms_sum * 1e-3) / 1e9
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        kernel = ("wt_delta_kernel<%s>" % args.op) if st.get("kernel") == 1 else ("wt_reduce_kernel<%s,f32>" % args.op)
-        if os.path.exists(tpath) and args.op == "mean":
+        if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
                     traffic = tj["hbm_bytes_per_algorithmic_byte"] * alg_bytes
+                    traffic_src = "PMC passes of %s (profiles/traffic.json: FETCH_SIZE + WRITE_SIZE per launch, ratio to that launch's algorithmic bytes) scaled to this launch" % tj.get("profile", "an earlier profile")
             except Exception:
                 traffic = None
+        bound = {"wt_delta_kernel": "hbm"}.get(kernel.split("<")[0], "hbm")
+        note = None
+        if kern == 0:
+            o = ops[-1]
+            if o in ("median", "wilcoxon", "mwu"):
+                bound, note = "issue", "value columns in LDS cap the waves per CU: dependent-VALU issue bound, not HBM (profiles/: SQ counters)"
+            else:
+                bound, note = "valu", "f32->f64 widen + add per (track, position): VALU bound (profiles/: VALUBusy)"
         res = {
-            "metric": "genomic bp/s (whole node) for 'mean' over N BigWig tracks",
-            "value": tot_bp * args.steps / elapsed,
-            "unit": "genomic bp/s",
+            "metric": "genomic bp/s (whole node) for 'mean' over N BigWig tracks" if ops == ["mean"] else
+                      "genomic bp/s (whole node) for '%s' over N tracks" % "+".join(ops),
+            "value": value, "unit": "genomic bp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int64" if st.get("kernel") == 1 else "f64", "data": "synthetic",
-            "config": {"workload": "%s over %d synthetic float32 run-list tracks, 24 chromosomes = GRCh38 x %g "
-                                   "(%.0f Mbp per GPU per step), mean run %g bp, 2%% gaps, tracks resident in HBM"
-                                   % (args.op, N, args.scale, total_bp / 1e6, args.mean_run),
-                       "op": args.op, "tracks": N, "mean_run_bp": args.mean_run, "bp_per_step_per_gpu": total_bp,
-                       "input_runs_per_gpu": n_intervals, "output_runs_per_gpu": n_runs,
-                       "window_bp": st["window_bp"], "lds_bytes_per_workgroup": st["lds_bytes"],
-                       "sharding": "one independent chromosome batch per GPU, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "kernel_ms": reduce_ms, "index_kernel_ms": index_ms,
-                         "tile_equivalent_GBs": tile_equiv},
-            "auc_check": tot_auc, "output_runs": tot_runs, "gen_seconds": gen_s,
+            "ms_per_step": elapsed / passes * 1e3,
+            "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
+            "dtype": "int64" if kern == 1 else "f64", "data": "synthetic",
+            "config": {"workload": "%s: %s over %d synthetic float32 run-list tracks, %d chromosome(s) = GRCh38 x %g = %.3f Gbp per step, "
+                                   "mean run %g bp, 2%% gaps; one step = one whole pass, chromosomes generated in HBM one at a time "
+                                   "(untimed) and processed resident (timed)"
+                                   % (args.config, "+".join(ops), N, len(chrom_ids), args.scale, genome_bp / 1e9, args.mean_run),
+                       "config": args.config, "ops": ops, "tracks": N, "mean_run_bp": args.mean_run,
+                       "genome_bp": genome_bp, "covered_bp_per_step": bp_per_pass,
+                       "input_runs_per_step": tot_int, "output_runs_per_step": tot_runs,
+                       "window_bp": stats_last.get("window_bp"), "lds_bytes_per_workgroup": stats_last.get("lds_bytes"),
+                       "sharding": ("replicas: every rank walks its own genome" if replicas else
+                                    "one genome, chromosomes from a shared host-side work queue (store counter), no data-path collective")
+                                   if world > 1 else "single GPU"},
+            "roofline": {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch": "the %d launches of one pass (one per chromosome%s)" % (len(per_item) * len(ops) if world == 1 else int(len(chrom_ids) * len(ops)), ", per reducer" if len(ops) > 1 else ""),
+                         "kernel_ms": kernel_ms_sum, "index_kernel_ms": idx_all / passes,
+                         "tile_equivalent_GBs": tile_equiv, "note": note},
+            "auc_check": tot_auc, "pearson_tracks_0_1": pearson, "output_runs": tot_runs,
+            "gen_seconds_total": gen_all, "pass_seconds": pass_s,
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(seg_off, start, finish, value, len(chrom_lens), N)
-            res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+            lens = [chrom_lens[c] for c in chrom_ids]
+            cb = cpu_baseline(chrom_ids, ops[-1], N, args.mean_run, lens, many_core=not args.no_many_core)
+            # the generator's chromosome ids: the sample is the largest chromosome of this configuration
+            res["cpu_baseline"] = cb
+            res["speedup_vs_cpu_baseline"] = value / cb["value"]
+            if "many_core" in cb and "value" in cb["many_core"]:
+                res["speedup_vs_many_core_cpu"] = value / cb["many_core"]["value"]
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

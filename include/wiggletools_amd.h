@@ -308,6 +308,13 @@ int wtamd_runs_mean(const wtamd_runs *runs, int64_t n_runs, double *mean, void *
  * NaN when T_XX*T_YY == 0 (statistics.c:421-423).  Slices of runs are merged with the reference's
  * own update formula, so the result agrees to rounding (not bit-for-bit). */
 int wtamd_pearson(wtamd_trackset *ts, double *result);
+/* The same as six moments {n, sum_X, sum_Y, T_XX, T_XY, T_YY} of this track set's part of the genome,
+ * so that shards (chromosomes on different GPUs) can be combined: gather the 6 doubles per shard
+ * (RCCL all_gather), then merge IN GENOME ORDER with wtamd_pearson_merge -- the reference's update is
+ * sequential (statistics.c:442-456), a pairwise merge agrees to rounding -- and finish. */
+int wtamd_pearson_moments(wtamd_trackset *ts, double *moments6);
+void wtamd_pearson_merge(double *a6, const double *b6);     /* a := a (+) b, b after a in genome order; HOST */
+double wtamd_pearson_finish(const double *m6);               /* T_XY / sqrt(T_XX T_YY), NaN if 0 (statistics.c:421-423) */
 
 /* The reference's `map`-able unary operators (src/unaryOps.c: scale :650-664, offset :722-734,
  * ln / log :760-813, exp :823-866, pow :873-899, abs :934-949; commandParser.c:115-211) applied to
@@ -436,6 +443,18 @@ uint32_t wtamd_bw_chrom_length(const wtamd_bw *, int i);
  * of runs; when that exceeds `capacity` nothing was written (call again with more room). */
 int64_t wtamd_bw_read_chrom(wtamd_bw *, const char *chrom, int box, int64_t capacity,
                             int32_t *start, int32_t *finish, float *value);
+
+/* ---- Synthetic workload generator of SURVEY 8d, on device (bench / test plumbing; csrc/wt_synth.hip).
+ * Counter-based: position x of (chromosome c, track t) is a breakpoint iff a hash of (seed, c, t, x)
+ * falls below 2^32 / mean_run, the run starting there takes value k/8 (k < levels) and its gap flag
+ * from a second hash -- any piece can be regenerated anywhere (wiggletools_amd/synthgen.py holds the
+ * numpy mirror the CPU baseline uses).  Two passes with the caller's exclusive scan in between:
+ * plan -> count (per 4096-position block) -> scan -> fill. */
+int wtamd_synth_plan(int n_chrom, const int32_t *chrom_len, int n_tracks, int64_t *n_blocks, int64_t *seg_first_block);
+int wtamd_synth_count(uint64_t seed, int n_chrom, const int32_t *chrom_len, int n_tracks, double mean_run, double gap_prob,
+                      int levels, int64_t *counts, void *stream);
+int wtamd_synth_fill(uint64_t seed, int n_chrom, const int32_t *chrom_len, int n_tracks, double mean_run, double gap_prob,
+                     int levels, const int64_t *block_off, int32_t *start, int32_t *finish, float *value, void *stream);
 
 /* Default value a reducer iterator advertises to its parent
  * (reference reducers.c ctor of each op, incl. float truncations). HOST only. */

@@ -69,6 +69,11 @@ def lib():
     L.wtamd_runs_compress.argtypes = [C.POINTER(Runs), C.c_int64, C.c_int32, C.POINTER(Runs), C.POINTER(C.c_int64), C.c_void_p]
     L.wtamd_trackset_validate.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.wtamd_pearson.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.wtamd_pearson_moments.argtypes = [C.c_void_p, C.c_void_p]
+    L.wtamd_pearson_merge.argtypes = [C.c_void_p, C.c_void_p]
+    L.wtamd_pearson_merge.restype = None
+    L.wtamd_pearson_finish.argtypes = [C.c_void_p]
+    L.wtamd_pearson_finish.restype = C.c_double
     L.wtamd_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.wtamd_bw_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     L.wtamd_bw_close.argtypes = [C.c_void_p]

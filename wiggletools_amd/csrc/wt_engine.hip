@@ -581,7 +581,8 @@ __global__ void wt_pearson_final_kernel(const WtMoments *partial, int n, double 
         WtMoments m = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < n; i++) wt_moments_merge(m, partial[i]);
         const double den = m.txx * m.tyy;
-        *out = den ? m.txy / sqrt(den) : __builtin_nan("");            // statistics.c:421-423
+        out[0] = den ? m.txy / sqrt(den) : __builtin_nan("");          // statistics.c:421-423
+        out[1] = m.n; out[2] = m.sx; out[3] = m.sy; out[4] = m.txx; out[5] = m.txy; out[6] = m.tyy;
     }
 }
 
@@ -1379,8 +1380,8 @@ int wtamd_runs_mean(const wtamd_runs *runs, int64_t n_runs, double *mean, void *
     return WTAMD_OK;
 }
 
-int wtamd_pearson(wtamd_trackset *ts, double *result) {
-    if (!ts || !result) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+// result[0] = correlation, result[1..6] = {n, sum_X, sum_Y, T_XX, T_XY, T_YY}
+static int wt_pearson_impl(wtamd_trackset *ts, double *result7) {
     if (ts->n_tracks != 2) return wt_fail(WTAMD_ERR_ARG, "wtamd_pearson: the track set must hold exactly two tracks");
     int64_t cap = wtamd_trackset_max_runs(ts);
     const int64_t alloc = cap > 0 ? cap : 1;
@@ -1399,17 +1400,51 @@ int wtamd_pearson(wtamd_trackset *ts, double *result) {
     WT_HIP(scope.alloc(&d_tile, sizeof(double) * alloc * 2));
     WT_HIP(scope.alloc(&d_inplay, sizeof(uint8_t) * alloc * 2));
     WT_HIP(scope.alloc(&d_partial, sizeof(WtMoments) * blocks));
-    WT_HIP(scope.alloc(&d_out, sizeof(double)));
+    WT_HIP(scope.alloc(&d_out, sizeof(double) * 7));
     int64_t n = 0;
     int rc = wt_reduce_impl(ts, WT_OP_MULTIPLEX, 0, 0, &d, d_tile, d_inplay, &n, nullptr);
     if (rc == WTAMD_OK) {
         hipLaunchKernelGGL(wt_pearson_kernel, dim3(blocks), dim3(256), 0, nullptr, d.start, d.finish, d_tile, d_inplay,
                            ts->defaults[0], ts->defaults[1], (long long) n, d_partial);
         hipLaunchKernelGGL(wt_pearson_final_kernel, dim3(1), dim3(64), 0, nullptr, d_partial, blocks, d_out);
-        if (hipGetLastError() != hipSuccess || hipMemcpy(result, d_out, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        if (hipGetLastError() != hipSuccess || hipMemcpy(result7, d_out, sizeof(double) * 7, hipMemcpyDeviceToHost) != hipSuccess)
             rc = wt_fail(WTAMD_ERR_HIP, "wtamd_pearson: kernel launch / copy failed");
     }
     return rc;
+}
+
+int wtamd_pearson(wtamd_trackset *ts, double *result) {
+    if (!ts || !result) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    double r[7];
+    const int rc = wt_pearson_impl(ts, r);
+    if (rc == WTAMD_OK) *result = r[0];
+    return rc;
+}
+
+int wtamd_pearson_moments(wtamd_trackset *ts, double *moments) {
+    if (!ts || !moments) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    double r[7];
+    const int rc = wt_pearson_impl(ts, r);
+    if (rc == WTAMD_OK) memcpy(moments, r + 1, sizeof(double) * 6);
+    return rc;
+}
+
+// a := a (+) b on the host, b following a in genome order -- the same pairwise step the kernels use
+void wtamd_pearson_merge(double *a, const double *b) {
+    if (b[0] == 0) return;
+    if (a[0] == 0) { memcpy(a, b, sizeof(double) * 6); return; }
+    const double n = a[0] + b[0];
+    const double dx = b[1] / b[0] - a[1] / a[0], dy = b[2] / b[0] - a[2] / a[0];
+    const double w = a[0] * b[0] / n;
+    a[3] += b[3] + dx * dx * w;
+    a[4] += b[4] + dx * dy * w;
+    a[5] += b[5] + dy * dy * w;
+    a[0] = n; a[1] += b[1]; a[2] += b[2];
+}
+
+double wtamd_pearson_finish(const double *m) {
+    const double den = m[3] * m[5];
+    return den ? m[4] / sqrt(den) : __builtin_nan("");          // statistics.c:421-423
 }
 
 int wtamd_trackset_validate(wtamd_trackset *ts, int64_t *n_bad, int64_t *first_bad) {

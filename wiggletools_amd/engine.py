@@ -145,6 +145,12 @@ class TrackSet:
         _lib.check(_lib.lib().wtamd_pearson(self._h, C.byref(out)))
         return out.value
 
+    def pearson_moments(self):
+        """{n, sum_X, sum_Y, T_XX, T_XY, T_YY} of this track set's part of the genome (6 doubles)."""
+        m = np.zeros(6, np.float64)
+        _lib.check(_lib.lib().wtamd_pearson_moments(self._h, m.ctypes.data))
+        return m
+
     # ---- host-output convenience (tests, drop-in layer) ----
     def reduce_host(self, op, flags=0, n_set0=0):
         """Returns (chrom, start, finish, value) numpy arrays."""

@@ -79,3 +79,41 @@ def allreduce_scalars(values, group=None):
     t = torch.tensor(list(values), dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return [float(x) for x in t.tolist()]
+
+
+def merge_moments(a, b):
+    """a (+) b for two Pearson moment vectors {n, sum_X, sum_Y, T_XX, T_XY, T_YY}, b after a in genome
+    order: the pairwise form of the reference's sequential update (statistics.c:442-456)."""
+    a = np.array(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if b[0] == 0:
+        return a
+    if a[0] == 0:
+        return b.copy()
+    n = a[0] + b[0]
+    dx, dy = b[1] / b[0] - a[1] / a[0], b[2] / b[0] - a[2] / a[0]
+    w = a[0] * b[0] / n
+    return np.array([n, a[1] + b[1], a[2] + b[2], a[3] + b[3] + dx * dx * w, a[4] + b[4] + dx * dy * w,
+                     a[5] + b[5] + dy * dy * w])
+
+
+def pearson_from_moments(rows):
+    """Pearson correlation from per-shard moment vectors listed in genome order (NaN when undefined,
+    statistics.c:421-423)."""
+    m = np.zeros(6)
+    for r in rows:
+        m = merge_moments(m, r)
+    den = m[3] * m[5]
+    return float(m[4] / np.sqrt(den)) if den else float("nan")
+
+
+def allgather_moments(mine, group=None):
+    """all_gather of one [n_items, 6] moment table per rank (rows a rank did not compute are zero)
+    -> their sum, i.e. the full table (each row is computed by exactly one rank)."""
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.as_tensor(np.asarray(mine, np.float64), device=dev)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t, group=group)
+    return torch.stack(out).sum(0).cpu().numpy()
