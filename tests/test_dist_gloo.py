@@ -84,3 +84,83 @@ def test_plan_shards_covers_every_position_once():
             assert owned[0][0] <= e[0] and owned[-1][1] >= e[1]
             for a, b in zip(owned, owned[1:]):
                 assert a[1] == b[0]
+
+
+def _moments_sequential(tile, inplay, start, finish, dx, dy):
+    """The reference's run-by-run update of {count, sum_X, sum_Y, T_XX, T_XY, T_YY}
+    (statistics.c:442-456, weights = run lengths) over a 2-track Multiplexer tile -- test helper
+    standing in for the device kernel (wt_pearson_kernel) in the GPU-less world-2 test."""
+    n = sx = sy = txx = txy = tyy = 0.0
+    for r in range(len(start)):
+        X = tile[r, 0] if inplay[r, 0] else dx
+        Y = tile[r, 1] if inplay[r, 1] else dy
+        L = float(finish[r] - start[r])
+        if n > 0:
+            nn = n + L
+            omx, nmx, omy, nmy, ratio = sx / n, sx / nn, sy / n, sy / nn, n / nn
+            txy += (nmx * omy + ratio * X * Y - nmx * Y - nmy * X) * L
+            txx += (nmx * (omx - 2 * X) + ratio * X * X) * L
+            tyy += (nmy * (omy - 2 * Y) + ratio * Y * Y) * L
+        n += L; sx += X * L; sy += Y * L
+    return np.array([n, sx, sy, txx, txy, tyy])
+
+
+def _pearson_worker(rank, world, port, q):
+    """Chromosomes dealt out by the shared work queue (a counter in the rendezvous store, as
+    bench.py --shard genome does); per-chromosome Pearson moments; all_gather; ordered merge."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    store = dist.distributed_c10d._get_default_store()
+    from emu import emu
+    from wiggletools_amd import shard
+    from wiggletools_amd.runlists import RunLists, synth
+    t = synth(2, [4000, 2500, 300, 3500, 900], mean_run=7, seed=4, gap_prob=0.1)
+    N = 2
+    table = np.zeros((t.n_chrom, 6))
+    mine = []
+    while True:
+        c = store.add("wt_queue_0", 1) - 1          # host-side work queue: the next chromosome
+        if c >= t.n_chrom:
+            break
+        mine.append(c)
+        a, b = int(t.seg_off[c * N]), int(t.seg_off[c * N + 2])
+        one = RunLists(1, 2, t.seg_off[c * N:c * N + 3] - t.seg_off[c * N], t.start[a:b], t.finish[a:b], t.value[a:b], t.defaults)
+        (chrom, s, f, tile, ip), _ = emu.reduce(one, "sum", multiplex=True)
+        table[c] = _moments_sequential(tile, ip, s, f, t.defaults[0], t.defaults[1])
+    full = shard.allgather_moments(table)
+    owners = [None] * world
+    dist.all_gather_object(owners, mine)
+    if rank == 0:
+        q.put((full, owners))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pearson_gather_and_ordered_merge(oracle):
+    """The genome-wide Pearson of a 2-track set sharded by chromosome over 2 ranks: 6 doubles per
+    shard through all_gather, merged pairwise in genome order == the unsharded sequential result."""
+    import torch.multiprocessing as mp
+    from wiggletools_amd import shard
+    from wiggletools_amd.runlists import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pearson_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    full, owners = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(owners[0] + owners[1]) == [0, 1, 2, 3, 4]             # every chromosome exactly once
+    t = synth(2, [4000, 2500, 300, 3500, 900], mean_run=7, seed=4, gap_prob=0.1)
+    exp = oracle.pearson(t.as_dict())
+    got = shard.pearson_from_moments([full[c] for c in range(t.n_chrom)])
+    assert abs(got - exp) <= 1e-9 * abs(exp), (got, exp)
+    # the order matters only to rounding; a wrong merge formula would not survive a shuffle either
+    shuffled = shard.pearson_from_moments([full[c] for c in (3, 0, 4, 2, 1)])
+    assert abs(shuffled - exp) <= 1e-9 * abs(exp)

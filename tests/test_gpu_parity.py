@@ -392,6 +392,31 @@ def test_gpu_pearson_golden_and_degenerate(oracle, engine):
     ts.close()
 
 
+def test_gpu_pearson_moments_per_chromosome_merge(oracle, engine):
+    """Multi-GPU readiness of the Pearson gather: the 6 moments of every chromosome on its own
+    (wtamd_pearson_moments), merged in genome order on the host (wtamd_pearson_merge / _finish and
+    their Python mirror in shard.py) == Pearson over the whole genome in one go == the oracle."""
+    import ctypes as C
+    from wiggletools_amd import _lib, shard
+    from wiggletools_amd.runlists import RunLists, synth
+    t = synth(2, [90000, 41000, 700, 66000], mean_run=9, gap_prob=0.1, seed=77)
+    exp = oracle.pearson(t.as_dict())
+    rows = []
+    for c in range(t.n_chrom):
+        a, b = int(t.seg_off[2 * c]), int(t.seg_off[2 * c + 2])
+        one = RunLists(1, 2, t.seg_off[2 * c:2 * c + 3] - t.seg_off[2 * c], t.start[a:b], t.finish[a:b], t.value[a:b], t.defaults)
+        ts = engine.TrackSet.from_runlists(one)
+        rows.append(ts.pearson_moments())
+        ts.close()
+    assert abs(shard.pearson_from_moments(rows) - exp) <= 1e-9 * abs(exp)
+    acc = np.zeros(6)
+    L = _lib.lib()
+    for r in rows:
+        L.wtamd_pearson_merge(acc.ctypes.data, np.ascontiguousarray(r).ctypes.data)
+    assert abs(L.wtamd_pearson_finish(acc.ctypes.data) - exp) <= 1e-9 * abs(exp)
+    assert acc[0] == sum(r[0] for r in rows)
+
+
 def test_gpu_input_contract_validation(engine):
     """wtamd_trackset_validate: zero-length, inverted and overlapping runs are counted; a run list
     may start a new (chrom, track) segment below the previous segment's last finish."""
