@@ -153,6 +153,62 @@ def cpu_baseline(chrom_ids, op, n_tracks, mean_run, chrom_lens, many_core=True, 
 
 
 # ---------------------------------------------------------------------------------------------
+# End to end through the drop-in layer: first pop -> last run on the host (SURVEY 8d metric 1)
+# ---------------------------------------------------------------------------------------------
+def e2e_dropin(op, n_tracks, mean_run, mbp, device):
+    """The reference's own C API (newMultiplexer + <op>Reduction) over N array-backed tracks in
+    PINNED host memory, from the constructor (which primes: the first pop) to the last run on the
+    host.  Two legs on the same tracks:
+      pop   the reference's protocol on both sides: children popped one interval per indirect call,
+            runs taken one pop at a time (what any foreign reader / consumer gets);
+      bulk  the library's bulk doors: children hand over SoA blocks that the copy engine reads where
+            they lie, runs taken in blocks.
+    Both run the pinned-staging / 3-stream pipeline of csrc/wt_pipe.h underneath."""
+    import torch
+    from wiggletools_amd import dropin, synthgen
+    L = int(mbp * 1e6)
+    seg, s, f, v = synthgen.device_tracks(SEED, [L], n_tracks, mean_run, 0.02, 800, device, chrom_ids=[40])
+    n = int(seg[-1])
+    hs, hf, hv = dropin.PinnedArray(n, np.int32), dropin.PinnedArray(n, np.int32), dropin.PinnedArray(n, np.float32)
+    torch.from_numpy(hs.array).copy_(s); torch.from_numpy(hf.array).copy_(f); torch.from_numpy(hv.array).copy_(v)
+    torch.cuda.synchronize()
+    del s, f, v
+    torch.cuda.empty_cache()
+
+    def readers(limit_bp):
+        its = []
+        for t in range(n_tracks):
+            a, b = int(seg[t]), int(seg[t + 1])
+            if limit_bp < L:
+                b = a + int(np.searchsorted(hs.array[a:b], limit_bp))
+            its.append(dropin.array_reader(["chr1"], [0, b - a], hs.ptr + 4 * a, hf.ptr + 4 * a, hv.ptr + 4 * a))
+        return its
+
+    out = {"tracks": n_tracks, "mean_run_bp": mean_run, "op": op, "host_bytes_per_bp": 12.0 * n / L,
+           "pcie_h2d_roofline_bp_per_s": 63e9 / (12.0 * n / L)}
+    # bulk leg
+    os.environ.pop("WTAMD_NO_BULK", None)
+    t0 = time.perf_counter()
+    r = dropin.reducer(op, readers(L), n_set0=n_tracks // 2)
+    runs, _ = dropin.drain_blocks(r)
+    dt = time.perf_counter() - t0
+    out["bulk"] = {"bp_per_s": L / dt, "seconds": dt, "bp": L, "runs": runs,
+                   "h2d_GBs": 12.0 * n / dt / 1e9, "d2h_GBs": 16.0 * runs / dt / 1e9}
+    # pop leg (a slice: it is ~50x slower)
+    os.environ["WTAMD_NO_BULK"] = "1"
+    pop_bp = int(min(L, 20e6))
+    t0 = time.perf_counter()
+    r = dropin.reducer(op, readers(pop_bp), n_set0=n_tracks // 2)
+    runs, bp, acc = dropin.drain_pops(r)
+    dt = time.perf_counter() - t0
+    os.environ.pop("WTAMD_NO_BULK", None)
+    out["pop"] = {"bp_per_s": bp / dt, "seconds": dt, "bp": bp, "runs": runs,
+                  "child_pops_per_s": (12.0 * n / L * bp / 12.0) / dt}
+    hs.free(); hf.free(); hv.free()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,6 +223,8 @@ def main():
     ap.add_argument("--shard", default="genome", choices=["genome", "replicas"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-many-core", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-mbp", type=float, default=100.0, help="chromosome length of the end-to-end (drop-in layer) leg")
     args = ap.parse_args()
 
     import torch
@@ -370,6 +428,11 @@ def main():
             "auc_check": tot_auc, "pearson_tracks_0_1": pearson, "output_runs": tot_runs,
             "gen_seconds_total": gen_all, "pass_seconds": pass_s,
         }
+        if world == 1 and not args.no_e2e:
+            try:
+                res["e2e"] = e2e_dropin(ops[-1], N, args.mean_run, args.e2e_mbp * args.scale if args.scale < 1 else args.e2e_mbp, device)
+            except Exception as e:      # never lose the bench line to an extra leg
+                res["e2e"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             lens = [chrom_lens[c] for c in chrom_ids]
             cb = cpu_baseline(chrom_ids, ops[-1], N, args.mean_run, lens, many_core=not args.no_many_core)

@@ -417,6 +417,13 @@ int wtamd_pipe_acquire(wtamd_pipe *, wtamd_pipe_batch *out);
 /* Enlarges the acquired slot's staging to >= min_capacity intervals (and adds the float64 value
  * array if want_f64), preserving the first `used` entries of every array; *out is refreshed. */
 int wtamd_pipe_grow(wtamd_pipe *, int64_t used, int64_t min_capacity, int want_f64, wtamd_pipe_batch *out);
+/* Bulk side door: `count` float32-valued intervals of the acquired slot, at interval offset `at`
+ * of its arrays, are NOT staged -- the pipe copies them to HBM straight from the caller's arrays at
+ * submit (hipMemcpyAsync).  The arrays must stay valid and unchanged until the batch has been
+ * collected and should be pinned (wtamd_host_alloc); pageable memory still works but the copy is
+ * then staged by the runtime.  The staging arrays need not cover such ranges. */
+int wtamd_pipe_put_direct(wtamd_pipe *, int64_t at, int64_t count, const int32_t *start, const int32_t *finish,
+                          const float *value);
 /* Ships the acquired slot: seg_off[n_tracks] intervals of one chromosome, runs whose start lies in
  * [range_lo, range_hi) are produced (same meaning as wtamd_tracks.range_lo/hi).  Asynchronous. */
 int wtamd_pipe_submit(wtamd_pipe *, int value_is_f64, int32_t range_lo, int32_t range_hi);
@@ -429,6 +436,33 @@ int wtamd_pipe_release(wtamd_pipe *);
 /* Submitted batches not yet collected. */
 int wtamd_pipe_in_flight(const wtamd_pipe *);
 int wtamd_pipe_get_stats(const wtamd_pipe *, wtamd_pipe_stats *out);
+
+/* Pinned (page-locked, DMA-able) host memory for bulk sources. */
+void *wtamd_host_alloc(size_t bytes);
+void wtamd_host_free(void *);
+
+/* ---- Bulk doors of the drop-in layer ------------------------------------------------------
+ * The reference's iterator protocol moves ONE interval per indirect call (wiggleIterator.c:57-60);
+ * its own readers soften that with 10 000-entry SoA blocks between threads (bufferedReader.c:21-28).
+ * A child iterator built by this library exposes such blocks to the Multiplexer directly (producer
+ * side), and a reducer hands its runs over in blocks (consumer side -- what TeeWiggleIterator copies
+ * into its 10 000-entry blocks one pop at a time, wigWriter.c:164-203).  Both stay ordinary
+ * WiggleIterators: pop() / seek() work as always, foreign iterators are drained with pop(). */
+
+/* Array-backed reader: one track as SoA run lists in host memory (chromosomes in strcmp order,
+ * chromosome c = slice [seg_off[c], seg_off[c+1]) of the arrays; 1-based start, exclusive finish,
+ * float32 value).  The arrays are borrowed (and read by DMA when pinned).  Bulk-capable. */
+WiggleIterator *wtamd_ArrayReader(int n_chrom, const char *const *chrom_names, const int64_t *seg_off,
+                                  const int32_t *start, const int32_t *finish, const float *value,
+                                  double default_value);
+/* Consumer door, for reducers built by this library: the runs from the iterator's current element
+ * to the end of the batch it belongs to, as arrays valid until the next call on `wi`.  Returns the
+ * number of runs (0 and wi->done at the end).  Mixes freely with pop(). */
+int64_t wtamd_iterator_next_block(WiggleIterator *wi, const char **chrom, const int32_t **start,
+                                  const int32_t **finish, const double **value);
+/* runWiggleIterator with counters: pops `wi` to the end one run at a time (the reference's own
+ * protocol, wiggleIterator.c:62-65); returns the number of runs, their covered bp and value sum. */
+int64_t wtamd_drain(WiggleIterator *wi, int64_t *covered_bp, double *value_sum);
 
 /* ---- BigWig section decoder (bulk side door; replaces what the reference gets from libBigWig
  * through src/bigWiggleReader.c:52-83).  HOST only. ---- */

@@ -113,6 +113,8 @@ class Harness:
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_reducer_default.restype = C.c_double
         L.ref_reducer_default.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.ref_set_modes.argtypes = [C.c_int, C.c_int]
+        L.ref_set_modes.restype = None
         L.ref_reduce_seek_held.restype = C.c_int64
         L.ref_reduce_seek_held.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int,
                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -120,6 +122,11 @@ class Harness:
         L.ref_multiset_seek_held.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int64,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         self.L = L
+
+    def set_modes(self, child_mode=0, block_mode=0):
+        """child_mode 1: children are the tested library's own bulk-capable wtamd_ArrayReader (float32
+        values); block_mode 1: one-sample reducer output is taken through wtamd_iterator_next_block."""
+        self.L.ref_set_modes(child_mode, block_mode)
 
     def reduce(self, t, op, flags=0, n_set0=0):
         s, keep = _pack(t)

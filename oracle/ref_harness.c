@@ -47,6 +47,9 @@ static Multiset *(*r_newMultiset)(Multiplexer **, int);
 static void (*r_popMultiplexer)(Multiplexer *);
 static void (*r_popMultiset)(Multiset *);
 static void (*r_seekMultiset)(Multiset *, const char *, int, int);
+static WiggleIterator *(*r_ArrayReader)(int, const char *const *, const int64_t *, const int32_t *, const int32_t *,
+                                        const float *, double);
+static int64_t (*r_next_block)(WiggleIterator *, const char **, const int32_t **, const int32_t **, const double **);
 static void (*r_pop)(WiggleIterator *);
 static void (*r_seek)(WiggleIterator *, const char *, int, int);
 static WiggleIterator *(*r_SmartReader)(char *, wt_bool);
@@ -89,6 +92,8 @@ int ref_open(const char *path) {
      * drop-in library lacks readers / integrators it does not replace */
 #define OPT(var, name) *(void **) (&var) = dlsym(g_lib, name)
     OPT(r_seekMultiset, "seekMultiset");
+    OPT(r_ArrayReader, "wtamd_ArrayReader");
+    OPT(r_next_block, "wtamd_iterator_next_block");
     OPT(r_SmartReader, "SmartReader");
     OPT(r_AUCIntegrator, "AUCIntegrator");
     OPT(r_PearsonIntegrator, "PearsonIntegrator");
@@ -160,8 +165,30 @@ static void arr_seek(WiggleIterator *wi, const char *chrom, int start, int finis
 }
 
 static int g_hold;     /* children made from now on are held until their first seek */
+static int g_child_mode;   /* 1: children are the tested library's own bulk-capable wtamd_ArrayReader */
+static int g_block_mode;   /* 1: reducer output is taken through wtamd_iterator_next_block */
+
+void ref_set_modes(int child_mode, int block_mode) { g_child_mode = child_mode; g_block_mode = block_mode; }
+
+/* One track of the [chrom][track] layout as contiguous float32 SoA arrays for wtamd_ArrayReader. */
+static WiggleIterator *make_array_child(const wto_tracks *t, char **names, int track) {
+    int64_t n = 0;
+    for (int c = 0; c < t->n_chrom; c++) n += t->seg_off[(int64_t) c * t->n_tracks + track + 1] - t->seg_off[(int64_t) c * t->n_tracks + track];
+    int64_t *so = (int64_t *) calloc((size_t) t->n_chrom + 1, sizeof(int64_t));
+    int32_t *s = (int32_t *) malloc(sizeof(int32_t) * (size_t) (n + 1)), *f = (int32_t *) malloc(sizeof(int32_t) * (size_t) (n + 1));
+    float *v = (float *) malloc(sizeof(float) * (size_t) (n + 1));
+    int64_t k = 0;
+    for (int c = 0; c < t->n_chrom; c++) {
+        int64_t lo = t->seg_off[(int64_t) c * t->n_tracks + track], hi = t->seg_off[(int64_t) c * t->n_tracks + track + 1];
+        so[c] = k;
+        for (int64_t g = lo; g < hi; g++, k++) { s[k] = t->start[g]; f[k] = t->finish[g]; v[k] = (float) t->value[g]; }
+    }
+    so[t->n_chrom] = k;
+    return r_ArrayReader(t->n_chrom, (const char *const *) names, so, s, f, v, t->defaults[track]);
+}
 
 static WiggleIterator *make_child(const wto_tracks *t, char **names, int track) {
+    if (g_child_mode == 1 && r_ArrayReader) return make_array_child(t, names, track);
     arr_iter *a = (arr_iter *) calloc(1, sizeof(arr_iter));
     a->t = t; a->names = names; a->track = track; a->c = 0; a->j = -1;
     a->hold = g_hold;
@@ -188,6 +215,26 @@ static Multiplexer *make_multiplexer(const wto_tracks *t, char **names, int lo, 
     return m;
 }
 
+/* Consumer bulk door: a few plain pops first (the two protocols mix), then whole blocks. */
+static int64_t take_blocks(WiggleIterator *r, int64_t cap, int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value) {
+    int64_t n = 0;
+    for (int k = 0; k < 3 && !r->done; k++) {
+        if (n >= cap) return -1;
+        o_chrom[n] = name_to_index(r->chrom); o_start[n] = r->start; o_finish[n] = r->finish; o_value[n] = r->value;
+        n++;
+        r_pop(r);
+    }
+    for (;;) {
+        const char *c; const int32_t *s, *f; const double *v;
+        int64_t m = r_next_block(r, &c, &s, &f, &v);
+        if (m < 0) return -5;
+        if (m == 0) break;
+        if (n + m > cap) return -1;
+        for (int64_t q = 0; q < m; q++) { o_chrom[n] = name_to_index(c); o_start[n] = s[q]; o_finish[n] = f[q]; o_value[n] = v[q]; n++; }
+    }
+    return r->done ? n : -6;
+}
+
 /* Runs the reference reducer `op` (0..9) and records every run it emits. */
 int64_t ref_reduce(const wto_tracks *t, int op, unsigned flags, int64_t cap,
                    int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value) {
@@ -195,6 +242,7 @@ int64_t ref_reduce(const wto_tracks *t, int op, unsigned flags, int64_t cap,
     char **names = make_names(t->n_chrom);
     Multiplexer *m = make_multiplexer(t, names, 0, t->n_tracks, flags & 1u);
     WiggleIterator *r = r_reduction[op](m);
+    if (g_block_mode && r_next_block) return take_blocks(r, cap, o_chrom, o_start, o_finish, o_value);
     int64_t n = 0;
     while (!r->done) {
         if (n >= cap) return -1;

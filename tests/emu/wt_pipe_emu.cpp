@@ -39,6 +39,8 @@ struct Slot {
     std::vector<double> ov, tile;
     std::vector<uint8_t> ip;
     int64_t n_runs = 0, covered = 0, n_int = 0;
+    struct Direct { int64_t at, count; const int32_t *start, *finish; const float *value; };
+    std::vector<Direct> direct;
 };
 }  // namespace
 
@@ -126,8 +128,24 @@ int wtamd_pipe_grow(wtamd_pipe *p, int64_t used, int64_t min_capacity, int want_
     return WTAMD_OK;
 }
 
+// The emulated pipe has no DMA: a direct range is remembered by POINTER (as the product does) and
+// read at submit, so a caller that changes or frees the arrays too early shows up in the tests too.
+int wtamd_pipe_put_direct(wtamd_pipe *p, int64_t at, int64_t count, const int32_t *start, const int32_t *finish,
+                          const float *value) {
+    if (!p || p->acquired < 0) { g_err = "no acquired slot"; return WTAMD_ERR_ARG; }
+    if (count <= 0) return WTAMD_OK;
+    Slot &s = p->slots[(size_t) p->acquired];
+    if (!s.direct.empty() && s.direct.back().at + s.direct.back().count > at) { g_err = "direct ranges out of order"; return WTAMD_ERR_ARG; }
+    s.direct.push_back({at, count, start, finish, value});
+    return WTAMD_OK;
+}
+
+void *wtamd_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+void wtamd_host_free(void *q) { free(q); }
+
 int wtamd_pipe_cancel(wtamd_pipe *p) {
     if (!p || p->acquired < 0) { g_err = "no acquired slot"; return WTAMD_ERR_ARG; }
+    p->slots[(size_t) p->acquired].direct.clear();
     p->slots[(size_t) p->acquired].state = 0;
     p->acquired = -1;
     return WTAMD_OK;
@@ -141,6 +159,32 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
     if (value_is_f64 && !s.has64) { g_err = "float64 values were never staged"; return WTAMD_ERR_ARG; }
     if ((int64_t) range_hi - range_lo > p->cfg.max_runs && range_hi != INT32_MAX) { g_err = "hi - lo above max_runs"; return WTAMD_ERR_ARG; }
     const bool tile = p->cfg.desc.op == WTAMD_OP_MULTIPLEX;
+    if (!s.direct.empty()) {                // merge the direct ranges with the staged ones
+        if (value_is_f64) { g_err = "direct ranges are float32"; return WTAMD_ERR_ARG; }
+        std::vector<int32_t> a((size_t) n), b((size_t) n);
+        std::vector<float> c((size_t) n);
+        int64_t pos = 0;
+        auto staged = [&](int64_t lo, int64_t hi) {
+            if (hi <= lo) return true;
+            if (hi > s.cap) return false;
+            memcpy(a.data() + lo, s.start.data() + lo, sizeof(int32_t) * (size_t) (hi - lo));
+            memcpy(b.data() + lo, s.finish.data() + lo, sizeof(int32_t) * (size_t) (hi - lo));
+            memcpy(c.data() + lo, s.v32.data() + lo, sizeof(float) * (size_t) (hi - lo));
+            return true;
+        };
+        for (const auto &d : s.direct) {
+            if (d.at + d.count > n || !staged(pos, d.at)) { g_err = "direct range / staging mismatch"; return WTAMD_ERR_ARG; }
+            memcpy(a.data() + d.at, d.start, sizeof(int32_t) * (size_t) d.count);
+            memcpy(b.data() + d.at, d.finish, sizeof(int32_t) * (size_t) d.count);
+            memcpy(c.data() + d.at, d.value, sizeof(float) * (size_t) d.count);
+            pos = d.at + d.count;
+        }
+        if (!staged(pos, n)) { g_err = "staged intervals beyond the staging capacity"; return WTAMD_ERR_ARG; }
+        s.start.swap(a); s.finish.swap(b); s.v32.swap(c);
+        if (n > s.cap) s.cap = n;
+        if ((int64_t) s.start.size() < s.cap) { s.start.resize((size_t) s.cap); s.finish.resize((size_t) s.cap); s.v32.resize((size_t) s.cap); }
+        s.direct.clear();
+    } else if (n > s.cap) { g_err = "staged intervals beyond the staging capacity"; return WTAMD_ERR_ARG; }
     int64_t cap = 2 * n + 8;
     s.os.assign((size_t) cap, 0); s.of.assign((size_t) cap, 0); s.ov.assign((size_t) cap, 0.0);
     if (tile) { s.tile.assign((size_t) cap * N, 0.0); s.ip.assign((size_t) cap * N, 0); }

@@ -256,3 +256,53 @@ def test_dropin_ctor_defaults(oracle, H):
         for op in ALL_MULTIPLEX_OPS:
             a, b = H.reducer_default(op, dv), oracle.reducer_default(op, dv)
             assert (np.isnan(a) and np.isnan(b)) or a == b, (op, dv)
+
+
+@pytest.fixture(params=[(1, 0), (1, 1), (0, 1)], ids=["bulk-children", "bulk-children+blocks", "blocks"])
+def doors(request, H):
+    """The bulk doors of the drop-in layer: children that are the library's own wtamd_ArrayReader
+    (whole SoA blocks instead of one pop per interval; big blocks go to HBM unstaged) and / or the
+    reducer's runs taken through wtamd_iterator_next_block (mixed with a few plain pops)."""
+    H.set_modes(*request.param)
+    yield request.param
+    H.set_modes(0, 0)
+
+
+@pytest.mark.parametrize("env", [{}, {"WTAMD_MIN_SPAN": "7", "WTAMD_BATCH_INTERVALS": "20", "WTEMU_PIPE_CAP": "3"},
+                                 {"WTAMD_MIN_SPAN": "300", "WTAMD_BATCH_INTERVALS": "2000"}],
+                         ids=["default-batches", "tiny-batches", "small-batches"])
+def test_dropin_bulk_doors(oracle, H, doors, env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for seed in range(12):
+        t = random_case(9300 + seed, max_len=3000)
+        d = t.as_dict()
+        for strict in (0, 1):
+            for op in ("mean", "median", "var", "max"):
+                assert_runs_equal(H.reduce(d, op, flags=strict), oracle.reduce(d, op, flags=strict), _tol(op),
+                                  "doors %s seed %d %s strict %d" % (doors, seed, op, strict))
+        if t.n_chrom > 1:       # seek on array readers: one chromosome, intervals clipped to the window
+            got = H.reduce_seek(d, "mean", 1, 50, 900)
+            assert_runs_equal(got, oracle.reduce(clip(t, 1, 50, 900).as_dict(), "mean"), 0.0, "seek, doors %s" % (doors,))
+    if doors[0]:
+        t = random_case(9400, n_tracks=7, max_len=3000)
+        d = t.as_dict()
+        for op in ("ttest", "mwu"):
+            assert_runs_equal(H.reduce(d, op, n_set0=3), oracle.reduce(d, op, n_set0=3), _tol(op), op)
+        exp, got = oracle.multiplex(d), H.multiplex(d)
+        assert len(got[0]) == len(exp[0])
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_dropin_bulk_long_tracks(oracle, H):
+    """Blocks big enough to bypass the staging (>= 64 intervals per track and batch)."""
+    from wiggletools_amd.runlists import synth
+    H.set_modes(1, 1)
+    try:
+        t = synth(6, [200000, 30000], mean_run=12, seed=21, gap_prob=0.05)
+        d = t.as_dict()
+        for op in ("mean", "min"):
+            assert_runs_equal(H.reduce(d, op), oracle.reduce(d, op), 0.0, op)
+    finally:
+        H.set_modes(0, 0)

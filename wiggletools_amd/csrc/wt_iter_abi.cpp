@@ -37,7 +37,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <deque>
+#include <new>
 #include <vector>
 
 #include "../../include/wiggletools_amd.h"
@@ -78,9 +80,24 @@ struct Interner {
     }
 };
 
+// Bulk side door of a child iterator built by this library (wtamd_ArrayReader, ...): first member of
+// its `data`; recognised by its pop function (wt_bulk_pop).  peek() exposes the upcoming intervals
+// of the current chromosome as SoA arrays, the first being the iterator's current element;
+// advance() consumes k of them and refreshes the iterator's visible fields.
+struct BulkSource {
+    int64_t (*peek)(BulkSource *, const int32_t **start, const int32_t **finish, const float **value);
+    void (*advance)(BulkSource *, WiggleIterator *, int64_t k);
+};
+
+void wt_bulk_pop(WiggleIterator *wi) {
+    BulkSource *b = (BulkSource *) wi->data;
+    b->advance(b, wi, 1);
+}
+
 // One child iterator plus intervals that were popped from it but pushed back.
 struct TrackSource {
     WiggleIterator *it = nullptr;
+    BulkSource *bulk = nullptr;     // non-NULL: the child hands over whole blocks
     std::deque<Ivl> pending;        // pushed back (take-over); precede the iterator's current element
     std::deque<Ivl> log;            // consumed by batches not yet handed to the consumer (Multiplexer mode)
     const char *raw = nullptr;      // last chrom pointer seen on `it` ...
@@ -93,6 +110,7 @@ struct TrackSource {
     bool empty() const { return pending.empty() && it->done; }
 };
 
+const int64_t kDirectMin = 64;              // bulk blocks of at least this many intervals bypass the staging
 const int64_t kFirstSpan = 2048;            // bp of a Multiplexer's priming batch
 const int64_t kReducerFirstSpan = 65536;    // bp of a reducer's first batch
 
@@ -107,6 +125,7 @@ struct Feeder {
     int depth = 1;                      // batches kept in flight
     bool keep_log = false;              // Multiplexer mode: remember what was consumed (take-over pushes it back)
     bool f64_mode = false;              // a value that is not float32-exact was seen
+    bool use_bulk = true;               // WTAMD_NO_BULK=1: children of this library are popped like foreign ones
     // drain position
     const char *chrom = nullptr;        // chromosome of the batch being / last drained
     bool continuing = false;            // next batch continues `chrom` at next_lo
@@ -133,6 +152,7 @@ struct Feeder {
         max_runs = max_runs_;
         target = env_i64("WTAMD_BATCH_INTERVALS", 4 << 20);
         min_span = env_i64("WTAMD_MIN_SPAN", kFirstSpan);       // tests cut every few bp to stress the seams
+        use_bulk = !getenv("WTAMD_NO_BULK");
         if (getenv("WTAMD_MIN_SPAN")) first_span = min_span;
         span = first_span < max_runs ? first_span : max_runs;
         if (wtamd_pipe_create(&cfg, &pipe) != WTAMD_OK) die("wtamd_pipe_create");
@@ -245,6 +265,32 @@ struct Feeder {
             }
             if (stop) continue;
             WiggleIterator *it = s.it;
+            if (s.bulk && use_bulk && !keep_log && !f64_mode) {
+                // bulk side door: whole blocks, no per-interval call; big blocks are not even
+                // staged -- the copy engine reads them where they lie
+                while (!it->done && s.it_chrom(names) == chrom) {
+                    const int32_t *bs, *bf;
+                    const float *bv;
+                    const int64_t cnt = s.bulk->peek(s.bulk, &bs, &bf, &bv);
+                    if (cnt <= 0) break;
+                    const int64_t k1 = std::lower_bound(bs, bs + cnt, hi) - bs;     // starts below the cut
+                    const bool reach = k1 > 0 && bf[k1 - 1] >= hi;                 // the last of them reaches it: seen again
+                    const bool sentinel = !reach && k1 < cnt;
+                    const int64_t include = k1 + (sentinel ? 1 : 0);
+                    if (include >= kDirectMin) {
+                        if (wtamd_pipe_put_direct(pipe, n, include, bs, bf, bv) != WTAMD_OK) die("wtamd_pipe_put_direct");
+                        n += include;
+                    } else {
+                        for (int64_t q = 0; q < include; q++) put(bs[q], bf[q], (double) bv[q]);
+                    }
+                    if (sentinel) { more = true; if (bs[k1] < sentinel_lo) sentinel_lo = bs[k1]; }
+                    if (reach) more = carry = true;
+                    const int64_t consumed = reach ? k1 - 1 : k1;
+                    if (consumed > 0) s.bulk->advance(s.bulk, it, consumed);
+                    if (reach || sentinel) break;
+                }
+                continue;
+            }
             while (!it->done) {
                 if (s.it_chrom(names) != chrom) break;
                 const int32_t st = it->start, fi = it->finish;
@@ -379,6 +425,7 @@ void mux_seek(Multiplexer *m, const char *chrom, int start, int finish) {
 struct RedState {
     Feeder fd;
     int64_t cur = 0;
+    bool block_done = false;            // wtamd_iterator_next_block delivered the rest of the current batch
     Multiplexer *multi = nullptr;       // one-sample
     Multiset *multiset = nullptr;       // two-sample
 };
@@ -393,6 +440,7 @@ void red_pop(WiggleIterator *wi) {
     if (wi->done) return;
     RedState *R = red_state(wi);
     Feeder &F = R->fd;
+    R->block_done = false;
     if (!F.holding || R->cur >= F.res.n_runs) {
         if (!F.next()) {
             wi->done = 1;
@@ -467,6 +515,89 @@ WiggleIterator *make_set_reducer(Multiset *ms, int op) {
     RedData *d = (RedData *) calloc(1, sizeof(RedData));
     d->state = R;
     return newWiggleIterator(d, &red_pop, &red_seek, NAN, 0);     // setComparisons.c:130,389
+}
+
+
+// ---------------------------------------------------------------------------
+// Array-backed reader (bulk-capable child iterator)
+// ---------------------------------------------------------------------------
+struct ArrReader {
+    BulkSource hdr;                 // must stay first (see wt_bulk_pop)
+    int n_chrom = 0;
+    char **names = nullptr;         // own copies: stable for the process lifetime
+    int64_t *seg_off = nullptr;     // own copy
+    const int32_t *start = nullptr, *finish = nullptr;
+    const float *value = nullptr;
+    int c = 0;                      // current chromosome
+    int64_t j = 0, end = 0;         // current interval, end of what this chromosome delivers
+    bool windowed = false;          // after seek(): one chromosome, intervals clipped to [win_start, win_finish)
+    int32_t win_start = 0, win_finish = 0;
+    bool done = false;
+    int32_t e_start = 0, e_finish = 0;      // the current element when it had to be clipped
+    float e_value = 0;
+
+    bool clipped(int64_t g) const { return windowed && (start[g] < win_start || finish[g] > win_finish); }
+
+    void settle(WiggleIterator *wi) {       // skip exhausted chromosomes, refresh the visible fields
+        while (!done && j >= end) {
+            if (windowed) { done = true; break; }
+            c++;
+            if (c >= n_chrom) { done = true; break; }
+            j = seg_off[c]; end = seg_off[c + 1];
+        }
+        if (done) { wi->done = 1; return; }
+        wi->chrom = names[c];
+        wi->start = start[j]; wi->finish = finish[j];
+        if (clipped(j)) {
+            if (wi->start < win_start) wi->start = win_start;
+            if (wi->finish > win_finish) wi->finish = win_finish;
+        }
+        wi->value = (double) value[j];
+    }
+};
+
+int64_t arr_peek(BulkSource *b, const int32_t **s, const int32_t **f, const float **v) {
+    ArrReader *a = (ArrReader *) b;
+    if (a->done || a->j >= a->end) return 0;
+    if (a->clipped(a->j)) {                 // a window edge: one clipped copy
+        a->e_start = a->start[a->j] < a->win_start ? a->win_start : a->start[a->j];
+        a->e_finish = a->finish[a->j] > a->win_finish ? a->win_finish : a->finish[a->j];
+        a->e_value = a->value[a->j];
+        *s = &a->e_start; *f = &a->e_finish; *v = &a->e_value;
+        return 1;
+    }
+    int64_t k = a->end;
+    if (a->windowed && k - 1 > a->j && a->clipped(k - 1)) k--;      // the far edge is delivered on its own
+    *s = a->start + a->j; *f = a->finish + a->j; *v = a->value + a->j;
+    return k - a->j;
+}
+
+void arr_advance(BulkSource *b, WiggleIterator *wi, int64_t k) {
+    ArrReader *a = (ArrReader *) b;
+    if (a->done) { wi->done = 1; return; }
+    a->j += k;
+    a->settle(wi);
+}
+
+void arr_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
+    // what the reference's readers deliver after seek (bigWiggleReader.c:125-145, wigReader /
+    // bedReader likewise): only that chromosome, intervals overlapping [start, finish), clipped
+    ArrReader *a = (ArrReader *) wi->data;
+    a->windowed = true;
+    a->win_start = start; a->win_finish = finish;
+    a->done = true;
+    for (int c = 0; c < a->n_chrom; c++)
+        if (strcmp(a->names[c], chrom) == 0) {
+            const int64_t lo = a->seg_off[c], hi = a->seg_off[c + 1];
+            a->c = c;
+            a->j = std::upper_bound(a->finish + lo, a->finish + hi, start) - a->finish;    // first finish > start
+            a->end = std::lower_bound(a->start + lo, a->start + hi, finish) - a->start;    // first start >= finish
+            a->done = a->j >= a->end;
+            break;
+        }
+    wi->done = 0;
+    if (a->done) { wi->done = 1; return; }
+    a->settle(wi);
 }
 
 // ---------------------------------------------------------------------------
@@ -683,6 +814,7 @@ Multiplexer *newMultiplexer(WiggleIterator **iters, int count, wt_bool strict) {
         m->default_values[i] = m->iters[i]->default_value;
         m->values[i] = m->iters[i]->default_value;
         S->fd.src[i].it = m->iters[i];
+        if (m->iters[i]->pop == &wt_bulk_pop) S->fd.src[i].bulk = (BulkSource *) m->iters[i]->data;
         S->fd.defaults.push_back(m->iters[i]->default_value);
     }
     popMultiplexer(m);                                              // primed like multiplexer.c:167
@@ -769,6 +901,64 @@ WiggleIterator *MWUReduction(Multiset *s) {
         exit(1);
     }
     return make_set_reducer(s, WTAMD_OP_MWU);
+}
+
+// ---------------------------------------------------------------------------
+// Bulk doors (include/wiggletools_amd.h)
+// ---------------------------------------------------------------------------
+WiggleIterator *wtamd_ArrayReader(int n_chrom, const char *const *chrom_names, const int64_t *seg_off,
+                                  const int32_t *start, const int32_t *finish, const float *value,
+                                  double default_value) {
+    ArrReader *a = new (calloc(1, sizeof(ArrReader))) ArrReader();     // free()-able, like every iterator's data
+    a->hdr.peek = &arr_peek;
+    a->hdr.advance = &arr_advance;
+    a->n_chrom = n_chrom;
+    a->names = (char **) calloc((size_t) (n_chrom > 0 ? n_chrom : 1), sizeof(char *));
+    a->seg_off = (int64_t *) calloc((size_t) n_chrom + 1, sizeof(int64_t));
+    for (int c = 0; c < n_chrom; c++) a->names[c] = strdup(chrom_names[c]);
+    for (int c = 0; c <= n_chrom; c++) a->seg_off[c] = seg_off[c];
+    a->start = start; a->finish = finish; a->value = value;
+    a->c = -1; a->j = 0; a->end = 0;           // settle() moves to the first non-empty chromosome
+    WiggleIterator *wi = (WiggleIterator *) calloc(1, sizeof(WiggleIterator));
+    wi->data = a;
+    wi->pop = &wt_bulk_pop;
+    wi->seek = &arr_seek;
+    wi->value = 1;
+    wi->default_value = default_value;
+    a->settle(wi);                             // a fresh iterator already holds its first element (wiggleIterator.c:32)
+    return wi;
+}
+
+int64_t wtamd_iterator_next_block(WiggleIterator *wi, const char **chrom, const int32_t **start,
+                                  const int32_t **finish, const double **value) {
+    if (!wi || wi->pop != &red_pop) return -1;          // reducers of this library only
+    RedState *R = red_state(wi);
+    if (R->block_done) red_pop(wi);                     // the previous block emptied its batch: fetch the next
+    if (wi->done) return 0;
+    Feeder &F = R->fd;
+    const int64_t first = R->cur - 1;                   // the iterator's current element
+    const int64_t n = F.res.n_runs - first;
+    if (chrom) *chrom = F.res_chrom;
+    *start = F.res.start + first;
+    *finish = F.res.finish + first;
+    *value = F.res.value + first;
+    R->cur = F.res.n_runs;
+    R->block_done = true;
+    return n;
+}
+
+int64_t wtamd_drain(WiggleIterator *wi, int64_t *covered_bp, double *value_sum) {
+    int64_t n = 0, bp = 0;
+    double acc = 0;
+    while (!wi->done) {
+        n++;
+        bp += wi->finish - wi->start;
+        if (wi->value == wi->value) acc += wi->value;
+        wi->pop(wi);
+    }
+    if (covered_bp) *covered_bp = bp;
+    if (value_sum) *value_sum = acc;
+    return n;
 }
 
 }  // extern "C"

@@ -49,6 +49,9 @@ struct WtSlot {
     int err = WTAMD_OK;
     std::string err_msg;
     int delta_W = 0;
+    // bulk side door: ranges of the batch that are copied to HBM straight from the caller's arrays
+    struct Direct { int64_t at, count; const int32_t *start, *finish; const float *value; };
+    std::vector<Direct> direct;
 };
 
 struct wtamd_pipe {
@@ -294,8 +297,21 @@ int wtamd_pipe_grow(wtamd_pipe *p, int64_t used, int64_t min_capacity, int want_
     return WTAMD_OK;
 }
 
+int wtamd_pipe_put_direct(wtamd_pipe *p, int64_t at, int64_t count, const int32_t *start, const int32_t *finish,
+                          const float *value) {
+    if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_put_direct: no acquired slot");
+    if (count <= 0) return WTAMD_OK;
+    if (at < 0 || !start || !finish || !value) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_put_direct: bad arguments");
+    WtSlot &s = p->slots[(size_t) p->acquired];
+    if (!s.direct.empty() && s.direct.back().at + s.direct.back().count > at)
+        return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_put_direct: ranges must be added in ascending order");
+    s.direct.push_back({at, count, start, finish, value});
+    return WTAMD_OK;
+}
+
 int wtamd_pipe_cancel(wtamd_pipe *p) {
     if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_cancel: no acquired slot");
+    p->slots[(size_t) p->acquired].direct.clear();
     p->slots[(size_t) p->acquired].state = 0;
     p->acquired = -1;
     return WTAMD_OK;
@@ -306,7 +322,19 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
     WtSlot &s = p->slots[(size_t) p->acquired];
     const int N = p->cfg.n_tracks;
     const int64_t n = s.h_seg[N];
-    if (s.h_seg[0] != 0 || n < 0 || n > s.cap) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: bad seg_off");
+    if (s.h_seg[0] != 0 || n < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: bad seg_off");
+    // staged ranges = [0, n) minus the direct ranges; they must lie inside the staging arrays
+    {
+        int64_t staged_end = 0, pos = 0;
+        for (const auto &d : s.direct) {
+            if (d.at + d.count > n) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: a direct range lies beyond seg_off[n_tracks]");
+            if (d.at > pos) staged_end = d.at;
+            pos = d.at + d.count;
+        }
+        if (pos < n) staged_end = n;
+        if (staged_end > s.cap) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: staged intervals beyond the staging capacity");
+        if (value_is_f64 && !s.direct.empty()) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: direct ranges are float32");
+    }
     for (int i = 0; i < N; i++)
         if (s.h_seg[i + 1] < s.h_seg[i]) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: seg_off not monotone");
     if (value_is_f64 && !s.has64) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: float64 values were never staged");
@@ -362,10 +390,23 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
     // rebind the slot's track set to this batch
     ts->n_intervals = n;
     ts->seg_off.assign(s.h_seg, s.h_seg + N + 1);
-    for (int i = 0; i < N; i++) {
-        const int64_t a = s.h_seg[i], b = s.h_seg[i + 1];
-        ts->first_start[(size_t) i] = b > a ? s.h_start[a] : 0;
-        ts->last_finish[(size_t) i] = b > a ? s.h_finish[b - 1] : 0;
+    {
+        // entry g of the batch: in the staging arrays or in a direct range
+        auto start_at = [&](int64_t g) -> int32_t {
+            size_t lo = 0, hi = s.direct.size();
+            while (lo < hi) { const size_t m = (lo + hi) / 2; if (s.direct[m].at + s.direct[m].count <= g) lo = m + 1; else hi = m; }
+            return (lo < s.direct.size() && s.direct[lo].at <= g) ? s.direct[lo].start[g - s.direct[lo].at] : s.h_start[g];
+        };
+        auto finish_at = [&](int64_t g) -> int32_t {
+            size_t lo = 0, hi = s.direct.size();
+            while (lo < hi) { const size_t m = (lo + hi) / 2; if (s.direct[m].at + s.direct[m].count <= g) lo = m + 1; else hi = m; }
+            return (lo < s.direct.size() && s.direct[lo].at <= g) ? s.direct[lo].finish[g - s.direct[lo].at] : s.h_finish[g];
+        };
+        for (int i = 0; i < N; i++) {
+            const int64_t a = s.h_seg[i], b = s.h_seg[i + 1];
+            ts->first_start[(size_t) i] = b > a ? start_at(a) : 0;
+            ts->last_finish[(size_t) i] = b > a ? finish_at(b - 1) : 0;
+        }
     }
     ts->range_lo[0] = range_lo;
     ts->range_hi[0] = range_hi;
@@ -383,11 +424,27 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
     WT_HIP(hipEventRecord(s.e_h0, p->s_copy));
     WT_HIP(hipMemcpyAsync(ts->d_seg_off, s.h_seg, sizeof(int64_t) * ((size_t) N + 1), hipMemcpyHostToDevice, p->s_copy));
     if (n > 0) {
-        WT_HIP(hipMemcpyAsync(s.d_start, s.h_start, sizeof(int32_t) * n, hipMemcpyHostToDevice, p->s_copy));
-        WT_HIP(hipMemcpyAsync(s.d_finish, s.h_finish, sizeof(int32_t) * n, hipMemcpyHostToDevice, p->s_copy));
-        if (f64) WT_HIP(hipMemcpyAsync(s.d_value, s.h_v64, sizeof(double) * n, hipMemcpyHostToDevice, p->s_copy));
-        else WT_HIP(hipMemcpyAsync(s.d_value, s.h_v32, sizeof(float) * n, hipMemcpyHostToDevice, p->s_copy));
+        auto staged = [&](int64_t a, int64_t b) -> int {        // staging [a, b) -> HBM
+            if (b <= a) return WTAMD_OK;
+            WT_HIP(hipMemcpyAsync(s.d_start + a, s.h_start + a, sizeof(int32_t) * (b - a), hipMemcpyHostToDevice, p->s_copy));
+            WT_HIP(hipMemcpyAsync(s.d_finish + a, s.h_finish + a, sizeof(int32_t) * (b - a), hipMemcpyHostToDevice, p->s_copy));
+            if (f64) WT_HIP(hipMemcpyAsync((double *) s.d_value + a, s.h_v64 + a, sizeof(double) * (b - a), hipMemcpyHostToDevice, p->s_copy));
+            else WT_HIP(hipMemcpyAsync((float *) s.d_value + a, s.h_v32 + a, sizeof(float) * (b - a), hipMemcpyHostToDevice, p->s_copy));
+            return WTAMD_OK;
+        };
+        int64_t pos = 0;
+        for (const auto &d : s.direct) {                        // the caller's arrays -> HBM, no staging copy
+            rc = staged(pos, d.at);
+            if (rc != WTAMD_OK) return rc;
+            WT_HIP(hipMemcpyAsync(s.d_start + d.at, d.start, sizeof(int32_t) * d.count, hipMemcpyHostToDevice, p->s_copy));
+            WT_HIP(hipMemcpyAsync(s.d_finish + d.at, d.finish, sizeof(int32_t) * d.count, hipMemcpyHostToDevice, p->s_copy));
+            WT_HIP(hipMemcpyAsync((float *) s.d_value + d.at, d.value, sizeof(float) * d.count, hipMemcpyHostToDevice, p->s_copy));
+            pos = d.at + d.count;
+        }
+        rc = staged(pos, n);
+        if (rc != WTAMD_OK) return rc;
     }
+    s.direct.clear();
     WT_HIP(hipEventRecord(s.e_h1, p->s_copy));
     p->st.h2d_bytes += (int64_t) sizeof(int64_t) * (N + 1) + n * (f64 ? 16 : 12);
 
@@ -467,6 +524,16 @@ int wtamd_pipe_release(wtamd_pipe *p) {
 }
 
 int wtamd_pipe_in_flight(const wtamd_pipe *p) { return p ? p->in_flight : 0; }
+
+void *wtamd_host_alloc(size_t bytes) {
+    void *q = nullptr;
+    if (hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return q;
+}
+
+void wtamd_host_free(void *q) {
+    if (q) (void) hipHostFree(q);
+}
 
 int wtamd_pipe_get_stats(const wtamd_pipe *p, wtamd_pipe_stats *out) {
     if (!p || !out) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
