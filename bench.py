@@ -430,7 +430,7 @@ def main():
         }
         if world == 1 and not args.no_e2e:
             try:
-                res["e2e"] = e2e_dropin(ops[-1], N, args.mean_run, args.e2e_mbp * args.scale if args.scale < 1 else args.e2e_mbp, device)
+                res["e2e"] = e2e_dropin(ops[-1], N, args.mean_run, args.e2e_mbp * min(1.0, 100.0 / N) * (args.scale if args.scale < 1 else 1.0), device)
             except Exception as e:      # never lose the bench line to an extra leg
                 res["e2e"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
