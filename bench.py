@@ -64,6 +64,30 @@ def _sample_tracks(chrom_id, chrom_len, n_tracks, mean_run, lo, hi):
     return d
 
 
+def effective_cores():
+    """Host cores this process may actually use: min(cpu_count, scheduler affinity, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(path).read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(per))))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except Exception:
+        pass
+    return n
+
+
 def _sample_tracks_device(chrom_id, chrom_len, n_tracks, mean_run, hi):
     """Same sample (run starts in [0, hi) of one chromosome) taken from the device generator: the
     single-thread leg's sample is tens of Mbp, which the numpy mirror would take longer to hash than
@@ -122,8 +146,9 @@ def cpu_baseline(chrom_ids, op, n_tracks, mean_run, chrom_lens, many_core=True, 
     out = {"value": bp / sec, "unit": "genomic bp/s", "cores": 1, "kind": kind,
            "sample": "%s over the bench's own %d tracks, first %d bp of the largest chromosome, one evaluation thread "
                      "(the reference never parallelises evaluation), sink=none; %.1f s" % (op, n_tracks, sample_bp, sec)}
-    nproc = os.cpu_count() or 1
+    nproc = effective_cores()
     out["host_cores"] = nproc
+    out["host_cores_note"] = "os.cpu_count() %d, cgroup / affinity limit %d" % (os.cpu_count() or 1, nproc)
     if many_core and nproc > 1:
         import multiprocessing as mp
         region = 30_000_000

@@ -165,7 +165,7 @@ static void arr_seek(WiggleIterator *wi, const char *chrom, int start, int finis
 }
 
 static int g_hold;     /* children made from now on are held until their first seek */
-static int g_child_mode;   /* 1: children are the tested library's own bulk-capable wtamd_ArrayReader */
+static int g_child_mode;   /* 1: children are the tested library's own bulk-capable wtamd_ArrayReader; 2: even tracks only */
 static int g_block_mode;   /* 1: reducer output is taken through wtamd_iterator_next_block */
 
 void ref_set_modes(int child_mode, int block_mode) { g_child_mode = child_mode; g_block_mode = block_mode; }
@@ -188,7 +188,7 @@ static WiggleIterator *make_array_child(const wto_tracks *t, char **names, int t
 }
 
 static WiggleIterator *make_child(const wto_tracks *t, char **names, int track) {
-    if (g_child_mode == 1 && r_ArrayReader) return make_array_child(t, names, track);
+    if (r_ArrayReader && (g_child_mode == 1 || (g_child_mode == 2 && (track & 1) == 0))) return make_array_child(t, names, track);
     arr_iter *a = (arr_iter *) calloc(1, sizeof(arr_iter));
     a->t = t; a->names = names; a->track = track; a->c = 0; a->j = -1;
     a->hold = g_hold;

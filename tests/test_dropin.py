@@ -306,3 +306,42 @@ def test_dropin_bulk_long_tracks(oracle, H):
             assert_runs_equal(H.reduce(d, op), oracle.reduce(d, op), 0.0, op)
     finally:
         H.set_modes(0, 0)
+
+
+def test_dropin_bulk_past_the_staging(oracle, H, monkeypatch):
+    """Unstaged blocks push the batch's interval count far past the (3-entry) staging arrays; the
+    few intervals that are staged after them (window edges, short blocks) must grow the staging
+    first."""
+    from wiggletools_amd.runlists import synth
+    monkeypatch.setenv("WTEMU_PIPE_CAP", "3")
+    H.set_modes(1, 1)
+    try:
+        t = synth(5, [60000, 900], mean_run=10, seed=23, gap_prob=0.05)
+        d = t.as_dict()
+        assert_runs_equal(H.reduce(d, "mean"), oracle.reduce(d, "mean"), 0.0, "mean")
+        got = H.reduce_seek(d, "max", 0, 20000, 55000)
+        assert_runs_equal(got, oracle.reduce(clip(t, 0, 20000, 55000).as_dict(), "max"), 0.0, "seek")
+    finally:
+        H.set_modes(0, 0)
+
+
+def test_dropin_mixed_children_and_float64_switch(oracle, H, monkeypatch):
+    """Even tracks are the library's bulk-capable array readers (float32), odd tracks foreign lazy
+    iterators, one of which delivers a value that is not float32-exact in the middle of a batch:
+    the bulk blocks are then staged (block copy) and the whole batch switches to float64."""
+    from wiggletools_amd.runlists import synth
+    monkeypatch.setenv("WTEMU_PIPE_CAP", "3")
+    H.set_modes(2, 0)
+    try:
+        t = synth(6, [50000, 4000], mean_run=8, seed=29, gap_prob=0.05, dtype=np.float64)
+        d = t.as_dict()
+        for op in ("mean", "median"):
+            assert_runs_equal(H.reduce(d, op), oracle.reduce(d, op), 0.0, op + " (float32-exact)")
+        N = t.n_tracks
+        a, b = int(t.seg_off[1]), int(t.seg_off[2])         # track 1 (foreign), chromosome 0
+        t.value[(a + b) // 2] = 0.1
+        d = t.as_dict()
+        for op in ("sum", "median", "stddev"):
+            assert_runs_equal(H.reduce(d, op), oracle.reduce(d, op), _tol(op), op + " (float64 switch)")
+    finally:
+        H.set_modes(0, 0)

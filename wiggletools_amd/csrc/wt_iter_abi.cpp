@@ -126,6 +126,7 @@ struct Feeder {
     bool keep_log = false;              // Multiplexer mode: remember what was consumed (take-over pushes it back)
     bool f64_mode = false;              // a value that is not float32-exact was seen
     bool use_bulk = true;               // WTAMD_NO_BULK=1: children of this library are popped like foreign ones
+    bool all_bulk = false;              // every child is a bulk source of this library (float32 SoA): unstaged DMA
     // drain position
     const char *chrom = nullptr;        // chromosome of the batch being / last drained
     bool continuing = false;            // next batch continues `chrom` at next_lo
@@ -153,6 +154,8 @@ struct Feeder {
         target = env_i64("WTAMD_BATCH_INTERVALS", 4 << 20);
         min_span = env_i64("WTAMD_MIN_SPAN", kFirstSpan);       // tests cut every few bp to stress the seams
         use_bulk = !getenv("WTAMD_NO_BULK");
+        all_bulk = !src.empty();
+        for (const auto &s : src) all_bulk = all_bulk && s.bulk != nullptr;
         if (getenv("WTAMD_MIN_SPAN")) first_span = min_span;
         span = first_span < max_runs ? first_span : max_runs;
         if (wtamd_pipe_create(&cfg, &pipe) != WTAMD_OK) die("wtamd_pipe_create");
@@ -231,7 +234,10 @@ struct Feeder {
         int64_t sentinel_lo = INT32_MAX;
 
         auto put = [&](int32_t st, int32_t fi, double v) {
-            if (n == b.capacity && wtamd_pipe_grow(pipe, n, 2 * b.capacity, f64_mode, &b) != WTAMD_OK) die("wtamd_pipe_grow");
+            if (n >= b.capacity) {      // (n may have jumped past the staging: direct ranges are not staged)
+                const int64_t want = 2 * b.capacity > n + 1 ? 2 * b.capacity : n + 1;
+                if (wtamd_pipe_grow(pipe, n < b.capacity ? n : b.capacity, want, f64_mode, &b) != WTAMD_OK) die("wtamd_pipe_grow");
+            }
             b.start[n] = st;
             b.finish[n] = fi;
             if (f64_mode) {
@@ -239,7 +245,7 @@ struct Feeder {
             } else {
                 const float f = (float) v;
                 if ((double) f != v && v == v) {        // not float32-exact (NaN is): float64 from here on
-                    if (wtamd_pipe_grow(pipe, n, b.capacity, 1, &b) != WTAMD_OK) die("wtamd_pipe_grow");
+                    if (wtamd_pipe_grow(pipe, n < b.capacity ? n : b.capacity, b.capacity, 1, &b) != WTAMD_OK) die("wtamd_pipe_grow");
                     for (int64_t k = 0; k < n; k++) b.value64[k] = (double) b.value32[k];
                     f64_mode = true;
                     b.value64[n] = v;
@@ -265,7 +271,7 @@ struct Feeder {
             }
             if (stop) continue;
             WiggleIterator *it = s.it;
-            if (s.bulk && use_bulk && !keep_log && !f64_mode) {
+            if (s.bulk && use_bulk && !keep_log) {
                 // bulk side door: whole blocks, no per-interval call; big blocks are not even
                 // staged -- the copy engine reads them where they lie
                 while (!it->done && s.it_chrom(names) == chrom) {
@@ -277,8 +283,20 @@ struct Feeder {
                     const bool reach = k1 > 0 && bf[k1 - 1] >= hi;                 // the last of them reaches it: seen again
                     const bool sentinel = !reach && k1 < cnt;
                     const int64_t include = k1 + (sentinel ? 1 : 0);
-                    if (include >= kDirectMin) {
+                    if (all_bulk && include >= kDirectMin) {
+                        // every track is float32 SoA of this library: no staging copy at all
                         if (wtamd_pipe_put_direct(pipe, n, include, bs, bf, bv) != WTAMD_OK) die("wtamd_pipe_put_direct");
+                        n += include;
+                    } else if (include >= kDirectMin) {
+                        // mixed with foreign iterators (which may switch the batch to float64): block copy into the staging
+                        if (n + include > b.capacity) {
+                            const int64_t want = 2 * b.capacity > n + include ? 2 * b.capacity : n + include;
+                            if (wtamd_pipe_grow(pipe, n < b.capacity ? n : b.capacity, want, f64_mode, &b) != WTAMD_OK) die("wtamd_pipe_grow");
+                        }
+                        memcpy(b.start + n, bs, sizeof(int32_t) * (size_t) include);
+                        memcpy(b.finish + n, bf, sizeof(int32_t) * (size_t) include);
+                        if (f64_mode) for (int64_t q = 0; q < include; q++) b.value64[n + q] = (double) bv[q];
+                        else memcpy(b.value32 + n, bv, sizeof(float) * (size_t) include);
                         n += include;
                     } else {
                         for (int64_t q = 0; q < include; q++) put(bs[q], bf[q], (double) bv[q]);
