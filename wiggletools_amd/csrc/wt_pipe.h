@@ -18,6 +18,57 @@
 #ifndef WT_PIPE_H_
 #define WT_PIPE_H_
 
+// Gather: ONE kernel pulls every range of a batch -- the caller's pinned SoA blocks (bulk side
+// door) and the staged ranges alike -- from host memory into the slot's device arrays.  The copy
+// engine needs three hipMemcpyAsync per track and batch (~10 us of launch overhead each: 300 calls
+// for 100 tracks, more than the transfer itself at 4 M intervals per batch); a kernel reading the
+// page-locked host arrays through the PCIe link has no per-range cost and keeps thousands of reads
+// in flight.  Host bandwidth is the bound either way (12 B per interval).
+struct WtGatherSeg {
+    const int32_t *start, *finish;
+    const float *value;
+    long long dst;                  // first interval of the range in the device arrays
+    long long count;
+    long long chunk_first;          // prefix sum of ceil(count / WT_GATHER_CHUNK)
+};
+#define WT_GATHER_CHUNK 4096
+
+__global__ void __launch_bounds__(256) wt_gather_kernel(const WtGatherSeg *segs, int n_segs, long long n_chunks,
+                                                         int32_t *d_start, int32_t *d_finish, float *d_value) {
+    for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        int lo = 0, hi = n_segs - 1;                    // last segment with chunk_first <= ch
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (segs[mid].chunk_first <= ch) lo = mid; else hi = mid - 1;
+        }
+        const WtGatherSeg g = segs[lo];
+        const long long a = (ch - g.chunk_first) * WT_GATHER_CHUNK;
+        long long b = a + WT_GATHER_CHUNK;
+        if (b > g.count) b = g.count;
+        // issue every load of the chunk before the first store: the link's latency is microseconds
+        int32_t vs[WT_GATHER_CHUNK / 256], vf[WT_GATHER_CHUNK / 256];
+        float vv[WT_GATHER_CHUNK / 256];
+#pragma unroll
+        for (int q = 0; q < WT_GATHER_CHUNK / 256; q++) {
+            const long long i = a + threadIdx.x + 256ll * q;
+            if (i < b) { vs[q] = __builtin_nontemporal_load(g.start + i); vf[q] = __builtin_nontemporal_load(g.finish + i); vv[q] = __builtin_nontemporal_load(g.value + i); }
+        }
+#pragma unroll
+        for (int q = 0; q < WT_GATHER_CHUNK / 256; q++) {
+            const long long i = a + threadIdx.x + 256ll * q;
+            if (i < b) { d_start[g.dst + i] = vs[q]; d_finish[g.dst + i] = vf[q]; d_value[g.dst + i] = vv[q]; }
+        }
+    }
+}
+
+// Page-locked (hipHostMalloc / hipHostRegister) host memory is readable by kernels; pageable memory
+// is not -- such ranges go through hipMemcpyAsync, which stages them.
+static bool wt_is_pinned(const void *q) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void) hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
 struct WtSlot {
     int state = 0;                  // 0 free, 1 acquired, 2 submitted, 3 collected
     int stage = 0;                  // submitted: 0 kernels enqueued, 1 D2H enqueued
@@ -52,6 +103,9 @@ struct WtSlot {
     // bulk side door: ranges of the batch that are copied to HBM straight from the caller's arrays
     struct Direct { int64_t at, count; const int32_t *start, *finish; const float *value; };
     std::vector<Direct> direct;
+    WtGatherSeg *h_segs = nullptr, *d_segs = nullptr;   // gather table: pinned staging + device copy
+    int64_t seg_cap = 0;
+    bool direct_pinned = true;      // every direct range of this batch lies in page-locked memory
 };
 
 struct wtamd_pipe {
@@ -62,6 +116,8 @@ struct wtamd_pipe {
     hipStream_t s_copy = nullptr, s_comp = nullptr, s_out = nullptr;
     bool delta_failed = false;      // a batch had many inexact windows: Sum / Mean stay on the general kernel
     bool tile = false;
+    bool gather = true;             // WTAMD_PIPE_GATHER=0: hipMemcpyAsync per range instead of the gather kernel
+    int num_cu = 256;
     wtamd_pipe_stats st{};
 };
 
@@ -74,6 +130,8 @@ static void wt_slot_free(WtSlot &s) {
     (void) hipFree(s.d_start); (void) hipFree(s.d_finish); (void) hipFree(s.d_value);
     (void) hipFree(s.d_os); (void) hipFree(s.d_of); (void) hipFree(s.d_ov); (void) hipFree(s.d_tile); (void) hipFree(s.d_ip);
     (void) hipFree(s.d_cro);
+    (void) hipFree(s.d_segs);
+    if (s.h_segs) (void) hipHostFree(s.h_segs);
     if (s.h_os) (void) hipHostFree(s.h_os);
     if (s.h_of) (void) hipHostFree(s.h_of);
     if (s.h_ov) (void) hipHostFree(s.h_ov);
@@ -206,6 +264,7 @@ int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
     p->defaults.assign(cfg->defaults, cfg->defaults + cfg->n_tracks);
     p->cfg.defaults = p->defaults.data();
     p->tile = tile;
+    if (getenv("WTAMD_PIPE_GATHER")) p->gather = atoi(getenv("WTAMD_PIPE_GATHER")) != 0;
     int ns = cfg->n_slots ? cfg->n_slots : 3;
     if (ns < 2) ns = 2;
     if (ns > 8) ns = 8;
@@ -305,6 +364,8 @@ int wtamd_pipe_put_direct(wtamd_pipe *p, int64_t at, int64_t count, const int32_
     WtSlot &s = p->slots[(size_t) p->acquired];
     if (!s.direct.empty() && s.direct.back().at + s.direct.back().count > at)
         return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_put_direct: ranges must be added in ascending order");
+    if (s.direct.empty()) s.direct_pinned = true;
+    if (p->gather && s.direct_pinned && !(wt_is_pinned(start) && wt_is_pinned(finish) && wt_is_pinned(value))) s.direct_pinned = false;
     s.direct.push_back({at, count, start, finish, value});
     return WTAMD_OK;
 }
@@ -423,7 +484,39 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
     // copy stream: pinned staging -> HBM
     WT_HIP(hipEventRecord(s.e_h0, p->s_copy));
     WT_HIP(hipMemcpyAsync(ts->d_seg_off, s.h_seg, sizeof(int64_t) * ((size_t) N + 1), hipMemcpyHostToDevice, p->s_copy));
-    if (n > 0) {
+    if (n > 0 && p->gather && !f64 && !s.direct.empty() && s.direct_pinned) {
+        // one table, one small copy, one kernel for the whole batch
+        const int64_t max_segs = 2 * (int64_t) s.direct.size() + 1;
+        if (s.seg_cap < max_segs) {
+            (void) hipFree(s.d_segs);
+            if (s.h_segs) (void) hipHostFree(s.h_segs);
+            s.d_segs = nullptr; s.h_segs = nullptr; s.seg_cap = 0;
+            const int64_t c = 2 * max_segs;
+            WT_HIP(hipHostMalloc((void **) &s.h_segs, sizeof(WtGatherSeg) * c, hipHostMallocDefault));
+            WT_HIP(hipMalloc(&s.d_segs, sizeof(WtGatherSeg) * c));
+            s.seg_cap = c;
+        }
+        int ns = 0;
+        long long chunks = 0;
+        auto add = [&](const int32_t *ps, const int32_t *pf, const float *pv, int64_t dst, int64_t count) {
+            if (count <= 0) return;
+            s.h_segs[ns++] = WtGatherSeg{ps, pf, pv, dst, count, chunks};
+            chunks += (count + WT_GATHER_CHUNK - 1) / WT_GATHER_CHUNK;
+        };
+        int64_t pos = 0;
+        for (const auto &d : s.direct) {
+            add(s.h_start + pos, s.h_finish + pos, s.h_v32 + pos, pos, d.at - pos);       // staged gap before it
+            add(d.start, d.finish, d.value, d.at, d.count);
+            pos = d.at + d.count;
+        }
+        add(s.h_start + pos, s.h_finish + pos, s.h_v32 + pos, pos, n - pos);
+        WT_HIP(hipMemcpyAsync(s.d_segs, s.h_segs, sizeof(WtGatherSeg) * ns, hipMemcpyHostToDevice, p->s_copy));
+        long long grid = chunks < 4ll * ts->num_cu ? chunks : 4ll * ts->num_cu;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(wt_gather_kernel, dim3((unsigned) grid), dim3(256), 0, p->s_copy, s.d_segs, ns, chunks,
+                           s.d_start, s.d_finish, (float *) s.d_value);
+        WT_HIP(hipGetLastError());
+    } else if (n > 0) {
         auto staged = [&](int64_t a, int64_t b) -> int {        // staging [a, b) -> HBM
             if (b <= a) return WTAMD_OK;
             WT_HIP(hipMemcpyAsync(s.d_start + a, s.h_start + a, sizeof(int32_t) * (b - a), hipMemcpyHostToDevice, p->s_copy));
