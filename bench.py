@@ -215,10 +215,18 @@ def e2e_dropin(op, n_tracks, mean_run, mbp, device):
     os.environ.pop("WTAMD_NO_BULK", None)
     t0 = time.perf_counter()
     r = dropin.reducer(op, readers(L), n_set0=n_tracks // 2)
-    runs, _ = dropin.drain_blocks(r)
+    marks = []
+    runs, _ = dropin.drain_blocks(r, on_block=lambda c, a, b, v: (marks.append((time.perf_counter(), int(b[-1]))), 0)[1])
     dt = time.perf_counter() - t0
+    st = dropin.pipe_stats(r)
     out["bulk"] = {"bp_per_s": L / dt, "seconds": dt, "bp": L, "runs": runs,
-                   "h2d_GBs": 12.0 * n / dt / 1e9, "d2h_GBs": 16.0 * runs / dt / 1e9}
+                   "h2d_GBs": 12.0 * n / dt / 1e9, "d2h_GBs": 16.0 * runs / dt / 1e9,
+                   "batches": st.get("batches"), "sum_h2d_ms": st.get("h2d_ms"), "sum_kernel_ms": st.get("kernel_ms"),
+                   "sum_d2h_ms": st.get("d2h_ms")}
+    # steady state: from the block that ends the first quarter to the last (buffers have stopped growing)
+    q = [m for m in marks if m[1] >= L // 4]
+    if len(q) >= 2 and q[-1][0] > q[0][0]:
+        out["bulk"]["steady_bp_per_s"] = (q[-1][1] - q[0][1]) / (q[-1][0] - q[0][0])
     # pop leg (a slice: it is ~50x slower)
     os.environ["WTAMD_NO_BULK"] = "1"
     pop_bp = int(min(L, 20e6))

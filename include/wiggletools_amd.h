@@ -460,6 +460,9 @@ WiggleIterator *wtamd_ArrayReader(int n_chrom, const char *const *chrom_names, c
  * number of runs (0 and wi->done at the end).  Mixes freely with pop(). */
 int64_t wtamd_iterator_next_block(WiggleIterator *wi, const char **chrom, const int32_t **start,
                                   const int32_t **finish, const double **value);
+/* Counters of the pipeline behind a reducer of this library (bytes over PCIe, summed kernel / copy
+ * durations from HIP events).  Returns WTAMD_ERR_ARG for any other iterator. */
+int wtamd_iterator_pipe_stats(WiggleIterator *wi, wtamd_pipe_stats *out);
 /* runWiggleIterator with counters: pops `wi` to the end one run at a time (the reference's own
  * protocol, wiggleIterator.c:62-65); returns the number of runs, their covered bp and value sum. */
 int64_t wtamd_drain(WiggleIterator *wi, int64_t *covered_bp, double *value_sum);

@@ -151,7 +151,7 @@ struct Feeder {
         cfg.max_intervals = 1 << 16;
         cfg.max_runs = max_runs_;
         max_runs = max_runs_;
-        target = env_i64("WTAMD_BATCH_INTERVALS", 4 << 20);
+        target = env_i64("WTAMD_BATCH_INTERVALS", 8 << 20);
         min_span = env_i64("WTAMD_MIN_SPAN", kFirstSpan);       // tests cut every few bp to stress the seams
         use_bulk = !getenv("WTAMD_NO_BULK");
         all_bulk = !src.empty();
@@ -508,7 +508,7 @@ void red_open(RedState *R, int op, uint32_t flags, int n_set0) {
     }
     wtamd_reduce_desc d = { op, flags, n_set0, 0 };
     R->fd.depth = pipe_depth();
-    R->fd.open(d, env_i64("WTAMD_BATCH_RUNS", 2 << 20), R->fd.depth + 1, kReducerFirstSpan);
+    R->fd.open(d, env_i64("WTAMD_BATCH_RUNS", 4 << 20), R->fd.depth + 1, kReducerFirstSpan);
 }
 
 WiggleIterator *make_reducer(Multiplexer *m, int op) {
@@ -963,6 +963,13 @@ int64_t wtamd_iterator_next_block(WiggleIterator *wi, const char **chrom, const 
     R->cur = F.res.n_runs;
     R->block_done = true;
     return n;
+}
+
+int wtamd_iterator_pipe_stats(WiggleIterator *wi, wtamd_pipe_stats *out) {
+    if (!wi || !out || wi->pop != &red_pop) return WTAMD_ERR_ARG;
+    RedState *R = red_state(wi);
+    if (!R->fd.pipe) return WTAMD_ERR_ARG;
+    return wtamd_pipe_get_stats(R->fd.pipe, out);
 }
 
 int64_t wtamd_drain(WiggleIterator *wi, int64_t *covered_bp, double *value_sum) {

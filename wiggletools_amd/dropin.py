@@ -110,6 +110,16 @@ def drain_blocks(wi, on_block=None):
             bp += on_block(chrom.value, sa, fa, va)
 
 
+def pipe_stats(wi):
+    from .pipe import PipeStats
+    L = _bind()
+    st = PipeStats()
+    L.wtamd_iterator_pipe_stats.argtypes = [C.c_void_p, C.POINTER(PipeStats)]
+    if L.wtamd_iterator_pipe_stats(wi, C.byref(st)) != 0:
+        return {}
+    return {k: getattr(st, k) for k, _ in PipeStats._fields_}
+
+
 def drain_pops(wi):
     """Consumes an iterator one pop at a time (in C); returns (runs, covered bp, value sum)."""
     L = _bind()
