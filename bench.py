@@ -222,7 +222,7 @@ def e2e_dropin(op, n_tracks, mean_run, mbp, device):
     out["bulk"] = {"bp_per_s": L / dt, "seconds": dt, "bp": L, "runs": runs,
                    "h2d_GBs": 12.0 * n / dt / 1e9, "d2h_GBs": 16.0 * runs / dt / 1e9,
                    "batches": st.get("batches"), "sum_h2d_ms": st.get("h2d_ms"), "sum_kernel_ms": st.get("kernel_ms"),
-                   "sum_d2h_ms": st.get("d2h_ms")}
+                   "sum_d2h_ms": st.get("d2h_ms"), "host_submit_ms": st.get("host_submit_ms"), "host_wait_ms": st.get("host_wait_ms")}
     # steady state: from the block that ends the first quarter to the last (buffers have stopped growing)
     q = [m for m in marks if m[1] >= L // 4]
     if len(q) >= 2 and q[-1][0] > q[0][0]:

@@ -408,6 +408,8 @@ typedef struct {
     double h2d_ms, d2h_ms;      /* same for the copies (events on their streams) */
     int32_t delta_batches;      /* batches the exact difference-array kernel evaluated */
     int32_t n_slots;
+    double host_submit_ms;      /* host time inside wtamd_pipe_submit (enqueueing; nothing there waits for the GPU) */
+    double host_wait_ms;        /* host time wtamd_pipe_collect spent waiting for a batch to finish */
 } wtamd_pipe_stats;
 
 int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out);

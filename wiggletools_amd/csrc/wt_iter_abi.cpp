@@ -38,6 +38,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <deque>
 #include <new>
 #include <vector>
@@ -52,6 +53,12 @@ namespace {
     fprintf(stderr, "wiggletools_amd: %s: %s\n", what, wtamd_last_error());
     exit(1);
 }
+
+double now_ms() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+const bool g_trace = getenv("WTAMD_TRACE") != nullptr;    // host-side timeline of the Feeder on stderr
 
 int64_t env_i64(const char *name, int64_t dflt) {
     const char *e = getenv(name);
@@ -223,6 +230,7 @@ struct Feeder {
         const int64_t hi64 = (int64_t) lo + span;
         const int32_t hi = hi64 >= INT32_MAX ? INT32_MAX : (int32_t) hi64;
 
+        const double t_drain0 = g_trace ? now_ms() : 0;
         wtamd_pipe_batch b;
         if (wtamd_pipe_acquire(pipe, &b) != WTAMD_OK) die("wtamd_pipe_acquire");
         if (f64_mode && !b.value64 && wtamd_pipe_grow(pipe, 0, b.capacity, 1, &b) != WTAMD_OK) die("wtamd_pipe_grow");
@@ -320,7 +328,9 @@ struct Feeder {
             }
         }
         b.seg_off[N] = n;
+        const double t_sub0 = g_trace ? now_ms() : 0;
         if (wtamd_pipe_submit(pipe, f64_mode ? 1 : 0, lo, hi) != WTAMD_OK) die("wtamd_pipe_submit");
+        if (g_trace) fprintf(stderr, "[feeder] drain %.3f -> %.3f submit -> %.3f  (%lld intervals, [%d, %d))\n", t_drain0, t_sub0, now_ms(), (long long) n, lo, hi);
         flights.push_back(std::move(fl));
         // where the next batch starts: at the cut if an interval reaches it, else at the first
         // interval beyond it (no track is in play in between: no run can start there)
@@ -355,7 +365,9 @@ struct Feeder {
         for (;;) {
             while ((int) flights.size() < depth && drain_and_submit()) { }
             if (flights.empty()) return false;
+            const double t_c0 = g_trace ? now_ms() : 0;
             if (wtamd_pipe_collect(pipe, &res) != WTAMD_OK) die("wtamd_pipe_collect");
+            if (g_trace) fprintf(stderr, "[feeder] collect %.3f -> %.3f (%lld runs, %d in flight)\n", t_c0, now_ms(), (long long) res.n_runs, (int) flights.size());
             res_chrom = flights.front().chrom;
             holding = true;
             if (res.n_runs > 0) return true;

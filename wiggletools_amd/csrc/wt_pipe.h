@@ -11,10 +11,15 @@
 //      result stream      D2H k-1 (exactly the emitted runs) | D2H k | ...   into PINNED output
 //
 // Events order the three streams per slot; nothing is allocated, freed or synchronised per batch
-// (staging, device buffers and window tables only ever grow), the run count travels back with the
-// kernel's counters and the D2H of the runs is issued as soon as that count is known (checked
-// whenever the pipe is entered, waited for only by collect()).  A batch whose difference-array
-// launch reported windows it could not prove exact gets the patch kernel before its D2H.
+// (staging, device buffers and window tables only ever grow) and the host never has to learn a
+// run count before the result can travel: the export kernel reads it on the device and writes
+// exactly the emitted runs (and the counters) into the slot's pinned output through the link.
+// All three legs are KERNELS -- gather (reads the page-locked run lists over PCIe), the
+// multiplex/reduce kernels, export (writes over PCIe) -- so consecutive batches overlap on the
+// GPU's queues without SDMA hand-offs in between (measured: with hipMemcpyAsync legs the next
+// batch's H2D did not start before the previous batch's D2H had finished).  A batch whose
+// difference-array launch reported windows it could not prove exact (rare: NaN, Inf, huge dynamic
+// range) is patched and exported again when it is collected.
 #ifndef WT_PIPE_H_
 #define WT_PIPE_H_
 
@@ -33,15 +38,27 @@ struct WtGatherSeg {
 };
 #define WT_GATHER_CHUNK 4096
 
+#define WT_GATHER_MAX_SEGS 1024      // table entries one launch caches in LDS (48 KB)
+
 __global__ void __launch_bounds__(256) wt_gather_kernel(const WtGatherSeg *segs, int n_segs, long long n_chunks,
                                                          int32_t *d_start, int32_t *d_finish, float *d_value) {
+    // the table lies in pinned HOST memory: every block pulls it into LDS once (one coalesced read
+    // through the link) instead of a separate H2D copy ahead of the launch
+    __shared__ WtGatherSeg tab[WT_GATHER_MAX_SEGS];
+    {
+        const long long *src = (const long long *) segs;
+        long long *dst = (long long *) tab;
+        const int words = n_segs * (int) (sizeof(WtGatherSeg) / 8);
+        for (int i = threadIdx.x; i < words; i += 256) dst[i] = __builtin_nontemporal_load(src + i);
+    }
+    __syncthreads();
     for (long long ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         int lo = 0, hi = n_segs - 1;                    // last segment with chunk_first <= ch
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (segs[mid].chunk_first <= ch) lo = mid; else hi = mid - 1;
+            if (tab[mid].chunk_first <= ch) lo = mid; else hi = mid - 1;
         }
-        const WtGatherSeg g = segs[lo];
+        const WtGatherSeg g = tab[lo];
         const long long a = (ch - g.chunk_first) * WT_GATHER_CHUNK;
         long long b = a + WT_GATHER_CHUNK;
         if (b > g.count) b = g.count;
@@ -61,6 +78,35 @@ __global__ void __launch_bounds__(256) wt_gather_kernel(const WtGatherSeg *segs,
     }
 }
 
+// Export: the emitted runs (their count is read on the device) and the launch counters go to the
+// slot's PINNED host output, written through the link by the kernel itself.
+__global__ void __launch_bounds__(256) wt_export_kernel(const unsigned long long *d_counters, unsigned long long *h_counters,
+                                                         long long capacity, int n_tracks,
+                                                         const int32_t *d_os, const int32_t *d_of, const double *d_ov,
+                                                         const double *d_tile, const uint8_t *d_ip,
+                                                         int32_t *h_os, int32_t *h_of, double *h_ov, double *h_tile, uint8_t *h_ip) {
+    long long n = (long long) d_counters[WT_CTR_RUNS];
+    if (n > capacity) n = capacity;
+    const long long stride = (long long) gridDim.x * 256, t = (long long) blockIdx.x * 256 + threadIdx.x;
+    {   // coordinates: 16 bytes per lane
+        const long long n4 = n >> 2;
+        const int4 *a = (const int4 *) d_os, *b = (const int4 *) d_of;
+        int4 *ha = (int4 *) h_os, *hb = (int4 *) h_of;
+        for (long long i = t; i < n4; i += stride) { ha[i] = a[i]; hb[i] = b[i]; }
+        for (long long i = (n4 << 2) + t; i < n; i += stride) { h_os[i] = d_os[i]; h_of[i] = d_of[i]; }
+        const long long n2 = n >> 1;
+        const double2 *v = (const double2 *) d_ov;
+        double2 *hv = (double2 *) h_ov;
+        for (long long i = t; i < n2; i += stride) hv[i] = v[i];
+        if (t == 0 && (n & 1)) h_ov[n - 1] = d_ov[n - 1];
+    }
+    if (d_tile) {
+        const long long m = n * n_tracks;
+        for (long long i = t; i < m; i += stride) { h_tile[i] = d_tile[i]; h_ip[i] = d_ip[i]; }
+    }
+    if (t < WT_CTR_N) h_counters[t] = d_counters[t];
+}
+
 // Page-locked (hipHostMalloc / hipHostRegister) host memory is readable by kernels; pageable memory
 // is not -- such ranges go through hipMemcpyAsync, which stages them.
 static bool wt_is_pinned(const void *q) {
@@ -71,7 +117,6 @@ static bool wt_is_pinned(const void *q) {
 
 struct WtSlot {
     int state = 0;                  // 0 free, 1 acquired, 2 submitted, 3 collected
-    int stage = 0;                  // submitted: 0 kernels enqueued, 1 D2H enqueued
     // input staging (pinned) and its device twin
     int64_t cap = 0;
     bool has64 = false;
@@ -103,7 +148,7 @@ struct WtSlot {
     // bulk side door: ranges of the batch that are copied to HBM straight from the caller's arrays
     struct Direct { int64_t at, count; const int32_t *start, *finish; const float *value; };
     std::vector<Direct> direct;
-    WtGatherSeg *h_segs = nullptr, *d_segs = nullptr;   // gather table: pinned staging + device copy
+    WtGatherSeg *h_segs = nullptr;  // gather table, pinned (the kernel reads it where it lies)
     int64_t seg_cap = 0;
     bool direct_pinned = true;      // every direct range of this batch lies in page-locked memory
 };
@@ -130,7 +175,6 @@ static void wt_slot_free(WtSlot &s) {
     (void) hipFree(s.d_start); (void) hipFree(s.d_finish); (void) hipFree(s.d_value);
     (void) hipFree(s.d_os); (void) hipFree(s.d_of); (void) hipFree(s.d_ov); (void) hipFree(s.d_tile); (void) hipFree(s.d_ip);
     (void) hipFree(s.d_cro);
-    (void) hipFree(s.d_segs);
     if (s.h_segs) (void) hipHostFree(s.h_segs);
     if (s.h_os) (void) hipHostFree(s.h_os);
     if (s.h_of) (void) hipHostFree(s.h_of);
@@ -193,60 +237,43 @@ static int wt_wait_event(hipEvent_t ev, const char *what) {
     }
 }
 
-// The run count (and the difference-array verdict) of a submitted batch is on the host: patch
-// the windows that were not provably exact, then ship exactly the emitted runs.
-static int wt_pipe_issue_d2h(wtamd_pipe *p, WtSlot &s) {
-    wtamd_trackset *ts = s.ts;
-    const unsigned long long *hc = ts->h_counters;
-    s.n_runs = (int64_t) hc[WT_CTR_RUNS];
-    s.covered = (int64_t) hc[WT_CTR_BP];
-    s.stage = 1;
-    if (hc[WT_CTR_ERROR] & WT_ERR_LOOKBACK) { s.err = WTAMD_ERR_INTERNAL; s.err_msg = "look-back timed out"; return WTAMD_OK; }
-    if (hc[WT_CTR_ERROR] & WT_ERR_CAPACITY) { s.err = WTAMD_ERR_CAPACITY; s.err_msg = "batch emitted more runs than the slot's output capacity (max_runs)"; return WTAMD_OK; }
-    hipEvent_t after = s.e_cnt;
-    const long long n_bad = (long long) hc[WT_CTR_DELTA_BAD];
-    if (s.used_delta && n_bad > 0) {
-        wtamd_runs runs{};
-        runs.capacity = s.ocap; runs.start = s.d_os; runs.finish = s.d_of; runs.value = s.d_ov; runs.chrom_run_off = s.d_cro;
-        const int rc = wt_launch_patch(ts, s.delta_W, p->cfg.desc.op, p->cfg.desc.flags, &runs, n_bad, p->s_comp);
-        if (rc != WTAMD_OK) { s.err = rc; s.err_msg = g_last_error; return WTAMD_OK; }
-        WT_HIP(hipEventRecord(s.e_patch, p->s_comp));
-        after = s.e_patch;
-        s.patched = true;
-        if (n_bad * 4 > (long long) ts->stats.n_windows) p->delta_failed = true;     // this data: general kernel from now on
-    }
+static int wt_pipe_enqueue_export(wtamd_pipe *p, WtSlot &s, hipEvent_t after) {
     WT_HIP(hipStreamWaitEvent(p->s_out, after, 0));
     WT_HIP(hipEventRecord(s.e_d0, p->s_out));
-    const int64_t n = s.n_runs;
-    if (n > 0) {
-        const int N = p->cfg.n_tracks;
-        WT_HIP(hipMemcpyAsync(s.h_os, s.d_os, sizeof(int32_t) * n, hipMemcpyDeviceToHost, p->s_out));
-        WT_HIP(hipMemcpyAsync(s.h_of, s.d_of, sizeof(int32_t) * n, hipMemcpyDeviceToHost, p->s_out));
-        WT_HIP(hipMemcpyAsync(s.h_ov, s.d_ov, sizeof(double) * n, hipMemcpyDeviceToHost, p->s_out));
-        p->st.d2h_bytes += 16 * n;
-        if (p->tile) {
-            WT_HIP(hipMemcpyAsync(s.h_tile, s.d_tile, sizeof(double) * n * N, hipMemcpyDeviceToHost, p->s_out));
-            WT_HIP(hipMemcpyAsync(s.h_ip, s.d_ip, sizeof(uint8_t) * n * N, hipMemcpyDeviceToHost, p->s_out));
-            p->st.d2h_bytes += 9 * n * N;
-        }
-    }
+    long long blocks = (s.ocap + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 2ll * s.ts->num_cu) blocks = 2ll * s.ts->num_cu;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wt_export_kernel, dim3((unsigned) blocks), dim3(256), 0, p->s_out, s.ts->d_counters, s.ts->h_counters,
+                       (long long) s.ocap, p->cfg.n_tracks, s.d_os, s.d_of, s.d_ov, p->tile ? s.d_tile : nullptr,
+                       p->tile ? s.d_ip : nullptr, s.h_os, s.h_of, s.h_ov, p->tile ? s.h_tile : nullptr, p->tile ? s.h_ip : nullptr);
+    WT_HIP(hipGetLastError());
     WT_HIP(hipEventRecord(s.e_d1, p->s_out));
     return WTAMD_OK;
 }
 
-// Non-blocking: issues the D2H of every submitted batch whose counters have arrived.
-static int wt_pipe_progress(wtamd_pipe *p) {
-    const int ns = (int) p->slots.size();
-    for (int k = 0, i = p->tail; k < ns; k++, i = (i + 1) % ns) {
-        WtSlot &s = p->slots[(size_t) i];
-        if (s.state == 3) continue;             // collected, being read
-        if (s.state != 2) break;
-        if (s.stage == 0) {
-            if (hipEventQuery(s.e_cnt) != hipSuccess) break;     // in order: later batches are behind it on the stream
-            const int rc = wt_pipe_issue_d2h(p, s);
-            if (rc != WTAMD_OK) return rc;
-        }
+// The batch's export has landed: read the counters; patch + export again if the difference-array
+// launch left windows it could not prove exact.
+static int wt_pipe_finish(wtamd_pipe *p, WtSlot &s) {
+    wtamd_trackset *ts = s.ts;
+    const unsigned long long *hc = ts->h_counters;
+    if (hc[WT_CTR_ERROR] & WT_ERR_LOOKBACK) return wt_fail(WTAMD_ERR_INTERNAL, "look-back timed out");
+    if (hc[WT_CTR_ERROR] & WT_ERR_CAPACITY) return wt_fail(WTAMD_ERR_CAPACITY, "batch emitted more runs than the slot's output capacity (max_runs)");
+    const long long n_bad = (long long) hc[WT_CTR_DELTA_BAD];
+    if (s.used_delta && n_bad > 0) {
+        wtamd_runs runs{};
+        runs.capacity = s.ocap; runs.start = s.d_os; runs.finish = s.d_of; runs.value = s.d_ov; runs.chrom_run_off = s.d_cro;
+        int rc = wt_launch_patch(ts, s.delta_W, p->cfg.desc.op, p->cfg.desc.flags, &runs, n_bad, p->s_comp);
+        if (rc != WTAMD_OK) return rc;
+        WT_HIP(hipEventRecord(s.e_patch, p->s_comp));
+        rc = wt_pipe_enqueue_export(p, s, s.e_patch);
+        if (rc != WTAMD_OK) return rc;
+        rc = wt_wait_event(s.e_d1, "patched result");
+        if (rc != WTAMD_OK) return rc;
+        s.patched = true;
+        if (n_bad * 4 > (long long) ts->stats.n_windows) p->delta_failed = true;     // this data: general kernel from now on
     }
+    s.n_runs = (int64_t) hc[WT_CTR_RUNS];
+    s.covered = (int64_t) hc[WT_CTR_BP];
     return WTAMD_OK;
 }
 
@@ -378,7 +405,16 @@ int wtamd_pipe_cancel(wtamd_pipe *p) {
     return WTAMD_OK;
 }
 
+static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi);
+
 int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = wt_pipe_submit_impl(p, value_is_f64, range_lo, range_hi);
+    if (p) p->st.host_submit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi) {
     if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: no acquired slot");
     WtSlot &s = p->slots[(size_t) p->acquired];
     const int N = p->cfg.n_tracks;
@@ -484,16 +520,14 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
     // copy stream: pinned staging -> HBM
     WT_HIP(hipEventRecord(s.e_h0, p->s_copy));
     WT_HIP(hipMemcpyAsync(ts->d_seg_off, s.h_seg, sizeof(int64_t) * ((size_t) N + 1), hipMemcpyHostToDevice, p->s_copy));
-    if (n > 0 && p->gather && !f64 && !s.direct.empty() && s.direct_pinned) {
+    if (n > 0 && p->gather && !f64 && !s.direct.empty() && s.direct_pinned && 2 * (int64_t) s.direct.size() + 1 <= WT_GATHER_MAX_SEGS) {
         // one table, one small copy, one kernel for the whole batch
         const int64_t max_segs = 2 * (int64_t) s.direct.size() + 1;
         if (s.seg_cap < max_segs) {
-            (void) hipFree(s.d_segs);
-            if (s.h_segs) (void) hipHostFree(s.h_segs);
-            s.d_segs = nullptr; s.h_segs = nullptr; s.seg_cap = 0;
+                    if (s.h_segs) (void) hipHostFree(s.h_segs);
+            s.h_segs = nullptr; s.seg_cap = 0;
             const int64_t c = 2 * max_segs;
             WT_HIP(hipHostMalloc((void **) &s.h_segs, sizeof(WtGatherSeg) * c, hipHostMallocDefault));
-            WT_HIP(hipMalloc(&s.d_segs, sizeof(WtGatherSeg) * c));
             s.seg_cap = c;
         }
         int ns = 0;
@@ -510,10 +544,9 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
             pos = d.at + d.count;
         }
         add(s.h_start + pos, s.h_finish + pos, s.h_v32 + pos, pos, n - pos);
-        WT_HIP(hipMemcpyAsync(s.d_segs, s.h_segs, sizeof(WtGatherSeg) * ns, hipMemcpyHostToDevice, p->s_copy));
-        long long grid = chunks < 4ll * ts->num_cu ? chunks : 4ll * ts->num_cu;
+        long long grid = chunks < 3ll * ts->num_cu ? chunks : 3ll * ts->num_cu;      // leaves wave slots for the compute kernels of the previous batch
         if (grid < 1) grid = 1;
-        hipLaunchKernelGGL(wt_gather_kernel, dim3((unsigned) grid), dim3(256), 0, p->s_copy, s.d_segs, ns, chunks,
+        hipLaunchKernelGGL(wt_gather_kernel, dim3((unsigned) grid), dim3(256), 0, p->s_copy, s.h_segs, ns, chunks,
                            s.d_start, s.d_finish, (float *) s.d_value);
         WT_HIP(hipGetLastError());
     } else if (n > 0) {
@@ -560,17 +593,18 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
     rc = wt_reduce_plan(ts, plan, op, p->cfg.desc.flags, p->cfg.desc.n_set0, &runs, p->tile ? s.d_tile : nullptr,
                         p->tile ? s.d_ip : nullptr, nullptr, p->s_comp);
     if (rc != WTAMD_OK) return rc;
-    WT_HIP(hipMemcpyAsync(ts->h_counters, ts->d_counters, sizeof(unsigned long long) * WT_CTR_N, hipMemcpyDeviceToHost, p->s_comp));
     WT_HIP(hipEventRecord(s.e_cnt, p->s_comp));
+    rc = wt_pipe_enqueue_export(p, s, s.e_cnt);
+    if (rc != WTAMD_OK) return rc;
 
-    s.n_int = n; s.f64 = f64; s.err = WTAMD_OK; s.stage = 0; s.state = 2;
+    s.n_int = n; s.f64 = f64; s.err = WTAMD_OK; s.state = 2;
     p->acquired = -1;
     p->head = (p->head + 1) % (int) p->slots.size();
     p->in_flight++;
     p->st.batches++;
     p->st.intervals += n;
     if (s.used_delta) p->st.delta_batches++;
-    return wt_pipe_progress(p);
+    return WTAMD_OK;
 }
 
 int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
@@ -579,26 +613,22 @@ int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
     if (p->held) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_collect: the previous result was not released");
     WtSlot &s = p->slots[(size_t) p->tail];
     if (s.state != 2) return wt_fail(WTAMD_ERR_INTERNAL, "wtamd_pipe_collect: slot order corrupted");
-    int rc = wt_pipe_progress(p);
-    if (rc != WTAMD_OK) return rc;
-    if (s.stage == 0) {
-        rc = wt_wait_event(s.e_cnt, "kernels");
-        if (rc != WTAMD_OK) return rc;
-        rc = wt_pipe_issue_d2h(p, s);
-        if (rc != WTAMD_OK) return rc;
-    }
+    const auto t_wait0 = std::chrono::steady_clock::now();
+    int rc = wt_wait_event(s.e_d1, "batch");
     s.state = 3;
     p->in_flight--;
     p->held = 1;
-    if (s.err != WTAMD_OK) return wt_fail(s.err, s.err_msg);
-    rc = wt_wait_event(s.e_d1, "result copy");
     if (rc != WTAMD_OK) return rc;
+    rc = wt_pipe_finish(p, s);
+    if (rc != WTAMD_OK) return rc;
+    p->st.host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wait0).count();
     float ms = 0;
     if (hipEventElapsedTime(&ms, s.e_h0, s.e_h1) == hipSuccess) p->st.h2d_ms += ms;
-    if (hipEventElapsedTime(&ms, s.e_k0, s.patched ? s.e_patch : s.e_cnt) == hipSuccess) p->st.kernel_ms += ms;
+    if (hipEventElapsedTime(&ms, s.e_k0, s.e_cnt) == hipSuccess) p->st.kernel_ms += ms;
     if (hipEventElapsedTime(&ms, s.e_d0, s.e_d1) == hipSuccess) p->st.d2h_ms += ms;
     p->st.runs += s.n_runs;
     p->st.covered_bp += s.covered;
+    p->st.d2h_bytes += s.n_runs * (16 + (p->tile ? 9 * (int64_t) p->cfg.n_tracks : 0));
     out->n_runs = s.n_runs;
     out->start = s.h_os; out->finish = s.h_of; out->value = s.h_ov;
     out->tile = p->tile ? s.h_tile : nullptr;
