@@ -162,6 +162,7 @@ struct wtamd_pipe {
     bool delta_failed = false;      // a batch had many inexact windows: Sum / Mean stay on the general kernel
     bool tile = false;
     bool gather = true;             // WTAMD_PIPE_GATHER=0: hipMemcpyAsync per range instead of the gather kernel
+    int gather_blocks = 64;         // WTAMD_GATHER_BLOCKS
     int num_cu = 256;
     wtamd_pipe_stats st{};
 };
@@ -292,6 +293,7 @@ int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
     p->cfg.defaults = p->defaults.data();
     p->tile = tile;
     if (getenv("WTAMD_PIPE_GATHER")) p->gather = atoi(getenv("WTAMD_PIPE_GATHER")) != 0;
+    if (getenv("WTAMD_GATHER_BLOCKS") && atoi(getenv("WTAMD_GATHER_BLOCKS")) > 0) p->gather_blocks = atoi(getenv("WTAMD_GATHER_BLOCKS"));
     int ns = cfg->n_slots ? cfg->n_slots : 3;
     if (ns < 2) ns = 2;
     if (ns > 8) ns = 8;
@@ -544,7 +546,13 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
             pos = d.at + d.count;
         }
         add(s.h_start + pos, s.h_finish + pos, s.h_v32 + pos, pos, n - pos);
-        long long grid = chunks < 3ll * ts->num_cu ? chunks : 3ll * ts->num_cu;      // leaves wave slots for the compute kernels of the previous batch
+        // Few blocks on purpose: every block keeps 48 KB of reads in flight, and whatever is queued
+        // on the link delays every OTHER host read by queue / bandwidth -- kernel arguments and the
+        // small tables of the compute kernels of the previous batch included (measured with 768
+        // blocks = 37 MB in flight: those kernels started ~1.7 ms late, right at the gather's tail).
+        // The bandwidth-delay product of the link is well below 1 MB.
+        long long grid = p->gather_blocks;
+        if (grid > chunks) grid = chunks;
         if (grid < 1) grid = 1;
         hipLaunchKernelGGL(wt_gather_kernel, dim3((unsigned) grid), dim3(256), 0, p->s_copy, s.h_segs, ns, chunks,
                            s.d_start, s.d_finish, (float *) s.d_value);
