@@ -29,7 +29,7 @@ struct EmuRun {
     bool patch = false;
     std::vector<PatchGroup> groups;
 
-    template <int OP, class ValT, class ScrT, int K, bool MULTI>
+    template <int OP, class ValT, class ScrT, int K, bool MULTI, int NR = 0>
     void run() {
         WtCtx c;
         wt_ctx_init(c, P, lds.data());
@@ -55,7 +55,7 @@ struct EmuRun {
             constexpr int npass = wt_eval_passes(OP);
             const int N = P.n_tracks, NC = P.chunk_tracks;
             constexpr bool multi = MULTI;
-            std::vector<WtAcc<K>> acc(T);
+            std::vector<WtAcc<K, NR>> acc(T);
             constexpr bool fuse = MULTI && OP != WT_OP_MULTIPLEX;      // as in wt_reduce_kernel
             wt_phase_header(P, c, k);
             for (int t = 0; t < T; t++) wt_phase_zero(P, c, true, t, T);
@@ -92,7 +92,7 @@ struct EmuRun {
                 if (pass == 0 && npass == 2) for (int t = 0; t < T; t++) wt_eval_mid<OP, K>(P, acc[t]);
             }
             for (int t = 0; t < T; t++) wt_phase_eval_finish<OP, ValT, ScrT, K>(P, c, acc[t], lanes[t], t, T);
-            if (OP == WT_OP_MWU) {
+            if (OP == WT_OP_MWU && NR == 0) {
                 for (int t = 0; t < T; t++) wt_phase_mwu_rank<ScrT>(P, c, t, T);
                 for (int t = 0; t < T; t++) wt_phase_mwu_tail<K>(P, c, acc[t], lanes[t], t, T);
             }
@@ -202,7 +202,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         EmuRun R;
         std::string err;
         if (delta) wt_make_delta_plan(R.plan, n_tracks);
-        else if (!wt_make_plan(n_tracks, op, s32, R.plan, err)) { fprintf(stderr, "wtemu: %s\n", err.c_str()); return -10; }
+        else if (!wt_make_plan(n_tracks, op, s32, R.plan, err, 80 * 1024, 160 * 1024, n_set0)) { fprintf(stderr, "wtemu: %s\n", err.c_str()); return -10; }
         WtWindowTables tab;
         wt_make_windows(n_chrom, n_tracks, seg_off, fs.data(), lf.data(), R.plan.W, tab, range_lo, range_hi);
         std::vector<uint32_t> widx((size_t) tab.n_rows * n_tracks, 0);
@@ -256,7 +256,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         if (total > 0) {
             if (delta) {
                 if (op == WT_OP_SUM) R.run_delta<WT_OP_SUM>(); else R.run_delta<WT_OP_MEAN>();
-            } else if (!wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R.plan.n_chunks > 1 || R.plan.scratch_slab > 0, R)) {
+            } else if (!wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R.plan.n_chunks > 1 || R.plan.scratch_slab > 0, R, R.plan.regcol)) {
                 return -11;
             }
         }

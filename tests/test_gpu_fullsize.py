@@ -25,12 +25,13 @@ sys.path.insert(0, ROOT)
 def test_gpu_full_size_properties(scale, monkeypatch):
     import torch
     import bench
+    from wiggletools_amd import synthgen
     from wiggletools_amd import engine
 
     dev = torch.device("cuda", 0)
     N = 100
     chrom_lens = [max(int(x * scale), 1) for x in bench.GRCH38]
-    seg_off, start, finish, value = bench.synth_device(N, chrom_lens, 16.0, 0.02, 7, dev)
+    seg_off, start, finish, value = synthgen.device_tracks(7, chrom_lens, N, 16.0, 0.02, 800, dev)
     stream = torch.cuda.current_stream().cuda_stream
     ts0 = engine.TrackSet.from_device(len(chrom_lens), N, seg_off, start, finish, value, np.zeros(N))
     assert ts0.validate() == (0, -1), "generator produced runs that violate the input contract"
@@ -111,13 +112,14 @@ def test_gpu_plans_agree_bitwise_at_scale(op, kw, monkeypatch):
     vs wide workgroups -- must give identical bits: 100 tracks, 62 Mbp (31 Mbp for median / MWU)."""
     import torch
     import bench
+    from wiggletools_amd import synthgen
     from wiggletools_amd import engine
 
     dev = torch.device("cuda", 0)
     N = 100
     scale = 0.01 if op in ("median", "mwu") else 0.02
     chrom_lens = [max(int(x * scale), 1) for x in bench.GRCH38]
-    seg_off, start, finish, value = bench.synth_device(N, chrom_lens, 16.0, 0.02, 3, dev)
+    seg_off, start, finish, value = synthgen.device_tracks(3, chrom_lens, N, 16.0, 0.02, 800, dev)
     stream = torch.cuda.current_stream().cuda_stream
     plans = [{}, {"WTAMD_CHUNK": "37"}]
     plans.append({"WTAMD_T": "64"} if op in ("median", "mwu") else {"WTAMD_PPT": "1", "WTAMD_T": "256"})

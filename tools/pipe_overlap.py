@@ -37,7 +37,7 @@ def inter(u, v):
 
 
 def main(d, out):
-    gather, comp, d2h, h2d = [], [], [], []
+    gather, comp, export, d2h, h2d = [], [], [], [], []
     names = {}
     for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -49,7 +49,7 @@ def main(d, out):
             names.setdefault(key, [0, 0])
             names[key][0] += 1
             names[key][1] += b - a
-            (gather if "wt_gather" in n else comp).append((a, b))
+            (gather if "wt_gather" in n else (export if "wt_export" in n else comp)).append((a, b))
     for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             a, b = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
@@ -65,15 +65,21 @@ def main(d, out):
     t0 = min(a for a, b in gather) if gather else min(a for a, b in comp)
     t1 = max(b for a, b in gather) if gather else max(b for a, b in comp)
     clip = lambda iv: [(max(a, t0), min(b, t1 + 5_000_000)) for a, b in iv if b > t0 and a < t1 + 5_000_000]
-    ug, uc, ud = union(clip(gather)), union(clip(comp)), union(clip(d2h))
+    ug, uc, ud = union(clip(gather)), union(clip(comp)), union(clip(export))
+    # steady state: the second half of the gather launches (buffers have stopped growing)
+    gs = sorted(gather)
+    half = gs[len(gs) // 2:]
+    steady_span = half[-1][1] - half[0][0] if len(half) > 1 else 0
+    steady_busy = sum(b - a for a, b in half)
     span = (t1 - t0)
-    res = {"span_ms": span / 1e6,
-           "gather_busy_ms": total(ug) / 1e6, "compute_busy_ms": total(uc) / 1e6, "d2h_busy_ms": total(ud) / 1e6,
-           "compute_under_gather_ms": inter(ug, uc) / 1e6, "d2h_under_gather_ms": inter(ug, ud) / 1e6,
-           "d2h_under_compute_ms": inter(uc, ud) / 1e6,
-           "frac_of_compute_hidden_under_gather": inter(ug, uc) / max(total(uc), 1),
-           "frac_of_d2h_hidden_under_gather_or_compute": inter(union(ug + uc), ud) / max(total(ud), 1),
-           "link_busy_frac_of_span": total(ug) / max(span, 1),
+    res = {"what": "rocprofv3 --kernel-trace of tools/e2e_only.py: H2D = wt_gather_kernel (copy stream), compute = wt_index + wt_delta (+ wt_reduce for the Multiplexer's priming batch), D2H = wt_export_kernel (result stream)",
+           "span_ms": span / 1e6,
+           "h2d_gather_busy_ms": total(ug) / 1e6, "compute_busy_ms": total(uc) / 1e6, "d2h_export_busy_ms": total(ud) / 1e6,
+           "compute_under_h2d_ms": inter(ug, uc) / 1e6, "d2h_under_h2d_ms": inter(ug, ud) / 1e6,
+           "frac_of_compute_hidden_under_h2d": inter(ug, uc) / max(total(uc), 1),
+           "frac_of_d2h_hidden_under_h2d": inter(ug, ud) / max(total(ud), 1),
+           "h2d_link_busy_frac_of_span": total(ug) / max(span, 1),
+           "steady_state_h2d_link_busy_frac": steady_busy / max(steady_span, 1),
            "kernels": {k: {"launches": v[0], "total_ms": v[1] / 1e6} for k, v in names.items()},
            "n_d2h_copies": len(d2h), "n_h2d_copies": len(h2d)}
     json.dump(res, open(out, "w"), indent=1)

@@ -755,19 +755,25 @@ WT_DEV void wt_for_tracks_deep(const WtParams &P, const WtCtx &c, int base, int 
 // out), so no flag is carried; min / max / median / MWU carry an explicit flag because
 // comparisons swallow NaN.  Median / MWU use K == 1 and this lane's LDS scratch column.
 // ---------------------------------------------------------------------------
-template <int K>
+// NR > 0 (median / MWU, K == 1, float tracks with float-exact defaults, at most NR tracks): the
+// position's value column lives in REGISTERS -- NR 32-bit slots with compile-time indices -- instead
+// of an LDS column.  The LDS columns (N * 4 B per lane) capped a CU at 4 waves, one per SIMD, and
+// both reducers were bound by dependent-instruction latency with nothing to interleave; the
+// register column leaves LDS to the bitmaps alone (3 workgroups of 256 lanes per CU at NR = 128).
+template <int K, int NR = 0>
 struct WtAcc {
     double a[K], b[K];        // sum|product|best|mean|s1 , squares|q1
     double c2[K], d[K];       // t-test: s2, q2
     bool nan[K];
+    uint32_t col[NR > 0 ? NR : 1];
 };
 
 WT_DEV constexpr int wt_eval_passes(int op) {
     return (op == WT_OP_VAR || op == WT_OP_STDDEV || op == WT_OP_ENTROPY || op == WT_OP_CV) ? 2 : 1;
 }
 
-template <int OP, int K>
-WT_DEV void wt_eval_init(WtAcc<K> &A) {
+template <int OP, int K, int NR>
+WT_DEV void wt_eval_init(WtAcc<K, NR> &A) {
 #pragma unroll
     for (int k = 0; k < K; k++) {
         A.a[k] = (OP == WT_OP_PRODUCT) ? 1.0 : 0.0;
@@ -778,13 +784,101 @@ WT_DEV void wt_eval_init(WtAcc<K> &A) {
 
 // Adds the tracks [t_lo, t_hi) (resident chunk, LDS rows relative to t_lo) in pass `pass`.
 // goff_run0: MULTIPLEX only -- global index of the run at the lane's first emitted position.
-template <int OP, class ValT, class ScrT, int K>
-WT_DEV void wt_eval_chunk(const WtParams &P, const WtCtx &c, int p0, WtAcc<K> &A, int pass, int t_lo, int t_hi,
+// Compare-exchange network over registers (bitonic sort, compile-time indices): v[0..NR) ascending
+// (DESC: descending) as unsigned keys.  NR * log2(NR) * (log2(NR) + 1) / 4 exchanges, two VALU each.
+template <int NR, bool DESC>
+WT_DEV void wt_sort_regs(uint32_t *v) {
+#pragma unroll
+    for (int k = 2; k <= NR; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int i = 0; i < NR; i++) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = v[i], b = v[l];
+                    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+                    const bool up = ((i & k) == 0) != DESC;
+                    v[i] = up ? lo : hi;
+                    v[l] = up ? hi : lo;
+                }
+            }
+        }
+    }
+}
+
+// Register column: the default-substituted values of the position at compile-time slots (median:
+// order-preserving keys, real tracks at slots pad_lo + i; MWU: float bits, set 0 at [0, NR/2),
+// set 1 at [NR/2, NR)).  The tracks are fetched by a ROLLED loop over blocks of WT_REGCOL_BLOCK
+// slots -- a fully unrolled gather made the compiler hoist every track's scalar state (buffer
+// descriptor, default, first-interval index) and spill hundreds of SGPRs and VGPRs -- and every
+// block is moved to its registers through a switch on the (uniform) block number.
+#define WT_REGCOL_BLOCK 8
+template <int NR, int B0 = 0>
+WT_DEV void wt_regcol_store(uint32_t *col, int blk, const uint32_t (&tmp)[WT_REGCOL_BLOCK]) {
+    if constexpr (B0 < NR / WT_REGCOL_BLOCK) {
+        if (blk == B0) {
+#pragma unroll
+            for (int q = 0; q < WT_REGCOL_BLOCK; q++) col[B0 * WT_REGCOL_BLOCK + q] = tmp[q];
+        } else {
+            wt_regcol_store<NR, B0 + 1>(col, blk, tmp);
+        }
+    }
+}
+
+template <int OP, class ValT, int NR>
+WT_DEV bool wt_gather_regs(const WtParams &P, const WtCtx &c, int p0, uint32_t *col) {
+    const int w32 = p0 >> 5, b0 = p0 & 31;
+    const uint32_t mask[1] = { (2u << b0) - 1u };
+    const int N = P.n_tracks, na = P.n_set0;
+    const double *dflt = P.defaults;
+    bool nan = false;
+    // Median: pads below and above place the wanted order statistic vals[N/2] (reducers.c:810) at
+    // the FIXED slot NR/2 of the sorted column: N/2 of the real keys and NR/2 - N/2 low pads lie
+    // below it.  MWU: pads are NaN (they compare false with everything).
+    const int pad_lo = NR / 2 - N / 2;
+#pragma unroll 1
+    for (int blk = 0; blk < NR / WT_REGCOL_BLOCK; blk++) {
+        uint32_t tmp[WT_REGCOL_BLOCK];
+        int trk[WT_REGCOL_BLOCK];
+        WtRawK<ValT, 1> raw[WT_REGCOL_BLOCK];
+#pragma unroll
+        for (int q = 0; q < WT_REGCOL_BLOCK; q++) {       // issue the block's gathers ...
+            const int s = blk * WT_REGCOL_BLOCK + q;
+            int i;
+            if (OP == WT_OP_MEDIAN) { i = s - pad_lo; if (i < 0 || i >= N) i = -1; }
+            else { i = s < NR / 2 ? (s < na ? s : -1) : (na + (s - NR / 2) < N ? na + (s - NR / 2) : -1); }
+            trk[q] = i;
+            if (i >= 0) wt_fetch_issue<ValT, 1>(P, c, i, w32, b0, mask, dflt[i], raw[q]);     // workgroup-uniform branch
+        }
+#pragma unroll
+        for (int q = 0; q < WT_REGCOL_BLOCK; q++) {       // ... then consume them
+            const int s = blk * WT_REGCOL_BLOCK + q;
+            uint32_t v = OP == WT_OP_MEDIAN ? (s < pad_lo ? 0u : 0xffffffffu) : 0x7fc00000u;
+            if (trk[q] >= 0) {
+                WtFetchK<1> F;
+                wt_fetch_finish<ValT, float, 1>(raw[q], b0, F);
+                nan |= wt_isnan(F.x[0]);
+                v = OP == WT_OP_MEDIAN ? wt_key32((float) F.x[0]) : __builtin_bit_cast(uint32_t, (float) F.x[0]);
+            }
+            tmp[q] = v;
+        }
+        wt_regcol_store<NR>(col, blk, tmp);
+    }
+    return nan;
+}
+
+template <int OP, class ValT, class ScrT, int K, int NR>
+WT_DEV void wt_eval_chunk(const WtParams &P, const WtCtx &c, int p0, WtAcc<K, NR> &A, int pass, int t_lo, int t_hi,
                           char *scratch, int lane_col, int colstride, unsigned emit_bits, long long run0) {
     const int w32 = p0 >> 5, b0 = p0 & 31;
     uint32_t mask[K];
 #pragma unroll
     for (int k = 0; k < K; k++) mask[k] = (2u << (b0 + k)) - 1u;
+    if constexpr (NR > 0 && (OP == WT_OP_MEDIAN || OP == WT_OP_MWU)) {
+        A.nan[0] = wt_gather_regs<OP, ValT, NR>(P, c, p0, A.col);
+        return;
+    }
 
     if (OP == WT_OP_SUM || OP == WT_OP_PRODUCT || OP == WT_OP_MEAN) {
         // reducers.c:259-292, 313-346, 367-402
@@ -902,8 +996,8 @@ WT_DEV void wt_eval_chunk(const WtParams &P, const WtCtx &c, int p0, WtAcc<K> &A
 }
 
 // Between the two passes of var / stddev / CV: the mean is final.
-template <int OP, int K>
-WT_DEV void wt_eval_mid(const WtParams &P, WtAcc<K> &A) {
+template <int OP, int K, int NR>
+WT_DEV void wt_eval_mid(const WtParams &P, WtAcc<K, NR> &A) {
 #pragma unroll
     for (int k = 0; k < K; k++) A.a[k] /= P.n_tracks;
 }
@@ -1012,10 +1106,80 @@ WT_DEV double wt_mwu_tail(const WtParams &P, char *attr_base, int col, int colst
     return (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
 }
 
-template <int OP, class ValT, class ScrT, int K>
-WT_DEV void wt_eval_finish(const WtParams &P, const WtAcc<K> &A, double (&res)[K], char *scratch, char *attr_base,
+// MWU over a register column (wt_gather_regs): set 0 sorted by a register network and parked in
+// this lane's LDS column (n_set0 * 4 B -- the only LDS the reducer needs); then ONE pass over the
+// sorted set-0 values e, each compared with the set-1 registers (compile-time indices):
+//   L_e = #set-1 values < x_e,   t_e = #set-1 values == x_e,   last_e = next set-0 value differs,
+// feeding the reference's tie state machine (setComparisons.c:335-359) in the reference's order --
+// the table's stable sort puts set-0 entries first inside a tie group, and tied set-0 entries are
+// interchangeable (same L, same t; `last` is positional).  No attribute slab, no second phase.
+template <int NR>
+WT_DEV double wt_mwu_regs(const WtParams &P, uint32_t *col, float *xs, int colstride) {
+    constexpr int H = NR / 2;
+    const int na = P.n_set0, nb = P.n_tracks - P.n_set0;
+    // sort set 0 as order-preserving keys (pads: 0xffffffff, they end up last)
+#pragma unroll
+    for (int s = 0; s < H; s++) col[s] = s < na ? wt_key32(__builtin_bit_cast(float, col[s])) : 0xffffffffu;
+    wt_sort_regs<H, false>(col);
+#pragma unroll
+    for (int s = 0; s < H; s++)
+        if (s < na) xs[(size_t) s * colstride] = wt_unkey32(col[s]);
+    float y[H];
+#pragma unroll
+    for (int s = 0; s < H; s++) y[s] = __builtin_bit_cast(float, col[H + s]);
+    const double mu = (double) (na * nb / 2);                               // :386 int division
+    const double sigma = sqrt((double) (na * nb * (na + nb + 1) / 12));     // :387 int division
+    double U1 = 0;
+    int ties = 0, prevTies = 0;
+    float x = xs[0];
+    for (int e = 0; e < na; e++) {
+        const float xn = e + 1 < na ? xs[(size_t) (e + 1) * colstride] : x;
+        int L = 0, t = 0;
+#pragma unroll
+        for (int s = 0; s < H; s++) { L += (y[s] < x); t += (y[s] == x); }
+        const bool last = (e + 1 == na) || !(xn == x);
+        U1 += L;                                      // :336  U1 += index - prev
+        if (ties) {                                   // :337-346
+            if (last) prevTies += t;
+            U1 -= prevTies / 2.0;
+            U1 += (ties - prevTies) / 2.0;
+            if (prevTies == ties) prevTies = ties = 0;
+        } else {                                      // :347-354
+            ties += t;
+            if (ties) U1 += ties / 2.0;
+        }
+        x = xn;
+    }
+    return (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
+}
+
+template <int OP, class ValT, class ScrT, int K, int NR>
+WT_DEV void wt_eval_finish(const WtParams &P, WtAcc<K, NR> &A, double (&res)[K], char *scratch, char *attr_base,
                            int lane_col, int colstride, unsigned emit_bits) {
     const int N = P.n_tracks;
+    if constexpr (NR > 0 && OP == WT_OP_MEDIAN) {
+        // vals[N/2] (reducers.c:810) sits at slot NR/2 of the sorted padded column (wt_gather_regs).
+        // Sort the lower half ascending and the upper half descending: the whole is bitonic, and
+        // after the first stage of its merge (slot i keeps min, slot i + NR/2 max) every upper
+        // element is >= every lower one -- slot NR/2 of the sorted column is the MINIMUM of the
+        // upper half: NR/2 max + NR/2 - 1 min instead of the full merge.
+        constexpr int H = NR / 2;
+        wt_sort_regs<H, false>(A.col);
+        wt_sort_regs<H, true>(A.col + H);
+        uint32_t m = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < H; i++) {
+            const uint32_t hi = A.col[i] > A.col[H + i] ? A.col[i] : A.col[H + i];
+            m = hi < m ? hi : m;
+        }
+        res[0] = A.nan[0] ? wt_nan() : (double) wt_unkey32(m);
+        return;
+    }
+    if constexpr (NR > 0 && OP == WT_OP_MWU) {
+        const double v = wt_mwu_regs<NR>(P, A.col, (float *) scratch + lane_col, colstride);
+        res[0] = A.nan[0] ? wt_nan() : v;
+        return;
+    }
     if (OP == WT_OP_SUM || OP == WT_OP_PRODUCT || OP == WT_OP_MEAN) {
 #pragma unroll
         for (int k = 0; k < K; k++) res[k] = (OP == WT_OP_MEAN) ? A.a[k] / N : A.a[k];
@@ -1187,10 +1351,10 @@ WT_DEV unsigned wt_lane_emit_bits(const WtParams &P, const WtCtx &c, int tid) {
     return (unsigned) ((c.E[p0 >> 6] >> (p0 & 63)) & ((1ull << K) - 1ull));
 }
 
-template <int OP, class ValT, class ScrT, int K>
+template <int OP, class ValT, class ScrT, int K, int NR>
 // `all`: the emitted bitmap is not known yet (first pass fused into the chunk sweep that builds it,
 // see the kernel): evaluate every position of every lane.
-WT_DEV void wt_phase_eval_chunk(const WtParams &P, WtCtx &c, WtAcc<K> &A, int pass, int t_lo, int t_hi, bool all,
+WT_DEV void wt_phase_eval_chunk(const WtParams &P, WtCtx &c, WtAcc<K, NR> &A, int pass, int t_lo, int t_hi, bool all,
                                 int tid, int nt) {
     const int p0 = tid * K;
     if (p0 >= P.W) return;
@@ -1205,8 +1369,8 @@ WT_DEV void wt_phase_eval_chunk(const WtParams &P, WtCtx &c, WtAcc<K> &A, int pa
     wt_eval_chunk<OP, ValT, ScrT, K>(P, c, p0, A, pass, t_lo, t_hi, c.scratch, tid, P.W, emit_bits, run0);
 }
 
-template <int OP, class ValT, class ScrT, int K>
-WT_DEV void wt_phase_eval_finish(const WtParams &P, WtCtx &c, const WtAcc<K> &A, WtLane<K> &L, int tid, int nt) {
+template <int OP, class ValT, class ScrT, int K, int NR>
+WT_DEV void wt_phase_eval_finish(const WtParams &P, WtCtx &c, WtAcc<K, NR> &A, WtLane<K> &L, int tid, int nt) {
     const unsigned emit_bits = wt_lane_emit_bits<K>(P, c, tid);
     if (!emit_bits) return;
     wt_eval_finish<OP, ValT, ScrT, K>(P, A, L.res, c.scratch, c.attr, tid, P.W, emit_bits);
@@ -1220,8 +1384,8 @@ WT_DEV void wt_phase_mwu_rank(const WtParams &P, WtCtx &c, int tid, int nt) {
     if (!((c.E[p >> 6] >> (p & 63)) & 1ull)) return;
     wt_mwu_rank<ScrT>(P, c.scratch, c.attr, p, P.W, part, nparts);
 }
-template <int K>
-WT_DEV void wt_phase_mwu_tail(const WtParams &P, WtCtx &c, const WtAcc<K> &A, WtLane<K> &L, int tid, int nt) {
+template <int K, int NR>
+WT_DEV void wt_phase_mwu_tail(const WtParams &P, WtCtx &c, const WtAcc<K, NR> &A, WtLane<K> &L, int tid, int nt) {
     if (tid >= P.W || !((c.E[tid >> 6] >> (tid & 63)) & 1ull)) return;
     L.res[0] = A.nan[0] ? wt_nan() : wt_mwu_tail(P, c.attr, tid, P.W);
 }

@@ -44,8 +44,8 @@
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-template <int OP, class ValT, class ScrT, int K, bool MULTI>
-__global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kernel(const WtParams P) {
+template <int OP, class ValT, class ScrT, int K, bool MULTI, int NR>
+__global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64 ? 3 : 4) : WT_MIN_WAVES(K)) wt_reduce_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
     wt_ctx_init(c, P, wt_lds);
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
         // tile, whose rows need the look-back offset first.
         constexpr bool FUSE = MULTI && OP != WT_OP_MULTIPLEX;
         constexpr int npass = wt_eval_passes(OP);
-        WtAcc<K> A;
+        WtAcc<K, NR> A;
         wt_eval_init<OP, K>(A);
         for (int ch = 0; ch < n_chunks; ch++) {
             const int t_lo = ch * NC, t_hi = (t_lo + NC < N) ? t_lo + NC : N;
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_reduce_kerne
             if (pass == 0 && npass == 2) wt_eval_mid<OP, K>(P, A);
         }
         wt_phase_eval_finish<OP, ValT, ScrT, K>(P, c, A, L, tid, nt);
-        if (OP == WT_OP_MWU) {      // the value columns are complete: rank with every lane, then the tie scan
+        if (OP == WT_OP_MWU && NR == 0) {      // the value columns are complete: rank with every lane, then the tie scan
             __syncthreads();
             wt_phase_mwu_rank<ScrT>(P, c, tid, nt);
             __syncthreads();
@@ -993,7 +993,8 @@ int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
     WtPlan plan;
     std::string err;
     if (wt_wants_delta(ts, op)) wt_make_delta_plan(plan, ts->n_tracks);
-    else if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
+    // (two-sample ops: the index only depends on the window width; the usual even split is assumed)
+    else if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err, 80 * 1024, 160 * 1024, ts->n_tracks / 2)) return wt_fail(WTAMD_ERR_ARG, err);
     WtWindows *w = nullptr;
     int rc = wt_get_windows(ts, plan.W, &w, (hipStream_t) stream);
     if (rc != WTAMD_OK) return rc;
@@ -1012,9 +1013,9 @@ struct WtLaunch {
     size_t *gscratch_bytes = nullptr;
     hipError_t err = hipSuccess;
 
-    template <int OP, class ValT, class ScrT, int K, bool MULTI>
+    template <int OP, class ValT, class ScrT, int K, bool MULTI, int NR = 0>
     void run() {
-        auto kern = wt_reduce_kernel<OP, ValT, ScrT, K, MULTI>;
+        auto kern = wt_reduce_kernel<OP, ValT, ScrT, K, MULTI, NR>;
         if (lds > 48 * 1024) {
             err = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;
@@ -1191,7 +1192,7 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
         }
         ts->delta_failed = true;
     }
-    if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
+    if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err, 80 * 1024, 160 * 1024, n_set0)) return wt_fail(WTAMD_ERR_ARG, err);
     return wt_reduce_plan(ts, plan, op, flags, n_set0, runs, d_tile, d_inplay, n_runs, s);
 }
 
@@ -1233,7 +1234,7 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
         WT_HIP(hipEventRecord(ts->ev_r0, s));
         if (plan.delta) {
             if (op == WT_OP_SUM) wt_launch_delta<WT_OP_SUM>(L); else wt_launch_delta<WT_OP_MEAN>(L);
-        } else if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, plan.n_chunks > 1 || plan.scratch_slab > 0, L)) {
+        } else if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, plan.n_chunks > 1 || plan.scratch_slab > 0, L, plan.regcol)) {
             return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
         }
         if (L.err != hipSuccess) return wt_fail(WTAMD_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(L.err));

@@ -28,6 +28,7 @@ struct WtPlan {
     long long scratch_slab = 0;   // > 0: scratch columns in global memory, this many bytes per workgroup
     long long attr_slab = 0;      // MWU: bytes of per-rank attributes per workgroup (always global)
     int ppt = 1;            // consecutive window positions per lane (1 or 4)
+    int regcol = 0;         // median / MWU: register slots of the per-lane value column (0: LDS / global columns)
 };
 
 static inline int wt_align16(int x) { return (x + 15) & ~15; }
@@ -37,7 +38,7 @@ static inline bool wt_op_needs_scratch(int op) { return op == WT_OP_MEDIAN || op
 // LDS bytes for a candidate (W, T)
 // n_tracks: all tracks (scratch columns); chunk: tracks whose bitmaps are resident at a time
 static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem, WtPlan &p, int chunk = 0,
-                            bool scratch_global = false) {
+                            bool scratch_global = false, int regcol = 0, int n_set0 = 0) {
     if (chunk <= 0 || chunk > n_tracks) chunk = n_tracks;
     p.chunk_tracks = chunk;
     p.n_chunks = (n_tracks + chunk - 1) / chunk;
@@ -60,12 +61,14 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
     p.off_scratch = o;
     long long scr_bytes = 0;
     if (op == WT_OP_MEDIAN || op == WT_OP_MWU) scr_bytes = (long long) n_tracks * W * scratch_elem;    // one column per position
+    if (regcol) scr_bytes = op == WT_OP_MWU ? (long long) n_set0 * W * 4 : 0;       // register columns: MWU parks the sorted set 0
     scr_bytes = (scr_bytes + 255) & ~255ll;
     p.scratch_slab = scratch_global ? scr_bytes : 0;
     // MWU: the per-rank attribute words (one u32 per set-0 track and lane, written once and read
     // once per run) always live in a global slab per workgroup: keeping them in LDS halved the lanes
     // per CU for the part that matters, the N^2 ranking over the value column
-    p.attr_slab = (op == WT_OP_MWU) ? (((long long) n_tracks * W * 4 + 255) & ~255ll) : 0;
+    p.attr_slab = (op == WT_OP_MWU && !regcol) ? (((long long) n_tracks * W * 4 + 255) & ~255ll) : 0;
+    p.regcol = regcol;
     if (!scratch_global) o = (int) std::min<long long>(o + scr_bytes, 1 << 30);
     p.off_shared = o;  o = wt_align16(o + (int) sizeof(WtShared));
     p.lds_bytes = o;
@@ -121,9 +124,33 @@ static inline bool wt_delta_eligible(int op, bool value_f64, int n_tracks, const
 // Chooses (positions per lane, T, W = ppt*T): the widest window whose bitmaps (and scratch
 // columns) fit one workgroup's LDS, 4 positions per lane when possible (instruction-level
 // parallelism, shared bitmap reads).  Environment overrides (experiments only): WTAMD_PPT, WTAMD_T.
+// Register-column slots for median / MWU (0: not applicable): float tracks with float-exact defaults
+// (scratch_f32), at most 128 tracks -- MWU: at most 64 per set.
+static inline int wt_regcol_slots(int n_tracks, int op, bool scratch_f32, int n_set0) {
+    if (!scratch_f32 || getenv("WTAMD_NO_REGCOL")) return 0;
+    if (getenv("WTAMD_CHUNK") || getenv("WTAMD_GLOBAL_SCRATCH") || getenv("WTAMD_PPT") || getenv("WTAMD_T") || getenv("WTAMD_MWU_LPP1"))
+        return 0;       // experiments / tests that force one of the column plans
+    int need = 0;
+    if (op == WT_OP_MEDIAN) need = n_tracks;
+    else if (op == WT_OP_MWU) need = 2 * std::max(n_set0, n_tracks - n_set0);
+    else return 0;
+    if (op == WT_OP_MWU && (n_set0 < 1 || n_set0 >= n_tracks)) return 0;
+    for (int nr : {32, 64, 128})
+        if (need <= nr) return nr;
+    return 0;
+}
+
 static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &out, std::string &err,
-                                int soft_limit = 80 * 1024, int hard_limit = 160 * 1024) {
+                                int soft_limit = 80 * 1024, int hard_limit = 160 * 1024, int n_set0 = 0) {
     const char *eP = getenv("WTAMD_PPT");
+    if (const int nr = wt_regcol_slots(n_tracks, op, scratch_f32, n_set0)) {
+        // one position per lane, 256 lanes: LDS holds the bitmaps only (+ MWU's sorted set 0)
+        WtPlan p;
+        wt_carve(n_tracks, op, 256, 256, 4, p, 0, false, nr, n_set0);
+        p.ppt = 1;
+        p.lanes_per_pos = 1;
+        if (p.n_chunks == 1 && p.lds_bytes <= hard_limit / 2 - 512) { out = p; return true; }
+    }
     const char *eT = getenv("WTAMD_T");
     const bool scr = wt_op_needs_scratch(op);
     const int scratch_elem = scr ? (scratch_f32 ? 4 : 8) : 0;
@@ -300,7 +327,19 @@ static inline void wt_dispatch_types(bool value_f64, bool scratch_f32, int ppt, 
 }
 
 template <class F>
-static inline bool wt_dispatch(int op, bool value_f64, bool scratch_f32, int ppt, bool multi, F &f) {
+static inline bool wt_dispatch(int op, bool value_f64, bool scratch_f32, int ppt, bool multi, F &f, int regcol = 0) {
+    if (regcol && (op == WT_OP_MEDIAN || op == WT_OP_MWU) && !value_f64 && scratch_f32 && !multi) {
+        if (op == WT_OP_MEDIAN) {
+            if (regcol == 32) f.template run<WT_OP_MEDIAN, float, float, 1, false, 32>();
+            else if (regcol == 64) f.template run<WT_OP_MEDIAN, float, float, 1, false, 64>();
+            else f.template run<WT_OP_MEDIAN, float, float, 1, false, 128>();
+        } else {
+            if (regcol == 32) f.template run<WT_OP_MWU, float, float, 1, false, 32>();
+            else if (regcol == 64) f.template run<WT_OP_MWU, float, float, 1, false, 64>();
+            else f.template run<WT_OP_MWU, float, float, 1, false, 128>();
+        }
+        return true;
+    }
     switch (op) {
     case WT_OP_SUM: wt_dispatch_types<WT_OP_SUM>(value_f64, scratch_f32, ppt, multi, f); return true;
     case WT_OP_PRODUCT: wt_dispatch_types<WT_OP_PRODUCT>(value_f64, scratch_f32, ppt, multi, f); return true;
