@@ -430,9 +430,9 @@ def test_plan_policy_snapshot():
     p = plan(500, "var")
     assert (p["W"], p["T"]) == (2048, 512) and p["n_chunks"] == 5        # chunks of <= 112 tracks
     p = plan(100, "median")
-    assert (p["W"], p["T"], p["lds"] < 24 * 1024) == (256, 256, True) and p["scratch_slab"] == 0     # round 2: value column in REGISTERS, LDS = bitmaps only
+    assert (p["W"], p["T"], p["lds"] < 48 * 1024) == (1024, 256, True) and p["scratch_slab"] == 0    # round 2: value column in REGISTERS, LDS = bitmaps only, 4 positions per lane
     p = plan(100, "mwu", n_set0=50)
-    assert (p["W"], p["T"]) == (256, 256) and p["lds"] < 80 * 1024       # register columns + the sorted set 0 (50 x 4 B per lane) in LDS
+    assert (p["W"], p["T"]) == (512, 256) and p["lds"] < 80 * 1024       # register columns + the sorted set 0 (50 x 4 B per lane) in LDS, 2 positions per lane
     p = plan(100, "mwu", n_set0=90)
     assert (p["W"], p["T"]) == (256, 512)                                # a set above 64 tracks: LDS columns, two lanes per run (round 1 plan)
     p = plan(200, "median")
@@ -440,7 +440,7 @@ def test_plan_policy_snapshot():
     p = plan(100, "median", dtype=np.float64)
     assert p["lds"] > 100 * 1024                                         # f64 values: one f64 column per lane in LDS
     p = plan(20, "mwu", n_set0=10)
-    assert (p["W"], p["T"]) == (256, 256)
+    assert (p["W"], p["T"]) == (512, 256)
     p = plan(100, "mean", dtype=np.float64)
     assert p["delta"] == 0 and p["W"] == 2048                            # f64 tracks: general kernel
     p = plan(1000, "median")

@@ -765,7 +765,10 @@ struct WtAcc {
     double a[K], b[K];        // sum|product|best|mean|s1 , squares|q1
     double c2[K], d[K];       // t-test: s2, q2
     bool nan[K];
-    uint32_t col[NR > 0 ? NR : 1];
+    // two half columns (median: lower / upper half of the padded column; MWU: set 0 / set 1).  Two
+    // arrays on purpose: as ONE 128-entry array the compiler kept the upper half in scratch memory
+    // and ran its sorting network through load / exchange / store round trips.
+    uint32_t col[NR > 0 ? NR / 2 : 1], col2[NR > 0 ? NR / 2 : 1];
 };
 
 WT_DEV constexpr int wt_eval_passes(int op) {
@@ -813,21 +816,27 @@ WT_DEV void wt_sort_regs(uint32_t *v) {
 // slots -- a fully unrolled gather made the compiler hoist every track's scalar state (buffer
 // descriptor, default, first-interval index) and spill hundreds of SGPRs and VGPRs -- and every
 // block is moved to its registers through a switch on the (uniform) block number.
+#ifndef WT_REGCOL_BLOCK
 #define WT_REGCOL_BLOCK 8
-template <int NR, int B0 = 0>
-WT_DEV void wt_regcol_store(uint32_t *col, int blk, const uint32_t (&tmp)[WT_REGCOL_BLOCK]) {
-    if constexpr (B0 < NR / WT_REGCOL_BLOCK) {
+#endif
+template <int NR>
+WT_DEV void wt_regcol_store(uint32_t *col, uint32_t *col2, int blk, const uint32_t (&tmp)[WT_REGCOL_BLOCK]) {
+    // independent uniform tests (no else-chain, no switch): every store keeps a constant index
+    wt_static_for<0, NR / WT_REGCOL_BLOCK>([&](auto bc) {
+        constexpr int B0 = decltype(bc)::value;
         if (blk == B0) {
 #pragma unroll
-            for (int q = 0; q < WT_REGCOL_BLOCK; q++) col[B0 * WT_REGCOL_BLOCK + q] = tmp[q];
-        } else {
-            wt_regcol_store<NR, B0 + 1>(col, blk, tmp);
+            for (int q = 0; q < WT_REGCOL_BLOCK; q++) {
+                constexpr int H = NR / 2;
+                if (B0 * WT_REGCOL_BLOCK < H) col[B0 * WT_REGCOL_BLOCK + q] = tmp[q];
+                else col2[B0 * WT_REGCOL_BLOCK + q - H] = tmp[q];
+            }
         }
-    }
+    });
 }
 
 template <int OP, class ValT, int NR>
-WT_DEV bool wt_gather_regs(const WtParams &P, const WtCtx &c, int p0, uint32_t *col) {
+WT_DEV bool wt_gather_regs(const WtParams &P, const WtCtx &c, int p0, uint32_t *col, uint32_t *col2) {
     const int w32 = p0 >> 5, b0 = p0 & 31;
     const uint32_t mask[1] = { (2u << b0) - 1u };
     const int N = P.n_tracks, na = P.n_set0;
@@ -863,9 +872,56 @@ WT_DEV bool wt_gather_regs(const WtParams &P, const WtCtx &c, int p0, uint32_t *
             }
             tmp[q] = v;
         }
-        wt_regcol_store<NR>(col, blk, tmp);
+        wt_regcol_store<NR>(col, col2, blk, tmp);
     }
     return nan;
+}
+
+// MWU over a register column (wt_gather_regs): set 0 sorted by a register network and parked in
+// this lane's LDS column (n_set0 * 4 B -- the only LDS the reducer needs); then ONE pass over the
+// sorted set-0 values e, each compared with the set-1 registers (compile-time indices):
+//   L_e = #set-1 values < x_e,   t_e = #set-1 values == x_e,   last_e = next set-0 value differs,
+// feeding the reference's tie state machine (setComparisons.c:335-359) in the reference's order --
+// the table's stable sort puts set-0 entries first inside a tie group, and tied set-0 entries are
+// interchangeable (same L, same t; `last` is positional).  No attribute slab, no second phase.
+template <int NR>
+WT_DEV double wt_mwu_regs(const WtParams &P, uint32_t *col, const uint32_t *col2, float *xs, int colstride) {
+    constexpr int H = NR / 2;
+    const int na = P.n_set0, nb = P.n_tracks - P.n_set0;
+    // sort set 0 as order-preserving keys (pads: 0xffffffff, they end up last)
+#pragma unroll
+    for (int s = 0; s < H; s++) col[s] = s < na ? wt_key32(__builtin_bit_cast(float, col[s])) : 0xffffffffu;
+    wt_sort_regs<H, false>(col);
+#pragma unroll
+    for (int s = 0; s < H; s++)
+        if (s < na) xs[(size_t) s * colstride] = wt_unkey32(col[s]);
+    float y[H];
+#pragma unroll
+    for (int s = 0; s < H; s++) y[s] = __builtin_bit_cast(float, col2[s]);
+    const double mu = (double) (na * nb / 2);                               // :386 int division
+    const double sigma = sqrt((double) (na * nb * (na + nb + 1) / 12));     // :387 int division
+    double U1 = 0;
+    int ties = 0, prevTies = 0;
+    float x = xs[0];
+    for (int e = 0; e < na; e++) {
+        const float xn = e + 1 < na ? xs[(size_t) (e + 1) * colstride] : x;
+        int L = 0, t = 0;
+#pragma unroll
+        for (int s = 0; s < H; s++) { L += (y[s] < x); t += (y[s] == x); }
+        const bool last = (e + 1 == na) || !(xn == x);
+        U1 += L;                                      // :336  U1 += index - prev
+        if (ties) {                                   // :337-346
+            if (last) prevTies += t;
+            U1 -= prevTies / 2.0;
+            U1 += (ties - prevTies) / 2.0;
+            if (prevTies == ties) prevTies = ties = 0;
+        } else {                                      // :347-354
+            ties += t;
+            if (ties) U1 += ties / 2.0;
+        }
+        x = xn;
+    }
+    return (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
 }
 
 template <int OP, class ValT, class ScrT, int K, int NR>
@@ -876,7 +932,36 @@ WT_DEV void wt_eval_chunk(const WtParams &P, const WtCtx &c, int p0, WtAcc<K, NR
 #pragma unroll
     for (int k = 0; k < K; k++) mask[k] = (2u << (b0 + k)) - 1u;
     if constexpr (NR > 0 && (OP == WT_OP_MEDIAN || OP == WT_OP_MWU)) {
-        A.nan[0] = wt_gather_regs<OP, ValT, NR>(P, c, p0, A.col);
+        // Register columns: the lane's K positions one after the other (the column is reused), each
+        // evaluated to the end -- gather, exchange network, result.  K = 4 positions per lane keep
+        // the window at 1024 bp for 256 lanes: the per-window costs (bitmaps, scans, look-back) are
+        // shared by four times the positions a one-position-per-lane window would hold.
+#pragma unroll 1
+        for (int k = 0; k < K; k++) {
+            if (!((emit_bits >> k) & 1u)) continue;
+            const bool nan = wt_gather_regs<OP, ValT, NR>(P, c, p0 + k, A.col, A.col2);
+            double v;
+            if constexpr (OP == WT_OP_MEDIAN) {
+                // vals[N/2] (reducers.c:810) sits at slot NR/2 of the sorted padded column.  Lower half
+                // ascending, upper half descending: the whole is bitonic, and after the first stage of
+                // its merge (slot i keeps min, slot i + NR/2 max) every upper element is >= every lower
+                // one -- slot NR/2 of the sorted column is the MINIMUM of the upper half: NR/2 max +
+                // NR/2 - 1 min instead of the full merge.
+                constexpr int H = NR / 2;
+                wt_sort_regs<H, false>(A.col);
+                wt_sort_regs<H, true>(A.col2);
+                uint32_t m = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < H; i++) {
+                    const uint32_t hi = A.col[i] > A.col2[i] ? A.col[i] : A.col2[i];
+                    m = hi < m ? hi : m;
+                }
+                v = (double) wt_unkey32(m);
+            } else {
+                v = wt_mwu_regs<NR>(P, A.col, A.col2, (float *) scratch + lane_col, P.W / K);
+            }
+            A.a[k] = nan ? wt_nan() : v;
+        }
         return;
     }
 
@@ -1106,78 +1191,13 @@ WT_DEV double wt_mwu_tail(const WtParams &P, char *attr_base, int col, int colst
     return (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
 }
 
-// MWU over a register column (wt_gather_regs): set 0 sorted by a register network and parked in
-// this lane's LDS column (n_set0 * 4 B -- the only LDS the reducer needs); then ONE pass over the
-// sorted set-0 values e, each compared with the set-1 registers (compile-time indices):
-//   L_e = #set-1 values < x_e,   t_e = #set-1 values == x_e,   last_e = next set-0 value differs,
-// feeding the reference's tie state machine (setComparisons.c:335-359) in the reference's order --
-// the table's stable sort puts set-0 entries first inside a tie group, and tied set-0 entries are
-// interchangeable (same L, same t; `last` is positional).  No attribute slab, no second phase.
-template <int NR>
-WT_DEV double wt_mwu_regs(const WtParams &P, uint32_t *col, float *xs, int colstride) {
-    constexpr int H = NR / 2;
-    const int na = P.n_set0, nb = P.n_tracks - P.n_set0;
-    // sort set 0 as order-preserving keys (pads: 0xffffffff, they end up last)
-#pragma unroll
-    for (int s = 0; s < H; s++) col[s] = s < na ? wt_key32(__builtin_bit_cast(float, col[s])) : 0xffffffffu;
-    wt_sort_regs<H, false>(col);
-#pragma unroll
-    for (int s = 0; s < H; s++)
-        if (s < na) xs[(size_t) s * colstride] = wt_unkey32(col[s]);
-    float y[H];
-#pragma unroll
-    for (int s = 0; s < H; s++) y[s] = __builtin_bit_cast(float, col[H + s]);
-    const double mu = (double) (na * nb / 2);                               // :386 int division
-    const double sigma = sqrt((double) (na * nb * (na + nb + 1) / 12));     // :387 int division
-    double U1 = 0;
-    int ties = 0, prevTies = 0;
-    float x = xs[0];
-    for (int e = 0; e < na; e++) {
-        const float xn = e + 1 < na ? xs[(size_t) (e + 1) * colstride] : x;
-        int L = 0, t = 0;
-#pragma unroll
-        for (int s = 0; s < H; s++) { L += (y[s] < x); t += (y[s] == x); }
-        const bool last = (e + 1 == na) || !(xn == x);
-        U1 += L;                                      // :336  U1 += index - prev
-        if (ties) {                                   // :337-346
-            if (last) prevTies += t;
-            U1 -= prevTies / 2.0;
-            U1 += (ties - prevTies) / 2.0;
-            if (prevTies == ties) prevTies = ties = 0;
-        } else {                                      // :347-354
-            ties += t;
-            if (ties) U1 += ties / 2.0;
-        }
-        x = xn;
-    }
-    return (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
-}
-
 template <int OP, class ValT, class ScrT, int K, int NR>
 WT_DEV void wt_eval_finish(const WtParams &P, WtAcc<K, NR> &A, double (&res)[K], char *scratch, char *attr_base,
                            int lane_col, int colstride, unsigned emit_bits) {
     const int N = P.n_tracks;
-    if constexpr (NR > 0 && OP == WT_OP_MEDIAN) {
-        // vals[N/2] (reducers.c:810) sits at slot NR/2 of the sorted padded column (wt_gather_regs).
-        // Sort the lower half ascending and the upper half descending: the whole is bitonic, and
-        // after the first stage of its merge (slot i keeps min, slot i + NR/2 max) every upper
-        // element is >= every lower one -- slot NR/2 of the sorted column is the MINIMUM of the
-        // upper half: NR/2 max + NR/2 - 1 min instead of the full merge.
-        constexpr int H = NR / 2;
-        wt_sort_regs<H, false>(A.col);
-        wt_sort_regs<H, true>(A.col + H);
-        uint32_t m = 0xffffffffu;
+    if constexpr (NR > 0 && (OP == WT_OP_MEDIAN || OP == WT_OP_MWU)) {      // evaluated to the end by wt_eval_chunk
 #pragma unroll
-        for (int i = 0; i < H; i++) {
-            const uint32_t hi = A.col[i] > A.col[H + i] ? A.col[i] : A.col[H + i];
-            m = hi < m ? hi : m;
-        }
-        res[0] = A.nan[0] ? wt_nan() : (double) wt_unkey32(m);
-        return;
-    }
-    if constexpr (NR > 0 && OP == WT_OP_MWU) {
-        const double v = wt_mwu_regs<NR>(P, A.col, (float *) scratch + lane_col, colstride);
-        res[0] = A.nan[0] ? wt_nan() : v;
+        for (int k = 0; k < K; k++) res[k] = A.a[k];
         return;
     }
     if (OP == WT_OP_SUM || OP == WT_OP_PRODUCT || OP == WT_OP_MEAN) {

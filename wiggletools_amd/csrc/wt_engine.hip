@@ -45,7 +45,10 @@
 // kernels
 // ---------------------------------------------------------------------------
 template <int OP, class ValT, class ScrT, int K, bool MULTI, int NR>
-__global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64 ? 3 : 4) : WT_MIN_WAVES(K)) wt_reduce_kernel(const WtParams P) {
+// (register columns, NR > 0: 256 lanes; the column + the exchange network's temporaries need more
+//  than the 168 VGPRs three waves per SIMD leave -- with that bound the compiler spilled 250
+//  registers into the middle of the network -- so NR = 128 runs two waves per SIMD, NR = 64 three)
+__global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64 ? 2 : (NR > 32 ? 3 : 4)) : WT_MIN_WAVES(K)) wt_reduce_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
     wt_ctx_init(c, P, wt_lds);

@@ -61,7 +61,7 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
     p.off_scratch = o;
     long long scr_bytes = 0;
     if (op == WT_OP_MEDIAN || op == WT_OP_MWU) scr_bytes = (long long) n_tracks * W * scratch_elem;    // one column per position
-    if (regcol) scr_bytes = op == WT_OP_MWU ? (long long) n_set0 * W * 4 : 0;       // register columns: MWU parks the sorted set 0
+    if (regcol) scr_bytes = op == WT_OP_MWU ? (long long) n_set0 * T * 4 : 0;       // register columns: MWU parks the sorted set 0, one column per LANE
     scr_bytes = (scr_bytes + 255) & ~255ll;
     p.scratch_slab = scratch_global ? scr_bytes : 0;
     // MWU: the per-rank attribute words (one u32 per set-0 track and lane, written once and read
@@ -144,10 +144,13 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
                                 int soft_limit = 80 * 1024, int hard_limit = 160 * 1024, int n_set0 = 0) {
     const char *eP = getenv("WTAMD_PPT");
     if (const int nr = wt_regcol_slots(n_tracks, op, scratch_f32, n_set0)) {
-        // one position per lane, 256 lanes: LDS holds the bitmaps only (+ MWU's sorted set 0)
+        // 256 lanes, several positions per lane evaluated one after the other: LDS holds the bitmaps
+        // only (+ MWU's sorted set 0, one column per lane).  Median: 4 positions (window 1024 bp); MWU: 2
+        // (512 bp) -- its set-0 column leaves less room for bitmaps if two workgroups are to share a CU.
         WtPlan p;
-        wt_carve(n_tracks, op, 256, 256, 4, p, 0, false, nr, n_set0);
-        p.ppt = 1;
+        const int kk = op == WT_OP_MEDIAN ? 4 : 2;
+        wt_carve(n_tracks, op, 256 * kk, 256, 4, p, 0, false, nr, n_set0);
+        p.ppt = kk;
         p.lanes_per_pos = 1;
         if (p.n_chunks == 1 && p.lds_bytes <= hard_limit / 2 - 512) { out = p; return true; }
     }
@@ -330,13 +333,13 @@ template <class F>
 static inline bool wt_dispatch(int op, bool value_f64, bool scratch_f32, int ppt, bool multi, F &f, int regcol = 0) {
     if (regcol && (op == WT_OP_MEDIAN || op == WT_OP_MWU) && !value_f64 && scratch_f32 && !multi) {
         if (op == WT_OP_MEDIAN) {
-            if (regcol == 32) f.template run<WT_OP_MEDIAN, float, float, 1, false, 32>();
-            else if (regcol == 64) f.template run<WT_OP_MEDIAN, float, float, 1, false, 64>();
-            else f.template run<WT_OP_MEDIAN, float, float, 1, false, 128>();
+            if (regcol == 32) f.template run<WT_OP_MEDIAN, float, float, 4, false, 32>();
+            else if (regcol == 64) f.template run<WT_OP_MEDIAN, float, float, 4, false, 64>();
+            else f.template run<WT_OP_MEDIAN, float, float, 4, false, 128>();
         } else {
-            if (regcol == 32) f.template run<WT_OP_MWU, float, float, 1, false, 32>();
-            else if (regcol == 64) f.template run<WT_OP_MWU, float, float, 1, false, 64>();
-            else f.template run<WT_OP_MWU, float, float, 1, false, 128>();
+            if (regcol == 32) f.template run<WT_OP_MWU, float, float, 2, false, 32>();
+            else if (regcol == 64) f.template run<WT_OP_MWU, float, float, 2, false, 64>();
+            else f.template run<WT_OP_MWU, float, float, 2, false, 128>();
         }
         return true;
     }
