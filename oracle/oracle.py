@@ -38,6 +38,17 @@ def build(force=False):
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
 
 
+def build_mixed():
+    """The mixed-link libraries (reference translation units + a drop-in library); see oracle/Makefile."""
+    if os.path.isdir("/root/reference/src"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "mixed"])
+
+
+def mixed_path(variant):
+    p = os.path.join(_HERE, "_ref", "libwiggletools_mixed_%s.so" % variant)
+    return p if os.path.exists(p) else None
+
+
 _oracle = None
 _ref = None
 
@@ -113,6 +124,14 @@ class Harness:
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_reducer_default.restype = C.c_double
         L.ref_reducer_default.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.ref_write_reduce.restype = C.c_int64
+        L.ref_write_reduce.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_char_p, C.c_int]
+        L.ref_mwrite.restype = C.c_int64
+        L.ref_mwrite.argtypes = [C.POINTER(_Tracks), C.c_uint, C.c_char_p, C.c_int]
+        L.ref_pearson.restype = C.c_double
+        L.ref_pearson.argtypes = [C.POINTER(_Tracks)]
+        L.ref_auc_of_reduce.restype = C.c_double
+        L.ref_auc_of_reduce.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint]
         L.ref_set_modes.argtypes = [C.c_int, C.c_int]
         L.ref_set_modes.restype = None
         L.ref_reduce_seek_held.restype = C.c_int64
@@ -122,6 +141,29 @@ class Harness:
         L.ref_multiset_seek_held.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_int64,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         self.L = L
+
+    def write_reduce(self, t, op, path, bedgraph=False, flags=0):
+        """The library's TeeWiggleIterator (`write` / `write_bg`) over its reducer `op`; returns the text."""
+        s, keep = _pack(t)
+        n = self.L.ref_write_reduce(C.byref(s), _opcode(op), flags, str(path).encode(), int(bedgraph))
+        if n < 0:
+            raise RuntimeError("ref_write_reduce returned %d" % n)
+        return open(path).read()
+
+    def mwrite(self, t, path, bedgraph=False, flags=0):
+        s, keep = _pack(t)
+        n = self.L.ref_mwrite(C.byref(s), flags, str(path).encode(), int(bedgraph))
+        if n < 0:
+            raise RuntimeError("ref_mwrite returned %d" % n)
+        return open(path).read()
+
+    def pearson(self, t):
+        s, keep = _pack(t)
+        return self.L.ref_pearson(C.byref(s))
+
+    def auc_of_reduce(self, t, op, flags=0):
+        s, keep = _pack(t)
+        return self.L.ref_auc_of_reduce(C.byref(s), _opcode(op), flags)
 
     def set_modes(self, child_mode=0, block_mode=0):
         """child_mode 1: children are the tested library's own bulk-capable wtamd_ArrayReader (float32

@@ -47,6 +47,8 @@ static Multiset *(*r_newMultiset)(Multiplexer **, int);
 static void (*r_popMultiplexer)(Multiplexer *);
 static void (*r_popMultiset)(Multiset *);
 static void (*r_seekMultiset)(Multiset *, const char *, int, int);
+static WiggleIterator *(*r_TeeWiggleIterator)(WiggleIterator *, FILE *, wt_bool, wt_bool);
+static Multiplexer *(*r_TeeMultiplexer)(Multiplexer *, FILE *, wt_bool, wt_bool);
 static WiggleIterator *(*r_ArrayReader)(int, const char *const *, const int64_t *, const int32_t *, const int32_t *,
                                         const float *, double);
 static int64_t (*r_next_block)(WiggleIterator *, const char **, const int32_t **, const int32_t **, const double **);
@@ -92,6 +94,8 @@ int ref_open(const char *path) {
      * drop-in library lacks readers / integrators it does not replace */
 #define OPT(var, name) *(void **) (&var) = dlsym(g_lib, name)
     OPT(r_seekMultiset, "seekMultiset");
+    OPT(r_TeeWiggleIterator, "TeeWiggleIterator");
+    OPT(r_TeeMultiplexer, "TeeMultiplexer");
     OPT(r_ArrayReader, "wtamd_ArrayReader");
     OPT(r_next_block, "wtamd_iterator_next_block");
     OPT(r_SmartReader, "SmartReader");
@@ -213,6 +217,36 @@ static Multiplexer *make_multiplexer(const wto_tracks *t, char **names, int lo, 
     Multiplexer *m = r_newMultiplexer(iters, n, (wt_bool) (strict != 0));
     free(iters);   /* newMultiplexer copies the array (multiplexer.c:160-166) */
     return m;
+}
+
+/* The reference's writers over the tested library's reducer / Multiplexer: `write` / `write_bg`
+ * (TeeWiggleIterator, wigWriter.c:261-276: CompressionWiggleIterator in front unless bedGraph, a
+ * writer thread printing 10 000-entry blocks) and `mwrite` / `mwrite_bg` (TeeMultiplexer,
+ * mWigWriter.c:286-327, which reads struct multiplexer_st fields directly, :182-197).  Returns the
+ * number of pops, < 0 when the library lacks the writers. */
+int64_t ref_write_reduce(const wto_tracks *t, int op, unsigned flags, const char *path, int bedgraph) {
+    if (!g_lib || op < 0 || op > 9 || !r_TeeWiggleIterator) return -2;
+    FILE *f = fopen(path, "w");
+    if (!f) return -3;
+    char **names = make_names(t->n_chrom);
+    Multiplexer *m = make_multiplexer(t, names, 0, t->n_tracks, flags & 1u);
+    WiggleIterator *w = r_TeeWiggleIterator(r_reduction[op](m), f, (wt_bool) bedgraph, 0);
+    int64_t n = 0;
+    while (!w->done) { n++; r_pop(w); }
+    fclose(f);
+    return n;
+}
+
+int64_t ref_mwrite(const wto_tracks *t, unsigned flags, const char *path, int bedgraph) {
+    if (!g_lib || !r_TeeMultiplexer) return -2;
+    FILE *f = fopen(path, "w");
+    if (!f) return -3;
+    char **names = make_names(t->n_chrom);
+    Multiplexer *m = r_TeeMultiplexer(make_multiplexer(t, names, 0, t->n_tracks, flags & 1u), f, (wt_bool) bedgraph, 0);
+    int64_t n = 0;
+    while (!m->done) { n++; r_popMultiplexer(m); }
+    fclose(f);
+    return n;
 }
 
 /* Consumer bulk door: a few plain pops first (the two protocols mix), then whole blocks. */

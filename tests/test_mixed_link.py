@@ -1,0 +1,87 @@
+"""Mixed link at the drop-in boundary: the reference's OWN translation units that
+read `struct multiplexer_st` fields or consume reducers -- statistics.c (PearsonIntegrator :414-465,
+AUCIntegrator :103-127), mWigWriter.c (TeeMultiplexer, which reads chrom / start / finish /
+values[] / inplay[] / default_values / count / done directly, :182-197), wigWriter.c
+(TeeWiggleIterator with CompressionWiggleIterator in front, :261-276) -- compiled unmodified
+WITHOUT multiplexer.c / multiSet.c / reducers.c and linked against the drop-in library
+(oracle/Makefile target `mixed`), running on top of the drop-in Multiplexer / reducers in one
+process.  Everything is compared with the all-reference build: text output byte for byte.
+
+"emu": drop-in layer over the emulated pipeline (CPU); "amd" (-m gpu): the product library.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import random_case
+
+
+_cache = {}
+
+
+@pytest.fixture(params=["emu", pytest.param("amd", marks=pytest.mark.gpu)])
+def M(request, oracle):
+    if not oracle.have_ref():
+        pytest.skip("compiled reference not available")
+    if request.param not in _cache:
+        if request.param == "emu":
+            from emu import build as emu_build
+            emu_build.build_dropin()
+        if "built" not in _cache:
+            oracle.build_mixed()
+            _cache["built"] = True
+        p = oracle.mixed_path(request.param)
+        if p is not None and request.param == "amd":
+            import torch
+            assert torch.cuda.is_available()
+        _cache[request.param] = oracle.Harness(p, "mixed_" + request.param) if p is not None else None
+    if _cache[request.param] is None:
+        pytest.skip("mixed-link library not built")
+    return _cache[request.param]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_reference_writers_over_dropin_reducers(oracle, M, tmp_path, seed):
+    """`write` (compressed, fixedStep / bedGraph mix, wigWriter.c:55-119) and `write_bg` of the
+    drop-in reducers through the reference's TeeWiggleIterator == the all-reference build."""
+    R = oracle.ref_harness()
+    t = random_case(9600 + seed, max_len=4000, dtype=np.float32)
+    d = t.as_dict()
+    for op in ("mean", "sum", "max", "median"):
+        for bg in (False, True):
+            a = M.write_reduce(d, op, tmp_path / "a.txt", bedgraph=bg)
+            b = R.write_reduce(d, op, tmp_path / "b.txt", bedgraph=bg)
+            assert a == b, (op, bg)
+            assert len(b) > 0 or t.n_intervals == 0
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_reference_mwrite_over_dropin_multiplexer(oracle, M, tmp_path, seed):
+    """TeeMultiplexer reads the drop-in Multiplexer's fields per pop (mWigWriter.c:182-197)."""
+    R = oracle.ref_harness()
+    t = random_case(9700 + seed, n_tracks=4, max_len=3000)
+    d = t.as_dict()
+    for strict in (0, 1):
+        for bg in (False, True):
+            a = M.mwrite(d, tmp_path / "a.txt", bedgraph=bg, flags=strict)
+            b = R.mwrite(d, tmp_path / "b.txt", bedgraph=bg, flags=strict)
+            assert a == b, (strict, bg)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_reference_integrators_over_dropin(oracle, M, seed):
+    """The reference's PearsonIntegrator walks the drop-in Multiplexer (inplay[], values[],
+    iters[i]->default_value, start, finish: statistics.c:432-442,464); its AUCIntegrator consumes the
+    drop-in reducer.  Same arithmetic on the same per-run values: bit-identical results."""
+    R = oracle.ref_harness()
+    from wiggletools_amd.runlists import synth
+    t = synth(2, [5000, 800], mean_run=6, gap_prob=0.1, seed=40 + seed)
+    if seed % 2:
+        t.defaults[:] = [0.5, -1.0]
+    d = t.as_dict()
+    assert M.pearson(d) == R.pearson(d)
+    t = random_case(9800 + seed, max_len=3000)
+    d = t.as_dict()
+    for op in ("mean", "max"):
+        assert M.auc_of_reduce(d, op) == R.auc_of_reduce(d, op), op
