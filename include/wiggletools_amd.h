@@ -435,6 +435,13 @@ int wtamd_pipe_cancel(wtamd_pipe *);
 int wtamd_pipe_collect(wtamd_pipe *, wtamd_pipe_result *out);
 /* Returns the oldest collected batch's slot to the pipe. */
 int wtamd_pipe_release(wtamd_pipe *);
+/* Turns the device-side run compression on / off for the batches submitted from now on: the
+ * reference's CompressionWiggleIterator rule (unaryOps.c:235-253) inside every batch, from the batch's
+ * first run that leads a group whatever came before it (the runs ahead of it may belong to the
+ * previous batch's last group -- only a consumer that knows that group's leader can tell -- and are
+ * passed through one by one).  Applying the reference's own wrapper to this output, as the default
+ * writer always does (wigWriter.c:263-267), yields exactly what it yields on the uncompressed runs. */
+int wtamd_pipe_set_compress(wtamd_pipe *, int on);
 /* Submitted batches not yet collected. */
 int wtamd_pipe_in_flight(const wtamd_pipe *);
 int wtamd_pipe_get_stats(const wtamd_pipe *, wtamd_pipe_stats *out);
@@ -462,6 +469,12 @@ WiggleIterator *wtamd_ArrayReader(int n_chrom, const char *const *chrom_names, c
  * number of runs (0 and wi->done at the end).  Mixes freely with pop(). */
 int64_t wtamd_iterator_next_block(WiggleIterator *wi, const char **chrom, const int32_t **start,
                                   const int32_t **finish, const double **value);
+/* Writer hand-off: asks a reducer of this library to merge its runs on the device before they
+ * cross PCIe (wtamd_pipe_set_compress on its pipeline; batches already in flight are unaffected).
+ * Meant for the iterator the default writer wraps in CompressionWiggleIterator anyway
+ * (TeeWiggleIterator, wigWriter.c:261-267): the text written is byte-identical, the pops and the
+ * D2H traffic shrink by the compression ratio.  Returns WTAMD_ERR_ARG for any other iterator. */
+int wtamd_iterator_compress_output(WiggleIterator *wi, int on);
 /* Counters of the pipeline behind a reducer of this library (bytes over PCIe, summed kernel / copy
  * durations from HIP events).  Returns WTAMD_ERR_ARG for any other iterator. */
 int wtamd_iterator_pipe_stats(WiggleIterator *wi, wtamd_pipe_stats *out);

@@ -132,6 +132,8 @@ class Harness:
         L.ref_pearson.argtypes = [C.POINTER(_Tracks)]
         L.ref_auc_of_reduce.restype = C.c_double
         L.ref_auc_of_reduce.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint]
+        L.ref_set_compress_mode.argtypes = [C.c_int]
+        L.ref_set_compress_mode.restype = None
         L.ref_set_modes.argtypes = [C.c_int, C.c_int]
         L.ref_set_modes.restype = None
         L.ref_reduce_seek_held.restype = C.c_int64
@@ -164,6 +166,10 @@ class Harness:
     def auc_of_reduce(self, t, op, flags=0):
         s, keep = _pack(t)
         return self.L.ref_auc_of_reduce(C.byref(s), _opcode(op), flags)
+
+    def set_compress_mode(self, on):
+        """write_reduce asks the reducer to merge its runs on the device (wtamd_iterator_compress_output)."""
+        self.L.ref_set_compress_mode(int(on))
 
     def set_modes(self, child_mode=0, block_mode=0):
         """child_mode 1: children are the tested library's own bulk-capable wtamd_ArrayReader (float32

@@ -52,6 +52,9 @@ static Multiplexer *(*r_TeeMultiplexer)(Multiplexer *, FILE *, wt_bool, wt_bool)
 static WiggleIterator *(*r_ArrayReader)(int, const char *const *, const int64_t *, const int32_t *, const int32_t *,
                                         const float *, double);
 static int64_t (*r_next_block)(WiggleIterator *, const char **, const int32_t **, const int32_t **, const double **);
+static int (*r_compress_output)(WiggleIterator *, int);
+static int g_compress_mode;    /* 1: reducers handed to the writers are asked to merge their runs on the device first */
+void ref_set_compress_mode(int on) { g_compress_mode = on; }
 static void (*r_pop)(WiggleIterator *);
 static void (*r_seek)(WiggleIterator *, const char *, int, int);
 static WiggleIterator *(*r_SmartReader)(char *, wt_bool);
@@ -98,6 +101,7 @@ int ref_open(const char *path) {
     OPT(r_TeeMultiplexer, "TeeMultiplexer");
     OPT(r_ArrayReader, "wtamd_ArrayReader");
     OPT(r_next_block, "wtamd_iterator_next_block");
+    OPT(r_compress_output, "wtamd_iterator_compress_output");
     OPT(r_SmartReader, "SmartReader");
     OPT(r_AUCIntegrator, "AUCIntegrator");
     OPT(r_PearsonIntegrator, "PearsonIntegrator");
@@ -230,7 +234,9 @@ int64_t ref_write_reduce(const wto_tracks *t, int op, unsigned flags, const char
     if (!f) return -3;
     char **names = make_names(t->n_chrom);
     Multiplexer *m = make_multiplexer(t, names, 0, t->n_tracks, flags & 1u);
-    WiggleIterator *w = r_TeeWiggleIterator(r_reduction[op](m), f, (wt_bool) bedgraph, 0);
+    WiggleIterator *red = r_reduction[op](m);
+    if (g_compress_mode && r_compress_output && !bedgraph && r_compress_output(red, 1) != 0) return -7;
+    WiggleIterator *w = r_TeeWiggleIterator(red, f, (wt_bool) bedgraph, 0);
     int64_t n = 0;
     while (!w->done) { n++; r_pop(w); }
     fclose(f);

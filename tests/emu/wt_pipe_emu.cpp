@@ -53,6 +53,7 @@ struct wtamd_pipe {
     int acquired = -1;
     int in_flight = 0;  // submitted, not collected
     int held = 0;       // collected, not released
+    bool compress = false;
     wtamd_pipe_stats st{};
 };
 
@@ -79,7 +80,14 @@ int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
         s.start.resize((size_t) cap); s.finish.resize((size_t) cap); s.v32.resize((size_t) cap);
     }
     p->st.n_slots = ns;
+    p->compress = (cfg->flags & WTAMD_PIPE_COMPRESS) != 0;
     *out = p;
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_set_compress(wtamd_pipe *p, int on) {
+    if (!p) return WTAMD_ERR_ARG;
+    p->compress = on != 0;
     return WTAMD_OK;
 }
 
@@ -197,12 +205,47 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
                                      tile ? s.ip.data() : nullptr, info, &range_lo, &range_hi);
     if (r < 0) { g_err = "emulator error " + std::to_string(r); return WTAMD_ERR_INTERNAL; }
     if (r > p->cfg.max_runs) { g_err = "more runs than max_runs"; return WTAMD_ERR_CAPACITY; }
-    s.n_runs = r; s.covered = info[4]; s.n_int = n;
+    long long rr = r;
+    if (p->compress && !tile && r > 0) {
+        // CompressionWiggleIterator's leader rule (reference unaryOps.c:235-253), sequentially -- with an
+        // OPEN START: the batch continues a previous one whose last group may reach into it, so the
+        // runs before the first run that leads a group whatever came before it (not contiguous,
+        // NaN-ness changes, or more than 2e-6 away from its predecessor) are passed through one by one
+        auto isnan_ = [](double x) { return x != x; };
+        long long f = r;
+        for (long long q = 1; q < r; q++) {
+            const double v = s.ov[(size_t) q], pv = s.ov[(size_t) q - 1];
+            const bool contiguous = s.os[(size_t) q] == s.of[(size_t) q - 1];
+            bool sure = !contiguous || isnan_(v) != isnan_(pv);
+            if (!sure && !isnan_(v)) { const double dd = v > pv ? v - pv : pv - v; sure = dd >= 2.000001e-6; }
+            if (sure) { f = q; break; }
+        }
+        long long o = f > 0 ? f - 1 : 0;       // runs [0, f) unchanged; the group of run f starts at output f
+        if (f < r) {
+            o = f;
+            s.os[(size_t) o] = s.os[(size_t) f]; s.ov[(size_t) o] = s.ov[(size_t) f];
+            double leader = s.ov[(size_t) f];
+            for (long long q = f + 1; q < r; q++) {
+                const double v = s.ov[(size_t) q];
+                const bool same = s.os[(size_t) q] == s.of[(size_t) q - 1] &&
+                                  ((isnan_(v) && isnan_(leader)) || (v - leader < 0.000001 && leader - v < 0.000001));
+                if (!same) {
+                    s.of[(size_t) o] = s.of[(size_t) q - 1];
+                    o++;
+                    s.os[(size_t) o] = s.os[(size_t) q]; s.ov[(size_t) o] = v;
+                    leader = v;
+                }
+            }
+            s.of[(size_t) o] = s.of[(size_t) r - 1];
+        }
+        rr = o + 1;
+    }
+    s.n_runs = rr; s.covered = info[4]; s.n_int = n;
     s.state = 2;
     p->acquired = -1;
     p->head = (p->head + 1) % (int) p->slots.size();
     p->in_flight++;
-    p->st.batches++; p->st.intervals += n; p->st.runs += r; p->st.covered_bp += info[4];
+    p->st.batches++; p->st.intervals += n; p->st.runs += rr; p->st.covered_bp += info[4];
     if (info[8]) p->st.delta_batches++;
     return WTAMD_OK;
 }

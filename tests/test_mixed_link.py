@@ -85,3 +85,28 @@ def test_reference_integrators_over_dropin(oracle, M, seed):
     d = t.as_dict()
     for op in ("mean", "max"):
         assert M.auc_of_reduce(d, op) == R.auc_of_reduce(d, op), op
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_device_side_compression_under_the_reference_writer(oracle, M, tmp_path, seed, monkeypatch):
+    """Writer hand-off: the reducer merges its runs on the device before they
+    cross PCIe (wtamd_iterator_compress_output), the reference's TeeWiggleIterator still wraps it
+    in its own CompressionWiggleIterator (wigWriter.c:263-267) -- the rule is idempotent, also
+    across the batch seams where a group stays split -- and the text is byte-identical."""
+    R = oracle.ref_harness()
+    from wiggletools_amd.runlists import synth
+    monkeypatch.setenv("WTAMD_MIN_SPAN", "300")
+    monkeypatch.setenv("WTAMD_BATCH_INTERVALS", "500")
+    # few levels + tiny differences: long mergeable stretches, uncertain neighbours (|dv| < 2e-6)
+    t = synth(3, [6000, 900], mean_run=5, gap_prob=0.05, seed=50 + seed, value_levels=2, dtype=np.float64)
+    rng = np.random.default_rng(seed)
+    t.value[:] = t.value + rng.integers(0, 3, len(t.value)) * 4e-7
+    d = t.as_dict()
+    M.set_compress_mode(1)
+    try:
+        for op in ("mean", "max", "sum"):
+            a = M.write_reduce(d, op, tmp_path / "a.txt")
+            b = R.write_reduce(d, op, tmp_path / "b.txt")
+            assert a == b, op
+    finally:
+        M.set_compress_mode(0)

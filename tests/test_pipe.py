@@ -75,6 +75,30 @@ def test_pipe_difference_array_with_patched_windows(oracle, lib, monkeypatch):
         assert st["delta_batches"] == st["batches"] > 1
 
 
+def test_pipe_device_side_compression(oracle, lib):
+    """WTAMD_PIPE_COMPRESS: every batch is merged on the device by CompressionWiggleIterator's rule, except
+    for its head (the runs before the first run that leads a group whatever preceded it: they may
+    belong to the previous batch's last group).  Contract: a consumer that applies the reference's
+    wrapper to this output gets what it gets on the uncompressed runs -- checked with the oracle's
+    restatement of the wrapper (itself pinned on the compiled reference, tests/test_oracle_vs_ref.py),
+    for batches of any size."""
+    from wiggletools_amd.pipe import stream_runlists
+    from wiggletools_amd.runlists import synth
+    t = synth(3, [9000, 700], mean_run=4, gap_prob=0.05, seed=8, value_levels=2, dtype=np.float64)
+    rng = np.random.default_rng(1)
+    t.value[:] = t.value + rng.integers(0, 3, len(t.value)) * 4e-7
+    t.value[50:60] = np.nan
+    d = t.as_dict()
+    for op in ("mean", "max"):
+        plain = oracle.reduce(d, op)
+        exp = oracle.compress(*plain)
+        for bp in (1 << 20, 700, 97):
+            got, st = stream_runlists(t, op, bp, depth=2, lib=lib, compress=True)
+            assert_runs_equal(oracle.compress(*got), exp, 0.0, "%s batches of %d bp" % (op, bp))
+            assert len(exp[0]) <= len(got[0]) < len(plain[0])
+            assert int((got[2] - got[1]).sum()) == int((plain[2] - plain[1]).sum())      # same coverage
+
+
 def test_pipe_contract_errors(lib):
     from wiggletools_amd import _lib
     from wiggletools_amd.pipe import Pipe

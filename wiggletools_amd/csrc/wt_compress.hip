@@ -35,8 +35,13 @@ namespace {
 __device__ __forceinline__ bool wc_isnan(double x) { return x != x; }
 
 // 1. classification -> LEAD / UNC bitmaps (bit r of word r/64)
+// (n_ptr != NULL: the run count is read on the device -- the streaming pipeline compresses a batch
+//  before its host has learnt how many runs the reduce kernel emitted; grids are then sized by capacity)
 __global__ void __launch_bounds__(WC_BLOCK) wc_classify(const int32_t *start, const int32_t *finish, const double *value,
-                                                        long long n, unsigned long long *lead, unsigned long long *unc) {
+                                                        long long n, const unsigned long long *n_ptr,
+                                                        unsigned long long *lead, unsigned long long *unc,
+                                                        unsigned long long *first_sure) {
+    if (n_ptr) n = (long long) *n_ptr < n ? (long long) *n_ptr : n;
     const long long r = (long long) blockIdx.x * WC_BLOCK + threadIdx.x;
     bool is_lead = false, is_unc = false;
     if (r < n) {
@@ -57,6 +62,25 @@ __global__ void __launch_bounds__(WC_BLOCK) wc_classify(const int32_t *start, co
     }
     const unsigned long long lb = __ballot(is_lead), ub = __ballot(is_unc);
     if ((threadIdx.x & 63) == 0 && r < n) { lead[r >> 6] = lb; unc[r >> 6] = ub; }
+    if (first_sure) {       // first run (other than run 0) that leads a group whatever came before it
+        const unsigned long long sure = r == 0 ? (lb & ~1ull) : lb;
+        if ((threadIdx.x & 63) == 0 && r < n && sure) atomicMin(first_sure, (unsigned long long) (r + (__ffsll(sure) - 1)));
+    }
+}
+
+// Open start (pipeline batches): the list continues a previous batch, whose last group may extend
+// into this one -- whether the runs BEFORE the first sure leader join that group depends on its
+// leader's value, which this batch does not know (and a compressed group hides its members'
+// values, so merging them here could change what the consumer's own CompressionWiggleIterator
+// decides).  They are passed through one by one: every run before the first sure leader leads.
+__global__ void __launch_bounds__(WC_BLOCK) wc_open_start(unsigned long long *lead, const unsigned long long *first_sure,
+                                                          long long n, const unsigned long long *n_ptr) {
+    if (n_ptr) n = (long long) *n_ptr < n ? (long long) *n_ptr : n;
+    long long f = (long long) (*first_sure < (unsigned long long) n ? *first_sure : (unsigned long long) n);
+    const long long w = (long long) blockIdx.x * WC_BLOCK + threadIdx.x;
+    if (w * 64 >= f) return;
+    const long long top = f - w * 64;
+    lead[w] |= top >= 64 ? ~0ull : ((1ull << top) - 1ull);
 }
 
 // chromosome starts are leaders whatever the coordinates say (strcmp(chrom) test, unaryOps.c:248)
@@ -85,8 +109,10 @@ __device__ long long wc_next(const unsigned long long *a, const unsigned long lo
 }
 
 // 2. resolve uncertain runs: one lane per sure leader
-__global__ void __launch_bounds__(WC_BLOCK) wc_resolve(const double *value, long long n, const unsigned long long *lead,
+__global__ void __launch_bounds__(WC_BLOCK) wc_resolve(const double *value, long long n, const unsigned long long *n_ptr,
+                                                       const unsigned long long *lead,
                                                        const unsigned long long *unc, unsigned long long *promoted) {
+    if (n_ptr) n = (long long) *n_ptr < n ? (long long) *n_ptr : n;
     const long long r = (long long) blockIdx.x * WC_BLOCK + threadIdx.x;
     if (r >= n || !((lead[r >> 6] >> (r & 63)) & 1ull)) return;
     double leader = value[r];
@@ -106,7 +132,9 @@ __global__ void __launch_bounds__(WC_BLOCK) wc_resolve(const double *value, long
 
 // 3a. final leader bitmap + per-block leader counts
 __global__ void __launch_bounds__(WC_BLOCK) wc_count(unsigned long long *lead, const unsigned long long *promoted,
-                                                     long long n_words, unsigned long long *block_count) {
+                                                     long long n_words, const unsigned long long *n_ptr,
+                                                     unsigned long long *block_count) {
+    if (n_ptr) { const long long nw = ((long long) *n_ptr + 63) >> 6; n_words = nw < n_words ? nw : n_words; }
     __shared__ unsigned int red[WC_BLOCK];
     const long long w0 = (long long) blockIdx.x * WC_WORDS_PER_BLOCK;
     unsigned int c = 0;
@@ -129,6 +157,7 @@ __global__ void __launch_bounds__(WC_BLOCK) wc_count(unsigned long long *lead, c
 
 // 3b. exclusive scan of the block counts (one block; the list is short: n / 131072 entries)
 __global__ void wc_scan_blocks(unsigned long long *block_count, long long n_blocks, unsigned long long *total) {
+    // (blocks beyond a device-side run count hold 0: wc_count writes every block)
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         unsigned long long run = 0;
         for (long long b = 0; b < n_blocks; b++) { const unsigned long long c = block_count[b]; block_count[b] = run; run += c; }
@@ -138,9 +167,15 @@ __global__ void wc_scan_blocks(unsigned long long *block_count, long long n_bloc
 
 // 3c. emit merged runs; also the per-chromosome offsets of the compressed list
 __global__ void __launch_bounds__(WC_BLOCK) wc_emit(const int32_t *start, const int32_t *finish, const double *value, long long n,
+                                                    const unsigned long long *n_ptr,
                                                     const unsigned long long *lead, long long n_words,
                                                     const unsigned long long *block_off, long long capacity,
                                                     int32_t *o_start, int32_t *o_finish, double *o_value) {
+    if (n_ptr) {
+        n = (long long) *n_ptr < n ? (long long) *n_ptr : n;
+        const long long nw = (n + 63) >> 6;
+        n_words = nw < n_words ? nw : n_words;
+    }
     __shared__ unsigned int pfx[WC_WORDS_PER_BLOCK];
     const long long w0 = (long long) blockIdx.x * WC_WORDS_PER_BLOCK;
     for (int k = threadIdx.x; k < WC_WORDS_PER_BLOCK; k += WC_BLOCK) {
@@ -222,13 +257,15 @@ extern "C" int wtamd_runs_compress(const wtamd_runs *in, int64_t n_runs, int32_t
     d_total = d_blk + n_blocks;
     WC_HIP(hipMemsetAsync(d_prom, 0, sizeof(unsigned long long) * n_words, s));
     const unsigned grid_runs = (unsigned) ((n + WC_BLOCK - 1) / WC_BLOCK);
-    hipLaunchKernelGGL(wc_classify, dim3(grid_runs), dim3(WC_BLOCK), 0, s, in->start, in->finish, in->value, n, d_lead, d_unc);
+    hipLaunchKernelGGL(wc_classify, dim3(grid_runs), dim3(WC_BLOCK), 0, s, in->start, in->finish, in->value, n, (const unsigned long long *) nullptr, d_lead, d_unc,
+                       (unsigned long long *) nullptr);
     hipLaunchKernelGGL(wc_chrom_starts, dim3((unsigned) ((n_chrom + 63) / 64)), dim3(64), 0, s, in->chrom_run_off, (int) n_chrom, n,
                        d_lead, d_unc);
-    hipLaunchKernelGGL(wc_resolve, dim3(grid_runs), dim3(WC_BLOCK), 0, s, in->value, n, d_lead, d_unc, d_prom);
-    hipLaunchKernelGGL(wc_count, dim3((unsigned) n_blocks), dim3(WC_BLOCK), 0, s, d_lead, d_prom, n_words, d_blk);
+    hipLaunchKernelGGL(wc_resolve, dim3(grid_runs), dim3(WC_BLOCK), 0, s, in->value, n, (const unsigned long long *) nullptr, d_lead, d_unc, d_prom);
+    hipLaunchKernelGGL(wc_count, dim3((unsigned) n_blocks), dim3(WC_BLOCK), 0, s, d_lead, d_prom, n_words, (const unsigned long long *) nullptr, d_blk);
     hipLaunchKernelGGL(wc_scan_blocks, dim3(1), dim3(64), 0, s, d_blk, n_blocks, d_total);
-    hipLaunchKernelGGL(wc_emit, dim3((unsigned) n_blocks), dim3(WC_BLOCK), 0, s, in->start, in->finish, in->value, n, d_lead, n_words,
+    hipLaunchKernelGGL(wc_emit, dim3((unsigned) n_blocks), dim3(WC_BLOCK), 0, s, in->start, in->finish, in->value, n,
+                       (const unsigned long long *) nullptr, d_lead, n_words,
                        d_blk, (long long) out->capacity, out->start, out->finish, out->value);
     unsigned long long total = 0;
     WC_HIP(hipGetLastError());
@@ -243,4 +280,37 @@ extern "C" int wtamd_runs_compress(const wtamd_runs *in, int64_t n_runs, int32_t
     (void) hipFree(d_lead); (void) hipFree(d_unc); (void) hipFree(d_prom); (void) hipFree(d_blk);
     *n_out = (int64_t) total;
     return (int64_t) total > out->capacity ? WTAMD_ERR_CAPACITY : WTAMD_OK;
+}
+
+
+// ---- in-stream flavour for the pipeline (wt_pipe.h): one chromosome, the run count still on the
+// device (*d_n, at most `capacity`), scratch provided by the caller (WC scratch words: see
+// wt_compress_scratch_words), nothing waits.  *d_n_out receives the number of merged runs.
+long long wt_compress_scratch_words(long long capacity) {
+    const long long n_words = (capacity + 63) >> 6;
+    const long long n_blocks = (n_words + WC_WORDS_PER_BLOCK - 1) / WC_WORDS_PER_BLOCK;
+    return 3 * n_words + n_blocks + 4;
+}
+
+int wt_compress_async(const int32_t *start, const int32_t *finish, const double *value, const unsigned long long *d_n,
+                      long long capacity, unsigned long long *scratch, int32_t *o_start, int32_t *o_finish, double *o_value,
+                      unsigned long long *d_n_out, hipStream_t s) {
+    if (capacity <= 0) return WTAMD_OK;
+    const long long n_words = (capacity + 63) >> 6;
+    const long long n_blocks = (n_words + WC_WORDS_PER_BLOCK - 1) / WC_WORDS_PER_BLOCK;
+    unsigned long long *d_lead = scratch, *d_unc = scratch + n_words, *d_prom = scratch + 2 * n_words, *d_blk = scratch + 3 * n_words;
+    unsigned long long *d_first = d_blk + n_blocks + 2;
+    WC_HIP(hipMemsetAsync(scratch, 0, sizeof(unsigned long long) * (size_t) (3 * n_words + n_blocks + 1), s));
+    WC_HIP(hipMemsetAsync(d_first, 0xff, sizeof(unsigned long long), s));
+    const unsigned grid_runs = (unsigned) ((capacity + WC_BLOCK - 1) / WC_BLOCK);
+    hipLaunchKernelGGL(wc_classify, dim3(grid_runs), dim3(WC_BLOCK), 0, s, start, finish, value, capacity, d_n, d_lead, d_unc, d_first);
+    hipLaunchKernelGGL(wc_open_start, dim3((unsigned) ((n_words + WC_BLOCK - 1) / WC_BLOCK)), dim3(WC_BLOCK), 0, s, d_lead, d_first,
+                       capacity, d_n);
+    hipLaunchKernelGGL(wc_resolve, dim3(grid_runs), dim3(WC_BLOCK), 0, s, value, capacity, d_n, d_lead, d_unc, d_prom);
+    hipLaunchKernelGGL(wc_count, dim3((unsigned) n_blocks), dim3(WC_BLOCK), 0, s, d_lead, d_prom, n_words, d_n, d_blk);
+    hipLaunchKernelGGL(wc_scan_blocks, dim3(1), dim3(64), 0, s, d_blk, n_blocks, d_n_out);
+    hipLaunchKernelGGL(wc_emit, dim3((unsigned) n_blocks), dim3(WC_BLOCK), 0, s, start, finish, value, capacity, d_n, d_lead, n_words,
+                       d_blk, capacity, o_start, o_finish, o_value);
+    WC_HIP(hipGetLastError());
+    return WTAMD_OK;
 }

@@ -977,6 +977,13 @@ int64_t wtamd_iterator_next_block(WiggleIterator *wi, const char **chrom, const 
     return n;
 }
 
+int wtamd_iterator_compress_output(WiggleIterator *wi, int on) {
+    if (!wi || wi->pop != &red_pop) return WTAMD_ERR_ARG;
+    RedState *R = red_state(wi);
+    if (!R->fd.pipe) return WTAMD_ERR_ARG;
+    return wtamd_pipe_set_compress(R->fd.pipe, on);
+}
+
 int wtamd_iterator_pipe_stats(WiggleIterator *wi, wtamd_pipe_stats *out) {
     if (!wi || !out || wi->pop != &red_pop) return WTAMD_ERR_ARG;
     RedState *R = red_state(wi);

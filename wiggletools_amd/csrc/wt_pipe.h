@@ -23,6 +23,12 @@
 #ifndef WT_PIPE_H_
 #define WT_PIPE_H_
 
+// wt_compress.hip
+long long wt_compress_scratch_words(long long capacity);
+int wt_compress_async(const int32_t *start, const int32_t *finish, const double *value, const unsigned long long *d_n,
+                      long long capacity, unsigned long long *scratch, int32_t *o_start, int32_t *o_finish, double *o_value,
+                      unsigned long long *d_n_out, hipStream_t s);
+
 // Gather: ONE kernel pulls every range of a batch -- the caller's pinned SoA blocks (bulk side
 // door) and the staged ranges alike -- from host memory into the slot's device arrays.  The copy
 // engine needs three hipMemcpyAsync per track and batch (~10 us of launch overhead each: 300 calls
@@ -80,12 +86,13 @@ __global__ void __launch_bounds__(256) wt_gather_kernel(const WtGatherSeg *segs,
 
 // Export: the emitted runs (their count is read on the device) and the launch counters go to the
 // slot's PINNED host output, written through the link by the kernel itself.
+#define WT_CTR_EXPORTED 6            // h_counters slot: runs the export kernel shipped (== WT_CTR_RUNS unless compressed)
 __global__ void __launch_bounds__(256) wt_export_kernel(const unsigned long long *d_counters, unsigned long long *h_counters,
-                                                         long long capacity, int n_tracks,
+                                                         const unsigned long long *n_src, long long capacity, int n_tracks,
                                                          const int32_t *d_os, const int32_t *d_of, const double *d_ov,
                                                          const double *d_tile, const uint8_t *d_ip,
                                                          int32_t *h_os, int32_t *h_of, double *h_ov, double *h_tile, uint8_t *h_ip) {
-    long long n = (long long) d_counters[WT_CTR_RUNS];
+    long long n = (long long) *n_src;
     if (n > capacity) n = capacity;
     const long long stride = (long long) gridDim.x * 256, t = (long long) blockIdx.x * 256 + threadIdx.x;
     {   // coordinates: 16 bytes per lane
@@ -104,7 +111,7 @@ __global__ void __launch_bounds__(256) wt_export_kernel(const unsigned long long
         const long long m = n * n_tracks;
         for (long long i = t; i < m; i += stride) { h_tile[i] = d_tile[i]; h_ip[i] = d_ip[i]; }
     }
-    if (t < WT_CTR_N) h_counters[t] = d_counters[t];
+    if (t < WT_CTR_N) h_counters[t] = t == WT_CTR_EXPORTED ? (unsigned long long) n : d_counters[t];
 }
 
 // Page-locked (hipHostMalloc / hipHostRegister) host memory is readable by kernels; pageable memory
@@ -149,6 +156,11 @@ struct WtSlot {
     struct Direct { int64_t at, count; const int32_t *start, *finish; const float *value; };
     std::vector<Direct> direct;
     WtGatherSeg *h_segs = nullptr;  // gather table, pinned (the kernel reads it where it lies)
+    // device-side run compression (WTAMD_PIPE_COMPRESS): merged runs + scratch bitmaps, sized with the output
+    int32_t *d_cs = nullptr, *d_cf = nullptr;
+    double *d_cv = nullptr;
+    unsigned long long *d_cscratch = nullptr, *d_cn = nullptr;
+    bool compressed = false;        // this batch's output went through the compression
     int64_t seg_cap = 0;
     bool direct_pinned = true;      // every direct range of this batch lies in page-locked memory
 };
@@ -161,6 +173,7 @@ struct wtamd_pipe {
     hipStream_t s_copy = nullptr, s_comp = nullptr, s_out = nullptr;
     bool delta_failed = false;      // a batch had many inexact windows: Sum / Mean stay on the general kernel
     bool tile = false;
+    bool compress = false;          // WTAMD_PIPE_COMPRESS: batches submitted from now on are merged on device before they travel
     bool gather = true;             // WTAMD_PIPE_GATHER=0: hipMemcpyAsync per range instead of the gather kernel
     int gather_blocks = 64;         // WTAMD_GATHER_BLOCKS
     int num_cu = 256;
@@ -176,6 +189,7 @@ static void wt_slot_free(WtSlot &s) {
     (void) hipFree(s.d_start); (void) hipFree(s.d_finish); (void) hipFree(s.d_value);
     (void) hipFree(s.d_os); (void) hipFree(s.d_of); (void) hipFree(s.d_ov); (void) hipFree(s.d_tile); (void) hipFree(s.d_ip);
     (void) hipFree(s.d_cro);
+    (void) hipFree(s.d_cs); (void) hipFree(s.d_cf); (void) hipFree(s.d_cv); (void) hipFree(s.d_cscratch); (void) hipFree(s.d_cn);
     if (s.h_segs) (void) hipHostFree(s.h_segs);
     if (s.h_os) (void) hipHostFree(s.h_os);
     if (s.h_of) (void) hipHostFree(s.h_of);
@@ -244,8 +258,10 @@ static int wt_pipe_enqueue_export(wtamd_pipe *p, WtSlot &s, hipEvent_t after) {
     long long blocks = (s.ocap + 256 * 16 - 1) / (256 * 16);
     if (blocks > 2ll * s.ts->num_cu) blocks = 2ll * s.ts->num_cu;
     if (blocks < 1) blocks = 1;
+    const bool cz = s.compressed;
     hipLaunchKernelGGL(wt_export_kernel, dim3((unsigned) blocks), dim3(256), 0, p->s_out, s.ts->d_counters, s.ts->h_counters,
-                       (long long) s.ocap, p->cfg.n_tracks, s.d_os, s.d_of, s.d_ov, p->tile ? s.d_tile : nullptr,
+                       cz ? (const unsigned long long *) s.d_cn : (const unsigned long long *) (s.ts->d_counters + WT_CTR_RUNS),
+                       (long long) s.ocap, p->cfg.n_tracks, cz ? s.d_cs : s.d_os, cz ? s.d_cf : s.d_of, cz ? s.d_cv : s.d_ov, p->tile ? s.d_tile : nullptr,
                        p->tile ? s.d_ip : nullptr, s.h_os, s.h_of, s.h_ov, p->tile ? s.h_tile : nullptr, p->tile ? s.h_ip : nullptr);
     WT_HIP(hipGetLastError());
     WT_HIP(hipEventRecord(s.e_d1, p->s_out));
@@ -265,6 +281,11 @@ static int wt_pipe_finish(wtamd_pipe *p, WtSlot &s) {
         runs.capacity = s.ocap; runs.start = s.d_os; runs.finish = s.d_of; runs.value = s.d_ov; runs.chrom_run_off = s.d_cro;
         int rc = wt_launch_patch(ts, s.delta_W, p->cfg.desc.op, p->cfg.desc.flags, &runs, n_bad, p->s_comp);
         if (rc != WTAMD_OK) return rc;
+        if (s.compressed) {
+            rc = wt_compress_async(s.d_os, s.d_of, s.d_ov, ts->d_counters + WT_CTR_RUNS, (long long) s.ocap, s.d_cscratch, s.d_cs, s.d_cf,
+                                   s.d_cv, s.d_cn, p->s_comp);
+            if (rc != WTAMD_OK) return wt_fail(rc, "run compression launch failed");
+        }
         WT_HIP(hipEventRecord(s.e_patch, p->s_comp));
         rc = wt_pipe_enqueue_export(p, s, s.e_patch);
         if (rc != WTAMD_OK) return rc;
@@ -273,7 +294,7 @@ static int wt_pipe_finish(wtamd_pipe *p, WtSlot &s) {
         s.patched = true;
         if (n_bad * 4 > (long long) ts->stats.n_windows) p->delta_failed = true;     // this data: general kernel from now on
     }
-    s.n_runs = (int64_t) hc[WT_CTR_RUNS];
+    s.n_runs = (int64_t) hc[WT_CTR_EXPORTED];
     s.covered = (int64_t) hc[WT_CTR_BP];
     return WTAMD_OK;
 }
@@ -284,14 +305,15 @@ int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
     if (!cfg || !out || cfg->n_tracks <= 0 || !cfg->defaults || cfg->max_runs <= 0)
         return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_create: bad configuration");
     if (cfg->flags & ~0u & ~WTAMD_PIPE_COMPRESS) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_create: unknown flag");
-    if (cfg->flags & WTAMD_PIPE_COMPRESS) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_create: WTAMD_PIPE_COMPRESS is not wired yet");
     const bool tile = cfg->desc.op == WTAMD_OP_MULTIPLEX;
+    if ((cfg->flags & WTAMD_PIPE_COMPRESS) && tile) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_create: the Multiplexer tile cannot be compressed");
     if (wtamd_device_count() <= 0) return wt_fail(WTAMD_ERR_NODEVICE, "no HIP device visible");
     wtamd_pipe *p = new wtamd_pipe();
     p->cfg = *cfg;
     p->defaults.assign(cfg->defaults, cfg->defaults + cfg->n_tracks);
     p->cfg.defaults = p->defaults.data();
     p->tile = tile;
+    p->compress = (cfg->flags & WTAMD_PIPE_COMPRESS) != 0;
     if (getenv("WTAMD_PIPE_GATHER")) p->gather = atoi(getenv("WTAMD_PIPE_GATHER")) != 0;
     if (getenv("WTAMD_GATHER_BLOCKS") && atoi(getenv("WTAMD_GATHER_BLOCKS")) > 0) p->gather_blocks = atoi(getenv("WTAMD_GATHER_BLOCKS"));
     int ns = cfg->n_slots ? cfg->n_slots : 3;
@@ -477,6 +499,8 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
         WT_HIP(hipHostMalloc((void **) &s.h_os, sizeof(int32_t) * c, hipHostMallocDefault));
         WT_HIP(hipHostMalloc((void **) &s.h_of, sizeof(int32_t) * c, hipHostMallocDefault));
         WT_HIP(hipHostMalloc((void **) &s.h_ov, sizeof(double) * c, hipHostMallocDefault));
+        (void) hipFree(s.d_cs); (void) hipFree(s.d_cf); (void) hipFree(s.d_cv); (void) hipFree(s.d_cscratch);
+        s.d_cs = s.d_cf = nullptr; s.d_cv = nullptr; s.d_cscratch = nullptr;
         if (p->tile) {
             WT_HIP(hipMalloc(&s.d_tile, sizeof(double) * c * N));
             WT_HIP(hipMalloc(&s.d_ip, sizeof(uint8_t) * c * N));
@@ -601,6 +625,19 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     rc = wt_reduce_plan(ts, plan, op, p->cfg.desc.flags, p->cfg.desc.n_set0, &runs, p->tile ? s.d_tile : nullptr,
                         p->tile ? s.d_ip : nullptr, nullptr, p->s_comp);
     if (rc != WTAMD_OK) return rc;
+    s.compressed = p->compress;
+    if (s.compressed) {
+        if (!s.d_cs) {          // (grow-only, with the output buffers)
+            WT_HIP(hipMalloc(&s.d_cs, sizeof(int32_t) * s.ocap));
+            WT_HIP(hipMalloc(&s.d_cf, sizeof(int32_t) * s.ocap));
+            WT_HIP(hipMalloc(&s.d_cv, sizeof(double) * s.ocap));
+            WT_HIP(hipMalloc(&s.d_cscratch, sizeof(unsigned long long) * (size_t) wt_compress_scratch_words((long long) s.ocap)));
+        }
+        if (!s.d_cn) WT_HIP(hipMalloc(&s.d_cn, sizeof(unsigned long long)));
+        rc = wt_compress_async(s.d_os, s.d_of, s.d_ov, ts->d_counters + WT_CTR_RUNS, (long long) s.ocap, s.d_cscratch, s.d_cs, s.d_cf,
+                               s.d_cv, s.d_cn, p->s_comp);
+        if (rc != WTAMD_OK) return wt_fail(rc, "run compression launch failed");
+    }
     WT_HIP(hipEventRecord(s.e_cnt, p->s_comp));
     rc = wt_pipe_enqueue_export(p, s, s.e_cnt);
     if (rc != WTAMD_OK) return rc;
@@ -655,6 +692,13 @@ int wtamd_pipe_release(wtamd_pipe *p) {
 }
 
 int wtamd_pipe_in_flight(const wtamd_pipe *p) { return p ? p->in_flight : 0; }
+
+int wtamd_pipe_set_compress(wtamd_pipe *p, int on) {
+    if (!p) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    if (on && p->tile) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_set_compress: the Multiplexer tile cannot be compressed");
+    p->compress = on != 0;
+    return WTAMD_OK;
+}
 
 void *wtamd_host_alloc(size_t bytes) {
     void *q = nullptr;

@@ -67,13 +67,13 @@ def _bind(L):
 
 class Pipe:
     def __init__(self, n_tracks, op, defaults=None, flags=0, n_set0=0, max_intervals=1 << 16, max_runs=1 << 21,
-                 n_slots=3, lib=None):
+                 n_slots=3, lib=None, compress=False):
         self.L = _bind(lib if lib is not None else _lib.lib())
         self.n_tracks = int(n_tracks)
         self.op = OP_MULTIPLEX if op == "multiplex" else opcode(op)
         self._defaults = np.ascontiguousarray(np.zeros(n_tracks) if defaults is None else defaults, np.float64)
         cfg = PipeConfig(self.n_tracks, n_slots, self._defaults.ctypes.data,
-                         _lib.ReduceDesc(self.op, flags, n_set0, 0), max_intervals, max_runs, 0, 0)
+                         _lib.ReduceDesc(self.op, flags, n_set0, 0), max_intervals, max_runs, 1 if compress else 0, 0)
         h = C.c_void_p()
         self._check(self.L.wtamd_pipe_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -147,14 +147,14 @@ class Pipe:
         return {k: getattr(s, k) for k, _ in PipeStats._fields_}
 
 
-def stream_runlists(rl, op, batch_bp, flags=0, n_set0=0, depth=2, lib=None, max_runs=None, max_intervals=64):
+def stream_runlists(rl, op, batch_bp, flags=0, n_set0=0, depth=2, lib=None, max_runs=None, max_intervals=64, compress=False):
     """Feeds a RunLists through a Pipe, chromosome by chromosome, `batch_bp` run starts per batch,
     `depth` batches in flight; returns (chrom, start, finish, value[, tile, inplay]) concatenated.
     The cuts follow the drop-in layer's rules: a batch holds every interval overlapping or
     touching [lo, hi] plus, per track, the first interval beyond hi."""
     N = rl.n_tracks
     p = Pipe(N, op, rl.defaults, flags, n_set0, max_intervals=max_intervals,
-             max_runs=max_runs if max_runs is not None else max(batch_bp, 1), n_slots=depth + 1, lib=lib)
+             max_runs=max_runs if max_runs is not None else max(batch_bp, 1), n_slots=depth + 1, lib=lib, compress=compress)
     f64 = rl.value.dtype == np.float64
     pieces, chroms, pending = [], [], []
 
