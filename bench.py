@@ -256,6 +256,7 @@ def main():
     ap.add_argument("--shard", default="genome", choices=["genome", "replicas"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-many-core", action="store_true")
+    ap.add_argument("--chroms", default=None, help="experiments: only these chromosomes of the configuration (comma separated indices)")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--e2e-mbp", type=float, default=100.0, help="chromosome length of the end-to-end (drop-in layer) leg")
     args = ap.parse_args()
@@ -284,7 +285,7 @@ def main():
     cfg = CONFIGS[args.config]
     ops = args.op.split(",") if args.op else cfg["ops"]
     N = args.tracks if args.tracks else cfg["tracks"]
-    chrom_ids = cfg["chroms"]
+    chrom_ids = cfg["chroms"] if not args.chroms else [int(x) for x in args.chroms.split(",")]
     chrom_lens = {c: max(int(GRCH38[c] * args.scale), 1) for c in chrom_ids}
     queue = sorted(chrom_ids, key=lambda c: -chrom_lens[c])         # host-side work queue: largest first
     genome_bp = sum(chrom_lens.values())

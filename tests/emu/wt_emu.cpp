@@ -37,6 +37,8 @@ struct EmuRun {
         if (P.g_scratch_slab) c.scratch = slab.data();      // one emulated workgroup: one slab
         if (P.g_attr_slab) c.attr = slab.data() + P.g_scratch_slab;
         const int T = plan.T;
+        if (NR > 0)
+            for (int i = 0; i < P.n_tracks; i++) c.dflt32[i] = (float) P.defaults[i];
         std::vector<WtLane<K>> lanes(T);
         size_t gi = 0, wi = 0;
         long long patch_goff = 0;

@@ -430,7 +430,7 @@ def test_plan_policy_snapshot():
     p = plan(500, "var")
     assert (p["W"], p["T"]) == (2048, 512) and p["n_chunks"] == 5        # chunks of <= 112 tracks
     p = plan(100, "median")
-    assert (p["W"], p["T"], p["lds"] < 48 * 1024) == (1024, 256, True) and p["scratch_slab"] == 0    # round 2: value column in REGISTERS, LDS = bitmaps only, 4 positions per lane
+    assert (p["W"], p["T"], p["lds"] < 32 * 1024) == (512, 256, True) and p["scratch_slab"] == 0     # round 2: value column in REGISTERS, LDS = bitmaps only, 2 positions per lane
     p = plan(100, "mwu", n_set0=50)
     assert (p["W"], p["T"]) == (512, 256) and p["lds"] < 80 * 1024       # register columns + the sorted set 0 (50 x 4 B per lane) in LDS, 2 positions per lane
     p = plan(100, "mwu", n_set0=90)

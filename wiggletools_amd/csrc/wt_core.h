@@ -114,6 +114,7 @@ struct WtParams {
     int32_t cpitch;               // u16 entries per cnt_i row (W/32, even)
     int32_t off_S, off_cnt, off_segtot, off_U, off_cover, off_E, off_epfx, off_nextw, off_gbase, off_scratch, off_shared;
     int32_t off_acc, off_ev, off_ltv, off_ltc, off_gtv, off_gtc, off_tbase, off_tpfx, off_tfirst, off_dsh;   // difference-array path (wt_delta.h)
+    int32_t off_dflt32;           // register-column median / MWU: float copy of defaults[] in LDS (filled once per workgroup)
     int32_t lds_bytes;
 };
 
@@ -149,6 +150,7 @@ struct WtCtx {
     long long *gbase;   // [n_tracks] global index of (first covering interval) - 1
     char *scratch;      // per-lane column scratch for median / MWU
     char *attr;         // MWU: per-rank attribute words [n_set0][lanes] (global slab of this workgroup)
+    float *dflt32;      // register-column kernels: defaults[] as float (LDS)
     WtShared *sh;
 };
 
@@ -164,6 +166,7 @@ WT_DEV void wt_ctx_init(WtCtx &c, const WtParams &P, char *lds) {
     c.gbase = (long long *) (lds + P.off_gbase);
     c.scratch = lds + P.off_scratch;
     c.attr = nullptr;
+    c.dflt32 = (float *) (lds + P.off_dflt32);
     c.sh = (WtShared *) (lds + P.off_shared);
 }
 
@@ -835,6 +838,64 @@ WT_DEV void wt_regcol_store(uint32_t *col, uint32_t *col2, int blk, const uint32
     });
 }
 
+#ifdef WT_REGCOL_FLAT
+// Variant: both passes fully unrolled, every load of the position in flight at once.
+//   A  per track: bitmap word + rank prefix + first-interval index from LDS, the value's address in
+//      VECTOR registers (no per-track buffer descriptor: no scalar state to hoist and spill), the
+//      global load issued straight into the slot's register; the coverage bit goes into a bit mask;
+//   B  per slot: default (LDS table, filled once per workgroup) where the track is absent, NaN
+//      test, key.
+template <int OP, int NR>
+WT_DEV int wt_regcol_track(int s, int N, int na, int pad_lo) {      // track held by slot s, or -1 (pad)
+    if (OP == WT_OP_MEDIAN) { const int i = s - pad_lo; return (i < 0 || i >= N) ? -1 : i; }
+    if (s < NR / 2) return s < na ? s : -1;
+    const int i = na + (s - NR / 2);
+    return i < N ? i : -1;
+}
+
+template <int OP, class ValT, int NR>
+WT_DEV bool wt_gather_regs(const WtParams &P, const WtCtx &c, int p0, uint32_t *col, uint32_t *col2) {
+    constexpr int H = NR / 2;
+    const int w32 = p0 >> 5, b0 = p0 & 31;
+    const uint32_t m0 = (2u << b0) - 1u;
+    const int N = P.n_tracks, na = P.n_set0;
+    const int pad_lo = NR / 2 - N / 2;
+    const uint32_t *vals = (const uint32_t *) P.value;
+    uint32_t cov[NR / 32];
+#pragma unroll
+    for (int q = 0; q < NR / 32; q++) cov[q] = 0;
+    wt_static_for<0, NR>([&](auto sc) {         // A: issue every load
+        constexpr int s = decltype(sc)::value;
+        const int i = wt_regcol_track<OP, NR>(s, N, na, pad_lo);
+        uint32_t raw = 0;
+        if (i >= 0) {                           // workgroup-uniform
+            const uint64_t scw = c.SC[(size_t) i * P.spitch + w32];
+            unsigned r = (unsigned) c.cnt[(size_t) i * P.cpitch + w32] + (unsigned) wt_popc32((uint32_t) scw & m0);
+            r = r ? r : 1u;                     // nothing started yet: not covered, the value is unused
+            raw = vals[c.gbase[i] + (long long) r];
+            cov[s >> 5] |= (((uint32_t) (scw >> 32) >> b0) & 1u) << (s & 31);
+        }
+        if constexpr (s < H) col[s] = raw; else col2[s - H] = raw;
+    });
+    bool nan = false;
+    wt_static_for<0, NR>([&](auto sc) {         // B: defaults, NaN, keys
+        constexpr int s = decltype(sc)::value;
+        const int i = wt_regcol_track<OP, NR>(s, N, na, pad_lo);
+        uint32_t v = OP == WT_OP_MEDIAN ? (s < pad_lo ? 0u : 0xffffffffu) : 0x7fc00000u;
+        if (i >= 0) {
+            uint32_t raw;
+            if constexpr (s < H) raw = col[s]; else raw = col2[s - H];
+            const uint32_t m = 0u - ((cov[s >> 5] >> (s & 31)) & 1u);
+            const uint32_t xb = (raw & m) | (__builtin_bit_cast(uint32_t, c.dflt32[i]) & ~m);
+            const float x = __builtin_bit_cast(float, xb);
+            nan |= wt_isnanf(x);
+            v = OP == WT_OP_MEDIAN ? wt_key32(x) : xb;
+        }
+        if constexpr (s < H) col[s] = v; else col2[s - H] = v;
+    });
+    return nan;
+}
+#else
 template <int OP, class ValT, int NR>
 WT_DEV bool wt_gather_regs(const WtParams &P, const WtCtx &c, int p0, uint32_t *col, uint32_t *col2) {
     const int w32 = p0 >> 5, b0 = p0 & 31;
@@ -876,6 +937,8 @@ WT_DEV bool wt_gather_regs(const WtParams &P, const WtCtx &c, int p0, uint32_t *
     }
     return nan;
 }
+
+#endif  // WT_REGCOL_FLAT
 
 // MWU over a register column (wt_gather_regs): set 0 sorted by a register network and parked in
 // this lane's LDS column (n_set0 * 4 B -- the only LDS the reducer needs); then ONE pass over the

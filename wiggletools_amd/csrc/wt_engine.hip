@@ -84,6 +84,8 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
     // MI355X; any instruction between the two regions hides it).  So the next ticket is taken in the
     // same lane-0 block as the statistics, followed by the barrier that publishes it.
     if (tid == 0) c.sh->ticket = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+    if (NR > 0)
+        for (int i = tid; i < P.n_tracks; i += nt) c.dflt32[i] = (float) P.defaults[i];
     __syncthreads();
     for (;;) {
         WT_MARK(1);

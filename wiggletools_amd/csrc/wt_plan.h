@@ -23,6 +23,7 @@ struct WtPlan {
     int off_acc = 0, off_ev = 0, off_ltv = 0, off_ltc = 0, off_gtv = 0, off_gtc = 0, off_tbase = 0, off_tpfx = 0, off_tfirst = 0, off_dsh = 0;
     bool delta = false;     // difference-array plan (wt_delta.h)
     int off_S = 0, off_cnt = 0, off_segtot = 0, off_U = 0, off_cover = 0, off_E = 0, off_epfx = 0, off_nextw = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
+    int off_dflt32 = 0;
     int lds_bytes = 0;
     int scratch_elem = 0;   // bytes per scratch element (0: op needs no scratch)
     long long scratch_slab = 0;   // > 0: scratch columns in global memory, this many bytes per workgroup
@@ -58,6 +59,7 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
     p.off_epfx = o;    o = wt_align16(o + (p.n_words + 1) * 4);
     p.off_nextw = o;   o = wt_align16(o + p.n_words * 2);
     p.off_gbase = o;   o = wt_align16(o + chunk * 8);
+    p.off_dflt32 = o;  if (regcol) o = wt_align16(o + n_tracks * 4);
     p.off_scratch = o;
     long long scr_bytes = 0;
     if (op == WT_OP_MEDIAN || op == WT_OP_MWU) scr_bytes = (long long) n_tracks * W * scratch_elem;    // one column per position
@@ -144,11 +146,12 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
                                 int soft_limit = 80 * 1024, int hard_limit = 160 * 1024, int n_set0 = 0) {
     const char *eP = getenv("WTAMD_PPT");
     if (const int nr = wt_regcol_slots(n_tracks, op, scratch_f32, n_set0)) {
-        // 256 lanes, several positions per lane evaluated one after the other: LDS holds the bitmaps
-        // only (+ MWU's sorted set 0, one column per lane).  Median: 4 positions (window 1024 bp); MWU: 2
-        // (512 bp) -- its set-0 column leaves less room for bitmaps if two workgroups are to share a CU.
+        // 256 lanes, two positions per lane evaluated one after the other (window 512 bp): LDS holds the
+        // bitmaps only (+ MWU's sorted set 0, one column per lane).  Measured on chromosome-sized
+        // items (MI355X, 100 tracks): median 13.1 ms per 31 Mbp with 2 positions per lane, 44 ms with 4
+        // (and 19 vs 18 ms on cache-resident 0.4 Mbp probes, which hide it), 30.4 ms with LDS columns.
         WtPlan p;
-        const int kk = op == WT_OP_MEDIAN ? 4 : 2;
+        const int kk = 2;
         wt_carve(n_tracks, op, 256 * kk, 256, 4, p, 0, false, nr, n_set0);
         p.ppt = kk;
         p.lanes_per_pos = 1;
@@ -243,6 +246,7 @@ static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     while ((1 << P.logW) < p.W) P.logW++;
     P.off_S = p.off_S; P.off_cnt = p.off_cnt; P.off_segtot = p.off_segtot; P.off_U = p.off_U; P.off_cover = p.off_cover; P.off_E = p.off_E;
     P.off_epfx = p.off_epfx; P.off_nextw = p.off_nextw; P.off_gbase = p.off_gbase; P.off_scratch = p.off_scratch;
+    P.off_dflt32 = p.off_dflt32;
     P.off_acc = p.off_acc; P.off_ev = p.off_ev; P.off_ltv = p.off_ltv; P.off_ltc = p.off_ltc;
     P.off_gtv = p.off_gtv; P.off_gtc = p.off_gtc; P.off_tbase = p.off_tbase; P.off_tpfx = p.off_tpfx; P.off_tfirst = p.off_tfirst; P.off_dsh = p.off_dsh;
     P.off_shared = p.off_shared; P.lds_bytes = p.lds_bytes;
@@ -333,9 +337,9 @@ template <class F>
 static inline bool wt_dispatch(int op, bool value_f64, bool scratch_f32, int ppt, bool multi, F &f, int regcol = 0) {
     if (regcol && (op == WT_OP_MEDIAN || op == WT_OP_MWU) && !value_f64 && scratch_f32 && !multi) {
         if (op == WT_OP_MEDIAN) {
-            if (regcol == 32) f.template run<WT_OP_MEDIAN, float, float, 4, false, 32>();
-            else if (regcol == 64) f.template run<WT_OP_MEDIAN, float, float, 4, false, 64>();
-            else f.template run<WT_OP_MEDIAN, float, float, 4, false, 128>();
+            if (regcol == 32) f.template run<WT_OP_MEDIAN, float, float, 2, false, 32>();
+            else if (regcol == 64) f.template run<WT_OP_MEDIAN, float, float, 2, false, 64>();
+            else f.template run<WT_OP_MEDIAN, float, float, 2, false, 128>();
         } else {
             if (regcol == 32) f.template run<WT_OP_MWU, float, float, 2, false, 32>();
             else if (regcol == 64) f.template run<WT_OP_MWU, float, float, 2, false, 64>();

@@ -77,10 +77,12 @@ __device__ __forceinline__ bool ws_run(const WsArgs &A, const WsKey &k, int32_t 
     return (uint32_t) g >= A.gap_thresh;
 }
 
-__global__ void __launch_bounds__(WS_BLOCK) ws_count_kernel(const WsArgs A, long long *counts) {
+// (grid-stride over the blocks: HIP caps a launch at 2^32 threads -- 500 tracks x chromosome 1 are 30 M blocks)
+__global__ void __launch_bounds__(WS_BLOCK) ws_count_kernel(const WsArgs A, long long *counts, long long n_blocks) {
+  for (long long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
     int c, t;
     int32_t x0;
-    ws_locate(A, blockIdx.x, c, t, x0);
+    ws_locate(A, blk, c, t, x0);
     const WsKey k = ws_key(A, c, t);
     const int32_t len = A.chrom_len[c];
     int n = 0;
@@ -98,15 +100,18 @@ __global__ void __launch_bounds__(WS_BLOCK) ws_count_kernel(const WsArgs A, long
     if (threadIdx.x == 0) {
         int tot = 0;
         for (int w = 0; w < WS_BLOCK / 64; w++) tot += wsum[w];
-        counts[blockIdx.x] = tot;
+        counts[blk] = tot;
     }
+    __syncthreads();
+  }
 }
 
 __global__ void __launch_bounds__(WS_BLOCK) ws_fill_kernel(const WsArgs A, const long long *block_off, int32_t *start,
-                                                            int32_t *finish, float *value) {
+                                                            int32_t *finish, float *value, long long n_blocks) {
+  for (long long blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
     int c, t;
     int32_t x0;
-    ws_locate(A, blockIdx.x, c, t, x0);
+    ws_locate(A, blk, c, t, x0);
     const WsKey k = ws_key(A, c, t);
     const int32_t len = A.chrom_len[c];
     const int32_t xa = x0 + (int32_t) threadIdx.x * WS_PER_LANE;
@@ -134,7 +139,7 @@ __global__ void __launch_bounds__(WS_BLOCK) ws_fill_kernel(const WsArgs A, const
     __syncthreads();
     int before = incl - n;
     for (int w = 0; w < (int) (threadIdx.x >> 6); w++) before += wsum[w];
-    long long g = block_off[blockIdx.x] + before;
+    long long g = block_off[blk] + before;
     // pass 2: a run ends at the next breakpoint (inside the lane's 16 positions, or scanned for)
     while (keepmask) {
         const int q = __ffs(keepmask) - 1;
@@ -156,6 +161,8 @@ __global__ void __launch_bounds__(WS_BLOCK) ws_fill_kernel(const WsArgs A, const
         value[g] = v;
         g++;
     }
+    __syncthreads();
+  }
 }
 
 int ws_args(unsigned long long seed, int n_chrom, const int32_t *chrom_len, int n_tracks, double mean_run, double gap_prob,
@@ -175,7 +182,6 @@ int ws_args(unsigned long long seed, int n_chrom, const int32_t *chrom_len, int 
     }
     A.chrom_block_off[n_chrom] = off;
     n_blocks = off;
-    if (off >= (1ll << 31)) return wt_fail_ext(WTAMD_ERR_ARG, "wtamd_synth: too many blocks for one launch (generate fewer chromosomes at a time)");
     return WTAMD_OK;
 }
 
@@ -208,7 +214,8 @@ int wtamd_synth_count(uint64_t seed, int n_chrom, const int32_t *chrom_len, int 
     long long nb = 0;
     const int rc = ws_args(seed, n_chrom, chrom_len, n_tracks, mean_run, gap_prob, levels, A, nb);
     if (rc != WTAMD_OK) return rc;
-    hipLaunchKernelGGL(ws_count_kernel, dim3((unsigned) nb), dim3(WS_BLOCK), 0, (hipStream_t) stream, A, (long long *) counts);
+    hipLaunchKernelGGL(ws_count_kernel, dim3((unsigned) (nb < (1ll << 22) ? nb : (1ll << 22))), dim3(WS_BLOCK), 0, (hipStream_t) stream, A,
+                       (long long *) counts, nb);
     if (hipGetLastError() != hipSuccess) return wt_fail_ext(WTAMD_ERR_HIP, "wtamd_synth_count: launch failed");
     return WTAMD_OK;
 }
@@ -220,8 +227,8 @@ int wtamd_synth_fill(uint64_t seed, int n_chrom, const int32_t *chrom_len, int n
     long long nb = 0;
     const int rc = ws_args(seed, n_chrom, chrom_len, n_tracks, mean_run, gap_prob, levels, A, nb);
     if (rc != WTAMD_OK) return rc;
-    hipLaunchKernelGGL(ws_fill_kernel, dim3((unsigned) nb), dim3(WS_BLOCK), 0, (hipStream_t) stream, A,
-                       (const long long *) block_off, start, finish, value);
+    hipLaunchKernelGGL(ws_fill_kernel, dim3((unsigned) (nb < (1ll << 22) ? nb : (1ll << 22))), dim3(WS_BLOCK), 0, (hipStream_t) stream, A,
+                       (const long long *) block_off, start, finish, value, nb);
     if (hipGetLastError() != hipSuccess) return wt_fail_ext(WTAMD_ERR_HIP, "wtamd_synth_fill: launch failed");
     return WTAMD_OK;
 }
