@@ -105,6 +105,7 @@ struct EmuRun {
 
     template <int OP>
     void run_delta() {
+        constexpr bool QQ = OP == WT_OP_VAR || OP == WT_OP_STDDEV || OP == WT_OP_ENTROPY || OP == WT_OP_CV;
         WtCtx c;
         wt_ctx_init(c, P, lds.data());
         WtDeltaCtx d;
@@ -117,7 +118,7 @@ struct EmuRun {
             const long long k = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
             if (k >= P.n_windows) break;
             wt_phase_header(P, c, k);
-            for (int t = 0; t < T; t++) wt_delta_zero(P, c, d, t, T);
+            for (int t = 0; t < T; t++) wt_delta_zero<QQ>(P, c, d, t, T);
             const int nchunks = (P.n_tracks + T - 1) / T;
             auto ranges = [&](int ch) {
                 for (int t = 0; t < T; t++) wt_delta_ranges1(P, c, d, ch * T, t, T);
@@ -135,30 +136,30 @@ struct EmuRun {
                 if (!ok) wt_delta_mark_bad(P, c, k);
                 for (int ch = 0; ch < nchunks; ch++) {
                     if (nchunks > 1) ranges(ch);
-                    for (int t = 0; t < T; t++) wt_delta_pass2(P, c, d, scale, ok, false, true, t, T);
+                    for (int t = 0; t < T; t++) wt_delta_pass2<QQ>(P, c, d, scale, ok, false, true, t, T);
                 }
                 if (any && ok) guess = scale;
             } else {                // speculative single pass with the workgroup's unit
                 for (int ch = 0; ch < nchunks; ch++) {
                     ranges(ch);
-                    for (int t = 0; t < T; t++) wt_delta_pass2(P, c, d, guess, true, true, true, t, T);
+                    for (int t = 0; t < T; t++) wt_delta_pass2<QQ>(P, c, d, guess, true, true, true, t, T);
                 }
                 int lo; bool ok;
                 scale = guess;
                 if (!wt_delta_window_verdict(P, d, guess, lo, ok)) {
                     n_redo++;
-                    for (int t = 0; t < T; t++) wt_delta_rezero(P, c, d, t, T);
+                    for (int t = 0; t < T; t++) wt_delta_rezero<QQ>(P, c, d, t, T);
                     if (!ok) wt_delta_mark_bad(P, c, k);
                     for (int ch = 0; ch < nchunks; ch++) {
                         if (nchunks > 1) ranges(ch);
-                        for (int t = 0; t < T; t++) wt_delta_pass2(P, c, d, lo, ok, false, false, t, T);
+                        for (int t = 0; t < T; t++) wt_delta_pass2<QQ>(P, c, d, lo, ok, false, false, t, T);
                     }
                     scale = lo;
                     if (ok) guess = lo;
                 }
             }
-            for (int t = 0; t < T; t++) wt_delta_scan1(P, c, d, dl[t], t, T);
-            for (int t = 0; t < T; t++) wt_delta_scan2(P, c, d, t, T);
+            for (int t = 0; t < T; t++) wt_delta_scan1<QQ>(P, c, d, dl[t], t, T);
+            for (int t = 0; t < T; t++) wt_delta_scan2<QQ>(P, c, d, t, T);
             for (int t = 0; t < T; t++) wt_delta_scan3<OP>(P, c, d, dl[t], lanes[t], scale, t, T);
             for (int t = 0; t < T; t++) wt_delta_nextw(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
@@ -203,7 +204,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         if (attempt == 0 && !delta) continue;
         EmuRun R;
         std::string err;
-        if (delta) wt_make_delta_plan(R.plan, n_tracks);
+        if (delta) wt_make_delta_plan(R.plan, n_tracks, wt_op_is_var_family(op));
         else if (!wt_make_plan(n_tracks, op, s32, R.plan, err, 80 * 1024, 160 * 1024, n_set0)) { fprintf(stderr, "wtemu: %s\n", err.c_str()); return -10; }
         WtWindowTables tab;
         wt_make_windows(n_chrom, n_tracks, seg_off, fs.data(), lf.data(), R.plan.W, tab, range_lo, range_hi);
@@ -257,7 +258,13 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         R.lds.assign((size_t) R.plan.lds_bytes + 64, 0);
         if (total > 0) {
             if (delta) {
-                if (op == WT_OP_SUM) R.run_delta<WT_OP_SUM>(); else R.run_delta<WT_OP_MEAN>();
+                switch (op) {
+                case WT_OP_SUM: R.run_delta<WT_OP_SUM>(); break;
+                case WT_OP_MEAN: R.run_delta<WT_OP_MEAN>(); break;
+                case WT_OP_VAR: R.run_delta<WT_OP_VAR>(); break;
+                case WT_OP_CV: R.run_delta<WT_OP_CV>(); break;
+                default: R.run_delta<WT_OP_STDDEV>(); break;
+                }
             } else if (!wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R.plan.n_chunks > 1 || R.plan.scratch_slab > 0, R, R.plan.regcol)) {
                 return -11;
             }

@@ -6,6 +6,7 @@ import pytest
 
 from helpers import ALL_MULTIPLEX_OPS, assert_runs_equal, random_case
 from emu import emu
+from wiggletools_amd.runlists import synth
 
 # values: sum/mean/min/max/median are bit-exact by construction (same op order);
 # var/stddev/cv go through sqrt/div in the same order as well -> bit-exact on CPU.
@@ -428,7 +429,9 @@ def test_plan_policy_snapshot():
     p = plan(100, "max")
     assert (p["W"], p["T"], p["n_chunks"]) == (2048, 512, 1)             # bitmaps of 100 tracks: half the LDS
     p = plan(500, "var")
-    assert (p["W"], p["T"]) == (2048, 512) and p["n_chunks"] == 5        # chunks of <= 112 tracks
+    assert (p["delta"], p["W"], p["T"]) == (1, 2048, 256)                # round 2: difference arrays with exact squares
+    p = plan(500, "var", no_delta=1)
+    assert (p["W"], p["T"]) == (2048, 512) and p["n_chunks"] == 5        # general kernel: chunks of <= 112 tracks
     p = plan(100, "median")
     assert (p["W"], p["T"], p["lds"] < 32 * 1024) == (512, 256, True) and p["scratch_slab"] == 0     # round 2: value column in REGISTERS, LDS = bitmaps only, 2 positions per lane
     p = plan(100, "mwu", n_set0=50)
@@ -445,3 +448,44 @@ def test_plan_policy_snapshot():
     assert p["delta"] == 0 and p["W"] == 2048                            # f64 tracks: general kernel
     p = plan(1000, "median")
     assert p["scratch_slab"] > 0                                         # columns in a global slab
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_emu_delta_var_family(oracle, seed):
+    """Var / StdDev / Entropy / CV over float tracks with zero defaults: difference arrays with exact
+    integer sum and sum of squares (wt_delta.h, WT_DELTA_QSHIFT) against the oracle's two sequential
+    f64 passes (reducers.c:428-479, 511-563, 672-725), 1e-12; coordinates bit-exact."""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([8, 9, 16, 33, 100, 200]))
+    t = synth(n, [int(rng.integers(200, 5000)), 300], mean_run=float(rng.choice([1, 3, 16, 60])), seed=seed,
+              gap_prob=float(rng.choice([0, 0.05, 0.5])), dtype=np.float32, value_levels=int(rng.choice([2, 800])))
+    if seed % 3 == 0:       # several binades of dynamic range, values that are not multiples of 1/8
+        t.value[:] = (t.value * rng.choice([1e-3, 1.0, 37.5], len(t.value))).astype(np.float32)
+    d = t.as_dict()
+    for op in ("var", "stddev", "cv", "entropy"):
+        for strict in (0, 1):
+            got, info = emu.reduce(t, op, flags=strict)
+            assert info["delta"] == 1, (op, info)
+            assert_runs_equal(got, oracle.reduce(d, op, flags=strict), 1e-12, "%s strict %d" % (op, strict))
+
+
+def test_emu_delta_var_family_patched_windows(oracle):
+    """NaN, Inf and a dynamic range beyond the exactness bound in a few windows: those windows are
+    recomputed by the general kernel's two passes (wt_patch_kernel), the rest stays on the exact path."""
+    t = synth(12, [30000], mean_run=9, seed=5, dtype=np.float32)
+    v = t.value
+    v[100] = np.nan
+    v[len(v) // 2] = np.inf
+    v[len(v) // 3] = 2.0 ** -120
+    v[len(v) // 3 + 1] = 2.0 ** 100
+    d = t.as_dict()
+    for op in ("var", "stddev", "cv"):
+        got, info = emu.reduce(t, op)
+        assert info["patched"] > 0 and info["delta"] == 1, info
+        assert_runs_equal(got, oracle.reduce(d, op), 1e-12, op)
+    # fewer than 8 tracks, non-zero defaults, f64 values: general kernel
+    t8 = synth(7, [3000], mean_run=5, seed=1, dtype=np.float32)
+    assert emu.reduce(t8, "var")[1]["delta"] == 0
+    t9 = synth(9, [3000], mean_run=5, seed=1, dtype=np.float32)
+    t9.defaults[2] = 1.0
+    assert emu.reduce(t9, "stddev")[1]["delta"] == 0

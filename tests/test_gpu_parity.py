@@ -417,6 +417,37 @@ def test_gpu_pearson_moments_per_chromosome_merge(oracle, engine):
     assert acc[0] == sum(r[0] for r in rows)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_gpu_difference_array_var_family(oracle, engine, seed):
+    """Var / StdDev / Entropy / CV over float tracks with zero defaults run the difference-array
+    kernel with exact integer sum and sum of squares (wt_delta.h, WT_DELTA_QSHIFT); the oracle does the
+    reference's two sequential f64 passes (reducers.c:428-479, 511-563, 672-725).  1e-12 relative,
+    coordinates bit-exact; strict and not; NaN / Inf / huge dynamic range windows patched."""
+    from wiggletools_amd.runlists import synth
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([8, 16, 33, 100, 500]))
+    t = synth(n, [int(rng.integers(2000, 60000)), 900], mean_run=float(rng.choice([1, 3, 16, 60])), seed=seed,
+              gap_prob=float(rng.choice([0, 0.05, 0.5])), dtype=np.float32, value_levels=int(rng.choice([2, 800])))
+    if seed % 3 == 0:
+        t.value[:] = (t.value * rng.choice([1e-3, 1.0, 37.5], len(t.value))).astype(np.float32)
+    if seed % 4 == 1:
+        t.value[7] = np.nan
+        t.value[len(t.value) // 2] = np.inf
+        t.value[len(t.value) // 3] = 2.0 ** -120
+        t.value[len(t.value) // 3 + 1] = 2.0 ** 100
+    d = t.as_dict()
+    ts = engine.TrackSet.from_runlists(t)
+    for op in ("var", "stddev", "cv", "entropy"):
+        for strict in (0, 1):
+            got = ts.reduce_host(op, flags=strict)
+            st = ts.stats()
+            assert st["kernel"] == 1, (op, st)
+            if seed % 4 == 1:
+                assert st["patched_windows"] > 0
+            assert_runs_equal(got, oracle.reduce(d, op, flags=strict), 1e-12, "%s strict %d" % (op, strict))
+    ts.close()
+
+
 def test_gpu_input_contract_validation(engine):
     """wtamd_trackset_validate: zero-length, inverted and overlapping runs are counted; a run list
     may start a new (chrom, track) segment below the previous segment's last finish."""

@@ -114,6 +114,8 @@ struct WtParams {
     int32_t cpitch;               // u16 entries per cnt_i row (W/32, even)
     int32_t off_S, off_cnt, off_segtot, off_U, off_cover, off_E, off_epfx, off_nextw, off_gbase, off_scratch, off_shared;
     int32_t off_acc, off_ev, off_ltv, off_ltc, off_gtv, off_gtc, off_tbase, off_tpfx, off_tfirst, off_dsh;   // difference-array path (wt_delta.h)
+    int32_t off_qa, off_ltq, off_gtq;   // ... its sum-of-squares accumulators (var / stddev / CV)
+    int32_t delta_q;                    // != 0: the launch accumulates squares too
     int32_t off_dflt32;           // register-column median / MWU: float copy of defaults[] in LDS (filled once per workgroup)
     int32_t lds_bytes;
 };

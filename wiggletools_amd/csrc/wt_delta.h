@@ -40,12 +40,28 @@
 #endif
 #define WT_DELTA_TILE (64 * WT_DELTA_U)
 #define WT_DELTA_TF 2048        // tiles whose first track is tabulated (beyond: binary search)
+#define WT_MAX_DELTA_T 512      // largest workgroup of the difference-array kernels
 
 struct WtDeltaShared {
     long long base_v;           // scaled sum of the intervals spanning w0
     int32_t base_c;             // their number
     int32_t emin, emax, bad;    // exponent range of the window's non-zero values, NaN/Inf seen
+    unsigned long long base_qa, base_qb;    // squares of the intervals spanning w0 (split, see WT_DELTA_QSHIFT)
 };
+
+// Var / StdDev / CV by difference arrays (round 2).  Beside S = sum of the scaled mantissas m_i of
+// the tracks in play, the window accumulates Q = sum of m_i^2 -- exactly: m_i < 2^53 / N (the span
+// test), so m_i^2 < 2^106 / N^2 does not fit 64 bits; it is split at bit WT_DELTA_QSHIFT into
+// a = m^2 >> 40 and b = m^2 & (2^40 - 1), accumulated in two u64 arrays (sums of at most N terms:
+// < 2^66 / N and < N * 2^40; N >= 8 is required) with wrap-around subtraction at the run's finish.
+// Per position, in 128-bit integers and with n = tracks in play:
+//   var    (reducers.c:428-479: mean over all N, squares over the tracks IN PLAY only)
+//          sum (mean - v)^2 = q^2 / N^2 * [ N^2 Q - (2N - n) S^2 ]
+//   stddev (reducers.c:511-563; entropy runs the same pop, :665: absent tracks enter as 0)
+//          sum (mean - x)^2 = q^2 / N   * [ N Q - S^2 ]
+// so the only roundings are the final conversions -- the reference's two sequential f64 passes
+// carry ~N ulp of their own; agreement is ~1e-14 relative (tests: 1e-12), coordinates bit-exact.
+#define WT_DELTA_QSHIFT 40
 
 struct WtDeltaCtx {
     long long *acc;             // [W] scaled value deltas
@@ -57,6 +73,9 @@ struct WtDeltaCtx {
     long long *tbase;           // [T] global index of the first interval of the chunk's track t in this window
     uint32_t *tpfx;             // [T + 1] exclusive prefix of the tracks' interval counts (flat index space)
     uint16_t *tfirst;           // [WT_DELTA_TF] first track of every tile of the flat space
+    unsigned long long *qa, *qb;        // [W] each: deltas of the squares' high / low parts (delta_q launches)
+    unsigned long long *ltqa, *ltqb;    // [T] lane totals
+    unsigned long long *gtqa, *gtqb;    // [T / 16] group (emulator) / wave (device) totals
     WtDeltaShared *dsh;
 };
 
@@ -67,6 +86,8 @@ struct WtDeltaLane {
     uint32_t evmask;            // bit k: position k is a true breakpoint
     long long wv;               // device: sum of the value deltas of the wave's lanes before this one
     int32_t wc;                 // device: same for the coverage deltas
+    unsigned long long pqa[WT_DELTA_K], pqb[WT_DELTA_K];    // delta_q launches: inclusive prefixes of the squares' parts
+    unsigned long long wqa, wqb;
 };
 
 WT_DEV void wt_delta_ctx_init(WtDeltaCtx &d, const WtParams &P, char *lds) {
@@ -79,6 +100,12 @@ WT_DEV void wt_delta_ctx_init(WtDeltaCtx &d, const WtParams &P, char *lds) {
     d.tbase = (long long *) (lds + P.off_tbase);
     d.tpfx = (uint32_t *) (lds + P.off_tpfx);
     d.tfirst = (uint16_t *) (lds + P.off_tfirst);
+    d.qa = (unsigned long long *) (lds + P.off_qa);
+    d.qb = d.qa + P.W;
+    d.ltqa = (unsigned long long *) (lds + P.off_ltq);
+    d.ltqb = d.ltqa + WT_MAX_DELTA_T;
+    d.gtqa = (unsigned long long *) (lds + P.off_gtq);
+    d.gtqb = d.gtqa + WT_MAX_DELTA_T / WT_DELTA_GROUP;
     d.dsh = (WtDeltaShared *) (lds + P.off_dsh);
 }
 
@@ -99,12 +126,28 @@ WT_DEV int wt_delta_max_span(int n_tracks) {
     return 29 - lg;
 }
 
+template <bool QQ = false>
 WT_DEV void wt_delta_zero(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
     for (int x = tid; x < P.W; x += nt) { d.acc[x] = 0; d.ev[x] = 0; }
+    if constexpr (QQ)
+        for (int x = tid; x < P.W; x += nt) { d.qa[x] = 0; d.qb[x] = 0; }
     if (tid == 0) {
         d.dsh->base_v = 0; d.dsh->base_c = 0;
+        if constexpr (QQ) { d.dsh->base_qa = 0; d.dsh->base_qb = 0; }
         d.dsh->emin = 255; d.dsh->emax = 0; d.dsh->bad = 0;
     }
+}
+
+// m^2 split at bit WT_DELTA_QSHIFT (m = |scaled mantissa| < 2^53)
+WT_DEV void wt_delta_square(unsigned long long m, unsigned long long &a, unsigned long long &b) {
+#ifdef WT_EMU
+    const unsigned __int128 sq = (unsigned __int128) m * m;
+    const unsigned long long hi = (unsigned long long) (sq >> 64), lo = (unsigned long long) sq;
+#else
+    const unsigned long long hi = __umul64hi(m, m), lo = m * m;
+#endif
+    a = (hi << (64 - WT_DELTA_QSHIFT)) | (lo >> WT_DELTA_QSHIFT);
+    b = lo & ((1ull << WT_DELTA_QSHIFT) - 1ull);
 }
 
 // ---- the window's intervals as ONE flat index space ----
@@ -227,6 +270,7 @@ WT_DEV bool wt_delta_verdict(const WtParams &P, const WtDeltaCtx &d, int &emin) 
     return !d.dsh->bad && (hi - lo) <= wt_delta_max_span(P.n_tracks);
 }
 
+template <bool QQ = false>
 WT_DEV void wt_delta_apply(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t s, int32_t f, uint32_t vb,
                            int emin, bool ok, int32_t &my_next) {
     const int32_t w0 = c.sh->w0, w1 = c.sh->w1;
@@ -240,6 +284,12 @@ WT_DEV void wt_delta_apply(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t s
         wt_lds_add32(&d.ev[s - w0], 1u);
         wt_lds_add64((unsigned long long *) &d.acc[f - w0], (unsigned long long) (-vi));
         wt_lds_add32(&d.ev[f - w0], 0x10000u);
+        if (QQ && vi) {
+            unsigned long long a, b;
+            wt_delta_square((unsigned long long) (vi < 0 ? -vi : vi), a, b);
+            wt_lds_add64(&d.qa[s - w0], a); wt_lds_add64(&d.qb[s - w0], b);
+            wt_lds_add64(&d.qa[f - w0], 0ull - a); wt_lds_add64(&d.qb[f - w0], 0ull - b);
+        }
         return;
     }
     if (f == w0) { wt_lds_add32(&d.ev[0], 0x00010001u); return; }    // true breakpoint at w0, covers nothing here
@@ -250,18 +300,23 @@ WT_DEV void wt_delta_apply(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t s
     long long vi = 0;
     if (ok && m) vi = (long long) ((unsigned long long) m << ((e ? e : 1) - emin));
     if (vb >> 31) vi = -vi;
+    unsigned long long qa = 0, qb = 0;
+    if (QQ && vi) wt_delta_square((unsigned long long) (vi < 0 ? -vi : vi), qa, qb);
     if (s < w0) {                               // spans w0: part of the window's base, not a breakpoint
         wt_lds_add64((unsigned long long *) &d.dsh->base_v, (unsigned long long) vi);
         wt_lds_addi32(&d.dsh->base_c, 1);
+        if (QQ && vi) { wt_lds_add64(&d.dsh->base_qa, qa); wt_lds_add64(&d.dsh->base_qb, qb); }
     } else {
         const int cs = s - w0;
         if (vi) wt_lds_add64((unsigned long long *) &d.acc[cs], (unsigned long long) vi);
         wt_lds_add32(&d.ev[cs], 1u);
+        if (QQ && vi) { wt_lds_add64(&d.qa[cs], qa); wt_lds_add64(&d.qb[cs], qb); }
     }
     if (f < w1) {
         const int cf = f - w0;
         if (vi) wt_lds_add64((unsigned long long *) &d.acc[cf], (unsigned long long) (-vi));
         wt_lds_add32(&d.ev[cf], 0x10000u);
+        if (QQ && vi) { wt_lds_add64(&d.qa[cf], 0ull - qa); wt_lds_add64(&d.qb[cf], 0ull - qb); }
     } else {
         my_next = f < my_next ? f : my_next;
     }
@@ -290,6 +345,7 @@ WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint3
 // `scale`: exponent of one unit of the scaled mantissas; `ok`: false -> the window is known not to be
 // exact (only coordinates matter); `collect`: also gather the exponent range of the values (the
 // speculative single-pass flavour, see wt_delta_window_verdict); `stats`: count the intervals.
+template <bool QQ = false>
 WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale, bool ok, bool collect, bool stats,
                            int tid, int nt) {
     const int wave = tid >> 6, lane = tid & 63, nwaves = nt >> 6;
@@ -314,7 +370,7 @@ WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale
                 emax = (nz && e > emax) ? e : emax;
                 // speculative pass: a value below the guessed unit would lose bits -- it is added as 0
                 // here and the window is redone (wt_delta_window_verdict)
-                wt_delta_apply(P, c, d, cur.s[u], cur.f[u], vb, scale, ok && e >= scale, my_next);
+                wt_delta_apply<QQ>(P, c, d, cur.s[u], cur.f[u], vb, scale, ok && e >= scale, my_next);
             }
         cur = nxt;
     }
@@ -359,12 +415,19 @@ WT_DEV void wt_delta_note_offset(const WtParams &P, WtCtx &c) {
 }
 
 // redo of a window: clear the accumulators only (the exponent range is kept)
+template <bool QQ = false>
 WT_DEV void wt_delta_rezero(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
     for (int x = tid; x < P.W; x += nt) { d.acc[x] = 0; d.ev[x] = 0; }
-    if (tid == 0) { d.dsh->base_v = 0; d.dsh->base_c = 0; }
+    if constexpr (QQ)
+        for (int x = tid; x < P.W; x += nt) { d.qa[x] = 0; d.qb[x] = 0; }
+    if (tid == 0) {
+        d.dsh->base_v = 0; d.dsh->base_c = 0;
+        if constexpr (QQ) { d.dsh->base_qa = 0; d.dsh->base_qb = 0; }
+    }
 }
 
 // scan step 1: the lane's 8 positions
+template <bool QQ = false>
 WT_DEV void wt_delta_scan1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLane &L, int tid, int nt) {
     const int p0 = tid * WT_DELTA_K;
     long long rv = 0;
@@ -382,9 +445,19 @@ WT_DEV void wt_delta_scan1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLa
     L.evmask = evm;
     d.ltv[tid] = rv;
     d.ltc[tid] = rc;
+    if constexpr (QQ) {
+        unsigned long long ra = 0, rb = 0;
+#pragma unroll
+        for (int k = 0; k < WT_DELTA_K; k++) {
+            ra += d.qa[p0 + k]; rb += d.qb[p0 + k];
+            L.pqa[k] = ra; L.pqb[k] = rb;
+        }
+        d.ltqa[tid] = ra; d.ltqb[tid] = rb;
+    }
 }
 
 // scan step 2: group totals (one lane per group of 16)
+template <bool QQ = false>
 WT_DEV void wt_delta_scan2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
     const int ngroups = nt / WT_DELTA_GROUP;
     if (tid >= ngroups) return;
@@ -396,6 +469,11 @@ WT_DEV void wt_delta_scan2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, 
     }
     d.gtv[tid] = sv;
     d.gtc[tid] = sc;
+    if constexpr (QQ) {
+        unsigned long long sa = 0, sb = 0;
+        for (int x = 0; x < WT_DELTA_GROUP; x++) { sa += d.ltqa[tid * WT_DELTA_GROUP + x]; sb += d.ltqb[tid * WT_DELTA_GROUP + x]; }
+        d.gtqa[tid] = sa; d.gtqb[tid] = sb;
+    }
 }
 
 // scan step 3: running sum / coverage of every position, breakpoint and emitted bytes, run values
@@ -404,14 +482,25 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
                            WtLane<WT_DELTA_K> &out, int emin, int tid, int nt) {
     long long bv = d.dsh->base_v;
     int32_t bc = d.dsh->base_c;
+    constexpr bool QQ = OP == WT_OP_VAR || OP == WT_OP_STDDEV || OP == WT_OP_ENTROPY || OP == WT_OP_CV;
+    unsigned long long bqa = QQ ? d.dsh->base_qa : 0ull, bqb = QQ ? d.dsh->base_qb : 0ull;
 #ifdef WT_EMU
     const int grp = tid / WT_DELTA_GROUP;
     for (int x = 0; x < grp; x++) { bv += d.gtv[x]; bc += d.gtc[x]; }
     for (int x = grp * WT_DELTA_GROUP; x < tid; x++) { bv += d.ltv[x]; bc += d.ltc[x]; }
+    if (QQ) {
+        for (int x = 0; x < grp; x++) { bqa += d.gtqa[x]; bqb += d.gtqb[x]; }
+        for (int x = grp * WT_DELTA_GROUP; x < tid; x++) { bqa += d.ltqa[x]; bqb += d.ltqb[x]; }
+    }
 #else
     for (int x = 0; x < (tid >> 6); x++) { bv += d.gtv[x]; bc += d.gtc[x]; }   // waves before this one (wt_delta_scan_w1)
     bv += L.wv;
     bc += L.wc;
+    if (QQ) {
+        for (int x = 0; x < (tid >> 6); x++) { bqa += d.gtqa[x]; bqb += d.gtqb[x]; }
+        bqa += L.wqa;
+        bqb += L.wqb;
+    }
 #endif
     const int N = P.n_tracks;
     const bool strict = (P.flags & WT_STRICT_SET0) != 0;
@@ -425,8 +514,32 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
         const int32_t cov = bc + L.pc[k];
         const bool pred = strict ? (cov == N) : (cov > 0);       // multiplexer.c:120,125
         if (((L.evmask >> k) & 1u) && pred && k < room) em |= 1u << k;
-        const double s = (double) (bv + L.pv[k]) * q;
-        out.res[k] = (OP == WT_OP_MEAN) ? s / N : s;
+        if constexpr (!QQ) {
+            const double s = (double) (bv + L.pv[k]) * q;
+            out.res[k] = (OP == WT_OP_MEAN) ? s / N : s;
+        } else {
+            // exact integers: S, n = cov, Q = (A << 40) + B (see WT_DELTA_QSHIFT)
+            const long long S = bv + L.pv[k];
+            const unsigned long long sa = (unsigned long long) (S < 0 ? -S : S);
+            const unsigned __int128 Q = ((unsigned __int128) (bqa + L.pqa[k]) << WT_DELTA_QSHIFT) + (unsigned __int128) (bqb + L.pqb[k]);
+            const unsigned __int128 s2 = (unsigned __int128) sa * sa;
+            unsigned __int128 I;
+            if (OP == WT_OP_VAR) I = (unsigned __int128) ((unsigned long long) N * (unsigned long long) N) * Q - (unsigned __int128) (unsigned long long) (2 * N - cov) * s2;
+            else I = (unsigned __int128) (unsigned long long) N * Q - s2;
+            const double Id = (double) (unsigned long long) (I >> 64) * 18446744073709551616.0 + (double) (unsigned long long) I;
+            double r;
+            if (OP == WT_OP_VAR) {
+                r = Id * q * q / ((double) N * (double) N) / N;                 // reducers.c:476  sum / count
+                if (N < 2) r = wt_nan();                                      // :464
+            } else {
+                r = sqrt(Id * q * q / N / N);                                 // :558  sqrt(sum / count)
+                if (OP == WT_OP_CV) {
+                    const double mean = (double) S * q / N;
+                    r = mean == 0 ? wt_nan() : r / mean;                      // :707-711
+                }
+            }
+            out.res[k] = r;
+        }
     }
     ((uint8_t *) c.U)[tid] = (uint8_t) L.evmask;
     ((uint8_t *) c.E)[tid] = (uint8_t) em;
@@ -534,8 +647,9 @@ WT_DEV void wt_delta_ranges_w2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int t
 }
 
 // value / coverage scan, step 1: the lane's 8 positions + the wave-level prefix
+template <bool QQ = false>
 WT_DEV void wt_delta_scan_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLane &L, int tid, int nt) {
-    wt_delta_scan1(P, c, d, L, tid, nt);
+    wt_delta_scan1<QQ>(P, c, d, L, tid, nt);
     const int lane = tid & 63;
     const long long rv = L.pv[WT_DELTA_K - 1];
     const int32_t rc = L.pc[WT_DELTA_K - 1];
@@ -544,6 +658,14 @@ WT_DEV void wt_delta_scan_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDelta
     L.wv = iv - rv;
     L.wc = ic - rc;
     if (lane == 63) { d.gtv[tid >> 6] = iv; d.gtc[tid >> 6] = ic; }
+    if constexpr (QQ) {
+        const unsigned long long ra = L.pqa[WT_DELTA_K - 1], rb = L.pqb[WT_DELTA_K - 1];
+        const unsigned long long ia = (unsigned long long) wt_wave_scan_i64((long long) ra, lane);
+        const unsigned long long ib = (unsigned long long) wt_wave_scan_i64((long long) rb, lane);
+        L.wqa = ia - ra;
+        L.wqb = ib - rb;
+        if (lane == 63) { d.gtqa[tid >> 6] = ia; d.gtqb[tid >> 6] = ib; }
+    }
 }
 
 // escan on wave 0: run-count prefix of the emitted bitmap; returns the window's run count

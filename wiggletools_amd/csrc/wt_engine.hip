@@ -198,13 +198,16 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
 
 // Exact difference-array path for Sum / Mean over float tracks (wt_delta.h): O(intervals) work
 // instead of O(tracks x runs); LDS independent of the track count.
+// (var / stddev / CV also accumulate the sum of squares: 256 lanes, two waves per SIMD)
+#define WT_DELTA_SQ(OP) ((OP) == WT_OP_VAR || (OP) == WT_OP_STDDEV || (OP) == WT_OP_ENTROPY || (OP) == WT_OP_CV)
 template <int OP>
-__global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParams P) {
+__global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? 256 : WT_MAX_BLOCK, WT_DELTA_SQ(OP) ? 2 : 4) wt_delta_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
     wt_ctx_init(c, P, wt_lds);
     WtDeltaCtx d;
     wt_delta_ctx_init(d, P, wt_lds);
+    constexpr bool QQ = WT_DELTA_SQ(OP);
     WtDeltaLane DL;
     WtLane<WT_DELTA_K> L;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
         k_dbg = k;
         if (k >= P.n_windows) break;
         const int nchunks = (P.n_tracks + nt - 1) / nt;
-        wt_delta_zero(P, c, d, tid, nt);
+        wt_delta_zero<QQ>(P, c, d, tid, nt);
         WT_TICK(0);
         WT_MARK(102);
         int scale = 1;
@@ -255,7 +258,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
                     wt_delta_ranges_w2(P, c, d, tid, nt);
                     __syncthreads();
                 }
-                wt_delta_pass2(P, c, d, scale, ok, false, true, tid, nt);
+                wt_delta_pass2<QQ>(P, c, d, scale, ok, false, true, tid, nt);
                 __syncthreads();
                 WT_TICK(3);
             }
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
                 wt_delta_ranges_w2(P, c, d, tid, nt);
                 __syncthreads();
                 WT_TICK(1);
-                wt_delta_pass2(P, c, d, guess, true, true, true, tid, nt);
+                wt_delta_pass2<QQ>(P, c, d, guess, true, true, true, tid, nt);
                 __syncthreads();
                 WT_TICK(3);
             }
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
             scale = guess;
             if (!wt_delta_window_verdict(P, d, guess, lo, ok)) {      // workgroup-uniform
                 __syncthreads();            // every lane has read the verdict fields
-                wt_delta_rezero(P, c, d, tid, nt);
+                wt_delta_rezero<QQ>(P, c, d, tid, nt);
                 if (!ok && tid == 0) wt_delta_mark_bad(P, c, k);
                 __syncthreads();
                 for (int ch = 0; ch < nchunks; ch++) {
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
                         wt_delta_ranges_w2(P, c, d, tid, nt);
                         __syncthreads();
                     }
-                    wt_delta_pass2(P, c, d, lo, ok, false, false, tid, nt);
+                    wt_delta_pass2<QQ>(P, c, d, lo, ok, false, false, tid, nt);
                     __syncthreads();
                 }
                 scale = lo;
@@ -295,7 +298,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, 4) wt_delta_kernel(const WtParam
             }
         }
         WT_MARK(105);
-        wt_delta_scan_w1(P, c, d, DL, tid, nt);
+        wt_delta_scan_w1<QQ>(P, c, d, DL, tid, nt);
         __syncthreads();
         WT_MARK(107);
         wt_delta_scan3<OP>(P, c, d, DL, L, scale, tid, nt);
@@ -380,6 +383,9 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_patch_kernel
             if (tid == 0) wt_phase_header(P, c, k);
             wt_phase_zero(P, c, true, tid, nt);
             __syncthreads();
+            // same sweeps as wt_reduce_kernel (chunked tracks: the first evaluation pass rides on the
+            // sweep that builds the bitmaps; var / stddev / CV take a second one)
+            constexpr int npass = wt_eval_passes(OP);
             WtAcc<K> A;
             wt_eval_init<OP, K>(A);
             for (int cc = 0; cc < n_chunks; cc++) {
@@ -394,18 +400,37 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_patch_kernel
                 __syncthreads();
                 wt_phase_count_b(P, c, t_lo, t_hi, tid, nt);
                 __syncthreads();
-                if (MULTI) {        // Sum / Mean are single-pass: the evaluation rides on the sweep
+                if (MULTI) {
                     wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, A, 0, t_lo, t_hi, true, tid, nt);
                     __syncthreads();
                 }
             }
+            if (MULTI && npass == 2) wt_eval_mid<OP, K>(P, A);
             wt_phase_emask(P, c, false, tid, nt);
             __syncthreads();
             wt_phase_escan(P, c, tid, nt);
             __syncthreads();
             const long long n_emit = (long long) c.epfx[P.n_words];
             if (tid == 0) { c.sh->n_emit = (int32_t) n_emit; c.sh->goffset = goff; }
-            if (!MULTI) wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, A, 0, 0, N, false, tid, nt);
+#pragma unroll
+            for (int pass = MULTI ? 1 : 0; pass < npass; pass++) {
+                for (int cc = 0; cc < n_chunks; cc++) {
+                    const int t_lo = cc * NC, t_hi = (t_lo + NC < N) ? t_lo + NC : N;
+                    if (MULTI) {
+                        wt_phase_zero(P, c, false, tid, nt);
+                        __syncthreads();
+                        wt_phase_load<ValT>(P, c, t_lo, t_hi, false, tid, nt);
+                        __syncthreads();
+                        wt_phase_count_a(P, c, t_lo, t_hi, tid, nt);
+                        __syncthreads();
+                        wt_phase_count_b(P, c, t_lo, t_hi, tid, nt);
+                        __syncthreads();
+                    }
+                    wt_phase_eval_chunk<OP, ValT, ScrT, K>(P, c, A, pass, t_lo, t_hi, false, tid, nt);
+                    if (MULTI) __syncthreads();
+                }
+                if (pass == 0 && npass == 2) wt_eval_mid<OP, K>(P, A);
+            }
             wt_phase_eval_finish<OP, ValT, ScrT, K>(P, c, A, L, tid, nt);
             __syncthreads();
             wt_phase_write<OP, ValT, K>(P, c, L, tid, nt);
@@ -997,7 +1022,7 @@ int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
     }
     WtPlan plan;
     std::string err;
-    if (wt_wants_delta(ts, op)) wt_make_delta_plan(plan, ts->n_tracks);
+    if (wt_wants_delta(ts, op)) wt_make_delta_plan(plan, ts->n_tracks, wt_op_is_var_family(op));
     // (two-sample ops: the index only depends on the window width; the usual even split is assumed)
     else if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err, 80 * 1024, 160 * 1024, ts->n_tracks / 2)) return wt_fail(WTAMD_ERR_ARG, err);
     WtWindows *w = nullptr;
@@ -1144,9 +1169,15 @@ static int wt_launch_patch(wtamd_trackset *ts, int delta_W, int op, uint32_t fla
     if (op == WT_OP_SUM) {
         if (plan.ppt == 4) { if (multi) WT_PATCH_GO(WT_OP_SUM, 4, true); else WT_PATCH_GO(WT_OP_SUM, 4, false); }
         else { if (multi) WT_PATCH_GO(WT_OP_SUM, 1, true); else WT_PATCH_GO(WT_OP_SUM, 1, false); }
-    } else {
+    } else if (op == WT_OP_MEAN) {
         if (plan.ppt == 4) { if (multi) WT_PATCH_GO(WT_OP_MEAN, 4, true); else WT_PATCH_GO(WT_OP_MEAN, 4, false); }
         else { if (multi) WT_PATCH_GO(WT_OP_MEAN, 1, true); else WT_PATCH_GO(WT_OP_MEAN, 1, false); }
+    } else {
+        // var / stddev / entropy / CV: 4 positions per lane only (what the plans pick unless forced)
+        if (plan.ppt != 4) return wt_fail(WTAMD_ERR_INTERNAL, "no general plan compatible with the difference-array windows");
+        if (op == WT_OP_VAR) { if (multi) WT_PATCH_GO(WT_OP_VAR, 4, true); else WT_PATCH_GO(WT_OP_VAR, 4, false); }
+        else if (op == WT_OP_CV) { if (multi) WT_PATCH_GO(WT_OP_CV, 4, true); else WT_PATCH_GO(WT_OP_CV, 4, false); }
+        else { if (multi) WT_PATCH_GO(WT_OP_STDDEV, 4, true); else WT_PATCH_GO(WT_OP_STDDEV, 4, false); }
     }
 #undef WT_PATCH_GO
     if (e != hipSuccess) return wt_fail(WTAMD_ERR_HIP, std::string("patch kernel launch: ") + hipGetErrorString(e));
@@ -1169,7 +1200,7 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
     // once per track set -- that first launch is waited for even when the caller asked for an
     // asynchronous one -- and later launches (patch included) need no host round trip.
     if (!d_tile && wt_wants_delta(ts, op)) {
-        wt_make_delta_plan(plan, ts->n_tracks);
+        wt_make_delta_plan(plan, ts->n_tracks, wt_op_is_var_family(op));
         int64_t n_probe = 0;
         const bool probe = !ts->delta_verified;
         const int rc = wt_reduce_plan(ts, plan, op, flags, n_set0, runs, d_tile, d_inplay,
@@ -1238,7 +1269,13 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
         WT_HIP(hipMemsetAsync(w->d_status, 0, sizeof(unsigned long long) * w->tab.n_windows, s));
         WT_HIP(hipEventRecord(ts->ev_r0, s));
         if (plan.delta) {
-            if (op == WT_OP_SUM) wt_launch_delta<WT_OP_SUM>(L); else wt_launch_delta<WT_OP_MEAN>(L);
+            switch (op) {
+            case WT_OP_SUM: wt_launch_delta<WT_OP_SUM>(L); break;
+            case WT_OP_MEAN: wt_launch_delta<WT_OP_MEAN>(L); break;
+            case WT_OP_VAR: wt_launch_delta<WT_OP_VAR>(L); break;
+            case WT_OP_CV: wt_launch_delta<WT_OP_CV>(L); break;
+            default: wt_launch_delta<WT_OP_STDDEV>(L); break;      // stddev, entropy (reducers.c:665)
+            }
         } else if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, plan.n_chunks > 1 || plan.scratch_slab > 0, L, plan.regcol)) {
             return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
         }

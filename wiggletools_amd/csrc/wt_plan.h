@@ -21,6 +21,7 @@ struct WtPlan {
     int chunk_tracks = 0, n_chunks = 1;   // tracks resident in LDS at a time / number of chunks
     int lanes_per_pos = 1;  // MWU: lanes of a workgroup sharing one window position (T = lanes_per_pos * W, K = 1)
     int off_acc = 0, off_ev = 0, off_ltv = 0, off_ltc = 0, off_gtv = 0, off_gtc = 0, off_tbase = 0, off_tpfx = 0, off_tfirst = 0, off_dsh = 0;
+    int off_qa = 0, off_ltq = 0, off_gtq = 0, delta_q = 0;
     bool delta = false;     // difference-array plan (wt_delta.h)
     int off_S = 0, off_cnt = 0, off_segtot = 0, off_U = 0, off_cover = 0, off_E = 0, off_epfx = 0, off_nextw = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
     int off_dflt32 = 0;
@@ -80,9 +81,15 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
 // does not depend on the track count.  WTAMD_DELTA_T overrides the workgroup size (tests).
 // Measured on MI355X (scale 0.01 probes, kernel + index ms at T = 256 / 512): mean of 100 tracks
 // 1.43+0.37 / 1.35+0.31, sum of 1000 tracks 9.2+3.5 / 8.4+2.8: the widest window wins here too.
-static inline void wt_make_delta_plan(WtPlan &p, int n_tracks) {
+static inline bool wt_op_is_var_family(int op) {
+    return op == WT_OP_VAR || op == WT_OP_STDDEV || op == WT_OP_ENTROPY || op == WT_OP_CV;
+}
+
+// `squares`: the launch also accumulates the sum of squares (var / stddev / CV): two more u64 arrays
+// per position, so the window is halved (W = 2048, 256 lanes) to keep two workgroups per CU.
+static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = false) {
     const char *eT = getenv("WTAMD_DELTA_T");
-    int T = eT ? atoi(eT) : 512;
+    int T = eT ? atoi(eT) : (squares ? 256 : 512);
     (void) n_tracks;
     if (T < 64 || T > 512 || (T & (T - 1))) T = 512;
     p = WtPlan();
@@ -104,6 +111,12 @@ static inline void wt_make_delta_plan(WtPlan &p, int n_tracks) {
     p.off_tpfx = o;   o = wt_align16(o + (T + 1) * 4);
     p.off_tfirst = o; o = wt_align16(o + WT_DELTA_TF * 2);
     p.off_dsh = o;    o = wt_align16(o + (int) sizeof(WtDeltaShared));
+    p.delta_q = squares ? 1 : 0;
+    if (squares) {
+        p.off_qa = o;  o = wt_align16(o + 2 * p.W * 8);
+        p.off_ltq = o; o = wt_align16(o + 2 * WT_MAX_DELTA_T * 8);
+        p.off_gtq = o; o = wt_align16(o + 2 * (WT_MAX_DELTA_T / WT_DELTA_GROUP) * 8);
+    }
     p.off_shared = o; o = wt_align16(o + (int) sizeof(WtShared));
     p.lds_bytes = o;
 }
@@ -112,7 +125,9 @@ static inline void wt_make_delta_plan(WtPlan &p, int n_tracks) {
 // path (the kernel still verifies every window's exponent range).
 static inline bool wt_delta_eligible(int op, bool value_f64, int n_tracks, const double *defaults) {
     if (getenv("WTAMD_NO_DELTA")) return false;
-    if (op != WT_OP_SUM && op != WT_OP_MEAN) return false;
+    const bool sq = wt_op_is_var_family(op);
+    if (op != WT_OP_SUM && op != WT_OP_MEAN && !sq) return false;
+    if (sq && (n_tracks < 8 || getenv("WTAMD_NO_DELTA_VAR"))) return false;     // (the split square accumulators need N >= 8)
     // a handful of tracks: nothing to gain over the general kernel
     // (measured: 10 tracks 0.77 general vs 0.53 ms difference array; 100 tracks 2.05 vs 1.33)
     const char *eM = getenv("WTAMD_DELTA_MIN_TRACKS");
@@ -249,6 +264,7 @@ static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.off_dflt32 = p.off_dflt32;
     P.off_acc = p.off_acc; P.off_ev = p.off_ev; P.off_ltv = p.off_ltv; P.off_ltc = p.off_ltc;
     P.off_gtv = p.off_gtv; P.off_gtc = p.off_gtc; P.off_tbase = p.off_tbase; P.off_tpfx = p.off_tpfx; P.off_tfirst = p.off_tfirst; P.off_dsh = p.off_dsh;
+    P.off_qa = p.off_qa; P.off_ltq = p.off_ltq; P.off_gtq = p.off_gtq; P.delta_q = p.delta_q;
     P.off_shared = p.off_shared; P.lds_bytes = p.lds_bytes;
 }
 
