@@ -441,8 +441,10 @@ def test_gpu_difference_array_var_family(oracle, engine, seed):
         for strict in (0, 1):
             got = ts.reduce_host(op, flags=strict)
             st = ts.stats()
-            assert st["kernel"] == 1, (op, st)
-            if seed % 4 == 1:
+            # (25 binades of dynamic range at 500 tracks exceed the exactness bound in most windows:
+            #  the whole launch is then redone by the general kernel -- also a path worth covering)
+            assert st["kernel"] == 1 or seed % 3 == 0, (op, st)
+            if seed % 4 == 1 and st["kernel"] == 1:
                 assert st["patched_windows"] > 0
             assert_runs_equal(got, oracle.reduce(d, op, flags=strict), 1e-12, "%s strict %d" % (op, strict))
     ts.close()
