@@ -241,6 +241,47 @@ def e2e_dropin(op, n_tracks, mean_run, mbp, device):
     return out
 
 
+def _bw_write_one(args):
+    from wiggletools_amd import bwwrite
+    path, L, s, f, v = args
+    return bwwrite.write_arrays(path, {"chr1": L}, {"chr1": (s - 1, f - 1, v)})
+
+
+def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
+    """FILES to result: N BigWig files (written here, untimed, from the same generator) -> the
+    library's BigWiggleReader (one decoding thread per file) -> newMultiplexer -> <op>Reduction ->
+    runs on the host.  What `wiggletools <op> *.bw` does in the reference (commandParser.c ->
+    bigWiggleReader.c -> multiplexer.c -> reducers.c), minus the text writer."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from wiggletools_amd import dropin, synthgen
+    L = int(mbp * 1e6)
+    seg, s, f, v = synthgen.device_tracks(SEED, [L], n_tracks, mean_run, 0.02, 800, device, chrom_ids=[41])
+    hs, hf, hv = s.cpu().numpy(), f.cpu().numpy(), v.cpu().numpy()
+    del s, f, v
+    d = tempfile.mkdtemp(prefix="wtamd_bw_")
+    try:
+        jobs = [(os.path.join(d, "t%03d.bw" % t), L + 1, hs[int(seg[t]):int(seg[t + 1])], hf[int(seg[t]):int(seg[t + 1])],
+                 hv[int(seg[t]):int(seg[t + 1])]) for t in range(n_tracks)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max(1, min(effective_cores(), 16))) as ex:     # zlib releases the GIL
+            list(ex.map(_bw_write_one, jobs))
+        write_s = time.perf_counter() - t0
+        size = sum(os.path.getsize(j[0]) for j in jobs)
+        t0 = time.perf_counter()
+        r = dropin.reducer(op, [dropin.bigwig_reader(j[0], box=True) for j in jobs], n_set0=n_tracks // 2)
+        runs, _ = dropin.drain_blocks(r)
+        dt = time.perf_counter() - t0
+        return {"tracks": n_tracks, "op": op, "bp": L, "seconds": dt, "bp_per_s": L / dt, "runs": runs,
+                "intervals": int(seg[-1]), "intervals_per_s": int(seg[-1]) / dt, "file_bytes": size,
+                "file_MBs": size / dt / 1e6, "decode_threads": n_tracks, "host_cores": effective_cores(),
+                "files_written_s": write_s,
+                "note": "bound by the host-side zlib decode (one producer thread per file on the cores above)"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 # ---------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -258,6 +299,7 @@ def main():
     ap.add_argument("--no-many-core", action="store_true")
     ap.add_argument("--chroms", default=None, help="experiments: only these chromosomes of the configuration (comma separated indices)")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-bw-mbp", type=float, default=8.0, help="region of the BigWig-files-to-result leg (0: skip)")
     ap.add_argument("--e2e-mbp", type=float, default=100.0, help="chromosome length of the end-to-end (drop-in layer) leg")
     args = ap.parse_args()
 
@@ -468,6 +510,11 @@ def main():
                 res["e2e"] = e2e_dropin(ops[-1], N, args.mean_run, args.e2e_mbp * min(1.0, 100.0 / N) * (args.scale if args.scale < 1 else 1.0), device)
             except Exception as e:      # never lose the bench line to an extra leg
                 res["e2e"] = {"error": repr(e)[:300]}
+            if args.e2e_bw_mbp > 0:
+                try:
+                    res["e2e_bigwig"] = e2e_bigwig(ops[-1], N, args.mean_run, args.e2e_bw_mbp * min(1.0, 100.0 / N) * (args.scale if args.scale < 1 else 1.0), device)
+                except Exception as e:
+                    res["e2e_bigwig"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             lens = [chrom_lens[c] for c in chrom_ids]
             cb = cpu_baseline(chrom_ids, ops[-1], N, args.mean_run, lens, many_core=not args.no_many_core)

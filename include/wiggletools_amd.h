@@ -464,6 +464,12 @@ void wtamd_host_free(void *);
 WiggleIterator *wtamd_ArrayReader(int n_chrom, const char *const *chrom_names, const int64_t *seg_off,
                                   const int32_t *start, const int32_t *finish, const float *value,
                                   double default_value);
+/* BigWig reader: the role of the reference's BigWiggleReader (src/bigWiggleReader.c:147-151) on this
+ * library's own section decoder -- chromosomes in strcmp order, 1-based starts, box != 0: intervals
+ * cut at the reference reader's 10 000-bp stretch edges (what `write_bg` parity needs); one producer
+ * thread per file decodes the next chromosome while the current one is consumed.  Bulk-capable.
+ * A file that is not BigWig: the reference's message and exit(1). */
+WiggleIterator *wtamd_BigWiggleReader(const char *path, int box);
 /* Consumer door, for reducers built by this library: the runs from the iterator's current element
  * to the end of the batch it belongs to, as arrays valid until the next call on `wi`.  Returns the
  * number of runs (0 and wi->done at the end).  Mixes freely with pop(). */

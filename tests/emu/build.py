@@ -23,13 +23,13 @@ def build_dropin(force=False):
     so = os.path.join(HERE, "libwt_dropin_emu.so")
     csrc = os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc")
     srcs = [os.path.join(HERE, "wt_emu.cpp"), os.path.join(HERE, "wt_pipe_emu.cpp"),
-            os.path.join(csrc, "wt_iter_abi.cpp"), os.path.join(csrc, "wt_defaults.cpp")]
+            os.path.join(csrc, "wt_iter_abi.cpp"), os.path.join(csrc, "wt_defaults.cpp"), os.path.join(csrc, "wt_bigwig.cpp")]
     deps = srcs + [os.path.join(csrc, "wt_core.h"), os.path.join(csrc, "wt_plan.h"), os.path.join(csrc, "wt_delta.h"),
                    os.path.join(HERE, "..", "..", "include", "wiggletools_amd.h")]
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in deps):
         return so
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
-                           "-Wno-unused-function", "-o", so] + srcs + ["-lm"])
+                           "-Wno-unused-function", "-o", so] + srcs + ["-lm", "-lz", "-lpthread"])
     return so
 
 

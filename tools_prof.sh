@@ -4,7 +4,7 @@
 # data generator launches thousands of torch kernels).
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
-ARGS="${BENCH_ARGS:---scale 0.05 --steps 5 --warmup 1 --no-cpu-baseline}"
+ARGS="${BENCH_ARGS:---steps 2 --warmup 1 --no-cpu-baseline --no-e2e}"
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python $R/bench.py $ARGS > $OUT/stats_run.log 2>&1

@@ -40,7 +40,11 @@
 #include <algorithm>
 #include <chrono>
 #include <deque>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/wiggletools_amd.h"
@@ -94,6 +98,9 @@ struct Interner {
 struct BulkSource {
     int64_t (*peek)(BulkSource *, const int32_t **start, const int32_t **finish, const float **value);
     void (*advance)(BulkSource *, WiggleIterator *, int64_t k);
+    // true: the arrays peek() points into never move or change (wtamd_ArrayReader) -- they may be read
+    // by the device later, where they lie; false: valid until the next advance() only (copied at once)
+    bool stable;
 };
 
 void wt_bulk_pop(WiggleIterator *wi) {
@@ -162,7 +169,7 @@ struct Feeder {
         min_span = env_i64("WTAMD_MIN_SPAN", kFirstSpan);       // tests cut every few bp to stress the seams
         use_bulk = !getenv("WTAMD_NO_BULK");
         all_bulk = !src.empty();
-        for (const auto &s : src) all_bulk = all_bulk && s.bulk != nullptr;
+        for (const auto &s : src) all_bulk = all_bulk && s.bulk != nullptr && s.bulk->stable;
         if (getenv("WTAMD_MIN_SPAN")) first_span = min_span;
         span = first_span < max_runs ? first_span : max_runs;
         if (wtamd_pipe_create(&cfg, &pipe) != WTAMD_OK) die("wtamd_pipe_create");
@@ -631,6 +638,197 @@ void arr_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
 }
 
 // ---------------------------------------------------------------------------
+// BigWig reader (bulk-capable child iterator) -- what the reference gets from libBigWig through
+// src/bigWiggleReader.c:52-123 + the producer thread of src/bufferedReader.c:118-134, on top of
+// this library's own section decoder (wt_bigwig.cpp): chromosomes in strcmp order (:91-101),
+// 1-based starts (:39-40), intervals boxed to 10 000-bp stretches (:42-44,73-83), float values.
+// One producer thread per file decodes the NEXT chromosome into the idle one of two SoA buffers
+// while the current one is being consumed -- whole chromosomes instead of the reference's
+// 10 000-entry blocks, the same role.  The buffers are recycled, so the source is not `stable`: the
+// Multiplexer copies each block into its pinned staging as it takes it (a memcpy, far cheaper than
+// the zlib decode that produced it).
+// ---------------------------------------------------------------------------
+struct BwBuffer {
+    int32_t *start = nullptr, *finish = nullptr;
+    float *value = nullptr;
+    int64_t cap = 0, n = 0;
+    int chrom = -1;             // index into BwReader::names, -1: nothing decoded
+};
+
+struct BwReader {
+    BulkSource hdr;             // must stay first
+    wtamd_bw *bw = nullptr;
+    std::vector<std::string> names;     // chromosomes in strcmp order
+    std::vector<char *> cnames;         // stable char* per chromosome
+    int box = 1;
+    BwBuffer buf[2];
+    int cur = 0;                // buffer being consumed
+    int64_t j = 0, end = 0;     // position / end inside it
+    bool done = false;
+    // window after seek(): one chromosome, clipped
+    bool windowed = false;
+    int32_t win_start = 0, win_finish = 0;
+    int32_t e_start = 0, e_finish = 0;
+    float e_value = 0;
+    // producer
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    int want = -1;              // chromosome index the producer should decode next into buffer `want_buf` (-1: idle)
+    int want_buf = 0;
+    bool ready = false, quit = false, failed = false;
+
+    bool clipped(int64_t g) const {
+        const BwBuffer &b = buf[cur];
+        return windowed && (b.start[g] < win_start || b.finish[g] > win_finish);
+    }
+};
+
+void bw_free(BwBuffer &b) {
+    free(b.start); free(b.finish); free(b.value);
+    b.start = b.finish = nullptr; b.value = nullptr; b.cap = 0;
+}
+
+bool bw_alloc(BwBuffer &b, int64_t cap) {
+    bw_free(b);
+    b.start = (int32_t *) malloc(sizeof(int32_t) * (size_t) cap);
+    b.finish = (int32_t *) malloc(sizeof(int32_t) * (size_t) cap);
+    b.value = (float *) malloc(sizeof(float) * (size_t) cap);
+    if (!b.start || !b.finish || !b.value) return false;
+    b.cap = cap;
+    return true;
+}
+
+void bw_decode(BwReader *r, int ci, BwBuffer &b) {
+    b.chrom = ci;
+    b.n = 0;
+    if (b.cap == 0 && !bw_alloc(b, 1 << 16)) { r->failed = true; return; }
+    int64_t n = wtamd_bw_read_chrom(r->bw, r->names[(size_t) ci].c_str(), r->box, b.cap, b.start, b.finish, b.value);
+    if (n > b.cap) {
+        if (!bw_alloc(b, n + n / 8)) { r->failed = true; return; }
+        n = wtamd_bw_read_chrom(r->bw, r->names[(size_t) ci].c_str(), r->box, b.cap, b.start, b.finish, b.value);
+    }
+    if (n < 0) { r->failed = true; return; }
+    b.n = n;
+}
+
+void bw_producer(BwReader *r) {
+    std::unique_lock<std::mutex> lk(r->mu);
+    for (;;) {
+        r->cv.wait(lk, [&] { return r->quit || r->want >= 0; });
+        if (r->quit) return;
+        const int ci = r->want, bi = r->want_buf;
+        lk.unlock();
+        bw_decode(r, ci, r->buf[bi]);
+        lk.lock();
+        r->want = -1;
+        r->ready = true;
+        r->cv.notify_all();
+    }
+}
+
+// asks the producer for chromosome ci in buffer bi (non-blocking)
+void bw_request(BwReader *r, int ci, int bi) {
+    std::lock_guard<std::mutex> lk(r->mu);
+    r->ready = false;
+    r->want = ci;
+    r->want_buf = bi;
+    r->cv.notify_all();
+}
+
+void bw_wait(BwReader *r) {
+    std::unique_lock<std::mutex> lk(r->mu);
+    r->cv.wait(lk, [&] { return r->ready; });
+    if (r->failed) { fprintf(stderr, "wiggletools_amd: BigWig decode failed\n"); exit(1); }
+}
+
+// moves to the next chromosome that has intervals (buffers alternate; the one after it is requested
+// right away so that its decode overlaps the consumption of this one)
+void bw_next_chrom(BwReader *r, WiggleIterator *wi, int ci) {
+    const int n = (int) r->names.size();
+    while (ci < n) {
+        bw_wait(r);             // the producer was asked for `ci` into the idle buffer when the previous one started
+        r->cur ^= 1;
+        if (ci + 1 < n) bw_request(r, ci + 1, r->cur ^ 1);
+        if (r->buf[r->cur].n > 0) {
+            r->j = 0; r->end = r->buf[r->cur].n;
+            return;
+        }
+        ci++;
+    }
+    r->done = true;
+    wi->done = 1;
+}
+
+void bw_settle(BwReader *r, WiggleIterator *wi) {
+    if (!r->done && r->j >= r->end) {
+        if (r->windowed) { r->done = true; }
+        else bw_next_chrom(r, wi, r->buf[r->cur].chrom + 1);
+    }
+    if (r->done) { wi->done = 1; return; }
+    const BwBuffer &b = r->buf[r->cur];
+    wi->chrom = r->cnames[(size_t) b.chrom];
+    wi->start = b.start[r->j]; wi->finish = b.finish[r->j];
+    if (r->clipped(r->j)) {
+        if (wi->start < r->win_start) wi->start = r->win_start;
+        if (wi->finish > r->win_finish) wi->finish = r->win_finish;
+    }
+    wi->value = (double) b.value[r->j];
+}
+
+int64_t bw_peek(BulkSource *bs, const int32_t **s, const int32_t **f, const float **v) {
+    BwReader *r = (BwReader *) bs;
+    if (r->done || r->j >= r->end) return 0;
+    const BwBuffer &b = r->buf[r->cur];
+    if (r->clipped(r->j)) {
+        r->e_start = b.start[r->j] < r->win_start ? r->win_start : b.start[r->j];
+        r->e_finish = b.finish[r->j] > r->win_finish ? r->win_finish : b.finish[r->j];
+        r->e_value = b.value[r->j];
+        *s = &r->e_start; *f = &r->e_finish; *v = &r->e_value;
+        return 1;
+    }
+    int64_t k = r->end;
+    if (r->windowed && k - 1 > r->j && r->clipped(k - 1)) k--;
+    *s = b.start + r->j; *f = b.finish + r->j; *v = b.value + r->j;
+    return k - r->j;
+}
+
+void bw_advance(BulkSource *bs, WiggleIterator *wi, int64_t k) {
+    BwReader *r = (BwReader *) bs;
+    if (r->done) { wi->done = 1; return; }
+    r->j += k;
+    bw_settle(r, wi);
+}
+
+void bw_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
+    // bigWiggleReader.c:125-145: the producer is restarted on [start, finish) of that chromosome;
+    // the first interval is clipped to `start` (:143-144), the stretches end at `finish`
+    BwReader *r = (BwReader *) wi->data;
+    r->windowed = true;
+    r->win_start = start; r->win_finish = finish;
+    r->done = true;
+    wi->done = 0;
+    int ci = -1;
+    for (size_t c = 0; c < r->names.size(); c++)
+        if (r->names[c] == chrom) ci = (int) c;
+    if (ci < 0) { wi->done = 1; return; }
+    if (r->buf[r->cur].chrom != ci) {
+        bw_wait(r);                         // whatever the producer is decoding lands first
+        if (r->buf[r->cur ^ 1].chrom != ci) {
+            bw_request(r, ci, r->cur ^ 1);
+            bw_wait(r);
+        }
+        r->cur ^= 1;
+    }
+    const BwBuffer &b = r->buf[r->cur];
+    r->j = std::upper_bound(b.finish, b.finish + b.n, start) - b.finish;       // first finish > start
+    r->end = std::lower_bound(b.start, b.start + b.n, finish) - b.start;       // first start >= finish
+    r->done = r->j >= r->end;
+    if (r->done) { wi->done = 1; return; }
+    bw_settle(r, wi);
+}
+
+// ---------------------------------------------------------------------------
 // Select / FillIn: host iterators over popMultiplexer (reference reducers.c:41-119)
 // ---------------------------------------------------------------------------
 struct SelData { Multiplexer *multi; int index; wt_bool trim; };
@@ -942,6 +1140,7 @@ WiggleIterator *wtamd_ArrayReader(int n_chrom, const char *const *chrom_names, c
     ArrReader *a = new (calloc(1, sizeof(ArrReader))) ArrReader();     // free()-able, like every iterator's data
     a->hdr.peek = &arr_peek;
     a->hdr.advance = &arr_advance;
+    a->hdr.stable = true;
     a->n_chrom = n_chrom;
     a->names = (char **) calloc((size_t) (n_chrom > 0 ? n_chrom : 1), sizeof(char *));
     a->seg_off = (int64_t *) calloc((size_t) n_chrom + 1, sizeof(int64_t));
@@ -975,6 +1174,34 @@ int64_t wtamd_iterator_next_block(WiggleIterator *wi, const char **chrom, const 
     R->cur = F.res.n_runs;
     R->block_done = true;
     return n;
+}
+
+WiggleIterator *wtamd_BigWiggleReader(const char *path, int box) {
+    wtamd_bw *bw = nullptr;
+    if (wtamd_bw_open(path, &bw) != WTAMD_OK) exit(1);     // message printed (bigWiggleReader.c:116-118)
+    BwReader *r = new BwReader();
+    r->hdr.peek = &bw_peek;
+    r->hdr.advance = &bw_advance;
+    r->hdr.stable = false;
+    r->bw = bw;
+    r->box = box;
+    for (int i = 0; i < wtamd_bw_n_chrom(bw); i++) r->names.push_back(wtamd_bw_chrom_name(bw, i));
+    std::sort(r->names.begin(), r->names.end(), [](const std::string &a, const std::string &b) { return strcmp(a.c_str(), b.c_str()) < 0; });
+    for (const std::string &n : r->names) r->cnames.push_back(strdup(n.c_str()));
+    r->th = std::thread(bw_producer, r);
+    r->th.detach();                             // lives for the process, like the reference's reader threads
+    WiggleIterator *wi = (WiggleIterator *) calloc(1, sizeof(WiggleIterator));
+    wi->data = r;
+    wi->pop = &wt_bulk_pop;
+    wi->seek = &bw_seek;
+    wi->value = 1;
+    wi->default_value = 0;                      // bigWiggleReader.c:150
+    if (r->names.empty()) { r->done = true; wi->done = 1; return wi; }
+    r->cur = 1;                                 // first chromosome goes to buffer 0
+    bw_request(r, 0, 0);
+    bw_next_chrom(r, wi, 0);
+    if (!r->done) bw_settle(r, wi);
+    return wi;
 }
 
 int wtamd_iterator_compress_output(WiggleIterator *wi, int on) {

@@ -25,6 +25,8 @@ def _bind():
     L.wtamd_host_free.restype = None
     L.wtamd_ArrayReader.restype = C.c_void_p
     L.wtamd_ArrayReader.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+    L.wtamd_BigWiggleReader.restype = C.c_void_p
+    L.wtamd_BigWiggleReader.argtypes = [C.c_char_p, C.c_int]
     L.newMultiplexer.restype = C.c_void_p
     L.newMultiplexer.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char]
     L.newMultiset.restype = C.c_void_p
@@ -67,6 +69,11 @@ def array_reader(chrom_names, seg_off, start_ptr, finish_ptr, value_ptr, default
     names = (C.c_char_p * len(chrom_names))(*[n.encode() for n in chrom_names])
     so = np.ascontiguousarray(seg_off, np.int64)
     return L.wtamd_ArrayReader(len(chrom_names), names, so.ctypes.data, start_ptr, finish_ptr, value_ptr, float(default_value))
+
+
+def bigwig_reader(path, box=True):
+    """wtamd_BigWiggleReader: the reference's BigWiggleReader role (bigWiggleReader.c:147-151), bulk-capable."""
+    return _bind().wtamd_BigWiggleReader(path.encode(), int(box))
 
 
 def multiplexer(iters, strict=False):
