@@ -345,6 +345,28 @@ int wtamd_runs_map(int map_op, double param, int64_t n_seg, const int64_t *seg_o
  * `default_value`, including the `float` truncation several constructors apply. */
 double wtamd_map_default(int map_op, double param, double default_value);
 
+/* The same operators INSIDE the streaming pipeline: one chain of up to WTAMD_MAP_CHAIN_MAX operators per
+ * track (applied first to last), run on device on every batch between its arrival in HBM and the
+ * Multiplexer -- `sum map ln a.bw b.bw` (README idiom; commandParser.c:115-211) without N host operator
+ * iterators in front of the engine.  The pipe's default values must already be the mapped ones
+ * (wtamd_map_default).  chains == NULL switches it off.  Mapped batches are f64. */
+#define WTAMD_MAP_CHAIN_MAX 4
+typedef struct wtamd_map_chain {
+    int32_t n_ops;
+    int32_t op[WTAMD_MAP_CHAIN_MAX];
+    double param[WTAMD_MAP_CHAIN_MAX];
+} wtamd_map_chain;
+struct wtamd_pipe;
+int wtamd_pipe_set_map(struct wtamd_pipe *p, const wtamd_map_chain *chains /* n_tracks entries */);
+/* Drop-in side: the operator iterator the reference's parser builds around a track (ScaleWiggleIterator,
+ * NaturalLogWiggleIterator, ... unaryOps.c:650-949, HighPassFilterWiggleIterator :386-419) as ONE
+ * constructor.  Handed to newMultiplexer / newMultiset of this library it is unwrapped: the child is
+ * drained raw (in blocks when it is bulk-capable) and the chain runs on device (wtamd_pipe_set_map);
+ * popped by anything else it follows the reference's per-interval protocol on the host.
+ * default_value = wtamd_map_default(op, param, child's).  Unknown operator or a chain deeper than
+ * WTAMD_MAP_CHAIN_MAX: message and exit(1). */
+WiggleIterator *wtamd_MapIterator(WiggleIterator *child, int map_op, double param);
+
 /* Run compression on device (reference CompressionWiggleIterator, unaryOps.c:235-253, which the
  * default writer applies, wigWriter.c:263-267): adjacent runs of one chromosome merge while
  * start == previous finish and (both NaN or |value - value of the group's first run| < 1e-6).
@@ -501,6 +523,14 @@ uint32_t wtamd_bw_chrom_length(const wtamd_bw *, int i);
  * of runs; when that exceeds `capacity` nothing was written (call again with more room). */
 int64_t wtamd_bw_read_chrom(wtamd_bw *, const char *chrom, int box, int64_t capacity,
                             int32_t *start, int32_t *finish, float *value);
+
+/* Streaming form (what wtamd_BigWiggleReader's producer thread calls): the runs of the next `max_blocks`
+ * data blocks of `chrom` from index-leaf position *cursor on (0: the chromosome's beginning), skipping
+ * blocks that lie wholly outside 0-based [lo0, hi0).  Returns the number of runs and advances *cursor;
+ * *last = 1 when no block of the chromosome (inside the window) is left.  More runs than `capacity`:
+ * nothing written, *cursor unchanged, the decoded part is kept for the repeated call. */
+int64_t wtamd_bw_read_part(wtamd_bw *, const char *chrom, int box, int64_t *cursor, int max_blocks, int32_t lo0, int32_t hi0,
+                           int64_t capacity, int32_t *start, int32_t *finish, float *value, int *last);
 
 /* ---- Synthetic workload generator of SURVEY 8d, on device (bench / test plumbing; csrc/wt_synth.hip).
  * Counter-based: position x of (chromosome c, track t) is a breakpoint iff a hash of (seed, c, t, x)

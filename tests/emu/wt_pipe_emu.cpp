@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/wiggletools_amd.h"
+#include "../../wiggletools_amd/csrc/wt_mapop.h"
 
 extern "C" long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const int32_t *start,
                                   const int32_t *finish, const void *value, int value_is_f64, const double *defaults,
@@ -54,6 +55,7 @@ struct wtamd_pipe {
     int in_flight = 0;  // submitted, not collected
     int held = 0;       // collected, not released
     bool compress = false;
+    std::vector<wtamd_map_chain> chains;    // wtamd_pipe_set_map (empty: off)
     wtamd_pipe_stats st{};
 };
 
@@ -88,6 +90,13 @@ int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
 int wtamd_pipe_set_compress(wtamd_pipe *p, int on) {
     if (!p) return WTAMD_ERR_ARG;
     p->compress = on != 0;
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_set_map(wtamd_pipe *p, const wtamd_map_chain *chains) {
+    if (!p) return WTAMD_ERR_ARG;
+    p->chains.clear();
+    if (chains) p->chains.assign(chains, chains + p->cfg.n_tracks);
     return WTAMD_OK;
 }
 
@@ -193,13 +202,37 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
         if ((int64_t) s.start.size() < s.cap) { s.start.resize((size_t) s.cap); s.finish.resize((size_t) s.cap); s.v32.resize((size_t) s.cap); }
         s.direct.clear();
     } else if (n > s.cap) { g_err = "staged intervals beyond the staging capacity"; return WTAMD_ERR_ARG; }
+    // operator chains: the batch is mapped (and compacted) before it is multiplexed, values become f64
+    std::vector<int64_t> mseg;
+    std::vector<int32_t> ms, mf;
+    std::vector<double> mv;
+    const bool mapped = !p->chains.empty();
+    if (mapped) {
+        mseg.assign((size_t) N + 1, 0);
+        for (int t = 0; t < N; t++) {
+            const wtamd_map_chain &c = p->chains[(size_t) t];
+            for (int64_t g = s.seg_off[(size_t) t]; g < s.seg_off[(size_t) t + 1]; g++) {
+                double v = value_is_f64 ? s.v64[(size_t) g] : (double) s.v32[(size_t) g];
+                bool keep = true;
+                for (int k = 0; k < c.n_ops && keep; k++) {
+                    const bool based = c.op[k] == WTAMD_MAP_LOG || c.op[k] == WTAMD_MAP_EXPB;
+                    v = wm_apply(c.op[k], c.param[k], based ? log(c.param[k]) : 1.0, v, keep);
+                }
+                if (keep) { ms.push_back(s.start[(size_t) g]); mf.push_back(s.finish[(size_t) g]); mv.push_back(v); }
+            }
+            mseg[(size_t) t + 1] = (int64_t) ms.size();
+        }
+        ms.push_back(0); mf.push_back(0); mv.push_back(0);      // never empty
+    }
     int64_t cap = 2 * n + 8;
     s.os.assign((size_t) cap, 0); s.of.assign((size_t) cap, 0); s.ov.assign((size_t) cap, 0.0);
     if (tile) { s.tile.assign((size_t) cap * N, 0.0); s.ip.assign((size_t) cap * N, 0); }
     int64_t cro[2] = {0, 0};
     long long info[12] = {0};
-    const long long r = wtemu_reduce(1, N, s.seg_off.data(), s.start.data(), s.finish.data(),
-                                     value_is_f64 ? (const void *) s.v64.data() : (const void *) s.v32.data(), value_is_f64,
+    const long long r = wtemu_reduce(1, N, mapped ? mseg.data() : s.seg_off.data(), mapped ? ms.data() : s.start.data(),
+                                     mapped ? mf.data() : s.finish.data(),
+                                     mapped ? (const void *) mv.data() : value_is_f64 ? (const void *) s.v64.data() : (const void *) s.v32.data(),
+                                     mapped ? 1 : value_is_f64,
                                      p->defaults.data(), p->cfg.desc.op, p->cfg.desc.flags, p->cfg.desc.n_set0, cap,
                                      s.os.data(), s.of.data(), s.ov.data(), cro, tile ? s.tile.data() : nullptr,
                                      tile ? s.ip.data() : nullptr, info, &range_lo, &range_hi);

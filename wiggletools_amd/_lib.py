@@ -44,6 +44,12 @@ def lib():
         raise ImportError(
             "wiggletools_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        # PyTorch's HIP runtime goes first: a process that loads this library (and with it /opt/rocm's
+        # libamdhip64) before torch ends up with two runtimes and torch.cuda.is_available() == False
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)   # RTLD_LOCAL: the library exports the reference's symbol names (pop, seek, ...)
     L.wtamd_last_error.restype = C.c_char_p
     L.wtamd_version.restype = C.c_char_p

@@ -47,6 +47,12 @@ struct wtamd_bw {
     std::vector<BwChrom> chroms;
     std::vector<BwBlock> blocks;
     std::string error;
+    std::vector<unsigned char> raw, plain;      // scratch of decode_block
+    // wtamd_bw_read_part: the last decoded part, kept when the caller's arrays were too small
+    void *part = nullptr;                       // std::vector<Triple> *
+    int64_t part_from = -1, part_to = -1;
+    int part_chrom = -1, part_blocks = 0, part_lo = 0, part_hi = 0;
+    bool part_last = false;
 };
 
 namespace {
@@ -113,13 +119,13 @@ struct Triple {
 };
 
 bool decode_block(wtamd_bw *bw, const BwBlock &b, uint32_t chrom_id, std::vector<Triple> &out) {
-    std::vector<unsigned char> raw(b.size);
+    std::vector<unsigned char> &raw = bw->raw, &plain = bw->plain;
+    raw.resize(b.size);
     if (!rd(bw->fp, b.offset, raw.data(), raw.size())) { bw->error = "short read of a data block"; return false; }
-    std::vector<unsigned char> plain;
     const unsigned char *d = raw.data();
     size_t dn = raw.size();
     if (bw->uncompress_buf) {
-        plain.resize(bw->uncompress_buf);
+        if (plain.size() < bw->uncompress_buf) plain.resize(bw->uncompress_buf);
         uLongf n = plain.size();
         if (uncompress(plain.data(), &n, raw.data(), raw.size()) != Z_OK) { bw->error = "zlib: bad data block"; return false; }
         d = plain.data();
@@ -158,6 +164,7 @@ int wtamd_bw_open(const char *path, wtamd_bw **out) {
         // message of the reference (bigWiggleReader.c:116-118) for a non-BigWig file
         fprintf(stderr, "File %s is not in BigWig format\n", path);
         if (bw->fp) fclose(bw->fp);
+    delete (std::vector<Triple> *) bw->part;
         delete bw;
         return WTAMD_ERR_ARG;
     }
@@ -182,6 +189,7 @@ int wtamd_bw_open(const char *path, wtamd_bw **out) {
 void wtamd_bw_close(wtamd_bw *bw) {
     if (!bw) return;
     if (bw->fp) fclose(bw->fp);
+    delete (std::vector<Triple> *) bw->part;
     delete bw;
 }
 
@@ -199,6 +207,84 @@ uint32_t wtamd_bw_chrom_length(const wtamd_bw *bw, int i) {
 // exclusive finish, sorted).  box != 0: cut at the reference reader's 10 000-bp stretch edges.
 // Returns the number of runs; if it exceeds `capacity` nothing is written and the caller
 // retries with a bigger buffer; < 0 on error.
+// Runs of `t` (0-based, sorted) as the reference's reader hands them over: 1-based, optionally cut at
+// its 10 000-bp stretch edges.  write == false only counts.
+static int64_t emit_runs(const std::vector<Triple> &t, int box, int64_t length, bool write, int32_t *start, int32_t *finish,
+                         float *value) {
+    const int64_t stretch = 10000;
+    int64_t n = 0;
+    for (const Triple &x : t) {
+        const int64_t s = (int64_t) x.start + 1, f = (int64_t) x.end + 1;      // bigWiggleReader.c:39-40
+        if (!box) {
+            if (write) { start[n] = (int32_t) s; finish[n] = (int32_t) f; value[n] = x.value; }
+            n++;
+            continue;
+        }
+        // stretches [1+10000k, 1+10000(k+1)) for 1+10000k < length  (bigWiggleReader.c:73-83)
+        for (int64_t k = (s - 1) / stretch; ; k++) {
+            const int64_t a = 1 + k * stretch, b = a + stretch;
+            if (a >= length || a >= f) break;
+            const int64_t bs = std::max(s, a), bf = std::min(f, b);          // :42-44
+            if (bs < bf) {
+                if (write) { start[n] = (int32_t) bs; finish[n] = (int32_t) bf; value[n] = x.value; }
+                n++;
+            }
+        }
+    }
+    return n;
+}
+
+int64_t wtamd_bw_read_part(wtamd_bw *bw, const char *chrom, int box, int64_t *cursor, int max_blocks, int32_t lo0, int32_t hi0,
+                           int64_t capacity, int32_t *start, int32_t *finish, float *value, int *last) {
+    if (!bw || !chrom || !cursor || !last || max_blocks <= 0) return -1;
+    const BwChrom *c = nullptr;
+    for (const BwChrom &x : bw->chroms)
+        if (x.name == chrom) c = &x;
+    if (!c) { *last = 1; return 0; }
+    if (!bw->part) bw->part = new std::vector<Triple>();
+    std::vector<Triple> &t = *(std::vector<Triple> *) bw->part;
+    const bool cached = bw->part_from == *cursor && bw->part_chrom == (int) c->id && bw->part_blocks == max_blocks &&
+                        bw->part_lo == lo0 && bw->part_hi == hi0;
+    if (!cached) {
+        t.clear();
+        int64_t i = *cursor;
+        const int64_t nb = (int64_t) bw->blocks.size();
+        int taken = 0;
+        bool ended = false;
+        for (; i < nb && taken < max_blocks; i++) {
+            const BwBlock &b = bw->blocks[(size_t) i];
+            if (b.end_chrom < c->id) continue;
+            if (b.start_chrom > c->id) { ended = true; break; }
+            if (b.end_chrom == c->id && (int64_t) b.end_base <= (int64_t) lo0) continue;             // wholly before the window
+            if (b.start_chrom == c->id && (int64_t) b.start_base >= (int64_t) hi0) { ended = true; break; }
+            if (!decode_block(bw, b, c->id, t)) { fprintf(stderr, "wiggletools_amd: %s\n", bw->error.c_str()); return -2; }
+            taken++;
+        }
+        if (!ended) {                       // anything of this chromosome left?
+            ended = true;
+            for (int64_t k = i; k < nb; k++) {
+                const BwBlock &b = bw->blocks[(size_t) k];
+                if (b.end_chrom < c->id) continue;
+                if (b.start_chrom > c->id) break;
+                if (b.start_chrom == c->id && (int64_t) b.start_base >= (int64_t) hi0) break;
+                ended = false;
+                break;
+            }
+        }
+        if (!std::is_sorted(t.begin(), t.end(), [](const Triple &a, const Triple &b) { return a.start < b.start; }))
+            std::stable_sort(t.begin(), t.end(), [](const Triple &a, const Triple &b) { return a.start < b.start; });
+        bw->part_from = *cursor; bw->part_to = i; bw->part_chrom = (int) c->id; bw->part_blocks = max_blocks;
+        bw->part_lo = lo0; bw->part_hi = hi0; bw->part_last = ended;
+    }
+    const int64_t n = emit_runs(t, box, c->length, false, nullptr, nullptr, nullptr);
+    if (n > capacity) return n;             // the part stays cached: the next call only writes
+    emit_runs(t, box, c->length, true, start, finish, value);
+    *cursor = bw->part_to;
+    *last = bw->part_last ? 1 : 0;
+    bw->part_from = -1;
+    return n;
+}
+
 int64_t wtamd_bw_read_chrom(wtamd_bw *bw, const char *chrom, int box, int64_t capacity,
                             int32_t *start, int32_t *finish, float *value) {
     if (!bw || !chrom) return -1;
@@ -212,33 +298,9 @@ int64_t wtamd_bw_read_chrom(wtamd_bw *bw, const char *chrom, int box, int64_t ca
             if (!decode_block(bw, b, c->id, t)) { fprintf(stderr, "wiggletools_amd: %s\n", bw->error.c_str()); return -2; }
     if (!std::is_sorted(t.begin(), t.end(), [](const Triple &a, const Triple &b) { return a.start < b.start; }))
         std::stable_sort(t.begin(), t.end(), [](const Triple &a, const Triple &b) { return a.start < b.start; });
-    // first pass counts, second pass writes (boxing can split runs)
-    const int64_t stretch = 10000;
-    const int64_t length = c->length;
-    for (int pass = 0; pass < 2; pass++) {
-        int64_t n = 0;
-        for (const Triple &x : t) {
-            int64_t s = (int64_t) x.start + 1, f = (int64_t) x.end + 1;      // bigWiggleReader.c:39-40
-            if (!box) {
-                if (pass) { start[n] = (int32_t) s; finish[n] = (int32_t) f; value[n] = x.value; }
-                n++;
-                continue;
-            }
-            // stretches [1+10000k, 1+10000(k+1)) for 1+10000k < length  (bigWiggleReader.c:73-83)
-            for (int64_t k = (s - 1) / stretch; ; k++) {
-                const int64_t a = 1 + k * stretch, b = a + stretch;
-                if (a >= length || a >= f) break;
-                const int64_t bs = std::max(s, a), bf = std::min(f, b);          // :42-44
-                if (bs < bf) {
-                    if (pass) { start[n] = (int32_t) bs; finish[n] = (int32_t) bf; value[n] = x.value; }
-                    n++;
-                }
-            }
-        }
-        if (pass == 0 && n > capacity) return n;
-        if (pass == 1) return n;
-    }
-    return 0;
+    const int64_t n = emit_runs(t, box, c->length, false, nullptr, nullptr, nullptr);
+    if (n > capacity) return n;
+    return emit_runs(t, box, c->length, true, start, finish, value);
 }
 
 }  // extern "C"

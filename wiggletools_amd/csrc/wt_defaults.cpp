@@ -83,3 +83,22 @@ extern "C" double wtamd_reducer_default(int op, int n, const double *d) {
         return NAN;
     }
 }
+
+// default_value of the operator iterator the reference builds around a track (host, like the constructors
+// it restates; several store through `float`)
+extern "C" double wtamd_map_default(int map_op, double param, double d) {
+    const bool nan = d != d;
+    switch (map_op) {
+    case WTAMD_MAP_SCALE: { float f = nan ? NAN : d * param; return f; }                  // unaryOps.c:675-680
+    case WTAMD_MAP_OFFSET: { float f = nan ? NAN : d + param; return f; }                 // :738-743
+    case WTAMD_MAP_LN: return (!nan && d > 0) ? log(d) / 1.0 : NAN;                       // :792-796
+    case WTAMD_MAP_LOG: return (!nan && d > 0) ? log(d) / log(param) : NAN;               // :807-811
+    case WTAMD_MAP_EXP: { float f = nan ? NAN : exp(d * 1.0); return f; }                 // :860-865
+    case WTAMD_MAP_EXPB: { float f = nan ? NAN : exp(d * log(param)); return f; }         // :847-852
+    case WTAMD_MAP_POW: return (!nan && (d > 0 || param > 0)) ? pow(d, param) : NAN;      // :895-899
+    case WTAMD_MAP_ABS: return nan ? NAN : fabs(d);
+    case WTAMD_MAP_GT: case WTAMD_MAP_GTE: case WTAMD_MAP_LT: case WTAMD_MAP_LTE: return 0;   // :419
+    default: return d;
+    }
+}
+

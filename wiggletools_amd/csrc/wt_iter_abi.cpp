@@ -48,6 +48,7 @@
 #include <vector>
 
 #include "../../include/wiggletools_amd.h"
+#include "wt_mapop.h"
 
 #define WT_WEAK __attribute__((weak))
 
@@ -114,6 +115,8 @@ struct TrackSource {
     BulkSource *bulk = nullptr;     // non-NULL: the child hands over whole blocks
     std::deque<Ivl> pending;        // pushed back (take-over); precede the iterator's current element
     std::deque<Ivl> log;            // consumed by batches not yet handed to the consumer (Multiplexer mode)
+    wtamd_map_chain chain{};        // operators wrapped around `it` (wtamd_MapIterator), run on device
+    bool drops = false;             // ... one of them drops runs (ln, log, gt, gte, lt, lte)
     const char *raw = nullptr;      // last chrom pointer seen on `it` ...
     const char *interned = nullptr; // ... and its interned name
 
@@ -123,6 +126,33 @@ struct TrackSource {
     }
     bool empty() const { return pending.empty() && it->done; }
 };
+
+// Batch seams under operators that drop runs.  A batch must hold, for every track, the first breakpoint
+// at or beyond its cut (the interval that reaches the cut or the first one past it); when the device
+// is going to DROP that interval the guarantee moves on to the next interval it keeps.  The host
+// cannot see the device's decision, so it evaluates the chain itself -- for these seam intervals
+// only -- and asks for certainty: kept, and not within rounding distance of a threshold when a
+// transcendental operator (whose last bits differ between libm implementations) came before it.
+bool wt_surely_kept(const wtamd_map_chain &c, double v) {
+    bool fuzzy = false;
+    for (int k = 0; k < c.n_ops; k++) {
+        const int op = c.op[k];
+        const double p = c.param[k];
+        if (op == WTAMD_MAP_LN || op == WTAMD_MAP_LOG) {
+            if (!(v != v) && (v <= 0 || (fuzzy && v < 1e-300))) return false;
+        } else if (op >= WTAMD_MAP_GT && op <= WTAMD_MAP_LTE) {
+            if (fuzzy && v == v) {
+                const double d = v > p ? v - p : p - v, m = std::max(std::fabs(v), std::fabs(p));
+                if (d <= 1e-9 * m) return false;
+            }
+        }
+        bool keep;
+        v = wm_apply(op, p, (op == WTAMD_MAP_LOG || op == WTAMD_MAP_EXPB) ? log(p) : 1.0, v, keep);
+        if (!keep) return false;
+        if (op == WTAMD_MAP_LN || op == WTAMD_MAP_LOG || op == WTAMD_MAP_EXP || op == WTAMD_MAP_EXPB || op == WTAMD_MAP_POW) fuzzy = true;
+    }
+    return true;
+}
 
 const int64_t kDirectMin = 64;              // bulk blocks of at least this many intervals bypass the staging
 const int64_t kFirstSpan = 2048;            // bp of a Multiplexer's priming batch
@@ -173,6 +203,10 @@ struct Feeder {
         if (getenv("WTAMD_MIN_SPAN")) first_span = min_span;
         span = first_span < max_runs ? first_span : max_runs;
         if (wtamd_pipe_create(&cfg, &pipe) != WTAMD_OK) die("wtamd_pipe_create");
+        bool any_map = false;
+        std::vector<wtamd_map_chain> chains;
+        for (const auto &s : src) { chains.push_back(s.chain); any_map = any_map || s.chain.n_ops > 0; }
+        if (any_map && wtamd_pipe_set_map(pipe, chains.data()) != WTAMD_OK) die("wtamd_pipe_set_map");
     }
 
     void close() {
@@ -271,6 +305,33 @@ struct Feeder {
             n++;
         };
 
+        // the stop interval X (first unconsumed element of the track: pending.front() or the iterator's
+        // current one) may be dropped by the track's operators: extend the batch, without consuming
+        // anything, to the first interval that surely is not (see wt_surely_kept)
+        auto lookahead = [&](TrackSource &s, double xv) {
+            if (!s.drops || wt_surely_kept(s.chain, xv)) return;
+            WiggleIterator *it = s.it;
+            if (s.pending.empty()) {
+                Ivl x = { chrom, it->start, it->finish, it->value };
+                s.pending.push_back(x);
+                it->pop(it);
+            }
+            for (size_t idx = 1;; idx++) {
+                Ivl h;
+                if (idx < s.pending.size()) {
+                    h = s.pending[idx];
+                    if (h.chrom != chrom) return;
+                } else {
+                    if (it->done || s.it_chrom(names) != chrom) return;
+                    h = Ivl{ chrom, it->start, it->finish, it->value };
+                    s.pending.push_back(h);
+                    it->pop(it);
+                }
+                put(h.start, h.finish, h.value);
+                if (wt_surely_kept(s.chain, h.value)) return;
+            }
+        };
+
         for (int i = 0; i < N; i++) {
             TrackSource &s = src[i];
             b.seg_off[i] = n;
@@ -279,8 +340,8 @@ struct Feeder {
                 const Ivl h = s.pending.front();
                 if (h.chrom != chrom) { stop = true; break; }
                 put(h.start, h.finish, h.value);
-                if (h.start >= hi) { more = true; if (h.start < sentinel_lo) sentinel_lo = h.start; stop = true; break; }
-                if (h.finish >= hi) { more = carry = true; stop = true; break; }     // reaches the cut: seen again
+                if (h.start >= hi) { more = true; if (h.start < sentinel_lo) sentinel_lo = h.start; stop = true; lookahead(s, h.value); break; }
+                if (h.finish >= hi) { more = carry = true; stop = true; lookahead(s, h.value); break; }     // reaches the cut: seen again
                 if (keep_log) { s.log.push_back(h); fl.consumed[i]++; }
                 s.pending.pop_front();
             }
@@ -319,8 +380,9 @@ struct Feeder {
                     if (sentinel) { more = true; if (bs[k1] < sentinel_lo) sentinel_lo = bs[k1]; }
                     if (reach) more = carry = true;
                     const int64_t consumed = reach ? k1 - 1 : k1;
+                    const double xv = (reach || sentinel) ? (double) bv[reach ? k1 - 1 : k1] : 0.0;     // (before advance(): the block may be recycled)
                     if (consumed > 0) s.bulk->advance(s.bulk, it, consumed);
-                    if (reach || sentinel) break;
+                    if (reach || sentinel) { lookahead(s, xv); break; }
                 }
                 continue;
             }
@@ -328,8 +390,8 @@ struct Feeder {
                 if (s.it_chrom(names) != chrom) break;
                 const int32_t st = it->start, fi = it->finish;
                 put(st, fi, it->value);
-                if (st >= hi) { more = true; if (st < sentinel_lo) sentinel_lo = st; break; }   // sentinel: stays current
-                if (fi >= hi) { more = carry = true; break; }                                    // reaches the cut: stays current
+                if (st >= hi) { more = true; if (st < sentinel_lo) sentinel_lo = st; lookahead(s, it->value); break; }   // sentinel: stays current
+                if (fi >= hi) { more = carry = true; lookahead(s, it->value); break; }                                    // reaches the cut: stays current
                 if (keep_log) { Ivl h = { chrom, st, fi, it->value }; s.log.push_back(h); fl.consumed[i]++; }
                 it->pop(it);
             }
@@ -642,17 +704,18 @@ void arr_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
 // src/bigWiggleReader.c:52-123 + the producer thread of src/bufferedReader.c:118-134, on top of
 // this library's own section decoder (wt_bigwig.cpp): chromosomes in strcmp order (:91-101),
 // 1-based starts (:39-40), intervals boxed to 10 000-bp stretches (:42-44,73-83), float values.
-// One producer thread per file decodes the NEXT chromosome into the idle one of two SoA buffers
-// while the current one is being consumed -- whole chromosomes instead of the reference's
-// 10 000-entry blocks, the same role.  The buffers are recycled, so the source is not `stable`: the
-// Multiplexer copies each block into its pinned staging as it takes it (a memcpy, far cheaper than
-// the zlib decode that produced it).
+// One producer thread per file decodes the NEXT part (a growing number of data blocks: 4, 16, 64,
+// 256 -- the first one is small so that constructors, which must prime, return quickly) into the
+// idle one of two SoA buffers while the current one is consumed: the reference's 10 000-entry
+// blocks (bufferedReader.c:21-28), a few hundred thousand entries at a time.  The buffers are
+// recycled, so the source is not `stable`: the Multiplexer copies each block into its pinned
+// staging as it takes it (a memcpy, far cheaper than the zlib decode that produced it).
 // ---------------------------------------------------------------------------
 struct BwBuffer {
     int32_t *start = nullptr, *finish = nullptr;
     float *value = nullptr;
     int64_t cap = 0, n = 0;
-    int chrom = -1;             // index into BwReader::names, -1: nothing decoded
+    int chrom = -1;             // index into BwReader::names; -1: end of the data
 };
 
 struct BwReader {
@@ -670,12 +733,16 @@ struct BwReader {
     int32_t win_start = 0, win_finish = 0;
     int32_t e_start = 0, e_finish = 0;
     float e_value = 0;
-    // producer
+    // producer: position in the file (touched by the producer thread only while a request is pending)
+    int p_chrom = 0;            // next chromosome index
+    int64_t p_cursor = 0;       // wtamd_bw_read_part cursor inside it
+    int p_blocks = 4;
+    bool p_single = false;      // stop after p_chrom (seek window)
+    int32_t p_lo0 = 0, p_hi0 = INT32_MAX;
     std::thread th;
     std::mutex mu;
     std::condition_variable cv;
-    int want = -1;              // chromosome index the producer should decode next into buffer `want_buf` (-1: idle)
-    int want_buf = 0;
+    int want_buf = -1;          // buffer the producer should fill next (-1: idle)
     bool ready = false, quit = false, failed = false;
 
     bool clipped(int64_t g) const {
@@ -699,39 +766,51 @@ bool bw_alloc(BwBuffer &b, int64_t cap) {
     return true;
 }
 
-void bw_decode(BwReader *r, int ci, BwBuffer &b) {
-    b.chrom = ci;
+// the next non-empty part of the file into b (producer thread)
+void bw_decode(BwReader *r, BwBuffer &b) {
     b.n = 0;
-    if (b.cap == 0 && !bw_alloc(b, 1 << 16)) { r->failed = true; return; }
-    int64_t n = wtamd_bw_read_chrom(r->bw, r->names[(size_t) ci].c_str(), r->box, b.cap, b.start, b.finish, b.value);
-    if (n > b.cap) {
-        if (!bw_alloc(b, n + n / 8)) { r->failed = true; return; }
-        n = wtamd_bw_read_chrom(r->bw, r->names[(size_t) ci].c_str(), r->box, b.cap, b.start, b.finish, b.value);
+    b.chrom = -1;
+    if (b.cap == 0 && !bw_alloc(b, 1 << 14)) { r->failed = true; return; }
+    while (r->p_chrom < (int) r->names.size()) {
+        int last = 0;
+        const char *name = r->names[(size_t) r->p_chrom].c_str();
+        int64_t n = wtamd_bw_read_part(r->bw, name, r->box, &r->p_cursor, r->p_blocks, r->p_lo0, r->p_hi0, b.cap, b.start, b.finish,
+                                       b.value, &last);
+        if (n > b.cap) {
+            if (!bw_alloc(b, n + n / 8)) { r->failed = true; return; }
+            n = wtamd_bw_read_part(r->bw, name, r->box, &r->p_cursor, r->p_blocks, r->p_lo0, r->p_hi0, b.cap, b.start, b.finish,
+                                   b.value, &last);
+        }
+        if (n < 0) { r->failed = true; return; }
+        const int ci = r->p_chrom;
+        if (r->p_blocks < 256) r->p_blocks *= 4;
+        if (last) {
+            r->p_chrom = r->p_single ? (int) r->names.size() : r->p_chrom + 1;
+            r->p_cursor = 0;
+        }
+        if (n > 0) { b.n = n; b.chrom = ci; return; }
     }
-    if (n < 0) { r->failed = true; return; }
-    b.n = n;
 }
 
 void bw_producer(BwReader *r) {
     std::unique_lock<std::mutex> lk(r->mu);
     for (;;) {
-        r->cv.wait(lk, [&] { return r->quit || r->want >= 0; });
+        r->cv.wait(lk, [&] { return r->quit || r->want_buf >= 0; });
         if (r->quit) return;
-        const int ci = r->want, bi = r->want_buf;
+        const int bi = r->want_buf;
         lk.unlock();
-        bw_decode(r, ci, r->buf[bi]);
+        bw_decode(r, r->buf[bi]);
         lk.lock();
-        r->want = -1;
+        r->want_buf = -1;
         r->ready = true;
         r->cv.notify_all();
     }
 }
 
-// asks the producer for chromosome ci in buffer bi (non-blocking)
-void bw_request(BwReader *r, int ci, int bi) {
+// asks the producer for the next part in buffer bi (does not wait)
+void bw_request(BwReader *r, int bi) {
     std::lock_guard<std::mutex> lk(r->mu);
     r->ready = false;
-    r->want = ci;
     r->want_buf = bi;
     r->cv.notify_all();
 }
@@ -742,29 +821,26 @@ void bw_wait(BwReader *r) {
     if (r->failed) { fprintf(stderr, "wiggletools_amd: BigWig decode failed\n"); exit(1); }
 }
 
-// moves to the next chromosome that has intervals (buffers alternate; the one after it is requested
-// right away so that its decode overlaps the consumption of this one)
-void bw_next_chrom(BwReader *r, WiggleIterator *wi, int ci) {
-    const int n = (int) r->names.size();
-    while (ci < n) {
-        bw_wait(r);             // the producer was asked for `ci` into the idle buffer when the previous one started
+// Switches to the part the producer has been decoding into the idle buffer and asks for the one after
+// it, whose decode then overlaps the consumption of this one.
+void bw_next_part(BwReader *r, WiggleIterator *wi) {
+    for (;;) {
+        bw_wait(r);
         r->cur ^= 1;
-        if (ci + 1 < n) bw_request(r, ci + 1, r->cur ^ 1);
-        if (r->buf[r->cur].n > 0) {
-            r->j = 0; r->end = r->buf[r->cur].n;
-            return;
+        const BwBuffer &b = r->buf[r->cur];
+        if (b.chrom < 0) { r->done = true; wi->done = 1; return; }
+        bw_request(r, r->cur ^ 1);
+        r->j = 0; r->end = b.n;
+        if (r->windowed) {
+            r->j = std::upper_bound(b.finish, b.finish + b.n, r->win_start) - b.finish;       // first finish > start
+            r->end = std::lower_bound(b.start, b.start + b.n, r->win_finish) - b.start;       // first start >= finish
         }
-        ci++;
+        if (r->j < r->end) return;
     }
-    r->done = true;
-    wi->done = 1;
 }
 
 void bw_settle(BwReader *r, WiggleIterator *wi) {
-    if (!r->done && r->j >= r->end) {
-        if (r->windowed) { r->done = true; }
-        else bw_next_chrom(r, wi, r->buf[r->cur].chrom + 1);
-    }
+    if (!r->done && r->j >= r->end) bw_next_part(r, wi);
     if (r->done) { wi->done = 1; return; }
     const BwBuffer &b = r->buf[r->cur];
     wi->chrom = r->cnames[(size_t) b.chrom];
@@ -804,28 +880,81 @@ void bw_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
     // bigWiggleReader.c:125-145: the producer is restarted on [start, finish) of that chromosome;
     // the first interval is clipped to `start` (:143-144), the stretches end at `finish`
     BwReader *r = (BwReader *) wi->data;
+    bw_wait(r);                             // whatever the producer is decoding lands first; it is idle afterwards
     r->windowed = true;
     r->win_start = start; r->win_finish = finish;
-    r->done = true;
+    r->done = false;
     wi->done = 0;
-    int ci = -1;
+    int ci = (int) r->names.size();
     for (size_t c = 0; c < r->names.size(); c++)
         if (r->names[c] == chrom) ci = (int) c;
-    if (ci < 0) { wi->done = 1; return; }
-    if (r->buf[r->cur].chrom != ci) {
-        bw_wait(r);                         // whatever the producer is decoding lands first
-        if (r->buf[r->cur ^ 1].chrom != ci) {
-            bw_request(r, ci, r->cur ^ 1);
-            bw_wait(r);
-        }
-        r->cur ^= 1;
-    }
-    const BwBuffer &b = r->buf[r->cur];
-    r->j = std::upper_bound(b.finish, b.finish + b.n, start) - b.finish;       // first finish > start
-    r->end = std::lower_bound(b.start, b.start + b.n, finish) - b.start;       // first start >= finish
-    r->done = r->j >= r->end;
-    if (r->done) { wi->done = 1; return; }
+    r->p_chrom = ci;                        // unknown chromosome: the producer reports the end at once
+    r->p_cursor = 0;
+    r->p_blocks = 4;
+    r->p_single = true;
+    r->p_lo0 = start > 0 ? start - 1 : 0;
+    r->p_hi0 = finish > 0 ? finish - 1 : 0;
+    r->j = r->end = 0;
+    bw_request(r, r->cur ^ 1);
     bw_settle(r, wi);
+}
+
+// ---------------------------------------------------------------------------
+// Operator iterator (wtamd_MapIterator): the reference's value maps around one track
+// (unaryOps.c:650-949, :386-419).  newMultiplexer unwraps it (wt_unwrap_maps): the engine drains
+// the raw child and runs the chain on device.  pop / seek below are the per-interval protocol for
+// any other consumer -- one wm_apply per interval, runs the operator drops are skipped
+// (LogWiggleIteratorPop :760-779, HighPassFilterWiggleIteratorPop :387-412).
+// ---------------------------------------------------------------------------
+struct MapIter {
+    WiggleIterator *child;
+    int op;
+    double param, lg;
+};
+
+void map_settle(WiggleIterator *wi) {
+    MapIter *m = (MapIter *) wi->data;
+    WiggleIterator *c = m->child;
+    while (!c->done) {
+        bool keep;
+        const double v = wm_apply(m->op, m->param, m->lg, c->value, keep);
+        if (keep) {
+            wi->chrom = c->chrom; wi->start = c->start; wi->finish = c->finish; wi->value = v;
+            return;
+        }
+        c->pop(c);
+    }
+    wi->done = 1;
+}
+
+void map_pop(WiggleIterator *wi) {
+    MapIter *m = (MapIter *) wi->data;
+    if (wi->done) return;
+    if (!m->child->done) m->child->pop(m->child);
+    map_settle(wi);
+}
+
+void map_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
+    MapIter *m = (MapIter *) wi->data;
+    m->child->done = 0;
+    m->child->seek(m->child, chrom, start, finish);
+    wi->done = 0;
+    map_settle(wi);
+}
+
+// Peels the wtamd_MapIterator layers off `wi`: returns the raw child, fills `chain` innermost first.
+WiggleIterator *wt_unwrap_maps(WiggleIterator *wi, wtamd_map_chain &chain) {
+    int ops[WTAMD_MAP_CHAIN_MAX];
+    double params[WTAMD_MAP_CHAIN_MAX];
+    int n = 0;
+    while (wi->pop == &map_pop && n < WTAMD_MAP_CHAIN_MAX) {
+        MapIter *m = (MapIter *) wi->data;
+        ops[n] = m->op; params[n] = m->param; n++;
+        wi = m->child;
+    }
+    chain.n_ops = n;
+    for (int k = 0; k < n; k++) { chain.op[k] = ops[n - 1 - k]; chain.param[k] = params[n - 1 - k]; }
+    return wi;
 }
 
 // ---------------------------------------------------------------------------
@@ -1041,8 +1170,14 @@ Multiplexer *newMultiplexer(WiggleIterator **iters, int count, wt_bool strict) {
         m->iters[i] = NonOverlappingWiggleIterator(iters[i]);       // multiplexer.c:163
         m->default_values[i] = m->iters[i]->default_value;
         m->values[i] = m->iters[i]->default_value;
-        S->fd.src[i].it = m->iters[i];
-        if (m->iters[i]->pop == &wt_bulk_pop) S->fd.src[i].bulk = (BulkSource *) m->iters[i]->data;
+        // operator iterators of this library are peeled off: the raw child is drained, the chain runs on device
+        WiggleIterator *raw = wt_unwrap_maps(m->iters[i], S->fd.src[i].chain);
+        S->fd.src[i].it = raw;
+        for (int k = 0; k < S->fd.src[i].chain.n_ops; k++) {
+            const int op = S->fd.src[i].chain.op[k];
+            if (op == WTAMD_MAP_LN || op == WTAMD_MAP_LOG || op >= WTAMD_MAP_GT) S->fd.src[i].drops = true;
+        }
+        if (raw->pop == &wt_bulk_pop) S->fd.src[i].bulk = (BulkSource *) raw->data;
         S->fd.defaults.push_back(m->iters[i]->default_value);
     }
     popMultiplexer(m);                                              // primed like multiplexer.c:167
@@ -1176,6 +1311,24 @@ int64_t wtamd_iterator_next_block(WiggleIterator *wi, const char **chrom, const 
     return n;
 }
 
+WiggleIterator *wtamd_MapIterator(WiggleIterator *child, int map_op, double param) {
+    if (map_op < 0 || map_op >= WTAMD_MAP_COUNT_) { puts("wtamd_MapIterator: unknown operator"); exit(1); }
+    if ((map_op == WTAMD_MAP_LOG || map_op == WTAMD_MAP_EXPB) && !(param > 0)) { puts("wtamd_MapIterator: base / radix must be positive"); exit(1); }
+    int depth = 1;
+    for (WiggleIterator *w = child; w->pop == &map_pop; w = ((MapIter *) w->data)->child) depth++;
+    if (depth > WTAMD_MAP_CHAIN_MAX) { puts("wtamd_MapIterator: operator chain too deep"); exit(1); }
+    MapIter *m = new MapIter{child, map_op, param, (map_op == WTAMD_MAP_LOG || map_op == WTAMD_MAP_EXPB) ? log(param) : 1.0};
+    WiggleIterator *wi = (WiggleIterator *) calloc(1, sizeof(WiggleIterator));
+    wi->data = m;
+    wi->pop = &map_pop;
+    wi->seek = &map_seek;
+    wi->value = 1;
+    wi->overlaps = child->overlaps;
+    wi->default_value = wtamd_map_default(map_op, param, child->default_value);
+    map_settle(wi);
+    return wi;
+}
+
 WiggleIterator *wtamd_BigWiggleReader(const char *path, int box) {
     wtamd_bw *bw = nullptr;
     if (wtamd_bw_open(path, &bw) != WTAMD_OK) exit(1);     // message printed (bigWiggleReader.c:116-118)
@@ -1196,11 +1349,9 @@ WiggleIterator *wtamd_BigWiggleReader(const char *path, int box) {
     wi->seek = &bw_seek;
     wi->value = 1;
     wi->default_value = 0;                      // bigWiggleReader.c:150
-    if (r->names.empty()) { r->done = true; wi->done = 1; return wi; }
-    r->cur = 1;                                 // first chromosome goes to buffer 0
-    bw_request(r, 0, 0);
-    bw_next_chrom(r, wi, 0);
-    if (!r->done) bw_settle(r, wi);
+    r->cur = 1;                                 // the first part goes to buffer 0
+    bw_request(r, 0);
+    bw_settle(r, wi);
     return wi;
 }
 

@@ -20,6 +20,7 @@
 
 #include "../../include/wiggletools_amd.h"
 #include "wt_devscope.h"
+#include "wt_mapop.h"
 
 #define WM_BLOCK 256
 #define WM_ITEMS 16
@@ -29,27 +30,6 @@ extern "C" const char *wtamd_last_error(void);
 int wt_fail_ext(int code, const std::string &msg);     // wt_engine.hip
 
 namespace {
-
-__device__ inline double wm_apply(int op, double param, double lg, double v, bool &keep) {
-    keep = true;
-    switch (op) {
-    case WTAMD_MAP_SCALE: return (v != v) ? v : param * v;                       // unaryOps.c:650-664
-    case WTAMD_MAP_OFFSET: return param + v;                                      // :722-734
-    case WTAMD_MAP_LN:
-    case WTAMD_MAP_LOG:                                                           // :760-779
-        if (v <= 0) keep = false;
-        return (v != v || v < 0) ? __builtin_nan("") : log(v) / lg;
-    case WTAMD_MAP_EXP:
-    case WTAMD_MAP_EXPB: return exp(v * lg);                                      // :823-835
-    case WTAMD_MAP_POW: return ((param < 0 && v <= 0) || v != v) ? __builtin_nan("") : pow(v, param);   // :873-889
-    case WTAMD_MAP_ABS: return (v != v) ? v : fabs(v);                            // :934-949
-    case WTAMD_MAP_GT: keep = !(v <= param || v != v); return 1.0;                // :386-419, value stays 1
-    case WTAMD_MAP_GTE: keep = !(v < param || v != v); return 1.0;
-    case WTAMD_MAP_LT: keep = !(-1 * v <= -param || v != v); return 1.0;          // commandParser.c:185-189
-    case WTAMD_MAP_LTE: keep = !(-1 * v < -param || v != v); return 1.0;
-    default: return v;
-    }
-}
 
 template <class ValT>
 __global__ void __launch_bounds__(WM_BLOCK) wm_map_kernel(int op, double param, double lg, const ValT *in, long long n,
@@ -154,25 +134,170 @@ __global__ void wm_seg_offsets(int op, double param, const ValT *in, const int64
     o_seg_off[s] = (int64_t) c;
 }
 
-}  // namespace
 
-extern "C" {
+// ---------------------------------------------------------------------------
+// Per-track operator chains inside the streaming pipeline (wtamd_pipe_set_map): the same operators,
+// a chain of up to WTAMD_MAP_CHAIN_MAX of them per track (`sum ln a scale 2 b` wraps tracks
+// differently; `map` wraps all of them alike, commandParser.c:115-211), applied to one batch
+// between its arrival in HBM and the window index.  Nothing returns to the host: run counts, block
+// offsets and the new segment offsets stay on device, the kernels after it read the compacted
+// lists through the rewritten seg_off[].
+// ---------------------------------------------------------------------------
+struct WmChain { int32_t n_ops; int32_t op[WTAMD_MAP_CHAIN_MAX]; double param[WTAMD_MAP_CHAIN_MAX]; double lg[WTAMD_MAP_CHAIN_MAX]; };
 
-double wtamd_map_default(int map_op, double param, double d) {
-    const bool nan = d != d;
-    switch (map_op) {
-    case WTAMD_MAP_SCALE: { float f = nan ? NAN : d * param; return f; }                  // unaryOps.c:675-680
-    case WTAMD_MAP_OFFSET: { float f = nan ? NAN : d + param; return f; }                 // :738-743
-    case WTAMD_MAP_LN: return (!nan && d > 0) ? log(d) / 1.0 : NAN;                       // :792-796
-    case WTAMD_MAP_LOG: return (!nan && d > 0) ? log(d) / log(param) : NAN;               // :807-811
-    case WTAMD_MAP_EXP: { float f = nan ? NAN : exp(d * 1.0); return f; }                 // :860-865
-    case WTAMD_MAP_EXPB: { float f = nan ? NAN : exp(d * log(param)); return f; }         // :847-852
-    case WTAMD_MAP_POW: return (!nan && (d > 0 || param > 0)) ? pow(d, param) : NAN;      // :895-899
-    case WTAMD_MAP_ABS: return nan ? NAN : fabs(d);
-    case WTAMD_MAP_GT: case WTAMD_MAP_GTE: case WTAMD_MAP_LT: case WTAMD_MAP_LTE: return 0;   // :419
-    default: return d;
+template <class ValT>
+__global__ void __launch_bounds__(WM_BLOCK) wm_chain_kernel(const WmChain *chains, const int64_t *seg, int n_tracks,
+                                                             const ValT *in, long long n, double *out, uint8_t *keep_flag,
+                                                             unsigned long long *block_keep) {
+    __shared__ unsigned int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const long long base = (long long) blockIdx.x * WM_TILE;
+    unsigned kept = 0;
+    int t = -1;
+    long long t_end = -1;
+    for (int q = 0; q < WM_ITEMS; q++) {
+        const long long g = base + threadIdx.x + (long long) q * WM_BLOCK;
+        if (g >= n) break;
+        if (g >= t_end) {       // track of run g: last t with seg[t] <= g
+            int lo = 0, hi = n_tracks;
+            while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (seg[m] <= g) lo = m; else hi = m; }
+            t = lo; t_end = seg[t + 1];
+        }
+        const WmChain &c = chains[t];
+        double v = (double) in[g];
+        bool keep = true;
+        for (int k = 0; k < c.n_ops && keep; k++) v = wm_apply(c.op[k], c.param[k], c.lg[k], v, keep);
+        out[g] = v;
+        if (keep_flag) keep_flag[g] = keep ? 1 : 0;
+        kept += keep ? 1u : 0u;
+    }
+    if (block_keep) {
+        atomicAdd(&cnt, kept);
+        __syncthreads();
+        if (threadIdx.x == 0) block_keep[blockIdx.x] = cnt;
     }
 }
+
+__global__ void __launch_bounds__(WM_BLOCK) wm_compact_flag_kernel(const uint8_t *keep_flag, const int32_t *start, const int32_t *finish,
+                                                                    const double *mapped, long long n,
+                                                                    const unsigned long long *block_off, int32_t *o_start,
+                                                                    int32_t *o_finish, double *o_value) {
+    __shared__ unsigned int wave_tot[WM_BLOCK / 64];
+    const long long base = (long long) blockIdx.x * WM_TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long off = block_off[blockIdx.x];
+    const long long g0 = base + (long long) threadIdx.x * WM_ITEMS;
+    unsigned mask = 0, mine = 0;
+#pragma unroll
+    for (int q = 0; q < WM_ITEMS; q++)
+        if (g0 + q < n && keep_flag[g0 + q]) { mask |= 1u << q; mine++; }
+    unsigned incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = (unsigned) __shfl_up((int) incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned before = incl - mine;
+    for (int w = 0; w < wave; w++) before += wave_tot[w];
+    unsigned long long o = off + before;
+#pragma unroll
+    for (int q = 0; q < WM_ITEMS; q++)
+        if ((mask >> q) & 1u) {
+            o_start[o] = start[g0 + q];
+            o_finish[o] = finish[g0 + q];
+            o_value[o] = mapped[g0 + q];
+            o++;
+        }
+}
+
+__global__ void wm_seg_offsets_flag(const uint8_t *keep_flag, const int64_t *seg_off, long long n_seg, long long n,
+                                    const unsigned long long *block_off, const unsigned long long *total, int64_t *o_seg_off) {
+    const long long s = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_seg) return;
+    const long long p = seg_off[s];
+    if (p >= n) { o_seg_off[s] = (int64_t) *total; return; }
+    const long long b = p / WM_TILE;
+    unsigned long long c = block_off[b];
+    for (long long g = b * WM_TILE; g < p; g++) c += keep_flag[g] ? 1ull : 0ull;
+    o_seg_off[s] = (int64_t) c;
+}
+
+}  // namespace
+
+// Scratch of wt_map_chain_async in 8-byte words for batches of up to `capacity` runs: the mapped
+// values before compaction, the block counts (+ total), the keep flags.
+long long wt_map_scratch_words(long long capacity) {
+    const long long nb = (capacity + WM_TILE - 1) / WM_TILE;
+    return capacity + (nb + 2) + (capacity + 7) / 8;
+}
+
+bool wt_map_op_drops(int op) { return op == WTAMD_MAP_LN || op == WTAMD_MAP_LOG || op >= WTAMD_MAP_GT; }
+
+// d_chains: n_tracks device WmChain records (wt_map_upload_chains).  `drops`: some chain holds an
+// operator that drops runs -- then o_start / o_finish / o_value receive the compacted lists and
+// d_seg_out the new offsets; otherwise only o_value is written (the coordinates and d_seg_in stay
+// what the kernels downstream read).  Everything is enqueued on `stream`, nothing waits.
+int wt_map_chain_async(const void *d_chains, int n_tracks, bool drops, const int64_t *d_seg_in, long long n, const int32_t *start,
+                       const int32_t *finish, const void *value, bool value_is_f64, unsigned long long *scratch,
+                       int32_t *o_start, int32_t *o_finish, double *o_value, int64_t *d_seg_out, hipStream_t stream) {
+    if (n <= 0) {
+        if (drops) return hipMemsetAsync(d_seg_out, 0, sizeof(int64_t) * ((size_t) n_tracks + 1), stream) == hipSuccess ? WTAMD_OK : WTAMD_ERR_HIP;
+        return WTAMD_OK;
+    }
+    const long long nb = (n + WM_TILE - 1) / WM_TILE;
+    double *d_mapped = drops ? (double *) scratch : o_value;
+    unsigned long long *d_blk = scratch + n;
+    uint8_t *d_flag = (uint8_t *) (d_blk + nb + 2);
+    const WmChain *ch = (const WmChain *) d_chains;
+    if (value_is_f64)
+        hipLaunchKernelGGL(wm_chain_kernel<double>, dim3((unsigned) nb), dim3(WM_BLOCK), 0, stream, ch, d_seg_in, n_tracks,
+                           (const double *) value, n, d_mapped, drops ? d_flag : nullptr, drops ? d_blk : nullptr);
+    else
+        hipLaunchKernelGGL(wm_chain_kernel<float>, dim3((unsigned) nb), dim3(WM_BLOCK), 0, stream, ch, d_seg_in, n_tracks,
+                           (const float *) value, n, d_mapped, drops ? d_flag : nullptr, drops ? d_blk : nullptr);
+    if (drops) {
+        hipLaunchKernelGGL(wm_scan_blocks, dim3(1), dim3(64), 0, stream, d_blk, nb, d_blk + nb);
+        hipLaunchKernelGGL(wm_compact_flag_kernel, dim3((unsigned) nb), dim3(WM_BLOCK), 0, stream, d_flag, start, finish, d_mapped, n,
+                           d_blk, o_start, o_finish, o_value);
+        hipLaunchKernelGGL(wm_seg_offsets_flag, dim3((unsigned) ((n_tracks + 1 + 255) / 256)), dim3(256), 0, stream, d_flag, d_seg_in,
+                           (long long) n_tracks, n, d_blk, d_blk + nb, d_seg_out);
+    }
+    return hipGetLastError() == hipSuccess ? WTAMD_OK : WTAMD_ERR_HIP;
+}
+
+// Host chains -> device records (log of the base / radix precomputed as wtamd_runs_map does).
+int wt_map_upload_chains(const wtamd_map_chain *chains, int n_tracks, void **d_out, bool *drops) {
+    std::vector<WmChain> h((size_t) n_tracks);
+    *drops = false;
+    for (int t = 0; t < n_tracks; t++) {
+        const wtamd_map_chain &c = chains[t];
+        if (c.n_ops < 0 || c.n_ops > WTAMD_MAP_CHAIN_MAX) return wt_fail_ext(WTAMD_ERR_ARG, "wtamd_pipe_set_map: chain length");
+        h[(size_t) t].n_ops = c.n_ops;
+        for (int k = 0; k < WTAMD_MAP_CHAIN_MAX; k++) {
+            const int op = k < c.n_ops ? c.op[k] : WTAMD_MAP_COUNT_;
+            if (k < c.n_ops && (op < 0 || op >= WTAMD_MAP_COUNT_)) return wt_fail_ext(WTAMD_ERR_ARG, "wtamd_pipe_set_map: unknown operator");
+            if (k < c.n_ops && (op == WTAMD_MAP_LOG || op == WTAMD_MAP_EXPB) && !(c.param[k] > 0))
+                return wt_fail_ext(WTAMD_ERR_ARG, "wtamd_pipe_set_map: base / radix must be positive");
+            h[(size_t) t].op[k] = op;
+            h[(size_t) t].param[k] = k < c.n_ops ? c.param[k] : 0;
+            h[(size_t) t].lg[k] = (op == WTAMD_MAP_LOG || op == WTAMD_MAP_EXPB) ? log(c.param[k]) : 1.0;
+            if (k < c.n_ops && wt_map_op_drops(op)) *drops = true;
+        }
+    }
+    void *d = nullptr;
+    if (hipMalloc(&d, sizeof(WmChain) * (size_t) n_tracks) != hipSuccess) return wt_fail_ext(WTAMD_ERR_HIP, "hipMalloc(map chains)");
+    if (hipMemcpy(d, h.data(), sizeof(WmChain) * (size_t) n_tracks, hipMemcpyHostToDevice) != hipSuccess) {
+        (void) hipFree(d);
+        return wt_fail_ext(WTAMD_ERR_HIP, "hipMemcpy(map chains)");
+    }
+    *d_out = d;
+    return WTAMD_OK;
+}
+
+extern "C" {
 
 #define WM_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) \
     return wt_fail_ext(WTAMD_ERR_HIP, std::string(#call ": ") + hipGetErrorString(e_)); } while (0)

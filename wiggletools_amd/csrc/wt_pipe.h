@@ -24,6 +24,11 @@
 #define WT_PIPE_H_
 
 // wt_compress.hip
+long long wt_map_scratch_words(long long capacity);                             // wt_map.hip
+int wt_map_upload_chains(const wtamd_map_chain *chains, int n_tracks, void **d_out, bool *drops);
+int wt_map_chain_async(const void *d_chains, int n_tracks, bool drops, const int64_t *d_seg_in, long long n, const int32_t *start,
+                       const int32_t *finish, const void *value, bool value_is_f64, unsigned long long *scratch,
+                       int32_t *o_start, int32_t *o_finish, double *o_value, int64_t *d_seg_out, hipStream_t stream);
 long long wt_compress_scratch_words(long long capacity);
 int wt_compress_async(const int32_t *start, const int32_t *finish, const double *value, const unsigned long long *d_n,
                       long long capacity, unsigned long long *scratch, int32_t *o_start, int32_t *o_finish, double *o_value,
@@ -161,6 +166,13 @@ struct WtSlot {
     double *d_cv = nullptr;
     unsigned long long *d_cscratch = nullptr, *d_cn = nullptr;
     bool compressed = false;        // this batch's output went through the compression
+    // operator chains (wtamd_pipe_set_map): mapped f64 values, compacted coordinates, raw offsets, scratch
+    int64_t mcap = 0;
+    bool m_has_coords = false;
+    int32_t *d_mstart = nullptr, *d_mfinish = nullptr;
+    double *d_mvalue = nullptr;
+    int64_t *d_mseg = nullptr;
+    unsigned long long *d_mscratch = nullptr;
     int64_t seg_cap = 0;
     bool direct_pinned = true;      // every direct range of this batch lies in page-locked memory
 };
@@ -176,6 +188,8 @@ struct wtamd_pipe {
     bool compress = false;          // WTAMD_PIPE_COMPRESS: batches submitted from now on are merged on device before they travel
     bool gather = true;             // WTAMD_PIPE_GATHER=0: hipMemcpyAsync per range instead of the gather kernel
     int gather_blocks = 64;         // WTAMD_GATHER_BLOCKS
+    void *d_chains = nullptr;       // wtamd_pipe_set_map: per-track operator chains on device
+    bool map_drops = false;         // ... some operator drops runs: batches are compacted
     int num_cu = 256;
     wtamd_pipe_stats st{};
 };
@@ -191,6 +205,7 @@ static void wt_slot_free(WtSlot &s) {
     (void) hipFree(s.d_cro);
     (void) hipFree(s.d_cs); (void) hipFree(s.d_cf); (void) hipFree(s.d_cv); (void) hipFree(s.d_cscratch); (void) hipFree(s.d_cn);
     if (s.h_segs) (void) hipHostFree(s.h_segs);
+    (void) hipFree(s.d_mstart); (void) hipFree(s.d_mfinish); (void) hipFree(s.d_mvalue); (void) hipFree(s.d_mseg); (void) hipFree(s.d_mscratch);
     if (s.h_os) (void) hipHostFree(s.h_os);
     if (s.h_of) (void) hipHostFree(s.h_of);
     if (s.h_ov) (void) hipHostFree(s.h_ov);
@@ -375,6 +390,7 @@ void wtamd_pipe_destroy(wtamd_pipe *p) {
     if (p->s_copy) (void) hipStreamDestroy(p->s_copy);
     if (p->s_comp) (void) hipStreamDestroy(p->s_comp);
     if (p->s_out) (void) hipStreamDestroy(p->s_out);
+    if (p->d_chains) (void) hipFree(p->d_chains);
     delete p;
 }
 
@@ -475,6 +491,21 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
         WT_HIP(hipMalloc(&s.d_value, (w64 ? 8 : 4) * (size_t) c));
         s.dcap = c; s.d_has64 = w64;
     }
+    const bool mapped = p->d_chains != nullptr;
+    if (mapped && (s.mcap < s.dcap || (p->map_drops && !s.m_has_coords))) {
+        (void) hipStreamSynchronize(p->s_comp);
+        (void) hipFree(s.d_mstart); (void) hipFree(s.d_mfinish); (void) hipFree(s.d_mvalue); (void) hipFree(s.d_mscratch);
+        s.d_mstart = s.d_mfinish = nullptr; s.d_mvalue = nullptr; s.d_mscratch = nullptr; s.mcap = 0; s.m_has_coords = false;
+        WT_HIP(hipMalloc(&s.d_mvalue, sizeof(double) * (size_t) s.dcap));
+        if (p->map_drops) {
+            WT_HIP(hipMalloc(&s.d_mstart, sizeof(int32_t) * (size_t) s.dcap));
+            WT_HIP(hipMalloc(&s.d_mfinish, sizeof(int32_t) * (size_t) s.dcap));
+            WT_HIP(hipMalloc(&s.d_mscratch, sizeof(unsigned long long) * (size_t) wt_map_scratch_words((long long) s.dcap)));
+            if (!s.d_mseg) WT_HIP(hipMalloc(&s.d_mseg, sizeof(int64_t) * ((size_t) N + 1)));
+            s.m_has_coords = true;
+        }
+        s.mcap = s.dcap;
+    }
     // output (grow-only, bounded by max_runs): a run is at least 1 bp and starts at an interval edge
     int64_t need_out = 2 * n;
     const int64_t span = (int64_t) range_hi - (int64_t) range_lo;
@@ -533,9 +564,14 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     }
     ts->range_lo[0] = range_lo;
     ts->range_hi[0] = range_hi;
-    ts->value_f64 = f64;
-    ts->scratch_f32 = !f64 && wt_defaults_fit_f32(ts->defaults.data(), N);
-    ts->d_start = s.d_start; ts->d_finish = s.d_finish; ts->d_value = s.d_value;
+    ts->value_f64 = f64 || mapped;
+    ts->scratch_f32 = !ts->value_f64 && wt_defaults_fit_f32(ts->defaults.data(), N);
+    // mapped batches: the kernels read the operator chains' output (the host-side seg_off[] / extents stay those
+    // of the raw lists: upper bounds, which is all the planning needs)
+    const bool compacted = mapped && p->map_drops;
+    ts->d_start = compacted ? s.d_mstart : s.d_start;
+    ts->d_finish = compacted ? s.d_mfinish : s.d_finish;
+    ts->d_value = mapped ? (void *) s.d_mvalue : s.d_value;
     ts->delta_failed = p->delta_failed;
     ts->delta_verified = false;
     ts->delta_n_bad = 0;
@@ -545,7 +581,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
 
     // copy stream: pinned staging -> HBM
     WT_HIP(hipEventRecord(s.e_h0, p->s_copy));
-    WT_HIP(hipMemcpyAsync(ts->d_seg_off, s.h_seg, sizeof(int64_t) * ((size_t) N + 1), hipMemcpyHostToDevice, p->s_copy));
+    WT_HIP(hipMemcpyAsync(compacted ? s.d_mseg : ts->d_seg_off, s.h_seg, sizeof(int64_t) * ((size_t) N + 1), hipMemcpyHostToDevice, p->s_copy));
     if (n > 0 && p->gather && !f64 && !s.direct.empty() && s.direct_pinned && 2 * (int64_t) s.direct.size() + 1 <= WT_GATHER_MAX_SEGS) {
         // one table, one small copy, one kernel for the whole batch
         const int64_t max_segs = 2 * (int64_t) s.direct.size() + 1;
@@ -609,6 +645,11 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     // compute stream: window index + fused multiplex / reduce, then the counters travel back
     WT_HIP(hipStreamWaitEvent(p->s_comp, s.e_h1, 0));
     WT_HIP(hipEventRecord(s.e_k0, p->s_comp));
+    if (mapped) {
+        rc = wt_map_chain_async(p->d_chains, N, p->map_drops, compacted ? s.d_mseg : ts->d_seg_off, (long long) n, s.d_start, s.d_finish,
+                                s.d_value, f64, s.d_mscratch, s.d_mstart, s.d_mfinish, s.d_mvalue, ts->d_seg_off, p->s_comp);
+        if (rc != WTAMD_OK) return wt_fail(rc, "operator chain launch failed");
+    }
     wtamd_runs runs{};
     runs.capacity = s.ocap; runs.start = s.d_os; runs.finish = s.d_of; runs.value = s.d_ov; runs.chrom_run_off = s.d_cro;
     const int op = p->cfg.desc.op;
@@ -698,6 +739,17 @@ int wtamd_pipe_set_compress(wtamd_pipe *p, int on) {
     if (on && p->tile) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_set_compress: the Multiplexer tile cannot be compressed");
     p->compress = on != 0;
     return WTAMD_OK;
+}
+
+int wtamd_pipe_set_map(wtamd_pipe *p, const wtamd_map_chain *chains) {
+    if (!p) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    if (p->in_flight > 0 || p->acquired >= 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_set_map: batches in flight");
+    if (p->d_chains) { (void) hipFree(p->d_chains); p->d_chains = nullptr; p->map_drops = false; }
+    if (!chains) return WTAMD_OK;
+    bool any = false;
+    for (int t = 0; t < p->cfg.n_tracks; t++) any = any || chains[t].n_ops != 0;
+    if (!any) return WTAMD_OK;
+    return wt_map_upload_chains(chains, p->cfg.n_tracks, &p->d_chains, &p->map_drops);
 }
 
 void *wtamd_host_alloc(size_t bytes) {
