@@ -445,6 +445,10 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_patch_kernel
 #define WT_INDEX_UNROLL 2
 #define WT_INDEX_CHUNK (256 * 4 * WT_INDEX_UNROLL)
 __global__ void __launch_bounds__(256) wt_index_kernel(const WtParams P, long long total, long long span) {
+    // a batch whose run lists were compacted on device (operator chains that drop runs) holds fewer
+    // intervals than the host counted: the device's seg_off[] is the authority
+    const long long dev_total = P.seg_off[(long long) P.n_chrom * P.n_tracks];
+    if (total > dev_total) total = dev_total;
     const long long begin0 = (long long) blockIdx.x * span;
     long long end0 = begin0 + span;
     if (end0 > total) end0 = total;
