@@ -442,7 +442,9 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_patch_kernel
 // Each block owns ONE contiguous span of intervals: a single binary search finds the
 // (chrom,track) segment of its first interval, every lane then walks its cursor forward.  The
 // finish[] reads of the next sub-chunk are in flight while the current one is applied.
+#ifndef WT_INDEX_UNROLL
 #define WT_INDEX_UNROLL 2
+#endif
 #define WT_INDEX_CHUNK (256 * 4 * WT_INDEX_UNROLL)
 __global__ void __launch_bounds__(256) wt_index_kernel(const WtParams P, long long total, long long span) {
     // a batch whose run lists were compacted on device (operator chains that drop runs) holds fewer
@@ -1332,6 +1334,13 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
             for (int q = 0; q < 8; q++)
                 fprintf(stderr, " %s %.1f%%", names[q], tot ? 100.0 * ts->h_counters[WT_CTR_PROF + q] / tot : 0.0);
             fprintf(stderr, " (total %.3g cycles over all workgroups)\n", (double) tot);
+            unsigned long long p2[8] = {0};
+            if (hipMemcpyFromSymbol(p2, HIP_SYMBOL(wt_prof2), sizeof p2) == hipSuccess && (p2[0] | p2[4])) {
+                fprintf(stderr, "[wt_profile] register column, cycles summed over waves: gather %.3g  sort/park %.3g  count loop %.3g  erf %.3g  median sort+select %.3g\n",
+                        (double) p2[0], (double) p2[1], (double) p2[2], (double) p2[3], (double) p2[4]);
+                unsigned long long z[8] = {0};
+                (void) hipMemcpyToSymbol(HIP_SYMBOL(wt_prof2), z, sizeof z);
+            }
         }
 #endif
         if (ts->h_counters[WT_CTR_ERROR] & WT_ERR_LOOKBACK) return wt_fail(WTAMD_ERR_INTERNAL, "look-back timed out");
