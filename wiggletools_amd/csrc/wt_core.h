@@ -946,57 +946,6 @@ WT_DEV bool wt_gather_regs(const WtParams &P, const WtCtx &c, int p0, uint32_t *
 
 #endif  // WT_REGCOL_FLAT
 
-// Sorted keys of one set, addressable by a wave-UNIFORM run-time index without leaving the register
-// file: hipcc lowers a uniform extractelement of a <= 32-lane vector to GPR-index mode
-// (s_set_gpr_idx_on ... v_mov), where an indexed C array would be demoted to scratch memory.
-#ifdef WT_EMU
-template <int H>
-struct WtKeyVec {
-    uint32_t v[H];
-    void load(const uint32_t *src) { for (int i = 0; i < H; i++) v[i] = src[i]; }
-    uint32_t get(int e) const { return v[e]; }
-};
-#else
-typedef uint32_t wt_v32u __attribute__((ext_vector_type(32)));
-typedef uint32_t wt_v16u __attribute__((ext_vector_type(16)));
-template <int H> struct WtKeyVec;
-template <> struct WtKeyVec<16> {
-    wt_v16u a;
-    WT_DEV void load(const uint32_t *src) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) a[i] = src[i];
-    }
-    WT_DEV uint32_t get(int e) const { return a[e & 15]; }
-};
-template <> struct WtKeyVec<32> {
-    wt_v32u a;
-    WT_DEV void load(const uint32_t *src) {
-#pragma unroll
-        for (int i = 0; i < 32; i++) a[i] = src[i];
-    }
-    WT_DEV uint32_t get(int e) const { return a[e & 31]; }
-};
-template <> struct WtKeyVec<64> {
-    wt_v32u a, b;
-    WT_DEV void load(const uint32_t *src) {
-#pragma unroll
-        for (int i = 0; i < 32; i++) { a[i] = src[i]; b[i] = src[32 + i]; }
-    }
-    WT_DEV uint32_t get(int e) const { return e < 32 ? a[e & 31] : b[e & 31]; }
-};
-#endif
-
-// MWU over a register column (wt_gather_regs).  Both sets are sorted by register networks as
-// order-preserving keys (-0.0 canonicalised to +0.0: the reference compares doubles).  Set 1 is
-// parked in this lane's LDS column (nb * 4 B -- the only LDS the reducer needs), set 0 stays in
-// registers (WtKeyVec).  ONE pass over the sorted set-0 values x_e; for each, two branch-free binary
-// searches in the LDS column (conflict-free: the column stride is a multiple of the bank count)
-//   L_e = #set-1 values < x_e,   t_e = #set-1 values == x_e,   last_e = next set-0 value differs,
-// feed the reference's tie state machine (setComparisons.c:335-359) in the reference's order --
-// the table's stable sort puts set-0 entries first inside a tie group, and tied set-0 entries are
-// interchangeable (same L, same t; `last` is positional).  2 log2(H) LDS probes per set-0 value
-// instead of 2 H compare / add-carry pairs (round-2 measurement: the pairs were 12.8 K of the
-// ~17 K VALU instructions per position at 50 v 50).
 #if defined(WT_PROFILE) && !defined(WT_EMU)
 // -DWT_PROFILE builds: cycles of the register-column reducers' sub-phases (lane 0 of every wave)
 __device__ unsigned long long wt_prof2[8];
@@ -1007,90 +956,56 @@ __device__ unsigned long long wt_prof2[8];
 #define WT_SUBTICK(slot) do { } while (0)
 #define WT_SUBTICK_BEGIN do { } while (0)
 #endif
-#ifndef WT_MWU_EB
-#define WT_MWU_EB 1      // set-0 values searched together (4 was no faster and miscompiled at NR = 128: kept at 1)
-#endif
+// (Round 2 also tried: both sets sorted, set 1 parked, two branch-free binary searches per set-0 value with
+// the set-0 keys in a register vector indexed in GPR-index mode.  No faster -- the kernel is bound by
+// instruction issue and the searches compiled to ~190 instructions per value, as many as the 2 x 64
+// compare / add-carry pairs below -- and the build was not stable at 128 slots on MI355X (sporadic
+// corrupted run counts at chromosome size), so it was dropped.  DESIGN 10.)
+// MWU over a register column (wt_gather_regs): set 0 sorted by a register network and parked in
+// this lane's LDS column (n_set0 * 4 B -- the only LDS the reducer needs); then ONE pass over the
+// sorted set-0 values e, each compared with the set-1 registers (compile-time indices):
+//   L_e = #set-1 values < x_e,   t_e = #set-1 values == x_e,   last_e = next set-0 value differs,
+// feeding the reference's tie state machine (setComparisons.c:335-359) in the reference's order --
+// the table's stable sort puts set-0 entries first inside a tie group, and tied set-0 entries are
+// interchangeable (same L, same t; `last` is positional).  No attribute slab, no second phase.
 template <int NR>
-WT_DEV double wt_mwu_regs(const WtParams &P, uint32_t *col, uint32_t *col2, uint32_t *ys, int colstride) {
+WT_DEV double wt_mwu_regs(const WtParams &P, uint32_t *col, const uint32_t *col2, float *xs, int colstride) {
     constexpr int H = NR / 2;
     const int na = P.n_set0, nb = P.n_tracks - P.n_set0;
-    WT_SUBTICK_BEGIN;
-    // set 1 -> keys, sorted, parked (pads 0xffffffff sort last and are not stored)
+    // sort set 0 as order-preserving keys (pads: 0xffffffff, they end up last)
 #pragma unroll
-    for (int s = 0; s < H; s++)
-        col2[s] = s < nb ? wt_key32(__builtin_bit_cast(float, col2[s] == 0x80000000u ? 0u : col2[s])) : 0xffffffffu;
-    wt_sort_regs<H, false>(col2);
-#pragma unroll
-    for (int s = 0; s < H; s++)
-        if (s < nb) ys[(size_t) s * colstride] = col2[s];
-    // set 0 -> keys, sorted, kept in registers
-#pragma unroll
-    for (int s = 0; s < H; s++)
-        col[s] = s < na ? wt_key32(__builtin_bit_cast(float, col[s] == 0x80000000u ? 0u : col[s])) : 0xffffffffu;
+    for (int s = 0; s < H; s++) col[s] = s < na ? wt_key32(__builtin_bit_cast(float, col[s])) : 0xffffffffu;
     wt_sort_regs<H, false>(col);
-    WtKeyVec<H> X;
-    X.load(col);
-    WT_SUBTICK(1);
+#pragma unroll
+    for (int s = 0; s < H; s++)
+        if (s < na) xs[(size_t) s * colstride] = wt_unkey32(col[s]);
+    float y[H];
+#pragma unroll
+    for (int s = 0; s < H; s++) y[s] = __builtin_bit_cast(float, col2[s]);
     const double mu = (double) (na * nb / 2);                               // :386 int division
     const double sigma = sqrt((double) (na * nb * (na + nb + 1) / 12));     // :387 int division
     double U1 = 0;
     int ties = 0, prevTies = 0;
-    // WT_MWU_EB set-0 values per round (their searches are independent; the state machine then consumes
-    // them in order).
-    for (int e0 = 0; e0 < na; e0 += WT_MWU_EB) {
-        uint32_t xv[WT_MWU_EB + 1];
-        int lb[WT_MWU_EB], ub[WT_MWU_EB];
+    float x = xs[0];
+    for (int e = 0; e < na; e++) {
+        const float xn = e + 1 < na ? xs[(size_t) (e + 1) * colstride] : x;
+        int L = 0, t = 0;
 #pragma unroll
-        for (int q = 0; q <= WT_MWU_EB; q++) xv[q] = X.get(e0 + q < na ? e0 + q : na - 1);
-#pragma unroll
-        for (int q = 0; q < WT_MWU_EB; q++) { lb[q] = 0; ub[q] = 0; }
-        // lb = #y < x, ub = #y <= x over the nb parked keys (entries at or beyond nb count as +inf)
-#pragma unroll
-        for (int step = H / 2; step >= 1; step >>= 1) {
-            uint32_t y1[WT_MWU_EB], y2[WT_MWU_EB];
-#pragma unroll
-            for (int q = 0; q < WT_MWU_EB; q++) {
-                const int i1 = lb[q] + step - 1, i2 = ub[q] + step - 1;
-                y1[q] = ys[(size_t) (i1 < nb ? i1 : nb - 1) * colstride];
-                y2[q] = ys[(size_t) (i2 < nb ? i2 : nb - 1) * colstride];
-            }
-#pragma unroll
-            for (int q = 0; q < WT_MWU_EB; q++) {
-                const int i1 = lb[q] + step - 1, i2 = ub[q] + step - 1;
-                lb[q] += (i1 < nb && y1[q] < xv[q]) ? step : 0;
-                ub[q] += (i2 < nb && y2[q] <= xv[q]) ? step : 0;
-            }
+        for (int s = 0; s < H; s++) { L += (y[s] < x); t += (y[s] == x); }
+        const bool last = (e + 1 == na) || !(xn == x);
+        U1 += L;                                      // :336  U1 += index - prev
+        if (ties) {                                   // :337-346
+            if (last) prevTies += t;
+            U1 -= prevTies / 2.0;
+            U1 += (ties - prevTies) / 2.0;
+            if (prevTies == ties) prevTies = ties = 0;
+        } else {                                      // :347-354
+            ties += t;
+            if (ties) U1 += ties / 2.0;
         }
-        if (nb == H) {              // the steps reach H - 1 at most
-            const uint32_t yl = ys[(size_t) (H - 1) * colstride];
-#pragma unroll
-            for (int q = 0; q < WT_MWU_EB; q++) {
-                lb[q] += (lb[q] == H - 1 && yl < xv[q]) ? 1 : 0;
-                ub[q] += (ub[q] == H - 1 && yl <= xv[q]) ? 1 : 0;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < WT_MWU_EB; q++) {
-            const int e = e0 + q;
-            if (e >= na) break;
-            const int L = lb[q], t = ub[q] - lb[q];
-            const bool last = (e + 1 == na) || xv[q + 1] != xv[q];
-            U1 += L;                                      // :336  U1 += index - prev
-            if (ties) {                                   // :337-346
-                if (last) prevTies += t;
-                U1 -= prevTies / 2.0;
-                U1 += (ties - prevTies) / 2.0;
-                if (prevTies == ties) prevTies = ties = 0;
-            } else {                                      // :347-354
-                ties += t;
-                if (ties) U1 += ties / 2.0;
-            }
-        }
+        x = xn;
     }
-    WT_SUBTICK(2);
-    const double r_ = (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
-    WT_SUBTICK(3);
-    return r_;
+    return (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
 }
 
 template <int OP, class ValT, class ScrT, int K, int NR>
@@ -1130,7 +1045,7 @@ WT_DEV void wt_eval_chunk(const WtParams &P, const WtCtx &c, int p0, WtAcc<K, NR
                 v = (double) wt_unkey32(m);
                 WT_SUBTICK(4);
             } else {
-                v = wt_mwu_regs<NR>(P, A.col, A.col2, (uint32_t *) scratch + lane_col, P.W / K);
+                v = wt_mwu_regs<NR>(P, A.col, A.col2, (float *) scratch + lane_col, P.W / K);
             }
             A.a[k] = nan ? wt_nan() : v;
         }

@@ -64,7 +64,7 @@ static inline void wt_carve(int n_tracks, int op, int W, int T, int scratch_elem
     p.off_scratch = o;
     long long scr_bytes = 0;
     if (op == WT_OP_MEDIAN || op == WT_OP_MWU) scr_bytes = (long long) n_tracks * W * scratch_elem;    // one column per position
-    if (regcol) scr_bytes = op == WT_OP_MWU ? (long long) (n_tracks - n_set0) * T * 4 : 0;       // register columns: MWU parks the sorted set 1, one column per LANE
+    if (regcol) scr_bytes = op == WT_OP_MWU ? (long long) n_set0 * T * 4 : 0;       // register columns: MWU parks the sorted set 0, one column per LANE
     scr_bytes = (scr_bytes + 255) & ~255ll;
     p.scratch_slab = scratch_global ? scr_bytes : 0;
     // MWU: the per-rank attribute words (one u32 per set-0 track and lane, written once and read
