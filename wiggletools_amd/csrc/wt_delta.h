@@ -329,6 +329,11 @@ struct WtDeltaBatch {
     bool in[WT_DELTA_U];
 };
 
+// The loads are UNCONDITIONAL: a flat index past the end reads interval 0 and is flagged `!in`.  With a
+// branch (or an exec-masked region the compiler may skip) around them, the number of loads in flight
+// is unknown to the compiler, and the consumer of the PREVIOUS tile gets `s_waitcnt vmcnt(0)` --
+// the prefetch is waited for before the tile it was meant to overlap is applied (round 2, read off
+// the ISA: that wait sat in front of every apply).
 WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, WtDeltaBatch &B) {
     const uint32_t *val = (const uint32_t *) P.value;
     long long g[WT_DELTA_U];
@@ -336,9 +341,10 @@ WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint3
 #pragma unroll
     for (int u = 0; u < WT_DELTA_U; u++) {
         B.in[u] = g[u] >= 0;
-        B.s[u] = B.in[u] ? P.start[g[u]] : 0;
-        B.f[u] = B.in[u] ? P.finish[g[u]] : 0;
-        B.b[u] = B.in[u] ? val[g[u]] : 0u;
+        const long long gs = g[u] >= 0 ? g[u] : 0;
+        B.s[u] = P.start[gs];
+        B.f[u] = P.finish[gs];
+        B.b[u] = val[gs];
     }
 }
 
@@ -357,7 +363,7 @@ WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale
     uint32_t tb = (uint32_t) wave * WT_DELTA_TILE;
     if (tb < M) wt_delta_fetch(P, d, nt, M, tb, lane, cur);
     for (; tb < M; tb += step) {
-        if (tb + step < M) wt_delta_fetch(P, d, nt, M, tb + step, lane, nxt);
+        wt_delta_fetch(P, d, nt, M, tb + step, lane, nxt);      // (past the end: harmless reads of interval 0)
 #pragma unroll
         for (int u = 0; u < WT_DELTA_U; u++)
             if (cur.in[u]) {
