@@ -363,14 +363,17 @@ WT_DEV void wt_load_fetch(const WtParams &P, const WtCtx &c, int i, int lane, Wt
     b.hi = row0[N + i];
     if (b.hi >= n) b.hi = n - 1;
 #pragma unroll
+    // unconditional loads (an index past the track's range reads interval 0 of the batch and is never
+    // applied): with a predicate -- or a branch -- around them the compiler cannot count the loads in
+    // flight and makes the consumer of the previous batch wait for all of them (see wt_delta_fetch)
     for (int u = 0; u < WT_LOAD_UNROLL; u++) {
         const long long jr = b.lo + lane + WT_LOAD_GROUP * u;
-        const bool ok = jr <= b.hi;
-        b.s[u] = ok ? P.start[b.off + jr] : 0;
-        b.f[u] = ok ? P.finish[b.off + jr] : 0;
+        const long long at = jr <= b.hi ? b.off + jr : 0;
+        b.s[u] = P.start[at];
+        b.f[u] = P.finish[at];
         // the value is not needed here: the load (coalesced, many in flight) warms L2 with the
         // very cache lines the eval phase gathers from, so those gathers stop paying HBM latency
-        b.v[u] = ok ? ((const ValT *) P.value)[b.off + jr] : (ValT) 0;
+        b.v[u] = ((const ValT *) P.value)[at];
     }
 }
 
@@ -405,7 +408,7 @@ WT_DEV void wt_phase_load(const WtParams &P, WtCtx &c, int t_lo, int t_hi, bool 
     for (int g = t_lo + group; g < t_hi; g += ngroups) {
         WtLoadBatch<ValT> nxt;
         const int gnext = g + ngroups;
-        if (gnext < t_hi) wt_load_fetch<ValT>(P, c, gnext, lane, nxt);
+        wt_load_fetch<ValT>(P, c, gnext < t_hi ? gnext : t_hi - 1, lane, nxt);     // (past the end: the last track again, unused)
         const int i = g - t_lo;
         uint64_t *SCi = c.SC + (size_t) i * P.spitch;
         uint16_t *pseudo = c.cnt + (size_t) i * P.cpitch + P.n_words * 2;
