@@ -184,8 +184,9 @@ def e2e_dropin(op, n_tracks, mean_run, mbp, device):
     """The reference's own C API (newMultiplexer + <op>Reduction) over N array-backed tracks in
     PINNED host memory, from the constructor (which primes: the first pop) to the last run on the
     host.  Two legs on the same tracks:
-      pop   the reference's protocol on both sides: children popped one interval per indirect call,
-            runs taken one pop at a time (what any foreign reader / consumer gets);
+      pop   the reference's protocol on both sides: children popped one interval per indirect call (by a
+            few worker threads, each child always by the same one), runs taken one pop at a time (what
+            any foreign reader / consumer gets);
       bulk  the library's bulk doors: children hand over SoA blocks that the copy engine reads where
             they lie, runs taken in blocks.
     Both run the pinned-staging / 3-stream pipeline of csrc/wt_pipe.h underneath."""
@@ -227,16 +228,24 @@ def e2e_dropin(op, n_tracks, mean_run, mbp, device):
     q = [m for m in marks if m[1] >= L // 4]
     if len(q) >= 2 and q[-1][0] > q[0][0]:
         out["bulk"]["steady_bp_per_s"] = (q[-1][1] - q[0][1]) / (q[-1][0] - q[0][0])
-    # pop leg (a slice: it is ~50x slower)
+    # pop legs (a slice: they are slower): children drained by the library's worker threads (a child always by
+    # the same thread; the default for 16 or more foreign children) and by ONE thread
     os.environ["WTAMD_NO_BULK"] = "1"
     pop_bp = int(min(L, 20e6))
-    t0 = time.perf_counter()
-    r = dropin.reducer(op, readers(pop_bp), n_set0=n_tracks // 2)
-    runs, bp, acc = dropin.drain_pops(r)
-    dt = time.perf_counter() - t0
+    for key, threads in (("pop", None), ("pop_one_drain_thread", "1")):
+        if threads is None:
+            os.environ.pop("WTAMD_DRAIN_THREADS", None)
+        else:
+            os.environ["WTAMD_DRAIN_THREADS"] = threads
+        t0 = time.perf_counter()
+        r = dropin.reducer(op, readers(pop_bp), n_set0=n_tracks // 2)
+        runs, bp, acc = dropin.drain_pops(r)
+        dt = time.perf_counter() - t0
+        out[key] = {"bp_per_s": bp / dt, "seconds": dt, "bp": bp, "runs": runs,
+                    "child_pops_per_s": (12.0 * n / L * bp / 12.0) / dt,
+                    "drain_threads": threads or ("auto: min(16, usable cores = %d) for >= 16 foreign children" % effective_cores())}
     os.environ.pop("WTAMD_NO_BULK", None)
-    out["pop"] = {"bp_per_s": bp / dt, "seconds": dt, "bp": bp, "runs": runs,
-                  "child_pops_per_s": (12.0 * n / L * bp / 12.0) / dt}
+    os.environ.pop("WTAMD_DRAIN_THREADS", None)
     hs.free(); hf.free(); hv.free()
     return out
 

@@ -345,3 +345,23 @@ def test_dropin_mixed_children_and_float64_switch(oracle, H, monkeypatch):
             assert_runs_equal(H.reduce(d, op), oracle.reduce(d, op), _tol(op), op + " (float64 switch)")
     finally:
         H.set_modes(0, 0)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_dropin_parallel_drain(oracle, H, tiny_batches, monkeypatch, seed):
+    """Foreign children dealt to worker threads (a child always to the same one), batches laid out in
+    track order afterwards: same runs as the single-threaded drain -- seams, carried intervals,
+    sentinels, the float64 switch, two-sample sets, seek."""
+    monkeypatch.setenv("WTAMD_DRAIN_THREADS", "3")
+    t = random_case(9500 + seed, n_tracks=int(4 + seed), max_len=900)
+    if seed % 2:
+        t.value[:: 7] = 0.1 + t.value[:: 7]         # not float32-exact: the batch that meets one switches to float64
+    d = t.as_dict()
+    for strict in (0, 1):
+        for op in ("mean", "max", "stddev", "median"):
+            assert_runs_equal(H.reduce(d, op, flags=strict), oracle.reduce(d, op, flags=strict), _tol(op),
+                              "threads seed %d %s strict %d" % (seed, op, strict))
+    n0 = t.n_tracks // 2
+    for op in ("ttest", "mwu"):
+        if n0 >= 3 and t.n_tracks - n0 >= 3:
+            assert_runs_equal(H.reduce(d, op, n_set0=n0), oracle.reduce(d, op, n_set0=n0), _tol(op), "threads %s" % op)

@@ -40,6 +40,7 @@
 #include <algorithm>
 #include <chrono>
 #include <deque>
+#include <functional>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -154,6 +155,86 @@ bool wt_surely_kept(const wtamd_map_chain &c, double v) {
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Parallel draining of foreign children.  The reference's protocol is one indirect call per interval;
+// one host thread sustains ~1.2e8 of them per second, which is what bounded the `pop` leg of the
+// end-to-end path.  The protocol only demands that ONE iterator is never entered by two
+// threads at once (its readers already run producer threads of their own: bufferedReader.c:118-134),
+// so the N children of a Multiplexer are dealt to a few worker threads -- a child always to the same
+// one -- which pop them into private buffers; the batch is then laid out in track order and the
+// workers copy their tracks into the pinned staging.  WTAMD_DRAIN_THREADS=1 switches it off.
+// ---------------------------------------------------------------------------
+struct DrainOut {
+    std::vector<int32_t> s, f;
+    std::vector<double> v;
+    bool more = false, carry = false, need64 = false;
+    int32_t sentinel_lo = INT32_MAX;
+    int64_t at = 0;
+    void clear() { s.clear(); f.clear(); v.clear(); more = carry = need64 = false; sentinel_lo = INT32_MAX; at = 0; }
+    void push(int32_t st, int32_t fi, double x) {
+        s.push_back(st); f.push_back(fi); v.push_back(x);
+        const float fl = (float) x;
+        if ((double) fl != x && x == x) need64 = true;
+    }
+};
+
+struct DrainPool {
+    int T = 0;
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    uint64_t gen = 0;
+    int pending = 0;
+    bool quit = false;
+    std::function<void(int)> job;
+
+    void start(int t) {
+        T = t;
+        for (int w = 0; w < T; w++) th.emplace_back([this, w] { loop(w); });
+    }
+    void loop(int w) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_go.wait(lk, [&] { return quit || gen != seen; });
+            if (quit) return;
+            seen = gen;
+            lk.unlock();
+            job(w);
+            lk.lock();
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+    void run(std::function<void(int)> j) {
+        std::unique_lock<std::mutex> lk(mu);
+        job = std::move(j);
+        pending = T;
+        gen++;
+        cv_go.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~DrainPool() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
+
+int wt_usable_cores() {
+    // container CPU quota first (the GPU box shows 256 logical CPUs and grants 16): "quota period" or "max period"
+    if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; long long period = 0;
+        const int got = fscanf(fp, "%63s %lld", q, &period);
+        fclose(fp);
+        if (got == 2 && period > 0 && strcmp(q, "max") != 0) {
+            const long long c = atoll(q) / period;
+            if (c >= 1) return (int) (c > 64 ? 64 : c);
+        }
+    }
+    const unsigned h = std::thread::hardware_concurrency();
+    return h ? (int) (h > 64 ? 64 : h) : 1;
+}
+
 const int64_t kDirectMin = 64;              // bulk blocks of at least this many intervals bypass the staging
 const int64_t kFirstSpan = 2048;            // bp of a Multiplexer's priming batch
 const int64_t kReducerFirstSpan = 65536;    // bp of a reducer's first batch
@@ -171,6 +252,8 @@ struct Feeder {
     bool f64_mode = false;              // a value that is not float32-exact was seen
     bool use_bulk = true;               // WTAMD_NO_BULK=1: children of this library are popped like foreign ones
     bool all_bulk = false;              // every child is a bulk source of this library (float32 SoA): unstaged DMA
+    DrainPool *pool = nullptr;          // parallel draining: every child is foreign, nothing is dropped on device
+    std::vector<DrainOut> outs;
     // drain position
     const char *chrom = nullptr;        // chromosome of the batch being / last drained
     bool continuing = false;            // next batch continues `chrom` at next_lo
@@ -207,11 +290,50 @@ struct Feeder {
         std::vector<wtamd_map_chain> chains;
         for (const auto &s : src) { chains.push_back(s.chain); any_map = any_map || s.chain.n_ops > 0; }
         if (any_map && wtamd_pipe_set_map(pipe, chains.data()) != WTAMD_OK) die("wtamd_pipe_set_map");
+        // parallel draining when every child is popped through the reference's protocol
+        bool eligible = !keep_log && !src.empty();
+        for (const auto &s : src) eligible = eligible && !(s.bulk && use_bulk) && !s.drops;
+        const char *et = getenv("WTAMD_DRAIN_THREADS");
+        int threads = et ? atoi(et) : (n_tracks() >= 16 ? std::min(wt_usable_cores(), 16) : 1);
+        if (threads > n_tracks()) threads = n_tracks();
+        if (eligible && threads >= 2 && !pool) {
+            pool = new DrainPool();
+            pool->start(threads);
+            outs.resize(src.size());
+        }
     }
 
     void close() {
         if (pipe) wtamd_pipe_destroy(pipe);
         pipe = nullptr;
+        delete pool;
+        pool = nullptr;
+    }
+
+    // One foreign child, popped up to the cut `hi` of chromosome `chrom` (interned) into `o`.  Worker
+    // threads run this: it must not intern (the table is not thread-safe) -- a raw name the source
+    // has not seen interned yet is compared by content.
+    void drain_foreign(TrackSource &s, const char *chrom, int32_t hi, DrainOut &o) {
+        o.clear();
+        while (!s.pending.empty()) {
+            const Ivl h = s.pending.front();
+            if (h.chrom != chrom) return;
+            o.push(h.start, h.finish, h.value);
+            if (h.start >= hi) { o.more = true; o.sentinel_lo = h.start; return; }
+            if (h.finish >= hi) { o.more = o.carry = true; return; }     // reaches the cut: seen again
+            s.pending.pop_front();
+        }
+        WiggleIterator *it = s.it;
+        while (!it->done) {
+            const char *rc = it->chrom;
+            if (rc == s.raw && s.interned) { if (s.interned != chrom) return; }
+            else if (strcmp(rc, chrom) != 0) return;
+            const int32_t st = it->start, fi = it->finish;
+            o.push(st, fi, it->value);
+            if (st >= hi) { o.more = true; o.sentinel_lo = st; return; }    // sentinel: stays current
+            if (fi >= hi) { o.more = o.carry = true; return; }              // reaches the cut: stays current
+            it->pop(it);
+        }
     }
 
     // Throws away everything in flight (results included).
@@ -332,7 +454,39 @@ struct Feeder {
             }
         };
 
-        for (int i = 0; i < N; i++) {
+        if (pool) {
+            const int T = pool->T;
+            const char *cname = chrom;
+            pool->run([&](int w) { for (int i = w; i < N; i += T) drain_foreign(src[(size_t) i], cname, hi, outs[(size_t) i]); });
+            bool need64 = false;
+            for (int i = 0; i < N; i++) {
+                DrainOut &o = outs[(size_t) i];
+                o.at = n;
+                n += (int64_t) o.s.size();
+                need64 = need64 || o.need64;
+                more = more || o.more; carry = carry || o.carry;
+                if (o.sentinel_lo < sentinel_lo) sentinel_lo = o.sentinel_lo;
+            }
+            if (need64) f64_mode = true;        // (nothing staged yet: no conversion of earlier entries needed)
+            if (n > b.capacity || (f64_mode && !b.value64)) {
+                const int64_t want = n > 2 * b.capacity ? n : 2 * b.capacity;
+                if (wtamd_pipe_grow(pipe, 0, n > b.capacity ? want : b.capacity, f64_mode, &b) != WTAMD_OK) die("wtamd_pipe_grow");
+            }
+            for (int i = 0; i < N; i++) b.seg_off[i] = outs[(size_t) i].at;
+            const bool w64 = f64_mode;
+            pool->run([&](int w) {
+                for (int i = w; i < N; i += T) {
+                    const DrainOut &o = outs[(size_t) i];
+                    const size_t k = o.s.size();
+                    if (!k) continue;
+                    memcpy(b.start + o.at, o.s.data(), sizeof(int32_t) * k);
+                    memcpy(b.finish + o.at, o.f.data(), sizeof(int32_t) * k);
+                    if (w64) memcpy(b.value64 + o.at, o.v.data(), sizeof(double) * k);
+                    else for (size_t q = 0; q < k; q++) b.value32[o.at + (int64_t) q] = (float) o.v[q];
+                }
+            });
+        }
+        for (int i = 0; i < N && !pool; i++) {
             TrackSource &s = src[i];
             b.seg_off[i] = n;
             bool stop = false;
