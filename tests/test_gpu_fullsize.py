@@ -142,3 +142,42 @@ def test_gpu_plans_agree_bitwise_at_scale(op, kw, monkeypatch):
             assert got[0] == ref[0], (env, got[0], ref[0])
             assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), env
             assert torch.equal(got[3], ref[3]), "plan %s changes the value bits of %s" % (env, op)
+
+
+@pytest.mark.parametrize("op", ["var", "stddev", "cv"])
+def test_gpu_var_family_two_algorithms_at_scale(op, monkeypatch):
+    """Variance family at 62 Mbp x 100 tracks through two independent algorithms: exact integer sums of
+    the scaled mantissas and of their squares with a 128-bit finish (difference arrays)
+    vs the reference's two sequential f64 passes per position (general kernel).  Coordinates and run
+    count identical; values within 1e-12 relative (the reference-order result carries ~N roundings,
+    the integer route one)."""
+    import torch
+    import bench
+    from wiggletools_amd import engine, synthgen
+
+    dev = torch.device("cuda", 0)
+    N = 100
+    chrom_lens = [max(int(x * 0.02), 1) for x in bench.GRCH38]
+    seg_off, start, finish, value = synthgen.device_tracks(5, chrom_lens, N, 16.0, 0.02, 800, dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    res = []
+    for no_delta in (False, True):
+        if no_delta:
+            monkeypatch.setenv("WTAMD_NO_DELTA_VAR", "1")
+        else:
+            monkeypatch.delenv("WTAMD_NO_DELTA_VAR", raising=False)
+        ts = engine.TrackSet.from_device(len(chrom_lens), N, seg_off, start, finish, value, np.zeros(N))
+        out = ts.alloc_runs()
+        n = ts.reduce(op, out, stream=stream, sync=True)
+        assert ts.stats()["kernel"] == (0 if no_delta else 1)
+        ts.close()
+        res.append((n, out.start[:n].clone(), out.finish[:n].clone(), out.value[:n].clone()))
+        del out
+    (na, sa, fa, va), (nb, sb, fb, vb) = res
+    assert na == nb and na > 1e7
+    assert torch.equal(sa, sb) and torch.equal(fa, fb)
+    assert torch.equal(torch.isnan(va), torch.isnan(vb))
+    ok = ~torch.isnan(va)
+    err = (va[ok] - vb[ok]).abs()
+    tol = 1e-12 * torch.maximum(vb[ok].abs(), torch.tensor(1e-300, dtype=torch.float64, device=dev))
+    assert bool((err <= tol).all()), float((err / tol).max())
