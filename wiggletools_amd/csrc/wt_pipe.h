@@ -188,6 +188,10 @@ struct wtamd_pipe {
     bool compress = false;          // WTAMD_PIPE_COMPRESS: batches submitted from now on are merged on device before they travel
     bool gather = true;             // WTAMD_PIPE_GATHER=0: hipMemcpyAsync per range instead of the gather kernel
     int gather_blocks = 64;         // WTAMD_GATHER_BLOCKS
+    // buffers a slot outgrew: released when the pipe is destroyed -- hipFree / hipHostFree wait for the
+    // whole device, i.e. for the batches in flight on the other slots (measured: 6-8 ms per growing
+    // submit while the pipeline ramps up)
+    std::vector<void *> dead_dev, dead_host;
     void *d_chains = nullptr;       // wtamd_pipe_set_map: per-track operator chains on device
     bool map_drops = false;         // ... some operator drops runs: batches are compacted
     int num_cu = 256;
@@ -391,6 +395,8 @@ void wtamd_pipe_destroy(wtamd_pipe *p) {
     if (p->s_comp) (void) hipStreamDestroy(p->s_comp);
     if (p->s_out) (void) hipStreamDestroy(p->s_out);
     if (p->d_chains) (void) hipFree(p->d_chains);
+    for (void *q : p->dead_dev) (void) hipFree(q);
+    for (void *q : p->dead_host) (void) hipHostFree(q);
     delete p;
 }
 
@@ -480,10 +486,9 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     // device twin of the staging (grow-only)
     const int64_t need_in = n > 0 ? n : 1;
     if (s.dcap < need_in || (f64 && !s.d_has64)) {
-        (void) hipStreamSynchronize(p->s_comp);         // an earlier batch of this slot has long been collected; be safe anyway
         int64_t c = s.dcap * 2 > need_in ? s.dcap * 2 : need_in;
         if (c < s.cap) c = s.cap;
-        (void) hipFree(s.d_start); (void) hipFree(s.d_finish); (void) hipFree(s.d_value);
+        for (void *q : {(void *) s.d_start, (void *) s.d_finish, s.d_value}) if (q) p->dead_dev.push_back(q);
         s.d_start = s.d_finish = nullptr; s.d_value = nullptr; s.dcap = 0;
         const bool w64 = f64 || s.d_has64 || s.has64;
         WT_HIP(hipMalloc(&s.d_start, sizeof(int32_t) * c));
@@ -493,8 +498,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     }
     const bool mapped = p->d_chains != nullptr;
     if (mapped && (s.mcap < s.dcap || (p->map_drops && !s.m_has_coords))) {
-        (void) hipStreamSynchronize(p->s_comp);
-        (void) hipFree(s.d_mstart); (void) hipFree(s.d_mfinish); (void) hipFree(s.d_mvalue); (void) hipFree(s.d_mscratch);
+        for (void *q : {(void *) s.d_mstart, (void *) s.d_mfinish, (void *) s.d_mvalue, (void *) s.d_mscratch}) if (q) p->dead_dev.push_back(q);
         s.d_mstart = s.d_mfinish = nullptr; s.d_mvalue = nullptr; s.d_mscratch = nullptr; s.mcap = 0; s.m_has_coords = false;
         WT_HIP(hipMalloc(&s.d_mvalue, sizeof(double) * (size_t) s.dcap));
         if (p->map_drops) {
@@ -516,13 +520,9 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
         int64_t c = s.ocap * 2 > need_out ? s.ocap * 2 : need_out;
         if (c > p->cfg.max_runs) c = p->cfg.max_runs;
         if (c < need_out) c = need_out;
-        (void) hipFree(s.d_os); (void) hipFree(s.d_of); (void) hipFree(s.d_ov); (void) hipFree(s.d_tile); (void) hipFree(s.d_ip);
+        for (void *q : {(void *) s.d_os, (void *) s.d_of, (void *) s.d_ov, (void *) s.d_tile, (void *) s.d_ip}) if (q) p->dead_dev.push_back(q);
         s.d_os = s.d_of = nullptr; s.d_ov = s.d_tile = nullptr; s.d_ip = nullptr;
-        if (s.h_os) (void) hipHostFree(s.h_os);
-        if (s.h_of) (void) hipHostFree(s.h_of);
-        if (s.h_ov) (void) hipHostFree(s.h_ov);
-        if (s.h_tile) (void) hipHostFree(s.h_tile);
-        if (s.h_ip) (void) hipHostFree(s.h_ip);
+        for (void *q : {(void *) s.h_os, (void *) s.h_of, (void *) s.h_ov, (void *) s.h_tile, (void *) s.h_ip}) if (q) p->dead_host.push_back(q);
         s.h_os = s.h_of = nullptr; s.h_ov = s.h_tile = nullptr; s.h_ip = nullptr; s.ocap = 0;
         WT_HIP(hipMalloc(&s.d_os, sizeof(int32_t) * c));
         WT_HIP(hipMalloc(&s.d_of, sizeof(int32_t) * c));
@@ -530,7 +530,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
         WT_HIP(hipHostMalloc((void **) &s.h_os, sizeof(int32_t) * c, hipHostMallocDefault));
         WT_HIP(hipHostMalloc((void **) &s.h_of, sizeof(int32_t) * c, hipHostMallocDefault));
         WT_HIP(hipHostMalloc((void **) &s.h_ov, sizeof(double) * c, hipHostMallocDefault));
-        (void) hipFree(s.d_cs); (void) hipFree(s.d_cf); (void) hipFree(s.d_cv); (void) hipFree(s.d_cscratch);
+        for (void *q : {(void *) s.d_cs, (void *) s.d_cf, (void *) s.d_cv, (void *) s.d_cscratch}) if (q) p->dead_dev.push_back(q);
         s.d_cs = s.d_cf = nullptr; s.d_cv = nullptr; s.d_cscratch = nullptr;
         if (p->tile) {
             WT_HIP(hipMalloc(&s.d_tile, sizeof(double) * c * N));
