@@ -484,7 +484,9 @@ def main():
         if kern == 0:
             o = ops[-1]
             if o in ("median", "wilcoxon", "mwu"):
-                bound, note = "issue", "value columns in LDS cap the waves per CU: dependent-VALU issue bound, not HBM (profiles/: SQ counters)"
+                bound, note = "issue", ("register-column reducer: bound by instruction issue (gather ~70 instructions per track and position, two 64-key "
+                                        "compare-exchange networks, the rank-sum count loop), not by HBM -- the frac against the HBM peak is reported for the "
+                                        "record only (DESIGN 10; profiles/r02_sq_c4_summary.json)")
             else:
                 bound, note = "valu", "f32->f64 widen + add per (track, position): VALU bound (profiles/: VALUBusy)"
         res = {
