@@ -38,6 +38,8 @@ def _bind(L):
     L.pop.restype = None
     L.seek.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
     L.seek.restype = None
+    L.destroyWiggleIterator.argtypes = [C.c_void_p]
+    L.destroyWiggleIterator.restype = None
     return L
 
 
@@ -152,6 +154,11 @@ def _run_single_reader(L, tmp_path):
         L.seek(wi, chrom.encode(), lo, hi)
         want = [(c, max(s, lo), min(f, hi), v) for c, s, f, v in exp if c == chrom and f > lo and s < hi]
         assert _pops(L, wi) == want
+    # the reference destroys iterators with free(data) (wiggleIterator.c:52-55): the handle is free()-able,
+    # the reader behind it (and its idle producer thread) stays
+    wi = L.wtamd_BigWiggleReader(paths[0].encode(), 1)
+    assert len(_pops(L, wi, limit=100)) == 100
+    L.destroyWiggleIterator(wi)
 
 
 def test_bigwig_reader_pop_and_seek_emu(emu_lib, tmp_path):

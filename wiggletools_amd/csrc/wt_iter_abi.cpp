@@ -873,7 +873,6 @@ struct BwBuffer {
 };
 
 struct BwReader {
-    BulkSource hdr;             // must stay first
     wtamd_bw *bw = nullptr;
     std::vector<std::string> names;     // chromosomes in strcmp order
     std::vector<char *> cnames;         // stable char* per chromosome
@@ -903,6 +902,13 @@ struct BwReader {
         const BwBuffer &b = buf[cur];
         return windowed && (b.start[g] < win_start || b.finish[g] > win_finish);
     }
+};
+
+// wi->data of a BigWig reader: free()-able like every iterator's data (wiggleIterator.c:52-55 frees it);
+// the reader proper -- buffers, file, producer thread -- lives on (idle) if the iterator is destroyed.
+struct BwHandle {
+    BulkSource hdr;             // must stay first (see wt_bulk_pop)
+    BwReader *r;
 };
 
 void bw_free(BwBuffer &b) {
@@ -1007,7 +1013,7 @@ void bw_settle(BwReader *r, WiggleIterator *wi) {
 }
 
 int64_t bw_peek(BulkSource *bs, const int32_t **s, const int32_t **f, const float **v) {
-    BwReader *r = (BwReader *) bs;
+    BwReader *r = ((BwHandle *) bs)->r;
     if (r->done || r->j >= r->end) return 0;
     const BwBuffer &b = r->buf[r->cur];
     if (r->clipped(r->j)) {
@@ -1024,7 +1030,7 @@ int64_t bw_peek(BulkSource *bs, const int32_t **s, const int32_t **f, const floa
 }
 
 void bw_advance(BulkSource *bs, WiggleIterator *wi, int64_t k) {
-    BwReader *r = (BwReader *) bs;
+    BwReader *r = ((BwHandle *) bs)->r;
     if (r->done) { wi->done = 1; return; }
     r->j += k;
     bw_settle(r, wi);
@@ -1033,7 +1039,7 @@ void bw_advance(BulkSource *bs, WiggleIterator *wi, int64_t k) {
 void bw_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
     // bigWiggleReader.c:125-145: the producer is restarted on [start, finish) of that chromosome;
     // the first interval is clipped to `start` (:143-144), the stretches end at `finish`
-    BwReader *r = (BwReader *) wi->data;
+    BwReader *r = ((BwHandle *) wi->data)->r;
     bw_wait(r);                             // whatever the producer is decoding lands first; it is idle afterwards
     r->windowed = true;
     r->win_start = start; r->win_finish = finish;
@@ -1471,7 +1477,9 @@ WiggleIterator *wtamd_MapIterator(WiggleIterator *child, int map_op, double para
     int depth = 1;
     for (WiggleIterator *w = child; w->pop == &map_pop; w = ((MapIter *) w->data)->child) depth++;
     if (depth > WTAMD_MAP_CHAIN_MAX) { puts("wtamd_MapIterator: operator chain too deep"); exit(1); }
-    MapIter *m = new MapIter{child, map_op, param, (map_op == WTAMD_MAP_LOG || map_op == WTAMD_MAP_EXPB) ? log(param) : 1.0};
+    MapIter *m = (MapIter *) calloc(1, sizeof(MapIter));        // free()-able, like every iterator's data
+    m->child = child; m->op = map_op; m->param = param;
+    m->lg = (map_op == WTAMD_MAP_LOG || map_op == WTAMD_MAP_EXPB) ? log(param) : 1.0;
     WiggleIterator *wi = (WiggleIterator *) calloc(1, sizeof(WiggleIterator));
     wi->data = m;
     wi->pop = &map_pop;
@@ -1487,9 +1495,11 @@ WiggleIterator *wtamd_BigWiggleReader(const char *path, int box) {
     wtamd_bw *bw = nullptr;
     if (wtamd_bw_open(path, &bw) != WTAMD_OK) exit(1);     // message printed (bigWiggleReader.c:116-118)
     BwReader *r = new BwReader();
-    r->hdr.peek = &bw_peek;
-    r->hdr.advance = &bw_advance;
-    r->hdr.stable = false;
+    BwHandle *h = (BwHandle *) calloc(1, sizeof(BwHandle));
+    h->hdr.peek = &bw_peek;
+    h->hdr.advance = &bw_advance;
+    h->hdr.stable = false;
+    h->r = r;
     r->bw = bw;
     r->box = box;
     for (int i = 0; i < wtamd_bw_n_chrom(bw); i++) r->names.push_back(wtamd_bw_chrom_name(bw, i));
@@ -1498,7 +1508,7 @@ WiggleIterator *wtamd_BigWiggleReader(const char *path, int box) {
     r->th = std::thread(bw_producer, r);
     r->th.detach();                             // lives for the process, like the reference's reader threads
     WiggleIterator *wi = (WiggleIterator *) calloc(1, sizeof(WiggleIterator));
-    wi->data = r;
+    wi->data = h;
     wi->pop = &wt_bulk_pop;
     wi->seek = &bw_seek;
     wi->value = 1;
