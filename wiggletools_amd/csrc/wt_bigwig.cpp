@@ -19,6 +19,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <climits>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -140,13 +141,20 @@ bool decode_block(wtamd_bw *bw, const BwBlock &b, uint32_t chrom_id, std::vector
     const unsigned char *p = d + 24;
     const size_t item = type == 1 ? 12 : type == 2 ? 8 : 4;
     if (24 + item * n_items > dn) { bw->error = "data block item count exceeds its size"; return false; }
-    for (uint16_t k = 0; k < n_items; k++, p += item) {
-        Triple t;
-        if (type == 1) { t.start = get<uint32_t>(p); t.end = get<uint32_t>(p + 4); t.value = get<float>(p + 8); }
-        else if (type == 2) { t.start = get<uint32_t>(p); t.end = t.start + span; t.value = get<float>(p + 4); }
-        else if (type == 3) { t.start = cstart + k * step; t.end = t.start + span; t.value = get<float>(p); }
-        else { bw->error = "unknown BigWig section type"; return false; }
-        out.push_back(t);
+    // one loop per section type (the type test used to sit inside the per-item loop)
+    const size_t at = out.size();
+    out.resize(at + n_items);
+    Triple *o = out.data() + at;
+    if (type == 1) {
+        for (uint16_t k = 0; k < n_items; k++, p += 12) { o[k].start = get<uint32_t>(p); o[k].end = get<uint32_t>(p + 4); o[k].value = get<float>(p + 8); }
+    } else if (type == 2) {
+        for (uint16_t k = 0; k < n_items; k++, p += 8) { o[k].start = get<uint32_t>(p); o[k].end = o[k].start + span; o[k].value = get<float>(p + 4); }
+    } else if (type == 3) {
+        for (uint16_t k = 0; k < n_items; k++, p += 4) { o[k].start = cstart + k * step; o[k].end = o[k].start + span; o[k].value = get<float>(p); }
+    } else {
+        out.resize(at);
+        bw->error = "unknown BigWig section type";
+        return false;
     }
     return true;
 }
@@ -209,14 +217,15 @@ uint32_t wtamd_bw_chrom_length(const wtamd_bw *bw, int i) {
 // retries with a bigger buffer; < 0 on error.
 // Runs of `t` (0-based, sorted) as the reference's reader hands them over: 1-based, optionally cut at
 // its 10 000-bp stretch edges.  write == false only counts.
+// Never writes beyond `cap` entries (it keeps counting): the caller compares the result with its capacity.
 static int64_t emit_runs(const std::vector<Triple> &t, int box, int64_t length, bool write, int32_t *start, int32_t *finish,
-                         float *value) {
+                         float *value, int64_t cap = INT64_MAX) {
     const int64_t stretch = 10000;
     int64_t n = 0;
     for (const Triple &x : t) {
         const int64_t s = (int64_t) x.start + 1, f = (int64_t) x.end + 1;      // bigWiggleReader.c:39-40
         if (!box) {
-            if (write) { start[n] = (int32_t) s; finish[n] = (int32_t) f; value[n] = x.value; }
+            if (write && n < cap) { start[n] = (int32_t) s; finish[n] = (int32_t) f; value[n] = x.value; }
             n++;
             continue;
         }
@@ -226,7 +235,7 @@ static int64_t emit_runs(const std::vector<Triple> &t, int box, int64_t length, 
             if (a >= length || a >= f) break;
             const int64_t bs = std::max(s, a), bf = std::min(f, b);          // :42-44
             if (bs < bf) {
-                if (write) { start[n] = (int32_t) bs; finish[n] = (int32_t) bf; value[n] = x.value; }
+                if (write && n < cap) { start[n] = (int32_t) bs; finish[n] = (int32_t) bf; value[n] = x.value; }
                 n++;
             }
         }
@@ -276,9 +285,19 @@ int64_t wtamd_bw_read_part(wtamd_bw *bw, const char *chrom, int box, int64_t *cu
         bw->part_from = *cursor; bw->part_to = i; bw->part_chrom = (int) c->id; bw->part_blocks = max_blocks;
         bw->part_lo = lo0; bw->part_hi = hi0; bw->part_last = ended;
     }
-    const int64_t n = emit_runs(t, box, c->length, false, nullptr, nullptr, nullptr);
-    if (n > capacity) return n;             // the part stays cached: the next call only writes
-    emit_runs(t, box, c->length, true, start, finish, value);
+    // pieces <= runs + stretch edges crossed: when the caller's arrays surely hold that, write at once
+    int64_t bound = (int64_t) t.size();
+    if (box && !t.empty()) bound += ((int64_t) t.back().end - (int64_t) t.front().start) / 10000 + 2 + (int64_t) t.size() / 64;
+    int64_t n;
+    if (!box || bound <= capacity) {
+        if ((int64_t) t.size() > capacity) return (int64_t) t.size();      // (box == 0: one piece per run)
+        n = emit_runs(t, box, c->length, true, start, finish, value, capacity);
+        if (n > capacity) return n;         // (overlapping runs in a malformed file can exceed the bound)
+    } else {
+        n = emit_runs(t, box, c->length, false, nullptr, nullptr, nullptr);
+        if (n > capacity) return n;         // the part stays cached: the next call only writes
+        emit_runs(t, box, c->length, true, start, finish, value);
+    }
     *cursor = bw->part_to;
     *last = bw->part_last ? 1 : 0;
     bw->part_from = -1;
@@ -300,7 +319,7 @@ int64_t wtamd_bw_read_chrom(wtamd_bw *bw, const char *chrom, int box, int64_t ca
         std::stable_sort(t.begin(), t.end(), [](const Triple &a, const Triple &b) { return a.start < b.start; });
     const int64_t n = emit_runs(t, box, c->length, false, nullptr, nullptr, nullptr);
     if (n > capacity) return n;
-    return emit_runs(t, box, c->length, true, start, finish, value);
+    return emit_runs(t, box, c->length, true, start, finish, value, capacity);
 }
 
 }  // extern "C"

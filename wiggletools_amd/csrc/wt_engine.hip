@@ -200,8 +200,11 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
 // instead of O(tracks x runs); LDS independent of the track count.
 // (var / stddev / CV also accumulate the sum of squares: 256 lanes, two waves per SIMD)
 #define WT_DELTA_SQ(OP) ((OP) == WT_OP_VAR || (OP) == WT_OP_STDDEV || (OP) == WT_OP_ENTROPY || (OP) == WT_OP_CV)
+#ifndef WT_DELTA_MIN_WAVES
+#define WT_DELTA_MIN_WAVES 4     // waves per SIMD the register allocation aims at (experiments: 6 spills)
+#endif
 template <int OP>
-__global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? 256 : WT_MAX_BLOCK, WT_DELTA_SQ(OP) ? 2 : 4) wt_delta_kernel(const WtParams P) {
+__global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? 256 : WT_MAX_BLOCK, WT_DELTA_SQ(OP) ? 2 : WT_DELTA_MIN_WAVES) wt_delta_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
     wt_ctx_init(c, P, wt_lds);
