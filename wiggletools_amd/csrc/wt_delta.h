@@ -36,7 +36,7 @@
 #define WT_DELTA_K 8            // positions per lane: one byte of the U / E bitmaps
 #define WT_DELTA_GROUP 16       // lanes per group in the hierarchical scan
 #ifndef WT_DELTA_U
-#define WT_DELTA_U 8            // flat interval indices per lane and tile (measured: 8 beats 4 and 2 on many / dense tracks)
+#define WT_DELTA_U 4            // flat interval indices per lane and tile (round 2, with the prefetch really in flight: 4 beats 8 by 4 % at 100 tracks, loses 1 % at 500; round 1 measured the opposite with the prefetch serialised)
 #endif
 #define WT_DELTA_TILE (64 * WT_DELTA_U)
 #define WT_DELTA_TF 2048        // tiles whose first track is tabulated (beyond: binary search)
