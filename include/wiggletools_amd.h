@@ -242,6 +242,7 @@ typedef struct {
 
 int wtamd_device_count(void);
 int wtamd_set_device(int ordinal);
+int wtamd_current_device(void);     /* the calling thread's device (-1: none); HIP devices are per thread */
 const char *wtamd_last_error(void);
 const char *wtamd_version(void);
 

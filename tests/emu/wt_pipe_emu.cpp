@@ -157,6 +157,8 @@ int wtamd_pipe_put_direct(wtamd_pipe *p, int64_t at, int64_t count, const int32_
     return WTAMD_OK;
 }
 
+int wtamd_current_device(void) { return 0; }
+int wtamd_set_device(int) { return WTAMD_OK; }
 void *wtamd_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 void wtamd_host_free(void *q) { free(q); }
 

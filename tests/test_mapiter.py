@@ -202,3 +202,42 @@ def test_map_chains_small_batches_gpu(amd_lib, oracle, monkeypatch):
 @pytest.mark.gpu
 def test_map_iterator_pop_protocol_gpu(amd_lib, oracle):
     _run_pop_protocol(amd_lib, oracle, 1e-12)
+
+
+def _nested(L, oracle, rtol, monkeypatch):
+    """Reducers of this library as CHILDREN of another Multiplexer (`sum mean a b : mean c d : ...`), popped by
+    the worker threads of the outer one: every inner reducer drives its own pipeline from the thread that
+    pops it (HIP's current device is per thread: the workers inherit the caller's)."""
+    monkeypatch.setenv("WTAMD_DRAIN_THREADS", "3")
+    t = random_case(9700, n_tracks=9, n_chrom=2, max_len=5000, dtype=np.float32)
+    t.defaults[:] = 0
+    groups = [list(range(0, 3)), list(range(3, 6)), list(range(6, 9))]
+    inner, inner_exp = [], []
+    for g in groups:
+        sub = t.subset(g)
+        its = (C.c_void_p * len(g))(*_readers(L, sub, [[]] * len(g)))
+        inner.append(L.MeanReduction(L.newMultiplexer(its, len(g), b"\x00")))
+        inner_exp.append(oracle.reduce(sub.as_dict(), "mean"))
+    outer = (C.c_void_p * 3)(*inner)
+    got = _blocks(L, L.SumReduction(L.newMultiplexer(outer, 3, b"\x00")))
+    # expected: the three mean run lists as tracks (default 0: reducers.c:416-420 of zero defaults), summed
+    seg_off, S, F, V = [0], [], [], []
+    for c in range(t.n_chrom):
+        for ch, s, f, v in inner_exp:
+            k = ch == c
+            S.append(s[k]); F.append(f[k]); V.append(v[k])
+            seg_off.append(seg_off[-1] + int(k.sum()))
+    mid = RunLists(t.n_chrom, 3, seg_off, np.concatenate(S), np.concatenate(F), np.concatenate(V), [0.0] * 3,
+                   chrom_names=t.chrom_names)
+    c, s, f, v = oracle.reduce(mid.as_dict(), "sum")
+    exp = [(t.chrom_names[a], int(b), int(d), float(x)) for a, b, d, x in zip(c, s, f, v)]
+    _close(got, exp, rtol)
+
+
+def test_nested_reducers_under_worker_threads_emu(emu_lib, oracle, monkeypatch):
+    _nested(emu_lib, oracle, 1e-15, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_nested_reducers_under_worker_threads_gpu(amd_lib, oracle, monkeypatch):
+    _nested(amd_lib, oracle, 1e-15, monkeypatch)

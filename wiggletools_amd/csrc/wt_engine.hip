@@ -753,6 +753,12 @@ int wtamd_set_device(int ordinal) {
     return WTAMD_OK;
 }
 
+int wtamd_current_device(void) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) { (void) hipGetLastError(); return -1; }
+    return d;
+}
+
 static int wt_trackset_common(const wtamd_tracks *t, wtamd_trackset *ts) {
     if (!t || t->n_chrom < 0 || t->n_tracks <= 0 || !t->seg_off || !t->defaults)
         return wt_fail(WTAMD_ERR_ARG, "wtamd_trackset_create: bad tracks descriptor");

@@ -190,7 +190,10 @@ struct DrainPool {
 
     void start(int t) {
         T = t;
-        for (int w = 0; w < T; w++) th.emplace_back([this, w] { loop(w); });
+        // HIP's current device is per thread: children that are reducers of this library issue HIP calls
+        // from the worker that pops them, which must land on the device the caller selected
+        const int dev = wtamd_current_device();
+        for (int w = 0; w < T; w++) th.emplace_back([this, w, dev] { if (dev >= 0) (void) wtamd_set_device(dev); loop(w); });
     }
     void loop(int w) {
         uint64_t seen = 0;
