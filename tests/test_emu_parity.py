@@ -186,6 +186,22 @@ def _delta_case(seed, n_tracks, clens, mean_run, value_fn, gap=0.1, first_start=
     return t
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_emu_delta_8192bp_windows(oracle, seed):
+    """1024-lane workgroups (8192-bp windows, 128 bitmap words): the layout the difference-array kernels
+    can be launched with since round 2 (WTAMD_DELTA_T=1024)."""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(2, 20))
+    t = _delta_case(200 + seed, n, [int(rng.integers(9000, 40000)), 700], float(rng.choice([1, 3, 16])),
+                    lambda r, k: r.integers(-800, 800, k) / 8.0, gap=float(rng.choice([0.0, 0.1])), first_start=int(rng.choice([1, 8193])))
+    d = t.as_dict()
+    for strict in (0, 1):
+        for op in ("sum", "mean"):
+            got, info = emu.reduce(t, op, flags=strict, delta_T=1024)
+            assert info["delta"] == 1 and info["W"] == 8192, info
+            assert_runs_equal(got, oracle.reduce(d, op, flags=strict), 0.0, "seed %d %s strict %d" % (seed, op, strict))
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_emu_delta_sum_mean_exact(oracle, seed):
     """Sum / Mean of float tracks with zero defaults through the difference-array path: bit-identical."""
@@ -429,7 +445,7 @@ def test_plan_policy_snapshot():
     p = plan(100, "max")
     assert (p["W"], p["T"], p["n_chunks"]) == (2048, 512, 1)             # bitmaps of 100 tracks: half the LDS
     p = plan(500, "var")
-    assert (p["delta"], p["W"], p["T"]) == (1, 2048, 256)                # round 2: difference arrays with exact squares
+    assert (p["delta"], p["W"], p["T"]) == (1, 4096, 512)                # round 2: difference arrays with exact squares (one 142 KB workgroup per CU)
     p = plan(500, "var", no_delta=1)
     assert (p["W"], p["T"]) == (2048, 512) and p["n_chunks"] == 5        # general kernel: chunks of <= 112 tracks
     p = plan(100, "median")
@@ -472,7 +488,7 @@ def test_emu_delta_var_family(oracle, seed):
 def test_emu_delta_var_family_patched_windows(oracle):
     """NaN, Inf and a dynamic range beyond the exactness bound in a few windows: those windows are
     recomputed by the general kernel's two passes (wt_patch_kernel), the rest stays on the exact path."""
-    t = synth(12, [30000], mean_run=9, seed=5, dtype=np.float32)
+    t = synth(12, [200000], mean_run=9, seed=5, dtype=np.float32)      # (49 windows of 4096 bp: a few bad ones are patched, many would redo the launch)
     v = t.value
     v[100] = np.nan
     v[len(v) // 2] = np.inf

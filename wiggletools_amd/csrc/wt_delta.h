@@ -40,7 +40,7 @@
 #endif
 #define WT_DELTA_TILE (64 * WT_DELTA_U)
 #define WT_DELTA_TF 2048        // tiles whose first track is tabulated (beyond: binary search)
-#define WT_MAX_DELTA_T 512      // largest workgroup of the difference-array kernels
+#define WT_MAX_DELTA_T 1024     // largest workgroup of the difference-array kernels (an 8192-bp window)
 
 struct WtDeltaShared {
     long long base_v;           // scaled sum of the intervals spanning w0
@@ -103,9 +103,9 @@ WT_DEV void wt_delta_ctx_init(WtDeltaCtx &d, const WtParams &P, char *lds) {
     d.qa = (unsigned long long *) (lds + P.off_qa);
     d.qb = d.qa + P.W;
     d.ltqa = (unsigned long long *) (lds + P.off_ltq);
-    d.ltqb = d.ltqa + WT_MAX_DELTA_T;
+    d.ltqb = d.ltqa + P.W / WT_DELTA_K;                 // (W / K = workgroup size)
     d.gtqa = (unsigned long long *) (lds + P.off_gtq);
-    d.gtqb = d.gtqa + WT_MAX_DELTA_T / WT_DELTA_GROUP;
+    d.gtqb = d.gtqa + P.W / WT_DELTA_K / WT_DELTA_GROUP;
     d.dsh = (WtDeltaShared *) (lds + P.off_dsh);
 }
 
@@ -676,11 +676,19 @@ WT_DEV void wt_delta_scan_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDelta
 
 // escan on wave 0: run-count prefix of the emitted bitmap; returns the window's run count
 WT_DEV unsigned wt_delta_escan_wave(const WtParams &P, WtCtx &c, int lane) {
-    const unsigned v = lane < P.n_words ? (unsigned) wt_popc64(c.E[lane]) : 0u;
-    const unsigned incl = wt_wave_scan_u32(v, lane);
-    if (lane < P.n_words) c.epfx[lane + 1] = incl;
+    // one lane per 64-position word, two words per lane for the 8192-bp window (128 words)
+    const unsigned v0 = lane < P.n_words ? (unsigned) wt_popc64(c.E[lane]) : 0u;
+    const unsigned incl0 = wt_wave_scan_u32(v0, lane);
+    if (lane < P.n_words) c.epfx[lane + 1] = incl0;
     if (lane == 0) c.epfx[0] = 0;
-    return (unsigned) __shfl((int) incl, 63);
+    unsigned total = (unsigned) __shfl((int) incl0, 63);
+    if (P.n_words > 64) {
+        const unsigned v1 = lane + 64 < P.n_words ? (unsigned) wt_popc64(c.E[lane + 64]) : 0u;
+        const unsigned incl1 = wt_wave_scan_u32(v1, lane) + total;
+        if (lane + 64 < P.n_words) c.epfx[lane + 65] = incl1;
+        total = (unsigned) __shfl((int) incl1, 63);
+    }
+    return total;
 }
 #endif
 

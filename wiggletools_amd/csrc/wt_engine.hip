@@ -198,13 +198,19 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
 
 // Exact difference-array path for Sum / Mean over float tracks (wt_delta.h): O(intervals) work
 // instead of O(tracks x runs); LDS independent of the track count.
-// (var / stddev / CV also accumulate the sum of squares: 256 lanes, two waves per SIMD)
+// (var / stddev / CV also accumulate the sum of squares: 512 lanes, one workgroup per CU)
 #define WT_DELTA_SQ(OP) ((OP) == WT_OP_VAR || (OP) == WT_OP_STDDEV || (OP) == WT_OP_ENTROPY || (OP) == WT_OP_CV)
 #ifndef WT_DELTA_MIN_WAVES
 #define WT_DELTA_MIN_WAVES 4     // waves per SIMD the register allocation aims at (experiments: 6 spills)
 #endif
+#ifndef WT_DELTA_SQ_BLOCK
+#define WT_DELTA_SQ_BLOCK 512    // workgroup of the launches that also accumulate squares
+#endif
+#ifndef WT_DELTA_BLOCK
+#define WT_DELTA_BLOCK 512
+#endif
 template <int OP>
-__global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? 256 : WT_MAX_BLOCK, WT_DELTA_SQ(OP) ? 2 : WT_DELTA_MIN_WAVES) wt_delta_kernel(const WtParams P) {
+__global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA_BLOCK, WT_DELTA_SQ(OP) ? 2 : WT_DELTA_MIN_WAVES) wt_delta_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
     wt_ctx_init(c, P, wt_lds);
@@ -1249,7 +1255,7 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
 
 static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32_t flags, int n_set0, wtamd_runs *runs,
                           double *d_tile, uint8_t *d_inplay, int64_t *n_runs, hipStream_t s) {
-    if (plan.T > WT_MAX_BLOCK) return wt_fail(WTAMD_ERR_ARG, "workgroup size above 512");
+    if (plan.T > (plan.delta ? (wt_op_is_var_family(op) ? WT_DELTA_SQ_BLOCK : WT_DELTA_BLOCK) : WT_MAX_BLOCK)) return wt_fail(WTAMD_ERR_ARG, "workgroup size above the kernel's launch bound");
     WtWindows *w = nullptr;
     int rc = wt_get_windows(ts, plan.W, &w, s);
     if (rc != WTAMD_OK) return rc;
