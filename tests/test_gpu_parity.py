@@ -428,6 +428,9 @@ def test_gpu_difference_array_var_family(oracle, engine, seed):
     n = int(rng.choice([8, 16, 33, 100, 500]))
     t = synth(n, [int(rng.integers(2000, 60000)), 900], mean_run=float(rng.choice([1, 3, 16, 60])), seed=seed,
               gap_prob=float(rng.choice([0, 0.05, 0.5])), dtype=np.float32, value_levels=int(rng.choice([2, 800])))
+    if seed % 4 == 1:
+        # the poisoned cases: 49 windows of 4096 bp, so that the few bad ones are PATCHED (many would redo the launch)
+        t = synth(16, [200000, 900], mean_run=16.0, seed=seed, gap_prob=0.05, dtype=np.float32, value_levels=800)
     if seed % 3 == 0:
         t.value[:] = (t.value * rng.choice([1e-3, 1.0, 37.5], len(t.value))).astype(np.float32)
     if seed % 4 == 1:
