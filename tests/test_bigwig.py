@@ -80,3 +80,54 @@ def test_bigwig_tracks_feed_the_oracle_like_wig_tracks(oracle):
     c, s, f, v = oracle.reduce(t.as_dict(), "mean")
     assert s.tolist() == list(range(1, 11))
     assert v.tolist() == [0.5, 1.5, 1, 3, 2, 4.5, 3, 6, 4, 4.5]
+
+
+def test_read_part_streams_a_chromosome_in_pieces(tmp_path):
+    """wtamd_bw_read_part (the reader iterator's producer calls it): successive parts concatenate to the
+    whole chromosome, `last` ends it, a too-small capacity returns the needed size without moving the
+    cursor, and a window skips the data blocks outside it."""
+    import ctypes as C
+    from wiggletools_amd import _lib, bwwrite
+    rng = np.random.default_rng(4)
+    n = 20000
+    ln, gap = rng.integers(1, 30, n), rng.integers(0, 3, n)
+    s = np.cumsum(ln + gap) - ln
+    e = s + ln
+    v = rng.integers(0, 100, n).astype(np.float32) / 4
+    p = str(tmp_path / "p.bw")
+    bwwrite.write_arrays(p, {"chr1": int(e[-1]) + 5, "chr2": 50}, {"chr1": (s, e, v), "chr2": (np.array([3]), np.array([9]), np.array([1.0], np.float32))},
+                         items_per_block=256)
+    bw = bigwig.BigWig(p)
+    whole = bw.read("chr1", box=True)
+    L = _lib.lib()
+    L.wtamd_bw_read_part.restype = C.c_int64
+    L.wtamd_bw_read_part.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.c_int, C.c_int32, C.c_int32, C.c_int64,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    cap = 1 << 16
+    S, F, V = np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.float32)
+
+    def parts(lo0, hi0, blocks):
+        cur, last, out, calls = C.c_int64(0), C.c_int(0), [], 0
+        while not last.value:
+            k = L.wtamd_bw_read_part(bw._h, b"chr1", 1, C.byref(cur), blocks, lo0, hi0, cap, S.ctypes.data, F.ctypes.data, V.ctypes.data, C.byref(last))
+            assert k >= 0
+            out.append((S[:k].copy(), F[:k].copy(), V[:k].copy()))
+            calls += 1
+        return [np.concatenate([o[q] for o in out]) for q in range(3)], calls
+
+    (a, b, c), calls = parts(0, 2 ** 31 - 1, 7)
+    assert calls > 5
+    assert np.array_equal(a, whole[0]) and np.array_equal(b, whole[1]) and np.array_equal(c, whole[2])
+    # capacity too small: the needed size comes back, the cursor stays, the retry delivers
+    cur, last = C.c_int64(0), C.c_int(0)
+    k = L.wtamd_bw_read_part(bw._h, b"chr1", 1, C.byref(cur), 4, 0, 2 ** 31 - 1, 10, S.ctypes.data, F.ctypes.data, V.ctypes.data, C.byref(last))
+    assert k > 10 and cur.value == 0
+    k2 = L.wtamd_bw_read_part(bw._h, b"chr1", 1, C.byref(cur), 4, 0, 2 ** 31 - 1, cap, S.ctypes.data, F.ctypes.data, V.ctypes.data, C.byref(last))
+    assert k2 == k and cur.value > 0 and np.array_equal(S[:k2], whole[0][:k2])
+    # a window: only the blocks overlapping it are decoded; every run overlapping it is there
+    lo, hi = int(s[n // 2]), int(s[n // 2 + 900])
+    (a, b, c), _ = parts(lo, hi, 64)
+    inside = (whole[1] - 1 > lo) & (whole[0] - 1 < hi)
+    assert a.size < whole[0].size // 4
+    assert set(zip(whole[0][inside].tolist(), whole[1][inside].tolist())) <= set(zip(a.tolist(), b.tolist()))
+    bw.close()
