@@ -136,6 +136,8 @@ class Harness:
         L.ref_set_compress_mode.restype = None
         L.ref_set_modes.argtypes = [C.c_int, C.c_int]
         L.ref_set_modes.restype = None
+        L.ref_set_map.argtypes = [C.c_int, C.c_double]
+        L.ref_set_map.restype = None
         L.ref_reduce_seek_held.restype = C.c_int64
         L.ref_reduce_seek_held.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int,
                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -170,6 +172,11 @@ class Harness:
     def set_compress_mode(self, on):
         """write_reduce asks the reducer to merge its runs on the device (wtamd_iterator_compress_output)."""
         self.L.ref_set_compress_mode(int(on))
+
+    def set_map(self, op=None, param=0.0):
+        """`map <op>`: every child is wrapped in one operator iterator -- the compiled reference's own
+        (unaryOps.c) or the tested library's wtamd_MapIterator.  None switches it off."""
+        self.L.ref_set_map(-1 if op is None else MAP_OPS[op], float(param))
 
     def set_modes(self, child_mode=0, block_mode=0):
         """child_mode 1: children are the tested library's own bulk-capable wtamd_ArrayReader (float32

@@ -53,6 +53,7 @@ static WiggleIterator *(*r_ArrayReader)(int, const char *const *, const int64_t 
                                         const float *, double);
 static int64_t (*r_next_block)(WiggleIterator *, const char **, const int32_t **, const int32_t **, const double **);
 static int (*r_compress_output)(WiggleIterator *, int);
+static WiggleIterator *(*r_MapIterator)(WiggleIterator *, int, double);     /* wtamd_MapIterator (tested library only) */
 static int g_compress_mode;    /* 1: reducers handed to the writers are asked to merge their runs on the device first */
 void ref_set_compress_mode(int on) { g_compress_mode = on; }
 static void (*r_pop)(WiggleIterator *);
@@ -102,6 +103,7 @@ int ref_open(const char *path) {
     OPT(r_ArrayReader, "wtamd_ArrayReader");
     OPT(r_next_block, "wtamd_iterator_next_block");
     OPT(r_compress_output, "wtamd_iterator_compress_output");
+    OPT(r_MapIterator, "wtamd_MapIterator");
     OPT(r_SmartReader, "SmartReader");
     OPT(r_AUCIntegrator, "AUCIntegrator");
     OPT(r_PearsonIntegrator, "PearsonIntegrator");
@@ -195,7 +197,39 @@ static WiggleIterator *make_array_child(const wto_tracks *t, char **names, int t
     return r_ArrayReader(t->n_chrom, (const char *const *) names, so, s, f, v, t->defaults[track]);
 }
 
+/* `map <op>`: every child wrapped in one operator iterator -- the reference's own constructors
+ * (unaryOps.c; commandParser.c:115-211 builds lt / lte as scale -1, gt -x) or, in the tested library,
+ * wtamd_MapIterator (whose chains then run on the device inside the pipeline). */
+static int g_map_op = -1;
+static double g_map_param;
+void ref_set_map(int map_op, double param) { g_map_op = map_op; g_map_param = param; }
+
+static WiggleIterator *wrap_map(WiggleIterator *c, int map_op, double param) {
+    if (r_MapIterator) return r_MapIterator(c, map_op, param);
+    switch (map_op) {
+    case 0: return r_ScaleWiggleIterator(c, param);
+    case 1: return r_ShiftWiggleIterator(c, param);
+    case 2: return r_NaturalLogWiggleIterator(c);
+    case 3: return r_LogWiggleIterator(c, param);
+    case 4: return r_NaturalExpWiggleIterator(c);
+    case 5: return r_ExpWiggleIterator(c, param);
+    case 6: return r_PowerWiggleIterator(c, param);
+    case 7: return r_AbsWiggleIterator(c);
+    case 8: return r_HighPassFilterWiggleIterator(c, param, 0);
+    case 9: return r_HighPassFilterWiggleIterator(c, param, 1);
+    case 10: return r_HighPassFilterWiggleIterator(r_ScaleWiggleIterator(c, -1), -param, 0);
+    case 11: return r_HighPassFilterWiggleIterator(r_ScaleWiggleIterator(c, -1), -param, 1);
+    default: return c;
+    }
+}
+
+static WiggleIterator *make_plain_child(const wto_tracks *t, char **names, int track);
 static WiggleIterator *make_child(const wto_tracks *t, char **names, int track) {
+    WiggleIterator *c = make_plain_child(t, names, track);
+    return g_map_op >= 0 ? wrap_map(c, g_map_op, g_map_param) : c;
+}
+
+static WiggleIterator *make_plain_child(const wto_tracks *t, char **names, int track) {
     if (r_ArrayReader && (g_child_mode == 1 || (g_child_mode == 2 && (track & 1) == 0))) return make_array_child(t, names, track);
     arr_iter *a = (arr_iter *) calloc(1, sizeof(arr_iter));
     a->t = t; a->names = names; a->track = track; a->c = 0; a->j = -1;
@@ -500,7 +534,7 @@ int64_t ref_map(const wto_tracks *t, int track, int map_op, double param, int64_
                 int32_t *o_chrom, int32_t *o_start, int32_t *o_finish, double *o_value, double *o_default) {
     if (!g_lib || !r_ScaleWiggleIterator) return -2;
     char **names = make_names(t->n_chrom);
-    WiggleIterator *c = make_child(t, names, track), *w = NULL;
+    WiggleIterator *c = make_plain_child(t, names, track), *w = NULL;
     switch (map_op) {
     case 0: w = r_ScaleWiggleIterator(c, param); break;
     case 1: w = r_ShiftWiggleIterator(c, param); break;

@@ -365,3 +365,36 @@ def test_dropin_parallel_drain(oracle, H, tiny_batches, monkeypatch, seed):
     for op in ("ttest", "mwu"):
         if n0 >= 3 and t.n_tracks - n0 >= 3:
             assert_runs_equal(H.reduce(d, op, n_set0=n0), oracle.reduce(d, op, n_set0=n0), _tol(op), "threads %s" % op)
+
+
+MAPS = [("scale", -2.5), ("offset", 3.25), ("ln", 0.0), ("log", 2.0), ("exp", 0.0), ("expb", 2.0), ("pow", 2.0),
+        ("abs", 0.0), ("gt", 2.5), ("gte", 2.5), ("lt", 2.5), ("lte", -1.0)]
+
+
+@pytest.mark.parametrize("mop,param", MAPS)
+def test_dropin_map_vs_reference_operator_iterators(oracle, H, mop, param, tiny_batches):
+    """`<reducer> map <op> tracks...`: the COMPILED REFERENCE with its own operator iterators in front of
+    its Multiplexer (ScaleWiggleIterator, NaturalLogWiggleIterator, ..., HighPassFilterWiggleIterator;
+    lt / lte as commandParser.c:185-199 builds them) against this library with wtamd_MapIterator, whose
+    chains run inside the pipeline.  Same harness, same children.  Emulated pipe: bit for bit (one libm);
+    product: 1e-12 for the transcendental operators (device libm), exact otherwise."""
+    R = oracle.ref_harness()
+    if R is None:
+        pytest.skip("compiled reference not available")
+    exact = mop in ("scale", "offset", "abs", "gt", "gte", "lt", "lte")
+    for seed in range(3):
+        t = random_case(9800 + seed, n_tracks=int(3 + 2 * seed), max_len=700, dtype=np.float32)
+        rng = np.random.default_rng(seed)
+        t.value[:] = (t.value * rng.choice([1.0, -1.0, 0.0], size=len(t.value), p=[0.6, 0.3, 0.1])).astype(np.float32)
+        t.value[:] = np.where(np.abs(t.value) > 60, t.value / 16, t.value)
+        d = t.as_dict()
+        try:
+            R.set_map(mop, param); H.set_map(mop, param)
+            for op in ("sum", "mean", "stddev", "median", "max"):
+                for strict in (0, 1):
+                    exp = R.reduce(d, op, flags=strict)
+                    got = H.reduce(d, op, flags=strict)
+                    tol = 0.0 if (exact and op in ("sum", "mean", "median", "max")) else 1e-12
+                    assert_runs_equal(got, exp, tol, "map %s %s seed %d strict %d" % (mop, op, seed, strict))
+        finally:
+            R.set_map(None); H.set_map(None)
