@@ -110,3 +110,29 @@ def test_device_side_compression_under_the_reference_writer(oracle, M, tmp_path,
             assert a == b, op
     finally:
         M.set_compress_mode(0)
+
+
+@pytest.mark.parametrize("mop,param", [("scale", 0.5), ("offset", -1.25), ("abs", 0.0), ("gt", 1.5), ("lte", 2.0)])
+def test_reference_writers_over_mapped_dropin_reducers(oracle, M, tmp_path, mop, param):
+    """`write mean map <op> ...` and `mwrite map <op> ...`: the reference's writers over the drop-in reducer /
+    Multiplexer whose children are wtamd_MapIterator handles (chains evaluated inside the pipeline), against
+    the all-reference build with the reference's own operator iterators.  The operators whose values are
+    exact on every libm: the text is byte-identical (the transcendental ones are compared as numbers in
+    tests/test_dropin.py)."""
+    R = oracle.ref_harness()
+    t = random_case(9900, n_tracks=5, max_len=3000, dtype=np.float32)
+    rng = np.random.default_rng(9)
+    t.value[:] = (t.value * rng.choice([1.0, -1.0, 0.0], size=len(t.value), p=[0.6, 0.3, 0.1])).astype(np.float32)
+    d = t.as_dict()
+    try:
+        M.set_map(mop, param); R.set_map(mop, param)
+        for op in ("mean", "max"):
+            for bg in (False, True):
+                a = M.write_reduce(d, op, tmp_path / "a.txt", bedgraph=bg)
+                b = R.write_reduce(d, op, tmp_path / "b.txt", bedgraph=bg)
+                assert a == b and len(b) > 0, (mop, op, bg)
+        a = M.mwrite(d, tmp_path / "a.txt", bedgraph=True, flags=0)
+        b = R.mwrite(d, tmp_path / "b.txt", bedgraph=True, flags=0)
+        assert a == b, mop
+    finally:
+        M.set_map(None); R.set_map(None)
