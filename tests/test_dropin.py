@@ -398,3 +398,27 @@ def test_dropin_map_vs_reference_operator_iterators(oracle, H, mop, param, tiny_
                     assert_runs_equal(got, exp, tol, "map %s %s seed %d strict %d" % (mop, op, seed, strict))
         finally:
             R.set_map(None); H.set_map(None)
+
+
+@pytest.mark.parametrize("mop,param", [("scale", 2.0), ("ln", 0.0), ("gte", 1.0)])
+def test_dropin_seek_with_mapped_children_vs_reference(oracle, H, mop, param):
+    """`seek chr s f <reducer> map <op> ...` with held children: the reference forwards the seek through its
+    operator iterators to the readers (unaryOps.c UnaryWiggleIteratorSeek), this library seeks the raw
+    children it unwrapped and maps the region's batches on device."""
+    R = oracle.ref_harness()
+    if R is None:
+        pytest.skip("compiled reference not available")
+    rng = np.random.default_rng(77)
+    t = random_case(7480, n_tracks=5, n_chrom=2, max_len=3000, dtype=np.float32)
+    t.value[:] = (t.value * rng.choice([1.0, -1.0, 0.0], size=len(t.value), p=[0.6, 0.3, 0.1])).astype(np.float32)
+    d = t.as_dict()
+    try:
+        R.set_map(mop, param); H.set_map(mop, param)
+        for (c, s, f) in _regions(rng, t, 4):
+            for op in ("mean", "max"):
+                for strict in (0, 1):
+                    ref = R.reduce_seek_held(d, op, c, s, f, flags=strict)
+                    got = H.reduce_seek_held(d, op, c, s, f, flags=strict)
+                    assert_runs_equal(got, ref, 0.0 if mop != "ln" else 1e-12, "seek %s map %s %s strict %d" % ((c, s, f), mop, op, strict))
+    finally:
+        R.set_map(None); H.set_map(None)
