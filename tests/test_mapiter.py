@@ -241,3 +241,38 @@ def test_nested_reducers_under_worker_threads_emu(emu_lib, oracle, monkeypatch):
 @pytest.mark.gpu
 def test_nested_reducers_under_worker_threads_gpu(amd_lib, oracle, monkeypatch):
     _nested(amd_lib, oracle, 1e-15, monkeypatch)
+
+
+def _two_sample(L, oracle, rtol):
+    """ttest / wilcoxon over two sets of mapped tracks (`ttest map ln a b c : map ln d e f`): two Multiplexers
+    under a Multiset, every child a wtamd_MapIterator handle."""
+    L.newMultiset.restype = C.c_void_p
+    L.newMultiset.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    for name in ("TTestReduction", "MWUReduction"):
+        getattr(L, name).restype = C.c_void_p
+        getattr(L, name).argtypes = [C.c_void_p]
+    for seed in (23, 24, 28):               # (_case: 3 + seed % 5 tracks -> 6, 7, 6)
+        t = _case(seed)
+        n0 = t.n_tracks // 2
+        for mk in (CHAINS[0], CHAINS[1], CHAINS[5]):
+            chains = mk(t.n_tracks)
+            exp_t = _expected_tracks(oracle, t, chains)
+            for red, op in (("TTestReduction", "ttest"), ("MWUReduction", "mwu")):
+                its = _readers(L, t, chains)
+                a = (C.c_void_p * n0)(*its[:n0])
+                b = (C.c_void_p * (t.n_tracks - n0))(*its[n0:])
+                ms = (C.c_void_p * 2)(L.newMultiplexer(a, n0, b"\x00"), L.newMultiplexer(b, t.n_tracks - n0, b"\x00"))
+                _KEEP.append(ms)
+                got = _blocks(L, getattr(L, red)(L.newMultiset(ms, 2)))
+                c, s, f, v = oracle.reduce(exp_t.as_dict(), op, n_set0=n0)
+                exp = [(t.chrom_names[x], int(y), int(z), float(w)) for x, y, z, w in zip(c, s, f, v)]
+                _close(got, exp, rtol)
+
+
+def test_two_sample_over_mapped_sets_emu(emu_lib, oracle):
+    _two_sample(emu_lib, oracle, 1e-12)
+
+
+@pytest.mark.gpu
+def test_two_sample_over_mapped_sets_gpu(amd_lib, oracle):
+    _two_sample(amd_lib, oracle, 1e-9)
