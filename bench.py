@@ -257,10 +257,12 @@ def _bw_write_one(args):
 
 
 def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
-    """FILES to result: N BigWig files (written here, untimed, from the same generator) -> the
-    library's BigWiggleReader (one decoding thread per file) -> newMultiplexer -> <op>Reduction ->
-    runs on the host.  What `wiggletools <op> *.bw` does in the reference (commandParser.c ->
-    bigWiggleReader.c -> multiplexer.c -> reducers.c), minus the text writer."""
+    """FILES to result: N BigWig files (written here, untimed, from the same generator; bedGraph sections of 1024
+    items, zlib level 1 -- SURVEY 8d's stored form) -> wtamd_BigWiggleReader x N -> newMultiplexer -> <op>Reduction ->
+    runs on the host.  What `wiggletools <op> *.bw` does in the reference (commandParser.c -> bigWiggleReader.c ->
+    multiplexer.c -> reducers.c), minus the text writer.  The sections travel to the GPU COMPRESSED and are inflated
+    and decoded there (csrc/wt_bwdev.hip); `host_decoder` times the library's host-side zlib route on a seek window of
+    the same files for comparison."""
     import shutil
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
@@ -269,7 +271,8 @@ def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
     seg, s, f, v = synthgen.device_tracks(SEED, [L], n_tracks, mean_run, 0.02, 800, device, chrom_ids=[41])
     hs, hf, hv = s.cpu().numpy(), f.cpu().numpy(), v.cpu().numpy()
     del s, f, v
-    d = tempfile.mkdtemp(prefix="wtamd_bw_")
+    base = os.environ.get("WTAMD_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 6.0 * len(hs) else None)
+    d = tempfile.mkdtemp(prefix="wtamd_bw_", dir=base)
     try:
         jobs = [(os.path.join(d, "t%03d.bw" % t), L + 1, hs[int(seg[t]):int(seg[t + 1])], hf[int(seg[t]):int(seg[t + 1])],
                  hv[int(seg[t]):int(seg[t + 1])]) for t in range(n_tracks)]
@@ -277,73 +280,105 @@ def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
         with ThreadPoolExecutor(max(1, min(effective_cores(), 16))) as ex:     # zlib releases the GIL
             list(ex.map(_bw_write_one, jobs))
         write_s = time.perf_counter() - t0
+        del hs, hf, hv
         size = sum(os.path.getsize(j[0]) for j in jobs)
+        n_int = int(seg[-1])
+        os.environ.pop("WTAMD_BW_DEVICE", None)
         t0 = time.perf_counter()
         r = dropin.reducer(op, [dropin.bigwig_reader(j[0], box=True) for j in jobs], n_set0=n_tracks // 2)
-        runs, _ = dropin.drain_blocks(r)
+        t_open = time.perf_counter() - t0
+        marks = []
+        runs, _ = dropin.drain_blocks(r, on_block=lambda c, a, b, v: (marks.append((time.perf_counter(), int(b[-1]))), 0)[1])
         dt = time.perf_counter() - t0
-        return {"tracks": n_tracks, "op": op, "bp": L, "seconds": dt, "bp_per_s": L / dt, "runs": runs,
-                "intervals": int(seg[-1]), "intervals_per_s": int(seg[-1]) / dt, "file_bytes": size,
-                "file_MBs": size / dt / 1e6, "decode_threads": n_tracks, "host_cores": effective_cores(),
-                "files_written_s": write_s,
-                "note": "bound by the host-side zlib decode (one producer thread per file on the cores above)"}
+        st = dropin.pipe_stats(r)
+        out = {"tracks": n_tracks, "op": op, "bp": L, "seconds": dt, "bp_per_s": L / dt, "runs": runs,
+               "intervals": n_int, "intervals_per_s": n_int / dt, "file_bytes": size, "file_bytes_per_bp": size / L,
+               "inbound_GBs": size / dt / 1e9, "pcie_h2d_roofline_bp_per_s": 63e9 / (size / L),
+               "open_seconds": t_open, "files_written_s": write_s, "files_dir": d.rsplit("/", 1)[0],
+               "host_cores": effective_cores(), "batches": st.get("batches"),
+               "sections_inflated_on_device": st.get("bw_sections"), "sum_device_decode_ms": st.get("bw_decode_ms"),
+               "sum_kernel_ms": st.get("kernel_ms"), "sum_d2h_ms": st.get("d2h_ms"), "host_submit_ms": st.get("host_submit_ms"),
+               "host_wait_ms": st.get("host_wait_ms"),
+               "decoder": "device (one lane per zlib stream)" if (st.get("bw_sections") or 0) > 0 else "host zlib"}
+        q = [m for m in marks if m[1] >= L // 4]        # ramp-up excluded: from the block ending the first quarter on
+        if len(q) >= 2 and q[-1][0] > q[0][0]:
+            out["steady_bp_per_s"] = (q[-1][1] - q[0][1]) / (q[-1][0] - q[0][0])
+        # the host-side decoder (round 2's route) on a window of the same files
+        try:
+            win = int(min(L, 8e6))
+            os.environ["WTAMD_BW_DEVICE"] = "0"
+            t0 = time.perf_counter()
+            r = dropin.reducer(op, [dropin.bigwig_reader(j[0], box=True) for j in jobs], n_set0=n_tracks // 2)
+            dropin.seek(r, "chr1", 1, win + 1)
+            runs_h, _ = dropin.drain_blocks(r)
+            dth = time.perf_counter() - t0
+            out["host_decoder"] = {"bp": win, "seconds": dth, "bp_per_s": win / dth, "runs": runs_h,
+                                   "note": "WTAMD_BW_DEVICE=0: zlib inflate + section decode on one host thread per file, seek window chr1:1-%d" % win}
+        except Exception as e:
+            out["host_decoder"] = {"error": repr(e)[:200]}
+        finally:
+            os.environ.pop("WTAMD_BW_DEVICE", None)
+        return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
 
-# ---------------------------------------------------------------------------------------------
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--op", default=None, help="override the configuration's reducer(s), comma separated")
-    ap.add_argument("--tracks", type=int, default=None)
-    ap.add_argument("--mean-run", type=float, default=16.0)
-    ap.add_argument("--scale", type=float, default=1.0, help="fraction of the GRCh38 chromosome lengths (1 = 3.1 Gbp)")
-    ap.add_argument("--n-set0", type=int, default=-1, help="two-sample ops: tracks in the first set (default N/2)")
-    ap.add_argument("--shard", default="genome", choices=["genome", "replicas"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-many-core", action="store_true")
-    ap.add_argument("--chroms", default=None, help="experiments: only these chromosomes of the configuration (comma separated indices)")
-    ap.add_argument("--no-e2e", action="store_true")
-    ap.add_argument("--e2e-bw-mbp", type=float, default=8.0, help="region of the BigWig-files-to-result leg (0: skip)")
-    ap.add_argument("--e2e-mbp", type=float, default=100.0, help="chromosome length of the end-to-end (drop-in layer) leg")
-    args = ap.parse_args()
-
+def e2e_sharded(ctx, op, n_tracks, mean_run, mbp):
+    """N GPUs, the end-to-end bulk leg per rank: every rank streams its own chromosome (array-backed tracks in pinned
+    host memory -> drop-in reducer -> runs on the host) over its own PCIe link; barrier, clock, max over ranks."""
     import torch
     import torch.distributed as dist
+    from wiggletools_amd import dropin, synthgen
+    L = int(mbp * 1e6 * min(1.0, 100.0 / n_tracks))
+    try:
+        seg, s, f, v = synthgen.device_tracks(SEED, [L], n_tracks, mean_run, 0.02, 800, ctx.device, chrom_ids=[50 + ctx.rank])
+        n = int(seg[-1])
+        hs, hf, hv = dropin.PinnedArray(n, np.int32), dropin.PinnedArray(n, np.int32), dropin.PinnedArray(n, np.float32)
+        torch.from_numpy(hs.array).copy_(s); torch.from_numpy(hf.array).copy_(f); torch.from_numpy(hv.array).copy_(v)
+        torch.cuda.synchronize()
+        del s, f, v
+        its = []
+        for t in range(n_tracks):
+            a, b = int(seg[t]), int(seg[t + 1])
+            its.append(dropin.array_reader(["chr1"], [0, b - a], hs.ptr + 4 * a, hf.ptr + 4 * a, hv.ptr + 4 * a))
+        dist.barrier()
+        t0 = time.perf_counter()
+        r = dropin.reducer(op, its, n_set0=n_tracks // 2)
+        runs, _ = dropin.drain_blocks(r)
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        hs.free(); hf.free(); hv.free()
+        return {"bp_per_s": ctx.world * L / float(t.item()), "seconds": float(t.item()), "bp_per_rank": L, "ranks": ctx.world,
+                "note": "bulk leg of e2e per rank, one chromosome each, every GPU on its own PCIe link; whole-node bp / max over ranks"}
+    except Exception as e:
+        return {"error": repr(e)[:300]}
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    store = None
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
-        try:
-            store = dist.distributed_c10d._get_default_store()
-        except Exception:
-            store = None
 
+# ---------------------------------------------------------------------------------------------
+class Ctx:
+    """What every measurement needs: device, distributed state."""
+    def __init__(self, device, rank, world, store, shard):
+        self.device, self.rank, self.world, self.store, self.shard = device, rank, world, store, shard
+        self.replicas = world > 1 and shard == "replicas"
+
+
+def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_set0_arg=-1, f64=False, want_moments=False):
+    """`steps` timed passes of `ops` over the chromosomes `chrom_ids` (GRCh38 lengths x scale), N tracks of mean run
+    `mean_run`: the tracks of one chromosome at a time are generated in HBM (untimed), then window index + fused
+    multiplex / reduce kernels run with inputs and outputs resident (timed).  Returns the record of this
+    configuration on rank 0 (None elsewhere): value, ms_per_step, roofline, bookkeeping.
+    f64: the tracks are handed over as float64 values (what an upstream operator produces): the general kernel."""
+    import torch
+    import torch.distributed as dist
     from wiggletools_amd import engine, synthgen
-
-    cfg = CONFIGS[args.config]
-    ops = args.op.split(",") if args.op else cfg["ops"]
-    N = args.tracks if args.tracks else cfg["tracks"]
-    chrom_ids = cfg["chroms"] if not args.chroms else [int(x) for x in args.chroms.split(",")]
-    chrom_lens = {c: max(int(GRCH38[c] * args.scale), 1) for c in chrom_ids}
+    device, world, rank, store, replicas = ctx.device, ctx.world, ctx.rank, ctx.store, ctx.replicas
+    chrom_lens = {c: max(int(GRCH38[c] * scale), 1) for c in chrom_ids}
     queue = sorted(chrom_ids, key=lambda c: -chrom_lens[c])         # host-side work queue: largest first
     genome_bp = sum(chrom_lens.values())
     two = any(engine.opcode(o) in (10, 11) for o in ops)
-    n_set0 = (args.n_set0 if args.n_set0 >= 0 else N // 2) if two else 0
+    n_set0 = (n_set0_arg if n_set0_arg >= 0 else N // 2) if two else 0
     stream = torch.cuda.current_stream().cuda_stream
-    replicas = world > 1 and args.shard == "replicas"
     seed = SEED + (rank if replicas else 0)
 
     def my_items(pass_no):
@@ -353,7 +388,7 @@ def main():
             yield from queue
         elif store is not None:
             while True:
-                k = store.add("wt_queue_%d" % pass_no, 1) - 1
+                k = store.add("wt_queue_%s_%d" % (name, pass_no), 1) - 1
                 if k >= len(queue):
                     return
                 yield queue[k]
@@ -366,22 +401,21 @@ def main():
                     yield c
 
     agg = dict(bp=0.0, auc=0.0, runs=0.0, intervals=0.0, windows=0.0)
-    moments = {}
-    stats_last = {}
-    per_item = {}
-    gen_s = 0.0
+    moments, stats_last, per_item = {}, {}, {}
+    gen_s = [0.0]
 
     def one_pass(pass_no, record):
-        nonlocal gen_s
         hot_s = 0.0
         idx_ms = red_ms = 0.0
         for c in my_items(pass_no):
             t0 = time.perf_counter()
-            seg, s, f, v = synthgen.device_tracks(seed, [chrom_lens[c]], N, args.mean_run, 0.02, 800, device, chrom_ids=[c])
+            seg, s, f, v = synthgen.device_tracks(seed, [chrom_lens[c]], N, mean_run, 0.02, 800, device, chrom_ids=[c])
+            if f64:
+                v = v.double()
             ts = engine.TrackSet.from_device(1, N, seg, s, f, v, np.zeros(N))
             out = ts.alloc_runs()
             torch.cuda.synchronize()
-            gen_s += time.perf_counter() - t0
+            gen_s[0] += time.perf_counter() - t0
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(1 + 2 * len(ops))]
             # ---- timed: inputs resident, outputs resident ----
             t0 = time.perf_counter()
@@ -407,25 +441,25 @@ def main():
                 agg["auc"] += out.auc()
                 stats_last.update(st)
                 per_item[c] = dt * 1e3
-                if args.config == "c5" or world > 1:
+                if want_moments or world > 1:
                     # Pearson moments of tracks 0 and 1 of this chromosome (scalar gather readiness)
                     a, b = int(seg[0]), int(seg[2])
-                    ts2 = engine.TrackSet.from_device(1, 2, seg[:3] - seg[0], s[a:b], f[a:b], v[a:b], np.zeros(2))
+                    ts2 = engine.TrackSet.from_device(1, 2, seg[:3] - seg[0], s[a:b], f[a:b], v[a:b].float() if f64 else v[a:b], np.zeros(2))
                     moments[c] = ts2.pearson_moments()
                     ts2.close()
             ts.close()
             del ts, out, s, f, v
         return hot_s, idx_ms, red_ms
 
-    for w in range(max(args.warmup, 0)):
+    for w in range(max(warmup, 0)):
         one_pass(-1 - w, False)
 
     pass_s, idx_tot, red_tot = [], 0.0, 0.0
-    for k in range(args.steps):
+    for k in range(steps):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        hs, im, rm = one_pass(k, k == args.steps - 1)
+        hs, im, rm = one_pass(k, k == steps - 1)
         t = torch.tensor([hs], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)        # a pass is over when the slowest rank is
@@ -435,7 +469,7 @@ def main():
     elapsed = float(sum(pass_s))
 
     # genome-wide scalars (RCCL over xGMI when world > 1): sums by all_reduce, Pearson by all_gather + ordered merge
-    vec = torch.tensor([agg["bp"], agg["auc"], agg["runs"], agg["intervals"], agg["windows"], idx_tot, red_tot, gen_s],
+    vec = torch.tensor([agg["bp"], agg["auc"], agg["runs"], agg["intervals"], agg["windows"], idx_tot, red_tot, gen_s[0]],
                        dtype=torch.float64, device=device)
     mom = torch.zeros((len(GRCH38), 6), dtype=torch.float64, device=device)
     for c, m in moments.items():
@@ -452,88 +486,208 @@ def main():
         rows = mom.cpu().numpy()
         order = sorted(chrom_ids, key=lambda c: ("chr%d" % (c + 1)).encode())       # strcmp order (multiplexer.c:56)
         pearson = shard.pearson_from_moments([rows[c] for c in order if rows[c][0] > 0])
+    if rank != 0:
+        return None
 
+    passes = steps
+    bp_per_pass = tot_bp                                # the record pass: every rank's share, summed
+    value = bp_per_pass * passes / elapsed
+    kern = stats_last.get("kernel", 0)
+    vt = "f64" if f64 else "f32"
+    kernel = ("wt_delta_kernel<%s>" % ops[-1]) if kern == 1 else ("wt_reduce_kernel<%s,%s>" % (ops[-1], vt))
+    # algorithmic bytes of the fused multiplex+reduce launches of ONE pass: every input run read
+    # once per launch (start, finish, value = 12 B; 16 B for float64 values), the two window-index rows per
+    # window, every output run written once (start, finish, f64 value = 16 B).  DESIGN.md 4.6.
+    # Launches differ in size (one per chromosome), so the rate is bytes of all launches of a pass /
+    # their summed durations (HIP events on the launch stream, around every launch) -- the
+    # duration-weighted mean of the per-launch rates; with N GPUs: the per-GPU mean.
+    alg_bytes = len(ops) * ((16.0 if f64 else 12.0) * tot_int + 16.0 * tot_runs) + 8.0 * N * tot_win
+    kernel_ms_sum = red_all / passes                    # per pass, summed over launches (and ranks)
+    achieved = alg_bytes / (kernel_ms_sum * 1e-3) / 1e9
+    tile_equiv = len(ops) * tot_runs * (4.0 * N + N / 8.0 + 24.0) / (kernel_ms_sum * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
+                traffic = tj["hbm_bytes_per_algorithmic_byte"] * alg_bytes
+                traffic_src = "PMC passes of %s (profiles/traffic.json: FETCH_SIZE + WRITE_SIZE per launch, ratio to that launch's algorithmic bytes) scaled to this launch" % tj.get("profile", "an earlier profile")
+        except Exception:
+            traffic = None
+    bound = "hbm"
+    note = None
+    if kern == 0:
+        o = ops[-1]
+        if o in ("median", "wilcoxon", "mwu"):
+            bound, note = "issue", ("register-column reducer: bound by instruction issue, not by HBM -- the frac against the HBM peak is "
+                                    "reported for the record only (DESIGN 10)")
+        else:
+            bound, note = "valu", "f32->f64 widen + add per (track, position): VALU bound (profiles/: VALUBusy)"
+    return {
+        "metric": "genomic bp/s (whole node) for 'mean' over N BigWig tracks" if ops == ["mean"] else
+                  "genomic bp/s (whole node) for '%s' over N tracks" % "+".join(ops),
+        "value": value, "unit": "genomic bp/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / passes * 1e3,
+        "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
+        # the arithmetic type of the path: the reference accumulates in f64; the difference-array kernel does it in
+        # exact int64 / 128-bit integers of the scaled float32 mantissas, which IS that f64 result
+        "dtype": "f64 (exact int64 accumulation)" if kern == 1 else "f64", "data": "synthetic",
+        "config": {"workload": "%s: %s over %d synthetic %s run-list tracks, %d chromosome(s) = GRCh38 x %g = %.3f Gbp per step, "
+                               "mean run %g bp, 2%% gaps; one step = one whole pass, chromosomes generated in HBM one at a time "
+                               "(untimed) and processed resident (timed)"
+                               % (name, "+".join(ops), N, "float64" if f64 else "float32", len(chrom_ids), scale, genome_bp / 1e9, mean_run),
+                   "config": name, "ops": ops, "tracks": N, "mean_run_bp": mean_run,
+                   "genome_bp": genome_bp, "covered_bp_per_step": bp_per_pass,
+                   "input_runs_per_step": tot_int, "output_runs_per_step": tot_runs,
+                   "window_bp": stats_last.get("window_bp"), "lds_bytes_per_workgroup": stats_last.get("lds_bytes"),
+                   "sharding": ("replicas: every rank walks its own genome" if replicas else
+                                "one genome, chromosomes from a shared host-side work queue (store counter), no data-path collective")
+                               if world > 1 else "single GPU"},
+        "roofline": {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": alg_bytes, "launch": "the %d launches of one pass (one per chromosome%s)" % (len(per_item) * len(ops) if world == 1 else int(len(chrom_ids) * len(ops)), ", per reducer" if len(ops) > 1 else ""),
+                     "kernel_ms": kernel_ms_sum, "index_kernel_ms": idx_all / passes,
+                     "frac_with_index": alg_bytes / ((kernel_ms_sum + idx_all / passes) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "tile_equivalent_GBs": tile_equiv, "note": note},
+        "auc_check": tot_auc, "pearson_tracks_0_1": pearson, "output_runs": tot_runs,
+        "gen_seconds_total": gen_all, "pass_seconds": pass_s,
+        "_chrom_lens": [chrom_lens[c] for c in chrom_ids],
+    }
+
+
+def with_cpu(res, chrom_ids, ops, N, mean_run, many_core):
+    lens = res.pop("_chrom_lens")
+    cb = cpu_baseline(chrom_ids, ops[-1], N, mean_run, lens, many_core=many_core)
+    res["cpu_baseline"] = cb
+    res["speedup_vs_cpu_baseline"] = res["value"] / cb["value"]
+    if "many_core" in cb and "value" in cb["many_core"]:
+        res["speedup_vs_many_core_cpu"] = res["value"] / cb["many_core"]["value"]
+    return res
+
+
+def slim(res):
+    """A sub-record of the driver line: the figures, without the long prose of the main record."""
+    keep = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline",
+            "speedup_vs_many_core_cpu", "auc_check", "output_runs", "pearson_tracks_0_1")
+    out = {k: res[k] for k in keep if k in res}
+    out["workload"] = res["config"]["workload"]
+    for k in ("traffic_source", "launch", "note"):
+        out["roofline"].pop(k, None)
+    if "cpu_baseline" in out:
+        for k in ("host_cores_note",):
+            out["cpu_baseline"].pop(k, None)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--op", default=None, help="override the configuration's reducer(s), comma separated")
+    ap.add_argument("--tracks", type=int, default=None)
+    ap.add_argument("--mean-run", type=float, default=16.0)
+    ap.add_argument("--scale", type=float, default=1.0, help="fraction of the GRCh38 chromosome lengths (1 = 3.1 Gbp)")
+    ap.add_argument("--n-set0", type=int, default=-1, help="two-sample ops: tracks in the first set (default N/2)")
+    ap.add_argument("--shard", default="genome", choices=["genome", "replicas"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-many-core", action="store_true")
+    ap.add_argument("--chroms", default=None, help="experiments: only these chromosomes of the configuration (comma separated indices)")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-sub", action="store_true", help="skip the sub-records (c3 / c4 / c5, mean run 1 / 200, other kernels) of the default line")
+    ap.add_argument("--sub-steps", type=int, default=2, help="timed passes of every sub-record")
+    ap.add_argument("--f64", action="store_true", help="hand the tracks over as float64 values (general kernel)")
+    ap.add_argument("--e2e-bw-mbp", type=float, default=248.956422, help="chromosome length of the BigWig-files-to-result leg (0: skip); default chromosome 1")
+    ap.add_argument("--e2e-mbp", type=float, default=248.956422, help="chromosome length of the end-to-end (drop-in layer) leg; default chromosome 1")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    store = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            store = None
+    ctx = Ctx(device, rank, world, store, args.shard)
+
+    cfg = CONFIGS[args.config]
+    ops = args.op.split(",") if args.op else cfg["ops"]
+    N = args.tracks if args.tracks else cfg["tracks"]
+    chrom_ids = cfg["chroms"] if not args.chroms else [int(x) for x in args.chroms.split(",")]
+    t_start = time.perf_counter()
+    res = measure(ctx, args.config, ops, N, chrom_ids, args.mean_run, args.steps, args.warmup, scale=args.scale,
+                  n_set0_arg=args.n_set0, f64=args.f64, want_moments=args.config == "c5")
+    default_line = args.config == "c2" and not args.op and not args.tracks and not args.chroms and args.scale == 1.0 and not args.f64
+    # multi-GPU: the e2e bulk leg per rank (every GPU has its own PCIe link) -- all ranks take part
+    e2e_multi = None
+    if world > 1 and not args.no_e2e:
+        e2e_multi = e2e_sharded(ctx, ops[-1], N, args.mean_run, min(args.e2e_mbp, 100.0))
     if rank == 0:
-        passes = args.steps
-        bp_per_pass = tot_bp                                # the record pass: every rank's share, summed
-        value = bp_per_pass * passes / elapsed
-        kern = stats_last.get("kernel", 0)
-        kernel = ("wt_delta_kernel<%s>" % ops[-1]) if kern == 1 else ("wt_reduce_kernel<%s,f32>" % ops[-1])
-        # algorithmic bytes of the fused multiplex+reduce launches of ONE pass: every input run read
-        # once per launch (start, finish, value = 12 B), the two window-index rows per window, every
-        # output run written once (start, finish, f64 value = 16 B).  DESIGN.md 4.6.
-        # Launches differ in size (one per chromosome), so the rate is bytes of all launches of a pass /
-        # their summed durations (HIP events on the launch stream, around every launch) -- the
-        # duration-weighted mean of the per-launch rates; with N GPUs: the per-GPU mean.
-        alg_bytes = len(ops) * (12.0 * tot_int + 16.0 * tot_runs) + 8.0 * N * tot_win
-        kernel_ms_sum = red_all / passes                    # per pass, summed over launches (and ranks)
-        achieved = alg_bytes / (kernel_ms_sum * 1e-3) / 1e9
-        tile_equiv = len(ops) * tot_runs * (4.0 * N + N / 8.0 + 24.0) / (kernel_ms_sum * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
-                    traffic = tj["hbm_bytes_per_algorithmic_byte"] * alg_bytes
-                    traffic_src = "PMC passes of %s (profiles/traffic.json: FETCH_SIZE + WRITE_SIZE per launch, ratio to that launch's algorithmic bytes) scaled to this launch" % tj.get("profile", "an earlier profile")
-            except Exception:
-                traffic = None
-        bound = {"wt_delta_kernel": "hbm"}.get(kernel.split("<")[0], "hbm")
-        note = None
-        if kern == 0:
-            o = ops[-1]
-            if o in ("median", "wilcoxon", "mwu"):
-                bound, note = "issue", ("register-column reducer: bound by instruction issue (gather ~70 instructions per track and position, two 64-key "
-                                        "compare-exchange networks, the rank-sum count loop), not by HBM -- the frac against the HBM peak is reported for the "
-                                        "record only (DESIGN 10; profiles/r02_sq_c4_summary.json)")
-            else:
-                bound, note = "valu", "f32->f64 widen + add per (track, position): VALU bound (profiles/: VALUBusy)"
-        res = {
-            "metric": "genomic bp/s (whole node) for 'mean' over N BigWig tracks" if ops == ["mean"] else
-                      "genomic bp/s (whole node) for '%s' over N tracks" % "+".join(ops),
-            "value": value, "unit": "genomic bp/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / passes * 1e3,
-            "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
-            "dtype": "int64" if kern == 1 else "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s over %d synthetic float32 run-list tracks, %d chromosome(s) = GRCh38 x %g = %.3f Gbp per step, "
-                                   "mean run %g bp, 2%% gaps; one step = one whole pass, chromosomes generated in HBM one at a time "
-                                   "(untimed) and processed resident (timed)"
-                                   % (args.config, "+".join(ops), N, len(chrom_ids), args.scale, genome_bp / 1e9, args.mean_run),
-                       "config": args.config, "ops": ops, "tracks": N, "mean_run_bp": args.mean_run,
-                       "genome_bp": genome_bp, "covered_bp_per_step": bp_per_pass,
-                       "input_runs_per_step": tot_int, "output_runs_per_step": tot_runs,
-                       "window_bp": stats_last.get("window_bp"), "lds_bytes_per_workgroup": stats_last.get("lds_bytes"),
-                       "sharding": ("replicas: every rank walks its own genome" if replicas else
-                                    "one genome, chromosomes from a shared host-side work queue (store counter), no data-path collective")
-                                   if world > 1 else "single GPU"},
-            "roofline": {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launch": "the %d launches of one pass (one per chromosome%s)" % (len(per_item) * len(ops) if world == 1 else int(len(chrom_ids) * len(ops)), ", per reducer" if len(ops) > 1 else ""),
-                         "kernel_ms": kernel_ms_sum, "index_kernel_ms": idx_all / passes,
-                         "tile_equivalent_GBs": tile_equiv, "note": note},
-            "auc_check": tot_auc, "pearson_tracks_0_1": pearson, "output_runs": tot_runs,
-            "gen_seconds_total": gen_all, "pass_seconds": pass_s,
-        }
         if world == 1 and not args.no_e2e:
+            fit = min(1.0, 100.0 / N) * (args.scale if args.scale < 1 else 1.0)
             try:
-                res["e2e"] = e2e_dropin(ops[-1], N, args.mean_run, args.e2e_mbp * min(1.0, 100.0 / N) * (args.scale if args.scale < 1 else 1.0), device)
+                res["e2e"] = e2e_dropin(ops[-1], N, args.mean_run, args.e2e_mbp * fit, device)
             except Exception as e:      # never lose the bench line to an extra leg
                 res["e2e"] = {"error": repr(e)[:300]}
             if args.e2e_bw_mbp > 0:
                 try:
-                    res["e2e_bigwig"] = e2e_bigwig(ops[-1], N, args.mean_run, args.e2e_bw_mbp * min(1.0, 100.0 / N) * (args.scale if args.scale < 1 else 1.0), device)
+                    res["e2e_bigwig"] = e2e_bigwig(ops[-1], N, args.mean_run, args.e2e_bw_mbp * fit, device)
                 except Exception as e:
                     res["e2e_bigwig"] = {"error": repr(e)[:300]}
+            # SURVEY 8d metric (1), first pop -> last result on the host, next to the resident-kernel `value`
+            res["value_e2e_bulk"] = (res["e2e"].get("bulk") or {}).get("bp_per_s")
+            res["value_e2e_bigwig"] = res.get("e2e_bigwig", {}).get("bp_per_s")
+        if e2e_multi is not None:
+            res["e2e_sharded"] = e2e_multi
         if world == 1 and not args.no_cpu_baseline:
-            lens = [chrom_lens[c] for c in chrom_ids]
-            cb = cpu_baseline(chrom_ids, ops[-1], N, args.mean_run, lens, many_core=not args.no_many_core)
-            # the generator's chromosome ids: the sample is the largest chromosome of this configuration
-            res["cpu_baseline"] = cb
-            res["speedup_vs_cpu_baseline"] = value / cb["value"]
-            if "many_core" in cb and "value" in cb["many_core"]:
-                res["speedup_vs_many_core_cpu"] = value / cb["many_core"]["value"]
+            with_cpu(res, chrom_ids, ops, N, args.mean_run, not args.no_many_core)
+        res.pop("_chrom_lens", None)
+    # the other BASELINE configurations and run lengths, as sub-records of the default line (one GPU)
+    if world == 1 and default_line and not args.no_sub:
+        subs, runs, others = {}, {}, {}
+
+        def sub(name, ops_, N_, chroms_, mean_run_, f64=False, cpu=True, moments=False):
+            try:
+                r = measure(ctx, name, ops_, N_, chroms_, mean_run_, args.sub_steps, 1, f64=f64, want_moments=moments)
+                if cpu and not args.no_cpu_baseline:
+                    with_cpu(r, chroms_, ops_, N_, mean_run_, not args.no_many_core)
+                r.pop("_chrom_lens", None)
+                return slim(r)
+            except Exception as e:
+                return {"error": repr(e)[:300]}
+
+        for name in ("c3", "c4", "c5"):
+            c = CONFIGS[name]
+            subs[name] = sub(name, c["ops"], c["tracks"], c["chroms"], args.mean_run, moments=name == "c5")
+        # C2 at the other run lengths of SURVEY 8d: mean run 1 bp on chromosomes 19-22 + Y (their 100 dense tracks fit HBM
+        # one chromosome at a time: 77 GB for chromosome 19), mean run 200 bp on the whole genome
+        runs["l1"] = sub("c2/l=1", ["mean"], 100, [18, 19, 20, 21, 23], 1.0, cpu=False)
+        runs["l200"] = sub("c2/l=200", ["mean"], 100, list(range(24)), 200.0, cpu=False)
+        # kernels the headline does not exercise, N = 100 on chromosome 21 (46.7 Mbp)
+        others["max"] = sub("max", ["max"], 100, [20], args.mean_run, cpu=False)
+        others["product"] = sub("product", ["product"], 100, [20], args.mean_run, cpu=False)
+        others["mean_f64_values"] = sub("mean/f64", ["mean"], 100, [20], args.mean_run, f64=True, cpu=False)
+        others["sum_500"] = sub("sum/500", ["sum"], 500, [20], args.mean_run, cpu=False)
+        if rank == 0:
+            res["configs"] = subs
+            res["c2_runs"] = runs
+            res["other_kernels"] = others
+    if rank == 0:
+        res["bench_seconds"] = time.perf_counter() - t_start
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -433,6 +433,8 @@ typedef struct {
     int32_t n_slots;
     double host_submit_ms;      /* host time inside wtamd_pipe_submit (enqueueing; nothing there waits for the GPU) */
     double host_wait_ms;        /* host time wtamd_pipe_collect spent waiting for a batch to finish */
+    int64_t bw_sections;        /* BigWig sections inflated on device (wtamd_pipe_submit_bw) */
+    double bw_decode_ms;        /* ... and the summed duration of their inflate / count / scan / scatter kernels (HIP events) */
 } wtamd_pipe_stats;
 
 int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out);
@@ -468,6 +470,47 @@ int wtamd_pipe_set_compress(wtamd_pipe *, int on);
 /* Submitted batches not yet collected. */
 int wtamd_pipe_in_flight(const wtamd_pipe *);
 int wtamd_pipe_get_stats(const wtamd_pipe *, wtamd_pipe_stats *out);
+
+/* ---- BigWig sections decoded ON THE DEVICE (csrc/wt_bwdev.hip, csrc/wt_inflate.h).  A batch may be handed
+ * over as the FILE BYTES of the BigWig data sections that overlap it instead of as run lists: the pipe
+ * ships the compressed bytes (2.5 x fewer than the run lists), inflates every section on the GPU -- one
+ * lane per zlib stream -- and expands the items into the slot's run lists with the reference reader's
+ * conventions (1-based starts, 10 000-bp boxing, seek window: src/bigWiggleReader.c:36-83,125-145).  This
+ * replaces the host-side inflate the reference gets from libBigWig; wtamd_BigWiggleReader children of a
+ * reducer of this library take this route on their own (WTAMD_BW_DEVICE=0 keeps the host decoder).
+ *
+ *   acquire -> wtamd_pipe_bw_reserve -> fill bytes[] and sections[] -> wtamd_pipe_submit_bw -> collect ...
+ *
+ * Sections are listed track by track (track-major, ascending position inside a track); a track's
+ * intervals must come out sorted and non-overlapping (checked on device: the batch fails otherwise). */
+typedef struct {
+    int64_t comp_off;               /* first byte of the section in bytes[] (any alignment) */
+    uint32_t comp_size;             /* its size there */
+    int32_t track;
+    uint32_t leaf_start, leaf_end;  /* extents of the section in the file's R-tree leaf, 0-based half-open: every item must
+                                       lie inside (checked on device) */
+} wtamd_bw_section;
+
+typedef struct {
+    uint32_t chrom_id;              /* the file's id of the batch's chromosome (sections of other ids yield nothing) */
+    uint32_t chrom_len;             /* its length in that file (bounds the boxing, bigWiggleReader.c:76) */
+    int32_t box;                    /* != 0: cut intervals at the reader's 10 000-bp stretch edges (:42-44,73-83) */
+    int32_t compressed;             /* != 0: sections are zlib streams (header uncompressBufSize != 0) */
+    int32_t clip_lo, clip_hi;       /* pieces are clipped to [clip_lo, clip_hi) (1-based) and dropped when empty */
+    int32_t first_section;          /* this track's slice of sections[]: [first_section, first_section + n_sections); */
+    int32_t n_sections;             /*   first_section of a track without sections = that of the next track           */
+    uint32_t plain_bytes;           /* upper bound of a section's inflated size (the file's uncompressBufSize; raw: its largest section) */
+    int32_t reserved;
+} wtamd_bw_track;
+
+/* Pinned staging of the acquired slot for `n_bytes` file bytes and `n_sections` table entries (grown on
+ * demand, contents undefined).  Pointers stay valid until the slot is submitted or cancelled. */
+int wtamd_pipe_bw_reserve(wtamd_pipe *, int64_t n_bytes, int64_t n_sections, uint8_t **bytes, wtamd_bw_section **sections);
+/* Ships the acquired slot as file bytes: tracks[n_tracks] describe the tracks, the tables / bytes are the
+ * reserved ones; runs whose start lies in [range_lo, range_hi) are produced, as for wtamd_pipe_submit.
+ * A malformed stream / section fails the batch at collect (WTAMD_ERR_INTERNAL with the cause). */
+int wtamd_pipe_submit_bw(wtamd_pipe *, int64_t n_bytes, int64_t n_sections, const wtamd_bw_track *tracks,
+                         int32_t range_lo, int32_t range_hi);
 
 /* Pinned (page-locked, DMA-able) host memory for bulk sources. */
 void *wtamd_host_alloc(size_t bytes);

@@ -13,7 +13,7 @@ def build(force=False):
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
         return so
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
-                           "-Wno-unused-function", "-o", so, srcs[0], "-lm"])
+                           "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", so, srcs[0], "-lm"])
     return so
 
 
@@ -29,7 +29,7 @@ def build_dropin(force=False):
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in deps):
         return so
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
-                           "-Wno-unused-function", "-o", so] + srcs + ["-lm", "-lz", "-lpthread"])
+                           "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", so] + srcs + ["-lm", "-lz", "-lpthread"])
     return so
 
 

@@ -16,6 +16,8 @@
 
 #include "../../include/wiggletools_amd.h"
 #include "../../wiggletools_amd/csrc/wt_mapop.h"
+#include "../../wiggletools_amd/csrc/wt_inflate.h"
+#include "../../wiggletools_amd/csrc/wt_bwdev_core.h"
 
 extern "C" long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const int32_t *start,
                                   const int32_t *finish, const void *value, int value_is_f64, const double *defaults,
@@ -42,6 +44,10 @@ struct Slot {
     int64_t n_runs = 0, covered = 0, n_int = 0;
     struct Direct { int64_t at, count; const int32_t *start, *finish; const float *value; };
     std::vector<Direct> direct;
+    // wtamd_pipe_bw_reserve: file bytes + section table of a batch that is decoded "on device"
+    std::vector<uint8_t> bw_bytes;
+    std::vector<wtamd_bw_section> bw_secs;
+    int64_t bw_res_bytes = -1, bw_res_secs = -1;
 };
 }  // namespace
 
@@ -283,6 +289,121 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
     p->st.batches++; p->st.intervals += n; p->st.runs += rr; p->st.covered_bp += info[4];
     if (info[8]) p->st.delta_batches++;
     return WTAMD_OK;
+}
+
+// ---- BigWig sections "on device": the kernels' own per-lane / per-item code (csrc/wt_inflate.h, csrc/wt_bwdev_core.h)
+// run one section after the other -- what csrc/wt_bwdev.hip runs one lane / one wavefront per section.
+
+// One zlib (or raw deflate) stream through the lane state machine; returns bytes produced or -(error).
+long long wtemu_inflate(const uint8_t *src, long long n, uint8_t *dst, long long cap, int raw_deflate) {
+    std::vector<uint16_t> perm(WT_INF_PERM), aux(WT_INF_AUX);
+    std::vector<uint8_t> ring(WT_INF_RING);
+    WtInfMem m{perm.data(), aux.data(), ring.data(), 1};
+    // the decoder reads whole aligned words around the stream and writes whole words: private padded copies
+    std::vector<uint8_t> in((size_t) n + 16, 0), out(((size_t) cap + 3) / 4 * 4 + 8, 0);
+    const int mis = (int) (n % 4);              // any alignment must work
+    if (n > 0) memcpy(in.data() + 4 + mis, src, (size_t) n);
+    WtInflate z;
+    wt_inf_begin(z, in.data() + 4 + mis, (uint32_t) n, out.data(), (uint32_t) cap, raw_deflate != 0);
+    while (wt_inf_step(z, m)) { }
+    const long long r = (long long) wt_inf_finish(z);
+    if (r > 0) memcpy(dst, out.data(), (size_t) r);
+    return r;
+}
+
+// The sections of a batch -> run lists (o_* sized `capacity`), seg_off[n_tracks + 1].  Returns the error bits.
+unsigned wtemu_bw_decode(const uint8_t *bytes, const wtamd_bw_section *secs, long long n_secs, const wtamd_bw_track *tracks,
+                         int n_tracks, long long capacity, int32_t *o_start, int32_t *o_finish, float *o_value, int64_t *seg_off) {
+    unsigned err = 0;
+    std::vector<std::vector<uint8_t>> plain((size_t) n_secs);
+    std::vector<long long> plen((size_t) n_secs, 0), cnt((size_t) n_secs, 0);
+    for (long long i = 0; i < n_secs; i++) {
+        const wtamd_bw_track &tk = tracks[secs[i].track];
+        uint32_t stride = ((tk.plain_bytes + 16) + 15u) & ~15u;
+        if (stride < 64) stride = 64;
+        plain[(size_t) i].assign(stride + 8, 0);
+        if (tk.compressed) plen[(size_t) i] = wtemu_inflate(bytes + secs[i].comp_off, secs[i].comp_size, plain[(size_t) i].data(), stride, 0);
+        else if (secs[i].comp_size > stride) plen[(size_t) i] = -WT_INF_ERR_SPACE;
+        else { memcpy(plain[(size_t) i].data(), bytes + secs[i].comp_off, secs[i].comp_size); plen[(size_t) i] = secs[i].comp_size; }
+    }
+    auto walk = [&](long long i, bool write, long long at) -> long long {
+        const wtamd_bw_section &sc = secs[i];
+        const wtamd_bw_track &tk = tracks[sc.track];
+        if (plen[(size_t) i] < 0) { err |= WT_BW_ERR_INFLATE; return 0; }
+        const uint8_t *p = plain[(size_t) i].data();
+        WtBwHdr h;
+        if (!wt_bw_parse_hdr(p, (uint32_t) plen[(size_t) i], h)) { err |= WT_BW_ERR_SECTION; return 0; }
+        if (h.chrom_id != tk.chrom_id) return 0;
+        long long n = 0;
+        for (uint32_t k = 0; k < h.count; k++) {
+            uint32_t s0, e0, vb;
+            wt_bw_item(p, h, k, s0, e0, vb);
+            if (s0 < sc.leaf_start || e0 > sc.leaf_end || e0 <= s0) err |= WT_BW_ERR_EXTENT;
+            if (e0 >= (uint32_t) WTAMD_MAX_COORD) err |= WT_BW_ERR_COORD;
+            if (k > 0) { uint32_t ps, pe, pv; wt_bw_item(p, h, k - 1, ps, pe, pv); if (s0 < pe) err |= WT_BW_ERR_EXTENT; }
+            float v;
+            memcpy(&v, &vb, 4);
+            n += wt_bw_pieces(s0, e0, tk, [&](int32_t a, int32_t b) {
+                if (write) { if (at < capacity) { o_start[at] = a; o_finish[at] = b; o_value[at] = v; } at++; }
+            });
+        }
+        return n;
+    };
+    long long total = 0;
+    for (long long i = 0; i < n_secs; i++) { cnt[(size_t) i] = walk(i, false, 0); total += cnt[(size_t) i]; }
+    if (total > capacity) err |= WT_BW_ERR_CAPACITY;
+    if (err) { for (int t = 0; t <= n_tracks; t++) seg_off[t] = 0; return err; }
+    long long at = 0;
+    std::vector<long long> off((size_t) n_secs + 1, 0);
+    for (long long i = 0; i < n_secs; i++) { off[(size_t) i] = at; walk(i, true, at); at += cnt[(size_t) i]; }
+    off[(size_t) n_secs] = at;
+    for (int t = 0; t < n_tracks; t++) seg_off[t] = tracks[t].first_section < n_secs ? off[(size_t) tracks[t].first_section] : at;
+    seg_off[n_tracks] = at;
+    return 0;
+}
+
+int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, uint8_t **bytes, wtamd_bw_section **sections) {
+    if (!p || p->acquired < 0 || n_bytes < 0 || n_sections < 0 || !bytes || !sections) { g_err = "wtamd_pipe_bw_reserve: bad arguments"; return WTAMD_ERR_ARG; }
+    Slot &s = p->slots[(size_t) p->acquired];
+    // fresh allocations on purpose (stale pointers must show up in the tests)
+    std::vector<uint8_t>((size_t) n_bytes + 16, 0xA5).swap(s.bw_bytes);
+    std::vector<wtamd_bw_section>((size_t) n_sections + 1).swap(s.bw_secs);
+    s.bw_res_bytes = n_bytes; s.bw_res_secs = n_sections;
+    *bytes = s.bw_bytes.data();
+    *sections = s.bw_secs.data();
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_submit_bw(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, const wtamd_bw_track *tracks,
+                         int32_t range_lo, int32_t range_hi) {
+    if (!p || p->acquired < 0 || !tracks) { g_err = "wtamd_pipe_submit_bw: no acquired slot"; return WTAMD_ERR_ARG; }
+    Slot &s = p->slots[(size_t) p->acquired];
+    const int N = p->cfg.n_tracks;
+    if (s.bw_res_bytes < 0 || n_bytes > s.bw_res_bytes || n_sections > s.bw_res_secs) { g_err = "wtamd_pipe_submit_bw: more than reserved"; return WTAMD_ERR_ARG; }
+    if (p->cfg.desc.op == WTAMD_OP_MULTIPLEX) { g_err = "wtamd_pipe_submit_bw: not for the tile"; return WTAMD_ERR_ARG; }
+    // the host's bound, as the product computes it (a decode producing more fails the batch)
+    int64_t bound = 0, next = 0;
+    for (int i = 0; i < N; i++) {
+        if (tracks[i].first_section != next) { g_err = "wtamd_pipe_submit_bw: sections must be listed track by track"; return WTAMD_ERR_ARG; }
+        for (int64_t q = next; q < next + tracks[i].n_sections; q++) {
+            const wtamd_bw_section &c = s.bw_secs[(size_t) q];
+            if (c.track != i || c.comp_off < 0 || c.comp_off + (int64_t) c.comp_size > n_bytes) { g_err = "wtamd_pipe_submit_bw: bad section entry"; return WTAMD_ERR_ARG; }
+            if (q > next && c.leaf_start < s.bw_secs[(size_t) q - 1].leaf_end) { g_err = "wtamd_pipe_submit_bw: sections not sorted / disjoint"; return WTAMD_ERR_ARG; }
+            bound += wt_bw_section_bound(tracks[i].plain_bytes, c.leaf_start, c.leaf_end, tracks[i].box);
+        }
+        next += tracks[i].n_sections;
+    }
+    if (next != n_sections) { g_err = "wtamd_pipe_submit_bw: section count mismatch"; return WTAMD_ERR_ARG; }
+    const int64_t cap = bound > 0 ? bound : 1;
+    s.start.assign((size_t) cap, 0); s.finish.assign((size_t) cap, 0); s.v32.assign((size_t) cap, 0.f);
+    if (s.has64) s.v64.assign((size_t) cap, 0.0);
+    s.cap = cap;
+    const unsigned e = wtemu_bw_decode(s.bw_bytes.data(), s.bw_secs.data(), n_sections, tracks, N, cap, s.start.data(), s.finish.data(),
+                                       s.v32.data(), s.seg_off.data());
+    s.bw_res_bytes = s.bw_res_secs = -1;
+    if (e) { g_err = "BigWig sections could not be decoded (bits " + std::to_string(e) + ")"; return WTAMD_ERR_INTERNAL; }
+    p->st.bw_sections += n_sections;
+    return wtamd_pipe_submit(p, 0, range_lo, range_hi);
 }
 
 int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {

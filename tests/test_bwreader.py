@@ -149,10 +149,19 @@ def _run_single_reader(L, tmp_path):
         exp += [(name, int(s), int(f), float(v)) for s, f, v in zip(t.start[a:b], t.finish[a:b], t.value[a:b])]
     wi = L.wtamd_BigWiggleReader(paths[0].encode(), 1)
     assert _pops(L, wi) == exp
+    # after seek the reference issues ONE region query (bigWiggleReader.c:91-92,125-145): intervals are boxed
+    # into [lo, hi) only (:42-44), NOT cut at the 10 000-bp stretch edges of a whole-chromosome read
+    u = bigwig.load_runlists(paths, box=False)
+    raw = []
+    for ci, name in enumerate(u.chrom_names):
+        a, b = u.seg_off[ci], u.seg_off[ci + 1]
+        raw += [(name, int(s), int(f), float(v)) for s, f, v in zip(u.start[a:b], u.finish[a:b], u.value[a:b])]
+    assert len(raw) < len(exp)              # some interval does cross a stretch edge
     wi = L.wtamd_BigWiggleReader(paths[0].encode(), 1)
-    for chrom, lo, hi in (("chr2", 10007, 23456), ("chr1", 1, 500), ("chr2", 40000, 50000), ("chrZ", 1, 10)):
+    for chrom, lo, hi in (("chr2", 10007, 23456), ("chr1", 1, 500), ("chr2", 40000, 50000), ("chrZ", 1, 10),
+                          ("chr1", 15000, 45000)):
         L.seek(wi, chrom.encode(), lo, hi)
-        want = [(c, max(s, lo), min(f, hi), v) for c, s, f, v in exp if c == chrom and f > lo and s < hi]
+        want = [(c, max(s, lo), min(f, hi), v) for c, s, f, v in raw if c == chrom and f > lo and s < hi]
         assert _pops(L, wi) == want
     # the reference destroys iterators with free(data) (wiggleIterator.c:52-55): the handle is free()-able,
     # the reader behind it (and its idle producer thread) stays

@@ -27,13 +27,11 @@
 #include <vector>
 
 #include "../../include/wiggletools_amd.h"
+#include "wt_bigwig_int.h"
 
 namespace {
 
-struct BwBlock {
-    uint32_t start_chrom, start_base, end_chrom, end_base;
-    uint64_t offset, size;
-};
+typedef WtBwLeaf BwBlock;
 
 struct BwChrom {
     std::string name;
@@ -54,6 +52,7 @@ struct wtamd_bw {
     int64_t part_from = -1, part_to = -1;
     int part_chrom = -1, part_blocks = 0, part_lo = 0, part_hi = 0;
     bool part_last = false;
+    std::vector<WtBwChromInfo> infos;           // wt_bw_chrom_info, one per chroms[] entry, computed on first use
 };
 
 namespace {
@@ -160,6 +159,42 @@ bool decode_block(wtamd_bw *bw, const BwBlock &b, uint32_t chrom_id, std::vector
 }
 
 }  // namespace
+
+const WtBwLeaf *wt_bw_leaves(const wtamd_bw *bw, int64_t *n) {
+    if (n) *n = (int64_t) bw->blocks.size();
+    return bw->blocks.data();
+}
+
+int wt_bw_fd(const wtamd_bw *bw) { return fileno(bw->fp); }
+
+uint32_t wt_bw_uncompress_buf(const wtamd_bw *bw) { return bw->uncompress_buf; }
+
+bool wt_bw_chrom_info(wtamd_bw *bw, const char *chrom, WtBwChromInfo *out) {
+    if (bw->infos.empty() && !bw->chroms.empty()) {
+        bw->infos.resize(bw->chroms.size());
+        for (size_t c = 0; c < bw->chroms.size(); c++) {
+            WtBwChromInfo &x = bw->infos[c];
+            x.id = bw->chroms[c].id; x.length = bw->chroms[c].length;
+            x.first = 0; x.count = 0; x.device_ok = true; x.max_size = 0;
+            int64_t last = -1;
+            for (int64_t i = 0; i < (int64_t) bw->blocks.size(); i++) {
+                const BwBlock &b = bw->blocks[(size_t) i];
+                if (b.start_chrom > x.id || b.end_chrom < x.id) continue;          // does not touch this chromosome
+                if (b.start_chrom != x.id || b.end_chrom != x.id) x.device_ok = false;     // a leaf spanning chromosomes
+                if (x.count == 0) x.first = i;
+                else if (i != last + 1 || b.start_base < bw->blocks[(size_t) last].end_base) x.device_ok = false;   // not contiguous / sorted / disjoint
+                if (b.end_base < b.start_base || b.size > 0x7FFFFFFFull) x.device_ok = false;
+                if (b.size > x.max_size) x.max_size = (uint32_t) std::min<uint64_t>(b.size, 0xFFFFFFFFull);
+                last = i;
+                x.count++;
+            }
+            if (!x.device_ok) x.count = last >= 0 ? last - x.first + 1 : 0;
+        }
+    }
+    for (size_t c = 0; c < bw->chroms.size(); c++)
+        if (bw->chroms[c].name == chrom) { *out = bw->infos[c]; return true; }
+    return false;
+}
 
 extern "C" {
 

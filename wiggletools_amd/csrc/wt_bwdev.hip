@@ -1,0 +1,293 @@
+// wt_bwdev.hip -- BigWig sections decoded ON THE DEVICE: compressed file bytes in, run lists
+// (start, finish, float value) of a pipeline batch out.  Replaces, for the file leg of the engine,
+// what the reference gets from libBigWig's host-side zlib inflate + interval loop
+// (src/bigWiggleReader.c:36-83) and what csrc/wt_bigwig.cpp does on host threads: with 100 files the
+// host inflate bounded the whole path at 1.6e7 bp/s, and the compressed bytes are 2.5 x
+// smaller than the run lists on the PCIe link.
+//
+// Kernels, all on the pipeline's decode stream, nothing returns to the host in between:
+//   wt_bw_copy_kernel     pinned host staging (file bytes as read) -> HBM, 16 B per lane
+//   wt_bw_inflate_kernel  ONE LANE PER SECTION: 64 independent zlib streams per wavefront
+//                         (csrc/wt_inflate.h: limit-based canonical Huffman decoding, tables 704 B of
+//                         LDS per lane interleaved across the wave, 64-byte LZ77 ring in LDS), plain
+//                         bytes to a strided scratch buffer.  Bound: dependent-instruction latency
+//                         (a serial bit stream per lane); throughput comes from sections in flight.
+//   wt_bw_count_kernel    one wavefront per section: header, per-item piece counts (1-based shift,
+//                         10 000-bp boxing, clip window: csrc/wt_bwdev_core.h), order / extent checks
+//   wt_bw_scan_kernel     one workgroup: exclusive scan over the sections -> piece offsets, the
+//                         batch's device-side seg_off[], total and error word (pinned host status)
+//   wt_bw_scatter_kernel  one wavefront per section: pieces to the slot's SoA arrays (coalesced)
+// HBM traffic: 4.8 B (compressed) + 2 x 12 B (plain, written and read twice) + 12 B per interval --
+// a few % of the reduce kernels' traffic; the inflate kernel is the one that costs time.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/wiggletools_amd.h"
+#include "wt_inflate.h"
+#include "wt_bwdev_core.h"
+
+int wt_fail_ext(int code, const std::string &msg);     // wt_engine.hip
+
+namespace {
+
+typedef unsigned int wt_u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) wt_bw_copy_kernel(const wt_u32x4 *src, wt_u32x4 *dst, long long n16) {
+    const long long stride = (long long) gridDim.x * 256 * 4;
+    for (long long i = (long long) blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride) {
+        wt_u32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (i + 256 * q < n16) v[q] = __builtin_nontemporal_load(src + i + 256 * q);
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (i + 256 * q < n16) dst[i + 256 * q] = v[q];
+    }
+}
+
+#define WT_BW_INF_LANES 64
+
+__global__ void __launch_bounds__(WT_BW_INF_LANES) wt_bw_inflate_kernel(const WtBwSection *secs, const WtBwTrack *tracks, int n_sec,
+                                                                         const uint8_t *comp, uint8_t *plain, uint32_t plain_stride,
+                                                                         int32_t *plain_len) {
+    __shared__ uint16_t s_perm[WT_INF_PERM * WT_BW_INF_LANES];
+    __shared__ uint16_t s_aux[WT_INF_AUX * WT_BW_INF_LANES];
+    __shared__ uint8_t s_ring[WT_INF_RING * WT_BW_INF_LANES];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x * WT_BW_INF_LANES + lane;
+    if (i >= n_sec) return;
+    const WtBwSection sc = secs[i];
+    const bool compressed = tracks[sc.track].compressed != 0;
+    WtInfMem m;
+    m.perm = s_perm + lane; m.aux = s_aux + lane; m.ring = s_ring + lane; m.stride = WT_BW_INF_LANES;
+    WtInflate z;
+    wt_inf_begin(z, comp + sc.comp_off, sc.comp_size, plain + (size_t) i * plain_stride, plain_stride, false);
+    if (!compressed) {          // an uncompressed file: the section bytes are copied (a stored block in disguise)
+        z.st = sc.comp_size ? WT_INF_ST_STORED : WT_INF_ST_DONE;
+        z.stored_rem = sc.comp_size;
+        z.last = true;
+        if (sc.comp_size > plain_stride) wt_inf_fail(z, WT_INF_ERR_SPACE);
+    }
+    while (wt_inf_step(z, m)) { }
+    plain_len[i] = (int32_t) wt_inf_finish(z);
+}
+
+__device__ __forceinline__ uint32_t wt_wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wt_wave_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(64) wt_bw_count_kernel(const WtBwSection *secs, const WtBwTrack *tracks, int n_sec,
+                                                          const uint8_t *plain, uint32_t plain_stride, const int32_t *plain_len,
+                                                          uint32_t *counts, uint32_t *err) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n_sec) return;
+    const WtBwSection sc = secs[i];
+    const WtBwTrack tk = tracks[sc.track];
+    const int32_t len = plain_len[i];
+    uint32_t bad = 0, total = 0;
+    if (len < 0) {
+        bad = WT_BW_ERR_INFLATE;
+    } else {
+        const uint8_t *p = plain + (size_t) i * plain_stride;
+        WtBwHdr h;
+        if (!wt_bw_parse_hdr(p, (uint32_t) len, h)) {
+            bad = WT_BW_ERR_SECTION;
+        } else if (h.chrom_id == tk.chrom_id) {     // (else: a block of another chromosome sharing the index leaf)
+            for (uint32_t k0 = 0; k0 < h.count; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                if (k < h.count) {
+                    uint32_t s0, e0, vb;
+                    wt_bw_item(p, h, k, s0, e0, vb);
+                    if (s0 < sc.leaf_start || e0 > sc.leaf_end || e0 <= s0) bad |= WT_BW_ERR_EXTENT;
+                    if (e0 >= (uint32_t) WTAMD_MAX_COORD) bad |= WT_BW_ERR_COORD;
+                    if (k > 0) {
+                        uint32_t ps, pe, pv;
+                        wt_bw_item(p, h, k - 1, ps, pe, pv);
+                        if (s0 < pe) bad |= WT_BW_ERR_EXTENT;       // unsorted or overlapping items
+                    }
+                    total += wt_bw_pieces(s0, e0, tk, [](int32_t, int32_t) {});
+                }
+            }
+        }
+    }
+    total = wt_wave_sum(total);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bad |= __shfl_xor(bad, o, 64);
+    if (lane == 0) {
+        counts[i] = total;
+        if (bad) atomicOr(err, bad);
+    }
+}
+
+// status[0] = error bits, status[1] = pieces of the batch (pinned host memory)
+__global__ void __launch_bounds__(1024) wt_bw_scan_kernel(const WtBwTrack *tracks, int n_tracks, int n_sec, const uint32_t *counts,
+                                                           long long *offsets, int64_t *seg_off, long long capacity,
+                                                           uint32_t *err, unsigned long long *status) {
+    __shared__ long long s_part[1024];
+    __shared__ long long s_carry;
+    const int t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_sec; base += 1024 * 8) {
+        long long v[8], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = base + t * 8 + q;
+            v[q] = i < n_sec ? (long long) counts[i] : 0;
+            sum += v[q];
+        }
+        s_part[t] = sum;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const long long x = t >= o ? s_part[t - o] : 0;
+            __syncthreads();
+            s_part[t] += x;
+            __syncthreads();
+        }
+        long long run = s_carry + s_part[t] - sum;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = base + t * 8 + q;
+            if (i < n_sec) offsets[i] = run;
+            run += v[q];
+        }
+        __syncthreads();
+        if (t == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+    const long long total = s_carry;
+    if (t == 0) offsets[n_sec] = total;
+    __syncthreads();
+    // any error: the batch is handed on EMPTY (the kernels downstream must not read what was not written)
+    const bool failed = *err != 0 || total > capacity;
+    for (int k = t; k <= n_tracks; k += 1024) {
+        long long o = total;
+        if (failed) o = 0;
+        else if (k < n_tracks) {
+            // the first section at or after this track's slice (empty slices take the next track's offset)
+            const int fs = tracks[k].first_section;
+            o = fs < n_sec ? offsets[fs] : total;
+        }
+        seg_off[k] = o;
+    }
+    if (t == 0) {
+        uint32_t e = *err;
+        if (total > capacity) e |= WT_BW_ERR_CAPACITY;
+        *err = e;
+        status[0] = e;
+        status[1] = (unsigned long long) total;
+    }
+}
+
+__global__ void __launch_bounds__(64) wt_bw_scatter_kernel(const WtBwSection *secs, const WtBwTrack *tracks, int n_sec,
+                                                            const uint8_t *plain, uint32_t plain_stride, const int32_t *plain_len,
+                                                            const long long *offsets, long long capacity, const uint32_t *err,
+                                                            int32_t *o_start, int32_t *o_finish, float *o_value) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n_sec) return;
+    if (*err) return;           // a failed batch is empty (see the scan kernel)
+    const int32_t len = plain_len[i];
+    if (len < 0) return;
+    const WtBwSection sc = secs[i];
+    const WtBwTrack tk = tracks[sc.track];
+    const uint8_t *p = plain + (size_t) i * plain_stride;
+    WtBwHdr h;
+    if (!wt_bw_parse_hdr(p, (uint32_t) len, h) || h.chrom_id != tk.chrom_id) return;
+    long long at = offsets[i];
+    const long long end = offsets[i + 1];
+    for (uint32_t k0 = 0; k0 < h.count; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        uint32_t s0 = 0, e0 = 0, vb = 0, n = 0;
+        if (k < h.count) {
+            wt_bw_item(p, h, k, s0, e0, vb);
+            n = wt_bw_pieces(s0, e0, tk, [](int32_t, int32_t) {});
+        }
+        const uint32_t incl = wt_wave_scan(n, lane);
+        long long w = at + (long long) (incl - n);
+        if (n) {
+            const float v = __uint_as_float(vb);
+            wt_bw_pieces(s0, e0, tk, [&](int32_t a, int32_t b) {
+                if (w < end && w < capacity) { o_start[w] = a; o_finish[w] = b; o_value[w] = v; }
+                w++;
+            });
+        }
+        at += (long long) __shfl(incl, 63, 64);
+    }
+}
+
+}  // namespace
+
+// scratch a batch of `n_sec` sections with `plain_stride` bytes each needs, in bytes
+long long wt_bw_scratch_bytes(long long n_sec, long long plain_stride) {
+    const long long n = n_sec > 0 ? n_sec : 1;
+    // plain | plain_len (i32) | counts (u32) | offsets (i64, n + 1) | err (u32, padded)
+    return n * plain_stride + n * 4 + n * 4 + (n + 1) * 8 + 64 + 256;
+}
+
+// Enqueues copy (on s_copy) -> [event] -> inflate, count, scan, scatter (on s_dec).
+//   h_bytes / d_bytes: the batch's staging (tables + file bytes), pinned host and device twin, n_bytes (padded to 16)
+//   d_comp: where the file bytes start inside d_bytes;  d_secs / d_tracks: the tables inside d_bytes
+//   scratch: wt_bw_scratch_bytes() of device memory
+//   d_seg_off: n_tracks + 1 offsets written on device;  h_status: 2 words of pinned host memory
+int wt_bw_decode_async(const void *h_bytes, void *d_bytes, long long n_bytes, const void *d_comp, const void *d_secs, const void *d_tracks, int n_tracks,
+                       long long n_sec, long long plain_stride, void *scratch, long long capacity, int32_t *o_start, int32_t *o_finish,
+                       float *o_value, int64_t *d_seg_off, unsigned long long *h_status, int copy_blocks, hipStream_t s_copy,
+                       hipEvent_t e_copied, hipStream_t s_dec) {
+    if (n_sec < 0 || n_sec > 0x7FFFFFFFll - 64 || plain_stride <= 0 || (plain_stride & 15) || plain_stride > 0x7FFFFFFFll)
+        return wt_fail_ext(WTAMD_ERR_ARG, "wt_bw_decode_async: bad section count / stride");
+    const long long n = n_sec > 0 ? n_sec : 1;
+    uint8_t *plain = (uint8_t *) scratch;
+    int32_t *plain_len = (int32_t *) (plain + n * plain_stride);
+    uint32_t *counts = (uint32_t *) (plain_len + n);
+    long long *offsets = (long long *) (((uintptr_t) (counts + n) + 7) & ~(uintptr_t) 7);
+    uint32_t *err = (uint32_t *) (offsets + n + 1);
+#define WT_BW_HIP(expr)                                                                                  \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return wt_fail_ext(WTAMD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+    const long long n16 = (n_bytes + 15) / 16;
+    if (n16 > 0) {
+        long long grid = copy_blocks > 0 ? copy_blocks : 64;
+        const long long need = (n16 + 1023) / 1024;
+        if (grid > need) grid = need;
+        hipLaunchKernelGGL(wt_bw_copy_kernel, dim3((unsigned) grid), dim3(256), 0, s_copy, (const wt_u32x4 *) h_bytes, (wt_u32x4 *) d_bytes, n16);
+        WT_BW_HIP(hipGetLastError());
+    }
+    WT_BW_HIP(hipEventRecord(e_copied, s_copy));
+    WT_BW_HIP(hipStreamWaitEvent(s_dec, e_copied, 0));
+    WT_BW_HIP(hipMemsetAsync(err, 0, sizeof(uint32_t), s_dec));
+    const WtBwSection *secs = (const WtBwSection *) d_secs;
+    const WtBwTrack *tracks = (const WtBwTrack *) d_tracks;
+    if (n_sec > 0) {
+        const unsigned g = (unsigned) ((n_sec + WT_BW_INF_LANES - 1) / WT_BW_INF_LANES);
+        hipLaunchKernelGGL(wt_bw_inflate_kernel, dim3(g), dim3(WT_BW_INF_LANES), 0, s_dec, secs, tracks, (int) n_sec,
+                           (const uint8_t *) d_comp, plain, (uint32_t) plain_stride, plain_len);
+        WT_BW_HIP(hipGetLastError());
+        hipLaunchKernelGGL(wt_bw_count_kernel, dim3((unsigned) n_sec), dim3(64), 0, s_dec, secs, tracks, (int) n_sec, plain,
+                           (uint32_t) plain_stride, plain_len, counts, err);
+        WT_BW_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(wt_bw_scan_kernel, dim3(1), dim3(1024), 0, s_dec, tracks, n_tracks, (int) n_sec, counts, offsets, d_seg_off,
+                       capacity, err, h_status);
+    WT_BW_HIP(hipGetLastError());
+    if (n_sec > 0) {
+        hipLaunchKernelGGL(wt_bw_scatter_kernel, dim3((unsigned) n_sec), dim3(64), 0, s_dec, secs, tracks, (int) n_sec, plain,
+                           (uint32_t) plain_stride, plain_len, offsets, capacity, err, o_start, o_finish, o_value);
+        WT_BW_HIP(hipGetLastError());
+    }
+#undef WT_BW_HIP
+    return WTAMD_OK;
+}

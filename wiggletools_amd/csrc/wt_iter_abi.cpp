@@ -50,6 +50,8 @@
 
 #include "../../include/wiggletools_amd.h"
 #include "wt_mapop.h"
+#include "wt_bigwig_int.h"
+#include <unistd.h>
 
 #define WT_WEAK __attribute__((weak))
 
@@ -120,9 +122,15 @@ struct TrackSource {
     bool drops = false;             // ... one of them drops runs (ln, log, gt, gte, lt, lte)
     const char *raw = nullptr;      // last chrom pointer seen on `it` ...
     const char *interned = nullptr; // ... and its interned name
+    int32_t seen_finish = 0;        // finish of the last element it_chrom() looked at
 
+    // A child may reuse ONE name buffer across chromosomes (same pointer, new content): inside a chromosome
+    // the starts never fall below the previous finish, so a coordinate that goes backwards is the cue to
+    // compare the content again (the reference's multiplexer compares by strcmp every time, multiplexer.c:56).
     const char *it_chrom(Interner &in) {
         if (it->chrom != raw || !interned) { raw = it->chrom; interned = in.get(raw); }
+        else if (it->start < seen_finish && strcmp(raw, interned) != 0) interned = in.get(raw);
+        seen_finish = it->finish;
         return interned;
     }
     bool empty() const { return pending.empty() && it->done; }
@@ -242,6 +250,24 @@ const int64_t kDirectMin = 64;              // bulk blocks of at least this many
 const int64_t kFirstSpan = 2048;            // bp of a Multiplexer's priming batch
 const int64_t kReducerFirstSpan = 65536;    // bp of a reducer's first batch
 
+// ---- BigWig files decoded on the device (details with the BigWig reader further down) ----
+struct BwReader;
+struct Feeder;
+struct BwDevTrack {
+    BwReader *r = nullptr;
+    int ci = 0;                     // chromosome (index into the reader's strcmp-sorted names); past the end: exhausted
+    bool have = false;              // info / cursor / cname describe chromosome ci
+    WtBwChromInfo info{};
+    int64_t cursor = 0;             // first index leaf (relative to info.first) that can still hold an interval reaching the next batch
+    int32_t clip_lo = 1, clip_hi = INT32_MAX;
+    int box = 1;
+    bool single = false;            // seek window: nothing after this chromosome
+    const char *cname = nullptr;    // interned name of chromosome ci
+};
+void bw_seek(WiggleIterator *wi, const char *chrom, int start, int finish);
+bool bwdev_eligible(const Feeder &F);
+bool bwdev_drain_and_submit(Feeder &F);
+
 // Drains the children into pipeline slots and keeps `depth` batches in flight.
 struct Feeder {
     std::vector<TrackSource> src;
@@ -250,13 +276,20 @@ struct Feeder {
     wtamd_pipe *pipe = nullptr;
     int64_t max_runs = 0;               // output capacity of a slot = upper bound of hi - lo
     int64_t target = 0;                 // intervals per steady-state batch
-    int depth = 1;                      // batches kept in flight
+    int depth = 1;                      // batches kept in flight (at most the pipe's slots - 1)
+    int n_slots_open = 3;
     bool keep_log = false;              // Multiplexer mode: remember what was consumed (take-over pushes it back)
     bool f64_mode = false;              // a value that is not float32-exact was seen
     bool use_bulk = true;               // WTAMD_NO_BULK=1: children of this library are popped like foreign ones
     bool all_bulk = false;              // every child is a bulk source of this library (float32 SoA): unstaged DMA
     DrainPool *pool = nullptr;          // parallel draining: every child is foreign, nothing is dropped on device
     std::vector<DrainOut> outs;
+    // every child is a wtamd_BigWiggleReader: the batches travel as FILE BYTES and are inflated / decoded on the
+    // device (wtamd_pipe_submit_bw); the readers' own host decoders idle
+    bool bw_mode = false, bw_dirty = true;
+    std::vector<BwDevTrack> bwt;
+    DrainPool *io_pool = nullptr;       // parallel pread() of the section bytes
+    int64_t bw_target_bytes = 0;
     // drain position
     const char *chrom = nullptr;        // chromosome of the batch being / last drained
     bool continuing = false;            // next batch continues `chrom` at next_lo
@@ -288,14 +321,24 @@ struct Feeder {
         for (const auto &s : src) all_bulk = all_bulk && s.bulk != nullptr && s.bulk->stable;
         if (getenv("WTAMD_MIN_SPAN")) first_span = min_span;
         span = first_span < max_runs ? first_span : max_runs;
+        bw_mode = desc.op != WTAMD_OP_MULTIPLEX && bwdev_eligible(*this);
+        bw_dirty = true;
+        bw_target_bytes = env_i64("WTAMD_BW_BATCH_BYTES", 128 << 20);
         if (wtamd_pipe_create(&cfg, &pipe) != WTAMD_OK) die("wtamd_pipe_create");
+        n_slots_open = n_slots ? std::min(std::max(n_slots, 2), 8) : 3;     // (wtamd_pipe_create's own clamp)
+        if (depth > n_slots_open - 1) depth = n_slots_open - 1;
         bool any_map = false;
         std::vector<wtamd_map_chain> chains;
         for (const auto &s : src) { chains.push_back(s.chain); any_map = any_map || s.chain.n_ops > 0; }
         if (any_map && wtamd_pipe_set_map(pipe, chains.data()) != WTAMD_OK) die("wtamd_pipe_set_map");
         // parallel draining when every child is popped through the reference's protocol
-        bool eligible = !keep_log && !src.empty();
+        bool eligible = !keep_log && !src.empty() && !bw_mode;
         for (const auto &s : src) eligible = eligible && !(s.bulk && use_bulk) && !s.drops;
+        if (bw_mode && !io_pool) {
+            const int t = std::max(1, std::min({wt_usable_cores(), 16, n_tracks()}));
+            io_pool = new DrainPool();
+            io_pool->start(t);
+        }
         const char *et = getenv("WTAMD_DRAIN_THREADS");
         int threads = et ? atoi(et) : (n_tracks() >= 16 ? std::min(wt_usable_cores(), 16) : 1);
         if (threads > n_tracks()) threads = n_tracks();
@@ -311,6 +354,8 @@ struct Feeder {
         pipe = nullptr;
         delete pool;
         pool = nullptr;
+        delete io_pool;
+        io_pool = nullptr;
     }
 
     // One foreign child, popped up to the cut `hi` of chromosome `chrom` (interned) into `o`.  Worker
@@ -329,9 +374,10 @@ struct Feeder {
         WiggleIterator *it = s.it;
         while (!it->done) {
             const char *rc = it->chrom;
-            if (rc == s.raw && s.interned) { if (s.interned != chrom) return; }
-            else if (strcmp(rc, chrom) != 0) return;
             const int32_t st = it->start, fi = it->finish;
+            if (rc == s.raw && s.interned && st >= s.seen_finish) { if (s.interned != chrom) return; }
+            else if (strcmp(rc, chrom) != 0) return;
+            s.seen_finish = fi;
             o.push(st, fi, it->value);
             if (st >= hi) { o.more = true; o.sentinel_lo = st; return; }    // sentinel: stays current
             if (fi >= hi) { o.more = o.carry = true; return; }              // reaches the cut: stays current
@@ -366,10 +412,24 @@ struct Feeder {
         drop_flights();
         for (auto &s : src) { s.pending.clear(); s.log.clear(); s.raw = nullptr; s.interned = nullptr; }
         continuing = false;
+        bw_dirty = true;        // (device-decoded files: the tracks' positions are read off the re-positioned readers again)
+    }
+
+    // A batch was cut at INT32_MAX (an open-ended interval: finish == INT32_MAX always "reaches the cut"):
+    // every interval of the chromosome that is still pending or current starts below the cut and was part
+    // of the batch, so it is consumed here instead of being carried into an endless series of empty batches.
+    void finish_open_ended(const char *c) {
+        for (auto &s : src) {
+            while (!s.pending.empty() && s.pending.front().chrom == c) s.pending.pop_front();
+            if (!s.pending.empty()) continue;
+            while (!s.it->done && s.it_chrom(names) == c) s.it->pop(s.it);
+        }
+        continuing = false;
     }
 
     // Fills one slot with the next batch and ships it.  False: the sources are exhausted.
     bool drain_and_submit() {
+        if (bw_mode) return bwdev_drain_and_submit(*this);
         const int N = n_tracks();
         int32_t lo;
         if (continuing) {
@@ -562,11 +622,12 @@ struct Feeder {
         // interval beyond it (no track is in play in between: no run can start there)
         continuing = more;
         next_lo = carry ? hi : (int32_t) sentinel_lo;
+        if (hi == INT32_MAX && more) finish_open_ended(chrom);    // no run can start at or beyond INT32_MAX: the chromosome is done
         // steer the span towards the interval budget, bounded by the slot's output capacity
         const int64_t max_span = max_runs < ((int64_t) 1 << 31) ? max_runs : ((int64_t) 1 << 31);
         int64_t want = span * 2;
         if (n > 0) {
-            const double per_bp = (double) n / (double) ((int64_t) hi - lo);
+            const double per_bp = (double) n / (double) std::max<int64_t>((int64_t) hi - lo, 1);
             const double w = (double) target / per_bp;
             want = w > 4e9 ? (int64_t) 4e9 : (int64_t) w;
             if (want > span * 8) want = span * 8;
@@ -589,6 +650,7 @@ struct Feeder {
             flights.pop_front();
         }
         for (;;) {
+            if (depth > n_slots_open - 1) depth = n_slots_open - 1;
             while ((int) flights.size() < depth && drain_and_submit()) { }
             if (flights.empty()) return false;
             const double t_c0 = g_trace ? now_ms() : 0;
@@ -894,6 +956,7 @@ struct BwReader {
     int64_t p_cursor = 0;       // wtamd_bw_read_part cursor inside it
     int p_blocks = 4;
     bool p_single = false;      // stop after p_chrom (seek window)
+    int p_box = 1;              // box of the parts being decoded: off inside a seek window (one region query, bigWiggleReader.c:91-92)
     int32_t p_lo0 = 0, p_hi0 = INT32_MAX;
     std::thread th;
     std::mutex mu;
@@ -937,11 +1000,11 @@ void bw_decode(BwReader *r, BwBuffer &b) {
     while (r->p_chrom < (int) r->names.size()) {
         int last = 0;
         const char *name = r->names[(size_t) r->p_chrom].c_str();
-        int64_t n = wtamd_bw_read_part(r->bw, name, r->box, &r->p_cursor, r->p_blocks, r->p_lo0, r->p_hi0, b.cap, b.start, b.finish,
+        int64_t n = wtamd_bw_read_part(r->bw, name, r->p_box, &r->p_cursor, r->p_blocks, r->p_lo0, r->p_hi0, b.cap, b.start, b.finish,
                                        b.value, &last);
         if (n > b.cap) {
             if (!bw_alloc(b, n + n / 8)) { r->failed = true; return; }
-            n = wtamd_bw_read_part(r->bw, name, r->box, &r->p_cursor, r->p_blocks, r->p_lo0, r->p_hi0, b.cap, b.start, b.finish,
+            n = wtamd_bw_read_part(r->bw, name, r->p_box, &r->p_cursor, r->p_blocks, r->p_lo0, r->p_hi0, b.cap, b.start, b.finish,
                                    b.value, &last);
         }
         if (n < 0) { r->failed = true; return; }
@@ -1040,8 +1103,9 @@ void bw_advance(BulkSource *bs, WiggleIterator *wi, int64_t k) {
 }
 
 void bw_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
-    // bigWiggleReader.c:125-145: the producer is restarted on [start, finish) of that chromosome;
-    // the first interval is clipped to `start` (:143-144), the stretches end at `finish`
+    // bigWiggleReader.c:125-145: the producer is restarted on ONE region query [start, finish) of that
+    // chromosome (:91-92 -> readBigWiggleRegion): intervals are boxed into that window only (:42-44), not
+    // into the 10 000-bp stretches of a whole-chromosome read (:73-83)
     BwReader *r = ((BwHandle *) wi->data)->r;
     bw_wait(r);                             // whatever the producer is decoding lands first; it is idle afterwards
     r->windowed = true;
@@ -1055,11 +1119,221 @@ void bw_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
     r->p_cursor = 0;
     r->p_blocks = 4;
     r->p_single = true;
+    r->p_box = 0;
     r->p_lo0 = start > 0 ? start - 1 : 0;
     r->p_hi0 = finish > 0 ? finish - 1 : 0;
     r->j = r->end = 0;
     bw_request(r, r->cur ^ 1);
     bw_settle(r, wi);
+}
+
+// ---------------------------------------------------------------------------
+// BigWig files decoded ON THE DEVICE.  When every child of a reducer is a wtamd_BigWiggleReader, the
+// Feeder does not drain intervals at all: per batch it lists, for every file, the index leaves (data
+// sections) overlapping the batch's window, pread()s their bytes -- still compressed -- into the slot's
+// pinned staging on a few I/O threads and ships them with wtamd_pipe_submit_bw.  The GPU inflates
+// (one lane per zlib stream), shifts to 1-based, boxes into the reference reader's 10 000-bp
+// stretches, clips to the seek window (bigWiggleReader.c:36-83,125-145) and multiplexes.  What the
+// host contributes is the R-tree arithmetic:
+//   * a batch [lo, hi) needs, per track, every interval starting below hi that is not wholly before
+//     lo, plus the first interval at or beyond hi (the sentinel that gives the last run its true
+//     finish): all leaves from the track's cursor that start below hi, and one more;
+//   * the cursor moves past a leaf once all of its intervals finish BELOW the next batch's start
+//     (a leaf ending exactly at the cut is seen again: its last finish is a breakpoint there).
+//     Leaves read twice are decoded twice -- one in ~85 at the default batch size.
+// Runs come out exactly as from the host decoder: the device applies the same arithmetic to the same
+// items (tests/test_bwdev.py: byte-for-byte the host path's output; WTAMD_BW_DEVICE=0 selects it).
+// ---------------------------------------------------------------------------
+BwReader *bwdev_reader(const TrackSource &s) {
+    if (!s.it || s.it->seek != &bw_seek || s.it->pop != &wt_bulk_pop) return nullptr;
+    return ((BwHandle *) s.it->data)->r;
+}
+
+bool bwdev_eligible(const Feeder &F) {
+    const char *e = getenv("WTAMD_BW_DEVICE");
+    if (e && atoi(e) == 0) return false;
+    if (F.keep_log || !F.use_bulk || F.src.empty()) return false;
+    for (const auto &s : F.src) {
+        BwReader *r = bwdev_reader(s);
+        if (!r || s.drops) return false;            // (operators that drop runs need the host's seam look-ahead)
+        for (const std::string &n : r->names) {
+            WtBwChromInfo ci;
+            if (!wt_bw_chrom_info(r->bw, n.c_str(), &ci) || !ci.device_ok) return false;
+        }
+    }
+    return true;
+}
+
+// Where every track stands: read off the readers (their current element, or what a Multiplexer had
+// popped and pushed back), once after open / seek.
+void bwdev_init(Feeder &F) {
+    F.bwt.assign(F.src.size(), BwDevTrack());
+    for (size_t i = 0; i < F.src.size(); i++) {
+        TrackSource &s = F.src[i];
+        BwDevTrack &t = F.bwt[i];
+        BwReader *r = bwdev_reader(s);
+        t.r = r;
+        t.ci = (int) r->names.size();
+        const char *rc = nullptr;
+        int32_t rs = 1;
+        if (!s.pending.empty()) { rc = s.pending.front().chrom; rs = s.pending.front().start; }
+        else if (!s.it->done) { rc = s.it->chrom; rs = s.it->start; }
+        s.pending.clear();
+        if (!rc) continue;
+        for (size_t c = 0; c < r->names.size(); c++)
+            if (r->names[c] == rc) t.ci = (int) c;
+        t.clip_lo = rs;
+        if (r->windowed) { t.clip_hi = r->win_finish; t.box = 0; t.single = true; }
+        else { t.clip_hi = INT32_MAX; t.box = r->box; t.single = false; }
+    }
+}
+
+// Makes t.info / t.cursor describe the track's next chromosome that still has leaves to deliver.
+void bwdev_settle(Feeder &F, BwDevTrack &t) {
+    const int nc = (int) t.r->names.size();
+    const WtBwLeaf *L = wt_bw_leaves(t.r->bw, nullptr);
+    while (t.ci < nc) {
+        if (!t.have) {
+            if (!wt_bw_chrom_info(t.r->bw, t.r->names[(size_t) t.ci].c_str(), &t.info)) { t.info.count = 0; }
+            // leaves that end at or before clip_lo hold nothing for this track (sorted, disjoint: binary search)
+            int64_t lo = 0, hi = t.info.count;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) / 2;
+                if ((int64_t) L[t.info.first + mid].end_base + 1 <= (int64_t) t.clip_lo) lo = mid + 1; else hi = mid;
+            }
+            t.cursor = lo;
+            t.cname = F.names.get(t.r->cnames[(size_t) t.ci]);
+            t.have = true;
+        }
+        if (t.cursor < t.info.count && (int64_t) L[t.info.first + t.cursor].start_base + 1 < (int64_t) t.clip_hi) return;
+        // chromosome finished
+        t.have = false;
+        if (t.single) { t.ci = nc; return; }
+        t.ci++;
+        t.clip_lo = 1;
+    }
+}
+
+bool bwdev_drain_and_submit(Feeder &F) {
+    const int N = F.n_tracks();
+    if (F.bw_dirty) { bwdev_init(F); F.bw_dirty = false; F.continuing = false; }
+    for (auto &t : F.bwt) bwdev_settle(F, t);
+    int32_t lo;
+    if (F.continuing) {
+        lo = F.next_lo;
+    } else {
+        F.chrom = nullptr;
+        for (const auto &t : F.bwt)
+            if (t.have && (!F.chrom || strcmp(t.cname, F.chrom) < 0)) F.chrom = t.cname;        // multiplexer.c:56
+        if (!F.chrom) return false;
+        int64_t m = INT32_MAX;
+        for (const auto &t : F.bwt) {
+            if (!t.have || t.cname != F.chrom) continue;
+            const WtBwLeaf &l = wt_bw_leaves(t.r->bw, nullptr)[t.info.first + t.cursor];
+            const int64_t st = std::max<int64_t>((int64_t) l.start_base + 1, t.clip_lo);
+            if (st < m) m = st;
+        }
+        lo = (int32_t) m;
+    }
+    const int64_t hi64 = (int64_t) lo + F.span;
+    const int32_t hi = hi64 >= INT32_MAX ? INT32_MAX : (int32_t) hi64;
+
+    const double t_drain0 = g_trace ? now_ms() : 0;
+    wtamd_pipe_batch b;
+    if (wtamd_pipe_acquire(F.pipe, &b) != WTAMD_OK) die("wtamd_pipe_acquire");
+    // the batch's sections and where their bytes come from
+    struct ReadOp { int fd; int64_t off, len, dst; };
+    std::vector<wtamd_bw_section> secs;
+    std::vector<wtamd_bw_track> tracks((size_t) N);
+    std::vector<ReadOp> ops;
+    int64_t n_bytes = 0;
+    bool more = false;
+    for (int i = 0; i < N; i++) {
+        BwDevTrack &t = F.bwt[(size_t) i];
+        wtamd_bw_track &k = tracks[(size_t) i];
+        memset(&k, 0, sizeof(k));
+        k.first_section = (int32_t) secs.size();
+        k.clip_lo = 1; k.clip_hi = INT32_MAX;
+        if (!t.have || t.cname != F.chrom) continue;
+        const WtBwLeaf *L = wt_bw_leaves(t.r->bw, nullptr) + t.info.first;
+        const uint32_t ub = wt_bw_uncompress_buf(t.r->bw);
+        k.chrom_id = t.info.id; k.chrom_len = t.info.length;
+        k.box = t.box; k.compressed = ub ? 1 : 0;
+        k.clip_lo = t.clip_lo; k.clip_hi = t.clip_hi;
+        k.plain_bytes = ub ? ub : t.info.max_size;
+        const int64_t stop = std::min<int64_t>(hi, t.clip_hi);     // leaves starting at or beyond it hold nothing below the cut
+        int64_t e = t.cursor;
+        while (e < t.info.count && (int64_t) L[e].start_base + 1 < stop) e++;
+        if (e < t.info.count && (int64_t) L[e].start_base + 1 < (int64_t) t.clip_hi) e++;        // the sentinel's leaf
+        const int fd = wt_bw_fd(t.r->bw);
+        for (int64_t q = t.cursor; q < e; q++) {
+            const WtBwLeaf &l = L[q];
+            if (!ops.empty() && ops.back().fd == fd && ops.back().off + ops.back().len == (int64_t) l.offset) ops.back().len += (int64_t) l.size;
+            else ops.push_back(ReadOp{ fd, (int64_t) l.offset, (int64_t) l.size, n_bytes });
+            wtamd_bw_section sc;
+            sc.comp_off = n_bytes; sc.comp_size = (uint32_t) l.size; sc.track = i;
+            sc.leaf_start = l.start_base; sc.leaf_end = l.end_base;
+            secs.push_back(sc);
+            n_bytes += (int64_t) l.size;
+        }
+        k.n_sections = (int32_t) (e - t.cursor);
+        // retire the leaves no later batch can need: every interval finishes below the cut
+        if (hi == INT32_MAX) t.cursor = t.info.count;
+        else while (t.cursor < t.info.count && (int64_t) L[t.cursor].end_base + 1 < (int64_t) hi) t.cursor++;
+        if (t.cursor < t.info.count && (int64_t) L[t.cursor].start_base + 1 < (int64_t) t.clip_hi && hi < t.clip_hi) more = true;
+        else { t.cursor = t.info.count; }       // nothing of this chromosome is left for this track
+    }
+    uint8_t *bytes = nullptr;
+    wtamd_bw_section *tab = nullptr;
+    if (wtamd_pipe_bw_reserve(F.pipe, n_bytes, (int64_t) secs.size(), &bytes, &tab) != WTAMD_OK) die("wtamd_pipe_bw_reserve");
+    if (!secs.empty()) memcpy(tab, secs.data(), sizeof(wtamd_bw_section) * secs.size());
+    const double t_read0 = g_trace ? now_ms() : 0;
+    {
+        const int T = F.io_pool ? F.io_pool->T : 1;
+        bool failed = false;
+        auto work = [&](int w) {
+            for (size_t q = (size_t) w; q < ops.size(); q += (size_t) T) {
+                int64_t done = 0;
+                while (done < ops[q].len) {
+                    const ssize_t got = pread(ops[q].fd, bytes + ops[q].dst + done, (size_t) (ops[q].len - done), (off_t) (ops[q].off + done));
+                    if (got <= 0) { failed = true; break; }
+                    done += got;
+                }
+            }
+        };
+        if (F.io_pool && ops.size() > 1) F.io_pool->run(work); else work(0);
+        if (failed) { fprintf(stderr, "wiggletools_amd: short read of BigWig data sections\n"); exit(1); }
+    }
+    const double t_sub0 = g_trace ? now_ms() : 0;
+    if (wtamd_pipe_submit_bw(F.pipe, n_bytes, (int64_t) secs.size(), tracks.data(), lo, hi) != WTAMD_OK) die("wtamd_pipe_submit_bw");
+    if (g_trace) fprintf(stderr, "[feeder] bw plan %.3f read %.3f submit %.3f -> %.3f  (%lld sections, %lld bytes, [%d, %d))\n", t_drain0, t_read0,
+                         t_sub0, now_ms(), (long long) secs.size(), (long long) n_bytes, lo, hi);
+    Feeder::Flight fl;
+    fl.chrom = F.chrom;
+    F.flights.push_back(std::move(fl));
+    F.continuing = more;
+    F.next_lo = hi;
+    if (more) {
+        // a gap in every track beyond the cut: no run can start inside it, the next batch begins where data does
+        int64_t first = INT32_MAX;
+        for (const auto &t : F.bwt) {
+            if (!t.have || t.cname != F.chrom || t.cursor >= t.info.count) continue;
+            first = std::min<int64_t>(first, (int64_t) wt_bw_leaves(t.r->bw, nullptr)[t.info.first + t.cursor].start_base + 1);
+        }
+        if (first > hi && first < INT32_MAX) F.next_lo = (int32_t) first;
+    }
+    // steer the span towards the byte budget, bounded by the slot's output capacity
+    const int64_t max_span = F.max_runs < ((int64_t) 1 << 31) ? F.max_runs : ((int64_t) 1 << 31);
+    int64_t want = F.span * 2;
+    if (n_bytes > 0) {
+        const double per_bp = (double) n_bytes / (double) std::max<int64_t>((int64_t) hi - lo, 1);
+        const double w = (double) F.bw_target_bytes / per_bp;
+        want = w > 4e9 ? (int64_t) 4e9 : (int64_t) w;
+        if (want > F.span * 8) want = F.span * 8;
+    }
+    if (want < F.min_span) want = F.min_span;
+    F.span = want < max_span ? want : max_span;
+    return true;
 }
 
 // ---------------------------------------------------------------------------
@@ -1505,6 +1779,7 @@ WiggleIterator *wtamd_BigWiggleReader(const char *path, int box) {
     h->r = r;
     r->bw = bw;
     r->box = box;
+    r->p_box = box;
     for (int i = 0; i < wtamd_bw_n_chrom(bw); i++) r->names.push_back(wtamd_bw_chrom_name(bw, i));
     std::sort(r->names.begin(), r->names.end(), [](const std::string &a, const std::string &b) { return strcmp(a.c_str(), b.c_str()) < 0; });
     for (const std::string &n : r->names) r->cnames.push_back(strdup(n.c_str()));

@@ -29,6 +29,11 @@ int wt_map_upload_chains(const wtamd_map_chain *chains, int n_tracks, void **d_o
 int wt_map_chain_async(const void *d_chains, int n_tracks, bool drops, const int64_t *d_seg_in, long long n, const int32_t *start,
                        const int32_t *finish, const void *value, bool value_is_f64, unsigned long long *scratch,
                        int32_t *o_start, int32_t *o_finish, double *o_value, int64_t *d_seg_out, hipStream_t stream);
+long long wt_bw_scratch_bytes(long long n_sec, long long plain_stride);           // wt_bwdev.hip
+int wt_bw_decode_async(const void *h_bytes, void *d_bytes, long long n_bytes, const void *d_comp, const void *d_secs, const void *d_tracks, int n_tracks,
+                       long long n_sec, long long plain_stride, void *scratch, long long capacity, int32_t *o_start, int32_t *o_finish,
+                       float *o_value, int64_t *d_seg_off, unsigned long long *h_status, int copy_blocks, hipStream_t s_copy,
+                       hipEvent_t e_copied, hipStream_t s_dec);
 long long wt_compress_scratch_words(long long capacity);
 int wt_compress_async(const int32_t *start, const int32_t *finish, const double *value, const unsigned long long *d_n,
                       long long capacity, unsigned long long *scratch, int32_t *o_start, int32_t *o_finish, double *o_value,
@@ -175,6 +180,18 @@ struct WtSlot {
     unsigned long long *d_mscratch = nullptr;
     int64_t seg_cap = 0;
     bool direct_pinned = true;      // every direct range of this batch lies in page-locked memory
+    // BigWig sections decoded on device (wtamd_pipe_submit_bw): pinned staging [track table | section table | file
+    // bytes] and its device twin (ONE copy kernel moves all three), decode scratch, status words
+    uint8_t *h_bw = nullptr, *d_bw = nullptr;
+    int64_t h_bw_cap = 0, d_bw_cap = 0;
+    int64_t bw_off_sec = 0, bw_off_bytes = 0;       // layout of the reserved staging
+    int64_t bw_res_bytes = -1, bw_res_secs = -1;     // what wtamd_pipe_bw_reserve was asked for (-1: nothing reserved)
+    void *d_bw_scratch = nullptr;
+    int64_t bw_scratch_cap = 0;
+    unsigned long long *h_bw_status = nullptr;       // pinned: error bits, pieces
+    hipEvent_t e_bwc = nullptr, e_bw0 = nullptr, e_bw1 = nullptr;
+    bool bw = false;                                 // the batch in flight came as file bytes
+    int64_t bw_secs = 0;
 };
 
 struct wtamd_pipe {
@@ -182,7 +199,7 @@ struct wtamd_pipe {
     std::vector<double> defaults;
     std::vector<WtSlot> slots;
     int head = 0, tail = 0, acquired = -1, in_flight = 0, held = 0;
-    hipStream_t s_copy = nullptr, s_comp = nullptr, s_out = nullptr;
+    hipStream_t s_copy = nullptr, s_comp = nullptr, s_out = nullptr, s_dec = nullptr;
     bool delta_failed = false;      // a batch had many inexact windows: Sum / Mean stay on the general kernel
     bool tile = false;
     bool compress = false;          // WTAMD_PIPE_COMPRESS: batches submitted from now on are merged on device before they travel
@@ -215,6 +232,11 @@ static void wt_slot_free(WtSlot &s) {
     if (s.h_ov) (void) hipHostFree(s.h_ov);
     if (s.h_tile) (void) hipHostFree(s.h_tile);
     if (s.h_ip) (void) hipHostFree(s.h_ip);
+    if (s.h_bw) (void) hipHostFree(s.h_bw);
+    if (s.h_bw_status) (void) hipHostFree(s.h_bw_status);
+    (void) hipFree(s.d_bw); (void) hipFree(s.d_bw_scratch);
+    for (hipEvent_t e : {s.e_bwc, s.e_bw0, s.e_bw1})
+        if (e) (void) hipEventDestroy(e);
     if (s.ts) {
         s.ts->d_start = s.ts->d_finish = nullptr; s.ts->d_value = nullptr;      // the slot's, freed above
         wtamd_trackset_destroy(s.ts);
@@ -390,7 +412,9 @@ void wtamd_pipe_destroy(wtamd_pipe *p) {
     if (p->s_copy) (void) hipStreamSynchronize(p->s_copy);
     if (p->s_comp) (void) hipStreamSynchronize(p->s_comp);
     if (p->s_out) (void) hipStreamSynchronize(p->s_out);
+    if (p->s_dec) (void) hipStreamSynchronize(p->s_dec);
     for (auto &s : p->slots) wt_slot_free(s);
+    if (p->s_dec) (void) hipStreamDestroy(p->s_dec);
     if (p->s_copy) (void) hipStreamDestroy(p->s_copy);
     if (p->s_comp) (void) hipStreamDestroy(p->s_comp);
     if (p->s_out) (void) hipStreamDestroy(p->s_out);
@@ -446,12 +470,16 @@ int wtamd_pipe_put_direct(wtamd_pipe *p, int64_t at, int64_t count, const int32_
 int wtamd_pipe_cancel(wtamd_pipe *p) {
     if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_cancel: no acquired slot");
     p->slots[(size_t) p->acquired].direct.clear();
+    p->slots[(size_t) p->acquired].bw_res_bytes = p->slots[(size_t) p->acquired].bw_res_secs = -1;
     p->slots[(size_t) p->acquired].state = 0;
     p->acquired = -1;
     return WTAMD_OK;
 }
 
-static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi);
+// bw_tracks != NULL: the batch came as BigWig file bytes (wtamd_pipe_submit_bw) -- the run lists are produced
+// on the device, the host only knows upper bounds of their sizes and extents.
+static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi,
+                               const wtamd_bw_track *bw_tracks = nullptr, int64_t bw_bytes = 0, int64_t bw_secs = 0);
 
 int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -460,14 +488,95 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
     return rc;
 }
 
-static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi) {
+static int64_t wt_align256(int64_t x) { return (x + 255) & ~(int64_t) 255; }
+
+int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, uint8_t **bytes, wtamd_bw_section **sections) {
+    if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_bw_reserve: no acquired slot");
+    if (n_bytes < 0 || n_sections < 0 || !bytes || !sections) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_bw_reserve: bad arguments");
+    WtSlot &s = p->slots[(size_t) p->acquired];
+    const int N = p->cfg.n_tracks;
+    s.bw_off_sec = wt_align256((int64_t) sizeof(wtamd_bw_track) * N);
+    s.bw_off_bytes = s.bw_off_sec + wt_align256((int64_t) sizeof(wtamd_bw_section) * n_sections);
+    const int64_t need = s.bw_off_bytes + wt_align256(n_bytes + 16);
+    if (s.h_bw_cap < need) {
+        if (s.h_bw) p->dead_host.push_back(s.h_bw);
+        s.h_bw = nullptr; s.h_bw_cap = 0;
+        const int64_t c = need + need / 4;
+        WT_HIP(hipHostMalloc((void **) &s.h_bw, (size_t) c, hipHostMallocDefault));
+        s.h_bw_cap = c;
+    }
+    s.bw_res_bytes = n_bytes; s.bw_res_secs = n_sections;
+    *bytes = s.h_bw + s.bw_off_bytes;
+    *sections = (wtamd_bw_section *) (s.h_bw + s.bw_off_sec);
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_submit_bw(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, const wtamd_bw_track *tracks,
+                         int32_t range_lo, int32_t range_hi) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: no acquired slot");
+    if (!tracks) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: tracks == NULL");
+    const int rc = wt_pipe_submit_impl(p, 0, range_lo, range_hi, tracks, n_bytes, n_sections);
+    p->st.host_submit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+// Host-side bounds of a batch that arrives as file bytes: seg_off[] (piece counts), per-track extents.
+static int wt_pipe_bw_bounds(wtamd_pipe *p, WtSlot &s, const wtamd_bw_track *tk, int64_t n_bytes, int64_t n_secs, int64_t *plain_stride) {
+    const int N = p->cfg.n_tracks;
+    if (s.bw_res_bytes < 0 || n_bytes > s.bw_res_bytes || n_secs > s.bw_res_secs || n_bytes < 0 || n_secs < 0)
+        return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: more bytes / sections than reserved");
+    if (p->tile) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: not available for the Multiplexer tile");
+    const wtamd_bw_section *sec = (const wtamd_bw_section *) (s.h_bw + s.bw_off_sec);
+    int64_t at = 0, next_sec = 0, stride = 64;
+    for (int i = 0; i < N; i++) {
+        const wtamd_bw_track &t = tk[i];
+        if (t.first_section != next_sec || t.n_sections < 0 || (int64_t) t.first_section + t.n_sections > n_secs)
+            return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: sections must be listed track by track");
+        s.h_seg[i] = at;
+        int32_t fs = 0, lf = 0;
+        for (int64_t q = t.first_section; q < (int64_t) t.first_section + t.n_sections; q++) {
+            const wtamd_bw_section &c = sec[q];
+            if (c.track != i || c.comp_off < 0 || c.comp_off + (int64_t) c.comp_size > n_bytes || c.leaf_end < c.leaf_start)
+                return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: bad section entry");
+            if (q > t.first_section && c.leaf_start < sec[q - 1].leaf_end)
+                return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: a track's sections must be sorted and disjoint");
+            if (!t.compressed && c.comp_size > t.plain_bytes) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: raw section larger than plain_bytes");
+            at += wt_bw_section_bound(t.plain_bytes, c.leaf_start, c.leaf_end, t.box);
+        }
+        if (t.n_sections > 0) {
+            const int64_t a = (int64_t) sec[t.first_section].leaf_start + 1, b = (int64_t) sec[t.first_section + t.n_sections - 1].leaf_end + 1;
+            fs = (int32_t) std::max<int64_t>(a, t.clip_lo);
+            lf = (int32_t) std::min<int64_t>(std::min<int64_t>(b, t.clip_hi), INT32_MAX);
+            if (lf <= fs) lf = fs + 1;
+            if ((int64_t) t.plain_bytes + 16 > stride) stride = (int64_t) t.plain_bytes + 16;
+        }
+        s.ts->first_start[(size_t) i] = fs;
+        s.ts->last_finish[(size_t) i] = lf;
+        next_sec += t.n_sections;
+    }
+    if (next_sec != n_secs) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: section count does not match the tracks");
+    s.h_seg[N] = at;
+    *plain_stride = (stride + 15) & ~(int64_t) 15;
+    return WTAMD_OK;
+}
+
+static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi,
+                               const wtamd_bw_track *bw_tracks, int64_t bw_bytes, int64_t bw_secs) {
     if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: no acquired slot");
     WtSlot &s = p->slots[(size_t) p->acquired];
     const int N = p->cfg.n_tracks;
+    const bool bw = bw_tracks != nullptr;
+    int64_t bw_stride = 0;
+    if (bw) {
+        if (!s.direct.empty()) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: the slot holds direct ranges");
+        const int rcb = wt_pipe_bw_bounds(p, s, bw_tracks, bw_bytes, bw_secs, &bw_stride);
+        if (rcb != WTAMD_OK) return rcb;
+    }
     const int64_t n = s.h_seg[N];
     if (s.h_seg[0] != 0 || n < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: bad seg_off");
     // staged ranges = [0, n) minus the direct ranges; they must lie inside the staging arrays
-    {
+    if (!bw) {
         int64_t staged_end = 0, pos = 0;
         for (const auto &d : s.direct) {
             if (d.at + d.count > n) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: a direct range lies beyond seg_off[n_tracks]");
@@ -544,7 +653,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     // rebind the slot's track set to this batch
     ts->n_intervals = n;
     ts->seg_off.assign(s.h_seg, s.h_seg + N + 1);
-    {
+    if (!bw) {
         // entry g of the batch: in the staging arrays or in a direct range
         auto start_at = [&](int64_t g) -> int32_t {
             size_t lo = 0, hi = s.direct.size();
@@ -581,8 +690,44 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
 
     // copy stream: pinned staging -> HBM
     WT_HIP(hipEventRecord(s.e_h0, p->s_copy));
+    s.bw = bw;
+    if (bw) {
+        // file bytes + tables: one copy kernel; inflate / count / scan / scatter on the decode stream write the
+        // run lists and the device-side seg_off[] (the authority downstream: the host's are upper bounds)
+        if (!p->s_dec) WT_HIP(hipStreamCreateWithFlags(&p->s_dec, hipStreamNonBlocking));
+        if (!s.e_bwc) { WT_HIP(hipEventCreate(&s.e_bwc)); WT_HIP(hipEventCreate(&s.e_bw0)); WT_HIP(hipEventCreate(&s.e_bw1)); }
+        if (!s.h_bw_status) WT_HIP(hipHostMalloc((void **) &s.h_bw_status, 64, hipHostMallocDefault));
+        const int64_t total = s.bw_off_bytes + wt_align256(bw_bytes + 16);
+        if (s.d_bw_cap < total) {
+            if (s.d_bw) p->dead_dev.push_back(s.d_bw);
+            s.d_bw = nullptr; s.d_bw_cap = 0;
+            const int64_t c = total + total / 4;
+            WT_HIP(hipMalloc((void **) &s.d_bw, (size_t) c));
+            s.d_bw_cap = c;
+        }
+        const int64_t need_scr = wt_bw_scratch_bytes(bw_secs, bw_stride);
+        if (s.bw_scratch_cap < need_scr) {
+            if (s.d_bw_scratch) p->dead_dev.push_back(s.d_bw_scratch);
+            s.d_bw_scratch = nullptr; s.bw_scratch_cap = 0;
+            const int64_t c = need_scr + need_scr / 4;
+            WT_HIP(hipMalloc(&s.d_bw_scratch, (size_t) c));
+            s.bw_scratch_cap = c;
+        }
+        memcpy(s.h_bw, bw_tracks, sizeof(wtamd_bw_track) * (size_t) N);
+        s.h_bw_status[0] = ~0ull; s.h_bw_status[1] = 0;
+        WT_HIP(hipEventRecord(s.e_bw0, p->s_dec));
+        rc = wt_bw_decode_async(s.h_bw, s.d_bw, total, s.d_bw + s.bw_off_bytes, s.d_bw + s.bw_off_sec, s.d_bw, N, bw_secs, bw_stride, s.d_bw_scratch,
+                                (long long) s.dcap, s.d_start, s.d_finish, (float *) s.d_value, compacted ? s.d_mseg : ts->d_seg_off,
+                                s.h_bw_status, p->gather_blocks, p->s_copy, s.e_bwc, p->s_dec);
+        if (rc != WTAMD_OK) return rc;
+        WT_HIP(hipEventRecord(s.e_bw1, p->s_dec));
+        s.bw_secs = bw_secs;
+        s.bw_res_bytes = s.bw_res_secs = -1;
+    } else {
     WT_HIP(hipMemcpyAsync(compacted ? s.d_mseg : ts->d_seg_off, s.h_seg, sizeof(int64_t) * ((size_t) N + 1), hipMemcpyHostToDevice, p->s_copy));
-    if (n > 0 && p->gather && !f64 && !s.direct.empty() && s.direct_pinned && 2 * (int64_t) s.direct.size() + 1 <= WT_GATHER_MAX_SEGS) {
+    }
+    if (bw) {
+    } else if (n > 0 && p->gather && !f64 && !s.direct.empty() && s.direct_pinned && 2 * (int64_t) s.direct.size() + 1 <= WT_GATHER_MAX_SEGS) {
         // one table, one small copy, one kernel for the whole batch
         const int64_t max_segs = 2 * (int64_t) s.direct.size() + 1;
         if (s.seg_cap < max_segs) {
@@ -639,8 +784,8 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
         if (rc != WTAMD_OK) return rc;
     }
     s.direct.clear();
-    WT_HIP(hipEventRecord(s.e_h1, p->s_copy));
-    p->st.h2d_bytes += (int64_t) sizeof(int64_t) * (N + 1) + n * (f64 ? 16 : 12);
+    WT_HIP(hipEventRecord(s.e_h1, bw ? p->s_dec : p->s_copy));    // (file bytes: the run lists exist once the decode stream is through)
+    p->st.h2d_bytes += bw ? s.bw_off_bytes + bw_bytes : (int64_t) sizeof(int64_t) * (N + 1) + n * (f64 ? 16 : 12);
 
     // compute stream: window index + fused multiplex / reduce, then the counters travel back
     WT_HIP(hipStreamWaitEvent(p->s_comp, s.e_h1, 0));
@@ -688,7 +833,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     p->head = (p->head + 1) % (int) p->slots.size();
     p->in_flight++;
     p->st.batches++;
-    p->st.intervals += n;
+    if (!bw) p->st.intervals += n;      // (file-byte batches: counted when collected, the device knows)
     if (s.used_delta) p->st.delta_batches++;
     return WTAMD_OK;
 }
@@ -705,6 +850,26 @@ int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
     p->in_flight--;
     p->held = 1;
     if (rc != WTAMD_OK) return rc;
+    if (s.bw) {
+        const unsigned long long e = s.h_bw_status[0];
+        if (e) {
+            std::string why = "BigWig sections could not be decoded on the device:";
+            if (e == ~0ull) why += " decode kernels did not report";
+            else {
+                if (e & WT_BW_ERR_INFLATE) why += " corrupt zlib stream;";
+                if (e & WT_BW_ERR_SECTION) why += " malformed section;";
+                if (e & WT_BW_ERR_EXTENT) why += " items outside their index leaf / out of order (WTAMD_BW_DEVICE=0 selects the host decoder);";
+                if (e & WT_BW_ERR_COORD) why += " coordinate above the supported maximum;";
+                if (e & WT_BW_ERR_CAPACITY) why += " more intervals than the host's bound;";
+            }
+            return wt_fail(WTAMD_ERR_INTERNAL, why);
+        }
+        s.n_int = (int64_t) s.h_bw_status[1];
+        p->st.intervals += s.n_int;
+        p->st.bw_sections += s.bw_secs;
+        float msb = 0;
+        if (hipEventElapsedTime(&msb, s.e_bw0, s.e_bw1) == hipSuccess) p->st.bw_decode_ms += msb;
+    }
     rc = wt_pipe_finish(p, s);
     if (rc != WTAMD_OK) return rc;
     p->st.host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wait0).count();

@@ -40,6 +40,8 @@ def _bind():
                                             C.POINTER(C.c_void_p)]
     L.wtamd_drain.restype = C.c_int64
     L.wtamd_drain.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    L.seek.restype = None
+    L.seek.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int]
     L._wt_dropin_bound = True
     return L
 
@@ -95,6 +97,11 @@ def reducer(op, iters, n_set0=0, strict=False):
 
 
 _KEEP = []
+
+
+def seek(wi, chrom, start, finish):
+    """The reference's seek() (wiggleIterator.c:67-70): restricts an iterator to chrom:[start, finish)."""
+    _bind().seek(wi, chrom.encode(), int(start), int(finish))
 
 
 def drain_blocks(wi, on_block=None):

@@ -36,7 +36,8 @@ class PipeStats(C.Structure):
     _fields_ = [("batches", C.c_int64), ("intervals", C.c_int64), ("runs", C.c_int64), ("covered_bp", C.c_int64),
                 ("h2d_bytes", C.c_int64), ("d2h_bytes", C.c_int64), ("kernel_ms", C.c_double), ("h2d_ms", C.c_double),
                 ("d2h_ms", C.c_double), ("delta_batches", C.c_int32), ("n_slots", C.c_int32),
-                ("host_submit_ms", C.c_double), ("host_wait_ms", C.c_double)]
+                ("host_submit_ms", C.c_double), ("host_wait_ms", C.c_double),
+                ("bw_sections", C.c_int64), ("bw_decode_ms", C.c_double)]
 
 
 def _view(ptr, n, dtype):
