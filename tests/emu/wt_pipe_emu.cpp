@@ -297,14 +297,14 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
 // One zlib (or raw deflate) stream through the lane state machine; returns bytes produced or -(error).
 long long wtemu_inflate(const uint8_t *src, long long n, uint8_t *dst, long long cap, int raw_deflate) {
     std::vector<uint16_t> perm(WT_INF_PERM), aux(WT_INF_AUX);
-    std::vector<uint8_t> ring(WT_INF_RING);
+    std::vector<uint32_t> ring(WT_INF_RING);
     WtInfMem m{perm.data(), aux.data(), ring.data(), 1};
-    // the decoder reads whole aligned words around the stream and writes whole words: private padded copies
-    std::vector<uint8_t> in((size_t) n + 16, 0), out(((size_t) cap + 3) / 4 * 4 + 8, 0);
-    const int mis = (int) (n % 4);              // any alignment must work
-    if (n > 0) memcpy(in.data() + 4 + mis, src, (size_t) n);
+    // the decoder reads whole aligned 16-byte chunks around the stream and writes whole words: private padded copies
+    std::vector<uint8_t> in((size_t) n + 96, 0), out(((size_t) cap + 3) / 4 * 4 + 8, 0);
+    const int mis = (int) (n % 16);             // any alignment must work
+    if (n > 0) memcpy(in.data() + 32 + mis, src, (size_t) n);
     WtInflate z;
-    wt_inf_begin(z, in.data() + 4 + mis, (uint32_t) n, out.data(), (uint32_t) cap, raw_deflate != 0);
+    wt_inf_begin(z, in.data() + 32 + mis, (uint32_t) n, out.data(), (uint32_t) cap, raw_deflate != 0);
     while (wt_inf_step(z, m)) { }
     const long long r = (long long) wt_inf_finish(z);
     if (r > 0) memcpy(dst, out.data(), (size_t) r);

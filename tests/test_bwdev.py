@@ -237,15 +237,27 @@ def test_device_decode_seek_gpu(amd_lib, oracle, tmp_path, monkeypatch):
     _seek_cases(amd_lib, oracle, tmp_path, monkeypatch)
 
 
+def _one_track(t, L):
+    """A dense synthetic track (1-based runs): mean run 16 bp, 2 % gaps, values k/8."""
+    rng = np.random.default_rng(100 + t)
+    n = L // 12
+    ln = rng.geometric(1 / 16.0, n).astype(np.int64)
+    gap = (rng.random(n) < 0.02) * rng.integers(1, 200, n)
+    f = np.cumsum(ln + gap)
+    s = f - ln
+    keep = f < L
+    return (s[keep] + 1).astype(np.int32), (f[keep] + 1).astype(np.int32), (rng.integers(0, 800, n)[keep] / 8).astype(np.float32)
+
+
 @pytest.mark.gpu
 def test_device_decode_larger_files_gpu(amd_lib, oracle, tmp_path, monkeypatch):
     """Bench-style files (wiggletools_amd/bwwrite.py: 1024-item bedGraph sections, zlib level 1), 12 tracks x 3 Mbp:
     thousands of sections per batch through the lane-per-section inflate; == host decoder run for run."""
-    from wiggletools_amd import bwwrite, synthgen
+    from wiggletools_amd import bwwrite
     n_tracks, L = 12, 3_000_000
     paths = []
     for t in range(n_tracks):
-        s, f, v = synthgen.track("chr1", 0, t, L, mean_run=16.0, seed=7)
+        s, f, v = _one_track(t, L)
         p = str(tmp_path / ("big%d.bw" % t))
         bwwrite.write_arrays(p, {"chr1": L + 10}, {"chr1": (s - 1, f - 1, v)})
         paths.append(p)

@@ -52,14 +52,15 @@ __global__ void __launch_bounds__(WT_BW_INF_LANES) wt_bw_inflate_kernel(const Wt
                                                                          int32_t *plain_len) {
     __shared__ uint16_t s_perm[WT_INF_PERM * WT_BW_INF_LANES];
     __shared__ uint16_t s_aux[WT_INF_AUX * WT_BW_INF_LANES];
-    __shared__ uint8_t s_ring[WT_INF_RING * WT_BW_INF_LANES];
+    __shared__ uint32_t s_ring[WT_INF_RING * WT_BW_INF_LANES];
     const int lane = threadIdx.x;
     const int i = blockIdx.x * WT_BW_INF_LANES + lane;
     if (i >= n_sec) return;
     const WtBwSection sc = secs[i];
     const bool compressed = tracks[sc.track].compressed != 0;
     WtInfMem m;
-    m.perm = s_perm + lane; m.aux = s_aux + lane; m.ring = s_ring + lane; m.stride = WT_BW_INF_LANES;
+    m.perm = (WT_AS_LDS uint16_t *) (s_perm + lane); m.aux = (WT_AS_LDS uint16_t *) (s_aux + lane);
+    m.ring = (WT_AS_LDS uint32_t *) (s_ring + lane); m.stride = WT_BW_INF_LANES;
     WtInflate z;
     wt_inf_begin(z, comp + sc.comp_off, sc.comp_size, plain + (size_t) i * plain_stride, plain_stride, false);
     if (!compressed) {          // an uncompressed file: the section bytes are copied (a stored block in disguise)

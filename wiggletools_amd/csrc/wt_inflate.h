@@ -11,13 +11,17 @@
 //     count[k] symbols of length k the left-aligned 15-bit window w of the stream has length
 //         len = 1 + #{ k in 1..14 : w >= lim[k] },   lim[k] = (first[k] + count[k]) << (15 - k)
 //     and the symbol is perm[adj[len] + (w >> (15 - len))].  The 2 x 15 limits live in REGISTERS
-//     (statically indexed arrays), `adj` (16 entries) and `perm` (the symbols sorted by code) in
-//     LDS -- 2 dependent LDS reads per symbol, 704 bytes of LDS per lane.
+//     and 2 x 15 adj values live in REGISTERS
+//     (statically indexed arrays), `perm` (the symbols sorted by code) in LDS -- ONE dependent LDS read
+//     per symbol, 768 bytes of LDS per lane.
 //   * the code lengths of a dynamic block are parked in the unused top 4 bits of perm[] while
 //     the table is built in place; the 19-symbol code-length code lives in two 64-bit registers.
-//   * LZ77 history: the last 64 output bytes of every lane are kept in an LDS ring; matches with a
-//     distance <= 64 (the bulk of them in 12-byte record data) never touch global memory, longer
-//     ones read the lane's own earlier output back.  Output is gathered to dwords in a register.
+//   * LZ77 history: the last 16 output DWORDS of every lane are kept in an LDS ring; a match with a
+//     distance <= 60 (the bulk of them in 12-byte record data) reads three of them -- one LDS round
+//     trip for up to 8 bytes -- and never touches global memory; longer ones read the lane's own
+//     earlier output back.  Output is gathered to dwords in a register and stored whole.
+//   * the input is prefetched 16 bytes (~16 symbols) ahead into registers: the loop never waits for
+//     a load it has just issued;
 //   * one state machine step per loop iteration, a match copies at most WT_INF_COPY bytes per
 //     iteration, so a lane inside a 258-byte match does not stall the 63 others.
 //
@@ -41,14 +45,34 @@
 #endif
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Explicit address spaces: with generic pointers hipcc folded "ring byte or far byte" into ONE flat_load per
+// byte followed by s_waitcnt vmcnt(0) lgkmcnt(0) -- every copied byte waited for every outstanding store.
+#define WT_AS_GLOBAL __attribute__((address_space(1)))
+#define WT_AS_LDS __attribute__((address_space(3)))
+#else
+#define WT_AS_GLOBAL
+#define WT_AS_LDS
+#endif
+
+// hipcc rewrites a chain `a = c_k ? t[k + 1] : a` over a statically indexed table into ONE variable-index load
+// t[len] -- and a variable index keeps the whole decoder state in scratch memory.  An empty asm on the running
+// value hides the chain from that rewrite (no instruction is emitted).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WT_INF_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define WT_INF_OPAQUE(x) (void) 0
+#endif
+
 #define WT_INF_PERM 320         // [0, 288) literal / length symbols, [288, 320) distance symbols
 #define WT_INF_DBASE 288
-#define WT_INF_AUX 32           // [0, 16) literal / length adj (or counters), [16, 32) distance
-#define WT_INF_RING 64
-#define WT_INF_COPY 4           // match bytes copied per state machine step
+#define WT_INF_AUX 32           // table construction scratch: counters / cursors, the code-length code's symbols
+#define WT_INF_RING 16          // dwords of LZ77 history per lane (the current partial dword included)
+#define WT_INF_RING_DIST 60     // matches up to this distance are served from the ring
+#define WT_INF_COPY 8           // match bytes copied per state machine step
 
 // bytes of "LDS" one lane needs
-#define WT_INF_LANE_BYTES (WT_INF_PERM * 2 + WT_INF_AUX * 2 + WT_INF_RING)
+#define WT_INF_LANE_BYTES (WT_INF_PERM * 2 + WT_INF_AUX * 2 + WT_INF_RING * 4)
 
 enum {
     WT_INF_OK = 0,
@@ -64,31 +88,36 @@ enum {
 enum { WT_INF_ST_ZHDR = 0, WT_INF_ST_BLOCK = 1, WT_INF_ST_SYM = 2, WT_INF_ST_STORED = 3, WT_INF_ST_DONE = 4, WT_INF_ST_ERR = 5 };
 
 struct WtInfMem {
-    uint16_t *perm;     // WT_INF_PERM entries
-    uint16_t *aux;      // WT_INF_AUX entries
-    uint8_t *ring;      // WT_INF_RING bytes
-    int stride;         // elements between consecutive entries of this lane
+    WT_AS_LDS uint16_t *perm;   // WT_INF_PERM entries
+    WT_AS_LDS uint16_t *aux;    // WT_INF_AUX entries
+    WT_AS_LDS uint32_t *ring;   // WT_INF_RING dwords
+    int stride;                 // elements between consecutive entries of this lane
 };
 
+struct WtInfQuad { uint32_t x, y, z, w; };
+
 struct WtInflate {
-    // input: 32-bit words at 4-byte aligned addresses
-    const uint32_t *in_w;       // aligned base
-    uint32_t in_next;           // next word to fetch
-    uint32_t in_words;          // words that may be read
-    uint32_t nw;                // prefetched word in_w[in_next - 1 + ...] (see wt_inf_fetch)
+    // input: 16-byte chunks at 16-byte aligned addresses; `cur` is being consumed, `nxt` is in flight
+    const WT_AS_GLOBAL uint32_t *in_w;  // aligned base
+    uint32_t in_chunk;          // next chunk to fetch
+    uint32_t in_chunks;         // chunks that may be read
+    WtInfQuad cur, nxt;
+    uint32_t qi;                // words of `cur` already taken (the queue is shifted, cur.x is the next one)
+    bool nxt_empty;             // `nxt` was moved into `cur` and its successor has not arrived yet
     uint64_t bb;                // bit buffer, LSB first
     int32_t bc;                 // valid bits in bb
     int64_t bits_left;          // bits of the stream not yet consumed (underflow = truncated input)
     // output
-    uint8_t *out;               // 4-byte aligned
+    WT_AS_GLOBAL uint32_t *out; // 4-byte aligned
     uint32_t out_pos, out_cap;
-    uint32_t acc;               // bytes of the current output dword
+    uint32_t acc;               // bytes of the current (partial) output dword
     // state
     int32_t st, err;
     uint32_t copy_rem, copy_dist;
     uint32_t stored_rem;
     bool last, raw;             // last block seen; raw deflate (no zlib wrapper)
     uint32_t llim[16], dlim[16];    // [1..15] used
+    int32_t ladj[16], dadj[16];
 };
 
 WT_HD uint32_t wt_inf_bitrev15(uint32_t x) {
@@ -101,41 +130,67 @@ WT_HD uint32_t wt_inf_bitrev15(uint32_t x) {
 #endif
 }
 
-WT_HD uint32_t wt_inf_load(const WtInflate &z, uint32_t i) { return i < z.in_words ? z.in_w[i] : 0u; }
+// Chunk i of the input (past the end: the last chunk again -- whatever bits a lane decodes from there, it has
+// over-read: bits_left < 0 fails the stream).  UNCONDITIONAL on purpose: a load under a branch is merged with the
+// "no load" value by a register copy, and the copy waits for the load right where it was issued.
+WT_HD WtInfQuad wt_inf_load(const WtInflate &z, uint32_t i) {
+    const uint32_t last = z.in_chunks ? z.in_chunks - 1u : 0u;
+    const WT_AS_GLOBAL uint32_t *p = z.in_w + 4 * (size_t) (i < last ? i : last);
+    WtInfQuad q;
+    q.x = p[0]; q.y = p[1]; q.z = p[2]; q.w = p[3];
+    return q;
+}
 
-// Starts a stream of `n_bytes` at `src` (any alignment; up to 3 bytes before and 3 after it, inside
-// the same allocation, are read and ignored) writing at most `cap` bytes to `dst` (4-byte aligned, cap
-// rounded up to a multiple of 4 must be writable).
+// The next 32 bits of the stream.  `nxt` was requested when `cur` became current: by the time it is needed the
+// 4 words of `cur` (~16 symbols) have been decoded.
+// (The queue is SHIFTED, never indexed: one variable index into the state struct and hipcc keeps the whole
+// struct in scratch memory.)  `nxt` is refilled by wt_inf_step's prefetch one step after it was moved into `cur`;
+// the blocking load here serves the block-header code, which reads many words inside one step.
+WT_HD uint32_t wt_inf_word(WtInflate &z) {
+    const uint32_t w = z.cur.x;
+    z.cur.x = z.cur.y; z.cur.y = z.cur.z; z.cur.z = z.cur.w;
+    z.qi++;
+    if (z.qi == 4) {
+        if (z.nxt_empty) { z.nxt = wt_inf_load(z, z.in_chunk); z.in_chunk++; }
+        z.cur = z.nxt;
+        z.qi = 0;
+        z.nxt_empty = true;
+    }
+    return w;
+}
+
+// Starts a stream of `n_bytes` at `src` (any alignment; the 16-byte aligned chunks around it must be readable
+// inside the same allocation -- up to 15 bytes before and 31 after) writing at most `cap` bytes to `dst` (4-byte
+// aligned, cap rounded up to a multiple of 4 must be writable).
 WT_HD void wt_inf_begin(WtInflate &z, const uint8_t *src, uint32_t n_bytes, uint8_t *dst, uint32_t cap, bool raw_deflate) {
     const uintptr_t a = (uintptr_t) src;
-    const uint32_t mis = (uint32_t) (a & 3u);
-    z.in_w = (const uint32_t *) (a - mis);
-    z.in_words = (mis + n_bytes + 3u) >> 2;
+    const uint32_t mis = (uint32_t) (a & 15u);
+    z.in_w = (const WT_AS_GLOBAL uint32_t *) (a - mis);
+    z.in_chunks = (mis + n_bytes + 15u) >> 4;
     z.bits_left = (int64_t) n_bytes * 8;
-    z.bb = 0; z.bc = 0;
-    z.in_next = 0;
-    if (z.in_words > 0) {
-        z.bb = (uint64_t) (z.in_w[0] >> (8 * mis));
-        z.bc = 32 - 8 * (int32_t) mis;
-        z.in_next = 1;
-    }
-    z.nw = wt_inf_load(z, z.in_next);
-    z.out = dst; z.out_pos = 0; z.out_cap = cap; z.acc = 0;
+    z.cur = wt_inf_load(z, 0);
+    z.nxt = wt_inf_load(z, 1);
+    z.in_chunk = 2;
+    z.qi = 0;
+    z.nxt_empty = false;
+    for (uint32_t k = 0; k < (mis >> 2); k++) (void) wt_inf_word(z);       // whole words before the stream are skipped
+    const uint32_t w0 = wt_inf_word(z);
+    z.bb = (uint64_t) (w0 >> (8 * (mis & 3u)));
+    z.bc = 32 - 8 * (int32_t) (mis & 3u);
+    z.out = (WT_AS_GLOBAL uint32_t *) dst; z.out_pos = 0; z.out_cap = cap; z.acc = 0;
     z.st = raw_deflate ? WT_INF_ST_BLOCK : WT_INF_ST_ZHDR;
     z.err = WT_INF_OK;
     z.copy_rem = z.copy_dist = 0; z.stored_rem = 0;
     z.last = false; z.raw = raw_deflate;
 #pragma unroll
-    for (int k = 0; k < 16; k++) { z.llim[k] = 0; z.dlim[k] = 0; }
+    for (int k = 0; k < 16; k++) { z.llim[k] = 0; z.dlim[k] = 0; z.ladj[k] = 0; z.dadj[k] = 0; }
 }
 
-// After this bc >= 33 (or the input is exhausted: zero bits follow, bits_left catches over-reads).
+// After this bc >= 33 (past the end of the input zero bits follow; bits_left catches over-reads).
 WT_HD void wt_inf_refill(WtInflate &z) {
     if (z.bc <= 32) {
-        z.bb |= (uint64_t) z.nw << z.bc;
+        z.bb |= (uint64_t) wt_inf_word(z) << z.bc;
         z.bc += 32;
-        z.in_next++;
-        z.nw = wt_inf_load(z, z.in_next);      // consumed at the next refill: its latency hides behind the decode
     }
 }
 
@@ -147,38 +202,44 @@ WT_HD uint32_t wt_inf_bits(WtInflate &z, int n) {      // n <= 32, after a refil
 
 WT_HD void wt_inf_fail(WtInflate &z, int code) { z.st = WT_INF_ST_ERR; z.err = code; z.copy_rem = 0; }
 
-// One Huffman symbol.  lim[1..15] registers, adj / perm in lane memory.  Returns -1 on a pattern no
-// code word matches.
-WT_HD int wt_inf_decode(WtInflate &z, const uint32_t (&lim)[16], const uint16_t *adj, const uint16_t *perm, int stride) {
+// One Huffman symbol.  lim[1..15] / adj[1..15] registers, perm in lane memory: ONE dependent LDS read.
+// Returns -1 on a pattern no code word matches.
+WT_HD int wt_inf_decode(WtInflate &z, const uint32_t (&lim)[16], const int32_t (&adj)[16], const WT_AS_LDS uint16_t *perm, int stride) {
     const uint32_t w = wt_inf_bitrev15((uint32_t) z.bb & 0x7FFFu);
     int len = 1;
+    int32_t a = adj[1];
 #pragma unroll
-    for (int k = 1; k <= 14; k++) len += (w >= lim[k]) ? 1 : 0;
+    for (int k = 1; k <= 14; k++) {
+        const bool ge = w >= lim[k];
+        len += ge ? 1 : 0;
+        a = ge ? adj[k + 1] : a;
+        WT_INF_OPAQUE(a);
+    }
     if (w >= lim[15]) return -1;
-    const int32_t a = (int32_t) (int16_t) adj[len * stride];
     const int32_t idx = a + (int32_t) (w >> (15 - len));
     z.bb >>= len; z.bc -= len; z.bits_left -= len;
     return (int) (perm[idx * stride] & 0x1FFu);
 }
 
-// Canonical table of the `n` symbols whose lengths sit in the top 4 bits of perm[0..n): fills lim[],
-// adj[] (16 entries) and the low 9 bits of perm[].  False: over-subscribed.
-WT_HD bool wt_inf_build(uint32_t (&lim)[16], uint16_t *adj, uint16_t *perm, int n, int stride) {
+// Canonical table of the `n` symbols whose lengths sit in the top 4 bits of perm[0..n): fills lim[], adj[] and
+// the low 9 bits of perm[]; `cnt` = 16 entries of scratch.  False: over-subscribed.
+WT_HD bool wt_inf_build(uint32_t (&lim)[16], int32_t (&adj)[16], WT_AS_LDS uint16_t *cnt, WT_AS_LDS uint16_t *perm, int n, int stride) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) adj[k * stride] = 0;
+    for (int k = 0; k < 16; k++) cnt[k * stride] = 0;
     for (int s = 0; s < n; s++) {
         const int l = perm[s * stride] >> 12;
-        adj[l * stride] = (uint16_t) (adj[l * stride] + 1);
+        cnt[l * stride] = (uint16_t) (cnt[l * stride] + 1);
     }
     uint32_t code = 0, off = 0;
     bool ok = true;
-    lim[0] = 0;
+    lim[0] = 0; adj[0] = 0;
 #pragma unroll
     for (int k = 1; k <= 15; k++) {
-        const uint32_t c = adj[k * stride];
+        const uint32_t c = cnt[k * stride];
         if (code + c > (1u << k)) ok = false;
         lim[k] = (code + c) << (15 - k);
-        adj[k * stride] = (uint16_t) off;           // insertion cursor of length k
+        adj[k] = (int32_t) off - (int32_t) code;    // (symbols shorter than k) - first code of length k
+        cnt[k * stride] = (uint16_t) off;           // insertion cursor of length k
         off += c;
         code = (code + c) << 1;
     }
@@ -186,31 +247,39 @@ WT_HD bool wt_inf_build(uint32_t (&lim)[16], uint16_t *adj, uint16_t *perm, int 
     for (int s = 0; s < n; s++) {
         const int l = perm[s * stride] >> 12;
         if (l) {
-            const uint32_t j = adj[l * stride];
-            adj[l * stride] = (uint16_t) (j + 1);
+            const uint32_t j = cnt[l * stride];
+            cnt[l * stride] = (uint16_t) (j + 1);
             perm[j * stride] = (uint16_t) ((perm[j * stride] & 0xF000u) | (uint32_t) s);
         }
-    }
-    // cursors -> adj[k] = (symbols shorter than k) - first code of length k
-    uint32_t prev_off = 0;
-#pragma unroll
-    for (int k = 1; k <= 15; k++) {
-        const uint32_t next = adj[k * stride];
-        const uint32_t first = (k == 1) ? 0u : (lim[k - 1] >> (15 - k));
-        adj[k * stride] = (uint16_t) (int16_t) ((int32_t) prev_off - (int32_t) first);
-        prev_off = next;
     }
     return true;
 }
 
-WT_HD void wt_inf_emit(WtInflate &z, const WtInfMem &m, uint32_t b) {
-    m.ring[(z.out_pos & (WT_INF_RING - 1)) * m.stride] = (uint8_t) b;
-    z.acc |= b << (8 * (z.out_pos & 3u));
-    z.out_pos++;
-    if ((z.out_pos & 3u) == 0) {
-        *(uint32_t *) (z.out + z.out_pos - 4) = z.acc;
-        z.acc = 0;
+// Appends the low n (1..8) bytes of `bytes` to the output: full dwords go to global memory and to the ring,
+// the partial one stays in `acc` (and in the ring, where matches look for it).
+WT_HD void wt_inf_put(WtInflate &z, const WtInfMem &m, uint64_t bytes, uint32_t n) {
+    if (n < 8) bytes &= (1ull << (8 * n)) - 1ull;
+    const uint32_t sh = (z.out_pos & 3u) * 8u;
+    const uint32_t d = z.out_pos >> 2;
+    const uint32_t e0 = z.acc | (uint32_t) (bytes << sh);
+    const uint64_t t = bytes >> (32u - sh);
+    const uint32_t e1 = (uint32_t) t, e2 = (uint32_t) (t >> 32);
+    const uint32_t total = (z.out_pos & 3u) + n;
+    const uint32_t full = total >> 2;
+    uint32_t acc = e0;
+    if (full >= 1) {
+        z.out[d] = e0;
+        m.ring[(d & (WT_INF_RING - 1)) * m.stride] = e0;
+        acc = e1;
+        if (full >= 2) {
+            z.out[d + 1] = e1;
+            m.ring[((d + 1) & (WT_INF_RING - 1)) * m.stride] = e1;
+            acc = e2;
+        }
     }
+    z.acc = acc;
+    z.out_pos += n;
+    m.ring[((z.out_pos >> 2) & (WT_INF_RING - 1)) * m.stride] = acc;
 }
 
 // Block header (RFC 1951 3.2.3 - 3.2.7): sets up the tables of a fixed / dynamic block or the byte
@@ -271,7 +340,7 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
             }
             if (!ok) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
         }
-        // its symbols sorted by code: aux[0..18] (the block's own adj[] is built afterwards)
+        // its symbols sorted by code: aux[0..18]
 #pragma unroll
         for (int s = 0; s < 19; s++) {
             const int l = (int) ((cl >> (3 * s)) & 7u);
@@ -288,12 +357,15 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
             wt_inf_refill(z);
             const uint32_t w7 = wt_inf_bitrev15((uint32_t) z.bb & 0x7Fu) >> 8;     // 7-bit window, first bit on top
             int len = 1;
+            int32_t a = cadj[1];
 #pragma unroll
-            for (int k = 1; k <= 6; k++) len += (w7 >= clim[k]) ? 1 : 0;
+            for (int k = 1; k <= 6; k++) {
+                const bool ge = w7 >= clim[k];
+                len += ge ? 1 : 0;
+                a = ge ? cadj[k + 1] : a;
+                WT_INF_OPAQUE(a);
+            }
             if (w7 >= clim[7]) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return; }
-            int32_t a = 0;
-#pragma unroll
-            for (int k = 1; k <= 7; k++) a = (len == k) ? cadj[k] : a;
             const uint32_t sym = m.aux[(a + (int32_t) (w7 >> (7 - len))) * S];
             z.bb >>= len; z.bc -= len; z.bits_left -= len;
             uint32_t rep = 1, val = sym;
@@ -314,36 +386,66 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
         }
         if ((m.perm[256 * S] >> 12) == 0) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }    // no end-of-block code
     }
-    if (!wt_inf_build(z.llim, m.aux, m.perm, 288, S) ||
-        !wt_inf_build(z.dlim, m.aux + 16 * S, m.perm + WT_INF_DBASE * S, 32, S)) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
+    if (!wt_inf_build(z.llim, z.ladj, m.aux, m.perm, 288, S) ||
+        !wt_inf_build(z.dlim, z.dadj, m.aux, m.perm + WT_INF_DBASE * S, 32, S)) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
     z.st = WT_INF_ST_SYM;
 }
 
+WT_HD bool wt_inf_step_body(WtInflate &z, const WtInfMem &m);
+
 // One step of the state machine.  Returns false once the lane has nothing more to do.
+// The input prefetch brackets the step: the 16-byte load of the chunk after next is ISSUED before the step's
+// work and its registers are only touched after it -- a load whose result is merged into the loop-carried state
+// right where it was issued costs a full memory round trip per chunk (hipcc copies it at the end of the
+// branch; seen in the ISA as s_waitcnt vmcnt(0) three instructions after the load).
 WT_HD bool wt_inf_step(WtInflate &z, const WtInfMem &m) {
     if (z.st >= WT_INF_ST_DONE) return false;
+    const bool need = z.nxt_empty;
+    const uint32_t chunk0 = z.in_chunk;
+    WtInfQuad tmp;                  // (only read under `need`)
+    if (need) tmp = wt_inf_load(z, chunk0);
+    const bool more = wt_inf_step_body(z, m);
+    if (need && z.nxt_empty && z.in_chunk == chunk0) { z.nxt = tmp; z.in_chunk = chunk0 + 1; z.nxt_empty = false; }
+    return more;
+}
+
+WT_HD bool wt_inf_step_body(WtInflate &z, const WtInfMem &m) {
     const int S = m.stride;
     if (z.copy_rem) {
-#pragma unroll
-        for (int q = 0; q < WT_INF_COPY; q++) {
-            if (z.copy_rem) {
-                uint32_t b;
-                if (z.copy_dist <= WT_INF_RING) b = m.ring[((z.out_pos - z.copy_dist) & (WT_INF_RING - 1)) * S];
-                else b = z.out[z.out_pos - z.copy_dist];        // flushed long ago (>= 64 bytes back)
-                wt_inf_emit(z, m, b);
-                z.copy_rem--;
-            }
+        // up to 8 bytes of the match: three dwords around the source, one LDS round trip
+        const uint32_t src = z.out_pos - z.copy_dist;
+        const uint32_t d0 = src >> 2;
+        uint32_t r0, r1, r2;
+        if (z.copy_dist <= WT_INF_RING_DIST) {
+            r0 = m.ring[(d0 & (WT_INF_RING - 1)) * S];
+            r1 = m.ring[((d0 + 1) & (WT_INF_RING - 1)) * S];
+            r2 = m.ring[((d0 + 2) & (WT_INF_RING - 1)) * S];
+        } else {                                    // flushed long ago (full dwords are stored at once)
+            r0 = z.out[d0]; r1 = z.out[d0 + 1]; r2 = z.out[d0 + 2];
         }
+        const uint32_t sh = (src & 3u) * 8u;
+        uint64_t w = ((uint64_t) r0 | ((uint64_t) r1 << 32)) >> sh;
+        if (sh) w |= (uint64_t) r2 << (64u - sh);
+        if (z.copy_dist < 8u) {                     // overlapping copy: the first `dist` bytes repeat
+            const uint32_t s8 = 8u * z.copy_dist;
+            w &= (1ull << s8) - 1ull;
+            w |= w << s8;
+            if (2u * s8 < 64u) w |= w << (2u * s8);
+            if (4u * s8 < 64u) w |= w << (4u * s8);
+        }
+        const uint32_t n = z.copy_rem < (uint32_t) WT_INF_COPY ? z.copy_rem : (uint32_t) WT_INF_COPY;
+        wt_inf_put(z, m, w, n);
+        z.copy_rem -= n;
         if (z.copy_rem) return true;
     }
     if (z.bits_left < 0) { wt_inf_fail(z, WT_INF_ERR_INPUT); return false; }
     if (z.st == WT_INF_ST_SYM) {
         wt_inf_refill(z);
-        const int sym = wt_inf_decode(z, z.llim, m.aux, m.perm, S);
+        const int sym = wt_inf_decode(z, z.llim, z.ladj, m.perm, S);
         if (sym < 0) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
         if (sym < 256) {
             if (z.out_pos >= z.out_cap) { wt_inf_fail(z, WT_INF_ERR_SPACE); return false; }
-            wt_inf_emit(z, m, (uint32_t) sym);
+            wt_inf_put(z, m, (uint64_t) sym, 1);
         } else if (sym == 256) {
             z.st = z.last ? WT_INF_ST_DONE : WT_INF_ST_BLOCK;
         } else {
@@ -357,7 +459,7 @@ WT_HD bool wt_inf_step(WtInflate &z, const WtInfMem &m) {
                 len = ((4u + (ls & 3u)) << e) + 3u + wt_inf_bits(z, (int) e);
             }
             wt_inf_refill(z);
-            const int ds = wt_inf_decode(z, z.dlim, m.aux + 16 * S, m.perm + WT_INF_DBASE * S, S);
+            const int ds = wt_inf_decode(z, z.dlim, z.dadj, m.perm + WT_INF_DBASE * S, S);
             if (ds < 0 || ds > 29) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
             uint32_t dist;
             if (ds < 4) dist = (uint32_t) ds + 1u;
@@ -372,21 +474,17 @@ WT_HD bool wt_inf_step(WtInflate &z, const WtInfMem &m) {
         return true;
     }
     if (z.st == WT_INF_ST_STORED) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (z.stored_rem) {
-                if (z.out_pos >= z.out_cap) { wt_inf_fail(z, WT_INF_ERR_SPACE); return false; }
-                if (q == 0 || q == 2) wt_inf_refill(z);
-                wt_inf_emit(z, m, wt_inf_bits(z, 8));
-                z.stored_rem--;
-            }
-        }
+        wt_inf_refill(z);
+        const uint32_t n = z.stored_rem < 4u ? z.stored_rem : 4u;
+        if (z.out_pos + n > z.out_cap) { wt_inf_fail(z, WT_INF_ERR_SPACE); return false; }
+        wt_inf_put(z, m, (uint64_t) wt_inf_bits(z, 8 * (int) n), n);
+        z.stored_rem -= n;
         if (!z.stored_rem) z.st = z.last ? WT_INF_ST_DONE : WT_INF_ST_BLOCK;
         return true;
     }
     if (z.st == WT_INF_ST_BLOCK) {
         wt_inf_block(z, m);
-        return z.st < WT_INF_ST_DONE || z.st == WT_INF_ST_DONE;
+        return z.st != WT_INF_ST_ERR;
     }
     // WT_INF_ST_ZHDR: RFC 1950 -- CMF, FLG
     wt_inf_refill(z);
@@ -400,7 +498,7 @@ WT_HD bool wt_inf_step(WtInflate &z, const WtInfMem &m) {
 WT_HD int64_t wt_inf_finish(WtInflate &z) {
     if (z.st == WT_INF_ST_DONE && z.bits_left < 0) { z.st = WT_INF_ST_ERR; z.err = WT_INF_ERR_INPUT; }
     if (z.st != WT_INF_ST_DONE) return -(int64_t) (z.err ? z.err : WT_INF_ERR_INPUT);
-    if (z.out_pos & 3u) *(uint32_t *) (z.out + (z.out_pos & ~3u)) = z.acc;
+    if (z.out_pos & 3u) z.out[z.out_pos >> 2] = z.acc;
     return (int64_t) z.out_pos;
 }
 

@@ -963,6 +963,9 @@ struct BwReader {
     std::condition_variable cv;
     int want_buf = -1;          // buffer the producer should fill next (-1: idle)
     bool ready = false, quit = false, failed = false;
+    bool started = false;       // the producer thread exists (it is created when the SECOND part is asked for: the
+                                // constructor decodes the priming block itself, and a reducer that ships the file's
+                                // sections to the device undecoded never needs the thread)
 
     bool clipped(int64_t g) const {
         const BwBuffer &b = buf[cur];
@@ -1049,8 +1052,18 @@ void bw_wait(BwReader *r) {
 
 // Switches to the part the producer has been decoding into the idle buffer and asks for the one after
 // it, whose decode then overlaps the consumption of this one.
+void bw_producer(BwReader *r);
+void bw_start(BwReader *r) {
+    if (r->started) return;
+    r->started = true;
+    r->th = std::thread(bw_producer, r);
+    r->th.detach();                             // lives for the process, like the reference's reader threads
+    bw_request(r, r->cur ^ 1);
+}
+
 void bw_next_part(BwReader *r, WiggleIterator *wi) {
     for (;;) {
+        bw_start(r);
         bw_wait(r);
         r->cur ^= 1;
         const BwBuffer &b = r->buf[r->cur];
@@ -1107,7 +1120,7 @@ void bw_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
     // chromosome (:91-92 -> readBigWiggleRegion): intervals are boxed into that window only (:42-44), not
     // into the 10 000-bp stretches of a whole-chromosome read (:73-83)
     BwReader *r = ((BwHandle *) wi->data)->r;
-    bw_wait(r);                             // whatever the producer is decoding lands first; it is idle afterwards
+    if (r->started) bw_wait(r);             // whatever the producer is decoding lands first; it is idle afterwards
     r->windowed = true;
     r->win_start = start; r->win_finish = finish;
     r->done = false;
@@ -1123,7 +1136,7 @@ void bw_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
     r->p_lo0 = start > 0 ? start - 1 : 0;
     r->p_hi0 = finish > 0 ? finish - 1 : 0;
     r->j = r->end = 0;
-    bw_request(r, r->cur ^ 1);
+    if (r->started) bw_request(r, r->cur ^ 1);      // (else bw_next_part starts the producer, which takes the request)
     bw_settle(r, wi);
 }
 
@@ -1783,16 +1796,20 @@ WiggleIterator *wtamd_BigWiggleReader(const char *path, int box) {
     for (int i = 0; i < wtamd_bw_n_chrom(bw); i++) r->names.push_back(wtamd_bw_chrom_name(bw, i));
     std::sort(r->names.begin(), r->names.end(), [](const std::string &a, const std::string &b) { return strcmp(a.c_str(), b.c_str()) < 0; });
     for (const std::string &n : r->names) r->cnames.push_back(strdup(n.c_str()));
-    r->th = std::thread(bw_producer, r);
-    r->th.detach();                             // lives for the process, like the reference's reader threads
     WiggleIterator *wi = (WiggleIterator *) calloc(1, sizeof(WiggleIterator));
     wi->data = h;
     wi->pop = &wt_bulk_pop;
     wi->seek = &bw_seek;
     wi->value = 1;
     wi->default_value = 0;                      // bigWiggleReader.c:150
-    r->cur = 1;                                 // the first part goes to buffer 0
-    bw_request(r, 0);
+    // priming (wiggleIterator.c:32): the first data block is decoded here, on the caller's thread -- 100 files used
+    // to cost 100 thread starts and hand-shakes before the first run could be computed
+    r->cur = 0;
+    r->p_blocks = 1;
+    bw_decode(r, r->buf[0]);
+    if (r->failed) { fprintf(stderr, "wiggletools_amd: BigWig decode failed\n"); exit(1); }
+    r->j = 0; r->end = r->buf[0].n;
+    if (r->buf[0].chrom < 0) r->done = true;
     bw_settle(r, wi);
     return wi;
 }

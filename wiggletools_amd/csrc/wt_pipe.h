@@ -497,7 +497,7 @@ int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, ui
     const int N = p->cfg.n_tracks;
     s.bw_off_sec = wt_align256((int64_t) sizeof(wtamd_bw_track) * N);
     s.bw_off_bytes = s.bw_off_sec + wt_align256((int64_t) sizeof(wtamd_bw_section) * n_sections);
-    const int64_t need = s.bw_off_bytes + wt_align256(n_bytes + 16);
+    const int64_t need = s.bw_off_bytes + wt_align256(n_bytes + 64);
     if (s.h_bw_cap < need) {
         if (s.h_bw) p->dead_host.push_back(s.h_bw);
         s.h_bw = nullptr; s.h_bw_cap = 0;
@@ -697,7 +697,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
         if (!p->s_dec) WT_HIP(hipStreamCreateWithFlags(&p->s_dec, hipStreamNonBlocking));
         if (!s.e_bwc) { WT_HIP(hipEventCreate(&s.e_bwc)); WT_HIP(hipEventCreate(&s.e_bw0)); WT_HIP(hipEventCreate(&s.e_bw1)); }
         if (!s.h_bw_status) WT_HIP(hipHostMalloc((void **) &s.h_bw_status, 64, hipHostMallocDefault));
-        const int64_t total = s.bw_off_bytes + wt_align256(bw_bytes + 16);
+        const int64_t total = s.bw_off_bytes + wt_align256(bw_bytes + 64);
         if (s.d_bw_cap < total) {
             if (s.d_bw) p->dead_dev.push_back(s.d_bw);
             s.d_bw = nullptr; s.d_bw_cap = 0;
