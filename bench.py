@@ -285,7 +285,9 @@ def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
         n_int = int(seg[-1])
         os.environ.pop("WTAMD_BW_DEVICE", None)
         t0 = time.perf_counter()
-        r = dropin.reducer(op, [dropin.bigwig_reader(j[0], box=True) for j in jobs], n_set0=n_tracks // 2)
+        readers = [dropin.bigwig_reader(j[0], box=True) for j in jobs]
+        t_readers = time.perf_counter() - t0
+        r = dropin.reducer(op, readers, n_set0=n_tracks // 2)
         t_open = time.perf_counter() - t0
         marks = []
         runs, _ = dropin.drain_blocks(r, on_block=lambda c, a, b, v: (marks.append((time.perf_counter(), int(b[-1]))), 0)[1])
@@ -294,7 +296,7 @@ def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
         out = {"tracks": n_tracks, "op": op, "bp": L, "seconds": dt, "bp_per_s": L / dt, "runs": runs,
                "intervals": n_int, "intervals_per_s": n_int / dt, "file_bytes": size, "file_bytes_per_bp": size / L,
                "inbound_GBs": size / dt / 1e9, "pcie_h2d_roofline_bp_per_s": 63e9 / (size / L),
-               "open_seconds": t_open, "files_written_s": write_s, "files_dir": d.rsplit("/", 1)[0],
+               "open_seconds": t_open, "open_readers_seconds": t_readers, "files_written_s": write_s, "files_dir": d.rsplit("/", 1)[0],
                "host_cores": effective_cores(), "batches": st.get("batches"),
                "sections_inflated_on_device": st.get("bw_sections"), "sum_device_decode_ms": st.get("bw_decode_ms"),
                "sum_kernel_ms": st.get("kernel_ms"), "sum_d2h_ms": st.get("d2h_ms"), "host_submit_ms": st.get("host_submit_ms"),

@@ -511,6 +511,10 @@ int wtamd_pipe_bw_reserve(wtamd_pipe *, int64_t n_bytes, int64_t n_sections, uin
  * A malformed stream / section fails the batch at collect (WTAMD_ERR_INTERNAL with the cause). */
 int wtamd_pipe_submit_bw(wtamd_pipe *, int64_t n_bytes, int64_t n_sections, const wtamd_bw_track *tracks,
                          int32_t range_lo, int32_t range_hi);
+/* How many sections one launch of the inflate kernel keeps resident on the device (wavefronts the GPU holds at
+ * once x 64 lanes): a batch of about that many sections fills the GPU exactly once -- fewer leave SIMDs idle, a
+ * few more cost a whole second round. */
+int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *);
 
 /* Pinned (page-locked, DMA-able) host memory for bulk sources. */
 void *wtamd_host_alloc(size_t bytes);

@@ -296,9 +296,9 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
 
 // One zlib (or raw deflate) stream through the lane state machine; returns bytes produced or -(error).
 long long wtemu_inflate(const uint8_t *src, long long n, uint8_t *dst, long long cap, int raw_deflate) {
-    std::vector<uint16_t> perm(WT_INF_PERM), aux(WT_INF_AUX);
+    std::vector<uint16_t> perm(WT_INF_PERM);
     std::vector<uint32_t> ring(WT_INF_RING);
-    WtInfMem m{perm.data(), aux.data(), ring.data(), 1};
+    WtInfMem m{perm.data(), ring.data(), 1};
     // the decoder reads whole aligned 16-byte chunks around the stream and writes whole words: private padded copies
     std::vector<uint8_t> in((size_t) n + 96, 0), out(((size_t) cap + 3) / 4 * 4 + 8, 0);
     const int mis = (int) (n % 16);             // any alignment must work
@@ -361,6 +361,8 @@ unsigned wtemu_bw_decode(const uint8_t *bytes, const wtamd_bw_section *secs, lon
     seg_off[n_tracks] = at;
     return 0;
 }
+
+int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *p) { return p ? 4096 : 0; }
 
 int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, uint8_t **bytes, wtamd_bw_section **sections) {
     if (!p || p->acquired < 0 || n_bytes < 0 || n_sections < 0 || !bytes || !sections) { g_err = "wtamd_pipe_bw_reserve: bad arguments"; return WTAMD_ERR_ARG; }

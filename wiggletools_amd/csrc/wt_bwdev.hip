@@ -8,8 +8,9 @@
 // Kernels, all on the pipeline's decode stream, nothing returns to the host in between:
 //   wt_bw_copy_kernel     pinned host staging (file bytes as read) -> HBM, 16 B per lane
 //   wt_bw_inflate_kernel  ONE LANE PER SECTION: 64 independent zlib streams per wavefront
-//                         (csrc/wt_inflate.h: limit-based canonical Huffman decoding, tables 704 B of
-//                         LDS per lane interleaved across the wave, 64-byte LZ77 ring in LDS), plain
+//                         (csrc/wt_inflate.h: limit-based canonical Huffman decoding, tables 576 B of
+//                         LDS per lane interleaved across the wave + a 64-byte LZ77 ring: 40 KB per
+//                         wavefront, four wavefronts per CU), plain
 //                         bytes to a strided scratch buffer.  Bound: dependent-instruction latency
 //                         (a serial bit stream per lane); throughput comes from sections in flight.
 //   wt_bw_count_kernel    one wavefront per section: header, per-item piece counts (1-based shift,
@@ -51,7 +52,6 @@ __global__ void __launch_bounds__(WT_BW_INF_LANES) wt_bw_inflate_kernel(const Wt
                                                                          const uint8_t *comp, uint8_t *plain, uint32_t plain_stride,
                                                                          int32_t *plain_len) {
     __shared__ uint16_t s_perm[WT_INF_PERM * WT_BW_INF_LANES];
-    __shared__ uint16_t s_aux[WT_INF_AUX * WT_BW_INF_LANES];
     __shared__ uint32_t s_ring[WT_INF_RING * WT_BW_INF_LANES];
     const int lane = threadIdx.x;
     const int i = blockIdx.x * WT_BW_INF_LANES + lane;
@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(WT_BW_INF_LANES) wt_bw_inflate_kernel(const Wt
     const WtBwSection sc = secs[i];
     const bool compressed = tracks[sc.track].compressed != 0;
     WtInfMem m;
-    m.perm = (WT_AS_LDS uint16_t *) (s_perm + lane); m.aux = (WT_AS_LDS uint16_t *) (s_aux + lane);
+    m.perm = (WT_AS_LDS uint16_t *) (s_perm + lane);
     m.ring = (WT_AS_LDS uint32_t *) (s_ring + lane); m.stride = WT_BW_INF_LANES;
     WtInflate z;
     wt_inf_begin(z, comp + sc.comp_off, sc.comp_size, plain + (size_t) i * plain_stride, plain_stride, false);
@@ -229,6 +229,16 @@ __global__ void __launch_bounds__(64) wt_bw_scatter_kernel(const WtBwSection *se
 }
 
 }  // namespace
+
+// sections resident per launch of the inflate kernel: CUs x wavefronts per CU x 64 lanes
+long long wt_bw_fill_sections(int num_cu) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wt_bw_inflate_kernel, WT_BW_INF_LANES, 0) != hipSuccess || per_cu < 1) {
+        (void) hipGetLastError();
+        per_cu = 3;
+    }
+    return (long long) num_cu * per_cu * WT_BW_INF_LANES;
+}
 
 // scratch a batch of `n_sec` sections with `plain_stride` bytes each needs, in bytes
 long long wt_bw_scratch_bytes(long long n_sec, long long plain_stride) {

@@ -12,10 +12,12 @@
 //         len = 1 + #{ k in 1..14 : w >= lim[k] },   lim[k] = (first[k] + count[k]) << (15 - k)
 //     and the symbol is perm[adj[len] + (w >> (15 - len))].  The 2 x 15 limits live in REGISTERS
 //     and 2 x 15 adj values live in REGISTERS
-//     (statically indexed arrays), `perm` (the symbols sorted by code) in LDS -- ONE dependent LDS read
-//     per symbol, 768 bytes of LDS per lane.
+//     (statically indexed arrays), `perm` (the 286 literal / length symbols sorted by code) in LDS --
+//     ONE dependent LDS read per symbol -- the 30 distance symbols in 5 registers: 640 bytes of LDS per lane,
+//     so that FOUR wavefronts (one per SIMD) share a CU's 160 KB.
 //   * the code lengths of a dynamic block are parked in the unused top 4 bits of perm[] while
-//     the table is built in place; the 19-symbol code-length code lives in two 64-bit registers.
+//     the table is built in place, the per-length counters borrow the ring's 16 slots (whose history waits
+//     in registers); the 19-symbol code-length code lives in 64-bit registers.
 //   * LZ77 history: the last 16 output DWORDS of every lane are kept in an LDS ring; a match with a
 //     distance <= 60 (the bulk of them in 12-byte record data) reads three of them -- one LDS round
 //     trip for up to 8 bytes -- and never touches global memory; longer ones read the lane's own
@@ -64,15 +66,13 @@
 #define WT_INF_OPAQUE(x) (void) 0
 #endif
 
-#define WT_INF_PERM 320         // [0, 288) literal / length symbols, [288, 320) distance symbols
-#define WT_INF_DBASE 288
-#define WT_INF_AUX 32           // table construction scratch: counters / cursors, the code-length code's symbols
-#define WT_INF_RING 16          // dwords of LZ77 history per lane (the current partial dword included)
-#define WT_INF_RING_DIST 60     // matches up to this distance are served from the ring
+#define WT_INF_PERM 288         // literal / length symbols sorted by code (the 30 distance symbols live in registers)
+#define WT_INF_RING 16          // dwords of LZ77 history per lane
+#define WT_INF_RING_DIST 56     // matches up to this distance are served from the ring
 #define WT_INF_COPY 8           // match bytes copied per state machine step
 
-// bytes of "LDS" one lane needs
-#define WT_INF_LANE_BYTES (WT_INF_PERM * 2 + WT_INF_AUX * 2 + WT_INF_RING * 4)
+// bytes of "LDS" one lane needs: 640 -> 40 KB per wavefront, four wavefronts per CU (one per SIMD)
+#define WT_INF_LANE_BYTES (WT_INF_PERM * 2 + WT_INF_RING * 4)
 
 enum {
     WT_INF_OK = 0,
@@ -89,8 +89,7 @@ enum { WT_INF_ST_ZHDR = 0, WT_INF_ST_BLOCK = 1, WT_INF_ST_SYM = 2, WT_INF_ST_STO
 
 struct WtInfMem {
     WT_AS_LDS uint16_t *perm;   // WT_INF_PERM entries
-    WT_AS_LDS uint16_t *aux;    // WT_INF_AUX entries
-    WT_AS_LDS uint32_t *ring;   // WT_INF_RING dwords
+    WT_AS_LDS uint32_t *ring;   // WT_INF_RING dwords (borrowed as 16 counters while a block's tables are built)
     int stride;                 // elements between consecutive entries of this lane
 };
 
@@ -104,9 +103,11 @@ struct WtInflate {
     WtInfQuad cur, nxt;
     uint32_t qi;                // words of `cur` already taken (the queue is shifted, cur.x is the next one)
     bool nxt_empty;             // `nxt` was moved into `cur` and its successor has not arrived yet
+    uint32_t words;             // words taken so far
+    uint32_t head_bits;         // bits of the first word that precede the stream
+    uint32_t n_bytes;
     uint64_t bb;                // bit buffer, LSB first
     int32_t bc;                 // valid bits in bb
-    int64_t bits_left;          // bits of the stream not yet consumed (underflow = truncated input)
     // output
     WT_AS_GLOBAL uint32_t *out; // 4-byte aligned
     uint32_t out_pos, out_cap;
@@ -118,6 +119,7 @@ struct WtInflate {
     bool last, raw;             // last block seen; raw deflate (no zlib wrapper)
     uint32_t llim[16], dlim[16];    // [1..15] used
     int32_t ladj[16], dadj[16];
+    uint32_t dperm[5];          // the distance symbols sorted by code, 5 bits each, 6 per word
 };
 
 WT_HD uint32_t wt_inf_bitrev15(uint32_t x) {
@@ -130,9 +132,9 @@ WT_HD uint32_t wt_inf_bitrev15(uint32_t x) {
 #endif
 }
 
-// Chunk i of the input (past the end: the last chunk again -- whatever bits a lane decodes from there, it has
-// over-read: bits_left < 0 fails the stream).  UNCONDITIONAL on purpose: a load under a branch is merged with the
-// "no load" value by a register copy, and the copy waits for the load right where it was issued.
+// Chunk i of the input (past the end: the last chunk again -- a lane that gets there has over-read and fails,
+// see wt_inf_overread).  UNCONDITIONAL on purpose: a load under a branch is merged with the "no load" value by a
+// register copy, and the copy waits for the load right where it was issued.
 WT_HD WtInfQuad wt_inf_load(const WtInflate &z, uint32_t i) {
     const uint32_t last = z.in_chunks ? z.in_chunks - 1u : 0u;
     const WT_AS_GLOBAL uint32_t *p = z.in_w + 4 * (size_t) (i < last ? i : last);
@@ -141,8 +143,15 @@ WT_HD WtInfQuad wt_inf_load(const WtInflate &z, uint32_t i) {
     return q;
 }
 
-// The next 32 bits of the stream.  `nxt` was requested when `cur` became current: by the time it is needed the
-// 4 words of `cur` (~16 symbols) have been decoded.
+WT_HD void wt_inf_fail(WtInflate &z, int code) { z.st = WT_INF_ST_ERR; z.err = code; z.copy_rem = 0; }
+
+// Bits consumed beyond the end of the stream?  (Checked when a chunk is fetched -- a stream that keeps decoding
+// garbage past its end cannot run forever -- and at the end.)
+WT_HD bool wt_inf_overread(const WtInflate &z) {
+    const int64_t consumed = (int64_t) z.words * 32 - (int64_t) z.head_bits - (int64_t) z.bc;
+    return consumed > (int64_t) z.n_bytes * 8;
+}
+
 // (The queue is SHIFTED, never indexed: one variable index into the state struct and hipcc keeps the whole
 // struct in scratch memory.)  `nxt` is refilled by wt_inf_step's prefetch one step after it was moved into `cur`;
 // the blocking load here serves the block-header code, which reads many words inside one step.
@@ -150,6 +159,7 @@ WT_HD uint32_t wt_inf_word(WtInflate &z) {
     const uint32_t w = z.cur.x;
     z.cur.x = z.cur.y; z.cur.y = z.cur.z; z.cur.z = z.cur.w;
     z.qi++;
+    z.words++;
     if (z.qi == 4) {
         if (z.nxt_empty) { z.nxt = wt_inf_load(z, z.in_chunk); z.in_chunk++; }
         z.cur = z.nxt;
@@ -167,16 +177,19 @@ WT_HD void wt_inf_begin(WtInflate &z, const uint8_t *src, uint32_t n_bytes, uint
     const uint32_t mis = (uint32_t) (a & 15u);
     z.in_w = (const WT_AS_GLOBAL uint32_t *) (a - mis);
     z.in_chunks = (mis + n_bytes + 15u) >> 4;
-    z.bits_left = (int64_t) n_bytes * 8;
+    z.n_bytes = n_bytes;
     z.cur = wt_inf_load(z, 0);
     z.nxt = wt_inf_load(z, 1);
     z.in_chunk = 2;
     z.qi = 0;
     z.nxt_empty = false;
+    z.words = 0;
     for (uint32_t k = 0; k < (mis >> 2); k++) (void) wt_inf_word(z);       // whole words before the stream are skipped
+    z.words = 0;
     const uint32_t w0 = wt_inf_word(z);
-    z.bb = (uint64_t) (w0 >> (8 * (mis & 3u)));
-    z.bc = 32 - 8 * (int32_t) (mis & 3u);
+    z.head_bits = 8u * (mis & 3u);
+    z.bb = (uint64_t) (w0 >> z.head_bits);
+    z.bc = 32 - (int32_t) z.head_bits;
     z.out = (WT_AS_GLOBAL uint32_t *) dst; z.out_pos = 0; z.out_cap = cap; z.acc = 0;
     z.st = raw_deflate ? WT_INF_ST_BLOCK : WT_INF_ST_ZHDR;
     z.err = WT_INF_OK;
@@ -184,9 +197,11 @@ WT_HD void wt_inf_begin(WtInflate &z, const uint8_t *src, uint32_t n_bytes, uint
     z.last = false; z.raw = raw_deflate;
 #pragma unroll
     for (int k = 0; k < 16; k++) { z.llim[k] = 0; z.dlim[k] = 0; z.ladj[k] = 0; z.dadj[k] = 0; }
+#pragma unroll
+    for (int k = 0; k < 5; k++) z.dperm[k] = 0;
 }
 
-// After this bc >= 33 (past the end of the input zero bits follow; bits_left catches over-reads).
+// After this bc >= 33 (past the end of the input the last chunk repeats; wt_inf_overread catches it).
 WT_HD void wt_inf_refill(WtInflate &z) {
     if (z.bc <= 32) {
         z.bb |= (uint64_t) wt_inf_word(z) << z.bc;
@@ -196,15 +211,13 @@ WT_HD void wt_inf_refill(WtInflate &z) {
 
 WT_HD uint32_t wt_inf_bits(WtInflate &z, int n) {      // n <= 32, after a refill guaranteeing enough bits
     const uint32_t v = (uint32_t) (z.bb & ((1ull << n) - 1ull));
-    z.bb >>= n; z.bc -= n; z.bits_left -= n;
+    z.bb >>= n; z.bc -= n;
     return v;
 }
 
-WT_HD void wt_inf_fail(WtInflate &z, int code) { z.st = WT_INF_ST_ERR; z.err = code; z.copy_rem = 0; }
-
-// One Huffman symbol.  lim[1..15] / adj[1..15] registers, perm in lane memory: ONE dependent LDS read.
-// Returns -1 on a pattern no code word matches.
-WT_HD int wt_inf_decode(WtInflate &z, const uint32_t (&lim)[16], const int32_t (&adj)[16], const WT_AS_LDS uint16_t *perm, int stride) {
+// Length and sorted-symbol index of the code word on top of the stream: lim[1..15] / adj[1..15] registers.
+// Returns false on a pattern no code word matches.
+WT_HD bool wt_inf_code(WtInflate &z, const uint32_t (&lim)[16], const int32_t (&adj)[16], int32_t &idx) {
     const uint32_t w = wt_inf_bitrev15((uint32_t) z.bb & 0x7FFFu);
     int len = 1;
     int32_t a = adj[1];
@@ -215,21 +228,14 @@ WT_HD int wt_inf_decode(WtInflate &z, const uint32_t (&lim)[16], const int32_t (
         a = ge ? adj[k + 1] : a;
         WT_INF_OPAQUE(a);
     }
-    if (w >= lim[15]) return -1;
-    const int32_t idx = a + (int32_t) (w >> (15 - len));
-    z.bb >>= len; z.bc -= len; z.bits_left -= len;
-    return (int) (perm[idx * stride] & 0x1FFu);
+    idx = a + (int32_t) (w >> (15 - len));
+    z.bb >>= len; z.bc -= len;
+    return w < lim[15];
 }
 
-// Canonical table of the `n` symbols whose lengths sit in the top 4 bits of perm[0..n): fills lim[], adj[] and
-// the low 9 bits of perm[]; `cnt` = 16 entries of scratch.  False: over-subscribed.
-WT_HD bool wt_inf_build(uint32_t (&lim)[16], int32_t (&adj)[16], WT_AS_LDS uint16_t *cnt, WT_AS_LDS uint16_t *perm, int n, int stride) {
-#pragma unroll
-    for (int k = 0; k < 16; k++) cnt[k * stride] = 0;
-    for (int s = 0; s < n; s++) {
-        const int l = perm[s * stride] >> 12;
-        cnt[l * stride] = (uint16_t) (cnt[l * stride] + 1);
-    }
+// lim[] / adj[] of a canonical code from the 16 per-length counts in cnt[] (lane memory); leaves the insertion
+// cursor of every length in cnt[].  False: over-subscribed.
+WT_HD bool wt_inf_limits(uint32_t (&lim)[16], int32_t (&adj)[16], WT_AS_LDS uint32_t *cnt, int stride) {
     uint32_t code = 0, off = 0;
     bool ok = true;
     lim[0] = 0; adj[0] = 0;
@@ -239,24 +245,15 @@ WT_HD bool wt_inf_build(uint32_t (&lim)[16], int32_t (&adj)[16], WT_AS_LDS uint1
         if (code + c > (1u << k)) ok = false;
         lim[k] = (code + c) << (15 - k);
         adj[k] = (int32_t) off - (int32_t) code;    // (symbols shorter than k) - first code of length k
-        cnt[k * stride] = (uint16_t) off;           // insertion cursor of length k
+        cnt[k * stride] = off;                      // insertion cursor of length k
         off += c;
         code = (code + c) << 1;
     }
-    if (!ok) return false;
-    for (int s = 0; s < n; s++) {
-        const int l = perm[s * stride] >> 12;
-        if (l) {
-            const uint32_t j = cnt[l * stride];
-            cnt[l * stride] = (uint16_t) (j + 1);
-            perm[j * stride] = (uint16_t) ((perm[j * stride] & 0xF000u) | (uint32_t) s);
-        }
-    }
-    return true;
+    return ok;
 }
 
 // Appends the low n (1..8) bytes of `bytes` to the output: full dwords go to global memory and to the ring,
-// the partial one stays in `acc` (and in the ring, where matches look for it).
+// the partial one stays in `acc` (it reaches the ring when a match is about to read it).
 WT_HD void wt_inf_put(WtInflate &z, const WtInfMem &m, uint64_t bytes, uint32_t n) {
     if (n < 8) bytes &= (1ull << (8 * n)) - 1ull;
     const uint32_t sh = (z.out_pos & 3u) * 8u;
@@ -264,8 +261,7 @@ WT_HD void wt_inf_put(WtInflate &z, const WtInfMem &m, uint64_t bytes, uint32_t 
     const uint32_t e0 = z.acc | (uint32_t) (bytes << sh);
     const uint64_t t = bytes >> (32u - sh);
     const uint32_t e1 = (uint32_t) t, e2 = (uint32_t) (t >> 32);
-    const uint32_t total = (z.out_pos & 3u) + n;
-    const uint32_t full = total >> 2;
+    const uint32_t full = ((z.out_pos & 3u) + n) >> 2;
     uint32_t acc = e0;
     if (full >= 1) {
         z.out[d] = e0;
@@ -279,11 +275,23 @@ WT_HD void wt_inf_put(WtInflate &z, const WtInfMem &m, uint64_t bytes, uint32_t 
     }
     z.acc = acc;
     z.out_pos += n;
-    m.ring[((z.out_pos >> 2) & (WT_INF_RING - 1)) * m.stride] = acc;
 }
 
-// Block header (RFC 1951 3.2.3 - 3.2.7): sets up the tables of a fixed / dynamic block or the byte
-// count of a stored one.
+// One literal: the common case of wt_inf_put.
+WT_HD void wt_inf_put1(WtInflate &z, const WtInfMem &m, uint32_t b) {
+    const uint32_t acc = z.acc | (b << ((z.out_pos & 3u) * 8u));
+    z.out_pos++;
+    z.acc = acc;
+    if ((z.out_pos & 3u) == 0) {
+        const uint32_t d = (z.out_pos >> 2) - 1u;
+        z.out[d] = acc;
+        m.ring[(d & (WT_INF_RING - 1)) * m.stride] = acc;
+        z.acc = 0;
+    }
+}
+
+// Block header (RFC 1951 3.2.3 - 3.2.7): sets up the tables of a fixed / dynamic block or the byte count of a
+// stored one.  Executed once or twice per stream: compactness matters more than speed here.
 WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
     const int S = m.stride;
     wt_inf_refill(z);
@@ -299,11 +307,18 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
         return;
     }
     if (type == 3) { wt_inf_fail(z, WT_INF_ERR_BLOCK); return; }
+    // the 16 ring slots become the per-length counters / cursors of the table construction: the history they hold
+    // (live when this is not the stream's first block) waits in registers
+    uint32_t saved[WT_INF_RING];
+#pragma unroll
+    for (int k = 0; k < WT_INF_RING; k++) saved[k] = m.ring[k * S];
+    WT_AS_LDS uint32_t *cnt = m.ring;
+    uint64_t dl0 = 0, dl1 = 0;                      // lengths of the distance symbols, 4 bits each (16 per word)
     int hlit = 288, hdist = 30;
     for (int s = 0; s < WT_INF_PERM; s++) m.perm[s * S] = 0;
     if (type == 1) {
         for (int s = 0; s < 288; s++) m.perm[s * S] = (uint16_t) ((s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8) << 12);
-        for (int s = 0; s < 30; s++) m.perm[(WT_INF_DBASE + s) * S] = (uint16_t) (5 << 12);
+        dl0 = 0x5555555555555555ull; dl1 = 0x0055555555555555ull;       // 30 codes of 5 bits
     } else {
         hlit = (int) wt_inf_bits(z, 5) + 257;
         hdist = (int) wt_inf_bits(z, 5) + 1;
@@ -318,9 +333,9 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
             if (i == 10) wt_inf_refill(z);
             if (i < hclen) cl |= (uint64_t) wt_inf_bits(z, 3) << (3 * order);
         }
-        uint64_t cnt = 0;                           // 8-bit counters per length
+        uint64_t cc = 0;                            // 8-bit counters per length
 #pragma unroll
-        for (int s = 0; s < 19; s++) cnt += 1ull << (8 * (int) ((cl >> (3 * s)) & 7u));
+        for (int s = 0; s < 19; s++) cc += 1ull << (8 * (int) ((cl >> (3 * s)) & 7u));
         uint32_t clim[8];
         int32_t cadj[8];
         uint64_t cur = 0;                           // insertion cursors, 8 bits per length
@@ -330,7 +345,7 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
             clim[0] = 0; cadj[0] = 0;
 #pragma unroll
             for (int k = 1; k <= 7; k++) {
-                const uint32_t c = (uint32_t) (cnt >> (8 * k)) & 255u;
+                const uint32_t c = (uint32_t) (cc >> (8 * k)) & 255u;
                 if (code + c > (1u << k)) ok = false;
                 clim[k] = (code + c) << (7 - k);
                 cadj[k] = (int32_t) off - (int32_t) code;
@@ -340,14 +355,15 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
             }
             if (!ok) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
         }
-        // its symbols sorted by code: aux[0..18]
+        // its symbols sorted by code, 5 bits each: 12 in cp0, the rest in cp1
+        uint64_t cp0 = 0, cp1 = 0;
 #pragma unroll
         for (int s = 0; s < 19; s++) {
             const int l = (int) ((cl >> (3 * s)) & 7u);
             if (l) {
                 const uint32_t j = (uint32_t) (cur >> (8 * l)) & 255u;
                 cur += 1ull << (8 * l);
-                m.aux[j * S] = (uint16_t) s;
+                if (j < 12u) cp0 |= (uint64_t) s << (5u * j); else cp1 |= (uint64_t) s << (5u * (j - 12u));
             }
         }
         const int total = hlit + hdist;
@@ -366,8 +382,9 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
                 WT_INF_OPAQUE(a);
             }
             if (w7 >= clim[7]) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return; }
-            const uint32_t sym = m.aux[(a + (int32_t) (w7 >> (7 - len))) * S];
-            z.bb >>= len; z.bc -= len; z.bits_left -= len;
+            const uint32_t j = (uint32_t) (a + (int32_t) (w7 >> (7 - len)));
+            const uint32_t sym = (uint32_t) ((j < 12u ? cp0 >> (5u * j) : cp1 >> (5u * (j - 12u))) & 31u);
+            z.bb >>= len; z.bc -= len;
             uint32_t rep = 1, val = sym;
             if (sym == 16) {
                 if (i == 0) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
@@ -376,18 +393,62 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
                 rep = 3 + wt_inf_bits(z, 3); val = 0;
             } else if (sym == 18) {
                 rep = 11 + wt_inf_bits(z, 7); val = 0;
+            } else if (sym > 18) {
+                wt_inf_fail(z, WT_INF_ERR_SYMBOL); return;
             }
             if (i + (int) rep > total) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
             for (uint32_t r = 0; r < rep; r++, i++) {
-                const int pos = i < hlit ? i : WT_INF_DBASE + (i - hlit);
-                m.perm[pos * S] = (uint16_t) (val << 12);
+                if (i < hlit) m.perm[i * S] = (uint16_t) (val << 12);
+                else {
+                    const uint32_t q = (uint32_t) (i - hlit);
+                    if (q < 16u) dl0 |= (uint64_t) val << (4u * q); else dl1 |= (uint64_t) val << (4u * (q - 16u));
+                }
             }
             prev = val;
         }
         if ((m.perm[256 * S] >> 12) == 0) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }    // no end-of-block code
     }
-    if (!wt_inf_build(z.llim, z.ladj, m.aux, m.perm, 288, S) ||
-        !wt_inf_build(z.dlim, z.dadj, m.aux, m.perm + WT_INF_DBASE * S, 32, S)) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
+    // literal / length table: counts -> limits -> symbols sorted by code, in place (lengths in the top 4 bits)
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 16; k++) cnt[k * S] = 0;
+    for (int s = 0; s < WT_INF_PERM; s++) {
+        const int l = m.perm[s * S] >> 12;
+        cnt[l * S] = cnt[l * S] + 1u;
+    }
+    ok = wt_inf_limits(z.llim, z.ladj, cnt, S) && ok;
+    for (int s = 0; s < WT_INF_PERM; s++) {
+        const int l = m.perm[s * S] >> 12;
+        if (l) {
+            const uint32_t j = cnt[l * S];
+            cnt[l * S] = j + 1u;
+            if (j < (uint32_t) WT_INF_PERM) m.perm[j * S] = (uint16_t) ((m.perm[j * S] & 0xF000u) | (uint32_t) s);
+        }
+    }
+    // distance table: 30 symbols, sorted into 5 registers
+#pragma unroll
+    for (int k = 0; k < 16; k++) cnt[k * S] = 0;
+    for (int s = 0; s < 30; s++) {
+        const uint32_t l = (uint32_t) ((s < 16 ? dl0 >> (4 * s) : dl1 >> (4 * (s - 16))) & 15u);
+        cnt[l * S] = cnt[l * S] + 1u;
+    }
+    ok = wt_inf_limits(z.dlim, z.dadj, cnt, S) && ok;
+    uint32_t dp[5] = {0u, 0u, 0u, 0u, 0u};
+    for (int s = 0; s < 30; s++) {
+        const uint32_t l = (uint32_t) ((s < 16 ? dl0 >> (4 * s) : dl1 >> (4 * (s - 16))) & 15u);
+        if (l) {
+            const uint32_t j = cnt[l * S];
+            cnt[l * S] = j + 1u;
+            const uint32_t word = j / 6u, sh = 5u * (j - 6u * word);
+#pragma unroll
+            for (int q = 0; q < 5; q++) dp[q] |= (word == (uint32_t) q) ? ((uint32_t) s << sh) : 0u;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; q++) z.dperm[q] = dp[q];
+#pragma unroll
+    for (int k = 0; k < WT_INF_RING; k++) m.ring[k * S] = saved[k];
+    if (!ok) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
     z.st = WT_INF_ST_SYM;
 }
 
@@ -403,7 +464,10 @@ WT_HD bool wt_inf_step(WtInflate &z, const WtInfMem &m) {
     const bool need = z.nxt_empty;
     const uint32_t chunk0 = z.in_chunk;
     WtInfQuad tmp;                  // (only read under `need`)
-    if (need) tmp = wt_inf_load(z, chunk0);
+    if (need) {
+        if (wt_inf_overread(z)) { wt_inf_fail(z, WT_INF_ERR_INPUT); return false; }
+        tmp = wt_inf_load(z, chunk0);
+    }
     const bool more = wt_inf_step_body(z, m);
     if (need && z.nxt_empty && z.in_chunk == chunk0) { z.nxt = tmp; z.in_chunk = chunk0 + 1; z.nxt_empty = false; }
     return more;
@@ -417,6 +481,7 @@ WT_HD bool wt_inf_step_body(WtInflate &z, const WtInfMem &m) {
         const uint32_t d0 = src >> 2;
         uint32_t r0, r1, r2;
         if (z.copy_dist <= WT_INF_RING_DIST) {
+            m.ring[((z.out_pos >> 2) & (WT_INF_RING - 1)) * S] = z.acc;        // the partial dword may be part of the source
             r0 = m.ring[(d0 & (WT_INF_RING - 1)) * S];
             r1 = m.ring[((d0 + 1) & (WT_INF_RING - 1)) * S];
             r2 = m.ring[((d0 + 2) & (WT_INF_RING - 1)) * S];
@@ -438,18 +503,18 @@ WT_HD bool wt_inf_step_body(WtInflate &z, const WtInfMem &m) {
         z.copy_rem -= n;
         if (z.copy_rem) return true;
     }
-    if (z.bits_left < 0) { wt_inf_fail(z, WT_INF_ERR_INPUT); return false; }
     if (z.st == WT_INF_ST_SYM) {
         wt_inf_refill(z);
-        const int sym = wt_inf_decode(z, z.llim, z.ladj, m.perm, S);
-        if (sym < 0) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
-        if (sym < 256) {
+        int32_t idx;
+        if (!wt_inf_code(z, z.llim, z.ladj, idx)) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
+        const uint32_t sym = m.perm[idx * S] & 0x1FFu;
+        if (sym < 256u) {
             if (z.out_pos >= z.out_cap) { wt_inf_fail(z, WT_INF_ERR_SPACE); return false; }
-            wt_inf_put(z, m, (uint64_t) sym, 1);
-        } else if (sym == 256) {
+            wt_inf_put1(z, m, sym);
+        } else if (sym == 256u) {
             z.st = z.last ? WT_INF_ST_DONE : WT_INF_ST_BLOCK;
         } else {
-            const uint32_t ls = (uint32_t) sym - 257u;
+            const uint32_t ls = sym - 257u;
             if (ls > 28u) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
             uint32_t len;
             if (ls < 8u) len = ls + 3u;
@@ -459,13 +524,21 @@ WT_HD bool wt_inf_step_body(WtInflate &z, const WtInfMem &m) {
                 len = ((4u + (ls & 3u)) << e) + 3u + wt_inf_bits(z, (int) e);
             }
             wt_inf_refill(z);
-            const int ds = wt_inf_decode(z, z.dlim, z.dadj, m.perm + WT_INF_DBASE * S, S);
-            if (ds < 0 || ds > 29) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
+            int32_t di;
+            if (!wt_inf_code(z, z.dlim, z.dadj, di) || (uint32_t) di > 29u) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
+            const uint32_t word = (uint32_t) di / 6u, dsh = 5u * ((uint32_t) di - 6u * word);
+            uint32_t dw = z.dperm[0];
+            dw = word == 1u ? z.dperm[1] : dw; WT_INF_OPAQUE(dw);
+            dw = word == 2u ? z.dperm[2] : dw; WT_INF_OPAQUE(dw);
+            dw = word == 3u ? z.dperm[3] : dw; WT_INF_OPAQUE(dw);
+            dw = word == 4u ? z.dperm[4] : dw; WT_INF_OPAQUE(dw);
+            const uint32_t ds = (dw >> dsh) & 31u;
+            if (ds > 29u) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
             uint32_t dist;
-            if (ds < 4) dist = (uint32_t) ds + 1u;
+            if (ds < 4u) dist = ds + 1u;
             else {
-                const uint32_t e = ((uint32_t) ds >> 1) - 1u;
-                dist = ((2u + ((uint32_t) ds & 1u)) << e) + 1u + wt_inf_bits(z, (int) e);
+                const uint32_t e = (ds >> 1) - 1u;
+                dist = ((2u + (ds & 1u)) << e) + 1u + wt_inf_bits(z, (int) e);
             }
             if (dist > z.out_pos) { wt_inf_fail(z, WT_INF_ERR_DIST); return false; }
             if (z.out_pos + len > z.out_cap) { wt_inf_fail(z, WT_INF_ERR_SPACE); return false; }
@@ -496,7 +569,7 @@ WT_HD bool wt_inf_step_body(WtInflate &z, const WtInfMem &m) {
 
 // Flushes the last partial dword; returns the number of bytes produced or -(error code).
 WT_HD int64_t wt_inf_finish(WtInflate &z) {
-    if (z.st == WT_INF_ST_DONE && z.bits_left < 0) { z.st = WT_INF_ST_ERR; z.err = WT_INF_ERR_INPUT; }
+    if (z.st == WT_INF_ST_DONE && wt_inf_overread(z)) { z.st = WT_INF_ST_ERR; z.err = WT_INF_ERR_INPUT; }
     if (z.st != WT_INF_ST_DONE) return -(int64_t) (z.err ? z.err : WT_INF_ERR_INPUT);
     if (z.out_pos & 3u) z.out[z.out_pos >> 2] = z.acc;
     return (int64_t) z.out_pos;

@@ -265,6 +265,8 @@ struct BwDevTrack {
     const char *cname = nullptr;    // interned name of chromosome ci
 };
 void bw_seek(WiggleIterator *wi, const char *chrom, int start, int finish);
+struct TrackSource;
+BwReader *bwdev_reader(const TrackSource &s);
 bool bwdev_eligible(const Feeder &F);
 bool bwdev_drain_and_submit(Feeder &F);
 
@@ -289,7 +291,7 @@ struct Feeder {
     bool bw_mode = false, bw_dirty = true;
     std::vector<BwDevTrack> bwt;
     DrainPool *io_pool = nullptr;       // parallel pread() of the section bytes
-    int64_t bw_target_bytes = 0;
+    int64_t bw_target_bytes = 0, bw_target_sections = 0;
     // drain position
     const char *chrom = nullptr;        // chromosome of the batch being / last drained
     bool continuing = false;            // next batch continues `chrom` at next_lo
@@ -323,8 +325,11 @@ struct Feeder {
         span = first_span < max_runs ? first_span : max_runs;
         bw_mode = desc.op != WTAMD_OP_MULTIPLEX && bwdev_eligible(*this);
         bw_dirty = true;
-        bw_target_bytes = env_i64("WTAMD_BW_BATCH_BYTES", 128 << 20);
+        bw_target_bytes = env_i64("WTAMD_BW_BATCH_BYTES", (int64_t) 1 << 30);
         if (wtamd_pipe_create(&cfg, &pipe) != WTAMD_OK) die("wtamd_pipe_create");
+        // a batch of file bytes should fill the GPU's inflate lanes once (a little less: a second round for a few
+        // sections would cost as much as the first)
+        bw_target_sections = env_i64("WTAMD_BW_BATCH_SECTIONS", bw_mode ? std::max<int64_t>(wtamd_pipe_bw_fill_sections(pipe) * 31 / 32, 64) : 0);
         n_slots_open = n_slots ? std::min(std::max(n_slots, 2), 8) : 3;     // (wtamd_pipe_create's own clamp)
         if (depth > n_slots_open - 1) depth = n_slots_open - 1;
         bool any_map = false;
@@ -808,7 +813,10 @@ void red_open(RedState *R, int op, uint32_t flags, int n_set0) {
     }
     wtamd_reduce_desc d = { op, flags, n_set0, 0 };
     R->fd.depth = pipe_depth();
-    R->fd.open(d, env_i64("WTAMD_BATCH_RUNS", 4 << 20), R->fd.depth + 1, kReducerFirstSpan);
+    // (file-byte batches are sized to fill the GPU's inflate lanes: ~65 000 sections, ~11 Mbp at 100 dense tracks)
+    bool all_bw = !R->fd.src.empty();
+    for (const auto &s : R->fd.src) all_bw = all_bw && bwdev_reader(s) != nullptr;
+    R->fd.open(d, env_i64("WTAMD_BATCH_RUNS", all_bw ? (16 << 20) : (4 << 20)), R->fd.depth + 1, kReducerFirstSpan);
 }
 
 WiggleIterator *make_reducer(Multiplexer *m, int op) {
@@ -1338,9 +1346,9 @@ bool bwdev_drain_and_submit(Feeder &F) {
     // steer the span towards the byte budget, bounded by the slot's output capacity
     const int64_t max_span = F.max_runs < ((int64_t) 1 << 31) ? F.max_runs : ((int64_t) 1 << 31);
     int64_t want = F.span * 2;
-    if (n_bytes > 0) {
-        const double per_bp = (double) n_bytes / (double) std::max<int64_t>((int64_t) hi - lo, 1);
-        const double w = (double) F.bw_target_bytes / per_bp;
+    if (n_bytes > 0 && !secs.empty()) {
+        const double bp = (double) std::max<int64_t>((int64_t) hi - lo, 1);
+        const double w = std::min((double) F.bw_target_bytes / ((double) n_bytes / bp), (double) F.bw_target_sections / ((double) secs.size() / bp));
         want = w > 4e9 ? (int64_t) 4e9 : (int64_t) w;
         if (want > F.span * 8) want = F.span * 8;
     }

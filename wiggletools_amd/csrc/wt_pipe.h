@@ -30,6 +30,7 @@ int wt_map_chain_async(const void *d_chains, int n_tracks, bool drops, const int
                        const int32_t *finish, const void *value, bool value_is_f64, unsigned long long *scratch,
                        int32_t *o_start, int32_t *o_finish, double *o_value, int64_t *d_seg_out, hipStream_t stream);
 long long wt_bw_scratch_bytes(long long n_sec, long long plain_stride);           // wt_bwdev.hip
+long long wt_bw_fill_sections(int num_cu);
 int wt_bw_decode_async(const void *h_bytes, void *d_bytes, long long n_bytes, const void *d_comp, const void *d_secs, const void *d_tracks, int n_tracks,
                        long long n_sec, long long plain_stride, void *scratch, long long capacity, int32_t *o_start, int32_t *o_finish,
                        float *o_value, int64_t *d_seg_off, unsigned long long *h_status, int copy_blocks, hipStream_t s_copy,
@@ -489,6 +490,11 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
 }
 
 static int64_t wt_align256(int64_t x) { return (x + 255) & ~(int64_t) 255; }
+
+int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *p) {
+    if (!p || p->slots.empty() || !p->slots[0].ts) return 0;
+    return (int64_t) wt_bw_fill_sections(p->slots[0].ts->num_cu);
+}
 
 int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, uint8_t **bytes, wtamd_bw_section **sections) {
     if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_bw_reserve: no acquired slot");
