@@ -268,12 +268,22 @@ def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
     from concurrent.futures import ThreadPoolExecutor
     from wiggletools_amd import dropin, synthgen
     L = int(mbp * 1e6)
-    seg, s, f, v = synthgen.device_tracks(SEED, [L], n_tracks, mean_run, 0.02, 800, device, chrom_ids=[41])
-    hs, hf, hv = s.cpu().numpy(), f.cpu().numpy(), v.cpu().numpy()
-    del s, f, v
-    base = os.environ.get("WTAMD_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 6.0 * len(hs) else None)
-    d = tempfile.mkdtemp(prefix="wtamd_bw_", dir=base)
-    try:
+    keep = os.environ.get("WTAMD_BENCH_BWDIR")          # experiments: files written once, reused by later runs
+    meta = os.path.join(keep, "meta_%d_%d.json" % (n_tracks, L)) if keep else None
+    if keep and os.path.exists(meta):
+        d, write_s = keep, 0.0
+        n_int = json.load(open(meta))["intervals"]
+        jobs = [(os.path.join(d, "t%03d.bw" % t),) for t in range(n_tracks)]
+    else:
+        seg, s, f, v = synthgen.device_tracks(SEED, [L], n_tracks, mean_run, 0.02, 800, device, chrom_ids=[41])
+        hs, hf, hv = s.cpu().numpy(), f.cpu().numpy(), v.cpu().numpy()
+        del s, f, v
+        base = os.environ.get("WTAMD_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 6.0 * len(hs) else None)
+        if keep:
+            os.makedirs(keep, exist_ok=True)
+            d = keep
+        else:
+            d = tempfile.mkdtemp(prefix="wtamd_bw_", dir=base)
         jobs = [(os.path.join(d, "t%03d.bw" % t), L + 1, hs[int(seg[t]):int(seg[t + 1])], hf[int(seg[t]):int(seg[t + 1])],
                  hv[int(seg[t]):int(seg[t + 1])]) for t in range(n_tracks)]
         t0 = time.perf_counter()
@@ -281,11 +291,14 @@ def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
             list(ex.map(_bw_write_one, jobs))
         write_s = time.perf_counter() - t0
         del hs, hf, hv
-        size = sum(os.path.getsize(j[0]) for j in jobs)
         n_int = int(seg[-1])
+        if keep:
+            json.dump({"intervals": n_int}, open(meta, "w"))
+    try:
+        size = sum(os.path.getsize(j[0]) for j in jobs)
         os.environ.pop("WTAMD_BW_DEVICE", None)
         t0 = time.perf_counter()
-        readers = [dropin.bigwig_reader(j[0], box=True) for j in jobs]
+        readers = dropin.bigwig_readers([j[0] for j in jobs], box=True)
         t_readers = time.perf_counter() - t0
         r = dropin.reducer(op, readers, n_set0=n_tracks // 2)
         t_open = time.perf_counter() - t0
@@ -306,6 +319,8 @@ def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
         if len(q) >= 2 and q[-1][0] > q[0][0]:
             out["steady_bp_per_s"] = (q[-1][1] - q[0][1]) / (q[-1][0] - q[0][0])
         # the host-side decoder (round 2's route) on a window of the same files
+        if os.environ.get("WTAMD_BENCH_NO_HOSTDEC"):
+            return out
         try:
             win = int(min(L, 8e6))
             os.environ["WTAMD_BW_DEVICE"] = "0"
@@ -322,7 +337,8 @@ def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
             os.environ.pop("WTAMD_BW_DEVICE", None)
         return out
     finally:
-        shutil.rmtree(d, ignore_errors=True)
+        if not keep:
+            shutil.rmtree(d, ignore_errors=True)
 
 
 def e2e_sharded(ctx, op, n_tracks, mean_run, mbp):

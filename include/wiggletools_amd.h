@@ -540,6 +540,9 @@ WiggleIterator *wtamd_ArrayReader(int n_chrom, const char *const *chrom_names, c
  * thread per file decodes the next chromosome while the current one is consumed.  Bulk-capable.
  * A file that is not BigWig: the reference's message and exit(1). */
 WiggleIterator *wtamd_BigWiggleReader(const char *path, int box);
+/* The same for n files at once, opened side by side on a few threads (every constructor reads its file's index and
+ * primes: ~1-2 ms per file, which 100 tracks would otherwise pay one after the other before the first run). */
+int wtamd_BigWiggleReaders(int n, const char *const *paths, int box, WiggleIterator **out);
 /* Consumer door, for reducers built by this library: the runs from the iterator's current element
  * to the end of the batch it belongs to, as arrays valid until the next call on `wi`.  Returns the
  * number of runs (0 and wi->done at the end).  Mixes freely with pop(). */

@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 
 #include "../../include/wiggletools_amd.h"
@@ -270,7 +272,12 @@ int wt_bw_decode_async(const void *h_bytes, void *d_bytes, long long n_bytes, co
         if (e_ != hipSuccess) return wt_fail_ext(WTAMD_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
     const long long n16 = (n_bytes + 15) / 16;
-    if (n16 > 0) {
+    // the copy engine by default (one contiguous range: no per-range cost), WTAMD_BW_COPY=kernel: the copy kernel
+    static const bool sdma = !(getenv("WTAMD_BW_COPY") && !strcmp(getenv("WTAMD_BW_COPY"), "kernel"));
+    if (n16 > 0 && sdma) {
+        // the copy engine instead of a kernel: nothing of the transfer runs on the CUs the inflate kernel occupies
+        WT_BW_HIP(hipMemcpyAsync(d_bytes, h_bytes, (size_t) n16 * 16, hipMemcpyHostToDevice, s_copy));
+    } else if (n16 > 0) {
         long long grid = copy_blocks > 0 ? copy_blocks : 64;
         const long long need = (n16 + 1023) / 1024;
         if (grid > need) grid = need;

@@ -155,13 +155,16 @@ WT_HD bool wt_inf_overread(const WtInflate &z) {
 // (The queue is SHIFTED, never indexed: one variable index into the state struct and hipcc keeps the whole
 // struct in scratch memory.)  `nxt` is refilled by wt_inf_step's prefetch one step after it was moved into `cur`;
 // the blocking load here serves the block-header code, which reads many words inside one step.
+// HOT = true (the symbol loop): `nxt` is known to be there (a step takes at most two words, the prefetch lands one
+// step after `nxt` was taken) -- no load, hence no wait, on this path.
+template <bool HOT>
 WT_HD uint32_t wt_inf_word(WtInflate &z) {
     const uint32_t w = z.cur.x;
     z.cur.x = z.cur.y; z.cur.y = z.cur.z; z.cur.z = z.cur.w;
     z.qi++;
     z.words++;
     if (z.qi == 4) {
-        if (z.nxt_empty) { z.nxt = wt_inf_load(z, z.in_chunk); z.in_chunk++; }
+        if (!HOT && z.nxt_empty) { z.nxt = wt_inf_load(z, z.in_chunk); z.in_chunk++; }
         z.cur = z.nxt;
         z.qi = 0;
         z.nxt_empty = true;
@@ -184,9 +187,9 @@ WT_HD void wt_inf_begin(WtInflate &z, const uint8_t *src, uint32_t n_bytes, uint
     z.qi = 0;
     z.nxt_empty = false;
     z.words = 0;
-    for (uint32_t k = 0; k < (mis >> 2); k++) (void) wt_inf_word(z);       // whole words before the stream are skipped
+    for (uint32_t k = 0; k < (mis >> 2); k++) (void) wt_inf_word<false>(z);       // whole words before the stream are skipped
     z.words = 0;
-    const uint32_t w0 = wt_inf_word(z);
+    const uint32_t w0 = wt_inf_word<false>(z);
     z.head_bits = 8u * (mis & 3u);
     z.bb = (uint64_t) (w0 >> z.head_bits);
     z.bc = 32 - (int32_t) z.head_bits;
@@ -202,9 +205,10 @@ WT_HD void wt_inf_begin(WtInflate &z, const uint8_t *src, uint32_t n_bytes, uint
 }
 
 // After this bc >= 33 (past the end of the input the last chunk repeats; wt_inf_overread catches it).
+template <bool HOT = false>
 WT_HD void wt_inf_refill(WtInflate &z) {
     if (z.bc <= 32) {
-        z.bb |= (uint64_t) wt_inf_word(z) << z.bc;
+        z.bb |= (uint64_t) wt_inf_word<HOT>(z) << z.bc;
         z.bc += 32;
     }
 }
@@ -453,6 +457,7 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
 }
 
 WT_HD bool wt_inf_step_body(WtInflate &z, const WtInfMem &m);
+WT_HD bool wt_inf_step_cold(WtInflate &z, const WtInfMem &m);
 
 // One step of the state machine.  Returns false once the lane has nothing more to do.
 // The input prefetch brackets the step: the 16-byte load of the chunk after next is ISSUED before the step's
@@ -504,7 +509,7 @@ WT_HD bool wt_inf_step_body(WtInflate &z, const WtInfMem &m) {
         if (z.copy_rem) return true;
     }
     if (z.st == WT_INF_ST_SYM) {
-        wt_inf_refill(z);
+        wt_inf_refill<true>(z);
         int32_t idx;
         if (!wt_inf_code(z, z.llim, z.ladj, idx)) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
         const uint32_t sym = m.perm[idx * S] & 0x1FFu;
@@ -523,7 +528,7 @@ WT_HD bool wt_inf_step_body(WtInflate &z, const WtInfMem &m) {
                 const uint32_t e = (ls - 4u) >> 2;
                 len = ((4u + (ls & 3u)) << e) + 3u + wt_inf_bits(z, (int) e);
             }
-            wt_inf_refill(z);
+            wt_inf_refill<true>(z);
             int32_t di;
             if (!wt_inf_code(z, z.dlim, z.dadj, di) || (uint32_t) di > 29u) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
             const uint32_t word = (uint32_t) di / 6u, dsh = 5u * ((uint32_t) di - 6u * word);
@@ -546,6 +551,13 @@ WT_HD bool wt_inf_step_body(WtInflate &z, const WtInfMem &m) {
         }
         return true;
     }
+    // every other state: rare, and it leaves `nxt` filled -- the symbol loop relies on it (wt_inf_word<true>)
+    const bool more = wt_inf_step_cold(z, m);
+    if (z.nxt_empty) { z.nxt = wt_inf_load(z, z.in_chunk); z.in_chunk++; z.nxt_empty = false; }
+    return more;
+}
+
+WT_HD bool wt_inf_step_cold(WtInflate &z, const WtInfMem &m) {
     if (z.st == WT_INF_ST_STORED) {
         wt_inf_refill(z);
         const uint32_t n = z.stored_rem < 4u ? z.stored_rem : 4u;

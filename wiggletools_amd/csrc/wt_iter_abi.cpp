@@ -822,8 +822,11 @@ void red_open(RedState *R, int op, uint32_t flags, int n_set0) {
 WiggleIterator *make_reducer(Multiplexer *m, int op) {
     RedState *R = new RedState();
     R->multi = m;
+    if (g_trace) fprintf(stderr, "[reducer] take-over %.3f\n", now_ms());
     red_take_over(R, m);
+    if (g_trace) fprintf(stderr, "[reducer] open %.3f\n", now_ms());
     red_open(R, op, m->strict ? WTAMD_STRICT_SET0 : 0u, 0);
+    if (g_trace) fprintf(stderr, "[reducer] opened %.3f\n", now_ms());
     RedData *d = (RedData *) calloc(1, sizeof(RedData));
     d->state = R;
     const double dflt = wtamd_reducer_default(op, m->count, m->default_values);
@@ -1619,6 +1622,7 @@ Multiplexer *newCoreMultiplexer(void *data, int count, void (*popFn)(Multiplexer
 }
 
 Multiplexer *newMultiplexer(WiggleIterator **iters, int count, wt_bool strict) {
+    if (g_trace) fprintf(stderr, "[multiplexer] new %.3f\n", now_ms());
     MuxState *S = new MuxState();
     Multiplexer *m = newCoreMultiplexer(S, count, &mux_pop, &mux_seek);
     m->strict = strict;
@@ -1639,6 +1643,7 @@ Multiplexer *newMultiplexer(WiggleIterator **iters, int count, wt_bool strict) {
         S->fd.defaults.push_back(m->iters[i]->default_value);
     }
     popMultiplexer(m);                                              // primed like multiplexer.c:167
+    if (g_trace) fprintf(stderr, "[multiplexer] primed %.3f\n", now_ms());
     return m;
 }
 
@@ -1820,6 +1825,18 @@ WiggleIterator *wtamd_BigWiggleReader(const char *path, int box) {
     if (r->buf[0].chrom < 0) r->done = true;
     bw_settle(r, wi);
     return wi;
+}
+
+int wtamd_BigWiggleReaders(int n, const char *const *paths, int box, WiggleIterator **out) {
+    if (n < 0 || (n > 0 && (!paths || !out))) return WTAMD_ERR_ARG;
+    if (g_trace) fprintf(stderr, "[readers] open %d files %.3f\n", n, now_ms());
+    const int T = std::max(1, std::min({n, wt_usable_cores(), 16}));
+    std::vector<std::thread> th;
+    for (int w = 0; w < T; w++)
+        th.emplace_back([=] { for (int i = w; i < n; i += T) out[i] = wtamd_BigWiggleReader(paths[i], box); });
+    for (auto &t : th) t.join();
+    if (g_trace) fprintf(stderr, "[readers] opened %.3f\n", now_ms());
+    return WTAMD_OK;
 }
 
 int wtamd_iterator_compress_output(WiggleIterator *wi, int on) {

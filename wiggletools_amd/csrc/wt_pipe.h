@@ -133,6 +133,60 @@ static bool wt_is_pinned(const void *q) {
     return a.type == hipMemoryTypeHost;
 }
 
+// Page-locked host memory is expensive to get (hipHostMalloc pins pages at ~6 GB/s: the three slots of a pipe that
+// streams 300 MB batches cost ~0.25 s) and to give back (hipHostFree waits for the device).  Buffers of 1 MB and more
+// are therefore kept in a process-wide pool when a pipe lets go of them and handed to the next pipe that asks for
+// the same size -- the Multiplexer a reducer takes over, the next reducer of a long-lived process.  Bounded by
+// WTAMD_PINNED_POOL_MB (default 4096; 0 switches the pool off).
+struct WtPinnedPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_list;        // by exact size
+    std::map<void *, size_t> size_of;               // every live buffer that came through here
+    size_t pooled = 0;
+    size_t limit() const {
+        const char *e = getenv("WTAMD_PINNED_POOL_MB");
+        return (size_t) (e ? atoll(e) : 4096) << 20;
+    }
+};
+static WtPinnedPool g_pinned_pool;
+
+static hipError_t wt_host_alloc(void **out, size_t bytes) {
+    if (bytes < 1) bytes = 1;
+    if (bytes >= (1u << 20)) {
+        std::lock_guard<std::mutex> lk(g_pinned_pool.mu);
+        auto it = g_pinned_pool.free_list.find(bytes);
+        if (it != g_pinned_pool.free_list.end()) {
+            *out = it->second;
+            g_pinned_pool.pooled -= bytes;
+            g_pinned_pool.free_list.erase(it);
+            return hipSuccess;
+        }
+    }
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e == hipSuccess && bytes >= (1u << 20)) {
+        std::lock_guard<std::mutex> lk(g_pinned_pool.mu);
+        g_pinned_pool.size_of[*out] = bytes;
+    }
+    return e;
+}
+
+static void wt_host_free(void *q) {
+    if (!q) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_pool.mu);
+        auto it = g_pinned_pool.size_of.find(q);
+        if (it != g_pinned_pool.size_of.end()) {
+            if (g_pinned_pool.pooled + it->second <= g_pinned_pool.limit()) {
+                g_pinned_pool.free_list.emplace(it->second, q);
+                g_pinned_pool.pooled += it->second;
+                return;
+            }
+            g_pinned_pool.size_of.erase(it);
+        }
+    }
+    (void) hipHostFree(q);
+}
+
 struct WtSlot {
     int state = 0;                  // 0 free, 1 acquired, 2 submitted, 3 collected
     // input staging (pinned) and its device twin
@@ -213,28 +267,29 @@ struct wtamd_pipe {
     void *d_chains = nullptr;       // wtamd_pipe_set_map: per-track operator chains on device
     bool map_drops = false;         // ... some operator drops runs: batches are compacted
     int num_cu = 256;
+    int compute_cus = 0;            // CUs the compute stream may use (all of them unless the PCIe kernels have their own)
     wtamd_pipe_stats st{};
 };
 
 static void wt_slot_free(WtSlot &s) {
-    if (s.h_seg) (void) hipHostFree(s.h_seg);
-    if (s.h_start) (void) hipHostFree(s.h_start);
-    if (s.h_finish) (void) hipHostFree(s.h_finish);
-    if (s.h_v32) (void) hipHostFree(s.h_v32);
-    if (s.h_v64) (void) hipHostFree(s.h_v64);
+    if (s.h_seg) wt_host_free(s.h_seg);
+    if (s.h_start) wt_host_free(s.h_start);
+    if (s.h_finish) wt_host_free(s.h_finish);
+    if (s.h_v32) wt_host_free(s.h_v32);
+    if (s.h_v64) wt_host_free(s.h_v64);
     (void) hipFree(s.d_start); (void) hipFree(s.d_finish); (void) hipFree(s.d_value);
     (void) hipFree(s.d_os); (void) hipFree(s.d_of); (void) hipFree(s.d_ov); (void) hipFree(s.d_tile); (void) hipFree(s.d_ip);
     (void) hipFree(s.d_cro);
     (void) hipFree(s.d_cs); (void) hipFree(s.d_cf); (void) hipFree(s.d_cv); (void) hipFree(s.d_cscratch); (void) hipFree(s.d_cn);
-    if (s.h_segs) (void) hipHostFree(s.h_segs);
+    if (s.h_segs) wt_host_free(s.h_segs);
     (void) hipFree(s.d_mstart); (void) hipFree(s.d_mfinish); (void) hipFree(s.d_mvalue); (void) hipFree(s.d_mseg); (void) hipFree(s.d_mscratch);
-    if (s.h_os) (void) hipHostFree(s.h_os);
-    if (s.h_of) (void) hipHostFree(s.h_of);
-    if (s.h_ov) (void) hipHostFree(s.h_ov);
-    if (s.h_tile) (void) hipHostFree(s.h_tile);
-    if (s.h_ip) (void) hipHostFree(s.h_ip);
-    if (s.h_bw) (void) hipHostFree(s.h_bw);
-    if (s.h_bw_status) (void) hipHostFree(s.h_bw_status);
+    if (s.h_os) wt_host_free(s.h_os);
+    if (s.h_of) wt_host_free(s.h_of);
+    if (s.h_ov) wt_host_free(s.h_ov);
+    if (s.h_tile) wt_host_free(s.h_tile);
+    if (s.h_ip) wt_host_free(s.h_ip);
+    if (s.h_bw) wt_host_free(s.h_bw);
+    if (s.h_bw_status) wt_host_free(s.h_bw_status);
     (void) hipFree(s.d_bw); (void) hipFree(s.d_bw_scratch);
     for (hipEvent_t e : {s.e_bwc, s.e_bw0, s.e_bw1})
         if (e) (void) hipEventDestroy(e);
@@ -250,11 +305,11 @@ static void wt_slot_free(WtSlot &s) {
 template <class T>
 static hipError_t wt_pinned_grow(T **p, int64_t old_n, int64_t used, int64_t new_n) {
     T *q = nullptr;
-    const hipError_t e = hipHostMalloc((void **) &q, sizeof(T) * (size_t) (new_n > 0 ? new_n : 1), hipHostMallocDefault);
+    const hipError_t e = wt_host_alloc((void **) &q, sizeof(T) * (size_t) (new_n > 0 ? new_n : 1));
     if (e != hipSuccess) return e;
     if (*p) {
         if (used > 0) memcpy(q, *p, sizeof(T) * (size_t) (used < old_n ? used : old_n));
-        (void) hipHostFree(*p);
+        wt_host_free(*p);
     }
     *p = q;
     return hipSuccess;
@@ -374,15 +429,42 @@ int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
         const int rc = wt_check_desc(&probe, &cfg->desc);
         if (rc != WTAMD_OK) return fail(rc);
     }
-    WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
-    WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_comp, hipStreamNonBlocking));
-    WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+    // The kernels that move data over PCIe (gather, export) are confined to a few CUs and the compute kernels to the
+    // others (CU masks): a wavefront waiting microseconds for host memory holds its CU's memory pipeline, and a
+    // latency-bound compute kernel sharing that CU (the per-lane inflate above all) crawls -- measured: the inflate
+    // kernel took 16.5 ms next to the copy / export kernels, 9.5 ms alone.  WTAMD_PCIE_CUS=0: no masks.
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        WT_PIPE_HIP(hipGetDevice(&dev));
+        WT_PIPE_HIP(hipGetDeviceProperties(&prop, dev));
+        p->num_cu = prop.multiProcessorCount;
+        int pcie_cus = getenv("WTAMD_PCIE_CUS") ? atoi(getenv("WTAMD_PCIE_CUS")) : 16;
+        if (p->num_cu < 64 || pcie_cus < 0 || pcie_cus * 2 > p->num_cu) pcie_cus = 0;
+        if (pcie_cus > 0) {
+            const int words = (p->num_cu + 31) / 32;
+            std::vector<uint32_t> lo((size_t) words, 0u), hi((size_t) words, 0u);
+            for (int c = 0; c < p->num_cu; c++) (c < pcie_cus ? lo : hi)[(size_t) c / 32] |= 1u << (c % 32);
+            if (hipExtStreamCreateWithCUMask(&p->s_copy, (uint32_t) words, lo.data()) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&p->s_out, (uint32_t) words, lo.data()) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&p->s_comp, (uint32_t) words, hi.data()) == hipSuccess) {
+                p->compute_cus = p->num_cu - pcie_cus;
+            } else {
+                (void) hipGetLastError();
+                for (hipStream_t *q : {&p->s_copy, &p->s_out, &p->s_comp}) { if (*q) (void) hipStreamDestroy(*q); *q = nullptr; }
+            }
+        }
+        if (!p->compute_cus) p->compute_cus = p->num_cu;
+    }
+    if (!p->s_copy) WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
+    if (!p->s_comp) WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_comp, hipStreamNonBlocking));
+    if (!p->s_out) WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
     p->slots.resize((size_t) ns);
     const int64_t cap0 = cfg->max_intervals > 0 ? cfg->max_intervals : 4096;
     const int N = cfg->n_tracks;
     std::vector<int64_t> seg0((size_t) N + 1, 0);
     for (auto &s : p->slots) {
-        WT_PIPE_HIP(hipHostMalloc((void **) &s.h_seg, sizeof(int64_t) * ((size_t) N + 1), hipHostMallocDefault));
+        WT_PIPE_HIP(wt_host_alloc((void **) &s.h_seg, sizeof(int64_t) * ((size_t) N + 1)));
         memset(s.h_seg, 0, sizeof(int64_t) * ((size_t) N + 1));
         int rc = wt_slot_grow_input(s, 0, cap0, false);
         if (rc != WTAMD_OK) return fail(rc);
@@ -413,15 +495,13 @@ void wtamd_pipe_destroy(wtamd_pipe *p) {
     if (p->s_copy) (void) hipStreamSynchronize(p->s_copy);
     if (p->s_comp) (void) hipStreamSynchronize(p->s_comp);
     if (p->s_out) (void) hipStreamSynchronize(p->s_out);
-    if (p->s_dec) (void) hipStreamSynchronize(p->s_dec);
     for (auto &s : p->slots) wt_slot_free(s);
-    if (p->s_dec) (void) hipStreamDestroy(p->s_dec);
     if (p->s_copy) (void) hipStreamDestroy(p->s_copy);
     if (p->s_comp) (void) hipStreamDestroy(p->s_comp);
     if (p->s_out) (void) hipStreamDestroy(p->s_out);
     if (p->d_chains) (void) hipFree(p->d_chains);
     for (void *q : p->dead_dev) (void) hipFree(q);
-    for (void *q : p->dead_host) (void) hipHostFree(q);
+    for (void *q : p->dead_host) wt_host_free(q);
     delete p;
 }
 
@@ -493,7 +573,7 @@ static int64_t wt_align256(int64_t x) { return (x + 255) & ~(int64_t) 255; }
 
 int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *p) {
     if (!p || p->slots.empty() || !p->slots[0].ts) return 0;
-    return (int64_t) wt_bw_fill_sections(p->slots[0].ts->num_cu);
+    return (int64_t) wt_bw_fill_sections(p->compute_cus ? p->compute_cus : p->slots[0].ts->num_cu);
 }
 
 int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, uint8_t **bytes, wtamd_bw_section **sections) {
@@ -508,7 +588,7 @@ int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, ui
         if (s.h_bw) p->dead_host.push_back(s.h_bw);
         s.h_bw = nullptr; s.h_bw_cap = 0;
         const int64_t c = need + need / 4;
-        WT_HIP(hipHostMalloc((void **) &s.h_bw, (size_t) c, hipHostMallocDefault));
+        WT_HIP(wt_host_alloc((void **) &s.h_bw, (size_t) c));
         s.h_bw_cap = c;
     }
     s.bw_res_bytes = n_bytes; s.bw_res_secs = n_sections;
@@ -642,16 +722,16 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
         WT_HIP(hipMalloc(&s.d_os, sizeof(int32_t) * c));
         WT_HIP(hipMalloc(&s.d_of, sizeof(int32_t) * c));
         WT_HIP(hipMalloc(&s.d_ov, sizeof(double) * c));
-        WT_HIP(hipHostMalloc((void **) &s.h_os, sizeof(int32_t) * c, hipHostMallocDefault));
-        WT_HIP(hipHostMalloc((void **) &s.h_of, sizeof(int32_t) * c, hipHostMallocDefault));
-        WT_HIP(hipHostMalloc((void **) &s.h_ov, sizeof(double) * c, hipHostMallocDefault));
+        WT_HIP(wt_host_alloc((void **) &s.h_os, sizeof(int32_t) * c));
+        WT_HIP(wt_host_alloc((void **) &s.h_of, sizeof(int32_t) * c));
+        WT_HIP(wt_host_alloc((void **) &s.h_ov, sizeof(double) * c));
         for (void *q : {(void *) s.d_cs, (void *) s.d_cf, (void *) s.d_cv, (void *) s.d_cscratch}) if (q) p->dead_dev.push_back(q);
         s.d_cs = s.d_cf = nullptr; s.d_cv = nullptr; s.d_cscratch = nullptr;
         if (p->tile) {
             WT_HIP(hipMalloc(&s.d_tile, sizeof(double) * c * N));
             WT_HIP(hipMalloc(&s.d_ip, sizeof(uint8_t) * c * N));
-            WT_HIP(hipHostMalloc((void **) &s.h_tile, sizeof(double) * c * N, hipHostMallocDefault));
-            WT_HIP(hipHostMalloc((void **) &s.h_ip, sizeof(uint8_t) * c * N, hipHostMallocDefault));
+            WT_HIP(wt_host_alloc((void **) &s.h_tile, sizeof(double) * c * N));
+            WT_HIP(wt_host_alloc((void **) &s.h_ip, sizeof(uint8_t) * c * N));
         }
         s.ocap = c;
     }
@@ -700,9 +780,11 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     if (bw) {
         // file bytes + tables: one copy kernel; inflate / count / scan / scatter on the decode stream write the
         // run lists and the device-side seg_off[] (the authority downstream: the host's are upper bounds)
-        if (!p->s_dec) WT_HIP(hipStreamCreateWithFlags(&p->s_dec, hipStreamNonBlocking));
+        // (on the COMPUTE stream: HIP maps its streams onto 4 hardware queues, and a fourth stream of the pipe landed
+        // on the copy stream's queue -- the next batch's copy then waited behind this batch's inflate kernel)
+        p->s_dec = p->s_comp;
         if (!s.e_bwc) { WT_HIP(hipEventCreate(&s.e_bwc)); WT_HIP(hipEventCreate(&s.e_bw0)); WT_HIP(hipEventCreate(&s.e_bw1)); }
-        if (!s.h_bw_status) WT_HIP(hipHostMalloc((void **) &s.h_bw_status, 64, hipHostMallocDefault));
+        if (!s.h_bw_status) WT_HIP(wt_host_alloc((void **) &s.h_bw_status, 64));
         const int64_t total = s.bw_off_bytes + wt_align256(bw_bytes + 64);
         if (s.d_bw_cap < total) {
             if (s.d_bw) p->dead_dev.push_back(s.d_bw);
@@ -737,10 +819,10 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
         // one table, one small copy, one kernel for the whole batch
         const int64_t max_segs = 2 * (int64_t) s.direct.size() + 1;
         if (s.seg_cap < max_segs) {
-                    if (s.h_segs) (void) hipHostFree(s.h_segs);
+                    if (s.h_segs) wt_host_free(s.h_segs);
             s.h_segs = nullptr; s.seg_cap = 0;
             const int64_t c = 2 * max_segs;
-            WT_HIP(hipHostMalloc((void **) &s.h_segs, sizeof(WtGatherSeg) * c, hipHostMallocDefault));
+            WT_HIP(wt_host_alloc((void **) &s.h_segs, sizeof(WtGatherSeg) * c));
             s.seg_cap = c;
         }
         int ns = 0;
@@ -925,12 +1007,12 @@ int wtamd_pipe_set_map(wtamd_pipe *p, const wtamd_map_chain *chains) {
 
 void *wtamd_host_alloc(size_t bytes) {
     void *q = nullptr;
-    if (hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    if (wt_host_alloc(&q, bytes ? bytes : 1) != hipSuccess) return nullptr;
     return q;
 }
 
 void wtamd_host_free(void *q) {
-    if (q) (void) hipHostFree(q);
+    if (q) wt_host_free(q);
 }
 
 int wtamd_pipe_get_stats(const wtamd_pipe *p, wtamd_pipe_stats *out) {

@@ -78,6 +78,17 @@ def bigwig_reader(path, box=True):
     return _bind().wtamd_BigWiggleReader(path.encode(), int(box))
 
 
+def bigwig_readers(paths, box=True):
+    """wtamd_BigWiggleReaders: n files opened side by side."""
+    L = _bind()
+    L.wtamd_BigWiggleReaders.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_void_p)]
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    out = (C.c_void_p * len(paths))()
+    if L.wtamd_BigWiggleReaders(len(paths), arr, int(box), out) != 0:
+        raise _lib.WtamdError("wtamd_BigWiggleReaders failed")
+    return list(out)
+
+
 def multiplexer(iters, strict=False):
     L = _bind()
     arr = (C.c_void_p * len(iters))(*iters)
