@@ -247,6 +247,7 @@ struct WtSlot {
     hipEvent_t e_bwc = nullptr, e_bw0 = nullptr, e_bw1 = nullptr;
     bool bw = false;                                 // the batch in flight came as file bytes
     int64_t bw_secs = 0;
+    bool export_pending = false;                     // the runs travel by copy engine once the host knows their count (collect)
 };
 
 struct wtamd_pipe {
@@ -267,7 +268,6 @@ struct wtamd_pipe {
     void *d_chains = nullptr;       // wtamd_pipe_set_map: per-track operator chains on device
     bool map_drops = false;         // ... some operator drops runs: batches are compacted
     int num_cu = 256;
-    int compute_cus = 0;            // CUs the compute stream may use (all of them unless the PCIe kernels have their own)
     wtamd_pipe_stats st{};
 };
 
@@ -429,36 +429,12 @@ int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
         const int rc = wt_check_desc(&probe, &cfg->desc);
         if (rc != WTAMD_OK) return fail(rc);
     }
-    // The kernels that move data over PCIe (gather, export) are confined to a few CUs and the compute kernels to the
-    // others (CU masks): a wavefront waiting microseconds for host memory holds its CU's memory pipeline, and a
-    // latency-bound compute kernel sharing that CU (the per-lane inflate above all) crawls -- measured: the inflate
-    // kernel took 16.5 ms next to the copy / export kernels, 9.5 ms alone.  WTAMD_PCIE_CUS=0: no masks.
-    {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        WT_PIPE_HIP(hipGetDevice(&dev));
-        WT_PIPE_HIP(hipGetDeviceProperties(&prop, dev));
-        p->num_cu = prop.multiProcessorCount;
-        int pcie_cus = getenv("WTAMD_PCIE_CUS") ? atoi(getenv("WTAMD_PCIE_CUS")) : 16;
-        if (p->num_cu < 64 || pcie_cus < 0 || pcie_cus * 2 > p->num_cu) pcie_cus = 0;
-        if (pcie_cus > 0) {
-            const int words = (p->num_cu + 31) / 32;
-            std::vector<uint32_t> lo((size_t) words, 0u), hi((size_t) words, 0u);
-            for (int c = 0; c < p->num_cu; c++) (c < pcie_cus ? lo : hi)[(size_t) c / 32] |= 1u << (c % 32);
-            if (hipExtStreamCreateWithCUMask(&p->s_copy, (uint32_t) words, lo.data()) == hipSuccess &&
-                hipExtStreamCreateWithCUMask(&p->s_out, (uint32_t) words, lo.data()) == hipSuccess &&
-                hipExtStreamCreateWithCUMask(&p->s_comp, (uint32_t) words, hi.data()) == hipSuccess) {
-                p->compute_cus = p->num_cu - pcie_cus;
-            } else {
-                (void) hipGetLastError();
-                for (hipStream_t *q : {&p->s_copy, &p->s_out, &p->s_comp}) { if (*q) (void) hipStreamDestroy(*q); *q = nullptr; }
-            }
-        }
-        if (!p->compute_cus) p->compute_cus = p->num_cu;
-    }
-    if (!p->s_copy) WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
-    if (!p->s_comp) WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_comp, hipStreamNonBlocking));
-    if (!p->s_out) WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+    // (Confining the PCIe-facing kernels to a few CUs with hipExtStreamCreateWithCUMask was tried: the inflate kernel
+    // got slower -- fewer CUs, 21 ms against 13.5 ms per batch -- and the masked streams crashed the process in the
+    // drop-in tests; tools/probes/cumask_probe.hip shows how the mask bits map to CUs on this GPU.)
+    WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_copy, hipStreamNonBlocking));
+    WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_comp, hipStreamNonBlocking));
+    WT_PIPE_HIP(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
     p->slots.resize((size_t) ns);
     const int64_t cap0 = cfg->max_intervals > 0 ? cfg->max_intervals : 4096;
     const int N = cfg->n_tracks;
@@ -573,7 +549,7 @@ static int64_t wt_align256(int64_t x) { return (x + 255) & ~(int64_t) 255; }
 
 int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *p) {
     if (!p || p->slots.empty() || !p->slots[0].ts) return 0;
-    return (int64_t) wt_bw_fill_sections(p->compute_cus ? p->compute_cus : p->slots[0].ts->num_cu);
+    return (int64_t) wt_bw_fill_sections(p->slots[0].ts->num_cu);
 }
 
 int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, uint8_t **bytes, wtamd_bw_section **sections) {
@@ -912,9 +888,22 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
                                s.d_cv, s.d_cn, p->s_comp);
         if (rc != WTAMD_OK) return wt_fail(rc, "run compression launch failed");
     }
-    WT_HIP(hipEventRecord(s.e_cnt, p->s_comp));
-    rc = wt_pipe_enqueue_export(p, s, s.e_cnt);
-    if (rc != WTAMD_OK) return rc;
+    // File-byte batches: the runs go home through the COPY ENGINE, not the export kernel.  Next to a kernel whose
+    // wavefronts wait on the PCIe link the per-lane inflate kernel of the following batch (a serial, latency-bound
+    // lane per stream) took 13.5 ms instead of 9.5; the copy engine costs no CU anything.  It needs the run count on
+    // the host: the counters travel first (128 bytes), the runs are requested when the batch is collected.
+    static const bool sdma_out = !(getenv("WTAMD_BW_EXPORT") && !strcmp(getenv("WTAMD_BW_EXPORT"), "kernel"));
+    s.export_pending = bw && sdma_out && !p->tile;
+    if (s.export_pending) {
+        WT_HIP(hipMemcpyAsync(ts->h_counters, ts->d_counters, sizeof(unsigned long long) * WT_CTR_N, hipMemcpyDeviceToHost, p->s_comp));
+        if (s.compressed)
+            WT_HIP(hipMemcpyAsync(ts->h_counters + WT_CTR_EXPORTED, s.d_cn, sizeof(unsigned long long), hipMemcpyDeviceToHost, p->s_comp));
+        WT_HIP(hipEventRecord(s.e_cnt, p->s_comp));
+    } else {
+        WT_HIP(hipEventRecord(s.e_cnt, p->s_comp));
+        rc = wt_pipe_enqueue_export(p, s, s.e_cnt);
+        if (rc != WTAMD_OK) return rc;
+    }
 
     s.n_int = n; s.f64 = f64; s.err = WTAMD_OK; s.state = 2;
     p->acquired = -1;
@@ -933,7 +922,27 @@ int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
     WtSlot &s = p->slots[(size_t) p->tail];
     if (s.state != 2) return wt_fail(WTAMD_ERR_INTERNAL, "wtamd_pipe_collect: slot order corrupted");
     const auto t_wait0 = std::chrono::steady_clock::now();
-    int rc = wt_wait_event(s.e_d1, "batch");
+    int rc = WTAMD_OK;
+    if (s.export_pending) {
+        s.export_pending = false;
+        rc = wt_wait_event(s.e_cnt, "batch kernels");
+        if (rc == WTAMD_OK) {
+            unsigned long long *hc = s.ts->h_counters;
+            if (!s.compressed) hc[WT_CTR_EXPORTED] = hc[WT_CTR_RUNS];
+            if ((int64_t) hc[WT_CTR_EXPORTED] > s.ocap) hc[WT_CTR_EXPORTED] = (unsigned long long) s.ocap;
+            const size_t nr = (size_t) hc[WT_CTR_EXPORTED];
+            const bool cz = s.compressed;
+            hipError_t e = hipEventRecord(s.e_d0, p->s_out);
+            if (e == hipSuccess && nr > 0) {
+                e = hipMemcpyAsync(s.h_os, cz ? s.d_cs : s.d_os, sizeof(int32_t) * nr, hipMemcpyDeviceToHost, p->s_out);
+                if (e == hipSuccess) e = hipMemcpyAsync(s.h_of, cz ? s.d_cf : s.d_of, sizeof(int32_t) * nr, hipMemcpyDeviceToHost, p->s_out);
+                if (e == hipSuccess) e = hipMemcpyAsync(s.h_ov, cz ? s.d_cv : s.d_ov, sizeof(double) * nr, hipMemcpyDeviceToHost, p->s_out);
+            }
+            if (e == hipSuccess) e = hipEventRecord(s.e_d1, p->s_out);
+            if (e != hipSuccess) rc = wt_fail(WTAMD_ERR_HIP, std::string("copy-engine export: ") + hipGetErrorString(e));
+        }
+    }
+    if (rc == WTAMD_OK) rc = wt_wait_event(s.e_d1, "batch");
     s.state = 3;
     p->in_flight--;
     p->held = 1;
