@@ -306,7 +306,25 @@ struct Feeder {
 
     int n_tracks() const { return (int) src.size(); }
 
+    // what open() was called with: a pipe that was released at the end of the data is opened again by seek()
+    wtamd_reduce_desc o_desc{};
+    int64_t o_max_runs = 0, o_first_span = 0;
+    int o_n_slots = 0;
+    bool opened_once = false, compress_on = false;
+    wtamd_pipe_stats last_stats{};      // of the pipe that was released
+
+    void reopen() { if (!pipe && opened_once) open(o_desc, o_max_runs, o_n_slots, o_first_span); }
+
+    // End of the data: the pipe's streams and buffers go back (the pinned ones into the process-wide pool, for
+    // the next reducer) instead of idling until the process exits.
+    void finish() {
+        if (!pipe) return;
+        wtamd_pipe_get_stats(pipe, &last_stats);
+        close();
+    }
+
     void open(const wtamd_reduce_desc &desc, int64_t max_runs_, int n_slots, int64_t first_span) {
+        o_desc = desc; o_max_runs = max_runs_; o_n_slots = n_slots; o_first_span = first_span; opened_once = true;
         wtamd_pipe_config cfg;
         memset(&cfg, 0, sizeof(cfg));
         cfg.n_tracks = n_tracks();
@@ -327,6 +345,7 @@ struct Feeder {
         bw_dirty = true;
         bw_target_bytes = env_i64("WTAMD_BW_BATCH_BYTES", (int64_t) 1 << 30);
         if (wtamd_pipe_create(&cfg, &pipe) != WTAMD_OK) die("wtamd_pipe_create");
+        if (compress_on && wtamd_pipe_set_compress(pipe, 1) != WTAMD_OK) die("wtamd_pipe_set_compress");
         // a batch of file bytes should fill the GPU's inflate lanes once (a little less: a second round for a few
         // sections would cost as much as the first)
         bw_target_sections = env_i64("WTAMD_BW_BATCH_SECTIONS", bw_mode ? std::max<int64_t>(wtamd_pipe_bw_fill_sections(pipe) * 31 / 32, 64) : 0);
@@ -714,7 +733,7 @@ void mux_pop(Multiplexer *m) {
     }
     if (!F.holding || S->cur >= F.res.n_runs) {
         if (F.holding) F.depth = pipe_depth();
-        if (!F.next()) { m->done = 1; return; }
+        if (!F.next()) { m->done = 1; F.finish(); S->open = false; return; }
         S->cur = 0;
     }
     const int N = m->count;
@@ -769,6 +788,7 @@ void red_pop(WiggleIterator *wi) {
             wi->done = 1;
             if (R->multi) R->multi->done = 1;
             if (R->multiset) R->multiset->done = 1;
+            F.finish();
             return;
         }
         R->cur = 0;
@@ -797,6 +817,7 @@ void red_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
     // seek the children, then pop once.
     RedState *R = red_state(wi);
     for (auto &s : R->fd.src) seek(s.it, chrom, start, finish);
+    R->fd.reopen();
     R->fd.reset();
     R->cur = 0;
     if (R->multi) R->multi->done = 0;
@@ -1842,14 +1863,19 @@ int wtamd_BigWiggleReaders(int n, const char *const *paths, int box, WiggleItera
 int wtamd_iterator_compress_output(WiggleIterator *wi, int on) {
     if (!wi || wi->pop != &red_pop) return WTAMD_ERR_ARG;
     RedState *R = red_state(wi);
-    if (!R->fd.pipe) return WTAMD_ERR_ARG;
+    R->fd.compress_on = on != 0;
+    if (!R->fd.pipe) return R->fd.opened_once ? WTAMD_OK : WTAMD_ERR_ARG;
     return wtamd_pipe_set_compress(R->fd.pipe, on);
 }
 
 int wtamd_iterator_pipe_stats(WiggleIterator *wi, wtamd_pipe_stats *out) {
     if (!wi || !out || wi->pop != &red_pop) return WTAMD_ERR_ARG;
     RedState *R = red_state(wi);
-    if (!R->fd.pipe) return WTAMD_ERR_ARG;
+    if (!R->fd.pipe) {
+        if (!R->fd.opened_once) return WTAMD_ERR_ARG;
+        *out = R->fd.last_stats;
+        return WTAMD_OK;
+    }
     return wtamd_pipe_get_stats(R->fd.pipe, out);
 }
 
