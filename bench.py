@@ -297,27 +297,38 @@ def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
     try:
         size = sum(os.path.getsize(j[0]) for j in jobs)
         os.environ.pop("WTAMD_BW_DEVICE", None)
-        t0 = time.perf_counter()
-        readers = dropin.bigwig_readers([j[0] for j in jobs], box=True)
-        t_readers = time.perf_counter() - t0
-        r = dropin.reducer(op, readers, n_set0=n_tracks // 2)
-        t_open = time.perf_counter() - t0
-        marks = []
-        runs, _ = dropin.drain_blocks(r, on_block=lambda c, a, b, v: (marks.append((time.perf_counter(), int(b[-1]))), 0)[1])
-        dt = time.perf_counter() - t0
-        st = dropin.pipe_stats(r)
-        out = {"tracks": n_tracks, "op": op, "bp": L, "seconds": dt, "bp_per_s": L / dt, "runs": runs,
-               "intervals": n_int, "intervals_per_s": n_int / dt, "file_bytes": size, "file_bytes_per_bp": size / L,
-               "inbound_GBs": size / dt / 1e9, "pcie_h2d_roofline_bp_per_s": 63e9 / (size / L),
-               "open_seconds": t_open, "open_readers_seconds": t_readers, "files_written_s": write_s, "files_dir": d.rsplit("/", 1)[0],
-               "host_cores": effective_cores(), "batches": st.get("batches"),
-               "sections_inflated_on_device": st.get("bw_sections"), "sum_device_decode_ms": st.get("bw_decode_ms"),
-               "sum_kernel_ms": st.get("kernel_ms"), "sum_d2h_ms": st.get("d2h_ms"), "host_submit_ms": st.get("host_submit_ms"),
-               "host_wait_ms": st.get("host_wait_ms"),
-               "decoder": "device (one lane per zlib stream)" if (st.get("bw_sections") or 0) > 0 else "host zlib"}
-        q = [m for m in marks if m[1] >= L // 4]        # ramp-up excluded: from the block ending the first quarter on
-        if len(q) >= 2 and q[-1][0] > q[0][0]:
-            out["steady_bp_per_s"] = (q[-1][1] - q[0][1]) / (q[-1][0] - q[0][0])
+
+        def run_once():
+            t0 = time.perf_counter()
+            readers = dropin.bigwig_readers([j[0] for j in jobs], box=True)
+            t_readers = time.perf_counter() - t0
+            r = dropin.reducer(op, readers, n_set0=n_tracks // 2)
+            t_open = time.perf_counter() - t0
+            marks = []
+            runs, _ = dropin.drain_blocks(r, on_block=lambda c, a, b, v: (marks.append((time.perf_counter(), int(b[-1]))), 0)[1])
+            dt = time.perf_counter() - t0
+            st = dropin.pipe_stats(r)
+            o = {"seconds": dt, "bp_per_s": L / dt, "runs": runs, "intervals_per_s": n_int / dt, "inbound_GBs": size / dt / 1e9,
+                 "open_seconds": t_open, "open_readers_seconds": t_readers, "batches": st.get("batches"),
+                 "sections_inflated_on_device": st.get("bw_sections"), "sum_device_decode_ms": st.get("bw_decode_ms"),
+                 "sum_kernel_ms": st.get("kernel_ms"), "sum_d2h_ms": st.get("d2h_ms"), "host_submit_ms": st.get("host_submit_ms"),
+                 "host_wait_ms": st.get("host_wait_ms")}
+            q = [m for m in marks if m[1] >= L // 4]        # ramp-up excluded: from the block ending the first quarter on
+            if len(q) >= 2 and q[-1][0] > q[0][0]:
+                o["steady_bp_per_s"] = (q[-1][1] - q[0][1]) / (q[-1][0] - q[0][0])
+            return o
+
+        cold = run_once()       # the process's first pipe: hardware queues are created, ~1.7 GB of staging is pinned
+        warm = run_once()       # a long-lived process: queues exist, the pinned pool holds the staging
+        out = {"tracks": n_tracks, "op": op, "bp": L, "intervals": n_int, "file_bytes": size, "file_bytes_per_bp": size / L,
+               "pcie_h2d_roofline_bp_per_s": 63e9 / (size / L), "files_written_s": write_s, "files_dir": d.rsplit("/", 1)[0],
+               "host_cores": effective_cores(),
+               "decoder": "device (one lane per zlib stream)" if (cold.get("sections_inflated_on_device") or 0) > 0 else "host zlib",
+               "timed": "open 100 files (index walk, priming) -> newMultiplexer -> MeanReduction -> every run on the host",
+               # `bp_per_s` = the cold run, everything included; `warm` = the same again in this process; `steady` = ramp-up excluded
+               "seconds": cold["seconds"], "bp_per_s": cold["bp_per_s"], "runs": cold["runs"],
+               "warm_bp_per_s": warm["bp_per_s"], "steady_bp_per_s": warm.get("steady_bp_per_s") or cold.get("steady_bp_per_s"),
+               "cold": cold, "warm": warm}
         # the host-side decoder (round 2's route) on a window of the same files
         if os.environ.get("WTAMD_BENCH_NO_HOSTDEC"):
             return out
@@ -669,6 +680,8 @@ def main():
             # SURVEY 8d metric (1), first pop -> last result on the host, next to the resident-kernel `value`
             res["value_e2e_bulk"] = (res["e2e"].get("bulk") or {}).get("bp_per_s")
             res["value_e2e_bigwig"] = res.get("e2e_bigwig", {}).get("bp_per_s")
+            res["value_e2e_bigwig_warm"] = res.get("e2e_bigwig", {}).get("warm_bp_per_s")
+            res["value_e2e_bigwig_steady"] = res.get("e2e_bigwig", {}).get("steady_bp_per_s")
         if e2e_multi is not None:
             res["e2e_sharded"] = e2e_multi
         if world == 1 and not args.no_cpu_baseline:

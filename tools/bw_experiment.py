@@ -15,12 +15,14 @@ for cfg in sys.argv[2:]:
     for kv in cfg.split():
         k, v = kv.split("=", 1)
         env[k] = v
-    env["WTAMD_E2E_REPS"] = "3"
+    env["WTAMD_E2E_REPS"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_bw_only.py"), mbp], env=env, capture_output=True, text=True)
     for line in r.stdout.strip().splitlines():
         try:
-            d = json.loads(line)
-            print("%-60s total %.3f s  %.3e bp/s  steady %.3e  open %.3f (readers %.3f)  submit %.0f ms  wait %.0f ms  decode %.0f ms  batches %d"
+            d0 = json.loads(line)
+            for kind in ("cold", "warm"):
+              d = d0[kind]
+              print(kind, "%-60s total %.3f s  %.3e bp/s  steady %.3e  open %.3f (readers %.3f)  submit %.0f ms  wait %.0f ms  decode %.0f ms  batches %d"
                   % (cfg or "(defaults)", d["seconds"], d["bp_per_s"], d.get("steady_bp_per_s", 0), d["open_seconds"], d["open_readers_seconds"],
                      d["host_submit_ms"], d["host_wait_ms"], d["sum_device_decode_ms"], d["batches"]), flush=True)
         except Exception as e:

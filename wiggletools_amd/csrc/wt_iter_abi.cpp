@@ -216,13 +216,20 @@ struct DrainPool {
             if (--pending == 0) cv_done.notify_all();
         }
     }
-    void run(std::function<void(int)> j) {
+    void start_job(std::function<void(int)> j) {       // returns at once; wait() before the next job
         std::unique_lock<std::mutex> lk(mu);
         job = std::move(j);
         pending = T;
         gen++;
         cv_go.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    void run(std::function<void(int)> j) {
+        start_job(std::move(j));
+        wait();
     }
     ~DrainPool() {
         { std::lock_guard<std::mutex> lk(mu); quit = true; }
@@ -292,6 +299,20 @@ struct Feeder {
     std::vector<BwDevTrack> bwt;
     DrainPool *io_pool = nullptr;       // parallel pread() of the section bytes
     int64_t bw_target_bytes = 0, bw_target_sections = 0;
+    // the NEXT file-byte batch: planned, its slot acquired and its bytes being read by the I/O threads while the batches
+    // in flight compute (read-ahead: the read of 300 MB is 5 ms of the chain results -> read -> ship -> inflate)
+    struct BwPlanned {
+        bool valid = false, reading = false, failed = false;
+        std::vector<wtamd_bw_section> secs;
+        std::vector<wtamd_bw_track> tracks;
+        struct ReadOp { int fd; int64_t off, len, dst; };
+        std::vector<ReadOp> ops;
+        uint8_t *bytes = nullptr;
+        int64_t n_bytes = 0;
+        int32_t lo = 0, hi = 0;
+        const char *chrom = nullptr;
+    } bwp;
+    bool bw_readahead = true;
     // drain position
     const char *chrom = nullptr;        // chromosome of the batch being / last drained
     bool continuing = false;            // next batch continues `chrom` at next_lo
@@ -344,6 +365,7 @@ struct Feeder {
         bw_mode = desc.op != WTAMD_OP_MULTIPLEX && bwdev_eligible(*this);
         bw_dirty = true;
         bw_target_bytes = env_i64("WTAMD_BW_BATCH_BYTES", (int64_t) 1 << 30);
+        bw_readahead = !(getenv("WTAMD_BW_READAHEAD") && atoi(getenv("WTAMD_BW_READAHEAD")) == 0);
         if (wtamd_pipe_create(&cfg, &pipe) != WTAMD_OK) die("wtamd_pipe_create");
         if (compress_on && wtamd_pipe_set_compress(pipe, 1) != WTAMD_OK) die("wtamd_pipe_set_compress");
         // a batch of file bytes should fill the GPU's inflate lanes once (a little less: a second round for a few
@@ -374,6 +396,7 @@ struct Feeder {
     }
 
     void close() {
+        drop_planned();
         if (pipe) wtamd_pipe_destroy(pipe);
         pipe = nullptr;
         delete pool;
@@ -409,9 +432,19 @@ struct Feeder {
         }
     }
 
+    // A read-ahead batch that will not be shipped: wait for its reads, give the slot back.
+    void drop_planned() {
+        if (!bwp.valid) return;
+        if (bwp.reading && io_pool) io_pool->wait();
+        bwp.reading = false;
+        bwp.valid = false;
+        if (pipe) wtamd_pipe_cancel(pipe);
+    }
+
     // Throws away everything in flight (results included).
     void drop_flights() {
         if (!pipe) return;
+        drop_planned();
         if (holding) { wtamd_pipe_release(pipe); holding = false; flights.pop_front(); }
         while (!flights.empty()) {
             wtamd_pipe_result r;
@@ -834,10 +867,16 @@ void red_open(RedState *R, int op, uint32_t flags, int n_set0) {
     }
     wtamd_reduce_desc d = { op, flags, n_set0, 0 };
     R->fd.depth = pipe_depth();
+    {   // file-byte batches (BigWig children): three in flight -- the chain results home -> read the next bytes -> ship ->
+        // inflate is longer than two batches cover (measured: 4.0 -> 4.2e8 bp/s whole run, 6.3 -> 7.9e8 steady)
+        bool bw_children = !R->fd.src.empty();
+        for (const auto &s : R->fd.src) bw_children = bw_children && bwdev_reader(s) != nullptr;
+        if (bw_children && !getenv("WTAMD_PIPE_DEPTH")) R->fd.depth = 3;
+    }
     // (file-byte batches are sized to fill the GPU's inflate lanes: ~65 000 sections, ~11 Mbp at 100 dense tracks)
     bool all_bw = !R->fd.src.empty();
     for (const auto &s : R->fd.src) all_bw = all_bw && bwdev_reader(s) != nullptr;
-    R->fd.open(d, env_i64("WTAMD_BATCH_RUNS", all_bw ? (16 << 20) : (4 << 20)), R->fd.depth + 1, kReducerFirstSpan);
+    R->fd.open(d, env_i64("WTAMD_BATCH_RUNS", all_bw ? (16 << 20) : (4 << 20)), R->fd.depth + (all_bw ? 2 : 1), kReducerFirstSpan);
 }
 
 WiggleIterator *make_reducer(Multiplexer *m, int op) {
@@ -1259,7 +1298,9 @@ void bwdev_settle(Feeder &F, BwDevTrack &t) {
     }
 }
 
-bool bwdev_drain_and_submit(Feeder &F) {
+// Plans the next batch (sections, window, cursors), acquires a slot for it and starts reading its bytes on the I/O
+// threads.  False: the files are exhausted.
+bool bwdev_plan(Feeder &F) {
     const int N = F.n_tracks();
     if (F.bw_dirty) { bwdev_init(F); F.bw_dirty = false; F.continuing = false; }
     for (auto &t : F.bwt) bwdev_settle(F, t);
@@ -1283,21 +1324,20 @@ bool bwdev_drain_and_submit(Feeder &F) {
     const int64_t hi64 = (int64_t) lo + F.span;
     const int32_t hi = hi64 >= INT32_MAX ? INT32_MAX : (int32_t) hi64;
 
-    const double t_drain0 = g_trace ? now_ms() : 0;
+    const double t_plan0 = g_trace ? now_ms() : 0;
     wtamd_pipe_batch b;
     if (wtamd_pipe_acquire(F.pipe, &b) != WTAMD_OK) die("wtamd_pipe_acquire");
-    // the batch's sections and where their bytes come from
-    struct ReadOp { int fd; int64_t off, len, dst; };
-    std::vector<wtamd_bw_section> secs;
-    std::vector<wtamd_bw_track> tracks((size_t) N);
-    std::vector<ReadOp> ops;
+    Feeder::BwPlanned &P = F.bwp;
+    P.secs.clear(); P.ops.clear();
+    P.tracks.assign((size_t) N, wtamd_bw_track());
+    P.lo = lo; P.hi = hi; P.chrom = F.chrom; P.failed = false;
     int64_t n_bytes = 0;
     bool more = false;
     for (int i = 0; i < N; i++) {
         BwDevTrack &t = F.bwt[(size_t) i];
-        wtamd_bw_track &k = tracks[(size_t) i];
+        wtamd_bw_track &k = P.tracks[(size_t) i];
         memset(&k, 0, sizeof(k));
-        k.first_section = (int32_t) secs.size();
+        k.first_section = (int32_t) P.secs.size();
         k.clip_lo = 1; k.clip_hi = INT32_MAX;
         if (!t.have || t.cname != F.chrom) continue;
         const WtBwLeaf *L = wt_bw_leaves(t.r->bw, nullptr) + t.info.first;
@@ -1313,12 +1353,12 @@ bool bwdev_drain_and_submit(Feeder &F) {
         const int fd = wt_bw_fd(t.r->bw);
         for (int64_t q = t.cursor; q < e; q++) {
             const WtBwLeaf &l = L[q];
-            if (!ops.empty() && ops.back().fd == fd && ops.back().off + ops.back().len == (int64_t) l.offset) ops.back().len += (int64_t) l.size;
-            else ops.push_back(ReadOp{ fd, (int64_t) l.offset, (int64_t) l.size, n_bytes });
+            if (!P.ops.empty() && P.ops.back().fd == fd && P.ops.back().off + P.ops.back().len == (int64_t) l.offset) P.ops.back().len += (int64_t) l.size;
+            else P.ops.push_back(Feeder::BwPlanned::ReadOp{ fd, (int64_t) l.offset, (int64_t) l.size, n_bytes });
             wtamd_bw_section sc;
             sc.comp_off = n_bytes; sc.comp_size = (uint32_t) l.size; sc.track = i;
             sc.leaf_start = l.start_base; sc.leaf_end = l.end_base;
-            secs.push_back(sc);
+            P.secs.push_back(sc);
             n_bytes += (int64_t) l.size;
         }
         k.n_sections = (int32_t) (e - t.cursor);
@@ -1328,34 +1368,29 @@ bool bwdev_drain_and_submit(Feeder &F) {
         if (t.cursor < t.info.count && (int64_t) L[t.cursor].start_base + 1 < (int64_t) t.clip_hi && hi < t.clip_hi) more = true;
         else { t.cursor = t.info.count; }       // nothing of this chromosome is left for this track
     }
-    uint8_t *bytes = nullptr;
+    P.n_bytes = n_bytes;
     wtamd_bw_section *tab = nullptr;
-    if (wtamd_pipe_bw_reserve(F.pipe, n_bytes, (int64_t) secs.size(), &bytes, &tab) != WTAMD_OK) die("wtamd_pipe_bw_reserve");
-    if (!secs.empty()) memcpy(tab, secs.data(), sizeof(wtamd_bw_section) * secs.size());
-    const double t_read0 = g_trace ? now_ms() : 0;
+    if (wtamd_pipe_bw_reserve(F.pipe, n_bytes, (int64_t) P.secs.size(), &P.bytes, &tab) != WTAMD_OK) die("wtamd_pipe_bw_reserve");
+    if (!P.secs.empty()) memcpy(tab, P.secs.data(), sizeof(wtamd_bw_section) * P.secs.size());
     {
         const int T = F.io_pool ? F.io_pool->T : 1;
-        bool failed = false;
-        auto work = [&](int w) {
-            for (size_t q = (size_t) w; q < ops.size(); q += (size_t) T) {
+        Feeder::BwPlanned *pp = &P;
+        auto work = [pp, T](int w) {
+            for (size_t q = (size_t) w; q < pp->ops.size(); q += (size_t) T) {
                 int64_t done = 0;
-                while (done < ops[q].len) {
-                    const ssize_t got = pread(ops[q].fd, bytes + ops[q].dst + done, (size_t) (ops[q].len - done), (off_t) (ops[q].off + done));
-                    if (got <= 0) { failed = true; break; }
+                while (done < pp->ops[q].len) {
+                    const ssize_t got = pread(pp->ops[q].fd, pp->bytes + pp->ops[q].dst + done, (size_t) (pp->ops[q].len - done), (off_t) (pp->ops[q].off + done));
+                    if (got <= 0) { pp->failed = true; break; }
                     done += got;
                 }
             }
         };
-        if (F.io_pool && ops.size() > 1) F.io_pool->run(work); else work(0);
-        if (failed) { fprintf(stderr, "wiggletools_amd: short read of BigWig data sections\n"); exit(1); }
+        if (F.io_pool && P.ops.size() > 1) { F.io_pool->start_job(work); P.reading = true; }
+        else { work(0); P.reading = false; }
     }
-    const double t_sub0 = g_trace ? now_ms() : 0;
-    if (wtamd_pipe_submit_bw(F.pipe, n_bytes, (int64_t) secs.size(), tracks.data(), lo, hi) != WTAMD_OK) die("wtamd_pipe_submit_bw");
-    if (g_trace) fprintf(stderr, "[feeder] bw plan %.3f read %.3f submit %.3f -> %.3f  (%lld sections, %lld bytes, [%d, %d))\n", t_drain0, t_read0,
-                         t_sub0, now_ms(), (long long) secs.size(), (long long) n_bytes, lo, hi);
-    Feeder::Flight fl;
-    fl.chrom = F.chrom;
-    F.flights.push_back(std::move(fl));
+    P.valid = true;
+    if (g_trace) fprintf(stderr, "[feeder] bw plan %.3f -> %.3f  (%lld sections, %lld bytes, [%d, %d))\n", t_plan0, now_ms(),
+                         (long long) P.secs.size(), (long long) n_bytes, lo, hi);
     F.continuing = more;
     F.next_lo = hi;
     if (more) {
@@ -1367,17 +1402,36 @@ bool bwdev_drain_and_submit(Feeder &F) {
         }
         if (first > hi && first < INT32_MAX) F.next_lo = (int32_t) first;
     }
-    // steer the span towards the byte budget, bounded by the slot's output capacity
+    // steer the span towards the section / byte budget, bounded by the slot's output capacity
     const int64_t max_span = F.max_runs < ((int64_t) 1 << 31) ? F.max_runs : ((int64_t) 1 << 31);
     int64_t want = F.span * 2;
-    if (n_bytes > 0 && !secs.empty()) {
+    if (n_bytes > 0 && !P.secs.empty()) {
         const double bp = (double) std::max<int64_t>((int64_t) hi - lo, 1);
-        const double w = std::min((double) F.bw_target_bytes / ((double) n_bytes / bp), (double) F.bw_target_sections / ((double) secs.size() / bp));
+        const double w = std::min((double) F.bw_target_bytes / ((double) n_bytes / bp), (double) F.bw_target_sections / ((double) P.secs.size() / bp));
         want = w > 4e9 ? (int64_t) 4e9 : (int64_t) w;
         if (want > F.span * 8) want = F.span * 8;
     }
     if (want < F.min_span) want = F.min_span;
     F.span = want < max_span ? want : max_span;
+    return true;
+}
+
+bool bwdev_drain_and_submit(Feeder &F) {
+    Feeder::BwPlanned &P = F.bwp;
+    if (!P.valid && !bwdev_plan(F)) return false;
+    const double t_wait0 = g_trace ? now_ms() : 0;
+    if (P.reading) { F.io_pool->wait(); P.reading = false; }
+    if (P.failed) { fprintf(stderr, "wiggletools_amd: short read of BigWig data sections\n"); exit(1); }
+    const double t_sub0 = g_trace ? now_ms() : 0;
+    if (wtamd_pipe_submit_bw(F.pipe, P.n_bytes, (int64_t) P.secs.size(), P.tracks.data(), P.lo, P.hi) != WTAMD_OK) die("wtamd_pipe_submit_bw");
+    if (g_trace) fprintf(stderr, "[feeder] bw read-wait %.3f submit %.3f -> %.3f  [%d, %d)\n", t_wait0, t_sub0, now_ms(), P.lo, P.hi);
+    Feeder::Flight fl;
+    fl.chrom = P.chrom;
+    F.flights.push_back(std::move(fl));
+    P.valid = false;
+    // read-ahead: the next batch's bytes are fetched while the consumer waits for results (needs a free slot:
+    // the pipe was opened with two more slots than batches in flight)
+    if (F.bw_readahead && (int) F.flights.size() + 2 <= F.n_slots_open) (void) bwdev_plan(F);
     return true;
 }
 
