@@ -867,12 +867,6 @@ void red_open(RedState *R, int op, uint32_t flags, int n_set0) {
     }
     wtamd_reduce_desc d = { op, flags, n_set0, 0 };
     R->fd.depth = pipe_depth();
-    {   // file-byte batches (BigWig children): three in flight -- the chain results home -> read the next bytes -> ship ->
-        // inflate is longer than two batches cover (measured: 4.0 -> 4.2e8 bp/s whole run, 6.3 -> 7.9e8 steady)
-        bool bw_children = !R->fd.src.empty();
-        for (const auto &s : R->fd.src) bw_children = bw_children && bwdev_reader(s) != nullptr;
-        if (bw_children && !getenv("WTAMD_PIPE_DEPTH")) R->fd.depth = 3;
-    }
     // (file-byte batches are sized to fill the GPU's inflate lanes: ~65 000 sections, ~11 Mbp at 100 dense tracks)
     bool all_bw = !R->fd.src.empty();
     for (const auto &s : R->fd.src) all_bw = all_bw && bwdev_reader(s) != nullptr;
