@@ -422,6 +422,10 @@ typedef struct {                /* pinned output of the oldest submitted batch, 
     const uint8_t *inplay;      /* WTAMD_OP_MULTIPLEX: n_runs * n_tracks flags, else NULL */
     int64_t covered_bp;         /* sum (finish - start) of the runs the kernels emitted (before compression) */
     int64_t n_intervals;        /* input intervals of the batch */
+    int32_t integ_valid;        /* the batch was integrated on device (wtamd_pipe_set_integrate): start / finish / value are NULL */
+    int32_t reserved;
+    double integ[6];            /* reducers: {sum of (finish - start) * value, span} over the non-NaN runs (statistics.c:62-120);
+                                   WTAMD_OP_MULTIPLEX over 2 tracks: the Pearson moments {n, sum_X, sum_Y, T_XX, T_XY, T_YY} (:414-465) */
 } wtamd_pipe_result;
 
 typedef struct {
@@ -467,6 +471,15 @@ int wtamd_pipe_release(wtamd_pipe *);
  * passed through one by one).  Applying the reference's own wrapper to this output, as the default
  * writer always does (wigWriter.c:263-267), yields exactly what it yields on the uncompressed runs. */
 int wtamd_pipe_set_compress(wtamd_pipe *, int on);
+/* Genome-wide integrators fused into the pipeline (reference AUCIntegrator / MeanIntegrator over a reducer,
+ * PearsonIntegrator over a 2-track Multiplexer: statistics.c:62-127,414-465): batches submitted from now on are
+ * integrated ON THE DEVICE and their runs never cross PCIe -- a result carries 2 (6) doubles instead of 16 bytes
+ * per run.  Sums are two-level (per lane slice, then ordered merge): agreement with the reference's sequential
+ * accumulation to rounding.  Not together with WTAMD_PIPE_COMPRESS. */
+int wtamd_pipe_set_integrate(wtamd_pipe *, int on);
+/* The same integrals of the batch currently held (collected, not released) when it travelled the ordinary way
+ * -- the batch a reducer's constructor primed with before an integrator took it over.  integ[6] as above. */
+int wtamd_pipe_integrate_held(wtamd_pipe *, double *integ);
 /* Submitted batches not yet collected. */
 int wtamd_pipe_in_flight(const wtamd_pipe *);
 int wtamd_pipe_get_stats(const wtamd_pipe *, wtamd_pipe_stats *out);
@@ -543,6 +556,17 @@ WiggleIterator *wtamd_BigWiggleReader(const char *path, int box);
 /* The same for n files at once, opened side by side on a few threads (every constructor reads its file's index and
  * primes: ~1-2 ms per file, which 100 tracks would otherwise pay one after the other before the first run). */
 int wtamd_BigWiggleReaders(int n, const char *const *paths, int box, WiggleIterator **out);
+/* Fused integrators (reference AUCIntegrator / MeanIntegrator, statistics.c:62-127; PearsonIntegrator :414-465; built
+ * by commandParser.c:653-704).  Same contract towards the consumer that prints the result: an iterator to be popped
+ * to its end whose `data` starts with the double result and whose `append` is the source
+ * (PrintStatisticsWiggleIteratorPop, statistics.c:574-590).  Handed a reducer / a 2-track Multiplexer of THIS library
+ * that nothing else has popped yet, the integration happens on the device batch by batch and no per-position run
+ * is exported: the iterator then yields ONE element per batch (the batch's window, value NaN) instead of one per run
+ * -- use the reference's own integrators when something downstream reads the runs.  Anything else: the reference's
+ * per-run pass-through on the host. */
+WiggleIterator *wtamd_AUCIntegrator(WiggleIterator *wi);
+WiggleIterator *wtamd_MeanIntegrator(WiggleIterator *wi);
+WiggleIterator *wtamd_PearsonIntegrator(Multiplexer *multi);
 /* Consumer door, for reducers built by this library: the runs from the iterator's current element
  * to the end of the batch it belongs to, as arrays valid until the next call on `wi`.  Returns the
  * number of runs (0 and wi->done at the end).  Mixes freely with pop(). */

@@ -132,6 +132,8 @@ class Harness:
         L.ref_pearson.argtypes = [C.POINTER(_Tracks)]
         L.ref_auc_of_reduce.restype = C.c_double
         L.ref_auc_of_reduce.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint]
+        L.ref_door_integrate.restype = C.c_double
+        L.ref_door_integrate.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int, C.c_void_p]
         L.ref_set_compress_mode.argtypes = [C.c_int]
         L.ref_set_compress_mode.restype = None
         L.ref_set_modes.argtypes = [C.c_int, C.c_int]
@@ -168,6 +170,15 @@ class Harness:
     def auc_of_reduce(self, t, op, flags=0):
         s, keep = _pack(t)
         return self.L.ref_auc_of_reduce(C.byref(s), _opcode(op), flags)
+
+    def door_integrate(self, t, kind, op="mean", flags=0):
+        """The tested library's fused integrator doors (wtamd_AUCIntegrator / wtamd_MeanIntegrator over reducer `op`,
+        wtamd_PearsonIntegrator over the 2-track Multiplexer); returns (result, pops, d2h bytes, runs)."""
+        s, keep = _pack(t)
+        info = np.zeros(3, np.int64)
+        k = {"auc": 0, "mean": 1, "pearson": 2}[kind]
+        r = self.L.ref_door_integrate(C.byref(s), _opcode(op) if k < 2 else 0, flags, k, info.ctypes.data)
+        return r, int(info[0]), int(info[1]), int(info[2])
 
     def set_compress_mode(self, on):
         """write_reduce asks the reducer to merge its runs on the device (wtamd_iterator_compress_output)."""

@@ -61,6 +61,11 @@ static void (*r_seek)(WiggleIterator *, const char *, int, int);
 static WiggleIterator *(*r_SmartReader)(char *, wt_bool);
 static WiggleIterator *(*r_AUCIntegrator)(WiggleIterator *);
 static WiggleIterator *(*r_PearsonIntegrator)(Multiplexer *);
+/* the tested library's fused integrator doors (wtamd_AUCIntegrator, ...) and its pipeline counters */
+static WiggleIterator *(*r_door_auc)(WiggleIterator *);
+static WiggleIterator *(*r_door_mean)(WiggleIterator *);
+static WiggleIterator *(*r_door_pearson)(Multiplexer *);
+static int (*r_pipe_stats)(WiggleIterator *, void *);
 static WiggleIterator *(*r_CompressionWiggleIterator)(WiggleIterator *);
 static WiggleIterator *(*r_ScaleWiggleIterator)(WiggleIterator *, double);
 static WiggleIterator *(*r_ShiftWiggleIterator)(WiggleIterator *, double);
@@ -107,6 +112,10 @@ int ref_open(const char *path) {
     OPT(r_SmartReader, "SmartReader");
     OPT(r_AUCIntegrator, "AUCIntegrator");
     OPT(r_PearsonIntegrator, "PearsonIntegrator");
+    OPT(r_door_auc, "wtamd_AUCIntegrator");
+    OPT(r_door_mean, "wtamd_MeanIntegrator");
+    OPT(r_door_pearson, "wtamd_PearsonIntegrator");
+    OPT(r_pipe_stats, "wtamd_iterator_pipe_stats");
     OPT(r_CompressionWiggleIterator, "CompressionWiggleIterator");
     OPT(r_ScaleWiggleIterator, "ScaleWiggleIterator");
     OPT(r_ShiftWiggleIterator, "ShiftWiggleIterator");
@@ -516,6 +525,33 @@ double ref_auc_of_reduce(const wto_tracks *t, int op, unsigned flags) {
 }
 
 /* Pearson of tracks 0 and 1 (statistics.c:414-465). */
+/* The tested library's integrator doors: kind 0 AUC, 1 mean over reducer `op`; 2 Pearson over the 2-track
+ * Multiplexer.  info[0] = pops the integrator needed, info[1] = bytes the pipeline shipped device -> host,
+ * info[2] = runs the reducer computed (kinds 0 / 1; -1 when the library has no counters). */
+double ref_door_integrate(const wto_tracks *t, int op, unsigned flags, int kind, int64_t *info) {
+    info[0] = info[1] = info[2] = -1;
+    if (!g_lib) return NAN;
+    char **names = make_names(t->n_chrom);
+    WiggleIterator *a = NULL, *r = NULL;
+    if (kind == 2) {
+        if (t->n_tracks != 2 || !r_door_pearson) return NAN;
+        a = r_door_pearson(make_multiplexer(t, names, 0, 2, 0));
+    } else {
+        if (op < 0 || op > 9 || !(kind ? r_door_mean : r_door_auc)) return NAN;
+        r = r_reduction[op](make_multiplexer(t, names, 0, t->n_tracks, flags & 1u));
+        a = (kind ? r_door_mean : r_door_auc)(r);
+    }
+    int64_t pops = 0;
+    while (!a->done) { r_pop(a); pops++; }
+    info[0] = pops;
+    if (r && r_pipe_stats) {
+        int64_t st[32];
+        memset(st, 0, sizeof st);
+        if (r_pipe_stats(r, st) == 0) { info[1] = st[5]; info[2] = st[2]; }    /* wtamd_pipe_stats: d2h_bytes, runs */
+    }
+    return *(double *) a->data;
+}
+
 double ref_pearson(const wto_tracks *t) {
     if (!g_lib || t->n_tracks != 2 || !r_PearsonIntegrator) return NAN;
     char **names = make_names(t->n_chrom);

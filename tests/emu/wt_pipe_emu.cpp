@@ -48,6 +48,8 @@ struct Slot {
     std::vector<uint8_t> bw_bytes;
     std::vector<wtamd_bw_section> bw_secs;
     int64_t bw_res_bytes = -1, bw_res_secs = -1;
+    bool integrated = false;
+    double integ[6] = {0, 0, 0, 0, 0, 0};
 };
 }  // namespace
 
@@ -60,12 +62,14 @@ struct wtamd_pipe {
     int acquired = -1;
     int in_flight = 0;  // submitted, not collected
     int held = 0;       // collected, not released
-    bool compress = false;
+    bool compress = false, integrate = false;
     std::vector<wtamd_map_chain> chains;    // wtamd_pipe_set_map (empty: off)
     wtamd_pipe_stats st{};
 };
 
 extern "C" {
+static void emu_integrals(const wtamd_pipe *p, const Slot &s, int64_t n, double *g);
+
 
 const char *wtamd_last_error(void) { return g_err.c_str(); }
 
@@ -163,6 +167,8 @@ int wtamd_pipe_put_direct(wtamd_pipe *p, int64_t at, int64_t count, const int32_
     return WTAMD_OK;
 }
 
+// WTEMU_DEVICES: how many GPUs the emulated runtime reports (the drop-in layer's WTAMD_DEVICES dealing is tested with it)
+int wtamd_device_count(void) { const char *e = getenv("WTEMU_DEVICES"); return e && atoi(e) > 0 ? atoi(e) : 1; }
 int wtamd_current_device(void) { return 0; }
 int wtamd_set_device(int) { return WTAMD_OK; }
 void *wtamd_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
@@ -247,7 +253,9 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
     if (r < 0) { g_err = "emulator error " + std::to_string(r); return WTAMD_ERR_INTERNAL; }
     if (r > p->cfg.max_runs) { g_err = "more runs than max_runs"; return WTAMD_ERR_CAPACITY; }
     long long rr = r;
-    if (p->compress && !tile && r > 0) {
+    s.integrated = p->integrate;
+    if (s.integrated) emu_integrals(p, s, r, s.integ);
+    if (p->compress && !tile && r > 0 && !s.integrated) {
         // CompressionWiggleIterator's leader rule (reference unaryOps.c:235-253), sequentially -- with an
         // OPEN START: the batch continues a previous one whose last group may reach into it, so the
         // runs before the first run that leads a group whatever came before it (not contiguous,
@@ -288,6 +296,47 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
     p->in_flight++;
     p->st.batches++; p->st.intervals += n; p->st.runs += rr; p->st.covered_bp += info[4];
     if (info[8]) p->st.delta_batches++;
+    return WTAMD_OK;
+}
+
+// ---- fused integrators (wtamd_pipe_set_integrate): the reference's own sequential updates (statistics.c:62-120,414-465)
+static void emu_integrals(const wtamd_pipe *p, const Slot &s, int64_t n, double *g) {
+    for (int k = 0; k < 6; k++) g[k] = 0;
+    if (p->cfg.desc.op == WTAMD_OP_MULTIPLEX) {
+        double cnt = 0, sx = 0, sy = 0, txx = 0, txy = 0, tyy = 0;
+        for (int64_t r = 0; r < n; r++) {
+            const double X = s.ip[(size_t) (2 * r)] ? s.tile[(size_t) (2 * r)] : p->defaults[0];
+            const double Y = s.ip[(size_t) (2 * r + 1)] ? s.tile[(size_t) (2 * r + 1)] : p->defaults[1];
+            const double L = (double) (s.of[(size_t) r] - s.os[(size_t) r]);
+            if (cnt > 0) {
+                const double omx = sx / cnt, nmx = sx / (cnt + L), omy = sy / cnt, nmy = sy / (cnt + L), ratio = cnt / (cnt + L);
+                txy += (nmx * omy + ratio * X * Y - nmx * Y - nmy * X) * L;
+                txx += (nmx * (omx - 2 * X) + ratio * X * X) * L;
+                tyy += (nmy * (omy - 2 * Y) + ratio * Y * Y) * L;
+            }
+            cnt += L; sx += X * L; sy += Y * L;
+        }
+        g[0] = cnt; g[1] = sx; g[2] = sy; g[3] = txx; g[4] = txy; g[5] = tyy;
+    } else {
+        for (int64_t r = 0; r < n; r++) {
+            const double v = s.ov[(size_t) r];
+            if (v == v) { const double L = (double) (s.of[(size_t) r] - s.os[(size_t) r]); g[0] += L * v; g[1] += L; }
+        }
+    }
+}
+
+int wtamd_pipe_set_integrate(wtamd_pipe *p, int on) {
+    if (!p) return WTAMD_ERR_ARG;
+    if (on && p->cfg.desc.op == WTAMD_OP_MULTIPLEX && p->cfg.n_tracks != 2) { g_err = "fused Pearson needs two tracks"; return WTAMD_ERR_ARG; }
+    p->integrate = on != 0;
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_integrate_held(wtamd_pipe *p, double *integ) {
+    if (!p || !integ || !p->held) { g_err = "no collected batch"; return WTAMD_ERR_ARG; }
+    const Slot &s = p->slots[(size_t) p->tail];
+    if (s.integrated) { for (int k = 0; k < 6; k++) integ[k] = s.integ[k]; return WTAMD_OK; }
+    emu_integrals(p, s, s.n_runs, integ);
     return WTAMD_OK;
 }
 
@@ -418,10 +467,15 @@ int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
     p->in_flight--;
     p->held = 1;
     const bool tile = p->cfg.desc.op == WTAMD_OP_MULTIPLEX;
+    p->st.d2h_bytes += s.integrated ? 176 : s.n_runs * (16 + (tile ? 9 * (int64_t) p->cfg.n_tracks : 0));
     out->n_runs = s.n_runs;
-    out->start = s.os.data(); out->finish = s.of.data(); out->value = s.ov.data();
-    out->tile = tile ? s.tile.data() : nullptr;
-    out->inplay = tile ? s.ip.data() : nullptr;
+    out->integ_valid = s.integrated ? 1 : 0;
+    out->reserved = 0;
+    for (int k = 0; k < 6; k++) out->integ[k] = s.integrated ? s.integ[k] : 0.0;
+    out->start = s.integrated ? nullptr : s.os.data(); out->finish = s.integrated ? nullptr : s.of.data();
+    out->value = s.integrated ? nullptr : s.ov.data();
+    out->tile = (tile && !s.integrated) ? s.tile.data() : nullptr;
+    out->inplay = (tile && !s.integrated) ? s.ip.data() : nullptr;
     out->covered_bp = s.covered;
     out->n_intervals = s.n_int;
     return WTAMD_OK;

@@ -164,3 +164,73 @@ def test_two_rank_pearson_gather_and_ordered_merge(oracle):
     # the order matters only to rounding; a wrong merge formula would not survive a shuffle either
     shuffled = shard.pearson_from_moments([full[c] for c in (3, 0, 4, 2, 1)])
     assert abs(shuffled - exp) <= 1e-9 * abs(exp)
+
+
+def _wilcoxon_worker(rank, world, port, q):
+    """BASELINE config C5 as specified: wilcoxon 50 v 50, chromosomes dealt by the shared work queue, per-position
+    output concatenated in chromosome order, plus the scalar `AUC wilcoxon ...` through an all_reduce."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    store = dist.distributed_c10d._get_default_store()
+    from emu import emu
+    from oracle import oracle as O
+    from wiggletools_amd import shard
+    from wiggletools_amd.runlists import RunLists, synth
+    N = 100
+    t = synth(N, [700, 450, 120, 600], mean_run=6, seed=12, gap_prob=0.05, value_levels=9)
+    order = sorted(range(t.n_chrom), key=lambda c: -(int(t.seg_off[(c + 1) * N]) - int(t.seg_off[c * N])))   # largest first
+    mine, auc_local, runs_local = {}, 0.0, 0.0
+    while True:
+        k = store.add("wt_queue_c5", 1) - 1
+        if k >= len(order):
+            break
+        c = order[k]
+        a, b = int(t.seg_off[c * N]), int(t.seg_off[(c + 1) * N])
+        one = RunLists(1, N, t.seg_off[c * N:(c + 1) * N + 1] - t.seg_off[c * N], t.start[a:b], t.finish[a:b], t.value[a:b], t.defaults)
+        got, _ = emu.reduce(one, "mwu", n_set0=50)
+        mine[c] = tuple(np.asarray(x) for x in got)
+        auc_local += O.auc(got[1], got[2], got[3])
+        runs_local += len(got[0])
+    auc, runs = shard.allreduce_scalars([auc_local, runs_local])
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if rank == 0:
+        q.put((auc, runs, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_wilcoxon_50v50_sharded_with_auc_gather(oracle):
+    import torch.multiprocessing as mp
+    from wiggletools_amd.runlists import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wilcoxon_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    auc, runs, gathered = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    t = synth(100, [700, 450, 120, 600], mean_run=6, seed=12, gap_prob=0.05, value_levels=9)
+    c, s, f, v = oracle.reduce(t.as_dict(), "mwu", n_set0=50)
+    owned = {}
+    for part in gathered:
+        assert not (set(part) & set(owned))            # every chromosome exactly once
+        owned.update(part)
+    assert sorted(owned) == list(range(t.n_chrom))
+    # per-position output concatenated in chromosome order == the unsharded run list, bit for bit
+    S = np.concatenate([owned[k][1] for k in range(t.n_chrom)])
+    F = np.concatenate([owned[k][2] for k in range(t.n_chrom)])
+    V = np.concatenate([owned[k][3] for k in range(t.n_chrom)])
+    C = np.concatenate([np.full(len(owned[k][1]), k) for k in range(t.n_chrom)])
+    assert np.array_equal(C, c) and np.array_equal(S, s) and np.array_equal(F, f)
+    assert np.array_equal(V.view(np.uint64), v.view(np.uint64))
+    assert runs == len(s)
+    ref = oracle.auc(s, f, v)
+    assert abs(auc - ref) <= 1e-9 * abs(ref)

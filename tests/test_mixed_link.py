@@ -136,3 +136,24 @@ def test_reference_writers_over_mapped_dropin_reducers(oracle, M, tmp_path, mop,
         assert a == b, mop
     finally:
         M.set_map(None); R.set_map(None)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_reference_integrator_vs_fused_door(oracle, M, seed, monkeypatch):
+    """`AUC mean ...`: the reference's own AUCIntegrator (statistics.c:103-127) over the drop-in MeanReduction -- it
+    pops every run after a full D2H -- against wtamd_AUCIntegrator over the same reducer, which integrates on the
+    device and ships no run; PearsonIntegrator likewise.  Equal to rounding."""
+    monkeypatch.setenv("WTAMD_MIN_SPAN", "128")
+    monkeypatch.setenv("WTAMD_BATCH_INTERVALS", "500")
+    t = random_case(9900 + seed, max_len=8000, dtype=np.float32)
+    d = t.as_dict()
+    for op in ("mean", "sum", "median"):
+        ref = M.auc_of_reduce(d, op)
+        got, pops, d2h, runs = M.door_integrate(d, "auc", op)
+        assert abs(got - ref) <= 1e-9 * max(1.0, abs(ref)) or (np.isnan(got) and np.isnan(ref)), (op, got, ref)
+        if runs > 4000:
+            assert d2h < 8 * runs          # the reference's route ships 16 bytes per run
+    t2 = random_case(9950 + seed, n_tracks=2, max_len=8000, dtype=np.float32)
+    ref = M.pearson(t2.as_dict())
+    got, pops, _, _ = M.door_integrate(t2.as_dict(), "pearson")
+    assert abs(got - ref) <= 1e-8 * max(1.0, abs(ref)) or (np.isnan(got) and np.isnan(ref))

@@ -2,6 +2,7 @@
 // (what the reference computes once in each reducer's constructor).  Host only.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "../../include/wiggletools_amd.h"
@@ -102,3 +103,35 @@ extern "C" double wtamd_map_default(int map_op, double param, double d) {
     }
 }
 
+extern "C" {
+
+// a := a (+) b on the host, b following a in genome order -- the same pairwise step the kernels use
+void wtamd_pearson_merge(double *a, const double *b) {
+    if (b[0] == 0) return;
+    if (a[0] == 0) { memcpy(a, b, sizeof(double) * 6); return; }
+    const double n = a[0] + b[0];
+    const double dx = b[1] / b[0] - a[1] / a[0], dy = b[2] / b[0] - a[2] / a[0];
+    const double w = a[0] * b[0] / n;
+    a[3] += b[3] + dx * dx * w;
+    a[4] += b[4] + dx * dy * w;
+    a[5] += b[5] + dy * dy * w;
+    a[0] = n; a[1] += b[1]; a[2] += b[2];
+}
+
+// T_XY / sqrt(T_XX T_YY), NaN when a track is constant (statistics.c:421-423: T_XX * T_YY == 0).  The reference's
+// sequential update leaves EXACTLY 0 for a constant track; the same update applied slice by slice and merged leaves
+// rounding noise of the order 1e-16 * n * mean^2 instead (the step subtracts two products of size mean^2), and
+// noise / noise would be returned as a correlation: T below 1e-14 * n * mean^2 (a scatter under 1e-7 of the mean,
+// the resolution of the float32 inputs) counts as constant.
+double wtamd_pearson_finish(const double *m) {
+    double txx = m[3], tyy = m[5];
+    if (m[0] > 0) {
+        const double mx = m[1] / m[0], my = m[2] / m[0];
+        if (txx <= m[0] * mx * mx * 1e-14) txx = 0;
+        if (tyy <= m[0] * my * my * 1e-14) tyy = 0;
+    }
+    const double den = txx * tyy;
+    return den ? m[4] / sqrt(den) : __builtin_nan("");
+}
+
+}  // extern "C"

@@ -516,9 +516,11 @@ __global__ void __launch_bounds__(256) wt_extents_kernel(const int64_t *seg_off,
 
 // AUC: statistics.c:103-120.  Deterministic two-level sum.
 __global__ void __launch_bounds__(256) wt_auc_kernel(const int32_t *start, const int32_t *finish, const double *value,
-                                                      long long n, double *partial, double *partial_span) {
+                                                      long long n, double *partial, double *partial_span,
+                                                      const unsigned long long *n_dev = nullptr) {
     __shared__ double red[256];
     double acc = 0, span = 0;
+    if (n_dev && (long long) *n_dev < n) n = (long long) *n_dev;       // (pipeline: the run count only exists on the device)
     const long long stride = (long long) gridDim.x * blockDim.x;
     for (long long r = (long long) blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
         const double v = value[r];
@@ -600,8 +602,9 @@ __device__ inline void wt_moments_merge(WtMoments &a, const WtMoments &b) {
 
 __global__ void __launch_bounds__(256) wt_pearson_kernel(const int32_t *start, const int32_t *finish, const double *tile,
                                                           const uint8_t *inplay, double dx, double dy, long long n,
-                                                          WtMoments *partial) {
+                                                          WtMoments *partial, const unsigned long long *n_dev = nullptr) {
     __shared__ WtMoments red[256];
+    if (n_dev && (long long) *n_dev < n) n = (long long) *n_dev;
     const long long total_lanes = (long long) gridDim.x * blockDim.x;
     const long long per = (n + total_lanes - 1) / total_lanes;          // contiguous slice per lane
     const long long lane_id = (long long) blockIdx.x * blockDim.x + threadIdx.x;
@@ -626,7 +629,13 @@ __global__ void wt_pearson_final_kernel(const WtMoments *partial, int n, double 
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         WtMoments m = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < n; i++) wt_moments_merge(m, partial[i]);
-        const double den = m.txx * m.tyy;
+        double txx = m.txx, tyy = m.tyy;                               // (constant track: see wtamd_pearson_finish)
+        if (m.n > 0) {
+            const double mx = m.sx / m.n, my = m.sy / m.n;
+            if (txx <= m.n * mx * mx * 1e-14) txx = 0;
+            if (tyy <= m.n * my * my * 1e-14) tyy = 0;
+        }
+        const double den = txx * tyy;
         out[0] = den ? m.txy / sqrt(den) : __builtin_nan("");          // statistics.c:421-423
         out[1] = m.n; out[2] = m.sx; out[3] = m.sy; out[4] = m.txx; out[5] = m.txy; out[6] = m.tyy;
     }
@@ -1501,23 +1510,7 @@ int wtamd_pearson_moments(wtamd_trackset *ts, double *moments) {
     return rc;
 }
 
-// a := a (+) b on the host, b following a in genome order -- the same pairwise step the kernels use
-void wtamd_pearson_merge(double *a, const double *b) {
-    if (b[0] == 0) return;
-    if (a[0] == 0) { memcpy(a, b, sizeof(double) * 6); return; }
-    const double n = a[0] + b[0];
-    const double dx = b[1] / b[0] - a[1] / a[0], dy = b[2] / b[0] - a[2] / a[0];
-    const double w = a[0] * b[0] / n;
-    a[3] += b[3] + dx * dx * w;
-    a[4] += b[4] + dx * dy * w;
-    a[5] += b[5] + dy * dy * w;
-    a[0] = n; a[1] += b[1]; a[2] += b[2];
-}
-
-double wtamd_pearson_finish(const double *m) {
-    const double den = m[3] * m[5];
-    return den ? m[4] / sqrt(den) : __builtin_nan("");          // statistics.c:421-423
-}
+// (wtamd_pearson_merge / wtamd_pearson_finish: host-only, csrc/wt_defaults.cpp)
 
 int wtamd_trackset_validate(wtamd_trackset *ts, int64_t *n_bad, int64_t *first_bad) {
     if (!ts || !n_bad) return wt_fail(WTAMD_ERR_ARG, "NULL argument");

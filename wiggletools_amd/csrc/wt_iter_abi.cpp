@@ -55,6 +55,8 @@
 
 #define WT_WEAK __attribute__((weak))
 
+extern "C" WiggleIterator *NonOverlappingWiggleIterator(WiggleIterator *);     // unaryOps.c:98-103 (weak definition below)
+
 namespace {
 
 [[noreturn]] void die(const char *what) {
@@ -282,11 +284,21 @@ struct Feeder {
     std::vector<TrackSource> src;
     std::vector<double> defaults;
     Interner names;
+    // One pipe per GPU (WTAMD_DEVICES=all | k; default 1): batches -- (chromosome, run-start range) work items, the
+    // reference's own sharding unit, python/wiggletools/parallelWiggleTools.py:63-68,103-113 -- are dealt to the pipes
+    // round robin and collected in submission order, i.e. in (strcmp(chrom), start) order (multiplexer.c:56).
+    // `pipe` is the pipe of the batch being filled / of the next collect.
+    std::vector<wtamd_pipe *> pipes;
+    std::vector<int> pipe_dev;          // device ordinal of every pipe
+    int home_dev = -1;                  // the caller's device: restored after every call into another device's pipe
+    int64_t dealt = 0;                  // batches submitted so far (round robin position)
     wtamd_pipe *pipe = nullptr;
+    wtamd_pipe *held_pipe = nullptr;    // pipe of the batch being read (holding)
     int64_t max_runs = 0;               // output capacity of a slot = upper bound of hi - lo
     int64_t target = 0;                 // intervals per steady-state batch
     int depth = 1;                      // batches kept in flight (at most the pipe's slots - 1)
     int n_slots_open = 3;
+    int n_pipes = 1;                    // depth counts batches in flight PER PIPE
     bool keep_log = false;              // Multiplexer mode: remember what was consumed (take-over pushes it back)
     bool f64_mode = false;              // a value that is not float32-exact was seen
     bool use_bulk = true;               // WTAMD_NO_BULK=1: children of this library are popped like foreign ones
@@ -311,6 +323,7 @@ struct Feeder {
         int64_t n_bytes = 0;
         int32_t lo = 0, hi = 0;
         const char *chrom = nullptr;
+        wtamd_pipe *pipe = nullptr;     // the pipe whose slot was acquired for it
     } bwp;
     bool bw_readahead = true;
     // drain position
@@ -319,11 +332,12 @@ struct Feeder {
     int32_t next_lo = 0;
     int64_t span = kFirstSpan, min_span = kFirstSpan;
     // batches in flight, oldest first
-    struct Flight { const char *chrom; std::vector<int32_t> consumed; };
+    struct Flight { const char *chrom; std::vector<int32_t> consumed; int32_t lo = 0, hi = 0; wtamd_pipe *pipe = nullptr; };
     std::deque<Flight> flights;
     bool holding = false;               // front flight was collected and is being read
     wtamd_pipe_result res{};
     const char *res_chrom = nullptr;
+    int32_t res_lo = 0, res_hi = 0;     // window of the batch being read
 
     int n_tracks() const { return (int) src.size(); }
 
@@ -340,8 +354,28 @@ struct Feeder {
     // the next reducer) instead of idling until the process exits.
     void finish() {
         if (!pipe) return;
-        wtamd_pipe_get_stats(pipe, &last_stats);
+        sum_stats(&last_stats);
         close();
+    }
+
+    // counters of all pipes together
+    void sum_stats(wtamd_pipe_stats *out) const {
+        memset(out, 0, sizeof(*out));
+        for (wtamd_pipe *q : pipes) {
+            wtamd_pipe_stats t;
+            if (wtamd_pipe_get_stats(q, &t) != WTAMD_OK) continue;
+            out->batches += t.batches; out->intervals += t.intervals; out->runs += t.runs; out->covered_bp += t.covered_bp;
+            out->h2d_bytes += t.h2d_bytes; out->d2h_bytes += t.d2h_bytes; out->kernel_ms += t.kernel_ms; out->h2d_ms += t.h2d_ms;
+            out->d2h_ms += t.d2h_ms; out->delta_batches += t.delta_batches; out->n_slots += t.n_slots;
+            out->host_submit_ms += t.host_submit_ms; out->host_wait_ms += t.host_wait_ms;
+            out->bw_sections += t.bw_sections; out->bw_decode_ms += t.bw_decode_ms;
+        }
+    }
+
+    // the pipe the next batch goes to (round robin), made current together with its device
+    void next_fill_pipe() {
+        const size_t k = (size_t) (dealt % (int64_t) pipes.size());
+        pipe = pipes[k];
     }
 
     void open(const wtamd_reduce_desc &desc, int64_t max_runs_, int n_slots, int64_t first_span) {
@@ -366,17 +400,41 @@ struct Feeder {
         bw_dirty = true;
         bw_target_bytes = env_i64("WTAMD_BW_BATCH_BYTES", (int64_t) 1 << 30);
         bw_readahead = !(getenv("WTAMD_BW_READAHEAD") && atoi(getenv("WTAMD_BW_READAHEAD")) == 0);
-        if (wtamd_pipe_create(&cfg, &pipe) != WTAMD_OK) die("wtamd_pipe_create");
-        if (compress_on && wtamd_pipe_set_compress(pipe, 1) != WTAMD_OK) die("wtamd_pipe_set_compress");
+        {
+            // WTAMD_DEVICES: "all" or a count; the pipes sit on the devices following the caller's (modulo the
+            // number of GPUs: a count above it -- a test aid -- puts several pipes on one device)
+            const char *ed = getenv("WTAMD_DEVICES");
+            const int n_dev = std::max(wtamd_device_count(), 1);
+            int want = 1;
+            if (ed && !strcmp(ed, "all")) want = n_dev;
+            else if (ed && atoi(ed) > 0) want = std::min(atoi(ed), 64);
+            if (desc.op == WTAMD_OP_MULTIPLEX) want = 1;        // (a Multiplexer that is popped run by run: one device)
+            home_dev = wtamd_current_device();
+            dealt = 0;
+            for (int k = 0; k < want; k++) {
+                const int dev = ((home_dev >= 0 ? home_dev : 0) + k) % n_dev;
+                if (home_dev >= 0 && wtamd_set_device(dev) != WTAMD_OK) die("wtamd_set_device");
+                wtamd_pipe *q = nullptr;
+                if (wtamd_pipe_create(&cfg, &q) != WTAMD_OK) die("wtamd_pipe_create");
+                pipes.push_back(q);
+                pipe_dev.push_back(dev);
+            }
+            if (home_dev >= 0) (void) wtamd_set_device(home_dev);
+            pipe = pipes[0];
+        }
+        for (wtamd_pipe *q : pipes)
+            if (compress_on && wtamd_pipe_set_compress(q, 1) != WTAMD_OK) die("wtamd_pipe_set_compress");
         // a batch of file bytes should fill the GPU's inflate lanes once (a little less: a second round for a few
         // sections would cost as much as the first)
         bw_target_sections = env_i64("WTAMD_BW_BATCH_SECTIONS", bw_mode ? std::max<int64_t>(wtamd_pipe_bw_fill_sections(pipe) * 31 / 32, 64) : 0);
         n_slots_open = n_slots ? std::min(std::max(n_slots, 2), 8) : 3;     // (wtamd_pipe_create's own clamp)
         if (depth > n_slots_open - 1) depth = n_slots_open - 1;
+        n_pipes = (int) pipes.size();
         bool any_map = false;
         std::vector<wtamd_map_chain> chains;
         for (const auto &s : src) { chains.push_back(s.chain); any_map = any_map || s.chain.n_ops > 0; }
-        if (any_map && wtamd_pipe_set_map(pipe, chains.data()) != WTAMD_OK) die("wtamd_pipe_set_map");
+        for (wtamd_pipe *q : pipes)
+            if (any_map && wtamd_pipe_set_map(q, chains.data()) != WTAMD_OK) die("wtamd_pipe_set_map");
         // parallel draining when every child is popped through the reference's protocol
         bool eligible = !keep_log && !src.empty() && !bw_mode;
         for (const auto &s : src) eligible = eligible && !(s.bulk && use_bulk) && !s.drops;
@@ -397,8 +455,9 @@ struct Feeder {
 
     void close() {
         drop_planned();
-        if (pipe) wtamd_pipe_destroy(pipe);
-        pipe = nullptr;
+        for (wtamd_pipe *q : pipes) wtamd_pipe_destroy(q);
+        pipes.clear(); pipe_dev.clear();
+        pipe = nullptr; held_pipe = nullptr;
         delete pool;
         pool = nullptr;
         delete io_pool;
@@ -438,18 +497,19 @@ struct Feeder {
         if (bwp.reading && io_pool) io_pool->wait();
         bwp.reading = false;
         bwp.valid = false;
-        if (pipe) wtamd_pipe_cancel(pipe);
+        if (bwp.pipe) wtamd_pipe_cancel(bwp.pipe);
     }
 
     // Throws away everything in flight (results included).
     void drop_flights() {
         if (!pipe) return;
         drop_planned();
-        if (holding) { wtamd_pipe_release(pipe); holding = false; flights.pop_front(); }
+        if (holding) { wtamd_pipe_release(held_pipe); holding = false; flights.pop_front(); }
         while (!flights.empty()) {
             wtamd_pipe_result r;
-            if (wtamd_pipe_collect(pipe, &r) != WTAMD_OK) die("wtamd_pipe_collect");
-            wtamd_pipe_release(pipe);
+            wtamd_pipe *q = flights.front().pipe;
+            if (wtamd_pipe_collect(q, &r) != WTAMD_OK) die("wtamd_pipe_collect");
+            wtamd_pipe_release(q);
             flights.pop_front();
         }
     }
@@ -515,10 +575,13 @@ struct Feeder {
 
         const double t_drain0 = g_trace ? now_ms() : 0;
         wtamd_pipe_batch b;
+        next_fill_pipe();
         if (wtamd_pipe_acquire(pipe, &b) != WTAMD_OK) die("wtamd_pipe_acquire");
         if (f64_mode && !b.value64 && wtamd_pipe_grow(pipe, 0, b.capacity, 1, &b) != WTAMD_OK) die("wtamd_pipe_grow");
         Flight fl;
         fl.chrom = chrom;
+        fl.lo = lo; fl.hi = hi;
+        fl.pipe = pipe;
         if (keep_log) fl.consumed.assign((size_t) N, 0);
         int64_t n = 0;
         bool carry = false, more = false;
@@ -675,6 +738,7 @@ struct Feeder {
         if (wtamd_pipe_submit(pipe, f64_mode ? 1 : 0, lo, hi) != WTAMD_OK) die("wtamd_pipe_submit");
         if (g_trace) fprintf(stderr, "[feeder] drain %.3f -> %.3f submit -> %.3f  (%lld intervals, [%d, %d))\n", t_drain0, t_sub0, now_ms(), (long long) n, lo, hi);
         flights.push_back(std::move(fl));
+        dealt++;
         // where the next batch starts: at the cut if an interval reaches it, else at the first
         // interval beyond it (no track is in play in between: no run can start there)
         continuing = more;
@@ -697,7 +761,7 @@ struct Feeder {
     // Next non-empty batch result; false when everything has been delivered.
     bool next() {
         if (holding) {
-            wtamd_pipe_release(pipe);
+            wtamd_pipe_release(held_pipe);
             holding = false;
             if (keep_log) {
                 const Flight &f = flights.front();
@@ -708,15 +772,17 @@ struct Feeder {
         }
         for (;;) {
             if (depth > n_slots_open - 1) depth = n_slots_open - 1;
-            while ((int) flights.size() < depth && drain_and_submit()) { }
+            while ((int) flights.size() < depth * n_pipes && drain_and_submit()) { }
             if (flights.empty()) return false;
             const double t_c0 = g_trace ? now_ms() : 0;
-            if (wtamd_pipe_collect(pipe, &res) != WTAMD_OK) die("wtamd_pipe_collect");
+            held_pipe = flights.front().pipe;
+            if (wtamd_pipe_collect(held_pipe, &res) != WTAMD_OK) die("wtamd_pipe_collect");
             if (g_trace) fprintf(stderr, "[feeder] collect %.3f -> %.3f (%lld runs, %d in flight)\n", t_c0, now_ms(), (long long) res.n_runs, (int) flights.size());
             res_chrom = flights.front().chrom;
+            res_lo = flights.front().lo; res_hi = flights.front().hi;
             holding = true;
-            if (res.n_runs > 0) return true;
-            wtamd_pipe_release(pipe);
+            if (res.n_runs > 0 || res.integ_valid) return true;
+            wtamd_pipe_release(held_pipe);
             holding = false;
             if (keep_log) {
                 const Flight &f = flights.front();
@@ -1320,8 +1386,11 @@ bool bwdev_plan(Feeder &F) {
 
     const double t_plan0 = g_trace ? now_ms() : 0;
     wtamd_pipe_batch b;
+    F.next_fill_pipe();
     if (wtamd_pipe_acquire(F.pipe, &b) != WTAMD_OK) die("wtamd_pipe_acquire");
     Feeder::BwPlanned &P = F.bwp;
+    P.pipe = F.pipe;
+    F.dealt++;                  // (the slot is taken: the next plan goes to the next pipe)
     P.secs.clear(); P.ops.clear();
     P.tracks.assign((size_t) N, wtamd_bw_track());
     P.lo = lo; P.hi = hi; P.chrom = F.chrom; P.failed = false;
@@ -1417,15 +1486,22 @@ bool bwdev_drain_and_submit(Feeder &F) {
     if (P.reading) { F.io_pool->wait(); P.reading = false; }
     if (P.failed) { fprintf(stderr, "wiggletools_amd: short read of BigWig data sections\n"); exit(1); }
     const double t_sub0 = g_trace ? now_ms() : 0;
-    if (wtamd_pipe_submit_bw(F.pipe, P.n_bytes, (int64_t) P.secs.size(), P.tracks.data(), P.lo, P.hi) != WTAMD_OK) die("wtamd_pipe_submit_bw");
+    if (wtamd_pipe_submit_bw(P.pipe, P.n_bytes, (int64_t) P.secs.size(), P.tracks.data(), P.lo, P.hi) != WTAMD_OK) die("wtamd_pipe_submit_bw");
     if (g_trace) fprintf(stderr, "[feeder] bw read-wait %.3f submit %.3f -> %.3f  [%d, %d)\n", t_wait0, t_sub0, now_ms(), P.lo, P.hi);
     Feeder::Flight fl;
     fl.chrom = P.chrom;
+    fl.lo = P.lo; fl.hi = P.hi;
+    fl.pipe = P.pipe;
     F.flights.push_back(std::move(fl));
     P.valid = false;
     // read-ahead: the next batch's bytes are fetched while the consumer waits for results (needs a free slot:
     // the pipe was opened with two more slots than batches in flight)
-    if (F.bw_readahead && (int) F.flights.size() + 2 <= F.n_slots_open) (void) bwdev_plan(F);
+    if (F.bw_readahead) {
+        const wtamd_pipe *target = F.pipes[(size_t) (F.dealt % (int64_t) F.pipes.size())];
+        int busy = 0;           // slots of that pipe in flight or being read by the consumer
+        for (const auto &f : F.flights) busy += f.pipe == target ? 1 : 0;
+        if (busy + 2 <= F.n_slots_open) (void) bwdev_plan(F);
+    }
     return true;
 }
 
@@ -1580,6 +1656,146 @@ void multiset_step(Multiset *s) {
         else if (!m->done && strcmp(m->chrom, s->chrom) == 0 && m->start < fin) fin = m->start;
     }
     s->finish = fin;
+}
+
+// ---------------------------------------------------------------------------
+// Genome-wide integrators (reference statistics.c:62-127 AUC / mean, :414-465 Pearson).  Towards the
+// consumer they are what the reference's are: an iterator popped to its end, `data` starting with the
+// double result, `append` = the source (PrintStatisticsWiggleIteratorPop reads exactly that).  Fused: the
+// source is a reducer (a 2-track Multiplexer) of this library that nothing has popped since its
+// constructor primed it -- the integrals are computed on the device batch by batch
+// (wtamd_pipe_set_integrate), one element per BATCH is handed on.  Otherwise: the reference's per-run
+// pass-through, on the host (like Select / FillIn, this is glue around pop()).
+// ---------------------------------------------------------------------------
+struct IntegData {
+    double res;                 // must stay first: the consumer prints *(double *) wi->data (statistics.c:579)
+    WiggleIterator *source;
+    Multiplexer *multi;
+    int kind;                   // 0 AUC, 1 mean, 2 Pearson
+    int fused;
+    int primed;                 // the held batch of the source has been absorbed
+    double sum, span;
+    double mom[6];              // fused Pearson: moments so far
+    int count;                  // host Pearson: the reference's `int count` (statistics.c:400), sums below
+    double sum_X, sum_Y, T_XX, T_XY, T_YY;
+};
+
+void integ_finish(WiggleIterator *wi, IntegData *d) {
+    if (d->kind == 0) d->res = d->sum;
+    else if (d->kind == 1) { if (d->span > 0) d->res = d->sum / d->span; }
+    else if (d->fused) d->res = wtamd_pearson_finish(d->mom);
+    else if (d->T_XX * d->T_YY != 0.0) d->res = d->T_XY / sqrt(d->T_XX * d->T_YY);
+    wi->done = 1;
+}
+
+void integ_absorb(IntegData *d, Feeder &F) {
+    double g[6];
+    if (F.res.integ_valid) memcpy(g, F.res.integ, sizeof g);
+    else if (wtamd_pipe_integrate_held(F.held_pipe, g) != WTAMD_OK) die("wtamd_pipe_integrate_held");
+    if (d->kind == 2) wtamd_pearson_merge(d->mom, g);
+    else { d->sum += g[0]; d->span += g[1]; if (d->kind == 0) d->res = d->sum; }
+}
+
+void integ_fused_pop(WiggleIterator *wi) {
+    if (wi->done) return;
+    IntegData *d = (IntegData *) wi->data;
+    Feeder &F = d->kind == 2 ? mux_state(d->multi)->fd : red_state(d->source)->fd;
+    if (!d->primed) {
+        d->primed = 1;
+        const bool empty = d->kind == 2 ? d->multi->done != 0 : d->source->done != 0;
+        if (empty || !F.pipe || !F.holding) { integ_finish(wi, d); return; }
+        for (wtamd_pipe *q : F.pipes)
+            if (wtamd_pipe_set_integrate(q, 1) != WTAMD_OK) die("wtamd_pipe_set_integrate");
+    } else if (!F.next()) {
+        if (d->kind == 2) d->multi->done = 1; else d->source->done = 1;
+        F.finish();
+        if (d->kind == 2) mux_state(d->multi)->open = false;
+        integ_finish(wi, d);
+        return;
+    } else if (d->kind == 2) {
+        F.depth = pipe_depth();             // (a Multiplexer primes with one batch in flight)
+    }
+    integ_absorb(d, F);
+    wi->chrom = (char *) F.res_chrom;
+    wi->start = F.res_lo; wi->finish = F.res_hi;
+    wi->value = NAN;
+}
+
+void integ_fused_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
+    // StatisticSeek / MeanSeek / PearsonSeek (statistics.c:38-43,84-88,406-410): seek the source, pop -- the sums go on
+    IntegData *d = (IntegData *) wi->data;
+    if (d->kind == 2) seekMultiplexer(d->multi, chrom, start, finish); else seek(d->source, chrom, start, finish);
+    d->primed = 0;
+    wi->done = 0;
+    integ_fused_pop(wi);
+}
+
+void integ_host_pop(WiggleIterator *wi) {
+    if (wi->done) return;
+    IntegData *d = (IntegData *) wi->data;
+    if (d->kind == 2) {                     // PearsonPop, statistics.c:414-458
+        Multiplexer *m = d->multi;
+        if (m->done) { integ_finish(wi, d); return; }
+        wi->chrom = m->chrom; wi->start = m->start; wi->finish = m->finish; wi->value = m->values[1];
+        const double X = m->inplay[0] ? m->values[0] : m->iters[0]->default_value;
+        const double Y = m->inplay[1] ? m->values[1] : m->iters[1]->default_value;
+        const int length = m->finish - m->start;
+        if (d->count) {
+            const double old_mean_X = d->sum_X / d->count, new_mean_X = d->sum_X / (d->count + length);
+            const double old_mean_Y = d->sum_Y / d->count, new_mean_Y = d->sum_Y / (d->count + length);
+            const double scaling_ratio = (double) d->count / (d->count + length);
+            d->T_XY += (new_mean_X * old_mean_Y + scaling_ratio * X * Y - new_mean_X * Y - new_mean_Y * X) * length;
+            d->T_XX += (new_mean_X * (old_mean_X - 2 * X) + scaling_ratio * X * X) * length;
+            d->T_YY += (new_mean_Y * (old_mean_Y - 2 * Y) + scaling_ratio * Y * Y) * length;
+        }
+        d->count += length;
+        d->sum_X += X * length;
+        d->sum_Y += Y * length;
+        popMultiplexer(m);
+        return;
+    }
+    WiggleIterator *src = d->source;        // MeanPop / AUCPop, statistics.c:62-82,103-120
+    if (src->done) { integ_finish(wi, d); return; }
+    wi->chrom = src->chrom; wi->start = src->start; wi->finish = src->finish; wi->value = src->value;
+    if (!(wi->value != wi->value)) {
+        d->sum += (wi->finish - wi->start) * wi->value;
+        d->span += (wi->finish - wi->start);
+        if (d->kind == 0) d->res = d->sum;
+    }
+    pop(src);
+}
+
+void integ_host_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
+    IntegData *d = (IntegData *) wi->data;
+    if (d->kind == 2) seekMultiplexer(d->multi, chrom, start, finish); else seek(d->source, chrom, start, finish);
+    wi->done = 0;
+    pop(wi);
+}
+
+WiggleIterator *make_integrator(WiggleIterator *src, Multiplexer *multi, int kind) {
+    IntegData *d = (IntegData *) calloc(1, sizeof(IntegData));
+    d->kind = kind;
+    d->multi = multi;
+    d->res = kind == 0 ? 0.0 : NAN;          // statistics.c:98,125,463
+    bool fused = !getenv("WTAMD_NO_FUSED_INTEGRATORS");
+    WiggleIterator *tail;
+    double dflt;
+    if (kind == 2) {
+        MuxState *S = multi->pop == &mux_pop ? mux_state(multi) : nullptr;
+        fused = fused && S && !S->taken_over && multi->count == 2 && (multi->done || (S->open && S->cur == 1 && S->fd.holding));
+        tail = multi->iters[1];
+        dflt = multi->iters[1]->default_value;
+    } else {
+        d->source = NonOverlappingWiggleIterator(src);
+        RedState *R = d->source->pop == &red_pop ? red_state(d->source) : nullptr;
+        fused = fused && R && (d->source->done || (R->cur == 1 && !R->block_done && R->fd.holding && R->fd.pipe));
+        tail = src;
+        dflt = src->default_value;
+    }
+    d->fused = fused ? 1 : 0;
+    WiggleIterator *wi = newWiggleIterator(d, fused ? &integ_fused_pop : &integ_host_pop, fused ? &integ_fused_seek : &integ_host_seek, dflt, 0);
+    wi->append = tail;
+    return wi;
 }
 
 }  // namespace
@@ -1896,6 +2112,13 @@ WiggleIterator *wtamd_BigWiggleReader(const char *path, int box) {
     return wi;
 }
 
+WiggleIterator *wtamd_AUCIntegrator(WiggleIterator *wi) { return make_integrator(wi, nullptr, 0); }
+WiggleIterator *wtamd_MeanIntegrator(WiggleIterator *wi) { return make_integrator(wi, nullptr, 1); }
+WiggleIterator *wtamd_PearsonIntegrator(Multiplexer *multi) {
+    if (multi->count != 2) { puts("wtamd_PearsonIntegrator: the Multiplexer must hold exactly two tracks"); exit(1); }
+    return make_integrator(nullptr, multi, 2);
+}
+
 int wtamd_BigWiggleReaders(int n, const char *const *paths, int box, WiggleIterator **out) {
     if (n < 0 || (n > 0 && (!paths || !out))) return WTAMD_ERR_ARG;
     if (g_trace) fprintf(stderr, "[readers] open %d files %.3f\n", n, now_ms());
@@ -1913,7 +2136,9 @@ int wtamd_iterator_compress_output(WiggleIterator *wi, int on) {
     RedState *R = red_state(wi);
     R->fd.compress_on = on != 0;
     if (!R->fd.pipe) return R->fd.opened_once ? WTAMD_OK : WTAMD_ERR_ARG;
-    return wtamd_pipe_set_compress(R->fd.pipe, on);
+    int rc = WTAMD_OK;
+    for (wtamd_pipe *q : R->fd.pipes) { const int r1 = wtamd_pipe_set_compress(q, on); if (r1 != WTAMD_OK) rc = r1; }
+    return rc;
 }
 
 int wtamd_iterator_pipe_stats(WiggleIterator *wi, wtamd_pipe_stats *out) {
@@ -1924,7 +2149,8 @@ int wtamd_iterator_pipe_stats(WiggleIterator *wi, wtamd_pipe_stats *out) {
         *out = R->fd.last_stats;
         return WTAMD_OK;
     }
-    return wtamd_pipe_get_stats(R->fd.pipe, out);
+    R->fd.sum_stats(out);
+    return WTAMD_OK;
 }
 
 int64_t wtamd_drain(WiggleIterator *wi, int64_t *covered_bp, double *value_sum) {

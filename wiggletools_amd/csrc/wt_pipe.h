@@ -248,10 +248,26 @@ struct WtSlot {
     bool bw = false;                                 // the batch in flight came as file bytes
     int64_t bw_secs = 0;
     bool export_pending = false;                     // the runs travel by copy engine once the host knows their count (collect)
+    // fused integrators (wtamd_pipe_set_integrate): partial sums / moments on device, the batch's integrals in pinned memory
+    char *d_integ = nullptr;
+    double *h_integ = nullptr;
+    bool integrated = false;
+};
+
+// HIP's current device is per thread; a pipe lives on the device that was current when it was created, and the drop-in
+// layer drives several pipes (one per GPU: WTAMD_DEVICES) from one thread.
+struct WtDevGuard {
+    int prev = -1;
+    explicit WtDevGuard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != dev && dev >= 0) { prev = cur; (void) hipSetDevice(dev); }
+    }
+    ~WtDevGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
 };
 
 struct wtamd_pipe {
     wtamd_pipe_config cfg;
+    int device = -1;
     std::vector<double> defaults;
     std::vector<WtSlot> slots;
     int head = 0, tail = 0, acquired = -1, in_flight = 0, held = 0;
@@ -259,6 +275,7 @@ struct wtamd_pipe {
     bool delta_failed = false;      // a batch had many inexact windows: Sum / Mean stay on the general kernel
     bool tile = false;
     bool compress = false;          // WTAMD_PIPE_COMPRESS: batches submitted from now on are merged on device before they travel
+    bool integrate = false;         // wtamd_pipe_set_integrate: batches submitted from now on are integrated on device, no runs travel
     bool gather = true;             // WTAMD_PIPE_GATHER=0: hipMemcpyAsync per range instead of the gather kernel
     int gather_blocks = 64;         // WTAMD_GATHER_BLOCKS
     // buffers a slot outgrew: released when the pipe is destroyed -- hipFree / hipHostFree wait for the
@@ -289,6 +306,8 @@ static void wt_slot_free(WtSlot &s) {
     if (s.h_tile) wt_host_free(s.h_tile);
     if (s.h_ip) wt_host_free(s.h_ip);
     if (s.h_bw) wt_host_free(s.h_bw);
+    if (s.h_integ) wt_host_free(s.h_integ);
+    (void) hipFree(s.d_integ);
     if (s.h_bw_status) wt_host_free(s.h_bw_status);
     (void) hipFree(s.d_bw); (void) hipFree(s.d_bw_scratch);
     for (hipEvent_t e : {s.e_bwc, s.e_bw0, s.e_bw1})
@@ -365,6 +384,35 @@ static int wt_pipe_enqueue_export(wtamd_pipe *p, WtSlot &s, hipEvent_t after) {
     return WTAMD_OK;
 }
 
+// Integrals of the slot's (uncompressed) device runs -> s.h_integ, on `st`: {sum len * value, span} over the non-NaN
+// runs (statistics.c:62-120), or the Pearson moments of the 2-track tile (:414-465).  The run count is read on
+// the device.
+#define WT_INTEG_BLOCKS 256
+static int wt_pipe_enqueue_integ(wtamd_pipe *p, WtSlot &s, hipStream_t st) {
+    const size_t need = sizeof(WtMoments) * WT_INTEG_BLOCKS + sizeof(double) * 16;
+    if (!s.d_integ) WT_HIP(hipMalloc((void **) &s.d_integ, need));
+    if (!s.h_integ) { WT_HIP(wt_host_alloc((void **) &s.h_integ, sizeof(double) * 8)); }
+    const unsigned long long *n_dev = s.ts->d_counters + WT_CTR_RUNS;
+    double *d_out = (double *) (s.d_integ + sizeof(WtMoments) * WT_INTEG_BLOCKS);
+    if (p->tile) {
+        if (p->cfg.n_tracks != 2) return wt_fail(WTAMD_ERR_ARG, "the fused Pearson integrator needs a Multiplexer of exactly two tracks");
+        hipLaunchKernelGGL(wt_pearson_kernel, dim3(WT_INTEG_BLOCKS), dim3(256), 0, st, s.d_os, s.d_of, s.d_tile, s.d_ip, p->defaults[0],
+                           p->defaults[1], (long long) s.ocap, (WtMoments *) s.d_integ, n_dev);
+        hipLaunchKernelGGL(wt_pearson_final_kernel, dim3(1), dim3(64), 0, st, (const WtMoments *) s.d_integ, WT_INTEG_BLOCKS, d_out);
+        WT_HIP(hipGetLastError());
+        WT_HIP(hipMemcpyAsync(s.h_integ, d_out + 1, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
+    } else {
+        double *part = (double *) s.d_integ;
+        hipLaunchKernelGGL(wt_auc_kernel, dim3(WT_INTEG_BLOCKS), dim3(256), 0, st, s.d_os, s.d_of, s.d_ov, (long long) s.ocap, part,
+                           part + WT_INTEG_BLOCKS, n_dev);
+        hipLaunchKernelGGL(wt_auc_final_kernel, dim3(1), dim3(64), 0, st, part, WT_INTEG_BLOCKS, d_out);
+        hipLaunchKernelGGL(wt_auc_final_kernel, dim3(1), dim3(64), 0, st, part + WT_INTEG_BLOCKS, WT_INTEG_BLOCKS, d_out + 1);
+        WT_HIP(hipGetLastError());
+        WT_HIP(hipMemcpyAsync(s.h_integ, d_out, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+    }
+    return WTAMD_OK;
+}
+
 // The batch's export has landed: read the counters; patch + export again if the difference-array
 // launch left windows it could not prove exact.
 static int wt_pipe_finish(wtamd_pipe *p, WtSlot &s) {
@@ -383,10 +431,17 @@ static int wt_pipe_finish(wtamd_pipe *p, WtSlot &s) {
                                    s.d_cv, s.d_cn, p->s_comp);
             if (rc != WTAMD_OK) return wt_fail(rc, "run compression launch failed");
         }
-        WT_HIP(hipEventRecord(s.e_patch, p->s_comp));
-        rc = wt_pipe_enqueue_export(p, s, s.e_patch);
-        if (rc != WTAMD_OK) return rc;
-        rc = wt_wait_event(s.e_d1, "patched result");
+        if (s.integrated) {
+            rc = wt_pipe_enqueue_integ(p, s, p->s_comp);
+            if (rc != WTAMD_OK) return rc;
+            WT_HIP(hipEventRecord(s.e_patch, p->s_comp));
+            rc = wt_wait_event(s.e_patch, "patched integrals");
+        } else {
+            WT_HIP(hipEventRecord(s.e_patch, p->s_comp));
+            rc = wt_pipe_enqueue_export(p, s, s.e_patch);
+            if (rc != WTAMD_OK) return rc;
+            rc = wt_wait_event(s.e_d1, "patched result");
+        }
         if (rc != WTAMD_OK) return rc;
         s.patched = true;
         if (n_bad * 4 > (long long) ts->stats.n_windows) p->delta_failed = true;     // this data: general kernel from now on
@@ -406,6 +461,7 @@ int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
     if ((cfg->flags & WTAMD_PIPE_COMPRESS) && tile) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_create: the Multiplexer tile cannot be compressed");
     if (wtamd_device_count() <= 0) return wt_fail(WTAMD_ERR_NODEVICE, "no HIP device visible");
     wtamd_pipe *p = new wtamd_pipe();
+    (void) hipGetDevice(&p->device);
     p->cfg = *cfg;
     p->defaults.assign(cfg->defaults, cfg->defaults + cfg->n_tracks);
     p->cfg.defaults = p->defaults.data();
@@ -466,6 +522,7 @@ int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
 }
 
 void wtamd_pipe_destroy(wtamd_pipe *p) {
+    WtDevGuard dev_guard_(p ? p->device : -1);
     if (!p) return;
     // everything still in flight must have left the buffers before they are freed
     if (p->s_copy) (void) hipStreamSynchronize(p->s_copy);
@@ -501,6 +558,7 @@ int wtamd_pipe_acquire(wtamd_pipe *p, wtamd_pipe_batch *out) {
 }
 
 int wtamd_pipe_grow(wtamd_pipe *p, int64_t used, int64_t min_capacity, int want_f64, wtamd_pipe_batch *out) {
+    WtDevGuard dev_guard_(p ? p->device : -1);
     if (!p || !out || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_grow: no acquired slot");
     WtSlot &s = p->slots[(size_t) p->acquired];
     if (used > s.cap || used < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_grow: used > capacity");
@@ -512,6 +570,7 @@ int wtamd_pipe_grow(wtamd_pipe *p, int64_t used, int64_t min_capacity, int want_
 
 int wtamd_pipe_put_direct(wtamd_pipe *p, int64_t at, int64_t count, const int32_t *start, const int32_t *finish,
                           const float *value) {
+    WtDevGuard dev_guard_(p ? p->device : -1);
     if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_put_direct: no acquired slot");
     if (count <= 0) return WTAMD_OK;
     if (at < 0 || !start || !finish || !value) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_put_direct: bad arguments");
@@ -539,6 +598,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
                                const wtamd_bw_track *bw_tracks = nullptr, int64_t bw_bytes = 0, int64_t bw_secs = 0);
 
 int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi) {
+    WtDevGuard dev_guard_(p ? p->device : -1);
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = wt_pipe_submit_impl(p, value_is_f64, range_lo, range_hi);
     if (p) p->st.host_submit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -553,6 +613,7 @@ int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *p) {
 }
 
 int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, uint8_t **bytes, wtamd_bw_section **sections) {
+    WtDevGuard dev_guard_(p ? p->device : -1);
     if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_bw_reserve: no acquired slot");
     if (n_bytes < 0 || n_sections < 0 || !bytes || !sections) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_bw_reserve: bad arguments");
     WtSlot &s = p->slots[(size_t) p->acquired];
@@ -575,6 +636,7 @@ int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, ui
 
 int wtamd_pipe_submit_bw(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, const wtamd_bw_track *tracks,
                          int32_t range_lo, int32_t range_hi) {
+    WtDevGuard dev_guard_(p ? p->device : -1);
     const auto t0 = std::chrono::steady_clock::now();
     if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: no acquired slot");
     if (!tracks) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: tracks == NULL");
@@ -875,7 +937,8 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     rc = wt_reduce_plan(ts, plan, op, p->cfg.desc.flags, p->cfg.desc.n_set0, &runs, p->tile ? s.d_tile : nullptr,
                         p->tile ? s.d_ip : nullptr, nullptr, p->s_comp);
     if (rc != WTAMD_OK) return rc;
-    s.compressed = p->compress;
+    s.integrated = p->integrate;
+    s.compressed = p->compress && !s.integrated;
     if (s.compressed) {
         if (!s.d_cs) {          // (grow-only, with the output buffers)
             WT_HIP(hipMalloc(&s.d_cs, sizeof(int32_t) * s.ocap));
@@ -893,8 +956,14 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     // lane per stream) took 13.5 ms instead of 9.5; the copy engine costs no CU anything.  It needs the run count on
     // the host: the counters travel first (128 bytes), the runs are requested when the batch is collected.
     static const bool sdma_out = !(getenv("WTAMD_BW_EXPORT") && !strcmp(getenv("WTAMD_BW_EXPORT"), "kernel"));
-    s.export_pending = bw && sdma_out && !p->tile;
-    if (s.export_pending) {
+    s.export_pending = bw && sdma_out && !p->tile && !s.integrated;
+    if (s.integrated) {
+        // fused integrator: two (six) doubles and the counters go home, the runs stay
+        rc = wt_pipe_enqueue_integ(p, s, p->s_comp);
+        if (rc != WTAMD_OK) return rc;
+        WT_HIP(hipMemcpyAsync(ts->h_counters, ts->d_counters, sizeof(unsigned long long) * WT_CTR_N, hipMemcpyDeviceToHost, p->s_comp));
+        WT_HIP(hipEventRecord(s.e_cnt, p->s_comp));
+    } else if (s.export_pending) {
         WT_HIP(hipMemcpyAsync(ts->h_counters, ts->d_counters, sizeof(unsigned long long) * WT_CTR_N, hipMemcpyDeviceToHost, p->s_comp));
         if (s.compressed)
             WT_HIP(hipMemcpyAsync(ts->h_counters + WT_CTR_EXPORTED, s.d_cn, sizeof(unsigned long long), hipMemcpyDeviceToHost, p->s_comp));
@@ -916,6 +985,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
 }
 
 int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
+    WtDevGuard dev_guard_(p ? p->device : -1);
     if (!p || !out) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
     if (p->in_flight <= 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_collect: nothing in flight");
     if (p->held) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_collect: the previous result was not released");
@@ -923,7 +993,10 @@ int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
     if (s.state != 2) return wt_fail(WTAMD_ERR_INTERNAL, "wtamd_pipe_collect: slot order corrupted");
     const auto t_wait0 = std::chrono::steady_clock::now();
     int rc = WTAMD_OK;
-    if (s.export_pending) {
+    if (s.integrated) {
+        rc = wt_wait_event(s.e_cnt, "batch kernels");
+        if (rc == WTAMD_OK) s.ts->h_counters[WT_CTR_EXPORTED] = s.ts->h_counters[WT_CTR_RUNS];
+    } else if (s.export_pending) {
         s.export_pending = false;
         rc = wt_wait_event(s.e_cnt, "batch kernels");
         if (rc == WTAMD_OK) {
@@ -942,7 +1015,7 @@ int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
             if (e != hipSuccess) rc = wt_fail(WTAMD_ERR_HIP, std::string("copy-engine export: ") + hipGetErrorString(e));
         }
     }
-    if (rc == WTAMD_OK) rc = wt_wait_event(s.e_d1, "batch");
+    if (rc == WTAMD_OK && !s.integrated) rc = wt_wait_event(s.e_d1, "batch");
     s.state = 3;
     p->in_flight--;
     p->held = 1;
@@ -973,14 +1046,18 @@ int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, s.e_h0, s.e_h1) == hipSuccess) p->st.h2d_ms += ms;
     if (hipEventElapsedTime(&ms, s.e_k0, s.e_cnt) == hipSuccess) p->st.kernel_ms += ms;
-    if (hipEventElapsedTime(&ms, s.e_d0, s.e_d1) == hipSuccess) p->st.d2h_ms += ms;
+    if (!s.integrated && hipEventElapsedTime(&ms, s.e_d0, s.e_d1) == hipSuccess) p->st.d2h_ms += ms;
     p->st.runs += s.n_runs;
     p->st.covered_bp += s.covered;
-    p->st.d2h_bytes += s.n_runs * (16 + (p->tile ? 9 * (int64_t) p->cfg.n_tracks : 0));
+    p->st.d2h_bytes += s.integrated ? (int64_t) (sizeof(unsigned long long) * WT_CTR_N + 48) : s.n_runs * (16 + (p->tile ? 9 * (int64_t) p->cfg.n_tracks : 0));
     out->n_runs = s.n_runs;
-    out->start = s.h_os; out->finish = s.h_of; out->value = s.h_ov;
-    out->tile = p->tile ? s.h_tile : nullptr;
-    out->inplay = p->tile ? s.h_ip : nullptr;
+    out->integ_valid = s.integrated ? 1 : 0;
+    out->reserved = 0;
+    for (int k = 0; k < 6; k++) out->integ[k] = s.integrated ? s.h_integ[k] : 0.0;
+    if (s.integrated && !p->tile) { out->integ[2] = out->integ[3] = out->integ[4] = out->integ[5] = 0.0; }
+    out->start = s.integrated ? nullptr : s.h_os; out->finish = s.integrated ? nullptr : s.h_of; out->value = s.integrated ? nullptr : s.h_ov;
+    out->tile = (p->tile && !s.integrated) ? s.h_tile : nullptr;
+    out->inplay = (p->tile && !s.integrated) ? s.h_ip : nullptr;
     out->covered_bp = s.covered;
     out->n_intervals = s.n_int;
     return WTAMD_OK;
@@ -1003,7 +1080,33 @@ int wtamd_pipe_set_compress(wtamd_pipe *p, int on) {
     return WTAMD_OK;
 }
 
+int wtamd_pipe_set_integrate(wtamd_pipe *p, int on) {
+    if (!p) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    if (on && p->tile && p->cfg.n_tracks != 2) return wt_fail(WTAMD_ERR_ARG, "the fused Pearson integrator needs a Multiplexer of exactly two tracks");
+    p->integrate = on != 0;
+    return WTAMD_OK;
+}
+
+int wtamd_pipe_integrate_held(wtamd_pipe *p, double *integ) {
+    WtDevGuard dev_guard_(p ? p->device : -1);
+    if (!p || !integ) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    if (!p->held) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_integrate_held: no collected batch");
+    WtSlot &s = p->slots[(size_t) p->tail];
+    for (int k = 0; k < 6; k++) integ[k] = 0.0;
+    if (!s.integrated) {
+        // the device still holds the batch's runs (d_os / d_of / d_ov, the tile): integrate them there, now
+        int rc = wt_pipe_enqueue_integ(p, s, p->s_comp);
+        if (rc != WTAMD_OK) return rc;
+        WT_HIP(hipEventRecord(s.e_patch, p->s_comp));
+        rc = wt_wait_event(s.e_patch, "integrals of the held batch");
+        if (rc != WTAMD_OK) return rc;
+    }
+    for (int k = 0; k < (p->tile ? 6 : 2); k++) integ[k] = s.h_integ[k];
+    return WTAMD_OK;
+}
+
 int wtamd_pipe_set_map(wtamd_pipe *p, const wtamd_map_chain *chains) {
+    WtDevGuard dev_guard_(p ? p->device : -1);
     if (!p) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
     if (p->in_flight > 0 || p->acquired >= 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_set_map: batches in flight");
     if (p->d_chains) { (void) hipFree(p->d_chains); p->d_chains = nullptr; p->map_drops = false; }

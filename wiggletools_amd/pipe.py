@@ -29,7 +29,8 @@ class PipeBatch(C.Structure):
 
 class PipeResult(C.Structure):
     _fields_ = [("n_runs", C.c_int64), ("start", C.c_void_p), ("finish", C.c_void_p), ("value", C.c_void_p),
-                ("tile", C.c_void_p), ("inplay", C.c_void_p), ("covered_bp", C.c_int64), ("n_intervals", C.c_int64)]
+                ("tile", C.c_void_p), ("inplay", C.c_void_p), ("covered_bp", C.c_int64), ("n_intervals", C.c_int64),
+                ("integ_valid", C.c_int32), ("reserved", C.c_int32), ("integ", C.c_double * 6)]
 
 
 class PipeStats(C.Structure):
