@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_perf.sh "<op> <tracks> <mean_run> [lib-variant]" ...   (runs on the GPU box)
+# usage: tools/perf.sh "<op> <tracks> <mean_run> [lib-variant]" ...   (runs on the GPU box)
 for cfg in "$@"; do
   set -- $cfg
   LIBV=""

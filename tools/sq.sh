@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box: SQ counter passes (instruction mix / busy cycles / instruction cache) of one bench
-# configuration.   usage: tools_sq.sh "<bench args>" [tag]   -> gpurun_out/sq_<tag>/summary.json
+# configuration.   usage: tools/sq.sh "<bench args>" [tag]   -> gpurun_out/sq_<tag>/summary.json
 R=$GRAFT_REPO_ROOT
 TAG=${2:-run}
 OUT=$R/gpurun_out/sq_$TAG

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box: quick sweeps of experiment builds / knobs on one real chromosome (chr21-sized, id 20).
-# usage: tools_sweep.sh "<config> <lib-suffix or -> [ENV=val ...]" ...
+# usage: tools/sweep.sh "<config> <lib-suffix or -> [ENV=val ...]" ...
 cd $GRAFT_REPO_ROOT
 for spec in "$@"; do
   set -- $spec

@@ -27,7 +27,11 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(HERE, s) for s in SRCS if os.path.exists(os.path.join(HERE, s))]
     deps = srcs + [os.path.join(HERE, d) for d in DEPS]
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(d) for d in deps):
+        if verbose:
+            print("wiggletools_amd: libwiggletools_amd.so is newer than its %d sources / headers: REUSED (force=True recompiles)" % len(deps))
         return SO
+    if verbose:
+        print("wiggletools_amd: COMPILING %d sources for gfx950 with hipcc" % len(srcs))
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, ".obj")

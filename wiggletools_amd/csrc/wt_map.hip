@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -145,9 +146,11 @@ __global__ void wm_seg_offsets(int op, double param, const ValT *in, const int64
 // ---------------------------------------------------------------------------
 struct WmChain { int32_t n_ops; int32_t op[WTAMD_MAP_CHAIN_MAX]; double param[WTAMD_MAP_CHAIN_MAX]; double lg[WTAMD_MAP_CHAIN_MAX]; };
 
-template <class ValT>
+// OutT = float: every operator of every chain is float32-exact on float32 input (abs, the comparisons, scale by +-1):
+// the batch stays float32 and with it on the exact difference-array kernels (wt_map_chain_f32_exact).
+template <class ValT, class OutT>
 __global__ void __launch_bounds__(WM_BLOCK) wm_chain_kernel(const WmChain *chains, const int64_t *seg, int n_tracks,
-                                                             const ValT *in, long long n, double *out, uint8_t *keep_flag,
+                                                             const ValT *in, long long n, OutT *out, uint8_t *keep_flag,
                                                              unsigned long long *block_keep) {
     __shared__ unsigned int cnt;
     if (threadIdx.x == 0) cnt = 0;
@@ -168,7 +171,7 @@ __global__ void __launch_bounds__(WM_BLOCK) wm_chain_kernel(const WmChain *chain
         double v = (double) in[g];
         bool keep = true;
         for (int k = 0; k < c.n_ops && keep; k++) v = wm_apply(c.op[k], c.param[k], c.lg[k], v, keep);
-        out[g] = v;
+        out[g] = (OutT) v;
         if (keep_flag) keep_flag[g] = keep ? 1 : 0;
         kept += keep ? 1u : 0u;
     }
@@ -179,10 +182,11 @@ __global__ void __launch_bounds__(WM_BLOCK) wm_chain_kernel(const WmChain *chain
     }
 }
 
+template <class OutT>
 __global__ void __launch_bounds__(WM_BLOCK) wm_compact_flag_kernel(const uint8_t *keep_flag, const int32_t *start, const int32_t *finish,
-                                                                    const double *mapped, long long n,
+                                                                    const OutT *mapped, long long n,
                                                                     const unsigned long long *block_off, int32_t *o_start,
-                                                                    int32_t *o_finish, double *o_value) {
+                                                                    int32_t *o_finish, OutT *o_value) {
     __shared__ unsigned int wave_tot[WM_BLOCK / 64];
     const long long base = (long long) blockIdx.x * WM_TILE;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -236,13 +240,22 @@ long long wt_map_scratch_words(long long capacity) {
 
 bool wt_map_op_drops(int op) { return op == WTAMD_MAP_LN || op == WTAMD_MAP_LOG || op >= WTAMD_MAP_GT; }
 
+// Operators whose result on a float32 value is a float32 whatever the value: |v|, the comparisons (1 or dropped),
+// scale by +-1 (the `diff` idiom: Sum over [a, scale -1 b], commandParser.c:589-600).
+bool wt_map_op_f32_exact(int op, double param) {
+    if (op == WTAMD_MAP_ABS || (op >= WTAMD_MAP_GT && op <= WTAMD_MAP_LTE)) return true;
+    if (op == WTAMD_MAP_SCALE) return param == 1.0 || param == -1.0;
+    if (op == WTAMD_MAP_OFFSET) return param == 0.0;
+    return false;
+}
+
 // d_chains: n_tracks device WmChain records (wt_map_upload_chains).  `drops`: some chain holds an
 // operator that drops runs -- then o_start / o_finish / o_value receive the compacted lists and
 // d_seg_out the new offsets; otherwise only o_value is written (the coordinates and d_seg_in stay
 // what the kernels downstream read).  Everything is enqueued on `stream`, nothing waits.
 int wt_map_chain_async(const void *d_chains, int n_tracks, bool drops, const int64_t *d_seg_in, long long n, const int32_t *start,
                        const int32_t *finish, const void *value, bool value_is_f64, unsigned long long *scratch,
-                       int32_t *o_start, int32_t *o_finish, double *o_value, int64_t *d_seg_out, hipStream_t stream) {
+                       int32_t *o_start, int32_t *o_finish, double *o_value, int64_t *d_seg_out, hipStream_t stream, bool out_f32) {
     if (n <= 0) {
         if (drops) return hipMemsetAsync(d_seg_out, 0, sizeof(int64_t) * ((size_t) n_tracks + 1), stream) == hipSuccess ? WTAMD_OK : WTAMD_ERR_HIP;
         return WTAMD_OK;
@@ -252,15 +265,23 @@ int wt_map_chain_async(const void *d_chains, int n_tracks, bool drops, const int
     unsigned long long *d_blk = scratch + n;
     uint8_t *d_flag = (uint8_t *) (d_blk + nb + 2);
     const WmChain *ch = (const WmChain *) d_chains;
+    if (out_f32 && value_is_f64) return WTAMD_ERR_ARG;      // (float32 output is for float32 input only)
     if (value_is_f64)
-        hipLaunchKernelGGL(wm_chain_kernel<double>, dim3((unsigned) nb), dim3(WM_BLOCK), 0, stream, ch, d_seg_in, n_tracks,
+        hipLaunchKernelGGL((wm_chain_kernel<double, double>), dim3((unsigned) nb), dim3(WM_BLOCK), 0, stream, ch, d_seg_in, n_tracks,
                            (const double *) value, n, d_mapped, drops ? d_flag : nullptr, drops ? d_blk : nullptr);
+    else if (out_f32)
+        hipLaunchKernelGGL((wm_chain_kernel<float, float>), dim3((unsigned) nb), dim3(WM_BLOCK), 0, stream, ch, d_seg_in, n_tracks,
+                           (const float *) value, n, (float *) d_mapped, drops ? d_flag : nullptr, drops ? d_blk : nullptr);
     else
-        hipLaunchKernelGGL(wm_chain_kernel<float>, dim3((unsigned) nb), dim3(WM_BLOCK), 0, stream, ch, d_seg_in, n_tracks,
+        hipLaunchKernelGGL((wm_chain_kernel<float, double>), dim3((unsigned) nb), dim3(WM_BLOCK), 0, stream, ch, d_seg_in, n_tracks,
                            (const float *) value, n, d_mapped, drops ? d_flag : nullptr, drops ? d_blk : nullptr);
     if (drops) {
         hipLaunchKernelGGL(wm_scan_blocks, dim3(1), dim3(64), 0, stream, d_blk, nb, d_blk + nb);
-        hipLaunchKernelGGL(wm_compact_flag_kernel, dim3((unsigned) nb), dim3(WM_BLOCK), 0, stream, d_flag, start, finish, d_mapped, n,
+        if (out_f32)
+            hipLaunchKernelGGL(wm_compact_flag_kernel<float>, dim3((unsigned) nb), dim3(WM_BLOCK), 0, stream, d_flag, start, finish,
+                               (const float *) d_mapped, n, d_blk, o_start, o_finish, (float *) o_value);
+        else
+            hipLaunchKernelGGL(wm_compact_flag_kernel<double>, dim3((unsigned) nb), dim3(WM_BLOCK), 0, stream, d_flag, start, finish, d_mapped, n,
                            d_blk, o_start, o_finish, o_value);
         hipLaunchKernelGGL(wm_seg_offsets_flag, dim3((unsigned) ((n_tracks + 1 + 255) / 256)), dim3(256), 0, stream, d_flag, d_seg_in,
                            (long long) n_tracks, n, d_blk, d_blk + nb, d_seg_out);
@@ -269,9 +290,15 @@ int wt_map_chain_async(const void *d_chains, int n_tracks, bool drops, const int
 }
 
 // Host chains -> device records (log of the base / radix precomputed as wtamd_runs_map does).
-int wt_map_upload_chains(const wtamd_map_chain *chains, int n_tracks, void **d_out, bool *drops) {
+int wt_map_upload_chains(const wtamd_map_chain *chains, int n_tracks, void **d_out, bool *drops, bool *f32_exact) {
     std::vector<WmChain> h((size_t) n_tracks);
     *drops = false;
+    if (f32_exact) {
+        *f32_exact = !getenv("WTAMD_MAP_F64");
+        for (int t = 0; t < n_tracks && *f32_exact; t++)
+            for (int k = 0; k < chains[t].n_ops && k < WTAMD_MAP_CHAIN_MAX; k++)
+                if (!wt_map_op_f32_exact(chains[t].op[k], chains[t].param[k])) *f32_exact = false;
+    }
     for (int t = 0; t < n_tracks; t++) {
         const wtamd_map_chain &c = chains[t];
         if (c.n_ops < 0 || c.n_ops > WTAMD_MAP_CHAIN_MAX) return wt_fail_ext(WTAMD_ERR_ARG, "wtamd_pipe_set_map: chain length");

@@ -25,10 +25,10 @@
 
 // wt_compress.hip
 long long wt_map_scratch_words(long long capacity);                             // wt_map.hip
-int wt_map_upload_chains(const wtamd_map_chain *chains, int n_tracks, void **d_out, bool *drops);
+int wt_map_upload_chains(const wtamd_map_chain *chains, int n_tracks, void **d_out, bool *drops, bool *f32_exact);
 int wt_map_chain_async(const void *d_chains, int n_tracks, bool drops, const int64_t *d_seg_in, long long n, const int32_t *start,
                        const int32_t *finish, const void *value, bool value_is_f64, unsigned long long *scratch,
-                       int32_t *o_start, int32_t *o_finish, double *o_value, int64_t *d_seg_out, hipStream_t stream);
+                       int32_t *o_start, int32_t *o_finish, double *o_value, int64_t *d_seg_out, hipStream_t stream, bool out_f32);
 long long wt_bw_scratch_bytes(long long n_sec, long long plain_stride);           // wt_bwdev.hip
 long long wt_bw_fill_sections(int num_cu);
 int wt_bw_decode_async(const void *h_bytes, void *d_bytes, long long n_bytes, const void *d_comp, const void *d_secs, const void *d_tracks, int n_tracks,
@@ -284,6 +284,7 @@ struct wtamd_pipe {
     std::vector<void *> dead_dev, dead_host;
     void *d_chains = nullptr;       // wtamd_pipe_set_map: per-track operator chains on device
     bool map_drops = false;         // ... some operator drops runs: batches are compacted
+    bool map_f32 = false;           // ... every operator is float32-exact: float32 batches stay float32 (and on the exact kernels)
     int num_cu = 256;
     wtamd_pipe_stats st{};
 };
@@ -797,7 +798,8 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     }
     ts->range_lo[0] = range_lo;
     ts->range_hi[0] = range_hi;
-    ts->value_f64 = f64 || mapped;
+    const bool map_f32 = mapped && p->map_f32 && !f64;
+    ts->value_f64 = f64 || (mapped && !map_f32);
     ts->scratch_f32 = !ts->value_f64 && wt_defaults_fit_f32(ts->defaults.data(), N);
     // mapped batches: the kernels read the operator chains' output (the host-side seg_off[] / extents stay those
     // of the raw lists: upper bounds, which is all the planning needs)
@@ -918,7 +920,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     WT_HIP(hipEventRecord(s.e_k0, p->s_comp));
     if (mapped) {
         rc = wt_map_chain_async(p->d_chains, N, p->map_drops, compacted ? s.d_mseg : ts->d_seg_off, (long long) n, s.d_start, s.d_finish,
-                                s.d_value, f64, s.d_mscratch, s.d_mstart, s.d_mfinish, s.d_mvalue, ts->d_seg_off, p->s_comp);
+                                s.d_value, f64, s.d_mscratch, s.d_mstart, s.d_mfinish, s.d_mvalue, ts->d_seg_off, p->s_comp, map_f32);
         if (rc != WTAMD_OK) return wt_fail(rc, "operator chain launch failed");
     }
     wtamd_runs runs{};
@@ -1109,12 +1111,12 @@ int wtamd_pipe_set_map(wtamd_pipe *p, const wtamd_map_chain *chains) {
     WtDevGuard dev_guard_(p ? p->device : -1);
     if (!p) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
     if (p->in_flight > 0 || p->acquired >= 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_set_map: batches in flight");
-    if (p->d_chains) { (void) hipFree(p->d_chains); p->d_chains = nullptr; p->map_drops = false; }
+    if (p->d_chains) { (void) hipFree(p->d_chains); p->d_chains = nullptr; p->map_drops = false; p->map_f32 = false; }
     if (!chains) return WTAMD_OK;
     bool any = false;
     for (int t = 0; t < p->cfg.n_tracks; t++) any = any || chains[t].n_ops != 0;
     if (!any) return WTAMD_OK;
-    return wt_map_upload_chains(chains, p->cfg.n_tracks, &p->d_chains, &p->map_drops);
+    return wt_map_upload_chains(chains, p->cfg.n_tracks, &p->d_chains, &p->map_drops, &p->map_f32);
 }
 
 void *wtamd_host_alloc(size_t bytes) {
