@@ -47,7 +47,7 @@ def pmc(dirn, ctr):
         for r in csv.DictReader(open(f)):
             name = r.get("Kernel_Name", "")
             if "wt_" not in name or r.get("Counter_Name") != ctr: continue
-            per.setdefault(name.split("(")[0][:70], []).append(float(r["Counter_Value"]))
+            per.setdefault(name.replace("(anonymous namespace)::", "").split("(")[0][:70], []).append(float(r["Counter_Value"]))
     return {k: {"launches": len(v), "mean": sum(v) / len(v), "max": max(v)} for k, v in per.items()}
 summary = {"c2": {"fetch": pmc("/tmp/p_fetch", "FETCH_SIZE"), "write": pmc("/tmp/p_write", "WRITE_SIZE")},
            "bigwig": {"fetch": pmc("/tmp/b_fetch", "FETCH_SIZE"), "write": pmc("/tmp/b_write", "WRITE_SIZE")}}
