@@ -9,7 +9,8 @@ def build(force=False):
     so = os.path.join(HERE, "libwt_emu.so")
     srcs = [os.path.join(HERE, "wt_emu.cpp"),
             os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc", "wt_core.h"),
-            os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc", "wt_plan.h")]
+            os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc", "wt_plan.h"),
+            os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc", "wt_delta.h")]
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
         return so
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",

@@ -186,6 +186,13 @@ WT_DEV void wt_lds_or32(uint32_t *p, uint32_t v) { *p |= v; }
 WT_DEV void wt_lds_and32(uint32_t *p, uint32_t v) { *p &= v; }
 WT_DEV void wt_lds_min32(int32_t *p, int32_t v) { if (v < *p) *p = v; }
 WT_DEV void wt_lds_add64(unsigned long long *p, unsigned long long v) { *p += v; }
+WT_DEV void wt_lds_sub64(unsigned long long *p, unsigned long long v) { *p -= v; }
+WT_DEV int32_t wt_uniform32(int32_t x) { return x; }
+// wave-wide reductions: the emulator runs one lane at a time, every lane is its own wave and its leader
+WT_DEV int32_t wt_wave_min_i32(int32_t x) { return x; }
+WT_DEV uint32_t wt_wave_min_u32(uint32_t x) { return x; }
+WT_DEV uint32_t wt_wave_max_u32(uint32_t x) { return x; }
+WT_DEV bool wt_wave_leader(int lane) { return true; }
 WT_DEV unsigned long long wt_glb_add64(unsigned long long *p, unsigned long long v) {
     unsigned long long o = *p; *p += v; return o;
 }
@@ -210,6 +217,28 @@ WT_DEV void wt_lds_or32(uint32_t *p, uint32_t v) { atomicOr((unsigned int *) p, 
 WT_DEV void wt_lds_and32(uint32_t *p, uint32_t v) { atomicAnd((unsigned int *) p, (unsigned int) v); }
 WT_DEV void wt_lds_min32(int32_t *p, int32_t v) { atomicMin(p, v); }
 WT_DEV void wt_lds_add64(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
+WT_DEV void wt_lds_sub64(unsigned long long *p, unsigned long long v) {      // ds_sub_u64: no negation in registers
+    __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+WT_DEV int32_t wt_uniform32(int32_t x) { return (int32_t) __builtin_amdgcn_readfirstlane((unsigned) x); }
+// Wave-wide reductions by xor butterfly: every lane ends with the result.  (An LDS atomic issued by all 64
+// lanes is turned by hipcc into a scalar loop over the active lanes -- ~450 SALU instructions per atomic.)
+WT_DEV int32_t wt_wave_min_i32(int32_t x) {
+#pragma unroll
+    for (int dd = 32; dd; dd >>= 1) { const int32_t o = __shfl_xor(x, dd); x = o < x ? o : x; }
+    return x;
+}
+WT_DEV uint32_t wt_wave_min_u32(uint32_t x) {
+#pragma unroll
+    for (int dd = 32; dd; dd >>= 1) { const uint32_t o = (uint32_t) __shfl_xor((int) x, dd); x = o < x ? o : x; }
+    return x;
+}
+WT_DEV uint32_t wt_wave_max_u32(uint32_t x) {
+#pragma unroll
+    for (int dd = 32; dd; dd >>= 1) { const uint32_t o = (uint32_t) __shfl_xor((int) x, dd); x = o > x ? o : x; }
+    return x;
+}
+WT_DEV bool wt_wave_leader(int lane) { return lane == 0; }
 WT_DEV unsigned long long wt_glb_add64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 WT_DEV void wt_glb_or64(unsigned long long *p, unsigned long long v) { atomicOr(p, v); }
 // Look-back words are 8-byte granules whose payload IS the flag: relaxed

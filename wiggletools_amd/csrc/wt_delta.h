@@ -70,7 +70,7 @@ struct WtDeltaCtx {
     int32_t *ltc;               // [T] lane totals (coverage)
     long long *gtv;             // [T / 16] group totals
     int32_t *gtc;
-    long long *tbase;           // [T] global index of the first interval of the chunk's track t in this window
+    long long *tbase;           // [T] global index of the first interval of the chunk's track t in this window minus tpfx[t], in BYTES of a 4-byte column: byte offset = tbase[t] + 4 * flat
     uint32_t *tpfx;             // [T + 1] exclusive prefix of the tracks' interval counts (flat index space)
     uint16_t *tfirst;           // [WT_DELTA_TF] first track of every tile of the flat space
     unsigned long long *qa, *qb;        // [W] each: deltas of the squares' high / low parts (delta_q launches)
@@ -159,7 +159,7 @@ WT_DEV void wt_delta_square(unsigned long long m, unsigned long long &a, unsigne
 WT_DEV void wt_delta_ranges1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0, int tid, int nt) {
     const int N = P.n_tracks;
     const int g = c0 + tid;
-    long long n = 0;
+    long long n = 0, first = 0;
     if (g < N) {
         const uint32_t *row0 = P.widx + (size_t) c.sh->row * N;
         const long long seg = (long long) c.sh->chrom * N + g;
@@ -169,8 +169,9 @@ WT_DEV void wt_delta_ranges1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0,
         long long hi = row0[N + g];
         if (hi >= cnt) hi = cnt - 1;
         n = hi >= lo ? hi - lo + 1 : 0;
-        d.tbase[tid] = off + lo;
+        first = off + lo;
     }
+    d.tbase[tid] = first * 4;
     d.ltc[tid] = (int32_t) n;
 }
 
@@ -189,6 +190,7 @@ WT_DEV void wt_delta_ranges3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid
     for (int x = grp * WT_DELTA_GROUP; x < tid; x++) pfx += (uint32_t) d.ltc[x];
     const uint32_t n = (uint32_t) d.ltc[tid];
     d.tpfx[tid] = pfx;
+    d.tbase[tid] -= 4ll * (long long) pfx;
     if (tid == nt - 1) d.tpfx[nt] = pfx + n;
     // first track of every tile of WT_DELTA_TILE flat indices (the slices partition the flat
     // space, so every tile start lies in exactly one non-empty slice)
@@ -206,7 +208,7 @@ WT_DEV int wt_delta_find(const uint32_t *tpfx, int nt, uint32_t jj, int i) {
     return lo;
 }
 
-// global interval indices of the lane's WT_DELTA_U flat indices of tile `tb` (-1: past the end)
+// byte offsets (into a 4-byte column) of the lane's WT_DELTA_U flat indices of tile `tb` (-1: past the end)
 WT_DEV void wt_delta_tile(const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, long long (&g)[WT_DELTA_U]) {
     const uint32_t tile = tb / WT_DELTA_TILE;
     int i = tile < WT_DELTA_TF ? (int) d.tfirst[tile] : wt_delta_find(d.tpfx, nt, tb, 0);
@@ -216,7 +218,7 @@ WT_DEV void wt_delta_tile(const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, 
         g[u] = -1;
         if (jj < M) {
             while (jj >= d.tpfx[i + 1]) i++;
-            g[u] = d.tbase[i] + (long long) (jj - d.tpfx[i]);
+            g[u] = d.tbase[i] + 4ll * (long long) jj;
         }
     }
 }
@@ -235,14 +237,14 @@ WT_DEV void wt_delta_pass1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, 
         long long g[WT_DELTA_U];
         wt_delta_tile(d, nt, M, tb, lane, g);
 #pragma unroll
-        for (int u = 0; u < WT_DELTA_U; u++) cur[u] = g[u] >= 0 ? val[g[u]] : 0u;
+        for (int u = 0; u < WT_DELTA_U; u++) cur[u] = g[u] >= 0 ? *(const uint32_t *) ((const char *) val + g[u]) : 0u;
     }
     for (; tb < M; tb += step) {
         if (tb + step < M) {
             long long g[WT_DELTA_U];
             wt_delta_tile(d, nt, M, tb + step, lane, g);
 #pragma unroll
-            for (int u = 0; u < WT_DELTA_U; u++) nxt[u] = g[u] >= 0 ? val[g[u]] : 0u;
+            for (int u = 0; u < WT_DELTA_U; u++) nxt[u] = g[u] >= 0 ? *(const uint32_t *) ((const char *) val + g[u]) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < WT_DELTA_U; u++) {
@@ -270,36 +272,51 @@ WT_DEV bool wt_delta_verdict(const WtParams &P, const WtDeltaCtx &d, int &emin) 
     return !d.dsh->bad && (hi - lo) <= wt_delta_max_span(P.n_tracks);
 }
 
+// ---- pass 2 ----
+// Per interval the wave spends instruction ISSUE, not bandwidth, so this is written for
+// the instruction count (round 3; read off the ISA):
+//   * w0 and the window width are arguments (SGPRs): read from LDS inside the loop they cost an
+//     `s_waitcnt lgkmcnt(0)` per interval, which also waited for the previous interval's four atomics;
+//   * the signed scaled mantissa is built in 32 bits and shifted once; the finish takes ds_sub_u64;
+//   * a value below the unit (`e < scale`) shifts by a wrapped count: the sum is garbage, and the
+//     window is redone anyway (wt_delta_window_verdict sees emin < guess) -- no select per value;
+//   * the exponent range is the unsigned min / max of the values' magnitude BITS (zero excluded from
+//     the minimum by the wrap of `key - 1`): four instructions instead of nine.
+struct WtDeltaRange {
+    uint32_t kmax, kmin;        // max of (bits & 0x7fffffff); min of (bits & 0x7fffffff) - 1 (zero wraps to the top)
+};
+
 template <bool QQ = false>
-WT_DEV void wt_delta_apply(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t s, int32_t f, uint32_t vb,
-                           int emin, bool ok, int32_t &my_next) {
-    const int32_t w0 = c.sh->w0, w1 = c.sh->w1;
-    if (s >= w0 && f < w1) {                    // the common case: the run lies inside the window -- no branches
-        const int e = (int) ((vb >> 23) & 0xffu);
-        const uint32_t frac = vb & 0x7fffffu;
-        const uint32_t m = (ok && e) ? (frac | 0x800000u) : (ok ? frac : 0u);
-        long long vi = (long long) ((unsigned long long) m << (ok ? (e ? e : 1) - emin : 0));
-        if (vb >> 31) vi = -vi;
-        wt_lds_add64((unsigned long long *) &d.acc[s - w0], (unsigned long long) vi);
-        wt_lds_add32(&d.ev[s - w0], 1u);
-        wt_lds_add64((unsigned long long *) &d.acc[f - w0], (unsigned long long) (-vi));
-        wt_lds_add32(&d.ev[f - w0], 0x10000u);
+WT_DEV void wt_delta_apply(WtDeltaCtx &d, WtCtx &c, int32_t w0, uint32_t width, int32_t s, int32_t f, uint32_t vb,
+                           int scale, bool ok, int32_t &my_next, WtDeltaRange &R) {
+    const uint32_t key = vb & 0x7fffffffu;
+    R.kmax = key > R.kmax ? key : R.kmax;
+    R.kmin = key - 1u < R.kmin ? key - 1u : R.kmin;
+    const uint32_t e = (vb >> 23) & 0xffu;
+    const uint32_t m = (vb & 0x7fffffu) | ((e < 1u ? e : 1u) << 23);    // hidden bit unless denormal / zero
+    const int32_t sgn = (int32_t) vb >> 31;
+    int32_t sm = (int32_t) ((m ^ (uint32_t) sgn) - (uint32_t) sgn);
+#ifdef WT_EMU
+    if (!ok) sm = 0;            // (a window known not to be exact: the device adds garbage, the patch kernel rewrites the values)
+#endif
+    const long long vi = (long long) ((unsigned long long) (long long) sm << (((e > 1u ? e : 1u) - (uint32_t) scale) & 63u));
+    const uint32_t cs = (uint32_t) (s - w0), cf = (uint32_t) (f - w0);
+    if (cs < width && cf < width) {             // the common case: the run lies inside the window -- no branches
+        wt_lds_add64((unsigned long long *) &d.acc[cs], (unsigned long long) vi);
+        wt_lds_add32(&d.ev[cs], 1u);
+        wt_lds_sub64((unsigned long long *) &d.acc[cf], (unsigned long long) vi);
+        wt_lds_add32(&d.ev[cf], 0x10000u);
         if (QQ && vi) {
             unsigned long long a, b;
             wt_delta_square((unsigned long long) (vi < 0 ? -vi : vi), a, b);
-            wt_lds_add64(&d.qa[s - w0], a); wt_lds_add64(&d.qb[s - w0], b);
-            wt_lds_add64(&d.qa[f - w0], 0ull - a); wt_lds_add64(&d.qb[f - w0], 0ull - b);
+            wt_lds_add64(&d.qa[cs], a); wt_lds_add64(&d.qb[cs], b);
+            wt_lds_sub64(&d.qa[cf], a); wt_lds_sub64(&d.qb[cf], b);
         }
         return;
     }
+    const int32_t w1 = w0 + (int32_t) width;
     if (f == w0) { wt_lds_add32(&d.ev[0], 0x00010001u); return; }    // true breakpoint at w0, covers nothing here
     if (s >= w1) { my_next = s < my_next ? s : my_next; return; }
-    const int e = (int) ((vb >> 23) & 0xffu);
-    const uint32_t frac = vb & 0x7fffffu;
-    const uint32_t m = e ? (frac | 0x800000u) : frac;
-    long long vi = 0;
-    if (ok && m) vi = (long long) ((unsigned long long) m << ((e ? e : 1) - emin));
-    if (vb >> 31) vi = -vi;
     unsigned long long qa = 0, qb = 0;
     if (QQ && vi) wt_delta_square((unsigned long long) (vi < 0 ? -vi : vi), qa, qb);
     if (s < w0) {                               // spans w0: part of the window's base, not a breakpoint
@@ -307,83 +324,112 @@ WT_DEV void wt_delta_apply(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t s
         wt_lds_addi32(&d.dsh->base_c, 1);
         if (QQ && vi) { wt_lds_add64(&d.dsh->base_qa, qa); wt_lds_add64(&d.dsh->base_qb, qb); }
     } else {
-        const int cs = s - w0;
         if (vi) wt_lds_add64((unsigned long long *) &d.acc[cs], (unsigned long long) vi);
         wt_lds_add32(&d.ev[cs], 1u);
         if (QQ && vi) { wt_lds_add64(&d.qa[cs], qa); wt_lds_add64(&d.qb[cs], qb); }
     }
     if (f < w1) {
-        const int cf = f - w0;
-        if (vi) wt_lds_add64((unsigned long long *) &d.acc[cf], (unsigned long long) (-vi));
+        if (vi) wt_lds_sub64((unsigned long long *) &d.acc[cf], (unsigned long long) vi);
         wt_lds_add32(&d.ev[cf], 0x10000u);
-        if (QQ && vi) { wt_lds_add64(&d.qa[cf], 0ull - qa); wt_lds_add64(&d.qb[cf], 0ull - qb); }
+        if (QQ && vi) { wt_lds_sub64(&d.qa[cf], qa); wt_lds_sub64(&d.qb[cf], qb); }
     } else {
         my_next = f < my_next ? f : my_next;
     }
 }
 
-// pass 2: the deltas (same software pipeline as pass 1)
+// the lane's WT_DELTA_U intervals of one tile (same software pipeline as pass 1)
 struct WtDeltaBatch {
     int32_t s[WT_DELTA_U], f[WT_DELTA_U];
     uint32_t b[WT_DELTA_U];
-    bool in[WT_DELTA_U];
 };
 
-// The loads are UNCONDITIONAL: a flat index past the end reads interval 0 and is flagged `!in`.  With a
-// branch (or an exec-masked region the compiler may skip) around them, the number of loads in flight
-// is unknown to the compiler, and the consumer of the PREVIOUS tile gets `s_waitcnt vmcnt(0)` --
-// the prefetch is waited for before the tile it was meant to overlap is applied (round 2, read off
-// the ISA: that wait sat in front of every apply).
+// The loads are UNCONDITIONAL and always in range: a flat index past the end is clamped to the last
+// one (the applying side masks it), a whole tile past the end re-reads the last tile.  With a branch (or
+// an exec-masked region the compiler may skip) around them, the number of loads in flight is unknown to
+// the compiler, and the consumer of the PREVIOUS tile gets `s_waitcnt vmcnt(0)` -- the prefetch is
+// waited for before the tile it was meant to overlap is applied (round 2, read off the ISA).
+// The track of a flat index: tfirst[] gives the tile's first one; the lane keeps the end of its
+// current slice and the slice's byte offset in registers and only walks tpfx[] when an index crosses it.
 WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, WtDeltaBatch &B) {
-    const uint32_t *val = (const uint32_t *) P.value;
-    long long g[WT_DELTA_U];
-    wt_delta_tile(d, nt, M, tb, lane, g);
+    const uint32_t last = (M - 1u) / WT_DELTA_TILE * WT_DELTA_TILE;
+    const uint32_t tbe = tb < last ? tb : last;
+    const uint32_t tile = tbe / WT_DELTA_TILE;
+    int i = tile < WT_DELTA_TF ? (int) d.tfirst[tile] : wt_delta_find(d.tpfx, nt, tbe, 0);
+    uint32_t hi = d.tpfx[i + 1];
+    long long dl = d.tbase[i];
 #pragma unroll
     for (int u = 0; u < WT_DELTA_U; u++) {
-        B.in[u] = g[u] >= 0;
-        const long long gs = g[u] >= 0 ? g[u] : 0;
-        B.s[u] = P.start[gs];
-        B.f[u] = P.finish[gs];
-        B.b[u] = val[gs];
+        uint32_t jj = tbe + (uint32_t) lane + 64u * (uint32_t) u;
+        jj = jj < M - 1u ? jj : M - 1u;
+        if (jj >= hi) {
+            do { i++; hi = d.tpfx[i + 1]; } while (jj >= hi);
+            dl = d.tbase[i];
+        }
+        const long long ob = dl + ((long long) jj << 2);
+        B.s[u] = *(const int32_t *) ((const char *) P.start + ob);
+        B.f[u] = *(const int32_t *) ((const char *) P.finish + ob);
+        B.b[u] = *(const uint32_t *) ((const char *) P.value + ob);
+    }
+}
+
+// every interval of the tile at flat index `tb`; only the window's last tile can be partial
+template <bool QQ = false>
+WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch &B, uint32_t tb, uint32_t M, int lane, int32_t w0,
+                                uint32_t width, int scale, bool ok, int32_t &my_next, WtDeltaRange &R) {
+    if (tb + WT_DELTA_TILE <= M) {
+#pragma unroll
+        for (int u = 0; u < WT_DELTA_U; u++)
+            wt_delta_apply<QQ>(d, c, w0, width, B.s[u], B.f[u], B.b[u], scale, ok, my_next, R);
+    } else {
+#pragma unroll
+        for (int u = 0; u < WT_DELTA_U; u++)
+            if (tb + (uint32_t) lane + 64u * (uint32_t) u < M)
+                wt_delta_apply<QQ>(d, c, w0, width, B.s[u], B.f[u], B.b[u], scale, ok, my_next, R);
     }
 }
 
 // `scale`: exponent of one unit of the scaled mantissas; `ok`: false -> the window is known not to be
-// exact (only coordinates matter); `collect`: also gather the exponent range of the values (the
+// exact (only coordinates matter); `collect`: also publish the exponent range of the values (the
 // speculative single-pass flavour, see wt_delta_window_verdict); `stats`: count the intervals.
 template <bool QQ = false>
 WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale, bool ok, bool collect, bool stats,
                            int tid, int nt) {
-    const int wave = tid >> 6, lane = tid & 63, nwaves = nt >> 6;
-    const uint32_t M = d.tpfx[nt];
+    const int wave = wt_uniform32(tid >> 6), lane = tid & 63, nwaves = nt >> 6;     // (uniform: the tile tests stay scalar)
+    const uint32_t M = (uint32_t) wt_uniform32((int32_t) d.tpfx[nt]);
+    const int32_t w0 = wt_uniform32(c.sh->w0);
+    const uint32_t width = (uint32_t) (wt_uniform32(c.sh->w1) - w0);
     const uint32_t step = (uint32_t) nwaves * WT_DELTA_TILE;
     int32_t my_next = 0x7fffffff;
-    int emin = 255, emax = 0, bad = 0;
-    WtDeltaBatch cur, nxt;
+    WtDeltaRange R;
+    R.kmax = 0u; R.kmin = 0xffffffffu;
     uint32_t tb = (uint32_t) wave * WT_DELTA_TILE;
-    if (tb < M) wt_delta_fetch(P, d, nt, M, tb, lane, cur);
-    for (; tb < M; tb += step) {
-        wt_delta_fetch(P, d, nt, M, tb + step, lane, nxt);      // (past the end: harmless reads of interval 0)
-#pragma unroll
-        for (int u = 0; u < WT_DELTA_U; u++)
-            if (cur.in[u]) {
-                const uint32_t vb = cur.b[u];
-                int e = (int) ((vb >> 23) & 0xffu);
-                if (e == 0xff) bad = 1;
-                e = e ? e : 1;
-                const bool nz = (vb & 0x7fffffffu) != 0u;
-                emin = (nz && e < emin) ? e : emin;
-                emax = (nz && e > emax) ? e : emax;
-                // speculative pass: a value below the guessed unit would lose bits -- it is added as 0
-                // here and the window is redone (wt_delta_window_verdict)
-                wt_delta_apply<QQ>(P, c, d, cur.s[u], cur.f[u], vb, scale, ok && e >= scale, my_next);
-            }
-        cur = nxt;
+    if (tb < M) {
+        // two register sets take turns (a `cur = nxt` copy is 12 moves per tile, and it put the wait for the
+        // prefetched tile at the end of the iteration that issued it)
+        WtDeltaBatch A, B;
+        wt_delta_fetch(P, d, nt, M, tb, lane, A);
+        for (;;) {
+            wt_delta_fetch(P, d, nt, M, tb + step, lane, B);    // (past the end: harmless re-reads of the last tile)
+            wt_delta_apply_tile<QQ>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R);
+            tb += step;
+            if (tb >= M) break;
+            wt_delta_fetch(P, d, nt, M, tb + step, lane, A);
+            wt_delta_apply_tile<QQ>(d, c, B, tb, M, lane, w0, width, scale, ok, my_next, R);
+            tb += step;
+            if (tb >= M) break;
+        }
     }
-    if (my_next != 0x7fffffff) wt_lds_min32(&c.sh->next_bp, my_next);
+    my_next = wt_wave_min_i32(my_next);
+    if (my_next != 0x7fffffff && wt_wave_leader(lane)) wt_lds_min32(&c.sh->next_bp, my_next);
     if (collect) {
-        if (emin <= emax) { wt_lds_min32(&d.dsh->emin, emin); wt_lds_max32(&d.dsh->emax, emax); }
-        if (bad) wt_lds_max32(&d.dsh->bad, 1);
+        // back to exponents: largest / smallest non-zero magnitude of the wave (denormals count as exponent 1)
+        const uint32_t kmax = wt_wave_max_u32(R.kmax), kmin = wt_wave_min_u32(R.kmin) + 1u;
+        if (kmax != 0u && wt_wave_leader(lane)) {
+            const int emax = (int) (kmax >> 23), emin = (int) (kmin >> 23);
+            wt_lds_min32(&d.dsh->emin, emin ? emin : 1);
+            wt_lds_max32(&d.dsh->emax, emax ? emax : 1);
+            if (emax == 0xff) wt_lds_max32(&d.dsh->bad, 1);
+        }
     }
     if (stats && tid == 0 && M) wt_lds_add64(&c.sh->n_intervals, (unsigned long long) M);
 }
@@ -647,6 +693,7 @@ WT_DEV void wt_delta_ranges_w2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int t
     for (int x = 0; x < wave; x++) pfx += (uint32_t) d.gtc[x];
     const uint32_t n = (uint32_t) d.ltc[tid];
     d.tpfx[tid] = pfx;
+    d.tbase[tid] -= 4ll * (long long) pfx;
     if (tid == nt - 1) d.tpfx[nt] = pfx + n;
     for (uint32_t b = (pfx + WT_DELTA_TILE - 1) / WT_DELTA_TILE; b * WT_DELTA_TILE < pfx + n && b < WT_DELTA_TF; b++)
         d.tfirst[b] = (uint16_t) tid;
