@@ -574,3 +574,30 @@ def test_gpu_many_small_chromosomes(oracle, engine, monkeypatch):
         got = ts.reduce_host(op, **kw)
         assert_runs_equal(got, exp, _tol(op), "scaffolds op %s" % op)
     ts.close()
+
+
+def test_gpu_searched_window_index_equals_scanned():
+    """The window index is built by search (coarse binary search + interpolation, csrc/wt_engine.hip
+    wt_index_search_kernel); WTAMD_INDEX_CHECK=1 also builds it by the scan over every finish[] and fails the
+    reduction if any entry differs.  The switch is read once per process: a child runs the cases."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, "tests")
+from helpers import random_case
+from wiggletools_amd import engine as E
+for seed in range(40):
+    rng = np.random.default_rng(9000 + seed)
+    t = random_case(9000 + seed, n_tracks=int(rng.integers(1, 40)), dtype=np.float32)
+    ts = E.TrackSet.from_runlists(t)
+    for op in ("mean", "max"):
+        ts.reduce_host(op)
+    ts.close()
+print("index-check-ok")
+'''
+    env = dict(os.environ, WTAMD_INDEX_CHECK="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "index-check-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

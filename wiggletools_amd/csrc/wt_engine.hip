@@ -473,35 +473,169 @@ __global__ void __launch_bounds__(256) wt_index_kernel(const WtParams P, long lo
     struct __attribute__((packed, aligned(4))) V4 { int32_t x[4]; };
     V4 f[WT_INDEX_UNROLL], nf[WT_INDEX_UNROLL];
     int32_t pf[WT_INDEX_UNROLL], npf[WT_INDEX_UNROLL];
+    // FULL sub-chunks: unconditional loads.  (Round 3, read off the ISA: with `if (more) fetch(next)` and the
+    // per-lane tail guards around the loads, the compiler could not count the loads in flight and waited for
+    // ALL of them before applying the current sub-chunk -- the prefetch overlapped nothing, and 1, 2 or 4
+    // vectors per lane made no difference.)  A prefetch past the last full sub-chunk re-reads that one.
+    const long long n_full = (end0 - begin0) / WT_INDEX_CHUNK;
     auto fetch = [&](long long base, V4 (&v)[WT_INDEX_UNROLL], int32_t (&p)[WT_INDEX_UNROLL]) {
 #pragma unroll
         for (int u = 0; u < WT_INDEX_UNROLL; u++) {
             const long long g = base + 4ll * (threadIdx.x + 256 * u);
-            if (g + 3 < end0) {
-                v[u] = *(const V4 *) (P.finish + g);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; q++) v[u].x[q] = (g + q < end0) ? P.finish[g + q] : 0;
-            }
-            p[u] = (g < end0 && g > 0) ? P.finish[g - 1] : 0;
+            v[u] = *(const V4 *) (P.finish + g);
+            p[u] = P.finish[g > 0 ? g - 1 : 0];
         }
     };
-    fetch(begin0, f, pf);
-    for (long long begin = begin0; begin < end0; begin += WT_INDEX_CHUNK) {
-        if (begin + WT_INDEX_CHUNK < end0) fetch(begin + WT_INDEX_CHUNK, nf, npf);
+    if (n_full > 0) {
+        const long long last_full = begin0 + (n_full - 1) * WT_INDEX_CHUNK;
+        fetch(begin0, f, pf);
+        for (long long begin = begin0; begin <= last_full; begin += WT_INDEX_CHUNK) {
+            const long long nb = begin + WT_INDEX_CHUNK;
+            fetch(nb <= last_full ? nb : last_full, nf, npf);
+#pragma unroll
+            for (int u = 0; u < WT_INDEX_UNROLL; u++) {
+                const long long g = begin + 4ll * (threadIdx.x + 256 * u);
+                int32_t prev = pf[u];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    wt_index_apply(P, cur, g + q, f[u].x[q], prev);
+                    prev = f[u].x[q];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < WT_INDEX_UNROLL; u++) { f[u] = nf[u]; pf[u] = npf[u]; }
+        }
+    }
+    // the partial sub-chunk at the end of the span (only the last block of a launch has one)
+    const long long begin = begin0 + n_full * WT_INDEX_CHUNK;
+    if (begin < end0) {
 #pragma unroll
         for (int u = 0; u < WT_INDEX_UNROLL; u++) {
             const long long g = begin + 4ll * (threadIdx.x + 256 * u);
-            int32_t prev = pf[u];
+            int32_t prev = (g < end0 && g > 0) ? P.finish[g - 1] : 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if (g + q < end0) wt_index_apply(P, cur, g + q, f[u].x[q], prev);
-                prev = f[u].x[q];
+                if (g + q < end0) {
+                    const int32_t fq = P.finish[g + q];
+                    wt_index_apply(P, cur, g + q, fq, prev);
+                    prev = fq;
+                }
             }
         }
-#pragma unroll
-        for (int u = 0; u < WT_INDEX_UNROLL; u++) { f[u] = nf[u]; pf[u] = npf[u]; }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Window index by SEARCH (round 3).  widx[row(b)][track] is the lower bound of the boundary b = cbase + m * W
+// in the track's finish[] (wt_index_apply's claims, restated), so nothing obliges the kernel to read every
+// finish: at a mean run of 16 bp the scan above reads 256 entries (1 KB) per boundary and stays near
+// 3.3 TB/s whatever its loads look like (1, 2 or 4 vectors in flight, long or short spans per block).
+//   coarse  every 64th row of every track by a plain binary search over the track's whole segment
+//           (one lane each; ~1 % of the boundaries, the upper levels of the search stay in L2);
+//   fine    a wave owns the 64 rows between two coarse rows of ONE track: each lane interpolates its boundary
+//           between the two coarse answers and gallops / bisects from the guess -- a few probes, almost all
+//           inside one or two 128-byte lines; the 16 waves of a workgroup (16 neighbouring tracks, same
+//           rows) exchange through LDS so that a row is written as one 64-byte piece.
+// (A first version found the bracket with a cooperative 64-ary search per wave: 17.7 ms against the scan's
+// 22-27 -- its 64 probes per step were 64 cache lines per step.)  Same result as the scan by construction;
+// WTAMD_INDEX=scan selects the scan, WTAMD_INDEX_CHECK=1 runs both and compares (tests).
+// ---------------------------------------------------------------------------
+#define WT_ISEARCH_ROWS 64
+#define WT_ISEARCH_TRACKS 16
+
+// chromosome of an index row: the rows of chromosome ch start at c_first_win[ch] + ch
+__device__ __forceinline__ int wt_index_row_chrom(const WtParams &P, long long row) {
+    int lo = 0;
+    for (int hi = P.n_chrom; hi - lo > 1;) {
+        const int mid = (lo + hi) >> 1;
+        if (P.c_first_win[mid] + mid <= row) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// first x in [lo, hi) with fin[x] >= b (hi if none), starting from a guess g in [lo, hi)
+__device__ __forceinline__ long long wt_lane_lower_bound(const int32_t *fin, long long lo, long long hi, long long g, long long b) {
+    if (lo >= hi) return lo;
+    if ((long long) fin[g] >= b) {
+        hi = g;
+        for (long long d = 1;; d <<= 1) {
+            const long long q = hi - d;
+            if (q < lo) break;
+            if ((long long) fin[q] < b) { lo = q + 1; break; }
+            hi = q;
+        }
+    } else {
+        lo = g + 1;
+        for (long long d = 1;; d <<= 1) {
+            const long long q = lo + d - 1;
+            if (q >= hi) break;
+            if ((long long) fin[q] >= b) { hi = q; break; }
+            lo = q + 1;
+        }
+    }
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if ((long long) fin[mid] < b) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// coarse[strip][track]: the index entry of row strip * 64
+__global__ void __launch_bounds__(256) wt_index_coarse_kernel(const WtParams P, long long n_strips, uint32_t *coarse) {
+    const long long t = (long long) blockIdx.x * 256 + threadIdx.x;
+    const int N = P.n_tracks;
+    if (t >= n_strips * N) return;
+    const long long strip = t / N;
+    const int i = (int) (t - strip * N);
+    const long long row = strip * WT_ISEARCH_ROWS;
+    const int ch = wt_index_row_chrom(P, row);
+    const long long m = row - (P.c_first_win[ch] + ch);
+    const long long seg = (long long) ch * N + i;
+    const long long s0 = P.seg_off[seg], n = P.seg_off[seg + 1] - s0;
+    const long long b = (long long) P.cbase[ch] + (m << P.logW);
+    coarse[t] = (uint32_t) wt_lane_lower_bound(P.finish + s0, 0, n, n >> 1, b);
+}
+
+__global__ void __launch_bounds__(WT_ISEARCH_ROWS * WT_ISEARCH_TRACKS) wt_index_search_kernel(const WtParams P, long long n_rows, long long n_strips,
+                                                                                              const uint32_t *coarse) {
+    __shared__ uint32_t out[WT_ISEARCH_ROWS][WT_ISEARCH_TRACKS + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = P.n_tracks;
+    const long long strip = blockIdx.x;
+    const long long r0 = strip * WT_ISEARCH_ROWS;
+    const int i = (int) blockIdx.y * WT_ISEARCH_TRACKS + wave;
+    if (i < N) {                                    // (wave-uniform)
+        long long row = r0 + lane;
+        if (row > n_rows - 1) row = n_rows - 1;     // the last strip: duplicates of the last row, not stored
+        const int ch = wt_index_row_chrom(P, row);
+        const long long m = row - (P.c_first_win[ch] + ch);
+        const long long seg = (long long) ch * N + i;
+        const long long s0 = P.seg_off[seg], n = P.seg_off[seg + 1] - s0;
+        const long long b = (long long) P.cbase[ch] + (m << P.logW);
+        const int32_t *fin = P.finish + s0;
+        // the bracket: the coarse answers of this strip's and the next strip's first rows, where they belong
+        // to the lane's chromosome (a strip may straddle a chromosome edge)
+        const int ch_first = __shfl(ch, 0);
+        const bool have_next = strip + 1 < n_strips;
+        const int ch_next = have_next ? wt_index_row_chrom(P, r0 + WT_ISEARCH_ROWS) : -1;
+        const bool real_a = ch == ch_first, real_b = ch == ch_next;
+        const long long A = real_a ? (long long) coarse[strip * N + i] : 0;
+        const long long B = real_b ? (long long) coarse[(strip + 1) * N + i] : n;
+        long long g = (real_a && real_b) ? A + (((B - A) * lane) >> 6) : (A + B) >> 1;
+        if (g > B - 1) g = B - 1;
+        out[lane][wave] = (uint32_t) wt_lane_lower_bound(fin, A, B, g, b);
+    }
+    __syncthreads();
+    const int orow = tid / WT_ISEARCH_TRACKS, ocol = tid % WT_ISEARCH_TRACKS;
+    const long long row = r0 + orow;
+    const int track = (int) blockIdx.y * WT_ISEARCH_TRACKS + ocol;
+    if (row < n_rows && track < N) P.widx[(size_t) row * N + track] = out[orow][ocol];
+}
+
+// check mode: number of entries in which two indices differ
+__global__ void __launch_bounds__(256) wt_index_compare_kernel(const uint32_t *a, const uint32_t *b, long long n, unsigned long long *diff) {
+    const long long t = (long long) blockIdx.x * 256 + threadIdx.x;
+    if (t < n && a[t] != b[t]) atomicAdd(diff, 1ull);
 }
 
 __global__ void __launch_bounds__(256) wt_extents_kernel(const int64_t *seg_off, const int32_t *start,
@@ -688,12 +822,13 @@ struct WtWindows {
     int32_t *d_cbase = nullptr, *d_cnwin = nullptr, *d_chi = nullptr, *d_win_chrom = nullptr;
     int64_t *d_cfirst = nullptr;
     uint32_t *d_widx = nullptr;
+    uint32_t *d_cidx = nullptr;         // coarse index of the searched window index (every 64th row)
     unsigned long long *d_status = nullptr;
     int32_t *d_bad_list = nullptr;      // difference-array launches: windows not provably exact ...
     long long *d_bad_goff = nullptr;    // ... and where their runs start (both [n_windows])
     bool indexed = false;
     // capacities of the device tables (entries); the tables are reused and only ever grow
-    int64_t cap_chrom = 0, cap_win = 0, cap_widx = 0, cap_bad = 0;
+    int64_t cap_chrom = 0, cap_win = 0, cap_widx = 0, cap_bad = 0, cap_cidx = 0;
     bool tab_valid = false;             // tab / device tables describe the track set's current data
     int64_t *h_tab = nullptr;           // pinned staging of the per-chromosome tables (pipeline slots: asynchronous upload)
 };
@@ -748,7 +883,7 @@ static hipError_t wt_grow(T **p, int64_t *cap, int64_t need) {
 
 static void wt_free_windows(WtWindows &w) {
     (void) hipFree(w.d_cbase); (void) hipFree(w.d_cnwin); (void) hipFree(w.d_chi); (void) hipFree(w.d_win_chrom); (void) hipFree(w.d_cfirst);
-    (void) hipFree(w.d_widx); (void) hipFree(w.d_status); (void) hipFree(w.d_bad_list); (void) hipFree(w.d_bad_goff);
+    (void) hipFree(w.d_widx); (void) hipFree(w.d_cidx); (void) hipFree(w.d_status); (void) hipFree(w.d_bad_list); (void) hipFree(w.d_bad_goff);
     if (w.h_tab) (void) hipHostFree(w.h_tab);
     w = WtWindows();
 }
@@ -969,6 +1104,7 @@ static int wt_get_windows(wtamd_trackset *ts, int W, WtWindows **out, hipStream_
         w.cap_win = c1 < c2 ? c1 : c2;
     }
     WT_HIP(wt_grow(&w.d_widx, &w.cap_widx, nwidx));
+    WT_HIP(wt_grow(&w.d_cidx, &w.cap_cidx, ((w.tab.n_rows > 0 ? w.tab.n_rows : 1) + WT_ISEARCH_ROWS - 1) / WT_ISEARCH_ROWS * (int64_t) ts->n_tracks));
     if (ts->n_chrom > 0) {
         if (ts->pipe_mode) {
             if (ts->n_chrom != 1) return wt_fail(WTAMD_ERR_INTERNAL, "pipeline slots hold one chromosome");
@@ -1008,18 +1144,65 @@ static int wt_build_index(wtamd_trackset *ts, WtWindows *w, const WtPlan &plan, 
     WtParams P;
     wt_fill_params(ts, w, plan, P);
     WT_HIP(hipEventRecord(ts->ev_i0, s));
-    WT_HIP(hipMemsetAsync(w->d_widx, 0, sizeof(uint32_t) * (size_t) w->tab.n_rows * ts->n_tracks, s));
-    if (ts->n_intervals > 0) {
-        const long long total = ts->n_intervals;
-        long long blocks = (total + WT_INDEX_CHUNK - 1) / WT_INDEX_CHUNK;
-        const long long cap = (long long) ts->num_cu * 8;      // 8 x 256 lanes = a full CU
-        if (blocks > cap) blocks = cap;
-        // contiguous span per block, a whole number of sub-chunks
-        long long span = (total + blocks - 1) / blocks;
-        span = (span + WT_INDEX_CHUNK - 1) / WT_INDEX_CHUNK * WT_INDEX_CHUNK;
-        blocks = (total + span - 1) / span;
-        hipLaunchKernelGGL(wt_index_kernel, dim3((unsigned) blocks), dim3(256), 0, s, P, total, span);
-        WT_HIP(hipGetLastError());
+    static const int mode = [] {            // 0: search (default), 1: scan, 2: both + compare
+        const char *e = getenv("WTAMD_INDEX"), *c = getenv("WTAMD_INDEX_CHECK");
+        if (c && atoi(c) > 0) return 2;
+        return (e && !strcmp(e, "scan")) ? 1 : 0;
+    }();
+    const size_t n_widx = (size_t) w->tab.n_rows * ts->n_tracks;
+    auto scan = [&](uint32_t *dst) -> int {
+        WtParams Q = P;
+        Q.widx = dst;
+        WT_HIP(hipMemsetAsync(dst, 0, sizeof(uint32_t) * n_widx, s));
+        if (ts->n_intervals > 0) {
+            const long long total = ts->n_intervals;
+            long long blocks = (total + WT_INDEX_CHUNK - 1) / WT_INDEX_CHUNK;
+            const long long cap = (long long) ts->num_cu * 8;      // 8 x 256 lanes = a full CU
+            if (blocks > cap) blocks = cap;
+            // contiguous span per block, a whole number of sub-chunks
+            long long span = (total + blocks - 1) / blocks;
+            span = (span + WT_INDEX_CHUNK - 1) / WT_INDEX_CHUNK * WT_INDEX_CHUNK;
+            blocks = (total + span - 1) / span;
+            hipLaunchKernelGGL(wt_index_kernel, dim3((unsigned) blocks), dim3(256), 0, s, Q, total, span);
+            WT_HIP(hipGetLastError());
+        }
+        return WTAMD_OK;
+    };
+    auto search = [&](uint32_t *dst) -> int {
+        WtParams Q = P;
+        Q.widx = dst;
+        const long long n_rows = w->tab.n_rows;
+        if (n_rows > 0 && ts->n_tracks > 0) {
+            const long long n_strips = (n_rows + WT_ISEARCH_ROWS - 1) / WT_ISEARCH_ROWS;
+            if (w->cap_cidx < n_strips * ts->n_tracks) return wt_fail(WTAMD_ERR_INTERNAL, "coarse window index not allocated");
+            hipLaunchKernelGGL(wt_index_coarse_kernel, dim3((unsigned) ((n_strips * ts->n_tracks + 255) / 256)), dim3(256), 0, s, Q, n_strips, w->d_cidx);
+            WT_HIP(hipGetLastError());
+            const dim3 grid((unsigned) n_strips, (unsigned) ((ts->n_tracks + WT_ISEARCH_TRACKS - 1) / WT_ISEARCH_TRACKS));
+            hipLaunchKernelGGL(wt_index_search_kernel, grid, dim3(WT_ISEARCH_ROWS * WT_ISEARCH_TRACKS), 0, s, Q, n_rows, n_strips, (const uint32_t *) w->d_cidx);
+            WT_HIP(hipGetLastError());
+        }
+        return WTAMD_OK;
+    };
+    if (mode == 1) {
+        if (int rc = scan(w->d_widx)) return rc;
+    } else {
+        if (int rc = search(w->d_widx)) return rc;
+    }
+    if (mode == 2 && n_widx > 0) {
+        uint32_t *other = nullptr;
+        unsigned long long *d_diff = nullptr, h_diff = 0;
+        WT_HIP(hipMalloc(&other, sizeof(uint32_t) * n_widx));
+        WT_HIP(hipMalloc(&d_diff, sizeof(unsigned long long)));
+        WT_HIP(hipMemsetAsync(d_diff, 0, sizeof(unsigned long long), s));
+        if (int rc = scan(other)) return rc;
+        hipLaunchKernelGGL(wt_index_compare_kernel, dim3((unsigned) ((n_widx + 255) / 256)), dim3(256), 0, s, w->d_widx, other, (long long) n_widx, d_diff);
+        WT_HIP(hipMemcpyAsync(&h_diff, d_diff, sizeof(h_diff), hipMemcpyDeviceToHost, s));
+        WT_HIP(hipStreamSynchronize(s));
+        (void) hipFree(other); (void) hipFree(d_diff);
+        if (h_diff) {
+            fprintf(stderr, "wiggletools_amd: WTAMD_INDEX_CHECK: the searched window index differs from the scanned one in %llu of %zu entries\n", h_diff, n_widx);
+            return wt_fail(WTAMD_ERR_INTERNAL, "window index check failed");
+        }
     }
     WT_HIP(hipEventRecord(ts->ev_i1, s));
     ts->have_index_time = true;
