@@ -131,6 +131,10 @@ struct WtShared {
     unsigned long long bp_sum;    // covered bp of this window
     unsigned long long n_intervals;
     int32_t bad_slot;             // difference-array kernel: slot of this window in bad_list, or -1
+    // difference-array kernel: the NEXT window of this workgroup, claimed while the current one is still being
+    // copied out (wt_phase_header_next / wt_phase_header_install)
+    int32_t nx_chrom, nx_w0, nx_emit_hi, nx_pad;
+    long long nx_ticket, nx_row;
 };
 
 // Per-lane state that lives across phases (registers on the GPU)
@@ -192,6 +196,7 @@ WT_DEV int32_t wt_uniform32(int32_t x) { return x; }
 WT_DEV int32_t wt_wave_min_i32(int32_t x) { return x; }
 WT_DEV uint32_t wt_wave_min_u32(uint32_t x) { return x; }
 WT_DEV uint32_t wt_wave_max_u32(uint32_t x) { return x; }
+WT_DEV unsigned long long wt_wave_sum_u64(unsigned long long x) { return x; }
 WT_DEV bool wt_wave_leader(int lane) { return true; }
 WT_DEV unsigned long long wt_glb_add64(unsigned long long *p, unsigned long long v) {
     unsigned long long o = *p; *p += v; return o;
@@ -236,6 +241,11 @@ WT_DEV uint32_t wt_wave_min_u32(uint32_t x) {
 WT_DEV uint32_t wt_wave_max_u32(uint32_t x) {
 #pragma unroll
     for (int dd = 32; dd; dd >>= 1) { const uint32_t o = (uint32_t) __shfl_xor((int) x, dd); x = o > x ? o : x; }
+    return x;
+}
+WT_DEV unsigned long long wt_wave_sum_u64(unsigned long long x) {
+#pragma unroll
+    for (int dd = 32; dd; dd >>= 1) x += (unsigned long long) __shfl_xor((long long) x, dd);
     return x;
 }
 WT_DEV bool wt_wave_leader(int lane) { return lane == 0; }
@@ -326,6 +336,36 @@ WT_DEV void wt_phase_header(const WtParams &P, WtCtx &c, long long k) {
     sh->w1 = sh->w0 + P.W;
     sh->emit_hi = P.c_hi[ch];
     sh->row = k + ch;                 // one extra boundary row per chromosome
+    sh->next_bp = 0x7fffffff;
+    sh->n_emit = 0;
+    sh->bp_sum = 0;
+    sh->n_intervals = 0;
+    sh->goffset = 0;
+    sh->bad_slot = -1;
+}
+
+// The same header, prepared early: the loads (win_chrom -> cbase / c_hi / c_first_win) are two dependent global
+// round trips behind the ticket's atomic, and nothing in them depends on the current window.  One lane fills
+// the nx_ fields while the current window is still in its look-back / copy-out; installing them is LDS only.
+WT_DEV void wt_phase_header_next(const WtParams &P, WtCtx &c, long long k) {
+    WtShared *sh = c.sh;
+    sh->nx_ticket = k;
+    if (k >= P.n_windows) return;
+    const int ch = P.win_chrom[k];
+    const long long m = k - P.c_first_win[ch];
+    sh->nx_chrom = ch;
+    sh->nx_w0 = P.cbase[ch] + (int32_t) m * P.W;
+    sh->nx_emit_hi = P.c_hi[ch];
+    sh->nx_row = k + ch;
+}
+WT_DEV void wt_phase_header_install(const WtParams &P, WtCtx &c) {
+    WtShared *sh = c.sh;
+    sh->ticket = sh->nx_ticket;
+    sh->chrom = sh->nx_chrom;
+    sh->w0 = sh->nx_w0;
+    sh->w1 = sh->nx_w0 + P.W;
+    sh->emit_hi = sh->nx_emit_hi;
+    sh->row = sh->nx_row;
     sh->next_bp = 0x7fffffff;
     sh->n_emit = 0;
     sh->bp_sum = 0;

@@ -156,13 +156,14 @@ WT_DEV void wt_delta_square(unsigned long long m, unsigned long long &a, unsigne
 // an exclusive scan of the counts gives every track its slice [tpfx[t], tpfx[t+1]) of the flat
 // space.  The passes then stride over flat indices: 64-lane tiles of 4 x 64 consecutive indices,
 // so loads are coalesced inside a track and every lane is busy whatever the tracks' densities.
-WT_DEV void wt_delta_ranges1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0, int tid, int nt) {
+// (`row`, `chrom`: of the window -- the current one's header, or the NEXT one's, see wt_delta_kernel)
+WT_DEV void wt_delta_ranges1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0, int tid, int nt, long long row, int chrom) {
     const int N = P.n_tracks;
     const int g = c0 + tid;
     long long n = 0, first = 0;
     if (g < N) {
-        const uint32_t *row0 = P.widx + (size_t) c.sh->row * N;
-        const long long seg = (long long) c.sh->chrom * N + g;
+        const uint32_t *row0 = P.widx + (size_t) row * N;
+        const long long seg = (long long) chrom * N + g;
         const long long off = P.seg_off[seg];
         const long long cnt = P.seg_off[seg + 1] - off;
         const long long lo = row0[g];
@@ -173,6 +174,9 @@ WT_DEV void wt_delta_ranges1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0,
     }
     d.tbase[tid] = first * 4;
     d.ltc[tid] = (int32_t) n;
+}
+WT_DEV void wt_delta_ranges1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0, int tid, int nt) {
+    wt_delta_ranges1(P, c, d, c0, tid, nt, c.sh->row, c.sh->chrom);
 }
 
 WT_DEV void wt_delta_ranges2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
@@ -601,22 +605,34 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
 // every store instruction touch 64 scattered 4/8-byte pieces.  Instead the runs are first placed
 // in LDS at their rank inside the window (acc[] / ev[] are dead after the scan and are exactly big
 // enough: one f64 and one u32 per position), then copied out with consecutive lanes writing
-// consecutive runs; the finish (next breakpoint) is looked up by the copying lane.
+// consecutive runs.  The u32 holds the run's start and finish, both relative to w0 (16 bits each;
+// WT_DELTA_FAR: the next breakpoint lies beyond the window, i.e. sh->next_bp): the staging lane has its
+// byte of the breakpoint bitmap in a register, so only the run that ends beyond the lane's own 8
+// positions needs the bitmap walk (round 3: the copying lanes used to walk it for every run -- three
+// dependent LDS round trips per run, 8 runs per lane).
+#define WT_DELTA_FAR 0xffffu
 template <int OP>
 WT_DEV void wt_delta_stage(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtLane<WT_DELTA_K> &L, int tid, int nt) {
     const unsigned em = ((const uint8_t *) c.E)[tid];
     if (!em) return;
+    const unsigned um = ((const uint8_t *) c.U)[tid];
     const int p0 = tid * WT_DELTA_K;
     const int w = p0 >> 6, b0 = p0 & 63;
     const uint64_t below0 = b0 ? wt_mask_incl(b0 - 1) : 0ull;
     unsigned idx = c.epfx[w] + (unsigned) wt_popc64(c.E[w] & below0);
+    // first breakpoint after the lane's last position
+    const int32_t after = wt_next_breakpoint(P, c, p0 + WT_DELTA_K - 1);
+    const int32_t w0 = c.sh->w0;
+    const uint32_t after_rel = after < c.sh->w1 ? (uint32_t) (after - w0) : WT_DELTA_FAR;
     double *sv = (double *) d.acc;
     uint32_t *sp = d.ev;
 #pragma unroll
     for (int k = 0; k < WT_DELTA_K; k++) {
         if (!((em >> k) & 1u)) continue;
+        const unsigned higher = k + 1 < WT_DELTA_K ? um >> (k + 1) : 0u;
+        const uint32_t fin_rel = higher ? (uint32_t) (p0 + k + 1 + wt_ctz64((uint64_t) higher)) : after_rel;
         sv[idx] = L.res[k];
-        sp[idx] = (uint32_t) (p0 + k);
+        sp[idx] = (uint32_t) (p0 + k) | (fin_rel << 16);
         idx++;
     }
 }
@@ -624,21 +640,23 @@ WT_DEV void wt_delta_stage(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtL
 WT_DEV void wt_delta_copy_out(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
     const int n = c.sh->n_emit;
     const long long goff = c.sh->goffset;
-    const int32_t w0 = c.sh->w0;
+    const int32_t w0 = c.sh->w0, far = c.sh->next_bp;
     const double *sv = (const double *) d.acc;
     const uint32_t *sp = d.ev;
     unsigned long long bp = 0;
     for (int i = tid; i < n; i += nt) {
-        const int p = (int) sp[i];
-        const int32_t fin = wt_next_breakpoint(P, c, p);
-        bp += (unsigned long long) (fin - (w0 + p));
+        const uint32_t pf = sp[i];
+        const int32_t st = w0 + (int32_t) (pf & 0xffffu);
+        const int32_t fin = (pf >> 16) == WT_DELTA_FAR ? far : w0 + (int32_t) (pf >> 16);
+        bp += (unsigned long long) (fin - st);
         const long long o = goff + i;
         if (o >= P.capacity) continue;
-        P.o_start[o] = w0 + p;
+        P.o_start[o] = st;
         P.o_finish[o] = fin;
         P.o_value[o] = sv[i];
     }
-    if (bp) wt_lds_add64(&c.sh->bp_sum, bp);
+    bp = wt_wave_sum_u64(bp);
+    if (bp && wt_wave_leader(tid & 63)) wt_lds_add64(&c.sh->bp_sum, bp);
 }
 
 // next non-empty word of U after every word (wt_next_breakpoint's jump table); one lane per word,
@@ -678,13 +696,16 @@ WT_DEV long long wt_wave_scan_i64(long long v, int lane) {
 }
 
 // ranges: lookup + wave-local exclusive prefix; the wave totals go to gtc[wave]
-WT_DEV void wt_delta_ranges_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0, int tid, int nt) {
-    wt_delta_ranges1(P, c, d, c0, tid, nt);
+WT_DEV void wt_delta_ranges_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0, int tid, int nt, long long row, int chrom) {
+    wt_delta_ranges1(P, c, d, c0, tid, nt, row, chrom);
     const int lane = tid & 63;
     const unsigned n = (unsigned) d.ltc[tid];
     const unsigned incl = wt_wave_scan_u32(n, lane);
     d.tpfx[tid] = incl - n;
     if (lane == 63) d.gtc[tid >> 6] = (int32_t) incl;
+}
+WT_DEV void wt_delta_ranges_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0, int tid, int nt) {
+    wt_delta_ranges_w1(P, c, d, c0, tid, nt, c.sh->row, c.sh->chrom);
 }
 
 WT_DEV void wt_delta_ranges_w2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
