@@ -103,7 +103,7 @@ struct EmuRun {
         }
     }
 
-    template <int OP>
+    template <int OP, bool DF = false>
     void run_delta() {
         constexpr bool QQ = OP == WT_OP_VAR || OP == WT_OP_STDDEV || OP == WT_OP_ENTROPY || OP == WT_OP_CV;
         WtCtx c;
@@ -136,13 +136,13 @@ struct EmuRun {
                 if (!ok) wt_delta_mark_bad(P, c, k);
                 for (int ch = 0; ch < nchunks; ch++) {
                     if (nchunks > 1) ranges(ch);
-                    for (int t = 0; t < T; t++) wt_delta_pass2<QQ>(P, c, d, scale, ok, false, true, t, T);
+                    for (int t = 0; t < T; t++) wt_delta_pass2<QQ, DF>(P, c, d, scale, ok, false, true, t, T, std::min(T, P.n_tracks - ch * T));
                 }
                 if (any && ok) guess = scale;
             } else {                // speculative single pass with the workgroup's unit
                 for (int ch = 0; ch < nchunks; ch++) {
                     ranges(ch);
-                    for (int t = 0; t < T; t++) wt_delta_pass2<QQ>(P, c, d, guess, true, true, true, t, T);
+                    for (int t = 0; t < T; t++) wt_delta_pass2<QQ, DF>(P, c, d, guess, true, true, true, t, T, std::min(T, P.n_tracks - ch * T));
                 }
                 int lo; bool ok;
                 scale = guess;
@@ -152,7 +152,7 @@ struct EmuRun {
                     if (!ok) wt_delta_mark_bad(P, c, k);
                     for (int ch = 0; ch < nchunks; ch++) {
                         if (nchunks > 1) ranges(ch);
-                        for (int t = 0; t < T; t++) wt_delta_pass2<QQ>(P, c, d, lo, ok, false, false, t, T);
+                        for (int t = 0; t < T; t++) wt_delta_pass2<QQ, DF>(P, c, d, lo, ok, false, false, t, T, std::min(T, P.n_tracks - ch * T));
                     }
                     scale = lo;
                     if (ok) guess = lo;
@@ -224,7 +224,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         P.capacity = capacity; P.o_start = o_start; P.o_finish = o_finish; P.o_value = o_value;
         P.chrom_run_off = chrom_run_off; P.o_tile = o_tile; P.o_inplay = o_inplay;
         wt_plan_to_params(R.plan, P);
-        if (delta) { P.bad_list = bad_list.data(); P.bad_goff = bad_goff.data(); }
+        if (delta) { P.bad_list = bad_list.data(); P.bad_goff = bad_goff.data(); wt_delta_defaults_params(defaults, n_tracks, P); }
         // few inexact windows: the general kernel rewrites the values of just those (the engine's
         // wt_patch_kernel); many: it redoes everything
         const bool patching = !delta && attempt == 1 && delta_bad > 0 && delta_bad * 4 <= (long long) delta_tab.n_windows &&
@@ -259,8 +259,8 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         if (total > 0) {
             if (delta) {
                 switch (op) {
-                case WT_OP_SUM: R.run_delta<WT_OP_SUM>(); break;
-                case WT_OP_MEAN: R.run_delta<WT_OP_MEAN>(); break;
+                case WT_OP_SUM: if (P.delta_df) R.run_delta<WT_OP_SUM, true>(); else R.run_delta<WT_OP_SUM>(); break;
+                case WT_OP_MEAN: if (P.delta_df) R.run_delta<WT_OP_MEAN, true>(); else R.run_delta<WT_OP_MEAN>(); break;
                 case WT_OP_VAR: R.run_delta<WT_OP_VAR>(); break;
                 case WT_OP_CV: R.run_delta<WT_OP_CV>(); break;
                 default: R.run_delta<WT_OP_STDDEV>(); break;

@@ -298,15 +298,58 @@ def test_emu_delta_inexact_windows_are_patched(oracle):
 
 def test_emu_delta_not_used_when_ineligible(oracle):
     t = _delta_case(9, 5, [700], 8, lambda r, k: r.random(k))
-    t.defaults[2] = 1.5                                    # a non-zero default value
+    t.defaults[2] = 0.1                                    # a non-zero default value that is not a float
     got, info = emu.reduce(t, "sum")
     assert info["delta"] == 0 and info["delta_bad"] == 0
     assert_runs_equal(got, oracle.reduce(t.as_dict(), "sum"), 0.0, "defaults")
+    t.defaults[2] = np.nan
+    got, info = emu.reduce(t, "sum")
+    assert info["delta"] == 0
+    assert_runs_equal(got, oracle.reduce(t.as_dict(), "sum"), 0.0, "NaN default")
+    # the var family's squares count the tracks in play only: zero defaults or the general kernel
+    t9 = _delta_case(10, 9, [700], 8, lambda r, k: r.random(k))
+    t9.defaults[2] = 1.5
+    got, info = emu.reduce(t9, "stddev")
+    assert info["delta"] == 0
+    assert_runs_equal(got, oracle.reduce(t9.as_dict(), "stddev"), 1e-12, "stddev with a default")
     from wiggletools_amd.runlists import synth
     t64 = synth(4, [700], mean_run=8, seed=3, dtype=np.float64)
     got, info = emu.reduce(t64, "mean")
     assert info["delta"] == 0
     assert_runs_equal(got, oracle.reduce(t64.as_dict(), "mean"), 0.0, "f64 tracks")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_emu_delta_nonzero_defaults_exact(oracle, seed):
+    """Round 3: non-zero defaults that are floats stay on the difference-array path (Sum / Mean): an absent
+    track is a term of the sum like any other (reducers.c:294-307, 375-401), so the window's base holds the sum
+    of the defaults and an interval adds value - default.  Tolerance 0, like the zero-default path; covers
+    negative and denormal defaults, more tracks than lanes, strict and not, and a default so far from the data
+    that the windows must be patched."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(4, 30)) if seed % 4 else int(rng.integers(65, 150))       # > 64 lanes: chunks of tracks
+    t = _delta_case(300 + seed, n, [int(rng.integers(600, 5000)), 300], float(rng.choice([1, 3, 16])),
+                    lambda r, k: r.integers(-800, 800, k) / 8.0, gap=float(rng.choice([0.0, 0.1, 0.5])))
+    which = rng.random(n) < 0.6
+    vals = rng.choice(np.array([1.5, -2.25, 0.125, 3.0, 1024.0, -0.0, 7.0], dtype=np.float32), n)
+    t.defaults[:] = np.where(which, vals, 0.0)
+    if seed % 6 == 1:                                      # everything denormal (exponent 1 without the hidden bit): still exact
+        t.value[:] = (t.value * np.float32(1e-42)).astype(np.float32)
+        t.defaults[:] = (t.defaults.astype(np.float32) * np.float32(1e-42)).astype(np.float64)
+    if not np.any(t.defaults != 0):
+        t.defaults[0] = 2.5
+    far = seed % 6 == 5
+    if far:
+        t.defaults[1] = float(np.float32(1e-30))           # outside any window's exact range with these values
+    d = t.as_dict()
+    for strict in (0, 1):
+        for op in ("sum", "mean"):
+            got, info = emu.reduce(t, op, flags=strict, delta_T=64, ppt=4, T=64)
+            if far:
+                assert info["delta_bad"] > 0, info         # patched windows or everything redone: still exact
+            else:
+                assert info["delta"] == 1 and info["delta_bad"] == 0, info
+            assert_runs_equal(got, oracle.reduce(d, op, flags=strict), 0.0, "seed %d %s strict %d %s" % (seed, op, strict, info))
 
 
 @pytest.mark.parametrize("seed", range(6))

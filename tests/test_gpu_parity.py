@@ -601,3 +601,39 @@ print("index-check-ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "index-check-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_gpu_difference_array_nonzero_defaults(oracle, engine, seed, monkeypatch):
+    """Non-zero defaults that are floats stay on the difference-array kernel (wt_delta_kernel<OP, DF = true>):
+    bit-identical Sum / Mean; a default far outside the data's exponent range goes to the patch / general kernel
+    and is still bit-identical; defaults that are not floats never take the path."""
+    from wiggletools_amd.runlists import synth
+    monkeypatch.setenv("WTAMD_DELTA_MIN_TRACKS", "1")
+    rng = np.random.default_rng(4200 + seed)
+    n = int(rng.integers(2, 40)) if seed % 3 else int(rng.integers(520, 700))       # > 512 tracks: chunks
+    t = synth(n, [int(rng.integers(3000, 60000)), 9000, 3], mean_run=float(rng.choice([1, 4, 16, 300])),
+              gap_prob=float(rng.choice([0.0, 0.1, 0.5])), seed=seed, first_start=int(rng.choice([1, 77, 5000])))
+    t.value[:] = (rng.integers(-800, 800, len(t.value)) / 8.0).astype(np.float32)
+    t.defaults[:] = np.where(rng.random(n) < 0.6, rng.choice(np.array([1.5, -2.25, 0.125, 3.0, 1024.0, 7.0]), n), 0.0)
+    t.defaults[0] = 2.5
+    d = t.as_dict()
+    ts = engine.TrackSet.from_runlists(t)
+    for strict in (0, 1):
+        for op in ("sum", "mean"):
+            got = ts.reduce_host(op, flags=strict)
+            st = ts.stats()
+            assert st["kernel"] == 1 and st["patched_windows"] == 0, st
+            assert_runs_equal(got, oracle.reduce(d, op, flags=strict), 0.0, "seed %d op %s strict %d" % (seed, op, strict))
+    ts.close()
+    t.defaults[1 % n] = float(np.float32(1e-30))           # no window can be exact with this term
+    ts = engine.TrackSet.from_runlists(t)
+    for op in ("sum", "mean"):
+        assert_runs_equal(ts.reduce_host(op), oracle.reduce(t.as_dict(), op), 0.0, "far default, seed %d op %s" % (seed, op))
+    ts.close()
+    t.defaults[1 % n] = 0.1                                # not a float
+    ts = engine.TrackSet.from_runlists(t)
+    got = ts.reduce_host("mean")
+    assert ts.stats()["kernel"] == 0
+    assert_runs_equal(got, oracle.reduce(t.as_dict(), "mean"), 0.0, "non-float default, seed %d" % seed)
+    ts.close()

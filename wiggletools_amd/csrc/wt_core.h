@@ -116,6 +116,9 @@ struct WtParams {
     int32_t off_acc, off_ev, off_ltv, off_ltc, off_gtv, off_gtc, off_tbase, off_tpfx, off_tfirst, off_dsh;   // difference-array path (wt_delta.h)
     int32_t off_qa, off_ltq, off_gtq;   // ... its sum-of-squares accumulators (var / stddev / CV)
     int32_t delta_q;                    // != 0: the launch accumulates squares too
+    int32_t off_tdef;                   // ... its per-track default bits (delta_df)
+    int32_t delta_df;                   // != 0: some default is non-zero (Sum / Mean): absent tracks add their defaults
+    int32_t def_emin, def_emax;         // exponent range of the non-zero defaults (255 / 0: none)
     int32_t off_dflt32;           // register-column median / MWU: float copy of defaults[] in LDS (filled once per workgroup)
     int32_t lds_bytes;
 };

@@ -73,6 +73,7 @@ struct WtDeltaCtx {
     long long *tbase;           // [T] global index of the first interval of the chunk's track t in this window minus tpfx[t], in BYTES of a 4-byte column: byte offset = tbase[t] + 4 * flat
     uint32_t *tpfx;             // [T + 1] exclusive prefix of the tracks' interval counts (flat index space)
     uint16_t *tfirst;           // [WT_DELTA_TF] first track of every tile of the flat space
+    uint32_t *tdef;             // [T] non-zero defaults (P.delta_df): the float bits of the chunk's track t's default value
     unsigned long long *qa, *qb;        // [W] each: deltas of the squares' high / low parts (delta_q launches)
     unsigned long long *ltqa, *ltqb;    // [T] lane totals
     unsigned long long *gtqa, *gtqb;    // [T / 16] group (emulator) / wave (device) totals
@@ -100,6 +101,7 @@ WT_DEV void wt_delta_ctx_init(WtDeltaCtx &d, const WtParams &P, char *lds) {
     d.tbase = (long long *) (lds + P.off_tbase);
     d.tpfx = (uint32_t *) (lds + P.off_tpfx);
     d.tfirst = (uint16_t *) (lds + P.off_tfirst);
+    d.tdef = (uint32_t *) (lds + P.off_tdef);
     d.qa = (unsigned long long *) (lds + P.off_qa);
     d.qb = d.qa + P.W;
     d.ltqa = (unsigned long long *) (lds + P.off_ltq);
@@ -134,7 +136,8 @@ WT_DEV void wt_delta_zero(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, i
     if (tid == 0) {
         d.dsh->base_v = 0; d.dsh->base_c = 0;
         if constexpr (QQ) { d.dsh->base_qa = 0; d.dsh->base_qb = 0; }
-        d.dsh->emin = 255; d.dsh->emax = 0; d.dsh->bad = 0;
+        // (non-zero defaults are terms of every position's sum: their exponents belong to every window's range)
+        d.dsh->emin = P.def_emin; d.dsh->emax = P.def_emax; d.dsh->bad = 0;
     }
 }
 
@@ -174,6 +177,7 @@ WT_DEV void wt_delta_ranges1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0,
     }
     d.tbase[tid] = first * 4;
     d.ltc[tid] = (int32_t) n;
+    if (P.delta_df) d.tdef[tid] = g < N ? __builtin_bit_cast(uint32_t, (float) P.defaults[g]) : 0u;
 }
 WT_DEV void wt_delta_ranges1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0, int tid, int nt) {
     wt_delta_ranges1(P, c, d, c0, tid, nt, c.sh->row, c.sh->chrom);
@@ -290,20 +294,29 @@ struct WtDeltaRange {
     uint32_t kmax, kmin;        // max of (bits & 0x7fffffff); min of (bits & 0x7fffffff) - 1 (zero wraps to the top)
 };
 
-template <bool QQ = false>
-WT_DEV void wt_delta_apply(WtDeltaCtx &d, WtCtx &c, int32_t w0, uint32_t width, int32_t s, int32_t f, uint32_t vb,
+// the float with bits `vb` in units of 2^(scale - 150): signed mantissa, shifted (a wrapped shift count -- a value
+// below the unit -- gives garbage, see above)
+WT_DEV long long wt_delta_scaled(uint32_t vb, int scale) {
+    const uint32_t e = (vb >> 23) & 0xffu;
+    const uint32_t m = (vb & 0x7fffffu) | ((e < 1u ? e : 1u) << 23);    // hidden bit unless denormal / zero
+    const int32_t sgn = (int32_t) vb >> 31;
+    const int32_t sm = (int32_t) ((m ^ (uint32_t) sgn) - (uint32_t) sgn);
+    return (long long) ((unsigned long long) (long long) sm << (((e > 1u ? e : 1u) - (uint32_t) scale) & 63u));
+}
+
+// DF (non-zero defaults, Sum / Mean): a track that is absent contributes its default, so the window's base holds
+// the sum of all defaults and an interval adds (value - default) while it lasts -- `db`: the default's bits.
+template <bool QQ = false, bool DF = false>
+WT_DEV void wt_delta_apply(WtDeltaCtx &d, WtCtx &c, int32_t w0, uint32_t width, int32_t s, int32_t f, uint32_t vb, uint32_t db,
                            int scale, bool ok, int32_t &my_next, WtDeltaRange &R) {
     const uint32_t key = vb & 0x7fffffffu;
     R.kmax = key > R.kmax ? key : R.kmax;
     R.kmin = key - 1u < R.kmin ? key - 1u : R.kmin;
-    const uint32_t e = (vb >> 23) & 0xffu;
-    const uint32_t m = (vb & 0x7fffffu) | ((e < 1u ? e : 1u) << 23);    // hidden bit unless denormal / zero
-    const int32_t sgn = (int32_t) vb >> 31;
-    int32_t sm = (int32_t) ((m ^ (uint32_t) sgn) - (uint32_t) sgn);
+    long long vi = wt_delta_scaled(vb, scale);
+    if (DF) vi -= wt_delta_scaled(db, scale);
 #ifdef WT_EMU
-    if (!ok) sm = 0;            // (a window known not to be exact: the device adds garbage, the patch kernel rewrites the values)
+    if (!ok) vi = 0;            // (a window known not to be exact: the device adds garbage, the patch kernel rewrites the values)
 #endif
-    const long long vi = (long long) ((unsigned long long) (long long) sm << (((e > 1u ? e : 1u) - (uint32_t) scale) & 63u));
     const uint32_t cs = (uint32_t) (s - w0), cf = (uint32_t) (f - w0);
     if (cs < width && cf < width) {             // the common case: the run lies inside the window -- no branches
         wt_lds_add64((unsigned long long *) &d.acc[cs], (unsigned long long) vi);
@@ -342,9 +355,11 @@ WT_DEV void wt_delta_apply(WtDeltaCtx &d, WtCtx &c, int32_t w0, uint32_t width, 
 }
 
 // the lane's WT_DELTA_U intervals of one tile (same software pipeline as pass 1)
+template <bool DF>
 struct WtDeltaBatch {
     int32_t s[WT_DELTA_U], f[WT_DELTA_U];
     uint32_t b[WT_DELTA_U];
+    uint32_t d[DF ? WT_DELTA_U : 1];    // DF: bits of the interval's track's default
 };
 
 // The loads are UNCONDITIONAL and always in range: a flat index past the end is clamped to the last
@@ -354,13 +369,15 @@ struct WtDeltaBatch {
 // waited for before the tile it was meant to overlap is applied (round 2, read off the ISA).
 // The track of a flat index: tfirst[] gives the tile's first one; the lane keeps the end of its
 // current slice and the slice's byte offset in registers and only walks tpfx[] when an index crosses it.
-WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, WtDeltaBatch &B) {
+template <bool DF>
+WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, WtDeltaBatch<DF> &B) {
     const uint32_t last = (M - 1u) / WT_DELTA_TILE * WT_DELTA_TILE;
     const uint32_t tbe = tb < last ? tb : last;
     const uint32_t tile = tbe / WT_DELTA_TILE;
     int i = tile < WT_DELTA_TF ? (int) d.tfirst[tile] : wt_delta_find(d.tpfx, nt, tbe, 0);
     uint32_t hi = d.tpfx[i + 1];
     long long dl = d.tbase[i];
+    uint32_t db = DF ? d.tdef[i] : 0u;
 #pragma unroll
     for (int u = 0; u < WT_DELTA_U; u++) {
         uint32_t jj = tbe + (uint32_t) lane + 64u * (uint32_t) u;
@@ -368,36 +385,39 @@ WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint3
         if (jj >= hi) {
             do { i++; hi = d.tpfx[i + 1]; } while (jj >= hi);
             dl = d.tbase[i];
+            if (DF) db = d.tdef[i];
         }
         const long long ob = dl + ((long long) jj << 2);
         B.s[u] = *(const int32_t *) ((const char *) P.start + ob);
         B.f[u] = *(const int32_t *) ((const char *) P.finish + ob);
         B.b[u] = *(const uint32_t *) ((const char *) P.value + ob);
+        if (DF) B.d[u] = db;
     }
 }
 
 // every interval of the tile at flat index `tb`; only the window's last tile can be partial
-template <bool QQ = false>
-WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch &B, uint32_t tb, uint32_t M, int lane, int32_t w0,
+template <bool QQ = false, bool DF = false>
+WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF> &B, uint32_t tb, uint32_t M, int lane, int32_t w0,
                                 uint32_t width, int scale, bool ok, int32_t &my_next, WtDeltaRange &R) {
     if (tb + WT_DELTA_TILE <= M) {
 #pragma unroll
         for (int u = 0; u < WT_DELTA_U; u++)
-            wt_delta_apply<QQ>(d, c, w0, width, B.s[u], B.f[u], B.b[u], scale, ok, my_next, R);
+            wt_delta_apply<QQ, DF>(d, c, w0, width, B.s[u], B.f[u], B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
     } else {
 #pragma unroll
         for (int u = 0; u < WT_DELTA_U; u++)
             if (tb + (uint32_t) lane + 64u * (uint32_t) u < M)
-                wt_delta_apply<QQ>(d, c, w0, width, B.s[u], B.f[u], B.b[u], scale, ok, my_next, R);
+                wt_delta_apply<QQ, DF>(d, c, w0, width, B.s[u], B.f[u], B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
     }
 }
 
 // `scale`: exponent of one unit of the scaled mantissas; `ok`: false -> the window is known not to be
 // exact (only coordinates matter); `collect`: also publish the exponent range of the values (the
-// speculative single-pass flavour, see wt_delta_window_verdict); `stats`: count the intervals.
-template <bool QQ = false>
+// speculative single-pass flavour, see wt_delta_window_verdict); `stats`: count the intervals;
+// `ntr`: tracks of this chunk (DF: their defaults go to the window's base).
+template <bool QQ = false, bool DF = false>
 WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale, bool ok, bool collect, bool stats,
-                           int tid, int nt) {
+                           int tid, int nt, int ntr = 0) {
     const int wave = wt_uniform32(tid >> 6), lane = tid & 63, nwaves = nt >> 6;     // (uniform: the tile tests stay scalar)
     const uint32_t M = (uint32_t) wt_uniform32((int32_t) d.tpfx[nt]);
     const int32_t w0 = wt_uniform32(c.sh->w0);
@@ -406,19 +426,25 @@ WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale
     int32_t my_next = 0x7fffffff;
     WtDeltaRange R;
     R.kmax = 0u; R.kmin = 0xffffffffu;
+    if (DF) {
+        // every track's default, present or not, in the units of this pass
+        unsigned long long dsum = (tid < ntr && ok) ? (unsigned long long) wt_delta_scaled(d.tdef[tid], scale) : 0ull;
+        dsum = wt_wave_sum_u64(dsum);
+        if (dsum && wt_wave_leader(lane)) wt_lds_add64((unsigned long long *) &d.dsh->base_v, dsum);
+    }
     uint32_t tb = (uint32_t) wave * WT_DELTA_TILE;
     if (tb < M) {
         // two register sets take turns (a `cur = nxt` copy is 12 moves per tile, and it put the wait for the
         // prefetched tile at the end of the iteration that issued it)
-        WtDeltaBatch A, B;
-        wt_delta_fetch(P, d, nt, M, tb, lane, A);
+        WtDeltaBatch<DF> A, B;
+        wt_delta_fetch<DF>(P, d, nt, M, tb, lane, A);
         for (;;) {
-            wt_delta_fetch(P, d, nt, M, tb + step, lane, B);    // (past the end: harmless re-reads of the last tile)
-            wt_delta_apply_tile<QQ>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R);
+            wt_delta_fetch<DF>(P, d, nt, M, tb + step, lane, B);    // (past the end: harmless re-reads of the last tile)
+            wt_delta_apply_tile<QQ, DF>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R);
             tb += step;
             if (tb >= M) break;
-            wt_delta_fetch(P, d, nt, M, tb + step, lane, A);
-            wt_delta_apply_tile<QQ>(d, c, B, tb, M, lane, w0, width, scale, ok, my_next, R);
+            wt_delta_fetch<DF>(P, d, nt, M, tb + step, lane, A);
+            wt_delta_apply_tile<QQ, DF>(d, c, B, tb, M, lane, w0, width, scale, ok, my_next, R);
             tb += step;
             if (tb >= M) break;
         }

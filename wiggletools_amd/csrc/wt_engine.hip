@@ -210,7 +210,8 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
 #ifndef WT_DELTA_BLOCK
 #define WT_DELTA_BLOCK 512
 #endif
-template <int OP>
+// DF: some track's default is non-zero (Sum / Mean; P.delta_df)
+template <int OP, bool DF = false>
 __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA_BLOCK, WT_DELTA_SQ(OP) ? 2 : WT_DELTA_MIN_WAVES) wt_delta_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
@@ -242,6 +243,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
         k_dbg = k;
         if (k >= P.n_windows) break;
         const int nchunks = (P.n_tracks + nt - 1) / nt;
+        auto ntr = [&](int ch) { const int r = P.n_tracks - ch * nt; return r < nt ? r : nt; };     // tracks of chunk ch
         wt_delta_zero<QQ>(P, c, d, tid, nt);
         WT_TICK(0);
         WT_MARK(102);
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
                     wt_delta_ranges_w2(P, c, d, tid, nt);
                     __syncthreads();
                 }
-                wt_delta_pass2<QQ>(P, c, d, scale, ok, false, true, tid, nt);
+                wt_delta_pass2<QQ, DF>(P, c, d, scale, ok, false, true, tid, nt, ntr(ch));
                 __syncthreads();
                 WT_TICK(3);
             }
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
                 wt_delta_ranges_w2(P, c, d, tid, nt);
                 __syncthreads();
                 WT_TICK(1);
-                wt_delta_pass2<QQ>(P, c, d, guess, true, true, true, tid, nt);
+                wt_delta_pass2<QQ, DF>(P, c, d, guess, true, true, true, tid, nt, ntr(ch));
                 __syncthreads();
                 WT_TICK(3);
             }
@@ -300,7 +302,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
                         wt_delta_ranges_w2(P, c, d, tid, nt);
                         __syncthreads();
                     }
-                    wt_delta_pass2<QQ>(P, c, d, lo, ok, false, false, tid, nt);
+                    wt_delta_pass2<QQ, DF>(P, c, d, lo, ok, false, false, tid, nt, ntr(ch));
                     __syncthreads();
                 }
                 scale = lo;
@@ -1309,9 +1311,9 @@ static hipError_t wt_launch_patch_t(const WtParams &P, const WtPatchArgs &Q, int
     return hipGetLastError();
 }
 
-template <int OP>
+template <int OP, bool DF = false>
 static void wt_launch_delta(WtLaunch &L) {
-    auto kern = wt_delta_kernel<OP>;
+    auto kern = wt_delta_kernel<OP, DF>;
     if (L.lds > 48 * 1024) {
         L.err = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds);
         if (L.err != hipSuccess) return;
@@ -1475,6 +1477,7 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
         }
         L.P.bad_list = w->d_bad_list;
         L.P.bad_goff = w->d_bad_goff;
+        wt_delta_defaults_params(ts->defaults.data(), ts->n_tracks, L.P);
     }
 
     WT_HIP(hipMemsetAsync(ts->d_counters, 0, sizeof(unsigned long long) * WT_CTR_N, s));
@@ -1484,8 +1487,8 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
         WT_HIP(hipEventRecord(ts->ev_r0, s));
         if (plan.delta) {
             switch (op) {
-            case WT_OP_SUM: wt_launch_delta<WT_OP_SUM>(L); break;
-            case WT_OP_MEAN: wt_launch_delta<WT_OP_MEAN>(L); break;
+            case WT_OP_SUM: if (L.P.delta_df) wt_launch_delta<WT_OP_SUM, true>(L); else wt_launch_delta<WT_OP_SUM>(L); break;
+            case WT_OP_MEAN: if (L.P.delta_df) wt_launch_delta<WT_OP_MEAN, true>(L); else wt_launch_delta<WT_OP_MEAN>(L); break;
             case WT_OP_VAR: wt_launch_delta<WT_OP_VAR>(L); break;
             case WT_OP_CV: wt_launch_delta<WT_OP_CV>(L); break;
             default: wt_launch_delta<WT_OP_STDDEV>(L); break;      // stddev, entropy (reducers.c:665)

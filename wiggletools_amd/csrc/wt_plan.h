@@ -20,7 +20,7 @@ struct WtPlan {
     int spitch = 0, cpitch = 0, count_segs = 8;
     int chunk_tracks = 0, n_chunks = 1;   // tracks resident in LDS at a time / number of chunks
     int lanes_per_pos = 1;  // MWU: lanes of a workgroup sharing one window position (T = lanes_per_pos * W, K = 1)
-    int off_acc = 0, off_ev = 0, off_ltv = 0, off_ltc = 0, off_gtv = 0, off_gtc = 0, off_tbase = 0, off_tpfx = 0, off_tfirst = 0, off_dsh = 0;
+    int off_acc = 0, off_ev = 0, off_ltv = 0, off_ltc = 0, off_gtv = 0, off_gtc = 0, off_tbase = 0, off_tpfx = 0, off_tfirst = 0, off_dsh = 0, off_tdef = 0;
     int off_qa = 0, off_ltq = 0, off_gtq = 0, delta_q = 0;
     bool delta = false;     // difference-array plan (wt_delta.h)
     int off_S = 0, off_cnt = 0, off_segtot = 0, off_U = 0, off_cover = 0, off_E = 0, off_epfx = 0, off_nextw = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
@@ -111,6 +111,7 @@ static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = fa
     p.off_tbase = o;  o = wt_align16(o + T * 8);
     p.off_tpfx = o;   o = wt_align16(o + (T + 1) * 4);
     p.off_tfirst = o; o = wt_align16(o + WT_DELTA_TF * 2);
+    p.off_tdef = o;   o = wt_align16(o + T * 4);
     p.off_dsh = o;    o = wt_align16(o + (int) sizeof(WtDeltaShared));
     p.delta_q = squares ? 1 : 0;
     if (squares) {
@@ -134,9 +135,33 @@ static inline bool wt_delta_eligible(int op, bool value_f64, int n_tracks, const
     const char *eM = getenv("WTAMD_DELTA_MIN_TRACKS");
     const int min_tracks = eM ? atoi(eM) : 4;
     if (value_f64 || n_tracks < min_tracks || n_tracks > 32767) return false;    // ev[] counts in 16-bit halves
-    for (int i = 0; i < n_tracks; i++)
-        if (!(defaults[i] == 0.0)) return false;
+    // Defaults: an absent track adds its default value (reducers.c:294-307, 375-401: every track's value or
+    // default is summed).  Zero never changes a sum; a non-zero default is one more term of every sum, which
+    // stays exact under the same condition as the values as long as it is itself a float (round 3: Sum / Mean
+    // only -- the squares of the var family count the tracks IN PLAY).  WTAMD_NO_DELTA_DEFAULTS: zero only.
+    for (int i = 0; i < n_tracks; i++) {
+        if (defaults[i] == 0.0) continue;
+        if (sq || getenv("WTAMD_NO_DELTA_DEFAULTS")) return false;
+        const float f = (float) defaults[i];
+        if (!((double) f == defaults[i]) || !(f - f == 0.0f)) return false;       // not a float / NaN / Inf
+    }
     return true;
+}
+
+// Difference-array launches: what the kernel needs to know about the defaults (after wt_plan_to_params).
+static inline void wt_delta_defaults_params(const double *defaults, int n_tracks, WtParams &P) {
+    P.delta_df = 0; P.def_emin = 255; P.def_emax = 0;
+    for (int i = 0; i < n_tracks; i++) {
+        if (defaults[i] == 0.0) continue;
+        const float f = (float) defaults[i];
+        uint32_t bits;
+        memcpy(&bits, &f, 4);
+        int e = (int) ((bits >> 23) & 0xffu);
+        if (e == 0) e = 1;                  // denormal: exponent 1 without the hidden bit
+        P.delta_df = 1;
+        if (e < P.def_emin) P.def_emin = e;
+        if (e > P.def_emax) P.def_emax = e;
+    }
 }
 
 // Chooses (positions per lane, T, W = ppt*T): the widest window whose bitmaps (and scratch
@@ -264,7 +289,8 @@ static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.off_epfx = p.off_epfx; P.off_nextw = p.off_nextw; P.off_gbase = p.off_gbase; P.off_scratch = p.off_scratch;
     P.off_dflt32 = p.off_dflt32;
     P.off_acc = p.off_acc; P.off_ev = p.off_ev; P.off_ltv = p.off_ltv; P.off_ltc = p.off_ltc;
-    P.off_gtv = p.off_gtv; P.off_gtc = p.off_gtc; P.off_tbase = p.off_tbase; P.off_tpfx = p.off_tpfx; P.off_tfirst = p.off_tfirst; P.off_dsh = p.off_dsh;
+    P.off_gtv = p.off_gtv; P.off_gtc = p.off_gtc; P.off_tbase = p.off_tbase; P.off_tpfx = p.off_tpfx; P.off_tfirst = p.off_tfirst; P.off_dsh = p.off_dsh; P.off_tdef = p.off_tdef;
+    P.delta_df = 0; P.def_emin = 255; P.def_emax = 0;
     P.off_qa = p.off_qa; P.off_ltq = p.off_ltq; P.off_gtq = p.off_gtq; P.delta_q = p.delta_q;
     P.off_shared = p.off_shared; P.lds_bytes = p.lds_bytes;
 }
