@@ -484,7 +484,7 @@ def test_plan_policy_snapshot():
         t = synth(n, [300], mean_run=8, seed=1, dtype=dtype)
         return emu.reduce(t, op, **kw)[1]
     p = plan(100, "mean")
-    assert (p["delta"], p["W"], p["T"]) == (1, 4096, 512)                # difference-array kernel
+    assert (p["delta"], p["W"], p["T"]) == (1, 8192, 1024)               # difference-array kernel (round 3: 1024 lanes, 8192-bp windows)
     p = plan(100, "max")
     assert (p["W"], p["T"], p["n_chunks"]) == (2048, 512, 1)             # bitmaps of 100 tracks: half the LDS
     p = plan(500, "var")

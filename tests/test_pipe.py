@@ -62,7 +62,7 @@ def test_pipe_difference_array_with_patched_windows(oracle, lib, monkeypatch):
     from wiggletools_amd.pipe import stream_runlists
     from wiggletools_amd.runlists import synth
     monkeypatch.setenv("WTAMD_DELTA_MIN_TRACKS", "1")
-    t = synth(6, [60000], mean_run=9, seed=3, dtype=np.float32)
+    t = synth(6, [240000], mean_run=9, seed=3, dtype=np.float32)        # (8192-bp windows: a batch needs > 4 per inexact one)
     v = t.value
     v[100] = np.nan
     v[len(v) // 2] = np.inf
@@ -70,7 +70,7 @@ def test_pipe_difference_array_with_patched_windows(oracle, lib, monkeypatch):
     v[len(v) // 3 + 1] = 2.0 ** 100
     d = t.as_dict()
     for op in ("sum", "mean"):
-        got, st = stream_runlists(t, op, 20000, depth=2, lib=lib)
+        got, st = stream_runlists(t, op, 80000, depth=2, lib=lib)
         assert_runs_equal(got, oracle.reduce(d, op), 0.0, op)
         assert st["delta_batches"] == st["batches"] > 1
 

@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
 #define WT_DELTA_SQ_BLOCK 512    // workgroup of the launches that also accumulate squares
 #endif
 #ifndef WT_DELTA_BLOCK
-#define WT_DELTA_BLOCK 512
+#define WT_DELTA_BLOCK 1024     // (launch bound; the plan's default, see wt_make_delta_plan)
 #endif
 // DF: some track's default is non-zero (Sum / Mean; P.delta_df)
 template <int OP, bool DF = false>

@@ -89,10 +89,14 @@ static inline bool wt_op_is_var_family(int op) {
 // per position: 142 KB of LDS for the 4096-bp window, one workgroup of 8 waves per CU -- measured 21 %
 // faster than 2048-bp windows (86 KB: also one workgroup per CU, but of 4 waves).
 static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = false) {
+    // Sum / Mean: 1024 lanes, an 8192-bp window, one workgroup of 16 waves per CU (round 3: 6 % faster than two
+    // workgroups of 512 once pass 2 had shed its instructions -- the per-window chain of dependent round trips
+    // is paid half as often; round 2 had measured +1.5 %).  With squares: 512 (142 KB of LDS at 4096 bp).
     const char *eT = getenv("WTAMD_DELTA_T");
-    int T = eT ? atoi(eT) : 512;
+    const int T0 = squares ? 512 : 1024;
+    int T = eT ? atoi(eT) : T0;
     (void) n_tracks;
-    if (T < 64 || T > WT_MAX_DELTA_T || (T & (T - 1)) || (squares && T > 512)) T = 512;
+    if (T < 64 || T > WT_MAX_DELTA_T || (T & (T - 1)) || (squares && T > 512)) T = T0;
     p = WtPlan();
     p.delta = true;
     p.T = T; p.ppt = WT_DELTA_K; p.W = WT_DELTA_K * T; p.n_words = p.W / 64;
