@@ -134,10 +134,6 @@ struct WtShared {
     unsigned long long bp_sum;    // covered bp of this window
     unsigned long long n_intervals;
     int32_t bad_slot;             // difference-array kernel: slot of this window in bad_list, or -1
-    // difference-array kernel: the NEXT window of this workgroup, claimed while the current one is still being
-    // copied out (wt_phase_header_next / wt_phase_header_install)
-    int32_t nx_chrom, nx_w0, nx_emit_hi, nx_pad;
-    long long nx_ticket, nx_row;
 };
 
 // Per-lane state that lives across phases (registers on the GPU)
@@ -339,36 +335,6 @@ WT_DEV void wt_phase_header(const WtParams &P, WtCtx &c, long long k) {
     sh->w1 = sh->w0 + P.W;
     sh->emit_hi = P.c_hi[ch];
     sh->row = k + ch;                 // one extra boundary row per chromosome
-    sh->next_bp = 0x7fffffff;
-    sh->n_emit = 0;
-    sh->bp_sum = 0;
-    sh->n_intervals = 0;
-    sh->goffset = 0;
-    sh->bad_slot = -1;
-}
-
-// The same header, prepared early: the loads (win_chrom -> cbase / c_hi / c_first_win) are two dependent global
-// round trips behind the ticket's atomic, and nothing in them depends on the current window.  One lane fills
-// the nx_ fields while the current window is still in its look-back / copy-out; installing them is LDS only.
-WT_DEV void wt_phase_header_next(const WtParams &P, WtCtx &c, long long k) {
-    WtShared *sh = c.sh;
-    sh->nx_ticket = k;
-    if (k >= P.n_windows) return;
-    const int ch = P.win_chrom[k];
-    const long long m = k - P.c_first_win[ch];
-    sh->nx_chrom = ch;
-    sh->nx_w0 = P.cbase[ch] + (int32_t) m * P.W;
-    sh->nx_emit_hi = P.c_hi[ch];
-    sh->nx_row = k + ch;
-}
-WT_DEV void wt_phase_header_install(const WtParams &P, WtCtx &c) {
-    WtShared *sh = c.sh;
-    sh->ticket = sh->nx_ticket;
-    sh->chrom = sh->nx_chrom;
-    sh->w0 = sh->nx_w0;
-    sh->w1 = sh->nx_w0 + P.W;
-    sh->emit_hi = sh->nx_emit_hi;
-    sh->row = sh->nx_row;
     sh->next_bp = 0x7fffffff;
     sh->n_emit = 0;
     sh->bp_sum = 0;
