@@ -13,6 +13,7 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tm
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_write -- python $R/bench.py $BARGS > $OUT/c2_write_run.log 2>&1
 export WTAMD_BENCH_BWDIR=/dev/shm/wtamd_r3 WTAMD_BENCH_NO_HOSTDEC=1
 MBP=${BW_MBP:-248.956422}
+if [ -z "$SKIP_BW" ]; then
 python $R/tools/e2e_bw_only.py $MBP > $OUT/bw_plain.json 2> $OUT/bw_plain.err        # writes the files, cold + warm figures
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/b_stats -- python $R/tools/e2e_bw_only.py $MBP > $OUT/bw_stats_run.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/b_fetch -- python $R/tools/e2e_bw_only.py $MBP > $OUT/bw_fetch_run.log 2>&1
@@ -25,6 +26,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_A
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/b_sq$i -- python $R/tools/e2e_bw_only.py $MBP > $OUT/bw_sq$i.log 2>&1
 done
+fi      # SKIP_BW
 python - <<PY
 import csv, glob, json, os
 out = "$OUT"
@@ -67,4 +69,4 @@ summary["inflate_sq"] = s
 json.dump(summary, open(os.path.join(out, "pmc_sq_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:3000])
 PY
-tail -c 600 $OUT/bw_plain.json
+[ -z "$SKIP_BW" ] && tail -c 600 $OUT/bw_plain.json
