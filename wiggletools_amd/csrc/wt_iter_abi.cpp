@@ -241,6 +241,10 @@ struct DrainPool {
 };
 
 int wt_usable_cores() {
+    // WTAMD_HOST_THREADS: the number the library's thread pools are sized by (experiments: a cgroup quota of 16 cores
+    // is exhausted by 16 busy workers + the feeder + the runtime's own threads, and the whole group is throttled)
+    static const int forced = [] { const char *e = getenv("WTAMD_HOST_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? (v > 64 ? 64 : v) : 0; }();
+    if (forced) return forced;
     // container CPU quota first (the GPU box shows 256 logical CPUs and grants 16): "quota period" or "max period"
     if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {
         char q[64]; long long period = 0;
