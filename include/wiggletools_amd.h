@@ -556,6 +556,12 @@ WiggleIterator *wtamd_BigWiggleReader(const char *path, int box);
 /* The same for n files at once, opened side by side on a few threads (every constructor reads its file's index and
  * primes: ~1-2 ms per file, which 100 tracks would otherwise pay one after the other before the first run). */
 int wtamd_BigWiggleReaders(int n, const char *const *paths, int box, WiggleIterator **out);
+/* Releases what destroyWiggleIterator (wiggleIterator.c:52-55) cannot know about: the file, the decode buffers and
+ * the producer thread (joined).  The iterator stays the caller's to free; it must not be popped, sought or given to
+ * a reducer afterwards.  A reader that is never closed keeps its file descriptor and, once its second part has been
+ * asked for, one idle thread for the life of the process (the reference's reader thread is never joined either,
+ * bigWiggleReader.c:147-151).  WTAMD_ERR_ARG for anything that is not an open wtamd_BigWiggleReader. */
+int wtamd_BigWiggleReader_close(WiggleIterator *wi);
 /* Fused integrators (reference AUCIntegrator / MeanIntegrator, statistics.c:62-127; PearsonIntegrator :414-465; built
  * by commandParser.c:653-704).  Same contract towards the consumer that prints the result: an iterator to be popped
  * to its end whose `data` starts with the double result and whose `append` is the source

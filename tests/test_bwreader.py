@@ -197,6 +197,37 @@ def test_bigwig_files_to_reducers_gpu(amd_lib, oracle, tmp_path):
     _run_all(amd_lib, oracle, tmp_path)
 
 
+def _close_case(L, tmp_path):
+    """wtamd_BigWiggleReader_close: after the priming block only (no producer thread yet) and after several parts
+    (thread running); anything else is refused."""
+    import threading
+    L.wtamd_BigWiggleReader_close.argtypes = [C.c_void_p]
+    L.wtamd_BigWiggleReader_close.restype = C.c_int
+    paths = _write_set(tmp_path, 2, seed=77, block=13)
+    before = threading.active_count()
+    wi = L.wtamd_BigWiggleReader(paths[0].encode(), 1)
+    assert L.wtamd_BigWiggleReader_close(wi) == 0
+    assert C.cast(wi, C.POINTER(WI)).contents.done
+    assert L.wtamd_BigWiggleReader_close(wi) != 0                  # already closed
+    wi = L.wtamd_BigWiggleReader(paths[1].encode(), 1)
+    got = _pops(L, wi, limit=500)                                   # several 13-item blocks: the producer was started
+    assert len(got) == 500
+    assert L.wtamd_BigWiggleReader_close(wi) == 0
+    assert threading.active_count() == before                       # (python's view; the native thread was joined)
+    its = (C.c_void_p * 1)(L.wtamd_BigWiggleReader(paths[0].encode(), 1))
+    m = L.newMultiplexer(its, 1, b"\x00")
+    assert L.wtamd_BigWiggleReader_close(L.MeanReduction(m)) != 0   # not a BigWig reader
+
+
+def test_bigwig_reader_close_emu(emu_lib, tmp_path):
+    _close_case(emu_lib, tmp_path)
+
+
+@pytest.mark.gpu
+def test_bigwig_reader_close_gpu(amd_lib, tmp_path):
+    _close_case(amd_lib, tmp_path)
+
+
 def test_array_writer_round_trip(tmp_path):
     """wiggletools_amd/bwwrite.py (bench files): two-level index, chromosomes without data."""
     from wiggletools_amd import bwwrite

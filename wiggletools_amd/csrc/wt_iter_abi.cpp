@@ -1191,8 +1191,7 @@ void bw_producer(BwReader *r);
 void bw_start(BwReader *r) {
     if (r->started) return;
     r->started = true;
-    r->th = std::thread(bw_producer, r);
-    r->th.detach();                             // lives for the process, like the reference's reader threads
+    r->th = std::thread(bw_producer, r);        // idles between requests; wtamd_BigWiggleReader_close ends and joins it
     bw_request(r, r->cur ^ 1);
 }
 
@@ -2114,6 +2113,29 @@ WiggleIterator *wtamd_BigWiggleReader(const char *path, int box) {
     if (r->buf[0].chrom < 0) r->done = true;
     bw_settle(r, wi);
     return wi;
+}
+
+// Releases what the reference's destroyWiggleIterator cannot know about: the file, the two decode buffers and the
+// producer thread (joined).  The iterator itself stays the caller's (free() / destroyWiggleIterator as usual); it
+// must not be popped, sought or handed to a reducer afterwards.  Readers that are never closed keep an idle thread
+// and a file descriptor each for the life of the process, like the reference's (bigWiggleReader.c never joins).
+int wtamd_BigWiggleReader_close(WiggleIterator *wi) {
+    if (!wi || wi->pop != &wt_bulk_pop || !wi->data) return WTAMD_ERR_ARG;
+    BwHandle *h = (BwHandle *) wi->data;
+    if (h->hdr.peek != &bw_peek || !h->r) return WTAMD_ERR_ARG;
+    BwReader *r = h->r;
+    if (r->started) {
+        { std::unique_lock<std::mutex> lk(r->mu); r->cv.wait(lk, [&] { return r->want_buf < 0; }); r->quit = true; }
+        r->cv.notify_all();
+        if (r->th.joinable()) r->th.join();
+    }
+    wtamd_bw_close(r->bw);
+    bw_free(r->buf[0]); bw_free(r->buf[1]);
+    // (the chromosome names stay: consumers may still hold the pointers they were handed)
+    delete r;
+    h->r = nullptr;
+    wi->done = true;
+    return WTAMD_OK;
 }
 
 WiggleIterator *wtamd_AUCIntegrator(WiggleIterator *wi) { return make_integrator(wi, nullptr, 0); }
