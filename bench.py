@@ -313,7 +313,15 @@ def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
         size = sum(os.path.getsize(j[0]) for j in jobs)
         os.environ.pop("WTAMD_BW_DEVICE", None)
 
+        def pool():
+            import ctypes as C
+            from wiggletools_amd import _lib
+            a = (C.c_int64 * 6)()
+            _lib.lib().wtamd_pool_stats(a)
+            return list(a)
+
         def run_once():
+            p0 = pool()
             t0 = time.perf_counter()
             readers = dropin.bigwig_readers([j[0] for j in jobs], box=True)
             t_readers = time.perf_counter() - t0
@@ -328,6 +336,10 @@ def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
                  "sections_inflated_on_device": st.get("bw_sections"), "sum_device_decode_ms": st.get("bw_decode_ms"),
                  "sum_kernel_ms": st.get("kernel_ms"), "sum_d2h_ms": st.get("d2h_ms"), "host_submit_ms": st.get("host_submit_ms"),
                  "host_wait_ms": st.get("host_wait_ms")}
+            p1 = pool()
+            # buffers of 1 MB and more this run had to get from the runtime instead of the process-wide pools
+            o["pinned_afresh"] = {"buffers": p1[0] - p0[0], "bytes": p1[1] - p0[1]}     # hipHostMalloc
+            o["device_afresh"] = {"buffers": p1[3] - p0[3], "bytes": p1[4] - p0[4]}     # hipMalloc
             q = [m for m in marks if m[1] >= L // 4]        # ramp-up excluded: from the block ending the first quarter on
             if len(q) >= 2 and q[-1][0] > q[0][0]:
                 o["steady_bp_per_s"] = (q[-1][1] - q[0][1]) / (q[-1][0] - q[0][0])

@@ -532,6 +532,11 @@ int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *);
 /* Pinned (page-locked, DMA-able) host memory for bulk sources. */
 void *wtamd_host_alloc(size_t bytes);
 void wtamd_host_free(void *);
+/* The process-wide pools behind the pipes: page-locked staging (also wtamd_host_alloc; WTAMD_PINNED_POOL_MB) and
+ * device buffers (WTAMD_DEVICE_POOL_MB).  out[0..2]: pinned buffers of 1 MB and more that had to be page-locked afresh
+ * so far (count, bytes) and the bytes resting in the pool now; out[3..5]: the same for device buffers (hipMalloc).  A
+ * second run of the same job in a process should add no misses. */
+void wtamd_pool_stats(int64_t out[6]);
 
 /* ---- Bulk doors of the drop-in layer ------------------------------------------------------
  * The reference's iterator protocol moves ONE interval per indirect call (wiggleIterator.c:57-60);

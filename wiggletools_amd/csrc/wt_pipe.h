@@ -143,6 +143,7 @@ struct WtPinnedPool {
     std::multimap<size_t, void *> free_list;        // by exact size
     std::map<void *, size_t> size_of;               // every live buffer that came through here
     size_t pooled = 0;
+    size_t misses = 0, miss_bytes = 0;              // buffers of 1 MB and more that had to be page-locked afresh
     size_t limit() const {
         const char *e = getenv("WTAMD_PINNED_POOL_MB");
         return (size_t) (e ? atoll(e) : 4096) << 20;
@@ -150,8 +151,21 @@ struct WtPinnedPool {
 };
 static WtPinnedPool g_pinned_pool;
 
+// Sizes of 1 MB and more are rounded up to eighths of their power of two before they reach the pool or the runtime:
+// the staging of a file-byte batch is sized by the batch (306 995 195 bytes, then 308 322 053, ...), so the next run
+// of the same job never asked for exactly what the previous one had returned and page-locked everything afresh --
+// 0.8 s of hipHostMalloc on hosts where that runs at 1.5 GB/s (round 3; seen as a second run SLOWER than the first).
+static size_t wt_pool_round(size_t bytes) {
+    if (bytes < (1u << 20)) return bytes;
+    int lg = 63;
+    while (!((bytes >> lg) & 1u)) lg--;
+    const size_t step = (size_t) 1 << (lg - 3);
+    return (bytes + step - 1) / step * step;
+}
+
 static hipError_t wt_host_alloc(void **out, size_t bytes) {
     if (bytes < 1) bytes = 1;
+    bytes = wt_pool_round(bytes);
     if (bytes >= (1u << 20)) {
         std::lock_guard<std::mutex> lk(g_pinned_pool.mu);
         auto it = g_pinned_pool.free_list.find(bytes);
@@ -166,6 +180,8 @@ static hipError_t wt_host_alloc(void **out, size_t bytes) {
     if (e == hipSuccess && bytes >= (1u << 20)) {
         std::lock_guard<std::mutex> lk(g_pinned_pool.mu);
         g_pinned_pool.size_of[*out] = bytes;
+        g_pinned_pool.misses++;
+        g_pinned_pool.miss_bytes += bytes;
     }
     return e;
 }
@@ -185,6 +201,69 @@ static void wt_host_free(void *q) {
         }
     }
     (void) hipHostFree(q);
+}
+
+// Device buffers of a pipe, the same way: a pipe frees everything it holds when its reducer reaches the end of the data
+// (35 hipFree calls, each of which synchronises the device and unmaps gigabytes), and the next reducer of the process
+// maps it all again -- on some hosts that made the SECOND run of a job 2 x slower than the first (0.9 s inside
+// wtamd_pipe_submit_bw for 27 batches; round 3).  Released buffers rest in a process-wide pool keyed by (device,
+// rounded size); a pipe is destroyed only after its streams have been synchronised, so nothing in the pool is still
+// in use.  Bounded by WTAMD_DEVICE_POOL_MB per process (default 65536 -- a pipe of 100 tracks holds 38 GB; 0 switches the pool off).
+struct WtDevPool {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void *> free_list;
+    std::map<void *, std::pair<int, size_t>> size_of;
+    size_t pooled = 0, misses = 0, miss_bytes = 0;
+    size_t limit() const {
+        const char *e = getenv("WTAMD_DEVICE_POOL_MB");
+        return (size_t) (e ? atoll(e) : 65536) << 20;
+    }
+};
+static WtDevPool g_dev_pool;
+
+template <class T>
+static hipError_t wt_dev_alloc(T **out, size_t bytes) {
+    if (bytes < 1) bytes = 1;
+    bytes = wt_pool_round(bytes);
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_dev_pool.mu);
+        auto it = g_dev_pool.free_list.find({dev, bytes});
+        if (it != g_dev_pool.free_list.end()) {
+            *out = (T *) it->second;
+            g_dev_pool.pooled -= bytes;
+            g_dev_pool.free_list.erase(it);
+            return hipSuccess;
+        }
+    }
+    void *q = nullptr;
+    const hipError_t e = hipMalloc(&q, bytes);
+    *out = (T *) q;
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_dev_pool.mu);
+        g_dev_pool.size_of[q] = {dev, bytes};
+        g_dev_pool.misses++;
+        g_dev_pool.miss_bytes += bytes;
+    }
+    return e;
+}
+
+static hipError_t wt_dev_free(void *q) {
+    if (!q) return hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_pool.mu);
+        auto it = g_dev_pool.size_of.find(q);
+        if (it != g_dev_pool.size_of.end()) {
+            if (g_dev_pool.pooled + it->second.second <= g_dev_pool.limit()) {
+                g_dev_pool.free_list.emplace(it->second, q);
+                g_dev_pool.pooled += it->second.second;
+                return hipSuccess;
+            }
+            g_dev_pool.size_of.erase(it);
+        }
+    }
+    return hipFree(q);
 }
 
 struct WtSlot {
@@ -295,12 +374,12 @@ static void wt_slot_free(WtSlot &s) {
     if (s.h_finish) wt_host_free(s.h_finish);
     if (s.h_v32) wt_host_free(s.h_v32);
     if (s.h_v64) wt_host_free(s.h_v64);
-    (void) hipFree(s.d_start); (void) hipFree(s.d_finish); (void) hipFree(s.d_value);
-    (void) hipFree(s.d_os); (void) hipFree(s.d_of); (void) hipFree(s.d_ov); (void) hipFree(s.d_tile); (void) hipFree(s.d_ip);
-    (void) hipFree(s.d_cro);
-    (void) hipFree(s.d_cs); (void) hipFree(s.d_cf); (void) hipFree(s.d_cv); (void) hipFree(s.d_cscratch); (void) hipFree(s.d_cn);
+    (void) wt_dev_free(s.d_start); (void) wt_dev_free(s.d_finish); (void) wt_dev_free(s.d_value);
+    (void) wt_dev_free(s.d_os); (void) wt_dev_free(s.d_of); (void) wt_dev_free(s.d_ov); (void) wt_dev_free(s.d_tile); (void) wt_dev_free(s.d_ip);
+    (void) wt_dev_free(s.d_cro);
+    (void) wt_dev_free(s.d_cs); (void) wt_dev_free(s.d_cf); (void) wt_dev_free(s.d_cv); (void) wt_dev_free(s.d_cscratch); (void) wt_dev_free(s.d_cn);
     if (s.h_segs) wt_host_free(s.h_segs);
-    (void) hipFree(s.d_mstart); (void) hipFree(s.d_mfinish); (void) hipFree(s.d_mvalue); (void) hipFree(s.d_mseg); (void) hipFree(s.d_mscratch);
+    (void) wt_dev_free(s.d_mstart); (void) wt_dev_free(s.d_mfinish); (void) wt_dev_free(s.d_mvalue); (void) wt_dev_free(s.d_mseg); (void) wt_dev_free(s.d_mscratch);
     if (s.h_os) wt_host_free(s.h_os);
     if (s.h_of) wt_host_free(s.h_of);
     if (s.h_ov) wt_host_free(s.h_ov);
@@ -308,9 +387,9 @@ static void wt_slot_free(WtSlot &s) {
     if (s.h_ip) wt_host_free(s.h_ip);
     if (s.h_bw) wt_host_free(s.h_bw);
     if (s.h_integ) wt_host_free(s.h_integ);
-    (void) hipFree(s.d_integ);
+    (void) wt_dev_free(s.d_integ);
     if (s.h_bw_status) wt_host_free(s.h_bw_status);
-    (void) hipFree(s.d_bw); (void) hipFree(s.d_bw_scratch);
+    (void) wt_dev_free(s.d_bw); (void) wt_dev_free(s.d_bw_scratch);
     for (hipEvent_t e : {s.e_bwc, s.e_bw0, s.e_bw1})
         if (e) (void) hipEventDestroy(e);
     if (s.ts) {
@@ -391,7 +470,7 @@ static int wt_pipe_enqueue_export(wtamd_pipe *p, WtSlot &s, hipEvent_t after) {
 #define WT_INTEG_BLOCKS 256
 static int wt_pipe_enqueue_integ(wtamd_pipe *p, WtSlot &s, hipStream_t st) {
     const size_t need = sizeof(WtMoments) * WT_INTEG_BLOCKS + sizeof(double) * 16;
-    if (!s.d_integ) WT_HIP(hipMalloc((void **) &s.d_integ, need));
+    if (!s.d_integ) WT_HIP(wt_dev_alloc((void **) &s.d_integ, need));
     if (!s.h_integ) { WT_HIP(wt_host_alloc((void **) &s.h_integ, sizeof(double) * 8)); }
     const unsigned long long *n_dev = s.ts->d_counters + WT_CTR_RUNS;
     double *d_out = (double *) (s.d_integ + sizeof(WtMoments) * WT_INTEG_BLOCKS);
@@ -515,7 +594,7 @@ int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
         s.ts->last_finish.assign((size_t) N, 0);
         s.ts->range_lo.assign(1, 0);
         s.ts->range_hi.assign(1, INT32_MAX);
-        WT_PIPE_HIP(hipMalloc(&s.d_cro, sizeof(int64_t) * 2));
+        WT_PIPE_HIP(wt_dev_alloc(&s.d_cro, sizeof(int64_t) * 2));
     }
 #undef WT_PIPE_HIP
     *out = p;
@@ -533,8 +612,8 @@ void wtamd_pipe_destroy(wtamd_pipe *p) {
     if (p->s_copy) (void) hipStreamDestroy(p->s_copy);
     if (p->s_comp) (void) hipStreamDestroy(p->s_comp);
     if (p->s_out) (void) hipStreamDestroy(p->s_out);
-    if (p->d_chains) (void) hipFree(p->d_chains);
-    for (void *q : p->dead_dev) (void) hipFree(q);
+    if (p->d_chains) (void) wt_dev_free(p->d_chains);
+    for (void *q : p->dead_dev) (void) wt_dev_free(q);
     for (void *q : p->dead_host) wt_host_free(q);
     delete p;
 }
@@ -725,21 +804,21 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
         for (void *q : {(void *) s.d_start, (void *) s.d_finish, s.d_value}) if (q) p->dead_dev.push_back(q);
         s.d_start = s.d_finish = nullptr; s.d_value = nullptr; s.dcap = 0;
         const bool w64 = f64 || s.d_has64 || s.has64;
-        WT_HIP(hipMalloc(&s.d_start, sizeof(int32_t) * c));
-        WT_HIP(hipMalloc(&s.d_finish, sizeof(int32_t) * c));
-        WT_HIP(hipMalloc(&s.d_value, (w64 ? 8 : 4) * (size_t) c));
+        WT_HIP(wt_dev_alloc(&s.d_start, sizeof(int32_t) * c));
+        WT_HIP(wt_dev_alloc(&s.d_finish, sizeof(int32_t) * c));
+        WT_HIP(wt_dev_alloc(&s.d_value, (w64 ? 8 : 4) * (size_t) c));
         s.dcap = c; s.d_has64 = w64;
     }
     const bool mapped = p->d_chains != nullptr;
     if (mapped && (s.mcap < s.dcap || (p->map_drops && !s.m_has_coords))) {
         for (void *q : {(void *) s.d_mstart, (void *) s.d_mfinish, (void *) s.d_mvalue, (void *) s.d_mscratch}) if (q) p->dead_dev.push_back(q);
         s.d_mstart = s.d_mfinish = nullptr; s.d_mvalue = nullptr; s.d_mscratch = nullptr; s.mcap = 0; s.m_has_coords = false;
-        WT_HIP(hipMalloc(&s.d_mvalue, sizeof(double) * (size_t) s.dcap));
+        WT_HIP(wt_dev_alloc(&s.d_mvalue, sizeof(double) * (size_t) s.dcap));
         if (p->map_drops) {
-            WT_HIP(hipMalloc(&s.d_mstart, sizeof(int32_t) * (size_t) s.dcap));
-            WT_HIP(hipMalloc(&s.d_mfinish, sizeof(int32_t) * (size_t) s.dcap));
-            WT_HIP(hipMalloc(&s.d_mscratch, sizeof(unsigned long long) * (size_t) wt_map_scratch_words((long long) s.dcap)));
-            if (!s.d_mseg) WT_HIP(hipMalloc(&s.d_mseg, sizeof(int64_t) * ((size_t) N + 1)));
+            WT_HIP(wt_dev_alloc(&s.d_mstart, sizeof(int32_t) * (size_t) s.dcap));
+            WT_HIP(wt_dev_alloc(&s.d_mfinish, sizeof(int32_t) * (size_t) s.dcap));
+            WT_HIP(wt_dev_alloc(&s.d_mscratch, sizeof(unsigned long long) * (size_t) wt_map_scratch_words((long long) s.dcap)));
+            if (!s.d_mseg) WT_HIP(wt_dev_alloc(&s.d_mseg, sizeof(int64_t) * ((size_t) N + 1)));
             s.m_has_coords = true;
         }
         s.mcap = s.dcap;
@@ -758,17 +837,17 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
         s.d_os = s.d_of = nullptr; s.d_ov = s.d_tile = nullptr; s.d_ip = nullptr;
         for (void *q : {(void *) s.h_os, (void *) s.h_of, (void *) s.h_ov, (void *) s.h_tile, (void *) s.h_ip}) if (q) p->dead_host.push_back(q);
         s.h_os = s.h_of = nullptr; s.h_ov = s.h_tile = nullptr; s.h_ip = nullptr; s.ocap = 0;
-        WT_HIP(hipMalloc(&s.d_os, sizeof(int32_t) * c));
-        WT_HIP(hipMalloc(&s.d_of, sizeof(int32_t) * c));
-        WT_HIP(hipMalloc(&s.d_ov, sizeof(double) * c));
+        WT_HIP(wt_dev_alloc(&s.d_os, sizeof(int32_t) * c));
+        WT_HIP(wt_dev_alloc(&s.d_of, sizeof(int32_t) * c));
+        WT_HIP(wt_dev_alloc(&s.d_ov, sizeof(double) * c));
         WT_HIP(wt_host_alloc((void **) &s.h_os, sizeof(int32_t) * c));
         WT_HIP(wt_host_alloc((void **) &s.h_of, sizeof(int32_t) * c));
         WT_HIP(wt_host_alloc((void **) &s.h_ov, sizeof(double) * c));
         for (void *q : {(void *) s.d_cs, (void *) s.d_cf, (void *) s.d_cv, (void *) s.d_cscratch}) if (q) p->dead_dev.push_back(q);
         s.d_cs = s.d_cf = nullptr; s.d_cv = nullptr; s.d_cscratch = nullptr;
         if (p->tile) {
-            WT_HIP(hipMalloc(&s.d_tile, sizeof(double) * c * N));
-            WT_HIP(hipMalloc(&s.d_ip, sizeof(uint8_t) * c * N));
+            WT_HIP(wt_dev_alloc(&s.d_tile, sizeof(double) * c * N));
+            WT_HIP(wt_dev_alloc(&s.d_ip, sizeof(uint8_t) * c * N));
             WT_HIP(wt_host_alloc((void **) &s.h_tile, sizeof(double) * c * N));
             WT_HIP(wt_host_alloc((void **) &s.h_ip, sizeof(uint8_t) * c * N));
         }
@@ -830,7 +909,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
             if (s.d_bw) p->dead_dev.push_back(s.d_bw);
             s.d_bw = nullptr; s.d_bw_cap = 0;
             const int64_t c = total + total / 4;
-            WT_HIP(hipMalloc((void **) &s.d_bw, (size_t) c));
+            WT_HIP(wt_dev_alloc((void **) &s.d_bw, (size_t) c));
             s.d_bw_cap = c;
         }
         const int64_t need_scr = wt_bw_scratch_bytes(bw_secs, bw_stride);
@@ -838,7 +917,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
             if (s.d_bw_scratch) p->dead_dev.push_back(s.d_bw_scratch);
             s.d_bw_scratch = nullptr; s.bw_scratch_cap = 0;
             const int64_t c = need_scr + need_scr / 4;
-            WT_HIP(hipMalloc(&s.d_bw_scratch, (size_t) c));
+            WT_HIP(wt_dev_alloc(&s.d_bw_scratch, (size_t) c));
             s.bw_scratch_cap = c;
         }
         memcpy(s.h_bw, bw_tracks, sizeof(wtamd_bw_track) * (size_t) N);
@@ -943,12 +1022,12 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     s.compressed = p->compress && !s.integrated;
     if (s.compressed) {
         if (!s.d_cs) {          // (grow-only, with the output buffers)
-            WT_HIP(hipMalloc(&s.d_cs, sizeof(int32_t) * s.ocap));
-            WT_HIP(hipMalloc(&s.d_cf, sizeof(int32_t) * s.ocap));
-            WT_HIP(hipMalloc(&s.d_cv, sizeof(double) * s.ocap));
-            WT_HIP(hipMalloc(&s.d_cscratch, sizeof(unsigned long long) * (size_t) wt_compress_scratch_words((long long) s.ocap)));
+            WT_HIP(wt_dev_alloc(&s.d_cs, sizeof(int32_t) * s.ocap));
+            WT_HIP(wt_dev_alloc(&s.d_cf, sizeof(int32_t) * s.ocap));
+            WT_HIP(wt_dev_alloc(&s.d_cv, sizeof(double) * s.ocap));
+            WT_HIP(wt_dev_alloc(&s.d_cscratch, sizeof(unsigned long long) * (size_t) wt_compress_scratch_words((long long) s.ocap)));
         }
-        if (!s.d_cn) WT_HIP(hipMalloc(&s.d_cn, sizeof(unsigned long long)));
+        if (!s.d_cn) WT_HIP(wt_dev_alloc(&s.d_cn, sizeof(unsigned long long)));
         rc = wt_compress_async(s.d_os, s.d_of, s.d_ov, ts->d_counters + WT_CTR_RUNS, (long long) s.ocap, s.d_cscratch, s.d_cs, s.d_cf,
                                s.d_cv, s.d_cn, p->s_comp);
         if (rc != WTAMD_OK) return wt_fail(rc, "run compression launch failed");
@@ -1111,7 +1190,7 @@ int wtamd_pipe_set_map(wtamd_pipe *p, const wtamd_map_chain *chains) {
     WtDevGuard dev_guard_(p ? p->device : -1);
     if (!p) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
     if (p->in_flight > 0 || p->acquired >= 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_set_map: batches in flight");
-    if (p->d_chains) { (void) hipFree(p->d_chains); p->d_chains = nullptr; p->map_drops = false; p->map_f32 = false; }
+    if (p->d_chains) { (void) wt_dev_free(p->d_chains); p->d_chains = nullptr; p->map_drops = false; p->map_f32 = false; }
     if (!chains) return WTAMD_OK;
     bool any = false;
     for (int t = 0; t < p->cfg.n_tracks; t++) any = any || chains[t].n_ops != 0;
@@ -1127,6 +1206,16 @@ void *wtamd_host_alloc(size_t bytes) {
 
 void wtamd_host_free(void *q) {
     if (q) wt_host_free(q);
+}
+
+void wtamd_pool_stats(int64_t out[6]) {
+    if (!out) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_pool.mu);
+        out[0] = (int64_t) g_pinned_pool.misses; out[1] = (int64_t) g_pinned_pool.miss_bytes; out[2] = (int64_t) g_pinned_pool.pooled;
+    }
+    std::lock_guard<std::mutex> lk(g_dev_pool.mu);
+    out[3] = (int64_t) g_dev_pool.misses; out[4] = (int64_t) g_dev_pool.miss_bytes; out[5] = (int64_t) g_dev_pool.pooled;
 }
 
 int wtamd_pipe_get_stats(const wtamd_pipe *p, wtamd_pipe_stats *out) {
