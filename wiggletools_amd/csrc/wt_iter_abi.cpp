@@ -2084,7 +2084,10 @@ WiggleIterator *wtamd_MapIterator(WiggleIterator *child, int map_op, double para
 
 WiggleIterator *wtamd_BigWiggleReader(const char *path, int box) {
     wtamd_bw *bw = nullptr;
+    static const bool trace_open = getenv("WTAMD_TRACE_OPEN") != nullptr;
+    const double t_open0 = trace_open ? now_ms() : 0;
     if (wtamd_bw_open(path, &bw) != WTAMD_OK) exit(1);     // message printed (bigWiggleReader.c:116-118)
+    const double t_open1 = trace_open ? now_ms() : 0;
     BwReader *r = new BwReader();
     BwHandle *h = (BwHandle *) calloc(1, sizeof(BwHandle));
     h->hdr.peek = &bw_peek;
@@ -2112,6 +2115,7 @@ WiggleIterator *wtamd_BigWiggleReader(const char *path, int box) {
     r->j = 0; r->end = r->buf[0].n;
     if (r->buf[0].chrom < 0) r->done = true;
     bw_settle(r, wi);
+    if (trace_open) fprintf(stderr, "[reader] open %.3f ms, names + priming block %.3f ms\n", t_open1 - t_open0, now_ms() - t_open1);
     return wi;
 }
 
