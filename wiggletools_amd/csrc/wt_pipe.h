@@ -137,7 +137,7 @@ static bool wt_is_pinned(const void *q) {
 // streams 300 MB batches cost ~0.25 s) and to give back (hipHostFree waits for the device).  Buffers of 1 MB and more
 // are therefore kept in a process-wide pool when a pipe lets go of them and handed to the next pipe that asks for
 // the same size -- the Multiplexer a reducer takes over, the next reducer of a long-lived process.  Bounded by
-// WTAMD_PINNED_POOL_MB (default 4096; 0 switches the pool off).
+// WTAMD_PINNED_POOL_MB (default 8192: a pipe of 100 BigWig tracks holds 3.7 GB; 0 switches the pool off).
 struct WtPinnedPool {
     std::mutex mu;
     std::multimap<size_t, void *> free_list;        // by exact size
@@ -146,7 +146,7 @@ struct WtPinnedPool {
     size_t misses = 0, miss_bytes = 0;              // buffers of 1 MB and more that had to be page-locked afresh
     size_t limit() const {
         const char *e = getenv("WTAMD_PINNED_POOL_MB");
-        return (size_t) (e ? atoll(e) : 4096) << 20;
+        return (size_t) (e ? atoll(e) : 8192) << 20;
     }
 };
 static WtPinnedPool g_pinned_pool;
