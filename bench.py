@@ -265,6 +265,13 @@ def e2e_dropin(op, n_tracks, mean_run, mbp, device):
     return out
 
 
+def trim_pools():
+    """The library keeps a finished reducer's staging and device buffers for the next one (csrc/wt_pipe.h); the bench's
+    other records allocate through torch and want that memory back."""
+    from wiggletools_amd import _lib
+    _lib.lib().wtamd_pool_trim()
+
+
 def _bw_write_one(args):
     from wiggletools_amd import bwwrite
     path, L, s, f, v = args
@@ -692,6 +699,7 @@ def main():
     e2e_multi = None
     if world > 1 and not args.no_e2e:
         e2e_multi = e2e_sharded(ctx, ops[-1], N, args.mean_run, min(args.e2e_mbp, 100.0))
+        trim_pools()
     if rank == 0:
         if world == 1 and not args.no_e2e:
             fit = min(1.0, 100.0 / N) * (args.scale if args.scale < 1 else 1.0)
@@ -704,6 +712,7 @@ def main():
                     res["e2e_bigwig"] = e2e_bigwig(ops[-1], N, args.mean_run, args.e2e_bw_mbp * fit, device)
                 except Exception as e:
                     res["e2e_bigwig"] = {"error": repr(e)[:300]}
+            trim_pools()
             # SURVEY 8d metric (1), first pop -> last result on the host, next to the resident-kernel `value`
             res["value_e2e_bulk"] = (res["e2e"].get("bulk") or {}).get("bp_per_s")
             res["value_e2e_bigwig"] = res.get("e2e_bigwig", {}).get("bp_per_s")

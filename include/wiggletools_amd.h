@@ -537,6 +537,9 @@ void wtamd_host_free(void *);
  * so far (count, bytes) and the bytes resting in the pool now; out[3..5]: the same for device buffers (hipMalloc).  A
  * second run of the same job in a process should add no misses. */
 void wtamd_pool_stats(int64_t out[6]);
+/* Gives every buffer resting in the two pools back to the runtime (a process that wants its device memory or its
+ * lockable pages for something else; the pools also do this on their own when an allocation of theirs fails). */
+void wtamd_pool_trim(void);
 
 /* ---- Bulk doors of the drop-in layer ------------------------------------------------------
  * The reference's iterator protocol moves ONE interval per indirect call (wiggleIterator.c:57-60);

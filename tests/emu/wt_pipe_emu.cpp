@@ -172,6 +172,7 @@ int wtamd_device_count(void) { const char *e = getenv("WTEMU_DEVICES"); return e
 int wtamd_current_device(void) { return 0; }
 int wtamd_set_device(int) { return WTAMD_OK; }
 void *wtamd_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+void wtamd_pool_trim(void) {}
 void wtamd_pool_stats(int64_t out[6]) { if (out) for (int i = 0; i < 6; i++) out[i] = 0; }       // (no pools to emulate)
 void wtamd_host_free(void *q) { free(q); }
 

@@ -548,3 +548,15 @@ def test_emu_delta_var_family_patched_windows(oracle):
     t9 = synth(9, [3000], mean_run=5, seed=1, dtype=np.float32)
     t9.defaults[2] = 1.0
     assert emu.reduce(t9, "stddev")[1]["delta"] == 0
+
+
+def test_emu_delta_more_tiles_than_the_first_track_table(oracle):
+    """A window whose flat interval space has more than WT_DELTA_TF (2048) tiles of 256: the tile's first track comes from
+    a binary search over tpfx[] instead of the tfirst[] table (csrc/wt_delta.h wt_delta_fetch).  Needs a wide window
+    and dense tracks: 4096 bp x 140 tracks at one interval per position = 573 000 intervals = 2240 tiles."""
+    t = _delta_case(77, 140, [9000], 1, lambda r, k: r.integers(-64, 64, k) / 4.0, gap=0.0)
+    d = t.as_dict()
+    for op in ("sum", "mean"):
+        got, info = emu.reduce(t, op, delta_T=512)
+        assert info["delta"] == 1 and info["W"] == 4096 and info["delta_bad"] == 0, info
+        assert_runs_equal(got, oracle.reduce(d, op), 0.0, op)

@@ -55,5 +55,10 @@ def test_second_reducer_allocates_nothing():
     assert s2[0] == s1[0] and s2[1] == s1[1], (s1, s2)      # ... the second page-locked nothing
     assert s2[3] == s1[3] and s2[4] == s1[4], (s1, s2)      # ... and mapped nothing
     assert s2[2] > 0 and s2[5] > 0                          # its buffers rest in the pools again
+    L.wtamd_pool_trim()
+    s3 = stats()
+    assert s3[2] == 0 and s3[5] == 0, s3                    # nothing rests in the pools after a trim
+    third = run()
+    assert third == first and stats()[3] > s3[3]            # and the next reducer goes to the runtime again
     for ps, pf, pv in keep:
         ps.free(); pf.free(); pv.free()

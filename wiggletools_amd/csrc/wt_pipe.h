@@ -140,7 +140,7 @@ static bool wt_is_pinned(const void *q) {
 // WTAMD_PINNED_POOL_MB (default 8192: a pipe of 100 BigWig tracks holds 3.7 GB; 0 switches the pool off).
 struct WtPinnedPool {
     std::mutex mu;
-    std::multimap<size_t, void *> free_list;        // by exact size
+    std::multimap<size_t, void *> free_list;        // by (rounded) size
     std::map<void *, size_t> size_of;               // every live buffer that came through here
     size_t pooled = 0;
     size_t misses = 0, miss_bytes = 0;              // buffers of 1 MB and more that had to be page-locked afresh
@@ -168,15 +168,32 @@ static hipError_t wt_host_alloc(void **out, size_t bytes) {
     bytes = wt_pool_round(bytes);
     if (bytes >= (1u << 20)) {
         std::lock_guard<std::mutex> lk(g_pinned_pool.mu);
-        auto it = g_pinned_pool.free_list.find(bytes);
-        if (it != g_pinned_pool.free_list.end()) {
+        // the smallest resting buffer that is large enough and at most a quarter larger (slot capacities grow by
+        // doubling from whatever the first batches needed, so two runs of one job rarely end on identical sizes)
+        auto it = g_pinned_pool.free_list.lower_bound(bytes);
+        if (it != g_pinned_pool.free_list.end() && it->first <= bytes + bytes / 4) {
             *out = it->second;
-            g_pinned_pool.pooled -= bytes;
+            g_pinned_pool.pooled -= it->first;
             g_pinned_pool.free_list.erase(it);
             return hipSuccess;
         }
     }
-    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        // the host refuses to page-lock more while buffers rest in the pool: give them all back and try once more
+        std::vector<void *> idle;
+        {
+            std::lock_guard<std::mutex> lk(g_pinned_pool.mu);
+            for (auto &kv : g_pinned_pool.free_list) { idle.push_back(kv.second); g_pinned_pool.size_of.erase(kv.second); }
+            g_pinned_pool.free_list.clear();
+            g_pinned_pool.pooled = 0;
+        }
+        if (!idle.empty()) {
+            (void) hipGetLastError();
+            for (void *x : idle) (void) hipHostFree(x);
+            e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+        }
+    }
     if (e == hipSuccess && bytes >= (1u << 20)) {
         std::lock_guard<std::mutex> lk(g_pinned_pool.mu);
         g_pinned_pool.size_of[*out] = bytes;
@@ -229,16 +246,31 @@ static hipError_t wt_dev_alloc(T **out, size_t bytes) {
     (void) hipGetDevice(&dev);
     {
         std::lock_guard<std::mutex> lk(g_dev_pool.mu);
-        auto it = g_dev_pool.free_list.find({dev, bytes});
-        if (it != g_dev_pool.free_list.end()) {
+        auto it = g_dev_pool.free_list.lower_bound({dev, bytes});       // (same rule as the pinned pool)
+        if (it != g_dev_pool.free_list.end() && it->first.first == dev && it->first.second <= bytes + bytes / 4) {
             *out = (T *) it->second;
-            g_dev_pool.pooled -= bytes;
+            g_dev_pool.pooled -= it->first.second;
             g_dev_pool.free_list.erase(it);
             return hipSuccess;
         }
     }
     void *q = nullptr;
-    const hipError_t e = hipMalloc(&q, bytes);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {
+        // out of device memory with buffers resting in the pool: give them all back and try once more
+        std::vector<void *> idle;
+        {
+            std::lock_guard<std::mutex> lk(g_dev_pool.mu);
+            for (auto &kv : g_dev_pool.free_list) { idle.push_back(kv.second); g_dev_pool.size_of.erase(kv.second); }
+            g_dev_pool.free_list.clear();
+            g_dev_pool.pooled = 0;
+        }
+        if (!idle.empty()) {
+            (void) hipGetLastError();
+            for (void *x : idle) (void) hipFree(x);
+            e = hipMalloc(&q, bytes);
+        }
+    }
     *out = (T *) q;
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lk(g_dev_pool.mu);
@@ -1206,6 +1238,24 @@ void *wtamd_host_alloc(size_t bytes) {
 
 void wtamd_host_free(void *q) {
     if (q) wt_host_free(q);
+}
+
+void wtamd_pool_trim(void) {
+    std::vector<void *> host, dev;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_pool.mu);
+        for (auto &kv : g_pinned_pool.free_list) { host.push_back(kv.second); g_pinned_pool.size_of.erase(kv.second); }
+        g_pinned_pool.free_list.clear();
+        g_pinned_pool.pooled = 0;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_dev_pool.mu);
+        for (auto &kv : g_dev_pool.free_list) { dev.push_back(kv.second); g_dev_pool.size_of.erase(kv.second); }
+        g_dev_pool.free_list.clear();
+        g_dev_pool.pooled = 0;
+    }
+    for (void *x : host) (void) hipHostFree(x);
+    for (void *x : dev) (void) hipFree(x);
 }
 
 void wtamd_pool_stats(int64_t out[6]) {
