@@ -426,7 +426,7 @@ class Ctx:
         self.replicas = world > 1 and shard == "replicas"
 
 
-def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_set0_arg=-1, f64=False, want_moments=False):
+def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_set0_arg=-1, f64=False, want_moments=False, values="k8"):
     """`steps` timed passes of `ops` over the chromosomes `chrom_ids` (GRCh38 lengths x scale), N tracks of mean run
     `mean_run`: the tracks of one chromosome at a time are generated in HBM (untimed), then window index + fused
     multiplex / reduce kernels run with inputs and outputs resident (timed).  Returns the record of this
@@ -473,6 +473,15 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
         for c in my_items(pass_no):
             t0 = time.perf_counter()
             seg, s, f, v = synthgen.device_tracks(seed, [chrom_lens[c]], N, mean_run, 0.02, 800, device, chrom_ids=[c])
+            if values == "full":
+                # every mantissa bit in use, and one value in a million 2^-60 times too small for its window to be summed
+                # exactly: those windows go to the patch kernel (the generator's k/8 values are the friendliest input the
+                # exactness proof can get; this is what less friendly data costs)
+                g = torch.arange(v.numel(), device=v.device, dtype=torch.int64)
+                h = (((g * 2654435761) ^ (g >> 7)) & 0x7FFFFF).to(torch.float32)
+                v = (v + 0.125) * (1.0 + h * (2.0 ** -23))
+                v[::1000003] *= 2.0 ** -60
+                del g, h
             if f64:
                 v = v.double()
             ts = engine.TrackSet.from_device(1, N, seg, s, f, v, np.zeros(N))
@@ -503,6 +512,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
                 agg["windows"] += st["n_windows"] * len(ops)
                 agg["auc"] += out.auc()
                 stats_last.update(st)
+                agg["patched"] = agg.get("patched", 0) + st.get("patched_windows", 0)
                 per_item[c] = dt * 1e3
                 if want_moments or world > 1:
                     # Pearson moments of tracks 0 and 1 of this chromosome (scalar gather readiness)
@@ -605,6 +615,8 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
                    "genome_bp": genome_bp, "covered_bp_per_step": bp_per_pass,
                    "input_runs_per_step": tot_int, "output_runs_per_step": tot_runs,
                    "window_bp": stats_last.get("window_bp"), "lds_bytes_per_workgroup": stats_last.get("lds_bytes"),
+                   "values": "k/8, k < 800 (exact in f32)" if values == "k8" else "full mantissas in [0.125, 200), one in 1 000 003 scaled by 2^-60",
+                   "windows_per_step": tot_win, "patched_windows_per_step": agg.get("patched", 0),      # (of the record pass; rank 0's share of the patched ones)
                    "sharding": ("replicas: every rank walks its own genome" if replicas else
                                 "one genome, chromosomes from a shared host-side work queue (store counter), no data-path collective")
                                if world > 1 else "single GPU"},
@@ -636,6 +648,8 @@ def slim(res):
             "speedup_vs_many_core_cpu", "auc_check", "output_runs", "pearson_tracks_0_1")
     out = {k: res[k] for k in keep if k in res}
     out["workload"] = res["config"]["workload"]
+    out["patched_windows_per_step"] = res["config"].get("patched_windows_per_step")
+    out["windows_per_step"] = res["config"].get("windows_per_step")
     for k in ("traffic_source", "launch", "note"):
         out["roofline"].pop(k, None)
     if "cpu_baseline" in out:
@@ -663,6 +677,7 @@ def main():
     ap.add_argument("--no-sub", action="store_true", help="skip the sub-records (c3 / c4 / c5, mean run 1 / 200, other kernels) of the default line")
     ap.add_argument("--sub-steps", type=int, default=2, help="timed passes of every sub-record")
     ap.add_argument("--f64", action="store_true", help="hand the tracks over as float64 values (general kernel)")
+    ap.add_argument("--values", default="k8", choices=["k8", "full"], help="k8: the generator's k/8 values; full: full mantissas and one value in a million outside its window's exact range (patched windows)")
     ap.add_argument("--e2e-bw-mbp", type=float, default=248.956422, help="chromosome length of the BigWig-files-to-result leg (0: skip); default chromosome 1")
     ap.add_argument("--e2e-mbp", type=float, default=248.956422, help="chromosome length of the end-to-end (drop-in layer) leg; default chromosome 1")
     args = ap.parse_args()
@@ -693,8 +708,8 @@ def main():
     chrom_ids = cfg["chroms"] if not args.chroms else [int(x) for x in args.chroms.split(",")]
     t_start = time.perf_counter()
     res = measure(ctx, args.config, ops, N, chrom_ids, args.mean_run, args.steps, args.warmup, scale=args.scale,
-                  n_set0_arg=args.n_set0, f64=args.f64, want_moments=args.config == "c5")
-    default_line = args.config == "c2" and not args.op and not args.tracks and not args.chroms and args.scale == 1.0 and not args.f64
+                  n_set0_arg=args.n_set0, f64=args.f64, want_moments=args.config == "c5", values=args.values)
+    default_line = args.config == "c2" and not args.op and not args.tracks and not args.chroms and args.scale == 1.0 and not args.f64 and args.values == "k8"
     # multi-GPU: the e2e bulk leg per rank (every GPU has its own PCIe link) -- all ranks take part
     e2e_multi = None
     if world > 1 and not args.no_e2e:
@@ -727,9 +742,9 @@ def main():
     if world == 1 and default_line and not args.no_sub:
         subs, runs, others = {}, {}, {}
 
-        def sub(name, ops_, N_, chroms_, mean_run_, f64=False, cpu=True, moments=False):
+        def sub(name, ops_, N_, chroms_, mean_run_, f64=False, cpu=True, moments=False, values="k8"):
             try:
-                r = measure(ctx, name, ops_, N_, chroms_, mean_run_, args.sub_steps, 1, f64=f64, want_moments=moments)
+                r = measure(ctx, name, ops_, N_, chroms_, mean_run_, args.sub_steps, 1, f64=f64, want_moments=moments, values=values)
                 if cpu and not args.no_cpu_baseline:
                     with_cpu(r, chroms_, ops_, N_, mean_run_, not args.no_many_core)
                 r.pop("_chrom_lens", None)
@@ -744,6 +759,9 @@ def main():
         # one chromosome at a time: 77 GB for chromosome 19), mean run 200 bp on the whole genome
         runs["l1"] = sub("c2/l=1", ["mean"], 100, [18, 19, 20, 21, 23], 1.0, cpu=False)
         runs["l200"] = sub("c2/l=200", ["mean"], 100, list(range(24)), 200.0, cpu=False)
+        # C2's kernel on data the exactness proof likes less: full mantissas, and one value in a million far outside its
+        # window's exact range (those windows are redone by the patch kernel), chromosome 21
+        runs["full_mantissa_patched"] = sub("c2/full mantissas + patched windows", ["mean"], 100, [20], args.mean_run, cpu=False, values="full")
         # kernels the headline does not exercise, N = 100 on chromosome 21 (46.7 Mbp)
         others["max"] = sub("max", ["max"], 100, [20], args.mean_run, cpu=False)
         others["product"] = sub("product", ["product"], 100, [20], args.mean_run, cpu=False)
