@@ -199,6 +199,8 @@ static hipError_t wt_host_alloc(void **out, size_t bytes) {
         g_pinned_pool.size_of[*out] = bytes;
         g_pinned_pool.misses++;
         g_pinned_pool.miss_bytes += bytes;
+        static const bool trace = getenv("WTAMD_TRACE_POOL") != nullptr;
+        if (trace) fprintf(stderr, "[pool] hipHostMalloc %.1f MB\n", bytes / 1048576.0);
     }
     return e;
 }
@@ -239,7 +241,7 @@ struct WtDevPool {
 static WtDevPool g_dev_pool;
 
 template <class T>
-static hipError_t wt_dev_alloc(T **out, size_t bytes) {
+static hipError_t wt_dev_alloc(T **out, size_t bytes, int line = __builtin_LINE()) {
     if (bytes < 1) bytes = 1;
     bytes = wt_pool_round(bytes);
     int dev = 0;
@@ -277,6 +279,8 @@ static hipError_t wt_dev_alloc(T **out, size_t bytes) {
         g_dev_pool.size_of[q] = {dev, bytes};
         g_dev_pool.misses++;
         g_dev_pool.miss_bytes += bytes;
+        static const bool trace = getenv("WTAMD_TRACE_POOL") != nullptr;
+        if (trace && bytes >= (1u << 20)) fprintf(stderr, "[pool] hipMalloc %.1f MB (device %d, wt_pipe.h:%d)\n", bytes / 1048576.0, dev, line);
     }
     return e;
 }
@@ -831,7 +835,12 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     // device twin of the staging (grow-only)
     const int64_t need_in = n > 0 ? n : 1;
     if (s.dcap < need_in || (f64 && !s.d_has64)) {
-        int64_t c = s.dcap * 2 > need_in ? s.dcap * 2 : need_in;
+        // an eighth of slack, not a doubling: the batches of a run settle on one size and wobble by a fraction of a
+        // percent around it (63 220 sections, then 63 502), and "twice the old capacity" answered the first batch that
+        // was a hair larger with three more arrays of 1.5 GB per slot -- 27.6 of the 37.6 GB a pipe of 100 BigWig tracks
+        // held, and most of the time its first run spent in hipMalloc (round 3, WTAMD_TRACE_POOL=1).  The ramp at the
+        // start of a run grows by factors anyway.
+        int64_t c = need_in + need_in / 8;
         if (c < s.cap) c = s.cap;
         for (void *q : {(void *) s.d_start, (void *) s.d_finish, s.d_value}) if (q) p->dead_dev.push_back(q);
         s.d_start = s.d_finish = nullptr; s.d_value = nullptr; s.dcap = 0;
