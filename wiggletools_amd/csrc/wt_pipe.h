@@ -871,7 +871,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     if (need_out > p->cfg.max_runs) need_out = p->cfg.max_runs;
     if (need_out < 1) need_out = 1;
     if (s.ocap < need_out) {
-        int64_t c = s.ocap * 2 > need_out ? s.ocap * 2 : need_out;
+        int64_t c = need_out + need_out / 8;        // (slack, not a doubling: see the device twins above)
         if (c > p->cfg.max_runs) c = p->cfg.max_runs;
         if (c < need_out) c = need_out;
         for (void *q : {(void *) s.d_os, (void *) s.d_of, (void *) s.d_ov, (void *) s.d_tile, (void *) s.d_ip}) if (q) p->dead_dev.push_back(q);
