@@ -29,19 +29,41 @@ class _Tracks(C.Structure):
                 ("value", C.c_void_p), ("defaults", C.c_void_p)]
 
 
+def _locked_make(target):
+    """One make at a time per checkout (pytest-xdist workers call this side by side); the Makefile builds every library
+    to a temporary name and rename()s it, so a process that has the old file dlopen'ed keeps a whole file."""
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-C", _HERE, target])
+
+
+def _newer(out, deps):
+    return os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps if os.path.exists(d))
+
+
 def build(force=False):
     """(Re)build the checker libraries with oracle/Makefile."""
-    need = force or not (os.path.exists(os.path.join(_HERE, "libwt_oracle.so"))
-                         and os.path.exists(os.path.join(_HERE, "libref_harness.so")))
+    mk = os.path.join(_HERE, "Makefile")
+    hdr = os.path.join(_HERE, "..", "include", "wiggletools_amd.h")
+    need = force or not (_newer(os.path.join(_HERE, "libwt_oracle.so"), [os.path.join(_HERE, "wt_oracle.c"), mk])
+                         and _newer(os.path.join(_HERE, "libref_harness.so"), [os.path.join(_HERE, "ref_harness.c"), hdr, mk]))
     ref_missing = not os.path.exists(os.path.join(_HERE, "_ref", "libwiggletools_ref.so"))
     if need or (ref_missing and os.path.isdir("/root/reference/src")):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+        _locked_make("all")
 
 
-def build_mixed():
-    """The mixed-link libraries (reference translation units + a drop-in library); see oracle/Makefile."""
-    if os.path.isdir("/root/reference/src"):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "mixed"])
+def build_mixed(force=False):
+    """The mixed-link libraries (reference translation units + a drop-in library); see oracle/Makefile.  Skipped when
+    both are newer than the drop-in libraries they link against."""
+    if not os.path.isdir("/root/reference/src"):
+        return
+    mk = os.path.join(_HERE, "Makefile")
+    pairs = (("amd", os.path.join(_HERE, "..", "wiggletools_amd", "csrc", "libwiggletools_amd.so")),
+             ("emu", os.path.join(_HERE, "..", "tests", "emu", "libwt_dropin_emu.so")))
+    if force or not all(_newer(os.path.join(_HERE, "_ref", "libwiggletools_mixed_%s.so" % v), [lib, mk])
+                        for v, lib in pairs if os.path.exists(lib)):
+        _locked_make("mixed")
 
 
 def mixed_path(variant):
@@ -134,6 +156,8 @@ class Harness:
         L.ref_auc_of_reduce.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint]
         L.ref_door_integrate.restype = C.c_double
         L.ref_door_integrate.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int, C.c_void_p]
+        L.ref_door_integrate_seek.restype = C.c_int
+        L.ref_door_integrate_seek.argtypes = [C.POINTER(_Tracks), C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_set_compress_mode.argtypes = [C.c_int]
         L.ref_set_compress_mode.restype = None
         L.ref_set_modes.argtypes = [C.c_int, C.c_int]
@@ -179,6 +203,19 @@ class Harness:
         k = {"auc": 0, "mean": 1, "pearson": 2}[kind]
         r = self.L.ref_door_integrate(C.byref(s), _opcode(op) if k < 2 else 0, flags, k, info.ctypes.data)
         return r, int(info[0]), int(info[1]), int(info[2])
+
+    def door_integrate_seek(self, t, kind, regions, op="mean", flags=0, pre_pops=0):
+        """The doors driven like `apply`: pre_pops pops, then seek + drain per region (chrom index, start, finish);
+        returns [value before the first seek, value after region 0, ...]."""
+        s, keep = _pack(t)
+        reg = np.ascontiguousarray(np.array(regions, np.int32).reshape(-1, 3))
+        out = np.zeros(1 + len(reg), np.float64)
+        k = {"auc": 0, "mean": 1, "pearson": 2}[kind]
+        rc = self.L.ref_door_integrate_seek(C.byref(s), _opcode(op) if k < 2 else 0, flags, k, pre_pops, len(reg),
+                                            reg.ctypes.data, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("ref_door_integrate_seek returned %d" % rc)
+        return out
 
     def set_compress_mode(self, on):
         """write_reduce asks the reducer to merge its runs on the device (wtamd_iterator_compress_output)."""

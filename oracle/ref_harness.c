@@ -552,6 +552,32 @@ double ref_door_integrate(const wto_tracks *t, int op, unsigned flags, int kind,
     return *(double *) a->data;
 }
 
+/* The same doors driven the way `apply` drives an integrator (apply.c: one seek per region, pop to the end, read the
+ * value): `pre_pops` pops first (a seek MID-STREAM: the source is primed and has batches under way), then for every
+ * region (chrom index, start, finish) seek + pop until done.  out[0] = the value before the first seek, out[1 + k] =
+ * the value after region k (the sums go on across seeks: statistics.c:38-43,84-88,406-410).  Returns 0, < 0 on error. */
+int ref_door_integrate_seek(const wto_tracks *t, int op, unsigned flags, int kind, int pre_pops, int n_regions,
+                            const int32_t *regions, double *out) {
+    if (!g_lib) return -2;
+    char **names = make_names(t->n_chrom);
+    WiggleIterator *a = NULL;
+    if (kind == 2) {
+        if (t->n_tracks != 2 || !r_door_pearson) return -3;
+        a = r_door_pearson(make_multiplexer(t, names, 0, 2, 0));
+    } else {
+        if (op < 0 || op > 9 || !(kind ? r_door_mean : r_door_auc)) return -3;
+        a = (kind ? r_door_mean : r_door_auc)(r_reduction[op](make_multiplexer(t, names, 0, t->n_tracks, flags & 1u)));
+    }
+    for (int k = 0; k < pre_pops && !a->done; k++) r_pop(a);
+    out[0] = *(double *) a->data;
+    for (int k = 0; k < n_regions; k++) {
+        r_seek(a, names[regions[3 * k]], regions[3 * k + 1], regions[3 * k + 2]);
+        while (!a->done) r_pop(a);
+        out[1 + k] = *(double *) a->data;
+    }
+    return 0;
+}
+
 double ref_pearson(const wto_tracks *t) {
     if (!g_lib || t->n_tracks != 2 || !r_PearsonIntegrator) return NAN;
     char **names = make_names(t->n_chrom);

@@ -1,8 +1,22 @@
 """Builds tests/emu/libwt_emu.so (CPU emulator of the HIP kernels, test-only)."""
+import fcntl
 import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _compile(so, deps, cmd_tail):
+    """g++ to a temporary name, rename() into place, one build at a time (pytest-xdist workers share the checkout)."""
+    with open(os.path.join(HERE, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in deps):
+            return so                                   # another worker built it while this one waited
+        tmp = "%s.tmp.%d" % (so, os.getpid())
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+                               "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", tmp] + cmd_tail)
+        os.replace(tmp, so)
+    return so
 
 
 def build(force=False):
@@ -13,9 +27,9 @@ def build(force=False):
             os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc", "wt_delta.h")]
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
         return so
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
-                           "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", so, srcs[0], "-lm"])
-    return so
+    if force and os.path.exists(so):
+        os.utime(srcs[0])
+    return _compile(so, srcs, [srcs[0], "-lm"])
 
 
 def build_dropin(force=False):
@@ -25,13 +39,14 @@ def build_dropin(force=False):
     csrc = os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc")
     srcs = [os.path.join(HERE, "wt_emu.cpp"), os.path.join(HERE, "wt_pipe_emu.cpp"),
             os.path.join(csrc, "wt_iter_abi.cpp"), os.path.join(csrc, "wt_defaults.cpp"), os.path.join(csrc, "wt_bigwig.cpp")]
-    deps = srcs + [os.path.join(csrc, "wt_core.h"), os.path.join(csrc, "wt_plan.h"), os.path.join(csrc, "wt_delta.h"),
-                   os.path.join(HERE, "..", "..", "include", "wiggletools_amd.h")]
+    deps = srcs + [os.path.join(csrc, h) for h in ("wt_core.h", "wt_plan.h", "wt_delta.h", "wt_inflate.h", "wt_bwdev_core.h",
+                                                    "wt_mapop.h", "wt_bigwig_int.h")] + \
+        [os.path.join(HERE, "..", "..", "include", "wiggletools_amd.h")]
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in deps):
         return so
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
-                           "-Wno-unused-function", "-Wno-unknown-pragmas", "-o", so] + srcs + ["-lm", "-lz", "-lpthread"])
-    return so
+    if force and os.path.exists(so):
+        os.utime(srcs[0])
+    return _compile(so, deps, srcs + ["-lm", "-lz", "-lpthread"])
 
 
 if __name__ == "__main__":

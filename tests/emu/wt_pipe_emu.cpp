@@ -346,20 +346,39 @@ int wtamd_pipe_integrate_held(wtamd_pipe *p, double *integ) {
 // run one section after the other -- what csrc/wt_bwdev.hip runs one lane / one wavefront per section.
 
 // One zlib (or raw deflate) stream through the lane state machine; returns bytes produced or -(error).
-long long wtemu_inflate(const uint8_t *src, long long n, uint8_t *dst, long long cap, int raw_deflate) {
-    std::vector<uint16_t> perm(WT_INF_PERM);
-    std::vector<uint32_t> ring(WT_INF_RING);
+}  // extern "C"
+template <int RING>
+static long long emu_inflate_ring(const uint8_t *src, long long n, uint8_t *dst, long long cap, int raw_deflate, long long *steps) {
+    std::vector<uint8_t> perm(WT_INF_PERM + 8, 0);
+    std::vector<uint32_t> ring(RING, 0);
     WtInfMem m{perm.data(), ring.data(), 1};
     // the decoder reads whole aligned 16-byte chunks around the stream and writes whole words: private padded copies
     std::vector<uint8_t> in((size_t) n + 96, 0), out(((size_t) cap + 3) / 4 * 4 + 8, 0);
     const int mis = (int) (n % 16);             // any alignment must work
     if (n > 0) memcpy(in.data() + 32 + mis, src, (size_t) n);
-    WtInflate z;
+    WtInflateT<RING> z;
     wt_inf_begin(z, in.data() + 32 + mis, (uint32_t) n, out.data(), (uint32_t) cap, raw_deflate != 0);
-    while (wt_inf_step(z, m)) { }
+    long long rounds = 0;
+    while (wt_inf_land(z, m)) {
+        for (int r = 0; r < WT_INF_ROUND; r++) wt_inf_step(z, m);
+        rounds++;
+    }
+    if (steps) *steps = rounds * WT_INF_ROUND;
     const long long r = (long long) wt_inf_finish(z);
     if (r > 0) memcpy(dst, out.data(), (size_t) r);
     return r;
+}
+
+extern "C" {
+// One zlib (or raw deflate) stream through the lane state machine; returns bytes produced or -(error).
+long long wtemu_inflate(const uint8_t *src, long long n, uint8_t *dst, long long cap, int raw_deflate) {
+    return emu_inflate_ring<WT_INF_RING>(src, n, dst, cap, raw_deflate, nullptr);
+}
+
+// The same with a ring of `ring` dwords (8 or 64: the two instantiations of the kernel); *steps = steps the lane took.
+long long wtemu_inflate_ring(const uint8_t *src, long long n, uint8_t *dst, long long cap, int raw_deflate, int ring, long long *steps) {
+    if (ring == 64) return emu_inflate_ring<64>(src, n, dst, cap, raw_deflate, steps);
+    return emu_inflate_ring<8>(src, n, dst, cap, raw_deflate, steps);
 }
 
 // The sections of a batch -> run lists (o_* sized `capacity`), seg_off[n_tracks + 1].  Returns the error bits.

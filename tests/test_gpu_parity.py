@@ -611,7 +611,8 @@ def test_gpu_difference_array_nonzero_defaults(oracle, engine, seed, monkeypatch
     from wiggletools_amd.runlists import synth
     monkeypatch.setenv("WTAMD_DELTA_MIN_TRACKS", "1")
     rng = np.random.default_rng(4200 + seed)
-    n = int(rng.integers(2, 40)) if seed % 3 else int(rng.integers(520, 700))       # > 512 tracks: chunks
+    n = int(rng.integers(2, 40)) if seed % 3 else int(rng.integers(520, 700))       # (one chunk of the default 1024-lane plan;
+    #  more tracks than lanes: test_gpu_difference_array_more_tracks_than_lanes)
     t = synth(n, [int(rng.integers(3000, 60000)), 9000, 3], mean_run=float(rng.choice([1, 4, 16, 300])),
               gap_prob=float(rng.choice([0.0, 0.1, 0.5])), seed=seed, first_start=int(rng.choice([1, 77, 5000])))
     t.value[:] = (rng.integers(-800, 800, len(t.value)) / 8.0).astype(np.float32)
@@ -636,4 +637,53 @@ def test_gpu_difference_array_nonzero_defaults(oracle, engine, seed, monkeypatch
     got = ts.reduce_host("mean")
     assert ts.stats()["kernel"] == 0
     assert_runs_equal(got, oracle.reduce(t.as_dict(), "mean"), 0.0, "non-float default, seed %d" % seed)
+    ts.close()
+
+
+@pytest.mark.parametrize("case", [(1100, None, 0), (1500, None, 1), (700, "256", 0), (700, "256", 1), (1300, "512", 1)])
+def test_gpu_difference_array_more_tracks_than_lanes(oracle, engine, case, monkeypatch):
+    """Sum / Mean on the difference-array kernel with MORE TRACKS THAN LANES -- the multi-chunk walk of
+    wt_delta_kernel<sum / mean> (csrc/wt_engine.hip, `N > T`): at the default 1024-lane plan (N = 1100, 1500) and with
+    WTAMD_DELTA_T = 256 / 512, zero and non-zero (float) defaults, strict and not, against the oracle at tolerance 0.
+    (Round 3 moved the default plan from 512 to 1024 lanes; the 520-700-track cases of the tests above stopped chunking.)"""
+    from wiggletools_amd.runlists import synth
+    n, T, with_defaults = case
+    monkeypatch.setenv("WTAMD_DELTA_MIN_TRACKS", "1")
+    if T:
+        monkeypatch.setenv("WTAMD_DELTA_T", T)
+    else:
+        monkeypatch.delenv("WTAMD_DELTA_T", raising=False)
+    rng = np.random.default_rng(n + 7 * with_defaults)
+    t = synth(n, [20000, 3], mean_run=40, gap_prob=0.1, seed=n)
+    t.value[:] = (rng.integers(-800, 800, len(t.value)) / 8.0).astype(np.float32)
+    if with_defaults:
+        t.defaults[:] = np.where(rng.random(n) < 0.5, rng.choice(np.array([1.5, -2.25, 0.125, 3.0]), n), 0.0)
+        t.defaults[n - 1] = 2.5         # a default in the LAST chunk
+    d = t.as_dict()
+    ts = engine.TrackSet.from_runlists(t)
+    lanes = int(T) if T else 1024
+    for strict in (0, 1):
+        for op in ("sum", "mean"):
+            got = ts.reduce_host(op, flags=strict)
+            st = ts.stats()
+            assert st["kernel"] == 1 and st["window_bp"] == 8 * lanes and st["patched_windows"] == 0, st
+            assert n > lanes
+            assert_runs_equal(got, oracle.reduce(d, op, flags=strict), 0.0, "N %d T %s op %s strict %d" % (n, T, op, strict))
+    ts.close()
+
+
+def test_gpu_c2_shape_long_runs(oracle, engine):
+    """BASELINE config C2's shape (mean, 100 float tracks, 2 % gaps, values k / 8) at MEAN RUN 200 bp: an 8192-bp window
+    of the default plan holds ~40 runs per track instead of 512 -- per-window fixed costs, window-base runs spanning
+    several windows -- against the oracle at tolerance 0."""
+    from wiggletools_amd.runlists import synth
+    t = synth(100, [300000, 70000], mean_run=200, gap_prob=0.02, seed=2024)
+    d = t.as_dict()
+    ts = engine.TrackSet.from_runlists(t)
+    for strict in (0, 1):
+        for op in ("mean", "sum"):
+            got = ts.reduce_host(op, flags=strict)
+            st = ts.stats()
+            assert st["kernel"] == 1 and st["window_bp"] == 8192, st
+            assert_runs_equal(got, oracle.reduce(d, op, flags=strict), 0.0, "run 200 op %s strict %d" % (op, strict))
     ts.close()

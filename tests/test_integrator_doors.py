@@ -105,3 +105,46 @@ def test_empty_and_golden(oracle, H):
     assert got == 0.0
     got, _, _, _ = H.door_integrate(e, "mean", "mean", 0)
     assert np.isnan(got)
+
+
+def _auc(runs):
+    c, s, f, v = runs
+    ok = ~np.isnan(v)
+    return float(((f.astype(np.int64) - s)[ok].astype(np.float64) * v[ok]).sum())
+
+
+@pytest.mark.parametrize("pre_pops", [0, 1, 3])
+def test_fused_auc_seek_per_region(oracle, H, pre_pops, monkeypatch):
+    """A fused integrator that is SEEKED -- `apply`'s use of it (one seek per region), and a seek in the middle of a
+    pass, when the source's pipes are still integrating on the device (the round-3 advisor's finding: the priming pop of
+    the seek read a batch that had shipped no runs and crashed).  The sums go on across seeks (statistics.c:38-43):
+    value after region k = value before the first seek + the AUC of the reducer over the regions so far (oracle over
+    the clipped tracks; the reference itself is not consulted for a seek on a primed Multiplexer)."""
+    from test_dropin import clip
+    monkeypatch.setenv("WTAMD_MIN_SPAN", "64")         # many batches: the pass is under way when the seek comes
+    monkeypatch.setenv("WTAMD_BATCH_INTERVALS", "200")
+    t = random_case(8900, n_tracks=6, n_chrom=2, max_len=9000)
+    d = t.as_dict()
+    regions = [(0, 100, 3000), (0, 2500, 2600), (1, 1, 50), (1, 10, 4000)]
+    for op in ("mean", "max"):
+        got = H.door_integrate_seek(d, "auc", regions, op=op, pre_pops=pre_pops)
+        want = got[0]
+        # (got[0]: what the constructor's own pop and the pre_pops absorbed -- whole batches, not runs)
+        for k, (c, s, f) in enumerate(regions):
+            want += _auc(oracle.reduce(clip(t, c, s, f).as_dict(), op))
+            assert _close(got[1 + k], want), (op, pre_pops, k, got[1 + k], want)
+
+
+def test_fused_pearson_seek(oracle, H, monkeypatch):
+    """wtamd_PearsonIntegrator seeked mid-stream and per region: the moments go on across seeks (statistics.c:406-410),
+    so the value is the correlation over everything absorbed so far -- whole batches here, single runs in the reference --
+    and has no closed expectation; what is checked is that every seek re-primes cleanly (no batch without runs is read)
+    and that the result stays a correlation.  Seeking a region TWICE in a row doubles every weight and leaves the
+    correlation of that region alone."""
+    monkeypatch.setenv("WTAMD_MIN_SPAN", "64")
+    monkeypatch.setenv("WTAMD_BATCH_INTERVALS", "200")
+    t = random_case(8950, n_tracks=2, n_chrom=2, max_len=9000)
+    d = t.as_dict()
+    for pre in (0, 2):
+        got = H.door_integrate_seek(d, "pearson", [(0, 100, 3000), (1, 10, 4000), (1, 10, 4000)], pre_pops=pre)
+        assert np.all(np.isfinite(got[1:])) and np.all(np.abs(got[1:]) <= 1.0 + 1e-12), got

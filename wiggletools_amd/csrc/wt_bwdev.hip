@@ -50,20 +50,23 @@ __global__ void __launch_bounds__(256) wt_bw_copy_kernel(const wt_u32x4 *src, wt
 
 #define WT_BW_INF_LANES 64
 
+// RING = 8: 320 B of LDS per lane, eight wavefronts per CU (two per SIMD); RING = 64: 544 B, four per CU, matches up to
+// 252 bytes back served from LDS (WTAMD_INFLATE_RING=64; kept for comparison).
+template <int RING>
 __global__ void __launch_bounds__(WT_BW_INF_LANES) wt_bw_inflate_kernel(const WtBwSection *secs, const WtBwTrack *tracks, int n_sec,
                                                                          const uint8_t *comp, uint8_t *plain, uint32_t plain_stride,
                                                                          int32_t *plain_len) {
-    __shared__ uint16_t s_perm[WT_INF_PERM * WT_BW_INF_LANES];
-    __shared__ uint32_t s_ring[WT_INF_RING * WT_BW_INF_LANES];
+    __shared__ uint32_t s_perm[(WT_INF_PERM / 4) * WT_BW_INF_LANES];
+    __shared__ uint32_t s_ring[RING * WT_BW_INF_LANES];
     const int lane = threadIdx.x;
     const int i = blockIdx.x * WT_BW_INF_LANES + lane;
     if (i >= n_sec) return;
     const WtBwSection sc = secs[i];
     const bool compressed = tracks[sc.track].compressed != 0;
     WtInfMem m;
-    m.perm = (WT_AS_LDS uint16_t *) (s_perm + lane);
+    m.perm = (WT_AS_LDS uint8_t *) (s_perm + lane);
     m.ring = (WT_AS_LDS uint32_t *) (s_ring + lane); m.stride = WT_BW_INF_LANES;
-    WtInflate z;
+    WtInflateT<RING> z;
     wt_inf_begin(z, comp + sc.comp_off, sc.comp_size, plain + (size_t) i * plain_stride, plain_stride, false);
     if (!compressed) {          // an uncompressed file: the section bytes are copied (a stored block in disguise)
         z.st = sc.comp_size ? WT_INF_ST_STORED : WT_INF_ST_DONE;
@@ -71,8 +74,12 @@ __global__ void __launch_bounds__(WT_BW_INF_LANES) wt_bw_inflate_kernel(const Wt
         z.last = true;
         if (sc.comp_size > plain_stride) wt_inf_fail(z, WT_INF_ERR_SPACE);
     }
-    while (wt_inf_step(z, m)) { }
-    plain_len[i] = (int32_t) wt_inf_finish(z);
+    plain_len[i] = (int32_t) wt_inf_run(z, m);
+}
+
+int wt_bw_inflate_ring() {
+    static const int ring = (getenv("WTAMD_INFLATE_RING") && atoi(getenv("WTAMD_INFLATE_RING")) == 64) ? 64 : 8;
+    return ring;
 }
 
 __device__ __forceinline__ uint32_t wt_wave_sum(uint32_t v) {
@@ -235,7 +242,10 @@ __global__ void __launch_bounds__(64) wt_bw_scatter_kernel(const WtBwSection *se
 // sections resident per launch of the inflate kernel: CUs x wavefronts per CU x 64 lanes
 long long wt_bw_fill_sections(int num_cu) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wt_bw_inflate_kernel, WT_BW_INF_LANES, 0) != hipSuccess || per_cu < 1) {
+    const hipError_t e = wt_bw_inflate_ring() == 64
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wt_bw_inflate_kernel<64>, WT_BW_INF_LANES, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wt_bw_inflate_kernel<8>, WT_BW_INF_LANES, 0);
+    if (e != hipSuccess || per_cu < 1) {
         (void) hipGetLastError();
         per_cu = 3;
     }
@@ -291,8 +301,12 @@ int wt_bw_decode_async(const void *h_bytes, void *d_bytes, long long n_bytes, co
     const WtBwTrack *tracks = (const WtBwTrack *) d_tracks;
     if (n_sec > 0) {
         const unsigned g = (unsigned) ((n_sec + WT_BW_INF_LANES - 1) / WT_BW_INF_LANES);
-        hipLaunchKernelGGL(wt_bw_inflate_kernel, dim3(g), dim3(WT_BW_INF_LANES), 0, s_dec, secs, tracks, (int) n_sec,
-                           (const uint8_t *) d_comp, plain, (uint32_t) plain_stride, plain_len);
+        if (wt_bw_inflate_ring() == 64)
+            hipLaunchKernelGGL(wt_bw_inflate_kernel<64>, dim3(g), dim3(WT_BW_INF_LANES), 0, s_dec, secs, tracks, (int) n_sec,
+                               (const uint8_t *) d_comp, plain, (uint32_t) plain_stride, plain_len);
+        else
+            hipLaunchKernelGGL(wt_bw_inflate_kernel<8>, dim3(g), dim3(WT_BW_INF_LANES), 0, s_dec, secs, tracks, (int) n_sec,
+                               (const uint8_t *) d_comp, plain, (uint32_t) plain_stride, plain_len);
         WT_BW_HIP(hipGetLastError());
         hipLaunchKernelGGL(wt_bw_count_kernel, dim3((unsigned) n_sec), dim3(64), 0, s_dec, secs, tracks, (int) n_sec, plain,
                            (uint32_t) plain_stride, plain_len, counts, err);

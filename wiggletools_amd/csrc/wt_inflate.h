@@ -6,34 +6,35 @@
 // independent, so here every lane of a wavefront inflates its own section: 64 streams per wavefront,
 // tens of thousands in flight per GPU, no cross-lane communication at all.
 //
-// What makes a serial bit-stream decoder fit a lane:
-//   * no look-up tables sized 2^bits: canonical Huffman decoding by LIMITS.  For a code with
-//     count[k] symbols of length k the left-aligned 15-bit window w of the stream has length
+// Round 4 rewrite.  The round-3 decoder took 11.1 ms per 63 500 sections with ONE wavefront per
+// SIMD, 42 % of its cycles waiting: a step was "one symbol OR 8 bytes of a match" (7 500 steps per section, each
+// paying for the literal, the match and the copy path because 64 lanes are never in the same state), the input
+// prefetch and every match beyond the LDS ring were loads whose results the same step consumed -- one global
+// round trip (s_waitcnt vmcnt(0), which on gfx9 also waits for the step's own stores) in most steps.  Now:
+//   * ONE STEP = ONE SYMBOL AND ITS FIRST 8 BYTES: decode a literal / length code; a length goes on to its
+//     distance and the first <= 8 bytes of the copy in the same step; literal byte, match bytes and stored bytes
+//     leave through ONE put.  5 400 steps per section instead of 7 500, and one copy of the code that is shared.
+//   * NO LOAD IS CONSUMED INSIDE A STEP.  Steps run in ROUNDS of WT_INF_ROUND; global loads (the next 16 input
+//     bytes, the source of a match beyond the ring) are issued whenever needed and LAND at the next round
+//     boundary (wt_inf_land) -- the only place that waits for memory.  A lane whose match source has not landed
+//     idles for the rest of its round (2 steps on average, ~7 % of the matches); a lane whose input queue is
+//     about to run dry idles likewise (32 buffered bytes: never, for streams that are not adversarial).
+//   * 320 BYTES OF LDS PER LANE instead of 640 -- TWO wavefronts per SIMD: the sorted symbol table holds the LOW
+//     BYTE of a symbol only (288 B) -- inside one code length the sorted symbols ascend, so "literal or length
+//     code" is index >= threshold[length], and the threshold rides in the register that already holds the
+//     length's index adjustment -- and the ring is 8 dwords.  The table is built without a second array: the
+//     code lengths of a dynamic block are DECODED TWICE (count, rewind the bit stream, place).
+//   * conflict-free LDS: a lane's bytes live in its own bank (dword-interleaved layout).
+//
+// Decoding itself is table-free canonical Huffman by LIMITS: for a code with count[k] symbols of length k the
+// left-aligned 15-bit window w of the stream has length
 //         len = 1 + #{ k in 1..14 : w >= lim[k] },   lim[k] = (first[k] + count[k]) << (15 - k)
-//     and the symbol is perm[adj[len] + (w >> (15 - len))].  The 2 x 15 limits live in REGISTERS
-//     and 2 x 15 adj values live in REGISTERS
-//     (statically indexed arrays), `perm` (the 286 literal / length symbols sorted by code) in LDS --
-//     ONE dependent LDS read per symbol -- the 30 distance symbols in 5 registers: 640 bytes of LDS per lane,
-//     so that FOUR wavefronts (one per SIMD) share a CU's 160 KB.
-//   * the code lengths of a dynamic block are parked in the unused top 4 bits of perm[] while
-//     the table is built in place, the per-length counters borrow the ring's 16 slots (whose history waits
-//     in registers); the 19-symbol code-length code lives in 64-bit registers.
-//   * LZ77 history: the last 16 output DWORDS of every lane are kept in an LDS ring; a match with a
-//     distance <= 60 (the bulk of them in 12-byte record data) reads three of them -- one LDS round
-//     trip for up to 8 bytes -- and never touches global memory; longer ones read the lane's own
-//     earlier output back.  Output is gathered to dwords in a register and stored whole.
-//   * the input is prefetched 16 bytes (~16 symbols) ahead into registers: the loop never waits for
-//     a load it has just issued;
-//   * one state machine step per loop iteration, a match copies at most WT_INF_COPY bytes per
-//     iteration, so a lane inside a 258-byte match does not stall the 63 others.
+// and the symbol is perm[adj[len] + (w >> (15 - len))].  2 x 15 limits, 2 x 15 adjustments in REGISTERS
+// (statically indexed), the 30 distance symbols in 5 registers.
 //
-// The same code compiles for the host (tests/emu, tests/test_inflate.py: checked against zlib's
-// own output on stored / fixed / dynamic streams of every compression level) -- `stride` is 1 there
-// and the "LDS" arrays are plain memory.
-//
-// Memory layout: element i of a lane's array lies at base[i * stride] (+ lane), stride = lanes of
-// the workgroup: lanes that walk their tables in lock step (table construction) hit consecutive
-// addresses, random accesses are at worst 2-way bank conflicted (u16).
+// The same code compiles for the host (tests/emu, tests/test_bwdev.py: checked against zlib's own output on
+// stored / fixed / dynamic streams of every compression level) -- `stride` is 1 there and the "LDS" arrays are
+// plain memory.
 #ifndef WT_INFLATE_H_
 #define WT_INFLATE_H_
 
@@ -66,13 +67,19 @@
 #define WT_INF_OPAQUE(x) (void) 0
 #endif
 
-#define WT_INF_PERM 288         // literal / length symbols sorted by code (the 30 distance symbols live in registers)
-#define WT_INF_RING 16          // dwords of LZ77 history per lane
-#define WT_INF_RING_DIST 56     // matches up to this distance are served from the ring
-#define WT_INF_COPY 8           // match bytes copied per state machine step
+#define WT_INF_PERM 288         // literal / length symbols sorted by code, low byte only
+#ifndef WT_INF_RING
+#define WT_INF_RING 8           // dwords of LZ77 history per lane (power of two, >= 8: its first 8 dwords double as
+#endif                          // the 16 per-length counters while a block's tables are built)
+#define WT_INF_RING_DIST(R) (4 * (R) - 4)  // matches up to this distance are served from a ring of R dwords
+#define WT_INF_COPY 8           // match bytes copied per step
+#define WT_INF_FAR 16           // bytes of a match beyond the ring fetched by one load (5 dwords)
+#ifndef WT_INF_ROUND
+#define WT_INF_ROUND 4          // steps between two landings
+#endif
 
-// bytes of "LDS" one lane needs: 640 -> 40 KB per wavefront, four wavefronts per CU (one per SIMD)
-#define WT_INF_LANE_BYTES (WT_INF_PERM * 2 + WT_INF_RING * 4)
+// bytes of "LDS" one lane needs with a ring of R dwords: 320 for R = 8 -> 20 KB per wavefront, EIGHT per CU
+#define WT_INF_LANE_BYTES(R) (WT_INF_PERM + 4 * (R))
 
 enum {
     WT_INF_OK = 0,
@@ -85,26 +92,53 @@ enum {
     WT_INF_ERR_INPUT = 7        // the stream ends before the final block does
 };
 
-enum { WT_INF_ST_ZHDR = 0, WT_INF_ST_BLOCK = 1, WT_INF_ST_SYM = 2, WT_INF_ST_STORED = 3, WT_INF_ST_DONE = 4, WT_INF_ST_ERR = 5 };
+// states: SYM and STORED produce output inside wt_inf_step; ZHDR and BLOCK are worked off at a round boundary
+enum { WT_INF_ST_SYM = 0, WT_INF_ST_STORED = 1, WT_INF_ST_ZHDR = 2, WT_INF_ST_BLOCK = 3, WT_INF_ST_DONE = 4, WT_INF_ST_ERR = 5 };
 
+// A lane's two arrays.  Element layout (S = stride = lanes of the workgroup): dword d of a lane lies S dwords
+// after its dword d - 1, i.e. every lane keeps to its own LDS bank whatever it indexes.
 struct WtInfMem {
-    WT_AS_LDS uint16_t *perm;   // WT_INF_PERM entries
-    WT_AS_LDS uint32_t *ring;   // WT_INF_RING dwords (borrowed as 16 counters while a block's tables are built)
-    int stride;                 // elements between consecutive entries of this lane
+    WT_AS_LDS uint8_t *perm;    // the lane's dword 0 of the symbol table (byte j at ((j >> 2) * S) * 4 + (j & 3))
+    WT_AS_LDS uint32_t *ring;   // the lane's dword 0 of the ring (dword k at k * S)
+    int stride;
 };
+
+WT_HD uint32_t wt_inf_perm_get(const WtInfMem &m, uint32_t j) { return m.perm[(((j >> 2) * (uint32_t) m.stride) << 2) + (j & 3u)]; }
+WT_HD void wt_inf_perm_set(const WtInfMem &m, uint32_t j, uint32_t v) { m.perm[(((j >> 2) * (uint32_t) m.stride) << 2) + (j & 3u)] = (uint8_t) v; }
+// the 16 per-length counters / cursors of the table construction: 16-bit halves of the ring's first 8 dwords
+WT_HD uint32_t wt_inf_cnt_get(const WtInfMem &m, uint32_t k) {
+    return ((WT_AS_LDS uint16_t *) m.ring)[(((k >> 1) * (uint32_t) m.stride) << 1) + (k & 1u)];
+}
+WT_HD void wt_inf_cnt_set(const WtInfMem &m, uint32_t k, uint32_t v) {
+    ((WT_AS_LDS uint16_t *) m.ring)[(((k >> 1) * (uint32_t) m.stride) << 1) + (k & 1u)] = (uint16_t) v;
+}
 
 struct WtInfQuad { uint32_t x, y, z, w; };
 
-struct WtInflate {
-    // input: 16-byte chunks at 16-byte aligned addresses; `cur` is being consumed, `nxt` is in flight
+// The landing registers of a match source beyond the ring.  On the device the load is INLINE ASSEMBLY with its
+// destination tied to these registers ("+v"): written as plain C++ the compiler gives the load fresh registers and
+// copies them into the loop-carried ones right behind it -- s_waitcnt vmcnt(1) inside the step, i.e. the global
+// round trip per step this design exists to avoid (86 % of the steps see a lane with such a match).  The compiler does
+// not know about that load; wt_inf_land() waits for it explicitly.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t wt_inf_u32x4 __attribute__((ext_vector_type(4)));
+struct WtInfFar { wt_inf_u32x4 q; uint32_t t; };
+#else
+struct WtInfFar { uint32_t q[4]; uint32_t t; };
+#endif
+
+template <int RING>
+struct WtInflateT {
+    // input: 16-byte chunks at 16-byte aligned addresses.  `cur` is being consumed (qn words left, shifted so that
+    // cur.x is the next one), `q1` follows it, `pend` is in flight and lands at the next round boundary.
     const WT_AS_GLOBAL uint32_t *in_w;  // aligned base
+    uint32_t mis;               // bytes between the aligned base and the stream
     uint32_t in_chunk;          // next chunk to fetch
     uint32_t in_chunks;         // chunks that may be read
-    WtInfQuad cur, nxt;
-    uint32_t qi;                // words of `cur` already taken (the queue is shifted, cur.x is the next one)
-    bool nxt_empty;             // `nxt` was moved into `cur` and its successor has not arrived yet
-    uint32_t words;             // words taken so far
-    uint32_t head_bits;         // bits of the first word that precede the stream
+    WtInfQuad cur, q1, pend;
+    uint32_t qn;
+    bool q1_valid, pend_valid;
+    uint32_t wpos;              // words taken so far, counted from the aligned base
     uint32_t n_bytes;
     uint64_t bb;                // bit buffer, LSB first
     int32_t bc;                 // valid bits in bb
@@ -117,8 +151,16 @@ struct WtInflate {
     uint32_t copy_rem, copy_dist;
     uint32_t stored_rem;
     bool last, raw;             // last block seen; raw deflate (no zlib wrapper)
+    // a match beyond the ring: WT_INF_FAR bytes of its source, loaded into fpend, landed into fq
+    uint32_t fq[5];
+    WtInfFar fpend;
+    uint32_t far_have;          // bytes of fq not yet copied
+    uint32_t far_len;           // bytes the load in flight will deliver
+    bool far_pending;
+    // tables: literal / length code and distance code
     uint32_t llim[16], dlim[16];    // [1..15] used
-    int32_t ladj[16], dadj[16];
+    uint32_t lpk[16];           // (index adjustment << 16) | first sorted index of the length that holds a symbol >= 256
+    int32_t dadj[16];
     uint32_t dperm[5];          // the distance symbols sorted by code, 5 bits each, 6 per word
 };
 
@@ -132,124 +174,150 @@ WT_HD uint32_t wt_inf_bitrev15(uint32_t x) {
 #endif
 }
 
-// Chunk i of the input (past the end: the last chunk again -- a lane that gets there has over-read and fails,
-// see wt_inf_overread).  UNCONDITIONAL on purpose: a load under a branch is merged with the "no load" value by a
-// register copy, and the copy waits for the load right where it was issued.
-WT_HD WtInfQuad wt_inf_load(const WtInflate &z, uint32_t i) {
-    const uint32_t last = z.in_chunks ? z.in_chunks - 1u : 0u;
-    const WT_AS_GLOBAL uint32_t *p = z.in_w + 4 * (size_t) (i < last ? i : last);
+// Chunk i of the input (callers keep i < in_chunks).
+template <int RING>
+WT_HD WtInfQuad wt_inf_load(const WtInflateT<RING> &z, uint32_t i) {
+    const WT_AS_GLOBAL uint32_t *p = z.in_w + 4 * (size_t) i;
     WtInfQuad q;
     q.x = p[0]; q.y = p[1]; q.z = p[2]; q.w = p[3];
     return q;
 }
 
-WT_HD void wt_inf_fail(WtInflate &z, int code) { z.st = WT_INF_ST_ERR; z.err = code; z.copy_rem = 0; }
+template <int RING>
+// (st is written LAST: two branches that end in stores of the same constant to different fields -- copy_rem = 0 here,
+// st = WT_INF_ST_SYM = 0 at the end of the block header -- are merged by hipcc into one store through a selected
+// pointer, and a selected pointer keeps the fields in scratch memory: a scratch reload at the top of the step loop and
+// with it an s_waitcnt vmcnt(0) per step.)
+WT_HD void wt_inf_fail(WtInflateT<RING> &z, int code) { z.copy_rem = 0; z.err = code; z.st = WT_INF_ST_ERR; }
 
-// Bits consumed beyond the end of the stream?  (Checked when a chunk is fetched -- a stream that keeps decoding
-// garbage past its end cannot run forever -- and at the end.)
-WT_HD bool wt_inf_overread(const WtInflate &z) {
-    const int64_t consumed = (int64_t) z.words * 32 - (int64_t) z.head_bits - (int64_t) z.bc;
-    return consumed > (int64_t) z.n_bytes * 8;
-}
+// bits of the stream consumed so far
+template <int RING>
+WT_HD int64_t wt_inf_bitpos(const WtInflateT<RING> &z) { return (int64_t) z.wpos * 32 - (int64_t) z.bc - 8 * (int64_t) z.mis; }
 
-// (The queue is SHIFTED, never indexed: one variable index into the state struct and hipcc keeps the whole
-// struct in scratch memory.)  `nxt` is refilled by wt_inf_step's prefetch one step after it was moved into `cur`;
-// the blocking load here serves the block-header code, which reads many words inside one step.
-// HOT = true (the symbol loop): `nxt` is known to be there (a step takes at most two words, the prefetch lands one
-// step after `nxt` was taken) -- no load, hence no wait, on this path.
-template <bool HOT>
-WT_HD uint32_t wt_inf_word(WtInflate &z) {
+template <int RING>
+WT_HD bool wt_inf_overread(const WtInflateT<RING> &z) { return wt_inf_bitpos(z) > (int64_t) z.n_bytes * 8; }
+
+// The next word of the queue.  (The queue is SHIFTED, never indexed: one variable index into the state struct and
+// hipcc keeps the whole struct in scratch memory.)  An empty queue yields zero words: the caller has made sure that
+// nothing more can arrive (end of the input; wt_inf_overread catches a stream that decodes beyond it).
+template <int RING>
+WT_HD uint32_t wt_inf_word(WtInflateT<RING> &z) {
     const uint32_t w = z.cur.x;
-    z.cur.x = z.cur.y; z.cur.y = z.cur.z; z.cur.z = z.cur.w;
-    z.qi++;
-    z.words++;
-    if (z.qi == 4) {
-        if (!HOT && z.nxt_empty) { z.nxt = wt_inf_load(z, z.in_chunk); z.in_chunk++; }
-        z.cur = z.nxt;
-        z.qi = 0;
-        z.nxt_empty = true;
-    }
+    z.cur.x = z.cur.y; z.cur.y = z.cur.z; z.cur.z = z.cur.w; z.cur.w = 0;
+    z.wpos++;
+    if (z.qn) z.qn--;
+    if (z.qn == 0 && z.q1_valid) { z.cur = z.q1; z.qn = 4; z.q1_valid = false; }
     return w;
 }
 
+// The blocking flavour for the block-header code, which reads many words at one go: fills the queue on the spot.
+template <int RING>
+WT_HD uint32_t wt_inf_word_cold(WtInflateT<RING> &z) {
+    if (z.qn == 0) {
+        if (z.pend_valid) { z.cur = z.pend; z.qn = 4; z.pend_valid = false; }
+        else if (z.in_chunk < z.in_chunks) { z.cur = wt_inf_load(z, z.in_chunk); z.in_chunk++; z.qn = 4; }
+    }
+    return wt_inf_word(z);
+}
+
+// Positions the reader at bit `pos` of the stream (blocking; whatever was in flight is dropped).
+template <int RING>
+WT_HD void wt_inf_seek_bits(WtInflateT<RING> &z, uint32_t pos) {
+    const uint32_t byte = z.mis + (pos >> 3), word = byte >> 2, ch = word >> 2;
+    const WtInfQuad zero = {0u, 0u, 0u, 0u};
+    z.cur = ch < z.in_chunks ? wt_inf_load(z, ch) : zero;
+    z.q1_valid = ch + 1u < z.in_chunks;
+    z.q1 = z.q1_valid ? wt_inf_load(z, ch + 1u) : zero;
+    z.in_chunk = ch + 2u;
+    z.pend_valid = false;
+    z.qn = 4;
+    z.wpos = word & ~3u;
+    for (uint32_t k = 0; k < (word & 3u); k++) (void) wt_inf_word(z);     // whole words before the position are skipped
+    const uint32_t w0 = wt_inf_word(z);
+    const uint32_t head = 8u * (byte & 3u) + (pos & 7u);
+    z.bb = (uint64_t) (w0 >> head);
+    z.bc = 32 - (int32_t) head;
+}
+
 // Starts a stream of `n_bytes` at `src` (any alignment; the 16-byte aligned chunks around it must be readable
-// inside the same allocation -- up to 15 bytes before and 31 after) writing at most `cap` bytes to `dst` (4-byte
+// inside the same allocation -- up to 15 bytes before and 15 after) writing at most `cap` bytes to `dst` (4-byte
 // aligned, cap rounded up to a multiple of 4 must be writable).
-WT_HD void wt_inf_begin(WtInflate &z, const uint8_t *src, uint32_t n_bytes, uint8_t *dst, uint32_t cap, bool raw_deflate) {
+template <int RING>
+WT_HD void wt_inf_begin(WtInflateT<RING> &z, const uint8_t *src, uint32_t n_bytes, uint8_t *dst, uint32_t cap, bool raw_deflate) {
     const uintptr_t a = (uintptr_t) src;
-    const uint32_t mis = (uint32_t) (a & 15u);
-    z.in_w = (const WT_AS_GLOBAL uint32_t *) (a - mis);
-    z.in_chunks = (mis + n_bytes + 15u) >> 4;
+    z.mis = (uint32_t) (a & 15u);
+    z.in_w = (const WT_AS_GLOBAL uint32_t *) (a - z.mis);
+    z.in_chunks = (z.mis + n_bytes + 15u) >> 4;
     z.n_bytes = n_bytes;
-    z.cur = wt_inf_load(z, 0);
-    z.nxt = wt_inf_load(z, 1);
-    z.in_chunk = 2;
-    z.qi = 0;
-    z.nxt_empty = false;
-    z.words = 0;
-    for (uint32_t k = 0; k < (mis >> 2); k++) (void) wt_inf_word<false>(z);       // whole words before the stream are skipped
-    z.words = 0;
-    const uint32_t w0 = wt_inf_word<false>(z);
-    z.head_bits = 8u * (mis & 3u);
-    z.bb = (uint64_t) (w0 >> z.head_bits);
-    z.bc = 32 - (int32_t) z.head_bits;
+    z.pend.x = z.pend.y = z.pend.z = z.pend.w = 0;
+    wt_inf_seek_bits(z, 0);
     z.out = (WT_AS_GLOBAL uint32_t *) dst; z.out_pos = 0; z.out_cap = cap; z.acc = 0;
     z.st = raw_deflate ? WT_INF_ST_BLOCK : WT_INF_ST_ZHDR;
     z.err = WT_INF_OK;
     z.copy_rem = z.copy_dist = 0; z.stored_rem = 0;
     z.last = false; z.raw = raw_deflate;
+    z.far_have = z.far_len = 0; z.far_pending = false;
 #pragma unroll
-    for (int k = 0; k < 16; k++) { z.llim[k] = 0; z.dlim[k] = 0; z.ladj[k] = 0; z.dadj[k] = 0; }
+    for (int k = 0; k < 5; k++) { z.fq[k] = 0; z.dperm[k] = 0; }
 #pragma unroll
-    for (int k = 0; k < 5; k++) z.dperm[k] = 0;
+    for (int k = 0; k < 4; k++) z.fpend.q[k] = 0;
+    z.fpend.t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { z.llim[k] = 0; z.dlim[k] = 0; z.lpk[k] = 0; z.dadj[k] = 0; }
 }
 
-// After this bc >= 33 (past the end of the input the last chunk repeats; wt_inf_overread catches it).
-template <bool HOT = false>
-WT_HD void wt_inf_refill(WtInflate &z) {
+// After this bc >= 33 (COLD: fills the queue on the spot; otherwise the caller has checked that two words wait).
+template <bool COLD, int RING>
+WT_HD void wt_inf_refill(WtInflateT<RING> &z) {
     if (z.bc <= 32) {
-        z.bb |= (uint64_t) wt_inf_word<HOT>(z) << z.bc;
+        const uint32_t w = COLD ? wt_inf_word_cold(z) : wt_inf_word(z);
+        z.bb |= (uint64_t) w << z.bc;
         z.bc += 32;
     }
 }
 
-WT_HD uint32_t wt_inf_bits(WtInflate &z, int n) {      // n <= 32, after a refill guaranteeing enough bits
+template <int RING>
+WT_HD uint32_t wt_inf_bits(WtInflateT<RING> &z, int n) {      // n <= 32, after a refill guaranteeing enough bits
     const uint32_t v = (uint32_t) (z.bb & ((1ull << n) - 1ull));
     z.bb >>= n; z.bc -= n;
     return v;
 }
 
-// Length and sorted-symbol index of the code word on top of the stream: lim[1..15] / adj[1..15] registers.
-// Returns false on a pattern no code word matches.
-WT_HD bool wt_inf_code(WtInflate &z, const uint32_t (&lim)[16], const int32_t (&adj)[16], int32_t &idx) {
+// Length and table word of the code word on top of the stream: lim[1..15] / tab[1..15] registers; idx_base = the
+// position of the code word among the code words of its length.  Returns false on a pattern no code word matches.
+template <int RING, class T>
+WT_HD bool wt_inf_code(WtInflateT<RING> &z, const uint32_t (&lim)[16], const T (&tab)[16], T &t, uint32_t &within) {
     const uint32_t w = wt_inf_bitrev15((uint32_t) z.bb & 0x7FFFu);
     int len = 1;
-    int32_t a = adj[1];
+    T a = tab[1];
 #pragma unroll
     for (int k = 1; k <= 14; k++) {
         const bool ge = w >= lim[k];
         len += ge ? 1 : 0;
-        a = ge ? adj[k + 1] : a;
+        a = ge ? tab[k + 1] : a;
         WT_INF_OPAQUE(a);
     }
-    idx = a + (int32_t) (w >> (15 - len));
+    t = a;
+    within = w >> (15 - len);
     z.bb >>= len; z.bc -= len;
     return w < lim[15];
 }
 
-// lim[] / adj[] of a canonical code from the 16 per-length counts in cnt[] (lane memory); leaves the insertion
-// cursor of every length in cnt[].  False: over-subscribed.
-WT_HD bool wt_inf_limits(uint32_t (&lim)[16], int32_t (&adj)[16], WT_AS_LDS uint32_t *cnt, int stride) {
+// lim[] of a canonical code from the 16 per-length counts (lane memory); calls tab(k, first code of length k,
+// symbols shorter than k) for k = 1..15 and leaves the insertion cursor of every length in the counters.
+// False: over-subscribed.
+template <class F>
+WT_HD bool wt_inf_limits(uint32_t (&lim)[16], const WtInfMem &m, F tab) {
     uint32_t code = 0, off = 0;
     bool ok = true;
-    lim[0] = 0; adj[0] = 0;
+    lim[0] = 0;
 #pragma unroll
     for (int k = 1; k <= 15; k++) {
-        const uint32_t c = cnt[k * stride];
+        const uint32_t c = wt_inf_cnt_get(m, (uint32_t) k);
         if (code + c > (1u << k)) ok = false;
         lim[k] = (code + c) << (15 - k);
-        adj[k] = (int32_t) off - (int32_t) code;    // (symbols shorter than k) - first code of length k
-        cnt[k * stride] = off;                      // insertion cursor of length k
+        tab(k, code, off);
+        wt_inf_cnt_set(m, (uint32_t) k, off);       // insertion cursor of length k
         off += c;
         code = (code + c) << 1;
     }
@@ -258,7 +326,8 @@ WT_HD bool wt_inf_limits(uint32_t (&lim)[16], int32_t (&adj)[16], WT_AS_LDS uint
 
 // Appends the low n (1..8) bytes of `bytes` to the output: full dwords go to global memory and to the ring,
 // the partial one stays in `acc` (it reaches the ring when a match is about to read it).
-WT_HD void wt_inf_put(WtInflate &z, const WtInfMem &m, uint64_t bytes, uint32_t n) {
+template <int RING>
+WT_HD void wt_inf_put(WtInflateT<RING> &z, const WtInfMem &m, uint64_t bytes, uint32_t n) {
     if (n < 8) bytes &= (1ull << (8 * n)) - 1ull;
     const uint32_t sh = (z.out_pos & 3u) * 8u;
     const uint32_t d = z.out_pos >> 2;
@@ -269,11 +338,11 @@ WT_HD void wt_inf_put(WtInflate &z, const WtInfMem &m, uint64_t bytes, uint32_t 
     uint32_t acc = e0;
     if (full >= 1) {
         z.out[d] = e0;
-        m.ring[(d & (WT_INF_RING - 1)) * m.stride] = e0;
+        m.ring[(d & (RING - 1)) * m.stride] = e0;
         acc = e1;
         if (full >= 2) {
             z.out[d + 1] = e1;
-            m.ring[((d + 1) & (WT_INF_RING - 1)) * m.stride] = e1;
+            m.ring[((d + 1) & (RING - 1)) * m.stride] = e1;
             acc = e2;
         }
     }
@@ -281,29 +350,65 @@ WT_HD void wt_inf_put(WtInflate &z, const WtInfMem &m, uint64_t bytes, uint32_t 
     z.out_pos += n;
 }
 
-// One literal: the common case of wt_inf_put.
-WT_HD void wt_inf_put1(WtInflate &z, const WtInfMem &m, uint32_t b) {
-    const uint32_t acc = z.acc | (b << ((z.out_pos & 3u) * 8u));
-    z.out_pos++;
-    z.acc = acc;
-    if ((z.out_pos & 3u) == 0) {
-        const uint32_t d = (z.out_pos >> 2) - 1u;
-        z.out[d] = acc;
-        m.ring[(d & (WT_INF_RING - 1)) * m.stride] = acc;
-        z.acc = 0;
+// The code lengths of a dynamic block's two alphabets (RFC 1951 3.2.7), run-length coded with the code-length
+// code: calls f(i, length) for i = 0 .. total - 1.  Run twice per block (count, then place).
+struct WtInfClen {
+    uint32_t clim[8];
+    int32_t cadj[8];
+    uint64_t cp0, cp1;          // the code-length symbols sorted by code, 5 bits each: 12 in cp0, the rest in cp1
+};
+
+template <int RING, class F>
+WT_HD bool wt_inf_lengths(WtInflateT<RING> &z, const WtInfClen &c, int total, F f) {
+    int i = 0;
+    uint32_t prev = 0;
+    while (i < total) {
+        wt_inf_refill<true>(z);
+        const uint32_t w7 = wt_inf_bitrev15((uint32_t) z.bb & 0x7Fu) >> 8;     // 7-bit window, first bit on top
+        int len = 1;
+        int32_t a = c.cadj[1];
+#pragma unroll
+        for (int k = 1; k <= 6; k++) {
+            const bool ge = w7 >= c.clim[k];
+            len += ge ? 1 : 0;
+            a = ge ? c.cadj[k + 1] : a;
+            WT_INF_OPAQUE(a);
+        }
+        if (w7 >= c.clim[7]) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
+        const uint32_t j = (uint32_t) (a + (int32_t) (w7 >> (7 - len)));
+        const uint32_t sym = (uint32_t) ((j < 12u ? c.cp0 >> (5u * j) : c.cp1 >> (5u * (j - 12u))) & 31u);
+        z.bb >>= len; z.bc -= len;
+        uint32_t rep = 1, val = sym;
+        if (sym == 16) {
+            if (i == 0) { wt_inf_fail(z, WT_INF_ERR_CODE); return false; }
+            rep = 3 + wt_inf_bits(z, 2); val = prev;
+        } else if (sym == 17) {
+            rep = 3 + wt_inf_bits(z, 3); val = 0;
+        } else if (sym == 18) {
+            rep = 11 + wt_inf_bits(z, 7); val = 0;
+        } else if (sym > 18) {
+            wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false;
+        }
+        if (i + (int) rep > total) { wt_inf_fail(z, WT_INF_ERR_CODE); return false; }
+        for (uint32_t r = 0; r < rep; r++, i++) f(i, val);
+        prev = val;
     }
+    return true;
 }
+
+WT_HD uint32_t wt_inf_fixed_length(int s) { return s < 144 ? 8u : s < 256 ? 9u : s < 280 ? 7u : 8u; }
 
 // Block header (RFC 1951 3.2.3 - 3.2.7): sets up the tables of a fixed / dynamic block or the byte count of a
 // stored one.  Executed once or twice per stream: compactness matters more than speed here.
-WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
+template <int RING>
+WT_HD void wt_inf_block(WtInflateT<RING> &z, const WtInfMem &m) {
     const int S = m.stride;
-    wt_inf_refill(z);
+    wt_inf_refill<true>(z);
     z.last = wt_inf_bits(z, 1) != 0;
     const uint32_t type = wt_inf_bits(z, 2);
     if (type == 0) {
         wt_inf_bits(z, z.bc & 7);                   // to the byte boundary (bc counts from it)
-        wt_inf_refill(z);
+        wt_inf_refill<true>(z);
         const uint32_t len = wt_inf_bits(z, 16), nlen = wt_inf_bits(z, 16);
         if ((len ^ nlen) != 0xFFFFu) { wt_inf_fail(z, WT_INF_ERR_BLOCK); return; }
         z.stored_rem = len;
@@ -311,17 +416,40 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
         return;
     }
     if (type == 3) { wt_inf_fail(z, WT_INF_ERR_BLOCK); return; }
-    // the 16 ring slots become the per-length counters / cursors of the table construction: the history they hold
-    // (live when this is not the stream's first block) waits in registers
-    uint32_t saved[WT_INF_RING];
+    // the ring's first 8 dwords become the 16 per-length counters / cursors of the table construction: the history
+    // they hold (live when this is not the stream's first block) waits in registers
+    uint32_t saved[8];
 #pragma unroll
-    for (int k = 0; k < WT_INF_RING; k++) saved[k] = m.ring[k * S];
-    WT_AS_LDS uint32_t *cnt = m.ring;
+    for (int k = 0; k < 8; k++) saved[k] = m.ring[k * S];
     uint64_t dl0 = 0, dl1 = 0;                      // lengths of the distance symbols, 4 bits each (16 per word)
+    uint32_t lits[16];                              // literals (symbols < 256) per length: the counters when symbol 256 comes up
     int hlit = 288, hdist = 30;
-    for (int s = 0; s < WT_INF_PERM; s++) m.perm[s * S] = 0;
+    bool ok = true;
+    WtInfClen c;
+    uint32_t mark = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { wt_inf_cnt_set(m, (uint32_t) k, 0); lits[k] = 0; }
+    auto count = [&](int i, uint32_t l) {
+        if (i == 256) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) lits[k] = wt_inf_cnt_get(m, (uint32_t) k);
+            if (l == 0) ok = false;                 // no end-of-block code
+        }
+        if (i < hlit) wt_inf_cnt_set(m, l, wt_inf_cnt_get(m, l) + 1u);
+        else {
+            const uint32_t q = (uint32_t) (i - hlit);
+            if (q < 16u) dl0 |= (uint64_t) l << (4u * q); else dl1 |= (uint64_t) l << (4u * (q - 16u));
+        }
+    };
+    auto place = [&](int i, uint32_t l) {
+        if (l && i < hlit) {
+            const uint32_t j = wt_inf_cnt_get(m, l);
+            wt_inf_cnt_set(m, l, j + 1u);
+            if (j < (uint32_t) WT_INF_PERM) wt_inf_perm_set(m, j, (uint32_t) i);
+        }
+    };
     if (type == 1) {
-        for (int s = 0; s < 288; s++) m.perm[s * S] = (uint16_t) ((s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8) << 12);
+        for (int s = 0; s < 288; s++) count(s, wt_inf_fixed_length(s));
         dl0 = 0x5555555555555555ull; dl1 = 0x0055555555555555ull;       // 30 codes of 5 bits
     } else {
         hlit = (int) wt_inf_bits(z, 5) + 257;
@@ -330,119 +458,80 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
         if (hlit > 286 || hdist > 30) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
         // the code-length code: 19 lengths of 3 bits, packed 3 bits per symbol
         uint64_t cl = 0;
-        wt_inf_refill(z);
+        wt_inf_refill<true>(z);
 #pragma unroll
         for (int i = 0; i < 19; i++) {
             const int order = i == 0 ? 16 : i == 1 ? 17 : i == 2 ? 18 : i == 3 ? 0 : (i & 1) ? (8 - ((i - 3) >> 1)) : (7 + ((i - 2) >> 1));
-            if (i == 10) wt_inf_refill(z);
+            if (i == 10) wt_inf_refill<true>(z);
             if (i < hclen) cl |= (uint64_t) wt_inf_bits(z, 3) << (3 * order);
         }
         uint64_t cc = 0;                            // 8-bit counters per length
 #pragma unroll
         for (int s = 0; s < 19; s++) cc += 1ull << (8 * (int) ((cl >> (3 * s)) & 7u));
-        uint32_t clim[8];
-        int32_t cadj[8];
         uint64_t cur = 0;                           // insertion cursors, 8 bits per length
         {
             uint32_t code = 0, off = 0;
-            bool ok = true;
-            clim[0] = 0; cadj[0] = 0;
+            bool cok = true;
+            c.clim[0] = 0; c.cadj[0] = 0;
 #pragma unroll
             for (int k = 1; k <= 7; k++) {
-                const uint32_t c = (uint32_t) (cc >> (8 * k)) & 255u;
-                if (code + c > (1u << k)) ok = false;
-                clim[k] = (code + c) << (7 - k);
-                cadj[k] = (int32_t) off - (int32_t) code;
+                const uint32_t n = (uint32_t) (cc >> (8 * k)) & 255u;
+                if (code + n > (1u << k)) cok = false;
+                c.clim[k] = (code + n) << (7 - k);
+                c.cadj[k] = (int32_t) off - (int32_t) code;
                 cur |= (uint64_t) off << (8 * k);
-                off += c;
-                code = (code + c) << 1;
+                off += n;
+                code = (code + n) << 1;
             }
-            if (!ok) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
+            if (!cok) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
         }
-        // its symbols sorted by code, 5 bits each: 12 in cp0, the rest in cp1
-        uint64_t cp0 = 0, cp1 = 0;
+        c.cp0 = 0; c.cp1 = 0;
 #pragma unroll
         for (int s = 0; s < 19; s++) {
             const int l = (int) ((cl >> (3 * s)) & 7u);
             if (l) {
                 const uint32_t j = (uint32_t) (cur >> (8 * l)) & 255u;
                 cur += 1ull << (8 * l);
-                if (j < 12u) cp0 |= (uint64_t) s << (5u * j); else cp1 |= (uint64_t) s << (5u * (j - 12u));
+                if (j < 12u) c.cp0 |= (uint64_t) s << (5u * j); else c.cp1 |= (uint64_t) s << (5u * (j - 12u));
             }
         }
-        const int total = hlit + hdist;
-        int i = 0;
-        uint32_t prev = 0;
-        while (i < total) {
-            wt_inf_refill(z);
-            const uint32_t w7 = wt_inf_bitrev15((uint32_t) z.bb & 0x7Fu) >> 8;     // 7-bit window, first bit on top
-            int len = 1;
-            int32_t a = cadj[1];
-#pragma unroll
-            for (int k = 1; k <= 6; k++) {
-                const bool ge = w7 >= clim[k];
-                len += ge ? 1 : 0;
-                a = ge ? cadj[k + 1] : a;
-                WT_INF_OPAQUE(a);
-            }
-            if (w7 >= clim[7]) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return; }
-            const uint32_t j = (uint32_t) (a + (int32_t) (w7 >> (7 - len)));
-            const uint32_t sym = (uint32_t) ((j < 12u ? cp0 >> (5u * j) : cp1 >> (5u * (j - 12u))) & 31u);
-            z.bb >>= len; z.bc -= len;
-            uint32_t rep = 1, val = sym;
-            if (sym == 16) {
-                if (i == 0) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
-                rep = 3 + wt_inf_bits(z, 2); val = prev;
-            } else if (sym == 17) {
-                rep = 3 + wt_inf_bits(z, 3); val = 0;
-            } else if (sym == 18) {
-                rep = 11 + wt_inf_bits(z, 7); val = 0;
-            } else if (sym > 18) {
-                wt_inf_fail(z, WT_INF_ERR_SYMBOL); return;
-            }
-            if (i + (int) rep > total) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
-            for (uint32_t r = 0; r < rep; r++, i++) {
-                if (i < hlit) m.perm[i * S] = (uint16_t) (val << 12);
-                else {
-                    const uint32_t q = (uint32_t) (i - hlit);
-                    if (q < 16u) dl0 |= (uint64_t) val << (4u * q); else dl1 |= (uint64_t) val << (4u * (q - 16u));
-                }
-            }
-            prev = val;
-        }
-        if ((m.perm[256 * S] >> 12) == 0) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }    // no end-of-block code
+        mark = (uint32_t) wt_inf_bitpos(z);
+        if (!wt_inf_lengths(z, c, hlit + hdist, count)) return;
     }
-    // literal / length table: counts -> limits -> symbols sorted by code, in place (lengths in the top 4 bits)
-    bool ok = true;
+    // literal / length code: limits, and per length (index adjustment << 16) | first index holding a symbol >= 256
+    uint32_t lpk[16];
+    lpk[0] = 0;
+    ok = wt_inf_limits(z.llim, m, [&](int k, uint32_t code, uint32_t off) {
+        lpk[k] = ((uint32_t) ((int32_t) off - (int32_t) code) << 16) | ((off + lits[k]) & 0xFFFFu);
+    }) && ok;
 #pragma unroll
-    for (int k = 0; k < 16; k++) cnt[k * S] = 0;
-    for (int s = 0; s < WT_INF_PERM; s++) {
-        const int l = m.perm[s * S] >> 12;
-        cnt[l * S] = cnt[l * S] + 1u;
-    }
-    ok = wt_inf_limits(z.llim, z.ladj, cnt, S) && ok;
-    for (int s = 0; s < WT_INF_PERM; s++) {
-        const int l = m.perm[s * S] >> 12;
-        if (l) {
-            const uint32_t j = cnt[l * S];
-            cnt[l * S] = j + 1u;
-            if (j < (uint32_t) WT_INF_PERM) m.perm[j * S] = (uint16_t) ((m.perm[j * S] & 0xF000u) | (uint32_t) s);
-        }
+    for (int k = 0; k < 16; k++) z.lpk[k] = lpk[k];
+    // ... its symbols sorted by code (low bytes): the lengths once more, this time to place them
+    if (type == 1) {
+        for (int s = 0; s < 288; s++) place(s, wt_inf_fixed_length(s));
+    } else {
+        // (the whole sequence again: a repeat code may run from one alphabet into the other)
+        wt_inf_seek_bits(z, mark);
+        if (!wt_inf_lengths(z, c, hlit + hdist, place)) return;
     }
     // distance table: 30 symbols, sorted into 5 registers
 #pragma unroll
-    for (int k = 0; k < 16; k++) cnt[k * S] = 0;
+    for (int k = 0; k < 16; k++) wt_inf_cnt_set(m, (uint32_t) k, 0);
     for (int s = 0; s < 30; s++) {
         const uint32_t l = (uint32_t) ((s < 16 ? dl0 >> (4 * s) : dl1 >> (4 * (s - 16))) & 15u);
-        cnt[l * S] = cnt[l * S] + 1u;
+        wt_inf_cnt_set(m, l, wt_inf_cnt_get(m, l) + 1u);
     }
-    ok = wt_inf_limits(z.dlim, z.dadj, cnt, S) && ok;
+    int32_t dadj[16];
+    dadj[0] = 0;
+    ok = wt_inf_limits(z.dlim, m, [&](int k, uint32_t code, uint32_t off) { dadj[k] = (int32_t) off - (int32_t) code; }) && ok;
+#pragma unroll
+    for (int k = 0; k < 16; k++) z.dadj[k] = dadj[k];
     uint32_t dp[5] = {0u, 0u, 0u, 0u, 0u};
     for (int s = 0; s < 30; s++) {
         const uint32_t l = (uint32_t) ((s < 16 ? dl0 >> (4 * s) : dl1 >> (4 * (s - 16))) & 15u);
         if (l) {
-            const uint32_t j = cnt[l * S];
-            cnt[l * S] = j + 1u;
+            const uint32_t j = wt_inf_cnt_get(m, l);
+            wt_inf_cnt_set(m, l, j + 1u);
             const uint32_t word = j / 6u, sh = 5u * (j - 6u * word);
 #pragma unroll
             for (int q = 0; q < 5; q++) dp[q] |= (word == (uint32_t) q) ? ((uint32_t) s << sh) : 0u;
@@ -451,140 +540,181 @@ WT_HD void wt_inf_block(WtInflate &z, const WtInfMem &m) {
 #pragma unroll
     for (int q = 0; q < 5; q++) z.dperm[q] = dp[q];
 #pragma unroll
-    for (int k = 0; k < WT_INF_RING; k++) m.ring[k * S] = saved[k];
+    for (int k = 0; k < 8; k++) m.ring[k * S] = saved[k];
     if (!ok) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
     z.st = WT_INF_ST_SYM;
 }
 
-WT_HD bool wt_inf_step_body(WtInflate &z, const WtInfMem &m);
-WT_HD bool wt_inf_step_cold(WtInflate &z, const WtInfMem &m);
-
-// One step of the state machine.  Returns false once the lane has nothing more to do.
-// The input prefetch brackets the step: the 16-byte load of the chunk after next is ISSUED before the step's
-// work and its registers are only touched after it -- a load whose result is merged into the loop-carried state
-// right where it was issued costs a full memory round trip per chunk (hipcc copies it at the end of the
-// branch; seen in the ISA as s_waitcnt vmcnt(0) three instructions after the load).
-WT_HD bool wt_inf_step(WtInflate &z, const WtInfMem &m) {
+// ---- round boundary: everything that waits for memory, and everything rare
+// Returns false once the lane has nothing more to do.
+template <int RING>
+WT_HD bool wt_inf_land(WtInflateT<RING> &z, const WtInfMem &m) {
     if (z.st >= WT_INF_ST_DONE) return false;
-    const bool need = z.nxt_empty;
-    const uint32_t chunk0 = z.in_chunk;
-    WtInfQuad tmp;                  // (only read under `need`)
-    if (need) {
-        if (wt_inf_overread(z)) { wt_inf_fail(z, WT_INF_ERR_INPUT); return false; }
-        tmp = wt_inf_load(z, chunk0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the round's one wait for memory: `pend` and `fpend` have landed
+#endif
+    if (z.pend_valid) {
+        if (z.qn == 0) { z.cur = z.pend; z.qn = 4; }
+        else { z.q1 = z.pend; z.q1_valid = true; }
+        z.pend_valid = false;
     }
-    const bool more = wt_inf_step_body(z, m);
-    if (need && z.nxt_empty && z.in_chunk == chunk0) { z.nxt = tmp; z.in_chunk = chunk0 + 1; z.nxt_empty = false; }
-    return more;
-}
-
-WT_HD bool wt_inf_step_body(WtInflate &z, const WtInfMem &m) {
-    const int S = m.stride;
-    if (z.copy_rem) {
-        // up to 8 bytes of the match: three dwords around the source, one LDS round trip
-        const uint32_t src = z.out_pos - z.copy_dist;
-        const uint32_t d0 = src >> 2;
-        uint32_t r0, r1, r2;
-        if (z.copy_dist <= WT_INF_RING_DIST) {
-            m.ring[((z.out_pos >> 2) & (WT_INF_RING - 1)) * S] = z.acc;        // the partial dword may be part of the source
-            r0 = m.ring[(d0 & (WT_INF_RING - 1)) * S];
-            r1 = m.ring[((d0 + 1) & (WT_INF_RING - 1)) * S];
-            r2 = m.ring[((d0 + 2) & (WT_INF_RING - 1)) * S];
-        } else {                                    // flushed long ago (full dwords are stored at once)
-            r0 = z.out[d0]; r1 = z.out[d0 + 1]; r2 = z.out[d0 + 2];
-        }
-        const uint32_t sh = (src & 3u) * 8u;
-        uint64_t w = ((uint64_t) r0 | ((uint64_t) r1 << 32)) >> sh;
-        if (sh) w |= (uint64_t) r2 << (64u - sh);
-        if (z.copy_dist < 8u) {                     // overlapping copy: the first `dist` bytes repeat
-            const uint32_t s8 = 8u * z.copy_dist;
-            w &= (1ull << s8) - 1ull;
-            w |= w << s8;
-            if (2u * s8 < 64u) w |= w << (2u * s8);
-            if (4u * s8 < 64u) w |= w << (4u * s8);
-        }
-        const uint32_t n = z.copy_rem < (uint32_t) WT_INF_COPY ? z.copy_rem : (uint32_t) WT_INF_COPY;
-        wt_inf_put(z, m, w, n);
-        z.copy_rem -= n;
-        if (z.copy_rem) return true;
+    if (z.far_pending) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) z.fq[k] = z.fpend.q[k];
+        z.fq[4] = z.fpend.t;
+        z.far_have = z.far_len;
+        z.far_pending = false;
     }
-    if (z.st == WT_INF_ST_SYM) {
+    if (wt_inf_overread(z)) { wt_inf_fail(z, WT_INF_ERR_INPUT); return false; }
+    if (z.st == WT_INF_ST_ZHDR) {                   // RFC 1950 -- CMF, FLG
         wt_inf_refill<true>(z);
-        int32_t idx;
-        if (!wt_inf_code(z, z.llim, z.ladj, idx)) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
-        const uint32_t sym = m.perm[idx * S] & 0x1FFu;
-        if (sym < 256u) {
-            if (z.out_pos >= z.out_cap) { wt_inf_fail(z, WT_INF_ERR_SPACE); return false; }
-            wt_inf_put1(z, m, sym);
-        } else if (sym == 256u) {
-            z.st = z.last ? WT_INF_ST_DONE : WT_INF_ST_BLOCK;
-        } else {
-            const uint32_t ls = sym - 257u;
-            if (ls > 28u) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
-            uint32_t len;
-            if (ls < 8u) len = ls + 3u;
-            else if (ls == 28u) len = 258u;
-            else {
-                const uint32_t e = (ls - 4u) >> 2;
-                len = ((4u + (ls & 3u)) << e) + 3u + wt_inf_bits(z, (int) e);
-            }
-            wt_inf_refill<true>(z);
-            int32_t di;
-            if (!wt_inf_code(z, z.dlim, z.dadj, di) || (uint32_t) di > 29u) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
-            const uint32_t word = (uint32_t) di / 6u, dsh = 5u * ((uint32_t) di - 6u * word);
-            uint32_t dw = z.dperm[0];
-            dw = word == 1u ? z.dperm[1] : dw; WT_INF_OPAQUE(dw);
-            dw = word == 2u ? z.dperm[2] : dw; WT_INF_OPAQUE(dw);
-            dw = word == 3u ? z.dperm[3] : dw; WT_INF_OPAQUE(dw);
-            dw = word == 4u ? z.dperm[4] : dw; WT_INF_OPAQUE(dw);
-            const uint32_t ds = (dw >> dsh) & 31u;
-            if (ds > 29u) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
-            uint32_t dist;
-            if (ds < 4u) dist = ds + 1u;
-            else {
-                const uint32_t e = (ds >> 1) - 1u;
-                dist = ((2u + (ds & 1u)) << e) + 1u + wt_inf_bits(z, (int) e);
-            }
-            if (dist > z.out_pos) { wt_inf_fail(z, WT_INF_ERR_DIST); return false; }
-            if (z.out_pos + len > z.out_cap) { wt_inf_fail(z, WT_INF_ERR_SPACE); return false; }
-            z.copy_rem = len; z.copy_dist = dist;
-        }
-        return true;
-    }
-    // every other state: rare, and it leaves `nxt` filled -- the symbol loop relies on it (wt_inf_word<true>)
-    const bool more = wt_inf_step_cold(z, m);
-    if (z.nxt_empty) { z.nxt = wt_inf_load(z, z.in_chunk); z.in_chunk++; z.nxt_empty = false; }
-    return more;
-}
-
-WT_HD bool wt_inf_step_cold(WtInflate &z, const WtInfMem &m) {
-    if (z.st == WT_INF_ST_STORED) {
-        wt_inf_refill(z);
-        const uint32_t n = z.stored_rem < 4u ? z.stored_rem : 4u;
-        if (z.out_pos + n > z.out_cap) { wt_inf_fail(z, WT_INF_ERR_SPACE); return false; }
-        wt_inf_put(z, m, (uint64_t) wt_inf_bits(z, 8 * (int) n), n);
-        z.stored_rem -= n;
-        if (!z.stored_rem) z.st = z.last ? WT_INF_ST_DONE : WT_INF_ST_BLOCK;
-        return true;
+        const uint32_t cmf = wt_inf_bits(z, 8), flg = wt_inf_bits(z, 8);
+        if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u || (flg & 32u)) { wt_inf_fail(z, WT_INF_ERR_HEADER); return false; }
+        z.st = WT_INF_ST_BLOCK;
     }
     if (z.st == WT_INF_ST_BLOCK) {
         wt_inf_block(z, m);
-        return z.st != WT_INF_ST_ERR;
+        if (z.st >= WT_INF_ST_DONE) return false;
     }
-    // WT_INF_ST_ZHDR: RFC 1950 -- CMF, FLG
-    wt_inf_refill(z);
-    const uint32_t cmf = wt_inf_bits(z, 8), flg = wt_inf_bits(z, 8);
-    if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u || (flg & 32u)) { wt_inf_fail(z, WT_INF_ERR_HEADER); return false; }
-    z.st = WT_INF_ST_BLOCK;
+    if (!z.q1_valid && !z.pend_valid && z.in_chunk < z.in_chunks) {
+        z.pend = wt_inf_load(z, z.in_chunk);
+        z.in_chunk++;
+        z.pend_valid = true;
+    }
     return true;
 }
 
+// ---- one step: at most one symbol, at most WT_INF_COPY bytes.  No load issued here is consumed here.
+template <int RING>
+WT_HD void wt_inf_step(WtInflateT<RING> &z, const WtInfMem &m) {
+    const int S = m.stride;
+    uint64_t bytes = 0;
+    uint32_t n = 0;
+    // two words cover the worst symbol (15 + 5 + 15 + 13 bits after a refill to >= 33)
+    const bool fed = z.qn + (z.q1_valid ? 4u : 0u) >= 2u || (!z.pend_valid && z.in_chunk >= z.in_chunks);
+    if (z.copy_rem == 0 && fed && z.st <= WT_INF_ST_STORED) {
+        wt_inf_refill<false>(z);
+        if (z.st == WT_INF_ST_SYM) {
+            uint32_t pk, within;
+            const bool hit = wt_inf_code(z, z.llim, z.lpk, pk, within);
+            const uint32_t idx = (uint32_t) (((int32_t) pk >> 16) + (int32_t) within);
+            const uint32_t s8 = hit ? wt_inf_perm_get(m, idx < (uint32_t) WT_INF_PERM ? idx : 0u) : 0u;
+            if (!hit) {
+                wt_inf_fail(z, WT_INF_ERR_SYMBOL);
+            } else if (idx < (pk & 0xFFFFu)) {      // a literal
+                if (z.out_pos >= z.out_cap) wt_inf_fail(z, WT_INF_ERR_SPACE);
+                else { bytes = s8; n = 1; }
+            } else if (s8 == 0u) {                  // 256: end of block
+                z.st = z.last ? WT_INF_ST_DONE : WT_INF_ST_BLOCK;
+            } else {
+                const uint32_t ls = s8 - 1u;        // length symbol 257 + ls
+                uint32_t len;
+                if (ls < 8u) len = ls + 3u;
+                else if (ls == 28u) len = 258u;
+                else {
+                    const uint32_t e = (ls - 4u) >> 2;
+                    len = ((4u + (ls & 3u)) << e) + 3u + wt_inf_bits(z, (int) (e < 6u ? e : 0u));
+                }
+                wt_inf_refill<false>(z);
+                int32_t da;
+                uint32_t dwithin;
+                const bool dhit = wt_inf_code(z, z.dlim, z.dadj, da, dwithin);
+                const uint32_t di = (uint32_t) (da + (int32_t) dwithin);
+                const uint32_t word = di / 6u, dsh = 5u * (di - 6u * word);
+                uint32_t dw = z.dperm[0];
+                dw = word == 1u ? z.dperm[1] : dw; WT_INF_OPAQUE(dw);
+                dw = word == 2u ? z.dperm[2] : dw; WT_INF_OPAQUE(dw);
+                dw = word == 3u ? z.dperm[3] : dw; WT_INF_OPAQUE(dw);
+                dw = word == 4u ? z.dperm[4] : dw; WT_INF_OPAQUE(dw);
+                const uint32_t ds = (dw >> dsh) & 31u;
+                uint32_t dist = ds + 1u;
+                if (ds >= 4u) {
+                    const uint32_t e = (ds >> 1) - 1u;
+                    dist = ((2u + (ds & 1u)) << e) + 1u + wt_inf_bits(z, (int) (e < 14u ? e : 0u));
+                }
+                if (ls > 28u || !dhit || di > 29u || ds > 29u) wt_inf_fail(z, WT_INF_ERR_SYMBOL);
+                else if (dist > z.out_pos) wt_inf_fail(z, WT_INF_ERR_DIST);
+                else if (z.out_pos + len > z.out_cap) wt_inf_fail(z, WT_INF_ERR_SPACE);
+                else { z.copy_rem = len; z.copy_dist = dist; }
+            }
+        } else {                                    // WT_INF_ST_STORED: up to 4 bytes (bc is a multiple of 8 here)
+            const uint32_t k = z.stored_rem < 4u ? z.stored_rem : 4u;
+            if (z.out_pos + k > z.out_cap) wt_inf_fail(z, WT_INF_ERR_SPACE);
+            else {
+                bytes = (uint64_t) wt_inf_bits(z, 8 * (int) k);
+                n = k;
+                z.stored_rem -= k;
+                if (!z.stored_rem) z.st = z.last ? WT_INF_ST_DONE : WT_INF_ST_BLOCK;
+            }
+        }
+    }
+    if (z.copy_rem) {
+        const uint32_t src = z.out_pos - z.copy_dist;
+        const uint32_t sh = (src & 3u) * 8u;
+        if (z.copy_dist <= (uint32_t) WT_INF_RING_DIST(RING)) {
+            // up to 8 bytes of the match: three dwords around the source, one LDS round trip
+            const uint32_t d0 = src >> 2;
+            m.ring[((z.out_pos >> 2) & (RING - 1)) * S] = z.acc;          // the partial dword may be part of the source
+            const uint32_t r0 = m.ring[(d0 & (RING - 1)) * S];
+            const uint32_t r1 = m.ring[((d0 + 1) & (RING - 1)) * S];
+            const uint32_t r2 = m.ring[((d0 + 2) & (RING - 1)) * S];
+            uint64_t w = ((uint64_t) r0 | ((uint64_t) r1 << 32)) >> sh;
+            if (sh) w |= (uint64_t) r2 << (64u - sh);
+            if (z.copy_dist < 8u) {                 // overlapping copy: the first `dist` bytes repeat
+                const uint32_t s8 = 8u * z.copy_dist;
+                w &= (1ull << s8) - 1ull;
+                w |= w << s8;
+                if (2u * s8 < 64u) w |= w << (2u * s8);
+                if (4u * s8 < 64u) w |= w << (4u * s8);
+            }
+            n = z.copy_rem < (uint32_t) WT_INF_COPY ? z.copy_rem : (uint32_t) WT_INF_COPY;
+            bytes = w;
+            z.copy_rem -= n;
+        } else if (z.far_have) {                    // landed: the next <= 8 bytes wait in fq (never overlapping: dist > FAR)
+            uint64_t w = ((uint64_t) z.fq[0] | ((uint64_t) z.fq[1] << 32)) >> sh;
+            if (sh) w |= (uint64_t) z.fq[2] << (64u - sh);
+            n = z.far_have < (uint32_t) WT_INF_COPY ? z.far_have : (uint32_t) WT_INF_COPY;
+            bytes = w;
+            z.far_have -= n;
+            z.copy_rem -= n;
+            z.fq[0] = z.fq[2]; z.fq[1] = z.fq[3]; z.fq[2] = z.fq[4];
+        } else if (!z.far_pending) {
+            // beyond the ring: the lane's own output is read back (full dwords were stored as they filled up, the
+            // partial one is flushed now); the bytes land at the next round boundary and the lane idles until then
+            const uint32_t d0 = src >> 2;
+            if (z.out_pos & 3u) z.out[z.out_pos >> 2] = z.acc;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const WT_AS_GLOBAL uint32_t *sp = z.out + d0;
+            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dword %1, %2, off offset:16"
+                         : "+v"(z.fpend.q), "+v"(z.fpend.t) : "v"(sp) : "memory");
+#else
+            for (int k = 0; k < 4; k++) z.fpend.q[k] = z.out[d0 + k];
+            z.fpend.t = z.out[d0 + 4];
+#endif
+            z.far_len = z.copy_rem < (uint32_t) WT_INF_FAR ? z.copy_rem : (uint32_t) WT_INF_FAR;
+            z.far_pending = true;
+        }
+    }
+    if (n) wt_inf_put(z, m, bytes, n);
+}
+
 // Flushes the last partial dword; returns the number of bytes produced or -(error code).
-WT_HD int64_t wt_inf_finish(WtInflate &z) {
+template <int RING>
+WT_HD int64_t wt_inf_finish(WtInflateT<RING> &z) {
     if (z.st == WT_INF_ST_DONE && wt_inf_overread(z)) { z.st = WT_INF_ST_ERR; z.err = WT_INF_ERR_INPUT; }
     if (z.st != WT_INF_ST_DONE) return -(int64_t) (z.err ? z.err : WT_INF_ERR_INPUT);
     if (z.out_pos & 3u) z.out[z.out_pos >> 2] = z.acc;
     return (int64_t) z.out_pos;
+}
+
+// The whole stream: rounds of WT_INF_ROUND steps between landings.
+template <int RING>
+WT_HD int64_t wt_inf_run(WtInflateT<RING> &z, const WtInfMem &m) {
+    while (wt_inf_land(z, m)) {
+#pragma unroll 1
+        for (int r = 0; r < WT_INF_ROUND; r++) wt_inf_step(z, m);
+    }
+    return wt_inf_finish(z);
 }
 
 #endif  // WT_INFLATE_H_

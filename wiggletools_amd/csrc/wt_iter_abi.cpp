@@ -837,6 +837,7 @@ void mux_pop(Multiplexer *m) {
     if (!F.holding || S->cur >= F.res.n_runs) {
         if (F.holding) F.depth = pipe_depth();
         if (!F.next()) { m->done = 1; F.finish(); S->open = false; return; }
+        if (F.res.integ_valid) die("popMultiplexer: the batch was integrated on the device (no runs came home)");
         S->cur = 0;
     }
     const int N = m->count;
@@ -894,6 +895,7 @@ void red_pop(WiggleIterator *wi) {
             F.finish();
             return;
         }
+        if (F.res.integ_valid) die("pop of a reducer whose batch was integrated on the device (no runs came home)");
         R->cur = 0;
     }
     const int64_t r = R->cur++;
@@ -1727,6 +1729,12 @@ void integ_fused_pop(WiggleIterator *wi) {
 void integ_fused_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
     // StatisticSeek / MeanSeek / PearsonSeek (statistics.c:38-43,84-88,406-410): seek the source, pop -- the sums go on
     IntegData *d = (IntegData *) wi->data;
+    // The source's seek re-primes by popping RUNS: its pipes go back to shipping them (a pass that ended mid-stream left
+    // them integrating: the priming pop would have read a batch without runs); the pop below switches them over again
+    // and integrates the primed batches where they lie.
+    Feeder &F = d->kind == 2 ? mux_state(d->multi)->fd : red_state(d->source)->fd;
+    for (wtamd_pipe *q : F.pipes)
+        if (wtamd_pipe_set_integrate(q, 0) != WTAMD_OK) die("wtamd_pipe_set_integrate");
     if (d->kind == 2) seekMultiplexer(d->multi, chrom, start, finish); else seek(d->source, chrom, start, finish);
     d->primed = 0;
     wi->done = 0;

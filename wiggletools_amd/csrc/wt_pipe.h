@@ -356,8 +356,8 @@ struct WtSlot {
     int64_t h_bw_cap = 0, d_bw_cap = 0;
     int64_t bw_off_sec = 0, bw_off_bytes = 0;       // layout of the reserved staging
     int64_t bw_res_bytes = -1, bw_res_secs = -1;     // what wtamd_pipe_bw_reserve was asked for (-1: nothing reserved)
-    void *d_bw_scratch = nullptr;
-    int64_t bw_scratch_cap = 0;
+    int64_t bw_bytes = 0, bw_stride = 0;             // of the batch in flight (a batch that overflowed its run lists is decoded again)
+    int64_t bw_bound = 0;                            // the host's upper bound of its intervals
     unsigned long long *h_bw_status = nullptr;       // pinned: error bits, pieces
     hipEvent_t e_bwc = nullptr, e_bw0 = nullptr, e_bw1 = nullptr;
     bool bw = false;                                 // the batch in flight came as file bytes
@@ -401,6 +401,16 @@ struct wtamd_pipe {
     bool map_drops = false;         // ... some operator drops runs: batches are compacted
     bool map_f32 = false;           // ... every operator is float32-exact: float32 batches stay float32 (and on the exact kernels)
     int num_cu = 256;
+    // File-byte batches: the inflate scratch is ONE per pipe -- every decode runs on the compute stream, in order, and
+    // is through with the scratch before the next one starts (round 3 kept 0.8 GB of it in each of four slots).
+    void *d_bw_scratch = nullptr;
+    int64_t bw_scratch_cap = 0;
+    // ... and their run lists are sized from the densest batch seen so far (intervals / host bound), not from the bound:
+    // the bound must assume 4-byte fixedStep items because the item type is inside the compressed stream, three times
+    // what bedGraph sections hold.  A batch that does not fit reports WT_BW_ERR_CAPACITY and is decoded again at full
+    // size when it is collected (wt_pipe_bw_redo); from then on the pipe sizes by the bound.  < 0: nothing seen yet.
+    double bw_density = -1.0;
+    int64_t bw_redone = 0;
     wtamd_pipe_stats st{};
 };
 
@@ -425,7 +435,7 @@ static void wt_slot_free(WtSlot &s) {
     if (s.h_integ) wt_host_free(s.h_integ);
     (void) wt_dev_free(s.d_integ);
     if (s.h_bw_status) wt_host_free(s.h_bw_status);
-    (void) wt_dev_free(s.d_bw); (void) wt_dev_free(s.d_bw_scratch);
+    (void) wt_dev_free(s.d_bw);
     for (hipEvent_t e : {s.e_bwc, s.e_bw0, s.e_bw1})
         if (e) (void) hipEventDestroy(e);
     if (s.ts) {
@@ -649,6 +659,7 @@ void wtamd_pipe_destroy(wtamd_pipe *p) {
     if (p->s_comp) (void) hipStreamDestroy(p->s_comp);
     if (p->s_out) (void) hipStreamDestroy(p->s_out);
     if (p->d_chains) (void) wt_dev_free(p->d_chains);
+    (void) wt_dev_free(p->d_bw_scratch);
     for (void *q : p->dead_dev) (void) wt_dev_free(q);
     for (void *q : p->dead_host) wt_host_free(q);
     delete p;
@@ -711,7 +722,7 @@ int wtamd_pipe_cancel(wtamd_pipe *p) {
 // bw_tracks != NULL: the batch came as BigWig file bytes (wtamd_pipe_submit_bw) -- the run lists are produced
 // on the device, the host only knows upper bounds of their sizes and extents.
 static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi,
-                               const wtamd_bw_track *bw_tracks = nullptr, int64_t bw_bytes = 0, int64_t bw_secs = 0);
+                               const wtamd_bw_track *bw_tracks = nullptr, int64_t bw_bytes = 0, int64_t bw_secs = 0, WtSlot *redo = nullptr);
 
 int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi) {
     WtDevGuard dev_guard_(p ? p->device : -1);
@@ -801,14 +812,16 @@ static int wt_pipe_bw_bounds(wtamd_pipe *p, WtSlot &s, const wtamd_bw_track *tk,
     return WTAMD_OK;
 }
 
+// redo != NULL: the file-byte batch of that (submitted) slot once more, its run lists at the size of the host's bound
+// -- everything the first submit staged (tables, file bytes, seg_off bounds) is still in place.
 static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t range_hi,
-                               const wtamd_bw_track *bw_tracks, int64_t bw_bytes, int64_t bw_secs) {
-    if (!p || p->acquired < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: no acquired slot");
-    WtSlot &s = p->slots[(size_t) p->acquired];
+                               const wtamd_bw_track *bw_tracks, int64_t bw_bytes, int64_t bw_secs, WtSlot *redo) {
+    if (!p || (!redo && p->acquired < 0)) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit: no acquired slot");
+    WtSlot &s = redo ? *redo : p->slots[(size_t) p->acquired];
     const int N = p->cfg.n_tracks;
     const bool bw = bw_tracks != nullptr;
-    int64_t bw_stride = 0;
-    if (bw) {
+    int64_t bw_stride = redo ? s.bw_stride : 0;
+    if (bw && !redo) {
         if (!s.direct.empty()) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_submit_bw: the slot holds direct ranges");
         const int rcb = wt_pipe_bw_bounds(p, s, bw_tracks, bw_bytes, bw_secs, &bw_stride);
         if (rcb != WTAMD_OK) return rcb;
@@ -833,7 +846,11 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     wtamd_trackset *ts = s.ts;
     const bool f64 = value_is_f64 != 0;
     // device twin of the staging (grow-only)
-    const int64_t need_in = n > 0 ? n : 1;
+    int64_t need_in = n > 0 ? n : 1;
+    if (bw && !redo && p->bw_density >= 0.0 && p->bw_density < 1.0) {
+        const int64_t by_density = (int64_t) ((double) n * p->bw_density * 1.125) + 65536;
+        if (by_density < need_in) need_in = by_density;
+    }
     if (s.dcap < need_in || (f64 && !s.d_has64)) {
         // an eighth of slack, not a doubling: the batches of a run settle on one size and wobble by a fraction of a
         // percent around it (63 220 sections, then 63 502), and "twice the old capacity" answered the first batch that
@@ -954,22 +971,22 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
             s.d_bw_cap = c;
         }
         const int64_t need_scr = wt_bw_scratch_bytes(bw_secs, bw_stride);
-        if (s.bw_scratch_cap < need_scr) {
-            if (s.d_bw_scratch) p->dead_dev.push_back(s.d_bw_scratch);
-            s.d_bw_scratch = nullptr; s.bw_scratch_cap = 0;
+        if (p->bw_scratch_cap < need_scr) {
+            if (p->d_bw_scratch) p->dead_dev.push_back(p->d_bw_scratch);
+            p->d_bw_scratch = nullptr; p->bw_scratch_cap = 0;
             const int64_t c = need_scr + need_scr / 4;
-            WT_HIP(wt_dev_alloc(&s.d_bw_scratch, (size_t) c));
-            s.bw_scratch_cap = c;
+            WT_HIP(wt_dev_alloc(&p->d_bw_scratch, (size_t) c));
+            p->bw_scratch_cap = c;
         }
-        memcpy(s.h_bw, bw_tracks, sizeof(wtamd_bw_track) * (size_t) N);
+        if (!redo) memcpy(s.h_bw, bw_tracks, sizeof(wtamd_bw_track) * (size_t) N);
         s.h_bw_status[0] = ~0ull; s.h_bw_status[1] = 0;
         WT_HIP(hipEventRecord(s.e_bw0, p->s_dec));
-        rc = wt_bw_decode_async(s.h_bw, s.d_bw, total, s.d_bw + s.bw_off_bytes, s.d_bw + s.bw_off_sec, s.d_bw, N, bw_secs, bw_stride, s.d_bw_scratch,
+        rc = wt_bw_decode_async(s.h_bw, s.d_bw, total, s.d_bw + s.bw_off_bytes, s.d_bw + s.bw_off_sec, s.d_bw, N, bw_secs, bw_stride, p->d_bw_scratch,
                                 (long long) s.dcap, s.d_start, s.d_finish, (float *) s.d_value, compacted ? s.d_mseg : ts->d_seg_off,
                                 s.h_bw_status, p->gather_blocks, p->s_copy, s.e_bwc, p->s_dec);
         if (rc != WTAMD_OK) return rc;
         WT_HIP(hipEventRecord(s.e_bw1, p->s_dec));
-        s.bw_secs = bw_secs;
+        s.bw_secs = bw_secs; s.bw_bytes = bw_bytes; s.bw_stride = bw_stride; s.bw_bound = n;
         s.bw_res_bytes = s.bw_res_secs = -1;
     } else {
     WT_HIP(hipMemcpyAsync(compacted ? s.d_mseg : ts->d_seg_off, s.h_seg, sizeof(int64_t) * ((size_t) N + 1), hipMemcpyHostToDevice, p->s_copy));
@@ -1096,7 +1113,9 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
         if (rc != WTAMD_OK) return rc;
     }
 
-    s.n_int = n; s.f64 = f64; s.err = WTAMD_OK; s.state = 2;
+    s.n_int = n; s.f64 = f64; s.err = WTAMD_OK;
+    if (redo) return WTAMD_OK;
+    s.state = 2;
     p->acquired = -1;
     p->head = (p->head + 1) % (int) p->slots.size();
     p->in_flight++;
@@ -1106,14 +1125,9 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     return WTAMD_OK;
 }
 
-int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
-    WtDevGuard dev_guard_(p ? p->device : -1);
-    if (!p || !out) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
-    if (p->in_flight <= 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_collect: nothing in flight");
-    if (p->held) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_collect: the previous result was not released");
-    WtSlot &s = p->slots[(size_t) p->tail];
-    if (s.state != 2) return wt_fail(WTAMD_ERR_INTERNAL, "wtamd_pipe_collect: slot order corrupted");
-    const auto t_wait0 = std::chrono::steady_clock::now();
+// Waits for the submitted batch of slot s (and, for file-byte batches whose runs travel by copy engine, asks for them
+// once their count is known).
+static int wt_pipe_wait_slot(wtamd_pipe *p, WtSlot &s) {
     int rc = WTAMD_OK;
     if (s.integrated) {
         rc = wt_wait_event(s.e_cnt, "batch kernels");
@@ -1138,6 +1152,25 @@ int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
         }
     }
     if (rc == WTAMD_OK && !s.integrated) rc = wt_wait_event(s.e_d1, "batch");
+    return rc;
+}
+
+int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
+    WtDevGuard dev_guard_(p ? p->device : -1);
+    if (!p || !out) return wt_fail(WTAMD_ERR_ARG, "NULL argument");
+    if (p->in_flight <= 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_collect: nothing in flight");
+    if (p->held) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_collect: the previous result was not released");
+    WtSlot &s = p->slots[(size_t) p->tail];
+    if (s.state != 2) return wt_fail(WTAMD_ERR_INTERNAL, "wtamd_pipe_collect: slot order corrupted");
+    const auto t_wait0 = std::chrono::steady_clock::now();
+    int rc = wt_pipe_wait_slot(p, s);
+    if (rc == WTAMD_OK && s.bw && s.h_bw_status[0] == WT_BW_ERR_CAPACITY && s.dcap < s.bw_bound) {
+        // more intervals than the run lists sized by density hold (the device wrote nothing): once more, at the bound
+        p->bw_density = 2.0;
+        p->bw_redone++;
+        rc = wt_pipe_submit_impl(p, 0, s.ts->range_lo[0], s.ts->range_hi[0], (const wtamd_bw_track *) s.h_bw, s.bw_bytes, s.bw_secs, &s);
+        if (rc == WTAMD_OK) rc = wt_pipe_wait_slot(p, s);
+    }
     s.state = 3;
     p->in_flight--;
     p->held = 1;
@@ -1157,6 +1190,10 @@ int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
             return wt_fail(WTAMD_ERR_INTERNAL, why);
         }
         s.n_int = (int64_t) s.h_bw_status[1];
+        if (s.bw_bound > 0 && p->bw_density < 1.0) {
+            const double d = (double) s.n_int / (double) s.bw_bound;
+            if (d > p->bw_density) p->bw_density = d;
+        }
         p->st.intervals += s.n_int;
         p->st.bw_sections += s.bw_secs;
         float msb = 0;
