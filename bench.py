@@ -386,6 +386,129 @@ def e2e_bigwig(op, n_tracks, mean_run, mbp, device):
             shutil.rmtree(d, ignore_errors=True)
 
 
+def chrom_name(c):
+    return "chr%d" % (c + 1) if c < 22 else ("chrX" if c == 22 else "chrY")
+
+
+def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device):
+    """The north-star measurement: `op` over n_tracks WHOLE-GENOME BigWig files -> result on the host.  Every file holds
+    all 24 chromosomes (GRCh38 lengths x `scale`, names chr1 .. chr22, chrX, chrY; the reader walks them in strcmp
+    order as reference src/bigWiggleReader.c:91-101 does, 10 000-bp stretches :52-83), bedGraph sections of 1024 items,
+    zlib level 1 (SURVEY 8d's stored form), written here untimed by the library's native writer (csrc/wt_bwwrite.cpp)
+    from the same counter-based generator as the resident legs.  Timed: open the files (index walk, priming) ->
+    newMultiplexer -> <op>Reduction -> every run on the host -- `wiggletools <op> *.bw` minus the text writer.  cold = the
+    process's first such run (hardware queues, pinned staging and device buffers obtained afresh), warm = the same again
+    (pools filled), steady = warm run from the first quarter of the genome on."""
+    import shutil
+    import tempfile
+    from wiggletools_amd import bwwrite, dropin, synthgen
+    import torch
+    lens = [max(int(g * scale), 1000) for g in GRCH38]
+    names = [chrom_name(c) for c in range(24)]
+    order = sorted(range(24), key=lambda c: names[c].encode())          # strcmp order = id order inside the files
+    genome_bp = sum(lens)
+    keep = os.environ.get("WTAMD_BENCH_BWDIR")
+    d = keep or tempfile.mkdtemp(prefix="wtamd_bwg_", dir=os.environ.get("WTAMD_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") else None))
+    os.makedirs(d, exist_ok=True)
+    paths = [os.path.join(d, "g%03d.bw" % t) for t in range(n_tracks)]
+    meta = os.path.join(d, "meta_genome_%d_%d.json" % (n_tracks, genome_bp))
+    try:
+        if keep and os.path.exists(meta):
+            m = json.load(open(meta))
+            n_int, write_s, gen_s, sections = m["intervals"], 0.0, 0.0, m["sections"]
+        else:
+            t0 = time.perf_counter()
+            fs = bwwrite.FileSet(paths, {names[c]: lens[c] + 1 for c in range(24)}, items_per_block=1024, level=1, threads=max(1, min(effective_cores(), 32)))
+            n_int, gen_s = 0, 0.0
+            for c in order:
+                g0 = time.perf_counter()
+                seg, s_, f_, v_ = synthgen.device_tracks(SEED, [lens[c]], n_tracks, mean_run, 0.02, 800, device, chrom_ids=[c])
+                hs, hf, hv = s_.cpu().numpy(), f_.cpu().numpy(), v_.cpu().numpy()
+                del s_, f_, v_
+                gen_s += time.perf_counter() - g0
+                fs.add_chrom(names[c], seg, hs, hf, hv)
+                n_int += int(seg[-1])
+                del hs, hf, hv
+            sections = int(sum(fs.close()))
+            write_s = time.perf_counter() - t0
+            torch.cuda.empty_cache()
+            if keep:
+                json.dump({"intervals": n_int, "sections": sections}, open(meta, "w"))
+        size = sum(os.path.getsize(p_) for p_ in paths)
+        os.environ.pop("WTAMD_BW_DEVICE", None)
+        starts = {}
+        acc = 0
+        for c in order:
+            starts[names[c].encode()] = acc
+            acc += lens[c]
+
+        def pool():
+            import ctypes as C
+            from wiggletools_amd import _lib
+            a = (C.c_int64 * 6)()
+            _lib.lib().wtamd_pool_stats(a)
+            return list(a)
+
+        def run_once():
+            p0 = pool()
+            t0 = time.perf_counter()
+            readers = dropin.bigwig_readers(paths, box=True)
+            t_readers = time.perf_counter() - t0
+            r = dropin.reducer(op, readers, n_set0=n_tracks // 2)
+            t_open = time.perf_counter() - t0
+            marks = []
+            seen = set()
+
+            def on_block(c, a, b, v):
+                marks.append((time.perf_counter(), starts[c] + int(b[-1])))
+                seen.add(c)
+                return 0
+            runs, _ = dropin.drain_blocks(r, on_block=on_block)
+            dt = time.perf_counter() - t0
+            st = dropin.pipe_stats(r)
+            o = {"seconds": dt, "bp_per_s": genome_bp / dt, "runs": runs, "chromosomes_seen": len(seen), "intervals_per_s": n_int / dt,
+                 "inbound_GBs": size / dt / 1e9, "open_seconds": t_open, "open_readers_seconds": t_readers, "batches": st.get("batches"),
+                 "sections_inflated_on_device": st.get("bw_sections"), "sum_device_decode_ms": st.get("bw_decode_ms"),
+                 "sum_kernel_ms": st.get("kernel_ms"), "sum_d2h_ms": st.get("d2h_ms"), "host_submit_ms": st.get("host_submit_ms"),
+                 "host_wait_ms": st.get("host_wait_ms")}
+            p1 = pool()
+            o["pinned_afresh"] = {"buffers": p1[0] - p0[0], "bytes": p1[1] - p0[1]}
+            o["device_afresh"] = {"buffers": p1[3] - p0[3], "bytes": p1[4] - p0[4]}
+            q = [m_ for m_ in marks if m_[1] >= genome_bp // 4]
+            if len(q) >= 2 and q[-1][0] > q[0][0]:
+                o["steady_bp_per_s"] = (q[-1][1] - q[0][1]) / (q[-1][0] - q[0][0])
+            return o
+
+        cold = run_once()
+        warm = run_once()
+        return {"tracks": n_tracks, "op": op, "chromosomes_per_file": 24, "genome_scale": scale, "bp": genome_bp, "intervals": n_int,
+                "sections": sections, "file_bytes": size, "file_bytes_per_bp": size / genome_bp,
+                "pcie_h2d_roofline_bp_per_s": 63e9 / (size / genome_bp), "files_written_s": write_s, "generate_s": gen_s,
+                "files_dir": d.rsplit("/", 1)[0], "host_cores": effective_cores(),
+                "decoder": "device (one lane per zlib stream)" if (cold.get("sections_inflated_on_device") or 0) > 0 else "host zlib",
+                "timed": "open %d files of 24 chromosomes each (index walk, priming) -> newMultiplexer -> %sReduction -> every run on the host" % (n_tracks, op.capitalize()),
+                "bp_per_s": cold["bp_per_s"], "warm_bp_per_s": warm["bp_per_s"],
+                "steady_bp_per_s": warm.get("steady_bp_per_s") or cold.get("steady_bp_per_s"), "cold": cold, "warm": warm}
+    finally:
+        if not keep:
+            shutil.rmtree(d, ignore_errors=True)
+
+
+def genome_file_scale(n_tracks, mean_run):
+    """Largest genome scale (<= 1/3: the writing of the files is untimed but not free -- 6e9 intervals take a minute of
+    zlib on 16 cores) whose file set fits half of what /dev/shm (or WTAMD_BENCH_TMP) has free; >= 1 Gbp when it can."""
+    import shutil
+    base = os.environ.get("WTAMD_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+    try:
+        free = shutil.disk_usage(base).free
+    except Exception:
+        free = 8e9
+    per_bp = 0.293 * n_tracks * 16.0 / mean_run        # file bytes per genomic bp: 29.2 measured at 100 tracks, mean run 16
+    want = float(os.environ.get("WTAMD_BENCH_GENOME_SCALE", 1.0 / 3.0))
+    fit = 0.5 * free / (per_bp * sum(GRCH38))
+    return max(min(want, fit), 0.0)
+
+
 def e2e_sharded(ctx, op, n_tracks, mean_run, mbp):
     """N GPUs, the end-to-end bulk leg per rank: every rank streams its own chromosome (array-backed tracks in pinned
     host memory -> drop-in reducer -> runs on the host) over its own PCIe link; barrier, clock, max over ranks."""
@@ -604,6 +727,9 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
         "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / passes * 1e3,
         "higher_is_better": True, "scaling": "weak" if replicas else "strong", "vs_baseline": None,
+        # what `value` is: index + fused multiplex / reduce kernels over run lists RESIDENT in HBM (SURVEY 8d metric 2's
+        # material, the contract's "inputs already resident"); files -> result on the host is config.north_star_files_to_result
+        "value_kind": "resident kernels (window index + fused multiplex/reduce), inputs and outputs in HBM",
         # the arithmetic type of the path: the reference accumulates in f64; the difference-array kernel does it in
         # exact int64 / 128-bit integers of the scaled float32 mantissas, which IS that f64 result
         "dtype": "f64 (exact int64 accumulation)" if kern == 1 else "f64", "data": "synthetic",
@@ -680,6 +806,8 @@ def main():
     ap.add_argument("--values", default="k8", choices=["k8", "full"], help="k8: the generator's k/8 values; full: full mantissas and one value in a million outside its window's exact range (patched windows)")
     ap.add_argument("--e2e-bw-mbp", type=float, default=248.956422, help="chromosome length of the BigWig-files-to-result leg (0: skip); default chromosome 1")
     ap.add_argument("--e2e-mbp", type=float, default=248.956422, help="chromosome length of the end-to-end (drop-in layer) leg; default chromosome 1")
+    ap.add_argument("--no-genome-files", action="store_true", help="skip the whole-genome BigWig-files-to-result leg (e2e_bigwig_genome)")
+    ap.add_argument("--chr1-files", action="store_true", help="also run round 3's one-chromosome file leg (e2e_bigwig: chromosome 1 x N files)")
     args = ap.parse_args()
 
     import torch
@@ -722,12 +850,30 @@ def main():
                 res["e2e"] = e2e_dropin(ops[-1], N, args.mean_run, args.e2e_mbp * fit, device)
             except Exception as e:      # never lose the bench line to an extra leg
                 res["e2e"] = {"error": repr(e)[:300]}
-            if args.e2e_bw_mbp > 0:
+            if args.e2e_bw_mbp > 0 and args.chr1_files:
                 try:
                     res["e2e_bigwig"] = e2e_bigwig(ops[-1], N, args.mean_run, args.e2e_bw_mbp * fit, device)
                 except Exception as e:
                     res["e2e_bigwig"] = {"error": repr(e)[:300]}
             trim_pools()
+            if not args.no_genome_files:
+                # THE north-star figure (BASELINE.json): `mean` over 100 whole-genome BigWig files -> result, >= 1e9 bp/s
+                try:
+                    gscale = genome_file_scale(N, args.mean_run) * (args.scale if args.scale < 1 else 1.0)
+                    g = e2e_bigwig_genome(ops[-1], N, args.mean_run, gscale, device) if gscale > 0.001 else {"error": "no room for the files"}
+                except Exception as e:
+                    g = {"error": repr(e)[:300]}
+                res["e2e_bigwig_genome"] = g
+                trim_pools()
+                # folded into `config` as well: the part of the line the driver keeps
+                res["config"]["north_star_files_to_result"] = {
+                    "what": "%s over %d BigWig files of 24 chromosomes each (GRCh38 x %.3g = %.3f Gbp), file open -> last run on the host"
+                            % (ops[-1], N, g.get("genome_scale", 0), g.get("bp", 0) / 1e9),
+                    "bp_per_s_cold": g.get("bp_per_s"), "bp_per_s_warm": g.get("warm_bp_per_s"), "bp_per_s_steady": g.get("steady_bp_per_s"),
+                    "target_bp_per_s": 1e9, "error": g.get("error")}
+                res["value_e2e_bigwig_genome"] = g.get("bp_per_s")
+                res["value_e2e_bigwig_genome_warm"] = g.get("warm_bp_per_s")
+                res["value_e2e_bigwig_genome_steady"] = g.get("steady_bp_per_s")
             # SURVEY 8d metric (1), first pop -> last result on the host, next to the resident-kernel `value`
             res["value_e2e_bulk"] = (res["e2e"].get("bulk") or {}).get("bp_per_s")
             res["value_e2e_bigwig"] = res.get("e2e_bigwig", {}).get("bp_per_s")

@@ -528,6 +528,12 @@ int wtamd_pipe_submit_bw(wtamd_pipe *, int64_t n_bytes, int64_t n_sections, cons
  * once x 64 lanes): a batch of about that many sections fills the GPU exactly once -- fewer leave SIMDs idle, a
  * few more cost a whole second round. */
 int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *);
+/* Why the last wtamd_pipe_collect of a file-byte batch failed: the device decoder's error bits (1 corrupt zlib stream or
+ * Adler-32 mismatch, 2 malformed section, 4 items outside their index leaf's extents / out of order, 8 coordinate above
+ * the maximum, 16 more intervals than the bound); 0: it did not fail there.  The drop-in layer answers 1 / 2 / 4 by going
+ * back to the host decoder from that batch on -- libBigWig, which the reference reads through, checks none of these
+ * extents (src/bigWiggleReader.c:52-83). */
+unsigned wtamd_pipe_bw_error(const wtamd_pipe *);
 
 /* Pinned (page-locked, DMA-able) host memory for bulk sources. */
 void *wtamd_host_alloc(size_t bytes);
@@ -620,6 +626,18 @@ int64_t wtamd_bw_read_chrom(wtamd_bw *, const char *chrom, int box, int64_t capa
  * nothing written, *cursor unchanged, the decoded part is kept for the repeated call. */
 int64_t wtamd_bw_read_part(wtamd_bw *, const char *chrom, int box, int64_t *cursor, int max_blocks, int32_t lo0, int32_t hi0,
                            int64_t capacity, int32_t *start, int32_t *finish, float *value, int *last);
+
+/* ---- BigWig WRITER (bench / test plumbing next to the synthetic generator; csrc/wt_bwwrite.cpp): bedGraph sections of
+ * `items_per_block` records, one zlib stream each, an R-tree index of as many levels as needed.  Chromosome names in
+ * strcmp order (= their ids).  Intervals use the engine's convention: 1-based start, exclusive finish. */
+typedef struct wtamd_bw_writer wtamd_bw_writer;
+int wtamd_bw_writer_open(const char *path, int n_chrom, const char *const *names, const uint32_t *lengths, int items_per_block,
+                         int zlib_level, wtamd_bw_writer **out);
+int wtamd_bw_writer_add(wtamd_bw_writer *, int chrom, int64_t n, const int32_t *start, const int32_t *finish, const float *value);
+int64_t wtamd_bw_writer_close(wtamd_bw_writer *);      /* index + header; returns the number of sections or < 0 */
+/* one chromosome of many files: track i = [seg_off[i], seg_off[i + 1]) of the arrays, dealt to `threads` workers */
+int wtamd_bw_writers_add_chrom(wtamd_bw_writer *const *writers, int n_tracks, int chrom, const int64_t *seg_off, const int32_t *start,
+                               const int32_t *finish, const float *value, int threads);
 
 /* ---- Synthetic workload generator of SURVEY 8d, on device (bench / test plumbing; csrc/wt_synth.hip).
  * Counter-based: position x of (chromosome c, track t) is a breakpoint iff a hash of (seed, c, t, x)

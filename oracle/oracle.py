@@ -44,10 +44,10 @@ def _newer(out, deps):
 
 def build(force=False):
     """(Re)build the checker libraries with oracle/Makefile."""
-    mk = os.path.join(_HERE, "Makefile")
     hdr = os.path.join(_HERE, "..", "include", "wiggletools_amd.h")
-    need = force or not (_newer(os.path.join(_HERE, "libwt_oracle.so"), [os.path.join(_HERE, "wt_oracle.c"), mk])
-                         and _newer(os.path.join(_HERE, "libref_harness.so"), [os.path.join(_HERE, "ref_harness.c"), hdr, mk]))
+    # (the same dependencies as the Makefile's rules: a file make would not rebuild must not count as stale here)
+    need = force or not (_newer(os.path.join(_HERE, "libwt_oracle.so"), [os.path.join(_HERE, "wt_oracle.c")])
+                         and _newer(os.path.join(_HERE, "libref_harness.so"), [os.path.join(_HERE, "ref_harness.c"), hdr]))
     ref_missing = not os.path.exists(os.path.join(_HERE, "_ref", "libwiggletools_ref.so"))
     if need or (ref_missing and os.path.isdir("/root/reference/src")):
         _locked_make("all")

@@ -146,7 +146,15 @@ typedef struct {
     /* held: no data until the first seek -- what the reference's readers do under the CLI's `seek`
      * (holdFire, commandParser.c:615-624, bufferedReader.c:164-166) */
     int hold;
+    /* child mode 3: the iterator hands out ONE name buffer and rewrites it per chromosome (allowed: readers only promise a
+     * stable char* while they stay on a chromosome; the reference's multiplexer compares by strcmp, multiplexer.c:56) */
+    char namebuf[64];
 } arr_iter;
+
+static int g_hold;     /* children made from now on are held until their first seek */
+static int g_child_mode;   /* 1: children are the tested library's own bulk-capable wtamd_ArrayReader; 2: even tracks only;
+                            * 3: plain children that reuse one name buffer across chromosomes */
+static int g_block_mode;   /* 1: reducer output is taken through wtamd_iterator_next_block */
 
 static void arr_pop(WiggleIterator *wi) {
     arr_iter *a = (arr_iter *) wi->data;
@@ -165,7 +173,8 @@ static void arr_pop(WiggleIterator *wi) {
             if (s < a->win_start) s = a->win_start;
             if (f > a->win_finish) f = a->win_finish;
         }
-        wi->chrom = a->names[a->c];
+        if (g_child_mode == 3) { strncpy(a->namebuf, a->names[a->c], sizeof a->namebuf - 1); wi->chrom = a->namebuf; }
+        else wi->chrom = a->names[a->c];
         wi->start = s; wi->finish = f;
         wi->value = t->value[a->j];
         a->j++;
@@ -182,10 +191,6 @@ static void arr_seek(WiggleIterator *wi, const char *chrom, int start, int finis
     wi->done = 0;
     arr_pop(wi);
 }
-
-static int g_hold;     /* children made from now on are held until their first seek */
-static int g_child_mode;   /* 1: children are the tested library's own bulk-capable wtamd_ArrayReader; 2: even tracks only */
-static int g_block_mode;   /* 1: reducer output is taken through wtamd_iterator_next_block */
 
 void ref_set_modes(int child_mode, int block_mode) { g_child_mode = child_mode; g_block_mode = block_mode; }
 

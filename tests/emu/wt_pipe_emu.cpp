@@ -50,6 +50,7 @@ struct Slot {
     int64_t bw_res_bytes = -1, bw_res_secs = -1;
     bool integrated = false;
     double integ[6] = {0, 0, 0, 0, 0, 0};
+    unsigned bw_err = 0;        // the "device" decoder's error bits: reported when the batch is collected
 };
 }  // namespace
 
@@ -63,6 +64,7 @@ struct wtamd_pipe {
     int in_flight = 0;  // submitted, not collected
     int held = 0;       // collected, not released
     bool compress = false, integrate = false;
+    unsigned last_bw_err = 0;
     std::vector<wtamd_map_chain> chains;    // wtamd_pipe_set_map (empty: off)
     wtamd_pipe_stats st{};
 };
@@ -392,7 +394,16 @@ unsigned wtemu_bw_decode(const uint8_t *bytes, const wtamd_bw_section *secs, lon
         uint32_t stride = ((tk.plain_bytes + 16) + 15u) & ~15u;
         if (stride < 64) stride = 64;
         plain[(size_t) i].assign(stride + 8, 0);
-        if (tk.compressed) plen[(size_t) i] = wtemu_inflate(bytes + secs[i].comp_off, secs[i].comp_size, plain[(size_t) i].data(), stride, 0);
+        if (tk.compressed) {
+            plen[(size_t) i] = wtemu_inflate(bytes + secs[i].comp_off, secs[i].comp_size, plain[(size_t) i].data(), stride, 0);
+            if (plen[(size_t) i] >= 0 && secs[i].comp_size >= 6) {      // Adler-32 against the trailer (the count kernel's check)
+                uint32_t a = 1, b = 0;
+                for (long long q = 0; q < plen[(size_t) i]; q++) { a = (a + plain[(size_t) i][(size_t) q]) % 65521u; b = (b + a) % 65521u; }
+                const uint8_t *t = bytes + secs[i].comp_off + secs[i].comp_size - 4;
+                const uint32_t want = ((uint32_t) t[0] << 24) | ((uint32_t) t[1] << 16) | ((uint32_t) t[2] << 8) | (uint32_t) t[3];
+                if (((b << 16) | a) != want) plen[(size_t) i] = -WT_INF_ERR_INPUT;
+            }
+        }
         else if (secs[i].comp_size > stride) plen[(size_t) i] = -WT_INF_ERR_SPACE;
         else { memcpy(plain[(size_t) i].data(), bytes + secs[i].comp_off, secs[i].comp_size); plen[(size_t) i] = secs[i].comp_size; }
     }
@@ -434,6 +445,8 @@ unsigned wtemu_bw_decode(const uint8_t *bytes, const wtamd_bw_section *secs, lon
 
 int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *p) { return p ? 4096 : 0; }
 
+unsigned wtamd_pipe_bw_error(const wtamd_pipe *p) { return p ? p->last_bw_err : 0u; }
+
 int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, uint8_t **bytes, wtamd_bw_section **sections) {
     if (!p || p->acquired < 0 || n_bytes < 0 || n_sections < 0 || !bytes || !sections) { g_err = "wtamd_pipe_bw_reserve: bad arguments"; return WTAMD_ERR_ARG; }
     Slot &s = p->slots[(size_t) p->acquired];
@@ -473,9 +486,10 @@ int wtamd_pipe_submit_bw(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, con
     const unsigned e = wtemu_bw_decode(s.bw_bytes.data(), s.bw_secs.data(), n_sections, tracks, N, cap, s.start.data(), s.finish.data(),
                                        s.v32.data(), s.seg_off.data());
     s.bw_res_bytes = s.bw_res_secs = -1;
-    if (e) { g_err = "BigWig sections could not be decoded (bits " + std::to_string(e) + ")"; return WTAMD_ERR_INTERNAL; }
     p->st.bw_sections += n_sections;
-    return wtamd_pipe_submit(p, 0, range_lo, range_hi);
+    const int rc = wtamd_pipe_submit(p, 0, range_lo, range_hi);     // (a failed decode left seg_off[] all zero: an empty batch)
+    if (rc == WTAMD_OK) s.bw_err = e;
+    return rc;
 }
 
 int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
@@ -487,6 +501,12 @@ int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
     s.state = 3;
     p->in_flight--;
     p->held = 1;
+    p->last_bw_err = s.bw_err;
+    if (s.bw_err) {
+        g_err = "BigWig sections could not be decoded (bits " + std::to_string(s.bw_err) + ")";
+        s.bw_err = 0;
+        return WTAMD_ERR_INTERNAL;
+    }
     const bool tile = p->cfg.desc.op == WTAMD_OP_MULTIPLEX;
     p->st.d2h_bytes += s.integrated ? 176 : s.n_runs * (16 + (tile ? 9 * (int64_t) p->cfg.n_tracks : 0));
     out->n_runs = s.n_runs;

@@ -112,3 +112,44 @@ def test_overlapping_index_leaves(tmp_path):
     lo, hi = recs[120][0], recs[130][1]
     qs, _, _ = bw.intervals("chr1", lo, hi)
     assert list(qs) == [r[0] for r in recs[120:131]]
+
+
+def test_native_fileset_writer_three_ways(tmp_path):
+    """csrc/wt_bwwrite.cpp through wiggletools_amd.bwwrite.FileSet -- the writer of bench.py's whole-genome inputs: several
+    files, several chromosomes (one of them without data), chromosome-wise calls with the tracks dealt to threads, and
+    MORE THAN 65 536 SECTIONS in one file (a three-level R-tree; bwwrite.write_arrays stopped at two).  Read back by the
+    library's host decoder and by the independent reader: the input, value bits included."""
+    rng = np.random.default_rng(12)
+    chroms = {"chr1": 4_000_000, "chr10": 900_000, "chr2": 50, "chrX": 2_000_000}
+    n_tracks = 3
+    paths = [str(tmp_path / ("fs%d.bw" % t)) for t in range(n_tracks)]
+    fs = bwwrite.FileSet(paths, chroms, items_per_block=5, level=1, threads=3)
+    truth = {}
+    for name in sorted(chroms, key=lambda x: x.encode()):
+        if name == "chr2":
+            continue                            # a chromosome of the tree that holds no data
+        seg, S, F, V = [0], [], [], []
+        for t in range(n_tracks):
+            n = 340_000 if (name == "chr1" and t == 0) else int(rng.integers(2000, 6000))
+            ln = rng.integers(1, 9, n)
+            gap = (rng.random(n) < 0.1) * rng.integers(1, 30, n)
+            f = np.cumsum(ln + gap) + 1
+            s = f - ln
+            keep = f < chroms[name]
+            s, f = s[keep].astype(np.int32), f[keep].astype(np.int32)
+            v = (rng.integers(-80, 80, int(keep.sum())) / 8).astype(np.float32)
+            S.append(s); F.append(f); V.append(v)
+            seg.append(seg[-1] + len(s))
+            truth[(t, name)] = (s.astype(np.int64) - 1, f.astype(np.int64) - 1, v)
+        fs.add_chrom(name, seg, np.concatenate(S), np.concatenate(F), np.concatenate(V))
+    sections = fs.close()
+    assert sections[0] > 65536
+    for t, path in enumerate(paths):
+        ind = IndependentBigWig(path)
+        assert set(ind.chroms) == set(chroms)
+        for name in chroms:
+            if name == "chr2":
+                assert len(ind.intervals(name)[0]) == 0
+                continue
+            _same(ind.intervals(name), truth[(t, name)])
+            _same(_lib_unboxed(path, name), truth[(t, name)])

@@ -270,3 +270,143 @@ def test_device_decode_larger_files_gpu(amd_lib, oracle, tmp_path, monkeypatch):
         assert (st.bw_sections > 0) == (dev == "1")
     assert len(res["1"]) > 1_000_000
     assert res["1"] == res["0"]
+
+
+def _genome_fileset(tmp_path, n_tracks, chroms, seed, items=64):
+    """Multi-chromosome files from the native writer (wiggletools_amd.bwwrite.FileSet), dense tracks of mean run 16 bp;
+    every third file lacks the second chromosome."""
+    from wiggletools_amd import bwwrite
+    rng = np.random.default_rng(seed)
+    paths = [str(tmp_path / ("g%d.bw" % t)) for t in range(n_tracks)]
+    fs = bwwrite.FileSet(paths, chroms, items_per_block=items, level=1, threads=4)
+    names = sorted(chroms, key=lambda x: x.encode())
+    for ci, name in enumerate(names):
+        seg, S, F, V = [0], [], [], []
+        for t in range(n_tracks):
+            L = chroms[name]
+            if ci == 1 and t % 3 == 2:
+                seg.append(seg[-1])
+                continue
+            n = L // 12
+            ln = rng.geometric(1 / 16.0, n).astype(np.int64)
+            gap = (rng.random(n) < 0.02) * rng.integers(1, 200, n)
+            f = np.cumsum(ln + gap) + 1 + int(rng.integers(0, 50))
+            s = f - ln
+            keep = f < L
+            S.append(s[keep].astype(np.int32)); F.append(f[keep].astype(np.int32))
+            V.append((rng.integers(0, 800, n)[keep] / 8).astype(np.float32))
+            seg.append(seg[-1] + int(keep.sum()))
+        fs.add_chrom(name, seg, np.concatenate(S), np.concatenate(F), np.concatenate(V))
+    fs.close()
+    return paths
+
+
+def _multichrom(L, oracle, tmp_path, monkeypatch, n_tracks, scale, batch_sections, min_span=None):
+    """Files that each hold SEVERAL chromosomes (the walk of reference src/bigWiggleReader.c:91-101 in strcmp order,
+    stretches :52-83) through the device decoder, batches of a few hundred sections so that every chromosome takes several
+    and every chromosome transition is a batch seam: == the host decoder == the oracle, run for run."""
+    chroms = {"chr1": 60 * scale, "chr10": 25 * scale + 1, "chr2": 41 * scale, "chrM": 900, "chrX": 33 * scale}
+    paths = _genome_fileset(tmp_path, n_tracks, chroms, seed=41)
+    monkeypatch.setenv("WTAMD_BW_BATCH_SECTIONS", str(batch_sections))
+    if min_span:
+        monkeypatch.setenv("WTAMD_MIN_SPAN", str(min_span))        # (also the first span: 65 536 bp otherwise)
+    res = {}
+    for dev in ("1", "0"):
+        monkeypatch.setenv("WTAMD_BW_DEVICE", dev)
+        wi, keep = _reduce(L, paths, "MeanReduction")
+        res[dev] = _blocks(L, wi)
+        st = _stats(L, wi)
+        assert (st.bw_sections > 0) == (dev == "1")
+        if dev == "1":
+            assert st.batches >= 3 * len(chroms) - 4, st.batches       # several batches per (large) chromosome
+    monkeypatch.delenv("WTAMD_BW_DEVICE")
+    assert [r[0] for r in res["1"][:1]] == ["chr1"] and {r[0] for r in res["1"]} == set(chroms)
+    assert res["1"] == res["0"]
+    _same(res["1"], _expected(oracle, paths, "mean"))
+
+
+def test_device_decode_multichrom_emu(emu_lib, oracle, tmp_path, monkeypatch):
+    _multichrom(emu_lib, oracle, tmp_path, monkeypatch, n_tracks=5, scale=1000, batch_sections=40, min_span=1000)
+
+
+@pytest.mark.gpu
+def test_device_decode_multichrom_gpu(amd_lib, oracle, tmp_path, monkeypatch):
+    _multichrom(amd_lib, oracle, tmp_path, monkeypatch, n_tracks=12, scale=20000, batch_sections=3000)
+
+
+def _shrink_leaf(path, leaf_no, by):
+    """Rewrites index leaf `leaf_no` of a (single-leaf-node or two-level) R-tree so that it claims to end `by` bases
+    early: its last items then lie beyond the extents the index states -- something libBigWig, hence the reference
+    (src/bigWiggleReader.c:52-83), never checks."""
+    import struct
+    raw = bytearray(open(path, "rb").read())
+    idx = struct.unpack_from("<Q", raw, 24)[0]
+    node = idx + 48
+    is_leaf, _, cnt = struct.unpack_from("<BBH", raw, node)
+    if not is_leaf:
+        node = struct.unpack_from("<Q", raw, node + 4 + 16)[0]       # first child
+        is_leaf, _, cnt = struct.unpack_from("<BBH", raw, node)
+    assert is_leaf and leaf_no < cnt
+    item = node + 4 + 32 * leaf_no
+    end = struct.unpack_from("<I", raw, item + 12)[0]
+    struct.pack_into("<I", raw, item + 12, end - by)
+    open(path, "wb").write(bytes(raw))
+
+
+def _fallback_case(L, oracle, tmp_path, monkeypatch, capfd):
+    """A file whose items reach beyond their index leaf's stated extents works with the reference; the device decoder
+    rejects the batch (error bit 4) and the drop-in layer goes on with the HOST decoder from that batch on -- mid-stream,
+    after batches that were decoded on the device -- instead of exiting (the round-3 advisor's finding).  The result is
+    the oracle's, run for run; WTAMD_BW_NO_FALLBACK=1 restores the loud failure."""
+    paths = _write_set(tmp_path, 4, seed=19, block=41)
+    victim = paths[1]
+    _shrink_leaf(victim, 30, 3)
+    monkeypatch.setenv("WTAMD_BW_BATCH_SECTIONS", "60")
+    monkeypatch.setenv("WTAMD_MIN_SPAN", "1500")
+    for op, name in (("MeanReduction", "mean"), ("MaxReduction", "max")):
+        wi, keep = _reduce(L, paths, op)
+        got = _blocks(L, wi)
+        st = _stats(L, wi)
+        _same(got, _expected(oracle, paths, name))
+        assert "continuing with the host decoder" in capfd.readouterr().err
+    # seek into the damaged region: same switch, the window's clipping kept
+    wi, keep = _reduce(L, paths, "SumReduction")
+    L.seek(wi, b"chr1", 100, 50000)
+    got = _pops(L, wi)
+    monkeypatch.setenv("WTAMD_BW_DEVICE", "0")
+    wi, keep = _reduce(L, paths, "SumReduction")
+    L.seek(wi, b"chr1", 100, 50000)
+    assert got == _pops(L, wi) and len(got) > 100
+    monkeypatch.delenv("WTAMD_BW_DEVICE")
+
+
+def test_device_decode_error_falls_back_to_host_emu(emu_lib, oracle, tmp_path, monkeypatch, capfd):
+    _fallback_case(emu_lib, oracle, tmp_path, monkeypatch, capfd)
+
+
+@pytest.mark.gpu
+def test_device_decode_error_falls_back_to_host_gpu(amd_lib, oracle, tmp_path, monkeypatch, capfd):
+    _fallback_case(amd_lib, oracle, tmp_path, monkeypatch, capfd)
+
+
+def test_adler32_mismatch_is_an_inflate_error_emu(emu_lib, tmp_path):
+    """A payload that still inflates but fails the zlib stream's Adler-32 trailer is rejected by the device route (the
+    count kernel's check) and then by the host decoder's zlib, as libBigWig's uncompress() would: exit(1), no result."""
+    import subprocess, sys, struct
+    recs = [(20 * k, 20 * k + 7, 1.0) for k in range(3000)]
+    p = str(tmp_path / "adler.bw")
+    write_bigwig(p, {"chr1": 80000}, {"chr1": recs}, items_per_block=256)
+    raw = bytearray(open(p, "rb").read())
+    idx = struct.unpack_from("<Q", raw, 24)[0]
+    off, size = struct.unpack_from("<QQ", raw, idx + 48 + 4 + 32 * 3 + 16)     # fourth section: offset, size
+    raw[off + size - 1] ^= 0x01                                               # last byte of its Adler-32
+    open(p, "wb").write(bytes(raw))
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from emu.build import build_dropin; L = C.CDLL(build_dropin());"
+            "L.wtamd_BigWiggleReader.restype = C.c_void_p; L.wtamd_BigWiggleReader.argtypes = [C.c_char_p, C.c_int];"
+            "L.newMultiplexer.restype = C.c_void_p; L.newMultiplexer.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_char];"
+            "L.MeanReduction.restype = C.c_void_p; L.MeanReduction.argtypes = [C.c_void_p]; L.wtamd_drain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p];"
+            "its = (C.c_void_p * 1)(L.wtamd_BigWiggleReader(%r, 1)); m = L.newMultiplexer(its, 1, b'\\0'); r = L.MeanReduction(m);"
+            "a = C.c_int64(); b = C.c_double(); L.wtamd_drain(r, C.byref(a), C.byref(b)); print('survived')"
+            % (os.path.dirname(os.path.abspath(__file__)), p.encode()))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 1 and "survived" not in r.stdout, (r.returncode, r.stdout, r.stderr[-500:])

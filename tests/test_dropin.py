@@ -422,3 +422,37 @@ def test_dropin_seek_with_mapped_children_vs_reference(oracle, H, mop, param):
                     assert_runs_equal(got, ref, 0.0 if mop != "ln" else 1e-12, "seek %s map %s %s strict %d" % ((c, s, f), mop, op, strict))
     finally:
         R.set_map(None); H.set_map(None)
+
+
+@pytest.mark.parametrize("tiny", [False, True])
+def test_dropin_children_reusing_one_name_buffer(oracle, H, tiny, monkeypatch):
+    """Foreign children that rewrite ONE chromosome-name buffer (same pointer, new content) and are SPARSE: the next
+    chromosome's first start lies beyond the previous chromosome's last finish, so no coordinate goes backwards at the
+    transition.  The reference compares names by content on every pop (multiplexer.c:56); round 3 re-compared only on
+    a coordinate regression and merged such a track's next chromosome into the previous one (the advisor's finding)."""
+    from wiggletools_amd.runlists import RunLists
+    if tiny:
+        monkeypatch.setenv("WTAMD_MIN_SPAN", "16")
+        monkeypatch.setenv("WTAMD_BATCH_INTERVALS", "24")
+    rng = np.random.default_rng(77)
+    tracks = []
+    for i in range(18):             # (>= 16 foreign children: the parallel drain's workers compare names too)
+        per_c, base = [], 1
+        for c in range(4):
+            rows, pos = [], base + int(rng.integers(0, 40))
+            for _ in range(int(rng.integers(1, 6))):
+                ln = int(rng.integers(1, 30))
+                rows.append((pos, pos + ln, float(rng.integers(1, 9))))
+                pos += ln + int(rng.integers(0, 25))
+            per_c.append(rows)
+            base = pos + 5          # the next chromosome starts beyond everything seen so far
+        tracks.append(per_c)
+    t = RunLists.from_lists(tracks, np.zeros(18))
+    d = t.as_dict()
+    H.set_modes(3, 0)
+    try:
+        for op in ("mean", "max"):
+            for strict in (0, 1):
+                assert_runs_equal(H.reduce(d, op, flags=strict), oracle.reduce(d, op, flags=strict), _tol(op), "name buffer %s" % op)
+    finally:
+        H.set_modes(0, 0)

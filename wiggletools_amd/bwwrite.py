@@ -3,10 +3,62 @@ records, zlib level 1, chromosome B+ tree with one leaf, R-tree of <= 256 x 256 
 that bench.py's file-to-result leg and the tests have real BigWig files to read (there is no network
 for public tracks and the reference's fixtures are 10 bp long); the product reads BigWig, it never
 writes it (the reference does not either: wigWriter.c emits text)."""
+import ctypes as C
 import struct
 import zlib
 
 import numpy as np
+
+
+class FileSet:
+    """N BigWig files written side by side by the library's native writer (csrc/wt_bwwrite.cpp): one chromosome of all
+    tracks per call, the tracks dealt to worker threads -- what bench.py's whole-genome file leg writes its 100 x 24
+    chromosome inputs with.  Chromosomes must be added in strcmp order of their names."""
+
+    def __init__(self, paths, chroms, items_per_block=1024, level=1, threads=16):
+        from . import _lib
+        self.L = _lib.lib()
+        self.L.wtamd_bw_writer_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        self.L.wtamd_bw_writers_add_chrom.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        self.L.wtamd_bw_writer_close.argtypes = [C.c_void_p]
+        self.L.wtamd_bw_writer_close.restype = C.c_int64
+        self.names = sorted(chroms, key=lambda s: s.encode())
+        arr = (C.c_char_p * len(self.names))(*[n.encode() for n in self.names])
+        lens = np.array([int(chroms[n]) for n in self.names], np.uint32)
+        self.threads = threads
+        self.handles = (C.c_void_p * len(paths))()
+        for i, p in enumerate(paths):
+            h = C.c_void_p()
+            if self.L.wtamd_bw_writer_open(str(p).encode(), len(self.names), arr, lens.ctypes.data, items_per_block, level, C.byref(h)) != 0:
+                raise RuntimeError("wtamd_bw_writer_open(%s) failed" % p)
+            self.handles[i] = h
+        self.sections = None
+
+    def add_chrom(self, name, seg_off, start, finish, value):
+        """One chromosome of every file: track i = [seg_off[i], seg_off[i + 1]) of the (host) arrays -- int64 seg_off,
+        int32 1-based start / exclusive finish, float32 value."""
+        seg_off = np.ascontiguousarray(seg_off, np.int64)
+        assert len(seg_off) == len(self.handles) + 1
+        start = np.ascontiguousarray(start, np.int32); finish = np.ascontiguousarray(finish, np.int32)
+        value = np.ascontiguousarray(value, np.float32)
+        rc = self.L.wtamd_bw_writers_add_chrom(self.handles, len(self.handles), self.names.index(name), seg_off.ctypes.data,
+                                               start.ctypes.data, finish.ctypes.data, value.ctypes.data, self.threads)
+        if rc != 0:
+            raise RuntimeError("wtamd_bw_writers_add_chrom(%s) failed: %d" % (name, rc))
+
+    def add_chrom_ptr(self, name, seg_off, start_ptr, finish_ptr, value_ptr):
+        """The same over raw host pointers (pinned staging of the generator's output)."""
+        seg_off = np.ascontiguousarray(seg_off, np.int64)
+        rc = self.L.wtamd_bw_writers_add_chrom(self.handles, len(self.handles), self.names.index(name), seg_off.ctypes.data,
+                                               start_ptr, finish_ptr, value_ptr, self.threads)
+        if rc != 0:
+            raise RuntimeError("wtamd_bw_writers_add_chrom(%s) failed: %d" % (name, rc))
+
+    def close(self):
+        self.sections = [int(self.L.wtamd_bw_writer_close(h)) for h in self.handles]
+        if min(self.sections) < 0:
+            raise RuntimeError("wtamd_bw_writer_close failed")
+        return self.sections
 
 _REC = np.dtype([("s", "<u4"), ("e", "<u4"), ("v", "<f4")])
 

@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libwiggletools_amd.so")
-SRCS = ["wt_engine.hip", "wt_compress.hip", "wt_map.hip", "wt_synth.hip", "wt_bwdev.hip", "wt_defaults.cpp", "wt_iter_abi.cpp", "wt_bigwig.cpp"]
+SRCS = ["wt_engine.hip", "wt_compress.hip", "wt_map.hip", "wt_synth.hip", "wt_bwdev.hip", "wt_defaults.cpp", "wt_iter_abi.cpp", "wt_bigwig.cpp", "wt_bwwrite.cpp"]
 LIBS = ["-lz"]
 DEPS = ["wt_core.h", "wt_delta.h", "wt_plan.h", "wt_devscope.h", "wt_pipe.h", "wt_mapop.h", "wt_inflate.h", "wt_bwdev_core.h", os.path.join("..", "..", "include", "wiggletools_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -36,6 +36,20 @@ def build_engine_variant(name, extra_flags):
     return out
 
 
+def build_source_variant(src, name, extra_flags):
+    """Experiment helper: recompiles ONE source with extra flags and links it with the objects of the last build() into
+    libwiggletools_amd_<name>.so (e.g. build_source_variant("wt_bwdev.hip", "round8", ["-DWT_INF_ROUND=8"]))."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, ".obj")
+    cflags = [f for f in FLAGS if f != "-shared"]
+    obj = os.path.join(objdir, "%s_%s.o" % (src, name))
+    subprocess.check_call([hipcc] + cflags + list(extra_flags) + ["-c", os.path.join(HERE, src), "-o", obj])
+    others = [os.path.join(objdir, s + ".o") for s in SRCS if s != src]
+    out = os.path.join(HERE, "libwiggletools_amd_%s.so" % name)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", obj] + others + LIBS + ["-o", out])
+    return out
+
+
 def build(force=False, verbose=False):
     """Every source to its own object (in parallel: wt_engine.hip alone takes minutes), then one link."""
     srcs = [os.path.join(HERE, s) for s in SRCS if os.path.exists(os.path.join(HERE, s))]
@@ -52,9 +66,26 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     cflags = [f for f in FLAGS if f != "-shared"]
 
+    def up_to_date(obj):
+        """The object is newer than its source and every header the compiler saw last time (-MMD dependency file)."""
+        dep = obj + ".d"
+        if force or not (os.path.exists(obj) and os.path.exists(dep)):
+            return False
+        try:
+            words = open(dep).read().replace("\\\n", " ").split()
+        except OSError:
+            return False
+        t = os.path.getmtime(obj)
+        files = [w for w in words[1:] if not w.endswith(":")]
+        return bool(files) and all(os.path.exists(f) and os.path.getmtime(f) <= t for f in files)
+
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        cmd = [hipcc] + cflags + ["-c", src, "-o", obj]
+        if up_to_date(obj):
+            if verbose:
+                print("wiggletools_amd: %s unchanged: object REUSED" % os.path.basename(src))
+            return obj
+        cmd = [hipcc] + cflags + ["-MMD", "-MF", obj + ".d", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

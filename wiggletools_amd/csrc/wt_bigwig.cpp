@@ -26,6 +26,7 @@
 #include <cstring>
 #include <ctime>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/wiggletools_amd.h"
@@ -54,7 +55,8 @@ struct wtamd_bw {
     int64_t part_from = -1, part_to = -1;
     int part_chrom = -1, part_blocks = 0, part_lo = 0, part_hi = 0;
     bool part_last = false;
-    std::vector<WtBwChromInfo> infos;           // wt_bw_chrom_info, one per chroms[] entry, computed on first use
+    std::vector<WtBwChromInfo> infos;           // wt_bw_chrom_info, one per chroms[] entry (bw_build_infos, at open)
+    std::unordered_map<std::string, size_t> by_name;
     // wtamd_bw_open only: a window of the file, so that the walk over the header, the chromosome tree and the R-tree
     // index costs a handful of pread() calls instead of two stdio seeks + reads per node (~500 system calls per file
     // of chromosome 1: 1.6 ms per file and NOT parallel on the hosts measured -- 100 files took 120-190 ms however
@@ -192,31 +194,51 @@ int wt_bw_fd(const wtamd_bw *bw) { return fileno(bw->fp); }
 
 uint32_t wt_bw_uncompress_buf(const wtamd_bw *bw) { return bw->uncompress_buf; }
 
-bool wt_bw_chrom_info(wtamd_bw *bw, const char *chrom, WtBwChromInfo *out) {
-    if (bw->infos.empty() && !bw->chroms.empty()) {
-        bw->infos.resize(bw->chroms.size());
-        for (size_t c = 0; c < bw->chroms.size(); c++) {
+// Per chromosome: its index leaves (a contiguous range of the R-tree's leaves in file order) and whether the device
+// route can take them.  ONE pass over the leaves (round 3 scanned all of them once per chromosome: O(chromosomes x
+// leaves), seconds per file for an assembly with thousands of contigs -- the advisor's finding); run by wtamd_bw_open,
+// i.e. on the threads that open the files side by side.
+static void bw_build_infos(wtamd_bw *bw) {
+    const size_t nc = bw->chroms.size();
+    bw->infos.resize(nc);
+    bw->by_name.clear();
+    std::vector<size_t> by_id(nc);
+    std::vector<int64_t> last(nc, -1);
+    for (size_t c = 0; c < nc; c++) {
+        WtBwChromInfo &x = bw->infos[c];
+        x.id = bw->chroms[c].id; x.length = bw->chroms[c].length;
+        x.first = 0; x.count = 0; x.device_ok = true; x.max_size = 0;
+        by_id[c] = c;
+        bw->by_name.emplace(bw->chroms[c].name, c);
+    }
+    std::sort(by_id.begin(), by_id.end(), [&](size_t a, size_t b) { return bw->chroms[a].id < bw->chroms[b].id; });
+    for (int64_t i = 0; i < (int64_t) bw->blocks.size(); i++) {
+        const BwBlock &b = bw->blocks[(size_t) i];
+        // the chromosomes this leaf touches: ids in [start_chrom, end_chrom] (one, in every file the usual tools write)
+        size_t q = (size_t) (std::lower_bound(by_id.begin(), by_id.end(), b.start_chrom,
+                                              [&](size_t a, uint32_t id) { return bw->chroms[a].id < id; }) - by_id.begin());
+        for (; q < nc && bw->chroms[by_id[q]].id <= b.end_chrom; q++) {
+            const size_t c = by_id[q];
             WtBwChromInfo &x = bw->infos[c];
-            x.id = bw->chroms[c].id; x.length = bw->chroms[c].length;
-            x.first = 0; x.count = 0; x.device_ok = true; x.max_size = 0;
-            int64_t last = -1;
-            for (int64_t i = 0; i < (int64_t) bw->blocks.size(); i++) {
-                const BwBlock &b = bw->blocks[(size_t) i];
-                if (b.start_chrom > x.id || b.end_chrom < x.id) continue;          // does not touch this chromosome
-                if (b.start_chrom != x.id || b.end_chrom != x.id) x.device_ok = false;     // a leaf spanning chromosomes
-                if (x.count == 0) x.first = i;
-                else if (i != last + 1 || b.start_base < bw->blocks[(size_t) last].end_base) x.device_ok = false;   // not contiguous / sorted / disjoint
-                if (b.end_base < b.start_base || b.size > 0x7FFFFFFFull) x.device_ok = false;
-                if (b.size > x.max_size) x.max_size = (uint32_t) std::min<uint64_t>(b.size, 0xFFFFFFFFull);
-                last = i;
-                x.count++;
-            }
-            if (!x.device_ok) x.count = last >= 0 ? last - x.first + 1 : 0;
+            if (b.start_chrom != x.id || b.end_chrom != x.id) x.device_ok = false;         // a leaf spanning chromosomes
+            if (x.count == 0) x.first = i;
+            else if (i != last[c] + 1 || b.start_base < bw->blocks[(size_t) last[c]].end_base) x.device_ok = false;   // not contiguous / sorted / disjoint
+            if (b.end_base < b.start_base || b.size > 0x7FFFFFFFull) x.device_ok = false;
+            if (b.size > x.max_size) x.max_size = (uint32_t) std::min<uint64_t>(b.size, 0xFFFFFFFFull);
+            last[c] = i;
+            x.count++;
         }
     }
-    for (size_t c = 0; c < bw->chroms.size(); c++)
-        if (bw->chroms[c].name == chrom) { *out = bw->infos[c]; return true; }
-    return false;
+    for (size_t c = 0; c < nc; c++)
+        if (!bw->infos[c].device_ok) bw->infos[c].count = last[c] >= 0 ? last[c] - bw->infos[c].first + 1 : 0;
+}
+
+bool wt_bw_chrom_info(wtamd_bw *bw, const char *chrom, WtBwChromInfo *out) {
+    if (bw->infos.size() != bw->chroms.size()) bw_build_infos(bw);
+    const auto it = bw->by_name.find(chrom);
+    if (it == bw->by_name.end()) return false;
+    *out = bw->infos[it->second];
+    return true;
 }
 
 extern "C" {
@@ -258,6 +280,7 @@ int wtamd_bw_open(const char *path, wtamd_bw **out) {
         return WTAMD_ERR_ARG;
     }
     std::vector<unsigned char>().swap(bw->win);
+    bw_build_infos(bw);
     if (trace) fprintf(stderr, "[bw_open] fopen %.3f ms, header + chromosome tree + index walk (%zu leaves) %.3f ms\n", t1 - t0, bw->blocks.size(), bw_now_ms() - t1);
     *out = bw;
     return WTAMD_OK;

@@ -98,7 +98,7 @@ __device__ __forceinline__ uint32_t wt_wave_scan(uint32_t v, int lane) {
     return v;
 }
 
-__global__ void __launch_bounds__(64) wt_bw_count_kernel(const WtBwSection *secs, const WtBwTrack *tracks, int n_sec,
+__global__ void __launch_bounds__(64) wt_bw_count_kernel(const WtBwSection *secs, const WtBwTrack *tracks, int n_sec, const uint8_t *comp,
                                                           const uint8_t *plain, uint32_t plain_stride, const int32_t *plain_len,
                                                           uint32_t *counts, uint32_t *err) {
     const int i = blockIdx.x, lane = threadIdx.x;
@@ -111,23 +111,48 @@ __global__ void __launch_bounds__(64) wt_bw_count_kernel(const WtBwSection *secs
         bad = WT_BW_ERR_INFLATE;
     } else {
         const uint8_t *p = plain + (size_t) i * plain_stride;
+        if (tk.compressed && sc.comp_size >= 6) {
+            // Adler-32 of what was inflated against the stream's trailer (RFC 1950; libBigWig's uncompress() checks it,
+            // so a damaged payload that still parses must not pass here either): A = 1 + sum d_i, B = sum of the running A.
+            // Every lane takes a slice; B = n + sum over slices of (their own B + bytes behind the slice x their A).
+            const uint32_t n = (uint32_t) len;
+            const uint32_t chunk = (((n + 63u) >> 6) + 3u) & ~3u;
+            const uint32_t lo = (uint32_t) lane * chunk, hi = lo + chunk < n ? lo + chunk : n;
+            uint32_t a = 0, b = 0;
+            for (uint32_t q = lo; q < hi; q += 4) {
+                const uint32_t w = *(const uint32_t *) (p + q);
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (q + k < hi) { a += (w >> (8 * k)) & 255u; b += a; }
+            }
+            unsigned long long A = a, B = (unsigned long long) b + (unsigned long long) (lo < n ? n - hi : 0u) * a;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { A += __shfl_xor(A, o, 64); B += __shfl_xor(B, o, 64); }
+            const uint32_t ad = (uint32_t) (((B + n) % 65521ull) << 16) | (uint32_t) ((A + 1ull) % 65521ull);
+            const uint8_t *t = comp + sc.comp_off + sc.comp_size - 4;
+            const uint32_t want = ((uint32_t) t[0] << 24) | ((uint32_t) t[1] << 16) | ((uint32_t) t[2] << 8) | (uint32_t) t[3];
+            if (ad != want) bad |= WT_BW_ERR_INFLATE;
+        }
         WtBwHdr h;
         if (!wt_bw_parse_hdr(p, (uint32_t) len, h)) {
-            bad = WT_BW_ERR_SECTION;
+            bad |= WT_BW_ERR_SECTION;
         } else if (h.chrom_id == tk.chrom_id) {     // (else: a block of another chromosome sharing the index leaf)
             for (uint32_t k0 = 0; k0 < h.count; k0 += 64) {
                 const uint32_t k = k0 + lane;
                 if (k < h.count) {
-                    uint32_t s0, e0, vb;
+                    uint32_t s0, e0, vb, item_bad = 0;
                     wt_bw_item(p, h, k, s0, e0, vb);
-                    if (s0 < sc.leaf_start || e0 > sc.leaf_end || e0 <= s0) bad |= WT_BW_ERR_EXTENT;
-                    if (e0 >= (uint32_t) WTAMD_MAX_COORD) bad |= WT_BW_ERR_COORD;
+                    if (s0 < sc.leaf_start || e0 > sc.leaf_end || e0 <= s0) item_bad |= WT_BW_ERR_EXTENT;
+                    if (e0 >= (uint32_t) WTAMD_MAX_COORD) item_bad |= WT_BW_ERR_COORD;
                     if (k > 0) {
                         uint32_t ps, pe, pv;
                         wt_bw_item(p, h, k - 1, ps, pe, pv);
-                        if (s0 < pe) bad |= WT_BW_ERR_EXTENT;       // unsorted or overlapping items
+                        if (s0 < pe) item_bad |= WT_BW_ERR_EXTENT;  // unsorted or overlapping items
                     }
-                    total += wt_bw_pieces(s0, e0, tk, [](int32_t, int32_t) {});
+                    // (a malformed item is not boxed: the batch is rejected anyway, and a bogus span would be walked
+                    // stretch by stretch -- up to 430 000 iterations of one lane)
+                    if (!item_bad) total += wt_bw_pieces(s0, e0, tk, [](int32_t, int32_t) {});
+                    bad |= item_bad;
                 }
             }
         }
@@ -308,7 +333,7 @@ int wt_bw_decode_async(const void *h_bytes, void *d_bytes, long long n_bytes, co
             hipLaunchKernelGGL(wt_bw_inflate_kernel<8>, dim3(g), dim3(WT_BW_INF_LANES), 0, s_dec, secs, tracks, (int) n_sec,
                                (const uint8_t *) d_comp, plain, (uint32_t) plain_stride, plain_len);
         WT_BW_HIP(hipGetLastError());
-        hipLaunchKernelGGL(wt_bw_count_kernel, dim3((unsigned) n_sec), dim3(64), 0, s_dec, secs, tracks, (int) n_sec, plain,
+        hipLaunchKernelGGL(wt_bw_count_kernel, dim3((unsigned) n_sec), dim3(64), 0, s_dec, secs, tracks, (int) n_sec, (const uint8_t *) d_comp, plain,
                            (uint32_t) plain_stride, plain_len, counts, err);
         WT_BW_HIP(hipGetLastError());
     }

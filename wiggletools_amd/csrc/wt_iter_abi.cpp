@@ -126,12 +126,13 @@ struct TrackSource {
     const char *interned = nullptr; // ... and its interned name
     int32_t seen_finish = 0;        // finish of the last element it_chrom() looked at
 
-    // A child may reuse ONE name buffer across chromosomes (same pointer, new content): inside a chromosome
-    // the starts never fall below the previous finish, so a coordinate that goes backwards is the cue to
-    // compare the content again (the reference's multiplexer compares by strcmp every time, multiplexer.c:56).
+    // A child may reuse ONE name buffer across chromosomes (same pointer, new content), so a pointer seen before is
+    // compared by CONTENT every time, as the reference's multiplexer does (strcmp per pop, multiplexer.c:56).  (Round 3
+    // compared only when a start fell below the previous finish: a sparse track whose next chromosome starts beyond
+    // the last finish kept the stale name and had its intervals merged into the wrong chromosome -- the advisor's
+    // finding.)
     const char *it_chrom(Interner &in) {
-        if (it->chrom != raw || !interned) { raw = it->chrom; interned = in.get(raw); }
-        else if (it->start < seen_finish && strcmp(raw, interned) != 0) interned = in.get(raw);
+        if (it->chrom != raw || !interned || strcmp(raw, interned) != 0) { raw = it->chrom; interned = in.get(raw); }
         seen_finish = it->finish;
         return interned;
     }
@@ -282,6 +283,7 @@ struct TrackSource;
 BwReader *bwdev_reader(const TrackSource &s);
 bool bwdev_eligible(const Feeder &F);
 bool bwdev_drain_and_submit(Feeder &F);
+void bwdev_fallback(Feeder &F, const char *chrom, int32_t lo, unsigned why);
 
 // Drains the children into pipeline slots and keeps `depth` batches in flight.
 struct Feeder {
@@ -485,8 +487,7 @@ struct Feeder {
         while (!it->done) {
             const char *rc = it->chrom;
             const int32_t st = it->start, fi = it->finish;
-            if (rc == s.raw && s.interned && st >= s.seen_finish) { if (s.interned != chrom) return; }
-            else if (strcmp(rc, chrom) != 0) return;
+            if (strcmp(rc, chrom) != 0) return;             // by content, every pop (multiplexer.c:56): see it_chrom
             s.seen_finish = fi;
             o.push(st, fi, it->value);
             if (st >= hi) { o.more = true; o.sentinel_lo = st; return; }    // sentinel: stays current
@@ -512,7 +513,8 @@ struct Feeder {
         while (!flights.empty()) {
             wtamd_pipe_result r;
             wtamd_pipe *q = flights.front().pipe;
-            if (wtamd_pipe_collect(q, &r) != WTAMD_OK) die("wtamd_pipe_collect");
+            // (results nobody will read: a file-byte batch that failed to decode may be among them)
+            if (wtamd_pipe_collect(q, &r) != WTAMD_OK && !wtamd_pipe_bw_error(q)) die("wtamd_pipe_collect");
             wtamd_pipe_release(q);
             flights.pop_front();
         }
@@ -780,7 +782,21 @@ struct Feeder {
             if (flights.empty()) return false;
             const double t_c0 = g_trace ? now_ms() : 0;
             held_pipe = flights.front().pipe;
-            if (wtamd_pipe_collect(held_pipe, &res) != WTAMD_OK) die("wtamd_pipe_collect");
+            if (wtamd_pipe_collect(held_pipe, &res) != WTAMD_OK) {
+                // A file-byte batch the device decoder rejected for something libBigWig -- what the reference reads
+                // through, src/bigWiggleReader.c:52-83 -- never looks at (items beyond their index leaf's extents, a
+                // section it cannot parse, a stream that does not inflate): the host decoder takes over from this
+                // batch on.  A truly corrupt stream fails there too, with the reader's own message.
+                const unsigned e = bw_mode ? wtamd_pipe_bw_error(held_pipe) : 0u;
+                static const bool no_fallback = getenv("WTAMD_BW_NO_FALLBACK") != nullptr;
+                if (!e || (e & ~7u) || no_fallback) die("wtamd_pipe_collect");
+                const char *fc = flights.front().chrom;
+                const int32_t flo = flights.front().lo;
+                wtamd_pipe_release(held_pipe);
+                flights.pop_front();
+                bwdev_fallback(*this, fc, flo, e);
+                continue;
+            }
             if (g_trace) fprintf(stderr, "[feeder] collect %.3f -> %.3f (%lld runs, %d in flight)\n", t_c0, now_ms(), (long long) res.n_runs, (int) flights.size());
             res_chrom = flights.front().chrom;
             res_lo = flights.front().lo; res_hi = flights.front().hi;
@@ -1153,6 +1169,7 @@ void bw_decode(BwReader *r, BwBuffer &b) {
         if (last) {
             r->p_chrom = r->p_single ? (int) r->names.size() : r->p_chrom + 1;
             r->p_cursor = 0;
+            if (!r->p_single) { r->p_lo0 = 0; r->p_hi0 = INT32_MAX; }      // (a restart position applies to its chromosome only)
         }
         if (n > 0) { b.n = n; b.chrom = ci; return; }
     }
@@ -1508,6 +1525,57 @@ bool bwdev_drain_and_submit(Feeder &F) {
         if (busy + 2 <= F.n_slots_open) (void) bwdev_plan(F);
     }
     return true;
+}
+
+// Repositions a reader on chromosome index ci (of its own, strcmp-sorted names) so that its current element is the
+// first interval finishing at or beyond `lo` -- boxed and windowed as before.  (The producer skips the data blocks
+// that end before lo; the caller pops past the few intervals of the first block kept that still finish below it.)
+void bw_restart(WiggleIterator *wi, int ci, int32_t lo) {
+    BwReader *r = ((BwHandle *) wi->data)->r;
+    if (r->started) bw_wait(r);
+    r->done = false;
+    wi->done = 0;
+    r->p_chrom = ci;
+    r->p_cursor = 0;
+    r->p_blocks = 4;
+    const int32_t lo0 = lo > 2 ? lo - 2 : 0;
+    if (r->windowed) {
+        r->p_single = true; r->p_box = 0;
+        r->p_lo0 = std::max<int32_t>(r->win_start > 0 ? r->win_start - 1 : 0, lo0);
+        r->p_hi0 = r->win_finish > 0 ? r->win_finish - 1 : 0;
+    } else {
+        r->p_single = false; r->p_box = r->box;
+        r->p_lo0 = lo0; r->p_hi0 = INT32_MAX;
+    }
+    r->j = r->end = 0;
+    if (r->started) bw_request(r, r->cur ^ 1);
+    bw_settle(r, wi);
+}
+
+// The device decoder gave up on the batch [lo, ...) of `chrom`: everything in flight is dropped, the readers are moved
+// to that position and the Feeder goes on draining them through their host decoders (bw_mode off for good).
+void bwdev_fallback(Feeder &F, const char *chrom, int32_t lo, unsigned why) {
+    fprintf(stderr, "wiggletools_amd: note: the device BigWig decoder rejected a batch at %s:%d (%s%s%s); continuing with the host decoder\n",
+            chrom, lo, (why & 1u) ? "zlib stream / checksum " : "", (why & 2u) ? "malformed section " : "",
+            (why & 4u) ? "items outside their index leaf or out of order" : "");
+    F.drop_flights();
+    F.bw_mode = false;
+    F.bw_dirty = true;
+    delete F.io_pool;
+    F.io_pool = nullptr;
+    for (auto &s : F.src) {
+        BwReader *r = bwdev_reader(s);
+        int ci = (int) r->names.size();
+        for (size_t c = r->names.size(); c-- > 0;)
+            if (strcmp(r->names[c].c_str(), chrom) >= 0) ci = (int) c;      // first chromosome at or after `chrom` (sorted names)
+        s.pending.clear(); s.log.clear(); s.raw = nullptr; s.interned = nullptr;
+        const bool on_it = ci < (int) r->names.size() && r->names[(size_t) ci] == chrom;
+        bw_restart(s.it, ci, on_it ? lo : 1);
+        while (on_it && !s.it->done && !strcmp(s.it->chrom, chrom) && s.it->finish < lo) s.it->pop(s.it);
+    }
+    F.chrom = chrom;
+    F.continuing = true;
+    F.next_lo = lo;
 }
 
 // ---------------------------------------------------------------------------

@@ -411,6 +411,7 @@ struct wtamd_pipe {
     // size when it is collected (wt_pipe_bw_redo); from then on the pipe sizes by the bound.  < 0: nothing seen yet.
     double bw_density = -1.0;
     int64_t bw_redone = 0;
+    unsigned last_bw_err = 0;       // wtamd_pipe_bw_error
     wtamd_pipe_stats st{};
 };
 
@@ -733,6 +734,8 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
 }
 
 static int64_t wt_align256(int64_t x) { return (x + 255) & ~(int64_t) 255; }
+
+unsigned wtamd_pipe_bw_error(const wtamd_pipe *p) { return p ? p->last_bw_err : 0u; }
 
 int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *p) {
     if (!p || p->slots.empty() || !p->slots[0].ts) return 0;
@@ -1175,9 +1178,11 @@ int wtamd_pipe_collect(wtamd_pipe *p, wtamd_pipe_result *out) {
     p->in_flight--;
     p->held = 1;
     if (rc != WTAMD_OK) return rc;
+    p->last_bw_err = 0;
     if (s.bw) {
         const unsigned long long e = s.h_bw_status[0];
         if (e) {
+            p->last_bw_err = e == ~0ull ? ~0u : (unsigned) e;
             std::string why = "BigWig sections could not be decoded on the device:";
             if (e == ~0ull) why += " decode kernels did not report";
             else {
