@@ -331,7 +331,7 @@ def test_device_decode_multichrom_emu(emu_lib, oracle, tmp_path, monkeypatch):
 
 @pytest.mark.gpu
 def test_device_decode_multichrom_gpu(amd_lib, oracle, tmp_path, monkeypatch):
-    _multichrom(amd_lib, oracle, tmp_path, monkeypatch, n_tracks=12, scale=20000, batch_sections=3000)
+    _multichrom(amd_lib, oracle, tmp_path, monkeypatch, n_tracks=12, scale=20000, batch_sections=1200, min_span=30000)
 
 
 def _shrink_leaf(path, leaf_no, by):
