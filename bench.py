@@ -390,7 +390,7 @@ def chrom_name(c):
     return "chr%d" % (c + 1) if c < 22 else ("chrX" if c == 22 else "chrY")
 
 
-def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device):
+def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None):
     """The north-star measurement: `op` over n_tracks WHOLE-GENOME BigWig files -> result on the host.  Every file holds
     all 24 chromosomes (GRCh38 lengths x `scale`, names chr1 .. chr22, chrX, chrY; the reader walks them in strcmp
     order as reference src/bigWiggleReader.c:91-101 does, 10 000-bp stretches :52-83), bedGraph sections of 1024 items,
@@ -404,6 +404,8 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device):
     from wiggletools_amd import bwwrite, dropin, synthgen
     import torch
     lens = [max(int(g * scale), 1000) for g in GRCH38]
+    if only is not None:                # experiments: data on these chromosomes only (the others stay in the files' trees, empty)
+        lens = [lens[c] if c in only else 0 for c in range(24)]
     names = [chrom_name(c) for c in range(24)]
     order = sorted(range(24), key=lambda c: names[c].encode())          # strcmp order = id order inside the files
     genome_bp = sum(lens)
@@ -411,7 +413,7 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device):
     d = keep or tempfile.mkdtemp(prefix="wtamd_bwg_", dir=os.environ.get("WTAMD_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") else None))
     os.makedirs(d, exist_ok=True)
     paths = [os.path.join(d, "g%03d.bw" % t) for t in range(n_tracks)]
-    meta = os.path.join(d, "meta_genome_%d_%d.json" % (n_tracks, genome_bp))
+    meta = os.path.join(d, "meta_genome_%d_%d_%s.json" % (n_tracks, genome_bp, "all" if only is None else "-".join(map(str, sorted(only)))))
     try:
         if keep and os.path.exists(meta):
             m = json.load(open(meta))
@@ -421,6 +423,8 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device):
             fs = bwwrite.FileSet(paths, {names[c]: lens[c] + 1 for c in range(24)}, items_per_block=1024, level=1, threads=max(1, min(effective_cores(), 32)))
             n_int, gen_s = 0, 0.0
             for c in order:
+                if lens[c] == 0:
+                    continue
                 g0 = time.perf_counter()
                 seg, s_, f_, v_ = synthgen.device_tracks(SEED, [lens[c]], n_tracks, mean_run, 0.02, 800, device, chrom_ids=[c])
                 hs, hf, hv = s_.cpu().numpy(), f_.cpu().numpy(), v_.cpu().numpy()

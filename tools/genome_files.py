@@ -16,6 +16,7 @@ if __name__ == "__main__":
     tracks = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     op = sys.argv[3] if len(sys.argv) > 3 else "mean"
     torch.cuda.set_device(0)
-    r = bench.e2e_bigwig_genome(op, tracks, 16.0, scale, torch.device("cuda", 0))
+    only = [int(x) for x in os.environ["WTAMD_GENOME_ONLY"].split(",")] if os.environ.get("WTAMD_GENOME_ONLY") else None
+    r = bench.e2e_bigwig_genome(op, tracks, 16.0, scale, torch.device("cuda", 0), only=only)
     r["env"] = {k: v for k, v in os.environ.items() if k.startswith("WTAMD_")}
     print(json.dumps(r))

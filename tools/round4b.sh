@@ -1,0 +1,63 @@
+#!/bin/bash
+# GPU call B of round 4: all -m gpu tests, SQ counters of the new inflate kernel at full batches, two pipes on one GPU,
+# more hardware queues, open trace.
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/r4b
+mkdir -p $OUT
+cd $R
+timeout 900 python -m pytest tests -q -m gpu > $OUT/gpu_tests.log 2>&1
+tail -4 $OUT/gpu_tests.log
+export WTAMD_BENCH_BWDIR=/dev/shm/wtamd_r4b
+export WTAMD_GENOME_ONLY=0,1          # chromosomes 1 and 2 only: full batches
+SCALE=0.5
+run() { name=$1; shift; env "$@" timeout 600 python tools/genome_files.py $SCALE > $OUT/ab_$name.json 2> $OUT/ab_$name.err; python - <<PY
+import json
+try:
+    d = json.loads(open("$OUT/ab_$name.json").read().strip().splitlines()[-1])
+    c, w = d["cold"], d["warm"]
+    print("%-14s cold %.3e warm %.3e steady %.3e | warm: %d batches %d sections, decode %.1f ms (%.2f ms/batch), kernels %.1f, submit %.0f wait %.0f open %.3f s | cold submit %.0f dev afresh %.1f GB"
+          % ("$name", d["bp_per_s"], d["warm_bp_per_s"], d.get("steady_bp_per_s") or 0, w["batches"], w["sections_inflated_on_device"], w["sum_device_decode_ms"], w["sum_device_decode_ms"] / max(w["batches"], 1),
+             w["sum_kernel_ms"], w["host_submit_ms"], w["host_wait_ms"], w["open_seconds"], c["host_submit_ms"], c["device_afresh"]["bytes"] / 1e9))
+except Exception as e:
+    print("$name failed:", e, open("$OUT/ab_$name.err").read()[-600:])
+PY
+}
+L=$R/wiggletools_amd/csrc
+run new            WTAMD_X=1
+run r3             WTAMD_LIB=$L/libwiggletools_amd_r3.so
+run new_63k        WTAMD_BW_BATCH_SECTIONS=61504
+run two_pipes      WTAMD_DEVICES=2
+run two_pipes_63k  WTAMD_DEVICES=2 WTAMD_BW_BATCH_SECTIONS=61504
+run hwq8           GPU_MAX_HW_QUEUES=8
+run two_pipes_hwq8 WTAMD_DEVICES=2 GPU_MAX_HW_QUEUES=8 WTAMD_BW_BATCH_SECTIONS=61504
+WTAMD_TRACE_OPEN=1 timeout 300 python tools/genome_files.py $SCALE > /dev/null 2> $OUT/open_trace.txt; grep -c . $OUT/open_trace.txt; head -5 $OUT/open_trace.txt
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bw -- python $R/tools/genome_files.py $SCALE > $OUT/stats_run.log 2>&1
+f=$(find /tmp/p_bw -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -i "wt_\|copyBuffer\|Name" $f | cut -c1-260 > $OUT/bw_kernel_stats.csv
+cut -c1-60,150-260 $OUT/bw_kernel_stats.csv | head -8
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" \
+           "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS" \
+           "VALUBusy SALUBusy MemUnitBusy MemUnitStalled LDSBankConflict" \
+           "SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_WAVES SQ_INST_CYCLES_VMEM_RD" \
+           "SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_WAIT_INST_LDS"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/b_sq$i -- python $R/tools/genome_files.py $SCALE > $OUT/bw_sq$i.log 2>&1
+done
+python - <<PY
+import csv, glob, json
+sq = {}
+for f in glob.glob("/tmp/b_sq*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "wt_bw_inflate" not in r.get("Kernel_Name", ""): continue
+        if float(r.get("Grid_Size", 0) or 0) < 100000: continue         # full launches only
+        sq.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+s = {k: sum(v) / len(v) for k, v in sq.items()}
+s["launches_averaged"] = {k: len(v) for k, v in sq.items()}
+if s.get("SQ_WAVE_CYCLES"):
+    s["derived_valu_insts_per_wave_cycle"] = s.get("SQ_INSTS_VALU", 0) / s["SQ_WAVE_CYCLES"]
+    s["derived_wait_any_share"] = s.get("SQ_WAIT_ANY", 0) / s["SQ_WAVE_CYCLES"]
+json.dump(s, open("$OUT/inflate_sq.json", "w"), indent=1)
+print(json.dumps(s, indent=1))
+PY
+rm -rf /dev/shm/wtamd_r4b

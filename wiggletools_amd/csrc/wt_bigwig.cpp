@@ -16,6 +16,8 @@
 //     1 (mod 10000) is dropped -- reproduced when boxing is on.
 // Pinned by the reference's own fixtures test/fixedStep.bw == fixedStep.wig and
 // variableStep.bw == variableStep.wig (reference test/test.py:28,52).
+#include <fcntl.h>
+#include <sys/resource.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -25,7 +27,9 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -249,8 +253,30 @@ static double bw_now_ms() {
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
+// The kernel grows a process's file-descriptor table by doubling, and a table shared by several threads is replaced
+// behind synchronize_rcu(): on the 256-CPU hosts measured, the open() that crossed 256 descriptors -- the SECOND job of
+// 100 files in a process, or the first of 300 -- stalled for 180 ms, and with it every opener thread queued behind it
+// (round 4: "open 100 files" 0.04 s in the cold run, 0.18 s in the warm one).  The first open of a process therefore
+// grows the table once, to 4096 entries, on a thread of its own: opens that still fit the old table do not wait.
+static void bw_grow_fd_table() {
+    std::thread([] {
+        struct rlimit rl;
+        int target = 4095;
+        if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur != RLIM_INFINITY && (long long) rl.rlim_cur - 1 < target) target = (int) rl.rlim_cur - 1;
+        const int fd = open("/dev/null", O_RDONLY | O_CLOEXEC);
+        if (fd < 0) return;
+        if (target > fd && fcntl(target, F_GETFD) == -1) {      // (not in use)
+            const int hi = dup2(fd, target);
+            if (hi >= 0) close(hi);
+        }
+        close(fd);
+    }).detach();
+}
+
 int wtamd_bw_open(const char *path, wtamd_bw **out) {
     if (!path || !out) return WTAMD_ERR_ARG;
+    static std::once_flag grow_once;
+    std::call_once(grow_once, bw_grow_fd_table);
     static const bool trace = getenv("WTAMD_TRACE_OPEN") != nullptr;
     const double t0 = trace ? bw_now_ms() : 0;
     wtamd_bw *bw = new wtamd_bw();

@@ -115,19 +115,24 @@ __global__ void __launch_bounds__(64) wt_bw_count_kernel(const WtBwSection *secs
             // Adler-32 of what was inflated against the stream's trailer (RFC 1950; libBigWig's uncompress() checks it,
             // so a damaged payload that still parses must not pass here either): A = 1 + sum d_i, B = sum of the running A.
             // Every lane takes a slice; B = n + sum over slices of (their own B + bytes behind the slice x their A).
+            // Lanes take the dwords of the section INTERLEAVED (one coalesced 256-byte read per wavefront instruction):
+            // A = 1 + sum d_i,  B = n + sum (n - i) d_i = n + n * sum d_i - sum i * d_i.
             const uint32_t n = (uint32_t) len;
-            const uint32_t chunk = (((n + 63u) >> 6) + 3u) & ~3u;
-            const uint32_t lo = (uint32_t) lane * chunk, hi = lo + chunk < n ? lo + chunk : n;
-            uint32_t a = 0, b = 0;
-            for (uint32_t q = lo; q < hi; q += 4) {
+            unsigned long long A = 0, C = 0;            // sum d_i, sum i * d_i of this lane's bytes
+            for (uint32_t q = 4u * (uint32_t) lane; q < n; q += 256u) {
                 const uint32_t w = *(const uint32_t *) (p + q);
+                uint32_t a = 0, c = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (q + k < hi) { a += (w >> (8 * k)) & 255u; b += a; }
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t d = q + k < n ? (w >> (8u * k)) & 255u : 0u;
+                    a += d; c += k * d;
+                }
+                A += a;
+                C += (unsigned long long) q * a + c;
             }
-            unsigned long long A = a, B = (unsigned long long) b + (unsigned long long) (lo < n ? n - hi : 0u) * a;
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) { A += __shfl_xor(A, o, 64); B += __shfl_xor(B, o, 64); }
+            for (int o = 32; o >= 1; o >>= 1) { A += __shfl_xor(A, o, 64); C += __shfl_xor(C, o, 64); }
+            const unsigned long long B = (unsigned long long) n * A - C;
             const uint32_t ad = (uint32_t) (((B + n) % 65521ull) << 16) | (uint32_t) ((A + 1ull) % 65521ull);
             const uint8_t *t = comp + sc.comp_off + sc.comp_size - 4;
             const uint32_t want = ((uint32_t) t[0] << 24) | ((uint32_t) t[1] << 16) | ((uint32_t) t[2] << 8) | (uint32_t) t[3];

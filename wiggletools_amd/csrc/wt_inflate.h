@@ -129,19 +129,20 @@ struct WtInfFar { uint32_t q[4]; uint32_t t; };
 
 template <int RING>
 struct WtInflateT {
-    // input: 16-byte chunks at 16-byte aligned addresses.  `cur` is being consumed (qn words left, shifted so that
-    // cur.x is the next one), `q1` follows it, `pend` is in flight and lands at the next round boundary.
+    // input: 16-byte chunks ("quads") at 16-byte aligned addresses.  The stream is read POSITIONALLY: `bp` is the bit of
+    // the current quad `cur` the next symbol starts at, `q1` is the quad behind it, `pend` is in flight and lands at the
+    // next round boundary.  A step peeks 64 bits at bp (wt_inf_peek: selects + two v_alignbit, no state) and adds what
+    // it consumed to bp; a bit BUFFER refilled word by word (round-4 first version) cost two conditional refills with
+    // their queue shifts per step, ~50 VALU instructions and six branches.
     const WT_AS_GLOBAL uint32_t *in_w;  // aligned base
     uint32_t mis;               // bytes between the aligned base and the stream
-    uint32_t in_chunk;          // next chunk to fetch
-    uint32_t in_chunks;         // chunks that may be read
+    uint32_t in_chunk;          // next quad to fetch
+    uint32_t in_chunks;         // quads that may be read
     WtInfQuad cur, q1, pend;
-    uint32_t qn;
     bool q1_valid, pend_valid;
-    uint32_t wpos;              // words taken so far, counted from the aligned base
+    uint32_t bp;                // 0 .. 127 (+ what the last step consumed: normalised at the start of the next)
+    uint32_t qbase;             // quads before `cur`
     uint32_t n_bytes;
-    uint64_t bb;                // bit buffer, LSB first
-    int32_t bc;                 // valid bits in bb
     // output
     WT_AS_GLOBAL uint32_t *out; // 4-byte aligned
     uint32_t out_pos, out_cap;
@@ -162,6 +163,7 @@ struct WtInflateT {
     uint32_t lpk[16];           // (index adjustment << 16) | first sorted index of the length that holds a symbol >= 256
     int32_t dadj[16];
     uint32_t dperm[5];          // the distance symbols sorted by code, 5 bits each, 6 per word
+    uint32_t lmax, dmax;        // longest code word of the two codes
 };
 
 WT_HD uint32_t wt_inf_bitrev15(uint32_t x) {
@@ -192,51 +194,74 @@ WT_HD void wt_inf_fail(WtInflateT<RING> &z, int code) { z.copy_rem = 0; z.err = 
 
 // bits of the stream consumed so far
 template <int RING>
-WT_HD int64_t wt_inf_bitpos(const WtInflateT<RING> &z) { return (int64_t) z.wpos * 32 - (int64_t) z.bc - 8 * (int64_t) z.mis; }
+WT_HD int64_t wt_inf_bitpos(const WtInflateT<RING> &z) { return (int64_t) z.qbase * 128 + (int64_t) z.bp - 8 * (int64_t) z.mis; }
 
 template <int RING>
 WT_HD bool wt_inf_overread(const WtInflateT<RING> &z) { return wt_inf_bitpos(z) > (int64_t) z.n_bytes * 8; }
 
-// The next word of the queue.  (The queue is SHIFTED, never indexed: one variable index into the state struct and
-// hipcc keeps the whole struct in scratch memory.)  An empty queue yields zero words: the caller has made sure that
-// nothing more can arrive (end of the input; wt_inf_overread catches a stream that decodes beyond it).
-template <int RING>
-WT_HD uint32_t wt_inf_word(WtInflateT<RING> &z) {
-    const uint32_t w = z.cur.x;
-    z.cur.x = z.cur.y; z.cur.y = z.cur.z; z.cur.z = z.cur.w; z.cur.w = 0;
-    z.wpos++;
-    if (z.qn) z.qn--;
-    if (z.qn == 0 && z.q1_valid) { z.cur = z.q1; z.qn = 4; z.q1_valid = false; }
-    return w;
+WT_HD uint32_t wt_inf_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {        // low 32 bits of (hi:lo) >> sh, sh < 32
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t) ((((uint64_t) hi << 32) | (uint64_t) lo) >> (sh & 31u));
+#endif
 }
 
-// The blocking flavour for the block-header code, which reads many words at one go: fills the queue on the spot.
+// 64 bits of the stream from bit bp (< 128) of the current quad on; the bits beyond `cur` come from q1 (whatever it
+// holds when it is not valid: a stream never CONSUMES bits it does not have, wt_inf_overread sees to the rest).
 template <int RING>
-WT_HD uint32_t wt_inf_word_cold(WtInflateT<RING> &z) {
-    if (z.qn == 0) {
-        if (z.pend_valid) { z.cur = z.pend; z.qn = 4; z.pend_valid = false; }
-        else if (z.in_chunk < z.in_chunks) { z.cur = wt_inf_load(z, z.in_chunk); z.in_chunk++; z.qn = 4; }
-    }
-    return wt_inf_word(z);
+WT_HD uint64_t wt_inf_peek(const WtInflateT<RING> &z) {
+    const uint32_t i = z.bp >> 5, sh = z.bp & 31u;
+    const bool i1 = i == 1u, i2 = i == 2u, i3 = i >= 3u;
+    uint32_t w0 = z.cur.x, w1 = z.cur.y, w2 = z.cur.z;
+    w0 = i1 ? z.cur.y : w0; w1 = i1 ? z.cur.z : w1; w2 = i1 ? z.cur.w : w2;
+    w0 = i2 ? z.cur.z : w0; w1 = i2 ? z.cur.w : w1; w2 = i2 ? z.q1.x : w2;
+    w0 = i3 ? z.cur.w : w0; w1 = i3 ? z.q1.x : w1; w2 = i3 ? z.q1.y : w2;
+    return (uint64_t) wt_inf_alignbit(w1, w0, sh) | ((uint64_t) wt_inf_alignbit(w2, w1, sh) << 32);
 }
 
 // Positions the reader at bit `pos` of the stream (blocking; whatever was in flight is dropped).
 template <int RING>
 WT_HD void wt_inf_seek_bits(WtInflateT<RING> &z, uint32_t pos) {
-    const uint32_t byte = z.mis + (pos >> 3), word = byte >> 2, ch = word >> 2;
+    const uint32_t t = 8u * z.mis + pos, qi = t >> 7;
     const WtInfQuad zero = {0u, 0u, 0u, 0u};
-    z.cur = ch < z.in_chunks ? wt_inf_load(z, ch) : zero;
-    z.q1_valid = ch + 1u < z.in_chunks;
-    z.q1 = z.q1_valid ? wt_inf_load(z, ch + 1u) : zero;
-    z.in_chunk = ch + 2u;
+    z.cur = qi < z.in_chunks ? wt_inf_load(z, qi) : zero;
+    z.q1_valid = qi + 1u < z.in_chunks;
+    z.q1 = z.q1_valid ? wt_inf_load(z, qi + 1u) : zero;
+    z.in_chunk = qi + 2u;
     z.pend_valid = false;
-    z.qn = 4;
-    z.wpos = word & ~3u;
-    for (uint32_t k = 0; k < (word & 3u); k++) (void) wt_inf_word(z);     // whole words before the position are skipped
-    const uint32_t w0 = wt_inf_word(z);
-    const uint32_t head = 8u * (byte & 3u) + (pos & 7u);
-    z.bb = (uint64_t) (w0 >> head);
-    z.bc = 32 - (int32_t) head;
+    z.bp = t & 127u;
+    z.qbase = qi;
+}
+
+// The blocking flavour of the reader, for the block-header code (which reads many words at one go): makes bp < 128
+// and q1 valid (while the input lasts), fetching on the spot.
+template <int RING>
+WT_HD void wt_inf_cold_norm(WtInflateT<RING> &z) {
+    const WtInfQuad zero = {0u, 0u, 0u, 0u};
+    while (z.bp >= 128u) {
+        if (z.q1_valid) z.cur = z.q1;
+        else if (z.pend_valid) { z.cur = z.pend; z.pend_valid = false; }
+        else if (z.in_chunk < z.in_chunks) { z.cur = wt_inf_load(z, z.in_chunk); z.in_chunk++; }
+        else z.cur = zero;
+        z.q1_valid = false;
+        z.q1 = zero;
+        z.bp -= 128u;
+        z.qbase++;
+    }
+    if (!z.q1_valid) {
+        if (z.pend_valid) { z.q1 = z.pend; z.pend_valid = false; z.q1_valid = true; }
+        else if (z.in_chunk < z.in_chunks) { z.q1 = wt_inf_load(z, z.in_chunk); z.in_chunk++; z.q1_valid = true; }
+    }
+}
+
+// the next n (<= 32) bits, consumed (cold paths only)
+template <int RING>
+WT_HD uint32_t wt_inf_bits(WtInflateT<RING> &z, int n) {
+    wt_inf_cold_norm(z);
+    const uint32_t v = (uint32_t) (wt_inf_peek(z) & ((1ull << n) - 1ull));
+    z.bp += (uint32_t) n;
+    return v;
 }
 
 // Starts a stream of `n_bytes` at `src` (any alignment; the 16-byte aligned chunks around it must be readable
@@ -257,6 +282,7 @@ WT_HD void wt_inf_begin(WtInflateT<RING> &z, const uint8_t *src, uint32_t n_byte
     z.copy_rem = z.copy_dist = 0; z.stored_rem = 0;
     z.last = false; z.raw = raw_deflate;
     z.far_have = z.far_len = 0; z.far_pending = false;
+    z.lmax = z.dmax = 1;
 #pragma unroll
     for (int k = 0; k < 5; k++) { z.fq[k] = 0; z.dperm[k] = 0; }
 #pragma unroll
@@ -266,54 +292,58 @@ WT_HD void wt_inf_begin(WtInflateT<RING> &z, const uint8_t *src, uint32_t n_byte
     for (int k = 0; k < 16; k++) { z.llim[k] = 0; z.dlim[k] = 0; z.lpk[k] = 0; z.dadj[k] = 0; }
 }
 
-// After this bc >= 33 (COLD: fills the queue on the spot; otherwise the caller has checked that two words wait).
-template <bool COLD, int RING>
-WT_HD void wt_inf_refill(WtInflateT<RING> &z) {
-    if (z.bc <= 32) {
-        const uint32_t w = COLD ? wt_inf_word_cold(z) : wt_inf_word(z);
-        z.bb |= (uint64_t) w << z.bc;
-        z.bc += 32;
-    }
+// true if the condition holds for ANY lane of the wavefront (wave-uniform: branches on it are scalar branches)
+WT_HD bool wt_inf_any(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(c) != 0ull;
+#else
+    return c;
+#endif
 }
 
-template <int RING>
-WT_HD uint32_t wt_inf_bits(WtInflateT<RING> &z, int n) {      // n <= 32, after a refill guaranteeing enough bits
-    const uint32_t v = (uint32_t) (z.bb & ((1ull << n) - 1ull));
-    z.bb >>= n; z.bc -= n;
-    return v;
-}
-
-// Length and table word of the code word on top of the stream: lim[1..15] / tab[1..15] registers; idx_base = the
-// position of the code word among the code words of its length.  Returns false on a pattern no code word matches.
-template <int RING, class T>
-WT_HD bool wt_inf_code(WtInflateT<RING> &z, const uint32_t (&lim)[16], const T (&tab)[16], T &t, uint32_t &within) {
-    const uint32_t w = wt_inf_bitrev15((uint32_t) z.bb & 0x7FFFu);
+// Length of the code word that starts the left-aligned 15-bit window w, and the table word of that length:
+// lim[1..15] / tab[1..15] registers.  (w >= lim[15]: no code word matches; the caller checks.)
+// A code whose longest word has M bits never needs the comparisons k >= M (lim[k] = lim[15] there): `maxlen` is the
+// lane's M, and the tail of the chain sits behind wave-uniform branches (K1 < K2: first comparisons of the two tails).
+template <int K1, int K2, class T>
+WT_HD int wt_inf_code(uint32_t w, const uint32_t (&lim)[16], const T (&tab)[16], uint32_t maxlen, T &t) {
     int len = 1;
     T a = tab[1];
-#pragma unroll
-    for (int k = 1; k <= 14; k++) {
-        const bool ge = w >= lim[k];
-        len += ge ? 1 : 0;
-        a = ge ? tab[k + 1] : a;
-        WT_INF_OPAQUE(a);
+#define WT_INF_CODE_STEP(k)                                                                       \
+    {                                                                                             \
+        const bool ge = w >= lim[k];                                                              \
+        len += ge ? 1 : 0;                                                                        \
+        a = ge ? tab[(k) + 1] : a;                                                                \
+        WT_INF_OPAQUE(a);                                                                         \
     }
+#pragma unroll
+    for (int k = 1; k < K1; k++) WT_INF_CODE_STEP(k)
+    if (wt_inf_any(maxlen > (uint32_t) K1)) {
+#pragma unroll
+        for (int k = K1; k < K2; k++) WT_INF_CODE_STEP(k)
+        if (wt_inf_any(maxlen > (uint32_t) K2)) {
+#pragma unroll
+            for (int k = K2; k <= 14; k++) WT_INF_CODE_STEP(k)
+        }
+    }
+#undef WT_INF_CODE_STEP
     t = a;
-    within = w >> (15 - len);
-    z.bb >>= len; z.bc -= len;
-    return w < lim[15];
+    return len;
 }
 
 // lim[] of a canonical code from the 16 per-length counts (lane memory); calls tab(k, first code of length k,
 // symbols shorter than k) for k = 1..15 and leaves the insertion cursor of every length in the counters.
 // False: over-subscribed.
 template <class F>
-WT_HD bool wt_inf_limits(uint32_t (&lim)[16], const WtInfMem &m, F tab) {
+WT_HD bool wt_inf_limits(uint32_t (&lim)[16], const WtInfMem &m, uint32_t &maxlen, F tab) {
     uint32_t code = 0, off = 0;
     bool ok = true;
     lim[0] = 0;
+    maxlen = 1;
 #pragma unroll
     for (int k = 1; k <= 15; k++) {
         const uint32_t c = wt_inf_cnt_get(m, (uint32_t) k);
+        if (c) maxlen = (uint32_t) k;
         if (code + c > (1u << k)) ok = false;
         lim[k] = (code + c) << (15 - k);
         tab(k, code, off);
@@ -324,28 +354,28 @@ WT_HD bool wt_inf_limits(uint32_t (&lim)[16], const WtInfMem &m, F tab) {
     return ok;
 }
 
-// Appends the low n (1..8) bytes of `bytes` to the output: full dwords go to global memory and to the ring,
-// the partial one stays in `acc` (it reaches the ring when a match is about to read it).
+// Appends the low n (0..8) bytes of `bytes` to the output: full dwords go to global memory and to the ring, the partial
+// one stays in `acc` (it reaches the ring when a match is about to read it).  Branch-free but for the two stores.
 template <int RING>
 WT_HD void wt_inf_put(WtInflateT<RING> &z, const WtInfMem &m, uint64_t bytes, uint32_t n) {
-    if (n < 8) bytes &= (1ull << (8 * n)) - 1ull;
+    bytes &= n < 8u ? (1ull << (8u * n)) - 1ull : ~0ull;
     const uint32_t sh = (z.out_pos & 3u) * 8u;
     const uint32_t d = z.out_pos >> 2;
     const uint32_t e0 = z.acc | (uint32_t) (bytes << sh);
     const uint64_t t = bytes >> (32u - sh);
     const uint32_t e1 = (uint32_t) t, e2 = (uint32_t) (t >> 32);
     const uint32_t full = ((z.out_pos & 3u) + n) >> 2;
-    uint32_t acc = e0;
-    if (full >= 1) {
+    if (full >= 1u) {
         z.out[d] = e0;
         m.ring[(d & (RING - 1)) * m.stride] = e0;
-        acc = e1;
-        if (full >= 2) {
-            z.out[d + 1] = e1;
-            m.ring[((d + 1) & (RING - 1)) * m.stride] = e1;
-            acc = e2;
-        }
     }
+    if (full >= 2u) {
+        z.out[d + 1] = e1;
+        m.ring[((d + 1) & (RING - 1)) * m.stride] = e1;
+    }
+    uint32_t acc = e0;
+    acc = full >= 1u ? e1 : acc;
+    acc = full >= 2u ? e2 : acc;
     z.acc = acc;
     z.out_pos += n;
 }
@@ -363,8 +393,8 @@ WT_HD bool wt_inf_lengths(WtInflateT<RING> &z, const WtInfClen &c, int total, F 
     int i = 0;
     uint32_t prev = 0;
     while (i < total) {
-        wt_inf_refill<true>(z);
-        const uint32_t w7 = wt_inf_bitrev15((uint32_t) z.bb & 0x7Fu) >> 8;     // 7-bit window, first bit on top
+        wt_inf_cold_norm(z);
+        const uint32_t w7 = wt_inf_bitrev15((uint32_t) wt_inf_peek(z) & 0x7Fu) >> 8;     // 7-bit window, first bit on top
         int len = 1;
         int32_t a = c.cadj[1];
 #pragma unroll
@@ -377,7 +407,7 @@ WT_HD bool wt_inf_lengths(WtInflateT<RING> &z, const WtInfClen &c, int total, F 
         if (w7 >= c.clim[7]) { wt_inf_fail(z, WT_INF_ERR_SYMBOL); return false; }
         const uint32_t j = (uint32_t) (a + (int32_t) (w7 >> (7 - len)));
         const uint32_t sym = (uint32_t) ((j < 12u ? c.cp0 >> (5u * j) : c.cp1 >> (5u * (j - 12u))) & 31u);
-        z.bb >>= len; z.bc -= len;
+        z.bp += (uint32_t) len;
         uint32_t rep = 1, val = sym;
         if (sym == 16) {
             if (i == 0) { wt_inf_fail(z, WT_INF_ERR_CODE); return false; }
@@ -403,12 +433,10 @@ WT_HD uint32_t wt_inf_fixed_length(int s) { return s < 144 ? 8u : s < 256 ? 9u :
 template <int RING>
 WT_HD void wt_inf_block(WtInflateT<RING> &z, const WtInfMem &m) {
     const int S = m.stride;
-    wt_inf_refill<true>(z);
     z.last = wt_inf_bits(z, 1) != 0;
     const uint32_t type = wt_inf_bits(z, 2);
     if (type == 0) {
-        wt_inf_bits(z, z.bc & 7);                   // to the byte boundary (bc counts from it)
-        wt_inf_refill<true>(z);
+        z.bp += (8u - (z.bp & 7u)) & 7u;           // to the byte boundary (quads are byte aligned)
         const uint32_t len = wt_inf_bits(z, 16), nlen = wt_inf_bits(z, 16);
         if ((len ^ nlen) != 0xFFFFu) { wt_inf_fail(z, WT_INF_ERR_BLOCK); return; }
         z.stored_rem = len;
@@ -458,11 +486,9 @@ WT_HD void wt_inf_block(WtInflateT<RING> &z, const WtInfMem &m) {
         if (hlit > 286 || hdist > 30) { wt_inf_fail(z, WT_INF_ERR_CODE); return; }
         // the code-length code: 19 lengths of 3 bits, packed 3 bits per symbol
         uint64_t cl = 0;
-        wt_inf_refill<true>(z);
 #pragma unroll
         for (int i = 0; i < 19; i++) {
             const int order = i == 0 ? 16 : i == 1 ? 17 : i == 2 ? 18 : i == 3 ? 0 : (i & 1) ? (8 - ((i - 3) >> 1)) : (7 + ((i - 2) >> 1));
-            if (i == 10) wt_inf_refill<true>(z);
             if (i < hclen) cl |= (uint64_t) wt_inf_bits(z, 3) << (3 * order);
         }
         uint64_t cc = 0;                            // 8-bit counters per length
@@ -501,7 +527,7 @@ WT_HD void wt_inf_block(WtInflateT<RING> &z, const WtInfMem &m) {
     // literal / length code: limits, and per length (index adjustment << 16) | first index holding a symbol >= 256
     uint32_t lpk[16];
     lpk[0] = 0;
-    ok = wt_inf_limits(z.llim, m, [&](int k, uint32_t code, uint32_t off) {
+    ok = wt_inf_limits(z.llim, m, z.lmax, [&](int k, uint32_t code, uint32_t off) {
         lpk[k] = ((uint32_t) ((int32_t) off - (int32_t) code) << 16) | ((off + lits[k]) & 0xFFFFu);
     }) && ok;
 #pragma unroll
@@ -523,7 +549,7 @@ WT_HD void wt_inf_block(WtInflateT<RING> &z, const WtInfMem &m) {
     }
     int32_t dadj[16];
     dadj[0] = 0;
-    ok = wt_inf_limits(z.dlim, m, [&](int k, uint32_t code, uint32_t off) { dadj[k] = (int32_t) off - (int32_t) code; }) && ok;
+    ok = wt_inf_limits(z.dlim, m, z.dmax, [&](int k, uint32_t code, uint32_t off) { dadj[k] = (int32_t) off - (int32_t) code; }) && ok;
 #pragma unroll
     for (int k = 0; k < 16; k++) z.dadj[k] = dadj[k];
     uint32_t dp[5] = {0u, 0u, 0u, 0u, 0u};
@@ -553,11 +579,7 @@ WT_HD bool wt_inf_land(WtInflateT<RING> &z, const WtInfMem &m) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the round's one wait for memory: `pend` and `fpend` have landed
 #endif
-    if (z.pend_valid) {
-        if (z.qn == 0) { z.cur = z.pend; z.qn = 4; }
-        else { z.q1 = z.pend; z.q1_valid = true; }
-        z.pend_valid = false;
-    }
+    if (z.pend_valid) { z.q1 = z.pend; z.q1_valid = true; z.pend_valid = false; }      // (only issued while q1 is empty)
     if (z.far_pending) {
 #pragma unroll
         for (int k = 0; k < 4; k++) z.fq[k] = z.fpend.q[k];
@@ -567,7 +589,6 @@ WT_HD bool wt_inf_land(WtInflateT<RING> &z, const WtInfMem &m) {
     }
     if (wt_inf_overread(z)) { wt_inf_fail(z, WT_INF_ERR_INPUT); return false; }
     if (z.st == WT_INF_ST_ZHDR) {                   // RFC 1950 -- CMF, FLG
-        wt_inf_refill<true>(z);
         const uint32_t cmf = wt_inf_bits(z, 8), flg = wt_inf_bits(z, 8);
         if ((cmf & 15u) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u || (flg & 32u)) { wt_inf_fail(z, WT_INF_ERR_HEADER); return false; }
         z.st = WT_INF_ST_BLOCK;
@@ -585,117 +606,140 @@ WT_HD bool wt_inf_land(WtInflateT<RING> &z, const WtInfMem &m) {
 }
 
 // ---- one step: at most one symbol, at most WT_INF_COPY bytes.  No load issued here is consumed here.
+// Written WITHOUT BRANCHES around arithmetic: 64 lanes are never in the same state, so a wavefront pays for every
+// path of every step anyway, and the structurised form of "if literal / if length / if refill ..." cost one SALU
+// instruction for every three VALU ones plus 36 branches per step (SQ counters of the first round-4 version: 3.1e9
+// VALU, 1.0e9 SALU, 0.32e9 branch instructions per launch; VALUBusy 53 % with two wavefronts per SIMD).  Every lane
+// decodes a literal / length code AND a distance code from its 64-bit window, reads the ring, and selects; the only
+// branches left guard memory operations and the rare paths (stored bytes, a match source beyond the ring).
 template <int RING>
 WT_HD void wt_inf_step(WtInflateT<RING> &z, const WtInfMem &m) {
     const int S = m.stride;
-    uint64_t bytes = 0;
-    uint32_t n = 0;
-    // two words cover the worst symbol (15 + 5 + 15 + 13 bits after a refill to >= 33)
-    const bool fed = z.qn + (z.q1_valid ? 4u : 0u) >= 2u || (!z.pend_valid && z.in_chunk >= z.in_chunks);
-    if (z.copy_rem == 0 && fed && z.st <= WT_INF_ST_STORED) {
-        wt_inf_refill<false>(z);
-        if (z.st == WT_INF_ST_SYM) {
-            uint32_t pk, within;
-            const bool hit = wt_inf_code(z, z.llim, z.lpk, pk, within);
-            const uint32_t idx = (uint32_t) (((int32_t) pk >> 16) + (int32_t) within);
-            const uint32_t s8 = hit ? wt_inf_perm_get(m, idx < (uint32_t) WT_INF_PERM ? idx : 0u) : 0u;
-            if (!hit) {
-                wt_inf_fail(z, WT_INF_ERR_SYMBOL);
-            } else if (idx < (pk & 0xFFFFu)) {      // a literal
-                if (z.out_pos >= z.out_cap) wt_inf_fail(z, WT_INF_ERR_SPACE);
-                else { bytes = s8; n = 1; }
-            } else if (s8 == 0u) {                  // 256: end of block
-                z.st = z.last ? WT_INF_ST_DONE : WT_INF_ST_BLOCK;
-            } else {
-                const uint32_t ls = s8 - 1u;        // length symbol 257 + ls
-                uint32_t len;
-                if (ls < 8u) len = ls + 3u;
-                else if (ls == 28u) len = 258u;
-                else {
-                    const uint32_t e = (ls - 4u) >> 2;
-                    len = ((4u + (ls & 3u)) << e) + 3u + wt_inf_bits(z, (int) (e < 6u ? e : 0u));
-                }
-                wt_inf_refill<false>(z);
-                int32_t da;
-                uint32_t dwithin;
-                const bool dhit = wt_inf_code(z, z.dlim, z.dadj, da, dwithin);
-                const uint32_t di = (uint32_t) (da + (int32_t) dwithin);
-                const uint32_t word = di / 6u, dsh = 5u * (di - 6u * word);
-                uint32_t dw = z.dperm[0];
-                dw = word == 1u ? z.dperm[1] : dw; WT_INF_OPAQUE(dw);
-                dw = word == 2u ? z.dperm[2] : dw; WT_INF_OPAQUE(dw);
-                dw = word == 3u ? z.dperm[3] : dw; WT_INF_OPAQUE(dw);
-                dw = word == 4u ? z.dperm[4] : dw; WT_INF_OPAQUE(dw);
-                const uint32_t ds = (dw >> dsh) & 31u;
-                uint32_t dist = ds + 1u;
-                if (ds >= 4u) {
-                    const uint32_t e = (ds >> 1) - 1u;
-                    dist = ((2u + (ds & 1u)) << e) + 1u + wt_inf_bits(z, (int) (e < 14u ? e : 0u));
-                }
-                if (ls > 28u || !dhit || di > 29u || ds > 29u) wt_inf_fail(z, WT_INF_ERR_SYMBOL);
-                else if (dist > z.out_pos) wt_inf_fail(z, WT_INF_ERR_DIST);
-                else if (z.out_pos + len > z.out_cap) wt_inf_fail(z, WT_INF_ERR_SPACE);
-                else { z.copy_rem = len; z.copy_dist = dist; }
-            }
-        } else {                                    // WT_INF_ST_STORED: up to 4 bytes (bc is a multiple of 8 here)
-            const uint32_t k = z.stored_rem < 4u ? z.stored_rem : 4u;
-            if (z.out_pos + k > z.out_cap) wt_inf_fail(z, WT_INF_ERR_SPACE);
-            else {
-                bytes = (uint64_t) wt_inf_bits(z, 8 * (int) k);
-                n = k;
-                z.stored_rem -= k;
-                if (!z.stored_rem) z.st = z.last ? WT_INF_ST_DONE : WT_INF_ST_BLOCK;
-            }
+    // ---- input window
+    const bool no_more = !z.pend_valid && z.in_chunk >= z.in_chunks;
+    const bool adv = z.bp >= 128u && (z.q1_valid || no_more);     // on to the next quad
+    z.cur.x = adv ? z.q1.x : z.cur.x; z.cur.y = adv ? z.q1.y : z.cur.y; z.cur.z = adv ? z.q1.z : z.cur.z; z.cur.w = adv ? z.q1.w : z.cur.w;
+    z.q1_valid = z.q1_valid && !adv;
+    z.bp -= adv ? 128u : 0u;
+    z.qbase += adv ? 1u : 0u;
+    // a symbol takes up to 48 bits (15 + 5 + 15 + 13): q1 must be there once bp is beyond 64 (or the input be over)
+    const bool fed = z.bp < 64u || (z.bp < 128u && (z.q1_valid || no_more));
+    const uint64_t win = wt_inf_peek(z);
+    const bool dec = z.copy_rem == 0u && fed && z.st == WT_INF_ST_SYM;
+    // ---- literal / length code
+    const uint32_t w1 = wt_inf_bitrev15((uint32_t) win & 0x7FFFu);
+    uint32_t pk;
+    const int len1 = wt_inf_code<12, 13>(w1, z.llim, z.lpk, z.lmax, pk);
+    const uint32_t idx = (uint32_t) (((int32_t) pk >> 16) + (int32_t) (w1 >> (15 - len1)));
+    const uint32_t s8 = wt_inf_perm_get(m, idx < (uint32_t) WT_INF_PERM ? idx : 0u);
+    const bool is_lit = idx < (pk & 0xFFFFu);
+    const uint64_t a1 = win >> len1;
+    // ---- distance code, decoded BEFORE the symbol is back from LDS: right behind the length code, as if the length
+    // had no extra bits (lengths 3 .. 10: all but one match in two thousand of 12-byte records; the others take the
+    // branch below) -- the table read and this chain overlap instead of following each other
+    uint32_t w2 = wt_inf_bitrev15((uint32_t) a1 & 0x7FFFu);
+    int32_t da;
+    int len2 = wt_inf_code<9, 11>(w2, z.dlim, z.dadj, z.dmax, da);
+    // ---- the symbol read as a length symbol 257 + ls
+    const uint32_t ls = s8 - 1u;
+    const bool l_ext = ls >= 8u && ls < 28u;
+    const uint32_t e = l_ext ? (ls - 4u) >> 2 : 0u;
+    uint32_t lbase = ((4u + (ls & 3u)) << e) + 3u;
+    lbase = ls < 8u ? ls + 3u : lbase;
+    lbase = ls == 28u ? 258u : lbase;
+    const uint32_t len = lbase + ((uint32_t) a1 & ((1u << e) - 1u));
+    uint64_t a2 = a1;
+    if (dec && !is_lit && l_ext) {                  // a length with extra bits: the distance code starts behind them
+        a2 = a1 >> e;
+        w2 = wt_inf_bitrev15((uint32_t) a2 & 0x7FFFu);
+        len2 = wt_inf_code<9, 11>(w2, z.dlim, z.dadj, z.dmax, da);
+    }
+    const uint32_t di = (uint32_t) (da + (int32_t) (w2 >> (15 - len2)));
+    const uint32_t word = di / 6u, dsh = 5u * (di - 6u * word);
+    uint32_t dw = z.dperm[0];
+    dw = word == 1u ? z.dperm[1] : dw; WT_INF_OPAQUE(dw);
+    dw = word == 2u ? z.dperm[2] : dw; WT_INF_OPAQUE(dw);
+    dw = word == 3u ? z.dperm[3] : dw; WT_INF_OPAQUE(dw);
+    dw = word == 4u ? z.dperm[4] : dw; WT_INF_OPAQUE(dw);
+    const uint32_t ds = (dw >> dsh) & 31u;
+    const bool d_ext = ds >= 4u && ds < 30u;
+    const uint32_t de = d_ext ? (ds >> 1) - 1u : 0u;
+    uint32_t dbase = ((2u + (ds & 1u)) << de) + 1u;
+    dbase = ds < 4u ? ds + 1u : dbase;
+    const uint64_t a3 = a2 >> len2;
+    const uint32_t dist = dbase + ((uint32_t) a3 & ((1u << de) - 1u));
+    // ---- what the symbol is, and whether it is acceptable (booleans: lane masks, combined on the scalar unit)
+    const bool is_eob = !is_lit && s8 == 0u;
+    const bool is_m = !is_lit && s8 != 0u;
+    const bool bad_sym = w1 >= z.llim[15] || (is_m && (ls > 28u || w2 >= z.dlim[15] || di > 29u || ds > 29u));
+    const bool bad_dist = is_m && dist > z.out_pos;
+    const bool bad_space = is_lit ? z.out_pos >= z.out_cap : (is_m && z.out_pos + len > z.out_cap);
+    const bool ok = dec && !(bad_sym || bad_dist || bad_space), fail = dec && (bad_sym || bad_dist || bad_space);
+    z.bp += ok ? (is_m ? (uint32_t) len1 + e + (uint32_t) len2 + de : (uint32_t) len1) : 0u;
+    if (fail) wt_inf_fail(z, bad_sym ? WT_INF_ERR_SYMBOL : bad_dist ? WT_INF_ERR_DIST : WT_INF_ERR_SPACE);      // (rare)
+    z.st = (ok && is_eob) ? (z.last ? WT_INF_ST_DONE : WT_INF_ST_BLOCK) : z.st;
+    z.copy_rem = (ok && is_m) ? len : z.copy_rem;
+    z.copy_dist = (ok && is_m) ? dist : z.copy_dist;
+    uint64_t bytes = (uint64_t) s8;
+    uint32_t n = (ok && is_lit) ? 1u : 0u;
+    // ---- stored bytes (rare: a wavefront usually skips this): up to 4 (the stream is byte aligned here)
+    if (z.st == WT_INF_ST_STORED && fed) {
+        const uint32_t k = z.stored_rem < 4u ? z.stored_rem : 4u;
+        if (z.out_pos + k > z.out_cap) wt_inf_fail(z, WT_INF_ERR_SPACE);
+        else {
+            bytes = win;
+            n = k;
+            z.bp += 8u * k;
+            z.stored_rem -= k;
+            if (!z.stored_rem) z.st = z.last ? WT_INF_ST_DONE : WT_INF_ST_BLOCK;
         }
     }
-    if (z.copy_rem) {
-        const uint32_t src = z.out_pos - z.copy_dist;
-        const uint32_t sh = (src & 3u) * 8u;
-        if (z.copy_dist <= (uint32_t) WT_INF_RING_DIST(RING)) {
-            // up to 8 bytes of the match: three dwords around the source, one LDS round trip
-            const uint32_t d0 = src >> 2;
-            m.ring[((z.out_pos >> 2) & (RING - 1)) * S] = z.acc;          // the partial dword may be part of the source
-            const uint32_t r0 = m.ring[(d0 & (RING - 1)) * S];
-            const uint32_t r1 = m.ring[((d0 + 1) & (RING - 1)) * S];
-            const uint32_t r2 = m.ring[((d0 + 2) & (RING - 1)) * S];
-            uint64_t w = ((uint64_t) r0 | ((uint64_t) r1 << 32)) >> sh;
-            if (sh) w |= (uint64_t) r2 << (64u - sh);
-            if (z.copy_dist < 8u) {                 // overlapping copy: the first `dist` bytes repeat
-                const uint32_t s8 = 8u * z.copy_dist;
-                w &= (1ull << s8) - 1ull;
-                w |= w << s8;
-                if (2u * s8 < 64u) w |= w << (2u * s8);
-                if (4u * s8 < 64u) w |= w << (4u * s8);
-            }
-            n = z.copy_rem < (uint32_t) WT_INF_COPY ? z.copy_rem : (uint32_t) WT_INF_COPY;
-            bytes = w;
-            z.copy_rem -= n;
-        } else if (z.far_have) {                    // landed: the next <= 8 bytes wait in fq (never overlapping: dist > FAR)
-            uint64_t w = ((uint64_t) z.fq[0] | ((uint64_t) z.fq[1] << 32)) >> sh;
-            if (sh) w |= (uint64_t) z.fq[2] << (64u - sh);
-            n = z.far_have < (uint32_t) WT_INF_COPY ? z.far_have : (uint32_t) WT_INF_COPY;
-            bytes = w;
-            z.far_have -= n;
-            z.copy_rem -= n;
-            z.fq[0] = z.fq[2]; z.fq[1] = z.fq[3]; z.fq[2] = z.fq[4];
-        } else if (!z.far_pending) {
-            // beyond the ring: the lane's own output is read back (full dwords were stored as they filled up, the
-            // partial one is flushed now); the bytes land at the next round boundary and the lane idles until then
-            const uint32_t d0 = src >> 2;
-            if (z.out_pos & 3u) z.out[z.out_pos >> 2] = z.acc;
+    // ---- match bytes: from the ring (every lane reads it, the lanes inside a match near enough use it) ...
+    const bool cp = z.copy_rem != 0u;
+    const bool near = z.copy_dist <= (uint32_t) WT_INF_RING_DIST(RING);
+    const uint32_t src = z.out_pos - z.copy_dist;
+    const uint32_t sh = (src & 3u) * 8u, d0 = src >> 2;
+    m.ring[((z.out_pos >> 2) & (RING - 1)) * S] = z.acc;                  // the partial dword may be part of the source
+    const uint32_t r0 = m.ring[(d0 & (RING - 1)) * S];
+    const uint32_t r1 = m.ring[((d0 + 1) & (RING - 1)) * S];
+    const uint32_t r2 = m.ring[((d0 + 2) & (RING - 1)) * S];
+    uint64_t w = (uint64_t) wt_inf_alignbit(r1, r0, sh) | ((uint64_t) wt_inf_alignbit(r2, r1, sh) << 32);
+    {                                               // overlapping copy: the first `dist` (< 8) bytes repeat
+        const uint32_t dd = z.copy_dist, s8b = 8u * (dd & 7u);
+        const bool o8 = dd < 8u, o4 = dd < 4u, o2 = dd < 2u;
+        w &= o8 ? (1ull << s8b) - 1ull : ~0ull;
+        w |= o8 ? w << s8b : 0ull;
+        w |= o4 ? w << ((2u * s8b) & 63u) : 0ull;
+        w |= o2 ? w << ((4u * s8b) & 63u) : 0ull;
+    }
+    // ... or from the bytes a load beyond the ring has landed (never overlapping: dist > WT_INF_FAR)
+    const bool far_take = cp && !near && z.far_have != 0u;
+    const uint64_t wf = (uint64_t) wt_inf_alignbit(z.fq[1], z.fq[0], sh) | ((uint64_t) wt_inf_alignbit(z.fq[2], z.fq[1], sh) << 32);
+    const uint32_t nc = z.copy_rem < (uint32_t) WT_INF_COPY ? z.copy_rem : (uint32_t) WT_INF_COPY;
+    const uint32_t nf = z.far_have < (uint32_t) WT_INF_COPY ? z.far_have : (uint32_t) WT_INF_COPY;
+    const bool use_ring = cp && near;
+    const uint32_t took = use_ring ? nc : (far_take ? nf : 0u);
+    bytes = use_ring ? w : (far_take ? wf : bytes);
+    n = (use_ring || far_take) ? took : n;
+    z.copy_rem -= took;
+    z.far_have -= far_take ? nf : 0u;
+    z.fq[0] = far_take ? z.fq[2] : z.fq[0]; z.fq[1] = far_take ? z.fq[3] : z.fq[1]; z.fq[2] = far_take ? z.fq[4] : z.fq[2];
+    if (cp && !near && !far_take && !z.far_pending) {
+        // beyond the ring: the lane's own output is read back (full dwords were stored as they filled up, the
+        // partial one is flushed now); the bytes land at the next round boundary and the lane idles until then
+        if (z.out_pos & 3u) z.out[z.out_pos >> 2] = z.acc;
 #if defined(__HIP_DEVICE_COMPILE__)
-            const WT_AS_GLOBAL uint32_t *sp = z.out + d0;
-            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dword %1, %2, off offset:16"
-                         : "+v"(z.fpend.q), "+v"(z.fpend.t) : "v"(sp) : "memory");
+        const WT_AS_GLOBAL uint32_t *sp = z.out + d0;
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dword %1, %2, off offset:16"
+                     : "+v"(z.fpend.q), "+v"(z.fpend.t) : "v"(sp) : "memory");
 #else
-            for (int k = 0; k < 4; k++) z.fpend.q[k] = z.out[d0 + k];
-            z.fpend.t = z.out[d0 + 4];
+        for (int k = 0; k < 4; k++) z.fpend.q[k] = z.out[d0 + k];
+        z.fpend.t = z.out[d0 + 4];
 #endif
-            z.far_len = z.copy_rem < (uint32_t) WT_INF_FAR ? z.copy_rem : (uint32_t) WT_INF_FAR;
-            z.far_pending = true;
-        }
+        z.far_len = z.copy_rem < (uint32_t) WT_INF_FAR ? z.copy_rem : (uint32_t) WT_INF_FAR;
+        z.far_pending = true;
     }
-    if (n) wt_inf_put(z, m, bytes, n);
+    wt_inf_put(z, m, bytes, n);
 }
 
 // Flushes the last partial dword; returns the number of bytes produced or -(error code).
