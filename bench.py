@@ -26,6 +26,10 @@ RCCL after the timed region: AUC / bp / run counts by all_reduce, the Pearson mo
 0,1 by all_gather + ordered pairwise merge (reference statistics.c:442-456 is sequential).
 --shard replicas: every rank walks its own genome (weak scaling).
 """
+import os as _os
+# (before the HIP runtime starts: HIP folds its streams onto 4 hardware queues by default, and two streams sharing a queue
+#  run one after the other -- the pipe's copy / compute / result streams next to torch's own; measured +6 % on the file leg)
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import json
 import os
@@ -499,8 +503,9 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None):
 
 
 def genome_file_scale(n_tracks, mean_run):
-    """Largest genome scale (<= 1/3: the writing of the files is untimed but not free -- 6e9 intervals take a minute of
-    zlib on 16 cores) whose file set fits half of what /dev/shm (or WTAMD_BENCH_TMP) has free; >= 1 Gbp when it can."""
+    """Largest genome scale <= 1 (WTAMD_BENCH_GENOME_SCALE) whose file set fits half of what /dev/shm (or WTAMD_BENCH_TMP)
+    has free.  (The writing of the files is untimed but not free: 1.9e10 intervals, 90 GB of files, take ~3 minutes of
+    zlib on 16 cores at full scale.)"""
     import shutil
     base = os.environ.get("WTAMD_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
     try:
@@ -508,7 +513,7 @@ def genome_file_scale(n_tracks, mean_run):
     except Exception:
         free = 8e9
     per_bp = 0.293 * n_tracks * 16.0 / mean_run        # file bytes per genomic bp: 29.2 measured at 100 tracks, mean run 16
-    want = float(os.environ.get("WTAMD_BENCH_GENOME_SCALE", 1.0 / 3.0))
+    want = float(os.environ.get("WTAMD_BENCH_GENOME_SCALE", 1.0))
     fit = 0.5 * free / (per_bp * sum(GRCH38))
     return max(min(want, fit), 0.0)
 

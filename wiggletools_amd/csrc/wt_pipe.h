@@ -358,6 +358,7 @@ struct WtSlot {
     int64_t bw_res_bytes = -1, bw_res_secs = -1;     // what wtamd_pipe_bw_reserve was asked for (-1: nothing reserved)
     int64_t bw_bytes = 0, bw_stride = 0;             // of the batch in flight (a batch that overflowed its run lists is decoded again)
     int64_t bw_bound = 0;                            // the host's upper bound of its intervals
+    int bw_dec = 0;                                  // decode stream (and scratch) of the batch
     unsigned long long *h_bw_status = nullptr;       // pinned: error bits, pieces
     hipEvent_t e_bwc = nullptr, e_bw0 = nullptr, e_bw1 = nullptr;
     bool bw = false;                                 // the batch in flight came as file bytes
@@ -387,6 +388,15 @@ struct wtamd_pipe {
     std::vector<WtSlot> slots;
     int head = 0, tail = 0, acquired = -1, in_flight = 0, held = 0;
     hipStream_t s_copy = nullptr, s_comp = nullptr, s_out = nullptr, s_dec = nullptr;
+    // File-byte batches are inflated / decoded on the compute stream.  WTAMD_BW_DECODE_STREAMS=2: on two streams of their
+    // own taking turns, so that the next batch's inflate kernel takes the lanes the part-filled last batch of a
+    // chromosome leaves idle (a launch costs ~12 ms however few sections it holds).  Measured (round 4, 100 files x 24
+    // chromosomes at GRCh38 x 0.2): SLOWER, 0.75 s against 0.68 s -- the workgroups of inflate(k + 1) hold their CUs for
+    // 12 ms and the reduce kernels of batch k, which need whole CUs, wait behind them; the host then waits longer for
+    // batch k and, with two batches in flight, submits k + 2 later.  Kept as a switch, off.
+    hipStream_t s_decs[2] = {nullptr, nullptr};
+    int n_decs = 0;
+    int64_t bw_batches = 0;
     bool delta_failed = false;      // a batch had many inexact windows: Sum / Mean stay on the general kernel
     bool tile = false;
     bool compress = false;          // WTAMD_PIPE_COMPRESS: batches submitted from now on are merged on device before they travel
@@ -403,8 +413,10 @@ struct wtamd_pipe {
     int num_cu = 256;
     // File-byte batches: the inflate scratch is ONE per pipe -- every decode runs on the compute stream, in order, and
     // is through with the scratch before the next one starts (round 3 kept 0.8 GB of it in each of four slots).
-    void *d_bw_scratch = nullptr;
+    void *d_bw_scratch = nullptr;   // (the scratch of the decode stream in use: d_bw_scratches[k])
     int64_t bw_scratch_cap = 0;
+    void *d_bw_scratches[2] = {nullptr, nullptr};
+    int64_t bw_scratch_caps[2] = {0, 0};
     // ... and their run lists are sized from the densest batch seen so far (intervals / host bound), not from the bound:
     // the bound must assume 4-byte fixedStep items because the item type is inside the compressed stream, three times
     // what bedGraph sections hold.  A batch that does not fit reports WT_BW_ERR_CAPACITY and is decoded again at full
@@ -654,13 +666,18 @@ void wtamd_pipe_destroy(wtamd_pipe *p) {
     // everything still in flight must have left the buffers before they are freed
     if (p->s_copy) (void) hipStreamSynchronize(p->s_copy);
     if (p->s_comp) (void) hipStreamSynchronize(p->s_comp);
+    for (int k = 0; k < 2; k++)
+        if (p->s_decs[k]) (void) hipStreamSynchronize(p->s_decs[k]);
     if (p->s_out) (void) hipStreamSynchronize(p->s_out);
     for (auto &s : p->slots) wt_slot_free(s);
     if (p->s_copy) (void) hipStreamDestroy(p->s_copy);
     if (p->s_comp) (void) hipStreamDestroy(p->s_comp);
     if (p->s_out) (void) hipStreamDestroy(p->s_out);
     if (p->d_chains) (void) wt_dev_free(p->d_chains);
-    (void) wt_dev_free(p->d_bw_scratch);
+    for (int k = 0; k < 2; k++) {
+        (void) wt_dev_free(p->d_bw_scratches[k]);
+        if (p->s_decs[k]) (void) hipStreamDestroy(p->s_decs[k]);
+    }
     for (void *q : p->dead_dev) (void) wt_dev_free(q);
     for (void *q : p->dead_host) wt_host_free(q);
     delete p;
@@ -962,7 +979,20 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
         // run lists and the device-side seg_off[] (the authority downstream: the host's are upper bounds)
         // (on the COMPUTE stream: HIP maps its streams onto 4 hardware queues, and a fourth stream of the pipe landed
         // on the copy stream's queue -- the next batch's copy then waited behind this batch's inflate kernel)
-        p->s_dec = p->s_comp;
+        {
+            if (p->n_decs == 0) {
+                const char *e = getenv("WTAMD_BW_DECODE_STREAMS");
+                p->n_decs = (e && atoi(e) == 2) ? 2 : -1;
+                for (int k = 0; k < 2 && p->n_decs == 2; k++) WT_HIP(hipStreamCreateWithFlags(&p->s_decs[k], hipStreamNonBlocking));
+            }
+            const int k = p->n_decs == 2 ? (int) (p->bw_batches & 1) : 0;
+            p->bw_batches++;
+            p->s_dec = p->n_decs == 2 ? p->s_decs[k] : p->s_comp;
+            // the slot's run lists and outputs were last touched by the kernels of its previous batch on the compute
+            // stream (long collected); the scratch is per decode stream
+            p->d_bw_scratch = p->d_bw_scratches[k]; p->bw_scratch_cap = p->bw_scratch_caps[k];
+            s.bw_dec = k;
+        }
         if (!s.e_bwc) { WT_HIP(hipEventCreate(&s.e_bwc)); WT_HIP(hipEventCreate(&s.e_bw0)); WT_HIP(hipEventCreate(&s.e_bw1)); }
         if (!s.h_bw_status) WT_HIP(wt_host_alloc((void **) &s.h_bw_status, 64));
         const int64_t total = s.bw_off_bytes + wt_align256(bw_bytes + 64);
@@ -980,6 +1010,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
             const int64_t c = need_scr + need_scr / 4;
             WT_HIP(wt_dev_alloc(&p->d_bw_scratch, (size_t) c));
             p->bw_scratch_cap = c;
+            p->d_bw_scratches[s.bw_dec] = p->d_bw_scratch; p->bw_scratch_caps[s.bw_dec] = c;
         }
         if (!redo) memcpy(s.h_bw, bw_tracks, sizeof(wtamd_bw_track) * (size_t) N);
         s.h_bw_status[0] = ~0ull; s.h_bw_status[1] = 0;
