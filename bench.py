@@ -26,10 +26,6 @@ RCCL after the timed region: AUC / bp / run counts by all_reduce, the Pearson mo
 0,1 by all_gather + ordered pairwise merge (reference statistics.c:442-456 is sequential).
 --shard replicas: every rank walks its own genome (weak scaling).
 """
-import os as _os
-# (before the HIP runtime starts: HIP folds its streams onto 4 hardware queues by default, and two streams sharing a queue
-#  run one after the other -- the pipe's copy / compute / result streams next to torch's own; measured +6 % on the file leg)
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import json
 import os
@@ -541,7 +537,7 @@ def e2e_sharded(ctx, op, n_tracks, mean_run, mbp):
         r = dropin.reducer(op, its, n_set0=n_tracks // 2)
         runs, _ = dropin.drain_blocks(r)
         dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        t = torch.tensor([dt], dtype=torch.float64, device=ctx.cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         hs.free(); hf.free(); hv.free()
         return {"bp_per_s": ctx.world * L / float(t.item()), "seconds": float(t.item()), "bp_per_rank": L, "ranks": ctx.world,
@@ -556,6 +552,7 @@ class Ctx:
     def __init__(self, device, rank, world, store, shard):
         self.device, self.rank, self.world, self.store, self.shard = device, rank, world, store, shard
         self.replicas = world > 1 and shard == "replicas"
+        self.cdev = device
 
 
 def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_set0_arg=-1, f64=False, want_moments=False, values="k8"):
@@ -665,7 +662,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
             dist.barrier()
         torch.cuda.synchronize()
         hs, im, rm = one_pass(k, k == steps - 1)
-        t = torch.tensor([hs], dtype=torch.float64, device=device)
+        t = torch.tensor([hs], dtype=torch.float64, device=ctx.cdev)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)        # a pass is over when the slowest rank is
             dist.barrier()
@@ -675,15 +672,27 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
 
     # genome-wide scalars (RCCL over xGMI when world > 1): sums by all_reduce, Pearson by all_gather + ordered merge
     vec = torch.tensor([agg["bp"], agg["auc"], agg["runs"], agg["intervals"], agg["windows"], idx_tot, red_tot, gen_s[0]],
-                       dtype=torch.float64, device=device)
-    mom = torch.zeros((len(GRCH38), 6), dtype=torch.float64, device=device)
+                       dtype=torch.float64, device=ctx.cdev)
+    mom = torch.zeros((len(GRCH38), 6), dtype=torch.float64, device=ctx.cdev)
     for c, m in moments.items():
-        mom[c] = torch.tensor(m, dtype=torch.float64, device=device)
+        mom[c] = torch.tensor(m, dtype=torch.float64, device=ctx.cdev)
+    queue_check = None
     if world > 1:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         gathered = [torch.zeros_like(mom) for _ in range(world)]
         dist.all_gather(gathered, mom)
         mom = gathered[0] if replicas else torch.stack(gathered).sum(0)   # every row is computed by exactly one rank
+        # the work queue of the record pass: who got which chromosome
+        mine = torch.zeros(len(GRCH38), dtype=torch.int64, device=ctx.cdev)
+        for c in per_item:
+            mine[c] = 1
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        cnt = torch.stack(got).sum(0).cpu().numpy()
+        want = np.zeros(len(GRCH38), np.int64)
+        want[list(chrom_ids)] = 1 if not replicas else world
+        queue_check = {"every_chromosome_exactly_once": bool((cnt == want).all()), "chromosomes_per_rank": [int(g.sum().item()) for g in got],
+                       "how": "tickets from a counter in the rendezvous store" if store is not None and not replicas else ("replicas" if replicas else "static deal")}
     tot_bp, tot_auc, tot_runs, tot_int, tot_win, idx_all, red_all, gen_all = [float(x) for x in vec.tolist()]
     pearson = None
     if moments or world > 1:
@@ -761,15 +770,15 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
                      "kernel_ms": kernel_ms_sum, "index_kernel_ms": idx_all / passes,
                      "frac_with_index": alg_bytes / ((kernel_ms_sum + idx_all / passes) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "tile_equivalent_GBs": tile_equiv, "note": note},
-        "auc_check": tot_auc, "pearson_tracks_0_1": pearson, "output_runs": tot_runs,
+        "auc_check": tot_auc, "pearson_tracks_0_1": pearson, "output_runs": tot_runs, "work_queue_check": queue_check,
         "gen_seconds_total": gen_all, "pass_seconds": pass_s,
         "_chrom_lens": [chrom_lens[c] for c in chrom_ids],
     }
 
 
-def with_cpu(res, chrom_ids, ops, N, mean_run, many_core):
+def with_cpu(res, chrom_ids, ops, N, mean_run, many_core, target_s=12.0):
     lens = res.pop("_chrom_lens")
-    cb = cpu_baseline(chrom_ids, ops[-1], N, mean_run, lens, many_core=many_core)
+    cb = cpu_baseline(chrom_ids, ops[-1], N, mean_run, lens, many_core=many_core, target_s=target_s)
     res["cpu_baseline"] = cb
     res["speedup_vs_cpu_baseline"] = res["value"] / cb["value"]
     if "many_core" in cb and "value" in cb["many_core"]:
@@ -805,6 +814,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the GRCh38 chromosome lengths (1 = 3.1 Gbp)")
     ap.add_argument("--n-set0", type=int, default=-1, help="two-sample ops: tracks in the first set (default N/2)")
     ap.add_argument("--shard", default="genome", choices=["genome", "replicas"])
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, collectives on the host) -- a does-it-run check, not a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-many-core", action="store_true")
     ap.add_argument("--chroms", default=None, help="experiments: only these chromosomes of the configuration (comma separated indices)")
@@ -828,16 +839,22 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     store = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         try:
             store = dist.distributed_c10d._get_default_store()
         except Exception:
             store = None
     ctx = Ctx(device, rank, world, store, args.shard)
+    ctx.cdev = torch.device("cpu") if args.dist_backend == "gloo" else device       # where collectives' tensors live
 
     cfg = CONFIGS[args.config]
     ops = args.op.split(",") if args.op else cfg["ops"]
@@ -901,7 +918,10 @@ def main():
             try:
                 r = measure(ctx, name, ops_, N_, chroms_, mean_run_, args.sub_steps, 1, f64=f64, want_moments=moments, values=values)
                 if cpu and not args.no_cpu_baseline:
-                    with_cpu(r, chroms_, ops_, N_, mean_run_, not args.no_many_core)
+                    # (one evaluation thread, a 6 s sample: the many-core figure of these configurations is in DESIGN.md 5
+                    #  from `bench.py --config c3 / c4 / c5`, which still measures it; the default line spends its minutes
+                    #  on the whole-genome file set)
+                    with_cpu(r, chroms_, ops_, N_, mean_run_, False, target_s=6.0)
                 r.pop("_chrom_lens", None)
                 return slim(r)
             except Exception as e:
