@@ -820,6 +820,7 @@ def main():
     ap.add_argument("--no-many-core", action="store_true")
     ap.add_argument("--chroms", default=None, help="experiments: only these chromosomes of the configuration (comma separated indices)")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--moments", action="store_true", help="also compute the Pearson moments of tracks 0, 1 per chromosome (always on with N > 1)")
     ap.add_argument("--no-sub", action="store_true", help="skip the sub-records (c3 / c4 / c5, mean run 1 / 200, other kernels) of the default line")
     ap.add_argument("--sub-steps", type=int, default=2, help="timed passes of every sub-record")
     ap.add_argument("--f64", action="store_true", help="hand the tracks over as float64 values (general kernel)")
@@ -862,7 +863,7 @@ def main():
     chrom_ids = cfg["chroms"] if not args.chroms else [int(x) for x in args.chroms.split(",")]
     t_start = time.perf_counter()
     res = measure(ctx, args.config, ops, N, chrom_ids, args.mean_run, args.steps, args.warmup, scale=args.scale,
-                  n_set0_arg=args.n_set0, f64=args.f64, want_moments=args.config == "c5", values=args.values)
+                  n_set0_arg=args.n_set0, f64=args.f64, want_moments=args.config == "c5" or args.moments, values=args.values)
     default_line = args.config == "c2" and not args.op and not args.tracks and not args.chroms and args.scale == 1.0 and not args.f64 and args.values == "k8"
     # multi-GPU: the e2e bulk leg per rank (every GPU has its own PCIe link) -- all ranks take part
     e2e_multi = None
