@@ -164,7 +164,7 @@ struct EmuRun {
             for (int t = 0; t < T; t++) wt_delta_nextw(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
             wt_phase_lookback(P, c, k);
-            wt_delta_note_offset(P, c);
+            for (int t = 0; t < WT_BAD_SUB; t++) wt_delta_note_offset(P, c, t);
             for (int t = 0; t < T; t++) wt_delta_stage<OP>(P, c, d, lanes[t], t, T);
             for (int t = 0; t < T; t++) wt_delta_copy_out(P, c, d, t, T);
             wt_window_stats(P, c);
@@ -211,7 +211,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         std::vector<uint32_t> widx((size_t) tab.n_rows * n_tracks, 0);
         std::vector<unsigned long long> status(tab.n_windows, 0);
         counters.assign(WT_CTR_N, 0);
-        if (delta) { bad_list.assign(tab.n_windows + 1, 0); bad_goff.assign(tab.n_windows + 1, 0); }
+        if (delta) { bad_list.assign(tab.n_windows + 1, 0); bad_goff.assign((tab.n_windows + 1) * WT_BAD_SUB, 0); }
 
         WtParams &P = R.P;
         memset(&P, 0, sizeof(P));
@@ -228,7 +228,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         // few inexact windows: the general kernel rewrites the values of just those (the engine's
         // wt_patch_kernel); many: it redoes everything
         const bool patching = !delta && attempt == 1 && delta_bad > 0 && delta_bad * 4 <= (long long) delta_tab.n_windows &&
-                              delta_W >= R.plan.W && delta_W % R.plan.W == 0;
+                              delta_W >= R.plan.W && delta_W % R.plan.W == 0 && delta_W / R.plan.W <= WT_BAD_SUB;
         if (patching) {
             const int ratio = delta_W / R.plan.W;
             R.patch = true;
@@ -236,13 +236,16 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
                 const long long kd = bad_list[j];
                 const int ch = delta_tab.win_chrom[kd];
                 const long long m = kd - delta_tab.c_first_win[ch];
-                EmuRun::PatchGroup g;
-                g.goff = bad_goff[j];
+                // (as the patch kernel: every narrower window is an item of its own, at the offset the difference-array
+                //  kernel recorded for its sub-range)
                 for (int h = 0; h < ratio; h++) {
                     const long long mg = m * ratio + h;
-                    if (mg < tab.c_nwin[ch]) g.wins.push_back(tab.c_first_win[ch] + mg);
+                    if (mg >= tab.c_nwin[ch]) continue;
+                    EmuRun::PatchGroup g;
+                    g.goff = bad_goff[j * WT_BAD_SUB + h * (WT_BAD_SUB / ratio)];
+                    g.wins.push_back(tab.c_first_win[ch] + mg);
+                    R.groups.push_back(g);
                 }
-                R.groups.push_back(g);
             }
             patched = delta_bad;
         }

@@ -491,9 +491,14 @@ WT_DEV void wt_delta_mark_bad(const WtParams &P, WtCtx &c, long long k) {
     c.sh->bad_slot = (int32_t) slot;
     if (P.bad_list) P.bad_list[slot] = (int32_t) k;
 }
-// after the look-back (same lane): where the window's runs start
-WT_DEV void wt_delta_note_offset(const WtParams &P, WtCtx &c) {
-    if (c.sh->bad_slot >= 0 && P.bad_goff) P.bad_goff[c.sh->bad_slot] = c.sh->goffset;
+// after the look-back (lanes 0 .. 15 of the wave that ran it): where the window's runs start, and where the runs of each
+// of its 16 sub-ranges start (the emitted bitmap's prefix counts are there: wt_delta_escan_wave) -- the patch kernel's
+// narrower windows then need no order among themselves (round 4: a patched 8192-bp window was four 2048-bp windows done
+// one after the other by one workgroup, because each one's output offset was the previous one's plus its run count).
+#define WT_BAD_SUB 16
+WT_DEV void wt_delta_note_offset(const WtParams &P, WtCtx &c, int lane) {
+    if (c.sh->bad_slot >= 0 && P.bad_goff && lane < WT_BAD_SUB)
+        P.bad_goff[(long long) c.sh->bad_slot * WT_BAD_SUB + lane] = c.sh->goffset + (long long) c.epfx[(lane * P.n_words) / WT_BAD_SUB];
 }
 
 // redo of a window: clear the accumulators only (the exponent range is kept)

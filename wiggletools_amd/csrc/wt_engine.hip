@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
         // (and the predecessors get that much longer to publish)
         if (tid < 64) {
             wt_lookback_complete(P, c, k, tid, mine);
-            if (tid == 0) wt_delta_note_offset(P, c);       // (lane 0 set the offset in the look-back)
+            wt_delta_note_offset(P, c, tid);                // (lane 0 set the offset in the look-back: same wave, LDS in order)
         }
         WT_TICK(6);
         wt_delta_stage<OP>(P, c, d, L, tid, nt);
@@ -359,9 +359,9 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
 // could not prove exact (a NaN, an Inf, too wide a dynamic range).  That kernel has already emitted
 // those windows' runs -- coordinates, run count, position in the output -- so this one only has
 // to recompute their values in the reference's own summation order and store them at the recorded
-// offsets: no ticket, no look-back, no statistics.  One difference-array window (4096 bp) is
-// `ratio` general windows; they are done in order by one workgroup, the run offset advancing by
-// each one's run count.
+// offsets: no ticket, no look-back, no statistics.  One difference-array window (8192 bp) is
+// `ratio` general windows; the difference-array kernel recorded the run offset of 16 sub-ranges of
+// every such window, so every (window, sub-window) pair is a work item of its own.
 struct WtPatchArgs {
     const int32_t *bad_list;            // difference-array window ids (slot order)
     const long long *bad_goff;          // first run of each
@@ -382,14 +382,19 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_patch_kernel
     const int tid = threadIdx.x, nt = blockDim.x;
     const long long n_bad = (long long) *Q.n_bad;
     const int N = P.n_tracks, NC = MULTI ? P.chunk_tracks : N, n_chunks = MULTI ? P.n_chunks : 1;
-    for (long long j = blockIdx.x; j < n_bad; j += gridDim.x) {
+    // work items = (window the difference-array kernel recorded, narrower window h inside it): independent of one
+    // another -- the recording kernel left the run offset of every sub-range (wt_delta_note_offset)
+    const long long n_items = n_bad * Q.ratio;
+    for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const long long j = item / Q.ratio;
+        const int h = (int) (item - j * Q.ratio);
         const long long kd = Q.bad_list[j];
         const int ch = Q.d_win_chrom[kd];
         const long long m = kd - Q.d_c_first_win[ch];
-        long long goff = Q.bad_goff[j];
-        for (int h = 0; h < Q.ratio; h++) {
+        const long long goff = Q.bad_goff[j * WT_BAD_SUB + h * (WT_BAD_SUB / Q.ratio)];
+        {
             const long long mg = m * Q.ratio + h;
-            if (mg >= P.c_nwin[ch]) break;                  // workgroup-uniform
+            if (mg >= P.c_nwin[ch]) continue;               // workgroup-uniform
             const long long k = P.c_first_win[ch] + mg;
             __syncthreads();                                // the previous window is done with the shared block
             if (tid == 0) wt_phase_header(P, c, k);
@@ -446,7 +451,6 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_patch_kernel
             wt_phase_eval_finish<OP, ValT, ScrT, K>(P, c, A, L, tid, nt);
             __syncthreads();
             wt_phase_write<OP, ValT, K>(P, c, L, tid, nt);
-            goff += n_emit;
         }
     }
 }
@@ -1305,7 +1309,7 @@ static hipError_t wt_launch_patch_t(const WtParams &P, const WtPatchArgs &Q, int
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
     long long g = (long long) num_cu * per_cu;
-    if (g > n_bad) g = n_bad;
+    if (g > n_bad * Q.ratio) g = n_bad * Q.ratio;
     if (g < 1) g = 1;
     hipLaunchKernelGGL(kern, dim3((unsigned) g), dim3((unsigned) T), (size_t) lds, s, P, Q);
     return hipGetLastError();
@@ -1357,7 +1361,7 @@ static int wt_launch_patch(wtamd_trackset *ts, int delta_W, int op, uint32_t fla
     WtPlan plan;
     std::string err;
     if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err)) return wt_fail(WTAMD_ERR_INTERNAL, err);
-    if (plan.scratch_slab > 0 || plan.W > delta_W || delta_W % plan.W != 0 || !ts->scratch_f32 || ts->value_f64)
+    if (plan.scratch_slab > 0 || plan.W > delta_W || delta_W % plan.W != 0 || delta_W / plan.W > WT_BAD_SUB || !ts->scratch_f32 || ts->value_f64)
         return wt_fail(WTAMD_ERR_INTERNAL, "no general plan compatible with the difference-array windows");
     WtWindows *dw = nullptr, *w = nullptr;
     int rc = wt_get_windows(ts, delta_W, &dw, s);
@@ -1472,8 +1476,8 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
         if (w->cap_bad < nwin) {
             int64_t c1 = w->cap_bad, c2 = w->cap_bad;
             WT_HIP(wt_grow(&w->d_bad_list, &c1, nwin));
-            WT_HIP(wt_grow(&w->d_bad_goff, &c2, nwin));
-            w->cap_bad = c1 < c2 ? c1 : c2;
+            WT_HIP(wt_grow(&w->d_bad_goff, &c2, nwin * WT_BAD_SUB));
+            w->cap_bad = c1 < c2 / WT_BAD_SUB ? c1 : c2 / WT_BAD_SUB;
         }
         L.P.bad_list = w->d_bad_list;
         L.P.bad_goff = w->d_bad_goff;

@@ -704,8 +704,9 @@ WT_HD void wt_inf_step(WtInflateT<RING> &z, const WtInfMem &m) {
     const uint32_t r1 = m.ring[((d0 + 1) & (RING - 1)) * S];
     const uint32_t r2 = m.ring[((d0 + 2) & (RING - 1)) * S];
     uint64_t w = (uint64_t) wt_inf_alignbit(r1, r0, sh) | ((uint64_t) wt_inf_alignbit(r2, r1, sh) << 32);
-    {                                               // overlapping copy: the first `dist` (< 8) bytes repeat
-        const uint32_t dd = z.copy_dist, s8b = 8u * (dd & 7u);
+    const uint32_t nc = z.copy_rem < (uint32_t) WT_INF_COPY ? z.copy_rem : (uint32_t) WT_INF_COPY;
+    if (wt_inf_any(cp && z.copy_dist < nc)) {      // overlapping copy (run-length-like matches: rare in record data --
+        const uint32_t dd = z.copy_dist, s8b = 8u * (dd & 7u);     // a wavefront usually skips this): the first `dist` bytes repeat
         const bool o8 = dd < 8u, o4 = dd < 4u, o2 = dd < 2u;
         w &= o8 ? (1ull << s8b) - 1ull : ~0ull;
         w |= o8 ? w << s8b : 0ull;
@@ -715,7 +716,6 @@ WT_HD void wt_inf_step(WtInflateT<RING> &z, const WtInfMem &m) {
     // ... or from the bytes a load beyond the ring has landed (never overlapping: dist > WT_INF_FAR)
     const bool far_take = cp && !near && z.far_have != 0u;
     const uint64_t wf = (uint64_t) wt_inf_alignbit(z.fq[1], z.fq[0], sh) | ((uint64_t) wt_inf_alignbit(z.fq[2], z.fq[1], sh) << 32);
-    const uint32_t nc = z.copy_rem < (uint32_t) WT_INF_COPY ? z.copy_rem : (uint32_t) WT_INF_COPY;
     const uint32_t nf = z.far_have < (uint32_t) WT_INF_COPY ? z.far_have : (uint32_t) WT_INF_COPY;
     const bool use_ring = cp && near;
     const uint32_t took = use_ring ? nc : (far_take ? nf : 0u);
