@@ -371,6 +371,30 @@ struct WtPatchArgs {
     int ratio;                          // its window width / this launch's
 };
 
+__device__ __forceinline__ long long wt_lane_lower_bound(const int32_t *fin, long long lo, long long hi, long long g, long long b);
+
+// The narrow-window index rows the patch kernel is going to read, and only those: for every window the
+// difference-array kernel recorded, the ratio + 1 boundaries inside it, per track, by binary search.  (Round 3 built the
+// WHOLE index at the patch kernel's window width whenever a launch had a window to patch -- 4 x the rows of the
+// 8192-bp index, a third of a millisecond per chromosome for a few hundred windows.)
+__global__ void __launch_bounds__(256) wt_patch_index_kernel(const WtParams P, const WtPatchArgs Q) {
+    const long long n_bad = (long long) *Q.n_bad;
+    const int N = P.n_tracks, R1 = Q.ratio + 1;
+    const long long total = n_bad * R1 * N;
+    for (long long t = (long long) blockIdx.x * 256 + threadIdx.x; t < total; t += (long long) gridDim.x * 256) {
+        const long long j = t / ((long long) R1 * N);
+        const int rem = (int) (t - j * R1 * N), r = rem / N, i = rem - r * N;
+        const long long kd = Q.bad_list[j];
+        const int ch = Q.d_win_chrom[kd];
+        const long long m = (kd - Q.d_c_first_win[ch]) * Q.ratio + r;
+        if (m > P.c_nwin[ch]) continue;             // (row c_nwin is the chromosome's last boundary)
+        const long long seg = (long long) ch * N + i;
+        const long long s0 = P.seg_off[seg], n = P.seg_off[seg + 1] - s0;
+        const long long b = (long long) P.cbase[ch] + (m << P.logW);
+        P.widx[(P.c_first_win[ch] + ch + m) * N + i] = (uint32_t) wt_lane_lower_bound(P.finish + s0, 0, n, n >> 1, b);
+    }
+}
+
 template <int OP, int K, bool MULTI>
 __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_patch_kernel(const WtParams P, const WtPatchArgs Q) {
     typedef float ValT;
@@ -1368,10 +1392,6 @@ static int wt_launch_patch(wtamd_trackset *ts, int delta_W, int op, uint32_t fla
     if (rc != WTAMD_OK) return rc;
     rc = wt_get_windows(ts, plan.W, &w, s);
     if (rc != WTAMD_OK) return rc;
-    if (!w->indexed) {
-        rc = wt_build_index(ts, w, plan, s);
-        if (rc != WTAMD_OK) return rc;
-    }
     WtParams P;
     wt_fill_params(ts, w, plan, P);
     P.op = op; P.flags = flags; P.n_set0 = 0;
@@ -1383,6 +1403,14 @@ static int wt_launch_patch(wtamd_trackset *ts, int delta_W, int op, uint32_t fla
     Q.n_bad = ts->d_counters + WT_CTR_DELTA_BAD;
     Q.d_win_chrom = dw->d_win_chrom; Q.d_c_first_win = dw->d_cfirst;
     Q.ratio = delta_W / plan.W;
+    if (!w->indexed) {
+        // no index at this window width yet: only the rows of the recorded windows are filled in (w->indexed stays false)
+        long long blocks = (n_bad * (Q.ratio + 1) * ts->n_tracks + 255) / 256;
+        if (blocks > 4ll * ts->num_cu) blocks = 4ll * ts->num_cu;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(wt_patch_index_kernel, dim3((unsigned) blocks), dim3(256), 0, s, P, Q);
+        WT_HIP(hipGetLastError());
+    }
     const bool multi = plan.n_chunks > 1;
     hipError_t e;
 #define WT_PATCH_GO(OPC, KK, MM) e = wt_launch_patch_t<OPC, KK, MM>(P, Q, plan.T, plan.lds_bytes, ts->num_cu, n_bad, s)
