@@ -147,15 +147,18 @@ struct EmuRun {
                 int lo; bool ok;
                 scale = guess;
                 if (!wt_delta_window_verdict(P, d, guess, lo, ok)) {
-                    n_redo++;
-                    for (int t = 0; t < T; t++) wt_delta_rezero<QQ>(P, c, d, t, T);
-                    if (!ok) wt_delta_mark_bad(P, c, k);
-                    for (int ch = 0; ch < nchunks; ch++) {
-                        if (nchunks > 1) ranges(ch);
-                        for (int t = 0; t < T; t++) wt_delta_pass2<QQ, DF>(P, c, d, lo, ok, false, false, t, T, std::min(T, P.n_tracks - ch * T));
+                    if (!ok) {
+                        wt_delta_mark_bad(P, c, k);         // (values rewritten by the patch; the structure is in place)
+                    } else {
+                        n_redo++;
+                        for (int t = 0; t < T; t++) wt_delta_rezero<QQ>(P, c, d, t, T);
+                        for (int ch = 0; ch < nchunks; ch++) {
+                            if (nchunks > 1) ranges(ch);
+                            for (int t = 0; t < T; t++) wt_delta_pass2<QQ, DF>(P, c, d, lo, ok, false, false, t, T, std::min(T, P.n_tracks - ch * T));
+                        }
+                        scale = lo;
+                        guess = lo;
                     }
-                    scale = lo;
-                    if (ok) guess = lo;
                 }
             }
             for (int t = 0; t < T; t++) wt_delta_scan1<QQ>(P, c, d, dl[t], t, T);

@@ -291,9 +291,15 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             bool ok;
             scale = guess;
             if (!wt_delta_window_verdict(P, d, guess, lo, ok)) {      // workgroup-uniform
+              if (!ok) {
+                // not provably exact whatever the unit: the patch kernel rewrites this window's values, and everything
+                // else about it -- breakpoints, coverage, run count -- is in place after the speculative pass.  (It used
+                // to be redone like the windows below: twice the time of a window, during which every later window sat
+                // in its look-back; 5 % such windows cost the kernel a third more time, round 4.)
+                if (tid == 0) wt_delta_mark_bad(P, c, k);
+              } else {
                 __syncthreads();            // every lane has read the verdict fields
                 wt_delta_rezero<QQ>(P, c, d, tid, nt);
-                if (!ok && tid == 0) wt_delta_mark_bad(P, c, k);
                 __syncthreads();
                 for (int ch = 0; ch < nchunks; ch++) {
                     if (nchunks > 1) {
@@ -306,7 +312,8 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
                     __syncthreads();
                 }
                 scale = lo;
-                if (ok) guess = lo;
+                guess = lo;
+              }
             }
         }
         WT_MARK(105);
