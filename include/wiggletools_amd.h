@@ -528,9 +528,6 @@ int wtamd_pipe_submit_bw(wtamd_pipe *, int64_t n_bytes, int64_t n_sections, cons
  * once x 64 lanes): a batch of about that many sections fills the GPU exactly once -- fewer leave SIMDs idle, a
  * few more cost a whole second round. */
 int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *);
-/* A hint, once per pipe: file-byte batches of about n_bytes / n_sections are coming.  The pipe page-locks its slots'
- * staging ahead, side by side on threads of their own (WTAMD_PIN_AHEAD=0: not). */
-int wtamd_pipe_bw_expect(wtamd_pipe *, int64_t n_bytes, int64_t n_sections);
 /* Why the last wtamd_pipe_collect of a file-byte batch failed: the device decoder's error bits (1 corrupt zlib stream or
  * Adler-32 mismatch, 2 malformed section, 4 items outside their index leaf's extents / out of order, 8 coordinate above
  * the maximum, 16 more intervals than the bound); 0: it did not fail there.  The drop-in layer answers 1 / 2 / 4 by going

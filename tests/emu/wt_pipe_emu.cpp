@@ -447,8 +447,6 @@ int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *p) { return p ? 4096 : 0; 
 
 unsigned wtamd_pipe_bw_error(const wtamd_pipe *p) { return p ? p->last_bw_err : 0u; }
 
-int wtamd_pipe_bw_expect(wtamd_pipe *p, int64_t, int64_t) { return p ? WTAMD_OK : WTAMD_ERR_ARG; }
-
 int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, uint8_t **bytes, wtamd_bw_section **sections) {
     if (!p || p->acquired < 0 || n_bytes < 0 || n_sections < 0 || !bytes || !sections) { g_err = "wtamd_pipe_bw_reserve: bad arguments"; return WTAMD_ERR_ARG; }
     Slot &s = p->slots[(size_t) p->acquired];

@@ -284,7 +284,6 @@ BwReader *bwdev_reader(const TrackSource &s);
 bool bwdev_eligible(const Feeder &F);
 bool bwdev_drain_and_submit(Feeder &F);
 void bwdev_fallback(Feeder &F, const char *chrom, int32_t lo, unsigned why);
-void bwdev_expect(Feeder &F);
 
 // Drains the children into pipeline slots and keeps `depth` batches in flight.
 struct Feeder {
@@ -434,7 +433,6 @@ struct Feeder {
         // a batch of file bytes should fill the GPU's inflate lanes once (a little less: a second round for a few
         // sections would cost as much as the first)
         bw_target_sections = env_i64("WTAMD_BW_BATCH_SECTIONS", bw_mode ? std::max<int64_t>(wtamd_pipe_bw_fill_sections(pipe) * 31 / 32, 64) : 0);
-        if (bw_mode) bwdev_expect(*this);
         n_slots_open = n_slots ? std::min(std::max(n_slots, 2), 8) : 3;     // (wtamd_pipe_create's own clamp)
         if (depth > n_slots_open - 1) depth = n_slots_open - 1;
         n_pipes = (int) pipes.size();
@@ -1330,29 +1328,6 @@ bool bwdev_eligible(const Feeder &F) {
         }
     }
     return true;
-}
-
-// What a full batch is going to weigh, from the files' indexes: the pipes pin their staging now, on threads of their
-// own, while the priming batches (65 536 bp, 512 kbp, ...) are under way.
-void bwdev_expect(Feeder &F) {
-    double bytes = 0, leaves = 0, bp = 0;
-    for (const auto &s : F.src) {
-        BwReader *r = bwdev_reader(s);
-        int64_t n = 0;
-        const WtBwLeaf *L = wt_bw_leaves(r->bw, &n);
-        for (int64_t q = 0; q < n; q += std::max<int64_t>(n / 64, 1)) {     // a sample of the leaves is enough
-            bytes += (double) L[q].size; leaves += 1;
-            if (L[q].start_chrom == L[q].end_chrom) bp += (double) L[q].end_base - (double) L[q].start_base;
-        }
-    }
-    if (leaves <= 0 || bp <= 0) return;
-    const double per_sec = bytes / leaves;
-    // a batch is cut by sections, by bytes or by the slot's output capacity (max_runs >= its span in bp)
-    double secs = (double) F.bw_target_sections;
-    secs = std::min(secs, (double) F.bw_target_bytes / per_sec);
-    secs = std::min(secs, (double) F.max_runs / (bp / leaves) * (double) F.n_tracks());
-    for (wtamd_pipe *q : F.pipes)
-        if (wtamd_pipe_bw_expect(q, (int64_t) (secs * per_sec * 1.10), (int64_t) (secs * 1.10) + F.n_tracks()) != WTAMD_OK) die("wtamd_pipe_bw_expect");
 }
 
 // Where every track stands: read off the readers (their current element, or what a Multiplexer had

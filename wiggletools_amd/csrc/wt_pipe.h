@@ -222,28 +222,6 @@ static void wt_host_free(void *q) {
     (void) hipHostFree(q);
 }
 
-// Page-locks `count` buffers of `bytes` each on threads of their own and leaves them resting in the pool: a pipe that
-// knows what its slots are going to ask for (file-byte batches: wtamd_pipe_bw_expect) has them pinned side by side
-// while its first, small batches are under way, instead of one after the other inside the submits of its first full
-// batches (hipHostMalloc pins at ~6.7 GB/s per call: 3.1 GB of staging were 0.45 s of the cold run's submits, round 4).
-static void wt_pin_ahead(int device, size_t bytes, int count) {
-    bytes = wt_pool_round(bytes);
-    if (bytes < (1u << 20)) return;
-    for (int k = 0; k < count; k++) {
-        std::thread([device, bytes] {
-            if (device >= 0) (void) hipSetDevice(device);
-            void *q = nullptr;
-            if (hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return; }
-            std::lock_guard<std::mutex> lk(g_pinned_pool.mu);
-            g_pinned_pool.size_of[q] = bytes;
-            g_pinned_pool.misses++;
-            g_pinned_pool.miss_bytes += bytes;
-            g_pinned_pool.free_list.emplace(bytes, q);
-            g_pinned_pool.pooled += bytes;
-        }).detach();
-    }
-}
-
 // Device buffers of a pipe, the same way: a pipe frees everything it holds when its reducer reaches the end of the data
 // (35 hipFree calls, each of which synchronises the device and unmaps gigabytes), and the next reducer of the process
 // maps it all again -- on some hosts that made the SECOND run of a job 2 x slower than the first (0.9 s inside
@@ -446,7 +424,6 @@ struct wtamd_pipe {
     double bw_density = -1.0;
     int64_t bw_redone = 0;
     unsigned last_bw_err = 0;       // wtamd_pipe_bw_error
-    bool pinned_ahead = false;      // wtamd_pipe_bw_expect ran
     wtamd_pipe_stats st{};
 };
 
@@ -780,18 +757,6 @@ unsigned wtamd_pipe_bw_error(const wtamd_pipe *p) { return p ? p->last_bw_err : 
 int64_t wtamd_pipe_bw_fill_sections(const wtamd_pipe *p) {
     if (!p || p->slots.empty() || !p->slots[0].ts) return 0;
     return (int64_t) wt_bw_fill_sections(p->slots[0].ts->num_cu);
-}
-
-int wtamd_pipe_bw_expect(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections) {
-    if (!p || n_bytes < 0 || n_sections < 0) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_bw_expect: bad arguments");
-    static const bool off = getenv("WTAMD_PIN_AHEAD") && atoi(getenv("WTAMD_PIN_AHEAD")) == 0;
-    if (off || p->pinned_ahead) return WTAMD_OK;
-    p->pinned_ahead = true;
-    // the staging wtamd_pipe_bw_reserve is going to ask for, once per slot (same layout and slack as there)
-    const int64_t off_bytes = wt_align256((int64_t) sizeof(wtamd_bw_track) * p->cfg.n_tracks) + wt_align256((int64_t) sizeof(wtamd_bw_section) * n_sections);
-    const int64_t need = off_bytes + wt_align256(n_bytes + 64);
-    wt_pin_ahead(p->device, (size_t) (need + need / 4), (int) p->slots.size());
-    return WTAMD_OK;
 }
 
 int wtamd_pipe_bw_reserve(wtamd_pipe *p, int64_t n_bytes, int64_t n_sections, uint8_t **bytes, wtamd_bw_section **sections) {
