@@ -958,7 +958,7 @@ void red_open(RedState *R, int op, uint32_t flags, int n_set0) {
     // (file-byte batches are sized to fill the GPU's inflate lanes: ~65 000 sections, ~11 Mbp at 100 dense tracks)
     bool all_bw = !R->fd.src.empty();
     for (const auto &s : R->fd.src) all_bw = all_bw && bwdev_reader(s) != nullptr;
-    R->fd.open(d, env_i64("WTAMD_BATCH_RUNS", all_bw ? (16 << 20) : (4 << 20)), R->fd.depth + (all_bw ? 2 : 1), kReducerFirstSpan);
+    R->fd.open(d, env_i64("WTAMD_BATCH_RUNS", all_bw ? (24 << 20) : (4 << 20)), R->fd.depth + (all_bw ? 2 : 1), kReducerFirstSpan);
 }
 
 WiggleIterator *make_reducer(Multiplexer *m, int op) {
@@ -1403,10 +1403,44 @@ bool bwdev_plan(Feeder &F) {
         }
         lo = (int32_t) m;
     }
-    const int64_t hi64 = (int64_t) lo + F.span;
+    // The cut: as far as the span goes (it grows by 8 per batch from the priming 65 536 bp), but never so far that the
+    // batch holds more sections than the GPU's inflate lanes -- every lane inflates one section, a launch takes ~13 ms
+    // whether 80 % or 100 % of the lanes are busy, and the sections beyond the lanes wait for a second round (+6 ms:
+    // 32 Mbp batches measured 19.5 ms against 12.5 ms for 16 Mbp ones).  The index tells how many sections a cut
+    // takes, so the cut is found by bisection instead of being steered by the previous batch's density (round 3; its
+    // batches wobbled around 80 % of the lanes because the span was also capped by the slots' output capacity).
+    const double t_plan0 = g_trace ? now_ms() : 0;
+    int64_t hi64 = std::min<int64_t>((int64_t) lo + F.span, INT32_MAX);
+    {
+        auto weigh = [&](int64_t cut, int64_t &secs, int64_t &bytes) {
+            secs = bytes = 0;
+            for (const auto &t : F.bwt) {
+                if (!t.have || t.cname != F.chrom || t.cursor >= t.info.count) continue;
+                const WtBwLeaf *L = wt_bw_leaves(t.r->bw, nullptr) + t.info.first;
+                const int64_t stop = std::min<int64_t>(cut, t.clip_hi);
+                // leaves from the cursor on that start below the cut, and the sentinel's
+                int64_t a = t.cursor, b2 = t.info.count;
+                while (a < b2) { const int64_t mid = (a + b2) / 2; if ((int64_t) L[mid].start_base + 1 < stop) a = mid + 1; else b2 = mid; }
+                int64_t e = a;
+                if (e < t.info.count && (int64_t) L[e].start_base + 1 < (int64_t) t.clip_hi) e++;
+                secs += e - t.cursor;
+                if (e > t.cursor) bytes += (int64_t) (L[e - 1].offset + L[e - 1].size - L[t.cursor].offset);     // (leaves of a chromosome lie one after the other)
+            }
+        };
+        int64_t secs, bytes;
+        weigh(hi64, secs, bytes);
+        if ((secs > F.bw_target_sections || bytes > F.bw_target_bytes) && hi64 > (int64_t) lo + F.min_span) {
+            int64_t good = (int64_t) lo + F.min_span, bad = hi64;        // the shortest cut always goes (progress)
+            while (bad - good > 64) {
+                const int64_t mid = good + (bad - good) / 2;
+                weigh(mid, secs, bytes);
+                if (secs > F.bw_target_sections || bytes > F.bw_target_bytes) bad = mid; else good = mid;
+            }
+            hi64 = good;
+        }
+    }
     const int32_t hi = hi64 >= INT32_MAX ? INT32_MAX : (int32_t) hi64;
 
-    const double t_plan0 = g_trace ? now_ms() : 0;
     wtamd_pipe_batch b;
     F.next_fill_pipe();
     if (wtamd_pipe_acquire(F.pipe, &b) != WTAMD_OK) die("wtamd_pipe_acquire");
@@ -1487,15 +1521,9 @@ bool bwdev_plan(Feeder &F) {
         }
         if (first > hi && first < INT32_MAX) F.next_lo = (int32_t) first;
     }
-    // steer the span towards the section / byte budget, bounded by the slot's output capacity
+    // the span grows by 8 per batch up to the slot's output capacity; the section / byte budget cuts it short (above)
     const int64_t max_span = F.max_runs < ((int64_t) 1 << 31) ? F.max_runs : ((int64_t) 1 << 31);
-    int64_t want = F.span * 2;
-    if (n_bytes > 0 && !P.secs.empty()) {
-        const double bp = (double) std::max<int64_t>((int64_t) hi - lo, 1);
-        const double w = std::min((double) F.bw_target_bytes / ((double) n_bytes / bp), (double) F.bw_target_sections / ((double) P.secs.size() / bp));
-        want = w > 4e9 ? (int64_t) 4e9 : (int64_t) w;
-        if (want > F.span * 8) want = F.span * 8;
-    }
+    int64_t want = std::max<int64_t>(F.span, (int64_t) hi - lo) * 8;
     if (want < F.min_span) want = F.min_span;
     F.span = want < max_span ? want : max_span;
     return true;
