@@ -430,9 +430,11 @@ struct Feeder {
         }
         for (wtamd_pipe *q : pipes)
             if (compress_on && wtamd_pipe_set_compress(q, 1) != WTAMD_OK) die("wtamd_pipe_set_compress");
-        // a batch of file bytes should fill the GPU's inflate lanes once (a little less: a second round for a few
-        // sections would cost as much as the first)
-        bw_target_sections = env_i64("WTAMD_BW_BATCH_SECTIONS", bw_mode ? std::max<int64_t>(wtamd_pipe_bw_fill_sections(pipe) * 31 / 32, 64) : 0);
+        // a batch of file bytes should fill the GPU's inflate lanes once, never more (a second round for a few sections
+        // costs half a launch again).  27/32 of the lanes: with two wavefronts per SIMD a launch's time grows with its
+        // fill (12.5 ms at 80 %, 15 ms at 100 %: the sections per millisecond stay the same), and the smaller batches keep
+        // less memory in flight -- measured (round 4, GRCh38 x 0.5): 80 / 88 / 94 / 100 % within noise of each other.
+        bw_target_sections = env_i64("WTAMD_BW_BATCH_SECTIONS", bw_mode ? std::max<int64_t>(wtamd_pipe_bw_fill_sections(pipe) * 27 / 32, 64) : 0);
         n_slots_open = n_slots ? std::min(std::max(n_slots, 2), 8) : 3;     // (wtamd_pipe_create's own clamp)
         if (depth > n_slots_open - 1) depth = n_slots_open - 1;
         n_pipes = (int) pipes.size();
@@ -958,7 +960,7 @@ void red_open(RedState *R, int op, uint32_t flags, int n_set0) {
     // (file-byte batches are sized to fill the GPU's inflate lanes: ~65 000 sections, ~11 Mbp at 100 dense tracks)
     bool all_bw = !R->fd.src.empty();
     for (const auto &s : R->fd.src) all_bw = all_bw && bwdev_reader(s) != nullptr;
-    R->fd.open(d, env_i64("WTAMD_BATCH_RUNS", all_bw ? (24 << 20) : (4 << 20)), R->fd.depth + (all_bw ? 2 : 1), kReducerFirstSpan);
+    R->fd.open(d, env_i64("WTAMD_BATCH_RUNS", all_bw ? (16 << 20) : (4 << 20)), R->fd.depth + (all_bw ? 2 : 1), kReducerFirstSpan);
 }
 
 WiggleIterator *make_reducer(Multiplexer *m, int op) {
