@@ -732,11 +732,28 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
             traffic = None
     bound = "hbm"
     note = None
+    issue = None
     if kern == 0:
         o = ops[-1]
         if o in ("median", "wilcoxon", "mwu"):
             bound, note = "issue", ("register-column reducer: bound by instruction issue, not by HBM -- the frac against the HBM peak is "
-                                    "reported for the record only (DESIGN 10)")
+                                    "reported for the record only (DESIGN 10); roofline.issue prices it against the VALU issue peak")
+            # VALU instructions per output run from the SQ counters of an earlier profile (profiles/issue.json, like
+            # traffic.json for the HBM bytes) x this run's output runs / this run's kernel time, against what the chip
+            # can issue: 256 CUs x 4 SIMDs x one wave-wide VALU instruction per 4 cycles at 2.4 GHz
+            ipath = os.path.join(ROOT, "profiles", "issue.json")
+            if os.path.exists(ipath):
+                try:
+                    ij = json.load(open(ipath)).get("median" if o == "median" else "wilcoxon")
+                    if ij:
+                        peak = 256 * 4 * 2.4e9 / 4.0
+                        ach = ij["valu_instructions_per_output_run"] * tot_runs / (kernel_ms_sum * 1e-3)
+                        issue = {"bound": "valu issue", "achieved": ach, "peak": peak, "unit": "wave-wide VALU instructions/s", "frac": ach / peak,
+                                 "valu_instructions_per_output_run": ij["valu_instructions_per_output_run"],
+                                 "salu_instructions_per_output_run": ij.get("salu_instructions_per_output_run"),
+                                 "source": ij.get("source")}
+                except Exception:
+                    issue = None
         else:
             bound, note = "valu", "f32->f64 widen + add per (track, position): VALU bound (profiles/: VALUBusy)"
     return {
@@ -771,7 +788,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
                      "algorithmic_bytes_per_launch": alg_bytes, "launch": "the %d launches of one pass (one per chromosome%s)" % (len(per_item) * len(ops) if world == 1 else int(len(chrom_ids) * len(ops)), ", per reducer" if len(ops) > 1 else ""),
                      "kernel_ms": kernel_ms_sum, "index_kernel_ms": idx_all / passes,
                      "frac_with_index": alg_bytes / ((kernel_ms_sum + idx_all / passes) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "tile_equivalent_GBs": tile_equiv, "note": note},
+                     "tile_equivalent_GBs": tile_equiv, "note": note, "issue": issue},
         "auc_check": tot_auc, "pearson_tracks_0_1": pearson, "output_runs": tot_runs, "work_queue_check": queue_check,
         "gen_seconds_total": gen_all, "pass_seconds": pass_s,
         "_chrom_lens": [chrom_lens[c] for c in chrom_ids],
