@@ -8,13 +8,14 @@
 // Kernels, all on the pipeline's decode stream, nothing returns to the host in between:
 //   wt_bw_copy_kernel     pinned host staging (file bytes as read) -> HBM, 16 B per lane
 //   wt_bw_inflate_kernel  ONE LANE PER SECTION: 64 independent zlib streams per wavefront
-//                         (csrc/wt_inflate.h: limit-based canonical Huffman decoding, tables 576 B of
-//                         LDS per lane interleaved across the wave + a 64-byte LZ77 ring: 40 KB per
-//                         wavefront, four wavefronts per CU), plain
-//                         bytes to a strided scratch buffer.  Bound: dependent-instruction latency
+//                         (csrc/wt_inflate.h: limit-based canonical Huffman decoding, one symbol and its first
+//                         8 bytes per branch-free step, loads landing at round boundaries; 288 B symbol table +
+//                         32 B LZ77 ring of LDS per lane: 20 KB per wavefront, EIGHT wavefronts per CU), plain
+//                         bytes to a strided scratch buffer.  Bound: dependent-instruction latency / VALU issue
 //                         (a serial bit stream per lane); throughput comes from sections in flight.
-//   wt_bw_count_kernel    one wavefront per section: header, per-item piece counts (1-based shift,
-//                         10 000-bp boxing, clip window: csrc/wt_bwdev_core.h), order / extent checks
+//   wt_bw_count_kernel    one wavefront per section: Adler-32 against the stream's trailer, header, per-item piece
+//                         counts (1-based shift, 10 000-bp boxing, clip window: csrc/wt_bwdev_core.h), order /
+//                         extent checks
 //   wt_bw_scan_kernel     one workgroup: exclusive scan over the sections -> piece offsets, the
 //                         batch's device-side seg_off[], total and error word (pinned host status)
 //   wt_bw_scatter_kernel  one wavefront per section: pieces to the slot's SoA arrays (coalesced)
