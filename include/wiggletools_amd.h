@@ -627,6 +627,19 @@ int64_t wtamd_bw_read_chrom(wtamd_bw *, const char *chrom, int box, int64_t capa
 int64_t wtamd_bw_read_part(wtamd_bw *, const char *chrom, int box, int64_t *cursor, int max_blocks, int32_t lo0, int32_t hi0,
                            int64_t capacity, int32_t *start, int32_t *finish, float *value, int *last);
 
+/* ---- Drop-in for the reference's src/bufferedReader.c (same five functions as src/bufferedReader.h:27-31, the
+ * struct opaque and free()-able as there): the producer / consumer block buffer of the binary-file readers
+ * (bigWiggleReader.c, bamReader.c, bigBedReader.c, bcfReader.c).  Link this library INSTEAD of bufferedReader.o and
+ * those readers, unchanged, hand their 10 000-entry blocks to a Multiplexer of this library whole (csrc/wt_bufreader.h). */
+typedef struct bufferedReaderData_st BufferedReaderData;
+void launchBufferedReader(void *(*readFileFunction)(void *), void *f_data, BufferedReaderData **buf_data);
+wt_bool pushValuesToBuffer(BufferedReaderData *data, const char *chrom, int start, int finish, double value);
+void endBufferedSignal(BufferedReaderData *data);
+void killBufferedReader(BufferedReaderData *data);
+void BufferedReaderPop(WiggleIterator *wi, BufferedReaderData *data);
+int compare_chrom_lengths(const void *A, const void *B);
+long long wtamd_bufreader_bulk_entries(void);      /* entries taken through the bulk door so far (tests) */
+
 /* ---- BigWig WRITER (bench / test plumbing next to the synthetic generator; csrc/wt_bwwrite.cpp): bedGraph sections of
  * `items_per_block` records, one zlib stream each, an R-tree index of as many levels as needed.  Chromosome names in
  * strcmp order (= their ids).  Intervals use the engine's convention: 1-based start, exclusive finish. */

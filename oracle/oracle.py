@@ -126,6 +126,7 @@ class Harness:
         if not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
             shutil.copyfile(src, dst)
         L = C.CDLL(dst)
+        self.lib_path = lib_path
         L.ref_open.argtypes = [C.c_char_p]
         if L.ref_open(lib_path.encode()) != 0:
             raise RuntimeError("ref_open(%s) failed" % lib_path)

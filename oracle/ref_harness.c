@@ -58,6 +58,13 @@ static int g_compress_mode;    /* 1: reducers handed to the writers are asked to
 void ref_set_compress_mode(int on) { g_compress_mode = on; }
 static void (*r_pop)(WiggleIterator *);
 static void (*r_seek)(WiggleIterator *, const char *, int, int);
+/* src/bufferedReader.h of the library under test (the reference's bufferedReader.o, or this repository's drop-in for it) */
+typedef struct bufferedReaderData_st BufData;
+static void (*r_launchBufferedReader)(void *(*)(void *), void *, BufData **);
+static wt_bool (*r_pushValuesToBuffer)(BufData *, const char *, int, int, double);
+static void (*r_endBufferedSignal)(BufData *);
+static void (*r_killBufferedReader)(BufData *);
+static void (*r_BufferedReaderPop)(WiggleIterator *, BufData *);
 static WiggleIterator *(*r_SmartReader)(char *, wt_bool);
 static WiggleIterator *(*r_AUCIntegrator)(WiggleIterator *);
 static WiggleIterator *(*r_PearsonIntegrator)(Multiplexer *);
@@ -103,6 +110,11 @@ int ref_open(const char *path) {
      * drop-in library lacks readers / integrators it does not replace */
 #define OPT(var, name) *(void **) (&var) = dlsym(g_lib, name)
     OPT(r_seekMultiset, "seekMultiset");
+    OPT(r_launchBufferedReader, "launchBufferedReader");
+    OPT(r_pushValuesToBuffer, "pushValuesToBuffer");
+    OPT(r_endBufferedSignal, "endBufferedSignal");
+    OPT(r_killBufferedReader, "killBufferedReader");
+    OPT(r_BufferedReaderPop, "BufferedReaderPop");
     OPT(r_TeeWiggleIterator, "TeeWiggleIterator");
     OPT(r_TeeMultiplexer, "TeeMultiplexer");
     OPT(r_ArrayReader, "wtamd_ArrayReader");
@@ -237,6 +249,66 @@ static WiggleIterator *wrap_map(WiggleIterator *c, int map_op, double param) {
     }
 }
 
+/* ---- child mode 4: a stand-in for the reference's binary-file readers, written against src/bufferedReader.h the way
+ * bigWiggleReader.c is (:85-150): a reader THREAD pushes the track's intervals into the library's block buffer
+ * (pushValuesToBuffer), the iterator's pop is BufferedReaderPop, seek kills + frees the buffer, relaunches the thread on
+ * the region and skips / clips like BigWiggleReaderSeek (:125-145).  (The real readers need libBigWig / htslib.) */
+typedef struct {
+    const wto_tracks *t;
+    char **names;
+    int track;
+    BufData *buf;
+    const char *chrom;      /* region after seek (NULL: everything) */
+    int start, stop;
+} buf_reader;
+
+static void *buf_reader_thread(void *ptr) {
+    buf_reader *d = (buf_reader *) ptr;
+    const wto_tracks *t = d->t;
+    for (int c = 0; c < t->n_chrom; c++) {
+        if (d->chrom && strcmp(d->names[c], d->chrom)) continue;
+        const int64_t seg = (int64_t) c * t->n_tracks + d->track;
+        for (int64_t j = t->seg_off[seg]; j < t->seg_off[seg + 1]; j++) {
+            int s = t->start[j], f = t->finish[j];
+            if (d->chrom) {         /* a region query hands back the overlapping intervals, boxed into it (:42-44) */
+                if (f <= d->start || s >= d->stop) continue;
+                if (s < d->start) s = d->start;
+                if (f > d->stop) f = d->stop;
+            }
+            if (r_pushValuesToBuffer(d->buf, d->names[c], s, f, t->value[j])) return NULL;      /* killed */
+        }
+    }
+    r_endBufferedSignal(d->buf);
+    return NULL;
+}
+
+static void buf_reader_pop(WiggleIterator *wi) {
+    buf_reader *d = (buf_reader *) wi->data;
+    r_BufferedReaderPop(wi, d->buf);
+}
+
+static void buf_reader_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
+    buf_reader *d = (buf_reader *) wi->data;
+    if (d->buf) {
+        r_killBufferedReader(d->buf);
+        free(d->buf);
+        d->buf = NULL;
+    }
+    d->chrom = chrom; d->start = start; d->stop = finish;
+    r_launchBufferedReader(&buf_reader_thread, d, &d->buf);
+    wi->done = 0;
+    buf_reader_pop(wi);
+    while (!wi->done && (strcmp(wi->chrom, chrom) < 0 || (strcmp(chrom, wi->chrom) == 0 && wi->finish <= start))) buf_reader_pop(wi);
+    if (!wi->done && strcmp(chrom, wi->chrom) == 0 && wi->start < start) wi->start = start;
+}
+
+static WiggleIterator *make_buffered_child(const wto_tracks *t, char **names, int track) {
+    buf_reader *d = (buf_reader *) calloc(1, sizeof(buf_reader));
+    d->t = t; d->names = names; d->track = track;
+    if (!g_hold) r_launchBufferedReader(&buf_reader_thread, d, &d->buf);       /* (held: launched by the first seek) */
+    return r_newWiggleIterator(d, buf_reader_pop, buf_reader_seek, t->defaults[track], 0);
+}
+
 static WiggleIterator *make_plain_child(const wto_tracks *t, char **names, int track);
 static WiggleIterator *make_child(const wto_tracks *t, char **names, int track) {
     WiggleIterator *c = make_plain_child(t, names, track);
@@ -245,6 +317,7 @@ static WiggleIterator *make_child(const wto_tracks *t, char **names, int track) 
 
 static WiggleIterator *make_plain_child(const wto_tracks *t, char **names, int track) {
     if (r_ArrayReader && (g_child_mode == 1 || (g_child_mode == 2 && (track & 1) == 0))) return make_array_child(t, names, track);
+    if (g_child_mode == 4 && r_launchBufferedReader) return make_buffered_child(t, names, track);
     arr_iter *a = (arr_iter *) calloc(1, sizeof(arr_iter));
     a->t = t; a->names = names; a->track = track; a->c = 0; a->j = -1;
     a->hold = g_hold;

@@ -456,3 +456,43 @@ def test_dropin_children_reusing_one_name_buffer(oracle, H, tiny, monkeypatch):
                 assert_runs_equal(H.reduce(d, op, flags=strict), oracle.reduce(d, op, flags=strict), _tol(op), "name buffer %s" % op)
     finally:
         H.set_modes(0, 0)
+
+
+@pytest.mark.parametrize("tiny", [False, True])
+def test_dropin_buffered_reader_children(oracle, H, tiny, monkeypatch):
+    """Children built on src/bufferedReader.h the way the reference's binary-file readers are (a reader thread pushing
+    into 10 000-entry blocks, pop = BufferedReaderPop; oracle/ref_harness.c child mode 4) -- over the COMPILED REFERENCE's
+    bufferedReader.o + Multiplexer and over this library's drop-in for both (csrc/wt_bufreader.h), where the Multiplexer
+    takes the buffer's blocks whole: same runs, and the oracle's.  Tracks long enough for several blocks and chromosome
+    changes inside a block; seek (kill + free + relaunch on the region) with held readers, as the CLI issues it."""
+    from wiggletools_amd.runlists import synth
+    if tiny:
+        monkeypatch.setenv("WTAMD_MIN_SPAN", "4000")
+        monkeypatch.setenv("WTAMD_BATCH_INTERVALS", "5000")
+    t = synth(5, [220000, 9000, 130000], mean_run=7, seed=404, gap_prob=0.2)      # ~ 25 000 intervals per track and chromosome
+    d = t.as_dict()
+    ref = oracle.ref_harness() if oracle.have_ref() else None
+    for L in [x for x in (H, ref) if x is not None]:
+        L.set_modes(4, 0)
+    import ctypes as C
+    lib = C.CDLL(H.lib_path)
+    lib.wtamd_bufreader_bulk_entries.restype = C.c_longlong
+    before = lib.wtamd_bufreader_bulk_entries()
+    try:
+        for op in ("mean", "max", "median"):
+            exp = oracle.reduce(d, op)
+            got = H.reduce(d, op)
+            assert_runs_equal(got, exp, _tol(op), "buffered children %s" % op)
+            if ref is not None:
+                assert_runs_equal(ref.reduce(d, op), exp, _tol(op), "reference over its own bufferedReader, %s" % op)
+        # the blocks went over whole: (almost) every entry of the three passes left through the bulk door
+        assert lib.wtamd_bufreader_bulk_entries() - before > 0.9 * 3 * len(t.start)
+        for (c, s, f) in ((0, 5000, 150000), (2, 1, 70000), (1, 100, 200)):
+            got = H.reduce_seek_held(d, "mean", c, s, f)
+            exp = oracle.reduce(clip(t, c, s, f).as_dict(), "mean")
+            assert_runs_equal(got, exp, 0.0, "buffered children, held seek %s" % ((c, s, f),))
+            if ref is not None:
+                assert_runs_equal(ref.reduce_seek_held(d, "mean", c, s, f), exp, 0.0, "reference, held seek %s" % ((c, s, f),))
+    finally:
+        for L in [x for x in (H, ref) if x is not None]:
+            L.set_modes(0, 0)

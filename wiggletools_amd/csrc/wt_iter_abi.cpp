@@ -38,6 +38,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <deque>
 #include <functional>
@@ -46,6 +47,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/wiggletools_amd.h"
@@ -113,6 +115,13 @@ void wt_bulk_pop(WiggleIterator *wi) {
     BulkSource *b = (BulkSource *) wi->data;
     b->advance(b, wi, 1);
 }
+
+}  // namespace
+
+// the reference's bufferedReader.c, replaced: every reader built on it becomes a bulk source (csrc/wt_bufreader.h)
+#include "wt_bufreader.h"
+
+namespace {
 
 // One child iterator plus intervals that were popped from it but pushed back.
 struct TrackSource {
@@ -556,6 +565,9 @@ struct Feeder {
     bool drain_and_submit() {
         if (bw_mode) return bwdev_drain_and_submit(*this);
         const int N = n_tracks();
+        if (!pool)      // (readers held until their first seek register their buffer then: commandParser.c:615-624)
+            for (auto &s : src)
+                if (!s.bulk && s.it->pop != &wt_bulk_pop) s.bulk = wt_bufreader_bulk(s.it);
         int32_t lo;
         if (continuing) {
             lo = next_lo;
@@ -2034,6 +2046,7 @@ Multiplexer *newMultiplexer(WiggleIterator **iters, int count, wt_bool strict) {
             if (op == WTAMD_MAP_LN || op == WTAMD_MAP_LOG || op >= WTAMD_MAP_GT) S->fd.src[i].drops = true;
         }
         if (raw->pop == &wt_bulk_pop) S->fd.src[i].bulk = (BulkSource *) raw->data;
+        else S->fd.src[i].bulk = wt_bufreader_bulk(raw);        // a reader on this library's bufferedReader (csrc/wt_bufreader.h)
         S->fd.defaults.push_back(m->iters[i]->default_value);
     }
     popMultiplexer(m);                                              // primed like multiplexer.c:167
