@@ -258,9 +258,20 @@ def e2e_dropin(op, n_tracks, mean_run, mbp, device):
         out[key] = {"bp_per_s": bp / dt, "seconds": dt, "bp": bp, "runs": runs,
                     "child_pops_per_s": float(pseg[-1]) / dt,
                     "drain_threads": threads or ("auto: min(16, usable cores = %d) for >= 16 foreign children" % effective_cores())}
-    ps.free(); pf.free(); pv.free()
+    # the same slice behind readers built on the buffered reader (csrc/wt_bufreader.h, the reference's bufferedReader.c
+    # replaced): a producer thread per track pushes one interval at a time, the Multiplexer takes the 10 000-entry blocks
+    # whole.  What an unchanged reference reader (bigWiggleReader.c, bamReader.c ...) gets once it links this library.
     os.environ.pop("WTAMD_NO_BULK", None)
     os.environ.pop("WTAMD_DRAIN_THREADS", None)
+    t0 = time.perf_counter()
+    r = dropin.reducer(op, [dropin.buffered_array_reader(["chr1"], [0, int(pseg[t + 1] - pseg[t])], ps.ptr + 4 * int(pseg[t]),
+                                                         pf.ptr + 4 * int(pseg[t]), pv.ptr + 4 * int(pseg[t])) for t in range(n_tracks)],
+                       n_set0=n_tracks // 2)
+    runs, bp = dropin.drain_blocks(r)
+    dt = time.perf_counter() - t0
+    out["buffered"] = {"bp_per_s": bp / dt, "seconds": dt, "bp": bp, "runs": runs, "child_entries_per_s": float(pseg[-1]) / dt,
+                       "note": "children = producer threads pushing into the buffered reader (one call per interval); blocks taken whole"}
+    ps.free(); pf.free(); pv.free()
     hs.free(); hf.free(); hv.free()
     return out
 

@@ -639,6 +639,12 @@ void killBufferedReader(BufferedReaderData *data);
 void BufferedReaderPop(WiggleIterator *wi, BufferedReaderData *data);
 int compare_chrom_lengths(const void *A, const void *B);
 long long wtamd_bufreader_bulk_entries(void);      /* entries taken through the bulk door so far (tests) */
+/* wtamd_ArrayReader's arrays behind a reader written like the reference's binary-file readers: a producer thread pushes
+ * one interval at a time (pushValuesToBuffer), pop is BufferedReaderPop -- the buffered reader's protocol with a producer
+ * that costs nothing else (tests, bench leg `e2e.buffered`). */
+WiggleIterator *wtamd_BufferedArrayReader(int n_chrom, const char *const *chrom_names, const int64_t *seg_off,
+                                          const int32_t *start, const int32_t *finish, const float *value,
+                                          double default_value);
 
 /* ---- BigWig WRITER (bench / test plumbing next to the synthetic generator; csrc/wt_bwwrite.cpp): bedGraph sections of
  * `items_per_block` records, one zlib stream each, an R-tree index of as many levels as needed.  Chromosome names in

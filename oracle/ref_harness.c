@@ -51,6 +51,8 @@ static WiggleIterator *(*r_TeeWiggleIterator)(WiggleIterator *, FILE *, wt_bool,
 static Multiplexer *(*r_TeeMultiplexer)(Multiplexer *, FILE *, wt_bool, wt_bool);
 static WiggleIterator *(*r_ArrayReader)(int, const char *const *, const int64_t *, const int32_t *, const int32_t *,
                                         const float *, double);
+static WiggleIterator *(*r_BufferedArrayReader)(int, const char *const *, const int64_t *, const int32_t *, const int32_t *,
+                                        const float *, double);
 static int64_t (*r_next_block)(WiggleIterator *, const char **, const int32_t **, const int32_t **, const double **);
 static int (*r_compress_output)(WiggleIterator *, int);
 static WiggleIterator *(*r_MapIterator)(WiggleIterator *, int, double);     /* wtamd_MapIterator (tested library only) */
@@ -118,6 +120,7 @@ int ref_open(const char *path) {
     OPT(r_TeeWiggleIterator, "TeeWiggleIterator");
     OPT(r_TeeMultiplexer, "TeeMultiplexer");
     OPT(r_ArrayReader, "wtamd_ArrayReader");
+    OPT(r_BufferedArrayReader, "wtamd_BufferedArrayReader");
     OPT(r_next_block, "wtamd_iterator_next_block");
     OPT(r_compress_output, "wtamd_iterator_compress_output");
     OPT(r_MapIterator, "wtamd_MapIterator");
@@ -220,6 +223,7 @@ static WiggleIterator *make_array_child(const wto_tracks *t, char **names, int t
         for (int64_t g = lo; g < hi; g++, k++) { s[k] = t->start[g]; f[k] = t->finish[g]; v[k] = (float) t->value[g]; }
     }
     so[t->n_chrom] = k;
+    if (g_child_mode == 5) return r_BufferedArrayReader(t->n_chrom, (const char *const *) names, so, s, f, v, t->defaults[track]);
     return r_ArrayReader(t->n_chrom, (const char *const *) names, so, s, f, v, t->defaults[track]);
 }
 
@@ -318,6 +322,7 @@ static WiggleIterator *make_child(const wto_tracks *t, char **names, int track) 
 static WiggleIterator *make_plain_child(const wto_tracks *t, char **names, int track) {
     if (r_ArrayReader && (g_child_mode == 1 || (g_child_mode == 2 && (track & 1) == 0))) return make_array_child(t, names, track);
     if (g_child_mode == 4 && r_launchBufferedReader) return make_buffered_child(t, names, track);
+    if (g_child_mode == 5 && r_BufferedArrayReader) return make_array_child(t, names, track);     /* the library's own reader on its buffered reader */
     arr_iter *a = (arr_iter *) calloc(1, sizeof(arr_iter));
     a->t = t; a->names = names; a->track = track; a->c = 0; a->j = -1;
     a->hold = g_hold;

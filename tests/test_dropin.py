@@ -458,8 +458,8 @@ def test_dropin_children_reusing_one_name_buffer(oracle, H, tiny, monkeypatch):
         H.set_modes(0, 0)
 
 
-@pytest.mark.parametrize("tiny", [False, True])
-def test_dropin_buffered_reader_children(oracle, H, tiny, monkeypatch):
+@pytest.mark.parametrize("tiny,threads", [(False, None), (True, None), (False, "3"), (True, "2")])
+def test_dropin_buffered_reader_children(oracle, H, tiny, threads, monkeypatch):
     """Children built on src/bufferedReader.h the way the reference's binary-file readers are (a reader thread pushing
     into 10 000-entry blocks, pop = BufferedReaderPop; oracle/ref_harness.c child mode 4) -- over the COMPILED REFERENCE's
     bufferedReader.o + Multiplexer and over this library's drop-in for both (csrc/wt_bufreader.h), where the Multiplexer
@@ -469,6 +469,8 @@ def test_dropin_buffered_reader_children(oracle, H, tiny, monkeypatch):
     if tiny:
         monkeypatch.setenv("WTAMD_MIN_SPAN", "4000")
         monkeypatch.setenv("WTAMD_BATCH_INTERVALS", "5000")
+    if threads:         # the children dealt to worker threads (the default from 16 children on): the blocks go over inside the workers
+        monkeypatch.setenv("WTAMD_DRAIN_THREADS", threads)
     t = synth(5, [220000, 9000, 130000], mean_run=7, seed=404, gap_prob=0.2)      # ~ 25 000 intervals per track and chromosome
     d = t.as_dict()
     ref = oracle.ref_harness() if oracle.have_ref() else None
@@ -493,6 +495,14 @@ def test_dropin_buffered_reader_children(oracle, H, tiny, monkeypatch):
             assert_runs_equal(got, exp, 0.0, "buffered children, held seek %s" % ((c, s, f),))
             if ref is not None:
                 assert_runs_equal(ref.reduce_seek_held(d, "mean", c, s, f), exp, 0.0, "reference, held seek %s" % ((c, s, f),))
+        # the library's own array reader on the same protocol (wtamd_BufferedArrayReader; the bench's `e2e.buffered` leg)
+        H.set_modes(5, 0)
+        before = lib.wtamd_bufreader_bulk_entries()
+        assert_runs_equal(H.reduce(d, "mean"), oracle.reduce(d, "mean"), 0.0, "wtamd_BufferedArrayReader children")
+        assert lib.wtamd_bufreader_bulk_entries() - before > 0.9 * len(t.start)
+        for (c, s, f) in ((0, 5000, 150000), (1, 100, 200)):
+            assert_runs_equal(H.reduce_seek(d, "mean", c, s, f), oracle.reduce(clip(t, c, s, f).as_dict(), "mean"), 0.0,
+                              "wtamd_BufferedArrayReader, seek %s" % ((c, s, f),))
     finally:
         for L in [x for x in (H, ref) if x is not None]:
             L.set_modes(0, 0)

@@ -62,18 +62,38 @@ std::mutex g_buf_mu;
 std::unordered_map<WiggleIterator *, WtBufBulk *> g_buf_doors;
 std::atomic<long long> g_buf_bulk_entries{0};      // entries that left through the bulk door (tests)
 
+// Blocks are recycled: the reference callocs five arrays per block (bufferedReader.c:21-28) -- 280 KB, i.e. an mmap, its
+// page faults and an munmap per 10 000 entries and thread, all of them under the process's address-space lock.
+std::mutex g_buf_pool_mu;
+WtBufBlock *g_buf_pool = nullptr;
+int g_buf_pool_n = 0;
+#define WT_BUF_POOL_MAX 1024        // blocks kept (280 MB at most)
+
 WtBufBlock *wt_buf_new_block() {
-    WtBufBlock *b = (WtBufBlock *) calloc(1, sizeof(WtBufBlock));
-    b->chrom = (const char **) calloc(WT_BUF_BLOCK, sizeof(char *));
-    b->start = (int *) calloc(WT_BUF_BLOCK, sizeof(int));
-    b->finish = (int *) calloc(WT_BUF_BLOCK, sizeof(int));
-    b->value = (double *) calloc(WT_BUF_BLOCK, sizeof(double));
-    b->v32 = (float *) calloc(WT_BUF_BLOCK, sizeof(float));
+    WtBufBlock *b = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_buf_pool_mu);
+        if (g_buf_pool) { b = g_buf_pool; g_buf_pool = b->next; g_buf_pool_n--; }
+    }
+    if (!b) {
+        b = (WtBufBlock *) calloc(1, sizeof(WtBufBlock));
+        b->chrom = (const char **) malloc(WT_BUF_BLOCK * sizeof(char *));
+        b->start = (int *) malloc(WT_BUF_BLOCK * sizeof(int));
+        b->finish = (int *) malloc(WT_BUF_BLOCK * sizeof(int));
+        b->value = (double *) malloc(WT_BUF_BLOCK * sizeof(double));
+        b->v32 = (float *) malloc(WT_BUF_BLOCK * sizeof(float));
+    }
     b->f32 = true;
+    b->count = 0;
+    b->next = nullptr;
     return b;
 }
 
 void wt_buf_free_block(WtBufBlock *b) {
+    {
+        std::lock_guard<std::mutex> lk(g_buf_pool_mu);
+        if (g_buf_pool_n < WT_BUF_POOL_MAX) { b->next = g_buf_pool; g_buf_pool = b; g_buf_pool_n++; return; }
+    }
     free(b->chrom); free(b->start); free(b->finish); free(b->value); free(b->v32);
     free(b);
 }

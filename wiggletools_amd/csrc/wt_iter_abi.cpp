@@ -187,14 +187,29 @@ bool wt_surely_kept(const wtamd_map_chain &c, double v) {
 struct DrainOut {
     std::vector<int32_t> s, f;
     std::vector<double> v;
+    std::vector<float> vf;          // f32: the values as float32 (children that hand over float blocks) -- else `v`
+    bool f32 = false;
     bool more = false, carry = false, need64 = false;
     int32_t sentinel_lo = INT32_MAX;
     int64_t at = 0;
-    void clear() { s.clear(); f.clear(); v.clear(); more = carry = need64 = false; sentinel_lo = INT32_MAX; at = 0; }
+    void clear(bool as_f32 = false) {
+        s.clear(); f.clear(); v.clear(); vf.clear();
+        f32 = as_f32;
+        more = carry = need64 = false; sentinel_lo = INT32_MAX; at = 0;
+    }
     void push(int32_t st, int32_t fi, double x) {
-        s.push_back(st); f.push_back(fi); v.push_back(x);
+        s.push_back(st); f.push_back(fi);
         const float fl = (float) x;
-        if ((double) fl != x && x == x) need64 = true;
+        const bool exact = !((double) fl != x && x == x);
+        if (f32 && exact) { vf.push_back(fl); return; }
+        if (f32) { v.assign(vf.begin(), vf.end()); vf.clear(); f32 = false; }
+        v.push_back(x);
+        if (!exact) need64 = true;
+    }
+    void append(const int32_t *bs, const int32_t *bf, const float *bv, int64_t k) {       // a block of float32 entries
+        s.insert(s.end(), bs, bs + k); f.insert(f.end(), bf, bf + k);
+        if (f32) vf.insert(vf.end(), bv, bv + k);
+        else v.insert(v.end(), bv, bv + k);
     }
 };
 
@@ -454,7 +469,7 @@ struct Feeder {
             if (any_map && wtamd_pipe_set_map(q, chains.data()) != WTAMD_OK) die("wtamd_pipe_set_map");
         // parallel draining when every child is popped through the reference's protocol
         bool eligible = !keep_log && !src.empty() && !bw_mode;
-        for (const auto &s : src) eligible = eligible && !(s.bulk && use_bulk) && !s.drops;
+        for (const auto &s : src) eligible = eligible && !(s.bulk && use_bulk && s.bulk->peek != &wt_buf_peek) && !s.drops;
         if (bw_mode && !io_pool) {
             const int t = std::max(1, std::min({wt_usable_cores(), 16, n_tracks()}));
             io_pool = new DrainPool();
@@ -485,7 +500,11 @@ struct Feeder {
     // threads run this: it must not intern (the table is not thread-safe) -- a raw name the source
     // has not seen interned yet is compared by content.
     void drain_foreign(TrackSource &s, const char *chrom, int32_t hi, DrainOut &o) {
-        o.clear();
+        // a reader on this library's buffered reader (csrc/wt_bufreader.h): its blocks go over whole, by the worker
+        // that owns the child (the door appears with the reader's first pop, which may be later than the constructor)
+        if (!s.bulk && use_bulk && s.it->pop != &wt_bulk_pop) s.bulk = wt_bufreader_bulk(s.it);
+        BulkSource *door = (s.bulk && use_bulk && s.bulk->peek == &wt_buf_peek) ? s.bulk : nullptr;
+        o.clear(door != nullptr);
         while (!s.pending.empty()) {
             const Ivl h = s.pending.front();
             if (h.chrom != chrom) return;
@@ -495,6 +514,21 @@ struct Feeder {
             s.pending.pop_front();
         }
         WiggleIterator *it = s.it;
+        while (door && !it->done && strcmp(it->chrom, chrom) == 0) {
+            const int32_t *bs, *bf;
+            const float *bv;
+            const int64_t cnt = door->peek(door, &bs, &bf, &bv);
+            if (cnt <= 0) break;                                            // (a value that is no float: one pop at a time, below)
+            const int64_t k1 = std::lower_bound(bs, bs + cnt, hi) - bs;     // starts below the cut
+            const bool reach = k1 > 0 && bf[k1 - 1] >= hi;                 // the last of them reaches it: seen again
+            const bool sentinel = !reach && k1 < cnt;
+            o.append(bs, bf, bv, k1 + (sentinel ? 1 : 0));
+            if (sentinel) { o.more = true; o.sentinel_lo = bs[k1]; }
+            if (reach) o.more = o.carry = true;
+            const int64_t consumed = reach ? k1 - 1 : k1;
+            if (consumed > 0) door->advance(door, it, consumed);
+            if (reach || sentinel) return;
+        }
         while (!it->done) {
             const char *rc = it->chrom;
             const int32_t st = it->start, fi = it->finish;
@@ -684,7 +718,10 @@ struct Feeder {
                     if (!k) continue;
                     memcpy(b.start + o.at, o.s.data(), sizeof(int32_t) * k);
                     memcpy(b.finish + o.at, o.f.data(), sizeof(int32_t) * k);
-                    if (w64) memcpy(b.value64 + o.at, o.v.data(), sizeof(double) * k);
+                    if (o.f32) {
+                        if (w64) for (size_t q = 0; q < k; q++) b.value64[o.at + (int64_t) q] = (double) o.vf[q];
+                        else memcpy(b.value32 + o.at, o.vf.data(), sizeof(float) * k);
+                    } else if (w64) memcpy(b.value64 + o.at, o.v.data(), sizeof(double) * k);
                     else for (size_t q = 0; q < k; q++) b.value32[o.at + (int64_t) q] = (float) o.v[q];
                 }
             });
@@ -2160,6 +2197,83 @@ WiggleIterator *wtamd_ArrayReader(int n_chrom, const char *const *chrom_names, c
     wi->value = 1;
     wi->default_value = default_value;
     a->settle(wi);                             // a fresh iterator already holds its first element (wiggleIterator.c:32)
+    return wi;
+}
+
+// The same arrays behind a reader written the way the reference writes its binary-file readers (bigWiggleReader.c:52-151,
+// bamReader.c, bigBedReader.c): a producer thread pushes one interval at a time into the buffered reader, the iterator's
+// pop is BufferedReaderPop.  It exists to exercise and to time the buffered reader's bulk door (csrc/wt_bufreader.h) with
+// a producer that costs nothing but the protocol.
+namespace {
+struct BufArrReader {
+    int n_chrom;
+    char **names;
+    int64_t *seg_off;
+    const int32_t *start, *finish;
+    const float *value;
+    BufferedReaderData *buf;
+    int only;                       // after seek(): this chromosome only, clipped to [win_start, win_finish)
+    int32_t win_start, win_finish;
+};
+
+void *bufarr_produce(void *arg) {
+    BufArrReader *a = (BufArrReader *) arg;
+    for (int c = 0; c < a->n_chrom; c++) {
+        if (a->only >= 0 && c != a->only) continue;
+        for (int64_t j = a->seg_off[c]; j < a->seg_off[c + 1]; j++) {
+            int32_t s = a->start[j], f = a->finish[j];
+            if (a->only >= 0) {
+                if (f <= a->win_start) continue;
+                if (s >= a->win_finish) break;
+                if (s < a->win_start) s = a->win_start;
+                if (f > a->win_finish) f = a->win_finish;
+            }
+            if (pushValuesToBuffer(a->buf, a->names[c], s, f, (double) a->value[j])) return nullptr;
+        }
+    }
+    endBufferedSignal(a->buf);
+    return nullptr;
+}
+
+void bufarr_pop(WiggleIterator *wi) {
+    BufArrReader *a = (BufArrReader *) wi->data;
+    BufferedReaderPop(wi, a->buf);
+}
+
+void bufarr_seek(WiggleIterator *wi, const char *chrom, int start, int finish) {
+    BufArrReader *a = (BufArrReader *) wi->data;
+    killBufferedReader(a->buf);
+    free(a->buf);
+    a->buf = nullptr;
+    a->only = a->n_chrom;           // unknown chromosome: nothing
+    for (int c = 0; c < a->n_chrom; c++)
+        if (strcmp(a->names[c], chrom) == 0) a->only = c;
+    a->win_start = start; a->win_finish = finish;
+    launchBufferedReader(&bufarr_produce, a, &a->buf);
+    wi->done = 0;
+    bufarr_pop(wi);
+}
+}  // namespace
+
+WiggleIterator *wtamd_BufferedArrayReader(int n_chrom, const char *const *chrom_names, const int64_t *seg_off,
+                                          const int32_t *start, const int32_t *finish, const float *value,
+                                          double default_value) {
+    BufArrReader *a = (BufArrReader *) calloc(1, sizeof(BufArrReader));
+    a->n_chrom = n_chrom;
+    a->names = (char **) calloc((size_t) (n_chrom > 0 ? n_chrom : 1), sizeof(char *));
+    a->seg_off = (int64_t *) calloc((size_t) n_chrom + 1, sizeof(int64_t));
+    for (int c = 0; c < n_chrom; c++) a->names[c] = strdup(chrom_names[c]);
+    for (int c = 0; c <= n_chrom; c++) a->seg_off[c] = seg_off[c];
+    a->start = start; a->finish = finish; a->value = value;
+    a->only = -1;
+    WiggleIterator *wi = (WiggleIterator *) calloc(1, sizeof(WiggleIterator));
+    wi->data = a;
+    wi->pop = &bufarr_pop;
+    wi->seek = &bufarr_seek;
+    wi->value = 1;
+    wi->default_value = default_value;
+    launchBufferedReader(&bufarr_produce, a, &a->buf);
+    bufarr_pop(wi);
     return wi;
 }
 

@@ -73,6 +73,17 @@ def array_reader(chrom_names, seg_off, start_ptr, finish_ptr, value_ptr, default
     return L.wtamd_ArrayReader(len(chrom_names), names, so.ctypes.data, start_ptr, finish_ptr, value_ptr, float(default_value))
 
 
+def buffered_array_reader(chrom_names, seg_off, start_ptr, finish_ptr, value_ptr, default_value=0.0):
+    """wtamd_BufferedArrayReader: the same arrays behind the reference's buffered-reader protocol (a producer thread
+    pushing one interval at a time, csrc/wt_bufreader.h)."""
+    L = _bind()
+    L.wtamd_BufferedArrayReader.restype = C.c_void_p
+    L.wtamd_BufferedArrayReader.argtypes = L.wtamd_ArrayReader.argtypes
+    names = (C.c_char_p * len(chrom_names))(*[n.encode() for n in chrom_names])
+    so = np.ascontiguousarray(seg_off, np.int64)
+    return L.wtamd_BufferedArrayReader(len(chrom_names), names, so.ctypes.data, start_ptr, finish_ptr, value_ptr, float(default_value))
+
+
 def bigwig_reader(path, box=True):
     """wtamd_BigWiggleReader: the reference's BigWiggleReader role (bigWiggleReader.c:147-151), bulk-capable."""
     return _bind().wtamd_BigWiggleReader(path.encode(), int(box))
