@@ -246,7 +246,7 @@ int wtamd_pipe_submit(wtamd_pipe *p, int value_is_f64, int32_t range_lo, int32_t
     s.os.assign((size_t) cap, 0); s.of.assign((size_t) cap, 0); s.ov.assign((size_t) cap, 0.0);
     if (tile) { s.tile.assign((size_t) cap * N, 0.0); s.ip.assign((size_t) cap * N, 0); }
     int64_t cro[2] = {0, 0};
-    long long info[12] = {0};
+    long long info[16] = {0};
     const long long r = wtemu_reduce(1, N, mapped ? mseg.data() : s.seg_off.data(), mapped ? ms.data() : s.start.data(),
                                      mapped ? mf.data() : s.finish.data(),
                                      mapped ? (const void *) mv.data() : value_is_f64 ? (const void *) s.v64.data() : (const void *) s.v32.data(),

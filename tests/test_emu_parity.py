@@ -492,6 +492,8 @@ def test_plan_policy_snapshot():
     p = plan(500, "var", no_delta=1)
     assert (p["W"], p["T"]) == (2048, 512) and p["n_chunks"] == 5        # general kernel: chunks of <= 112 tracks
     p = plan(100, "median")
+    assert (p["walk"], p["W"], p["T"], p["lds"] < 80 * 1024) == (1, 2048, 128, True)                  # round 4: walking, 128 lanes x 16 positions, two workgroups per CU
+    p = plan(100, "median", no_walk=1)
     assert (p["W"], p["T"], p["lds"] < 32 * 1024) == (512, 256, True) and p["scratch_slab"] == 0     # round 2: value column in REGISTERS, LDS = bitmaps only, 2 positions per lane
     p = plan(100, "mwu", n_set0=50)
     assert (p["W"], p["T"]) == (512, 256) and p["lds"] < 80 * 1024       # register columns + the sorted set 0 (50 x 4 B per lane) in LDS, 2 positions per lane
@@ -560,3 +562,59 @@ def test_emu_delta_more_tiles_than_the_first_track_table(oracle):
         got, info = emu.reduce(t, op, delta_T=512)
         assert info["delta"] == 1 and info["W"] == 4096 and info["delta_bad"] == 0, info
         assert_runs_equal(got, oracle.reduce(d, op), 0.0, op)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_emu_median_walk_fuzz(oracle, seed):
+    """MedianReduction by walking (csrc/wt_walk.h): a lane carries its column of current values over consecutive positions,
+    events in, the order statistic moved by sweeps.  Against the oracle (reducers.c:780-813) at tolerance 0 and against the
+    bitmap kernel (WTAMD_NO_WALK), over lane counts, stretch lengths, slabs too small for a window (several rounds), gaps,
+    ties (2 value levels), NaN, non-zero defaults, the strict predicate and ranges."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.choice([1, 2, 3, 7, 8, 31, 32, 33, 64, 65, 100, 128]))
+    lens = [int(rng.integers(40, 6000)), int(rng.integers(1, 400))]
+    defaults = None
+    if rng.random() < 0.4:
+        defaults = rng.integers(-3, 4, n).astype(np.float64) / 4.0
+    t = synth(n, lens, mean_run=float(rng.choice([1, 2, 5, 16, 70])), seed=seed, gap_prob=float(rng.choice([0, 0.05, 0.5, 0.9])),
+              dtype=np.float32, value_levels=int(rng.choice([2, 5, 800])), nan_prob=float(rng.choice([0, 0, 0.002])), defaults=defaults,
+              first_start=int(rng.choice([1, 1, 777])))
+    T = int(rng.choice([64, 128, 256]))
+    if n > T:
+        T = 128
+    S = int(rng.choice([4, 8, 16]))
+    cap = None if rng.random() < 0.5 else 2 * n * S + int(rng.integers(0, 200))
+    flags = int(rng.choice([0, 0, 1]))
+    ranges = None
+    if rng.random() < 0.3:
+        ranges = [(int(rng.integers(1, L // 2 + 2)), int(rng.integers(L // 2 + 1, L + 60))) for L in lens]
+    got, info = emu.reduce(t, "median", flags=flags, walk_T=T, walk_S=S, walk_cap=cap, ranges=ranges)
+    assert info["walk"] == 1 and (info["W"], info["T"]) == (T * S, T)
+    tt = t if ranges is None else t      # (the oracle takes the same ranges below)
+    exp = oracle.reduce(tt.as_dict(), "median", flags=flags) if ranges is None else None
+    old, info2 = emu.reduce(t, "median", flags=flags, no_walk=1, ranges=ranges)
+    assert info2["walk"] == 0
+    assert_runs_equal(got, old, 0.0, "walking vs bitmap kernel")
+    if exp is not None:
+        assert_runs_equal(got, exp, 0.0, "walking vs oracle")
+    if cap is not None and t.n_intervals > 4 * cap:
+        assert info["walk_rounds"] > info["n_windows"]       # some window needed more than one slab
+
+
+def test_emu_median_walk_dense_and_sparse(oracle):
+    """The extremes: every track a run per base pair (the most events a window can hold), and tracks with one run each."""
+    from wiggletools_amd.runlists import RunLists
+    rng = np.random.default_rng(5)
+    n, L = 9, 700
+    per_bp = [[(p, p + 1, float(rng.integers(0, 50)) / 4.0) for p in range(1, L)] for _ in range(n)]
+    t = _f32(RunLists.from_lists([per_bp]))
+    got, info = emu.reduce(t, "median", walk_T=64, walk_S=4, walk_cap=2 * n * 4)
+    assert info["walk"] == 1 and info["walk_rounds"] > info["n_windows"]
+    assert_runs_equal(got, oracle.reduce(t.as_dict(), "median"), 0.0, "one run per bp")
+    one = [[(int(rng.integers(1, 3000)), 0, float(i))] for i in range(n)]
+    one = [[(s, s + int(rng.integers(1, 4000)), v)] for [(s, _, v)] in one]
+    t = _f32(RunLists.from_lists([one]))
+    for flags in (0, 1):
+        got, info = emu.reduce(t, "median", flags=flags)
+        assert info["walk"] == 1
+        assert_runs_equal(got, oracle.reduce(t.as_dict(), "median", flags=flags), 0.0, "one run per track")

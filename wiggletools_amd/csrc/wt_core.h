@@ -120,6 +120,8 @@ struct WtParams {
     int32_t delta_df;                   // != 0: some default is non-zero (Sum / Mean): absent tracks add their defaults
     int32_t def_emin, def_emax;         // exponent range of the non-zero defaults (255 / 0: none)
     int32_t off_dflt32;           // register-column median / MWU: float copy of defaults[] in LDS (filled once per workgroup)
+    int32_t off_wcol, off_wcnt, off_woff, off_wtot, off_wbase, off_wgt, off_wncov, off_wfe, off_wdk;   // median by walking (wt_walk.h)
+    int32_t walk_S;               // ... positions per lane (0: not a walking launch)
     int32_t lds_bytes;
 };
 
@@ -1563,8 +1565,11 @@ WT_DEV void wt_lookback_finish(const WtParams &P, WtCtx &c, long long k, unsigne
 
 // Sequential flavour (one lane): used by the CPU emulator, kept as the plain statement
 // of the protocol.
+WT_DEV void wt_phase_lookback(const WtParams &P, WtCtx &c, long long k, unsigned long long mine);
 WT_DEV void wt_phase_lookback(const WtParams &P, WtCtx &c, long long k) {
-    const unsigned long long mine = c.epfx[P.n_words];
+    wt_phase_lookback(P, c, k, (unsigned long long) c.epfx[P.n_words]);
+}
+WT_DEV void wt_phase_lookback(const WtParams &P, WtCtx &c, long long k, unsigned long long mine) {
     c.sh->n_emit = (int32_t) mine;
     unsigned long long excl = 0;
     if (k > 0) {
@@ -1738,5 +1743,6 @@ WT_DEV void wt_index_apply(const WtParams &P, WtIndexCursor &c, long long g, int
 }
 
 #include "wt_delta.h"
+#include "wt_walk.h"
 
 #endif  // WT_CORE_H_

@@ -1104,7 +1104,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     if (s.used_delta) {
         wt_make_delta_plan(plan, N, wt_op_is_var_family(op));
         s.delta_W = plan.W;
-    } else if (!wt_make_plan(N, op, ts->scratch_f32, plan, err, 80 * 1024, 160 * 1024, p->cfg.desc.n_set0)) {
+    } else if (!wt_pick_plan(ts, op, p->cfg.desc.n_set0, plan, err)) {
         return wt_fail(WTAMD_ERR_ARG, err);
     }
     rc = wt_reduce_plan(ts, plan, op, p->cfg.desc.flags, p->cfg.desc.n_set0, &runs, p->tile ? s.d_tile : nullptr,

@@ -31,6 +31,8 @@ struct WtPlan {
     long long attr_slab = 0;      // MWU: bytes of per-rank attributes per workgroup (always global)
     int ppt = 1;            // consecutive window positions per lane (1 or 4)
     int regcol = 0;         // median / MWU: register slots of the per-lane value column (0: LDS / global columns)
+    int walk_S = 0;         // median by walking (wt_walk.h): positions per lane (0: not that plan)
+    int off_wcol = 0, off_wcnt = 0, off_woff = 0, off_wtot = 0, off_wbase = 0, off_wgt = 0, off_wncov = 0, off_wfe = 0, off_wdk = 0;
 };
 
 static inline int wt_align16(int x) { return (x + 15) & ~15; }
@@ -168,6 +170,54 @@ static inline void wt_delta_defaults_params(const double *defaults, int n_tracks
     }
 }
 
+// Median by walking (wt_walk.h): T lanes x S consecutive positions each; the lanes' value columns (N x 4 bytes per
+// lane) are what fills the LDS.  The first median of a stretch comes from the register network of the bitmap kernel,
+// hence `nr` slots (wt_regcol_slots) and at most 128 tracks; the window's runs are enumerated through the
+// difference-array kernel's flat index space, one chunk: N <= T.
+// WTAMD_WALK_T / WTAMD_WALK_S: experiments.  The slab holds the events of a window: 16 per bp, at least what the longest
+// stretch of one lane can hold (2 N S), never more than the whole track set has (tests with tiny inputs).
+static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, long long n_intervals, int hard_limit = 160 * 1024) {
+    const char *eT = getenv("WTAMD_WALK_T"), *eS = getenv("WTAMD_WALK_S");
+    int S = eS ? atoi(eS) : 16;
+    if (S != 4 && S != 8 && S != 16) S = 16;
+    const int want = eT ? atoi(eT) : 128;
+    for (int T : {want, 256, 128, 64}) {
+        if (T != 64 && T != 128 && T != 256) continue;
+        if (n_tracks > T) continue;
+        WtPlan q;
+        q.T = T; q.W = T * S; q.n_words = q.W / 64; q.ppt = S; q.walk_S = S; q.regcol = nr;
+        q.chunk_tracks = n_tracks; q.n_chunks = 1;
+        int o = 0;
+        q.off_wcol = o;   o = wt_align16(o + n_tracks * T * 4);
+        q.off_wcnt = o;   o = wt_align16(o + q.W * 4);
+        q.off_woff = o;   o = wt_align16(o + (q.W + 1) * 4);
+        q.off_wtot = o;   o = wt_align16(o + T * 4);
+        q.off_wbase = o;  o = wt_align16(o + (T + 1) * 4);
+        q.off_wgt = o;    o = wt_align16(o + (T / 64 + 1) * 4);
+        q.off_wncov = o;  o = wt_align16(o + T * 4);
+        q.off_wfe = o;    o = wt_align16(o + T * 4);
+        q.off_wdk = o;    o = wt_align16(o + n_tracks * 4);
+        q.off_tbase = o;  o = wt_align16(o + T * 8);
+        q.off_ltc = o;    o = wt_align16(o + T * 4);
+        q.off_gtc = o;    o = wt_align16(o + (T / WT_DELTA_GROUP + 1) * 4);
+        q.off_tpfx = o;   o = wt_align16(o + (T + 1) * 4);
+        q.off_tfirst = o; o = wt_align16(o + WT_DELTA_TF * 2);
+        q.off_shared = o; o = wt_align16(o + (int) sizeof(WtShared));
+        q.lds_bytes = o;
+        if (q.lds_bytes > hard_limit - 1024) continue;
+        long long cap = 16ll * q.W;
+        const long long lane_max = 2ll * n_tracks * S;
+        if (cap < lane_max) cap = lane_max;
+        const long long all = 2 * n_intervals + 2;
+        if (cap > all) cap = all < lane_max ? lane_max : all;
+        if (const char *eC = getenv("WTAMD_WALK_CAP")) { const long long c = atoll(eC); if (c >= lane_max) cap = c; }
+        q.scratch_slab = (cap * 8 + 255) & ~255ll;
+        p = q;
+        return true;
+    }
+    return false;
+}
+
 // Chooses (positions per lane, T, W = ppt*T): the widest window whose bitmaps (and scratch
 // columns) fit one workgroup's LDS, 4 positions per lane when possible (instruction-level
 // parallelism, shared bitmap reads).  Environment overrides (experiments only): WTAMD_PPT, WTAMD_T.
@@ -296,6 +346,8 @@ static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.off_gtv = p.off_gtv; P.off_gtc = p.off_gtc; P.off_tbase = p.off_tbase; P.off_tpfx = p.off_tpfx; P.off_tfirst = p.off_tfirst; P.off_dsh = p.off_dsh; P.off_tdef = p.off_tdef;
     P.delta_df = 0; P.def_emin = 255; P.def_emax = 0;
     P.off_qa = p.off_qa; P.off_ltq = p.off_ltq; P.off_gtq = p.off_gtq; P.delta_q = p.delta_q;
+    P.off_wcol = p.off_wcol; P.off_wcnt = p.off_wcnt; P.off_woff = p.off_woff; P.off_wtot = p.off_wtot; P.off_wbase = p.off_wbase;
+    P.off_wgt = p.off_wgt; P.off_wncov = p.off_wncov; P.off_wfe = p.off_wfe; P.off_wdk = p.off_wdk; P.walk_S = p.walk_S;
     P.off_shared = p.off_shared; P.lds_bytes = p.lds_bytes;
 }
 
