@@ -23,15 +23,15 @@ def lib():
 
 
 def reduce(t, op, flags=0, n_set0=0, ppt=None, T=None, multiplex=False, ranges=None, chunk=None, global_scratch=None, delta_T=None, no_delta=None,
-           no_walk=None, walk_T=None, walk_S=None, walk_cap=None):
+           no_walk=None, walk_T=None, walk_S=None, walk_capp=None, walk_ov=None):
     """t: RunLists.  Returns (chrom, start, finish, value) [+ (tile, inplay) if multiplex], info."""
     from oracle.oracle import OPS
     opcode = 12 if multiplex else (OPS[op] if isinstance(op, str) else int(op))
     old = {k: os.environ.get(k) for k in ("WTAMD_PPT", "WTAMD_T", "WTAMD_CHUNK", "WTAMD_GLOBAL_SCRATCH", "WTAMD_DELTA_T", "WTAMD_NO_DELTA", "WTAMD_DELTA_MIN_TRACKS",
-                                             "WTAMD_NO_WALK", "WTAMD_WALK_T", "WTAMD_WALK_S", "WTAMD_WALK_CAP")}
+                                             "WTAMD_NO_WALK", "WTAMD_WALK_T", "WTAMD_WALK_S", "WTAMD_WALK_CAPP", "WTAMD_WALK_OV")}
     try:
         for k, v in (("WTAMD_PPT", ppt), ("WTAMD_T", T), ("WTAMD_CHUNK", chunk), ("WTAMD_GLOBAL_SCRATCH", global_scratch), ("WTAMD_DELTA_T", delta_T), ("WTAMD_NO_DELTA", no_delta), ("WTAMD_DELTA_MIN_TRACKS", 1),
-                     ("WTAMD_NO_WALK", no_walk), ("WTAMD_WALK_T", walk_T), ("WTAMD_WALK_S", walk_S), ("WTAMD_WALK_CAP", walk_cap)):
+                     ("WTAMD_NO_WALK", no_walk), ("WTAMD_WALK_T", walk_T), ("WTAMD_WALK_S", walk_S), ("WTAMD_WALK_CAPP", walk_capp), ("WTAMD_WALK_OV", walk_ov)):
             if v is None:
                 os.environ.pop(k, None)
             else:
@@ -67,5 +67,5 @@ def reduce(t, op, flags=0, n_set0=0, ppt=None, T=None, multiplex=False, ranges=N
     out = (chrom, os_[:n].copy(), of[:n].copy(), ov[:n].copy())
     if multiplex:
         out = (chrom, os_[:n].copy(), of[:n].copy(), tile[:n].copy(), ip[:n].copy())
-    return out, dict(W=int(info[0]), T=int(info[1]), lds=int(info[2]), n_windows=int(info[3]), n_chunks=int(info[6]), scratch_slab=int(info[7]), delta=int(info[8]), delta_bad=int(info[9]), delta_redo=int(info[10]), patched=int(info[11]), walk=int(info[12]), walk_rounds=int(info[13]),
+    return out, dict(W=int(info[0]), T=int(info[1]), lds=int(info[2]), n_windows=int(info[3]), n_chunks=int(info[6]), scratch_slab=int(info[7]), delta=int(info[8]), delta_bad=int(info[9]), delta_redo=int(info[10]), patched=int(info[11]), walk=int(info[12]), walk_rounds=int(info[13]), walk_fallback=int(info[14]),
                      covered_bp=int(info[4]), n_intervals=int(info[5]))

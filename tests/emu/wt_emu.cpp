@@ -104,7 +104,6 @@ struct EmuRun {
     }
 
     // wt_walk_kernel, phase by phase
-    template <int NR>
     void run_walk() {
         WtCtx c{};
         c.sh = (WtShared *) (lds.data() + P.off_shared);
@@ -120,24 +119,31 @@ struct EmuRun {
             const long long k = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
             if (k >= P.n_windows) break;
             wt_phase_header(P, c, k);
-            for (int t = 0; t < T; t++) wt_walk_zero(P, w, t, T);
+            for (int t = 0; t < T; t++) wt_walk_zero(P, c, w, t, T);
             for (int t = 0; t < T; t++) wt_delta_ranges1(P, c, d, 0, t, T);
             for (int t = 0; t < T; t++) wt_delta_ranges2(P, c, d, t, T);
             for (int t = 0; t < T; t++) wt_delta_ranges3(P, c, d, t, T);
             for (int t = 0; t < T; t++) wt_walk_pass<false>(P, c, w, d, 0u, 0u, t, T);
-            for (int t = 0; t < T; t++) wt_walk_offsets1(P, w, t, T);
-            for (int t = 0; t < T; t++) wt_walk_scan_b(w, t, T);
-            for (int t = 0; t < T; t++) wt_walk_offsets2(P, w, t, T);
             for (int t = 0; t < T; t++) { L[t].evmask = 0; L[t].emitmask = 0; }
-            for (int l0 = 0; l0 < T;) {
-                const int l1 = wt_walk_round_end(w, l0, T);
-                const uint32_t ev0 = w.base[l0], ev1 = w.base[l1];
-                if (ev1 > ev0) {
-                    n_rounds++;
-                    for (int t = 0; t < T; t++) wt_walk_pass<true>(P, c, w, d, ev0, ev1, t, T);
-                    for (int t = l0; t < l1; t++) wt_walk_lane<NR>(P, c, w, L[t], ev0, t, T);
+            if (getenv("WTEMU_DEBUG")) fprintf(stderr, "[walk] window %lld: novf %u ov_cap %u capp %d cap %u\n", k, w.novf[0], w.ov_cap, w.capp, w.cap);
+            if (w.novf[0] <= w.ov_cap) {
+                n_rounds++;
+                for (int t = 0; t < T; t++) wt_walk_lane<true>(P, c, w, L[t], 0u, t, T);
+            } else {
+                n_fallback++;
+                for (int t = 0; t < T; t++) wt_walk_offsets1(P, w, t, T);
+                for (int t = 0; t < T; t++) wt_walk_scan_b(w, t, T);
+                for (int t = 0; t < T; t++) wt_walk_offsets2(P, w, t, T);
+                for (int l0 = 0; l0 < T;) {
+                    const int l1 = wt_walk_round_end(w, l0, T);
+                    const uint32_t ev0 = w.base[l0], ev1 = w.base[l1];
+                    if (ev1 > ev0) {
+                        n_rounds++;
+                        for (int t = 0; t < T; t++) wt_walk_pass<true>(P, c, w, d, ev0, ev1, t, T);
+                        for (int t = l0; t < l1; t++) wt_walk_lane<false>(P, c, w, L[t], ev0, t, T);
+                    }
+                    l0 = l1;
                 }
-                l0 = l1;
             }
             for (int t = 0; t < T; t++) wt_walk_scan_a(w, (uint32_t) wt_popc32(L[t].emitmask), t, T);
             for (int t = 0; t < T; t++) wt_walk_scan_b(w, t, T);
@@ -146,7 +152,7 @@ struct EmuRun {
             wt_window_stats(P, c);
         }
     }
-    long long n_rounds = 0;
+    long long n_rounds = 0, n_fallback = 0;
 
     template <int OP, bool DF = false>
     void run_delta() {
@@ -239,7 +245,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         if (seg_off[s + 1] > seg_off[s]) { fs[s] = start[seg_off[s]]; lf[s] = finish[seg_off[s + 1] - 1]; }
     const int64_t total = seg_off[n_seg];
     std::vector<unsigned long long> counters(WT_CTR_N, 0);
-    long long used_delta = 0, delta_bad = 0, n_redo_total = 0, patched = 0, walk_used = 0, walk_rounds = 0;
+    long long used_delta = 0, delta_bad = 0, n_redo_total = 0, patched = 0, walk_used = 0, walk_rounds = 0, walk_fallback = 0;
     std::vector<int32_t> bad_list;
     std::vector<long long> bad_goff;
     WtWindowTables delta_tab;
@@ -257,7 +263,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
             // the engine's wt_pick_plan: the median over float tracks walks
             bool walk = false;
             if (op == WT_OP_MEDIAN && !value_is_f64 && !o_tile && !getenv("WTAMD_NO_WALK"))
-                if (const int nr = wt_regcol_slots(n_tracks, op, s32, n_set0)) walk = wt_make_walk_plan(R.plan, n_tracks, nr, total);
+                if (const int nr = wt_regcol_slots(n_tracks, op, s32, n_set0)) walk = wt_make_walk_plan(R.plan, n_tracks, nr, 0.0);
             if (!walk && !wt_make_plan(n_tracks, op, s32, R.plan, err, 80 * 1024, 160 * 1024, n_set0)) { fprintf(stderr, "wtemu: %s\n", err.c_str()); return -10; }
         }
         WtWindowTables tab;
@@ -323,14 +329,12 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
                 default: R.run_delta<WT_OP_STDDEV>(); break;
                 }
             } else if (R.plan.walk_S) {
-                if (R.plan.regcol == 32) R.run_walk<32>();
-                else if (R.plan.regcol == 64) R.run_walk<64>();
-                else R.run_walk<128>();
+                R.run_walk();
             } else if (!wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R.plan.n_chunks > 1 || R.plan.scratch_slab > 0, R, R.plan.regcol)) {
                 return -11;
             }
         }
-        if (R.plan.walk_S) { walk_used = 1; walk_rounds = R.n_rounds; }
+        if (R.plan.walk_S) { walk_used = 1; walk_rounds = R.n_rounds; walk_fallback = R.n_fallback; }
         if (info && !patching) { info[0] = R.plan.W; info[1] = R.plan.T; info[2] = R.plan.lds_bytes; info[3] = tab.n_windows; info[6] = R.plan.n_chunks; info[7] = R.plan.scratch_slab;
                     info[4] = (long long) counters[WT_CTR_BP]; info[5] = (long long) counters[WT_CTR_INTERVALS]; }
         if (delta) {
@@ -347,7 +351,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         }
     }
     if (info) { info[8] = used_delta; info[9] = delta_bad; info[10] = n_redo_total; info[11] = patched; }
-    if (info) { info[12] = walk_used; info[13] = walk_rounds; }
+    if (info) { info[12] = walk_used; info[13] = walk_rounds; info[14] = walk_fallback; }
     if (counters[WT_CTR_ERROR] & WT_ERR_CAPACITY) return -1;
     if (counters[WT_CTR_ERROR]) return -2;
     return (long long) counters[WT_CTR_RUNS];

@@ -492,7 +492,7 @@ def test_plan_policy_snapshot():
     p = plan(500, "var", no_delta=1)
     assert (p["W"], p["T"]) == (2048, 512) and p["n_chunks"] == 5        # general kernel: chunks of <= 112 tracks
     p = plan(100, "median")
-    assert (p["walk"], p["W"], p["T"], p["lds"] < 80 * 1024) == (1, 2048, 128, True)                  # round 4: walking, 128 lanes x 16 positions, two workgroups per CU
+    assert (p["walk"], p["W"], p["T"]) == (1, 4096, 256)                                              # round 4: walking, 256 lanes x 16 positions, one workgroup per CU
     p = plan(100, "median", no_walk=1)
     assert (p["W"], p["T"], p["lds"] < 32 * 1024) == (512, 256, True) and p["scratch_slab"] == 0     # round 2: value column in REGISTERS, LDS = bitmaps only, 2 positions per lane
     p = plan(100, "mwu", n_set0=50)
@@ -583,22 +583,25 @@ def test_emu_median_walk_fuzz(oracle, seed):
     if n > T:
         T = 128
     S = int(rng.choice([4, 8, 16]))
-    cap = None if rng.random() < 0.5 else 2 * n * S + int(rng.integers(0, 200))
+    # event slots per position / entries of the overflow list: the defaults (16, 2048) hold ordinary windows; small ones
+    # send events through the overflow list, none at all sends every window with a full position to the fallback (its
+    # events sorted into the slab by a second pass, in rounds when they do not fit at once)
+    capp, ov = [(None, None), (None, None), (2, None), (1, 5), (2, 0), (1, 0)][int(rng.integers(0, 6))]
     flags = int(rng.choice([0, 0, 1]))
     ranges = None
     if rng.random() < 0.3:
         ranges = [(int(rng.integers(1, L // 2 + 2)), int(rng.integers(L // 2 + 1, L + 60))) for L in lens]
-    got, info = emu.reduce(t, "median", flags=flags, walk_T=T, walk_S=S, walk_cap=cap, ranges=ranges)
-    assert info["walk"] == 1 and (info["W"], info["T"]) == (T * S, T)
-    tt = t if ranges is None else t      # (the oracle takes the same ranges below)
-    exp = oracle.reduce(tt.as_dict(), "median", flags=flags) if ranges is None else None
+    got, info = emu.reduce(t, "median", flags=flags, walk_T=T, walk_S=S, walk_capp=capp, walk_ov=ov, ranges=ranges)
+    assert info["walk"] == 1 and info["W"] == info["T"] * S
+    assert info["T"] == T or n * T * 4 > 120 * 1024         # (the columns of 256 lanes do not fit: 128)
+    exp = oracle.reduce(t.as_dict(), "median", flags=flags) if ranges is None else None
     old, info2 = emu.reduce(t, "median", flags=flags, no_walk=1, ranges=ranges)
     assert info2["walk"] == 0
     assert_runs_equal(got, old, 0.0, "walking vs bitmap kernel")
     if exp is not None:
         assert_runs_equal(got, exp, 0.0, "walking vs oracle")
-    if cap is not None and t.n_intervals > 4 * cap:
-        assert info["walk_rounds"] > info["n_windows"]       # some window needed more than one slab
+    if ov == 0 and n >= 8 and t.n_intervals > 50 * n:
+        assert info["walk_fallback"] > 0
 
 
 def test_emu_median_walk_dense_and_sparse(oracle):
@@ -607,13 +610,19 @@ def test_emu_median_walk_dense_and_sparse(oracle):
     rng = np.random.default_rng(5)
     n, L = 9, 700
     per_bp = [[(p, p + 1, float(rng.integers(0, 50)) / 4.0) for p in range(1, L)] for _ in range(n)]
-    t = _f32(RunLists.from_lists([per_bp]))
-    got, info = emu.reduce(t, "median", walk_T=64, walk_S=4, walk_cap=2 * n * 4)
-    assert info["walk"] == 1 and info["walk_rounds"] > info["n_windows"]
-    assert_runs_equal(got, oracle.reduce(t.as_dict(), "median"), 0.0, "one run per bp")
+    t = _f32(RunLists.from_lists([[r] for r in per_bp]))         # (track, chromosome)
+    got, info = emu.reduce(t, "median", walk_T=64, walk_S=4, walk_capp=2, walk_ov=0)
+    assert info["walk"] == 1 and info["walk_fallback"] == info["n_windows"] and info["walk_rounds"] > info["n_windows"]      # sorted, in rounds
+    assert_runs_equal(got, oracle.reduce(t.as_dict(), "median"), 0.0, "one run per bp, fallback")
+    # a few positions with more events than slots: those go through the overflow list, no fallback
+    burst = [[(100, 100 + 7 * (i + 1), float(i)), (400 + i // 3, 500, float(-i))] for i in range(n)]
+    t2 = _f32(RunLists.from_lists([[r] for r in burst]))
+    got, info = emu.reduce(t2, "median", walk_T=64, walk_S=4, walk_capp=4)
+    assert info["walk"] == 1 and info["walk_fallback"] == 0
+    assert_runs_equal(got, oracle.reduce(t2.as_dict(), "median"), 0.0, "nine starts at one position, overflow list")
     one = [[(int(rng.integers(1, 3000)), 0, float(i))] for i in range(n)]
     one = [[(s, s + int(rng.integers(1, 4000)), v)] for [(s, _, v)] in one]
-    t = _f32(RunLists.from_lists([one]))
+    t = _f32(RunLists.from_lists([[r] for r in one]))
     for flags in (0, 1):
         got, info = emu.reduce(t, "median", flags=flags)
         assert info["walk"] == 1

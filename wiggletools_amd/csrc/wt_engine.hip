@@ -362,83 +362,6 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
 #endif
 }
 
-// MedianReduction by walking (wt_walk.h): a lane carries its column of current values from one position to the next.
-// T lanes (128: two workgroups per CU at 100 tracks) x S positions each; persistent workgroups, window tickets, ordered
-// output through the look-back chain like the other kernels.
-template <int NR>
-__global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
-    extern __shared__ __attribute__((aligned(16))) char wt_lds[];
-    WtCtx c{};
-    c.sh = (WtShared *) (wt_lds + P.off_shared);
-    WtDeltaCtx d;
-    wt_delta_ctx_init(d, P, wt_lds);
-    WtWalkCtx w;
-    wt_walk_ctx_init(w, P, wt_lds, P.g_scratch + (size_t) blockIdx.x * (size_t) P.g_scratch_slab);
-    const int tid = threadIdx.x, nt = blockDim.x;
-    long long k_dbg = -1;
-    (void) k_dbg;
-    if (tid == 0) {
-        const long long k0 = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
-        c.sh->ticket = k0;
-        if (k0 < P.n_windows) wt_phase_header(P, c, k0);
-    }
-    wt_walk_defaults(P, w, tid, nt);
-    __syncthreads();
-    for (;;) {
-        const long long k = c.sh->ticket;
-        k_dbg = k;
-        if (k >= P.n_windows) break;
-        WT_MARK(201);
-        wt_walk_zero(P, w, tid, nt);
-        wt_delta_ranges_w1(P, c, d, 0, tid, nt);
-        __syncthreads();
-        wt_delta_ranges_w2(P, c, d, tid, nt);
-        __syncthreads();
-        WT_MARK(202);
-        wt_walk_pass<false>(P, c, w, d, 0u, 0u, tid, nt);
-        __syncthreads();
-        wt_walk_offsets1(P, w, tid, nt);
-        __syncthreads();
-        wt_walk_scan_b(w, tid, nt);
-        __syncthreads();
-        wt_walk_offsets2(P, w, tid, nt);
-        __syncthreads();
-        WT_MARK(203);
-        WtWalkLane L;
-        L.evmask = 0; L.emitmask = 0;
-        for (int l0 = 0; l0 < nt;) {
-            const int l1 = wt_walk_round_end(w, l0, nt);
-            const uint32_t ev0 = w.base[l0], ev1 = w.base[l1];
-            if (ev1 > ev0) {                    // (uniform)
-                wt_walk_pass<true>(P, c, w, d, ev0, ev1, tid, nt);
-                __syncthreads();                // the events are in the slab (and read back past the L1: wt_walk_event)
-                if (tid >= l0 && tid < l1) wt_walk_lane<NR>(P, c, w, L, ev0, tid, nt);
-                __syncthreads();                // before the next round reuses the slab / base[] is rewritten
-            }
-            l0 = l1;
-        }
-        WT_MARK(204);
-        wt_walk_scan_a(w, (uint32_t) wt_popc32(L.emitmask), tid, nt);
-        __syncthreads();
-        wt_walk_scan_b(w, tid, nt);
-        __syncthreads();
-        const unsigned long long mine = w.base[nt];
-        if (tid == 0) wt_lookback_publish(P, c, k, mine);
-        if (tid < 64) wt_lookback_complete(P, c, k, tid, mine);
-        __syncthreads();
-        WT_MARK(205);
-        wt_walk_write(P, c, w, L, tid, nt);
-        __syncthreads();
-        if (tid == 0) {
-            wt_window_stats(P, c);
-            const long long kn = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
-            c.sh->ticket = kn;
-            if (kn < P.n_windows) wt_phase_header(P, c, kn);
-        }
-        __syncthreads();
-    }
-}
-
 // Patch kernel: the general bitmap multiplexer over just the windows the difference-array kernel
 // could not prove exact (a NaN, an Inf, too wide a dynamic range).  That kernel has already emitted
 // those windows' runs -- coordinates, run count, position in the output -- so this one only has
@@ -1331,12 +1254,30 @@ static bool wt_wants_delta(const wtamd_trackset *ts, int op) {
     return !ts->delta_failed && wt_delta_eligible(op, ts->value_f64, ts->n_tracks, ts->defaults.data());
 }
 
+// Events (run starts, plus a finish wherever a gap follows) per base pair the track set is expected to hold: the walking
+// kernel sizes its per-position slots from it.  Contiguous runs assumed for a quarter of them to be followed by a gap.
+static double wt_events_per_bp(const wtamd_trackset *ts) {
+    const int N = ts->n_tracks;
+    double span = 0;
+    for (int c = 0; c < ts->n_chrom; c++) {
+        int64_t lo = INT64_MAX, hi = INT64_MIN;
+        for (int i = 0; i < N; i++) {
+            const size_t s = (size_t) c * N + i;
+            if (s + 1 >= ts->seg_off.size() || ts->seg_off[s + 1] <= ts->seg_off[s] || s >= ts->first_start.size()) continue;
+            lo = std::min<int64_t>(lo, ts->first_start[s]);
+            hi = std::max<int64_t>(hi, ts->last_finish[s]);
+        }
+        if (hi > lo) span += (double) (hi - lo);
+    }
+    return span > 0 ? 1.25 * (double) ts->n_intervals / span : 0.0;
+}
+
 // The general (non difference-array) plan: MedianReduction over float tracks walks (wt_walk.h), everything else
 // -- and the median with WTAMD_NO_WALK=1, or when a Multiplexer tile is wanted -- takes the bitmap kernel.
 static bool wt_pick_plan(const wtamd_trackset *ts, int op, int n_set0, WtPlan &plan, std::string &err) {
     if (op == WT_OP_MEDIAN && !ts->value_f64 && !getenv("WTAMD_NO_WALK"))
         if (const int nr = wt_regcol_slots(ts->n_tracks, op, ts->scratch_f32, n_set0))
-            if (wt_make_walk_plan(plan, ts->n_tracks, nr, ts->n_intervals)) return true;
+            if (wt_make_walk_plan(plan, ts->n_tracks, nr, wt_events_per_bp(ts))) return true;
     return wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err, 80 * 1024, 160 * 1024, n_set0);
 }
 
@@ -1432,33 +1373,8 @@ static hipError_t wt_launch_patch_t(const WtParams &P, const WtPatchArgs &Q, int
     return hipGetLastError();
 }
 
-template <int NR>
-static void wt_launch_walk(WtLaunch &L) {
-    auto kern = wt_walk_kernel<NR>;
-    if (L.lds > 48 * 1024) {
-        L.err = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, L.lds);
-        if (L.err != hipSuccess) return;
-    }
-    int per_cu = 0;
-    L.err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, L.T, (size_t) L.lds);
-    if (L.err != hipSuccess) return;
-    if (per_cu < 1) per_cu = 1;
-    long long g = (long long) L.num_cu * per_cu;
-    if (g > L.P.n_windows) g = L.P.n_windows;
-    if (g < 1) g = 1;
-    const size_t need = (size_t) g * (size_t) L.P.g_scratch_slab;      // one slab of events per resident workgroup
-    if (*L.gscratch_bytes < need) {
-        (void) hipFree(*L.gscratch);        // synchronises with earlier launches
-        *L.gscratch = nullptr; *L.gscratch_bytes = 0;
-        L.err = hipMalloc((void **) L.gscratch, need);
-        if (L.err != hipSuccess) return;
-        *L.gscratch_bytes = need;
-    }
-    L.P.g_scratch = *L.gscratch;
-    L.grid = (int) g;
-    hipLaunchKernelGGL(kern, dim3((unsigned) g), dim3((unsigned) L.T), (size_t) L.lds, L.stream, L.P);
-    L.err = hipGetLastError();
-}
+// csrc/wt_walk.hip (its own translation unit: the three instantiations of the kernel take minutes to compile)
+hipError_t wt_walk_launch(WtParams &P, int nr, int T, int lds, int num_cu, char **gscratch, size_t *gscratch_bytes, hipStream_t s, int *grid);
 
 template <int OP, bool DF = false>
 static void wt_launch_delta(WtLaunch &L) {
@@ -1647,9 +1563,7 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
             default: wt_launch_delta<WT_OP_STDDEV>(L); break;      // stddev, entropy (reducers.c:665)
             }
         } else if (plan.walk_S) {
-            if (plan.regcol == 32) wt_launch_walk<32>(L);
-            else if (plan.regcol == 64) wt_launch_walk<64>(L);
-            else wt_launch_walk<128>(L);
+            L.err = wt_walk_launch(L.P, plan.regcol, L.T, L.lds, L.num_cu, L.gscratch, L.gscratch_bytes, L.stream, &L.grid);
         } else if (!wt_dispatch(op, ts->value_f64, ts->scratch_f32, plan.ppt, plan.n_chunks > 1 || plan.scratch_slab > 0, L, plan.regcol)) {
             return wt_fail(WTAMD_ERR_ARG, "op not dispatchable");
         }
@@ -1691,6 +1605,17 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
         ts->stats.covered_bp = (int64_t) ts->h_counters[WT_CTR_BP];
         ts->stats.n_intervals = (int64_t) ts->h_counters[WT_CTR_INTERVALS];
         *n_runs = ts->stats.n_runs;
+        if (plan.walk_S) {      // (-DWT_PROFILE builds of wt_walk.hip: cycles of wave 0 per phase, summed over the workgroups)
+            static const bool show = getenv("WTAMD_WALK_PROF") != nullptr;
+            if (show) {
+                static const char *names_w[8] = {"zero+ranges", "count", "offsets", "scatter", "events", "first-median", "moves", "rest"};
+                unsigned long long tot = 0;
+                for (int q = 0; q < 8; q++) tot += ts->h_counters[WT_CTR_PROF + q];
+                fprintf(stderr, "[wt_walk_profile]");
+                for (int q = 0; q < 8; q++) fprintf(stderr, " %s %.1f%%", names_w[q], tot ? 100.0 * ts->h_counters[WT_CTR_PROF + q] / tot : 0.0);
+                fprintf(stderr, " (total %.3g cycles)\n", (double) tot);
+            }
+        }
 #ifdef WT_PROFILE
         {
             static const char *names_g[8] = {"zero", "load", "count", "emask+escan", "eval", "lookback", "write", "-"};

@@ -32,7 +32,9 @@ struct WtPlan {
     int ppt = 1;            // consecutive window positions per lane (1 or 4)
     int regcol = 0;         // median / MWU: register slots of the per-lane value column (0: LDS / global columns)
     int walk_S = 0;         // median by walking (wt_walk.h): positions per lane (0: not that plan)
-    int off_wcol = 0, off_wcnt = 0, off_woff = 0, off_wtot = 0, off_wbase = 0, off_wgt = 0, off_wncov = 0, off_wfe = 0, off_wdk = 0;
+    int walk_capp = 0;      // ... fixed event slots per position
+    int walk_ov = 0;        // ... entries of the overflow list
+    int off_wcol = 0, off_wcnt = 0, off_woff = 0, off_wtot = 0, off_wbase = 0, off_wgt = 0, off_wncov = 0, off_wfe = 0, off_wdk = 0, off_wseg = 0, off_wguess = 0;
 };
 
 static inline int wt_align16(int x) { return (x + 15) & ~15; }
@@ -171,16 +173,19 @@ static inline void wt_delta_defaults_params(const double *defaults, int n_tracks
 }
 
 // Median by walking (wt_walk.h): T lanes x S consecutive positions each; the lanes' value columns (N x 4 bytes per
-// lane) are what fills the LDS.  The first median of a stretch comes from the register network of the bitmap kernel,
-// hence `nr` slots (wt_regcol_slots) and at most 128 tracks; the window's runs are enumerated through the
-// difference-array kernel's flat index space, one chunk: N <= T.
-// WTAMD_WALK_T / WTAMD_WALK_S: experiments.  The slab holds the events of a window: 16 per bp, at least what the longest
-// stretch of one lane can hold (2 N S), never more than the whole track set has (tests with tiny inputs).
-static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, long long n_intervals, int hard_limit = 160 * 1024) {
+// lane) are what fills the LDS.  Same domain as the register columns of the bitmap kernel (wt_regcol_slots: float
+// tracks, float-exact defaults, at most 128 of them); the window's runs are enumerated through the difference-array
+// kernel's flat index space, one chunk: N <= T.
+// WTAMD_WALK_T / WTAMD_WALK_S: experiments.  The slab of a workgroup: event slots per position (WTAMD_WALK_CAPP; sized
+// from the data's density) + an overflow list of WTAMD_WALK_OV entries; a window with more than a few events beyond their
+// slots (WT_WALK_OV_SCAN: a lane scans the whole list for every such position) falls back to sorting its events into the
+// same memory, in as many rounds as it takes: at least the 2 N S events the stretch of one lane can hold fit.
+// events_per_bp: what the data is expected to hold (the host's estimate from the run count and the covered span; <= 0: unknown).
+static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double events_per_bp, int hard_limit = 160 * 1024) {
     const char *eT = getenv("WTAMD_WALK_T"), *eS = getenv("WTAMD_WALK_S");
     int S = eS ? atoi(eS) : 16;
     if (S != 4 && S != 8 && S != 16) S = 16;
-    const int want = eT ? atoi(eT) : 128;
+    const int want = eT ? atoi(eT) : 256;
     for (int T : {want, 256, 128, 64}) {
         if (T != 64 && T != 128 && T != 256) continue;
         if (n_tracks > T) continue;
@@ -188,7 +193,7 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, long long 
         q.T = T; q.W = T * S; q.n_words = q.W / 64; q.ppt = S; q.walk_S = S; q.regcol = nr;
         q.chunk_tracks = n_tracks; q.n_chunks = 1;
         int o = 0;
-        q.off_wcol = o;   o = wt_align16(o + n_tracks * T * 4);
+        q.off_wcol = o;   o = wt_align16(o + ((n_tracks + 7) & ~7) * T * 4);        // (WT_WALK_PAD rows)
         q.off_wcnt = o;   o = wt_align16(o + q.W * 4);
         q.off_woff = o;   o = wt_align16(o + (q.W + 1) * 4);
         q.off_wtot = o;   o = wt_align16(o + T * 4);
@@ -197,6 +202,8 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, long long 
         q.off_wncov = o;  o = wt_align16(o + T * 4);
         q.off_wfe = o;    o = wt_align16(o + T * 4);
         q.off_wdk = o;    o = wt_align16(o + n_tracks * 4);
+        q.off_wseg = o;   o = wt_align16(o + 2 * T * 8);
+        q.off_wguess = o; o = wt_align16(o + 8);       // (+ the overflow counter)
         q.off_tbase = o;  o = wt_align16(o + T * 8);
         q.off_ltc = o;    o = wt_align16(o + T * 4);
         q.off_gtc = o;    o = wt_align16(o + (T / WT_DELTA_GROUP + 1) * 4);
@@ -205,13 +212,21 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, long long 
         q.off_shared = o; o = wt_align16(o + (int) sizeof(WtShared));
         q.lds_bytes = o;
         if (q.lds_bytes > hard_limit - 1024) continue;
-        long long cap = 16ll * q.W;
-        const long long lane_max = 2ll * n_tracks * S;
-        if (cap < lane_max) cap = lane_max;
-        const long long all = 2 * n_intervals + 2;
-        if (cap > all) cap = all < lane_max ? lane_max : all;
-        if (const char *eC = getenv("WTAMD_WALK_CAP")) { const long long c = atoll(eC); if (c >= lane_max) cap = c; }
-        q.scratch_slab = (cap * 8 + 255) & ~255ll;
+        // slots per position: 2.5 x the expected events (a Poisson tail of 2e-4 per position at 6 events), 8 .. 64
+        int capp = 16;
+        if (events_per_bp > 0) {
+            capp = 8;
+            while (capp < 64 && capp < 2.5 * events_per_bp) capp <<= 1;
+        }
+        if (const char *eC = getenv("WTAMD_WALK_CAPP")) { const int c = atoi(eC); if (c >= 1 && c <= 64 && !(c & (c - 1))) capp = c; }
+        long long ov = 2048;
+        if (const char *eO = getenv("WTAMD_WALK_OV")) { const long long c = atoll(eO); if (c >= 0) ov = c; }
+        q.walk_capp = capp;
+        q.walk_ov = (int) ov;
+        long long bytes = (long long) q.W * capp * 8 + (ov > 8 ? ov : 8) * 12;      // (the fixed fetch may read 8 events past the slots)
+        const long long lane_max = 2ll * n_tracks * S * 8;
+        if (bytes < lane_max) bytes = lane_max;
+        q.scratch_slab = (bytes + 255) & ~255ll;
         p = q;
         return true;
     }
@@ -348,6 +363,7 @@ static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.off_qa = p.off_qa; P.off_ltq = p.off_ltq; P.off_gtq = p.off_gtq; P.delta_q = p.delta_q;
     P.off_wcol = p.off_wcol; P.off_wcnt = p.off_wcnt; P.off_woff = p.off_woff; P.off_wtot = p.off_wtot; P.off_wbase = p.off_wbase;
     P.off_wgt = p.off_wgt; P.off_wncov = p.off_wncov; P.off_wfe = p.off_wfe; P.off_wdk = p.off_wdk; P.walk_S = p.walk_S;
+    P.off_wseg = p.off_wseg; P.off_wguess = p.off_wguess; P.walk_capp = p.walk_capp; P.walk_ov = p.walk_ov;
     P.off_shared = p.off_shared; P.lds_bytes = p.lds_bytes;
 }
 

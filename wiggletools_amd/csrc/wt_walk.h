@@ -13,15 +13,14 @@
 //            writes its value into that lane's column: the columns start out right without any look-up.
 //   offsets  prefix sums of the counts: the events of a position are a contiguous slice of the workgroup's slab
 //   scatter  second pass over the runs: every event to its slot (track, new key, coverage change)
-//   walk     per lane: the median of its first position by the sorting network (as the bitmap kernel does for every
-//            position), then position by position: apply the events (old key out, new key in, the counts of keys
-//            below / not above the current median m kept up to date), and when the wanted rank k = N/2 has left
-//            [lt, le) move m: ONE sweep over the column collects the four nearest keys on the side m has to move to
-//            (ties are handled as a multiset, so the result is the exact order statistic, bit for bit what the
-//            sort gives)
+//   walk     per lane, position by position: apply the events (old key out, new key in, the counts of keys below / not
+//            above the current median m kept up to date), and when the wanted rank k = N/2 has left [lt, le) move m: ONE
+//            sweep over the column collects the 2 / 4 / 8 nearest keys on the side m has to move to (ties are handled as
+//            a multiset, so the result is the exact order statistic, bit for bit what a sort gives).  The first median
+//            of a stretch starts from the last one any lane of the workgroup found (same distribution: a few ranks off).
 //   emit     run count scan, look-back, the lanes write their runs
 //
-// Eligibility (host): float tracks, float-exact defaults, N <= 128 (the first median uses the register network).
+// Eligibility (host): float tracks, float-exact defaults, N <= 128.
 // The output is the bitmap kernel's, bit for bit (same keys, same order statistic, NaN if any value is NaN).
 #ifndef WT_WALK_H_
 #define WT_WALK_H_
@@ -30,8 +29,11 @@
 #define WT_WALK_INC 0x10000u           // event: the track becomes covered
 #define WT_WALK_DEC 0x20000u           // event: the track stops being covered
 #define WT_WALK_MAX_S 16
+#define WT_WALK_PAD 8                  // col[] has a multiple of this many rows (the sweeps' block)
+#define WT_WALK_OV_SCAN 32             // events beyond their positions' slots a window may have and still be walked from the slots
 
 struct alignas(8) WtWalkEvent { uint32_t key, meta; };     // meta: track | WT_WALK_INC | WT_WALK_DEC
+struct WtWalkOvf { uint32_t pos, key, meta; };             // an event that did not fit its position's fixed slots
 
 struct WtWalkCtx {
     uint32_t *col;      // [N][T] current keys, one column per lane
@@ -43,9 +45,17 @@ struct WtWalkCtx {
     int32_t *ncov;      // [T] tracks covering the position before the lane's first one
     int32_t *fe;        // [T] first position (window-relative) of the lane's stretch that has an event, or -1
     uint32_t *dkey;     // [N] keys of the defaults
-    WtWalkEvent *slab;  // this workgroup's events (global)
-    uint32_t cap;       // events the slab holds
-    int S;              // positions per lane
+    long long *seg0, *seg1;     // [T] byte offsets (4-byte columns) of the first run of the track's segment / one past its last
+    uint32_t *guess;    // [1] a recent median of this workgroup (where a stretch's first selection starts)
+    WtWalkEvent *slab;  // this workgroup's events (global): capp slots per position, or (fallback) the sorted sequence
+    WtWalkOvf *ovf;     // ... behind the fixed slots: the events beyond a position's slots
+    uint32_t *novf;     // [1] how many of those (LDS)
+    uint32_t cap;       // events the slab holds (sorted use)
+    uint32_t ov_cap;    // entries of ovf[]
+    int capp;           // fixed slots per position (a power of two)
+    int npad;           // rows of col[]: N rounded up to the sweeps' block (the extra rows hold 0xffffffff)
+    int S;              // positions per lane (a power of two)
+    int logS;
 };
 
 WT_DEV void wt_walk_ctx_init(WtWalkCtx &w, const WtParams &P, char *lds, char *slab) {
@@ -58,9 +68,19 @@ WT_DEV void wt_walk_ctx_init(WtWalkCtx &w, const WtParams &P, char *lds, char *s
     w.ncov = (int32_t *) (lds + P.off_wncov);
     w.fe = (int32_t *) (lds + P.off_wfe);
     w.dkey = (uint32_t *) (lds + P.off_wdk);
+    w.seg0 = (long long *) (lds + P.off_wseg);
+    w.seg1 = w.seg0 + P.W / P.walk_S;
+    w.guess = (uint32_t *) (lds + P.off_wguess);
     w.slab = (WtWalkEvent *) slab;
     w.cap = (uint32_t) (P.g_scratch_slab / (long long) sizeof(WtWalkEvent));
+    w.capp = P.walk_capp;
+    w.ovf = (WtWalkOvf *) (slab + (size_t) P.W * (size_t) P.walk_capp * sizeof(WtWalkEvent));
+    w.ov_cap = (uint32_t) (P.walk_ov < WT_WALK_OV_SCAN ? P.walk_ov : WT_WALK_OV_SCAN);
+    w.novf = w.guess + 1;
+    w.npad = (P.n_tracks + WT_WALK_PAD - 1) & ~(WT_WALK_PAD - 1);
     w.S = P.walk_S;
+    w.logS = 0;
+    while ((1 << w.logS) < w.S) w.logS++;
 }
 
 // order-preserving key of the float with bits `vb`; every NaN gets the same one, above +Inf
@@ -71,14 +91,22 @@ WT_DEV uint32_t wt_walk_key(uint32_t vb) {
 // once per workgroup
 WT_DEV void wt_walk_defaults(const WtParams &P, WtWalkCtx &w, int tid, int nt) {
     for (int i = tid; i < P.n_tracks; i += nt) w.dkey[i] = wt_walk_key(__builtin_bit_cast(uint32_t, (float) P.defaults[i]));
+    if (tid == 0) w.guess[0] = 0x80000000u;        // (the key of 0.0; any key will do)
 }
 
 // per window: no events, nothing covered, every column holds the defaults
-WT_DEV void wt_walk_zero(const WtParams &P, WtWalkCtx &w, int tid, int nt) {
+WT_DEV void wt_walk_zero(const WtParams &P, const WtCtx &c, WtWalkCtx &w, int tid, int nt) {
     for (int x = tid; x < P.W; x += nt) w.cnt[x] = 0;
     w.ncov[tid] = 0;
     const int N = P.n_tracks;
     for (int i = 0; i < N; i++) w.col[i * nt + tid] = w.dkey[i];
+    for (int i = N; i < w.npad; i++) w.col[i * nt + tid] = 0xffffffffu;       // (above every key, never NaN's)
+    if (tid == 0) w.novf[0] = 0;
+    if (tid < N) {          // the segment of track `tid` on this window's chromosome
+        const long long seg = (long long) c.sh->chrom * N + tid;
+        w.seg0[tid] = P.seg_off[seg] * 4;
+        w.seg1[tid] = P.seg_off[seg + 1] * 4;
+    }
 }
 
 // ---- the window's runs, twice (count, scatter): the flat index space of wt_delta.h ----
@@ -91,15 +119,14 @@ struct WtWalkBatch {
 };
 
 // (unconditional, always in range: see wt_delta_fetch)
-WT_DEV void wt_walk_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, int chrom, WtWalkBatch &B) {
+WT_DEV void wt_walk_fetch(const WtParams &P, const WtDeltaCtx &d, const WtWalkCtx &w, int nt, uint32_t M, uint32_t tb, int lane, WtWalkBatch &B) {
     const uint32_t lastt = (M - 1u) / WT_DELTA_TILE * WT_DELTA_TILE;
     const uint32_t tbe = tb < lastt ? tb : lastt;
     const uint32_t tile = tbe / WT_DELTA_TILE;
     int i = tile < WT_DELTA_TF ? (int) d.tfirst[tile] : wt_delta_find(d.tpfx, nt, tbe, 0);
     uint32_t hi = d.tpfx[i + 1];
     long long dl = d.tbase[i];
-    const int N = P.n_tracks;
-    long long s0 = P.seg_off[(long long) chrom * N + i] * 4, s1 = P.seg_off[(long long) chrom * N + i + 1] * 4;
+    long long s0 = w.seg0[i], s1 = w.seg1[i];
 #pragma unroll
     for (int u = 0; u < WT_DELTA_U; u++) {
         uint32_t jj = tbe + (uint32_t) lane + 64u * (uint32_t) u;
@@ -107,7 +134,7 @@ WT_DEV void wt_walk_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint32
         if (jj >= hi) {
             do { i++; hi = d.tpfx[i + 1]; } while (jj >= hi);
             dl = d.tbase[i];
-            s0 = P.seg_off[(long long) chrom * N + i] * 4; s1 = P.seg_off[(long long) chrom * N + i + 1] * 4;
+            s0 = w.seg0[i]; s1 = w.seg1[i];
         }
         const long long ob = dl + ((long long) jj << 2);
         const bool fst = ob <= s0, lst = ob + 4 >= s1;
@@ -121,32 +148,52 @@ WT_DEV void wt_walk_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint32
     }
 }
 
-// one run, count pass
-WT_DEV void wt_walk_count1(const WtParams &P, WtWalkCtx &w, int nt, int32_t w0, int32_t width, int trk, int32_t s, int32_t f, int32_t ns,
-                           bool last, uint32_t vb, int32_t &my_next) {
-    const int32_t cs = s - w0, cf = f - w0;     // cf >= 0: the window's runs finish at or beyond w0
-    if (cs >= width) { my_next = s < my_next ? s : my_next; return; }
-    if (cs >= 0) wt_lds_add32(&w.cnt[cs], 1u);
-    if (cf < width) {
-        if (last || ns != f) wt_lds_add32(&w.cnt[cf], 1u);       // (else the next run's start event says it all)
+#ifdef WT_EMU
+WT_DEV uint32_t wt_lds_inc_rtn(uint32_t *p) { return (*p)++; }
+#else
+WT_DEV uint32_t wt_lds_inc_rtn(uint32_t *p) { return atomicAdd((unsigned int *) p, 1u); }
+#endif
+
+// an event of position cs: counted, and placed in one of the position's fixed slots -- or, beyond them, in the overflow list
+WT_DEV void wt_walk_place(WtWalkCtx &w, int32_t cs, uint32_t key, uint32_t meta) {
+    const uint32_t slot = wt_lds_inc_rtn(&w.cnt[cs]);
+    if (slot < (uint32_t) w.capp) {
+        WtWalkEvent e;
+        e.key = key; e.meta = meta;
+        w.slab[(uint32_t) cs * (uint32_t) w.capp + slot] = e;
     } else {
-        my_next = f < my_next ? f : my_next;
-    }
-    // the lanes whose first position a lies in (s, f]: the run covers the position before a
-    const int S = w.S;
-    int l = cs < 0 ? 0 : cs / S + 1;
-    int lh = cf / S;
-    if (lh > nt - 1) lh = nt - 1;
-    if (l <= lh) {
-        const uint32_t key = wt_walk_key(vb);
-        for (; l <= lh; l++) {
-            w.col[trk * nt + l] = key;
-            wt_lds_addi32(&w.ncov[l], 1);
+        const uint32_t j = wt_lds_inc_rtn(w.novf);
+        if (j < w.ov_cap) {
+            WtWalkOvf o;
+            o.pos = (uint32_t) cs; o.key = key; o.meta = meta;
+            w.ovf[j] = o;
         }
     }
 }
 
-// one run, scatter pass (cnt[] counts down: the slots of a position are handed out from the last to the first)
+// one run, first pass: its events counted and placed, the columns it covers from before initialised
+WT_DEV void wt_walk_count1(const WtParams &P, WtWalkCtx &w, int nt, int32_t w0, int32_t width, int trk, int32_t s, int32_t f, int32_t ps,
+                           int32_t ns, bool first, bool last, uint32_t vb, int32_t &my_next) {
+    const int32_t cs = s - w0, cf = f - w0;     // cf >= 0: the window's runs finish at or beyond w0
+    if (cs >= width) { my_next = s < my_next ? s : my_next; return; }
+    const uint32_t key = wt_walk_key(vb);
+    if (cs >= 0) wt_walk_place(w, cs, key, (uint32_t) trk | ((first || ps != s) ? WT_WALK_INC : 0u));
+    if (cf < width) {
+        if (last || ns != f) wt_walk_place(w, cf, w.dkey[trk], (uint32_t) trk | WT_WALK_DEC);      // (else the next run's start event says it all)
+    } else {
+        my_next = f < my_next ? f : my_next;
+    }
+    // the lanes whose first position a lies in (s, f]: the run covers the position before a
+    int l = cs < 0 ? 0 : (cs >> w.logS) + 1;       // (no division: 30 instructions each on this machine)
+    int lh = cf >> w.logS;
+    if (lh > nt - 1) lh = nt - 1;
+    for (; l <= lh; l++) {
+        w.col[trk * nt + l] = key;
+        wt_lds_addi32(&w.ncov[l], 1);
+    }
+}
+
+// one run, scatter pass of the fallback (cnt[] counts down: the slots of a position are handed out from the last to the first)
 WT_DEV void wt_walk_scatter1(const WtParams &P, WtWalkCtx &w, int32_t w0, int32_t width, uint32_t ev0, uint32_t ev1, int trk, int32_t s,
                              int32_t f, int32_t ps, int32_t ns, bool first, bool last, uint32_t vb) {
     const int32_t cs = s - w0, cf = f - w0;
@@ -181,14 +228,15 @@ WT_DEV void wt_walk_scatter1(const WtParams &P, WtWalkCtx &w, int32_t w0, int32_
     }
 }
 
-// Both passes: SCATTER == false counts; SCATTER == true places the events whose position's first slot lies in [ev0, ev1).
+// The passes over the window's runs.  SCATTER == false: the first pass -- events counted per position and placed in the
+// position's fixed slots (all a window of ordinary data needs).  SCATTER == true: the fallback's second pass, the events
+// whose position's first slot lies in [ev0, ev1) to their place in the sorted sequence.
 template <bool SCATTER>
 WT_DEV void wt_walk_pass(const WtParams &P, WtCtx &c, WtWalkCtx &w, WtDeltaCtx &d, uint32_t ev0, uint32_t ev1, int tid, int nt) {
     const int wave = wt_uniform32(tid >> 6), lane = tid & 63, nwaves = nt >> 6;
     const uint32_t M = (uint32_t) wt_uniform32((int32_t) d.tpfx[nt]);
     const int32_t w0 = wt_uniform32(c.sh->w0);
     const int32_t width = wt_uniform32(c.sh->w1) - w0;
-    const int chrom = wt_uniform32(c.sh->chrom);
     const uint32_t step = (uint32_t) nwaves * WT_DELTA_TILE;
     int32_t my_next = 0x7fffffff;
     auto apply = [&](const WtWalkBatch &B, uint32_t tb) {
@@ -196,20 +244,27 @@ WT_DEV void wt_walk_pass(const WtParams &P, WtCtx &c, WtWalkCtx &w, WtDeltaCtx &
         for (int u = 0; u < WT_DELTA_U; u++)
             if (tb + (uint32_t) lane + 64u * (uint32_t) u < M) {
                 if (SCATTER) wt_walk_scatter1(P, w, w0, width, ev0, ev1, B.trk[u], B.s[u], B.f[u], B.ps[u], B.ns[u], B.first[u], B.last[u], B.b[u]);
-                else wt_walk_count1(P, w, nt, w0, width, B.trk[u], B.s[u], B.f[u], B.ns[u], B.last[u], B.b[u], my_next);
+                else wt_walk_count1(P, w, nt, w0, width, B.trk[u], B.s[u], B.f[u], B.ps[u], B.ns[u], B.first[u], B.last[u], B.b[u], my_next);
             }
     };
     uint32_t tb = (uint32_t) wave * WT_DELTA_TILE;
     if (tb < M) {
-        WtWalkBatch A, B;
-        wt_walk_fetch(P, d, nt, M, tb, lane, chrom, A);
+        // three register sets take turns: two tiles' loads are in flight while one is applied (a workgroup is two to four
+        // waves, one per SIMD: nothing else hides the latency of the loads)
+        WtWalkBatch Q0, Q1, Q2;
+        wt_walk_fetch(P, d, w, nt, M, tb, lane, Q0);
+        wt_walk_fetch(P, d, w, nt, M, tb + step, lane, Q1);         // (past the end: harmless re-reads of the last tile)
         for (;;) {
-            wt_walk_fetch(P, d, nt, M, tb + step, lane, chrom, B);
-            apply(A, tb);
+            wt_walk_fetch(P, d, w, nt, M, tb + 2u * step, lane, Q2);
+            apply(Q0, tb);
             tb += step;
             if (tb >= M) break;
-            wt_walk_fetch(P, d, nt, M, tb + step, lane, chrom, A);
-            apply(B, tb);
+            wt_walk_fetch(P, d, w, nt, M, tb + 2u * step, lane, Q0);
+            apply(Q1, tb);
+            tb += step;
+            if (tb >= M) break;
+            wt_walk_fetch(P, d, w, nt, M, tb + 2u * step, lane, Q1);
+            apply(Q2, tb);
             tb += step;
             if (tb >= M) break;
         }
@@ -278,90 +333,151 @@ WT_DEV int wt_walk_round_end(const WtWalkCtx &w, int l0, int nt) {
 }
 
 // ---- selection ----
-// lt = #{keys < m}, le = #{keys <= m}, nn = #{NaN}
+#ifdef WT_EMU
+WT_DEV bool wt_walk_any(bool x) { return x; }
+#else
+WT_DEV bool wt_walk_any(bool x) { return __ballot(x) != 0ull; }     // over the lanes that are active here
+#endif
+#define WT_WALK_RB WT_WALK_PAD       // keys of the column read ahead per block
+
+// f(key) for every row of the lane's column (w.npad of them, a multiple of WT_WALK_RB: the rows past the tracks hold
+// 0xffffffff); the LDS reads of the next block are issued before this one is consumed
+template <class F>
+WT_DEV void wt_walk_for_keys(const WtWalkCtx &w, int nt, int tid, F &&f) {
+    const uint32_t *p = w.col + tid;
+    const int R = w.npad;
+    uint32_t cur[WT_WALK_RB], nxt[WT_WALK_RB];
+#pragma unroll
+    for (int u = 0; u < WT_WALK_RB; u++) cur[u] = p[u * nt];
+    for (int i = 0; i < R; i += WT_WALK_RB) {
+        if (i + WT_WALK_RB < R) {
+#pragma unroll
+            for (int u = 0; u < WT_WALK_RB; u++) nxt[u] = p[(i + WT_WALK_RB + u) * nt];
+        }
+#pragma unroll
+        for (int u = 0; u < WT_WALK_RB; u++) f(cur[u]);
+#pragma unroll
+        for (int u = 0; u < WT_WALK_RB; u++) cur[u] = nxt[u];
+    }
+}
+
+// lt = #{keys < m}, le = #{keys <= m}
 WT_DEV void wt_walk_recount(const WtWalkCtx &w, int N, int nt, int tid, uint32_t m, int &lt, int &le) {
     int a = 0, b = 0;
-    for (int i = 0; i < N; i++) {
-        const uint32_t x = w.col[i * nt + tid];
-        a += x < m ? 1 : 0;
-        b += x <= m ? 1 : 0;
-    }
+    wt_walk_for_keys(w, nt, tid, [&](uint32_t x) { a += x < m ? 1 : 0; b += x <= m ? 1 : 0; });     // (the pad rows are above every m)
     lt = a; le = b;
 }
 
-// Moves m to the key of rank k (0-based, ties as a multiset) given lt / le for the current m.
+// compare-exchange
+#define WT_WALK_CE(x, y) do { const uint32_t lo_ = (x) < (y) ? (x) : (y); (y) = (x) < (y) ? (y) : (x); (x) = lo_; } while (0)
+// b[0 .. WD) ascending (WD = 2, 4, 8: optimal networks of 1, 5, 19 exchanges)
+template <int WD>
+WT_DEV void wt_walk_sort_block(uint32_t (&b)[WD]) {
+    if constexpr (WD == 2) {
+        WT_WALK_CE(b[0], b[1]);
+    } else if constexpr (WD == 4) {
+        WT_WALK_CE(b[0], b[1]); WT_WALK_CE(b[2], b[3]); WT_WALK_CE(b[0], b[2]); WT_WALK_CE(b[1], b[3]); WT_WALK_CE(b[1], b[2]);
+    } else {
+        WT_WALK_CE(b[0], b[1]); WT_WALK_CE(b[2], b[3]); WT_WALK_CE(b[4], b[5]); WT_WALK_CE(b[6], b[7]);
+        WT_WALK_CE(b[0], b[2]); WT_WALK_CE(b[1], b[3]); WT_WALK_CE(b[4], b[6]); WT_WALK_CE(b[5], b[7]);
+        WT_WALK_CE(b[1], b[2]); WT_WALK_CE(b[5], b[6]); WT_WALK_CE(b[0], b[4]); WT_WALK_CE(b[3], b[7]);
+        WT_WALK_CE(b[1], b[5]); WT_WALK_CE(b[2], b[6]);
+        WT_WALK_CE(b[1], b[4]); WT_WALK_CE(b[3], b[6]);
+        WT_WALK_CE(b[2], b[4]); WT_WALK_CE(b[3], b[5]);
+        WT_WALK_CE(b[3], b[4]);
+    }
+}
+
+// One sweep: the WD smallest of the (flipped) keys above mf, ascending, ties kept (0xffffffff: none -- no key is 0 or ~0:
+// wt_walk_key), then the move.  True: m, lt, le are final.
+// The column is taken WD keys at a time: the block is sorted by a network and merged with the running WD smallest
+// (element-wise minimum against the reversed block leaves the WD smallest of both as a bitonic sequence, log2 WD
+// exchange stages sort it) -- 12 instructions per key at WD = 8 where inserting key by key takes 20.
+template <int WD>
+WT_DEV bool wt_walk_move(const WtWalkCtx &w, int N, int nt, int tid, int k, uint32_t &m, int &lt, int &le) {
+    const bool up = k >= le;
+    const uint32_t flip = up ? 0u : 0xffffffffu;    // moving down is moving up among the complemented keys
+    const uint32_t mf = m ^ flip;
+    const int j = up ? k - le : lt - 1 - k;         // wanted: the j-th smallest of the (flipped) keys above mf
+    uint32_t a[WD];
+#pragma unroll
+    for (int q = 0; q < WD; q++) a[q] = 0xffffffffu;
+    const uint32_t *p = w.col + tid;
+    const int R = w.npad;                           // (a multiple of 8, hence of WD; the pad rows never pass the test below)
+    uint32_t cur[WD], nxt[WD];
+#pragma unroll
+    for (int u = 0; u < WD; u++) cur[u] = p[u * nt];
+    for (int i = 0; i < R; i += WD) {
+        if (i + WD < R) {
+#pragma unroll
+            for (int u = 0; u < WD; u++) nxt[u] = p[(i + WD + u) * nt];
+        }
+        uint32_t b[WD];
+#pragma unroll
+        for (int u = 0; u < WD; u++) {
+            const uint32_t x = cur[u] ^ flip;
+            b[u] = x > mf ? x : 0xffffffffu;
+        }
+        wt_walk_sort_block<WD>(b);
+#pragma unroll
+        for (int u = 0; u < WD; u++) a[u] = a[u] < b[WD - 1 - u] ? a[u] : b[WD - 1 - u];
+#pragma unroll
+        for (int d = WD / 2; d >= 1; d >>= 1) {
+#pragma unroll
+            for (int u = 0; u < WD; u++)
+                if ((u & d) == 0) WT_WALK_CE(a[u], a[u + d]);
+        }
+#pragma unroll
+        for (int u = 0; u < WD; u++) cur[u] = nxt[u];
+    }
+    if (j >= WD) {                      // further away than the sweep reaches: go on from its far end
+        m = a[WD - 1] ^ flip;
+        wt_walk_recount(w, N, nt, tid, m, lt, le);
+        return false;
+    }
+    uint32_t aj = a[0];
+#pragma unroll
+    for (int q = 1; q < WD; q++) aj = q == j ? a[q] : aj;
+    int first = WD - 1, last = 0;
+#pragma unroll
+    for (int q = WD - 1; q >= 0; q--) first = a[q] == aj ? q : first;
+#pragma unroll
+    for (int q = 0; q < WD; q++) last = a[q] == aj ? q : last;
+    m = aj ^ flip;
+    if (last == WD - 1) {               // more keys equal to it may lie beyond the ones collected
+        wt_walk_recount(w, N, nt, tid, m, lt, le);
+        return false;
+    }
+    if (up) { lt = le + first; le = le + last + 1; }
+    else { const int l0 = lt; le = l0 - first; lt = l0 - last - 1; }
+    return true;
+}
+
+// Moves m to the key of rank k (0-based, ties as a multiset) given lt / le for the current m.  The sweep's width follows
+// the furthest move any lane of the wave has to make (2, 4 or 8 keys).
+#if defined(WT_WALK_COUNT) && !defined(WT_EMU)
+__device__ unsigned long long wt_walk_dbg[8];
+#define WT_WALK_CNT(slot) do { if (tid < 64) { const unsigned long long act_ = __ballot(true); if ((tid & 63) == __ffsll(act_) - 1) atomicAdd(&wt_walk_dbg[slot], 1ull); } } while (0)
+#else
+#define WT_WALK_CNT(slot) do { } while (0)
+#endif
 WT_DEV void wt_walk_select(const WtWalkCtx &w, int N, int nt, int tid, int k, uint32_t &m, int &lt, int &le) {
+    WT_WALK_CNT(0);
     for (;;) {
         if (lt <= k && k < le) return;
-        const bool up = k >= le;
-        // moving down is moving up among the complemented keys
-        const uint32_t flip = up ? 0u : 0xffffffffu;
-        const uint32_t mf = m ^ flip;
-        const int j = up ? k - le : lt - 1 - k;         // wanted: the j-th smallest of the (flipped) keys above mf
-        uint32_t a0 = 0xffffffffu, a1 = 0xffffffffu, a2 = 0xffffffffu, a3 = 0xffffffffu;       // (no key is 0 or ~0: wt_walk_key)
-        for (int i = 0; i < N; i++) {
-            const uint32_t x = w.col[i * nt + tid] ^ flip;
-            uint32_t t = x > mf ? x : 0xffffffffu;
-            uint32_t lo;
-            lo = a0 < t ? a0 : t; t = a0 < t ? t : a0; a0 = lo;
-            lo = a1 < t ? a1 : t; t = a1 < t ? t : a1; a1 = lo;
-            lo = a2 < t ? a2 : t; t = a2 < t ? t : a2; a2 = lo;
-            a3 = a3 < t ? a3 : t;
-        }
-        if (j > 3) {                        // further away than the sweep reaches: start again from its far end
-            m = a3 ^ flip;
-            wt_walk_recount(w, N, nt, tid, m, lt, le);
-            continue;
-        }
-        const uint32_t aj = j == 0 ? a0 : (j == 1 ? a1 : (j == 2 ? a2 : a3));
-        const int first = a0 == aj ? 0 : (a1 == aj ? 1 : (a2 == aj ? 2 : 3));
-        const int last = a3 == aj ? 3 : (a2 == aj ? 2 : (a1 == aj ? 1 : 0));
-        m = aj ^ flip;
-        if (last == 3) {                    // more keys equal to it may lie beyond the four
-            wt_walk_recount(w, N, nt, tid, m, lt, le);
-            continue;
-        }
-        if (up) { lt = le + first; le = le + last + 1; }
-        else { const int l0 = lt; le = l0 - first; lt = l0 - last - 1; }
-        return;
-    }
-}
-
-// The median of the lane's column from nothing: the bitmap kernel's register network (wt_eval_chunk), fed from LDS.
-template <int NR>
-WT_DEV uint32_t wt_walk_first_median(const WtWalkCtx &w, int N, int nt, int tid) {
-    constexpr int H = NR / 2;
-    uint32_t lo[H], hi[H];
-    const int pad_lo = H - N / 2;
-    wt_static_for<0, NR>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        const int i = s - pad_lo;
-        uint32_t v = s < pad_lo ? 0u : 0xffffffffu;
-        if (i >= 0 && i < N) v = w.col[i * nt + tid];
-        if constexpr (s < H) lo[s] = v; else hi[s - H] = v;
-    });
-    wt_sort_regs<H, false>(lo);
-    wt_sort_regs<H, true>(hi);
-    uint32_t m = 0xffffffffu;
-#pragma unroll
-    for (int i = 0; i < H; i++) {
-        const uint32_t x = lo[i] > hi[i] ? lo[i] : hi[i];
-        m = x < m ? x : m;
-    }
-    return m;
-}
-
-// An event of the slab, written by another wave of this workgroup before the last barrier: read at agent scope, so
-// that a line of the slab this CU's vector cache still holds from an earlier window is not what comes back.
-WT_DEV WtWalkEvent wt_walk_event(const WtWalkEvent *p) {
-#ifdef WT_EMU
-    return *p;
+        WT_WALK_CNT(1);
+        const int j = k >= le ? k - le : lt - 1 - k;
+        if (j > 7) WT_WALK_CNT(2);
+        bool done;
+#if defined(WT_WALK_WD)
+        done = wt_walk_move<WT_WALK_WD>(w, N, nt, tid, k, m, lt, le);
 #else
-    const unsigned long long x = __hip_atomic_load((const unsigned long long *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    WtWalkEvent e;
-    e.key = (uint32_t) x; e.meta = (uint32_t) (x >> 32);
-    return e;
+        if (wt_walk_any(j > 3)) done = wt_walk_move<8>(w, N, nt, tid, k, m, lt, le);
+        else if (wt_walk_any(j > 1)) done = wt_walk_move<4>(w, N, nt, tid, k, m, lt, le);
+        else done = wt_walk_move<2>(w, N, nt, tid, k, m, lt, le);
 #endif
+        if (done) return;
+    }
 }
 
 // per-lane state across the rounds of a window
@@ -370,50 +486,131 @@ struct WtWalkLane {
 };
 
 // The lane's stretch.  ev0: index (in the window's event sequence) of the first event the slab holds.
-template <int NR>
-WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalkLane &L, uint32_t ev0, int tid, int nt) {
+#if defined(WT_PROFILE) && !defined(WT_EMU)
+#define WT_WALK_T0 unsigned long long wt_wt = __builtin_readcyclecounter()
+#define WT_WALK_TICK(slot) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (prof) prof[slot] += t_ - wt_wt; wt_wt = t_; } while (0)
+#else
+#define WT_WALK_T0 do { } while (0)
+#define WT_WALK_TICK(slot) do { } while (0)
+#endif
+#define WT_WALK_EB 8        // events fetched per batch
+// The lane's stretch.  (The slab was written by the other waves of this workgroup before the last barrier: same CU, same
+// vector cache -- plain loads.)
+//   FIXED   the events of position p are cnt[p] of the slots slab[p * capp ..] (+ the overflow list beyond capp)
+//   !FIXED  (fallback) the sorted sequence: the events of p are slab[off[p] - ev0 .. off[p + 1] - ev0)
+template <bool FIXED>
+WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalkLane &L, uint32_t ev0, int tid, int nt,
+                         unsigned long long *prof = nullptr) {
     const int N = P.n_tracks, S = w.S, a = tid * S, k = N / 2;
     const bool strict = (P.flags & WT_STRICT_SET0) != 0;
     const int32_t room = c.sh->emit_hi - (c.sh->w0 + a);       // positions of the stretch below the range end
     uint32_t evmask = 0, emitmask = 0;
-    uint32_t o = w.off[a];
-    if (w.off[a + S] != o) {
-        uint32_t m = 0;
-        int lt = 0, le = 0, nn = 0;
-        bool have = false;          // the median of the column is known (lazily: only where a run is emitted)
-        for (int i = 0; i < N; i++) nn += w.col[i * nt + tid] == WT_WALK_NANKEY ? 1 : 0;
-        int ncov = w.ncov[tid];
-        for (int s = 0; s < S; s++) {
-            const uint32_t o1 = w.off[a + s + 1];
-            if (o1 == o) continue;
-            evmask |= 1u << s;
-            for (uint32_t e = o; e < o1; e++) {
-                const WtWalkEvent ev = wt_walk_event(&w.slab[e - ev0]);
-                const int trk = (int) (ev.meta & 0xffffu);
-                const uint32_t nk = ev.key;
-                const uint32_t ok = w.col[trk * nt + tid];
-                w.col[trk * nt + tid] = nk;
-                if (have) {
-                    lt += (nk < m ? 1 : 0) - (ok < m ? 1 : 0);
-                    le += (nk <= m ? 1 : 0) - (ok <= m ? 1 : 0);
-                }
-                nn += (nk == WT_WALK_NANKEY ? 1 : 0) - (ok == WT_WALK_NANKEY ? 1 : 0);
-                ncov += (int) ((ev.meta >> 16) & 1u) - (int) ((ev.meta >> 17) & 1u);
-            }
-            o = o1;
-            const bool emit = (strict ? ncov == N : ncov > 0) && s < room;     // multiplexer.c:120,125
-            if (!emit) continue;
-            emitmask |= 1u << s;
-            if (!have) {
-                m = wt_walk_first_median<NR>(w, N, nt, tid);
-                wt_walk_recount(w, N, nt, tid, m, lt, le);
-                have = true;
-            } else {
-                wt_walk_select(w, N, nt, tid, k, m, lt, le);
-            }
-            w.cnt[a + s] = nn ? WT_WALK_NANKEY : m;         // (cnt[] is all zeros after the scatter pass: the results live there)
+    uint32_t m = 0;
+    int lt = 0, le = 0, nn = 0, ncov = 0;
+    bool have = false;              // the median of the column is known (lazily: only where a run is emitted)
+    bool started = false;           // nn / ncov are initialised (at the stretch's first event)
+    uint32_t *col = w.col + tid;
+    const uint32_t novf = FIXED ? (w.novf[0] < w.ov_cap ? w.novf[0] : w.ov_cap) : 0u;
+
+    auto apply = [&](const WtWalkEvent (&ev)[WT_WALK_EB], uint32_t nvalid) {
+        // their tracks' old keys first (no track has two events at one position), then the updates
+        uint32_t ok[WT_WALK_EB];
+        uint32_t trk[WT_WALK_EB];
+#pragma unroll
+        for (int u = 0; u < WT_WALK_EB; u++) {
+            const uint32_t t = ev[u].meta & 0xffffu;
+            trk[u] = t < (uint32_t) N ? t : 0u;         // (a slot beyond the position's count holds anything)
+            ok[u] = col[trk[u] * (uint32_t) nt];
         }
+#pragma unroll
+        for (int u = 0; u < WT_WALK_EB; u++) {
+            if ((uint32_t) u >= nvalid) continue;
+            const uint32_t nk = ev[u].key;
+            col[trk[u] * (uint32_t) nt] = nk;
+            if (have) {
+                lt += (nk < m ? 1 : 0) - (ok[u] < m ? 1 : 0);
+                le += (nk <= m ? 1 : 0) - (ok[u] <= m ? 1 : 0);
+            }
+            nn += (nk == WT_WALK_NANKEY ? 1 : 0) - (ok[u] == WT_WALK_NANKEY ? 1 : 0);
+            ncov += (int) ((ev[u].meta >> 16) & 1u) - (int) ((ev[u].meta >> 17) & 1u);
+        }
+    };
+    // WT_WALK_EB events from slab index `from` on.  Sorted: the first `n` exist (the others: the last one again).  FIXED: the
+    // position's slots as they are (the slab ends in the overflow list, at least WT_WALK_EB events long: no read past it).
+    auto fetch = [&](uint32_t from, uint32_t n, WtWalkEvent (&ev)[WT_WALK_EB]) {
+#pragma unroll
+        for (int u = 0; u < WT_WALK_EB; u++) ev[u] = w.slab[from + (FIXED || (uint32_t) u < n ? (uint32_t) u : n - 1u)];
+    };
+
+    // The next position's first events are fetched right after this position's have been applied, i.e. before its
+    // sweep -- which hides the loads.  FIXED: the slots of position a + s + 1 (used if that position has events);
+    // sorted: the next events of the sequence, whatever position they belong to.
+    WtWalkEvent pre[WT_WALK_EB];
+    uint32_t pre_at = 0xffffffffu;              // slab index pre[] was fetched from
+    uint32_t o = FIXED ? 0u : w.off[a];
+    const uint32_t o_end = FIXED ? 0u : w.off[a + S];
+    if (FIXED) { fetch((uint32_t) a * (uint32_t) w.capp, 1u, pre); pre_at = (uint32_t) a * (uint32_t) w.capp; }
+    else if (o_end != o) { fetch(o - ev0, o_end - o, pre); pre_at = o - ev0; }
+    int fe = -1;
+    for (int s = 0; s < S; s++) {
+        uint32_t n, from;
+        if (FIXED) { n = w.cnt[a + s]; from = (uint32_t) (a + s) * (uint32_t) w.capp; }
+        else { const uint32_t o1 = w.off[a + s + 1]; n = o1 - o; from = o - ev0; o = o1; }
+        if (!n) continue;
+        WT_WALK_T0;
+        if (!started) {
+            started = true;
+            wt_walk_for_keys(w, nt, tid, [&](uint32_t x) { nn += x == WT_WALK_NANKEY ? 1 : 0; });
+            ncov = w.ncov[tid];
+        }
+        if (fe < 0) fe = a + s;
+        evmask |= 1u << s;
+        const uint32_t nslot = FIXED ? (n < (uint32_t) w.capp ? n : (uint32_t) w.capp) : n;
+        for (uint32_t e = 0; e < nslot; e += WT_WALK_EB) {
+            WtWalkEvent ev[WT_WALK_EB];
+            const uint32_t left = nslot - e;
+            if (e == 0 && pre_at == from) {
+#pragma unroll
+                for (int u = 0; u < WT_WALK_EB; u++) ev[u] = pre[u];
+            } else {
+                fetch(from + e, left, ev);
+            }
+            apply(ev, left);
+        }
+        if (FIXED && n > nslot) {               // the position's events beyond its slots: somewhere in the overflow list
+            for (uint32_t j = 0; j < novf; j++) {
+                const WtWalkOvf q = w.ovf[j];
+                if (q.pos != (uint32_t) (a + s)) continue;
+                WtWalkEvent ev[WT_WALK_EB];
+#pragma unroll
+                for (int u = 0; u < WT_WALK_EB; u++) { ev[u].key = q.key; ev[u].meta = q.meta; }
+                apply(ev, 1u);
+            }
+        }
+        if (FIXED) {
+            if (s + 1 < S) { pre_at = from + (uint32_t) w.capp; fetch(pre_at, 1u, pre); }
+        } else if (o < o_end) {
+            pre_at = o - ev0;
+            fetch(pre_at, o_end - o, pre);
+        }
+        WT_WALK_TICK(4);
+        const bool emit = (strict ? ncov == N : ncov > 0) && s < room;     // multiplexer.c:120,125
+        if (!emit) continue;
+        emitmask |= 1u << s;
+        if (!have) {
+            m = w.guess[0];
+            wt_walk_recount(w, N, nt, tid, m, lt, le);
+            have = true;
+            wt_walk_select(w, N, nt, tid, k, m, lt, le);
+            WT_WALK_TICK(5);
+        } else {
+            wt_walk_select(w, N, nt, tid, k, m, lt, le);
+            WT_WALK_TICK(6);
+        }
+        w.cnt[a + s] = nn ? WT_WALK_NANKEY : m;         // (the position's count is not needed any more: the result lives there)
     }
+    if (have) w.guess[0] = m;       // (any lane's: the next stretch's first selection starts there)
+    w.fe[tid] = fe;
     L.evmask = evmask; L.emitmask = emitmask;
 }
 

@@ -1,0 +1,160 @@
+// wt_walk.hip -- gfx950 kernel of MedianReduction by walking (logic in wt_walk.h) and its launcher, a translation unit of
+// its own next to wt_engine.hip.  Compiled only by hipcc --offload-arch=gfx950.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#include "../../include/wiggletools_amd.h"
+#include "wt_core.h"
+
+#define WT_MARK(x) do { } while (0)
+#ifdef WT_PROFILE
+#define WT_TICK(slot) do { if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+        prof[slot] += t_ - t_last; t_last = t_; } } while (0)
+#else
+#define WT_TICK(slot) do { } while (0)
+#endif
+
+// MedianReduction by walking (wt_walk.h): a lane carries its column of current values from one position to the next.
+// T lanes (128: two workgroups per CU at 100 tracks) x S positions each; persistent workgroups, window tickets, ordered
+// output through the look-back chain like the other kernels.
+__global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
+    extern __shared__ __attribute__((aligned(16))) char wt_lds[];
+    WtCtx c{};
+    c.sh = (WtShared *) (wt_lds + P.off_shared);
+    WtDeltaCtx d;
+    wt_delta_ctx_init(d, P, wt_lds);
+    WtWalkCtx w;
+    wt_walk_ctx_init(w, P, wt_lds, P.g_scratch + (size_t) blockIdx.x * (size_t) P.g_scratch_slab);
+    const int tid = threadIdx.x, nt = blockDim.x;
+    long long k_dbg = -1;
+    (void) k_dbg;
+#ifdef WT_PROFILE
+    // cycles of wave 0: 0 zero + ranges, 1 count pass, 2 offsets, 3 scatter pass, 4 events, 5 first median, 6 moves of
+    // the median (4-6: lane 0's view inside the walk), 7 everything else (run-count scan, look-back, write, ticket)
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
+    if (tid == 0) {
+        const long long k0 = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+        c.sh->ticket = k0;
+        if (k0 < P.n_windows) wt_phase_header(P, c, k0);
+    }
+    wt_walk_defaults(P, w, tid, nt);
+    __syncthreads();
+    for (;;) {
+        const long long k = c.sh->ticket;
+        k_dbg = k;
+        if (k >= P.n_windows) break;
+        WT_MARK(201);
+        wt_walk_zero(P, c, w, tid, nt);
+        wt_delta_ranges_w1(P, c, d, 0, tid, nt);
+        __syncthreads();
+        wt_delta_ranges_w2(P, c, d, tid, nt);
+        __syncthreads();
+        WT_TICK(0);
+        WT_MARK(202);
+        wt_walk_pass<false>(P, c, w, d, 0u, 0u, tid, nt);
+        __syncthreads();                        // the events are in the slab, the counts in cnt[]
+        WT_TICK(1);
+        WtWalkLane L;
+        L.evmask = 0; L.emitmask = 0;
+        if (w.novf[0] <= w.ov_cap) {            // (uniform) every position's events fit its slots + the overflow list
+#ifdef WT_PROFILE
+            wt_walk_lane<true>(P, c, w, L, 0u, tid, nt, tid == 0 ? prof : nullptr);
+            if (tid == 0) t_last = __builtin_readcyclecounter();
+#else
+            wt_walk_lane<true>(P, c, w, L, 0u, tid, nt);
+#endif
+            __syncthreads();
+            WT_TICK(7);
+        } else {
+            // a window denser than that: its events sorted by position into the same memory (a second pass over the
+            // runs), as many lanes' worth at a time as fit
+            wt_walk_offsets1(P, w, tid, nt);
+            __syncthreads();
+            wt_walk_scan_b(w, tid, nt);
+            __syncthreads();
+            wt_walk_offsets2(P, w, tid, nt);
+            __syncthreads();
+            WT_TICK(2);
+            WT_MARK(203);
+            for (int l0 = 0; l0 < nt;) {
+                const int l1 = wt_walk_round_end(w, l0, nt);
+                const uint32_t ev0 = w.base[l0], ev1 = w.base[l1];
+                if (ev1 > ev0) {                    // (uniform)
+                    wt_walk_pass<true>(P, c, w, d, ev0, ev1, tid, nt);
+                    __syncthreads();
+                    WT_TICK(3);
+                    if (tid >= l0 && tid < l1) wt_walk_lane<false>(P, c, w, L, ev0, tid, nt);
+                    __syncthreads();                // before the next round reuses the slab
+                    WT_TICK(7);
+                }
+                l0 = l1;
+            }
+        }
+        WT_MARK(204);
+        wt_walk_scan_a(w, (uint32_t) wt_popc32(L.emitmask), tid, nt);
+        __syncthreads();
+        wt_walk_scan_b(w, tid, nt);
+        __syncthreads();
+        const unsigned long long mine = w.base[nt];
+        if (tid == 0) wt_lookback_publish(P, c, k, mine);
+        if (tid < 64) wt_lookback_complete(P, c, k, tid, mine);
+        __syncthreads();
+        WT_MARK(205);
+        wt_walk_write(P, c, w, L, tid, nt);
+        __syncthreads();
+        if (tid == 0) {
+            wt_window_stats(P, c);
+            const long long kn = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+            c.sh->ticket = kn;
+            if (kn < P.n_windows) wt_phase_header(P, c, kn);
+        }
+        __syncthreads();
+        WT_TICK(7);
+    }
+#ifdef WT_PROFILE
+    if (tid == 0)
+        for (int q = 0; q < 8; q++) wt_glb_add64(&P.counters[WT_CTR_PROF + q], prof[q]);
+#endif
+}
+
+#ifdef WT_WALK_COUNT
+extern "C" void wtamd_walk_dbg_print(void) {
+    unsigned long long h[8] = {0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(wt_walk_dbg), sizeof h) == hipSuccess)
+        fprintf(stderr, "[wt_walk_count] select calls %llu  move iterations %llu  with a lane beyond 8 ranks %llu\n", h[0], h[1], h[2]);
+    unsigned long long z[8] = {0};
+    (void) hipMemcpyToSymbol(HIP_SYMBOL(wt_walk_dbg), z, sizeof z);
+}
+#endif
+
+// (nr: the register-column slots the bitmap kernel would use for this track count -- eligibility only)
+hipError_t wt_walk_launch(WtParams &P, int nr, int T, int lds, int num_cu, char **gscratch, size_t *gscratch_bytes, hipStream_t s, int *grid) {
+    (void) nr;
+    auto kern = wt_walk_kernel;
+    hipError_t e = hipSuccess;
+    if (lds > 48 * 1024) {
+        e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, T, (size_t) lds);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    long long g = (long long) num_cu * per_cu;
+    if (g > P.n_windows) g = P.n_windows;
+    if (g < 1) g = 1;
+    const size_t need = (size_t) g * (size_t) P.g_scratch_slab;        // one slab of events per resident workgroup
+    if (*gscratch_bytes < need) {
+        (void) hipFree(*gscratch);          // synchronises with earlier launches
+        *gscratch = nullptr; *gscratch_bytes = 0;
+        e = hipMalloc((void **) gscratch, need);
+        if (e != hipSuccess) return e;
+        *gscratch_bytes = need;
+    }
+    P.g_scratch = *gscratch;
+    *grid = (int) g;
+    hipLaunchKernelGGL(kern, dim3((unsigned) g), dim3((unsigned) T), (size_t) lds, s, P);
+    return hipGetLastError();
+}
