@@ -236,7 +236,8 @@ typedef struct {
     float index_ms;          /* last window-index kernel time (HIP events)     */
     float reduce_ms;         /* last multiplex+reduce kernel time (HIP events) */
     int32_t kernel;          /* kernel of the last reduction: 0 general bitmap multiplexer (wt_reduce_kernel),
-                                1 exact difference array for Sum / Mean (wt_delta_kernel)             */
+                                1 exact difference array for Sum / Mean (wt_delta_kernel),
+                                2 median by walking (wt_walk_kernel)                                  */
     int32_t patched_windows; /* difference-array windows whose values the general kernel rewrote (NaN, Inf, wide range) */
 } wtamd_stats;
 

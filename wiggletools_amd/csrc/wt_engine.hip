@@ -1574,7 +1574,7 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
     ts->stats.n_windows = w->tab.n_windows;
     ts->stats.window_bp = plan.W;
     ts->stats.lds_bytes = plan.lds_bytes;
-    ts->stats.kernel = plan.delta ? 1 : 0;
+    ts->stats.kernel = plan.delta ? 1 : (plan.walk_S ? 2 : 0);     // (2: median by walking, csrc/wt_walk.h)
     ts->stats.patched_windows = 0;
     if (n_runs) {
         WT_HIP(hipMemcpyAsync(ts->h_counters, ts->d_counters, sizeof(unsigned long long) * WT_CTR_N, hipMemcpyDeviceToHost, s));
