@@ -687,3 +687,36 @@ def test_gpu_c2_shape_long_runs(oracle, engine):
             assert st["kernel"] == 1 and st["window_bp"] == 8192, st
             assert_runs_equal(got, oracle.reduce(d, op, flags=strict), 0.0, "run 200 op %s strict %d" % (op, strict))
     ts.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_gpu_median_walk_paths(oracle, engine, seed, monkeypatch):
+    """MedianReduction by walking (csrc/wt_walk.h) on the device: the default plan, small workgroups / stretches, slots too
+    few for the data (overflow list) and no overflow list at all (every window falls back to the sorted events, in rounds)
+    -- against the oracle (reducers.c:780-813) and against the bitmap kernel (WTAMD_NO_WALK), tolerance 0; gaps, ties,
+    NaN, non-zero defaults, the strict predicate."""
+    from wiggletools_amd.runlists import synth
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.choice([1, 3, 8, 33, 64, 100, 128]))
+    defaults = rng.integers(-3, 4, n).astype(np.float64) / 4.0 if rng.random() < 0.4 else None
+    t = synth(n, [int(rng.integers(3000, 60000)), int(rng.integers(1, 900))], mean_run=float(rng.choice([1, 2, 5, 16, 70])), seed=seed,
+              gap_prob=float(rng.choice([0, 0.05, 0.5])), dtype=np.float32, value_levels=int(rng.choice([2, 5, 800])),
+              nan_prob=float(rng.choice([0, 0, 0.001])), defaults=defaults)
+    env = [dict(), dict(WTAMD_WALK_T="128"), dict(WTAMD_WALK_T="64", WTAMD_WALK_S="8"), dict(WTAMD_WALK_CAPP="2"),
+           dict(WTAMD_WALK_CAPP="1", WTAMD_WALK_OV="0"), dict(WTAMD_WALK_CAPP="2", WTAMD_WALK_OV="0", WTAMD_WALK_T="64", WTAMD_WALK_S="4")][seed % 6]
+    flags = int(rng.choice([0, 0, 1]))
+    d = t.as_dict()
+    exp = oracle.reduce(d, "median", flags=flags)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ts = engine.TrackSet.from_runlists(t)
+    got = ts.reduce_host("median", flags=flags)
+    assert ts.stats()["kernel"] == 2, "the walking kernel did not run"
+    assert_runs_equal(got, exp, 0.0, "walking %s" % (env,))
+    ts.close()
+    monkeypatch.setenv("WTAMD_NO_WALK", "1")
+    ts = engine.TrackSet.from_runlists(t)
+    old = ts.reduce_host("median", flags=flags)
+    assert ts.stats()["kernel"] == 0
+    assert_runs_equal(old, exp, 0.0, "bitmap kernel")
+    ts.close()

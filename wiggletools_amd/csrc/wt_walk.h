@@ -455,27 +455,14 @@ WT_DEV bool wt_walk_move(const WtWalkCtx &w, int N, int nt, int tid, int k, uint
 
 // Moves m to the key of rank k (0-based, ties as a multiset) given lt / le for the current m.  The sweep's width follows
 // the furthest move any lane of the wave has to make (2, 4 or 8 keys).
-#if defined(WT_WALK_COUNT) && !defined(WT_EMU)
-__device__ unsigned long long wt_walk_dbg[8];
-#define WT_WALK_CNT(slot) do { if (tid < 64) { const unsigned long long act_ = __ballot(true); if ((tid & 63) == __ffsll(act_) - 1) atomicAdd(&wt_walk_dbg[slot], 1ull); } } while (0)
-#else
-#define WT_WALK_CNT(slot) do { } while (0)
-#endif
 WT_DEV void wt_walk_select(const WtWalkCtx &w, int N, int nt, int tid, int k, uint32_t &m, int &lt, int &le) {
-    WT_WALK_CNT(0);
     for (;;) {
         if (lt <= k && k < le) return;
-        WT_WALK_CNT(1);
         const int j = k >= le ? k - le : lt - 1 - k;
-        if (j > 7) WT_WALK_CNT(2);
         bool done;
-#if defined(WT_WALK_WD)
-        done = wt_walk_move<WT_WALK_WD>(w, N, nt, tid, k, m, lt, le);
-#else
         if (wt_walk_any(j > 3)) done = wt_walk_move<8>(w, N, nt, tid, k, m, lt, le);
         else if (wt_walk_any(j > 1)) done = wt_walk_move<4>(w, N, nt, tid, k, m, lt, le);
         else done = wt_walk_move<2>(w, N, nt, tid, k, m, lt, le);
-#endif
         if (done) return;
     }
 }

@@ -119,16 +119,6 @@ __global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
 #endif
 }
 
-#ifdef WT_WALK_COUNT
-extern "C" void wtamd_walk_dbg_print(void) {
-    unsigned long long h[8] = {0};
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(wt_walk_dbg), sizeof h) == hipSuccess)
-        fprintf(stderr, "[wt_walk_count] select calls %llu  move iterations %llu  with a lane beyond 8 ranks %llu\n", h[0], h[1], h[2]);
-    unsigned long long z[8] = {0};
-    (void) hipMemcpyToSymbol(HIP_SYMBOL(wt_walk_dbg), z, sizeof z);
-}
-#endif
-
 // (nr: the register-column slots the bitmap kernel would use for this track count -- eligibility only)
 hipError_t wt_walk_launch(WtParams &P, int nr, int T, int lds, int num_cu, char **gscratch, size_t *gscratch_bytes, hipStream_t s, int *grid) {
     (void) nr;
