@@ -121,8 +121,7 @@ struct EmuRun {
             wt_phase_header(P, c, k);
             for (int t = 0; t < T; t++) wt_walk_zero(P, c, w, t, T);
             for (int t = 0; t < T; t++) wt_delta_ranges1(P, c, d, 0, t, T);
-            for (int t = 0; t < T; t++) wt_delta_ranges2(P, c, d, t, T);
-            for (int t = 0; t < T; t++) wt_delta_ranges3(P, c, d, t, T);
+            for (int t = 0; t < T; t++) wt_walk_ranges3(d, t, T);
             for (int t = 0; t < T; t++) wt_walk_pass<false>(P, c, w, d, 0u, 0u, t, T);
             for (int t = 0; t < T; t++) { L[t].evmask = 0; L[t].emitmask = 0; }
             if (getenv("WTEMU_DEBUG")) fprintf(stderr, "[walk] window %lld: novf %u ov_cap %u capp %d cap %u\n", k, w.novf[0], w.ov_cap, w.capp, w.cap);

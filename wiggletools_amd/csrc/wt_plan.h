@@ -34,6 +34,7 @@ struct WtPlan {
     int walk_S = 0;         // median by walking (wt_walk.h): positions per lane (0: not that plan)
     int walk_capp = 0;      // ... fixed event slots per position
     int walk_ov = 0;        // ... entries of the overflow list
+    int walk_off_at = 0;    // ... where the fallback's offsets start in the workgroup's slab (bytes)
     int off_wcol = 0, off_wcnt = 0, off_woff = 0, off_wtot = 0, off_wbase = 0, off_wgt = 0, off_wncov = 0, off_wfe = 0, off_wdk = 0, off_wseg = 0, off_wguess = 0;
 };
 
@@ -182,12 +183,16 @@ static inline void wt_delta_defaults_params(const double *defaults, int n_tracks
 // same memory, in as many rounds as it takes: at least the 2 N S events the stretch of one lane can hold fit.
 // events_per_bp: what the data is expected to hold (the host's estimate from the run count and the covered span; <= 0: unknown).
 static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double events_per_bp, int hard_limit = 160 * 1024) {
+    // 256 lanes x 32 positions (an 8192-bp window, one workgroup per CU) when the columns fit, else fewer positions, then
+    // fewer lanes.  Measured (MI355X, chromosome 21, 100 tracks): 256 x 32 11.8 ms, 64 x 32 11.9, 256 x 16 12.6, 128 x 32 12.8,
+    // 128 x 16 14.3: the per-window chains of dependent loads are what the wider window saves.
     const char *eT = getenv("WTAMD_WALK_T"), *eS = getenv("WTAMD_WALK_S");
-    int S = eS ? atoi(eS) : 16;
-    if (S != 4 && S != 8 && S != 16) S = 16;
-    const int want = eT ? atoi(eT) : 256;
-    for (int T : {want, 256, 128, 64}) {
+    const int wantT = eT ? atoi(eT) : 256, wantS = eS ? atoi(eS) : 32;
+    struct Cand { int T, S; };
+    for (const Cand cd : {Cand{wantT, wantS}, Cand{wantT, 16}, Cand{256, 16}, Cand{128, 16}, Cand{64, 16}}) {
+        const int T = cd.T, S = cd.S;
         if (T != 64 && T != 128 && T != 256) continue;
+        if (S != 4 && S != 8 && S != 16 && S != 32) continue;
         if (n_tracks > T) continue;
         WtPlan q;
         q.T = T; q.W = T * S; q.n_words = q.W / 64; q.ppt = S; q.walk_S = S; q.regcol = nr;
@@ -195,7 +200,7 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double eve
         int o = 0;
         q.off_wcol = o;   o = wt_align16(o + ((n_tracks + 7) & ~7) * T * 4);        // (WT_WALK_PAD rows)
         q.off_wcnt = o;   o = wt_align16(o + q.W * 4);
-        q.off_woff = o;   o = wt_align16(o + (q.W + 1) * 4);
+        q.off_woff = 0;                                                             // (the fallback's offsets live in the slab)
         q.off_wtot = o;   o = wt_align16(o + T * 4);
         q.off_wbase = o;  o = wt_align16(o + (T + 1) * 4);
         q.off_wgt = o;    o = wt_align16(o + (T / 64 + 1) * 4);
@@ -208,7 +213,7 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double eve
         q.off_ltc = o;    o = wt_align16(o + T * 4);
         q.off_gtc = o;    o = wt_align16(o + (T / WT_DELTA_GROUP + 1) * 4);
         q.off_tpfx = o;   o = wt_align16(o + (T + 1) * 4);
-        q.off_tfirst = o; o = wt_align16(o + WT_DELTA_TF * 2);
+        q.off_tfirst = o; o = wt_align16(o + WT_WALK_TF * 2);
         q.off_shared = o; o = wt_align16(o + (int) sizeof(WtShared));
         q.lds_bytes = o;
         if (q.lds_bytes > hard_limit - 1024) continue;
@@ -226,7 +231,9 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double eve
         long long bytes = (long long) q.W * capp * 8 + (ov > 8 ? ov : 8) * 12;      // (the fixed fetch may read 8 events past the slots)
         const long long lane_max = 2ll * n_tracks * S * 8;
         if (bytes < lane_max) bytes = lane_max;
-        q.scratch_slab = (bytes + 255) & ~255ll;
+        bytes = (bytes + 255) & ~255ll;
+        q.walk_off_at = (int) bytes;
+        q.scratch_slab = (bytes + (long long) (q.W + 1) * 4 + 255) & ~255ll;
         p = q;
         return true;
     }
@@ -363,7 +370,7 @@ static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.off_qa = p.off_qa; P.off_ltq = p.off_ltq; P.off_gtq = p.off_gtq; P.delta_q = p.delta_q;
     P.off_wcol = p.off_wcol; P.off_wcnt = p.off_wcnt; P.off_woff = p.off_woff; P.off_wtot = p.off_wtot; P.off_wbase = p.off_wbase;
     P.off_wgt = p.off_wgt; P.off_wncov = p.off_wncov; P.off_wfe = p.off_wfe; P.off_wdk = p.off_wdk; P.walk_S = p.walk_S;
-    P.off_wseg = p.off_wseg; P.off_wguess = p.off_wguess; P.walk_capp = p.walk_capp; P.walk_ov = p.walk_ov;
+    P.off_wseg = p.off_wseg; P.off_wguess = p.off_wguess; P.walk_capp = p.walk_capp; P.walk_ov = p.walk_ov; P.walk_off_at = p.walk_off_at;
     P.off_shared = p.off_shared; P.lds_bytes = p.lds_bytes;
 }
 

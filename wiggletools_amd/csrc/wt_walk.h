@@ -28,8 +28,9 @@
 #define WT_WALK_NANKEY 0xfffffffeu     // every NaN (no other value has this key: wt_walk_key)
 #define WT_WALK_INC 0x10000u           // event: the track becomes covered
 #define WT_WALK_DEC 0x20000u           // event: the track stops being covered
-#define WT_WALK_MAX_S 16
+#define WT_WALK_MAX_S 32               // (the lanes' position masks are 32 bits)
 #define WT_WALK_PAD 8                  // col[] has a multiple of this many rows (the sweeps' block)
+#define WT_WALK_TF 256                 // tiles of the flat run space whose first track is tabulated (wt_delta.h tabulates 2048: 4 KB)
 #define WT_WALK_OV_SCAN 32             // events beyond their positions' slots a window may have and still be walked from the slots
 
 struct alignas(8) WtWalkEvent { uint32_t key, meta; };     // meta: track | WT_WALK_INC | WT_WALK_DEC
@@ -38,7 +39,7 @@ struct WtWalkOvf { uint32_t pos, key, meta; };             // an event that did 
 struct WtWalkCtx {
     uint32_t *col;      // [N][T] current keys, one column per lane
     uint32_t *cnt;      // [W] events per position (count pass); slot countdown (scatter); the lanes' results (walk)
-    uint32_t *off;      // [W + 1] first event of every position (index into the window's event sequence)
+    uint32_t *off;      // [W + 1] fallback: first event of every position (index into the window's event sequence); in the slab
     uint32_t *tot;      // [T] scan scratch
     uint32_t *base;     // [T + 1] scan result
     uint32_t *gt;       // [T / 64 + 1] wave totals
@@ -61,7 +62,6 @@ struct WtWalkCtx {
 WT_DEV void wt_walk_ctx_init(WtWalkCtx &w, const WtParams &P, char *lds, char *slab) {
     w.col = (uint32_t *) (lds + P.off_wcol);
     w.cnt = (uint32_t *) (lds + P.off_wcnt);
-    w.off = (uint32_t *) (lds + P.off_woff);
     w.tot = (uint32_t *) (lds + P.off_wtot);
     w.base = (uint32_t *) (lds + P.off_wbase);
     w.gt = (uint32_t *) (lds + P.off_wgt);
@@ -72,7 +72,8 @@ WT_DEV void wt_walk_ctx_init(WtWalkCtx &w, const WtParams &P, char *lds, char *s
     w.seg1 = w.seg0 + P.W / P.walk_S;
     w.guess = (uint32_t *) (lds + P.off_wguess);
     w.slab = (WtWalkEvent *) slab;
-    w.cap = (uint32_t) (P.g_scratch_slab / (long long) sizeof(WtWalkEvent));
+    w.cap = (uint32_t) ((long long) P.walk_off_at / (long long) sizeof(WtWalkEvent));
+    w.off = (uint32_t *) (slab + P.walk_off_at);
     w.capp = P.walk_capp;
     w.ovf = (WtWalkOvf *) (slab + (size_t) P.W * (size_t) P.walk_capp * sizeof(WtWalkEvent));
     w.ov_cap = (uint32_t) (P.walk_ov < WT_WALK_OV_SCAN ? P.walk_ov : WT_WALK_OV_SCAN);
@@ -109,7 +110,33 @@ WT_DEV void wt_walk_zero(const WtParams &P, const WtCtx &c, WtWalkCtx &w, int ti
     }
 }
 
-// ---- the window's runs, twice (count, scatter): the flat index space of wt_delta.h ----
+// ---- the window's runs as the flat index space of wt_delta.h (wt_delta_ranges1 + the scans below: the same as
+// wt_delta_ranges2 / 3 and wt_delta_ranges_w2 with a shorter table of tile starts) ----
+#ifdef WT_EMU
+WT_DEV void wt_walk_ranges3(WtDeltaCtx &d, int tid, int nt) {
+    uint32_t pfx = 0;
+    for (int x = 0; x < tid; x++) pfx += (uint32_t) d.ltc[x];
+    const uint32_t n = (uint32_t) d.ltc[tid];
+    d.tpfx[tid] = pfx;
+    d.tbase[tid] -= 4ll * (long long) pfx;
+    if (tid == nt - 1) d.tpfx[nt] = pfx + n;
+    for (uint32_t b = (pfx + WT_DELTA_TILE - 1) / WT_DELTA_TILE; b * WT_DELTA_TILE < pfx + n && b < WT_WALK_TF; b++)
+        d.tfirst[b] = (uint16_t) tid;
+}
+#else
+WT_DEV void wt_walk_ranges_w2(WtDeltaCtx &d, int tid, int nt) {
+    const int wave = tid >> 6;
+    uint32_t pfx = d.tpfx[tid];
+    for (int x = 0; x < wave; x++) pfx += (uint32_t) d.gtc[x];
+    const uint32_t n = (uint32_t) d.ltc[tid];
+    d.tpfx[tid] = pfx;
+    d.tbase[tid] -= 4ll * (long long) pfx;
+    if (tid == nt - 1) d.tpfx[nt] = pfx + n;
+    for (uint32_t b = (pfx + WT_DELTA_TILE - 1) / WT_DELTA_TILE; b * WT_DELTA_TILE < pfx + n && b < WT_WALK_TF; b++)
+        d.tfirst[b] = (uint16_t) tid;
+}
+#endif
+
 struct WtWalkBatch {
     int32_t s[WT_DELTA_U], f[WT_DELTA_U];
     int32_t ps[WT_DELTA_U], ns[WT_DELTA_U];     // finish of the track's previous run, start of its next one (of the FILE, not the window)
@@ -123,7 +150,7 @@ WT_DEV void wt_walk_fetch(const WtParams &P, const WtDeltaCtx &d, const WtWalkCt
     const uint32_t lastt = (M - 1u) / WT_DELTA_TILE * WT_DELTA_TILE;
     const uint32_t tbe = tb < lastt ? tb : lastt;
     const uint32_t tile = tbe / WT_DELTA_TILE;
-    int i = tile < WT_DELTA_TF ? (int) d.tfirst[tile] : wt_delta_find(d.tpfx, nt, tbe, 0);
+    int i = tile < WT_WALK_TF ? (int) d.tfirst[tile] : wt_delta_find(d.tpfx, nt, tbe, 0);
     uint32_t hi = d.tpfx[i + 1];
     long long dl = d.tbase[i];
     long long s0 = w.seg0[i], s1 = w.seg1[i];

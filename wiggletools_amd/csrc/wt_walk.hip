@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
         wt_walk_zero(P, c, w, tid, nt);
         wt_delta_ranges_w1(P, c, d, 0, tid, nt);
         __syncthreads();
-        wt_delta_ranges_w2(P, c, d, tid, nt);
+        wt_walk_ranges_w2(d, tid, nt);
         __syncthreads();
         WT_TICK(0);
         WT_MARK(202);
