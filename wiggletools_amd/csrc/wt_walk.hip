@@ -99,11 +99,18 @@ __global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
         __syncthreads();
         const unsigned long long mine = w.base[nt];
         if (tid == 0) wt_lookback_publish(P, c, k, mine);
+        WT_TICK(7);
         if (tid < 64) wt_lookback_complete(P, c, k, tid, mine);
         __syncthreads();
+#ifdef WT_PROFILE_LB
+        WT_TICK(2);                             // (experiment: the look-back's wait alone, in the "offsets" slot)
+#endif
         WT_MARK(205);
         wt_walk_write(P, c, w, L, tid, nt);
         __syncthreads();
+#ifdef WT_PROFILE_LB
+        WT_TICK(3);                             // (experiment: the write, in the "scatter" slot)
+#endif
         if (tid == 0) {
             wt_window_stats(P, c);
             const long long kn = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
