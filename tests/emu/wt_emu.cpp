@@ -123,8 +123,10 @@ struct EmuRun {
             for (int t = 0; t < T; t++) wt_delta_ranges1(P, c, d, 0, t, T);
             for (int t = 0; t < T; t++) wt_walk_ranges3(d, t, T);
             for (int t = 0; t < T; t++) wt_walk_pass<false>(P, c, w, d, 0u, 0u, t, T);
-            for (int t = 0; t < T; t++) { L[t].evmask = 0; L[t].emitmask = 0; }
-            if (getenv("WTEMU_DEBUG")) fprintf(stderr, "[walk] window %lld: novf %u ov_cap %u capp %d cap %u\n", k, w.novf[0], w.ov_cap, w.capp, w.cap);
+            for (int t = 0; t < T; t++) wt_walk_emits(P, c, w, L[t], t, T);
+            for (int t = 0; t < T; t++) wt_walk_scan_a(w, (uint32_t) wt_popc32(L[t].emitmask), t, T);
+            for (int t = 0; t < T; t++) wt_walk_scan_b(w, t, T);
+            const unsigned long long mine = w.base[T];
             if (w.novf[0] <= w.ov_cap) {
                 n_rounds++;
                 for (int t = 0; t < T; t++) wt_walk_lane<true>(P, c, w, L[t], 0u, t, T);
@@ -143,9 +145,10 @@ struct EmuRun {
                     }
                     l0 = l1;
                 }
+                for (int t = 0; t < T; t++) wt_walk_scan_a(w, (uint32_t) wt_popc32(L[t].emitmask), t, T);
+                for (int t = 0; t < T; t++) wt_walk_scan_b(w, t, T);
             }
-            for (int t = 0; t < T; t++) wt_walk_scan_a(w, (uint32_t) wt_popc32(L[t].emitmask), t, T);
-            for (int t = 0; t < T; t++) wt_walk_scan_b(w, t, T);
+            if ((unsigned long long) w.base[T] != mine) { fprintf(stderr, "wtemu: walking kernel: run count changed\n"); abort(); }
             wt_phase_lookback(P, c, k, (unsigned long long) w.base[T]);
             for (int t = 0; t < T; t++) wt_walk_write(P, c, w, L[t], t, T);
             wt_window_stats(P, c);

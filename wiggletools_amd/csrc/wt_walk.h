@@ -30,6 +30,10 @@
 #define WT_WALK_DEC 0x20000u           // event: the track stops being covered
 #define WT_WALK_MAX_S 32               // (the lanes' position masks are 32 bits)
 #define WT_WALK_PAD 8                  // col[] has a multiple of this many rows (the sweeps' block)
+// a position's counter word: events (12 bits) | of which the track becomes covered (10 bits) | stops being covered (10 bits)
+#define WT_WALK_NMASK 0xfffu
+#define WT_WALK_CINC (1u << 12)
+#define WT_WALK_CDEC (1u << 22)
 #define WT_WALK_TF 256                 // tiles of the flat run space whose first track is tabulated (wt_delta.h tabulates 2048: 4 KB)
 #define WT_WALK_OV_SCAN 32             // events beyond their positions' slots a window may have and still be walked from the slots
 
@@ -176,20 +180,21 @@ WT_DEV void wt_walk_fetch(const WtParams &P, const WtDeltaCtx &d, const WtWalkCt
 }
 
 #ifdef WT_EMU
-WT_DEV uint32_t wt_lds_inc_rtn(uint32_t *p) { return (*p)++; }
+WT_DEV uint32_t wt_lds_add_rtn(uint32_t *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 #else
-WT_DEV uint32_t wt_lds_inc_rtn(uint32_t *p) { return atomicAdd((unsigned int *) p, 1u); }
+WT_DEV uint32_t wt_lds_add_rtn(uint32_t *p, uint32_t v) { return atomicAdd((unsigned int *) p, v); }
 #endif
 
 // an event of position cs: counted, and placed in one of the position's fixed slots -- or, beyond them, in the overflow list
 WT_DEV void wt_walk_place(WtWalkCtx &w, int32_t cs, uint32_t key, uint32_t meta) {
-    const uint32_t slot = wt_lds_inc_rtn(&w.cnt[cs]);
+    // (the coverage changes ride in the same word: the window's run count is known before any event is applied)
+    const uint32_t slot = wt_lds_add_rtn(&w.cnt[cs], 1u + ((meta & WT_WALK_INC) ? WT_WALK_CINC : 0u) + ((meta & WT_WALK_DEC) ? WT_WALK_CDEC : 0u)) & WT_WALK_NMASK;
     if (slot < (uint32_t) w.capp) {
         WtWalkEvent e;
         e.key = key; e.meta = meta;
         w.slab[(uint32_t) cs * (uint32_t) w.capp + slot] = e;
     } else {
-        const uint32_t j = wt_lds_inc_rtn(w.novf);
+        const uint32_t j = wt_lds_add_rtn(w.novf, 1u);
         if (j < w.ov_cap) {
             WtWalkOvf o;
             o.pos = (uint32_t) cs; o.key = key; o.meta = meta;
@@ -229,9 +234,9 @@ WT_DEV void wt_walk_scatter1(const WtParams &P, WtWalkCtx &w, int32_t w0, int32_
         const uint32_t at = w.off[cs];
         if (at >= ev0 && at < ev1) {                            // (positions of the lanes of this round)
 #ifdef WT_EMU
-            const uint32_t old = w.cnt[cs]--;
+            const uint32_t old = (w.cnt[cs]--) & WT_WALK_NMASK;
 #else
-            const uint32_t old = atomicSub((unsigned int *) &w.cnt[cs], 1u);
+            const uint32_t old = atomicSub((unsigned int *) &w.cnt[cs], 1u) & WT_WALK_NMASK;
 #endif
             WtWalkEvent e;
             e.key = wt_walk_key(vb);
@@ -243,9 +248,9 @@ WT_DEV void wt_walk_scatter1(const WtParams &P, WtWalkCtx &w, int32_t w0, int32_
         const uint32_t at = w.off[cf];
         if (at >= ev0 && at < ev1) {
 #ifdef WT_EMU
-            const uint32_t old = w.cnt[cf]--;
+            const uint32_t old = (w.cnt[cf]--) & WT_WALK_NMASK;
 #else
-            const uint32_t old = atomicSub((unsigned int *) &w.cnt[cf], 1u);
+            const uint32_t old = atomicSub((unsigned int *) &w.cnt[cf], 1u) & WT_WALK_NMASK;
 #endif
             WtWalkEvent e;
             e.key = w.dkey[trk];
@@ -334,7 +339,7 @@ WT_DEV void wt_walk_offsets1(const WtParams &P, WtWalkCtx &w, int tid, int nt) {
     uint32_t sum = 0;
     int fe = -1;
     for (int s = 0; s < S; s++) {
-        const uint32_t n = w.cnt[a + s];
+        const uint32_t n = w.cnt[a + s] & WT_WALK_NMASK;
         if (n && fe < 0) fe = a + s;
         sum += n;
     }
@@ -345,7 +350,7 @@ WT_DEV void wt_walk_offsets1(const WtParams &P, WtWalkCtx &w, int tid, int nt) {
 WT_DEV void wt_walk_offsets2(const WtParams &P, WtWalkCtx &w, int tid, int nt) {
     const int S = w.S, a = tid * S;
     uint32_t o = w.base[tid];
-    for (int s = 0; s < S; s++) { w.off[a + s] = o; o += w.cnt[a + s]; }
+    for (int s = 0; s < S; s++) { w.off[a + s] = o; o += w.cnt[a + s] & WT_WALK_NMASK; }
     if (tid == nt - 1) w.off[P.W] = o;
 }
 
@@ -500,6 +505,27 @@ struct WtWalkLane {
 };
 
 // The lane's stretch.  ev0: index (in the window's event sequence) of the first event the slab holds.
+// Which of the lane's positions have events, and which start an emitted run -- from the counter words alone (events and
+// coverage changes per position), before any event is applied: the window's run count goes to the look-back chain ahead of
+// the walk, so that no successor ever waits for it.
+WT_DEV void wt_walk_emits(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalkLane &L, int tid, int nt) {
+    const int N = P.n_tracks, S = w.S, a = tid * S;
+    const bool strict = (P.flags & WT_STRICT_SET0) != 0;
+    const int32_t room = c.sh->emit_hi - (c.sh->w0 + a);       // positions of the stretch below the range end
+    uint32_t evmask = 0, emitmask = 0;
+    int ncov = w.ncov[tid], fe = -1;
+    for (int s = 0; s < S; s++) {
+        const uint32_t v = w.cnt[a + s];
+        if (!(v & WT_WALK_NMASK)) continue;
+        if (fe < 0) fe = a + s;
+        evmask |= 1u << s;
+        ncov += (int) ((v >> 12) & 0x3ffu) - (int) (v >> 22);
+        if ((strict ? ncov == N : ncov > 0) && s < room) emitmask |= 1u << s;      // multiplexer.c:120,125
+    }
+    w.fe[tid] = fe;
+    L.evmask = evmask; L.emitmask = emitmask;
+}
+
 #if defined(WT_PROFILE) && !defined(WT_EMU)
 #define WT_WALK_T0 unsigned long long wt_wt = __builtin_readcyclecounter()
 #define WT_WALK_TICK(slot) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (prof) prof[slot] += t_ - wt_wt; wt_wt = t_; } while (0)
@@ -516,13 +542,11 @@ template <bool FIXED>
 WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalkLane &L, uint32_t ev0, int tid, int nt,
                          unsigned long long *prof = nullptr) {
     const int N = P.n_tracks, S = w.S, a = tid * S, k = N / 2;
-    const bool strict = (P.flags & WT_STRICT_SET0) != 0;
-    const int32_t room = c.sh->emit_hi - (c.sh->w0 + a);       // positions of the stretch below the range end
-    uint32_t evmask = 0, emitmask = 0;
+    const uint32_t emitmask = L.emitmask;       // (wt_walk_emits)
     uint32_t m = 0;
-    int lt = 0, le = 0, nn = 0, ncov = 0;
+    int lt = 0, le = 0, nn = 0;
     bool have = false;              // the median of the column is known (lazily: only where a run is emitted)
-    bool started = false;           // nn / ncov are initialised (at the stretch's first event)
+    bool started = false;           // nn is initialised (at the stretch's first event)
     uint32_t *col = w.col + tid;
     const uint32_t novf = FIXED ? (w.novf[0] < w.ov_cap ? w.novf[0] : w.ov_cap) : 0u;
 
@@ -546,7 +570,6 @@ WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalk
                 le += (nk <= m ? 1 : 0) - (ok[u] <= m ? 1 : 0);
             }
             nn += (nk == WT_WALK_NANKEY ? 1 : 0) - (ok[u] == WT_WALK_NANKEY ? 1 : 0);
-            ncov += (int) ((ev[u].meta >> 16) & 1u) - (int) ((ev[u].meta >> 17) & 1u);
         }
     };
     // WT_WALK_EB events from slab index `from` on.  Sorted: the first `n` exist (the others: the last one again).  FIXED: the
@@ -565,20 +588,16 @@ WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalk
     const uint32_t o_end = FIXED ? 0u : w.off[a + S];
     if (FIXED) { fetch((uint32_t) a * (uint32_t) w.capp, 1u, pre); pre_at = (uint32_t) a * (uint32_t) w.capp; }
     else if (o_end != o) { fetch(o - ev0, o_end - o, pre); pre_at = o - ev0; }
-    int fe = -1;
     for (int s = 0; s < S; s++) {
         uint32_t n, from;
-        if (FIXED) { n = w.cnt[a + s]; from = (uint32_t) (a + s) * (uint32_t) w.capp; }
+        if (FIXED) { n = w.cnt[a + s] & WT_WALK_NMASK; from = (uint32_t) (a + s) * (uint32_t) w.capp; }
         else { const uint32_t o1 = w.off[a + s + 1]; n = o1 - o; from = o - ev0; o = o1; }
         if (!n) continue;
         WT_WALK_T0;
         if (!started) {
             started = true;
             wt_walk_for_keys(w, nt, tid, [&](uint32_t x) { nn += x == WT_WALK_NANKEY ? 1 : 0; });
-            ncov = w.ncov[tid];
         }
-        if (fe < 0) fe = a + s;
-        evmask |= 1u << s;
         const uint32_t nslot = FIXED ? (n < (uint32_t) w.capp ? n : (uint32_t) w.capp) : n;
         for (uint32_t e = 0; e < nslot; e += WT_WALK_EB) {
             WtWalkEvent ev[WT_WALK_EB];
@@ -608,9 +627,7 @@ WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalk
             fetch(pre_at, o_end - o, pre);
         }
         WT_WALK_TICK(4);
-        const bool emit = (strict ? ncov == N : ncov > 0) && s < room;     // multiplexer.c:120,125
-        if (!emit) continue;
-        emitmask |= 1u << s;
+        if (!((emitmask >> s) & 1u)) continue;
         if (!have) {
             m = w.guess[0];
             wt_walk_recount(w, N, nt, tid, m, lt, le);
@@ -624,8 +641,6 @@ WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalk
         w.cnt[a + s] = nn ? WT_WALK_NANKEY : m;         // (the position's count is not needed any more: the result lives there)
     }
     if (have) w.guess[0] = m;       // (any lane's: the next stretch's first selection starts there)
-    w.fe[tid] = fe;
-    L.evmask = evmask; L.emitmask = emitmask;
 }
 
 // first breakpoint after the lane's stretch

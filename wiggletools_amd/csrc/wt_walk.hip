@@ -57,7 +57,14 @@ __global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
         __syncthreads();                        // the events are in the slab, the counts in cnt[]
         WT_TICK(1);
         WtWalkLane L;
-        L.evmask = 0; L.emitmask = 0;
+        // positions with events / emitted runs per lane, the window's run count: published before the walk
+        wt_walk_emits(P, c, w, L, tid, nt);
+        wt_walk_scan_a(w, (uint32_t) wt_popc32(L.emitmask), tid, nt);
+        __syncthreads();
+        wt_walk_scan_b(w, tid, nt);
+        __syncthreads();
+        const unsigned long long mine = w.base[nt];
+        if (tid == 0) wt_lookback_publish(P, c, k, mine);
         if (w.novf[0] <= w.ov_cap) {            // (uniform) every position's events fit its slots + the overflow list
 #ifdef WT_PROFILE
             wt_walk_lane<true>(P, c, w, L, 0u, tid, nt, tid == 0 ? prof : nullptr);
@@ -70,6 +77,7 @@ __global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
         } else {
             // a window denser than that: its events sorted by position into the same memory (a second pass over the
             // runs), as many lanes' worth at a time as fit
+            __syncthreads();                    // (base[] is about to hold the lanes' event offsets)
             wt_walk_offsets1(P, w, tid, nt);
             __syncthreads();
             wt_walk_scan_b(w, tid, nt);
@@ -91,14 +99,13 @@ __global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
                 }
                 l0 = l1;
             }
+            // the lanes' run offsets again (base[] held the event offsets meanwhile)
+            wt_walk_scan_a(w, (uint32_t) wt_popc32(L.emitmask), tid, nt);
+            __syncthreads();
+            wt_walk_scan_b(w, tid, nt);
+            __syncthreads();
         }
         WT_MARK(204);
-        wt_walk_scan_a(w, (uint32_t) wt_popc32(L.emitmask), tid, nt);
-        __syncthreads();
-        wt_walk_scan_b(w, tid, nt);
-        __syncthreads();
-        const unsigned long long mine = w.base[nt];
-        if (tid == 0) wt_lookback_publish(P, c, k, mine);
         WT_TICK(7);
         if (tid < 64) wt_lookback_complete(P, c, k, tid, mine);
         __syncthreads();
