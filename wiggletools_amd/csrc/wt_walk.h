@@ -281,22 +281,17 @@ WT_DEV void wt_walk_pass(const WtParams &P, WtCtx &c, WtWalkCtx &w, WtDeltaCtx &
     };
     uint32_t tb = (uint32_t) wave * WT_DELTA_TILE;
     if (tb < M) {
-        // three register sets take turns: two tiles' loads are in flight while one is applied (a workgroup is two to four
-        // waves, one per SIMD: nothing else hides the latency of the loads)
-        WtWalkBatch Q0, Q1, Q2;
-        wt_walk_fetch(P, d, w, nt, M, tb, lane, Q0);
-        wt_walk_fetch(P, d, w, nt, M, tb + step, lane, Q1);         // (past the end: harmless re-reads of the last tile)
+        // two register sets take turns: the next tile's loads are in flight while this one is applied (a third set, two
+        // tiles ahead, measured no faster and costs registers and code)
+        WtWalkBatch A, B;
+        wt_walk_fetch(P, d, w, nt, M, tb, lane, A);
         for (;;) {
-            wt_walk_fetch(P, d, w, nt, M, tb + 2u * step, lane, Q2);
-            apply(Q0, tb);
+            wt_walk_fetch(P, d, w, nt, M, tb + step, lane, B);      // (past the end: harmless re-reads of the last tile)
+            apply(A, tb);
             tb += step;
             if (tb >= M) break;
-            wt_walk_fetch(P, d, w, nt, M, tb + 2u * step, lane, Q0);
-            apply(Q1, tb);
-            tb += step;
-            if (tb >= M) break;
-            wt_walk_fetch(P, d, w, nt, M, tb + 2u * step, lane, Q1);
-            apply(Q2, tb);
+            wt_walk_fetch(P, d, w, nt, M, tb + step, lane, A);
+            apply(B, tb);
             tb += step;
             if (tb >= M) break;
         }
