@@ -60,6 +60,10 @@ struct WtBufBulk {
 
 std::mutex g_buf_mu;
 std::unordered_map<WiggleIterator *, WtBufBulk *> g_buf_doors;
+// buffers between launchBufferedReader and killBufferedReader.  A door outlives its iterator (the reference frees iterators
+// with plain free(): nobody tells this file), and the allocator may hand the same address to a new, unrelated iterator:
+// a door is only trusted while the buffer it points at is one of these.
+std::unordered_map<const void *, bool> g_buf_live;
 std::atomic<long long> g_buf_bulk_entries{0};      // entries that left through the bulk door (tests)
 
 // Blocks are recycled: the reference callocs five arrays per block (bufferedReader.c:21-28) -- 280 KB, i.e. an mmap, its
@@ -147,7 +151,17 @@ void wt_buf_register(WiggleIterator *wi, BufferedReaderData *d) {
 BulkSource *wt_bufreader_bulk(WiggleIterator *wi) {
     std::lock_guard<std::mutex> lk(g_buf_mu);
     const auto it = g_buf_doors.find(wi);
-    return it == g_buf_doors.end() ? nullptr : &it->second->hdr;
+    if (it == g_buf_doors.end()) return nullptr;
+    WtBufBulk *door = it->second;
+    if (!door->data || !g_buf_live.count(door->data)) return nullptr;      // (a door left behind by an iterator long gone)
+    return &door->hdr;
+}
+
+// the buffer a door may use right now, or NULL (per block of 10 000 entries: the lock is not on the per-interval path)
+BufferedReaderData *wt_buf_door_data(WtBufBulk *door) {
+    std::lock_guard<std::mutex> lk(g_buf_mu);
+    BufferedReaderData *d = door->data;
+    return d && g_buf_live.count(d) ? d : nullptr;
 }
 
 }  // namespace
@@ -160,6 +174,7 @@ void launchBufferedReader(void *(*readFileFunction)(void *), void *f_data, Buffe
     d->readerData = f_data;
     pthread_mutex_init(&d->mu, nullptr);
     pthread_cond_init(&d->cv, nullptr);
+    { std::lock_guard<std::mutex> lk(g_buf_mu); g_buf_live[d] = true; }
     const int err = pthread_create(&d->thread, nullptr, readFileFunction, f_data);
     if (err) {
         fprintf(stderr, "Could not create new thread %i\n", err);      // bufferedReader.c:133-135
@@ -192,6 +207,7 @@ void endBufferedSignal(BufferedReaderData *d) {
 }
 
 void killBufferedReader(BufferedReaderData *d) {
+    { std::lock_guard<std::mutex> lk(g_buf_mu); g_buf_live.erase(d); }
     if (d->killed) return;
     pthread_mutex_lock(&d->mu);
     d->blockCount = -1;
@@ -245,7 +261,7 @@ namespace {
 int64_t wt_buf_peek(BulkSource *bs, const int32_t **s, const int32_t **f, const float **v) {
     WtBufBulk *door = (WtBufBulk *) bs;
     WiggleIterator *wi = door->wi;
-    BufferedReaderData *d = door->data;
+    BufferedReaderData *d = wt_buf_door_data(door);
     if (wi->done || !d || !d->block || d->readIndex < 1) return 0;
     const WtBufBlock *b = d->block;
     const int cur = d->readIndex - 1;
@@ -268,7 +284,7 @@ int64_t wt_buf_peek(BulkSource *bs, const int32_t **s, const int32_t **f, const 
 // k (<= what peek returned) entries are consumed: the iterator's visible fields move to the element after them.
 void wt_buf_advance(BulkSource *bs, WiggleIterator *wi, int64_t k) {
     WtBufBulk *door = (WtBufBulk *) bs;
-    BufferedReaderData *d = door->data;
+    BufferedReaderData *d = wt_buf_door_data(door);
     if (wi->done || k <= 0) return;
     if (!d || !d->block) { wi->done = 1; return; }
     g_buf_bulk_entries += k;
