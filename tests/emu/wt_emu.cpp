@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <thread>
 
 #include "../../wiggletools_amd/csrc/wt_core.h"
 #include "../../wiggletools_amd/csrc/wt_plan.h"
@@ -124,28 +125,40 @@ struct EmuRun {
             for (int t = 0; t < T; t++) wt_walk_ranges3(d, t, T);
             for (int t = 0; t < T; t++) wt_walk_pass<false>(P, c, w, d, 0u, 0u, t, T);
             for (int t = 0; t < T; t++) wt_walk_emits(P, c, w, L[t], t, T);
-            for (int t = 0; t < T; t++) wt_walk_scan_a(w, (uint32_t) wt_popc32(L[t].emitmask), t, T);
+            for (int t = 0; t < T; t++) wt_walk_scan_a(w, wt_walk_emit_count(w, L[t], t), t, T);
             for (int t = 0; t < T; t++) wt_walk_scan_b(w, t, T);
             const unsigned long long mine = w.base[T];
+            // pair mode: the two lanes of a stretch run side by side (they exchange values: wt_pair_xchg), one pair at a time
+            auto walk_lanes = [&](int l0, int l1, uint32_t ev0, bool fixed) {
+                if (!w.pair) {
+                    for (int t = l0; t < l1; t++) { if (fixed) wt_walk_lane<true, false>(P, c, w, L[t], ev0, t, T); else wt_walk_lane<false, false>(P, c, w, L[t], ev0, t, T); }
+                    return;
+                }
+                for (int q = l0; q < l1; q++) {
+                    std::thread odd([&, q] { if (fixed) wt_walk_lane<true, true>(P, c, w, L[2 * q + 1], ev0, 2 * q + 1, T); else wt_walk_lane<false, true>(P, c, w, L[2 * q + 1], ev0, 2 * q + 1, T); });
+                    if (fixed) wt_walk_lane<true, true>(P, c, w, L[2 * q], ev0, 2 * q, T); else wt_walk_lane<false, true>(P, c, w, L[2 * q], ev0, 2 * q, T);
+                    odd.join();
+                }
+            };
             if (w.novf[0] <= w.ov_cap) {
                 n_rounds++;
-                for (int t = 0; t < T; t++) wt_walk_lane<true>(P, c, w, L[t], 0u, t, T);
+                walk_lanes(0, w.nstr, 0u, true);
             } else {
                 n_fallback++;
                 for (int t = 0; t < T; t++) wt_walk_offsets1(P, w, t, T);
                 for (int t = 0; t < T; t++) wt_walk_scan_b(w, t, T);
                 for (int t = 0; t < T; t++) wt_walk_offsets2(P, w, t, T);
-                for (int l0 = 0; l0 < T;) {
+                for (int l0 = 0; l0 < w.nstr;) {
                     const int l1 = wt_walk_round_end(w, l0, T);
-                    const uint32_t ev0 = w.base[l0], ev1 = w.base[l1];
+                    const uint32_t ev0 = w.base[l0 << w.pair], ev1 = w.base[l1 << w.pair];
                     if (ev1 > ev0) {
                         n_rounds++;
                         for (int t = 0; t < T; t++) wt_walk_pass<true>(P, c, w, d, ev0, ev1, t, T);
-                        for (int t = l0; t < l1; t++) wt_walk_lane<false>(P, c, w, L[t], ev0, t, T);
+                        walk_lanes(l0, l1, ev0, false);
                     }
                     l0 = l1;
                 }
-                for (int t = 0; t < T; t++) wt_walk_scan_a(w, (uint32_t) wt_popc32(L[t].emitmask), t, T);
+                for (int t = 0; t < T; t++) wt_walk_scan_a(w, wt_walk_emit_count(w, L[t], t), t, T);
                 for (int t = 0; t < T; t++) wt_walk_scan_b(w, t, T);
             }
             if ((unsigned long long) w.base[T] != mine) { fprintf(stderr, "wtemu: walking kernel: run count changed\n"); abort(); }

@@ -492,7 +492,9 @@ def test_plan_policy_snapshot():
     p = plan(500, "var", no_delta=1)
     assert (p["W"], p["T"]) == (2048, 512) and p["n_chunks"] == 5        # general kernel: chunks of <= 112 tracks
     p = plan(100, "median")
-    assert (p["walk"], p["W"], p["T"]) == (1, 8192, 256)                                              # round 4: walking, 256 lanes x 32 positions, one workgroup per CU
+    assert (p["walk"], p["W"], p["T"]) == (1, 2048, 256)                                              # round 4: walking, two lanes per stretch: 128 stretches x 16 positions, two workgroups per CU
+    p = plan(100, "median", walk_pair=0)
+    assert (p["walk"], p["W"], p["T"]) == (1, 8192, 256)                                              # ... one lane per stretch: 256 lanes x 32 positions, one workgroup per CU
     p = plan(100, "median", no_walk=1)
     assert (p["W"], p["T"], p["lds"] < 32 * 1024) == (512, 256, True) and p["scratch_slab"] == 0     # round 2: value column in REGISTERS, LDS = bitmaps only, 2 positions per lane
     p = plan(100, "mwu", n_set0=50)
@@ -587,13 +589,16 @@ def test_emu_median_walk_fuzz(oracle, seed):
     # send events through the overflow list, none at all sends every window with a full position to the fallback (its
     # events sorted into the slab by a second pass, in rounds when they do not fit at once)
     capp, ov = [(None, None), (None, None), (2, None), (1, 5), (2, 0), (1, 0)][int(rng.integers(0, 6))]
+    pair = int(seed % 2)            # one lane per stretch / two lanes (half the column each, values exchanged inside the pair)
+    if pair and capp == 1:
+        capp = 2                    # (a slot per lane of the pair at least)
     flags = int(rng.choice([0, 0, 1]))
     ranges = None
     if rng.random() < 0.3:
         ranges = [(int(rng.integers(1, L // 2 + 2)), int(rng.integers(L // 2 + 1, L + 60))) for L in lens]
-    got, info = emu.reduce(t, "median", flags=flags, walk_T=T, walk_S=S, walk_capp=capp, walk_ov=ov, ranges=ranges)
+    got, info = emu.reduce(t, "median", flags=flags, walk_T=T, walk_S=S, walk_capp=capp, walk_ov=ov, walk_pair=pair, ranges=ranges)
     assert info["walk"] == 1
-    assert (info["T"], info["W"]) == (T, T * S) or n * T * 4 + T * S * 4 > 100 * 1024      # (the columns of 256 lanes do not fit: fewer positions, fewer lanes)
+    assert (info["T"], info["W"]) == (T, (T >> pair) * S) or n * T * 4 + T * S * 4 > 100 * 1024 or (T >> pair) * S < 64      # (the columns of 256 lanes do not fit: fewer positions, fewer lanes)
     exp = oracle.reduce(t.as_dict(), "median", flags=flags) if ranges is None else None
     old, info2 = emu.reduce(t, "median", flags=flags, no_walk=1, ranges=ranges)
     assert info2["walk"] == 0
@@ -604,26 +609,28 @@ def test_emu_median_walk_fuzz(oracle, seed):
         assert info["walk_fallback"] > 0
 
 
-def test_emu_median_walk_dense_and_sparse(oracle):
-    """The extremes: every track a run per base pair (the most events a window can hold), and tracks with one run each."""
+@pytest.mark.parametrize("pair", [0, 1])
+def test_emu_median_walk_dense_and_sparse(oracle, pair):
+    """The extremes: every track a run per base pair (the most events a window can hold), and tracks with one run each;
+    one lane per stretch and two."""
     from wiggletools_amd.runlists import RunLists
     rng = np.random.default_rng(5)
     n, L = 9, 700
     per_bp = [[(p, p + 1, float(rng.integers(0, 50)) / 4.0) for p in range(1, L)] for _ in range(n)]
     t = _f32(RunLists.from_lists([[r] for r in per_bp]))         # (track, chromosome)
-    got, info = emu.reduce(t, "median", walk_T=64, walk_S=4, walk_capp=2, walk_ov=0)
+    got, info = emu.reduce(t, "median", walk_T=64, walk_S=4, walk_capp=2, walk_ov=0, walk_pair=pair)
     assert info["walk"] == 1 and info["walk_fallback"] == info["n_windows"] and info["walk_rounds"] > info["n_windows"]      # sorted, in rounds
     assert_runs_equal(got, oracle.reduce(t.as_dict(), "median"), 0.0, "one run per bp, fallback")
     # a few positions with more events than slots: those go through the overflow list, no fallback
     burst = [[(100, 100 + 7 * (i + 1), float(i)), (400 + i // 3, 500, float(-i))] for i in range(n)]
     t2 = _f32(RunLists.from_lists([[r] for r in burst]))
-    got, info = emu.reduce(t2, "median", walk_T=64, walk_S=4, walk_capp=4)
+    got, info = emu.reduce(t2, "median", walk_T=64, walk_S=4, walk_capp=4, walk_pair=pair)
     assert info["walk"] == 1 and info["walk_fallback"] == 0
     assert_runs_equal(got, oracle.reduce(t2.as_dict(), "median"), 0.0, "nine starts at one position, overflow list")
     one = [[(int(rng.integers(1, 3000)), 0, float(i))] for i in range(n)]
     one = [[(s, s + int(rng.integers(1, 4000)), v)] for [(s, _, v)] in one]
     t = _f32(RunLists.from_lists([[r] for r in one]))
     for flags in (0, 1):
-        got, info = emu.reduce(t, "median", flags=flags)
+        got, info = emu.reduce(t, "median", flags=flags, walk_pair=pair)
         assert info["walk"] == 1
         assert_runs_equal(got, oracle.reduce(t.as_dict(), "median", flags=flags), 0.0, "one run per track")

@@ -689,7 +689,7 @@ def test_gpu_c2_shape_long_runs(oracle, engine):
     ts.close()
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(18))
 def test_gpu_median_walk_paths(oracle, engine, seed, monkeypatch):
     """MedianReduction by walking (csrc/wt_walk.h) on the device: the default plan, small workgroups / stretches, slots too
     few for the data (overflow list) and no overflow list at all (every window falls back to the sorted events, in rounds)
@@ -703,7 +703,8 @@ def test_gpu_median_walk_paths(oracle, engine, seed, monkeypatch):
               gap_prob=float(rng.choice([0, 0.05, 0.5])), dtype=np.float32, value_levels=int(rng.choice([2, 5, 800])),
               nan_prob=float(rng.choice([0, 0, 0.001])), defaults=defaults)
     env = [dict(), dict(WTAMD_WALK_T="128"), dict(WTAMD_WALK_T="64", WTAMD_WALK_S="8"), dict(WTAMD_WALK_CAPP="2"),
-           dict(WTAMD_WALK_CAPP="1", WTAMD_WALK_OV="0"), dict(WTAMD_WALK_CAPP="2", WTAMD_WALK_OV="0", WTAMD_WALK_T="64", WTAMD_WALK_S="4")][seed % 6]
+           dict(WTAMD_WALK_CAPP="2", WTAMD_WALK_OV="0"), dict(WTAMD_WALK_CAPP="2", WTAMD_WALK_OV="0", WTAMD_WALK_T="64", WTAMD_WALK_S="4")][seed % 6]
+    env = dict(env, WTAMD_WALK_PAIR=str((seed // 3) % 2))       # one lane per stretch / two (the default)
     flags = int(rng.choice([0, 0, 1]))
     d = t.as_dict()
     exp = oracle.reduce(d, "median", flags=flags)

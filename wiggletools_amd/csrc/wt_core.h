@@ -124,6 +124,7 @@ struct WtParams {
     int32_t walk_S;               // ... positions per lane (0: not a walking launch)
     int32_t walk_capp;            // ... fixed event slots per position
     int32_t walk_ov;              // ... entries of the overflow list behind them
+    int32_t walk_pair;            // ... 1: two lanes per stretch
     int32_t walk_off_at;          // ... byte offset, in the workgroup's slab, of the fallback's offsets off[W + 1]
     int32_t lds_bytes;
 };

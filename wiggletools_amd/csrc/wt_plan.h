@@ -35,6 +35,7 @@ struct WtPlan {
     int walk_capp = 0;      // ... fixed event slots per position
     int walk_ov = 0;        // ... entries of the overflow list
     int walk_off_at = 0;    // ... where the fallback's offsets start in the workgroup's slab (bytes)
+    int walk_pair = 0;      // ... 1: two lanes per stretch (half the column each)
     int off_wcol = 0, off_wcnt = 0, off_woff = 0, off_wtot = 0, off_wbase = 0, off_wgt = 0, off_wncov = 0, off_wfe = 0, off_wdk = 0, off_wseg = 0, off_wguess = 0;
 };
 
@@ -183,22 +184,27 @@ static inline void wt_delta_defaults_params(const double *defaults, int n_tracks
 // same memory, in as many rounds as it takes: at least the 2 N S events the stretch of one lane can hold fit.
 // events_per_bp: what the data is expected to hold (the host's estimate from the run count and the covered span; <= 0: unknown).
 static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double events_per_bp, int hard_limit = 160 * 1024) {
-    // 256 lanes x 32 positions (an 8192-bp window, one workgroup per CU) when the columns fit, else fewer positions, then
-    // fewer lanes.  Measured (MI355X, chromosome 21, 100 tracks): 256 x 32 11.8 ms, 64 x 32 11.9, 256 x 16 12.6, 128 x 32 12.8,
-    // 128 x 16 14.3: the per-window chains of dependent loads are what the wider window saves.
-    const char *eT = getenv("WTAMD_WALK_T"), *eS = getenv("WTAMD_WALK_S");
-    const int wantT = eT ? atoi(eT) : 256, wantS = eS ? atoi(eS) : 32;
+    // One lane per stretch: 256 lanes x 32 positions (an 8192-bp window, one workgroup per CU) when the columns fit, else fewer
+    // positions, then fewer lanes.  Measured (MI355X, chromosome 21, 100 tracks): 256 x 32 11.8 ms, 64 x 32 11.9, 256 x 16 12.6,
+    // 128 x 32 12.8, 128 x 16 14.3: the per-window chains of dependent loads are what the wider window saves.
+    // Pair mode (the default; WTAMD_WALK_PAIR=0 for the above): two lanes per stretch, half the column each -- twice the lanes
+    // per CU: 256 lanes = 128 stretches x 16 positions (a 2048-bp window, 72 KB, two workgroups per CU) 9.9-10.0 ms, 64 x 32
+    // the same, 128 x 16 10.0, 256 x 8 10.6, 512 lanes (one workgroup of 8 waves) x 16 / 32 11.4-11.5.
+    const char *eT = getenv("WTAMD_WALK_T"), *eS = getenv("WTAMD_WALK_S"), *eP = getenv("WTAMD_WALK_PAIR");
+    const int pair = eP ? (atoi(eP) != 0 ? 1 : 0) : WT_WALK_PAIR_DEFAULT;
+    const int wantT = eT ? atoi(eT) : 256, wantS = eS ? atoi(eS) : (pair ? 16 : 32);
     struct Cand { int T, S; };
     for (const Cand cd : {Cand{wantT, wantS}, Cand{wantT, 16}, Cand{256, 16}, Cand{128, 16}, Cand{64, 16}}) {
         const int T = cd.T, S = cd.S;
-        if (T != 64 && T != 128 && T != 256) continue;
+        if (T != 64 && T != 128 && T != 256 && !(pair && T == 512)) continue;
         if (S != 4 && S != 8 && S != 16 && S != 32) continue;
         if (n_tracks > T) continue;
         WtPlan q;
-        q.T = T; q.W = T * S; q.n_words = q.W / 64; q.ppt = S; q.walk_S = S; q.regcol = nr;
+        q.T = T; q.W = (T >> pair) * S; q.n_words = q.W / 64; q.ppt = S; q.walk_S = S; q.regcol = nr; q.walk_pair = pair;
+        if (q.W < 64) continue;
         q.chunk_tracks = n_tracks; q.n_chunks = 1;
         int o = 0;
-        q.off_wcol = o;   o = wt_align16(o + ((n_tracks + 7) & ~7) * T * 4);        // (WT_WALK_PAD rows)
+        q.off_wcol = o;   o = wt_align16(o + (((pair ? (n_tracks + 1) / 2 : n_tracks) + 7) & ~7) * T * 4);        // (WT_WALK_PAD rows)
         q.off_wcnt = o;   o = wt_align16(o + q.W * 4);
         q.off_woff = 0;                                                             // (the fallback's offsets live in the slab)
         q.off_wtot = o;   o = wt_align16(o + T * 4);
@@ -207,7 +213,7 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double eve
         q.off_wncov = o;  o = wt_align16(o + T * 4);
         q.off_wfe = o;    o = wt_align16(o + T * 4);
         q.off_wdk = o;    o = wt_align16(o + n_tracks * 4);
-        q.off_wseg = o;   o = wt_align16(o + 2 * T * 8);
+        q.off_wseg = o;   o = wt_align16(o + 2 * n_tracks * 8);
         q.off_wguess = o; o = wt_align16(o + 8);       // (+ the overflow counter)
         q.off_tbase = o;  o = wt_align16(o + T * 8);
         q.off_ltc = o;    o = wt_align16(o + T * 4);
@@ -229,7 +235,7 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double eve
         q.walk_capp = capp;
         q.walk_ov = (int) ov;
         long long bytes = (long long) q.W * capp * 8 + (ov > 8 ? ov : 8) * 12;      // (the fixed fetch may read 8 events past the slots)
-        const long long lane_max = 2ll * n_tracks * S * 8;
+        const long long lane_max = 2ll * n_tracks * S * 8;      // (the events one stretch can hold)
         if (bytes < lane_max) bytes = lane_max;
         bytes = (bytes + 255) & ~255ll;
         q.walk_off_at = (int) bytes;
@@ -370,7 +376,7 @@ static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.off_qa = p.off_qa; P.off_ltq = p.off_ltq; P.off_gtq = p.off_gtq; P.delta_q = p.delta_q;
     P.off_wcol = p.off_wcol; P.off_wcnt = p.off_wcnt; P.off_woff = p.off_woff; P.off_wtot = p.off_wtot; P.off_wbase = p.off_wbase;
     P.off_wgt = p.off_wgt; P.off_wncov = p.off_wncov; P.off_wfe = p.off_wfe; P.off_wdk = p.off_wdk; P.walk_S = p.walk_S;
-    P.off_wseg = p.off_wseg; P.off_wguess = p.off_wguess; P.walk_capp = p.walk_capp; P.walk_ov = p.walk_ov; P.walk_off_at = p.walk_off_at;
+    P.off_wseg = p.off_wseg; P.off_wguess = p.off_wguess; P.walk_capp = p.walk_capp; P.walk_ov = p.walk_ov; P.walk_off_at = p.walk_off_at; P.walk_pair = p.walk_pair;
     P.off_shared = p.off_shared; P.lds_bytes = p.lds_bytes;
 }
 

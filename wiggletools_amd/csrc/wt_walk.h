@@ -24,6 +24,9 @@
 // The output is the bitmap kernel's, bit for bit (same keys, same order statistic, NaN if any value is NaN).
 #ifndef WT_WALK_H_
 #define WT_WALK_H_
+#ifdef WT_EMU
+#include <atomic>
+#endif
 
 #define WT_WALK_NANKEY 0xfffffffeu     // every NaN (no other value has this key: wt_walk_key)
 #define WT_WALK_INC 0x10000u           // event: the track becomes covered
@@ -34,6 +37,14 @@
 #define WT_WALK_NMASK 0xfffu
 #define WT_WALK_CINC (1u << 12)
 #define WT_WALK_CDEC (1u << 22)
+// pair mode, while the events sit in their slots: events of the even tracks (7 bits) | of the odd tracks (7) | covered (8) |
+// uncovered (8) -- every lane of a pair has its own slots (half of the position's) and its own count
+#define WT_WALK_PNMASK 0x7fu
+#define WT_WALK_PCINC (1u << 14)
+#define WT_WALK_PCDEC (1u << 22)
+#ifndef WT_WALK_PAIR_DEFAULT
+#define WT_WALK_PAIR_DEFAULT 1          // two lanes per stretch (WTAMD_WALK_PAIR=0: one)
+#endif
 #define WT_WALK_TF 256                 // tiles of the flat run space whose first track is tabulated (wt_delta.h tabulates 2048: 4 KB)
 #define WT_WALK_OV_SCAN 32             // events beyond their positions' slots a window may have and still be walked from the slots
 
@@ -59,8 +70,11 @@ struct WtWalkCtx {
     uint32_t ov_cap;    // entries of ovf[]
     int capp;           // fixed slots per position (a power of two)
     int npad;           // rows of col[]: N rounded up to the sweeps' block (the extra rows hold 0xffffffff)
-    int S;              // positions per lane (a power of two)
+    int S;              // positions per stretch (a power of two)
     int logS;
+    int pair;           // 1: TWO lanes per stretch -- lane 2q + h holds the tracks i = h (mod 2) of stretch q (row i >> 1): half the
+                        //    column per lane, twice the lanes per CU; counts and candidates are exchanged inside the lane pair
+    int nstr;           // stretches of the window (lanes, or half of them)
 };
 
 WT_DEV void wt_walk_ctx_init(WtWalkCtx &w, const WtParams &P, char *lds, char *slab) {
@@ -73,7 +87,7 @@ WT_DEV void wt_walk_ctx_init(WtWalkCtx &w, const WtParams &P, char *lds, char *s
     w.fe = (int32_t *) (lds + P.off_wfe);
     w.dkey = (uint32_t *) (lds + P.off_wdk);
     w.seg0 = (long long *) (lds + P.off_wseg);
-    w.seg1 = w.seg0 + P.W / P.walk_S;
+    w.seg1 = w.seg0 + P.n_tracks;
     w.guess = (uint32_t *) (lds + P.off_wguess);
     w.slab = (WtWalkEvent *) slab;
     w.cap = (uint32_t) ((long long) P.walk_off_at / (long long) sizeof(WtWalkEvent));
@@ -82,11 +96,40 @@ WT_DEV void wt_walk_ctx_init(WtWalkCtx &w, const WtParams &P, char *lds, char *s
     w.ovf = (WtWalkOvf *) (slab + (size_t) P.W * (size_t) P.walk_capp * sizeof(WtWalkEvent));
     w.ov_cap = (uint32_t) (P.walk_ov < WT_WALK_OV_SCAN ? P.walk_ov : WT_WALK_OV_SCAN);
     w.novf = w.guess + 1;
-    w.npad = (P.n_tracks + WT_WALK_PAD - 1) & ~(WT_WALK_PAD - 1);
+    w.pair = P.walk_pair;
+    w.nstr = P.W / P.walk_S;
+    w.npad = ((w.pair ? (P.n_tracks + 1) / 2 : P.n_tracks) + WT_WALK_PAD - 1) & ~(WT_WALK_PAD - 1);
     w.S = P.walk_S;
     w.logS = 0;
     while ((1 << w.logS) < w.S) w.logS++;
 }
+
+// ---- the two lanes of a stretch (pair mode): the partner lane's value ----
+#ifdef WT_EMU
+// (the emulator runs the two lanes of a pair on two threads, one pair at a time: a rendezvous through a mailbox)
+struct WtEmuPairBox {
+    std::atomic<uint32_t> box[2];
+    std::atomic<int> count{0}, sense{0};
+    int local_sense[2] = {0, 0};
+    void barrier(int h) {
+        const int sns = (local_sense[h] ^= 1);
+        if (count.fetch_add(1) == 1) { count.store(0); sense.store(sns); }
+        else while (sense.load() != sns) { }
+    }
+    uint32_t xchg(int h, uint32_t x) {
+        box[h].store(x);
+        barrier(h);
+        const uint32_t r = box[1 - h].load();
+        barrier(h);
+        return r;
+    }
+};
+inline WtEmuPairBox &wt_emu_pairbox() { static WtEmuPairBox b; return b; }
+WT_DEV uint32_t wt_pair_xchg(uint32_t x, int tid) { return wt_emu_pairbox().xchg(tid & 1, x); }
+#else
+// quad_perm [1, 0, 3, 2]: lanes 2q and 2q + 1 swap (both are active wherever this is called: a pair never diverges)
+WT_DEV uint32_t wt_pair_xchg(uint32_t x, int tid) { return (uint32_t) __builtin_amdgcn_mov_dpp((int) x, 0xB1, 0xf, 0xf, false); }
+#endif
 
 // order-preserving key of the float with bits `vb`; every NaN gets the same one, above +Inf
 WT_DEV uint32_t wt_walk_key(uint32_t vb) {
@@ -102,10 +145,12 @@ WT_DEV void wt_walk_defaults(const WtParams &P, WtWalkCtx &w, int tid, int nt) {
 // per window: no events, nothing covered, every column holds the defaults
 WT_DEV void wt_walk_zero(const WtParams &P, const WtCtx &c, WtWalkCtx &w, int tid, int nt) {
     for (int x = tid; x < P.W; x += nt) w.cnt[x] = 0;
-    w.ncov[tid] = 0;
-    const int N = P.n_tracks;
-    for (int i = 0; i < N; i++) w.col[i * nt + tid] = w.dkey[i];
-    for (int i = N; i < w.npad; i++) w.col[i * nt + tid] = 0xffffffffu;       // (above every key, never NaN's)
+    if (tid < w.nstr) w.ncov[tid] = 0;
+    const int N = P.n_tracks, h = w.pair ? tid & 1 : 0;
+    for (int r = 0; r < w.npad; r++) {
+        const int i = w.pair ? 2 * r + h : r;               // the track of row r of this lane's column
+        w.col[r * nt + tid] = i < N ? w.dkey[i] : 0xffffffffu;      // (rows past the tracks: above every key, never NaN's)
+    }
     if (tid == 0) w.novf[0] = 0;
     if (tid < N) {          // the segment of track `tid` on this window's chromosome
         const long long seg = (long long) c.sh->chrom * N + tid;
@@ -185,14 +230,30 @@ WT_DEV uint32_t wt_lds_add_rtn(uint32_t *p, uint32_t v) { const uint32_t o = *p;
 WT_DEV uint32_t wt_lds_add_rtn(uint32_t *p, uint32_t v) { return atomicAdd((unsigned int *) p, v); }
 #endif
 
+// the fields of a counter word (as the first pass leaves it)
+WT_DEV uint32_t wt_walk_cnt_n(const WtWalkCtx &w, uint32_t v) { return w.pair ? (v & WT_WALK_PNMASK) + ((v >> 7) & WT_WALK_PNMASK) : (v & WT_WALK_NMASK); }
+WT_DEV int wt_walk_cnt_dcov(const WtWalkCtx &w, uint32_t v) {
+    return w.pair ? (int) ((v >> 14) & 0xffu) - (int) ((v >> 22) & 0xffu) : (int) ((v >> 12) & 0x3ffu) - (int) (v >> 22);
+}
+
 // an event of position cs: counted, and placed in one of the position's fixed slots -- or, beyond them, in the overflow list
 WT_DEV void wt_walk_place(WtWalkCtx &w, int32_t cs, uint32_t key, uint32_t meta) {
     // (the coverage changes ride in the same word: the window's run count is known before any event is applied)
-    const uint32_t slot = wt_lds_add_rtn(&w.cnt[cs], 1u + ((meta & WT_WALK_INC) ? WT_WALK_CINC : 0u) + ((meta & WT_WALK_DEC) ? WT_WALK_CDEC : 0u)) & WT_WALK_NMASK;
-    if (slot < (uint32_t) w.capp) {
+    uint32_t slot, cap, at;
+    if (w.pair) {
+        const uint32_t half = meta & 1u;        // (the track's parity: the lane of the pair that holds it)
+        slot = (wt_lds_add_rtn(&w.cnt[cs], (1u << (7u * half)) + ((meta & WT_WALK_INC) ? WT_WALK_PCINC : 0u) + ((meta & WT_WALK_DEC) ? WT_WALK_PCDEC : 0u)) >> (7u * half)) & WT_WALK_PNMASK;
+        cap = (uint32_t) w.capp >> 1;
+        at = (((uint32_t) cs << 1) | half) * cap;
+    } else {
+        slot = wt_lds_add_rtn(&w.cnt[cs], 1u + ((meta & WT_WALK_INC) ? WT_WALK_CINC : 0u) + ((meta & WT_WALK_DEC) ? WT_WALK_CDEC : 0u)) & WT_WALK_NMASK;
+        cap = (uint32_t) w.capp;
+        at = (uint32_t) cs * cap;
+    }
+    if (slot < cap) {
         WtWalkEvent e;
         e.key = key; e.meta = meta;
-        w.slab[(uint32_t) cs * (uint32_t) w.capp + slot] = e;
+        w.slab[at + slot] = e;
     } else {
         const uint32_t j = wt_lds_add_rtn(w.novf, 1u);
         if (j < w.ov_cap) {
@@ -218,9 +279,10 @@ WT_DEV void wt_walk_count1(const WtParams &P, WtWalkCtx &w, int nt, int32_t w0, 
     // the lanes whose first position a lies in (s, f]: the run covers the position before a
     int l = cs < 0 ? 0 : (cs >> w.logS) + 1;       // (no division: 30 instructions each on this machine)
     int lh = cf >> w.logS;
-    if (lh > nt - 1) lh = nt - 1;
+    if (lh > w.nstr - 1) lh = w.nstr - 1;
+    const int row = (trk >> w.pair) * nt, half = trk & w.pair;
     for (; l <= lh; l++) {
-        w.col[trk * nt + l] = key;
+        w.col[row + ((l << w.pair) | half)] = key;
         wt_lds_addi32(&w.ncov[l], 1);
     }
 }
@@ -329,33 +391,36 @@ WT_DEV void wt_walk_scan_b(WtWalkCtx &w, int tid, int nt) {
 #endif
 
 // offsets, step 1: the lane's S positions
+// (pair mode: the even lane of a pair speaks for the stretch; base[q << pair] is stretch q's prefix)
 WT_DEV void wt_walk_offsets1(const WtParams &P, WtWalkCtx &w, int tid, int nt) {
-    const int S = w.S, a = tid * S;
+    const int S = w.S, a = (tid >> w.pair) * S;
     uint32_t sum = 0;
-    int fe = -1;
-    for (int s = 0; s < S; s++) {
-        const uint32_t n = w.cnt[a + s] & WT_WALK_NMASK;
-        if (n && fe < 0) fe = a + s;
-        sum += n;
-    }
-    w.fe[tid] = fe;
+    if (!(w.pair && (tid & 1)))
+        for (int s = 0; s < S; s++) {
+            const uint32_t v = w.cnt[a + s], n = wt_walk_cnt_n(w, v);
+            // (pair mode: from here on the word holds the position's events as ONE count, like without pairs)
+            if (w.pair) w.cnt[a + s] = n | ((v >> 14) & 0xffu) << 12 | ((v >> 22) & 0xffu) << 22;
+            sum += n;
+        }
     wt_walk_scan_a(w, sum, tid, nt);
 }
 // step 2 (after wt_walk_scan_b and a barrier): off[]
 WT_DEV void wt_walk_offsets2(const WtParams &P, WtWalkCtx &w, int tid, int nt) {
-    const int S = w.S, a = tid * S;
+    if (w.pair && (tid & 1)) return;
+    const int S = w.S, q = tid >> w.pair, a = q * S;
     uint32_t o = w.base[tid];
     for (int s = 0; s < S; s++) { w.off[a + s] = o; o += w.cnt[a + s] & WT_WALK_NMASK; }
-    if (tid == nt - 1) w.off[P.W] = o;
+    if (q == w.nstr - 1) w.off[P.W] = o;
 }
 
 // The lanes [l0, l1) whose events one slab holds: l1 = the first lane at which they would not fit any more (every lane
 // computes the same; a lane's own events always fit: cap >= 2 N S, wt_make_walk_plan).
+// (l0, l1: stretches)
 WT_DEV int wt_walk_round_end(const WtWalkCtx &w, int l0, int nt) {
-    const uint32_t b0 = w.base[l0];
-    if (w.base[nt] - b0 <= w.cap) return nt;
+    const uint32_t b0 = w.base[l0 << w.pair];
+    if (w.base[nt] - b0 <= w.cap) return w.nstr;
     int l1 = l0 + 1;
-    while (l1 < nt && w.base[l1 + 1] - b0 <= w.cap) l1++;
+    while (l1 < w.nstr && w.base[(l1 + 1) << w.pair] - b0 <= w.cap) l1++;
     return l1;
 }
 
@@ -415,17 +480,25 @@ WT_DEV void wt_walk_sort_block(uint32_t (&b)[WD]) {
     }
 }
 
+// total over the lanes of a stretch (pair mode: this lane's and its partner's)
+template <bool PAIR>
+WT_DEV int wt_walk_tot(int x, int tid) { return PAIR ? x + (int) wt_pair_xchg((uint32_t) x, tid) : x; }
+
 // One sweep: the WD smallest of the (flipped) keys above mf, ascending, ties kept (0xffffffff: none -- no key is 0 or ~0:
-// wt_walk_key), then the move.  True: m, lt, le are final.
+// wt_walk_key), then the move.  True: m and the counts are final.
 // The column is taken WD keys at a time: the block is sorted by a network and merged with the running WD smallest
 // (element-wise minimum against the reversed block leaves the WD smallest of both as a bitonic sequence, log2 WD
 // exchange stages sort it) -- 12 instructions per key at WD = 8 where inserting key by key takes 20.
-template <int WD>
-WT_DEV bool wt_walk_move(const WtWalkCtx &w, int N, int nt, int tid, int k, uint32_t &m, int &lt, int &le) {
-    const bool up = k >= le;
+// lt / le: THIS LANE's counts (#{own keys < m}, #{own keys <= m}); LT / LE: the stretch's (pair mode: both lanes').
+// Pair mode: each lane sweeps its half of the column, the two lists are exchanged and merged (both lanes hold the same
+// WD candidates then), and every decision below is taken on the merged list and the totals -- the two lanes never diverge
+// around an exchange.
+template <int WD, bool PAIR>
+WT_DEV bool wt_walk_move(const WtWalkCtx &w, int nt, int tid, int k, uint32_t &m, int &lt, int &le, int LT, int LE) {
+    const bool up = k >= LE;
     const uint32_t flip = up ? 0u : 0xffffffffu;    // moving down is moving up among the complemented keys
     const uint32_t mf = m ^ flip;
-    const int j = up ? k - le : lt - 1 - k;         // wanted: the j-th smallest of the (flipped) keys above mf
+    const int j = up ? k - LE : LT - 1 - k;         // wanted: the j-th smallest of the (flipped) keys above mf
     uint32_t a[WD];
 #pragma unroll
     for (int q = 0; q < WD; q++) a[q] = 0xffffffffu;
@@ -457,39 +530,65 @@ WT_DEV bool wt_walk_move(const WtWalkCtx &w, int N, int nt, int tid, int k, uint
 #pragma unroll
         for (int u = 0; u < WD; u++) cur[u] = nxt[u];
     }
+    uint32_t g[WD];                                 // the stretch's WD candidates
+    if (PAIR) {
+        uint32_t o[WD];
+#pragma unroll
+        for (int u = 0; u < WD; u++) o[u] = wt_pair_xchg(a[u], tid);
+#pragma unroll
+        for (int u = 0; u < WD; u++) g[u] = a[u] < o[WD - 1 - u] ? a[u] : o[WD - 1 - u];
+#pragma unroll
+        for (int d = WD / 2; d >= 1; d >>= 1) {
+#pragma unroll
+            for (int u = 0; u < WD; u++)
+                if ((u & d) == 0) WT_WALK_CE(g[u], g[u + d]);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < WD; u++) g[u] = a[u];
+    }
     if (j >= WD) {                      // further away than the sweep reaches: go on from its far end
-        m = a[WD - 1] ^ flip;
-        wt_walk_recount(w, N, nt, tid, m, lt, le);
+        m = g[WD - 1] ^ flip;
+        wt_walk_recount(w, 0, nt, tid, m, lt, le);
         return false;
     }
-    uint32_t aj = a[0];
+    uint32_t gj = g[0];
 #pragma unroll
-    for (int q = 1; q < WD; q++) aj = q == j ? a[q] : aj;
-    int first = WD - 1, last = 0;
+    for (int q = 1; q < WD; q++) gj = q == j ? g[q] : gj;
+    int last = 0;
 #pragma unroll
-    for (int q = WD - 1; q >= 0; q--) first = a[q] == aj ? q : first;
-#pragma unroll
-    for (int q = 0; q < WD; q++) last = a[q] == aj ? q : last;
-    m = aj ^ flip;
+    for (int q = 0; q < WD; q++) last = g[q] == gj ? q : last;
+    m = gj ^ flip;
     if (last == WD - 1) {               // more keys equal to it may lie beyond the ones collected
-        wt_walk_recount(w, N, nt, tid, m, lt, le);
+        wt_walk_recount(w, 0, nt, tid, m, lt, le);
         return false;
     }
-    if (up) { lt = le + first; le = le + last + 1; }
-    else { const int l0 = lt; le = l0 - first; lt = l0 - last - 1; }
+    // this lane's counts for the new m, from its own list: c1 keys between the old and the new m, c2 equal to the new one --
+    // unless the list is full and ends at or before the new m (more of the lane's keys may lie there: recount)
+    if (a[WD - 1] != 0xffffffffu && a[WD - 1] <= gj) {
+        wt_walk_recount(w, 0, nt, tid, m, lt, le);
+        return true;
+    }
+    int c1 = 0, c2 = 0;
+#pragma unroll
+    for (int q = 0; q < WD; q++) { c1 += a[q] < gj ? 1 : 0; c2 += a[q] == gj ? 1 : 0; }
+    if (up) { const int l0 = le; lt = l0 + c1; le = l0 + c1 + c2; }
+    else { const int l0 = lt; le = l0 - c1; lt = l0 - c1 - c2; }
     return true;
 }
 
-// Moves m to the key of rank k (0-based, ties as a multiset) given lt / le for the current m.  The sweep's width follows
-// the furthest move any lane of the wave has to make (2, 4 or 8 keys).
-WT_DEV void wt_walk_select(const WtWalkCtx &w, int N, int nt, int tid, int k, uint32_t &m, int &lt, int &le) {
+// Moves m to the key of rank k (0-based, ties as a multiset) of the stretch's column, given this lane's counts lt / le for the
+// current m.  The sweep's width follows the furthest move any lane of the wave has to make (2, 4 or 8 keys).
+template <bool PAIR>
+WT_DEV void wt_walk_select(const WtWalkCtx &w, int nt, int tid, int k, uint32_t &m, int &lt, int &le) {
     for (;;) {
-        if (lt <= k && k < le) return;
-        const int j = k >= le ? k - le : lt - 1 - k;
+        const int LT = wt_walk_tot<PAIR>(lt, tid), LE = wt_walk_tot<PAIR>(le, tid);
+        if (LT <= k && k < LE) return;
+        const int j = k >= LE ? k - LE : LT - 1 - k;
         bool done;
-        if (wt_walk_any(j > 3)) done = wt_walk_move<8>(w, N, nt, tid, k, m, lt, le);
-        else if (wt_walk_any(j > 1)) done = wt_walk_move<4>(w, N, nt, tid, k, m, lt, le);
-        else done = wt_walk_move<2>(w, N, nt, tid, k, m, lt, le);
+        if (wt_walk_any(j > 3)) done = wt_walk_move<8, PAIR>(w, nt, tid, k, m, lt, le, LT, LE);
+        else if (wt_walk_any(j > 1)) done = wt_walk_move<4, PAIR>(w, nt, tid, k, m, lt, le, LT, LE);
+        else done = wt_walk_move<2, PAIR>(w, nt, tid, k, m, lt, le, LT, LE);
         if (done) return;
     }
 }
@@ -504,21 +603,25 @@ struct WtWalkLane {
 // coverage changes per position), before any event is applied: the window's run count goes to the look-back chain ahead of
 // the walk, so that no successor ever waits for it.
 WT_DEV void wt_walk_emits(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalkLane &L, int tid, int nt) {
-    const int N = P.n_tracks, S = w.S, a = tid * S;
+    const int N = P.n_tracks, S = w.S, q = tid >> w.pair, a = q * S;         // (pair mode: both lanes of the stretch compute the same)
     const bool strict = (P.flags & WT_STRICT_SET0) != 0;
     const int32_t room = c.sh->emit_hi - (c.sh->w0 + a);       // positions of the stretch below the range end
     uint32_t evmask = 0, emitmask = 0;
-    int ncov = w.ncov[tid], fe = -1;
+    int ncov = w.ncov[q], fe = -1;
     for (int s = 0; s < S; s++) {
         const uint32_t v = w.cnt[a + s];
-        if (!(v & WT_WALK_NMASK)) continue;
+        if (!wt_walk_cnt_n(w, v)) continue;
         if (fe < 0) fe = a + s;
         evmask |= 1u << s;
-        ncov += (int) ((v >> 12) & 0x3ffu) - (int) (v >> 22);
+        ncov += wt_walk_cnt_dcov(w, v);
         if ((strict ? ncov == N : ncov > 0) && s < room) emitmask |= 1u << s;      // multiplexer.c:120,125
     }
-    w.fe[tid] = fe;
+    w.fe[q] = fe;
     L.evmask = evmask; L.emitmask = emitmask;
+}
+// what the lane adds to the scan of the run counts (pair mode: the even lane speaks for the stretch)
+WT_DEV uint32_t wt_walk_emit_count(const WtWalkCtx &w, const WtWalkLane &L, int tid) {
+    return (w.pair && (tid & 1)) ? 0u : (uint32_t) wt_popc32(L.emitmask);
 }
 
 #if defined(WT_PROFILE) && !defined(WT_EMU)
@@ -533,10 +636,11 @@ WT_DEV void wt_walk_emits(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWal
 // vector cache -- plain loads.)
 //   FIXED   the events of position p are cnt[p] of the slots slab[p * capp ..] (+ the overflow list beyond capp)
 //   !FIXED  (fallback) the sorted sequence: the events of p are slab[off[p] - ev0 .. off[p + 1] - ev0)
-template <bool FIXED>
+template <bool FIXED, bool PAIR>
 WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalkLane &L, uint32_t ev0, int tid, int nt,
                          unsigned long long *prof = nullptr) {
-    const int N = P.n_tracks, S = w.S, a = tid * S, k = N / 2;
+    const int N = P.n_tracks, S = w.S, a = (PAIR ? tid >> 1 : tid) * S, k = N / 2;
+    const uint32_t half = PAIR ? (uint32_t) (tid & 1) : 0u;       // this lane's tracks: i = half (mod 2), row i >> 1
     const uint32_t emitmask = L.emitmask;       // (wt_walk_emits)
     uint32_t m = 0;
     int lt = 0, le = 0, nn = 0;
@@ -549,15 +653,18 @@ WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalk
         // their tracks' old keys first (no track has two events at one position), then the updates
         uint32_t ok[WT_WALK_EB];
         uint32_t trk[WT_WALK_EB];
+        bool mine[WT_WALK_EB];
 #pragma unroll
         for (int u = 0; u < WT_WALK_EB; u++) {
-            const uint32_t t = ev[u].meta & 0xffffu;
-            trk[u] = t < (uint32_t) N ? t : 0u;         // (a slot beyond the position's count holds anything)
+            uint32_t t = ev[u].meta & 0xffffu;
+            t = t < (uint32_t) N ? t : 0u;              // (a slot beyond the position's count holds anything)
+            mine[u] = (uint32_t) u < nvalid && (!PAIR || (t & 1u) == half);
+            trk[u] = PAIR ? t >> 1 : t;                 // its row in this lane's column (the partner's events: read, not applied)
             ok[u] = col[trk[u] * (uint32_t) nt];
         }
 #pragma unroll
         for (int u = 0; u < WT_WALK_EB; u++) {
-            if ((uint32_t) u >= nvalid) continue;
+            if (!mine[u]) continue;
             const uint32_t nk = ev[u].key;
             col[trk[u] * (uint32_t) nt] = nk;
             if (have) {
@@ -581,19 +688,26 @@ WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalk
     uint32_t pre_at = 0xffffffffu;              // slab index pre[] was fetched from
     uint32_t o = FIXED ? 0u : w.off[a];
     const uint32_t o_end = FIXED ? 0u : w.off[a + S];
-    if (FIXED) { fetch((uint32_t) a * (uint32_t) w.capp, 1u, pre); pre_at = (uint32_t) a * (uint32_t) w.capp; }
+    // FIXED: this lane's slots of a position (pair mode: its half of them -- the events of its own tracks)
+    const uint32_t lcap = FIXED ? (PAIR ? (uint32_t) w.capp >> 1 : (uint32_t) w.capp) : 0u;
+    auto slots_of = [&](int pos) { return PAIR ? ((((uint32_t) pos) << 1) | half) * lcap : (uint32_t) pos * lcap; };
+    if (FIXED) { pre_at = slots_of(a); fetch(pre_at, 1u, pre); }
     else if (o_end != o) { fetch(o - ev0, o_end - o, pre); pre_at = o - ev0; }
     for (int s = 0; s < S; s++) {
-        uint32_t n, from;
-        if (FIXED) { n = w.cnt[a + s] & WT_WALK_NMASK; from = (uint32_t) (a + s) * (uint32_t) w.capp; }
-        else { const uint32_t o1 = w.off[a + s + 1]; n = o1 - o; from = o - ev0; o = o1; }
-        if (!n) continue;
+        uint32_t n, from, ntot;
+        if (FIXED) {
+            const uint32_t v = w.cnt[a + s];
+            ntot = wt_walk_cnt_n(w, v);
+            n = PAIR ? (v >> (7u * half)) & WT_WALK_PNMASK : ntot;          // (the lane's own events)
+            from = slots_of(a + s);
+        } else { const uint32_t o1 = w.off[a + s + 1]; n = o1 - o; ntot = n; from = o - ev0; o = o1; }
+        if (!ntot) continue;
         WT_WALK_T0;
         if (!started) {
             started = true;
             wt_walk_for_keys(w, nt, tid, [&](uint32_t x) { nn += x == WT_WALK_NANKEY ? 1 : 0; });
         }
-        const uint32_t nslot = FIXED ? (n < (uint32_t) w.capp ? n : (uint32_t) w.capp) : n;
+        const uint32_t nslot = FIXED ? (n < lcap ? n : lcap) : n;
         for (uint32_t e = 0; e < nslot; e += WT_WALK_EB) {
             WtWalkEvent ev[WT_WALK_EB];
             const uint32_t left = nslot - e;
@@ -608,7 +722,7 @@ WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalk
         if (FIXED && n > nslot) {               // the position's events beyond its slots: somewhere in the overflow list
             for (uint32_t j = 0; j < novf; j++) {
                 const WtWalkOvf q = w.ovf[j];
-                if (q.pos != (uint32_t) (a + s)) continue;
+                if (q.pos != (uint32_t) (a + s) || (PAIR && (q.meta & 1u) != half)) continue;
                 WtWalkEvent ev[WT_WALK_EB];
 #pragma unroll
                 for (int u = 0; u < WT_WALK_EB; u++) { ev[u].key = q.key; ev[u].meta = q.meta; }
@@ -616,7 +730,7 @@ WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalk
             }
         }
         if (FIXED) {
-            if (s + 1 < S) { pre_at = from + (uint32_t) w.capp; fetch(pre_at, 1u, pre); }
+            if (s + 1 < S) { pre_at = slots_of(a + s + 1); fetch(pre_at, 1u, pre); }
         } else if (o < o_end) {
             pre_at = o - ev0;
             fetch(pre_at, o_end - o, pre);
@@ -624,47 +738,52 @@ WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalk
         WT_WALK_TICK(4);
         if (!((emitmask >> s) & 1u)) continue;
         if (!have) {
-            m = w.guess[0];
+            const uint32_t g0 = w.guess[0], g1 = PAIR ? wt_pair_xchg(g0, tid) : g0;
+            m = half ? g1 : g0;                         // (both lanes of a pair start from the even lane's reading)
             wt_walk_recount(w, N, nt, tid, m, lt, le);
             have = true;
-            wt_walk_select(w, N, nt, tid, k, m, lt, le);
+            wt_walk_select<PAIR>(w, nt, tid, k, m, lt, le);
             WT_WALK_TICK(5);
         } else {
-            wt_walk_select(w, N, nt, tid, k, m, lt, le);
+            wt_walk_select<PAIR>(w, nt, tid, k, m, lt, le);
             WT_WALK_TICK(6);
         }
-        w.cnt[a + s] = nn ? WT_WALK_NANKEY : m;         // (the position's count is not needed any more: the result lives there)
+        // (the position's count is not needed any more: the result lives there; pair mode: both lanes store the same)
+        w.cnt[a + s] = wt_walk_tot<PAIR>(nn, tid) ? WT_WALK_NANKEY : m;
     }
     if (have) w.guess[0] = m;       // (any lane's: the next stretch's first selection starts there)
 }
 
-// first breakpoint after the lane's stretch
-WT_DEV int32_t wt_walk_next_after(const WtCtx &c, const WtWalkCtx &w, int tid, int nt) {
-    for (int l = tid + 1; l < nt; l++)
+// first breakpoint after stretch q
+WT_DEV int32_t wt_walk_next_after(const WtCtx &c, const WtWalkCtx &w, int q) {
+    for (int l = q + 1; l < w.nstr; l++)
         if (w.fe[l] >= 0) return c.sh->w0 + w.fe[l];
     return c.sh->next_bp;
 }
 
-// the lane's runs, at their global positions (base[]: exclusive prefix of the lanes' run counts)
+// the stretch's runs, at their global positions (base[]: exclusive prefix of the run counts; pair mode: the two lanes take
+// every other run)
 WT_DEV void wt_walk_write(const WtParams &P, WtCtx &c, const WtWalkCtx &w, const WtWalkLane &L, int tid, int nt) {
     if (!L.emitmask) return;
-    const int S = w.S, a = tid * S;
+    const int S = w.S, q = tid >> w.pair, a = q * S, half = w.pair ? tid & 1 : 0;
     const int32_t w0 = c.sh->w0;
-    long long idx = c.sh->goffset + (long long) w.base[tid];
+    long long idx = c.sh->goffset + (long long) w.base[q << w.pair];
     int32_t after = 0;
     bool have_after = false;
     unsigned long long bp = 0;
+    int rank = 0;
     for (int s = 0; s < S; s++) {
         if (!((L.emitmask >> s) & 1u)) continue;
+        const long long o = idx++;
+        if (w.pair && (rank++ & 1) != half) continue;
         const uint32_t later = s + 1 < 32 ? (L.evmask >> (s + 1)) : 0u;
         int32_t fin;
         if (later) {
             fin = w0 + a + s + 1 + (int32_t) wt_ctz64((uint64_t) later);
         } else {
-            if (!have_after) { after = wt_walk_next_after(c, w, tid, nt); have_after = true; }
+            if (!have_after) { after = wt_walk_next_after(c, w, q); have_after = true; }
             fin = after;
         }
-        const long long o = idx++;
         bp += (unsigned long long) (fin - (w0 + a + s));
         if (o >= P.capacity) continue;
         const uint32_t key = w.cnt[a + s];

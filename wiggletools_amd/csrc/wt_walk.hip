@@ -17,7 +17,8 @@
 // MedianReduction by walking (wt_walk.h): a lane carries its column of current values from one position to the next.
 // T lanes (128: two workgroups per CU at 100 tracks) x S positions each; persistent workgroups, window tickets, ordered
 // output through the look-back chain like the other kernels.
-__global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
+template <int MAXT, bool PAIR>
+__global__ void __launch_bounds__(MAXT, 1) wt_walk_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c{};
     c.sh = (WtShared *) (wt_lds + P.off_shared);
@@ -25,6 +26,7 @@ __global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
     wt_delta_ctx_init(d, P, wt_lds);
     WtWalkCtx w;
     wt_walk_ctx_init(w, P, wt_lds, P.g_scratch + (size_t) blockIdx.x * (size_t) P.g_scratch_slab);
+    w.pair = PAIR ? 1 : 0;                      // (== P.walk_pair: a constant of this instantiation from here on)
     const int tid = threadIdx.x, nt = blockDim.x;
     long long k_dbg = -1;
     (void) k_dbg;
@@ -59,7 +61,7 @@ __global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
         WtWalkLane L;
         // positions with events / emitted runs per lane, the window's run count: published before the walk
         wt_walk_emits(P, c, w, L, tid, nt);
-        wt_walk_scan_a(w, (uint32_t) wt_popc32(L.emitmask), tid, nt);
+        wt_walk_scan_a(w, wt_walk_emit_count(w, L, tid), tid, nt);
         __syncthreads();
         wt_walk_scan_b(w, tid, nt);
         __syncthreads();
@@ -67,10 +69,10 @@ __global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
         if (tid == 0) wt_lookback_publish(P, c, k, mine);
         if (w.novf[0] <= w.ov_cap) {            // (uniform) every position's events fit its slots + the overflow list
 #ifdef WT_PROFILE
-            wt_walk_lane<true>(P, c, w, L, 0u, tid, nt, tid == 0 ? prof : nullptr);
+            wt_walk_lane<true, PAIR>(P, c, w, L, 0u, tid, nt, tid == 0 ? prof : nullptr);
             if (tid == 0) t_last = __builtin_readcyclecounter();
 #else
-            wt_walk_lane<true>(P, c, w, L, 0u, tid, nt);
+            wt_walk_lane<true, PAIR>(P, c, w, L, 0u, tid, nt);
 #endif
             __syncthreads();
             WT_TICK(7);
@@ -86,21 +88,21 @@ __global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
             __syncthreads();
             WT_TICK(2);
             WT_MARK(203);
-            for (int l0 = 0; l0 < nt;) {
+            for (int l0 = 0; l0 < w.nstr;) {        // (stretches)
                 const int l1 = wt_walk_round_end(w, l0, nt);
-                const uint32_t ev0 = w.base[l0], ev1 = w.base[l1];
+                const uint32_t ev0 = w.base[l0 << w.pair], ev1 = w.base[l1 << w.pair];
                 if (ev1 > ev0) {                    // (uniform)
                     wt_walk_pass<true>(P, c, w, d, ev0, ev1, tid, nt);
                     __syncthreads();
                     WT_TICK(3);
-                    if (tid >= l0 && tid < l1) wt_walk_lane<false>(P, c, w, L, ev0, tid, nt);
+                    if ((tid >> w.pair) >= l0 && (tid >> w.pair) < l1) wt_walk_lane<false, PAIR>(P, c, w, L, ev0, tid, nt);
                     __syncthreads();                // before the next round reuses the slab
                     WT_TICK(7);
                 }
                 l0 = l1;
             }
             // the lanes' run offsets again (base[] held the event offsets meanwhile)
-            wt_walk_scan_a(w, (uint32_t) wt_popc32(L.emitmask), tid, nt);
+            wt_walk_scan_a(w, wt_walk_emit_count(w, L, tid), tid, nt);
             __syncthreads();
             wt_walk_scan_b(w, tid, nt);
             __syncthreads();
@@ -136,7 +138,7 @@ __global__ void __launch_bounds__(256, 1) wt_walk_kernel(const WtParams P) {
 // (nr: the register-column slots the bitmap kernel would use for this track count -- eligibility only)
 hipError_t wt_walk_launch(WtParams &P, int nr, int T, int lds, int num_cu, char **gscratch, size_t *gscratch_bytes, hipStream_t s, int *grid) {
     (void) nr;
-    auto kern = wt_walk_kernel;
+    auto kern = P.walk_pair ? (T > 256 ? wt_walk_kernel<512, true> : wt_walk_kernel<256, true>) : wt_walk_kernel<256, false>;
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024) {
         e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
