@@ -120,7 +120,7 @@ struct WtParams {
     int32_t delta_df;                   // != 0: some default is non-zero (Sum / Mean): absent tracks add their defaults
     int32_t def_emin, def_emax;         // exponent range of the non-zero defaults (255 / 0: none)
     int32_t off_dflt32;           // register-column median / MWU: float copy of defaults[] in LDS (filled once per workgroup)
-    int32_t off_wcol, off_wcnt, off_woff, off_wtot, off_wbase, off_wgt, off_wncov, off_wfe, off_wdk, off_wseg, off_wguess;   // median by walking (wt_walk.h)
+    int32_t off_wcol, off_wcnt, off_woff, off_wtot, off_wbase, off_wgt, off_wncov, off_wfe, off_wdk, off_wguess;   // median by walking (wt_walk.h)
     int32_t walk_S;               // ... positions per lane (0: not a walking launch)
     int32_t walk_capp;            // ... fixed event slots per position
     int32_t walk_ov;              // ... entries of the overflow list behind them

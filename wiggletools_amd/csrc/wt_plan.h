@@ -36,7 +36,7 @@ struct WtPlan {
     int walk_ov = 0;        // ... entries of the overflow list
     int walk_off_at = 0;    // ... where the fallback's offsets start in the workgroup's slab (bytes)
     int walk_pair = 0;      // ... 1: two lanes per stretch (half the column each)
-    int off_wcol = 0, off_wcnt = 0, off_woff = 0, off_wtot = 0, off_wbase = 0, off_wgt = 0, off_wncov = 0, off_wfe = 0, off_wdk = 0, off_wseg = 0, off_wguess = 0;
+    int off_wcol = 0, off_wcnt = 0, off_woff = 0, off_wtot = 0, off_wbase = 0, off_wgt = 0, off_wncov = 0, off_wfe = 0, off_wdk = 0, off_wguess = 0;
 };
 
 static inline int wt_align16(int x) { return (x + 15) & ~15; }
@@ -213,7 +213,6 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double eve
         q.off_wncov = o;  o = wt_align16(o + T * 4);
         q.off_wfe = o;    o = wt_align16(o + T * 4);
         q.off_wdk = o;    o = wt_align16(o + n_tracks * 4);
-        q.off_wseg = o;   o = wt_align16(o + 2 * n_tracks * 8);
         q.off_wguess = o; o = wt_align16(o + 8);       // (+ the overflow counter)
         q.off_tbase = o;  o = wt_align16(o + T * 8);
         q.off_ltc = o;    o = wt_align16(o + T * 4);
@@ -376,7 +375,7 @@ static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.off_qa = p.off_qa; P.off_ltq = p.off_ltq; P.off_gtq = p.off_gtq; P.delta_q = p.delta_q;
     P.off_wcol = p.off_wcol; P.off_wcnt = p.off_wcnt; P.off_woff = p.off_woff; P.off_wtot = p.off_wtot; P.off_wbase = p.off_wbase;
     P.off_wgt = p.off_wgt; P.off_wncov = p.off_wncov; P.off_wfe = p.off_wfe; P.off_wdk = p.off_wdk; P.walk_S = p.walk_S;
-    P.off_wseg = p.off_wseg; P.off_wguess = p.off_wguess; P.walk_capp = p.walk_capp; P.walk_ov = p.walk_ov; P.walk_off_at = p.walk_off_at; P.walk_pair = p.walk_pair;
+    P.off_wguess = p.off_wguess; P.walk_capp = p.walk_capp; P.walk_ov = p.walk_ov; P.walk_off_at = p.walk_off_at; P.walk_pair = p.walk_pair;
     P.off_shared = p.off_shared; P.lds_bytes = p.lds_bytes;
 }
 

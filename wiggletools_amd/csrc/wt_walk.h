@@ -61,7 +61,6 @@ struct WtWalkCtx {
     int32_t *ncov;      // [T] tracks covering the position before the lane's first one
     int32_t *fe;        // [T] first position (window-relative) of the lane's stretch that has an event, or -1
     uint32_t *dkey;     // [N] keys of the defaults
-    long long *seg0, *seg1;     // [T] byte offsets (4-byte columns) of the first run of the track's segment / one past its last
     uint32_t *guess;    // [1] a recent median of this workgroup (where a stretch's first selection starts)
     WtWalkEvent *slab;  // this workgroup's events (global): capp slots per position, or (fallback) the sorted sequence
     WtWalkOvf *ovf;     // ... behind the fixed slots: the events beyond a position's slots
@@ -86,8 +85,6 @@ WT_DEV void wt_walk_ctx_init(WtWalkCtx &w, const WtParams &P, char *lds, char *s
     w.ncov = (int32_t *) (lds + P.off_wncov);
     w.fe = (int32_t *) (lds + P.off_wfe);
     w.dkey = (uint32_t *) (lds + P.off_wdk);
-    w.seg0 = (long long *) (lds + P.off_wseg);
-    w.seg1 = w.seg0 + P.n_tracks;
     w.guess = (uint32_t *) (lds + P.off_wguess);
     w.slab = (WtWalkEvent *) slab;
     w.cap = (uint32_t) ((long long) P.walk_off_at / (long long) sizeof(WtWalkEvent));
@@ -152,11 +149,6 @@ WT_DEV void wt_walk_zero(const WtParams &P, const WtCtx &c, WtWalkCtx &w, int ti
         w.col[r * nt + tid] = i < N ? w.dkey[i] : 0xffffffffu;      // (rows past the tracks: above every key, never NaN's)
     }
     if (tid == 0) w.novf[0] = 0;
-    if (tid < N) {          // the segment of track `tid` on this window's chromosome
-        const long long seg = (long long) c.sh->chrom * N + tid;
-        w.seg0[tid] = P.seg_off[seg] * 4;
-        w.seg1[tid] = P.seg_off[seg + 1] * 4;
-    }
 }
 
 // ---- the window's runs as the flat index space of wt_delta.h (wt_delta_ranges1 + the scans below: the same as
@@ -191,7 +183,7 @@ struct WtWalkBatch {
     int32_t ps[WT_DELTA_U], ns[WT_DELTA_U];     // finish of the track's previous run, start of its next one (of the FILE, not the window)
     uint32_t b[WT_DELTA_U];
     int trk[WT_DELTA_U];
-    bool first[WT_DELTA_U], last[WT_DELTA_U];   // the run is the first / last of its (chromosome, track) segment
+    bool first[WT_DELTA_U], last[WT_DELTA_U];   // the run is the track's first / last of the window
 };
 
 // (unconditional, always in range: see wt_delta_fetch)
@@ -200,20 +192,22 @@ WT_DEV void wt_walk_fetch(const WtParams &P, const WtDeltaCtx &d, const WtWalkCt
     const uint32_t tbe = tb < lastt ? tb : lastt;
     const uint32_t tile = tbe / WT_DELTA_TILE;
     int i = tile < WT_WALK_TF ? (int) d.tfirst[tile] : wt_delta_find(d.tpfx, nt, tbe, 0);
-    uint32_t hi = d.tpfx[i + 1];
+    uint32_t lo = d.tpfx[i], hi = d.tpfx[i + 1];
     long long dl = d.tbase[i];
-    long long s0 = w.seg0[i], s1 = w.seg1[i];
 #pragma unroll
     for (int u = 0; u < WT_DELTA_U; u++) {
         uint32_t jj = tbe + (uint32_t) lane + 64u * (uint32_t) u;
         jj = jj < M - 1u ? jj : M - 1u;
         if (jj >= hi) {
-            do { i++; hi = d.tpfx[i + 1]; } while (jj >= hi);
+            do { i++; lo = hi; hi = d.tpfx[i + 1]; } while (jj >= hi);
             dl = d.tbase[i];
-            s0 = w.seg0[i]; s1 = w.seg1[i];
         }
         const long long ob = dl + ((long long) jj << 2);
-        const bool fst = ob <= s0, lst = ob + 4 >= s1;
+        // first / last run of the track IN THIS WINDOW: what the events need to know.  A first run that starts inside the
+        // window follows a run that ended before it (the range starts at the first run with finish >= w0): it covers anew,
+        // like the first run of the file.  A last run that ends inside the window is the file's last (the range ends at
+        // the first run with finish >= w1): nothing starts where it ends.
+        const bool fst = jj == lo, lst = jj + 1u == hi;
         B.s[u] = *(const int32_t *) ((const char *) P.start + ob);
         B.f[u] = *(const int32_t *) ((const char *) P.finish + ob);
         B.b[u] = *(const uint32_t *) ((const char *) P.value + ob);
@@ -658,7 +652,7 @@ WT_DEV void wt_walk_lane(const WtParams &P, const WtCtx &c, WtWalkCtx &w, WtWalk
         for (int u = 0; u < WT_WALK_EB; u++) {
             uint32_t t = ev[u].meta & 0xffffu;
             t = t < (uint32_t) N ? t : 0u;              // (a slot beyond the position's count holds anything)
-            mine[u] = (uint32_t) u < nvalid && (!PAIR || (t & 1u) == half);
+            mine[u] = (uint32_t) u < nvalid && (!PAIR || FIXED || (t & 1u) == half);      // (FIXED: the lane's own slots hold its own tracks' events)
             trk[u] = PAIR ? t >> 1 : t;                 // its row in this lane's column (the partner's events: read, not applied)
             ok[u] = col[trk[u] * (uint32_t) nt];
         }
