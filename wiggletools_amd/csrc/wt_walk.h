@@ -2,26 +2,33 @@
 //
 // The bitmap kernel (wt_reduce_kernel) evaluates every run of the output from scratch: N gathers and a sorting
 // network per position, although between neighbouring runs only the tracks with a breakpoint there change -- ~6 of
-// 100 at the benchmark's density (reducers.c:780-813 itself re-sorts all N values per pop).  Here a lane owns S
-// CONSECUTIVE positions of the window and carries the column of the N current values (order-preserving keys, in
-// LDS, [track][lane]) from one to the next:
+// 100 at the benchmark's density (reducers.c:780-813 itself re-sorts all N values per pop).  Here a STRETCH of S
+// consecutive positions of the window is walked by the same lane -- or, by default, by a PAIR of lanes that hold half the
+// tracks each -- which carries the column of the current values (order-preserving keys, in LDS, [row][lane]) from one
+// position to the next.  Per window (a barrier between the phases):
 //
-//   ranges   the window's runs of every track as one flat index space (wt_delta_ranges*)
-//   count    per run: an EVENT at its start (the track takes the run's value) and one at its finish (the track falls
-//            back to its default) unless the next run of the track starts right there; events are counted per
-//            position (LDS atomics).  A run that covers the first position of a lane's stretch from before it
-//            writes its value into that lane's column: the columns start out right without any look-up.
-//   offsets  prefix sums of the counts: the events of a position are a contiguous slice of the workgroup's slab
-//   scatter  second pass over the runs: every event to its slot (track, new key, coverage change)
-//   walk     per lane, position by position: apply the events (old key out, new key in, the counts of keys below / not
-//            above the current median m kept up to date), and when the wanted rank k = N/2 has left [lt, le) move m: ONE
-//            sweep over the column collects the 2 / 4 / 8 nearest keys on the side m has to move to (ties are handled as
-//            a multiset, so the result is the exact order statistic, bit for bit what a sort gives).  The first median
-//            of a stretch starts from the last one any lane of the workgroup found (same distribution: a few ranks off).
-//   emit     run count scan, look-back, the lanes write their runs
+//   ranges   the window's runs of every track as one flat index space (wt_delta_ranges1, wt_walk_ranges*)
+//   pass     one pass over the runs: an EVENT at a run's start (the track takes the run's value) and one at its finish (the
+//            track falls back to its default) unless the next run of the track starts right there.  An event is counted
+//            in its position's counter word (with the coverage change it brings) and placed in one of the position's
+//            fixed slots of the workgroup's slab (global memory), beyond them in an overflow list.  A run that covers the
+//            first position of a stretch from before it writes its value into that stretch's column: the columns start
+//            out right without any look-up.
+//   emits    from the counter words alone: which positions start an emitted run; the window's run count is scanned and
+//            published to the look-back chain before anything else happens
+//   walk     position by position: apply the events (old key out, new key in, the counts of keys below / not above the
+//            current median m kept up to date), and when the wanted rank k = N/2 has left [lt, le) move m: ONE sweep over
+//            the column collects the 2 / 4 / 8 nearest keys on the side m has to move to (ties are handled as a multiset,
+//            so the result is the exact order statistic, bit for bit what a sort gives).  A stretch's first median
+//            starts from the last one any lane of the workgroup found (same distribution: a few ranks off).
+//            Pair mode: each lane sweeps its half, counts and candidates are exchanged inside the pair (DPP).
+//   write    the look-back completes, the lanes write their runs
+//   (fallback, a window with too many events beyond their slots: offsets from the counts, a second pass sorting the
+//    events by position into the same slab, in rounds of as many stretches as fit; same walk)
 //
 // Eligibility (host): float tracks, float-exact defaults, N <= 128.
 // The output is the bitmap kernel's, bit for bit (same keys, same order statistic, NaN if any value is NaN).
+// DESIGN 4.11 has the measurements.
 #ifndef WT_WALK_H_
 #define WT_WALK_H_
 #ifdef WT_EMU
