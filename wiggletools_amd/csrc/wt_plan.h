@@ -193,9 +193,13 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double eve
     const char *eT = getenv("WTAMD_WALK_T"), *eS = getenv("WTAMD_WALK_S"), *eP = getenv("WTAMD_WALK_PAIR");
     const int pair = eP ? (atoi(eP) != 0 ? 1 : 0) : WT_WALK_PAIR_DEFAULT;
     const int wantT = eT ? atoi(eT) : 256, wantS = eS ? atoi(eS) : (pair ? 16 : 32);
-    struct Cand { int T, S; };
-    for (const Cand cd : {Cand{wantT, wantS}, Cand{wantT, 16}, Cand{256, 16}, Cand{128, 16}, Cand{64, 16}}) {
+    // (pair mode: twice through the candidates -- first only what leaves room for a second workgroup on the CU: two
+    //  workgroups of 4 waves beat one of 8, their phases overlap)
+    struct Cand { int T, S; bool half_cu; };
+    for (const Cand cd : {Cand{wantT, wantS, pair != 0}, Cand{128, 16, pair != 0}, Cand{64, 32, pair != 0},
+                          Cand{wantT, wantS, false}, Cand{wantT, 16, false}, Cand{256, 16, false}, Cand{128, 16, false}, Cand{64, 16, false}}) {
         const int T = cd.T, S = cd.S;
+        if (cd.half_cu && (eT || eS) && (T != wantT || S != wantS)) continue;       // (an explicit request is tried as it is first)
         if (T != 64 && T != 128 && T != 256 && !(pair && T == 512)) continue;
         if (S != 4 && S != 8 && S != 16 && S != 32) continue;
         if (n_tracks > T) continue;
@@ -222,6 +226,7 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double eve
         q.off_shared = o; o = wt_align16(o + (int) sizeof(WtShared));
         q.lds_bytes = o;
         if (q.lds_bytes > hard_limit - 1024) continue;
+        if (cd.half_cu && q.lds_bytes > hard_limit / 2 - 512) continue;
         // slots per position: 2.5 x the expected events (a Poisson tail of 2e-4 per position at 6 events), 8 .. 64
         int capp = 16;
         if (events_per_bp > 0) {
