@@ -32,7 +32,9 @@ def _pick_type(recs, mix):
     return 1
 
 
-def write_bigwig(path, chroms, data, items_per_block=512, compress=True, mix_types=False):
+def write_bigwig(path, chroms, data, items_per_block=512, compress=True, mix_types=False, pad=0):
+    """pad: bytes of padding behind every compressed section that the index leaf's size INCLUDES (zlib readers stop at the
+    end of the stream; a device decoder must find the Adler-32 trailer where the stream ends, not where the leaf ends)."""
     names = sorted(chroms)
     ids = {c: i for i, c in enumerate(names)}
     key = max(len(c) for c in names)
@@ -50,7 +52,7 @@ def write_bigwig(path, chroms, data, items_per_block=512, compress=True, mix_typ
                 if j >= 3:
                     chunk = chunk[:j]
             raw = _section(ids[c], chunk, _pick_type(chunk, mix_types))
-            sections.append((ids[c], chunk[0][0], chunk[-1][1], zlib.compress(raw) if compress else raw, len(raw)))
+            sections.append((ids[c], chunk[0][0], chunk[-1][1], (zlib.compress(raw) + b"\xa5" * pad) if compress else raw, len(raw)))
             k += len(chunk)
     ubuf = max([s[4] for s in sections] + [1]) if compress else 0
     header_size = 64

@@ -350,7 +350,7 @@ int wtamd_pipe_integrate_held(wtamd_pipe *p, double *integ) {
 // One zlib (or raw deflate) stream through the lane state machine; returns bytes produced or -(error).
 }  // extern "C"
 template <int RING>
-static long long emu_inflate_ring(const uint8_t *src, long long n, uint8_t *dst, long long cap, int raw_deflate, long long *steps) {
+static long long emu_inflate_ring(const uint8_t *src, long long n, uint8_t *dst, long long cap, int raw_deflate, long long *steps, uint32_t *end_byte = nullptr) {
     std::vector<uint8_t> perm(WT_INF_PERM + 8, 0);
     std::vector<uint32_t> ring(RING, 0);
     WtInfMem m{perm.data(), ring.data(), 1};
@@ -367,6 +367,7 @@ static long long emu_inflate_ring(const uint8_t *src, long long n, uint8_t *dst,
     }
     if (steps) *steps = rounds * WT_INF_ROUND;
     const long long r = (long long) wt_inf_finish(z);
+    if (end_byte) *end_byte = wt_inf_end_byte(z);
     if (r > 0) memcpy(dst, out.data(), (size_t) r);
     return r;
 }
@@ -395,13 +396,17 @@ unsigned wtemu_bw_decode(const uint8_t *bytes, const wtamd_bw_section *secs, lon
         if (stride < 64) stride = 64;
         plain[(size_t) i].assign(stride + 8, 0);
         if (tk.compressed) {
-            plen[(size_t) i] = wtemu_inflate(bytes + secs[i].comp_off, secs[i].comp_size, plain[(size_t) i].data(), stride, 0);
+            uint32_t at = 0;        // end of the final block: where the trailer sits (a leaf may carry padding behind its stream)
+            plen[(size_t) i] = emu_inflate_ring<WT_INF_RING>(bytes + secs[i].comp_off, secs[i].comp_size, plain[(size_t) i].data(), stride, 0, nullptr, &at);
             if (plen[(size_t) i] >= 0 && secs[i].comp_size >= 6) {      // Adler-32 against the trailer (the count kernel's check)
                 uint32_t a = 1, b = 0;
                 for (long long q = 0; q < plen[(size_t) i]; q++) { a = (a + plain[(size_t) i][(size_t) q]) % 65521u; b = (b + a) % 65521u; }
-                const uint8_t *t = bytes + secs[i].comp_off + secs[i].comp_size - 4;
-                const uint32_t want = ((uint32_t) t[0] << 24) | ((uint32_t) t[1] << 16) | ((uint32_t) t[2] << 8) | (uint32_t) t[3];
-                if (((b << 16) | a) != want) plen[(size_t) i] = -WT_INF_ERR_INPUT;
+                if (at + 4u > secs[i].comp_size) plen[(size_t) i] = -WT_INF_ERR_INPUT;
+                else {
+                    const uint8_t *t = bytes + secs[i].comp_off + at;
+                    const uint32_t want = ((uint32_t) t[0] << 24) | ((uint32_t) t[1] << 16) | ((uint32_t) t[2] << 8) | (uint32_t) t[3];
+                    if (((b << 16) | a) != want) plen[(size_t) i] = -WT_INF_ERR_INPUT;
+                }
             }
         }
         else if (secs[i].comp_size > stride) plen[(size_t) i] = -WT_INF_ERR_SPACE;

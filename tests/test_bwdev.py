@@ -389,6 +389,32 @@ def test_device_decode_error_falls_back_to_host_gpu(amd_lib, oracle, tmp_path, m
     _fallback_case(amd_lib, oracle, tmp_path, monkeypatch, capfd)
 
 
+def _padded_leaves_case(L, oracle, tmp_path, monkeypatch, capfd):
+    """Index leaves whose size includes padding BEHIND the zlib stream (zlib / libBigWig stop at the end of the stream and
+    never look at it).  The device route finds the Adler-32 trailer where the final block ended (the inflate kernel's
+    consumed-byte count), not at the end of the leaf: such files stay on the device decoder -- round 4 rejected every
+    section of them and fell back to the host decoder for the rest of the run (the advisor's finding)."""
+    paths = _write_set(tmp_path, 4, seed=23, block=53, pad=5)
+    monkeypatch.setenv("WTAMD_BW_BATCH_SECTIONS", "80")
+    monkeypatch.setenv("WTAMD_MIN_SPAN", "1500")
+    for op, name in (("MeanReduction", "mean"), ("MaxReduction", "max")):
+        wi, keep = _reduce(L, paths, op)
+        got = _blocks(L, wi)
+        st = _stats(L, wi)
+        _same(got, _expected(oracle, paths, name))
+        assert st.bw_sections > 0
+        assert "continuing with the host decoder" not in capfd.readouterr().err
+
+
+def test_padded_index_leaves_stay_on_device_emu(emu_lib, oracle, tmp_path, monkeypatch, capfd):
+    _padded_leaves_case(emu_lib, oracle, tmp_path, monkeypatch, capfd)
+
+
+@pytest.mark.gpu
+def test_padded_index_leaves_stay_on_device_gpu(amd_lib, oracle, tmp_path, monkeypatch, capfd):
+    _padded_leaves_case(amd_lib, oracle, tmp_path, monkeypatch, capfd)
+
+
 def test_adler32_mismatch_is_an_inflate_error_emu(emu_lib, tmp_path):
     """A payload that still inflates but fails the zlib stream's Adler-32 trailer is rejected by the device route (the
     count kernel's check) and then by the host decoder's zlib, as libBigWig's uncompress() would: exit(1), no result."""

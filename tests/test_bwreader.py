@@ -98,7 +98,7 @@ def _same(got, exp):
         assert g[3] == e[3] or (np.isnan(g[3]) and np.isnan(e[3])), (g, e)
 
 
-def _write_set(tmp_path, n_tracks, seed, chroms=None, density=0.8, block=97):
+def _write_set(tmp_path, n_tracks, seed, chroms=None, density=0.8, block=97, pad=0):
     rng = np.random.default_rng(seed)
     chroms = chroms or {"chr1": 60000, "chr10": 25001, "chr2": 41000, "chrM": 900}
     paths = []
@@ -116,7 +116,7 @@ def _write_set(tmp_path, n_tracks, seed, chroms=None, density=0.8, block=97):
                 pos += ln
             data[c] = recs
         p = str(tmp_path / ("t%d.bw" % t))
-        write_bigwig(p, mine, data, items_per_block=block, compress=(t % 2 == 0), mix_types=True)
+        write_bigwig(p, mine, data, items_per_block=block, compress=(t % 2 == 0), mix_types=True, pad=pad)
         paths.append(p)
     return paths
 

@@ -458,6 +458,39 @@ def test_dropin_children_reusing_one_name_buffer(oracle, H, tiny, monkeypatch):
         H.set_modes(0, 0)
 
 
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("threads", [None, "1", "3"])
+def test_dropin_buffered_reader_non_float_values(oracle, H, threads, monkeypatch):
+    """Buffered-reader children (child mode 4) whose values are NOT float32-exact (0.1 * k as double): wt_buf_peek offers
+    nothing for such an element and the track must fall back to one pop at a time -- the batch turns float64.  Round 4's
+    SERIAL drain (the default below 16 tracks) skipped to the next track instead: the child never advanced and the Feeder
+    span for ever (the advisor's finding, reproduced with 5 tracks; the parallel drain was right).  One track turns
+    non-float only half-way through, so the switch happens inside a chromosome and inside a block."""
+    from wiggletools_amd.runlists import synth, RunLists
+    monkeypatch.setenv("WTAMD_MIN_SPAN", "4000")
+    monkeypatch.setenv("WTAMD_BATCH_INTERVALS", "5000")
+    if threads:
+        monkeypatch.setenv("WTAMD_DRAIN_THREADS", threads)
+    t = synth(5, [60000, 3000], mean_run=5, seed=1404, gap_prob=0.1, dtype=np.float64)
+    v = t.value.copy()
+    N = t.n_tracks
+    for c in range(t.n_chrom):
+        for i in range(N):
+            lo, hi = int(t.seg_off[c * N + i]), int(t.seg_off[c * N + i + 1])
+            if i in (0, 3):
+                v[lo:hi] = v[lo:hi] * 8 * 0.1                   # 0.1 * k
+            elif i == 2 and c == 0:
+                v[(lo + hi) // 2:hi] = v[(lo + hi) // 2:hi] * 8 * 0.1
+    t = RunLists(t.n_chrom, N, t.seg_off, t.start, t.finish, v, t.defaults)
+    d = t.as_dict()
+    H.set_modes(4, 0)
+    try:
+        for op in ("mean", "max"):
+            assert_runs_equal(H.reduce(d, op), oracle.reduce(d, op), _tol(op), "non-float buffered children %s" % op)
+    finally:
+        H.set_modes(0, 0)
+
+
 @pytest.mark.parametrize("tiny,threads", [(False, None), (True, None), (False, "3"), (True, "2")])
 def test_dropin_buffered_reader_children(oracle, H, tiny, threads, monkeypatch):
     """Children built on src/bufferedReader.h the way the reference's binary-file readers are (a reader thread pushing

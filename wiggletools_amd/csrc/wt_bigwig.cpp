@@ -265,8 +265,11 @@ static void bw_grow_fd_table() {
         if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur != RLIM_INFINITY && (long long) rl.rlim_cur - 1 < target) target = (int) rl.rlim_cur - 1;
         const int fd = open("/dev/null", O_RDONLY | O_CLOEXEC);
         if (fd < 0) return;
-        if (target > fd && fcntl(target, F_GETFD) == -1) {      // (not in use)
-            const int hi = dup2(fd, target);
+        // F_DUPFD_CLOEXEC takes the lowest FREE descriptor >= target: it can never close a descriptor another thread of the
+        // host application opened in the meantime (round 4 used F_GETFD + dup2(fd, target), a check-then-act race that
+        // dup2 resolves by silently closing whatever sits at `target`: the advisor's finding).  WTAMD_NO_FD_GROW=1: off.
+        if (target > fd && !getenv("WTAMD_NO_FD_GROW")) {
+            const int hi = fcntl(fd, F_DUPFD_CLOEXEC, target);
             if (hi >= 0) close(hi);
         }
         close(fd);

@@ -154,6 +154,17 @@ BulkSource *wt_bufreader_bulk(WiggleIterator *wi) {
     if (it == g_buf_doors.end()) return nullptr;
     WtBufBulk *door = it->second;
     if (!door->data || !g_buf_live.count(door->data)) return nullptr;      // (a door left behind by an iterator long gone)
+    // The reference frees iterators with plain free() and not every owner calls killBufferedReader first: the buffer of a
+    // dead iterator then stays in g_buf_live, and a NEW, unrelated iterator the allocator places at the same address would
+    // inherit its door (the advisor's finding).  A door is therefore trusted only while the iterator SHOWS the entry its
+    // buffer says is current -- which is what BufferedReaderPop(wi, data) left there; a reader may have clipped the start
+    // after a seek (bigWiggleReader.c:143-144), so name pointer and finish are compared.
+    const BufferedReaderData *d = door->data;
+    if (!wi->done) {
+        if (!d->block || d->readIndex < 1 || d->readIndex > d->block->count) return nullptr;
+        const int cur = d->readIndex - 1;
+        if (wi->chrom != (char *) d->block->chrom[cur] || wi->finish != d->block->finish[cur]) return nullptr;
+    }
     return &door->hdr;
 }
 

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) wt_bw_copy_kernel(const wt_u32x4 *src, wt
 template <int RING>
 __global__ void __launch_bounds__(WT_BW_INF_LANES) wt_bw_inflate_kernel(const WtBwSection *secs, const WtBwTrack *tracks, int n_sec,
                                                                          const uint8_t *comp, uint8_t *plain, uint32_t plain_stride,
-                                                                         int32_t *plain_len) {
+                                                                         int32_t *plain_len, uint32_t *trailer_at) {
     __shared__ uint32_t s_perm[(WT_INF_PERM / 4) * WT_BW_INF_LANES];
     __shared__ uint32_t s_ring[RING * WT_BW_INF_LANES];
     const int lane = threadIdx.x;
@@ -76,6 +76,10 @@ __global__ void __launch_bounds__(WT_BW_INF_LANES) wt_bw_inflate_kernel(const Wt
         if (sc.comp_size > plain_stride) wt_inf_fail(z, WT_INF_ERR_SPACE);
     }
     plain_len[i] = (int32_t) wt_inf_run(z, m);
+    // where the stream's final block ended: the Adler-32 trailer sits THERE, not at the end of the index leaf -- a leaf may
+    // carry padding behind its stream (round 4 read the trailer at comp_off + comp_size - 4 and rejected such files: the
+    // advisor's finding).  Kept in counts[], which the count kernel reads before it writes the section's count there.
+    trailer_at[i] = wt_inf_end_byte(z);
 }
 
 int wt_bw_inflate_ring() {
@@ -135,9 +139,14 @@ __global__ void __launch_bounds__(64) wt_bw_count_kernel(const WtBwSection *secs
             for (int o = 32; o >= 1; o >>= 1) { A += __shfl_xor(A, o, 64); C += __shfl_xor(C, o, 64); }
             const unsigned long long B = (unsigned long long) n * A - C;
             const uint32_t ad = (uint32_t) (((B + n) % 65521ull) << 16) | (uint32_t) ((A + 1ull) % 65521ull);
-            const uint8_t *t = comp + sc.comp_off + sc.comp_size - 4;
-            const uint32_t want = ((uint32_t) t[0] << 24) | ((uint32_t) t[1] << 16) | ((uint32_t) t[2] << 8) | (uint32_t) t[3];
-            if (ad != want) bad |= WT_BW_ERR_INFLATE;
+            const uint32_t at = counts[i];              // left there by the inflate kernel: the end of the final block
+            if (at + 4u > sc.comp_size) {
+                bad |= WT_BW_ERR_INFLATE;               // no room for a trailer: truncated
+            } else {
+                const uint8_t *t = comp + sc.comp_off + at;
+                const uint32_t want = ((uint32_t) t[0] << 24) | ((uint32_t) t[1] << 16) | ((uint32_t) t[2] << 8) | (uint32_t) t[3];
+                if (ad != want) bad |= WT_BW_ERR_INFLATE;
+            }
         }
         WtBwHdr h;
         if (!wt_bw_parse_hdr(p, (uint32_t) len, h)) {
@@ -334,10 +343,10 @@ int wt_bw_decode_async(const void *h_bytes, void *d_bytes, long long n_bytes, co
         const unsigned g = (unsigned) ((n_sec + WT_BW_INF_LANES - 1) / WT_BW_INF_LANES);
         if (wt_bw_inflate_ring() == 64)
             hipLaunchKernelGGL(wt_bw_inflate_kernel<64>, dim3(g), dim3(WT_BW_INF_LANES), 0, s_dec, secs, tracks, (int) n_sec,
-                               (const uint8_t *) d_comp, plain, (uint32_t) plain_stride, plain_len);
+                               (const uint8_t *) d_comp, plain, (uint32_t) plain_stride, plain_len, counts);
         else
             hipLaunchKernelGGL(wt_bw_inflate_kernel<8>, dim3(g), dim3(WT_BW_INF_LANES), 0, s_dec, secs, tracks, (int) n_sec,
-                               (const uint8_t *) d_comp, plain, (uint32_t) plain_stride, plain_len);
+                               (const uint8_t *) d_comp, plain, (uint32_t) plain_stride, plain_len, counts);
         WT_BW_HIP(hipGetLastError());
         hipLaunchKernelGGL(wt_bw_count_kernel, dim3((unsigned) n_sec), dim3(64), 0, s_dec, secs, tracks, (int) n_sec, (const uint8_t *) d_comp, plain,
                            (uint32_t) plain_stride, plain_len, counts, err);

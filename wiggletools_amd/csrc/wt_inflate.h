@@ -196,6 +196,10 @@ WT_HD void wt_inf_fail(WtInflateT<RING> &z, int code) { z.copy_rem = 0; z.err = 
 template <int RING>
 WT_HD int64_t wt_inf_bitpos(const WtInflateT<RING> &z) { return (int64_t) z.qbase * 128 + (int64_t) z.bp - 8 * (int64_t) z.mis; }
 
+// byte offset, from the start of the stream, of what follows the final block (a zlib stream's Adler-32 trailer)
+template <int RING>
+WT_HD uint32_t wt_inf_end_byte(const WtInflateT<RING> &z) { const int64_t b = wt_inf_bitpos(z); return b > 0 ? (uint32_t) ((b + 7) >> 3) : 0u; }
+
 template <int RING>
 WT_HD bool wt_inf_overread(const WtInflateT<RING> &z) { return wt_inf_bitpos(z) > (int64_t) z.n_bytes * 8; }
 
