@@ -135,7 +135,7 @@ def cpu_baseline(chrom_ids, op, n_tracks, mean_run, chrom_lens, many_core=True, 
     (b) reference-style many-core: one process per 30 Mbp region on every host core
     (reference python/wiggletools/parallelWiggleTools.py:63,109), each timing a bounded slice of
     its region.  Both on the bench's own tracks of the largest chromosome, sink = none."""
-    n_set0 = n_tracks // 2 if op == "wilcoxon" else 0
+    n_set0 = n_tracks // 2 if op in ("wilcoxon", "mwu", "ttest") else 0
     k0 = int(np.argmax(chrom_lens))
     c0, clen = int(chrom_ids[k0]), int(chrom_lens[k0])
     probe = _sample_tracks(c0, clen, n_tracks, mean_run, 0, min(100_000, clen))
@@ -401,7 +401,7 @@ def chrom_name(c):
     return "chr%d" % (c + 1) if c < 22 else ("chrX" if c == 22 else "chrY")
 
 
-def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None):
+def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None, level=1, runs=2):
     """The north-star measurement: `op` over n_tracks WHOLE-GENOME BigWig files -> result on the host.  Every file holds
     all 24 chromosomes (GRCh38 lengths x `scale`, names chr1 .. chr22, chrX, chrY; the reader walks them in strcmp
     order as reference src/bigWiggleReader.c:91-101 does, 10 000-bp stretches :52-83), bedGraph sections of 1024 items,
@@ -424,14 +424,14 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None):
     d = keep or tempfile.mkdtemp(prefix="wtamd_bwg_", dir=os.environ.get("WTAMD_BENCH_TMP") or ("/dev/shm" if os.path.isdir("/dev/shm") else None))
     os.makedirs(d, exist_ok=True)
     paths = [os.path.join(d, "g%03d.bw" % t) for t in range(n_tracks)]
-    meta = os.path.join(d, "meta_genome_%d_%d_%s.json" % (n_tracks, genome_bp, "all" if only is None else "-".join(map(str, sorted(only)))))
+    meta = os.path.join(d, "meta_genome_%d_%d_%s_z%d.json" % (n_tracks, genome_bp, "all" if only is None else "-".join(map(str, sorted(only))), level))
     try:
         if keep and os.path.exists(meta):
             m = json.load(open(meta))
             n_int, write_s, gen_s, sections = m["intervals"], 0.0, 0.0, m["sections"]
         else:
             t0 = time.perf_counter()
-            fs = bwwrite.FileSet(paths, {names[c]: lens[c] + 1 for c in range(24)}, items_per_block=1024, level=1, threads=max(1, min(effective_cores(), 32)))
+            fs = bwwrite.FileSet(paths, {names[c]: lens[c] + 1 for c in range(24)}, items_per_block=1024, level=level, threads=max(1, min(effective_cores(), 32)))
             n_int, gen_s = 0, 0.0
             for c in order:
                 if lens[c] == 0:
@@ -495,8 +495,8 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None):
             return o
 
         cold = run_once()
-        warm = run_once()
-        return {"tracks": n_tracks, "op": op, "chromosomes_per_file": 24, "genome_scale": scale, "bp": genome_bp, "intervals": n_int,
+        warm = run_once() if runs > 1 else cold
+        return {"tracks": n_tracks, "op": op, "chromosomes_per_file": 24, "genome_scale": scale, "bp": genome_bp, "intervals": n_int, "zlib_level": level,
                 "sections": sections, "file_bytes": size, "file_bytes_per_bp": size / genome_bp,
                 "pcie_h2d_roofline_bp_per_s": 63e9 / (size / genome_bp), "files_written_s": write_s, "generate_s": gen_s,
                 "files_dir": d.rsplit("/", 1)[0], "host_cores": effective_cores(),
@@ -564,6 +564,7 @@ class Ctx:
         self.device, self.rank, self.world, self.store, self.shard = device, rank, world, store, shard
         self.replicas = world > 1 and shard == "replicas"
         self.cdev = device
+        self.use_dist = world > 1       # --force-dist: the collectives also run with a world of ONE rank (RCCL initialised on a 1-GPU box)
 
 
 def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_set0_arg=-1, f64=False, want_moments=False, values="k8"):
@@ -576,6 +577,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
     import torch.distributed as dist
     from wiggletools_amd import engine, synthgen
     device, world, rank, store, replicas = ctx.device, ctx.world, ctx.rank, ctx.store, ctx.replicas
+    use_dist = ctx.use_dist
     chrom_lens = {c: max(int(GRCH38[c] * scale), 1) for c in chrom_ids}
     queue = sorted(chrom_ids, key=lambda c: -chrom_lens[c])         # host-side work queue: largest first
     genome_bp = sum(chrom_lens.values())
@@ -587,7 +589,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
     def my_items(pass_no):
         """Work queue of one pass.  One GPU / replicas: every chromosome.  Sharded genome: tickets
         from a counter in the rendezvous store (dynamic), else a static largest-first deal."""
-        if world == 1 or replicas:
+        if (world == 1 and not (use_dist and store is not None)) or replicas:
             yield from queue
         elif store is not None:
             while True:
@@ -655,7 +657,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
                 stats_last.update(st)
                 agg["patched"] = agg.get("patched", 0) + st.get("patched_windows", 0)
                 per_item[c] = dt * 1e3
-                if want_moments or world > 1:
+                if want_moments or use_dist:
                     # Pearson moments of tracks 0 and 1 of this chromosome (scalar gather readiness)
                     a, b = int(seg[0]), int(seg[2])
                     ts2 = engine.TrackSet.from_device(1, 2, seg[:3] - seg[0], s[a:b], f[a:b], v[a:b].float() if f64 else v[a:b], np.zeros(2))
@@ -670,12 +672,12 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
 
     pass_s, idx_tot, red_tot = [], 0.0, 0.0
     for k in range(steps):
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         hs, im, rm = one_pass(k, k == steps - 1)
         t = torch.tensor([hs], dtype=torch.float64, device=ctx.cdev)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)        # a pass is over when the slowest rank is
             dist.barrier()
         pass_s.append(float(t.item()))
@@ -689,7 +691,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
     for c, m in moments.items():
         mom[c] = torch.tensor(m, dtype=torch.float64, device=ctx.cdev)
     queue_check = None
-    if world > 1:
+    if use_dist:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         gathered = [torch.zeros_like(mom) for _ in range(world)]
         dist.all_gather(gathered, mom)
@@ -707,7 +709,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
                        "how": "tickets from a counter in the rendezvous store" if store is not None and not replicas else ("replicas" if replicas else "static deal")}
     tot_bp, tot_auc, tot_runs, tot_int, tot_win, idx_all, red_all, gen_all = [float(x) for x in vec.tolist()]
     pearson = None
-    if moments or world > 1:
+    if moments or use_dist:
         from wiggletools_amd import shard
         rows = mom.cpu().numpy()
         order = sorted(chrom_ids, key=lambda c: ("chr%d" % (c + 1)).encode())       # strcmp order (multiplexer.c:56)
@@ -781,10 +783,10 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
         # the arithmetic type of the path: the reference accumulates in f64; the difference-array kernel does it in
         # exact int64 / 128-bit integers of the scaled float32 mantissas, which IS that f64 result
         "dtype": "f64 (exact int64 accumulation)" if kern == 1 else "f64", "data": "synthetic",
-        "config": {"workload": "%s: %s over %d synthetic %s run-list tracks, %d chromosome(s) = GRCh38 x %g = %.3f Gbp per step, "
-                               "mean run %g bp, 2%% gaps; one step = one whole pass, chromosomes generated in HBM one at a time "
-                               "(untimed) and processed resident (timed)"
-                               % (name, "+".join(ops), N, "float64" if f64 else "float32", len(chrom_ids), scale, genome_bp / 1e9, mean_run),
+        # (the driver's record truncates strings at 120 characters: the workload fits, the prose is in workload_note)
+        "config": {"workload": "%s: %s, %d %s tracks, %d chrom(s) GRCh38 x %g = %.3f Gbp/step, run %g bp, resident in HBM"
+                               % (name, "+".join(ops), N, "f64" if f64 else "f32", len(chrom_ids), scale, genome_bp / 1e9, mean_run),
+                   "workload_note": "synthetic run-list tracks, 2% gaps; one step = one whole pass, chromosomes generated in HBM one at a time (untimed) and processed resident (timed)",
                    "config": name, "ops": ops, "tracks": N, "mean_run_bp": mean_run,
                    "genome_bp": genome_bp, "covered_bp_per_step": bp_per_pass,
                    "input_runs_per_step": tot_int, "output_runs_per_step": tot_runs,
@@ -802,6 +804,8 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
                      "frac_with_index": alg_bytes / ((kernel_ms_sum + idx_all / passes) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "tile_equivalent_GBs": tile_equiv, "note": note, "issue": issue},
         "auc_check": tot_auc, "pearson_tracks_0_1": pearson, "output_runs": tot_runs, "work_queue_check": queue_check,
+        "collectives": ({"backend": dist.get_backend(), "world": world, "ran": ["barrier", "all_reduce(max) of the pass time", "all_reduce(sum) of the scalars",
+                                                                                "all_gather of the Pearson moments", "all_gather of the work-queue record"]} if use_dist else None),
         "gen_seconds_total": gen_all, "pass_seconds": pass_s,
         "_chrom_lens": [chrom_lens[c] for c in chrom_ids],
     }
@@ -847,6 +851,8 @@ def main():
     ap.add_argument("--shard", default="genome", choices=["genome", "replicas"])
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: the N > 1 path on a box with fewer GPUs than ranks (ranks share devices, collectives on the host) -- a does-it-run check, not a scaling number")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (and with backend nccl: RCCL) even for a world of one rank, and run the work queue + scalar collectives through it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-many-core", action="store_true")
     ap.add_argument("--chroms", default=None, help="experiments: only these chromosomes of the configuration (comma separated indices)")
@@ -876,7 +882,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     store = None
-    if world > 1:
+    if world > 1 or args.force_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "gloo":
             dist.init_process_group("gloo")
         else:
@@ -887,6 +899,7 @@ def main():
             store = None
     ctx = Ctx(device, rank, world, store, args.shard)
     ctx.cdev = torch.device("cpu") if args.dist_backend == "gloo" else device       # where collectives' tensors live
+    ctx.use_dist = world > 1 or args.force_dist
 
     cfg = CONFIGS[args.config]
     ops = args.op.split(",") if args.op else cfg["ops"]
@@ -923,12 +936,35 @@ def main():
                     g = {"error": repr(e)[:300]}
                 res["e2e_bigwig_genome"] = g
                 trim_pools()
-                # folded into `config` as well: the part of the line the driver keeps
-                res["config"]["north_star_files_to_result"] = {
-                    "what": "%s over %d BigWig files of 24 chromosomes each (GRCh38 x %.3g = %.3f Gbp), file open -> last run on the host"
-                            % (ops[-1], N, g.get("genome_scale", 0), g.get("bp", 0) / 1e9),
-                    "bp_per_s_cold": g.get("bp_per_s"), "bp_per_s_warm": g.get("warm_bp_per_s"), "bp_per_s_steady": g.get("steady_bp_per_s"),
-                    "target_bp_per_s": 1e9, "error": g.get("error")}
+                # SCALAR keys of `config`: the part of the line the driver keeps (round 4 nested them in a dict, which the
+                # driver's record dropped).  cold = what a CLI process gets: the process's first pipe, nothing pooled.
+                cfgd = res["config"]
+                cfgd["e2e_files_what"] = "%s, %d whole-genome BigWig files (24 chroms, %.3f Gbp), open -> last run on host" % (ops[-1], N, g.get("bp", 0) / 1e9)
+                cfgd["e2e_files_cold_bp_per_s"] = g.get("bp_per_s")
+                cfgd["e2e_files_warm_bp_per_s"] = g.get("warm_bp_per_s")
+                cfgd["e2e_files_steady_bp_per_s"] = g.get("steady_bp_per_s")
+                cfgd["e2e_files_cold_seconds"] = (g.get("cold") or {}).get("seconds")
+                cfgd["e2e_files_target_bp_per_s"] = 1e9
+                if g.get("error"):
+                    cfgd["e2e_files_error"] = str(g.get("error"))[:110]
+                # the same pipeline on files written at zlib level 6 (libBigWig's / wigToBigWig's default; SURVEY 8d's stored
+                # form is level 1) next to level 1 on the same two chromosomes (21, 22: writing 90 GB at level 6 would take
+                # the bench ten minutes of host zlib)
+                if gscale >= 0.999 and not os.environ.get("WTAMD_BENCH_NO_LEVELS"):
+                    lv = {}
+                    for level in (1, 6):
+                        try:
+                            q = e2e_bigwig_genome(ops[-1], N, args.mean_run, 1.0, device, only=[20, 21], level=level)
+                            lv["z%d" % level] = {k: q.get(k) for k in ("zlib_level", "bp", "file_bytes", "file_bytes_per_bp", "files_written_s", "sections",
+                                                                       "bp_per_s", "warm_bp_per_s", "steady_bp_per_s")}
+                            lv["z%d" % level]["warm_sum_device_decode_ms"] = (q.get("warm") or {}).get("sum_device_decode_ms")
+                            lv["z%d" % level]["warm_seconds"] = (q.get("warm") or {}).get("seconds")
+                        except Exception as e:
+                            lv["z%d" % level] = {"error": repr(e)[:300]}
+                        trim_pools()
+                    res["e2e_bigwig_levels"] = lv
+                    cfgd["e2e_files_z6_warm_bp_per_s_chr21_22"] = lv.get("z6", {}).get("warm_bp_per_s")
+                    cfgd["e2e_files_z1_warm_bp_per_s_chr21_22"] = lv.get("z1", {}).get("warm_bp_per_s")
                 res["value_e2e_bigwig_genome"] = g.get("bp_per_s")
                 res["value_e2e_bigwig_genome_warm"] = g.get("warm_bp_per_s")
                 res["value_e2e_bigwig_genome_steady"] = g.get("steady_bp_per_s")
@@ -962,6 +998,8 @@ def main():
         for name in ("c3", "c4", "c5"):
             c = CONFIGS[name]
             subs[name] = sub(name, c["ops"], c["tracks"], c["chroms"], args.mean_run, moments=name == "c5")
+        # the other two-sample reducer north_star names (Welch t-test, setComparisons.c:35-121), same shape as C5
+        subs["ttest"] = sub("ttest", ["ttest"], 100, list(range(24)), args.mean_run)
         # C2 at the other run lengths of SURVEY 8d: mean run 1 bp on chromosomes 19-22 + Y (their 100 dense tracks fit HBM
         # one chromosome at a time: 77 GB for chromosome 19), mean run 200 bp on the whole genome
         runs["l1"] = sub("c2/l=1", ["mean"], 100, [18, 19, 20, 21, 23], 1.0, cpu=False)
@@ -979,10 +1017,26 @@ def main():
             res["configs"] = subs
             res["c2_runs"] = runs
             res["other_kernels"] = others
+            # ... and their headline figures as scalar keys of `config` (what the driver's record keeps)
+            def put(key, rec, what):
+                if isinstance(rec, dict) and "error" not in rec:
+                    v = rec.get("roofline", {}).get(what) if what in ("frac", "kernel_ms") else rec.get(what)
+                    if v is not None:
+                        res["config"][key] = v
+            for name in ("c3", "c4", "c5", "ttest"):
+                put("%s_hbm_frac" % name, subs.get(name), "frac")
+                put("%s_bp_per_s" % name, subs.get(name), "value")
+                put("%s_ms_per_step" % name, subs.get(name), "ms_per_step")
+            put("c2_l1_hbm_frac", runs.get("l1"), "frac")
+            put("c2_l200_hbm_frac", runs.get("l200"), "frac")
+            put("c2_full_mantissa_hbm_frac", runs.get("full_mantissa"), "frac")
+            put("c2_patched_hbm_frac", runs.get("full_mantissa_patched"), "frac")
+            for name in ("max", "product", "mean_f64_values", "sum_500"):
+                put("%s_hbm_frac" % name, others.get(name), "frac")
     if rank == 0:
         res["bench_seconds"] = time.perf_counter() - t_start
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.destroy_process_group()
 
 

@@ -178,6 +178,7 @@ static hipError_t wt_host_alloc(void **out, size_t bytes) {
             return hipSuccess;
         }
     }
+    const auto t_alloc0 = std::chrono::steady_clock::now();
     hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
     if (e != hipSuccess) {
         // the host refuses to page-lock more while buffers rest in the pool: give them all back and try once more
@@ -200,7 +201,8 @@ static hipError_t wt_host_alloc(void **out, size_t bytes) {
         g_pinned_pool.misses++;
         g_pinned_pool.miss_bytes += bytes;
         static const bool trace = getenv("WTAMD_TRACE_POOL") != nullptr;
-        if (trace) fprintf(stderr, "[pool] hipHostMalloc %.1f MB\n", bytes / 1048576.0);
+        if (trace) fprintf(stderr, "[pool] hipHostMalloc %.1f MB in %.1f ms\n", bytes / 1048576.0,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc0).count());
     }
     return e;
 }
@@ -257,6 +259,7 @@ static hipError_t wt_dev_alloc(T **out, size_t bytes, int line = __builtin_LINE(
         }
     }
     void *q = nullptr;
+    const auto t_alloc0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&q, bytes);
     if (e != hipSuccess) {
         // out of device memory with buffers resting in the pool: give them all back and try once more
@@ -280,7 +283,8 @@ static hipError_t wt_dev_alloc(T **out, size_t bytes, int line = __builtin_LINE(
         g_dev_pool.misses++;
         g_dev_pool.miss_bytes += bytes;
         static const bool trace = getenv("WTAMD_TRACE_POOL") != nullptr;
-        if (trace && bytes >= (1u << 20)) fprintf(stderr, "[pool] hipMalloc %.1f MB (device %d, wt_pipe.h:%d)\n", bytes / 1048576.0, dev, line);
+        if (trace && bytes >= (1u << 20)) fprintf(stderr, "[pool] hipMalloc %.1f MB in %.1f ms (device %d, wt_pipe.h:%d)\n", bytes / 1048576.0,
+                                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc0).count(), dev, line);
     }
     return e;
 }
