@@ -401,7 +401,7 @@ def chrom_name(c):
     return "chr%d" % (c + 1) if c < 22 else ("chrX" if c == 22 else "chrY")
 
 
-def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None, level=1, runs=2):
+def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None, level=1, runs=2, fresh_process=False):
     """The north-star measurement: `op` over n_tracks WHOLE-GENOME BigWig files -> result on the host.  Every file holds
     all 24 chromosomes (GRCh38 lengths x `scale`, names chr1 .. chr22, chrX, chrY; the reader walks them in strcmp
     order as reference src/bigWiggleReader.c:91-101 does, 10 000-bp stretches :52-83), bedGraph sections of 1024 items,
@@ -464,8 +464,18 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None, level=1,
             _lib.lib().wtamd_pool_stats(a)
             return list(a)
 
+        def vmstat():
+            keys = ("numa_pages_migrated", "numa_hint_faults", "pgmigrate_success", "pgfault", "pgmajfault", "thp_fault_alloc", "pswpin", "pswpout",
+                    "pgscan_kswapd", "pgscan_direct", "pgsteal_kswapd", "compact_stall", "thp_collapse_alloc")
+            try:
+                kv = dict(l.split() for l in open("/proc/vmstat"))
+                return {k: int(kv[k]) for k in keys if k in kv}
+            except Exception:
+                return {}
+
         def run_once():
             p0 = pool()
+            v0 = vmstat() if os.environ.get("WTAMD_BENCH_VMSTAT") else None
             t0 = time.perf_counter()
             readers = dropin.bigwig_readers(paths, box=True)
             t_readers = time.perf_counter() - t0
@@ -489,6 +499,9 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None, level=1,
             p1 = pool()
             o["pinned_afresh"] = {"buffers": p1[0] - p0[0], "bytes": p1[1] - p0[1]}
             o["device_afresh"] = {"buffers": p1[3] - p0[3], "bytes": p1[4] - p0[4]}
+            if v0 is not None:
+                v1 = vmstat()
+                o["vmstat_delta"] = {k: v1[k] - v0[k] for k in v0 if v1.get(k, 0) != v0[k]}
             q = [m_ for m_ in marks if m_[1] >= genome_bp // 4]
             if len(q) >= 2 and q[-1][0] > q[0][0]:
                 o["steady_bp_per_s"] = (q[-1][1] - q[0][1]) / (q[-1][0] - q[0][0])
@@ -496,7 +509,20 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None, level=1,
 
         cold = run_once()
         warm = run_once() if runs > 1 else cold
-        return {"tracks": n_tracks, "op": op, "chromosomes_per_file": 24, "genome_scale": scale, "bp": genome_bp, "intervals": n_int, "zlib_level": level,
+        # ... and in a FRESH process, which is what a `wiggletools mean *.bw` invocation is: nothing of this process's state
+        # (runtime up, code object loaded, queues, pools) helps it (tools/cli_cold.py; the files are still in place)
+        fresh = None
+        if fresh_process:
+            import subprocess
+            try:
+                env = {k: v for k, v in os.environ.items() if not k.startswith("WTAMD_TRACE")}
+                pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_cold.py"), d, str(n_tracks), op, str(genome_bp)],
+                                    capture_output=True, text=True, timeout=600, env=env)
+                lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+                fresh = json.loads(lines[-1]) if lines else {"error": (pr.stderr or "no output")[-300:]}
+            except Exception as e:
+                fresh = {"error": repr(e)[:300]}
+        return {"fresh_process": fresh, "tracks": n_tracks, "op": op, "chromosomes_per_file": 24, "genome_scale": scale, "bp": genome_bp, "intervals": n_int, "zlib_level": level,
                 "sections": sections, "file_bytes": size, "file_bytes_per_bp": size / genome_bp,
                 "pcie_h2d_roofline_bp_per_s": 63e9 / (size / genome_bp), "files_written_s": write_s, "generate_s": gen_s,
                 "files_dir": d.rsplit("/", 1)[0], "host_cores": effective_cores(),
@@ -931,7 +957,7 @@ def main():
                 # THE north-star figure (BASELINE.json): `mean` over 100 whole-genome BigWig files -> result, >= 1e9 bp/s
                 try:
                     gscale = genome_file_scale(N, args.mean_run) * (args.scale if args.scale < 1 else 1.0)
-                    g = e2e_bigwig_genome(ops[-1], N, args.mean_run, gscale, device) if gscale > 0.001 else {"error": "no room for the files"}
+                    g = e2e_bigwig_genome(ops[-1], N, args.mean_run, gscale, device, fresh_process=True) if gscale > 0.001 else {"error": "no room for the files"}
                 except Exception as e:
                     g = {"error": repr(e)[:300]}
                 res["e2e_bigwig_genome"] = g
@@ -945,6 +971,10 @@ def main():
                 cfgd["e2e_files_steady_bp_per_s"] = g.get("steady_bp_per_s")
                 cfgd["e2e_files_cold_seconds"] = (g.get("cold") or {}).get("seconds")
                 cfgd["e2e_files_target_bp_per_s"] = 1e9
+                fp = g.get("fresh_process") or {}
+                cfgd["e2e_files_fresh_process_bp_per_s"] = fp.get("bp_per_s")                   # first library call -> last run, new process
+                cfgd["e2e_files_fresh_process_seconds"] = fp.get("seconds")
+                cfgd["e2e_files_fresh_process_library_load_s"] = fp.get("library_load_s")       # dlopen: the HIP runtime's shared objects
                 if g.get("error"):
                     cfgd["e2e_files_error"] = str(g.get("error"))[:110]
                 # the same pipeline on files written at zlib level 6 (libBigWig's / wigToBigWig's default; SURVEY 8d's stored

@@ -244,6 +244,9 @@ typedef struct {
 int wtamd_device_count(void);
 int wtamd_set_device(int ordinal);
 int wtamd_current_device(void);     /* the calling thread's device (-1: none); HIP devices are per thread */
+/* Starts the HIP runtime (device discovery, code object, first hardware queues: ~0.2 s in a fresh process) on a helper thread,
+ * once per process; returns at once.  wtamd_BigWiggleReaders calls it before it opens its files; the first pipe waits for it. */
+void wtamd_warmup_async(void);
 const char *wtamd_last_error(void);
 const char *wtamd_version(void);
 

@@ -172,6 +172,7 @@ int wtamd_pipe_put_direct(wtamd_pipe *p, int64_t at, int64_t count, const int32_
 // WTEMU_DEVICES: how many GPUs the emulated runtime reports (the drop-in layer's WTAMD_DEVICES dealing is tested with it)
 int wtamd_device_count(void) { const char *e = getenv("WTEMU_DEVICES"); return e && atoi(e) > 0 ? atoi(e) : 1; }
 int wtamd_current_device(void) { return 0; }
+void wtamd_warmup_async(void) { }
 int wtamd_set_device(int) { return WTAMD_OK; }
 void *wtamd_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 void wtamd_pool_trim(void) {}

@@ -17,6 +17,6 @@ if __name__ == "__main__":
     op = sys.argv[3] if len(sys.argv) > 3 else "mean"
     torch.cuda.set_device(0)
     only = [int(x) for x in os.environ["WTAMD_GENOME_ONLY"].split(",")] if os.environ.get("WTAMD_GENOME_ONLY") else None
-    r = bench.e2e_bigwig_genome(op, tracks, 16.0, scale, torch.device("cuda", 0), only=only)
+    r = bench.e2e_bigwig_genome(op, tracks, 16.0, scale, torch.device("cuda", 0), only=only, fresh_process=bool(os.environ.get("WTAMD_FRESH")))
     r["env"] = {k: v for k, v in os.environ.items() if k.startswith("WTAMD_")}
     print(json.dumps(r))

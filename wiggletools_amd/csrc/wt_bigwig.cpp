@@ -16,12 +16,14 @@
 //     1 (mod 10000) is dropped -- reproduced when boxing is on.
 // Pinned by the reference's own fixtures test/fixedStep.bw == fixedStep.wig and
 // variableStep.bw == variableStep.wig (reference test/test.py:28,52).
+#include <dirent.h>
 #include <fcntl.h>
 #include <sys/resource.h>
 #include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cstdint>
 #include <cstdio>
@@ -253,33 +255,56 @@ static double bw_now_ms() {
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-// The kernel grows a process's file-descriptor table by doubling, and a table shared by several threads is replaced
-// behind synchronize_rcu(): on the 256-CPU hosts measured, the open() that crossed 256 descriptors -- the SECOND job of
-// 100 files in a process, or the first of 300 -- stalled for 180 ms, and with it every opener thread queued behind it
-// (round 4: "open 100 files" 0.04 s in the cold run, 0.18 s in the warm one).  The first open of a process therefore
-// grows the table once, to 4096 entries, on a thread of its own: opens that still fit the old table do not wait.
-static void bw_grow_fd_table() {
-    std::thread([] {
-        struct rlimit rl;
-        int target = 4095;
-        if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur != RLIM_INFINITY && (long long) rl.rlim_cur - 1 < target) target = (int) rl.rlim_cur - 1;
-        const int fd = open("/dev/null", O_RDONLY | O_CLOEXEC);
-        if (fd < 0) return;
-        // F_DUPFD_CLOEXEC takes the lowest FREE descriptor >= target: it can never close a descriptor another thread of the
-        // host application opened in the meantime (round 4 used F_GETFD + dup2(fd, target), a check-then-act race that
-        // dup2 resolves by silently closing whatever sits at `target`: the advisor's finding).  WTAMD_NO_FD_GROW=1: off.
-        if (target > fd && !getenv("WTAMD_NO_FD_GROW")) {
-            const int hi = fcntl(fd, F_DUPFD_CLOEXEC, target);
-            if (hi >= 0) close(hi);
-        }
-        close(fd);
-    }).detach();
+// The kernel grows a process's file-descriptor table by doubling (64 -> 128 -> 256 ...), and the table of a process with
+// more than one thread is replaced behind synchronize_rcu(): on the 256-CPU hosts measured that is 140-180 ms, paid by the
+// open() that crosses the boundary and by every other thread whose open needs the new table meanwhile -- the second job of
+// 100 files in a process (round 4: 0.18 s instead of 0.04 s to open them) or, round 5's trace of a FRESH process, 16 of
+// the 100 fopen() calls of the first job (138.8 ms each, the other 84: 0.02 ms).  A single-threaded process grows its
+// table without any grace period, so:
+//   * when this library is loaded into a process that has one thread (a C program linked against it: the reference's CLI),
+//     its constructor grows the table to 4096 entries on the spot -- microseconds;
+//   * otherwise (an interpreter that already runs worker threads) a helper thread starts growing it at load time -- the
+//     grace period runs while the host program goes about its own start-up -- and the first open makes sure of it.
+// F_DUPFD_CLOEXEC takes the lowest FREE descriptor >= target: it never closes a descriptor another thread of the host
+// application opened in the meantime (round 4 used F_GETFD + dup2, which can: the advisor's finding).  WTAMD_NO_FD_GROW=1: off.
+static std::atomic<int> g_fd_grown{0};       // 0 not yet, 1 under way or done
+
+static void bw_grow_fd_table_now() {
+    struct rlimit rl;
+    int target = 4095;
+    if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur != RLIM_INFINITY && (long long) rl.rlim_cur - 1 < target) target = (int) rl.rlim_cur - 1;
+    const int fd = open("/dev/null", O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return;
+    if (target > fd) {
+        const int hi = fcntl(fd, F_DUPFD_CLOEXEC, target);
+        if (hi >= 0) close(hi);
+    }
+    close(fd);
 }
+
+static int bw_thread_count() {
+    int n = 0;
+    if (DIR *d = opendir("/proc/self/task")) {
+        while (struct dirent *e = readdir(d))
+            if (e->d_name[0] != '.') n++;
+        closedir(d);
+    }
+    return n;
+}
+
+static void bw_grow_fd_table(bool at_load) {
+    if (getenv("WTAMD_NO_FD_GROW")) return;
+    int expect = 0;
+    if (!g_fd_grown.compare_exchange_strong(expect, 1)) return;
+    if (at_load && bw_thread_count() == 1) { bw_grow_fd_table_now(); return; }     // no other thread: no grace period
+    std::thread(bw_grow_fd_table_now).detach();
+}
+
+__attribute__((constructor)) static void bw_library_loaded() { bw_grow_fd_table(true); }
 
 int wtamd_bw_open(const char *path, wtamd_bw **out) {
     if (!path || !out) return WTAMD_ERR_ARG;
-    static std::once_flag grow_once;
-    std::call_once(grow_once, bw_grow_fd_table);
+    bw_grow_fd_table(false);        // (already done by the library's constructor unless that was switched off)
     static const bool trace = getenv("WTAMD_TRACE_OPEN") != nullptr;
     const double t0 = trace ? bw_now_ms() : 0;
     wtamd_bw *bw = new wtamd_bw();

@@ -19,6 +19,8 @@
 #include <chrono>
 #include <cstdio>
 #include <thread>
+#include <atomic>
+#include <sys/mman.h>
 #include <unistd.h>
 #include <cstring>
 #include <map>
@@ -934,6 +936,43 @@ int wtamd_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// The first HIP call of a process brings the runtime up (device discovery, the library's code object, the first hardware
+// queues): 170 ms between newMultiplexer and the first batch in the trace of a fresh `mean *.bw` process (round 5,
+// tools/cli_cold.py) -- spent AFTER the 100 files had been opened, although neither needs the other.  The callers that
+// know GPU work is coming (wtamd_BigWiggleReaders: it opens the files on worker threads) start it on a helper thread
+// first; wtamd_pipe_create waits for the helper.  The helper works on the default device (a process that selects another
+// one has called into HIP already: the runtime is up and this costs nothing).
+__global__ void wt_warm_kernel(int *p) { if (p && threadIdx.x == 4096) *p = 0; }
+
+static std::mutex g_warm_mu;
+static std::thread *g_warm_thread = nullptr;
+static bool g_warm_started = false;
+
+static void wt_warmup_join() {
+    std::thread *t = nullptr;
+    { std::lock_guard<std::mutex> lk(g_warm_mu); t = g_warm_thread; g_warm_thread = nullptr; }
+    if (t) { t->join(); delete t; }
+}
+
+void wtamd_warmup_async(void) {
+    std::lock_guard<std::mutex> lk(g_warm_mu);
+    if (g_warm_started || getenv("WTAMD_NO_WARMUP")) return;
+    g_warm_started = true;
+    g_warm_thread = new std::thread([] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void) hipGetLastError(); return; }
+        hipStream_t st[3] = {nullptr, nullptr, nullptr};
+        for (auto &s : st)
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+        for (auto &s : st)
+            if (s) hipLaunchKernelGGL(wt_warm_kernel, dim3(1), dim3(64), 0, s, (int *) nullptr);
+        for (auto &s : st)
+            if (s) { (void) hipStreamSynchronize(s); (void) hipStreamDestroy(s); }
+        (void) hipGetLastError();
+    });
+    atexit(wt_warmup_join);         // (a process that exits before it ever built a pipe must not leave the helper inside the runtime)
 }
 
 int wtamd_set_device(int ordinal) {

@@ -2392,6 +2392,8 @@ WiggleIterator *wtamd_PearsonIntegrator(Multiplexer *multi) {
 int wtamd_BigWiggleReaders(int n, const char *const *paths, int box, WiggleIterator **out) {
     if (n < 0 || (n > 0 && (!paths || !out))) return WTAMD_ERR_ARG;
     if (g_trace) fprintf(stderr, "[readers] open %d files %.3f\n", n, now_ms());
+    // files opened side by side are about to feed a reducer: the HIP runtime starts up on a helper thread meanwhile
+    if (n >= 2 && !(getenv("WTAMD_BW_DEVICE") && atoi(getenv("WTAMD_BW_DEVICE")) == 0)) wtamd_warmup_async();
     const int T = std::max(1, std::min({n, wt_usable_cores(), 16}));
     std::vector<std::thread> th;
     for (int w = 0; w < T; w++)

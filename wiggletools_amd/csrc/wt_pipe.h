@@ -127,7 +127,9 @@ __global__ void __launch_bounds__(256) wt_export_kernel(const unsigned long long
 
 // Page-locked (hipHostMalloc / hipHostRegister) host memory is readable by kernels; pageable memory
 // is not -- such ranges go through hipMemcpyAsync, which stages them.
+static bool wt_is_registered(const void *q);
 static bool wt_is_pinned(const void *q) {
+    if (wt_is_registered(q)) return true;       // (this library's own mmap + hipHostRegister buffers, below)
     hipPointerAttribute_t a;
     if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void) hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
@@ -163,6 +165,98 @@ static size_t wt_pool_round(size_t bytes) {
     return (bytes + step - 1) / step * step;
 }
 
+// Page-locking by the page.  hipHostMalloc allocates AND faults AND pins from one thread: 176-229 ms per GiB on the
+// MI355X hosts measured (tools/probes/cold_probe.hip; 4.3 GB of staging = 0.3-0.8 s of a cold file-byte run, round 4's
+// "pinned_afresh").  The same GiB as an anonymous mapping with transparent huge pages, faulted in by 16 threads
+// (4 ms) and then registered (hipHostRegister: 2 ms -- 512 huge pages to pin instead of 262 144 small ones) costs 6 ms,
+// and the copy engine reads it at the same 57 GB/s.  Buffers of 2 MB and more take that route (WTAMD_PIN=malloc: the
+// old one); anything the runtime refuses falls back to hipHostMalloc.
+struct WtRegistered { void *base; size_t map_len; };
+static std::mutex g_reg_mu;
+static std::map<void *, WtRegistered> g_registered;        // registered mappings, by the pointer handed out
+static std::atomic<int> g_reg_state{0};                      // 0 untried, 1 works, -1 does not (hipHostMalloc from then on)
+
+static bool wt_is_registered(const void *q) {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_registered.upper_bound((void *) q);
+    if (it == g_registered.begin()) return false;
+    --it;
+    return (const char *) q < (const char *) it->second.base + it->second.map_len;
+}
+
+static int wt_pin_threads() {
+    static const int n = [] {
+        int c = (int) std::thread::hardware_concurrency();
+        if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {       // (the container's CPU quota: the GPU boxes show 256 CPUs and grant 16)
+            char q[64]; long long period = 0;
+            if (fscanf(fp, "%63s %lld", q, &period) == 2 && period > 0 && strcmp(q, "max") != 0) {
+                const long long k = atoll(q) / period;
+                if (k >= 1 && k < c) c = (int) k;
+            }
+            fclose(fp);
+        }
+        return c < 1 ? 1 : (c > 16 ? 16 : c);
+    }();
+    return n;
+}
+
+static bool wt_pin_by_register(void **out, size_t bytes) {
+    static const bool off = getenv("WTAMD_PIN") && !strcmp(getenv("WTAMD_PIN"), "malloc");
+    if (off || g_reg_state.load() < 0 || bytes < ((size_t) 2 << 20)) return false;
+    const size_t huge = (size_t) 2 << 20;
+    const size_t len = (bytes + huge - 1) / huge * huge;
+    void *base = mmap(nullptr, len + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (base == MAP_FAILED) return false;
+    char *p = (char *) (((uintptr_t) base + huge - 1) & ~(uintptr_t) (huge - 1));
+#ifdef MADV_HUGEPAGE
+    (void) madvise(p, len, MADV_HUGEPAGE);
+#endif
+    // fault the pages in from several threads (one touch per 4 KB: right with and without huge pages)
+    int T = wt_pin_threads();
+    const size_t per_thread_min = (size_t) 32 << 20;
+    if ((size_t) T > len / per_thread_min) T = (int) (len / per_thread_min);
+    if (T < 1) T = 1;
+    const size_t slice = (len / (size_t) T + huge - 1) / huge * huge;
+    auto touch = [p, len, slice](int t) {
+        const size_t a = slice * (size_t) t, b = a + slice < len ? a + slice : len;
+        for (size_t q = a; q < b; q += 4096) ((volatile char *) p)[q] = 0;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(touch, t);
+    touch(0);
+    for (auto &t : th) t.join();
+    void *dp = nullptr;
+    if (hipHostRegister(p, len, hipHostRegisterDefault) != hipSuccess ||
+        hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || dp != (void *) p) {
+        // (kernels of the pipe read and write the staging through the HOST address: it must be the device's too)
+        (void) hipGetLastError();
+        if (dp) (void) hipHostUnregister(p);
+        munmap(base, len + huge);
+        g_reg_state.store(-1);
+        return false;
+    }
+    g_reg_state.store(1);
+    { std::lock_guard<std::mutex> lk(g_reg_mu); g_registered[p] = WtRegistered{base, len + huge}; }
+    *out = p;
+    return true;
+}
+
+static hipError_t wt_pin_raw_alloc(void **out, size_t bytes) {
+    if (wt_pin_by_register(out, bytes)) return hipSuccess;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault);
+}
+
+static void wt_pin_raw_free(void *q) {
+    WtRegistered r{nullptr, 0};
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        auto it = g_registered.find(q);
+        if (it != g_registered.end()) { r = it->second; g_registered.erase(it); }
+    }
+    if (r.base) { (void) hipHostUnregister(q); munmap(r.base, r.map_len); }
+    else (void) hipHostFree(q);
+}
+
 static hipError_t wt_host_alloc(void **out, size_t bytes) {
     if (bytes < 1) bytes = 1;
     bytes = wt_pool_round(bytes);
@@ -179,7 +273,7 @@ static hipError_t wt_host_alloc(void **out, size_t bytes) {
         }
     }
     const auto t_alloc0 = std::chrono::steady_clock::now();
-    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    hipError_t e = wt_pin_raw_alloc(out, bytes);
     if (e != hipSuccess) {
         // the host refuses to page-lock more while buffers rest in the pool: give them all back and try once more
         std::vector<void *> idle;
@@ -191,8 +285,8 @@ static hipError_t wt_host_alloc(void **out, size_t bytes) {
         }
         if (!idle.empty()) {
             (void) hipGetLastError();
-            for (void *x : idle) (void) hipHostFree(x);
-            e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+            for (void *x : idle) wt_pin_raw_free(x);
+            e = wt_pin_raw_alloc(out, bytes);
         }
     }
     if (e == hipSuccess && bytes >= (1u << 20)) {
@@ -201,7 +295,7 @@ static hipError_t wt_host_alloc(void **out, size_t bytes) {
         g_pinned_pool.misses++;
         g_pinned_pool.miss_bytes += bytes;
         static const bool trace = getenv("WTAMD_TRACE_POOL") != nullptr;
-        if (trace) fprintf(stderr, "[pool] hipHostMalloc %.1f MB in %.1f ms\n", bytes / 1048576.0,
+        if (trace) fprintf(stderr, "[pool] page-locked %.1f MB (%s) in %.1f ms\n", bytes / 1048576.0, g_registered.count(*out) ? "mmap + hipHostRegister" : "hipHostMalloc",
                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc0).count());
     }
     return e;
@@ -221,7 +315,7 @@ static void wt_host_free(void *q) {
             g_pinned_pool.size_of.erase(it);
         }
     }
-    (void) hipHostFree(q);
+    wt_pin_raw_free(q);
 }
 
 // Device buffers of a pipe, the same way: a pipe frees everything it holds when its reducer reaches the end of the data
@@ -602,6 +696,7 @@ int wtamd_pipe_create(const wtamd_pipe_config *cfg, wtamd_pipe **out) {
     if (cfg->flags & ~0u & ~WTAMD_PIPE_COMPRESS) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_create: unknown flag");
     const bool tile = cfg->desc.op == WTAMD_OP_MULTIPLEX;
     if ((cfg->flags & WTAMD_PIPE_COMPRESS) && tile) return wt_fail(WTAMD_ERR_ARG, "wtamd_pipe_create: the Multiplexer tile cannot be compressed");
+    wt_warmup_join();           // (wtamd_warmup_async: the runtime's start-up, if a helper thread is at it)
     if (wtamd_device_count() <= 0) return wt_fail(WTAMD_ERR_NODEVICE, "no HIP device visible");
     wtamd_pipe *p = new wtamd_pipe();
     (void) hipGetDevice(&p->device);
@@ -1340,7 +1435,7 @@ void wtamd_pool_trim(void) {
         g_dev_pool.free_list.clear();
         g_dev_pool.pooled = 0;
     }
-    for (void *x : host) (void) hipHostFree(x);
+    for (void *x : host) wt_pin_raw_free(x);
     for (void *x : dev) (void) hipFree(x);
 }
 
