@@ -450,6 +450,9 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None, level=1,
             if keep:
                 json.dump({"intervals": n_int, "sections": sections}, open(meta, "w"))
         size = sum(os.path.getsize(p_) for p_ in paths)
+        read_through_s = None
+        if not os.environ.get("WTAMD_BENCH_NO_READ_THROUGH"):
+            read_through_s = read_through(paths)[1]
         os.environ.pop("WTAMD_BW_DEVICE", None)
         starts = {}
         acc = 0
@@ -522,7 +525,7 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None, level=1,
                 fresh = json.loads(lines[-1]) if lines else {"error": (pr.stderr or "no output")[-300:]}
             except Exception as e:
                 fresh = {"error": repr(e)[:300]}
-        return {"fresh_process": fresh, "tracks": n_tracks, "op": op, "chromosomes_per_file": 24, "genome_scale": scale, "bp": genome_bp, "intervals": n_int, "zlib_level": level,
+        return {"fresh_process": fresh, "files_read_through_s": read_through_s, "tracks": n_tracks, "op": op, "chromosomes_per_file": 24, "genome_scale": scale, "bp": genome_bp, "intervals": n_int, "zlib_level": level,
                 "sections": sections, "file_bytes": size, "file_bytes_per_bp": size / genome_bp,
                 "pcie_h2d_roofline_bp_per_s": 63e9 / (size / genome_bp), "files_written_s": write_s, "generate_s": gen_s,
                 "files_dir": d.rsplit("/", 1)[0], "host_cores": effective_cores(),
@@ -533,6 +536,34 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None, level=1,
     finally:
         if not keep:
             shutil.rmtree(d, ignore_errors=True)
+
+
+def read_through(paths, threads=16):
+    """Reads every file once, untimed.  A tmpfs page that was just WRITTEN is read at half speed the first time (measured:
+    19-20 GB/s on the first pass over freshly written files, 40-44 GB/s on every later one, whatever posix_fadvise says --
+    the kernel's page-cache bookkeeping of the first access): without this the 'cold' run of the file leg measured the page
+    cache's first read of 90 GB (1.0 s of it at full scale: round 5) and not the library's cold start.  Input files of a
+    real invocation were written long before and have been read before."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(p):
+        fd = os.open(p, os.O_RDONLY)
+        try:
+            buf = bytearray(8 << 20)
+            mv = memoryview(buf)
+            off = 0
+            while True:
+                n = os.preadv(fd, [mv], off)
+                if n <= 0:
+                    break
+                off += n
+        finally:
+            os.close(fd)
+        return off
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max(1, min(threads, effective_cores()))) as ex:
+        total = sum(ex.map(one, paths))
+    return total, time.perf_counter() - t0
 
 
 def genome_file_scale(n_tracks, mean_run):

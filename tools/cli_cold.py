@@ -16,6 +16,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 if __name__ == "__main__":
+    os.environ["WTAMD_NO_TORCH"] = "1"          # this process links the system's HIP runtime only
     t_l0 = time.perf_counter()
     ctypes.CDLL(os.environ.get("WTAMD_LIB") or os.path.join(ROOT, "wiggletools_amd", "csrc", "libwiggletools_amd.so"), mode=ctypes.RTLD_GLOBAL)
     t_l1 = time.perf_counter()

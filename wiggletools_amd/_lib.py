@@ -45,6 +45,8 @@ def lib():
             "wiggletools_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
     try:
+        if os.environ.get("WTAMD_NO_TORCH"):     # (tools/cli_cold.py: a process that never touches torch, like the reference's CLI)
+            raise ImportError
         # PyTorch's HIP runtime goes first: a process that loads this library (and with it /opt/rocm's
         # libamdhip64) before torch ends up with two runtimes and torch.cuda.is_available() == False
         import torch  # noqa: F401

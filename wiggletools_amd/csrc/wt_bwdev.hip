@@ -22,6 +22,7 @@
 // HBM traffic: 4.8 B (compressed) + 2 x 12 B (plain, written and read twice) + 12 B per interval --
 // a few % of the reduce kernels' traffic; the inflate kernel is the one that costs time.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include <cstdint>
 #include <cstdlib>
@@ -281,14 +282,41 @@ __global__ void __launch_bounds__(64) wt_bw_scatter_kernel(const WtBwSection *se
 
 // sections resident per launch of the inflate kernel: CUs x wavefronts per CU x 64 lanes
 long long wt_bw_fill_sections(int num_cu) {
+    const void *kern = wt_bw_inflate_ring() == 64 ? (const void *) wt_bw_inflate_kernel<64> : (const void *) wt_bw_inflate_kernel<8>;
     int per_cu = 0;
-    const hipError_t e = wt_bw_inflate_ring() == 64
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wt_bw_inflate_kernel<64>, WT_BW_INF_LANES, 0)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wt_bw_inflate_kernel<8>, WT_BW_INF_LANES, 0);
-    if (e != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, WT_BW_INF_LANES, 0) != hipSuccess || per_cu < 1) {
         (void) hipGetLastError();
-        per_cu = 3;
+        per_cu = 0;
     }
+    // The runtime's occupancy calculator is not the hardware's dispatcher: the same code object gets 8 workgroups per CU from
+    // the HIP runtime PyTorch bundles and 4 from ROCm 7.2's own (round 5: a process linked against /opt/rocm sized its batches
+    // for half the lanes -- 98 batches of 55 296 sections where the other runtime cut 59 of 100 000 -- and inflated at 5.8
+    // instead of 8.1 sections / us).  What the workgroups of this kernel need is known: static LDS and registers
+    // (hipFuncGetAttributes) against the CU's 160 KB of LDS and 512 registers per SIMD lane; the larger of the two answers
+    // is used -- a batch twice the resident lanes costs a second round of the launch, half a batch wastes half the GPU.
+    hipFuncAttributes fa{};
+    int by_need = 0;
+    if (hipFuncGetAttributes(&fa, kern) == hipSuccess) {
+        int dev = 0;
+        (void) hipGetDevice(&dev);
+        int lds_cu = 0;
+        if (hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || lds_cu <= 0) { (void) hipGetLastError(); lds_cu = 160 * 1024; }
+        const int by_lds = fa.sharedSizeBytes > 0 ? lds_cu / (int) fa.sharedSizeBytes : 32;
+        const int regs = fa.numRegs > 0 ? (fa.numRegs + 7) & ~7 : 128;
+        int waves_simd = 512 / regs;
+        if (waves_simd > 8) waves_simd = 8;
+        if (waves_simd < 1) waves_simd = 1;
+        by_need = std::min(by_lds, 4 * waves_simd);      // (one wavefront per workgroup, four SIMDs per CU)
+        if (by_need > 32) by_need = 32;
+    } else {
+        (void) hipGetLastError();
+    }
+    if (const char *e = getenv("WTAMD_BW_WAVES_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 32) { per_cu = v; by_need = 0; } }
+    static const bool trace = getenv("WTAMD_TRACE") != nullptr;
+    if (trace) fprintf(stderr, "[bwdev] inflate kernel: %d workgroups per CU by the runtime's calculator, %d by LDS / registers (%d B, %d regs)\n", per_cu, by_need,
+                       (int) fa.sharedSizeBytes, (int) fa.numRegs);
+    if (by_need > per_cu) per_cu = by_need;
+    if (per_cu < 1) per_cu = 3;
     return (long long) num_cu * per_cu * WT_BW_INF_LANES;
 }
 
