@@ -126,7 +126,13 @@ struct WtParams {
     int32_t walk_ov;              // ... entries of the overflow list behind them
     int32_t walk_pair;            // ... 1: two lanes per stretch
     int32_t walk_off_at;          // ... byte offset, in the workgroup's slab, of the fallback's offsets off[W + 1]
+    int32_t walk_mwu;             // ... 1: the walking launch is MWUReduction's (wt_mwalk.h): lane h of a pair holds SET h's column
     int32_t lds_bytes;
+    // Mann-Whitney: 2 erf(-|U1 - mu| / sigma) for |U1 - mu| = k / 2, k = 0 .. mwu_kmax (the last entry: erf has reached -1 for good);
+    // filled on the host with the host's libm (wt_mwu_make_table, wt_plan.h).  NULL: the device's erf.
+    const double *mwu_table;
+    int32_t mwu_kmax;
+    int32_t pad1;
 };
 
 // Block-shared scalars (live in LDS at off_shared)
@@ -1015,6 +1021,21 @@ __device__ unsigned long long wt_prof2[8];
 // feeding the reference's tie state machine (setComparisons.c:335-359) in the reference's order --
 // the table's stable sort puts set-0 entries first inside a tie group, and tied set-0 entries are
 // interchangeable (same L, same t; `last` is positional).  No attribute slab, no second phase.
+// setComparisons.c:361-366 for U1 (a multiple of 1/2, whatever the tie state machine did): mu is an integer (:386, C int division),
+// so |U1 - mu| = k / 2 exactly and the reference's value is a function of the integer k alone -- read from a table the HOST
+// filled with the reference's own expression and the host's erf (bit-identical to what the reference prints on this
+// platform; the device's erf agrees to ~1e-16 and costs ~3 000 instructions per position, a fifth of the register-column
+// kernel).
+WT_DEV double wt_mwu_value(const WtParams &P, double U1, double mu, double sigma) {
+    if (P.mwu_table) {
+        const double d = U1 > mu ? U1 - mu : mu - U1;
+        const double k2 = d * 2.0;
+        const int k = k2 >= (double) P.mwu_kmax ? P.mwu_kmax : (int) k2;
+        return P.mwu_table[k];
+    }
+    return (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
+}
+
 template <int NR>
 WT_DEV double wt_mwu_regs(const WtParams &P, uint32_t *col, const uint32_t *col2, float *xs, int colstride) {
     constexpr int H = NR / 2;
@@ -1052,7 +1073,7 @@ WT_DEV double wt_mwu_regs(const WtParams &P, uint32_t *col, const uint32_t *col2
         }
         x = xn;
     }
-    return (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
+    return wt_mwu_value(P, U1, mu, sigma);
 }
 
 template <int OP, class ValT, class ScrT, int K, int NR>
@@ -1322,7 +1343,7 @@ WT_DEV double wt_mwu_tail(const WtParams &P, char *attr_base, int col, int colst
             if (ties) U1 += ties / 2.0;
         }
     }
-    return (U1 > mu) ? 2 * erf((mu - U1) / sigma) : 2 * erf((U1 - mu) / sigma);
+    return wt_mwu_value(P, U1, mu, sigma);
 }
 
 template <int OP, class ValT, class ScrT, int K, int NR>
@@ -1748,5 +1769,6 @@ WT_DEV void wt_index_apply(const WtParams &P, WtIndexCursor &c, long long g, int
 
 #include "wt_delta.h"
 #include "wt_walk.h"
+#include "wt_mwalk.h"
 
 #endif  // WT_CORE_H_

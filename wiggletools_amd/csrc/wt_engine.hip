@@ -891,6 +891,8 @@ struct wtamd_trackset {
     int64_t *d_chrom_run_off = nullptr;         // scratch when the caller passes none
     char *d_gscratch = nullptr;                 // median / MWU columns of very many tracks (grown on demand)
     size_t gscratch_bytes = 0;
+    double *d_mwu_table = nullptr;              // MWUReduction's last step as a table (wt_mwu_make_table), for set sizes mwu_n1 / mwu_n2
+    int mwu_n1 = -1, mwu_n2 = -1, mwu_kmax = 0;
     std::map<int, WtWindows> windows;           // keyed by W
     hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
     bool have_index_time = false, have_reduce_time = false;
@@ -1116,7 +1118,7 @@ int wtamd_trackset_create_device(const wtamd_tracks *t, wtamd_trackset **out) {
 void wtamd_trackset_destroy(wtamd_trackset *ts) {
     if (!ts) return;
     if (ts->owns) { (void) hipFree(ts->d_start); (void) hipFree(ts->d_finish); (void) hipFree(ts->d_value); }
-    (void) hipFree(ts->d_seg_off); (void) hipFree(ts->d_defaults); (void) hipFree(ts->d_counters); (void) hipFree(ts->d_chrom_run_off); (void) hipFree(ts->d_gscratch);
+    (void) hipFree(ts->d_seg_off); (void) hipFree(ts->d_defaults); (void) hipFree(ts->d_counters); (void) hipFree(ts->d_chrom_run_off); (void) hipFree(ts->d_gscratch); (void) hipFree(ts->d_mwu_table);
     if (ts->h_counters) (void) hipHostFree(ts->h_counters);
     if (ts->h_debug) (void) hipHostFree(ts->h_debug);
     for (auto &kv : ts->windows) wt_free_windows(kv.second);
@@ -1317,6 +1319,11 @@ static bool wt_pick_plan(const wtamd_trackset *ts, int op, int n_set0, WtPlan &p
     if (op == WT_OP_MEDIAN && !ts->value_f64 && !getenv("WTAMD_NO_WALK"))
         if (const int nr = wt_regcol_slots(ts->n_tracks, op, ts->scratch_f32, n_set0))
             if (wt_make_walk_plan(plan, ts->n_tracks, nr, wt_events_per_bp(ts))) return true;
+    // MWUReduction over float tracks walks too (wt_mwalk.h; WTAMD_NO_MWALK=1: the bitmap kernel's register columns)
+    // (same domain as its register columns, wt_regcol_slots: float tracks, float-exact defaults, at most 64 per set)
+    if (op == WT_OP_MWU && !ts->value_f64 && !getenv("WTAMD_NO_MWALK") && !getenv("WTAMD_NO_WALK"))
+        if (const int nr = wt_regcol_slots(ts->n_tracks, op, ts->scratch_f32, n_set0))
+            if (wt_make_walk_plan(plan, ts->n_tracks, nr, wt_events_per_bp(ts), 160 * 1024, n_set0)) return true;
     return wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err, 80 * 1024, 160 * 1024, n_set0);
 }
 
@@ -1575,6 +1582,19 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
     L.P.o_tile = d_tile; L.P.o_inplay = d_inplay;
     L.T = plan.T; L.lds = plan.lds_bytes; L.stream = s; L.num_cu = ts->num_cu;
     L.gscratch = &ts->d_gscratch; L.gscratch_bytes = &ts->gscratch_bytes;
+    if (op == WT_OP_MWU && !getenv("WTAMD_MWU_DEVICE_ERF")) {
+        const int n1 = n_set0, n2 = ts->n_tracks - n_set0;
+        if (ts->mwu_n1 != n1 || ts->mwu_n2 != n2 || !ts->d_mwu_table) {
+            std::vector<double> t;
+            wt_mwu_make_table(n1, n2, t);
+            if (ts->d_mwu_table) { WT_HIP(hipStreamSynchronize(s)); (void) hipFree(ts->d_mwu_table); ts->d_mwu_table = nullptr; }
+            WT_HIP(hipMalloc((void **) &ts->d_mwu_table, sizeof(double) * t.size()));
+            WT_HIP(hipMemcpy(ts->d_mwu_table, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+            ts->mwu_n1 = n1; ts->mwu_n2 = n2; ts->mwu_kmax = (int) t.size() - 1;
+        }
+        L.P.mwu_table = ts->d_mwu_table;
+        L.P.mwu_kmax = ts->mwu_kmax;
+    }
     if (plan.delta) {
         const int64_t nwin = w->tab.n_windows > 0 ? w->tab.n_windows : 1;
         if (w->cap_bad < nwin) {
@@ -1613,7 +1633,7 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
     ts->stats.n_windows = w->tab.n_windows;
     ts->stats.window_bp = plan.W;
     ts->stats.lds_bytes = plan.lds_bytes;
-    ts->stats.kernel = plan.delta ? 1 : (plan.walk_S ? 2 : 0);     // (2: median by walking, csrc/wt_walk.h)
+    ts->stats.kernel = plan.delta ? 1 : (plan.walk_S ? (plan.walk_mwu ? 3 : 2) : 0);     // (2: median by walking, csrc/wt_walk.h; 3: MWU by walking, csrc/wt_mwalk.h)
     ts->stats.patched_windows = 0;
     if (n_runs) {
         WT_HIP(hipMemcpyAsync(ts->h_counters, ts->d_counters, sizeof(unsigned long long) * WT_CTR_N, hipMemcpyDeviceToHost, s));

@@ -6,6 +6,7 @@
 #define WT_PLAN_H_
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <string>
@@ -36,6 +37,7 @@ struct WtPlan {
     int walk_ov = 0;        // ... entries of the overflow list
     int walk_off_at = 0;    // ... where the fallback's offsets start in the workgroup's slab (bytes)
     int walk_pair = 0;      // ... 1: two lanes per stretch (half the column each)
+    int walk_mwu = 0;       // ... 1: MWUReduction by walking (wt_mwalk.h): the two lanes of a stretch hold one SET each
     int off_wcol = 0, off_wcnt = 0, off_woff = 0, off_wtot = 0, off_wbase = 0, off_wgt = 0, off_wncov = 0, off_wfe = 0, off_wdk = 0, off_wguess = 0;
 };
 
@@ -183,7 +185,9 @@ static inline void wt_delta_defaults_params(const double *defaults, int n_tracks
 // slots (WT_WALK_OV_SCAN: a lane scans the whole list for every such position) falls back to sorting its events into the
 // same memory, in as many rounds as it takes: at least the 2 N S events the stretch of one lane can hold fit.
 // events_per_bp: what the data is expected to hold (the host's estimate from the run count and the covered span; <= 0: unknown).
-static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double events_per_bp, int hard_limit = 160 * 1024) {
+// mwu_n_set0 >= 0: MWUReduction by walking (wt_mwalk.h) -- always two lanes per stretch, lane h of a pair holds the column of
+// SET h (max(n1, n2) rows); 1 <= n1, n2 <= 64.
+static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double events_per_bp, int hard_limit = 160 * 1024, int mwu_n_set0 = -1) {
     // One lane per stretch: 256 lanes x 32 positions (an 8192-bp window, one workgroup per CU) when the columns fit, else fewer
     // positions, then fewer lanes.  Measured (MI355X, chromosome 21, 100 tracks): 256 x 32 11.8 ms, 64 x 32 11.9, 256 x 16 12.6,
     // 128 x 32 12.8, 128 x 16 14.3: the per-window chains of dependent loads are what the wider window saves.
@@ -191,7 +195,10 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double eve
     // per CU: 256 lanes = 128 stretches x 16 positions (a 2048-bp window, 72 KB, two workgroups per CU) 9.9-10.0 ms, 64 x 32
     // the same, 128 x 16 10.0, 256 x 8 10.6, 512 lanes (one workgroup of 8 waves) x 16 / 32 11.4-11.5.
     const char *eT = getenv("WTAMD_WALK_T"), *eS = getenv("WTAMD_WALK_S"), *eP = getenv("WTAMD_WALK_PAIR");
-    const int pair = eP ? (atoi(eP) != 0 ? 1 : 0) : WT_WALK_PAIR_DEFAULT;
+    const bool mwu = mwu_n_set0 >= 0;
+    const int n_big = mwu ? std::max(mwu_n_set0, n_tracks - mwu_n_set0) : 0;
+    if (mwu && (mwu_n_set0 < 1 || n_tracks - mwu_n_set0 < 1 || n_big > 64)) return false;
+    const int pair = mwu ? 1 : (eP ? (atoi(eP) != 0 ? 1 : 0) : WT_WALK_PAIR_DEFAULT);
     const int wantT = eT ? atoi(eT) : 256, wantS = eS ? atoi(eS) : (pair ? 16 : 32);
     // (pair mode: twice through the candidates -- first only what leaves room for a second workgroup on the CU: two
     //  workgroups of 4 waves beat one of 8, their phases overlap)
@@ -204,11 +211,11 @@ static inline bool wt_make_walk_plan(WtPlan &p, int n_tracks, int nr, double eve
         if (S != 4 && S != 8 && S != 16 && S != 32) continue;
         if (n_tracks > T) continue;
         WtPlan q;
-        q.T = T; q.W = (T >> pair) * S; q.n_words = q.W / 64; q.ppt = S; q.walk_S = S; q.regcol = nr; q.walk_pair = pair;
+        q.T = T; q.W = (T >> pair) * S; q.n_words = q.W / 64; q.ppt = S; q.walk_S = S; q.regcol = nr; q.walk_pair = pair; q.walk_mwu = mwu ? 1 : 0;
         if (q.W < 64) continue;
         q.chunk_tracks = n_tracks; q.n_chunks = 1;
         int o = 0;
-        q.off_wcol = o;   o = wt_align16(o + (((pair ? (n_tracks + 1) / 2 : n_tracks) + 7) & ~7) * T * 4);        // (WT_WALK_PAD rows)
+        q.off_wcol = o;   o = wt_align16(o + (((mwu ? n_big : (pair ? (n_tracks + 1) / 2 : n_tracks)) + 7) & ~7) * T * 4);        // (WT_WALK_PAD rows)
         q.off_wcnt = o;   o = wt_align16(o + q.W * 4);
         q.off_woff = 0;                                                             // (the fallback's offsets live in the slab)
         q.off_wtot = o;   o = wt_align16(o + T * 4);
@@ -365,6 +372,21 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
     return false;
 }
 
+// MWUReduction's last step as a table (WtParams::mwu_table): entry k = the reference's value for |U1 - mu| = k / 2, computed
+// with the reference's own expression (setComparisons.c:361-366, mu and sigma from the constructor's C integer divisions,
+// :386-387) and THIS host's erf; the table ends where erf has reached -1 exactly (every larger k reads the last entry).
+static inline void wt_mwu_make_table(int n1, int n2, std::vector<double> &t) {
+    const double mu = (double) (n1 * n2 / 2);
+    const double sigma = sqrt((double) (n1 * n2 * (n1 + n2 + 1) / 12));
+    t.clear();
+    for (int k = 0; k < (1 << 20); k++) {
+        const double U1 = mu + 0.5 * (double) k;            // (U1 > mu: the first branch; U1 < mu gives the same argument)
+        const double v = k == 0 ? 2 * erf((U1 - mu) / sigma) : 2 * erf((mu - U1) / sigma);
+        t.push_back(v);
+        if (v == -2.0) break;                               // (sigma == 0: entry 0 is NaN -- 0 / 0 -- and entry 1 already -2)
+    }
+}
+
 static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.W = p.W; P.n_words = p.n_words; P.spitch = p.spitch; P.cpitch = p.cpitch; P.count_segs = p.count_segs;
     P.chunk_tracks = p.chunk_tracks; P.n_chunks = p.n_chunks;
@@ -381,6 +403,7 @@ static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.off_wcol = p.off_wcol; P.off_wcnt = p.off_wcnt; P.off_woff = p.off_woff; P.off_wtot = p.off_wtot; P.off_wbase = p.off_wbase;
     P.off_wgt = p.off_wgt; P.off_wncov = p.off_wncov; P.off_wfe = p.off_wfe; P.off_wdk = p.off_wdk; P.walk_S = p.walk_S;
     P.off_wguess = p.off_wguess; P.walk_capp = p.walk_capp; P.walk_ov = p.walk_ov; P.walk_off_at = p.walk_off_at; P.walk_pair = p.walk_pair;
+    P.walk_mwu = p.walk_mwu;
     P.off_shared = p.off_shared; P.lds_bytes = p.lds_bytes;
 }
 

@@ -81,7 +81,17 @@ struct WtWalkCtx {
     int pair;           // 1: TWO lanes per stretch -- lane 2q + h holds the tracks i = h (mod 2) of stretch q (row i >> 1): half the
                         //    column per lane, twice the lanes per CU; counts and candidates are exchanged inside the lane pair
     int nstr;           // stretches of the window (lanes, or half of them)
+    int mwu;            // 1: MWUReduction's walk (wt_mwalk.h; pair mode): the lane's "half" is its SET, row r of lane h holds track
+                        //    r of set h -- tracks are renumbered 2 r + h wherever this file says "track" (wt_mw_vtrack)
 };
+
+// MWUReduction by walking: track -> its number in the pair mode's terms (parity = set = the lane of the pair, >> 1 = row), and back
+WT_DEV int wt_mw_vtrack(const WtParams &P, int trk) { return trk < P.n_set0 ? 2 * trk : 2 * (trk - P.n_set0) + 1; }
+WT_DEV int wt_mw_row_track(const WtParams &P, int r, int h) {
+    const int n1 = P.n_set0, n2 = P.n_tracks - P.n_set0;
+    if (h == 0) return r < n1 ? r : -1;
+    return r < n2 ? n1 + r : -1;
+}
 
 WT_DEV void wt_walk_ctx_init(WtWalkCtx &w, const WtParams &P, char *lds, char *slab) {
     w.col = (uint32_t *) (lds + P.off_wcol);
@@ -101,8 +111,10 @@ WT_DEV void wt_walk_ctx_init(WtWalkCtx &w, const WtParams &P, char *lds, char *s
     w.ov_cap = (uint32_t) (P.walk_ov < WT_WALK_OV_SCAN ? P.walk_ov : WT_WALK_OV_SCAN);
     w.novf = w.guess + 1;
     w.pair = P.walk_pair;
+    w.mwu = P.walk_mwu;
     w.nstr = P.W / P.walk_S;
-    w.npad = ((w.pair ? (P.n_tracks + 1) / 2 : P.n_tracks) + WT_WALK_PAD - 1) & ~(WT_WALK_PAD - 1);
+    const int n_big = P.n_set0 > P.n_tracks - P.n_set0 ? P.n_set0 : P.n_tracks - P.n_set0;
+    w.npad = ((w.mwu ? n_big : (w.pair ? (P.n_tracks + 1) / 2 : P.n_tracks)) + WT_WALK_PAD - 1) & ~(WT_WALK_PAD - 1);
     w.S = P.walk_S;
     w.logS = 0;
     while ((1 << w.logS) < w.S) w.logS++;
@@ -149,11 +161,11 @@ WT_DEV void wt_walk_defaults(const WtParams &P, WtWalkCtx &w, int tid, int nt) {
 // per window: no events, nothing covered, every column holds the defaults
 WT_DEV void wt_walk_zero(const WtParams &P, const WtCtx &c, WtWalkCtx &w, int tid, int nt) {
     for (int x = tid; x < P.W; x += nt) w.cnt[x] = 0;
-    if (tid < w.nstr) w.ncov[tid] = 0;
+    if (tid < w.nstr || w.mwu) w.ncov[tid] = 0;         // (MWU: per lane -- the tracks of the lane's SET in play)
     const int N = P.n_tracks, h = w.pair ? tid & 1 : 0;
     for (int r = 0; r < w.npad; r++) {
-        const int i = w.pair ? 2 * r + h : r;               // the track of row r of this lane's column
-        w.col[r * nt + tid] = i < N ? w.dkey[i] : 0xffffffffu;      // (rows past the tracks: above every key, never NaN's)
+        const int i = w.mwu ? wt_mw_row_track(P, r, h) : (w.pair ? 2 * r + h : r);      // the track of row r of this lane's column
+        w.col[r * nt + tid] = (i >= 0 && i < N) ? w.dkey[i] : 0xffffffffu;      // (rows past the tracks: above every key, never NaN's)
     }
     if (tid == 0) w.novf[0] = 0;
 }
@@ -271,9 +283,10 @@ WT_DEV void wt_walk_count1(const WtParams &P, WtWalkCtx &w, int nt, int32_t w0, 
     const int32_t cs = s - w0, cf = f - w0;     // cf >= 0: the window's runs finish at or beyond w0
     if (cs >= width) { my_next = s < my_next ? s : my_next; return; }
     const uint32_t key = wt_walk_key(vb);
-    if (cs >= 0) wt_walk_place(w, cs, key, (uint32_t) trk | ((first || ps != s) ? WT_WALK_INC : 0u));
+    const int vt = w.mwu ? wt_mw_vtrack(P, trk) : trk;      // (the track's number in the events and the columns)
+    if (cs >= 0) wt_walk_place(w, cs, key, (uint32_t) vt | ((first || ps != s) ? WT_WALK_INC : 0u));
     if (cf < width) {
-        if (last || ns != f) wt_walk_place(w, cf, w.dkey[trk], (uint32_t) trk | WT_WALK_DEC);      // (else the next run's start event says it all)
+        if (last || ns != f) wt_walk_place(w, cf, w.dkey[trk], (uint32_t) vt | WT_WALK_DEC);      // (else the next run's start event says it all)
     } else {
         my_next = f < my_next ? f : my_next;
     }
@@ -281,10 +294,10 @@ WT_DEV void wt_walk_count1(const WtParams &P, WtWalkCtx &w, int nt, int32_t w0, 
     int l = cs < 0 ? 0 : (cs >> w.logS) + 1;       // (no division: 30 instructions each on this machine)
     int lh = cf >> w.logS;
     if (lh > w.nstr - 1) lh = w.nstr - 1;
-    const int row = (trk >> w.pair) * nt, half = trk & w.pair;
+    const int row = (vt >> w.pair) * nt, half = vt & w.pair;
     for (; l <= lh; l++) {
         w.col[row + ((l << w.pair) | half)] = key;
-        wt_lds_addi32(&w.ncov[l], 1);
+        wt_lds_addi32(&w.ncov[w.mwu ? ((l << 1) | half) : l], 1);
     }
 }
 
@@ -303,7 +316,7 @@ WT_DEV void wt_walk_scatter1(const WtParams &P, WtWalkCtx &w, int32_t w0, int32_
 #endif
             WtWalkEvent e;
             e.key = wt_walk_key(vb);
-            e.meta = (uint32_t) trk | ((first || ps != s) ? WT_WALK_INC : 0u);
+            e.meta = (uint32_t) (w.mwu ? wt_mw_vtrack(P, trk) : trk) | ((first || ps != s) ? WT_WALK_INC : 0u);
             w.slab[at - ev0 + old - 1u] = e;
         }
     }
@@ -317,7 +330,7 @@ WT_DEV void wt_walk_scatter1(const WtParams &P, WtWalkCtx &w, int32_t w0, int32_
 #endif
             WtWalkEvent e;
             e.key = w.dkey[trk];
-            e.meta = (uint32_t) trk | WT_WALK_DEC;
+            e.meta = (uint32_t) (w.mwu ? wt_mw_vtrack(P, trk) : trk) | WT_WALK_DEC;
             w.slab[at - ev0 + old - 1u] = e;
         }
     }

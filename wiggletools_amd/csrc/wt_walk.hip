@@ -135,10 +135,88 @@ __global__ void __launch_bounds__(MAXT, 1) wt_walk_kernel(const WtParams P) {
 #endif
 }
 
+// MWUReduction by walking (wt_mwalk.h): the same window machinery; the two lanes of a stretch hold one SET each.  Which
+// positions emit a run is only known once the events have been applied (tracks in play per set), so the window's run count
+// goes to the look-back chain after the walk.
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT, 1) wt_mwalk_kernel(const WtParams P) {
+    extern __shared__ __attribute__((aligned(16))) char wt_lds[];
+    WtCtx c{};
+    c.sh = (WtShared *) (wt_lds + P.off_shared);
+    WtDeltaCtx d;
+    wt_delta_ctx_init(d, P, wt_lds);
+    WtWalkCtx w;
+    wt_walk_ctx_init(w, P, wt_lds, P.g_scratch + (size_t) blockIdx.x * (size_t) P.g_scratch_slab);
+    w.pair = 1; w.mwu = 1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) {
+        const long long k0 = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+        c.sh->ticket = k0;
+        if (k0 < P.n_windows) wt_phase_header(P, c, k0);
+    }
+    wt_walk_defaults(P, w, tid, nt);
+    __syncthreads();
+    for (;;) {
+        const long long k = c.sh->ticket;
+        if (k >= P.n_windows) break;
+        wt_walk_zero(P, c, w, tid, nt);
+        wt_delta_ranges_w1(P, c, d, 0, tid, nt);
+        __syncthreads();
+        wt_walk_ranges_w2(d, tid, nt);
+        __syncthreads();
+        wt_walk_pass<false>(P, c, w, d, 0u, 0u, tid, nt);
+        __syncthreads();                        // the events are in the slab, the counts in cnt[]
+        WtWalkLane L;
+        wt_mwalk_events(P, c, w, L, tid, nt);
+        if (w.novf[0] <= w.ov_cap) {            // (uniform) every position's events fit its slots + the overflow list
+            wt_mwalk_lane<true>(P, c, w, L, 0u, tid, nt);
+            __syncthreads();
+        } else {
+            // a window denser than that: its events sorted by position into the same memory, as many stretches at a time as fit
+            __syncthreads();
+            wt_walk_offsets1(P, w, tid, nt);
+            __syncthreads();
+            wt_walk_scan_b(w, tid, nt);
+            __syncthreads();
+            wt_walk_offsets2(P, w, tid, nt);
+            __syncthreads();
+            for (int l0 = 0; l0 < w.nstr;) {
+                const int l1 = wt_walk_round_end(w, l0, nt);
+                const uint32_t ev0 = w.base[l0 << 1], ev1 = w.base[l1 << 1];
+                if (ev1 > ev0) {                    // (uniform)
+                    wt_walk_pass<true>(P, c, w, d, ev0, ev1, tid, nt);
+                    __syncthreads();
+                    if ((tid >> 1) >= l0 && (tid >> 1) < l1) wt_mwalk_lane<false>(P, c, w, L, ev0, tid, nt);
+                    __syncthreads();                // before the next round reuses the slab
+                }
+                l0 = l1;
+            }
+        }
+        // the lanes' run offsets, the window's run count
+        wt_walk_scan_a(w, wt_walk_emit_count(w, L, tid), tid, nt);
+        __syncthreads();
+        wt_walk_scan_b(w, tid, nt);
+        __syncthreads();
+        const unsigned long long mine = w.base[nt];
+        if (tid == 0) wt_lookback_publish(P, c, k, mine);
+        if (tid < 64) wt_lookback_complete(P, c, k, tid, mine);
+        __syncthreads();
+        wt_mwalk_write(P, c, w, L, tid, nt);
+        __syncthreads();
+        if (tid == 0) {
+            wt_window_stats(P, c);
+            const long long kn = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+            c.sh->ticket = kn;
+            if (kn < P.n_windows) wt_phase_header(P, c, kn);
+        }
+        __syncthreads();
+    }
+}
+
 // (nr: the register-column slots the bitmap kernel would use for this track count -- eligibility only)
 hipError_t wt_walk_launch(WtParams &P, int nr, int T, int lds, int num_cu, char **gscratch, size_t *gscratch_bytes, hipStream_t s, int *grid) {
     (void) nr;
-    auto kern = P.walk_pair ? (T > 256 ? wt_walk_kernel<512, true> : wt_walk_kernel<256, true>) : wt_walk_kernel<256, false>;
+    auto kern = P.walk_mwu ? wt_mwalk_kernel<256> : (P.walk_pair ? (T > 256 ? wt_walk_kernel<512, true> : wt_walk_kernel<256, true>) : wt_walk_kernel<256, false>);
     hipError_t e = hipSuccess;
     if (lds > 48 * 1024) {
         e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
