@@ -779,7 +779,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
     value = bp_per_pass * passes / elapsed
     kern = stats_last.get("kernel", 0)
     vt = "f64" if f64 else "f32"
-    kernel = ("wt_delta_kernel<%s>" % ops[-1]) if kern == 1 else ("wt_walk_kernel" if kern == 2 else "wt_reduce_kernel<%s,%s>" % (ops[-1], vt))
+    kernel = ("wt_delta_kernel<%s>" % ops[-1]) if kern == 1 else ("wt_walk_kernel" if kern == 2 else ("wt_mwalk_kernel" if kern == 3 else "wt_reduce_kernel<%s,%s>" % (ops[-1], vt)))
     # algorithmic bytes of the fused multiplex+reduce launches of ONE pass: every input run read
     # once per launch (start, finish, value = 12 B; 16 B for float64 values), the two window-index rows per
     # window, every output run written once (start, finish, f64 value = 16 B).  DESIGN.md 4.6.
@@ -803,10 +803,10 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
     bound = "hbm"
     note = None
     issue = None
-    if kern in (0, 2):
+    if kern in (0, 2, 3):
         o = ops[-1]
         if o in ("median", "wilcoxon", "mwu"):
-            bound, note = "issue", (("median by walking (csrc/wt_walk.h)" if kern == 2 else "register-column reducer") +
+            bound, note = "issue", (("median by walking (csrc/wt_walk.h)" if kern == 2 else ("MWU by walking (csrc/wt_mwalk.h)" if kern == 3 else "register-column reducer")) +
                                     ": bound by instruction issue and latency, not by HBM -- the frac against the HBM peak is "
                                     "reported for the record only (DESIGN 10); roofline.issue prices it against the VALU issue peak")
             # VALU instructions per output run from the SQ counters of an earlier profile (profiles/issue.json, like
@@ -815,7 +815,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
             ipath = os.path.join(ROOT, "profiles", "issue.json")
             if os.path.exists(ipath):
                 try:
-                    ij = json.load(open(ipath)).get(("median_walk" if kern == 2 else "median") if o == "median" else "wilcoxon")
+                    ij = json.load(open(ipath)).get(("median_walk" if kern == 2 else "median") if o == "median" else ("wilcoxon_walk" if kern == 3 else "wilcoxon"))
                     if ij:
                         peak = 256 * 4 * 2.4e9 / 4.0
                         ach = ij["valu_instructions_per_output_run"] * tot_runs / (kernel_ms_sum * 1e-3)

@@ -25,7 +25,8 @@ def build(force=False):
             os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc", "wt_core.h"),
             os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc", "wt_plan.h"),
             os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc", "wt_delta.h"),
-            os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc", "wt_walk.h")]
+            os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc", "wt_walk.h"),
+            os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc", "wt_mwalk.h")]
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
         return so
     if force and os.path.exists(so):
@@ -40,7 +41,7 @@ def build_dropin(force=False):
     csrc = os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc")
     srcs = [os.path.join(HERE, "wt_emu.cpp"), os.path.join(HERE, "wt_pipe_emu.cpp"),
             os.path.join(csrc, "wt_iter_abi.cpp"), os.path.join(csrc, "wt_defaults.cpp"), os.path.join(csrc, "wt_bigwig.cpp")]
-    deps = srcs + [os.path.join(csrc, h) for h in ("wt_core.h", "wt_plan.h", "wt_delta.h", "wt_walk.h", "wt_bufreader.h", "wt_inflate.h", "wt_bwdev_core.h",
+    deps = srcs + [os.path.join(csrc, h) for h in ("wt_core.h", "wt_plan.h", "wt_delta.h", "wt_walk.h", "wt_mwalk.h", "wt_bufreader.h", "wt_inflate.h", "wt_bwdev_core.h",
                                                     "wt_mapop.h", "wt_bigwig_int.h")] + \
         [os.path.join(HERE, "..", "..", "include", "wiggletools_amd.h")]
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in deps):

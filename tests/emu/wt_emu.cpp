@@ -167,6 +167,60 @@ struct EmuRun {
             wt_window_stats(P, c);
         }
     }
+    // wt_mwalk_kernel, phase by phase (the two lanes of a stretch side by side: they exchange values, wt_pair_xchg)
+    void run_mwalk() {
+        WtCtx c{};
+        c.sh = (WtShared *) (lds.data() + P.off_shared);
+        WtDeltaCtx d;
+        wt_delta_ctx_init(d, P, lds.data());
+        std::vector<char> slab((size_t) P.g_scratch_slab + 64);
+        WtWalkCtx w;
+        wt_walk_ctx_init(w, P, lds.data(), slab.data());
+        const int T = plan.T;
+        for (int t = 0; t < T; t++) wt_walk_defaults(P, w, t, T);
+        std::vector<WtWalkLane> L(T);
+        for (;;) {
+            const long long k = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
+            if (k >= P.n_windows) break;
+            wt_phase_header(P, c, k);
+            for (int t = 0; t < T; t++) wt_walk_zero(P, c, w, t, T);
+            for (int t = 0; t < T; t++) wt_delta_ranges1(P, c, d, 0, t, T);
+            for (int t = 0; t < T; t++) wt_walk_ranges3(d, t, T);
+            for (int t = 0; t < T; t++) wt_walk_pass<false>(P, c, w, d, 0u, 0u, t, T);
+            for (int t = 0; t < T; t++) wt_mwalk_events(P, c, w, L[t], t, T);
+            auto walk_lanes = [&](int l0, int l1, uint32_t ev0, bool fixed) {
+                for (int q = l0; q < l1; q++) {
+                    std::thread odd([&, q] { if (fixed) wt_mwalk_lane<true>(P, c, w, L[2 * q + 1], ev0, 2 * q + 1, T); else wt_mwalk_lane<false>(P, c, w, L[2 * q + 1], ev0, 2 * q + 1, T); });
+                    if (fixed) wt_mwalk_lane<true>(P, c, w, L[2 * q], ev0, 2 * q, T); else wt_mwalk_lane<false>(P, c, w, L[2 * q], ev0, 2 * q, T);
+                    odd.join();
+                }
+            };
+            if (w.novf[0] <= w.ov_cap) {
+                n_rounds++;
+                walk_lanes(0, w.nstr, 0u, true);
+            } else {
+                n_fallback++;
+                for (int t = 0; t < T; t++) wt_walk_offsets1(P, w, t, T);
+                for (int t = 0; t < T; t++) wt_walk_scan_b(w, t, T);
+                for (int t = 0; t < T; t++) wt_walk_offsets2(P, w, t, T);
+                for (int l0 = 0; l0 < w.nstr;) {
+                    const int l1 = wt_walk_round_end(w, l0, T);
+                    const uint32_t ev0 = w.base[l0 << 1], ev1 = w.base[l1 << 1];
+                    if (ev1 > ev0) {
+                        n_rounds++;
+                        for (int t = 0; t < T; t++) wt_walk_pass<true>(P, c, w, d, ev0, ev1, t, T);
+                        walk_lanes(l0, l1, ev0, false);
+                    }
+                    l0 = l1;
+                }
+            }
+            for (int t = 0; t < T; t++) wt_walk_scan_a(w, wt_walk_emit_count(w, L[t], t), t, T);
+            for (int t = 0; t < T; t++) wt_walk_scan_b(w, t, T);
+            wt_phase_lookback(P, c, k, (unsigned long long) w.base[T]);
+            for (int t = 0; t < T; t++) wt_mwalk_write(P, c, w, L[t], t, T);
+            wt_window_stats(P, c);
+        }
+    }
     long long n_rounds = 0, n_fallback = 0;
 
     template <int OP, bool DF = false>
@@ -279,6 +333,9 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
             bool walk = false;
             if (op == WT_OP_MEDIAN && !value_is_f64 && !o_tile && !getenv("WTAMD_NO_WALK"))
                 if (const int nr = wt_regcol_slots(n_tracks, op, s32, n_set0)) walk = wt_make_walk_plan(R.plan, n_tracks, nr, 0.0);
+            // ... and so does MWU (wt_mwalk.h)
+            if (op == WT_OP_MWU && !value_is_f64 && !o_tile && !getenv("WTAMD_NO_MWALK") && !getenv("WTAMD_NO_WALK"))
+                if (const int nr = wt_regcol_slots(n_tracks, op, s32, n_set0)) walk = wt_make_walk_plan(R.plan, n_tracks, nr, 0.0, 160 * 1024, n_set0);
             if (!walk && !wt_make_plan(n_tracks, op, s32, R.plan, err, 80 * 1024, 160 * 1024, n_set0)) { fprintf(stderr, "wtemu: %s\n", err.c_str()); return -10; }
         }
         WtWindowTables tab;
@@ -299,6 +356,11 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         P.capacity = capacity; P.o_start = o_start; P.o_finish = o_finish; P.o_value = o_value;
         P.chrom_run_off = chrom_run_off; P.o_tile = o_tile; P.o_inplay = o_inplay;
         wt_plan_to_params(R.plan, P);
+        std::vector<double> mwu_table;
+        if (op == WT_OP_MWU && !getenv("WTAMD_MWU_DEVICE_ERF")) {
+            wt_mwu_make_table(n_set0, n_tracks - n_set0, mwu_table);
+            P.mwu_table = mwu_table.data(); P.mwu_kmax = (int) mwu_table.size() - 1;
+        }
         if (delta) { P.bad_list = bad_list.data(); P.bad_goff = bad_goff.data(); wt_delta_defaults_params(defaults, n_tracks, P); }
         // few inexact windows: the general kernel rewrites the values of just those (the engine's
         // wt_patch_kernel); many: it redoes everything
@@ -343,6 +405,8 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
                 case WT_OP_CV: R.run_delta<WT_OP_CV>(); break;
                 default: R.run_delta<WT_OP_STDDEV>(); break;
                 }
+            } else if (R.plan.walk_S && R.plan.walk_mwu) {
+                R.run_mwalk();
             } else if (R.plan.walk_S) {
                 R.run_walk();
             } else if (!wt_dispatch(op, value_is_f64 != 0, s32, R.plan.ppt, R.plan.n_chunks > 1 || R.plan.scratch_slab > 0, R, R.plan.regcol)) {

@@ -498,7 +498,9 @@ def test_plan_policy_snapshot():
     p = plan(100, "median", no_walk=1)
     assert (p["W"], p["T"], p["lds"] < 32 * 1024) == (512, 256, True) and p["scratch_slab"] == 0     # round 2: value column in REGISTERS, LDS = bitmaps only, 2 positions per lane
     p = plan(100, "mwu", n_set0=50)
-    assert (p["W"], p["T"]) == (512, 256) and p["lds"] < 80 * 1024       # register columns + the sorted set 0 (50 x 4 B per lane) in LDS, 2 positions per lane
+    assert (p["walk"], p["W"], p["T"]) == (1, 2048, 256) and p["lds"] < 80 * 1024    # round 5: walking (wt_mwalk.h), the two lanes of a stretch hold one set each; two workgroups per CU
+    p = plan(100, "mwu", n_set0=50, no_mwalk=1)
+    assert (p["walk"], p["W"], p["T"]) == (0, 512, 256) and p["lds"] < 80 * 1024       # register columns + the sorted set 0 (50 x 4 B per lane) in LDS, 2 positions per lane
     p = plan(100, "mwu", n_set0=90)
     assert (p["W"], p["T"]) == (256, 512)                                # a set above 64 tracks: LDS columns, two lanes per run (round 1 plan)
     p = plan(200, "median")
@@ -506,6 +508,8 @@ def test_plan_policy_snapshot():
     p = plan(100, "median", dtype=np.float64)
     assert p["lds"] > 100 * 1024                                         # f64 values: one f64 column per lane in LDS
     p = plan(20, "mwu", n_set0=10)
+    assert (p["walk"], p["W"], p["T"]) == (1, 2048, 256)
+    p = plan(20, "mwu", n_set0=10, no_mwalk=1)
     assert (p["W"], p["T"]) == (512, 256)
     p = plan(100, "mean", dtype=np.float64)
     assert p["delta"] == 0 and p["W"] == 2048                            # f64 tracks: general kernel
@@ -607,6 +611,65 @@ def test_emu_median_walk_fuzz(oracle, seed):
         assert_runs_equal(got, exp, 0.0, "walking vs oracle")
     if ov == 0 and n >= 8 and t.n_intervals > 50 * n:
         assert info["walk_fallback"] > 0
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_emu_mwu_walk_fuzz(oracle, seed):
+    """MWUReduction by walking (csrc/wt_mwalk.h): a pair of lanes carries the two sets' columns over consecutive positions and keeps
+    S = #{y < x} and the tie groups (value, c0, c1, r0) up to date event by event; the reference's leaking tie state machine
+    (setComparisons.c:328-359) runs over the groups.  Against the oracle's literal scan at tolerance 0 -- value included: the
+    table of 2 erf(-k / 2 sigma) is the host's -- and against the bitmap kernel (WTAMD_NO_MWALK), over set sizes (1 v 1 ...
+    64 v 64), value levels (2: everything ties, more groups than the lanes keep -> enumeration; 14-40: around the slots'
+    capacity; 800: a few groups), NaN, non-zero defaults, both strict flags, stretch lengths, slots too few for a position
+    (overflow list) and none at all (fallback: events sorted into the slab, in rounds), ranges."""
+    rng = np.random.default_rng(7000 + seed)
+    n1, n2 = [(1, 1), (1, 3), (2, 2), (3, 1), (5, 7), (8, 8), (17, 33), (50, 50), (64, 64), (3, 50), (40, 9), (30, 30)][seed % 12]
+    n = n1 + n2
+    lens = [int(rng.integers(40, 2500)), int(rng.integers(1, 300))]
+    defaults = None
+    if rng.random() < 0.4:
+        defaults = rng.integers(-3, 4, n).astype(np.float64) / 4.0
+    t = synth(n, lens, mean_run=float(rng.choice([1, 2, 5, 16, 70])), seed=seed, gap_prob=float(rng.choice([0, 0.05, 0.5, 0.9])),
+              dtype=np.float32, value_levels=int(rng.choice([2, 5, 14, 25, 40, 800])), nan_prob=float(rng.choice([0, 0, 0.002])), defaults=defaults,
+              first_start=int(rng.choice([1, 1, 777])))
+    S = int(rng.choice([4, 8, 16, 32]))
+    capp, ov = [(None, None), (None, None), (2, None), (2, 5), (2, 0), (4, 0)][int(rng.integers(0, 6))]
+    flags = int(rng.choice([0, 0, 1, 2, 3]))
+    ranges = None
+    if rng.random() < 0.3:
+        ranges = [(int(rng.integers(1, L // 2 + 2)), int(rng.integers(L // 2 + 1, L + 60))) for L in lens]
+    got, info = emu.reduce(t, "mwu", flags=flags, n_set0=n1, walk_S=S, walk_capp=capp, walk_ov=ov, ranges=ranges)
+    assert info["walk"] == 1
+    old, info2 = emu.reduce(t, "mwu", flags=flags, n_set0=n1, no_mwalk=1, ranges=ranges)
+    assert info2["walk"] == 0
+    assert_runs_equal(got, old, 0.0, "walking vs bitmap kernel")
+    if ranges is None:
+        assert_runs_equal(got, oracle.reduce(t.as_dict(), "mwu", flags=flags, n_set0=n1), 0.0, "walking vs oracle")
+    if ov == 0 and n >= 8 and t.n_intervals > 50 * n:
+        assert info["walk_fallback"] > 0
+
+
+def test_emu_mwu_walk_tie_structures(oracle):
+    """Hand-made columns for the tie state machine: a single set-0 entry tied with set 1 (the state LEAKS into the following
+    groups), several entries in one group (reset at the last one), leaked state running over tie-free entries to the end of
+    set 0, previousTies overshooting ties (never reset) -- each as a track set whose values change one track at a time, so
+    that every configuration is reached by EVENTS from the previous one, not by the stretch's initialisation."""
+    from wiggletools_amd.runlists import RunLists
+    rng = np.random.default_rng(11)
+    n1, n2, L = 6, 7, 900
+    tracks = []
+    for i in range(n1 + n2):
+        rows, pos = [], 1
+        while pos < L:
+            ln = int(rng.integers(1, 9))
+            rows.append((pos, min(pos + ln, L), float(rng.integers(0, 4))))      # four values: ties everywhere
+            pos += ln
+        tracks.append([rows])
+    t = _f32(RunLists.from_lists(tracks))
+    for S in (4, 16, 32):
+        got, info = emu.reduce(t, "mwu", n_set0=n1, walk_S=S)
+        assert info["walk"] == 1
+        assert_runs_equal(got, oracle.reduce(t.as_dict(), "mwu", n_set0=n1), 0.0, "tie structures, S = %d" % S)
 
 
 @pytest.mark.parametrize("pair", [0, 1])

@@ -689,6 +689,41 @@ def test_gpu_c2_shape_long_runs(oracle, engine):
     ts.close()
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_gpu_mwu_walk_paths(oracle, engine, seed, monkeypatch):
+    """MWUReduction by walking (csrc/wt_mwalk.h) on the device: the default plan, short stretches, slots too few for the data
+    (overflow list), no overflow list at all (fallback: sorted events, in rounds) -- against the oracle's literal scan
+    (setComparisons.c:293-366) and against the bitmap kernel (WTAMD_NO_MWALK), tolerance 0 (the erf table is the host's);
+    set sizes 1 v 1 ... 64 v 64, value levels from "everything ties" (more tie groups than the lanes keep: enumeration) to a
+    few groups, NaN, non-zero defaults, both strict flags."""
+    from wiggletools_amd.runlists import synth
+    rng = np.random.default_rng(8000 + seed)
+    n1, n2 = [(1, 1), (2, 3), (8, 8), (17, 33), (50, 50), (64, 64), (3, 50), (40, 9)][seed % 8]
+    n = n1 + n2
+    defaults = rng.integers(-3, 4, n).astype(np.float64) / 4.0 if rng.random() < 0.4 else None
+    t = synth(n, [int(rng.integers(3000, 40000)), int(rng.integers(1, 900))], mean_run=float(rng.choice([1, 2, 5, 16, 70])), seed=seed,
+              gap_prob=float(rng.choice([0, 0.05, 0.5])), dtype=np.float32, value_levels=int(rng.choice([2, 5, 14, 30, 800])),
+              nan_prob=float(rng.choice([0, 0, 0.001])), defaults=defaults)
+    env = [dict(), dict(WTAMD_WALK_S="8"), dict(WTAMD_WALK_S="32"), dict(WTAMD_WALK_CAPP="2"),
+           dict(WTAMD_WALK_CAPP="2", WTAMD_WALK_OV="0"), dict(WTAMD_WALK_CAPP="4", WTAMD_WALK_OV="0", WTAMD_WALK_S="4")][seed % 6]
+    flags = int(rng.choice([0, 0, 1, 2, 3]))
+    d = t.as_dict()
+    exp = oracle.reduce(d, "mwu", flags=flags, n_set0=n1)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ts = engine.TrackSet.from_runlists(t)
+    got = ts.reduce_host("mwu", flags=flags, n_set0=n1)
+    assert ts.stats()["kernel"] == 3, "the walking MWU kernel did not run"
+    assert_runs_equal(got, exp, 0.0, "walking %s" % (env,))
+    ts.close()
+    monkeypatch.setenv("WTAMD_NO_MWALK", "1")
+    ts = engine.TrackSet.from_runlists(t)
+    old = ts.reduce_host("mwu", flags=flags, n_set0=n1)
+    assert ts.stats()["kernel"] == 0
+    assert_runs_equal(old, exp, 0.0, "bitmap kernel")
+    ts.close()
+
+
 @pytest.mark.parametrize("seed", range(18))
 def test_gpu_median_walk_paths(oracle, engine, seed, monkeypatch):
     """MedianReduction by walking (csrc/wt_walk.h) on the device: the default plan, small workgroups / stretches, slots too
