@@ -41,7 +41,7 @@ def build_dropin(force=False):
     csrc = os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc")
     srcs = [os.path.join(HERE, "wt_emu.cpp"), os.path.join(HERE, "wt_pipe_emu.cpp"),
             os.path.join(csrc, "wt_iter_abi.cpp"), os.path.join(csrc, "wt_defaults.cpp"), os.path.join(csrc, "wt_bigwig.cpp")]
-    deps = srcs + [os.path.join(csrc, h) for h in ("wt_core.h", "wt_plan.h", "wt_delta.h", "wt_walk.h", "wt_mwalk.h", "wt_bufreader.h", "wt_inflate.h", "wt_bwdev_core.h",
+    deps = srcs + [os.path.join(csrc, h) for h in ("wt_core.h", "wt_plan.h", "wt_delta.h", "wt_walk.h", "wt_mwalk.h", "wt_abi_common.h", "wt_abi_feeder.h", "wt_abi_reduce.h", "wt_abi_readers.h", "wt_abi_bwdev.h", "wt_abi_ops.h", "wt_abi_integrators.h", "wt_bufreader.h", "wt_inflate.h", "wt_bwdev_core.h",
                                                     "wt_mapop.h", "wt_bigwig_int.h")] + \
         [os.path.join(HERE, "..", "..", "include", "wiggletools_amd.h")]
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in deps):

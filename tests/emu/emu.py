@@ -23,15 +23,15 @@ def lib():
 
 
 def reduce(t, op, flags=0, n_set0=0, ppt=None, T=None, multiplex=False, ranges=None, chunk=None, global_scratch=None, delta_T=None, no_delta=None,
-           no_walk=None, walk_T=None, walk_S=None, walk_capp=None, walk_ov=None, walk_pair=None, no_mwalk=None):
+           no_walk=None, walk_T=None, walk_S=None, walk_capp=None, walk_ov=None, walk_pair=None, mwalk=None):
     """t: RunLists.  Returns (chrom, start, finish, value) [+ (tile, inplay) if multiplex], info."""
     from oracle.oracle import OPS
     opcode = 12 if multiplex else (OPS[op] if isinstance(op, str) else int(op))
     old = {k: os.environ.get(k) for k in ("WTAMD_PPT", "WTAMD_T", "WTAMD_CHUNK", "WTAMD_GLOBAL_SCRATCH", "WTAMD_DELTA_T", "WTAMD_NO_DELTA", "WTAMD_DELTA_MIN_TRACKS",
-                                             "WTAMD_NO_WALK", "WTAMD_WALK_T", "WTAMD_WALK_S", "WTAMD_WALK_CAPP", "WTAMD_WALK_OV", "WTAMD_WALK_PAIR", "WTAMD_NO_MWALK")}
+                                             "WTAMD_NO_WALK", "WTAMD_WALK_T", "WTAMD_WALK_S", "WTAMD_WALK_CAPP", "WTAMD_WALK_OV", "WTAMD_WALK_PAIR", "WTAMD_MWALK")}
     try:
         for k, v in (("WTAMD_PPT", ppt), ("WTAMD_T", T), ("WTAMD_CHUNK", chunk), ("WTAMD_GLOBAL_SCRATCH", global_scratch), ("WTAMD_DELTA_T", delta_T), ("WTAMD_NO_DELTA", no_delta), ("WTAMD_DELTA_MIN_TRACKS", 1),
-                     ("WTAMD_NO_WALK", no_walk), ("WTAMD_WALK_T", walk_T), ("WTAMD_WALK_S", walk_S), ("WTAMD_WALK_CAPP", walk_capp), ("WTAMD_WALK_OV", walk_ov), ("WTAMD_WALK_PAIR", walk_pair), ("WTAMD_NO_MWALK", no_mwalk)):
+                     ("WTAMD_NO_WALK", no_walk), ("WTAMD_WALK_T", walk_T), ("WTAMD_WALK_S", walk_S), ("WTAMD_WALK_CAPP", walk_capp), ("WTAMD_WALK_OV", walk_ov), ("WTAMD_WALK_PAIR", walk_pair), ("WTAMD_MWALK", mwalk)):
             if v is None:
                 os.environ.pop(k, None)
             else:

@@ -333,8 +333,8 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
             bool walk = false;
             if (op == WT_OP_MEDIAN && !value_is_f64 && !o_tile && !getenv("WTAMD_NO_WALK"))
                 if (const int nr = wt_regcol_slots(n_tracks, op, s32, n_set0)) walk = wt_make_walk_plan(R.plan, n_tracks, nr, 0.0);
-            // ... and so does MWU (wt_mwalk.h)
-            if (op == WT_OP_MWU && !value_is_f64 && !o_tile && !getenv("WTAMD_NO_MWALK") && !getenv("WTAMD_NO_WALK"))
+            // ... and so does MWU when asked to (wt_mwalk.h; WTAMD_MWALK=1: the engine's switch)
+            if (op == WT_OP_MWU && !value_is_f64 && !o_tile && getenv("WTAMD_MWALK") && atoi(getenv("WTAMD_MWALK")) != 0 && !getenv("WTAMD_NO_WALK"))
                 if (const int nr = wt_regcol_slots(n_tracks, op, s32, n_set0)) walk = wt_make_walk_plan(R.plan, n_tracks, nr, 0.0, 160 * 1024, n_set0);
             if (!walk && !wt_make_plan(n_tracks, op, s32, R.plan, err, 80 * 1024, 160 * 1024, n_set0)) { fprintf(stderr, "wtemu: %s\n", err.c_str()); return -10; }
         }

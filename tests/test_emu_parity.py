@@ -498,9 +498,9 @@ def test_plan_policy_snapshot():
     p = plan(100, "median", no_walk=1)
     assert (p["W"], p["T"], p["lds"] < 32 * 1024) == (512, 256, True) and p["scratch_slab"] == 0     # round 2: value column in REGISTERS, LDS = bitmaps only, 2 positions per lane
     p = plan(100, "mwu", n_set0=50)
-    assert (p["walk"], p["W"], p["T"]) == (1, 2048, 256) and p["lds"] < 80 * 1024    # round 5: walking (wt_mwalk.h), the two lanes of a stretch hold one set each; two workgroups per CU
-    p = plan(100, "mwu", n_set0=50, no_mwalk=1)
     assert (p["walk"], p["W"], p["T"]) == (0, 512, 256) and p["lds"] < 80 * 1024       # register columns + the sorted set 0 (50 x 4 B per lane) in LDS, 2 positions per lane
+    p = plan(100, "mwu", n_set0=50, mwalk=1)
+    assert (p["walk"], p["W"], p["T"]) == (1, 2048, 256) and p["lds"] < 80 * 1024    # round 5, opt-in (measured slower): walking (wt_mwalk.h), the two lanes of a stretch hold one set each
     p = plan(100, "mwu", n_set0=90)
     assert (p["W"], p["T"]) == (256, 512)                                # a set above 64 tracks: LDS columns, two lanes per run (round 1 plan)
     p = plan(200, "median")
@@ -508,8 +508,6 @@ def test_plan_policy_snapshot():
     p = plan(100, "median", dtype=np.float64)
     assert p["lds"] > 100 * 1024                                         # f64 values: one f64 column per lane in LDS
     p = plan(20, "mwu", n_set0=10)
-    assert (p["walk"], p["W"], p["T"]) == (1, 2048, 256)
-    p = plan(20, "mwu", n_set0=10, no_mwalk=1)
     assert (p["W"], p["T"]) == (512, 256)
     p = plan(100, "mean", dtype=np.float64)
     assert p["delta"] == 0 and p["W"] == 2048                            # f64 tracks: general kernel
@@ -618,7 +616,8 @@ def test_emu_mwu_walk_fuzz(oracle, seed):
     """MWUReduction by walking (csrc/wt_mwalk.h): a pair of lanes carries the two sets' columns over consecutive positions and keeps
     S = #{y < x} and the tie groups (value, c0, c1, r0) up to date event by event; the reference's leaking tie state machine
     (setComparisons.c:328-359) runs over the groups.  Against the oracle's literal scan at tolerance 0 -- value included: the
-    table of 2 erf(-k / 2 sigma) is the host's -- and against the bitmap kernel (WTAMD_NO_MWALK), over set sizes (1 v 1 ...
+    table of 2 erf(-k / 2 sigma) is the host's -- and against the bitmap kernel (the default: the walking kernel measured slower on
+    MI355X and is selected by WTAMD_MWALK=1), over set sizes (1 v 1 ...
     64 v 64), value levels (2: everything ties, more groups than the lanes keep -> enumeration; 14-40: around the slots'
     capacity; 800: a few groups), NaN, non-zero defaults, both strict flags, stretch lengths, slots too few for a position
     (overflow list) and none at all (fallback: events sorted into the slab, in rounds), ranges."""
@@ -638,9 +637,9 @@ def test_emu_mwu_walk_fuzz(oracle, seed):
     ranges = None
     if rng.random() < 0.3:
         ranges = [(int(rng.integers(1, L // 2 + 2)), int(rng.integers(L // 2 + 1, L + 60))) for L in lens]
-    got, info = emu.reduce(t, "mwu", flags=flags, n_set0=n1, walk_S=S, walk_capp=capp, walk_ov=ov, ranges=ranges)
+    got, info = emu.reduce(t, "mwu", flags=flags, n_set0=n1, walk_S=S, walk_capp=capp, walk_ov=ov, ranges=ranges, mwalk=1)
     assert info["walk"] == 1
-    old, info2 = emu.reduce(t, "mwu", flags=flags, n_set0=n1, no_mwalk=1, ranges=ranges)
+    old, info2 = emu.reduce(t, "mwu", flags=flags, n_set0=n1, ranges=ranges)
     assert info2["walk"] == 0
     assert_runs_equal(got, old, 0.0, "walking vs bitmap kernel")
     if ranges is None:
@@ -667,7 +666,7 @@ def test_emu_mwu_walk_tie_structures(oracle):
         tracks.append([rows])
     t = _f32(RunLists.from_lists(tracks))
     for S in (4, 16, 32):
-        got, info = emu.reduce(t, "mwu", n_set0=n1, walk_S=S)
+        got, info = emu.reduce(t, "mwu", n_set0=n1, walk_S=S, mwalk=1)
         assert info["walk"] == 1
         assert_runs_equal(got, oracle.reduce(t.as_dict(), "mwu", n_set0=n1), 0.0, "tie structures, S = %d" % S)
 

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libwiggletools_amd.so")
 SRCS = ["wt_engine.hip", "wt_walk.hip", "wt_compress.hip", "wt_map.hip", "wt_synth.hip", "wt_bwdev.hip", "wt_defaults.cpp", "wt_iter_abi.cpp", "wt_bigwig.cpp", "wt_bwwrite.cpp"]
 LIBS = ["-lz"]
-DEPS = ["wt_core.h", "wt_delta.h", "wt_walk.h", "wt_mwalk.h", "wt_bufreader.h", "wt_bigwig_int.h", "wt_plan.h", "wt_devscope.h", "wt_pipe.h", "wt_mapop.h", "wt_inflate.h", "wt_bwdev_core.h", os.path.join("..", "..", "include", "wiggletools_amd.h")]
+DEPS = ["wt_abi_common.h", "wt_abi_feeder.h", "wt_abi_reduce.h", "wt_abi_readers.h", "wt_abi_bwdev.h", "wt_abi_ops.h", "wt_abi_integrators.h", "wt_core.h", "wt_delta.h", "wt_walk.h", "wt_mwalk.h", "wt_bufreader.h", "wt_bigwig_int.h", "wt_plan.h", "wt_devscope.h", "wt_pipe.h", "wt_mapop.h", "wt_inflate.h", "wt_bwdev_core.h", os.path.join("..", "..", "include", "wiggletools_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 

@@ -1319,9 +1319,12 @@ static bool wt_pick_plan(const wtamd_trackset *ts, int op, int n_set0, WtPlan &p
     if (op == WT_OP_MEDIAN && !ts->value_f64 && !getenv("WTAMD_NO_WALK"))
         if (const int nr = wt_regcol_slots(ts->n_tracks, op, ts->scratch_f32, n_set0))
             if (wt_make_walk_plan(plan, ts->n_tracks, nr, wt_events_per_bp(ts))) return true;
-    // MWUReduction over float tracks walks too (wt_mwalk.h; WTAMD_NO_MWALK=1: the bitmap kernel's register columns)
-    // (same domain as its register columns, wt_regcol_slots: float tracks, float-exact defaults, at most 64 per set)
-    if (op == WT_OP_MWU && !ts->value_f64 && !getenv("WTAMD_NO_MWALK") && !getenv("WTAMD_NO_WALK"))
+    // MWUReduction by walking (wt_mwalk.h) is built, bit-exact on every path and NOT the default: measured on MI355X it needs
+    // 284 wave-wide VALU instructions per output run where the bitmap kernel's register columns need 253 (chromosome 21:
+    // 43.9 against 35.6 ms; profiles/r05_mwu_walk_vs_bitmap.json).  WTAMD_MWALK=1 selects it
+    // (same domain as the register columns, wt_regcol_slots: float tracks, float-exact defaults, at most 64 per set).
+    static const bool mwalk = getenv("WTAMD_MWALK") && atoi(getenv("WTAMD_MWALK")) != 0;
+    if (op == WT_OP_MWU && mwalk && !ts->value_f64 && !getenv("WTAMD_NO_WALK"))
         if (const int nr = wt_regcol_slots(ts->n_tracks, op, ts->scratch_f32, n_set0))
             if (wt_make_walk_plan(plan, ts->n_tracks, nr, wt_events_per_bp(ts), 160 * 1024, n_set0)) return true;
     return wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err, 80 * 1024, 160 * 1024, n_set0);
