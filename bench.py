@@ -1011,7 +1011,7 @@ def main():
                 # the same pipeline on files written at zlib level 6 (libBigWig's / wigToBigWig's default; SURVEY 8d's stored
                 # form is level 1) next to level 1 on the same two chromosomes (21, 22: writing 90 GB at level 6 would take
                 # the bench ten minutes of host zlib)
-                if gscale >= 0.999 and not os.environ.get("WTAMD_BENCH_NO_LEVELS"):
+                if (gscale >= 0.999 or os.environ.get("WTAMD_BENCH_FORCE_LEVELS")) and not os.environ.get("WTAMD_BENCH_NO_LEVELS"):
                     lv = {}
                     for level in (1, 6):
                         try:

@@ -418,7 +418,7 @@ WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint3
 // window (the branch-free common case of wt_delta_apply), the later one is not the first of its track here, the
 // coordinates meet.  Bit-identical by construction; the emulator re-reads the neighbour's interval instead.
 #ifndef WT_DELTA_MERGE
-#define WT_DELTA_MERGE 1
+#define WT_DELTA_MERGE 0            // (measured on MI355X, round 5: no effect -- C2 66.50 against 66.83 ms, C3 70.58 against 70.49: the atomics are not what pass 2 waits for)
 #endif
 #define WT_DELTA_NOCOORD ((int32_t) 0x80000000)         // "no such neighbour": never equals a coordinate (they are >= 0)
 #ifndef WT_EMU

@@ -346,8 +346,14 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
         WT_TICK(6);
         wt_delta_stage<OP>(P, c, d, L, tid, nt);
         __syncthreads();
+#ifdef WT_PROFILE_TAIL
+        WT_TICK(2);                 // (experiment: the tail of a window apart -- staging here, copy-out in "write", ticket + header in "zero")
+#endif
         wt_delta_copy_out(P, c, d, tid, nt);
         __syncthreads();
+#ifdef WT_PROFILE_TAIL
+        WT_TICK(7);
+#endif
         WT_MARK(111);
         if (tid == 0) {
             wt_window_stats(P, c);
@@ -356,7 +362,11 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             if (kn < P.n_windows) wt_phase_header(P, c, kn);
         }
         __syncthreads();
+#ifdef WT_PROFILE_TAIL
+        WT_TICK(0);
+#else
         WT_TICK(7);
+#endif
     }
 #ifdef WT_PROFILE
     if (tid == 0)
