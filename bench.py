@@ -1024,6 +1024,9 @@ def main():
                             lv["z%d" % level] = {"error": repr(e)[:300]}
                         trim_pools()
                     res["e2e_bigwig_levels"] = lv
+                    # (97 Mbp: a quarter of a second, half of it start-up -- the steady figures compare the decoders)
+                    cfgd["e2e_files_z6_steady_bp_per_s_chr21_22"] = lv.get("z6", {}).get("steady_bp_per_s")
+                    cfgd["e2e_files_z1_steady_bp_per_s_chr21_22"] = lv.get("z1", {}).get("steady_bp_per_s")
                     cfgd["e2e_files_z6_warm_bp_per_s_chr21_22"] = lv.get("z6", {}).get("warm_bp_per_s")
                     cfgd["e2e_files_z1_warm_bp_per_s_chr21_22"] = lv.get("z1", {}).get("warm_bp_per_s")
                 res["value_e2e_bigwig_genome"] = g.get("bp_per_s")

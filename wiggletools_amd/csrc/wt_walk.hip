@@ -27,6 +27,7 @@ __global__ void __launch_bounds__(MAXT, 1) wt_walk_kernel(const WtParams P) {
     WtWalkCtx w;
     wt_walk_ctx_init(w, P, wt_lds, P.g_scratch + (size_t) blockIdx.x * (size_t) P.g_scratch_slab);
     w.pair = PAIR ? 1 : 0;                      // (== P.walk_pair: a constant of this instantiation from here on)
+    w.mwu = 0;                                  // (... and so is this: the MWU branches of the shared phases fold away)
     const int tid = threadIdx.x, nt = blockDim.x;
     long long k_dbg = -1;
     (void) k_dbg;
