@@ -808,7 +808,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
         if o in ("median", "wilcoxon", "mwu"):
             bound, note = "issue", (("median by walking (csrc/wt_walk.h)" if kern == 2 else ("MWU by walking (csrc/wt_mwalk.h)" if kern == 3 else "register-column reducer")) +
                                     ": bound by instruction issue and latency, not by HBM -- the frac against the HBM peak is "
-                                    "reported for the record only (DESIGN 10); roofline.issue prices it against the VALU issue peak")
+                                    "reported for the record only (DESIGN A.1); roofline.issue prices it against the VALU issue peak")
             # VALU instructions per output run from the SQ counters of an earlier profile (profiles/issue.json, like
             # traffic.json for the HBM bytes) x this run's output runs / this run's kernel time, against what the chip
             # can issue: 256 CUs x 4 SIMDs x one wave-wide VALU instruction per 4 cycles at 2.4 GHz

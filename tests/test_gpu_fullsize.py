@@ -147,7 +147,7 @@ def test_gpu_plans_agree_bitwise_at_scale(op, kw, monkeypatch):
 @pytest.mark.parametrize("op", ["var", "stddev", "cv"])
 def test_gpu_var_family_two_algorithms_at_scale(op, monkeypatch):
     """Variance family at 62 Mbp x 100 tracks through two independent algorithms: exact integer sums of
-    the scaled mantissas and of their squares with a 128-bit finish (difference arrays, DESIGN 4.9)
+    the scaled mantissas and of their squares with a 128-bit finish (difference arrays, DESIGN 4.2)
     vs the reference's two sequential f64 passes per position (general kernel).  Coordinates and run
     count identical; values within 1e-12 relative (the reference-order result carries ~N roundings,
     the integer route one)."""

@@ -694,7 +694,7 @@ def test_gpu_mwu_walk_paths(oracle, engine, seed, monkeypatch):
     """MWUReduction by walking (csrc/wt_mwalk.h) on the device: the default plan, short stretches, slots too few for the data
     (overflow list), no overflow list at all (fallback: sorted events, in rounds) -- against the oracle's literal scan
     (setComparisons.c:293-366) and against the bitmap kernel (the default; the walking kernel is selected by WTAMD_MWALK=1: it
-    measured slower, DESIGN 4.8), tolerance 0 (the erf table is the host's);
+    measured slower, DESIGN 4.6), tolerance 0 (the erf table is the host's);
     set sizes 1 v 1 ... 64 v 64, value levels from "everything ties" (more tie groups than the lanes keep: enumeration) to a
     few groups, NaN, non-zero defaults, both strict flags."""
     from wiggletools_amd.runlists import synth

@@ -5,7 +5,7 @@ Expected: the oracle's operator restatement (pinned bit for bit on the compiled 
 iterators, tests/test_oracle_vs_ref.py) applied per track, then the oracle's reducer.
 
 CPU: host layer over the emulated pipeline (bit-exact: same libm); `-m gpu`: the product (transcendental
-operators to 1e-12 relative -- device libm, DESIGN 4.5; the others exact)."""
+operators to 1e-12 relative -- device libm, DESIGN 4.8; the others exact)."""
 import ctypes as C
 
 import numpy as np

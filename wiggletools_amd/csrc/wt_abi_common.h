@@ -62,7 +62,7 @@ bool wt_surely_kept(const wtamd_map_chain &c, double v) {
 // ---------------------------------------------------------------------------
 // Parallel draining of foreign children.  The reference's protocol is one indirect call per interval;
 // one host thread sustains ~1.2e8 of them per second, which is what bounded the `pop` leg of the
-// end-to-end path (DESIGN 11.4).  The protocol only demands that ONE iterator is never entered by two
+// end-to-end path (DESIGN 6.8).  The protocol only demands that ONE iterator is never entered by two
 // threads at once (its readers already run producer threads of their own: bufferedReader.c:118-134),
 // so the N children of a Multiplexer are dealt to a few worker threads -- a child always to the same
 // one -- which pop them into private buffers; the batch is then laid out in track order and the

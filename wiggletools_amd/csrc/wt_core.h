@@ -1013,7 +1013,7 @@ __device__ unsigned long long wt_prof2[8];
 // the set-0 keys in a register vector indexed in GPR-index mode.  No faster -- the kernel is bound by
 // instruction issue and the searches compiled to ~190 instructions per value, as many as the 2 x 64
 // compare / add-carry pairs below -- and the build was not stable at 128 slots on MI355X (sporadic
-// corrupted run counts at chromosome size), so it was dropped.  DESIGN 10.)
+// corrupted run counts at chromosome size), so it was dropped.  DESIGN A.1.)
 // MWU over a register column (wt_gather_regs): set 0 sorted by a register network and parked in
 // this lane's LDS column (n_set0 * 4 B -- the only LDS the reducer needs); then ONE pass over the
 // sorted set-0 values e, each compared with the set-1 registers (compile-time indices):

@@ -281,7 +281,7 @@ WT_DEV bool wt_delta_verdict(const WtParams &P, const WtDeltaCtx &d, int &emin) 
 }
 
 // ---- pass 2 ----
-// Per interval the wave spends instruction ISSUE, not bandwidth, so this is written for
+// Per interval the wave spends instruction ISSUE, not bandwidth (DESIGN A.1; round 5's phase profile, DESIGN 4.1, reads differently: the pass runs at 0.81 of the HBM peak), so this is written for
 // the instruction count (round 3; read off the ISA):
 //   * w0 and the window width are arguments (SGPRs): read from LDS inside the loop they cost an
 //     `s_waitcnt lgkmcnt(0)` per interval, which also waited for the previous interval's four atomics;

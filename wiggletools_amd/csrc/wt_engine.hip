@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
 // (var / stddev / CV also accumulate the sum of squares: 512 lanes, one workgroup per CU)
 #define WT_DELTA_SQ(OP) ((OP) == WT_OP_VAR || (OP) == WT_OP_STDDEV || (OP) == WT_OP_ENTROPY || (OP) == WT_OP_CV)
 #ifndef WT_DELTA_MIN_WAVES
-#define WT_DELTA_MIN_WAVES 4     // waves per SIMD the register allocation aims at (experiments: 6 spills)
+#define WT_DELTA_MIN_WAVES 4     // waves per SIMD the register allocation aims at (experiments: 6 spills, see DESIGN A.1)
 #endif
 #ifndef WT_DELTA_SQ_BLOCK
 #define WT_DELTA_SQ_BLOCK 512    // workgroup of the launches that also accumulate squares
@@ -1331,7 +1331,7 @@ static bool wt_pick_plan(const wtamd_trackset *ts, int op, int n_set0, WtPlan &p
             if (wt_make_walk_plan(plan, ts->n_tracks, nr, wt_events_per_bp(ts))) return true;
     // MWUReduction by walking (wt_mwalk.h) is built, bit-exact on every path and NOT the default: measured on MI355X it needs
     // 284 wave-wide VALU instructions per output run where the bitmap kernel's register columns need 253 (chromosome 21:
-    // 43.9 against 35.6 ms; profiles/r05_mwu_walk_vs_bitmap.json, DESIGN 4.8).  WTAMD_MWALK=1 selects it
+    // 43.9 against 35.6 ms; profiles/r05_mwu_walk_vs_bitmap.json, DESIGN 4.6).  WTAMD_MWALK=1 selects it
     // (same domain as the register columns, wt_regcol_slots: float tracks, float-exact defaults, at most 64 per set).
     static const bool mwalk = getenv("WTAMD_MWALK") && atoi(getenv("WTAMD_MWALK")) != 0;
     if (op == WT_OP_MWU && mwalk && !ts->value_f64 && !getenv("WTAMD_NO_WALK"))

@@ -2,11 +2,11 @@
 //
 // Why: a BigWig file is a list of independent zlib streams ("sections" of <= a few thousand items,
 // reference src/bigWiggleReader.c:52-83 reads them through libBigWig, which inflates every one on the
-// host).  The file leg of the engine was bound by exactly that host inflate.  Sections are
+// host).  The file leg of the engine was bound by exactly that host inflate (DESIGN A.5).  Sections are
 // independent, so here every lane of a wavefront inflates its own section: 64 streams per wavefront,
 // tens of thousands in flight per GPU, no cross-lane communication at all.
 //
-// Round 4 rewrite (DESIGN 13.3).  The round-3 decoder took 11.1 ms per 63 500 sections with ONE wavefront per
+// Round 4 rewrite (DESIGN 4.9).  The round-3 decoder took 11.1 ms per 63 500 sections with ONE wavefront per
 // SIMD, 42 % of its cycles waiting: a step was "one symbol OR 8 bytes of a match" (7 500 steps per section, each
 // paying for the literal, the match and the copy path because 64 lanes are never in the same state), the input
 // prefetch and every match beyond the LDS ring were loads whose results the same step consumed -- one global

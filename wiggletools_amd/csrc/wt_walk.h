@@ -28,7 +28,7 @@
 //
 // Eligibility (host): float tracks, float-exact defaults, N <= 128.
 // The output is the bitmap kernel's, bit for bit (same keys, same order statistic, NaN if any value is NaN).
-// DESIGN 4.11 has the measurements.
+// DESIGN 4.5 has the measurements.
 #ifndef WT_WALK_H_
 #define WT_WALK_H_
 #ifdef WT_EMU
