@@ -1636,13 +1636,36 @@ WT_DEV void wt_lookback_complete(const WtParams &P, WtCtx &c, long long k, int l
 WT_DEV void wt_lookback_complete(const WtParams &P, WtCtx &c, long long k, int lane) {
     wt_lookback_complete(P, c, k, lane, (unsigned long long) c.epfx[P.n_words]);
 }
+#ifndef WT_LOOKBACK_DEPTH
+#define WT_LOOKBACK_DEPTH 1     // status words per lane fetched at once (4: one round trip covers 256 predecessors -- measured, round 5: no effect)
+#endif
 WT_DEV void wt_lookback_complete(const WtParams &P, WtCtx &c, long long k, int lane, unsigned long long mine) {
     unsigned long long excl = 0;
     long long base = k - 1;
+    // A persistent grid keeps ~one window per workgroup in flight (256 on this GPU, 512 with two workgroups per CU), and a window
+    // that has just published its count typically finds that many predecessors still without an inclusive prefix: at 64 status
+    // words per round trip that is up to four DEPENDENT round trips.  With WT_LOOKBACK_DEPTH > 1 the words of the next rounds are
+    // requested together (a round whose words were not all ready polls as before).  Measured on MI355X (round 5, tools/r5_ab.sh,
+    // depth 4 against 1 on one box, twice): C2 67.96 / 68.10 against 67.94 / 67.71 ms, mean run 200 33.03 / 32.94 against 32.92 /
+    // 32.83, C3 70.63 / 70.60 against 70.43 / 70.41 -- the look-back's 8-11 % of a window is waiting for the predecessors to
+    // PUBLISH, not for the round trips that fetch what they published.  Default 1.
+    unsigned long long ahead[WT_LOOKBACK_DEPTH];
+    int have = 0;               // rounds of ahead[] not yet consumed (ahead[WT_LOOKBACK_DEPTH - have] is the next)
     while (base >= 0) {
         const long long j = base - lane;
-        // windows before the first one behave like a published prefix of 0
-        unsigned long long v = (j >= 0) ? wt_status_load(&P.status[j]) : WT_FLAG_PFX;
+        if (have == 0) {
+#pragma unroll
+            for (int r = 0; r < WT_LOOKBACK_DEPTH; r++) {
+                const long long jr = j - 64ll * r;
+                // windows before the first one behave like a published prefix of 0
+                ahead[r] = (jr >= 0) ? wt_status_load(&P.status[jr]) : WT_FLAG_PFX;
+            }
+            have = WT_LOOKBACK_DEPTH;
+        }
+        unsigned long long v = ahead[0];
+#pragma unroll
+        for (int r = 1; r < WT_LOOKBACK_DEPTH; r++) v = (WT_LOOKBACK_DEPTH - have == r) ? ahead[r] : v;
+        have--;
         unsigned long long pfx;
         unsigned spins = 0;
         for (;;) {
