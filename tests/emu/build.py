@@ -34,6 +34,17 @@ def build(force=False):
     return _compile(so, srcs, [srcs[0], "-lm"])
 
 
+def build_variant(name, flags):
+    """tests/emu/libwt_emu_<name>.so: the emulator compiled with extra flags (compile-time switches of the kernels' logic that are
+    not the default, e.g. -DWT_DELTA_MERGE=1), rebuilt when a source is newer."""
+    so = os.path.join(HERE, "libwt_emu_%s.so" % name)
+    csrc = os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc")
+    srcs = [os.path.join(HERE, "wt_emu.cpp")] + [os.path.join(csrc, h) for h in ("wt_core.h", "wt_plan.h", "wt_delta.h", "wt_walk.h", "wt_mwalk.h")]
+    if os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
+        return so
+    return _compile(so, srcs, list(flags) + [srcs[0], "-lm"])
+
+
 def build_dropin(force=False):
     """tests/emu/libwt_dropin_emu.so: the product's drop-in layer (csrc/wt_iter_abi.cpp,
     csrc/wt_defaults.cpp) linked against the emulated pipeline (wt_pipe_emu.cpp + wt_emu.cpp)."""

@@ -7,12 +7,20 @@ import numpy as np
 from . import build as _build
 
 _lib = None
+_variant = None         # (name, flags): the emulator compiled with extra flags (use_variant)
+
+
+def use_variant(name=None, flags=()):
+    """Switches the emulator library: None = the default build, else tests/emu/libwt_emu_<name>.so compiled with `flags`."""
+    global _lib, _variant
+    _variant = (name, tuple(flags)) if name else None
+    _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        L = C.CDLL(_build.build())
+        L = C.CDLL(_build.build_variant(*_variant) if _variant else _build.build())
         L.wtemu_reduce.restype = C.c_longlong
         L.wtemu_reduce.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_longlong,

@@ -611,6 +611,33 @@ def test_emu_median_walk_fuzz(oracle, seed):
         assert info["walk_fallback"] > 0
 
 
+def test_emu_delta_merged_atomics(oracle):
+    """wt_delta.h with -DWT_DELTA_MERGE=1 (not the default: it measured no faster on MI355X): where a track's runs are contiguous the
+    lane of the later run adds v - v' at the shared position and the earlier one skips its finish -- two LDS atomics per run
+    instead of four, eight -> four with squares.  Integer adds commute: Sum / Mean bit-exact, the var family at 1e-12, non-zero
+    defaults, gaps (no merge across them), more tracks than lanes, ranges."""
+    emu.use_variant("merge", ["-DWT_DELTA_MERGE=1"])
+    try:
+        for seed in range(8):
+            rng = np.random.default_rng(9100 + seed)
+            n = int(rng.choice([3, 8, 64, 100, 300]))
+            defaults = (rng.integers(-3, 4, n).astype(np.float64) / 4.0) if seed % 3 == 1 else None
+            t = synth(n, [int(rng.integers(200, 5000)), int(rng.integers(1, 300))], mean_run=float(rng.choice([1, 3, 16, 70])), seed=seed,
+                      gap_prob=float(rng.choice([0, 0.05, 0.5])), dtype=np.float32, value_levels=int(rng.choice([5, 800])), defaults=defaults)
+            flags = int(rng.choice([0, 1]))
+            for op in ("sum", "mean"):
+                got, info = emu.reduce(t, op, flags=flags, delta_T=int(rng.choice([64, 256, 1024])))
+                assert info["delta"] == 1
+                assert_runs_equal(got, oracle.reduce(t.as_dict(), op, flags=flags), 0.0, "merged %s seed %d" % (op, seed))
+            if defaults is None and n >= 8:
+                for op in ("var", "stddev"):
+                    got, info = emu.reduce(t, op, flags=flags, delta_T=int(rng.choice([64, 256, 512])))
+                    assert info["delta"] == 1
+                    assert_runs_equal(got, oracle.reduce(t.as_dict(), op, flags=flags), 1e-12, "merged %s seed %d" % (op, seed))
+    finally:
+        emu.use_variant(None)
+
+
 @pytest.mark.parametrize("seed", range(36))
 def test_emu_mwu_walk_fuzz(oracle, seed):
     """MWUReduction by walking (csrc/wt_mwalk.h): a pair of lanes carries the two sets' columns over consecutive positions and keeps

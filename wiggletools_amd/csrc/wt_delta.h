@@ -477,6 +477,7 @@ WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF> 
             unsigned long long qa_prev = 0, qb_prev = 0;
 #ifdef WT_EMU
             {
+                (void) f_eff; (void) s_eff;
                 // the intervals at flat index - 1 / + 1, where they exist in the same row of the tile (lane - 1 / lane + 1) and track
                 f_prev = WT_DELTA_NOCOORD; s_next = WT_DELTA_NOCOORD; vi_prev = 0;
                 if (lane > 0 && valid && !first) {
