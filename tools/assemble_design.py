@@ -1,7 +1,8 @@
 """One-off (round 5): DESIGN.md rewritten as a CURRENT-STATE document.  The old file's sections (cut into /tmp/design_parts by
 heading) are put in numeric order, kernel by kernel, with cross references renumbered; what is history (per-round diaries,
 "tried and dropped" lists, review tables) goes to the appendix; the sections written new come from tools/design_new/*.md.
-Usage: python tools/assemble_design.py /tmp/design_parts tools/design_new > DESIGN.md"""
+Usage: git show f894be8:DESIGN.md | python tools/split_design_r4.py /tmp/design_parts; python tools/assemble_design.py /tmp/design_parts tools/design_new > /tmp/D.md;
+       python tools/fill_design.py /tmp/D.md > DESIGN.md"""
 import glob
 import os
 import re
