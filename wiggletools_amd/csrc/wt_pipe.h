@@ -226,11 +226,11 @@ static bool wt_pin_by_register(void **out, size_t bytes) {
     touch(0);
     for (auto &t : th) t.join();
     void *dp = nullptr;
-    if (hipHostRegister(p, len, hipHostRegisterDefault) != hipSuccess ||
-        hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || dp != (void *) p) {
+    const bool registered = hipHostRegister(p, len, hipHostRegisterDefault) == hipSuccess;
+    if (!registered || hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || dp != (void *) p) {
         // (kernels of the pipe read and write the staging through the HOST address: it must be the device's too)
         (void) hipGetLastError();
-        if (dp) (void) hipHostUnregister(p);
+        if (registered) (void) hipHostUnregister(p);
         munmap(base, len + huge);
         g_reg_state.store(-1);
         return false;
