@@ -35,6 +35,9 @@
 
 #define WT_DELTA_K 8            // positions per lane: one byte of the U / E bitmaps
 #define WT_DELTA_GROUP 16       // lanes per group in the hierarchical scan
+#ifndef WT_DELTA_PARK
+#define WT_DELTA_PARK 1         // runs that cross a window edge are parked and applied once per wavefront (see wt_delta_apply_or_park)
+#endif
 #ifndef WT_DELTA_U
 #define WT_DELTA_U 4            // flat interval indices per lane and tile (round 2, with the prefetch really in flight: 4 beats 8 by 4 % at 100 tracks, loses 1 % at 500; round 1 measured the opposite with the prefetch serialised)
 #endif
@@ -354,6 +357,78 @@ WT_DEV void wt_delta_apply(WtDeltaCtx &d, WtCtx &c, int32_t w0, uint32_t width, 
     }
 }
 
+// ---- runs that cross a window edge wait for the end of the pass (round 5) ----
+// A run that is not wholly inside the window -- it spans w0 (part of the window's base), ends beyond w1, starts at or
+// after w1 (the index is generous), finishes exactly at w0 -- takes wt_delta_apply's other branch: ~90 instructions and
+// ten branches, executed by the whole wavefront for the one or two lanes that need it.  Every track has one run across
+// each edge, so at 100 tracks and mean run 16 one wave row in four went that way (at mean run 200: every row), and
+// forcing every run onto the branch-free path (results wrong: profiles/r05_delta_pass2_experiments.txt, B) made the pass
+// 20 % shorter.  So the loop only PARKS such a run in three registers of its lane; a lane that already holds one makes
+// the wavefront work the parked ones off first (rare: two of a lane's ~50 runs per window), and what is parked when the
+// pass ends is worked off once -- one trip through the long branch per wavefront and window instead of a dozen.
+// Integer adds commute: bit-identical.  (`mask`: wave-uniform, which lanes hold a run.)
+template <bool DF>
+struct WtDeltaPend {
+    unsigned long long mask;
+    int32_t s, f;
+    uint32_t b;
+    uint32_t d[DF ? 1 : 1];
+};
+#ifdef WT_EMU
+WT_DEV unsigned long long wt_delta_ballot(bool c) { return c ? 1ull : 0ull; }           // (the emulator's lanes run alone)
+WT_DEV bool wt_delta_in_mask(unsigned long long m, int lane) { return m != 0ull; }
+#else
+WT_DEV unsigned long long wt_delta_ballot(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+WT_DEV bool wt_delta_in_mask(unsigned long long m, int lane) { return (m >> lane) & 1ull; }
+#endif
+template <bool QQ, bool DF>
+WT_DEV void wt_delta_flush(WtDeltaCtx &d, WtCtx &c, WtDeltaPend<DF> &pn, int lane, int32_t w0, uint32_t width, int scale, bool ok,
+                           int32_t &my_next) {
+    if (wt_delta_in_mask(pn.mask, lane)) {
+        WtDeltaRange scrap;     // (the exponent range took the run when it was parked)
+        scrap.kmax = 0u; scrap.kmin = 0xffffffffu;
+        wt_delta_apply<QQ, DF>(d, c, w0, width, pn.s, pn.f, pn.b, DF ? pn.d[0] : 0u, scale, ok, my_next, scrap);
+    }
+    pn.mask = 0ull;
+}
+// one run of the pass: inside the window -> the four (QQ: eight) atomics; not -> parked
+template <bool QQ, bool DF>
+WT_DEV void wt_delta_apply_or_park(WtDeltaCtx &d, WtCtx &c, WtDeltaPend<DF> &pn, int lane, bool valid, int32_t w0, uint32_t width,
+                                   int32_t s, int32_t f, uint32_t vb, uint32_t db, int scale, bool ok, int32_t &my_next, WtDeltaRange &R) {
+    const uint32_t cs = (uint32_t) (s - w0), cf = (uint32_t) (f - w0);
+    const bool inside = cs < width && cf < width;
+    if (valid) {
+        const uint32_t key = vb & 0x7fffffffu;
+        R.kmax = key > R.kmax ? key : R.kmax;
+        R.kmin = key - 1u < R.kmin ? key - 1u : R.kmin;
+    }
+    if (valid && inside) {
+        long long vi = wt_delta_scaled(vb, scale);
+        if (DF) vi -= wt_delta_scaled(db, scale);
+#ifdef WT_EMU
+        if (!ok) vi = 0;
+#endif
+        wt_lds_add64((unsigned long long *) &d.acc[cs], (unsigned long long) vi);
+        wt_lds_add32(&d.ev[cs], 1u);
+        wt_lds_sub64((unsigned long long *) &d.acc[cf], (unsigned long long) vi);
+        wt_lds_add32(&d.ev[cf], 0x10000u);
+        if (QQ && vi) {
+            unsigned long long a, b;
+            wt_delta_square((unsigned long long) (vi < 0 ? -vi : vi), a, b);
+            wt_lds_add64(&d.qa[cs], a); wt_lds_add64(&d.qb[cs], b);
+            wt_lds_sub64(&d.qa[cf], a); wt_lds_sub64(&d.qb[cf], b);
+        }
+    }
+    const bool park = valid && !inside;
+    const unsigned long long pm = wt_delta_ballot(park);
+    if (pm & pn.mask) wt_delta_flush<QQ, DF>(d, c, pn, lane, w0, width, scale, ok, my_next);     // (wave-uniform, rare)
+    pn.s = park ? s : pn.s;
+    pn.f = park ? f : pn.f;
+    pn.b = park ? vb : pn.b;
+    if (DF) pn.d[0] = park ? db : pn.d[0];
+    pn.mask |= pm;
+}
+
 // the lane's WT_DELTA_U intervals of one tile (same software pipeline as pass 1)
 template <bool DF>
 struct WtDeltaBatch {
@@ -451,7 +526,7 @@ WT_DEV void wt_delta_apply_merged(WtDeltaCtx &d, uint32_t cs, uint32_t cf, long 
 // every interval of the tile at flat index `tb`; only the window's last tile can be partial
 template <bool QQ = false, bool DF = false>
 WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF> &B, uint32_t tb, uint32_t M, int lane, int32_t w0,
-                                uint32_t width, int scale, bool ok, int32_t &my_next, WtDeltaRange &R, const WtParams *Pp = nullptr) {
+                                uint32_t width, int scale, bool ok, int32_t &my_next, WtDeltaRange &R, WtDeltaPend<DF> &pn, const WtParams *Pp = nullptr) {
 #if WT_DELTA_MERGE
     {
         const bool full = tb + WT_DELTA_TILE <= M;
@@ -526,6 +601,18 @@ WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF> 
         return;
     }
 #endif
+#if WT_DELTA_PARK
+    if (tb + WT_DELTA_TILE <= M) {
+#pragma unroll
+        for (int u = 0; u < WT_DELTA_U; u++)
+            wt_delta_apply_or_park<QQ, DF>(d, c, pn, lane, true, w0, width, B.s[u], B.f[u], B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
+    } else {
+#pragma unroll
+        for (int u = 0; u < WT_DELTA_U; u++)
+            wt_delta_apply_or_park<QQ, DF>(d, c, pn, lane, tb + (uint32_t) lane + 64u * (uint32_t) u < M, w0, width, B.s[u], B.f[u], B.b[u],
+                                           DF ? B.d[u] : 0u, scale, ok, my_next, R);
+    }
+#else
     if (tb + WT_DELTA_TILE <= M) {
 #pragma unroll
         for (int u = 0; u < WT_DELTA_U; u++)
@@ -536,6 +623,7 @@ WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF> 
             if (tb + (uint32_t) lane + 64u * (uint32_t) u < M)
                 wt_delta_apply<QQ, DF>(d, c, w0, width, B.s[u], B.f[u], B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
     }
+#endif
 }
 
 // `scale`: exponent of one unit of the scaled mantissas; `ok`: false -> the window is known not to be
@@ -564,17 +652,20 @@ WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale
         // two register sets take turns (a `cur = nxt` copy is 12 moves per tile, and it put the wait for the
         // prefetched tile at the end of the iteration that issued it)
         WtDeltaBatch<DF> A, B;
+        WtDeltaPend<DF> pn;
+        pn.mask = 0ull; pn.s = 0; pn.f = 0; pn.b = 0u; pn.d[0] = 0u;
         wt_delta_fetch<DF>(P, d, nt, M, tb, lane, A);
         for (;;) {
             wt_delta_fetch<DF>(P, d, nt, M, tb + step, lane, B);    // (past the end: harmless re-reads of the last tile)
-            wt_delta_apply_tile<QQ, DF>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R, &P);
+            wt_delta_apply_tile<QQ, DF>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R, pn, &P);
             tb += step;
             if (tb >= M) break;
             wt_delta_fetch<DF>(P, d, nt, M, tb + step, lane, A);
-            wt_delta_apply_tile<QQ, DF>(d, c, B, tb, M, lane, w0, width, scale, ok, my_next, R, &P);
+            wt_delta_apply_tile<QQ, DF>(d, c, B, tb, M, lane, w0, width, scale, ok, my_next, R, pn, &P);
             tb += step;
             if (tb >= M) break;
         }
+        if (pn.mask) wt_delta_flush<QQ, DF>(d, c, pn, lane, w0, width, scale, ok, my_next);      // the runs across the window's edges
     }
     my_next = wt_wave_min_i32(my_next);
     if (my_next != 0x7fffffff && wt_wave_leader(lane)) wt_lds_min32(&c.sh->next_bp, my_next);
