@@ -89,6 +89,8 @@ add(new("044_erf_table"))
 add("")
 add(body(10, "### 4.5 MedianReduction by walking: `wt_walk_kernel` (`csrc/wt_walk.h`, `csrc/wt_walk.hip`)"))
 add("")
+add(new("045_walk_round5"))
+add("")
 add(new("046_mwalk"))
 add("")
 add(body(6, "### 4.7 Window index: `wt_index_coarse_kernel` + `wt_index_search_kernel` (`wt_index_kernel` = the scan)"))

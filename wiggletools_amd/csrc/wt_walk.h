@@ -277,6 +277,93 @@ WT_DEV void wt_walk_place(WtWalkCtx &w, int32_t cs, uint32_t key, uint32_t meta)
     }
 }
 
+// The first pass over ONE TILE of runs (round 5).  wt_walk_count1 below does a run at a time: up to two LDS atomics WITH
+// return per run (the event's slot in its position), each followed by the store that needs the returned slot -- eight
+// dependent LDS round trips per tile and lane, behind whatever the other wavefronts have queued, at two wavefronts per
+// SIMD.  Here the tile's (up to) eight atomics and the four reads of the tracks' default keys are issued back to back and
+// waited for once; the events are stored and the columns initialised afterwards.  Same events, same counter words; the
+// order in which a position's slots are handed out was never defined (the lanes race for them).
+#ifndef WT_WALK_COUNT_TILE
+#define WT_WALK_COUNT_TILE 1
+#endif
+WT_DEV uint32_t wt_walk_place_inc(const WtWalkCtx &w, uint32_t meta) {
+    if (w.pair) return (1u << (7u * (meta & 1u))) + ((meta & WT_WALK_INC) ? WT_WALK_PCINC : 0u) + ((meta & WT_WALK_DEC) ? WT_WALK_PCDEC : 0u);
+    return 1u + ((meta & WT_WALK_INC) ? WT_WALK_CINC : 0u) + ((meta & WT_WALK_DEC) ? WT_WALK_CDEC : 0u);
+}
+// `old`: what the atomic on cnt[cs] returned
+WT_DEV void wt_walk_place_store(WtWalkCtx &w, int32_t cs, uint32_t key, uint32_t meta, uint32_t old) {
+    uint32_t slot, cap, at;
+    if (w.pair) {
+        const uint32_t half = meta & 1u;
+        slot = (old >> (7u * half)) & WT_WALK_PNMASK;
+        cap = (uint32_t) w.capp >> 1;
+        at = (((uint32_t) cs << 1) | half) * cap;
+    } else {
+        slot = old & WT_WALK_NMASK;
+        cap = (uint32_t) w.capp;
+        at = (uint32_t) cs * cap;
+    }
+    if (slot < cap) {
+        WtWalkEvent e;
+        e.key = key; e.meta = meta;
+        w.slab[at + slot] = e;
+    } else {
+        const uint32_t j = wt_lds_add_rtn(w.novf, 1u);
+        if (j < w.ov_cap) {
+            WtWalkOvf o;
+            o.pos = (uint32_t) cs; o.key = key; o.meta = meta;
+            w.ovf[j] = o;
+        }
+    }
+}
+WT_DEV void wt_walk_count_tile(const WtParams &P, WtWalkCtx &w, int nt, int32_t w0, int32_t width, const WtWalkBatch &B, uint32_t tb, uint32_t M,
+                               int lane, int32_t &my_next) {
+    bool inw[WT_DELTA_U], ds[WT_DELTA_U], df[WT_DELTA_U];
+    int32_t cs[WT_DELTA_U], cf[WT_DELTA_U];
+    uint32_t key[WT_DELTA_U], kf[WT_DELTA_U], ms[WT_DELTA_U], mf[WT_DELTA_U], rs[WT_DELTA_U], rf[WT_DELTA_U];
+    int vt[WT_DELTA_U];
+#pragma unroll
+    for (int u = 0; u < WT_DELTA_U; u++) {
+        const bool valid = tb + (uint32_t) lane + 64u * (uint32_t) u < M;
+        const int32_t s = B.s[u], f = B.f[u];
+        cs[u] = s - w0; cf[u] = f - w0;         // cf >= 0: the window's runs finish at or beyond w0
+        inw[u] = valid && cs[u] < width;
+        if (valid && cs[u] >= width) my_next = s < my_next ? s : my_next;
+        if (inw[u] && cf[u] >= width) my_next = f < my_next ? f : my_next;
+        key[u] = wt_walk_key(B.b[u]);
+        vt[u] = w.mwu ? wt_mw_vtrack(P, B.trk[u]) : B.trk[u];
+        ds[u] = inw[u] && cs[u] >= 0;
+        df[u] = inw[u] && cf[u] < width && (B.last[u] || B.ns[u] != f);    // (else the next run's start event says it all)
+        ms[u] = (uint32_t) vt[u] | ((B.first[u] || B.ps[u] != s) ? WT_WALK_INC : 0u);
+        mf[u] = (uint32_t) vt[u] | WT_WALK_DEC;
+    }
+    // everything that has to come back from the LDS, in one go
+#pragma unroll
+    for (int u = 0; u < WT_DELTA_U; u++) kf[u] = w.dkey[B.trk[u]];
+#pragma unroll
+    for (int u = 0; u < WT_DELTA_U; u++) rs[u] = ds[u] ? wt_lds_add_rtn(&w.cnt[cs[u]], wt_walk_place_inc(w, ms[u])) : 0u;
+#pragma unroll
+    for (int u = 0; u < WT_DELTA_U; u++) rf[u] = df[u] ? wt_lds_add_rtn(&w.cnt[cf[u]], wt_walk_place_inc(w, mf[u])) : 0u;
+#pragma unroll
+    for (int u = 0; u < WT_DELTA_U; u++) {
+        if (ds[u]) wt_walk_place_store(w, cs[u], key[u], ms[u], rs[u]);
+        if (df[u]) wt_walk_place_store(w, cf[u], kf[u], mf[u], rf[u]);
+    }
+    // the lanes whose first position a lies in (s, f]: the run covers the position before a
+#pragma unroll
+    for (int u = 0; u < WT_DELTA_U; u++) {
+        if (!inw[u]) continue;
+        int l = cs[u] < 0 ? 0 : (cs[u] >> w.logS) + 1;     // (no division: 30 instructions each on this machine)
+        int lh = cf[u] >> w.logS;
+        if (lh > w.nstr - 1) lh = w.nstr - 1;
+        const int row = (vt[u] >> w.pair) * nt, half = vt[u] & w.pair;
+        for (; l <= lh; l++) {
+            w.col[row + ((l << w.pair) | half)] = key[u];
+            wt_lds_addi32(&w.ncov[w.mwu ? ((l << 1) | half) : l], 1);
+        }
+    }
+}
+
 // one run, first pass: its events counted and placed, the columns it covers from before initialised
 WT_DEV void wt_walk_count1(const WtParams &P, WtWalkCtx &w, int nt, int32_t w0, int32_t width, int trk, int32_t s, int32_t f, int32_t ps,
                            int32_t ns, bool first, bool last, uint32_t vb, int32_t &my_next) {
@@ -348,6 +435,9 @@ WT_DEV void wt_walk_pass(const WtParams &P, WtCtx &c, WtWalkCtx &w, WtDeltaCtx &
     const uint32_t step = (uint32_t) nwaves * WT_DELTA_TILE;
     int32_t my_next = 0x7fffffff;
     auto apply = [&](const WtWalkBatch &B, uint32_t tb) {
+#if WT_WALK_COUNT_TILE
+        if (!SCATTER) { wt_walk_count_tile(P, w, nt, w0, width, B, tb, M, lane, my_next); return; }
+#endif
 #pragma unroll
         for (int u = 0; u < WT_DELTA_U; u++)
             if (tb + (uint32_t) lane + 64u * (uint32_t) u < M) {
