@@ -281,14 +281,15 @@ struct EmuRun {
                     }
                 }
             }
-            for (int t = 0; t < T; t++) wt_delta_scan1<QQ>(P, c, d, dl[t], t, T);
-            for (int t = 0; t < T; t++) wt_delta_scan2<QQ>(P, c, d, t, T);
-            for (int t = 0; t < T; t++) wt_delta_scan3<OP>(P, c, d, dl[t], lanes[t], scale, t, T);
+            const int TS = P.W / WT_DELTA_K;        // the scans' lanes (wt_delta_kernel: nts)
+            for (int t = 0; t < TS; t++) wt_delta_scan1<QQ>(P, c, d, dl[t], t, TS);
+            for (int t = 0; t < TS; t++) wt_delta_scan2<QQ>(P, c, d, t, TS);
+            for (int t = 0; t < TS; t++) wt_delta_scan3<OP>(P, c, d, dl[t], lanes[t], scale, t, TS);
             for (int t = 0; t < T; t++) wt_delta_nextw(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
             wt_phase_lookback(P, c, k);
             for (int t = 0; t < WT_BAD_SUB; t++) wt_delta_note_offset(P, c, t);
-            for (int t = 0; t < T; t++) wt_delta_stage<OP>(P, c, d, lanes[t], t, T);
+            for (int t = 0; t < TS; t++) wt_delta_stage<OP>(P, c, d, lanes[t], t, TS);
             for (int t = 0; t < T; t++) wt_delta_copy_out(P, c, d, t, T);
             wt_window_stats(P, c);
         }

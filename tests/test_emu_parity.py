@@ -202,6 +202,26 @@ def test_emu_delta_8192bp_windows(oracle, seed):
             assert_runs_equal(got, oracle.reduce(d, op, flags=strict), 0.0, "seed %d %s strict %d" % (seed, op, strict))
 
 
+def test_emu_delta_every_run_crosses_a_window_edge(oracle):
+    """Runs longer than a window, 300 tracks: every run of every window is one wt_delta_apply_or_park PARKS, and a lane
+    meets several of them per pass (flat indices l, l + 64, ... of a tile): the flush inside the loop, not only the one
+    at the end.  Both workgroup sizes, sum / mean / the squares, zero and non-zero defaults."""
+    from wiggletools_amd.runlists import RunLists, synth
+    t = synth(300, [70000, 9000], mean_run=11000, gap_prob=0.05, seed=77)
+    d = t.as_dict()
+    for T in (1024, 512):
+        for op, tol in (("sum", 0.0), ("mean", 0.0), ("var", 1e-12), ("stddev", 1e-12)):
+            if T == 1024 and op in ("var", "stddev"):
+                continue
+            got, info = emu.reduce(t, op, flags=1, delta_T=T)
+            assert info["delta"] == 1, info
+            assert_runs_equal(got, oracle.reduce(d, op, flags=1), tol, "long runs T %d op %s" % (T, op))
+    t2 = RunLists(t.n_chrom, t.n_tracks, t.seg_off, t.start, t.finish, t.value, np.where(np.arange(t.n_tracks) % 3 == 0, 1.5, 0.0))
+    got, info = emu.reduce(t2, "mean", delta_T=1024)
+    assert info["delta"] == 1, info
+    assert_runs_equal(got, oracle.reduce(t2.as_dict(), "mean"), 0.0, "long runs, defaults")
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_emu_delta_sum_mean_exact(oracle, seed):
     """Sum / Mean of float tracks with zero defaults through the difference-array path: bit-identical."""
@@ -488,7 +508,8 @@ def test_plan_policy_snapshot():
     p = plan(100, "max")
     assert (p["W"], p["T"], p["n_chunks"]) == (2048, 512, 1)             # bitmaps of 100 tracks: half the LDS
     p = plan(500, "var")
-    assert (p["delta"], p["W"], p["T"]) == (1, 4096, 512)                # round 2: difference arrays with exact squares (one 142 KB workgroup per CU)
+    assert (p["delta"], p["W"], p["T"]) == (1, 4096, 1024)               # difference arrays with exact squares: 4096-bp windows (147 KB); round 5: 1024 lanes for the passes, the first 512 run the scans
+    assert p["lds"] <= 160 * 1024
     p = plan(500, "var", no_delta=1)
     assert (p["W"], p["T"]) == (2048, 512) and p["n_chunks"] == 5        # general kernel: chunks of <= 112 tracks
     p = plan(100, "median")

@@ -689,6 +689,31 @@ def test_gpu_c2_shape_long_runs(oracle, engine):
     ts.close()
 
 
+def test_gpu_difference_array_every_run_crosses_a_window_edge(oracle, engine):
+    """Runs LONGER than a window, 300 tracks: every run of every window crosses an edge (spans w0, ends beyond w1, or
+    both), a window's flat space is one or two runs per track, and lane l of a wavefront holds flat indices l, l + 64,
+    l + 128, l + 192 of a tile -- several parked runs per lane, i.e. the in-loop flush of wt_delta_apply_or_park, not
+    only the one at the end of the pass.  Sum / mean (DF and not) and the squares, against the oracle."""
+    from wiggletools_amd.runlists import RunLists, synth
+    t = synth(300, [120000, 30000], mean_run=11000, gap_prob=0.05, seed=77)
+    d = t.as_dict()
+    ts = engine.TrackSet.from_runlists(t)
+    for op, tol in (("sum", 0.0), ("mean", 0.0), ("var", 1e-12), ("stddev", 1e-12)):
+        for strict in (0, 1):
+            got = ts.reduce_host(op, flags=strict)
+            assert ts.stats()["kernel"] == 1, ts.stats()
+            assert_runs_equal(got, oracle.reduce(d, op, flags=strict), tol, "long runs op %s strict %d" % (op, strict))
+    ts.close()
+    # non-zero defaults (the DF instantiation parks the default's bits with the run)
+    t2 = RunLists(t.n_chrom, t.n_tracks, t.seg_off, t.start, t.finish, t.value, np.where(np.arange(t.n_tracks) % 3 == 0, 1.5, 0.0))
+    ts = engine.TrackSet.from_runlists(t2)
+    for op in ("sum", "mean"):
+        got = ts.reduce_host(op)
+        assert ts.stats()["kernel"] == 1, ts.stats()
+        assert_runs_equal(got, oracle.reduce(t2.as_dict(), op), 0.0, "long runs, defaults, op %s" % op)
+    ts.close()
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_gpu_mwu_walk_paths(oracle, engine, seed, monkeypatch):
     """MWUReduction by walking (csrc/wt_mwalk.h) on the device: the default plan, short stretches, slots too few for the data

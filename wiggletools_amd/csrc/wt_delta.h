@@ -108,7 +108,7 @@ WT_DEV void wt_delta_ctx_init(WtDeltaCtx &d, const WtParams &P, char *lds) {
     d.qa = (unsigned long long *) (lds + P.off_qa);
     d.qb = d.qa + P.W;
     d.ltqa = (unsigned long long *) (lds + P.off_ltq);
-    d.ltqb = d.ltqa + P.W / WT_DELTA_K;                 // (W / K = workgroup size)
+    d.ltqb = d.ltqa + P.W / WT_DELTA_K;                 // (W / K = lanes of the scans)
     d.gtqa = (unsigned long long *) (lds + P.off_gtq);
     d.gtqb = d.gtqa + P.W / WT_DELTA_K / WT_DELTA_GROUP;
     d.dsh = (WtDeltaShared *) (lds + P.off_dsh);

@@ -207,14 +207,14 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
 #define WT_DELTA_MIN_WAVES 4     // waves per SIMD the register allocation aims at (experiments: 6 spills, see DESIGN A.1)
 #endif
 #ifndef WT_DELTA_SQ_BLOCK
-#define WT_DELTA_SQ_BLOCK 512    // workgroup of the launches that also accumulate squares
+#define WT_DELTA_SQ_BLOCK 1024   // workgroup of the launches that also accumulate squares (the scans: the first 512 lanes, see wt_make_delta_plan)
 #endif
 #ifndef WT_DELTA_BLOCK
 #define WT_DELTA_BLOCK 1024     // (launch bound; the plan's default, see wt_make_delta_plan)
 #endif
 // DF: some track's default is non-zero (Sum / Mean; P.delta_df)
 template <int OP, bool DF = false>
-__global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA_BLOCK, WT_DELTA_SQ(OP) ? 2 : WT_DELTA_MIN_WAVES) wt_delta_kernel(const WtParams P) {
+__global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA_BLOCK, WT_DELTA_MIN_WAVES) wt_delta_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
     wt_ctx_init(c, P, wt_lds);
@@ -224,6 +224,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
     WtDeltaLane DL;
     WtLane<WT_DELTA_K> L;
     const int tid = threadIdx.x, nt = blockDim.x;
+    const int nts = P.W / WT_DELTA_K;       // lanes of the scans and the staging (8 positions each): all of them, or the first 512 of 1024 (squares)
     int guess = 0;              // the workgroup's unit exponent (0: none yet); uniform across the lanes
     long long k_dbg = -1;
     (void) k_dbg;
@@ -319,10 +320,10 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             }
         }
         WT_MARK(105);
-        wt_delta_scan_w1<QQ>(P, c, d, DL, tid, nt);
+        if (tid < nts) wt_delta_scan_w1<QQ>(P, c, d, DL, tid, nts);
         __syncthreads();
         WT_MARK(107);
-        wt_delta_scan3<OP>(P, c, d, DL, L, scale, tid, nt);
+        if (tid < nts) wt_delta_scan3<OP>(P, c, d, DL, L, scale, tid, nts);
         __syncthreads();
         WT_TICK(4);
         WT_MARK(108);
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             wt_delta_note_offset(P, c, tid);                // (lane 0 set the offset in the look-back: same wave, LDS in order)
         }
         WT_TICK(6);
-        wt_delta_stage<OP>(P, c, d, L, tid, nt);
+        if (tid < nts) wt_delta_stage<OP>(P, c, d, L, tid, nts);
         __syncthreads();
 #ifdef WT_PROFILE_TAIL
         WT_TICK(2);                 // (experiment: the tail of a window apart -- staging here, copy-out in "write", ticket + header in "zero")

@@ -99,15 +99,20 @@ static inline bool wt_op_is_var_family(int op) {
 static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = false) {
     // Sum / Mean: 1024 lanes, an 8192-bp window, one workgroup of 16 waves per CU (round 3: 6 % faster than two
     // workgroups of 512 once pass 2 had shed its instructions -- the per-window chain of dependent round trips
-    // is paid half as often; round 2 had measured +1.5 %).  With squares: 512 (142 KB of LDS at 4096 bp).
+    // is paid half as often; round 2 had measured +1.5 %).
+    // With squares the window stays at 4096 bp (142 KB of LDS: four 64-bit accumulators per position) but the workgroup
+    // is 1024 lanes all the same since round 5: the passes over the runs -- 88 % of a window, each of VALU, LDS and loads
+    // ~40 % busy at two wavefronts per SIMD -- are flat loops any number of wavefronts can share; the scans, which own
+    // 8 positions per lane, are run by the first W / 8 = 512 lanes (wt_delta_kernel: `nts`).  WTAMD_DELTA_T=512: as before.
     const char *eT = getenv("WTAMD_DELTA_T");
-    const int T0 = squares ? 512 : 1024;
+    const int T0 = 1024;
     int T = eT ? atoi(eT) : T0;
     (void) n_tracks;
-    if (T < 64 || T > WT_MAX_DELTA_T || (T & (T - 1)) || (squares && T > 512)) T = T0;
+    if (T < 64 || T > WT_MAX_DELTA_T || (T & (T - 1))) T = T0;
+    const int TS = squares && T > 512 ? 512 : T;       // lanes of the scans: one per WT_DELTA_K positions
     p = WtPlan();
     p.delta = true;
-    p.T = T; p.ppt = WT_DELTA_K; p.W = WT_DELTA_K * T; p.n_words = p.W / 64;
+    p.T = T; p.ppt = WT_DELTA_K; p.W = WT_DELTA_K * TS; p.n_words = p.W / 64;
     p.chunk_tracks = 0; p.n_chunks = 1;
     int o = 0;
     p.off_acc = o;    o = wt_align16(o + p.W * 8);
@@ -116,20 +121,20 @@ static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = fa
     p.off_E = o;      o = wt_align16(o + p.n_words * 8);
     p.off_epfx = o;   o = wt_align16(o + (p.n_words + 1) * 4);
     p.off_nextw = o;  o = wt_align16(o + p.n_words * 2);
-    p.off_ltv = o;    o = wt_align16(o + T * 8);
-    p.off_ltc = o;    o = wt_align16(o + T * 4);
-    p.off_gtv = o;    o = wt_align16(o + (T / WT_DELTA_GROUP) * 8);
+    p.off_ltv = o;    o = wt_align16(o + TS * 8);
+    p.off_ltc = o;    o = wt_align16(o + T * 4);                        // (the tracks' run counts AND the scan lanes' totals)
+    p.off_gtv = o;    o = wt_align16(o + (TS / WT_DELTA_GROUP) * 8);
     p.off_gtc = o;    o = wt_align16(o + (T / WT_DELTA_GROUP) * 4);
     p.off_tbase = o;  o = wt_align16(o + T * 8);
     p.off_tpfx = o;   o = wt_align16(o + (T + 1) * 4);
     p.off_tfirst = o; o = wt_align16(o + WT_DELTA_TF * 2);
-    p.off_tdef = o;   o = wt_align16(o + T * 4);
+    p.off_tdef = o;   o = wt_align16(o + (squares ? 0 : T * 4));        // (non-zero defaults: Sum / Mean only)
     p.off_dsh = o;    o = wt_align16(o + (int) sizeof(WtDeltaShared));
     p.delta_q = squares ? 1 : 0;
     if (squares) {
         p.off_qa = o;  o = wt_align16(o + 2 * p.W * 8);
-        p.off_ltq = o; o = wt_align16(o + 2 * T * 8);
-        p.off_gtq = o; o = wt_align16(o + 2 * (T / WT_DELTA_GROUP) * 8);
+        p.off_ltq = o; o = wt_align16(o + 2 * TS * 8);
+        p.off_gtq = o; o = wt_align16(o + 2 * (TS / WT_DELTA_GROUP) * 8);
     }
     p.off_shared = o; o = wt_align16(o + (int) sizeof(WtShared));
     p.lds_bytes = o;
