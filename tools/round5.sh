@@ -16,10 +16,12 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/p_fetch -- python $R/bench.py $BARGS > $OUT/c2_fetch_run.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/p_write -- python $R/bench.py $BARGS > $OUT/c2_write_run.log 2>&1
 i=0
+if [ -z "$SKIP_C5" ]; then
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "VALUBusy SALUBusy SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/p_c5_$i -- python $R/bench.py --config c5 --chroms 20 --steps 1 --warmup 1 --no-cpu-baseline --no-e2e --no-sub > $OUT/c5_sq$i.log 2>&1
 done
+fi
 python - <<PY
 import csv, glob, json, os
 out = "$OUT"

@@ -36,7 +36,7 @@
 #define WT_DELTA_K 8            // positions per lane: one byte of the U / E bitmaps
 #define WT_DELTA_GROUP 16       // lanes per group in the hierarchical scan
 #ifndef WT_DELTA_PARK
-#define WT_DELTA_PARK 1         // runs that cross a window edge are parked and applied once per wavefront (see wt_delta_apply_or_park)
+#define WT_DELTA_PARK 1         // runs that cross a window edge are parked and applied once per wavefront -- by the launches with squares (see wt_delta_apply_tile)
 #endif
 #ifndef WT_DELTA_U
 #define WT_DELTA_U 4            // flat interval indices per lane and tile (round 2, with the prefetch really in flight: 4 beats 8 by 4 % at 100 tracks, loses 1 % at 500; round 1 measured the opposite with the prefetch serialised)
@@ -601,29 +601,32 @@ WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF> 
         return;
     }
 #endif
-#if WT_DELTA_PARK
-    if (tb + WT_DELTA_TILE <= M) {
+    // WT_DELTA_PARK: 1 = the launches with squares park (their long branch is twice as long and, at 500 tracks and 4096-bp
+    // windows, every second wave row took it: -10 %); Sum / Mean do not (C2 the same to 1 % on a fast box, 4 % slower under
+    // the profiler on a slow one: two more spilled registers and 5 % more HBM traffic); 2 = everybody parks; 0 = nobody.
+    if constexpr (WT_DELTA_PARK == 2 || (WT_DELTA_PARK == 1 && QQ)) {
+        if (tb + WT_DELTA_TILE <= M) {
 #pragma unroll
-        for (int u = 0; u < WT_DELTA_U; u++)
-            wt_delta_apply_or_park<QQ, DF>(d, c, pn, lane, true, w0, width, B.s[u], B.f[u], B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
+            for (int u = 0; u < WT_DELTA_U; u++)
+                wt_delta_apply_or_park<QQ, DF>(d, c, pn, lane, true, w0, width, B.s[u], B.f[u], B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
+        } else {
+#pragma unroll
+            for (int u = 0; u < WT_DELTA_U; u++)
+                wt_delta_apply_or_park<QQ, DF>(d, c, pn, lane, tb + (uint32_t) lane + 64u * (uint32_t) u < M, w0, width, B.s[u], B.f[u], B.b[u],
+                                               DF ? B.d[u] : 0u, scale, ok, my_next, R);
+        }
     } else {
+        if (tb + WT_DELTA_TILE <= M) {
 #pragma unroll
-        for (int u = 0; u < WT_DELTA_U; u++)
-            wt_delta_apply_or_park<QQ, DF>(d, c, pn, lane, tb + (uint32_t) lane + 64u * (uint32_t) u < M, w0, width, B.s[u], B.f[u], B.b[u],
-                                           DF ? B.d[u] : 0u, scale, ok, my_next, R);
-    }
-#else
-    if (tb + WT_DELTA_TILE <= M) {
-#pragma unroll
-        for (int u = 0; u < WT_DELTA_U; u++)
-            wt_delta_apply<QQ, DF>(d, c, w0, width, B.s[u], B.f[u], B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
-    } else {
-#pragma unroll
-        for (int u = 0; u < WT_DELTA_U; u++)
-            if (tb + (uint32_t) lane + 64u * (uint32_t) u < M)
+            for (int u = 0; u < WT_DELTA_U; u++)
                 wt_delta_apply<QQ, DF>(d, c, w0, width, B.s[u], B.f[u], B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
+        } else {
+#pragma unroll
+            for (int u = 0; u < WT_DELTA_U; u++)
+                if (tb + (uint32_t) lane + 64u * (uint32_t) u < M)
+                    wt_delta_apply<QQ, DF>(d, c, w0, width, B.s[u], B.f[u], B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
+        }
     }
-#endif
 }
 
 // `scale`: exponent of one unit of the scaled mantissas; `ok`: false -> the window is known not to be

@@ -224,7 +224,10 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
     WtDeltaLane DL;
     WtLane<WT_DELTA_K> L;
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int nts = P.W / WT_DELTA_K;       // lanes of the scans and the staging (8 positions each): all of them, or the first 512 of 1024 (squares)
+    // lanes of the scans and the staging (8 positions each): all of them -- or, with squares, the first 512 of 1024.  (Sum / Mean must not
+    // see a run-time bound here: the guard alone cost wt_delta_kernel<mean> 31 more spilled registers and a quarter more HBM traffic.)
+    const int nts = QQ ? P.W / WT_DELTA_K : nt;
+#define WT_SCAN_LANE (!QQ || tid < nts)
     int guess = 0;              // the workgroup's unit exponent (0: none yet); uniform across the lanes
     long long k_dbg = -1;
     (void) k_dbg;
@@ -320,10 +323,10 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             }
         }
         WT_MARK(105);
-        if (tid < nts) wt_delta_scan_w1<QQ>(P, c, d, DL, tid, nts);
+        if (WT_SCAN_LANE) wt_delta_scan_w1<QQ>(P, c, d, DL, tid, nts);
         __syncthreads();
         WT_MARK(107);
-        if (tid < nts) wt_delta_scan3<OP>(P, c, d, DL, L, scale, tid, nts);
+        if (WT_SCAN_LANE) wt_delta_scan3<OP>(P, c, d, DL, L, scale, tid, nts);
         __syncthreads();
         WT_TICK(4);
         WT_MARK(108);
@@ -345,7 +348,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             wt_delta_note_offset(P, c, tid);                // (lane 0 set the offset in the look-back: same wave, LDS in order)
         }
         WT_TICK(6);
-        if (tid < nts) wt_delta_stage<OP>(P, c, d, L, tid, nts);
+        if (WT_SCAN_LANE) wt_delta_stage<OP>(P, c, d, L, tid, nts);
         __syncthreads();
 #ifdef WT_PROFILE_TAIL
         WT_TICK(2);                 // (experiment: the tail of a window apart -- staging here, copy-out in "write", ticket + header in "zero")
@@ -374,6 +377,8 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
         for (int q = 0; q < 8; q++) wt_glb_add64(&P.counters[WT_CTR_PROF + q], prof[q]);
 #endif
 }
+
+#undef WT_SCAN_LANE
 
 // Patch kernel: the general bitmap multiplexer over just the windows the difference-array kernel
 // could not prove exact (a NaN, an Inf, too wide a dynamic range).  That kernel has already emitted
