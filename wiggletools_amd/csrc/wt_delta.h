@@ -83,14 +83,21 @@ struct WtDeltaCtx {
     WtDeltaShared *dsh;
 };
 
-// per-lane registers across the scan's barriers
+// per-lane registers across the scan's barriers.  Round 5: only the lane's TOTALS and what the wavefront's scan makes of them -- the
+// inclusive prefixes of its 8 positions (8 x value, coverage and, with squares, two more 64-bit sums: up to 56 registers) used to be
+// carried from scan 1 to scan 3; scan 3 now reads the lane's 8 positions from LDS a second time (224 bytes) and forms the prefixes as
+// it goes.  The launches with squares, at 1024 lanes and 128 registers each, had 115 registers in scratch memory because of them.
+// Sum / Mean keep their prefixes in registers as before (24 of them: they fit, and at mean run 200, where the scans are a fifth of a
+// window, the second read cost 7 %).
 struct WtDeltaLane {
-    long long pv[WT_DELTA_K];   // inclusive prefix of the lane's value deltas
-    int32_t pc[WT_DELTA_K];     // inclusive prefix of the lane's coverage deltas
-    uint32_t evmask;            // bit k: position k is a true breakpoint
+    long long pv[WT_DELTA_K];   // Sum / Mean: inclusive prefix of the lane's value deltas
+    int32_t pc[WT_DELTA_K];     // Sum / Mean: inclusive prefix of the lane's coverage deltas
+    uint32_t evmask;            // Sum / Mean: bit k: position k is a true breakpoint
+    long long tv;               // sum of the lane's value deltas
+    int32_t tc;                 // ... of its coverage deltas
     long long wv;               // device: sum of the value deltas of the wave's lanes before this one
     int32_t wc;                 // device: same for the coverage deltas
-    unsigned long long pqa[WT_DELTA_K], pqb[WT_DELTA_K];    // delta_q launches: inclusive prefixes of the squares' parts
+    unsigned long long tqa, tqb;    // delta_q launches: the lane's sums of the squares' parts
     unsigned long long wqa, wqb;
 };
 
@@ -746,25 +753,22 @@ WT_DEV void wt_delta_scan1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLa
         const uint32_t e = d.ev[p0 + k];
         rv += d.acc[p0 + k];
         rc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
-        L.pv[k] = rv;
-        L.pc[k] = rc;
-        evm |= (e != 0u ? 1u : 0u) << k;
+        if constexpr (!QQ) { L.pv[k] = rv; L.pc[k] = rc; evm |= (e != 0u ? 1u : 0u) << k; }
     }
-    L.evmask = evm;
+    if constexpr (!QQ) L.evmask = evm;
+    L.tv = rv;
+    L.tc = rc;
     d.ltv[tid] = rv;
     d.ltc[tid] = rc;
     if constexpr (QQ) {
         unsigned long long ra = 0, rb = 0;
 #pragma unroll
-        for (int k = 0; k < WT_DELTA_K; k++) {
-            ra += d.qa[p0 + k]; rb += d.qb[p0 + k];
-            L.pqa[k] = ra; L.pqb[k] = rb;
-        }
+        for (int k = 0; k < WT_DELTA_K; k++) { ra += d.qa[p0 + k]; rb += d.qb[p0 + k]; }
+        L.tqa = ra; L.tqb = rb;
         d.ltqa[tid] = ra; d.ltqb[tid] = rb;
     }
 }
 
-// scan step 2: group totals (one lane per group of 16)
 template <bool QQ = false>
 WT_DEV void wt_delta_scan2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
     const int ngroups = nt / WT_DELTA_GROUP;
@@ -816,20 +820,30 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
     // 2^(emin - 150): the weight of one unit of the scaled mantissas
     const double q = __builtin_bit_cast(double, (uint64_t) (emin - 150 + 1023) << 52);
     const long long room = (long long) c.sh->emit_hi - ((long long) c.sh->w0 + p0);
-    uint32_t em = 0;
+    uint32_t em = 0, evmask = 0;
+    if constexpr (!QQ) evmask = L.evmask;
 #pragma unroll
     for (int k = 0; k < WT_DELTA_K; k++) {
-        const int32_t cov = bc + L.pc[k];
-        const bool pred = strict ? (cov == N) : (cov > 0);       // multiplexer.c:120,125
-        if (((L.evmask >> k) & 1u) && pred && k < room) em |= 1u << k;
         if constexpr (!QQ) {
+            const int32_t cov = bc + L.pc[k];
+            const bool pred = strict ? (cov == N) : (cov > 0);       // multiplexer.c:120,125
+            if (((evmask >> k) & 1u) && pred && k < room) em |= 1u << k;
             const double s = (double) (bv + L.pv[k]) * q;
             out.res[k] = (OP == WT_OP_MEAN) ? s / N : s;
         } else {
+            // the lane's 8 positions once more (scan 1 kept only their totals): running sums from the lane's base on
+            const uint32_t e = d.ev[p0 + k];
+            bv += d.acc[p0 + k];
+            bc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
+            bqa += d.qa[p0 + k]; bqb += d.qb[p0 + k];
+            evmask |= (e != 0u ? 1u : 0u) << k;
+            const int32_t cov = bc;
+            const bool pred = strict ? (cov == N) : (cov > 0);       // multiplexer.c:120,125
+            if (e != 0u && pred && k < room) em |= 1u << k;
             // exact integers: S, n = cov, Q = (A << 40) + B (see WT_DELTA_QSHIFT)
-            const long long S = bv + L.pv[k];
+            const long long S = bv;
             const unsigned long long sa = (unsigned long long) (S < 0 ? -S : S);
-            const unsigned __int128 Q = ((unsigned __int128) (bqa + L.pqa[k]) << WT_DELTA_QSHIFT) + (unsigned __int128) (bqb + L.pqb[k]);
+            const unsigned __int128 Q = ((unsigned __int128) bqa << WT_DELTA_QSHIFT) + (unsigned __int128) bqb;
             const unsigned __int128 s2 = (unsigned __int128) sa * sa;
             unsigned __int128 I;
             if (OP == WT_OP_VAR) I = (unsigned __int128) ((unsigned long long) N * (unsigned long long) N) * Q - (unsigned __int128) (unsigned long long) (2 * N - cov) * s2;
@@ -849,7 +863,7 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
             out.res[k] = r;
         }
     }
-    ((uint8_t *) c.U)[tid] = (uint8_t) L.evmask;
+    ((uint8_t *) c.U)[tid] = (uint8_t) evmask;
     ((uint8_t *) c.E)[tid] = (uint8_t) em;
 }
 
@@ -977,15 +991,15 @@ template <bool QQ = false>
 WT_DEV void wt_delta_scan_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLane &L, int tid, int nt) {
     wt_delta_scan1<QQ>(P, c, d, L, tid, nt);
     const int lane = tid & 63;
-    const long long rv = L.pv[WT_DELTA_K - 1];
-    const int32_t rc = L.pc[WT_DELTA_K - 1];
+    const long long rv = L.tv;
+    const int32_t rc = L.tc;
     const long long iv = wt_wave_scan_i64(rv, lane);
     const int32_t ic = (int32_t) wt_wave_scan_u32((unsigned) rc, lane);
     L.wv = iv - rv;
     L.wc = ic - rc;
     if (lane == 63) { d.gtv[tid >> 6] = iv; d.gtc[tid >> 6] = ic; }
     if constexpr (QQ) {
-        const unsigned long long ra = L.pqa[WT_DELTA_K - 1], rb = L.pqb[WT_DELTA_K - 1];
+        const unsigned long long ra = L.tqa, rb = L.tqb;
         const unsigned long long ia = (unsigned long long) wt_wave_scan_i64((long long) ra, lane);
         const unsigned long long ib = (unsigned long long) wt_wave_scan_i64((long long) rb, lane);
         L.wqa = ia - ra;
