@@ -66,4 +66,9 @@ if missing:
 text = re.sub(r"@@([A-Z0-9_]+)@@", lambda m: V.get(m.group(1), m.group(0)), text)
 # the drop-in layer's file was split this round
 text = text.replace("Host C++ (`csrc/wt_iter_abi.cpp`), because", "Host C++ (`csrc/wt_iter_abi.cpp` + the `csrc/wt_abi_*.h` it includes: common, feeder, reduce, readers, bwdev, ops, integrators -- one translation unit), because")
+# §4.2's description was written in round 2: say so where the plan has changed since
+text = text.replace("Window: 4096 bp, 512 lanes, ONE 142 KB workgroup (8 waves) per CU.  The first version",
+                    "Window: 4096 bp; rounds 2-4: 512 lanes, ONE 142 KB workgroup (8 waves) per CU (round 5: 1024 lanes, 147 KB, 16 waves -- \"Today\" below).  The first version")
+text = text.replace("C3 on MI355X: var + stddev over 500 tracks of chromosome 1 in 100 ms (both reducers, index once):",
+                    "C3 on MI355X in round 2: var + stddev over 500 tracks of chromosome 1 in 100 ms (both reducers, index once):")
 sys.stdout.write(text)
