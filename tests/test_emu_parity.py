@@ -508,7 +508,7 @@ def test_plan_policy_snapshot():
     p = plan(100, "max")
     assert (p["W"], p["T"], p["n_chunks"]) == (2048, 512, 1)             # bitmaps of 100 tracks: half the LDS
     p = plan(500, "var")
-    assert (p["delta"], p["W"], p["T"]) == (1, 4096, 1024)               # difference arrays with exact squares: 4096-bp windows (147 KB); round 5: 1024 lanes for the passes, the first 512 run the scans
+    assert (p["delta"], p["W"], p["T"]) == (1, 4096, 768)                # difference arrays with exact squares: 4096-bp windows; round 5: 768 lanes for the passes (168 registers each), the first 512 run the scans
     assert p["lds"] <= 160 * 1024
     p = plan(500, "var", no_delta=1)
     assert (p["W"], p["T"]) == (2048, 512) and p["n_chunks"] == 5        # general kernel: chunks of <= 112 tracks

@@ -44,6 +44,7 @@
 #define WT_DELTA_TILE (64 * WT_DELTA_U)
 #define WT_DELTA_TF 2048        // tiles whose first track is tabulated (beyond: binary search)
 #define WT_MAX_DELTA_T 1024     // largest workgroup of the difference-array kernels (an 8192-bp window)
+#define WT_DELTA_SQ_T0 768      // workgroup (and launch bound) of the launches with squares: 12 wavefronts share the passes, the first 8 run the scans
 
 struct WtDeltaShared {
     long long base_v;           // scaled sum of the intervals spanning w0

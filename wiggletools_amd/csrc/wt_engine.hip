@@ -207,14 +207,14 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
 #define WT_DELTA_MIN_WAVES 4     // waves per SIMD the register allocation aims at (experiments: 6 spills, see DESIGN A.1)
 #endif
 #ifndef WT_DELTA_SQ_BLOCK
-#define WT_DELTA_SQ_BLOCK 1024   // workgroup of the launches that also accumulate squares (the scans: the first 512 lanes, see wt_make_delta_plan)
+#define WT_DELTA_SQ_BLOCK WT_DELTA_SQ_T0   // workgroup of the launches that also accumulate squares (768: three wavefronts per SIMD, 168 registers; the scans: the first 512 lanes, see wt_make_delta_plan)
 #endif
 #ifndef WT_DELTA_BLOCK
 #define WT_DELTA_BLOCK 1024     // (launch bound; the plan's default, see wt_make_delta_plan)
 #endif
 // DF: some track's default is non-zero (Sum / Mean; P.delta_df)
 template <int OP, bool DF = false>
-__global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA_BLOCK, WT_DELTA_MIN_WAVES) wt_delta_kernel(const WtParams P) {
+__global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA_BLOCK, WT_DELTA_SQ(OP) ? 3 : WT_DELTA_MIN_WAVES) wt_delta_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
     wt_ctx_init(c, P, wt_lds);

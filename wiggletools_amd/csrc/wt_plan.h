@@ -94,21 +94,28 @@ static inline bool wt_op_is_var_family(int op) {
 }
 
 // `squares`: the launch also accumulates the sum of squares (var / stddev / CV): two more u64 arrays
-// per position: 142 KB of LDS for the 4096-bp window, one workgroup of 8 waves per CU -- measured 21 %
+// per position: ~145 KB of LDS for the 4096-bp window, one workgroup per CU -- measured 21 %
 // faster than 2048-bp windows (86 KB: also one workgroup per CU, but of 4 waves).
 static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = false) {
     // Sum / Mean: 1024 lanes, an 8192-bp window, one workgroup of 16 waves per CU (round 3: 6 % faster than two
     // workgroups of 512 once pass 2 had shed its instructions -- the per-window chain of dependent round trips
     // is paid half as often; round 2 had measured +1.5 %).
-    // With squares the window stays at 4096 bp (142 KB of LDS: four 64-bit accumulators per position) but the workgroup
-    // is 1024 lanes all the same since round 5: the passes over the runs -- 88 % of a window, each of VALU, LDS and loads
-    // ~40 % busy at two wavefronts per SIMD -- are flat loops any number of wavefronts can share; the scans, which own
-    // 8 positions per lane, are run by the first W / 8 = 512 lanes (wt_delta_kernel: `nts`).  WTAMD_DELTA_T=512: as before.
+    // With squares the window stays at 4096 bp (four 64-bit accumulators per position) but the workgroup is 768 lanes since
+    // round 5: the passes over the runs -- 88 % of a window, each of VALU, LDS and loads ~40 % busy at two wavefronts per
+    // SIMD -- are flat loops any number of wavefronts can share; the scans, which own 8 positions per lane, are run by the
+    // first W / 8 = 512 lanes (wt_delta_kernel: `nts`).  768 and not 1024: three wavefronts per SIMD leave 168 registers per
+    // lane, which the scans' 128-bit arithmetic fits into; at 128 they spilled 41 (C3: 57.5 against 55.5 ms; 512 lanes: 63.2).
+    // WTAMD_DELTA_T=512: as before round 5; WTAMD_DELTA_SQ_T: any multiple of 64 from 512 to the launch bound.
     const char *eT = getenv("WTAMD_DELTA_T");
-    const int T0 = 1024;
+    const int T0 = squares ? WT_DELTA_SQ_T0 : 1024;
     int T = eT ? atoi(eT) : T0;
     (void) n_tracks;
-    if (T < 64 || T > WT_MAX_DELTA_T || (T & (T - 1))) T = T0;
+    const int Tmax = squares ? WT_DELTA_SQ_T0 : WT_MAX_DELTA_T;
+    if (T < 64 || T > Tmax || ((T & (T - 1)) && !(squares && T > 512 && T % 64 == 0))) T = T0;
+    if (squares && !eT) {
+        const char *eS = getenv("WTAMD_DELTA_SQ_T");
+        if (eS && atoi(eS) >= 512 && atoi(eS) <= Tmax && atoi(eS) % 64 == 0) T = atoi(eS);
+    }
     const int TS = squares && T > 512 ? 512 : T;       // lanes of the scans: one per WT_DELTA_K positions
     p = WtPlan();
     p.delta = true;
