@@ -497,6 +497,32 @@ def test_emu_edge_data_only_in_late_tracks_and_late_chromosomes(oracle):
         assert_runs_equal(got, oracle.reduce(t.as_dict(), op), 0.0, op)
 
 
+def test_emu_delta_squares_workgroup_sizes(oracle, monkeypatch):
+    """The launches with squares: the passes over the runs are shared by ALL the workgroup's wavefronts, the scans are run by
+    the first W / 8 = 512 lanes -- 768 lanes by default (round 5), any multiple of 64 from 512 to 768 through
+    WTAMD_DELTA_SQ_T, the old 512-lane layout through WTAMD_DELTA_T; same results, same 4096-bp windows."""
+    from wiggletools_amd.runlists import synth
+    t = synth(40, [30000, 5000], mean_run=6, gap_prob=0.05, seed=31)
+    d = t.as_dict()
+    exp = {op: oracle.reduce(d, op) for op in ("var", "stddev", "cv")}
+    for env, want_T in ((None, 768), ("512", 512), ("640", 640), ("768", 768), ("1024", 768), ("700", 768)):
+        if env is None:
+            monkeypatch.delenv("WTAMD_DELTA_SQ_T", raising=False)
+        else:
+            monkeypatch.setenv("WTAMD_DELTA_SQ_T", env)
+        for op in ("var", "stddev", "cv"):
+            got, info = emu.reduce(t, op)
+            assert (info["delta"], info["W"], info["T"]) == (1, 4096, want_T), (env, info)
+            assert_runs_equal(got, exp[op], 1e-12, "squares, WTAMD_DELTA_SQ_T=%s, op %s" % (env, op))
+    monkeypatch.delenv("WTAMD_DELTA_SQ_T", raising=False)
+    got, info = emu.reduce(t, "var", delta_T=512)
+    assert (info["W"], info["T"]) == (4096, 512), info
+    assert_runs_equal(got, exp["var"], 1e-12, "squares, 512 lanes")
+    got, info = emu.reduce(t, "var", delta_T=256)
+    assert (info["W"], info["T"]) == (2048, 256), info
+    assert_runs_equal(got, exp["var"], 1e-12, "squares, 256 lanes")
+
+
 def test_plan_policy_snapshot():
     """The execution plans the measurements in DESIGN.md were taken with (MI355X, round 1)."""
     from wiggletools_amd.runlists import synth
