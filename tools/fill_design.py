@@ -71,4 +71,6 @@ text = text.replace("Window: 4096 bp, 512 lanes, ONE 142 KB workgroup (8 waves) 
                     "Window: 4096 bp; rounds 2-4: 512 lanes, ONE 142 KB workgroup (8 waves) per CU (round 5: 1024 lanes, 147 KB, 16 waves -- \"Today\" below).  The first version")
 text = text.replace("C3 on MI355X: var + stddev over 500 tracks of chromosome 1 in 100 ms (both reducers, index once):",
                     "C3 on MI355X in round 2: var + stddev over 500 tracks of chromosome 1 in 100 ms (both reducers, index once):")
+text = text.replace("CU; rounds 1-2 and the launches with squares: T = 512, W = 4096, 66 KB, 2 workgroups / CU):",
+                    "CU; rounds 1-2: T = 512, W = 4096, 66 KB, 2 workgroups / CU; the launches with squares: W = 4096, 146 KB, one workgroup of 768 lanes of which the first 512 run steps 3-5, §4.2):")
 sys.stdout.write(text)
