@@ -36,7 +36,7 @@ def build(force=False):
 
 def build_variant(name, flags):
     """tests/emu/libwt_emu_<name>.so: the emulator compiled with extra flags (compile-time switches of the kernels' logic that are
-    not the default, e.g. -DWT_DELTA_MERGE=1), rebuilt when a source is newer."""
+    not the default, e.g. -DWT_DELTA_PARK=2), rebuilt when a source is newer."""
     so = os.path.join(HERE, "libwt_emu_%s.so" % name)
     csrc = os.path.join(HERE, "..", "..", "wiggletools_amd", "csrc")
     srcs = [os.path.join(HERE, "wt_emu.cpp")] + [os.path.join(csrc, h) for h in ("wt_core.h", "wt_plan.h", "wt_delta.h", "wt_walk.h", "wt_mwalk.h")]

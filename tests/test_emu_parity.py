@@ -497,6 +497,26 @@ def test_emu_edge_data_only_in_late_tracks_and_late_chromosomes(oracle):
         assert_runs_equal(got, oracle.reduce(t.as_dict(), op), 0.0, op)
 
 
+def test_emu_delta_everybody_parks(oracle):
+    """wt_delta.h with -DWT_DELTA_PARK=2 (not the default: only the launches with squares park runs that cross a window edge;
+    for Sum / Mean it measured a wash with two more spilled registers): Sum / Mean with zero and non-zero defaults through
+    wt_delta_apply_or_park and its two flushes, against the oracle at tolerance 0."""
+    from wiggletools_amd.runlists import RunLists, synth
+    emu.use_variant("park2", ["-DWT_DELTA_PARK=2"])
+    try:
+        t = synth(300, [70000, 9000], mean_run=11000, gap_prob=0.05, seed=78)      # every run crosses an edge: flushes inside the loop
+        t2 = RunLists(t.n_chrom, t.n_tracks, t.seg_off, t.start, t.finish, t.value, np.where(np.arange(t.n_tracks) % 3 == 0, 1.5, 0.0))
+        u = synth(60, [50000], mean_run=9, gap_prob=0.1, seed=79)                   # ordinary signal: one flush per wavefront and window
+        for case, name in ((t, "long"), (t2, "long, defaults"), (u, "dense")):
+            for op in ("sum", "mean"):
+                for flags in (0, 1):
+                    got, info = emu.reduce(case, op, flags=flags, delta_T=1024)
+                    assert info["delta"] == 1, info
+                    assert_runs_equal(got, oracle.reduce(case.as_dict(), op, flags=flags), 0.0, "park2 %s %s strict %d" % (name, op, flags))
+    finally:
+        emu.use_variant(None)
+
+
 def test_emu_delta_squares_workgroup_sizes(oracle, monkeypatch):
     """The launches with squares: the passes over the runs are shared by ALL the workgroup's wavefronts, the scans are run by
     the first W / 8 = 512 lanes -- 768 lanes by default (round 5), any multiple of 64 from 512 to 768 through
@@ -656,33 +676,6 @@ def test_emu_median_walk_fuzz(oracle, seed):
         assert_runs_equal(got, exp, 0.0, "walking vs oracle")
     if ov == 0 and n >= 8 and t.n_intervals > 50 * n:
         assert info["walk_fallback"] > 0
-
-
-def test_emu_delta_merged_atomics(oracle):
-    """wt_delta.h with -DWT_DELTA_MERGE=1 (not the default: it measured no faster on MI355X): where a track's runs are contiguous the
-    lane of the later run adds v - v' at the shared position and the earlier one skips its finish -- two LDS atomics per run
-    instead of four, eight -> four with squares.  Integer adds commute: Sum / Mean bit-exact, the var family at 1e-12, non-zero
-    defaults, gaps (no merge across them), more tracks than lanes, ranges."""
-    emu.use_variant("merge", ["-DWT_DELTA_MERGE=1"])
-    try:
-        for seed in range(8):
-            rng = np.random.default_rng(9100 + seed)
-            n = int(rng.choice([3, 8, 64, 100, 300]))
-            defaults = (rng.integers(-3, 4, n).astype(np.float64) / 4.0) if seed % 3 == 1 else None
-            t = synth(n, [int(rng.integers(200, 5000)), int(rng.integers(1, 300))], mean_run=float(rng.choice([1, 3, 16, 70])), seed=seed,
-                      gap_prob=float(rng.choice([0, 0.05, 0.5])), dtype=np.float32, value_levels=int(rng.choice([5, 800])), defaults=defaults)
-            flags = int(rng.choice([0, 1]))
-            for op in ("sum", "mean"):
-                got, info = emu.reduce(t, op, flags=flags, delta_T=int(rng.choice([64, 256, 1024])))
-                assert info["delta"] == 1
-                assert_runs_equal(got, oracle.reduce(t.as_dict(), op, flags=flags), 0.0, "merged %s seed %d" % (op, seed))
-            if defaults is None and n >= 8:
-                for op in ("var", "stddev"):
-                    got, info = emu.reduce(t, op, flags=flags, delta_T=int(rng.choice([64, 256, 512])))
-                    assert info["delta"] == 1
-                    assert_runs_equal(got, oracle.reduce(t.as_dict(), op, flags=flags), 1e-12, "merged %s seed %d" % (op, seed))
-    finally:
-        emu.use_variant(None)
 
 
 @pytest.mark.parametrize("seed", range(36))

@@ -443,10 +443,6 @@ struct WtDeltaBatch {
     int32_t s[WT_DELTA_U], f[WT_DELTA_U];
     uint32_t b[WT_DELTA_U];
     uint32_t d[DF ? WT_DELTA_U : 1];    // DF: bits of the interval's track's default
-    uint32_t edge;                      // bit u: the interval is the FIRST of its track in this window; bit 8 + u: the last
-#ifdef WT_EMU
-    long long ob[WT_DELTA_U];           // (emulator: byte offset of the interval -- the neighbour lanes' intervals are re-read)
-#endif
 };
 
 // The loads are UNCONDITIONAL and always in range: a flat index past the end is clamped to the last
@@ -462,17 +458,15 @@ WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint3
     const uint32_t tbe = tb < last ? tb : last;
     const uint32_t tile = tbe / WT_DELTA_TILE;
     int i = tile < WT_DELTA_TF ? (int) d.tfirst[tile] : wt_delta_find(d.tpfx, nt, tbe, 0);
-    uint32_t lo = d.tpfx[i], hi = d.tpfx[i + 1];
+    uint32_t hi = d.tpfx[i + 1];
     long long dl = d.tbase[i];
     uint32_t db = DF ? d.tdef[i] : 0u;
-    uint32_t edge = 0u;
 #pragma unroll
     for (int u = 0; u < WT_DELTA_U; u++) {
         uint32_t jj = tbe + (uint32_t) lane + 64u * (uint32_t) u;
         jj = jj < M - 1u ? jj : M - 1u;
         if (jj >= hi) {
             do { i++; hi = d.tpfx[i + 1]; } while (jj >= hi);
-            lo = d.tpfx[i];
             dl = d.tbase[i];
             if (DF) db = d.tdef[i];
         }
@@ -481,134 +475,18 @@ WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint3
         B.f[u] = *(const int32_t *) ((const char *) P.finish + ob);
         B.b[u] = *(const uint32_t *) ((const char *) P.value + ob);
         if (DF) B.d[u] = db;
-        edge |= (jj == lo ? 1u : 0u) << u;
-        edge |= (jj + 1u == hi ? 0x100u : 0u) << u;
-#ifdef WT_EMU
-        B.ob[u] = ob;
-#endif
     }
-    B.edge = edge;
 }
 
-// ---- contiguous runs share an atomic ----
-// The lanes of a tile row hold CONSECUTIVE intervals of a track, and where the data is contiguous (a run starts where
-// the track's previous one finishes -- 98 % of the bench's runs, most signal tracks) the lane of the previous interval
-// subtracts at the very position where this lane adds: acc[p] += v; ev[p] += 1 here, acc[p] -= v'; ev[p] += 0x10000
-// there.  Integer adds commute, so ONE lane does acc[p] += v - v'; ev[p] += 0x10001 and the other skips its finish: two
-// LDS atomics per interval instead of four (they are what pass 2 waits for: LDSBankConflict 27 % of the LDS cycles at
-// four per interval, 33 % at the eight of the launches with squares).  Both decide from the same three facts,
-// each lane computing them for itself and passing them one lane along (DPP wave shifts): both intervals lie inside the
-// window (the branch-free common case of wt_delta_apply), the later one is not the first of its track here, the
-// coordinates meet.  Bit-identical by construction; the emulator re-reads the neighbour's interval instead.
-#ifndef WT_DELTA_MERGE
-#define WT_DELTA_MERGE 0            // (measured on MI355X, round 5: no effect -- C2 66.50 against 66.83 ms, C3 70.58 against 70.49: the atomics are not what pass 2 waits for)
-#endif
-#define WT_DELTA_NOCOORD ((int32_t) 0x80000000)         // "no such neighbour": never equals a coordinate (they are >= 0)
-#ifndef WT_EMU
-WT_DEV int32_t wt_dpp_from_prev(int32_t x, int32_t dflt) {       // lane l gets lane l - 1's value; lane 0: dflt
-    return __builtin_amdgcn_update_dpp(dflt, x, 0x138, 0xf, 0xf, false);        // wave_shr:1
-}
-WT_DEV int32_t wt_dpp_from_next(int32_t x, int32_t dflt) {       // lane l gets lane l + 1's value; lane 63: dflt
-    return __builtin_amdgcn_update_dpp(dflt, x, 0x130, 0xf, 0xf, false);        // wave_shl:1
-}
-#endif
-
-// the common case of wt_delta_apply with the merge; false: not the common case (the caller takes wt_delta_apply)
-template <bool QQ, bool DF>
-WT_DEV void wt_delta_apply_merged(WtDeltaCtx &d, uint32_t cs, uint32_t cf, long long vi, bool common, bool merge_start, bool skip_finish,
-                                  long long vi_prev, unsigned long long qa, unsigned long long qb, unsigned long long qa_prev, unsigned long long qb_prev) {
-    if (!common) return;
-    wt_lds_add64((unsigned long long *) &d.acc[cs], (unsigned long long) (vi - (merge_start ? vi_prev : 0ll)));
-    wt_lds_add32(&d.ev[cs], merge_start ? 0x10001u : 1u);
-    if (QQ) {
-        wt_lds_add64(&d.qa[cs], qa - (merge_start ? qa_prev : 0ull));
-        wt_lds_add64(&d.qb[cs], qb - (merge_start ? qb_prev : 0ull));
-    }
-    if (!skip_finish) {
-        wt_lds_sub64((unsigned long long *) &d.acc[cf], (unsigned long long) vi);
-        wt_lds_add32(&d.ev[cf], 0x10000u);
-        if (QQ) { wt_lds_sub64(&d.qa[cf], qa); wt_lds_sub64(&d.qb[cf], qb); }
-    }
-}
+// (Round 5 tried "contiguous runs share an atomic" here: where a track's runs are contiguous the lane of the previous run subtracts at
+// the very position where this lane adds, so one lane can do both -- two LDS atomics per run instead of four, the facts passed one lane
+// along by DPP wave shifts, bit-identical.  No effect on MI355X: C2 66.50 against 66.83 ms, C3 70.58 against 70.49; the code is
+// tools/experiments/r5_delta_merged_atomics.patch, the record DESIGN 4.1.)
 
 // every interval of the tile at flat index `tb`; only the window's last tile can be partial
 template <bool QQ = false, bool DF = false>
 WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF> &B, uint32_t tb, uint32_t M, int lane, int32_t w0,
-                                uint32_t width, int scale, bool ok, int32_t &my_next, WtDeltaRange &R, WtDeltaPend<DF> &pn, const WtParams *Pp = nullptr) {
-#if WT_DELTA_MERGE
-    {
-        const bool full = tb + WT_DELTA_TILE <= M;
-#pragma unroll
-        for (int u = 0; u < WT_DELTA_U; u++) {
-            const bool valid = full || tb + (uint32_t) lane + 64u * (uint32_t) u < M;
-            const int32_t s = B.s[u], f = B.f[u];
-            const uint32_t cs = (uint32_t) (s - w0), cf = (uint32_t) (f - w0);
-            const bool common = valid && cs < width && cf < width;
-            const bool first = (B.edge >> u) & 1u, last = (B.edge >> (8 + u)) & 1u;
-            long long vi = wt_delta_scaled(B.b[u], scale);
-            if (DF) vi -= wt_delta_scaled(B.d[u], scale);
-            unsigned long long qa = 0, qb = 0;
-#ifdef WT_EMU
-            if (!ok) vi = 0;
-#endif
-            if (QQ) wt_delta_square((unsigned long long) (vi < 0 ? -vi : vi), qa, qb);
-            // what the neighbours need to know, and what they say
-            const int32_t f_eff = common ? f : WT_DELTA_NOCOORD;
-            const int32_t s_eff = (common && !first) ? s : WT_DELTA_NOCOORD;
-            int32_t f_prev, s_next;
-            long long vi_prev;
-            unsigned long long qa_prev = 0, qb_prev = 0;
-#ifdef WT_EMU
-            {
-                (void) f_eff; (void) s_eff;
-                // the intervals at flat index - 1 / + 1, where they exist in the same row of the tile (lane - 1 / lane + 1) and track
-                f_prev = WT_DELTA_NOCOORD; s_next = WT_DELTA_NOCOORD; vi_prev = 0;
-                if (lane > 0 && valid && !first) {
-                    const int32_t ps = *(const int32_t *) ((const char *) Pp->start + B.ob[u] - 4), pf = *(const int32_t *) ((const char *) Pp->finish + B.ob[u] - 4);
-                    const uint32_t pb = *(const uint32_t *) ((const char *) Pp->value + B.ob[u] - 4);
-                    if ((uint32_t) (ps - w0) < width && (uint32_t) (pf - w0) < width) {
-                        f_prev = pf;
-                        vi_prev = wt_delta_scaled(pb, scale);
-                        if (DF) vi_prev -= wt_delta_scaled(B.d[u], scale);
-                        if (!ok) vi_prev = 0;
-                        if (QQ) wt_delta_square((unsigned long long) (vi_prev < 0 ? -vi_prev : vi_prev), qa_prev, qb_prev);
-                    }
-                }
-                const bool next_valid = lane < 63 && (full || tb + (uint32_t) lane + 1u + 64u * (uint32_t) u < M);
-                if (next_valid && valid && !last) {
-                    const int32_t ns = *(const int32_t *) ((const char *) Pp->start + B.ob[u] + 4), nf = *(const int32_t *) ((const char *) Pp->finish + B.ob[u] + 4);
-                    if ((uint32_t) (ns - w0) < width && (uint32_t) (nf - w0) < width) s_next = ns;
-                }
-            }
-#else
-            f_prev = wt_dpp_from_prev(f_eff, WT_DELTA_NOCOORD);
-            s_next = wt_dpp_from_next(s_eff, WT_DELTA_NOCOORD);
-            {
-                const int32_t lo32 = wt_dpp_from_prev((int32_t) (uint32_t) (unsigned long long) vi, 0);
-                const int32_t hi32 = wt_dpp_from_prev((int32_t) (uint32_t) ((unsigned long long) vi >> 32), 0);
-                vi_prev = (long long) (((unsigned long long) (uint32_t) hi32 << 32) | (unsigned long long) (uint32_t) lo32);
-                if (QQ) {
-                    const int32_t a0 = wt_dpp_from_prev((int32_t) (uint32_t) qa, 0), a1 = wt_dpp_from_prev((int32_t) (uint32_t) (qa >> 32), 0);
-                    const int32_t b0 = wt_dpp_from_prev((int32_t) (uint32_t) qb, 0), b1 = wt_dpp_from_prev((int32_t) (uint32_t) (qb >> 32), 0);
-                    qa_prev = ((unsigned long long) (uint32_t) a1 << 32) | (unsigned long long) (uint32_t) a0;
-                    qb_prev = ((unsigned long long) (uint32_t) b1 << 32) | (unsigned long long) (uint32_t) b0;
-                }
-            }
-#endif
-            const bool merge_start = common && !first && f_prev == s;          // (f_prev: NOCOORD unless the previous interval is all inside too)
-            const bool skip_finish = common && s_next == f;                      // (s_next: NOCOORD unless the next one is inside and of this track)
-            if (common) {
-                const uint32_t key = B.b[u] & 0x7fffffffu;
-                R.kmax = key > R.kmax ? key : R.kmax;
-                R.kmin = key - 1u < R.kmin ? key - 1u : R.kmin;
-            }
-            wt_delta_apply_merged<QQ, DF>(d, cs, cf, vi, common, merge_start, skip_finish, vi_prev, qa, qb, qa_prev, qb_prev);
-            if (valid && !common)
-                wt_delta_apply<QQ, DF>(d, c, w0, width, s, f, B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
-        }
-        return;
-    }
-#endif
+                                uint32_t width, int scale, bool ok, int32_t &my_next, WtDeltaRange &R, WtDeltaPend<DF> &pn) {
     // WT_DELTA_PARK: 1 = the launches with squares park (their long branch is twice as long and, at 500 tracks and 4096-bp
     // windows, every second wave row took it: -10 %); Sum / Mean do not (C2 the same to 1 % on a fast box, 4 % slower under
     // the profiler on a slow one: two more spilled registers and 5 % more HBM traffic); 2 = everybody parks; 0 = nobody.
@@ -668,11 +546,11 @@ WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale
         wt_delta_fetch<DF>(P, d, nt, M, tb, lane, A);
         for (;;) {
             wt_delta_fetch<DF>(P, d, nt, M, tb + step, lane, B);    // (past the end: harmless re-reads of the last tile)
-            wt_delta_apply_tile<QQ, DF>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R, pn, &P);
+            wt_delta_apply_tile<QQ, DF>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
             tb += step;
             if (tb >= M) break;
             wt_delta_fetch<DF>(P, d, nt, M, tb + step, lane, A);
-            wt_delta_apply_tile<QQ, DF>(d, c, B, tb, M, lane, w0, width, scale, ok, my_next, R, pn, &P);
+            wt_delta_apply_tile<QQ, DF>(d, c, B, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
             tb += step;
             if (tb >= M) break;
         }
