@@ -941,8 +941,12 @@ def compact(res):
             c["many_core_value"] = mc["value"]
             c["many_core_cores"] = mc.get("cores")
         out["cpu_baseline"] = c
-    for k in ("speedup_vs_cpu_baseline", "speedup_vs_many_core_cpu", "output_runs", "auc_check", "bench_seconds", "full_record"):
+    for k in ("speedup_vs_cpu_baseline", "speedup_vs_many_core_cpu", "output_runs", "auc_check", "pearson_tracks_0_1", "bench_seconds", "full_record"):
         if k in res:
+            out[k] = res[k]
+    # multi-GPU runs: which collectives ran on which backend, and the work queue's check (small dicts)
+    for k in ("collectives", "work_queue_check"):
+        if isinstance(res.get(k), dict) and len(json.dumps(res[k])) < 700:
             out[k] = res[k]
     out = _sig(out)
     line = json.dumps(out, separators=(",", ":"))

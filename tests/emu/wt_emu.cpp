@@ -225,20 +225,22 @@ struct EmuRun {
 
     template <int OP, bool DF = false>
     void run_delta() {
-        constexpr bool QQ = OP == WT_OP_VAR || OP == WT_OP_STDDEV || OP == WT_OP_ENTROPY || OP == WT_OP_CV;
+        constexpr bool TT = OP == WT_OP_TTEST;      // two sets per position (wt_delta_scan3_tt)
+        constexpr bool QQ = OP == WT_OP_VAR || OP == WT_OP_STDDEV || OP == WT_OP_ENTROPY || OP == WT_OP_CV || TT;
         WtCtx c;
         wt_ctx_init(c, P, lds.data());
         WtDeltaCtx d;
         wt_delta_ctx_init(d, P, lds.data());
         const int T = plan.T;
         std::vector<WtDeltaLane> dl(T);
+        std::vector<WtDeltaLane2> dl2(T);
         int guess = 0;      // the workgroup's unit exponent (0: none yet)
         std::vector<WtLane<WT_DELTA_K>> lanes(T);
         for (;;) {
             const long long k = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
             if (k >= P.n_windows) break;
             wt_phase_header(P, c, k);
-            for (int t = 0; t < T; t++) wt_delta_zero<QQ>(P, c, d, t, T);
+            for (int t = 0; t < T; t++) wt_delta_zero<QQ, TT>(P, c, d, t, T);
             const int nchunks = (P.n_tracks + T - 1) / T;
             auto ranges = [&](int ch) {
                 for (int t = 0; t < T; t++) wt_delta_ranges1(P, c, d, ch * T, t, T);
@@ -256,13 +258,13 @@ struct EmuRun {
                 if (!ok) wt_delta_mark_bad(P, c, k);
                 for (int ch = 0; ch < nchunks; ch++) {
                     if (nchunks > 1) ranges(ch);
-                    for (int t = 0; t < T; t++) wt_delta_pass2<QQ, DF>(P, c, d, scale, ok, false, true, t, T, std::min(T, P.n_tracks - ch * T));
+                    for (int t = 0; t < T; t++) wt_delta_pass2<QQ, DF, TT>(P, c, d, scale, ok, false, true, t, T, std::min(T, P.n_tracks - ch * T), ch * T);
                 }
                 if (any && ok) guess = scale;
             } else {                // speculative single pass with the workgroup's unit
                 for (int ch = 0; ch < nchunks; ch++) {
                     ranges(ch);
-                    for (int t = 0; t < T; t++) wt_delta_pass2<QQ, DF>(P, c, d, guess, true, true, true, t, T, std::min(T, P.n_tracks - ch * T));
+                    for (int t = 0; t < T; t++) wt_delta_pass2<QQ, DF, TT>(P, c, d, guess, true, true, true, t, T, std::min(T, P.n_tracks - ch * T), ch * T);
                 }
                 int lo; bool ok;
                 scale = guess;
@@ -271,10 +273,10 @@ struct EmuRun {
                         wt_delta_mark_bad(P, c, k);         // (values rewritten by the patch; the structure is in place)
                     } else {
                         n_redo++;
-                        for (int t = 0; t < T; t++) wt_delta_rezero<QQ>(P, c, d, t, T);
+                        for (int t = 0; t < T; t++) wt_delta_rezero<QQ, TT>(P, c, d, t, T);
                         for (int ch = 0; ch < nchunks; ch++) {
                             if (nchunks > 1) ranges(ch);
-                            for (int t = 0; t < T; t++) wt_delta_pass2<QQ, DF>(P, c, d, lo, ok, false, false, t, T, std::min(T, P.n_tracks - ch * T));
+                            for (int t = 0; t < T; t++) wt_delta_pass2<QQ, DF, TT>(P, c, d, lo, ok, false, false, t, T, std::min(T, P.n_tracks - ch * T), ch * T);
                         }
                         scale = lo;
                         guess = lo;
@@ -282,13 +284,22 @@ struct EmuRun {
                 }
             }
             const int TS = P.W / WT_DELTA_K;        // the scans' lanes (wt_delta_kernel: nts)
-            for (int t = 0; t < TS; t++) wt_delta_scan1<QQ>(P, c, d, dl[t], t, TS);
-            for (int t = 0; t < TS; t++) wt_delta_scan2<QQ>(P, c, d, t, TS);
-            for (int t = 0; t < TS; t++) wt_delta_scan3<OP>(P, c, d, dl[t], lanes[t], scale, t, TS);
+            if constexpr (TT) {
+                for (int t = 0; t < TS; t++) wt_delta_scan1_tt(P, c, d, dl2[t], t, TS);
+                for (int t = 0; t < TS; t++) wt_delta_scan2_tt(P, c, d, t, TS);
+                for (int t = 0; t < TS; t++) wt_delta_scan3_tt(P, c, d, dl2[t], lanes[t], scale, t, TS);
+                for (int t = 0; t < T; t++) wt_delta_tail_tt(P, d, t, T);
+                if (d.dsh->risk && c.sh->bad_slot < 0) wt_delta_mark_bad(P, c, k);
+            } else {
+                for (int t = 0; t < TS; t++) wt_delta_scan1<QQ>(P, c, d, dl[t], t, TS);
+                for (int t = 0; t < TS; t++) wt_delta_scan2<QQ>(P, c, d, t, TS);
+                for (int t = 0; t < TS; t++) wt_delta_scan3<OP>(P, c, d, dl[t], lanes[t], scale, t, TS);
+            }
             for (int t = 0; t < T; t++) wt_delta_nextw(P, c, t, T);
             for (int t = 0; t < T; t++) wt_phase_escan(P, c, t, T);
             wt_phase_lookback(P, c, k);
             for (int t = 0; t < WT_BAD_SUB; t++) wt_delta_note_offset(P, c, t);
+            if constexpr (TT) for (int t = 0; t < TS; t++) wt_delta_load_res_tt(P, d, lanes[t], t);
             for (int t = 0; t < TS; t++) wt_delta_stage<OP>(P, c, d, lanes[t], t, TS);
             for (int t = 0; t < T; t++) wt_delta_copy_out(P, c, d, t, T);
             wt_window_stats(P, c);
@@ -328,7 +339,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         if (attempt == 0 && !delta) continue;
         EmuRun R;
         std::string err;
-        if (delta) wt_make_delta_plan(R.plan, n_tracks, wt_op_is_var_family(op));
+        if (delta) wt_make_delta_plan_for(R.plan, n_tracks, op);
         else {
             // the engine's wt_pick_plan: the median over float tracks walks
             bool walk = false;
@@ -404,6 +415,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
                 case WT_OP_MEAN: if (P.delta_df) R.run_delta<WT_OP_MEAN, true>(); else R.run_delta<WT_OP_MEAN>(); break;
                 case WT_OP_VAR: R.run_delta<WT_OP_VAR>(); break;
                 case WT_OP_CV: R.run_delta<WT_OP_CV>(); break;
+                case WT_OP_TTEST: R.run_delta<WT_OP_TTEST>(); break;
                 default: R.run_delta<WT_OP_STDDEV>(); break;
                 }
             } else if (R.plan.walk_S && R.plan.walk_mwu) {
@@ -436,5 +448,11 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
     if (counters[WT_CTR_ERROR]) return -2;
     return (long long) counters[WT_CTR_RUNS];
 }
+
+// the device's form of the t-test's tail (wt_core.h wt_tdist_2Q_fast: the device reducers' wt_ttest_tail) and the oracle's form
+// beside it, for tests/test_tdist_fast.py
+double wtemu_tdist_2q_fast(double t, double nu) { return wt_tdist_2Q_fast(t, nu); }
+double wtemu_tdist_2q(double t, double nu) { return 2 * wt_tdist_Q(t, nu); }
+double wtemu_lgamma_half_diff(double a) { return wt_lgamma_half_diff(a); }
 
 }  // extern "C"

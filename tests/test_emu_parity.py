@@ -763,3 +763,100 @@ def test_emu_median_walk_dense_and_sparse(oracle, pair):
         got, info = emu.reduce(t, "median", flags=flags, walk_pair=pair)
         assert info["walk"] == 1
         assert_runs_equal(got, oracle.reduce(t.as_dict(), "median", flags=flags), 0.0, "one run per track")
+
+
+# ---- TTestReduction by difference arrays (round 6: wt_delta.h, wt_delta_scan3_tt) ----
+@pytest.mark.parametrize("seed", range(16))
+def test_emu_delta_ttest(oracle, seed):
+    """Welch's t-test over two sets of float tracks: per set the exact integer sum and sum of squares of the tracks IN PLAY
+    (setComparisons.c:60-81), the reference's own arithmetic from there on (:88-117).  Values on a coarse grid (the
+    reference's sums do not round): bit for bit; full mantissas: 1e-9 (the reference's sum of squares carries its own
+    rounding); coordinates and the set of emitted runs (both sets in play, :48-54; the four strictness flags) exact."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.choice([8, 9, 16, 33, 100, 200]))
+    n1 = int(rng.integers(3, n - 2))
+    levels = int(rng.choice([2, 800]))
+    t = synth(n, [int(rng.integers(200, 7000)), 300], mean_run=float(rng.choice([1, 3, 16, 60])), seed=seed,
+              gap_prob=float(rng.choice([0, 0.05, 0.5])), dtype=np.float32, value_levels=levels)
+    coarse = seed % 3 != 0
+    if not coarse:          # several binades of dynamic range, values that are not multiples of 1/8
+        t.value[:] = (t.value * rng.choice([1e-3, 1.0, 37.5], len(t.value))).astype(np.float32)
+    d = t.as_dict()
+    for flags in (0, 1, 2, 3):
+        got, info = emu.reduce(t, "ttest", flags=flags, n_set0=n1)
+        # (delta 0 with bad windows: more than a quarter of these few windows had to be patched -- exponent range or cancelling
+        #  variance in a set of three or four tracks -- and the general kernel redid the launch)
+        assert (info["delta"] == 1 and info["W"] == 2048 and info["T"] == 768) or info["delta_bad"] > 0, info
+        exp = oracle.reduce(d, "ttest", flags=flags, n_set0=n1)
+        assert_runs_equal(got, exp, 0.0 if coarse else 1e-9,
+                          "ttest seed %d flags %d n1 %d %s" % (seed, flags, n1, info))
+
+
+def test_emu_delta_ttest_long_runs_and_edges(oracle):
+    """Runs longer than a window (every run is parked, both sets' bases carry the sums across the edge), a breakpoint exactly
+    on a window edge in one set only, a set that leaves play for a while."""
+    from wiggletools_amd.runlists import RunLists
+    t = synth(24, [30000, 5000], mean_run=5000, gap_prob=0.2, seed=91, dtype=np.float32, value_levels=40)
+    d = t.as_dict()
+    for n1 in (3, 12, 21):
+        for flags in (0, 3):
+            got, info = emu.reduce(t, "ttest", flags=flags, n_set0=n1)
+            assert info["delta"] == 1, info
+            assert_runs_equal(got, oracle.reduce(d, "ttest", flags=flags, n_set0=n1), 0.0, "long runs n1 %d flags %d" % (n1, flags))
+    # set 1 (tracks 4..7) only covers [2049, 4097): no run before, breakpoints on both window edges
+    tracks = []         # [track][chromosome] -> [(start, finish, value)]
+    for i in range(8):
+        if i < 4:
+            s = list(range(1, 6001, 10 + i))
+            tracks.append([[(a, b, (j * (i + 3)) % 17 / 4.0 + 3 * i) for j, (a, b) in enumerate(zip(s, s[1:] + [6001]))]])
+        else:
+            s = list(range(2049, 4097, 64 * (i - 3)))
+            tracks.append([[(a, b, (j * (i + 1)) % 5 / 2.0 + 3 * i) for j, (a, b) in enumerate(zip(s, s[1:] + [4097]))]])
+    t2 = RunLists.from_lists(tracks, dtype=np.float32)
+    got, info = emu.reduce(t2, "ttest", n_set0=4)
+    exp = oracle.reduce(t2.as_dict(), "ttest", n_set0=4)
+    assert info["delta"] == 1 and len(exp[0]) > 100, info
+    assert exp[1].min() == 2049 and exp[2].max() == 4097
+    assert_runs_equal(got, exp, 0.0, "window edges")
+
+
+def test_emu_delta_ttest_cancelling_variance_is_patched(oracle):
+    """Both sets fully in play with nearly equal values: var = meanSq - mean^2 cancels, the reference's result is made of its
+    own rounding errors -- such windows (wt_ttest_stat: var * 2^10 < meanSq at an emitted position) are recorded and the
+    general kernel, which adds in the reference's order, rewrites them: bit-identical with the oracle there too.  NaN / Inf /
+    too wide an exponent range: the same route."""
+    t = synth(10, [60000], mean_run=40, gap_prob=0.0, seed=17, dtype=np.float32, value_levels=800)
+    d0 = t.as_dict()
+    got, info = emu.reduce(t, "ttest", n_set0=5)
+    assert info["delta"] == 1 and info["delta_bad"] == 0, info
+    # windows 3 and 11 (2048 bp each): every value 1000.1 +- a few ulp
+    v = t.value
+    rng = np.random.default_rng(3)
+    for w in (3, 11):
+        m = (t.start >= 1 + w * 2048 - 200) & (t.start < 1 + (w + 1) * 2048)
+        v[m] = (np.float32(1000.1) + rng.integers(-2, 3, int(m.sum())).astype(np.float32) * np.float32(6.1e-5)).astype(np.float32)
+    v[len(v) // 2] = np.nan
+    d = t.as_dict()
+    got, info = emu.reduce(t, "ttest", n_set0=5)
+    assert info["delta"] == 1 and 3 <= info["delta_bad"] <= 7 and info["patched"] == info["delta_bad"], info
+    exp = oracle.reduce(d, "ttest", n_set0=5)
+    assert_runs_equal(got, exp, 1e-9, "patched")
+    # ... and inside the patched windows the values are the general kernel's, i.e. the oracle's bits
+    inside = ((exp[1] >= 1 + 3 * 2048) & (exp[1] < 1 + 4 * 2048)) | ((exp[1] >= 1 + 11 * 2048) & (exp[1] < 1 + 12 * 2048))
+    assert inside.sum() > 50
+    assert np.array_equal(got[3][inside], exp[3][inside], equal_nan=True)
+
+
+def test_emu_delta_ttest_not_used_when_ineligible(oracle):
+    t7 = synth(7, [3000], mean_run=5, seed=1, dtype=np.float32)
+    assert emu.reduce(t7, "ttest", n_set0=3)[1]["W"] != 2048 or emu.reduce(t7, "ttest", n_set0=3)[1]["T"] != 768
+    t64 = synth(12, [3000], mean_run=5, seed=1, dtype=np.float64)
+    got, info = emu.reduce(t64, "ttest", n_set0=6)
+    assert info["delta"] == 0 and info["delta_bad"] == 0
+    # defaults play no part in the t-test (setComparisons.c:69-81): non-zero defaults stay on the difference arrays
+    t9 = synth(40, [30000], mean_run=5, seed=1, dtype=np.float32, value_levels=800)
+    t9.defaults[2] = 1.5
+    t9.defaults[30] = -7.0
+    got, info = emu.reduce(t9, "ttest", n_set0=14)
+    assert info["delta"] == 1, info
+    assert_runs_equal(got, oracle.reduce(t9.as_dict(), "ttest", n_set0=14), 0.0, "defaults ignored")

@@ -453,6 +453,66 @@ def test_gpu_difference_array_var_family(oracle, engine, seed):
     ts.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_gpu_difference_array_ttest(oracle, engine, seed):
+    """TTestReduction by difference arrays (round 6: wt_delta_kernel<ttest>, wt_delta_scan3_tt): per set the exact integer sum
+    and sum of squares of the tracks in play (setComparisons.c:60-81), the reference's arithmetic from there (:88-117).
+    1e-9 against the oracle (coarse values and full mantissas); coordinates and emitted runs exact under the four strictness flags;
+    NaN / Inf / wide exponent range / cancelling variance: those windows come from the general kernel (wt_patch_kernel)."""
+    from wiggletools_amd.runlists import synth
+    rng = np.random.default_rng(7100 + seed)
+    n = int(rng.choice([8, 16, 33, 100, 200, 900]))
+    n1 = int(rng.integers(3, n - 2)) if seed % 2 else n // 2
+    t = synth(n, [int(rng.integers(3000, 90000)), 900], mean_run=float(rng.choice([1, 3, 16, 60, 3000])), seed=seed,
+              gap_prob=float(rng.choice([0, 0.05, 0.5])), dtype=np.float32, value_levels=800)
+    if seed % 3 == 0:
+        t.value[:] = (t.value * rng.choice([0.3, 1.0, 37.5], len(t.value))).astype(np.float32)
+    if seed % 4 == 1:
+        t = synth(40, [200000, 900], mean_run=16.0, seed=seed, gap_prob=0.05, dtype=np.float32, value_levels=800)     # 98 windows: a few bad ones are patched
+        t.value[7] = np.nan
+        t.value[len(t.value) // 2] = np.inf
+        t.value[len(t.value) // 3] = 2.0 ** -120
+        t.value[len(t.value) // 3 + 1] = 2.0 ** 100
+        n, n1 = 40, 17
+    d = t.as_dict()
+    ts = engine.TrackSet.from_runlists(t)
+    for flags in (0, 1, 2, 3):
+        got = ts.reduce_host("ttest", flags=flags, n_set0=n1)
+        st = ts.stats()
+        assert st["kernel"] == 1 and st["window_bp"] == 2048, st
+        if seed % 4 == 1:
+            assert st["patched_windows"] > 0, st
+        # (1e-9 on the device whatever the values: its lgamma / log / exp are not the host's; the emulator's test holds the
+        #  coarse-grid cases to tolerance 0)
+        assert_runs_equal(got, oracle.reduce(d, "ttest", flags=flags, n_set0=n1), 1e-9,
+                          "ttest seed %d flags %d n %d n1 %d %s" % (seed, flags, n, n1, st))
+    ts.close()
+
+
+@pytest.mark.gpu
+def test_gpu_difference_array_ttest_vs_general_kernel(oracle, engine, monkeypatch):
+    """The two routes of TTestReduction on the same 100 tracks x 300 kbp (50 v 50, the shape of the bench record): coordinates
+    equal, values equal bit for bit (k/8 values: neither route's sums round); and the second launch -- verdict known, no
+    host round trip -- gives the same runs as the first."""
+    from wiggletools_amd.runlists import synth
+    t = synth(100, [300000, 5000], mean_run=16.0, seed=4, gap_prob=0.02, dtype=np.float32, value_levels=800)
+    ts = engine.TrackSet.from_runlists(t)
+    a = ts.reduce_host("ttest", n_set0=50)
+    assert ts.stats()["kernel"] == 1
+    a2 = ts.reduce_host("ttest", n_set0=50)
+    monkeypatch.setenv("WTAMD_NO_DELTA_TTEST", "1")
+    ts2 = engine.TrackSet.from_runlists(t)
+    b = ts2.reduce_host("ttest", n_set0=50)
+    assert ts2.stats()["kernel"] == 0
+    for x, y, z in zip(a, b, a2):
+        assert np.array_equal(x, y, equal_nan=True) and np.array_equal(x, z, equal_nan=True)
+    assert len(a[0]) > 250000
+    exp = oracle.reduce(t.as_dict(), "ttest", n_set0=50)
+    assert_runs_equal(a, exp, 1e-9, "ttest 50 v 50")
+    ts.close(); ts2.close()
+
+
 def test_gpu_input_contract_validation(engine):
     """wtamd_trackset_validate: zero-length, inverted and overlapping runs are counted; a run list
     may start a new (chrom, track) segment below the previous segment's last finish."""

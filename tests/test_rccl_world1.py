@@ -20,7 +20,12 @@ def _line(cmd):
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert lines, r.stdout[-2000:]
-    return json.loads(lines[-1])
+    compact = json.loads(lines[-1])             # the driver's line: the last one of stdout, small
+    assert len(lines[-1]) < 6000 and "roofline" in compact
+    # the full record (every figure at full precision) goes to stderr and to --full-record
+    full = [l for l in r.stderr.splitlines() if l.startswith("bench full record: ")]
+    assert full, r.stderr[-2000:]
+    return json.loads(full[-1][len("bench full record: "):])
 
 
 @pytest.mark.gpu

@@ -132,7 +132,7 @@ struct WtParams {
     // filled on the host with the host's libm (wt_mwu_make_table, wt_plan.h).  NULL: the device's erf.
     const double *mwu_table;
     int32_t mwu_kmax;
-    int32_t pad1;
+    int32_t delta_ns;             // difference-array launches: sets per position (0 / 1: one; 2: TTestReduction, wt_delta.h)
 };
 
 // Block-shared scalars (live in LDS at off_shared)
@@ -333,6 +333,105 @@ WT_DEV double wt_tdist_Q(double t, double nu) {
     double x = nu / (nu + t * t);
     double tail = 0.5 * wt_inc_beta(nu / 2, 0.5, x);
     return t >= 0 ? tail : 1 - tail;
+}
+
+// ---------------------------------------------------------------------------
+// The same tail, written for the device (round 6): 2 Q(t; nu) = I_x(nu/2, 1/2), x = nu / (nu + t^2), t >= 0.
+// wt_tdist_Q above costs ~2000 wave instructions per call -- two lgamma, and six f64 divisions per round of the modified
+// Lentz continued fraction -- and a launch evaluates it once per output run.  Here:
+//   * lgamma(a + 1/2) - lgamma(a) is ONE asymptotic series, 1/2 ln a + sum_k (2^(1-k) - 2) B_k / (k (k - 1) a^(k-1)) over even k
+//     (Bernoulli polynomials at 1/2: B_k(1/2) = (2^(1-k) - 1) B_k), through k = 12 at a >= 16 (next term 3e-18); a smaller a is
+//     shifted up: D(a) = D(a + j) - ln prod_{i<j} (a + i + 1/2) / (a + i).  One log, one or two divisions;
+//   * the continued fraction 1 / (1 + d1 / (1 + d2 / ...)), d_n = p_n / q_n (the coefficients of wt_betacf), is run as the
+//     equivalent fraction with partial numerators p_n q_(n-1) and denominators q_n by the forward recurrence
+//     A_n = q_n A_(n-1) + p_n q_(n-1) A_(n-2) (same for B): no division until the very end; the four running terms are scaled
+//     back by a power of two now and then; converged when |B_n A_(n-1) - B_(n-1) A_n| < eps |A_n B_(n-1)|, i.e. when Lentz's
+//     ratio of successive approximants is within eps of 1.
+// Same mathematical quantity as wt_tdist_Q, rounded differently (~1e-15 relative apart; tests/test_tdist_fast.py holds it to 1e-12
+// against the oracle's over the (t, nu) plane).  The device's reducers call wt_ttest_tail; the emulator keeps the oracle's form.
+// ---------------------------------------------------------------------------
+WT_DEV double wt_lgamma_half_diff(double a) {
+    // lgamma(a + 1/2) - lgamma(a), a > 0
+    double num = 1.0, den = 1.0;
+    while (a < 16.0) { num *= a + 0.5; den *= a; a += 1.0; }
+    const double r = 1.0 / a, r2 = r * r;
+    double sres = 691.0 / 180224.0;
+    sres = sres * r2 - 31.0 / 18432.0;
+    sres = sres * r2 + 17.0 / 14336.0;
+    sres = sres * r2 - 1.0 / 640.0;
+    sres = sres * r2 + 1.0 / 192.0;
+    sres = sres * r2 - 1.0 / 8.0;
+    double dres = 0.5 * log(a) + sres * r;
+    if (num != 1.0) dres -= log(num / den);
+    return dres;
+}
+
+// h = 1 / (1 + d1 / (1 + d2 / ...)) with wt_betacf's coefficients
+WT_DEV double wt_betacf_wallis(double a, double b, double x) {
+    const double eps = 1e-16;
+    // n = 0: A_0 = 1, B_0 = 1 (f_0 = 1), A_-1 = 1, B_-1 = 0; q_0 = 1
+    double A2 = 1.0, B2 = 0.0, A1 = 1.0, B1 = 1.0, qprev = 1.0;
+    // n = 1 (the odd formula at m = 0): p = -(a + b) x a, q = a (a + 1) -- reduced by a: p = -(a + b) x, q = a + 1
+    {
+        const double p = -(a + b) * x, q = a + 1.0;
+        const double c = p * qprev;
+        const double An = q * A1 + c * A2, Bn = q * B1 + c * B2;
+        A2 = A1; B2 = B1; A1 = An; B1 = Bn; qprev = q;
+    }
+    for (int m = 1; m <= 10000; m++) {
+        const double m2 = 2.0 * m, am2 = a + m2;
+        // even step n = 2 m
+        {
+            const double p = m * (b - m) * x, q = (am2 - 1.0) * am2;
+            const double c = p * qprev;
+            const double An = q * A1 + c * A2, Bn = q * B1 + c * B2;
+            A2 = A1; B2 = B1; A1 = An; B1 = Bn; qprev = q;
+        }
+        // odd step n = 2 m + 1
+        {
+            const double p = -(a + m) * (a + b + m) * x, q = am2 * (am2 + 1.0);
+            const double c = p * qprev;
+            const double An = q * A1 + c * A2, Bn = q * B1 + c * B2;
+            A2 = A1; B2 = B1; A1 = An; B1 = Bn; qprev = q;
+        }
+        // h_n / h_(n-1) - 1 over the last step (wt_betacf's `del`)
+        const double lhs = fabs(B1 * A2 - B2 * A1), rhs = fabs(A1 * B2);
+        if (lhs < eps * rhs) break;
+        // scale by a power of two: the terms grow by ~q per step
+        if (fabs(A1) > 1e60) {
+            const double sc = 1e-60;
+            A1 *= sc; B1 *= sc; A2 *= sc; B2 *= sc;
+        }
+    }
+    return B1 / A1;
+}
+
+WT_DEV double wt_tdist_2Q_fast(double t, double nu) {
+    if (wt_isnan(t) || wt_isnan(nu) || nu <= 0) return wt_nan();
+    if (isinf(t)) return t > 0 ? 0.0 : 2.0;
+    const double a = nu / 2, b = 0.5;
+    const double x = nu / (nu + t * t);
+    double I;
+    if (x <= 0) I = 0;
+    else if (x >= 1) I = 1;
+    else {
+        const double lg_half = 0.57236494292470008707;      // lgamma(1/2) = ln sqrt(pi)
+        const double lnfront = wt_lgamma_half_diff(a) - lg_half + a * log(x) + b * log1p(-x);
+        const bool flip = !(x < (a + 1) / (a + b + 2));
+        const double a2 = flip ? b : a, b2 = flip ? a : b, x2 = flip ? 1 - x : x;
+        const double r = exp(lnfront) * wt_betacf_wallis(a2, b2, x2) / a2;
+        I = flip ? 1 - r : r;
+    }
+    return t >= 0 ? I : 2 - I;
+}
+
+// what the two-sample t-test's reducers store (setComparisons.c:117: 2 * gsl_cdf_tdist_Q(t, nu))
+WT_DEV double wt_ttest_tail(double t, double nu) {
+#ifdef WT_EMU
+    return 2 * wt_tdist_Q(t, nu);           // the oracle's form, operation for operation
+#else
+    return wt_tdist_2Q_fast(t, nu);
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1415,7 +1514,7 @@ WT_DEV void wt_eval_finish(const WtParams &P, WtAcc<K, NR> &A, double (&res)[K],
         // (positions that start no emitted run are skipped: the tail is the expensive part)
 #pragma unroll 1
         for (int k = 0; k < K; k++)
-            res[k] = (wt_isnan(tt[k]) || !((emit_bits >> k) & 1u)) ? wt_nan() : 2 * wt_tdist_Q(tt[k], nn[k]);
+            res[k] = (wt_isnan(tt[k]) || !((emit_bits >> k) & 1u)) ? wt_nan() : wt_ttest_tail(tt[k], nn[k]);
         return;
     }
     if (OP == WT_OP_MEDIAN) {

@@ -51,6 +51,11 @@ struct WtDeltaShared {
     int32_t base_c;             // their number
     int32_t emin, emax, bad;    // exponent range of the window's non-zero values, NaN/Inf seen
     unsigned long long base_qa, base_qb;    // squares of the intervals spanning w0 (split, see WT_DELTA_QSHIFT)
+    // two-sample launches (TTestReduction, wt_delta_scan3_tt): the same four for the SECOND set, and "a position of this
+    // window cancels too much for the exact sums to stand in for the reference's rounded ones" (the window is then patched)
+    long long base_v1;
+    unsigned long long base_qa1, base_qb1;
+    int32_t base_c1, risk;
 };
 
 // Var / StdDev / CV by difference arrays (round 2).  Beside S = sum of the scaled mantissas m_i of
@@ -82,6 +87,7 @@ struct WtDeltaCtx {
     unsigned long long *ltqa, *ltqb;    // [T] lane totals
     unsigned long long *gtqa, *gtqb;    // [T / 16] group (emulator) / wave (device) totals
     WtDeltaShared *dsh;
+    int32_t np;                 // accumulator entries per array: W, or 2 W with the second set's positions behind the first's (two-sample launches)
 };
 
 // per-lane registers across the scan's barriers.  Round 5: only the lane's TOTALS and what the wavefront's scan makes of them -- the
@@ -113,12 +119,14 @@ WT_DEV void wt_delta_ctx_init(WtDeltaCtx &d, const WtParams &P, char *lds) {
     d.tpfx = (uint32_t *) (lds + P.off_tpfx);
     d.tfirst = (uint16_t *) (lds + P.off_tfirst);
     d.tdef = (uint32_t *) (lds + P.off_tdef);
+    const int ns = P.delta_ns > 1 ? P.delta_ns : 1;     // sets (two-sample launches: 2)
+    d.np = ns * P.W;
     d.qa = (unsigned long long *) (lds + P.off_qa);
-    d.qb = d.qa + P.W;
+    d.qb = d.qa + d.np;
     d.ltqa = (unsigned long long *) (lds + P.off_ltq);
-    d.ltqb = d.ltqa + P.W / WT_DELTA_K;                 // (W / K = lanes of the scans)
+    d.ltqb = d.ltqa + ns * (P.W / WT_DELTA_K);          // (W / K = lanes of the scans)
     d.gtqa = (unsigned long long *) (lds + P.off_gtq);
-    d.gtqb = d.gtqa + P.W / WT_DELTA_K / WT_DELTA_GROUP;
+    d.gtqb = d.gtqa + ns * (P.W / WT_DELTA_K / WT_DELTA_GROUP);
     d.dsh = (WtDeltaShared *) (lds + P.off_dsh);
 }
 
@@ -139,14 +147,16 @@ WT_DEV int wt_delta_max_span(int n_tracks) {
     return 29 - lg;
 }
 
-template <bool QQ = false>
+template <bool QQ = false, bool TT = false>
 WT_DEV void wt_delta_zero(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
-    for (int x = tid; x < P.W; x += nt) { d.acc[x] = 0; d.ev[x] = 0; }
+    const int np = TT ? 2 * P.W : P.W;
+    for (int x = tid; x < np; x += nt) { d.acc[x] = 0; d.ev[x] = 0; }
     if constexpr (QQ)
-        for (int x = tid; x < P.W; x += nt) { d.qa[x] = 0; d.qb[x] = 0; }
+        for (int x = tid; x < np; x += nt) { d.qa[x] = 0; d.qb[x] = 0; }
     if (tid == 0) {
         d.dsh->base_v = 0; d.dsh->base_c = 0;
         if constexpr (QQ) { d.dsh->base_qa = 0; d.dsh->base_qb = 0; }
+        if constexpr (TT) { d.dsh->base_v1 = 0; d.dsh->base_c1 = 0; d.dsh->base_qa1 = 0; d.dsh->base_qb1 = 0; d.dsh->risk = 0; }
         // (non-zero defaults are terms of every position's sum: their exponents belong to every window's range)
         d.dsh->emin = P.def_emin; d.dsh->emax = P.def_emax; d.dsh->bad = 0;
     }
@@ -317,7 +327,9 @@ WT_DEV long long wt_delta_scaled(uint32_t vb, int scale) {
 
 // DF (non-zero defaults, Sum / Mean): a track that is absent contributes its default, so the window's base holds
 // the sum of all defaults and an interval adds (value - default) while it lasts -- `db`: the default's bits.
-template <bool QQ = false, bool DF = false>
+// TT (two-sample launches): `db` is not a default's bits but the run's POSITION OFFSET -- 0 for a track of the first set, W for one of
+// the second, whose accumulator entries lie behind the first's -- and the window's base is kept per set.
+template <bool QQ = false, bool DF = false, bool TT = false>
 WT_DEV void wt_delta_apply(WtDeltaCtx &d, WtCtx &c, int32_t w0, uint32_t width, int32_t s, int32_t f, uint32_t vb, uint32_t db,
                            int scale, bool ok, int32_t &my_next, WtDeltaRange &R) {
     const uint32_t key = vb & 0x7fffffffu;
@@ -325,41 +337,43 @@ WT_DEV void wt_delta_apply(WtDeltaCtx &d, WtCtx &c, int32_t w0, uint32_t width, 
     R.kmin = key - 1u < R.kmin ? key - 1u : R.kmin;
     long long vi = wt_delta_scaled(vb, scale);
     if (DF) vi -= wt_delta_scaled(db, scale);
+    const uint32_t po = TT ? db : 0u;
 #ifdef WT_EMU
     if (!ok) vi = 0;            // (a window known not to be exact: the device adds garbage, the patch kernel rewrites the values)
 #endif
     const uint32_t cs = (uint32_t) (s - w0), cf = (uint32_t) (f - w0);
     if (cs < width && cf < width) {             // the common case: the run lies inside the window -- no branches
-        wt_lds_add64((unsigned long long *) &d.acc[cs], (unsigned long long) vi);
-        wt_lds_add32(&d.ev[cs], 1u);
-        wt_lds_sub64((unsigned long long *) &d.acc[cf], (unsigned long long) vi);
-        wt_lds_add32(&d.ev[cf], 0x10000u);
+        wt_lds_add64((unsigned long long *) &d.acc[po + cs], (unsigned long long) vi);
+        wt_lds_add32(&d.ev[po + cs], 1u);
+        wt_lds_sub64((unsigned long long *) &d.acc[po + cf], (unsigned long long) vi);
+        wt_lds_add32(&d.ev[po + cf], 0x10000u);
         if (QQ && vi) {
             unsigned long long a, b;
             wt_delta_square((unsigned long long) (vi < 0 ? -vi : vi), a, b);
-            wt_lds_add64(&d.qa[cs], a); wt_lds_add64(&d.qb[cs], b);
-            wt_lds_sub64(&d.qa[cf], a); wt_lds_sub64(&d.qb[cf], b);
+            wt_lds_add64(&d.qa[po + cs], a); wt_lds_add64(&d.qb[po + cs], b);
+            wt_lds_sub64(&d.qa[po + cf], a); wt_lds_sub64(&d.qb[po + cf], b);
         }
         return;
     }
     const int32_t w1 = w0 + (int32_t) width;
-    if (f == w0) { wt_lds_add32(&d.ev[0], 0x00010001u); return; }    // true breakpoint at w0, covers nothing here
+    if (f == w0) { wt_lds_add32(&d.ev[po], 0x00010001u); return; }    // true breakpoint at w0, covers nothing here
     if (s >= w1) { my_next = s < my_next ? s : my_next; return; }
     unsigned long long qa = 0, qb = 0;
     if (QQ && vi) wt_delta_square((unsigned long long) (vi < 0 ? -vi : vi), qa, qb);
     if (s < w0) {                               // spans w0: part of the window's base, not a breakpoint
-        wt_lds_add64((unsigned long long *) &d.dsh->base_v, (unsigned long long) vi);
-        wt_lds_addi32(&d.dsh->base_c, 1);
-        if (QQ && vi) { wt_lds_add64(&d.dsh->base_qa, qa); wt_lds_add64(&d.dsh->base_qb, qb); }
+        const bool second = TT && po != 0u;
+        wt_lds_add64((unsigned long long *) (second ? &d.dsh->base_v1 : &d.dsh->base_v), (unsigned long long) vi);
+        wt_lds_addi32(second ? &d.dsh->base_c1 : &d.dsh->base_c, 1);
+        if (QQ && vi) { wt_lds_add64(second ? &d.dsh->base_qa1 : &d.dsh->base_qa, qa); wt_lds_add64(second ? &d.dsh->base_qb1 : &d.dsh->base_qb, qb); }
     } else {
-        if (vi) wt_lds_add64((unsigned long long *) &d.acc[cs], (unsigned long long) vi);
-        wt_lds_add32(&d.ev[cs], 1u);
-        if (QQ && vi) { wt_lds_add64(&d.qa[cs], qa); wt_lds_add64(&d.qb[cs], qb); }
+        if (vi) wt_lds_add64((unsigned long long *) &d.acc[po + cs], (unsigned long long) vi);
+        wt_lds_add32(&d.ev[po + cs], 1u);
+        if (QQ && vi) { wt_lds_add64(&d.qa[po + cs], qa); wt_lds_add64(&d.qb[po + cs], qb); }
     }
     if (f < w1) {
-        if (vi) wt_lds_sub64((unsigned long long *) &d.acc[cf], (unsigned long long) vi);
-        wt_lds_add32(&d.ev[cf], 0x10000u);
-        if (QQ && vi) { wt_lds_sub64(&d.qa[cf], qa); wt_lds_sub64(&d.qb[cf], qb); }
+        if (vi) wt_lds_sub64((unsigned long long *) &d.acc[po + cf], (unsigned long long) vi);
+        wt_lds_add32(&d.ev[po + cf], 0x10000u);
+        if (QQ && vi) { wt_lds_sub64(&d.qa[po + cf], qa); wt_lds_sub64(&d.qb[po + cf], qb); }
     } else {
         my_next = f < my_next ? f : my_next;
     }
@@ -389,22 +403,23 @@ WT_DEV bool wt_delta_in_mask(unsigned long long m, int lane) { return m != 0ull;
 WT_DEV unsigned long long wt_delta_ballot(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 WT_DEV bool wt_delta_in_mask(unsigned long long m, int lane) { return (m >> lane) & 1ull; }
 #endif
-template <bool QQ, bool DF>
-WT_DEV void wt_delta_flush(WtDeltaCtx &d, WtCtx &c, WtDeltaPend<DF> &pn, int lane, int32_t w0, uint32_t width, int scale, bool ok,
+template <bool QQ, bool DF, bool TT = false>
+WT_DEV void wt_delta_flush(WtDeltaCtx &d, WtCtx &c, WtDeltaPend<DF || TT> &pn, int lane, int32_t w0, uint32_t width, int scale, bool ok,
                            int32_t &my_next) {
     if (wt_delta_in_mask(pn.mask, lane)) {
         WtDeltaRange scrap;     // (the exponent range took the run when it was parked)
         scrap.kmax = 0u; scrap.kmin = 0xffffffffu;
-        wt_delta_apply<QQ, DF>(d, c, w0, width, pn.s, pn.f, pn.b, DF ? pn.d[0] : 0u, scale, ok, my_next, scrap);
+        wt_delta_apply<QQ, DF, TT>(d, c, w0, width, pn.s, pn.f, pn.b, (DF || TT) ? pn.d[0] : 0u, scale, ok, my_next, scrap);
     }
     pn.mask = 0ull;
 }
 // one run of the pass: inside the window -> the four (QQ: eight) atomics; not -> parked
-template <bool QQ, bool DF>
-WT_DEV void wt_delta_apply_or_park(WtDeltaCtx &d, WtCtx &c, WtDeltaPend<DF> &pn, int lane, bool valid, int32_t w0, uint32_t width,
+template <bool QQ, bool DF, bool TT = false>
+WT_DEV void wt_delta_apply_or_park(WtDeltaCtx &d, WtCtx &c, WtDeltaPend<DF || TT> &pn, int lane, bool valid, int32_t w0, uint32_t width,
                                    int32_t s, int32_t f, uint32_t vb, uint32_t db, int scale, bool ok, int32_t &my_next, WtDeltaRange &R) {
-    const uint32_t cs = (uint32_t) (s - w0), cf = (uint32_t) (f - w0);
-    const bool inside = cs < width && cf < width;
+    const uint32_t rs = (uint32_t) (s - w0), rf = (uint32_t) (f - w0);
+    const bool inside = rs < width && rf < width;
+    const uint32_t cs = TT ? rs + db : rs, cf = TT ? rf + db : rf;          // (TT: `db` is the set's position offset)
     if (valid) {
         const uint32_t key = vb & 0x7fffffffu;
         R.kmax = key > R.kmax ? key : R.kmax;
@@ -429,11 +444,11 @@ WT_DEV void wt_delta_apply_or_park(WtDeltaCtx &d, WtCtx &c, WtDeltaPend<DF> &pn,
     }
     const bool park = valid && !inside;
     const unsigned long long pm = wt_delta_ballot(park);
-    if (pm & pn.mask) wt_delta_flush<QQ, DF>(d, c, pn, lane, w0, width, scale, ok, my_next);     // (wave-uniform, rare)
+    if (pm & pn.mask) wt_delta_flush<QQ, DF, TT>(d, c, pn, lane, w0, width, scale, ok, my_next);     // (wave-uniform, rare)
     pn.s = park ? s : pn.s;
     pn.f = park ? f : pn.f;
     pn.b = park ? vb : pn.b;
-    if (DF) pn.d[0] = park ? db : pn.d[0];
+    if (DF || TT) pn.d[0] = park ? db : pn.d[0];
     pn.mask |= pm;
 }
 
@@ -452,8 +467,9 @@ struct WtDeltaBatch {
 // waited for before the tile it was meant to overlap is applied (round 2, read off the ISA).
 // The track of a flat index: tfirst[] gives the tile's first one; the lane keeps the end of its
 // current slice and the slice's byte offset in registers and only walks tpfx[] when an index crosses it.
-template <bool DF>
-WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, WtDeltaBatch<DF> &B) {
+// (TT: B.d[] carries the run's position offset -- 0 / W by the set of its track, slot i of the chunk starting at track c0)
+template <bool DF, bool TT = false>
+WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, WtDeltaBatch<DF || TT> &B, int c0 = 0) {
     const uint32_t last = (M - 1u) / WT_DELTA_TILE * WT_DELTA_TILE;
     const uint32_t tbe = tb < last ? tb : last;
     const uint32_t tile = tbe / WT_DELTA_TILE;
@@ -461,6 +477,7 @@ WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint3
     uint32_t hi = d.tpfx[i + 1];
     long long dl = d.tbase[i];
     uint32_t db = DF ? d.tdef[i] : 0u;
+    if (TT) db = c0 + i >= P.n_set0 ? (uint32_t) P.W : 0u;
 #pragma unroll
     for (int u = 0; u < WT_DELTA_U; u++) {
         uint32_t jj = tbe + (uint32_t) lane + 64u * (uint32_t) u;
@@ -469,12 +486,13 @@ WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint3
             do { i++; hi = d.tpfx[i + 1]; } while (jj >= hi);
             dl = d.tbase[i];
             if (DF) db = d.tdef[i];
+            if (TT) db = c0 + i >= P.n_set0 ? (uint32_t) P.W : 0u;
         }
         const long long ob = dl + ((long long) jj << 2);
         B.s[u] = *(const int32_t *) ((const char *) P.start + ob);
         B.f[u] = *(const int32_t *) ((const char *) P.finish + ob);
         B.b[u] = *(const uint32_t *) ((const char *) P.value + ob);
-        if (DF) B.d[u] = db;
+        if (DF || TT) B.d[u] = db;
     }
 }
 
@@ -484,9 +502,9 @@ WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint3
 // tools/experiments/r5_delta_merged_atomics.patch, the record DESIGN 4.1.)
 
 // every interval of the tile at flat index `tb`; only the window's last tile can be partial
-template <bool QQ = false, bool DF = false>
-WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF> &B, uint32_t tb, uint32_t M, int lane, int32_t w0,
-                                uint32_t width, int scale, bool ok, int32_t &my_next, WtDeltaRange &R, WtDeltaPend<DF> &pn) {
+template <bool QQ = false, bool DF = false, bool TT = false>
+WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF || TT> &B, uint32_t tb, uint32_t M, int lane, int32_t w0,
+                                uint32_t width, int scale, bool ok, int32_t &my_next, WtDeltaRange &R, WtDeltaPend<DF || TT> &pn) {
     // WT_DELTA_PARK: 1 = the launches with squares park (their long branch is twice as long and, at 500 tracks and 4096-bp
     // windows, every second wave row took it: -10 %); Sum / Mean do not (C2 the same to 1 % on a fast box, 4 % slower under
     // the profiler on a slow one: two more spilled registers and 5 % more HBM traffic); 2 = everybody parks; 0 = nobody.
@@ -494,23 +512,23 @@ WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF> 
         if (tb + WT_DELTA_TILE <= M) {
 #pragma unroll
             for (int u = 0; u < WT_DELTA_U; u++)
-                wt_delta_apply_or_park<QQ, DF>(d, c, pn, lane, true, w0, width, B.s[u], B.f[u], B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
+                wt_delta_apply_or_park<QQ, DF, TT>(d, c, pn, lane, true, w0, width, B.s[u], B.f[u], B.b[u], (DF || TT) ? B.d[u] : 0u, scale, ok, my_next, R);
         } else {
 #pragma unroll
             for (int u = 0; u < WT_DELTA_U; u++)
-                wt_delta_apply_or_park<QQ, DF>(d, c, pn, lane, tb + (uint32_t) lane + 64u * (uint32_t) u < M, w0, width, B.s[u], B.f[u], B.b[u],
-                                               DF ? B.d[u] : 0u, scale, ok, my_next, R);
+                wt_delta_apply_or_park<QQ, DF, TT>(d, c, pn, lane, tb + (uint32_t) lane + 64u * (uint32_t) u < M, w0, width, B.s[u], B.f[u], B.b[u],
+                                               (DF || TT) ? B.d[u] : 0u, scale, ok, my_next, R);
         }
     } else {
         if (tb + WT_DELTA_TILE <= M) {
 #pragma unroll
             for (int u = 0; u < WT_DELTA_U; u++)
-                wt_delta_apply<QQ, DF>(d, c, w0, width, B.s[u], B.f[u], B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
+                wt_delta_apply<QQ, DF, TT>(d, c, w0, width, B.s[u], B.f[u], B.b[u], (DF || TT) ? B.d[u] : 0u, scale, ok, my_next, R);
         } else {
 #pragma unroll
             for (int u = 0; u < WT_DELTA_U; u++)
                 if (tb + (uint32_t) lane + 64u * (uint32_t) u < M)
-                    wt_delta_apply<QQ, DF>(d, c, w0, width, B.s[u], B.f[u], B.b[u], DF ? B.d[u] : 0u, scale, ok, my_next, R);
+                    wt_delta_apply<QQ, DF, TT>(d, c, w0, width, B.s[u], B.f[u], B.b[u], (DF || TT) ? B.d[u] : 0u, scale, ok, my_next, R);
         }
     }
 }
@@ -519,9 +537,10 @@ WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF> 
 // exact (only coordinates matter); `collect`: also publish the exponent range of the values (the
 // speculative single-pass flavour, see wt_delta_window_verdict); `stats`: count the intervals;
 // `ntr`: tracks of this chunk (DF: their defaults go to the window's base).
-template <bool QQ = false, bool DF = false>
+// `c0`: first track of the chunk (TT: the set of a track is a matter of its number).
+template <bool QQ = false, bool DF = false, bool TT = false>
 WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale, bool ok, bool collect, bool stats,
-                           int tid, int nt, int ntr = 0) {
+                           int tid, int nt, int ntr = 0, int c0 = 0) {
     const int wave = wt_uniform32(tid >> 6), lane = tid & 63, nwaves = nt >> 6;     // (uniform: the tile tests stay scalar)
     const uint32_t M = (uint32_t) wt_uniform32((int32_t) d.tpfx[nt]);
     const int32_t w0 = wt_uniform32(c.sh->w0);
@@ -540,21 +559,21 @@ WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale
     if (tb < M) {
         // two register sets take turns (a `cur = nxt` copy is 12 moves per tile, and it put the wait for the
         // prefetched tile at the end of the iteration that issued it)
-        WtDeltaBatch<DF> A, B;
-        WtDeltaPend<DF> pn;
+        WtDeltaBatch<DF || TT> A, B;
+        WtDeltaPend<DF || TT> pn;
         pn.mask = 0ull; pn.s = 0; pn.f = 0; pn.b = 0u; pn.d[0] = 0u;
-        wt_delta_fetch<DF>(P, d, nt, M, tb, lane, A);
+        wt_delta_fetch<DF, TT>(P, d, nt, M, tb, lane, A, c0);
         for (;;) {
-            wt_delta_fetch<DF>(P, d, nt, M, tb + step, lane, B);    // (past the end: harmless re-reads of the last tile)
-            wt_delta_apply_tile<QQ, DF>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
+            wt_delta_fetch<DF, TT>(P, d, nt, M, tb + step, lane, B, c0);    // (past the end: harmless re-reads of the last tile)
+            wt_delta_apply_tile<QQ, DF, TT>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
             tb += step;
             if (tb >= M) break;
-            wt_delta_fetch<DF>(P, d, nt, M, tb + step, lane, A);
-            wt_delta_apply_tile<QQ, DF>(d, c, B, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
+            wt_delta_fetch<DF, TT>(P, d, nt, M, tb + step, lane, A, c0);
+            wt_delta_apply_tile<QQ, DF, TT>(d, c, B, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
             tb += step;
             if (tb >= M) break;
         }
-        if (pn.mask) wt_delta_flush<QQ, DF>(d, c, pn, lane, w0, width, scale, ok, my_next);      // the runs across the window's edges
+        if (pn.mask) wt_delta_flush<QQ, DF, TT>(d, c, pn, lane, w0, width, scale, ok, my_next);      // the runs across the window's edges
     }
     my_next = wt_wave_min_i32(my_next);
     if (my_next != 0x7fffffff && wt_wave_leader(lane)) wt_lds_min32(&c.sh->next_bp, my_next);
@@ -609,14 +628,16 @@ WT_DEV void wt_delta_note_offset(const WtParams &P, WtCtx &c, int lane) {
 }
 
 // redo of a window: clear the accumulators only (the exponent range is kept)
-template <bool QQ = false>
+template <bool QQ = false, bool TT = false>
 WT_DEV void wt_delta_rezero(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
-    for (int x = tid; x < P.W; x += nt) { d.acc[x] = 0; d.ev[x] = 0; }
+    const int np = TT ? 2 * P.W : P.W;
+    for (int x = tid; x < np; x += nt) { d.acc[x] = 0; d.ev[x] = 0; }
     if constexpr (QQ)
-        for (int x = tid; x < P.W; x += nt) { d.qa[x] = 0; d.qb[x] = 0; }
+        for (int x = tid; x < np; x += nt) { d.qa[x] = 0; d.qb[x] = 0; }
     if (tid == 0) {
         d.dsh->base_v = 0; d.dsh->base_c = 0;
         if constexpr (QQ) { d.dsh->base_qa = 0; d.dsh->base_qb = 0; }
+        if constexpr (TT) { d.dsh->base_v1 = 0; d.dsh->base_c1 = 0; d.dsh->base_qa1 = 0; d.dsh->base_qb1 = 0; }
     }
 }
 
@@ -744,6 +765,169 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
     }
     ((uint8_t *) c.U)[tid] = (uint8_t) evmask;
     ((uint8_t *) c.E)[tid] = (uint8_t) em;
+}
+
+// ---- two-sample launches: TTestReduction by difference arrays (round 6) ----
+// Reference setComparisons.c:35-121: at every run where BOTH sets have a track in play (:48-54), per set the sum and the sum of
+// squares of the values IN PLAY (:69-81; defaults play no part) and the set's size as the count (:66-67), then Welch's t, its
+// degrees of freedom and the Student tail.  The two sums per set are what the launches with squares accumulate -- S = sum of
+// the scaled mantissas, Q = sum of their squares, exactly -- so the window keeps them twice: the second set's accumulator
+// entries lie W behind the first's (wt_delta_fetch: a run's position offset), 56 bytes per position, a 2048-bp window.
+// From (double) S * q and (double) Q * q^2 on, the arithmetic is the reference's, operation for operation: where the
+// reference's own sums do not round (values on a coarse grid, counts) the result is the reference's bit for bit; where they
+// do, its sum of squares carries up to n ulp and the difference of (:91-92) `meanSq - mean * mean` magnifies that by
+// meanSq / var.  A window with an emitted position where var * 2^10 < meanSq in a set is therefore recorded like a window
+// whose exponent range is too wide (`risk` -> wt_delta_mark_bad): the general kernel, which adds in the reference's order,
+// rewrites its values.
+struct WtDeltaLane2 {
+    long long tv[2];            // the lane's totals per set: value deltas,
+    int32_t tc[2];              // ... coverage deltas,
+    unsigned long long tqa[2], tqb[2];      // ... the squares' two parts
+    long long wv[2];            // device: the same summed over the wave's lanes before this one
+    int32_t wc[2];
+    unsigned long long wqa[2], wqb[2];
+};
+
+WT_DEV void wt_delta_scan1_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLane2 &L, int tid, int nt) {
+    const int p0 = tid * WT_DELTA_K;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int o = s * P.W + p0;
+        long long rv = 0;
+        int32_t rc = 0;
+        unsigned long long ra = 0, rb = 0;
+#pragma unroll
+        for (int k = 0; k < WT_DELTA_K; k++) {
+            const uint32_t e = d.ev[o + k];
+            rv += d.acc[o + k];
+            rc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
+            ra += d.qa[o + k];
+            rb += d.qb[o + k];
+        }
+        L.tv[s] = rv; L.tc[s] = rc; L.tqa[s] = ra; L.tqb[s] = rb;
+        d.ltv[s * nt + tid] = rv;
+        d.ltc[s * nt + tid] = rc;
+        d.ltqa[s * nt + tid] = ra;
+        d.ltqb[s * nt + tid] = rb;
+    }
+}
+
+// (the emulator's middle step: group totals)
+WT_DEV void wt_delta_scan2_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+    const int ngroups = nt / WT_DELTA_GROUP;
+    if (tid >= ngroups) return;
+    for (int s = 0; s < 2; s++) {
+        long long sv = 0;
+        int32_t sc = 0;
+        unsigned long long sa = 0, sb = 0;
+        for (int x = 0; x < WT_DELTA_GROUP; x++) {
+            const int j = s * nt + tid * WT_DELTA_GROUP + x;
+            sv += d.ltv[j]; sc += d.ltc[j]; sa += d.ltqa[j]; sb += d.ltqb[j];
+        }
+        d.gtv[s * ngroups + tid] = sv; d.gtc[s * ngroups + tid] = sc;
+        d.gtqa[s * ngroups + tid] = sa; d.gtqb[s * ngroups + tid] = sb;
+    }
+}
+
+// Welch's t and its degrees of freedom from the two sets' sums, setComparisons.c:88-113 operation for operation
+// (the same lines as the general kernel's wt_eval_finish<TTEST>); t = NaN where the reference answers NaN (:98).
+WT_DEV void wt_ttest_stat(double sum1, double sumsq1, double sum2, double sumsq2, int na, int nb, double &t_out, double &nu_out, bool &risk) {
+    const double m1 = sum1 / na, m2 = sum2 / nb;
+    const double msq1 = sumsq1 / na, msq2 = sumsq2 / nb;
+    const double var1 = msq1 - m1 * m1, var2 = msq2 - m2 * m2;
+    double t = (m1 - m2) / sqrt(var1 / na + var2 / nb);
+    if (t < 0) t = -t;
+    const double den = var1 / na + var2 / nb;
+    const double c1 = (double) ((long long) na * na * (na - 1));
+    const double c2 = (double) ((long long) nb * nb * (nb - 1));
+    nu_out = den * den / ((var1 * var1) / c1 + (var2 * var2) / c2);
+    t_out = (var1 + var2 == 0) ? wt_nan() : t;
+    risk = (var1 * 1024.0 < msq1) || (var2 * 1024.0 < msq2);
+}
+
+// scan step 3 of a two-sample launch: running sums of both sets at every position, breakpoint and emitted bytes, the test
+WT_DEV void wt_delta_scan3_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtDeltaLane2 &L,
+                              WtLane<WT_DELTA_K> &out, int emin, int tid, int nt) {
+    long long bv[2] = {d.dsh->base_v, d.dsh->base_v1};
+    int32_t bc[2] = {d.dsh->base_c, d.dsh->base_c1};
+    unsigned long long bqa[2] = {d.dsh->base_qa, d.dsh->base_qa1}, bqb[2] = {d.dsh->base_qb, d.dsh->base_qb1};
+#ifdef WT_EMU
+    const int grp = tid / WT_DELTA_GROUP, ngroups = nt / WT_DELTA_GROUP;
+    for (int s = 0; s < 2; s++) {
+        for (int x = 0; x < grp; x++) { bv[s] += d.gtv[s * ngroups + x]; bc[s] += d.gtc[s * ngroups + x]; bqa[s] += d.gtqa[s * ngroups + x]; bqb[s] += d.gtqb[s * ngroups + x]; }
+        for (int x = grp * WT_DELTA_GROUP; x < tid; x++) { bv[s] += d.ltv[s * nt + x]; bc[s] += d.ltc[s * nt + x]; bqa[s] += d.ltqa[s * nt + x]; bqb[s] += d.ltqb[s * nt + x]; }
+    }
+#else
+    const int nwaves = nt >> 6;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        for (int x = 0; x < (tid >> 6); x++) { bv[s] += d.gtv[s * nwaves + x]; bc[s] += d.gtc[s * nwaves + x]; bqa[s] += d.gtqa[s * nwaves + x]; bqb[s] += d.gtqb[s * nwaves + x]; }
+        bv[s] += L.wv[s]; bc[s] += L.wc[s]; bqa[s] += L.wqa[s]; bqb[s] += L.wqb[s];
+    }
+#endif
+    const int na = P.n_set0, nb = P.n_tracks - P.n_set0;
+    const bool strict0 = (P.flags & WT_STRICT_SET0) != 0, strict1 = (P.flags & WT_STRICT_SET1) != 0;
+    const int p0 = tid * WT_DELTA_K;
+    const double q = __builtin_bit_cast(double, (uint64_t) (emin - 150 + 1023) << 52);      // the weight of one unit of the scaled mantissas
+    const long long room = (long long) c.sh->emit_hi - ((long long) c.sh->w0 + p0);
+    uint32_t em = 0, evmask = 0;
+    bool any_risk = false;
+    // The statistic t and the degrees of freedom of position k go to the SECOND set's value and square slots of that position,
+    // which only this lane reads and which are dead once read; the Student tail -- the expensive part: logs, an exponential, a
+    // continued fraction -- is a phase of its own over ALL the workgroup's lanes (wt_delta_tail_tt: run here, by the 256 scan
+    // lanes for their 8 positions each, a 2048-bp window spent 120 of its 149 us in eight tails back to back on four
+    // wavefronts), and wt_delta_load_res_tt brings a lane's 8 results back for the staging.
+    double *res = (double *) (d.acc + P.W + p0);
+    double *dof = (double *) (d.qa + P.W + p0);
+#pragma unroll 1
+    for (int k = 0; k < WT_DELTA_K; k++) {
+        uint32_t eany = 0;
+        double sum[2], sumsq[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const int o = s * P.W + p0 + k;
+            const uint32_t e = d.ev[o];
+            eany |= e;
+            bv[s] += d.acc[o];
+            bc[s] += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
+            bqa[s] += d.qa[o]; bqb[s] += d.qb[o];
+            // exact integers: S and Q = (A << 40) + B (see WT_DELTA_QSHIFT); S * q is the reference's sum whenever that did not round
+            const unsigned __int128 Q = ((unsigned __int128) bqa[s] << WT_DELTA_QSHIFT) + (unsigned __int128) bqb[s];
+            sum[s] = (double) bv[s] * q;
+            sumsq[s] = ((double) (unsigned long long) (Q >> 64) * 18446744073709551616.0 + (double) (unsigned long long) Q) * q * q;
+        }
+        evmask |= (eany != 0u ? 1u : 0u) << k;
+        const bool pred = (strict0 ? bc[0] == na : bc[0] > 0) && (strict1 ? bc[1] == nb : bc[1] > 0);    // multiplexer.c:120,125; setComparisons.c:48-54
+        const bool emit = eany != 0u && pred && k < room;
+        if (emit) em |= 1u << k;
+        double t, nu;
+        bool risk;
+        wt_ttest_stat(sum[0], sumsq[0], sum[1], sumsq[1], na, nb, t, nu, risk);
+        any_risk |= emit && risk;
+        // (positions that start no emitted run are skipped by the tail: NaN)
+        res[k] = emit ? t : wt_nan();
+        dof[k] = nu;
+    }
+    if (any_risk) d.dsh->risk = 1;
+    ((uint8_t *) c.U)[tid] = (uint8_t) evmask;
+    ((uint8_t *) c.E)[tid] = (uint8_t) em;
+}
+
+// the tail of every emitted position of the window: all lanes, consecutive lanes consecutive positions
+WT_DEV void wt_delta_tail_tt(const WtParams &P, WtDeltaCtx &d, int tid, int nt) {
+    double *res = (double *) (d.acc + P.W);
+    const double *dof = (const double *) (d.qa + P.W);
+    for (int p = tid; p < P.W; p += nt) {
+        const double t = res[p];
+        if (!wt_isnan(t)) res[p] = wt_ttest_tail(t, dof[p]);        // setComparisons.c:117
+    }
+}
+
+// before the staging of a two-sample launch: the lane's 8 results, from where wt_delta_tail_tt left them
+WT_DEV void wt_delta_load_res_tt(const WtParams &P, const WtDeltaCtx &d, WtLane<WT_DELTA_K> &out, int tid) {
+    const double *res = (const double *) (d.acc + P.W + tid * WT_DELTA_K);
+#pragma unroll
+    for (int k = 0; k < WT_DELTA_K; k++) out.res[k] = res[k];
 }
 
 // Output staging.  A lane owns 8 consecutive positions, so writing its runs straight to HBM makes
@@ -884,6 +1068,24 @@ WT_DEV void wt_delta_scan_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDelta
         L.wqa = ia - ra;
         L.wqb = ib - rb;
         if (lane == 63) { d.gtqa[tid >> 6] = ia; d.gtqb[tid >> 6] = ib; }
+    }
+}
+
+// ... of a two-sample launch: both sets' four totals (gt*[s * nwaves + wave]: the wave totals per set)
+WT_DEV void wt_delta_scan_w1_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLane2 &L, int tid, int nt) {
+    wt_delta_scan1_tt(P, c, d, L, tid, nt);
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const long long iv = wt_wave_scan_i64(L.tv[s], lane);
+        const int32_t ic = (int32_t) wt_wave_scan_u32((unsigned) L.tc[s], lane);
+        const unsigned long long ia = (unsigned long long) wt_wave_scan_i64((long long) L.tqa[s], lane);
+        const unsigned long long ib = (unsigned long long) wt_wave_scan_i64((long long) L.tqb[s], lane);
+        L.wv[s] = iv - L.tv[s];
+        L.wc[s] = ic - L.tc[s];
+        L.wqa[s] = ia - L.tqa[s];
+        L.wqb[s] = ib - L.tqb[s];
+        if (lane == 63) { d.gtv[s * nwaves + wave] = iv; d.gtc[s * nwaves + wave] = ic; d.gtqa[s * nwaves + wave] = ia; d.gtqb[s * nwaves + wave] = ib; }
     }
 }
 

@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
 // Exact difference-array path for Sum / Mean over float tracks (wt_delta.h): O(intervals) work
 // instead of O(tracks x runs); LDS independent of the track count.
 // (var / stddev / CV also accumulate the sum of squares: 512 lanes, one workgroup per CU)
-#define WT_DELTA_SQ(OP) ((OP) == WT_OP_VAR || (OP) == WT_OP_STDDEV || (OP) == WT_OP_ENTROPY || (OP) == WT_OP_CV)
+#define WT_DELTA_SQ(OP) ((OP) == WT_OP_VAR || (OP) == WT_OP_STDDEV || (OP) == WT_OP_ENTROPY || (OP) == WT_OP_CV || (OP) == WT_OP_TTEST)
 #ifndef WT_DELTA_MIN_WAVES
 #define WT_DELTA_MIN_WAVES 4     // waves per SIMD the register allocation aims at (experiments: 6 spills, see DESIGN A.1)
 #endif
@@ -221,7 +221,10 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
     WtDeltaCtx d;
     wt_delta_ctx_init(d, P, wt_lds);
     constexpr bool QQ = WT_DELTA_SQ(OP);
+    constexpr bool TT = OP == WT_OP_TTEST;      // two sets per position (wt_delta_scan3_tt)
     WtDeltaLane DL;
+    WtDeltaLane2 DL2;
+    (void) DL; (void) DL2;
     WtLane<WT_DELTA_K> L;
     const int tid = threadIdx.x, nt = blockDim.x;
     // lanes of the scans and the staging (8 positions each): all of them -- or, with squares, the first 512 of 1024.  (Sum / Mean must not
@@ -250,7 +253,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
         if (k >= P.n_windows) break;
         const int nchunks = (P.n_tracks + nt - 1) / nt;
         auto ntr = [&](int ch) { const int r = P.n_tracks - ch * nt; return r < nt ? r : nt; };     // tracks of chunk ch
-        wt_delta_zero<QQ>(P, c, d, tid, nt);
+        wt_delta_zero<QQ, TT>(P, c, d, tid, nt);
         WT_TICK(0);
         WT_MARK(102);
         int scale = 1;
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
                     wt_delta_ranges_w2(P, c, d, tid, nt);
                     __syncthreads();
                 }
-                wt_delta_pass2<QQ, DF>(P, c, d, scale, ok, false, true, tid, nt, ntr(ch));
+                wt_delta_pass2<QQ, DF, TT>(P, c, d, scale, ok, false, true, tid, nt, ntr(ch), ch * nt);
                 __syncthreads();
                 WT_TICK(3);
             }
@@ -289,7 +292,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
                 wt_delta_ranges_w2(P, c, d, tid, nt);
                 __syncthreads();
                 WT_TICK(1);
-                wt_delta_pass2<QQ, DF>(P, c, d, guess, true, true, true, tid, nt, ntr(ch));
+                wt_delta_pass2<QQ, DF, TT>(P, c, d, guess, true, true, true, tid, nt, ntr(ch), ch * nt);
                 __syncthreads();
                 WT_TICK(3);
             }
@@ -305,7 +308,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
                 if (tid == 0) wt_delta_mark_bad(P, c, k);
               } else {
                 __syncthreads();            // every lane has read the verdict fields
-                wt_delta_rezero<QQ>(P, c, d, tid, nt);
+                wt_delta_rezero<QQ, TT>(P, c, d, tid, nt);
                 __syncthreads();
                 for (int ch = 0; ch < nchunks; ch++) {
                     if (nchunks > 1) {
@@ -314,7 +317,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
                         wt_delta_ranges_w2(P, c, d, tid, nt);
                         __syncthreads();
                     }
-                    wt_delta_pass2<QQ, DF>(P, c, d, lo, ok, false, false, tid, nt, ntr(ch));
+                    wt_delta_pass2<QQ, DF, TT>(P, c, d, lo, ok, false, false, tid, nt, ntr(ch), ch * nt);
                     __syncthreads();
                 }
                 scale = lo;
@@ -323,11 +326,21 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             }
         }
         WT_MARK(105);
-        if (WT_SCAN_LANE) wt_delta_scan_w1<QQ>(P, c, d, DL, tid, nts);
-        __syncthreads();
-        WT_MARK(107);
-        if (WT_SCAN_LANE) wt_delta_scan3<OP>(P, c, d, DL, L, scale, tid, nts);
-        __syncthreads();
+        if constexpr (TT) {
+            if (tid < nts) wt_delta_scan_w1_tt(P, c, d, DL2, tid, nts);
+            __syncthreads();
+            WT_MARK(107);
+            if (tid < nts) wt_delta_scan3_tt(P, c, d, DL2, L, scale, tid, nts);
+            __syncthreads();
+            // a position whose variance cancels too much for the exact sums (wt_delta_scan3_tt): the window's values are the general kernel's
+            if (tid == 0 && d.dsh->risk && c.sh->bad_slot < 0) wt_delta_mark_bad(P, c, k);
+        } else {
+            if (WT_SCAN_LANE) wt_delta_scan_w1<QQ>(P, c, d, DL, tid, nts);
+            __syncthreads();
+            WT_MARK(107);
+            if (WT_SCAN_LANE) wt_delta_scan3<OP>(P, c, d, DL, L, scale, tid, nts);
+            __syncthreads();
+        }
         WT_TICK(4);
         WT_MARK(108);
         // wave 0: run-count scan and look-back back to back (it owns the counts); the last lanes
@@ -339,6 +352,11 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             if (tid == 0) wt_lookback_publish(P, c, k, mine);
         }
         wt_delta_nextw(P, c, tid, nt);
+        // two-sample launches: the Student tail of every emitted position, all lanes (wave 0 has published the window's run count first)
+        if constexpr (TT) {
+            wt_delta_tail_tt(P, d, tid, nt);
+            WT_TICK(2);             // (profile builds: the tail in the slot of the exponent-range pass, which only a workgroup's first window runs)
+        }
         __syncthreads();
         WT_MARK(110);
         // the look-back's round trips to the status words overlap the staging of the other waves
@@ -348,6 +366,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             wt_delta_note_offset(P, c, tid);                // (lane 0 set the offset in the look-back: same wave, LDS in order)
         }
         WT_TICK(6);
+        if constexpr (TT) { if (tid < nts) wt_delta_load_res_tt(P, d, L, tid); }
         if (WT_SCAN_LANE) wt_delta_stage<OP>(P, c, d, L, tid, nts);
         __syncthreads();
 #ifdef WT_PROFILE_TAIL
@@ -472,7 +491,7 @@ __global__ void __launch_bounds__(WT_MAX_BLOCK, WT_MIN_WAVES(K)) wt_patch_kernel
                 }
             }
             if (MULTI && npass == 2) wt_eval_mid<OP, K>(P, A);
-            wt_phase_emask(P, c, false, tid, nt);
+            wt_phase_emask(P, c, OP == WT_OP_TTEST, tid, nt);
             __syncthreads();
             wt_phase_escan(P, c, tid, nt);
             __syncthreads();
@@ -917,9 +936,11 @@ struct wtamd_trackset {
     int num_cu = 256;
     bool scratch_f32 = false;
     // Sum / Mean over float tracks: what a completed difference-array launch found out about this data
-    bool delta_failed = false;                  // many windows are not provably exact: Sum / Mean use the general kernel
-    bool delta_verified = false;                // verdict known: delta_n_bad windows (few) get patched by the general kernel
-    long long delta_n_bad = 0;
+    // the difference-array launches' verdict on this data, per class of reducer -- [0] Sum / Mean / the var family (exponent range
+    // of a window), [1] TTestReduction (its own, narrower windows, and positions whose variance cancels: wt_delta_scan3_tt)
+    bool delta_failed_[2] = {false, false};     // many windows are not provably exact: the class uses the general kernel
+    bool delta_verified_[2] = {false, false};   // verdict known: delta_n_bad windows (few) get patched by the general kernel
+    long long delta_n_bad_[2] = {0, 0};
     // pipeline slot (wt_pipe.h): the run lists are rebound per batch, device tables are reused,
     // every upload is asynchronous on the launch stream from pinned staging
     bool pipe_mode = false;
@@ -1307,8 +1328,9 @@ static int wt_build_index(wtamd_trackset *ts, WtWindows *w, const WtPlan &plan, 
 // The plan a reduction of `op` will run with first: the exact difference-array plan for Sum /
 // Mean over float tracks with zero defaults (until a window of this data proved inexact), else the
 // general bitmap plan.
+static inline int wt_delta_class(int op) { return op == WT_OP_TTEST ? 1 : 0; }
 static bool wt_wants_delta(const wtamd_trackset *ts, int op) {
-    return !ts->delta_failed && wt_delta_eligible(op, ts->value_f64, ts->n_tracks, ts->defaults.data());
+    return !ts->delta_failed_[wt_delta_class(op)] && wt_delta_eligible(op, ts->value_f64, ts->n_tracks, ts->defaults.data());
 }
 
 // Events (run starts, plus a finish wherever a gap follows) per base pair the track set is expected to hold: the walking
@@ -1350,9 +1372,7 @@ int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
     if (!ts) return wt_fail(WTAMD_ERR_ARG, "ts == NULL");
     // an explicit re-index means the run lists may have been rewritten in place (zero-copy track
     // sets): what was learnt about their values is void, the next Sum / Mean verifies again
-    ts->delta_verified = false;
-    ts->delta_failed = false;
-    ts->delta_n_bad = 0;
+    for (int q = 0; q < 2; q++) { ts->delta_verified_[q] = false; ts->delta_failed_[q] = false; ts->delta_n_bad_[q] = 0; }
     for (auto &kv : ts->windows) kv.second.indexed = false;     // every width's index describes the old data
     if (!ts->owns && !ts->pipe_mode) {
         // zero-copy track set rewritten in place: its runs may start earlier / end later than
@@ -1365,7 +1385,7 @@ int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
     }
     WtPlan plan;
     std::string err;
-    if (wt_wants_delta(ts, op)) wt_make_delta_plan(plan, ts->n_tracks, wt_op_is_var_family(op));
+    if (wt_wants_delta(ts, op)) wt_make_delta_plan_for(plan, ts->n_tracks, op);
     // (two-sample ops: the index only depends on the window width; the usual even split is assumed)
     else if (!wt_pick_plan(ts, op, ts->n_tracks / 2, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
     WtWindows *w = nullptr;
@@ -1482,7 +1502,7 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
 
 // The general kernel over the `n_bad` windows the difference-array launch (window width delta_W,
 // just finished or still running on `s`) recorded as not provably exact.
-static int wt_launch_patch(wtamd_trackset *ts, int delta_W, int op, uint32_t flags, wtamd_runs *runs, long long n_bad,
+static int wt_launch_patch(wtamd_trackset *ts, int delta_W, int op, uint32_t flags, int n_set0, wtamd_runs *runs, long long n_bad,
                            hipStream_t s) {
     WtPlan plan;
     std::string err;
@@ -1496,7 +1516,7 @@ static int wt_launch_patch(wtamd_trackset *ts, int delta_W, int op, uint32_t fla
     if (rc != WTAMD_OK) return rc;
     WtParams P;
     wt_fill_params(ts, w, plan, P);
-    P.op = op; P.flags = flags; P.n_set0 = 0;
+    P.op = op; P.flags = flags; P.n_set0 = op == WT_OP_TTEST ? n_set0 : 0;
     P.capacity = runs->capacity;
     P.o_start = runs->start; P.o_finish = runs->finish; P.o_value = runs->value;
     P.chrom_run_off = runs->chrom_run_off ? runs->chrom_run_off : ts->d_chrom_run_off;
@@ -1522,6 +1542,9 @@ static int wt_launch_patch(wtamd_trackset *ts, int delta_W, int op, uint32_t fla
     } else if (op == WT_OP_MEAN) {
         if (plan.ppt == 4) { if (multi) WT_PATCH_GO(WT_OP_MEAN, 4, true); else WT_PATCH_GO(WT_OP_MEAN, 4, false); }
         else { if (multi) WT_PATCH_GO(WT_OP_MEAN, 1, true); else WT_PATCH_GO(WT_OP_MEAN, 1, false); }
+    } else if (op == WT_OP_TTEST) {
+        if (plan.ppt != 4) return wt_fail(WTAMD_ERR_INTERNAL, "no general plan compatible with the difference-array windows");
+        if (multi) WT_PATCH_GO(WT_OP_TTEST, 4, true); else WT_PATCH_GO(WT_OP_TTEST, 4, false);
     } else {
         // var / stddev / entropy / CV: 4 positions per lane only (what the plans pick unless forced)
         if (plan.ppt != 4) return wt_fail(WTAMD_ERR_INTERNAL, "no general plan compatible with the difference-array windows");
@@ -1550,14 +1573,15 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
     // once per track set -- that first launch is waited for even when the caller asked for an
     // asynchronous one -- and later launches (patch included) need no host round trip.
     if (!d_tile && wt_wants_delta(ts, op)) {
-        wt_make_delta_plan(plan, ts->n_tracks, wt_op_is_var_family(op));
+        wt_make_delta_plan_for(plan, ts->n_tracks, op);
+        const int dc = wt_delta_class(op);
         int64_t n_probe = 0;
-        const bool probe = !ts->delta_verified;
+        const bool probe = !ts->delta_verified_[dc];
         const int rc = wt_reduce_plan(ts, plan, op, flags, n_set0, runs, d_tile, d_inplay,
                                       (probe && !n_runs) ? &n_probe : n_runs, s);
         if (!probe) {
-            if (ts->delta_n_bad > 0 && (rc == WTAMD_OK || rc == WTAMD_ERR_CAPACITY)) {
-                const int rp = wt_launch_patch(ts, plan.W, op, flags, runs, ts->delta_n_bad, s);
+            if (ts->delta_n_bad_[dc] > 0 && (rc == WTAMD_OK || rc == WTAMD_ERR_CAPACITY)) {
+                const int rp = wt_launch_patch(ts, plan.W, op, flags, n_set0, runs, ts->delta_n_bad_[dc], s);
                 if (rp != WTAMD_OK) return rp;
                 if (n_runs) WT_HIP(hipStreamSynchronize(s));
             }
@@ -1565,18 +1589,18 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
         }
         if (rc != WTAMD_OK && rc != WTAMD_ERR_CAPACITY) return rc;
         const long long n_bad = (long long) ts->h_counters[WT_CTR_DELTA_BAD];
-        if (n_bad == 0) { ts->delta_verified = true; ts->delta_n_bad = 0; return rc; }
+        if (n_bad == 0) { ts->delta_verified_[dc] = true; ts->delta_n_bad_[dc] = 0; return rc; }
         if (n_bad * 4 <= (long long) ts->stats.n_windows && !getenv("WTAMD_NO_PATCH")) {
-            const int rp = wt_launch_patch(ts, plan.W, op, flags, runs, n_bad, s);
+            const int rp = wt_launch_patch(ts, plan.W, op, flags, n_set0, runs, n_bad, s);
             if (rp == WTAMD_OK) {
                 WT_HIP(hipStreamSynchronize(s));
-                ts->delta_verified = true;
-                ts->delta_n_bad = n_bad;
+                ts->delta_verified_[dc] = true;
+                ts->delta_n_bad_[dc] = n_bad;
                 return rc;
             }
             if (rp != WTAMD_ERR_INTERNAL) return rp;        // INTERNAL: no compatible general plan -> full redo
         }
-        ts->delta_failed = true;
+        ts->delta_failed_[dc] = true;
     }
     if (!wt_pick_plan(ts, op, n_set0, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
     return wt_reduce_plan(ts, plan, op, flags, n_set0, runs, d_tile, d_inplay, n_runs, s);
@@ -1584,7 +1608,7 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
 
 static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32_t flags, int n_set0, wtamd_runs *runs,
                           double *d_tile, uint8_t *d_inplay, int64_t *n_runs, hipStream_t s) {
-    if (plan.T > (plan.delta ? (wt_op_is_var_family(op) ? WT_DELTA_SQ_BLOCK : WT_DELTA_BLOCK) : WT_MAX_BLOCK)) return wt_fail(WTAMD_ERR_ARG, "workgroup size above the kernel's launch bound");
+    if (plan.T > (plan.delta ? ((wt_op_is_var_family(op) || op == WT_OP_TTEST) ? WT_DELTA_SQ_BLOCK : WT_DELTA_BLOCK) : WT_MAX_BLOCK)) return wt_fail(WTAMD_ERR_ARG, "workgroup size above the kernel's launch bound");
     WtWindows *w = nullptr;
     int rc = wt_get_windows(ts, plan.W, &w, s);
     if (rc != WTAMD_OK) return rc;
@@ -1638,6 +1662,7 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
             case WT_OP_MEAN: if (L.P.delta_df) wt_launch_delta<WT_OP_MEAN, true>(L); else wt_launch_delta<WT_OP_MEAN>(L); break;
             case WT_OP_VAR: wt_launch_delta<WT_OP_VAR>(L); break;
             case WT_OP_CV: wt_launch_delta<WT_OP_CV>(L); break;
+            case WT_OP_TTEST: wt_launch_delta<WT_OP_TTEST>(L); break;
             default: wt_launch_delta<WT_OP_STDDEV>(L); break;      // stddev, entropy (reducers.c:665)
             }
         } else if (plan.walk_S) {

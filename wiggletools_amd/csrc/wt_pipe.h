@@ -661,7 +661,7 @@ static int wt_pipe_finish(wtamd_pipe *p, WtSlot &s) {
     if (s.used_delta && n_bad > 0) {
         wtamd_runs runs{};
         runs.capacity = s.ocap; runs.start = s.d_os; runs.finish = s.d_of; runs.value = s.d_ov; runs.chrom_run_off = s.d_cro;
-        int rc = wt_launch_patch(ts, s.delta_W, p->cfg.desc.op, p->cfg.desc.flags, &runs, n_bad, p->s_comp);
+        int rc = wt_launch_patch(ts, s.delta_W, p->cfg.desc.op, p->cfg.desc.flags, p->cfg.desc.n_set0, &runs, n_bad, p->s_comp);
         if (rc != WTAMD_OK) return rc;
         if (s.compressed) {
             rc = wt_compress_async(s.d_os, s.d_of, s.d_ov, ts->d_counters + WT_CTR_RUNS, (long long) s.ocap, s.d_cscratch, s.d_cs, s.d_cf,
@@ -1063,9 +1063,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     ts->d_start = compacted ? s.d_mstart : s.d_start;
     ts->d_finish = compacted ? s.d_mfinish : s.d_finish;
     ts->d_value = mapped ? (void *) s.d_mvalue : s.d_value;
-    ts->delta_failed = p->delta_failed;
-    ts->delta_verified = false;
-    ts->delta_n_bad = 0;
+    for (int q = 0; q < 2; q++) { ts->delta_failed_[q] = p->delta_failed; ts->delta_verified_[q] = false; ts->delta_n_bad_[q] = 0; }
     for (auto &kv : ts->windows) { kv.second.tab_valid = false; kv.second.indexed = false; }
     int rc = wt_check_extents(ts);
     if (rc != WTAMD_OK) return rc;
@@ -1201,7 +1199,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     s.used_delta = !p->tile && wt_wants_delta(ts, op);
     s.patched = false;
     if (s.used_delta) {
-        wt_make_delta_plan(plan, N, wt_op_is_var_family(op));
+        wt_make_delta_plan_for(plan, N, op);
         s.delta_W = plan.W;
     } else if (!wt_pick_plan(ts, op, p->cfg.desc.n_set0, plan, err)) {
         return wt_fail(WTAMD_ERR_ARG, err);

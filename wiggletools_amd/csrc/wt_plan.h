@@ -23,6 +23,7 @@ struct WtPlan {
     int lanes_per_pos = 1;  // MWU: lanes of a workgroup sharing one window position (T = lanes_per_pos * W, K = 1)
     int off_acc = 0, off_ev = 0, off_ltv = 0, off_ltc = 0, off_gtv = 0, off_gtc = 0, off_tbase = 0, off_tpfx = 0, off_tfirst = 0, off_dsh = 0, off_tdef = 0;
     int off_qa = 0, off_ltq = 0, off_gtq = 0, delta_q = 0;
+    int delta_ns = 1;       // difference-array plan: sets whose sums a position keeps (2: TTestReduction, wt_delta_scan3_tt)
     bool delta = false;     // difference-array plan (wt_delta.h)
     int off_S = 0, off_cnt = 0, off_segtot = 0, off_U = 0, off_cover = 0, off_E = 0, off_epfx = 0, off_nextw = 0, off_gbase = 0, off_scratch = 0, off_shared = 0;
     int off_dflt32 = 0;
@@ -96,7 +97,10 @@ static inline bool wt_op_is_var_family(int op) {
 // `squares`: the launch also accumulates the sum of squares (var / stddev / CV): two more u64 arrays
 // per position: ~145 KB of LDS for the 4096-bp window, one workgroup per CU -- measured 21 %
 // faster than 2048-bp windows (86 KB: also one workgroup per CU, but of 4 waves).
-static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = false) {
+// `two_sets` (round 6, TTestReduction): sums, squares and coverage of TWO sets per position -- 56 bytes: a 2048-bp window (115 KB),
+// 256 lanes for the scans, and like every launch with squares 768 for the passes over the runs.
+static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = false, bool two_sets = false) {
+    if (two_sets) squares = true;
     // Sum / Mean: 1024 lanes, an 8192-bp window, one workgroup of 16 waves per CU (round 3: 6 % faster than two
     // workgroups of 512 once pass 2 had shed its instructions -- the per-window chain of dependent round trips
     // is paid half as often; round 2 had measured +1.5 %).
@@ -116,22 +120,29 @@ static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = fa
         const char *eS = getenv("WTAMD_DELTA_SQ_T");
         if (eS && atoi(eS) >= 512 && atoi(eS) <= Tmax && atoi(eS) % 64 == 0) T = atoi(eS);
     }
-    const int TS = squares && T > 512 ? 512 : T;       // lanes of the scans: one per WT_DELTA_K positions
+    int TS = squares && T > 512 ? 512 : T;             // lanes of the scans: one per WT_DELTA_K positions
+    const int ns = two_sets ? 2 : 1;
+    if (two_sets) {
+        const char *e2 = getenv("WTAMD_DELTA_TT_W");    // experiments: window of the two-sample launches (1024 / 2048)
+        TS = (e2 && atoi(e2) == 1024) ? 128 : 256;
+        if (T < TS) T = TS;
+    }
     p = WtPlan();
     p.delta = true;
+    p.delta_ns = ns;
     p.T = T; p.ppt = WT_DELTA_K; p.W = WT_DELTA_K * TS; p.n_words = p.W / 64;
     p.chunk_tracks = 0; p.n_chunks = 1;
     int o = 0;
-    p.off_acc = o;    o = wt_align16(o + p.W * 8);
-    p.off_ev = o;     o = wt_align16(o + p.W * 4);
+    p.off_acc = o;    o = wt_align16(o + ns * p.W * 8);
+    p.off_ev = o;     o = wt_align16(o + ns * p.W * 4);
     p.off_U = o;      o = wt_align16(o + p.n_words * 8);
     p.off_E = o;      o = wt_align16(o + p.n_words * 8);
     p.off_epfx = o;   o = wt_align16(o + (p.n_words + 1) * 4);
     p.off_nextw = o;  o = wt_align16(o + p.n_words * 2);
-    p.off_ltv = o;    o = wt_align16(o + TS * 8);
-    p.off_ltc = o;    o = wt_align16(o + T * 4);                        // (the tracks' run counts AND the scan lanes' totals)
-    p.off_gtv = o;    o = wt_align16(o + (TS / WT_DELTA_GROUP) * 8);
-    p.off_gtc = o;    o = wt_align16(o + (T / WT_DELTA_GROUP) * 4);
+    p.off_ltv = o;    o = wt_align16(o + ns * TS * 8);
+    p.off_ltc = o;    o = wt_align16(o + std::max(T, ns * TS) * 4);     // (the tracks' run counts AND the scan lanes' totals)
+    p.off_gtv = o;    o = wt_align16(o + ns * (TS / WT_DELTA_GROUP) * 8);
+    p.off_gtc = o;    o = wt_align16(o + (std::max(T, ns * TS) / WT_DELTA_GROUP) * 4);
     p.off_tbase = o;  o = wt_align16(o + T * 8);
     p.off_tpfx = o;   o = wt_align16(o + (T + 1) * 4);
     p.off_tfirst = o; o = wt_align16(o + WT_DELTA_TF * 2);
@@ -139,12 +150,17 @@ static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = fa
     p.off_dsh = o;    o = wt_align16(o + (int) sizeof(WtDeltaShared));
     p.delta_q = squares ? 1 : 0;
     if (squares) {
-        p.off_qa = o;  o = wt_align16(o + 2 * p.W * 8);
-        p.off_ltq = o; o = wt_align16(o + 2 * TS * 8);
-        p.off_gtq = o; o = wt_align16(o + 2 * (TS / WT_DELTA_GROUP) * 8);
+        p.off_qa = o;  o = wt_align16(o + 2 * ns * p.W * 8);
+        p.off_ltq = o; o = wt_align16(o + 2 * ns * TS * 8);
+        p.off_gtq = o; o = wt_align16(o + 2 * ns * (TS / WT_DELTA_GROUP) * 8);
     }
     p.off_shared = o; o = wt_align16(o + (int) sizeof(WtShared));
     p.lds_bytes = o;
+}
+
+// the difference-array plan of reducer `op` (squares for the var family, two sets for the t-test)
+static inline void wt_make_delta_plan_for(WtPlan &p, int n_tracks, int op) {
+    wt_make_delta_plan(p, n_tracks, wt_op_is_var_family(op), op == WT_OP_TTEST);
 }
 
 // Sum / Mean over float tracks whose defaults are all zero can take the exact difference-array
@@ -152,6 +168,10 @@ static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = fa
 static inline bool wt_delta_eligible(int op, bool value_f64, int n_tracks, const double *defaults) {
     if (getenv("WTAMD_NO_DELTA")) return false;
     const bool sq = wt_op_is_var_family(op);
+    if (op == WT_OP_TTEST) {
+        // TTestReduction (round 6): sums and squares of the values in play per set; defaults play no part (setComparisons.c:69-81)
+        return !getenv("WTAMD_NO_DELTA_TTEST") && !value_f64 && n_tracks >= 8 && n_tracks <= 32767;
+    }
     if (op != WT_OP_SUM && op != WT_OP_MEAN && !sq) return false;
     if (sq && (n_tracks < 8 || getenv("WTAMD_NO_DELTA_VAR"))) return false;     // (the split square accumulators need N >= 8)
     // a handful of tracks: nothing to gain over the general kernel
@@ -175,6 +195,7 @@ static inline bool wt_delta_eligible(int op, bool value_f64, int n_tracks, const
 // Difference-array launches: what the kernel needs to know about the defaults (after wt_plan_to_params).
 static inline void wt_delta_defaults_params(const double *defaults, int n_tracks, WtParams &P) {
     P.delta_df = 0; P.def_emin = 255; P.def_emax = 0;
+    if (P.op == WT_OP_TTEST) return;        // (setComparisons.c:69-81: only tracks in play are summed -- P.op is set before this call)
     for (int i = 0; i < n_tracks; i++) {
         if (defaults[i] == 0.0) continue;
         const float f = (float) defaults[i];
@@ -411,7 +432,7 @@ static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
     P.off_acc = p.off_acc; P.off_ev = p.off_ev; P.off_ltv = p.off_ltv; P.off_ltc = p.off_ltc;
     P.off_gtv = p.off_gtv; P.off_gtc = p.off_gtc; P.off_tbase = p.off_tbase; P.off_tpfx = p.off_tpfx; P.off_tfirst = p.off_tfirst; P.off_dsh = p.off_dsh; P.off_tdef = p.off_tdef;
     P.delta_df = 0; P.def_emin = 255; P.def_emax = 0;
-    P.off_qa = p.off_qa; P.off_ltq = p.off_ltq; P.off_gtq = p.off_gtq; P.delta_q = p.delta_q;
+    P.off_qa = p.off_qa; P.off_ltq = p.off_ltq; P.off_gtq = p.off_gtq; P.delta_q = p.delta_q; P.delta_ns = p.delta_ns;
     P.off_wcol = p.off_wcol; P.off_wcnt = p.off_wcnt; P.off_woff = p.off_woff; P.off_wtot = p.off_wtot; P.off_wbase = p.off_wbase;
     P.off_wgt = p.off_wgt; P.off_wncov = p.off_wncov; P.off_wfe = p.off_wfe; P.off_wdk = p.off_wdk; P.walk_S = p.walk_S;
     P.off_wguess = p.off_wguess; P.walk_capp = p.walk_capp; P.walk_ov = p.walk_ov; P.walk_off_at = p.walk_off_at; P.walk_pair = p.walk_pair;
