@@ -790,14 +790,19 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
     kernel_ms_sum = red_all / passes                    # per pass, summed over launches (and ranks)
     achieved = alg_bytes / (kernel_ms_sum * 1e-3) / 1e9
     tile_equiv = len(ops) * tot_runs * (4.0 * N + N / 8.0 + 24.0) / (kernel_ms_sum * 1e-3) / 1e9
+    # measured HBM traffic of THIS kernel: profiles/traffic.json keeps, per kernel label, the ratio of a PMC pass's FETCH_SIZE + WRITE_SIZE
+    # to that launch's algorithmic bytes (tools/round6.sh); a kernel without a pass of its own gets null -- never another kernel's ratio
     traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
-                traffic = tj["hbm_bytes_per_algorithmic_byte"] * alg_bytes
-                traffic_src = "PMC passes of %s (profiles/traffic.json: FETCH_SIZE + WRITE_SIZE per launch, ratio to that launch's algorithmic bytes) scaled to this launch" % tj.get("profile", "an earlier profile")
+            ent = (tj.get("kernels") or {}).get(kernel)
+            if ent is None and tj.get("kernel") == kernel:
+                ent = tj                                   # (round 5's single-kernel file)
+            if ent is not None:
+                traffic = ent["hbm_bytes_per_algorithmic_byte"] * alg_bytes
+                traffic_src = "PMC passes of %s (profiles/traffic.json: FETCH_SIZE + WRITE_SIZE per launch, ratio to that launch's algorithmic bytes) scaled to this launch" % ent.get("profile", "an earlier profile")
         except Exception:
             traffic = None
     bound = "hbm"

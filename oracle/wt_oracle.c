@@ -209,20 +209,23 @@ static double betacf(double a, double b, double x) {
     return h;
 }
 
-static double inc_beta(double a, double b, double x) {
+/* y = 1 - x, handed over by the caller who can form it WITHOUT the cancellation (round 6: with 1 - x of the rounded
+ * x = nu / (nu + t^2) a small t -- p close to 1 -- lost all but a few digits of 1 - p: t = 2e-5, nu = 898 came out 1e-9
+ * off; gsl_cdf_tdist_Q, which this stands in for, has no such loss) */
+static double inc_beta(double a, double b, double x, double y) {
     if (x <= 0) return 0;
-    if (x >= 1) return 1;
-    double lnfront = lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log1p(-x);
+    if (y <= 0) return 1;
+    double lnfront = lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log(y);
     if (x < (a + 1) / (a + b + 2))
         return exp(lnfront) * betacf(a, b, x) / a;
-    return 1 - exp(lnfront) * betacf(b, a, 1 - x) / b;
+    return 1 - exp(lnfront) * betacf(b, a, y) / b;
 }
 
 double wto_tdist_Q(double t, double nu) {
     if (isnan(t) || isnan(nu) || nu <= 0) return NAN;
     if (isinf(t)) return t > 0 ? 0 : 1;
-    double x = nu / (nu + t * t);
-    double tail = 0.5 * inc_beta(nu / 2, 0.5, x);
+    double x = nu / (nu + t * t), y = t * t / (nu + t * t);
+    double tail = 0.5 * inc_beta(nu / 2, 0.5, x, y);
     return t >= 0 ? tail : 1 - tail;
 }
 

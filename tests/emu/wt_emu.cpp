@@ -285,9 +285,10 @@ struct EmuRun {
             }
             const int TS = P.W / WT_DELTA_K;        // the scans' lanes (wt_delta_kernel: nts)
             if constexpr (TT) {
-                for (int t = 0; t < TS; t++) wt_delta_scan1_tt(P, c, d, dl2[t], t, TS);
-                for (int t = 0; t < TS; t++) wt_delta_scan2_tt(P, c, d, t, TS);
-                for (int t = 0; t < TS; t++) wt_delta_scan3_tt(P, c, d, dl2[t], lanes[t], scale, t, TS);
+                for (int t = 0; t < 2 * TS; t++) wt_delta_scan1_tt(P, c, d, dl2[t], t, TS);
+                for (int t = 0; t < 2 * TS; t++) wt_delta_scan2_tt(P, c, d, t, TS);
+                for (int t = 0; t < 2 * TS; t++) wt_delta_scan3_tt(P, c, d, dl2[t], scale, t, TS);
+                for (int t = 0; t < T; t++) wt_delta_combine_tt(P, c, d, t, T);
                 for (int t = 0; t < T; t++) wt_delta_tail_tt(P, d, t, T);
                 if (d.dsh->risk && c.sh->bad_slot < 0) wt_delta_mark_bad(P, c, k);
             } else {

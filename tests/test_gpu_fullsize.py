@@ -123,15 +123,22 @@ def test_gpu_plans_agree_bitwise_at_scale(op, kw, monkeypatch):
     stream = torch.cuda.current_stream().cuda_stream
     plans = [{}, {"WTAMD_CHUNK": "37"}]
     plans.append({"WTAMD_T": "64"} if op in ("median", "mwu") else {"WTAMD_PPT": "1", "WTAMD_T": "256"})
+    if op == "ttest":
+        # round 6: TTestReduction's default is the difference-array kernel (exact integer sums per set); the plans of the general
+        # kernel with it switched off -- and the default beside them: the generator's k/8 values make every route's sums exact,
+        # so t, the degrees of freedom and with them the tail agree bit for bit
+        plans = [dict(p, WTAMD_NO_DELTA_TTEST="1") for p in plans] + [{}]
     ref = None
     for env in plans:
-        for k in ("WTAMD_CHUNK", "WTAMD_PPT", "WTAMD_T"):
+        for k in ("WTAMD_CHUNK", "WTAMD_PPT", "WTAMD_T", "WTAMD_NO_DELTA_TTEST"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ts = engine.TrackSet.from_device(len(chrom_lens), N, seg_off, start, finish, value, np.zeros(N))
         out = ts.alloc_runs()
         n = ts.reduce(op, out, stream=stream, sync=True, **kw)
+        if op == "ttest":
+            assert ts.stats()["kernel"] == (0 if "WTAMD_NO_DELTA_TTEST" in env else 1), (env, ts.stats())
         ts.close()
         got = (n, out.start[:n].clone(), out.finish[:n].clone(), out.value[:n].view(torch.int64).clone())
         del out
@@ -144,9 +151,11 @@ def test_gpu_plans_agree_bitwise_at_scale(op, kw, monkeypatch):
             assert torch.equal(got[3], ref[3]), "plan %s changes the value bits of %s" % (env, op)
 
 
-@pytest.mark.parametrize("op", ["var", "stddev", "cv"])
-def test_gpu_var_family_two_algorithms_at_scale(op, monkeypatch):
-    """Variance family at 62 Mbp x 100 tracks through two independent algorithms: exact integer sums of
+@pytest.mark.parametrize("op,N,scale", [("var", 100, 0.02), ("stddev", 100, 0.02), ("cv", 100, 0.02),
+                                        ("var", 500, 0.01), ("stddev", 500, 0.01)])
+def test_gpu_var_family_two_algorithms_at_scale(op, N, scale, monkeypatch):
+    """Variance family at 62 Mbp x 100 tracks -- and at BASELINE config 3's width, 500 tracks x 31 Mbp (the 768-lane layout of
+    the launches with squares; the general kernel in chunks of tracks) -- through two independent algorithms: exact integer sums of
     the scaled mantissas and of their squares with a 128-bit finish (difference arrays)
     vs the reference's two sequential f64 passes per position (general kernel).  Coordinates and run
     count identical; values within 1e-12 relative (the reference-order result carries ~N roundings,
@@ -156,8 +165,7 @@ def test_gpu_var_family_two_algorithms_at_scale(op, monkeypatch):
     from wiggletools_amd import engine, synthgen
 
     dev = torch.device("cuda", 0)
-    N = 100
-    chrom_lens = [max(int(x * 0.02), 1) for x in bench.GRCH38]
+    chrom_lens = [max(int(x * scale), 1) for x in bench.GRCH38]
     seg_off, start, finish, value = synthgen.device_tracks(5, chrom_lens, N, 16.0, 0.02, 800, dev)
     stream = torch.cuda.current_stream().cuda_stream
     res = []

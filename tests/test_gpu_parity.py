@@ -483,9 +483,11 @@ def test_gpu_difference_array_ttest(oracle, engine, seed):
         assert st["kernel"] == 1 and st["window_bp"] == 2048, st
         if seed % 4 == 1:
             assert st["patched_windows"] > 0, st
-        # (1e-9 on the device whatever the values: its lgamma / log / exp are not the host's; the emulator's test holds the
-        #  coarse-grid cases to tolerance 0)
-        assert_runs_equal(got, oracle.reduce(d, "ttest", flags=flags, n_set0=n1), 1e-9,
+        # 1e-9 on the device where the sums are exact on both sides (coarse values: what differs is the device's log / exp; the
+        # emulator's test holds those cases to tolerance 0).  Full mantissas: the reference's own sum of squares rounds n times,
+        # the exact sums once, and a p-value deep in the tail magnifies a relative change of t by ~t^2 (900 tracks, t ~ 6:
+        # 1.7e-9 measured) -- 1e-7 there; BASELINE.json's bound for float statistics is 1e-6.
+        assert_runs_equal(got, oracle.reduce(d, "ttest", flags=flags, n_set0=n1), 1e-7 if seed % 3 == 0 else 1e-9,
                           "ttest seed %d flags %d n %d n1 %d %s" % (seed, flags, n, n1, st))
     ts.close()
 

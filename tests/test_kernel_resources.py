@@ -79,6 +79,16 @@ def test_squares_difference_array_kernels_spill_nothing(kernels):
         assert k["spill"] == 0 and k["scratch"] == 0, (op, k)
 
 
+def test_two_sample_difference_array_kernel_budget(kernels):
+    """wt_delta_kernel<ttest> (round 6): 768 lanes, 168 registers; its scans (two sets' 128-bit sums per lane) and the Student tail
+    spill -- a few hundred bytes of scratch written and read in the scan phases only: the passes over the runs touch none
+    (read off the ISA: tools/kernel_asm.py 10 0).  The budget holds the regression class: a change that lets the spills grow
+    past this or reach the pass shows up here."""
+    k = _delta(kernels, 10, False)
+    assert k["max_wg"] == 768 and k["vgpr"] <= 170, k
+    assert k["spill"] <= 120 and k["scratch"] <= 512, k
+
+
 def test_walking_and_inflate_kernels_use_no_scratch(kernels):
     for name, k in kernels.items():
         if "wt_walk_kernel" in name or "wt_mwalk_kernel" in name or "wt_bw_inflate_kernel" in name:

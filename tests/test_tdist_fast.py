@@ -35,19 +35,20 @@ def test_fast_tail_equals_the_oracle_form(lib):
     nus = np.concatenate([[1e-3, 0.5, 1.0, 2.0, 2.5, 3.0, 31.9, 32.0, 32.1, 98.0, 1000.0, 65534.0], rng.uniform(1.0, 200.0, 3000), np.geomspace(0.1, 6e4, 1000)])
     # both forms compute a * log(x) and (the oracle's) lgamma(a + 1/2) - lgamma(a) of two numbers ~ a ln a: their common
     # rounding grows with a = nu / 2 (at nu = 65534 the oracle's form is 1.9e-11 off the true value, this one 4e-12: mpmath)
-    def tol(nu, b):
-        return (1e-12 + 1e-15 * nu * math.log(nu + 2.0)) * abs(b) + 1e-300
-    worst = 0.0
+    # (both forms take y = 1 - x = t^2 / (nu + t^2) as computed, not 1 - x of the rounded x: round 6 -- before, the oracle's form
+    #  gave 0.99999999431700 for t = 1e-8, nu = 1/2, true 0.99999999460647)
+    def tol(nu, b, t=1.0):
+        # ... and below t = 3 (nu <= 2000) the device's form takes the fraction in y = 1 - x for the sake of the wavefront's slowest
+        # lane: its result 1 - r carries the front factor's a * 1e-16 as an ABSOLUTE error
+        wide = 3e-16 * (nu / 2 + 8.0) if t < 3.0 and nu <= 2000.0 else 0.0
+        return (1e-12 + 1e-15 * nu * math.log(nu + 2.0)) * abs(b) + 1e-300 + wide
     for t in ts[:12]:
         for nu in nus[:12]:
             a, b = lib.wtemu_tdist_2q_fast(float(t), float(nu)), lib.wtemu_tdist_2q(float(t), float(nu))
-            assert abs(a - b) <= tol(nu, b), (t, nu, a, b)
+            assert abs(a - b) <= tol(nu, b, t), (t, nu, a, b)
     for t, nu in zip(ts[12:], nus[12:]):
         a, b = lib.wtemu_tdist_2q_fast(float(t), float(nu)), lib.wtemu_tdist_2q(float(t), float(nu))
-        assert abs(a - b) <= tol(nu, b), (t, nu, a, b)
-        if b > 0 and nu <= 200:
-            worst = max(worst, abs(a - b) / b)
-    assert worst < 2e-12         # (nu <= 200)
+        assert abs(a - b) <= tol(nu, b, t), (t, nu, a, b)
     # the special values of wt_tdist_Q
     assert math.isnan(lib.wtemu_tdist_2q_fast(float("nan"), 5.0)) and math.isnan(lib.wtemu_tdist_2q_fast(1.0, float("nan")))
     assert math.isnan(lib.wtemu_tdist_2q_fast(1.0, 0.0)) and math.isnan(lib.wtemu_tdist_2q_fast(1.0, -3.0))
@@ -76,4 +77,5 @@ def test_fast_tail_against_mpmath(lib):
         T, NU = mp.mpf(float(t)), mp.mpf(float(nu))
         want = float(mp.betainc(NU / 2, mp.mpf("0.5"), 0, NU / (NU + T * T), regularized=True))
         got = lib.wtemu_tdist_2q_fast(float(t), float(nu))
-        assert abs(got - want) <= (1e-12 + 1e-15 * nu) * want + 1e-300, (t, nu, got, want)
+        wide = 3e-16 * (nu / 2 + 8.0) if t < 3.0 and nu <= 2000.0 else 0.0        # (see tol() above)
+        assert abs(got - want) <= (1e-12 + 1e-15 * nu) * want + 1e-300 + wide, (t, nu, got, want)

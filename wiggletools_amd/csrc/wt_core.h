@@ -312,17 +312,18 @@ WT_DEV double wt_betacf(double a, double b, double x) {
     return h;
 }
 
-WT_DEV double wt_inc_beta(double a, double b, double x) {
+// (y = 1 - x, formed by the caller without the cancellation: oracle/wt_oracle.c inc_beta)
+WT_DEV double wt_inc_beta(double a, double b, double x, double y) {
     if (x <= 0) return 0;
-    if (x >= 1) return 1;
+    if (y <= 0) return 1;
     // the t-test always comes with b = 1/2 (or a = 1/2 after the symmetry swap): lgamma(1/2) = ln sqrt(pi)
     const double lg_half = 0.57236494292470008707;
     const double lga = (a == 0.5) ? lg_half : lgamma(a), lgb = (b == 0.5) ? lg_half : lgamma(b);
-    double lnfront = lgamma(a + b) - lga - lgb + a * log(x) + b * log1p(-x);
+    double lnfront = lgamma(a + b) - lga - lgb + a * log(x) + b * log(y);
     // one continued-fraction evaluation with the arguments chosen per lane (a divergent if / else
     // made every wave run both); same arithmetic per lane as the two-branch form
     const bool flip = !(x < (a + 1) / (a + b + 2));
-    const double a2 = flip ? b : a, b2 = flip ? a : b, x2 = flip ? 1 - x : x;
+    const double a2 = flip ? b : a, b2 = flip ? a : b, x2 = flip ? y : x;
     const double r = exp(lnfront) * wt_betacf(a2, b2, x2) / a2;
     return flip ? 1 - r : r;
 }
@@ -330,8 +331,8 @@ WT_DEV double wt_inc_beta(double a, double b, double x) {
 WT_DEV double wt_tdist_Q(double t, double nu) {
     if (wt_isnan(t) || wt_isnan(nu) || nu <= 0) return wt_nan();
     if (isinf(t)) return t > 0 ? 0.0 : 1.0;
-    double x = nu / (nu + t * t);
-    double tail = 0.5 * wt_inc_beta(nu / 2, 0.5, x);
+    double x = nu / (nu + t * t), y = t * t / (nu + t * t);
+    double tail = 0.5 * wt_inc_beta(nu / 2, 0.5, x, y);
     return t >= 0 ? tail : 1 - tail;
 }
 
@@ -350,10 +351,13 @@ WT_DEV double wt_tdist_Q(double t, double nu) {
 // Same mathematical quantity as wt_tdist_Q, rounded differently (~1e-15 relative apart; tests/test_tdist_fast.py holds it to 1e-12
 // against the oracle's over the (t, nu) plane).  The device's reducers call wt_ttest_tail; the emulator keeps the oracle's form.
 // ---------------------------------------------------------------------------
-WT_DEV double wt_lgamma_half_diff(double a) {
-    // lgamma(a + 1/2) - lgamma(a), a > 0
+// exp(lgamma(a + 1/2) - lgamma(a)) = sqrt(a') exp(S(a')) den / num with a' = a + j >= 16: returns S(a') (|S| < 1 / 128), a', num / den
+WT_DEV double wt_gamma_half_ratio_parts(double a, double &a_shifted, double &num_over_den) {
     double num = 1.0, den = 1.0;
-    while (a < 16.0) { num *= a + 0.5; den *= a; a += 1.0; }
+    bool shifted = false;
+    while (a < 16.0) { num *= a + 0.5; den *= a; a += 1.0; shifted = true; }
+    num_over_den = shifted ? num / den : 1.0;
+    a_shifted = a;
     const double r = 1.0 / a, r2 = r * r;
     double sres = 691.0 / 180224.0;
     sres = sres * r2 - 31.0 / 18432.0;
@@ -361,13 +365,18 @@ WT_DEV double wt_lgamma_half_diff(double a) {
     sres = sres * r2 - 1.0 / 640.0;
     sres = sres * r2 + 1.0 / 192.0;
     sres = sres * r2 - 1.0 / 8.0;
-    double dres = 0.5 * log(a) + sres * r;
-    if (num != 1.0) dres -= log(num / den);
-    return dres;
+    return sres * r;
+}
+WT_DEV double wt_lgamma_half_diff(double a) {
+    // lgamma(a + 1/2) - lgamma(a), a > 0 (the tests' view of the series)
+    double as, nd;
+    const double sres = wt_gamma_half_ratio_parts(a, as, nd);
+    return 0.5 * log(as) + sres - (nd != 1.0 ? log(nd) : 0.0);
 }
 
 // h = 1 / (1 + d1 / (1 + d2 / ...)) with wt_betacf's coefficients
-WT_DEV double wt_betacf_wallis(double a, double b, double x) {
+// (returned as the pair A, B with h = B / A: the caller has more to divide by)
+WT_DEV void wt_betacf_wallis(double a, double b, double x, double &A_out, double &B_out) {
     const double eps = 1e-16;
     // n = 0: A_0 = 1, B_0 = 1 (f_0 = 1), A_-1 = 1, B_-1 = 0; q_0 = 1
     double A2 = 1.0, B2 = 0.0, A1 = 1.0, B1 = 1.0, qprev = 1.0;
@@ -403,23 +412,33 @@ WT_DEV double wt_betacf_wallis(double a, double b, double x) {
             A1 *= sc; B1 *= sc; A2 *= sc; B2 *= sc;
         }
     }
-    return B1 / A1;
+    A_out = A1; B_out = B1;
 }
 
 WT_DEV double wt_tdist_2Q_fast(double t, double nu) {
     if (wt_isnan(t) || wt_isnan(nu) || nu <= 0) return wt_nan();
     if (isinf(t)) return t > 0 ? 0.0 : 2.0;
     const double a = nu / 2, b = 0.5;
-    const double x = nu / (nu + t * t);
+    const double t2 = t * t, inv = 1.0 / (nu + t2);
+    const double x = nu * inv, y = t2 * inv;            // y = 1 - x, to full relative accuracy
     double I;
     if (x <= 0) I = 0;
-    else if (x >= 1) I = 1;
+    else if (y <= 0) I = 1;
     else {
-        const double lg_half = 0.57236494292470008707;      // lgamma(1/2) = ln sqrt(pi)
-        const double lnfront = wt_lgamma_half_diff(a) - lg_half + a * log(x) + b * log1p(-x);
-        const bool flip = !(x < (a + 1) / (a + b + 2));
-        const double a2 = flip ? b : a, b2 = flip ? a : b, x2 = flip ? 1 - x : x;
-        const double r = exp(lnfront) * wt_betacf_wallis(a2, b2, x2) / a2;
+        // the front factor x^a (1 - x)^b / B(a, b) with b = 1/2: ONE log and ONE exponential --
+        //   Gamma(a + 1/2) / Gamma(a) = sqrt(a') exp(S(a')) den / num,  Gamma(1/2) = sqrt(pi),  (1 - x)^(1/2) = sqrt(y)
+        double as, nd;
+        const double sres = wt_gamma_half_ratio_parts(a, as, nd);
+        const double front = exp(a * log(x) + sres) * sqrt(as * y * 0.31830988618379067154);       // 1 / pi
+        // which side: the textbook rule x >= (a + 1) / (a + b + 2) -- and every t < 3: just below that rule's switch the fraction
+        // in x needs 30-40 rounds (nu = 98: 38 at t = 1.8, 20 at t = 3) where the one in y needs 8-12, and the 64 lanes of a
+        // wavefront wait for the slowest.  The price: r ~ 1 carries the front factor's a * 1e-16, so 1 - r >= 0.0027 is good to
+        // a * 4e-14 relative there (nu = 98: 2e-12) -- hence only up to nu = 2000
+        const bool flip = !(x * (a + b + 2) < a + 1) || (t2 < 9.0 && a <= 1000.0);
+        const double a2 = flip ? b : a, b2 = flip ? a : b, x2 = flip ? y : x;
+        double A, B;
+        wt_betacf_wallis(a2, b2, x2, A, B);
+        const double r = front * B / (A * a2 * nd);
         I = flip ? 1 - r : r;
     }
     return t >= 0 ? I : 2 - I;

@@ -779,54 +779,57 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
 // meanSq / var.  A window with an emitted position where var * 2^10 < meanSq in a set is therefore recorded like a window
 // whose exponent range is too wide (`risk` -> wt_delta_mark_bad): the general kernel, which adds in the reference's order,
 // rewrites its values.
+// The scans of a two-sample launch are split BY SET: lanes [0, nts) own set 0's 8 positions each, lanes [nts, 2 nts) set 1's (whole
+// wavefronts either way) -- half the registers of a lane that carried both sets (which spilled 80), and twice the wavefronts.
+//   A  wt_delta_scan1_tt     the lane's totals of its set + the wave-level prefix (device) / group totals (emulator, scan2)
+//   B  wt_delta_scan3_tt     running sums at the lane's 8 positions, left IN PLACE as what the test needs: acc[] <- (double) S q,
+//                            qa[] <- (double) Q q^2, ev[] <- coverage << 1 | breakpoint
+//   C  wt_delta_combine_tt   one lane per POSITION, all the workgroup's lanes: both sets' sums -> emitted?, t, degrees of freedom;
+//                            the breakpoint / emitted words are the wavefront's ballots
+//   D  wt_delta_tail_tt      the Student tail of the emitted positions (beside the look-back of wave 0)
 struct WtDeltaLane2 {
-    long long tv[2];            // the lane's totals per set: value deltas,
-    int32_t tc[2];              // ... coverage deltas,
-    unsigned long long tqa[2], tqb[2];      // ... the squares' two parts
-    long long wv[2];            // device: the same summed over the wave's lanes before this one
-    int32_t wc[2];
-    unsigned long long wqa[2], wqb[2];
+    long long tv;               // the lane's totals of ITS set: value deltas,
+    int32_t tc;                 // ... coverage deltas,
+    unsigned long long tqa, tqb;            // ... the squares' two parts
+    long long wv;               // device: the same summed over the wave's lanes before this one
+    int32_t wc;
+    unsigned long long wqa, wqb;
 };
 
-WT_DEV void wt_delta_scan1_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLane2 &L, int tid, int nt) {
-    const int p0 = tid * WT_DELTA_K;
+// (tid: 0 .. 2 nts - 1; the lane's set is tid / nts, its positions 8 (tid % nts) ..)
+WT_DEV void wt_delta_scan1_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLane2 &L, int tid, int nts) {
+    const int s = tid >= nts ? 1 : 0;
+    const int o = s * P.W + (tid - s * nts) * WT_DELTA_K;
+    long long rv = 0;
+    int32_t rc = 0;
+    unsigned long long ra = 0, rb = 0;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-        const int o = s * P.W + p0;
-        long long rv = 0;
-        int32_t rc = 0;
-        unsigned long long ra = 0, rb = 0;
-#pragma unroll
-        for (int k = 0; k < WT_DELTA_K; k++) {
-            const uint32_t e = d.ev[o + k];
-            rv += d.acc[o + k];
-            rc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
-            ra += d.qa[o + k];
-            rb += d.qb[o + k];
-        }
-        L.tv[s] = rv; L.tc[s] = rc; L.tqa[s] = ra; L.tqb[s] = rb;
-        d.ltv[s * nt + tid] = rv;
-        d.ltc[s * nt + tid] = rc;
-        d.ltqa[s * nt + tid] = ra;
-        d.ltqb[s * nt + tid] = rb;
+    for (int k = 0; k < WT_DELTA_K; k++) {
+        const uint32_t e = d.ev[o + k];
+        rv += d.acc[o + k];
+        rc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
+        ra += d.qa[o + k];
+        rb += d.qb[o + k];
     }
+    L.tv = rv; L.tc = rc; L.tqa = ra; L.tqb = rb;
+    d.ltv[tid] = rv;
+    d.ltc[tid] = rc;
+    d.ltqa[tid] = ra;
+    d.ltqb[tid] = rb;
 }
 
-// (the emulator's middle step: group totals)
-WT_DEV void wt_delta_scan2_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
-    const int ngroups = nt / WT_DELTA_GROUP;
+// (the emulator's middle step: group totals; groups never straddle the sets: nts is a multiple of WT_DELTA_GROUP)
+WT_DEV void wt_delta_scan2_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nts) {
+    const int ngroups = 2 * nts / WT_DELTA_GROUP;
     if (tid >= ngroups) return;
-    for (int s = 0; s < 2; s++) {
-        long long sv = 0;
-        int32_t sc = 0;
-        unsigned long long sa = 0, sb = 0;
-        for (int x = 0; x < WT_DELTA_GROUP; x++) {
-            const int j = s * nt + tid * WT_DELTA_GROUP + x;
-            sv += d.ltv[j]; sc += d.ltc[j]; sa += d.ltqa[j]; sb += d.ltqb[j];
-        }
-        d.gtv[s * ngroups + tid] = sv; d.gtc[s * ngroups + tid] = sc;
-        d.gtqa[s * ngroups + tid] = sa; d.gtqb[s * ngroups + tid] = sb;
+    long long sv = 0;
+    int32_t sc = 0;
+    unsigned long long sa = 0, sb = 0;
+    for (int x = 0; x < WT_DELTA_GROUP; x++) {
+        const int j = tid * WT_DELTA_GROUP + x;
+        sv += d.ltv[j]; sc += d.ltc[j]; sa += d.ltqa[j]; sb += d.ltqb[j];
     }
+    d.gtv[tid] = sv; d.gtc[tid] = sc; d.gtqa[tid] = sa; d.gtqb[tid] = sb;
 }
 
 // Welch's t and its degrees of freedom from the two sets' sums, setComparisons.c:88-113 operation for operation
@@ -845,72 +848,70 @@ WT_DEV void wt_ttest_stat(double sum1, double sumsq1, double sum2, double sumsq2
     risk = (var1 * 1024.0 < msq1) || (var2 * 1024.0 < msq2);
 }
 
-// scan step 3 of a two-sample launch: running sums of both sets at every position, breakpoint and emitted bytes, the test
-WT_DEV void wt_delta_scan3_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtDeltaLane2 &L,
-                              WtLane<WT_DELTA_K> &out, int emin, int tid, int nt) {
-    long long bv[2] = {d.dsh->base_v, d.dsh->base_v1};
-    int32_t bc[2] = {d.dsh->base_c, d.dsh->base_c1};
-    unsigned long long bqa[2] = {d.dsh->base_qa, d.dsh->base_qa1}, bqb[2] = {d.dsh->base_qb, d.dsh->base_qb1};
+// phase B: the running sums of the lane's set at its 8 positions, left in place for wt_delta_combine_tt
+WT_DEV void wt_delta_scan3_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtDeltaLane2 &L, int emin, int tid, int nts) {
+    const int s = tid >= nts ? 1 : 0;
+    long long bv = s ? d.dsh->base_v1 : d.dsh->base_v;
+    int32_t bc = s ? d.dsh->base_c1 : d.dsh->base_c;
+    unsigned long long bqa = s ? d.dsh->base_qa1 : d.dsh->base_qa, bqb = s ? d.dsh->base_qb1 : d.dsh->base_qb;
 #ifdef WT_EMU
-    const int grp = tid / WT_DELTA_GROUP, ngroups = nt / WT_DELTA_GROUP;
-    for (int s = 0; s < 2; s++) {
-        for (int x = 0; x < grp; x++) { bv[s] += d.gtv[s * ngroups + x]; bc[s] += d.gtc[s * ngroups + x]; bqa[s] += d.gtqa[s * ngroups + x]; bqb[s] += d.gtqb[s * ngroups + x]; }
-        for (int x = grp * WT_DELTA_GROUP; x < tid; x++) { bv[s] += d.ltv[s * nt + x]; bc[s] += d.ltc[s * nt + x]; bqa[s] += d.ltqa[s * nt + x]; bqb[s] += d.ltqb[s * nt + x]; }
-    }
+    const int grp = tid / WT_DELTA_GROUP, grp0 = s * nts / WT_DELTA_GROUP;
+    for (int x = grp0; x < grp; x++) { bv += d.gtv[x]; bc += d.gtc[x]; bqa += d.gtqa[x]; bqb += d.gtqb[x]; }
+    for (int x = grp * WT_DELTA_GROUP; x < tid; x++) { bv += d.ltv[x]; bc += d.ltc[x]; bqa += d.ltqa[x]; bqb += d.ltqb[x]; }
 #else
-    const int nwaves = nt >> 6;
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        for (int x = 0; x < (tid >> 6); x++) { bv[s] += d.gtv[s * nwaves + x]; bc[s] += d.gtc[s * nwaves + x]; bqa[s] += d.gtqa[s * nwaves + x]; bqb[s] += d.gtqb[s * nwaves + x]; }
-        bv[s] += L.wv[s]; bc[s] += L.wc[s]; bqa[s] += L.wqa[s]; bqb[s] += L.wqb[s];
-    }
+    for (int x = s * (nts >> 6); x < (tid >> 6); x++) { bv += d.gtv[x]; bc += d.gtc[x]; bqa += d.gtqa[x]; bqb += d.gtqb[x]; }   // the set's waves before this one
+    bv += L.wv; bc += L.wc; bqa += L.wqa; bqb += L.wqb;
 #endif
+    const int o = s * P.W + (tid - s * nts) * WT_DELTA_K;
+    const double q = __builtin_bit_cast(double, (uint64_t) (emin - 150 + 1023) << 52);      // the weight of one unit of the scaled mantissas
+    double *sum = (double *) d.acc, *sumsq = (double *) d.qa;
+#pragma unroll
+    for (int k = 0; k < WT_DELTA_K; k++) {
+        const uint32_t e = d.ev[o + k];
+        bv += d.acc[o + k];
+        bc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
+        bqa += d.qa[o + k]; bqb += d.qb[o + k];
+        // exact integers: S and Q = (A << 40) + B (see WT_DELTA_QSHIFT); S * q is the reference's sum whenever that did not round
+        const unsigned __int128 Q = ((unsigned __int128) bqa << WT_DELTA_QSHIFT) + (unsigned __int128) bqb;
+        sum[o + k] = (double) bv * q;
+        sumsq[o + k] = ((double) (unsigned long long) (Q >> 64) * 18446744073709551616.0 + (double) (unsigned long long) Q) * q * q;
+        d.ev[o + k] = ((uint32_t) bc << 1) | (e != 0u ? 1u : 0u);
+    }
+}
+
+// phase C: one lane per position (wave `tid >> 6` takes the 64-position words wave, wave + nwaves, ...).  t (NaN: no emitted run
+// starts here, or the reference's own NaN) and the degrees of freedom go to the second set's slots of the position -- this
+// lane has just read them -- for wt_delta_tail_tt.
+WT_DEV void wt_delta_combine_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
     const int na = P.n_set0, nb = P.n_tracks - P.n_set0;
     const bool strict0 = (P.flags & WT_STRICT_SET0) != 0, strict1 = (P.flags & WT_STRICT_SET1) != 0;
-    const int p0 = tid * WT_DELTA_K;
-    const double q = __builtin_bit_cast(double, (uint64_t) (emin - 150 + 1023) << 52);      // the weight of one unit of the scaled mantissas
-    const long long room = (long long) c.sh->emit_hi - ((long long) c.sh->w0 + p0);
-    uint32_t em = 0, evmask = 0;
+    const long long room = (long long) c.sh->emit_hi - (long long) c.sh->w0;
+    const int lane = tid & 63, nwaves = nt >> 6;
+    double *sum = (double *) d.acc, *sumsq = (double *) d.qa;
     bool any_risk = false;
-    // The statistic t and the degrees of freedom of position k go to the SECOND set's value and square slots of that position,
-    // which only this lane reads and which are dead once read; the Student tail -- the expensive part: logs, an exponential, a
-    // continued fraction -- is a phase of its own over ALL the workgroup's lanes (wt_delta_tail_tt: run here, by the 256 scan
-    // lanes for their 8 positions each, a 2048-bp window spent 120 of its 149 us in eight tails back to back on four
-    // wavefronts), and wt_delta_load_res_tt brings a lane's 8 results back for the staging.
-    double *res = (double *) (d.acc + P.W + p0);
-    double *dof = (double *) (d.qa + P.W + p0);
-#pragma unroll 1
-    for (int k = 0; k < WT_DELTA_K; k++) {
-        uint32_t eany = 0;
-        double sum[2], sumsq[2];
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-            const int o = s * P.W + p0 + k;
-            const uint32_t e = d.ev[o];
-            eany |= e;
-            bv[s] += d.acc[o];
-            bc[s] += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
-            bqa[s] += d.qa[o]; bqb[s] += d.qb[o];
-            // exact integers: S and Q = (A << 40) + B (see WT_DELTA_QSHIFT); S * q is the reference's sum whenever that did not round
-            const unsigned __int128 Q = ((unsigned __int128) bqa[s] << WT_DELTA_QSHIFT) + (unsigned __int128) bqb[s];
-            sum[s] = (double) bv[s] * q;
-            sumsq[s] = ((double) (unsigned long long) (Q >> 64) * 18446744073709551616.0 + (double) (unsigned long long) Q) * q * q;
-        }
-        evmask |= (eany != 0u ? 1u : 0u) << k;
-        const bool pred = (strict0 ? bc[0] == na : bc[0] > 0) && (strict1 ? bc[1] == nb : bc[1] > 0);    // multiplexer.c:120,125; setComparisons.c:48-54
-        const bool emit = eany != 0u && pred && k < room;
-        if (emit) em |= 1u << k;
+    for (int w = tid >> 6; w < P.n_words; w += nwaves) {
+        const int p = w * 64 + lane;
+        const uint32_t cv0 = d.ev[p], cv1 = d.ev[P.W + p];
+        const bool eany = ((cv0 | cv1) & 1u) != 0u;
+        const int32_t c0 = (int32_t) (cv0 >> 1), c1 = (int32_t) (cv1 >> 1);
+        const bool pred = (strict0 ? c0 == na : c0 > 0) && (strict1 ? c1 == nb : c1 > 0);     // multiplexer.c:120,125; setComparisons.c:48-54
+        const bool emit = eany && pred && p < room;
         double t, nu;
         bool risk;
-        wt_ttest_stat(sum[0], sumsq[0], sum[1], sumsq[1], na, nb, t, nu, risk);
+        wt_ttest_stat(sum[p], sumsq[p], sum[P.W + p], sumsq[P.W + p], na, nb, t, nu, risk);
         any_risk |= emit && risk;
-        // (positions that start no emitted run are skipped by the tail: NaN)
-        res[k] = emit ? t : wt_nan();
-        dof[k] = nu;
+        sum[P.W + p] = emit ? t : wt_nan();
+        sumsq[P.W + p] = nu;
+#ifdef WT_EMU
+        if (lane == 0) { c.U[w] = 0; c.E[w] = 0; }         // (the emulator's lanes run one after the other, lane 0 of a word first)
+        c.U[w] |= (uint64_t) (eany ? 1 : 0) << lane;
+        c.E[w] |= (uint64_t) (emit ? 1 : 0) << lane;
+#else
+        const uint64_t ub = __builtin_amdgcn_ballot_w64(eany), eb = __builtin_amdgcn_ballot_w64(emit);
+        if (lane == 0) { c.U[w] = ub; c.E[w] = eb; }
+#endif
     }
     if (any_risk) d.dsh->risk = 1;
-    ((uint8_t *) c.U)[tid] = (uint8_t) evmask;
-    ((uint8_t *) c.E)[tid] = (uint8_t) em;
 }
 
 // the tail of every emitted position of the window: all lanes, consecutive lanes consecutive positions
@@ -1071,22 +1072,19 @@ WT_DEV void wt_delta_scan_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDelta
     }
 }
 
-// ... of a two-sample launch: both sets' four totals (gt*[s * nwaves + wave]: the wave totals per set)
-WT_DEV void wt_delta_scan_w1_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLane2 &L, int tid, int nt) {
-    wt_delta_scan1_tt(P, c, d, L, tid, nt);
-    const int lane = tid & 63, wave = tid >> 6, nwaves = nt >> 6;
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        const long long iv = wt_wave_scan_i64(L.tv[s], lane);
-        const int32_t ic = (int32_t) wt_wave_scan_u32((unsigned) L.tc[s], lane);
-        const unsigned long long ia = (unsigned long long) wt_wave_scan_i64((long long) L.tqa[s], lane);
-        const unsigned long long ib = (unsigned long long) wt_wave_scan_i64((long long) L.tqb[s], lane);
-        L.wv[s] = iv - L.tv[s];
-        L.wc[s] = ic - L.tc[s];
-        L.wqa[s] = ia - L.tqa[s];
-        L.wqb[s] = ib - L.tqb[s];
-        if (lane == 63) { d.gtv[s * nwaves + wave] = iv; d.gtc[s * nwaves + wave] = ic; d.gtqa[s * nwaves + wave] = ia; d.gtqb[s * nwaves + wave] = ib; }
-    }
+// ... of a two-sample launch: the lane's set's four totals (gt*[tid >> 6]: the wave totals; waves are whole in one set)
+WT_DEV void wt_delta_scan_w1_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLane2 &L, int tid, int nts) {
+    wt_delta_scan1_tt(P, c, d, L, tid, nts);
+    const int lane = tid & 63, wave = tid >> 6;
+    const long long iv = wt_wave_scan_i64(L.tv, lane);
+    const int32_t ic = (int32_t) wt_wave_scan_u32((unsigned) L.tc, lane);
+    const unsigned long long ia = (unsigned long long) wt_wave_scan_i64((long long) L.tqa, lane);
+    const unsigned long long ib = (unsigned long long) wt_wave_scan_i64((long long) L.tqb, lane);
+    L.wv = iv - L.tv;
+    L.wc = ic - L.tc;
+    L.wqa = ia - L.tqa;
+    L.wqb = ib - L.tqb;
+    if (lane == 63) { d.gtv[wave] = iv; d.gtc[wave] = ic; d.gtqa[wave] = ia; d.gtqb[wave] = ib; }
 }
 
 // escan on wave 0: run-count prefix of the emitted bitmap; returns the window's run count

@@ -327,10 +327,13 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
         }
         WT_MARK(105);
         if constexpr (TT) {
-            if (tid < nts) wt_delta_scan_w1_tt(P, c, d, DL2, tid, nts);
+            // the scans split by set over 2 nts lanes, then one lane per position (wt_delta.h: phases A - C)
+            if (tid < 2 * nts) wt_delta_scan_w1_tt(P, c, d, DL2, tid, nts);
             __syncthreads();
             WT_MARK(107);
-            if (tid < nts) wt_delta_scan3_tt(P, c, d, DL2, L, scale, tid, nts);
+            if (tid < 2 * nts) wt_delta_scan3_tt(P, c, d, DL2, scale, tid, nts);
+            __syncthreads();
+            wt_delta_combine_tt(P, c, d, tid, nt);
             __syncthreads();
             // a position whose variance cancels too much for the exact sums (wt_delta_scan3_tt): the window's values are the general kernel's
             if (tid == 0 && d.dsh->risk && c.sh->bad_slot < 0) wt_delta_mark_bad(P, c, k);
@@ -352,11 +355,6 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             if (tid == 0) wt_lookback_publish(P, c, k, mine);
         }
         wt_delta_nextw(P, c, tid, nt);
-        // two-sample launches: the Student tail of every emitted position, all lanes (wave 0 has published the window's run count first)
-        if constexpr (TT) {
-            wt_delta_tail_tt(P, d, tid, nt);
-            WT_TICK(2);             // (profile builds: the tail in the slot of the exponent-range pass, which only a workgroup's first window runs)
-        }
         __syncthreads();
         WT_MARK(110);
         // the look-back's round trips to the status words overlap the staging of the other waves
@@ -366,7 +364,14 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             wt_delta_note_offset(P, c, tid);                // (lane 0 set the offset in the look-back: same wave, LDS in order)
         }
         WT_TICK(6);
-        if constexpr (TT) { if (tid < nts) wt_delta_load_res_tt(P, d, L, tid); }
+        if constexpr (TT) {
+            // two-sample launches: the Student tail of every emitted position is what the look-back of wave 0 overlaps -- the other
+            // wavefronts share the window's positions (the staging needs their results: one more barrier)
+            if (tid >= 64) wt_delta_tail_tt(P, d, tid - 64, nt - 64);
+            __syncthreads();
+            WT_TICK(2);             // (profile builds: the tail, less the look-back, in the slot of the exponent-range pass)
+            if (tid < nts) wt_delta_load_res_tt(P, d, L, tid);
+        }
         if (WT_SCAN_LANE) wt_delta_stage<OP>(P, c, d, L, tid, nts);
         __syncthreads();
 #ifdef WT_PROFILE_TAIL
@@ -1508,7 +1513,9 @@ static int wt_launch_patch(wtamd_trackset *ts, int delta_W, int op, uint32_t fla
     std::string err;
     if (!wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err)) return wt_fail(WTAMD_ERR_INTERNAL, err);
     if (plan.scratch_slab > 0 || plan.W > delta_W || delta_W % plan.W != 0 || delta_W / plan.W > WT_BAD_SUB || !ts->scratch_f32 || ts->value_f64)
-        return wt_fail(WTAMD_ERR_INTERNAL, "no general plan compatible with the difference-array windows");
+        return wt_fail(WTAMD_ERR_INTERNAL, "no general plan compatible with the difference-array windows (general W " + std::to_string(plan.W) + ", difference-array W " +
+                       std::to_string(delta_W) + ", slab " + std::to_string((long long) plan.scratch_slab) + ", float staging " + std::to_string((int) ts->scratch_f32) + ", f64 values " +
+                       std::to_string((int) ts->value_f64) + ")");
     WtWindows *dw = nullptr, *w = nullptr;
     int rc = wt_get_windows(ts, delta_W, &dw, s);
     if (rc != WTAMD_OK) return rc;

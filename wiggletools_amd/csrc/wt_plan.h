@@ -125,7 +125,7 @@ static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = fa
     if (two_sets) {
         const char *e2 = getenv("WTAMD_DELTA_TT_W");    // experiments: window of the two-sample launches (1024 / 2048)
         TS = (e2 && atoi(e2) == 1024) ? 128 : 256;
-        if (T < TS) T = TS;
+        if (T < 2 * TS) T = 2 * TS;         // (the scans split by set: 2 TS lanes)
     }
     p = WtPlan();
     p.delta = true;
@@ -158,6 +158,8 @@ static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = fa
     p.lds_bytes = o;
 }
 
+static inline bool wt_defaults_fit_f32(const double *d, int n);
+
 // the difference-array plan of reducer `op` (squares for the var family, two sets for the t-test)
 static inline void wt_make_delta_plan_for(WtPlan &p, int n_tracks, int op) {
     wt_make_delta_plan(p, n_tracks, wt_op_is_var_family(op), op == WT_OP_TTEST);
@@ -170,7 +172,9 @@ static inline bool wt_delta_eligible(int op, bool value_f64, int n_tracks, const
     const bool sq = wt_op_is_var_family(op);
     if (op == WT_OP_TTEST) {
         // TTestReduction (round 6): sums and squares of the values in play per set; defaults play no part (setComparisons.c:69-81)
-        return !getenv("WTAMD_NO_DELTA_TTEST") && !value_f64 && n_tracks >= 8 && n_tracks <= 32767;
+        // (... but the general kernel that patches a window reads them into its float staging: defaults that are no floats keep
+        //  the whole reduction on the general kernel's f64 staging, wt_launch_patch)
+        return !getenv("WTAMD_NO_DELTA_TTEST") && !value_f64 && n_tracks >= 8 && n_tracks <= 32767 && wt_defaults_fit_f32(defaults, n_tracks);
     }
     if (op != WT_OP_SUM && op != WT_OP_MEAN && !sq) return false;
     if (sq && (n_tracks < 8 || getenv("WTAMD_NO_DELTA_VAR"))) return false;     // (the split square accumulators need N >= 8)
