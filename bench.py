@@ -450,6 +450,21 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None, level=1,
             if keep:
                 json.dump({"intervals": n_int, "sections": sections}, open(meta, "w"))
         size = sum(os.path.getsize(p_) for p_ in paths)
+
+        def fresh_run():
+            """`wiggletools <op> *.bw` as a process of its own (tools/cli_cold.py): nothing of this process's state helps it."""
+            import subprocess
+            try:
+                env = {k: v for k, v in os.environ.items() if not k.startswith("WTAMD_TRACE")}
+                pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_cold.py"), d, str(n_tracks), op, str(genome_bp)],
+                                    capture_output=True, text=True, timeout=600, env=env)
+                lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+                return json.loads(lines[-1]) if lines else {"error": (pr.stderr or "no output")[-300:]}
+            except Exception as e:
+                return {"error": repr(e)[:300]}
+        # the very first read of the freshly WRITTEN files (tmpfs pages read at half speed the first time: read_through below) by a
+        # fresh process -- reported beside the figures taken after the read-through, which is what round 5 on quotes as cold
+        first_touch = fresh_run() if (fresh_process and write_s > 0 and not os.environ.get("WTAMD_BENCH_NO_READ_THROUGH")) else None
         read_through_s = None
         if not os.environ.get("WTAMD_BENCH_NO_READ_THROUGH"):
             read_through_s = read_through(paths)[1]
@@ -514,18 +529,8 @@ def e2e_bigwig_genome(op, n_tracks, mean_run, scale, device, only=None, level=1,
         warm = run_once() if runs > 1 else cold
         # ... and in a FRESH process, which is what a `wiggletools mean *.bw` invocation is: nothing of this process's state
         # (runtime up, code object loaded, queues, pools) helps it (tools/cli_cold.py; the files are still in place)
-        fresh = None
-        if fresh_process:
-            import subprocess
-            try:
-                env = {k: v for k, v in os.environ.items() if not k.startswith("WTAMD_TRACE")}
-                pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_cold.py"), d, str(n_tracks), op, str(genome_bp)],
-                                    capture_output=True, text=True, timeout=600, env=env)
-                lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
-                fresh = json.loads(lines[-1]) if lines else {"error": (pr.stderr or "no output")[-300:]}
-            except Exception as e:
-                fresh = {"error": repr(e)[:300]}
-        return {"fresh_process": fresh, "files_read_through_s": read_through_s, "tracks": n_tracks, "op": op, "chromosomes_per_file": 24, "genome_scale": scale, "bp": genome_bp, "intervals": n_int, "zlib_level": level,
+        fresh = fresh_run() if fresh_process else None
+        return {"fresh_process": fresh, "fresh_process_first_touch": first_touch, "files_read_through_s": read_through_s, "tracks": n_tracks, "op": op, "chromosomes_per_file": 24, "genome_scale": scale, "bp": genome_bp, "intervals": n_int, "zlib_level": level,
                 "sections": sections, "file_bytes": size, "file_bytes_per_bp": size / genome_bp,
                 "pcie_h2d_roofline_bp_per_s": 63e9 / (size / genome_bp), "files_written_s": write_s, "generate_s": gen_s,
                 "files_dir": d.rsplit("/", 1)[0], "host_cores": effective_cores(),
@@ -1030,7 +1035,11 @@ def main():
     if world > 1 or args.force_dist:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
+            if "MASTER_PORT" not in os.environ:     # a free port (a fixed one collides between concurrent runs)
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -1094,6 +1103,8 @@ def main():
                 cfgd["e2e_files_fresh_process_bp_per_s"] = fp.get("bp_per_s")                   # first library call -> last run, new process
                 cfgd["e2e_files_fresh_process_seconds"] = fp.get("seconds")
                 cfgd["e2e_files_fresh_process_library_load_s"] = fp.get("library_load_s")       # dlopen: the HIP runtime's shared objects
+                # ... and the same before anything had read the freshly written files (the page cache's first read of 90 GB included)
+                cfgd["e2e_files_first_touch_bp_per_s"] = (g.get("fresh_process_first_touch") or {}).get("bp_per_s")
                 if g.get("error"):
                     cfgd["e2e_files_error"] = str(g.get("error"))[:110]
                 # the same pipeline on files written at zlib level 6 (libBigWig's / wigToBigWig's default; SURVEY 8d's stored

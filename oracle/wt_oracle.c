@@ -293,8 +293,11 @@ static double red_mwu(int n1, int n2, const double *v, const char *ip, const dou
         tab[i].set = (i >= n1);
     }
     vsp_sort(tab, tmp, N);
-    double mu = (double) (n1 * n2 / 2);
-    double sigma = sqrt((double) (n1 * n2 * (n1 + n2 + 1) / 12));
+    /* setComparisons.c:386-387: C int products (undefined once they overflow, ~1300 tracks per set; here they wrap as the
+     * engine's do, csrc/wt_plan.h wt_mwu_make_table) and int divisions */
+    const int n12 = (int) ((unsigned) n1 * (unsigned) n2);
+    double mu = (double) (n12 / 2);
+    double sigma = sqrt((double) ((int) ((unsigned) n12 * ((unsigned) n1 + (unsigned) n2 + 1u)) / 12));
     double U1 = 0;
     int prev = 0, ties = 0, prevTies = 0;
     for (int idx = 0; idx < N && prev < n1; idx++) {

@@ -226,6 +226,7 @@ struct EmuRun {
     template <int OP, bool DF = false>
     void run_delta() {
         constexpr bool TT = OP == WT_OP_TTEST;      // two sets per position (wt_delta_scan3_tt)
+        constexpr bool MM = OP == WT_OP_MAX || OP == WT_OP_MIN;     // range updates of a segment tree (wt_delta_apply_mm)
         constexpr bool QQ = OP == WT_OP_VAR || OP == WT_OP_STDDEV || OP == WT_OP_ENTROPY || OP == WT_OP_CV || TT;
         WtCtx c;
         wt_ctx_init(c, P, lds.data());
@@ -234,13 +235,15 @@ struct EmuRun {
         const int T = plan.T;
         std::vector<WtDeltaLane> dl(T);
         std::vector<WtDeltaLane2> dl2(T);
+        std::vector<int32_t> wc_mm(T, 0);
         int guess = 0;      // the workgroup's unit exponent (0: none yet)
         std::vector<WtLane<WT_DELTA_K>> lanes(T);
         for (;;) {
             const long long k = (long long) wt_glb_add64(&P.counters[WT_CTR_TICKET], 1ull);
             if (k >= P.n_windows) break;
             wt_phase_header(P, c, k);
-            for (int t = 0; t < T; t++) wt_delta_zero<QQ, TT>(P, c, d, t, T);
+            if constexpr (MM) { for (int t = 0; t < T; t++) wt_delta_zero_mm<OP == WT_OP_MAX>(P, c, d, t, T); }
+            else for (int t = 0; t < T; t++) wt_delta_zero<QQ, TT>(P, c, d, t, T);
             const int nchunks = (P.n_tracks + T - 1) / T;
             auto ranges = [&](int ch) {
                 for (int t = 0; t < T; t++) wt_delta_ranges1(P, c, d, ch * T, t, T);
@@ -248,7 +251,13 @@ struct EmuRun {
                 for (int t = 0; t < T; t++) wt_delta_ranges3(P, c, d, t, T);
             };
             int scale = 1;
-            if (guess == 0) {       // no unit exponent known yet: range pass, then the delta pass
+            if constexpr (MM) {
+                for (int ch = 0; ch < nchunks; ch++) {
+                    ranges(ch);
+                    for (int t = 0; t < T; t++) wt_delta_pass_mm<OP == WT_OP_MAX>(P, c, d, t, T);
+                }
+                if (d.dsh->bad) wt_delta_mark_bad(P, c, k);
+            } else if (guess == 0) {       // no unit exponent known yet: range pass, then the delta pass
                 for (int ch = 0; ch < nchunks; ch++) {
                     ranges(ch);
                     for (int t = 0; t < T; t++) wt_delta_pass1(P, c, d, t, T);
@@ -291,6 +300,10 @@ struct EmuRun {
                 for (int t = 0; t < T; t++) wt_delta_combine_tt(P, c, d, t, T);
                 for (int t = 0; t < T; t++) wt_delta_tail_tt(P, d, t, T);
                 if (d.dsh->risk && c.sh->bad_slot < 0) wt_delta_mark_bad(P, c, k);
+            } else if constexpr (MM) {
+                for (int t = 0; t < TS; t++) wt_delta_scan1_mm(P, c, d, wc_mm[t], t, TS);
+                for (int t = 0; t < TS; t++) wt_delta_scan2_mm(P, c, d, t, TS);
+                for (int t = 0; t < TS; t++) wt_delta_scan3_mm<OP == WT_OP_MAX>(P, c, d, 0, lanes[t], t, TS);
             } else {
                 for (int t = 0; t < TS; t++) wt_delta_scan1<QQ>(P, c, d, dl[t], t, TS);
                 for (int t = 0; t < TS; t++) wt_delta_scan2<QQ>(P, c, d, t, TS);
@@ -371,8 +384,7 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
         wt_plan_to_params(R.plan, P);
         std::vector<double> mwu_table;
         if (op == WT_OP_MWU && !getenv("WTAMD_MWU_DEVICE_ERF")) {
-            wt_mwu_make_table(n_set0, n_tracks - n_set0, mwu_table);
-            P.mwu_table = mwu_table.data(); P.mwu_kmax = (int) mwu_table.size() - 1;
+            if (wt_mwu_make_table(n_set0, n_tracks - n_set0, mwu_table)) { P.mwu_table = mwu_table.data(); P.mwu_kmax = (int) mwu_table.size() - 1; }
         }
         if (delta) { P.bad_list = bad_list.data(); P.bad_goff = bad_goff.data(); wt_delta_defaults_params(defaults, n_tracks, P); }
         // few inexact windows: the general kernel rewrites the values of just those (the engine's
@@ -417,6 +429,8 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
                 case WT_OP_VAR: R.run_delta<WT_OP_VAR>(); break;
                 case WT_OP_CV: R.run_delta<WT_OP_CV>(); break;
                 case WT_OP_TTEST: R.run_delta<WT_OP_TTEST>(); break;
+                case WT_OP_MAX: R.run_delta<WT_OP_MAX>(); break;
+                case WT_OP_MIN: R.run_delta<WT_OP_MIN>(); break;
                 default: R.run_delta<WT_OP_STDDEV>(); break;
                 }
             } else if (R.plan.walk_S && R.plan.walk_mwu) {

@@ -482,9 +482,12 @@ def test_emu_edge_very_many_tracks_small_workgroup(oracle):
     got, info = emu.reduce(t, "sum", delta_T=64)
     assert info["delta"] == 1
     assert_runs_equal(got, oracle.reduce(d, "sum"), 0.0, "delta 2000 tracks")
-    got, info = emu.reduce(t, "max", ppt=4, T=64)
+    got, info = emu.reduce(t, "product", ppt=4, T=64)
     assert info["n_chunks"] > 1
-    assert_runs_equal(got, oracle.reduce(d, "max"), 0.0, "general 2000 tracks")
+    assert_runs_equal(got, oracle.reduce(d, "product"), 0.0, "general 2000 tracks")
+    got, info = emu.reduce(t, "max", delta_T=64)            # (round 6: max / min ride the difference-array kernel's passes)
+    assert info["delta"] == 1
+    assert_runs_equal(got, oracle.reduce(d, "max"), 0.0, "segment tree, 2000 tracks")
 
 
 def test_emu_edge_data_only_in_late_tracks_and_late_chromosomes(oracle):
@@ -552,7 +555,9 @@ def test_plan_policy_snapshot():
     p = plan(100, "mean")
     assert (p["delta"], p["W"], p["T"]) == (1, 8192, 1024)               # difference-array kernel (round 3: 1024 lanes, 8192-bp windows)
     p = plan(100, "max")
-    assert (p["W"], p["T"], p["n_chunks"]) == (2048, 512, 1)             # bitmaps of 100 tracks: half the LDS
+    assert (p["delta"], p["W"], p["T"]) == (1, 8192, 1024)               # round 6: max / min by range updates of a segment tree in the difference-array kernel
+    p = plan(100, "product")
+    assert (p["W"], p["T"], p["n_chunks"]) == (2048, 512, 1)             # general kernel: bitmaps of 100 tracks: half the LDS
     p = plan(500, "var")
     assert (p["delta"], p["W"], p["T"]) == (1, 4096, 768)                # difference arrays with exact squares: 4096-bp windows; round 5: 768 lanes for the passes (168 registers each), the first 512 run the scans
     assert p["lds"] <= 160 * 1024
@@ -860,3 +865,48 @@ def test_emu_delta_ttest_not_used_when_ineligible(oracle):
     got, info = emu.reduce(t9, "ttest", n_set0=14)
     assert info["delta"] == 1, info
     assert_runs_equal(got, oracle.reduce(t9.as_dict(), "ttest", n_set0=14), 0.0, "defaults ignored")
+
+
+# ---- MaxReduction / MinReduction by range updates of a segment tree (round 6: wt_delta.h, wt_delta_apply_mm) ----
+@pytest.mark.parametrize("seed", range(12))
+def test_emu_delta_min_max(oracle, seed):
+    """Float tracks with zero defaults: a run is a range update (atomic max / min of order-preserving keys on its canonical nodes of
+    the window's segment tree), a position's value the max over its ancestors, `max(.., 0)` where a track is not in play
+    (reducers.c:125-168, 192-235).  Bit for bit: negative values, all tracks in play or not, runs of one position and runs longer than
+    a window, strict and not, more tracks than lanes."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([4, 9, 33, 100, 300, 1500]))
+    t = synth(n, [int(rng.integers(200, 30000)), 300], mean_run=float(rng.choice([1, 3, 16, 60, 5000, 20000])), seed=seed,
+              gap_prob=float(rng.choice([0, 0.05, 0.5])), dtype=np.float32, value_levels=int(rng.choice([2, 800])))
+    t.value[:] = ((t.value - rng.choice([0, 3, 50])) * rng.choice([1.0, 1e-3, 7.7], len(t.value))).astype(np.float32)
+    t.value[t.value == 0] = 0.0         # (no -0.0: that is the next test's subject)
+    d = t.as_dict()
+    for op in ("max", "min"):
+        for flags in (0, 1):
+            got, info = emu.reduce(t, op, flags=flags, delta_T=int(rng.choice([64, 256, 1024])))
+            assert info["delta"] == 1 and info["delta_bad"] == 0, info
+            assert_runs_equal(got, oracle.reduce(d, op, flags=flags), 0.0, "%s seed %d flags %d %s" % (op, seed, flags, info))
+
+
+def test_emu_delta_min_max_patched_and_ineligible(oracle):
+    """A NaN (the reference answers NaN) or a -0.0 (the one value whose outcome depends on the reference's track order) sends its window to
+    the general kernel; Inf is an ordinary value; non-zero defaults and float64 values keep the whole reduction on the general kernel."""
+    t = synth(12, [400000], mean_run=9, seed=5, dtype=np.float32)      # 49 windows of 8192 bp
+    v = t.value
+    v[100] = np.nan
+    v[len(v) // 2] = np.inf
+    v[len(v) // 3] = -np.inf
+    v[len(v) // 4] = -0.0
+    d = t.as_dict()
+    for op in ("max", "min"):
+        got, info = emu.reduce(t, op)
+        assert info["delta"] == 1 and 2 <= info["delta_bad"] <= 8 and info["patched"] == info["delta_bad"], info
+        exp = oracle.reduce(d, op)
+        assert_runs_equal(got, exp, 0.0, op)
+        assert np.isnan(exp[3]).any() and np.isinf(exp[3]).any()
+        assert np.array_equal(np.signbit(got[3]), np.signbit(exp[3]))       # ... the sign of every zero included
+    t9 = synth(9, [3000], mean_run=5, seed=1, dtype=np.float32)
+    t9.defaults[2] = 1.0
+    assert emu.reduce(t9, "max")[1]["delta"] == 0
+    t64 = synth(9, [3000], mean_run=5, seed=1, dtype=np.float64)
+    assert emu.reduce(t64, "min")[1]["delta"] == 0

@@ -123,6 +123,9 @@ def test_gpu_plans_agree_bitwise_at_scale(op, kw, monkeypatch):
     stream = torch.cuda.current_stream().cuda_stream
     plans = [{}, {"WTAMD_CHUNK": "37"}]
     plans.append({"WTAMD_T": "64"} if op in ("median", "mwu") else {"WTAMD_PPT": "1", "WTAMD_T": "256"})
+    if op == "max":
+        # round 6: Max / Min default to the difference-array kernel's segment tree; the general kernel's plans with it switched off
+        plans = [dict(p, WTAMD_NO_DELTA_MINMAX="1") for p in plans] + [{}]
     if op == "ttest":
         # round 6: TTestReduction's default is the difference-array kernel (exact integer sums per set); the plans of the general
         # kernel with it switched off -- and the default beside them: the generator's k/8 values make every route's sums exact,
@@ -130,15 +133,15 @@ def test_gpu_plans_agree_bitwise_at_scale(op, kw, monkeypatch):
         plans = [dict(p, WTAMD_NO_DELTA_TTEST="1") for p in plans] + [{}]
     ref = None
     for env in plans:
-        for k in ("WTAMD_CHUNK", "WTAMD_PPT", "WTAMD_T", "WTAMD_NO_DELTA_TTEST"):
+        for k in ("WTAMD_CHUNK", "WTAMD_PPT", "WTAMD_T", "WTAMD_NO_DELTA_TTEST", "WTAMD_NO_DELTA_MINMAX"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ts = engine.TrackSet.from_device(len(chrom_lens), N, seg_off, start, finish, value, np.zeros(N))
         out = ts.alloc_runs()
         n = ts.reduce(op, out, stream=stream, sync=True, **kw)
-        if op == "ttest":
-            assert ts.stats()["kernel"] == (0 if "WTAMD_NO_DELTA_TTEST" in env else 1), (env, ts.stats())
+        if op in ("ttest", "max"):
+            assert ts.stats()["kernel"] == (0 if ("WTAMD_NO_DELTA_TTEST" in env or "WTAMD_NO_DELTA_MINMAX" in env) else 1), (env, ts.stats())
         ts.close()
         got = (n, out.start[:n].clone(), out.finish[:n].clone(), out.value[:n].view(torch.int64).clone())
         del out

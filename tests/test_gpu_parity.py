@@ -515,6 +515,40 @@ def test_gpu_difference_array_ttest_vs_general_kernel(oracle, engine, monkeypatc
     ts.close(); ts2.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_gpu_difference_array_min_max(oracle, engine, seed):
+    """MaxReduction / MinReduction by range updates of a segment tree (round 6: wt_delta_kernel<max | min>, wt_delta_apply_mm) against the
+    oracle, bit for bit: negative values, full mantissas, runs from one position to longer than a window, strict and not, more tracks
+    than lanes; a NaN / a -0.0 in a window: that window comes from the general kernel (wt_patch_kernel), signs of zeros included."""
+    from wiggletools_amd.runlists import synth
+    rng = np.random.default_rng(9100 + seed)
+    n = int(rng.choice([4, 9, 33, 100, 300, 1500]))
+    t = synth(n, [int(rng.integers(3000, 90000)), 900], mean_run=float(rng.choice([1, 3, 16, 60, 5000, 20000])), seed=seed,
+              gap_prob=float(rng.choice([0, 0.05, 0.5])), dtype=np.float32, value_levels=int(rng.choice([2, 800])))
+    t.value[:] = ((t.value - rng.choice([0, 3, 50])) * rng.choice([1.0, 1e-3, 7.7], len(t.value))).astype(np.float32)
+    t.value[t.value == 0] = 0.0
+    if seed % 4 == 1:
+        t = synth(40, [600000, 900], mean_run=16.0, seed=seed, gap_prob=0.05, dtype=np.float32, value_levels=800)     # 74 windows: a few bad ones are patched
+        t.value[:] = (t.value - 40).astype(np.float32)
+        t.value[7] = np.nan
+        t.value[len(t.value) // 2] = np.inf
+        t.value[len(t.value) // 3] = -0.0
+    d = t.as_dict()
+    ts = engine.TrackSet.from_runlists(t)
+    for op in ("max", "min"):
+        for flags in (0, 1):
+            got = ts.reduce_host(op, flags=flags)
+            st = ts.stats()
+            assert st["kernel"] == 1 and st["window_bp"] == 8192, st
+            if seed % 4 == 1:
+                assert st["patched_windows"] > 0, st
+            exp = oracle.reduce(d, op, flags=flags)
+            assert_runs_equal(got, exp, 0.0, "%s seed %d flags %d %s" % (op, seed, flags, st))
+            assert np.array_equal(np.signbit(got[3]), np.signbit(exp[3]))
+    ts.close()
+
+
 def test_gpu_input_contract_validation(engine):
     """wtamd_trackset_validate: zero-length, inverted and overlapping runs are counted; a run list
     may start a new (chrom, track) segment below the previous segment's last finish."""

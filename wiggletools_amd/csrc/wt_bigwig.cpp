@@ -292,15 +292,27 @@ static int bw_thread_count() {
     return n;
 }
 
+// The helper thread (a multi-threaded host: the kernel's grace period, 140-180 ms, is kept off the caller's clock) is JOINED when the
+// library is unloaded or the process exits -- detached, it could still be inside this library's code after a dlclose (the
+// advisor's finding, round 5).  Load-time side effects of the library: INTEGRATION.md 5.
+static std::mutex g_fd_mu;
+static std::thread *g_fd_thread = nullptr;
+
 static void bw_grow_fd_table(bool at_load) {
     if (getenv("WTAMD_NO_FD_GROW")) return;
     int expect = 0;
     if (!g_fd_grown.compare_exchange_strong(expect, 1)) return;
     if (at_load && bw_thread_count() == 1) { bw_grow_fd_table_now(); return; }     // no other thread: no grace period
-    std::thread(bw_grow_fd_table_now).detach();
+    std::lock_guard<std::mutex> lk(g_fd_mu);
+    g_fd_thread = new std::thread(bw_grow_fd_table_now);
 }
 
 __attribute__((constructor)) static void bw_library_loaded() { bw_grow_fd_table(true); }
+__attribute__((destructor)) static void bw_library_unloaded() {
+    std::thread *t = nullptr;
+    { std::lock_guard<std::mutex> lk(g_fd_mu); t = g_fd_thread; g_fd_thread = nullptr; }
+    if (t) { if (t->joinable()) t->join(); delete t; }
+}
 
 int wtamd_bw_open(const char *path, wtamd_bw **out) {
     if (!path || !out) return WTAMD_ERR_ARG;

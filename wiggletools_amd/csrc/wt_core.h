@@ -200,6 +200,8 @@ WT_DEV void wt_lds_xor64(uint64_t *p, uint64_t v) { *p ^= v; }
 WT_DEV void wt_lds_or32(uint32_t *p, uint32_t v) { *p |= v; }
 WT_DEV void wt_lds_and32(uint32_t *p, uint32_t v) { *p &= v; }
 WT_DEV void wt_lds_min32(int32_t *p, int32_t v) { if (v < *p) *p = v; }
+WT_DEV void wt_lds_umax32(uint32_t *p, uint32_t v) { if (v > *p) *p = v; }
+WT_DEV void wt_lds_umin32(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
 WT_DEV void wt_lds_add64(unsigned long long *p, unsigned long long v) { *p += v; }
 WT_DEV void wt_lds_sub64(unsigned long long *p, unsigned long long v) { *p -= v; }
 WT_DEV int32_t wt_uniform32(int32_t x) { return x; }
@@ -232,6 +234,8 @@ WT_DEV void wt_lds_xor64(uint64_t *p, uint64_t v) { atomicXor((unsigned long lon
 WT_DEV void wt_lds_or32(uint32_t *p, uint32_t v) { atomicOr((unsigned int *) p, (unsigned int) v); }
 WT_DEV void wt_lds_and32(uint32_t *p, uint32_t v) { atomicAnd((unsigned int *) p, (unsigned int) v); }
 WT_DEV void wt_lds_min32(int32_t *p, int32_t v) { atomicMin(p, v); }
+WT_DEV void wt_lds_umax32(uint32_t *p, uint32_t v) { atomicMax((unsigned int *) p, (unsigned int) v); }
+WT_DEV void wt_lds_umin32(uint32_t *p, uint32_t v) { atomicMin((unsigned int *) p, (unsigned int) v); }
 WT_DEV void wt_lds_add64(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
 WT_DEV void wt_lds_sub64(unsigned long long *p, unsigned long long v) {      // ds_sub_u64: no negation in registers
     __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1456,8 +1460,10 @@ WT_DEV void wt_mwu_rank(const WtParams &P, char *scratch, char *attr_base, int c
 WT_DEV double wt_mwu_tail(const WtParams &P, char *attr_base, int col, int colstride) {
     const int na = P.n_set0, nb = P.n_tracks - P.n_set0;
     const uint32_t *attr = (const uint32_t *) attr_base + col;
-    const double mu = (double) (na * nb / 2);                               // :386 int division
-    const double sigma = sqrt((double) (na * nb * (na + nb + 1) / 12));     // :387 int division
+    // (:386-387: C int products and divisions; wrapping like wt_mwu_make_table's)
+    const int nab = (int) ((unsigned) na * (unsigned) nb);
+    const double mu = (double) (nab / 2);
+    const double sigma = sqrt((double) ((int) ((unsigned) nab * ((unsigned) na + (unsigned) nb + 1u)) / 12));
     double U1 = 0;
     int ties = 0, prevTies = 0;
     for (int q = 0; q < na; q++) {

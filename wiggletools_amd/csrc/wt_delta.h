@@ -767,6 +767,163 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
     ((uint8_t *) c.E)[tid] = (uint8_t) em;
 }
 
+// ---- MaxReduction / MinReduction over float tracks with zero defaults (round 6): a segment tree of range updates ----
+// Reference reducers.c:125-168 / 192-235: the largest (smallest) of every track's value -- or, for a track not in play, its default (0 for
+// track 0 whatever its default: the seed) -- NaN if any of them is NaN.  The general kernel gathers all N tracks at every run start (VALU
+// bound, 0.15 of the HBM roofline).  With all defaults 0 the answer at position p is
+//     max(v of the runs covering p)            if every track is in play there (coverage == N),
+//     max(that, 0)                             otherwise,
+// and "the runs covering p" is a RANGE UPDATE per run: the window's positions are the leaves of a segment tree (2 W u32 nodes where
+// Sum / Mean keep their W 64-bit accumulators: the same 64 KB), a run [l, r) takes atomic max on its <= 2 log2(r - l) canonical nodes
+// (order-preserving keys of the float bits, wt_key32), and a position's value is the max over its log2(W) + 1 ancestors -- read by the scan,
+// 25 LDS reads for a lane's 8 positions (the levels above the lane's 8 leaves are common to them).  O(runs x log(run length)) instead of
+// O(tracks x positions); max is idempotent and order-free, so the result is the reference's bit for bit: a float widened to double is
+// exact, and the one place where the reference's order shows -- which of -0.0 and +0.0 it keeps -- is kept out: a window holding a NaN
+// (the reference answers NaN there) or a -0.0 is recorded (wt_delta_mark_bad) and redone by the general kernel, like a window
+// Sum / Mean cannot prove exact.  Breakpoints, coverage, emitted runs: the ev[] counters of Sum / Mean, unchanged.
+template <bool ISMAX>
+WT_DEV void wt_delta_tree_update(uint32_t *tree, uint32_t W, uint32_t l, uint32_t r, uint32_t key) {
+    for (l += W, r += W; l < r; l >>= 1, r >>= 1) {
+        if (l & 1u) { if (ISMAX) wt_lds_umax32(&tree[l], key); else wt_lds_umin32(&tree[l], key); l++; }
+        if (r & 1u) { --r; if (ISMAX) wt_lds_umax32(&tree[r], key); else wt_lds_umin32(&tree[r], key); }
+    }
+}
+
+template <bool ISMAX>
+WT_DEV void wt_delta_zero_mm(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+    uint32_t *tree = (uint32_t *) d.acc;
+    const uint32_t none = ISMAX ? 0u : 0xffffffffu;         // below / above every key
+    for (int x = tid; x < 2 * P.W; x += nt) tree[x] = none;
+    for (int x = tid; x < P.W; x += nt) d.ev[x] = 0;
+    if (tid == 0) { d.dsh->base_v = 0; d.dsh->base_c = 0; d.dsh->emin = 255; d.dsh->emax = 0; d.dsh->bad = 0; }
+}
+
+// one run: the coverage / breakpoint counters exactly as wt_delta_apply keeps them, and the range update
+template <bool ISMAX>
+WT_DEV void wt_delta_apply_mm(WtDeltaCtx &d, WtCtx &c, int32_t w0, uint32_t width, int32_t s, int32_t f, uint32_t vb, int32_t &my_next, bool &bad) {
+    bad |= (vb & 0x7fffffffu) > 0x7f800000u || vb == 0x80000000u;       // NaN, -0.0
+    const uint32_t key = wt_key32(__builtin_bit_cast(float, vb));
+    const uint32_t cs = (uint32_t) (s - w0), cf = (uint32_t) (f - w0);
+    uint32_t l, r;
+    if (cs < width && cf < width) {             // the common case: the run lies inside the window
+        wt_lds_add32(&d.ev[cs], 1u);
+        wt_lds_add32(&d.ev[cf], 0x10000u);
+        l = cs; r = cf;
+    } else {
+        const int32_t w1 = w0 + (int32_t) width;
+        if (f == w0) { wt_lds_add32(&d.ev[0], 0x00010001u); return; }    // true breakpoint at w0, covers nothing here
+        if (s >= w1) { my_next = s < my_next ? s : my_next; return; }
+        if (s < w0) { wt_lds_addi32(&d.dsh->base_c, 1); l = 0u; }        // spans w0: part of the window's base coverage, not a breakpoint
+        else { wt_lds_add32(&d.ev[cs], 1u); l = cs; }
+        if (f < w1) { wt_lds_add32(&d.ev[cf], 0x10000u); r = cf; }
+        else { my_next = f < my_next ? f : my_next; r = width; }
+    }
+    wt_delta_tree_update<ISMAX>((uint32_t *) d.acc, width, l, r, key);
+}
+
+// the pass over the window's runs (the flat index space and the tile pipeline of wt_delta_pass2)
+template <bool ISMAX>
+WT_DEV void wt_delta_pass_mm(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+    const int wave = wt_uniform32(tid >> 6), lane = tid & 63, nwaves = nt >> 6;
+    const uint32_t M = (uint32_t) wt_uniform32((int32_t) d.tpfx[nt]);
+    const int32_t w0 = wt_uniform32(c.sh->w0);
+    const uint32_t width = (uint32_t) (wt_uniform32(c.sh->w1) - w0);
+    const uint32_t step = (uint32_t) nwaves * WT_DELTA_TILE;
+    int32_t my_next = 0x7fffffff;
+    bool bad = false;
+    uint32_t tb = (uint32_t) wave * WT_DELTA_TILE;
+    if (tb < M) {
+        WtDeltaBatch<false> A, B;
+        auto apply = [&](const WtDeltaBatch<false> &T, uint32_t at) {
+            if (at + WT_DELTA_TILE <= M) {
+#pragma unroll
+                for (int u = 0; u < WT_DELTA_U; u++) wt_delta_apply_mm<ISMAX>(d, c, w0, width, T.s[u], T.f[u], T.b[u], my_next, bad);
+            } else {
+#pragma unroll
+                for (int u = 0; u < WT_DELTA_U; u++)
+                    if (at + (uint32_t) lane + 64u * (uint32_t) u < M) wt_delta_apply_mm<ISMAX>(d, c, w0, width, T.s[u], T.f[u], T.b[u], my_next, bad);
+            }
+        };
+        wt_delta_fetch<false>(P, d, nt, M, tb, lane, A);
+        for (;;) {
+            wt_delta_fetch<false>(P, d, nt, M, tb + step, lane, B);    // (past the end: harmless re-reads of the last tile)
+            apply(A, tb);
+            tb += step;
+            if (tb >= M) break;
+            wt_delta_fetch<false>(P, d, nt, M, tb + step, lane, A);
+            apply(B, tb);
+            tb += step;
+            if (tb >= M) break;
+        }
+    }
+    my_next = wt_wave_min_i32(my_next);
+    if (my_next != 0x7fffffff && wt_wave_leader(lane)) wt_lds_min32(&c.sh->next_bp, my_next);
+    if (wt_delta_ballot(bad) != 0ull && wt_wave_leader(lane)) wt_lds_max32(&d.dsh->bad, 1);
+    if (tid == 0 && M) wt_lds_add64(&c.sh->n_intervals, (unsigned long long) M);
+}
+
+// scan step 1: the lane's coverage total (the values need no prefix)
+WT_DEV void wt_delta_scan1_mm(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t &tc, int tid, int nt) {
+    const int p0 = tid * WT_DELTA_K;
+    int32_t rc = 0;
+#pragma unroll
+    for (int k = 0; k < WT_DELTA_K; k++) {
+        const uint32_t e = d.ev[p0 + k];
+        rc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
+    }
+    tc = rc;
+    d.ltc[tid] = rc;
+}
+WT_DEV void wt_delta_scan2_mm(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {     // (emulator: group totals)
+    const int ngroups = nt / WT_DELTA_GROUP;
+    if (tid >= ngroups) return;
+    int32_t sc = 0;
+    for (int x = 0; x < WT_DELTA_GROUP; x++) sc += d.ltc[tid * WT_DELTA_GROUP + x];
+    d.gtc[tid] = sc;
+}
+
+// scan step 3: coverage at every position, breakpoint and emitted bytes, and the run values from the tree
+// (`wc`: device -- the coverage deltas of the wave's lanes before this one)
+template <bool ISMAX>
+WT_DEV void wt_delta_scan3_mm(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t wc, WtLane<WT_DELTA_K> &out, int tid, int nt) {
+    int32_t bc = d.dsh->base_c;
+#ifdef WT_EMU
+    const int grp = tid / WT_DELTA_GROUP;
+    for (int x = 0; x < grp; x++) bc += d.gtc[x];
+    for (int x = grp * WT_DELTA_GROUP; x < tid; x++) bc += d.ltc[x];
+#else
+    for (int x = 0; x < (tid >> 6); x++) bc += d.gtc[x];
+    bc += wc;
+#endif
+    const int N = P.n_tracks;
+    const bool strict = (P.flags & WT_STRICT_SET0) != 0;
+    const int p0 = tid * WT_DELTA_K;
+    const long long room = (long long) c.sh->emit_hi - ((long long) c.sh->w0 + p0);
+    const uint32_t *tree = (const uint32_t *) d.acc;
+    const uint32_t W = (uint32_t) P.W;
+    auto best = [](uint32_t a, uint32_t b) { return ISMAX ? (a > b ? a : b) : (a < b ? a : b); };
+    // the ancestors above the lane's 8 leaves are the same for all of them: node (p0 + W) >> 3 and up
+    uint32_t top = ISMAX ? 0u : 0xffffffffu;
+    for (uint32_t n = ((uint32_t) p0 + W) >> 3; n >= 1u; n >>= 1) top = best(top, tree[n]);
+    uint32_t em = 0, evmask = 0;
+#pragma unroll
+    for (int k = 0; k < WT_DELTA_K; k++) {
+        const uint32_t e = d.ev[p0 + k];
+        bc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
+        evmask |= (e != 0u ? 1u : 0u) << k;
+        const bool pred = strict ? (bc == N) : (bc > 0);            // multiplexer.c:120,125
+        if (e != 0u && pred && k < room) em |= 1u << k;
+        const uint32_t leaf = (uint32_t) (p0 + k) + W;
+        const uint32_t key = best(best(tree[leaf], tree[leaf >> 1]), best(tree[leaf >> 2], top));
+        double v = (double) wt_unkey32(key);
+        // a track that is not in play enters with its default, 0 (reducers.c:141-152; track 0: the seed, :143-146)
+        if (bc < N) v = ISMAX ? (v < 0.0 ? 0.0 : v) : (v > 0.0 ? 0.0 : v);
+        out.res[k] = v;
+    }
+    ((uint8_t *) c.U)[tid] = (uint8_t) evmask;
+    ((uint8_t *) c.E)[tid] = (uint8_t) em;
+}
+
 // ---- two-sample launches: TTestReduction by difference arrays (round 6) ----
 // Reference setComparisons.c:35-121: at every run where BOTH sets have a track in play (:48-54), per set the sum and the sum of
 // squares of the values IN PLAY (:69-81; defaults play no part) and the set's size as the count (:66-67), then Welch's t, its
@@ -1070,6 +1227,16 @@ WT_DEV void wt_delta_scan_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDelta
         L.wqb = ib - rb;
         if (lane == 63) { d.gtqa[tid >> 6] = ia; d.gtqb[tid >> 6] = ib; }
     }
+}
+
+// ... of a min / max launch: coverage only
+WT_DEV void wt_delta_scan_w1_mm(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t &wc, int tid, int nt) {
+    int32_t tc;
+    wt_delta_scan1_mm(P, c, d, tc, tid, nt);
+    const int lane = tid & 63;
+    const int32_t ic = (int32_t) wt_wave_scan_u32((unsigned) tc, lane);
+    wc = ic - tc;
+    if (lane == 63) d.gtc[tid >> 6] = ic;
 }
 
 // ... of a two-sample launch: the lane's set's four totals (gt*[tid >> 6]: the wave totals; waves are whole in one set)

@@ -222,6 +222,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
     wt_delta_ctx_init(d, P, wt_lds);
     constexpr bool QQ = WT_DELTA_SQ(OP);
     constexpr bool TT = OP == WT_OP_TTEST;      // two sets per position (wt_delta_scan3_tt)
+    constexpr bool MM = OP == WT_OP_MAX || OP == WT_OP_MIN;     // range updates of a segment tree (wt_delta_apply_mm)
     WtDeltaLane DL;
     WtDeltaLane2 DL2;
     (void) DL; (void) DL2;
@@ -253,11 +254,25 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
         if (k >= P.n_windows) break;
         const int nchunks = (P.n_tracks + nt - 1) / nt;
         auto ntr = [&](int ch) { const int r = P.n_tracks - ch * nt; return r < nt ? r : nt; };     // tracks of chunk ch
-        wt_delta_zero<QQ, TT>(P, c, d, tid, nt);
+        if constexpr (MM) wt_delta_zero_mm<OP == WT_OP_MAX>(P, c, d, tid, nt);
+        else wt_delta_zero<QQ, TT>(P, c, d, tid, nt);
         WT_TICK(0);
         WT_MARK(102);
         int scale = 1;
-        if (guess == 0) {
+        if constexpr (MM) {
+            // one pass, no unit exponent: a float's order-preserving key needs none
+            for (int ch = 0; ch < nchunks; ch++) {
+                wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
+                __syncthreads();
+                wt_delta_ranges_w2(P, c, d, tid, nt);
+                __syncthreads();
+                WT_TICK(1);
+                wt_delta_pass_mm<OP == WT_OP_MAX>(P, c, d, tid, nt);
+                __syncthreads();
+                WT_TICK(3);
+            }
+            if (tid == 0 && d.dsh->bad) wt_delta_mark_bad(P, c, k);     // a NaN or a -0.0: the general kernel's window
+        } else if (guess == 0) {
             // no unit exponent known to this workgroup yet: exponent-range pass, then the delta pass
             for (int ch = 0; ch < nchunks; ch++) {
                 wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
@@ -337,6 +352,13 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             __syncthreads();
             // a position whose variance cancels too much for the exact sums (wt_delta_scan3_tt): the window's values are the general kernel's
             if (tid == 0 && d.dsh->risk && c.sh->bad_slot < 0) wt_delta_mark_bad(P, c, k);
+        } else if constexpr (MM) {
+            int32_t wc_mm = 0;
+            wt_delta_scan_w1_mm(P, c, d, wc_mm, tid, nt);
+            __syncthreads();
+            WT_MARK(107);
+            wt_delta_scan3_mm<OP == WT_OP_MAX>(P, c, d, wc_mm, L, tid, nt);
+            __syncthreads();
         } else {
             if (WT_SCAN_LANE) wt_delta_scan_w1<QQ>(P, c, d, DL, tid, nts);
             __syncthreads();
@@ -933,6 +955,7 @@ struct wtamd_trackset {
     size_t gscratch_bytes = 0;
     double *d_mwu_table = nullptr;              // MWUReduction's last step as a table (wt_mwu_make_table), for set sizes mwu_n1 / mwu_n2
     int mwu_n1 = -1, mwu_n2 = -1, mwu_kmax = 0;
+    std::vector<double *> mwu_retired;          // tables of earlier set sizes (freed with the track set)
     std::map<int, WtWindows> windows;           // keyed by W
     hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
     bool have_index_time = false, have_reduce_time = false;
@@ -943,9 +966,10 @@ struct wtamd_trackset {
     // Sum / Mean over float tracks: what a completed difference-array launch found out about this data
     // the difference-array launches' verdict on this data, per class of reducer -- [0] Sum / Mean / the var family (exponent range
     // of a window), [1] TTestReduction (its own, narrower windows, and positions whose variance cancels: wt_delta_scan3_tt)
-    bool delta_failed_[2] = {false, false};     // many windows are not provably exact: the class uses the general kernel
-    bool delta_verified_[2] = {false, false};   // verdict known: delta_n_bad windows (few) get patched by the general kernel
-    long long delta_n_bad_[2] = {0, 0};
+    // [2] Max / Min (only a NaN or a -0.0 sends a window to the general kernel)
+    bool delta_failed_[3] = {false, false, false};      // many windows are not provably exact: the class uses the general kernel
+    bool delta_verified_[3] = {false, false, false};    // verdict known: delta_n_bad windows (few) get patched by the general kernel
+    long long delta_n_bad_[3] = {0, 0, 0};
     // pipeline slot (wt_pipe.h): the run lists are rebound per batch, device tables are reused,
     // every upload is asynchronous on the launch stream from pinned staging
     bool pipe_mode = false;
@@ -1000,13 +1024,23 @@ static void wt_warmup_join() {
     if (t) { t->join(); delete t; }
 }
 
+// The helper is a new thread: HIP's current device is per thread, so it is told which device to warm -- the one the caller
+// selected (wtamd_set_device, or the calling thread's current device when that was set through the runtime, e.g. by
+// torch.cuda.set_device in a one-process-per-GPU job).  With several devices visible and none selected the warm-up is skipped:
+// a context on GPU 0 from every rank would help nobody.
+static std::atomic<int> g_device_chosen{-1};
+
 void wtamd_warmup_async(void) {
     std::lock_guard<std::mutex> lk(g_warm_mu);
     if (g_warm_started || getenv("WTAMD_NO_WARMUP")) return;
+    int n = 0, cur = -1;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void) hipGetLastError(); return; }
+    int ordinal = g_device_chosen.load();
+    if (ordinal < 0 && hipGetDevice(&cur) == hipSuccess && (n == 1 || cur > 0)) ordinal = cur;     // (cur == 0 of several: nobody chose yet)
+    if (ordinal < 0 || ordinal >= n) return;                    // (not started: a later call, after wtamd_set_device, may)
     g_warm_started = true;
-    g_warm_thread = new std::thread([] {
-        int n = 0;
-        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void) hipGetLastError(); return; }
+    g_warm_thread = new std::thread([ordinal] {
+        if (hipSetDevice(ordinal) != hipSuccess) { (void) hipGetLastError(); return; }
         hipStream_t st[3] = {nullptr, nullptr, nullptr};
         for (auto &s : st)
             if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
@@ -1020,7 +1054,9 @@ void wtamd_warmup_async(void) {
 }
 
 int wtamd_set_device(int ordinal) {
+    wt_warmup_join();               // (a helper still warming another device finishes first)
     WT_HIP(hipSetDevice(ordinal));
+    g_device_chosen.store(ordinal);
     return WTAMD_OK;
 }
 
@@ -1161,6 +1197,7 @@ void wtamd_trackset_destroy(wtamd_trackset *ts) {
     if (!ts) return;
     if (ts->owns) { (void) hipFree(ts->d_start); (void) hipFree(ts->d_finish); (void) hipFree(ts->d_value); }
     (void) hipFree(ts->d_seg_off); (void) hipFree(ts->d_defaults); (void) hipFree(ts->d_counters); (void) hipFree(ts->d_chrom_run_off); (void) hipFree(ts->d_gscratch); (void) hipFree(ts->d_mwu_table);
+    for (double *q : ts->mwu_retired) (void) hipFree(q);
     if (ts->h_counters) (void) hipHostFree(ts->h_counters);
     if (ts->h_debug) (void) hipHostFree(ts->h_debug);
     for (auto &kv : ts->windows) wt_free_windows(kv.second);
@@ -1333,7 +1370,7 @@ static int wt_build_index(wtamd_trackset *ts, WtWindows *w, const WtPlan &plan, 
 // The plan a reduction of `op` will run with first: the exact difference-array plan for Sum /
 // Mean over float tracks with zero defaults (until a window of this data proved inexact), else the
 // general bitmap plan.
-static inline int wt_delta_class(int op) { return op == WT_OP_TTEST ? 1 : 0; }
+static inline int wt_delta_class(int op) { return op == WT_OP_TTEST ? 1 : ((op == WT_OP_MAX || op == WT_OP_MIN) ? 2 : 0); }
 static bool wt_wants_delta(const wtamd_trackset *ts, int op) {
     return !ts->delta_failed_[wt_delta_class(op)] && wt_delta_eligible(op, ts->value_f64, ts->n_tracks, ts->defaults.data());
 }
@@ -1377,7 +1414,7 @@ int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
     if (!ts) return wt_fail(WTAMD_ERR_ARG, "ts == NULL");
     // an explicit re-index means the run lists may have been rewritten in place (zero-copy track
     // sets): what was learnt about their values is void, the next Sum / Mean verifies again
-    for (int q = 0; q < 2; q++) { ts->delta_verified_[q] = false; ts->delta_failed_[q] = false; ts->delta_n_bad_[q] = 0; }
+    for (int q = 0; q < 3; q++) { ts->delta_verified_[q] = false; ts->delta_failed_[q] = false; ts->delta_n_bad_[q] = 0; }
     for (auto &kv : ts->windows) kv.second.indexed = false;     // every width's index describes the old data
     if (!ts->owns && !ts->pipe_mode) {
         // zero-copy track set rewritten in place: its runs may start earlier / end later than
@@ -1549,6 +1586,10 @@ static int wt_launch_patch(wtamd_trackset *ts, int delta_W, int op, uint32_t fla
     } else if (op == WT_OP_MEAN) {
         if (plan.ppt == 4) { if (multi) WT_PATCH_GO(WT_OP_MEAN, 4, true); else WT_PATCH_GO(WT_OP_MEAN, 4, false); }
         else { if (multi) WT_PATCH_GO(WT_OP_MEAN, 1, true); else WT_PATCH_GO(WT_OP_MEAN, 1, false); }
+    } else if (op == WT_OP_MAX || op == WT_OP_MIN) {
+        if (plan.ppt != 4) return wt_fail(WTAMD_ERR_INTERNAL, "no general plan compatible with the difference-array windows");
+        if (op == WT_OP_MAX) { if (multi) WT_PATCH_GO(WT_OP_MAX, 4, true); else WT_PATCH_GO(WT_OP_MAX, 4, false); }
+        else { if (multi) WT_PATCH_GO(WT_OP_MIN, 4, true); else WT_PATCH_GO(WT_OP_MIN, 4, false); }
     } else if (op == WT_OP_TTEST) {
         if (plan.ppt != 4) return wt_fail(WTAMD_ERR_INTERNAL, "no general plan compatible with the difference-array windows");
         if (multi) WT_PATCH_GO(WT_OP_TTEST, 4, true); else WT_PATCH_GO(WT_OP_TTEST, 4, false);
@@ -1634,13 +1675,18 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
     L.gscratch = &ts->d_gscratch; L.gscratch_bytes = &ts->gscratch_bytes;
     if (op == WT_OP_MWU && !getenv("WTAMD_MWU_DEVICE_ERF")) {
         const int n1 = n_set0, n2 = ts->n_tracks - n_set0;
-        if (ts->mwu_n1 != n1 || ts->mwu_n2 != n2 || !ts->d_mwu_table) {
+        if (ts->mwu_n1 != n1 || ts->mwu_n2 != n2) {
+            // (a table per pair of set sizes; the previous pair's table may still be read by a launch in flight on ANY stream of
+            //  this track set: it is retired, not freed -- wtamd_trackset_destroy frees them all)
             std::vector<double> t;
-            wt_mwu_make_table(n1, n2, t);
-            if (ts->d_mwu_table) { WT_HIP(hipStreamSynchronize(s)); (void) hipFree(ts->d_mwu_table); ts->d_mwu_table = nullptr; }
-            WT_HIP(hipMalloc((void **) &ts->d_mwu_table, sizeof(double) * t.size()));
-            WT_HIP(hipMemcpy(ts->d_mwu_table, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
-            ts->mwu_n1 = n1; ts->mwu_n2 = n2; ts->mwu_kmax = (int) t.size() - 1;
+            const bool have = wt_mwu_make_table(n1, n2, t);
+            if (ts->d_mwu_table) { ts->mwu_retired.push_back(ts->d_mwu_table); ts->d_mwu_table = nullptr; }
+            if (have) {
+                WT_HIP(hipMalloc((void **) &ts->d_mwu_table, sizeof(double) * t.size()));
+                WT_HIP(hipMemcpyAsync(ts->d_mwu_table, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, s));
+                WT_HIP(hipStreamSynchronize(s));                // (t is a local)
+            }
+            ts->mwu_n1 = n1; ts->mwu_n2 = n2; ts->mwu_kmax = have ? (int) t.size() - 1 : 0;
         }
         L.P.mwu_table = ts->d_mwu_table;
         L.P.mwu_kmax = ts->mwu_kmax;
@@ -1670,6 +1716,8 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
             case WT_OP_VAR: wt_launch_delta<WT_OP_VAR>(L); break;
             case WT_OP_CV: wt_launch_delta<WT_OP_CV>(L); break;
             case WT_OP_TTEST: wt_launch_delta<WT_OP_TTEST>(L); break;
+            case WT_OP_MAX: wt_launch_delta<WT_OP_MAX>(L); break;
+            case WT_OP_MIN: wt_launch_delta<WT_OP_MIN>(L); break;
             default: wt_launch_delta<WT_OP_STDDEV>(L); break;      // stddev, entropy (reducers.c:665)
             }
         } else if (plan.walk_S) {

@@ -171,17 +171,18 @@ static size_t wt_pool_round(size_t bytes) {
 // (4 ms) and then registered (hipHostRegister: 2 ms -- 512 huge pages to pin instead of 262 144 small ones) costs 6 ms,
 // and the copy engine reads it at the same 57 GB/s.  Buffers of 2 MB and more take that route (WTAMD_PIN=malloc: the
 // old one); anything the runtime refuses falls back to hipHostMalloc.
-struct WtRegistered { void *base; size_t map_len; };
+struct WtRegistered { void *base; size_t map_len; size_t len; };   // the mapping (for munmap) and the page-locked bytes from the pointer handed out
 static std::mutex g_reg_mu;
 static std::map<void *, WtRegistered> g_registered;        // registered mappings, by the pointer handed out
 static std::atomic<int> g_reg_state{0};                      // 0 untried, 1 works, -1 does not (hipHostMalloc from then on)
+static std::atomic<int> g_reg_failures{0};                   // hipHostRegister refusals in a row (a transient one -- RLIMIT_MEMLOCK on one large buffer -- does not end the route)
 
 static bool wt_is_registered(const void *q) {
     std::lock_guard<std::mutex> lk(g_reg_mu);
     auto it = g_registered.upper_bound((void *) q);
     if (it == g_registered.begin()) return false;
     --it;
-    return (const char *) q < (const char *) it->second.base + it->second.map_len;
+    return (const char *) q < (const char *) it->first + it->second.len;       // (the mapping's alignment slack behind it is NOT page-locked)
 }
 
 static int wt_pin_threads() {
@@ -230,13 +231,16 @@ static bool wt_pin_by_register(void **out, size_t bytes) {
     if (!registered || hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || dp != (void *) p) {
         // (kernels of the pipe read and write the staging through the HOST address: it must be the device's too)
         (void) hipGetLastError();
+        // a host pointer that is not the device's: this runtime cannot do it, ever; a refused registration: maybe just this size, now
+        const bool never = registered;
         if (registered) (void) hipHostUnregister(p);
         munmap(base, len + huge);
-        g_reg_state.store(-1);
+        if (never || g_reg_failures.fetch_add(1) + 1 >= 3) g_reg_state.store(-1);
         return false;
     }
     g_reg_state.store(1);
-    { std::lock_guard<std::mutex> lk(g_reg_mu); g_registered[p] = WtRegistered{base, len + huge}; }
+    g_reg_failures.store(0);
+    { std::lock_guard<std::mutex> lk(g_reg_mu); g_registered[p] = WtRegistered{base, len + huge, len}; }
     *out = p;
     return true;
 }
@@ -295,7 +299,9 @@ static hipError_t wt_host_alloc(void **out, size_t bytes) {
         g_pinned_pool.misses++;
         g_pinned_pool.miss_bytes += bytes;
         static const bool trace = getenv("WTAMD_TRACE_POOL") != nullptr;
-        if (trace) fprintf(stderr, "[pool] page-locked %.1f MB (%s) in %.1f ms\n", bytes / 1048576.0, g_registered.count(*out) ? "mmap + hipHostRegister" : "hipHostMalloc",
+        bool by_register = false;
+        if (trace) { std::lock_guard<std::mutex> lk2(g_reg_mu); by_register = g_registered.count(*out) != 0; }
+        if (trace) fprintf(stderr, "[pool] page-locked %.1f MB (%s) in %.1f ms\n", bytes / 1048576.0, by_register ? "mmap + hipHostRegister" : "hipHostMalloc",
                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc0).count());
     }
     return e;
@@ -1063,7 +1069,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     ts->d_start = compacted ? s.d_mstart : s.d_start;
     ts->d_finish = compacted ? s.d_mfinish : s.d_finish;
     ts->d_value = mapped ? (void *) s.d_mvalue : s.d_value;
-    for (int q = 0; q < 2; q++) { ts->delta_failed_[q] = p->delta_failed; ts->delta_verified_[q] = false; ts->delta_n_bad_[q] = 0; }
+    for (int q = 0; q < 3; q++) { ts->delta_failed_[q] = p->delta_failed; ts->delta_verified_[q] = false; ts->delta_n_bad_[q] = 0; }
     for (auto &kv : ts->windows) { kv.second.tab_valid = false; kv.second.indexed = false; }
     int rc = wt_check_extents(ts);
     if (rc != WTAMD_OK) return rc;

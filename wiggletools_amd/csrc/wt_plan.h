@@ -176,7 +176,9 @@ static inline bool wt_delta_eligible(int op, bool value_f64, int n_tracks, const
         //  the whole reduction on the general kernel's f64 staging, wt_launch_patch)
         return !getenv("WTAMD_NO_DELTA_TTEST") && !value_f64 && n_tracks >= 8 && n_tracks <= 32767 && wt_defaults_fit_f32(defaults, n_tracks);
     }
-    if (op != WT_OP_SUM && op != WT_OP_MEAN && !sq) return false;
+    const bool mm = op == WT_OP_MAX || op == WT_OP_MIN;        // round 6: range updates of a segment tree (wt_delta.h); zero defaults only
+    if (mm && getenv("WTAMD_NO_DELTA_MINMAX")) return false;
+    if (op != WT_OP_SUM && op != WT_OP_MEAN && !sq && !mm) return false;
     if (sq && (n_tracks < 8 || getenv("WTAMD_NO_DELTA_VAR"))) return false;     // (the split square accumulators need N >= 8)
     // a handful of tracks: nothing to gain over the general kernel
     // (measured: 10 tracks 0.77 general vs 0.53 ms difference array; 100 tracks 2.05 vs 1.33)
@@ -189,7 +191,7 @@ static inline bool wt_delta_eligible(int op, bool value_f64, int n_tracks, const
     // only -- the squares of the var family count the tracks IN PLAY).  WTAMD_NO_DELTA_DEFAULTS: zero only.
     for (int i = 0; i < n_tracks; i++) {
         if (defaults[i] == 0.0) continue;
-        if (sq || getenv("WTAMD_NO_DELTA_DEFAULTS")) return false;
+        if (sq || mm || getenv("WTAMD_NO_DELTA_DEFAULTS")) return false;
         const float f = (float) defaults[i];
         if (!((double) f == defaults[i]) || !(f - f == 0.0f)) return false;       // not a float / NaN / Inf
     }
@@ -412,16 +414,26 @@ static inline bool wt_make_plan(int n_tracks, int op, bool scratch_f32, WtPlan &
 // MWUReduction's last step as a table (WtParams::mwu_table): entry k = the reference's value for |U1 - mu| = k / 2, computed
 // with the reference's own expression (setComparisons.c:361-366, mu and sigma from the constructor's C integer divisions,
 // :386-387) and THIS host's erf; the table ends where erf has reached -1 exactly (every larger k reads the last entry).
-static inline void wt_mwu_make_table(int n1, int n2, std::vector<double> &t) {
-    const double mu = (double) (n1 * n2 / 2);
-    const double sigma = sqrt((double) (n1 * n2 * (n1 + n2 + 1) / 12));
+// The constructor's products are C ints in the reference (n1 * n2 * (n1 + n2 + 1) overflows from ~1300 tracks per set on: undefined there);
+// here they wrap as two's-complement integers do, so host, emulator and oracle agree with each other whatever the sizes.
+static inline int wt_mwu_wrap_mul(int a, int b) { return (int) ((unsigned) a * (unsigned) b); }
+// Returns false when no table stands in for erf (the cap was reached before erf got to -1: sets so large that sigma is huge): the
+// caller leaves mwu_table NULL and the kernel calls erf itself.  sigma NaN (a product that wrapped negative) or 0: short tables
+// with the reference's own NaN / -2 results.
+static inline bool wt_mwu_make_table(int n1, int n2, std::vector<double> &t) {
+    const double mu = (double) (wt_mwu_wrap_mul(n1, n2) / 2);
+    const double sigma = sqrt((double) (wt_mwu_wrap_mul(wt_mwu_wrap_mul(n1, n2), (int) ((unsigned) n1 + (unsigned) n2 + 1u)) / 12));
     t.clear();
-    for (int k = 0; k < (1 << 20); k++) {
+    if (sigma != sigma) { t.push_back(sigma); return true; }        // every run NaN: erf(x / NaN)
+    const int cap = 1 << 20;
+    for (int k = 0; k < cap; k++) {
         const double U1 = mu + 0.5 * (double) k;            // (U1 > mu: the first branch; U1 < mu gives the same argument)
         const double v = k == 0 ? 2 * erf((U1 - mu) / sigma) : 2 * erf((mu - U1) / sigma);
         t.push_back(v);
-        if (v == -2.0) break;                               // (sigma == 0: entry 0 is NaN -- 0 / 0 -- and entry 1 already -2)
+        if (v == -2.0) return true;                         // (sigma == 0: entry 0 is NaN -- 0 / 0 -- and entry 1 already -2)
     }
+    t.clear();
+    return false;
 }
 
 static inline void wt_plan_to_params(const WtPlan &p, WtParams &P) {
