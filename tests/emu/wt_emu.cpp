@@ -469,5 +469,38 @@ long long wtemu_reduce(int n_chrom, int n_tracks, const int64_t *seg_off, const 
 double wtemu_tdist_2q_fast(double t, double nu) { return wt_tdist_2Q_fast(t, nu); }
 double wtemu_tdist_2q(double t, double nu) { return 2 * wt_tdist_Q(t, nu); }
 double wtemu_lgamma_half_diff(double a) { return wt_lgamma_half_diff(a); }
+// wt_div_n (csrc/wt_delta.h) against the division it stands in for: `cases` quotients per count n in [n_lo, n_hi], chosen to sit on and beside
+// the doubles' rounding boundaries (s = RN(n (m + h ulp)) for h in {0, 1/2} -+ a few ulp) and at random; returns the mismatches
+long long wtemu_div_n_mismatches(int n_lo, int n_hi, int cases, unsigned long long seed) {
+    long long bad = 0;
+    unsigned long long x = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (int n = n_lo; n <= n_hi; n++) {
+        const double dn = (double) n, y = 1.0 / dn;
+        for (int c = 0; c < cases; c++) {
+            const unsigned long long r = rnd();
+            const unsigned long long mant = (r & ((1ull << 52) - 1)) | (c % 7 == 0 ? ((1ull << 52) - 1) & ~((r >> 52) & 0xff) : 0ull) ;
+            const int e = (int) (rnd() % 300) - 150;
+            double m = ldexp(1.0 + (double) (mant & ((1ull << 52) - 1)) * 0x1p-52, e);
+            double s;
+            switch (c % 4) {
+            case 0: s = m; break;                                                   // any double
+            case 1: s = m * dn; break;                                              // a quotient next to a double
+            case 2: s = (m + ldexp(1.0, e - 53)) * dn; break;                       // ... next to a midpoint
+            default: s = (double) (long long) (rnd() >> 11) * ldexp(1.0, e - 60); break;    // an integer sum times a unit
+            }
+            for (int d = -2; d <= 2; d++) {
+                double t = s;
+                for (int q = 0; q < (d < 0 ? -d : d); q++) t = nextafter(t, d < 0 ? -INFINITY : INFINITY);
+                for (int sg = 0; sg < 2; sg++) {
+                    const double v = sg ? -t : t;
+                    const double a = wt_div_n(v, dn, y), b = v / dn;
+                    if (!(a == b) || std::signbit(a) != std::signbit(b)) bad++;
+                }
+            }
+        }
+    }
+    return bad;
+}
 
 }  // extern "C"

@@ -241,27 +241,71 @@ WT_DEV void wt_lds_sub64(unsigned long long *p, unsigned long long v) {      // 
     __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 WT_DEV int32_t wt_uniform32(int32_t x) { return (int32_t) __builtin_amdgcn_readfirstlane((unsigned) x); }
-// Wave-wide reductions by xor butterfly: every lane ends with the result.  (An LDS atomic issued by all 64
-// lanes is turned by hipcc into a scalar loop over the active lanes -- ~450 SALU instructions per atomic.)
-WT_DEV int32_t wt_wave_min_i32(int32_t x) {
-#pragma unroll
-    for (int dd = 32; dd; dd >>= 1) { const int32_t o = __shfl_xor(x, dd); x = o < x ? o : x; }
+// Wave-wide scans and reductions on DPP row shifts / row broadcasts (GFX9 has both): 6 cross-lane steps of one VALU
+// instruction each.  (Rounds 1-5 used __shfl_up / __shfl_xor: ds_bpermute_b32 -- an LDS-queue round trip per step, behind whatever
+// LDS traffic the wavefront had outstanding; 110 of them in wt_delta_kernel<mean>.  An LDS atomic issued by all 64 lanes is
+// turned by hipcc into a scalar loop over the active lanes -- ~450 SALU instructions per atomic -- hence reductions at all.)
+// All 64 lanes must be active.  `ID`: the operation's identity (what a lane without a source keeps).
+#define WT_DPP_STEP(x, id, ctrl, rows) (uint32_t) __builtin_amdgcn_update_dpp((int) (id), (int) (x), ctrl, rows, 0xf, false)
+template <class F>
+WT_DEV uint32_t wt_wave_scan32(uint32_t x, uint32_t id, F f) {     // inclusive
+    x = f(x, WT_DPP_STEP(x, id, 0x111, 0xf));        // row_shr:1
+    x = f(x, WT_DPP_STEP(x, id, 0x112, 0xf));        // row_shr:2
+    x = f(x, WT_DPP_STEP(x, id, 0x114, 0xf));        // row_shr:4
+    x = f(x, WT_DPP_STEP(x, id, 0x118, 0xf));        // row_shr:8
+    x = f(x, WT_DPP_STEP(x, id, 0x142, 0xa));        // row_bcast:15 -> rows 1, 3
+    x = f(x, WT_DPP_STEP(x, id, 0x143, 0xc));        // row_bcast:31 -> rows 2, 3
     return x;
+}
+WT_DEV unsigned long long wt_wave_scan_add64(unsigned long long x) {     // inclusive
+    auto step = [](unsigned long long v, int ctrl_rows) {
+        uint32_t lo = (uint32_t) v, hi = (uint32_t) (v >> 32), tl, th;
+        switch (ctrl_rows) {
+        case 0: tl = WT_DPP_STEP(lo, 0, 0x111, 0xf); th = WT_DPP_STEP(hi, 0, 0x111, 0xf); break;
+        case 1: tl = WT_DPP_STEP(lo, 0, 0x112, 0xf); th = WT_DPP_STEP(hi, 0, 0x112, 0xf); break;
+        case 2: tl = WT_DPP_STEP(lo, 0, 0x114, 0xf); th = WT_DPP_STEP(hi, 0, 0x114, 0xf); break;
+        case 3: tl = WT_DPP_STEP(lo, 0, 0x118, 0xf); th = WT_DPP_STEP(hi, 0, 0x118, 0xf); break;
+        case 4: tl = WT_DPP_STEP(lo, 0, 0x142, 0xa); th = WT_DPP_STEP(hi, 0, 0x142, 0xa); break;
+        default: tl = WT_DPP_STEP(lo, 0, 0x143, 0xc); th = WT_DPP_STEP(hi, 0, 0x143, 0xc); break;
+        }
+        return v + (((unsigned long long) th << 32) | tl);
+    };
+#pragma unroll
+    for (int q = 0; q < 6; q++) x = step(x, q);
+    return x;
+}
+WT_DEV uint32_t wt_wave_last32(uint32_t x) { return (uint32_t) __builtin_amdgcn_readlane((int) x, 63); }
+WT_DEV int32_t wt_wave_min_i32(int32_t x) {
+    return (int32_t) wt_wave_last32(wt_wave_scan32((uint32_t) x, 0x7fffffffu, [](uint32_t a, uint32_t b) { return (uint32_t) ((int32_t) b < (int32_t) a ? (int32_t) b : (int32_t) a); }));
 }
 WT_DEV uint32_t wt_wave_min_u32(uint32_t x) {
-#pragma unroll
-    for (int dd = 32; dd; dd >>= 1) { const uint32_t o = (uint32_t) __shfl_xor((int) x, dd); x = o < x ? o : x; }
-    return x;
+    return wt_wave_last32(wt_wave_scan32(x, 0xffffffffu, [](uint32_t a, uint32_t b) { return b < a ? b : a; }));
 }
 WT_DEV uint32_t wt_wave_max_u32(uint32_t x) {
-#pragma unroll
-    for (int dd = 32; dd; dd >>= 1) { const uint32_t o = (uint32_t) __shfl_xor((int) x, dd); x = o > x ? o : x; }
-    return x;
+    return wt_wave_last32(wt_wave_scan32(x, 0u, [](uint32_t a, uint32_t b) { return b > a ? b : a; }));
 }
 WT_DEV unsigned long long wt_wave_sum_u64(unsigned long long x) {
-#pragma unroll
-    for (int dd = 32; dd; dd >>= 1) x += (unsigned long long) __shfl_xor((long long) x, dd);
-    return x;
+    x = wt_wave_scan_add64(x);
+    return ((unsigned long long) wt_wave_last32((uint32_t) (x >> 32)) << 32) | wt_wave_last32((uint32_t) x);
+}
+// Sum of arr[first .. wave) for a workgroup's per-wavefront totals (at most 16 wavefronts: one row of lanes; `first`, `wave` uniform):
+// one LDS read per lane and four row shifts instead of a loop of up to fifteen dependent LDS round trips on the last wavefront
+// (round 6: that loop sat in every cross-wavefront prefix of the difference-array kernels' scans).  All 64 lanes active.
+WT_DEV uint32_t wt_waves_before32(const uint32_t *arr, int first, int wave, int lane) {
+    uint32_t v = (lane >= first && lane < wave) ? arr[lane & 15] : 0u;
+    v += WT_DPP_STEP(v, 0, 0x111, 0xf);
+    v += WT_DPP_STEP(v, 0, 0x112, 0xf);
+    v += WT_DPP_STEP(v, 0, 0x114, 0xf);
+    v += WT_DPP_STEP(v, 0, 0x118, 0xf);
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, 15);
+}
+WT_DEV unsigned long long wt_waves_before64(const unsigned long long *arr, int first, int wave, int lane) {
+    unsigned long long v = (lane >= first && lane < wave) ? arr[lane & 15] : 0ull;
+#define WT_ROW64(ctrl) do { const uint32_t tl_ = WT_DPP_STEP((uint32_t) v, 0, ctrl, 0xf), th_ = WT_DPP_STEP((uint32_t) (v >> 32), 0, ctrl, 0xf); \
+                            v += ((unsigned long long) th_ << 32) | tl_; } while (0)
+    WT_ROW64(0x111); WT_ROW64(0x112); WT_ROW64(0x114); WT_ROW64(0x118);
+#undef WT_ROW64
+    return ((unsigned long long) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (v >> 32), 15) << 32) | (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, 15);
 }
 WT_DEV bool wt_wave_leader(int lane) { return lane == 0; }
 WT_DEV unsigned long long wt_glb_add64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
@@ -1820,9 +1864,7 @@ WT_DEV void wt_lookback_complete(const WtParams &P, WtCtx &c, long long k, int l
         }
         const int p = pfx ? (int) wt_ctz64(pfx) : 63;
         unsigned long long part = (lane <= p) ? (v & WT_VAL_MASK) : 0ull;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) part += (unsigned long long) __shfl_xor((long long) part, d);
-        excl += part;
+        excl += wt_wave_sum_u64(part);
         if (pfx) break;
         base -= 64;
     }

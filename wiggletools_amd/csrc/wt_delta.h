@@ -688,6 +688,19 @@ WT_DEV void wt_delta_scan2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, 
     }
 }
 
+// s / n for an integer 1 <= n < 2^15 (the track count; `y` = 1.0 / n, correctly rounded), correctly rounded -- bit for bit the quotient the
+// reference computes (reducers.c:375-401: sum / count) in three instructions instead of the compiler's division sequence (two
+// v_div_scale, a quarter-rate v_rcp_f64, six fma, v_div_fmas, v_div_fixup: it is a fifth of the scan's arithmetic, round 6).
+//   q0 = RN(s y) is within two ulp of s / n;  r = s - n q0 is exact (a multiple of ulp(q0), at most 17 bits: one fma);
+//   q0 + r / n = s / n exactly, and q0 + r y differs from that by 2^-105 relative;  the quotient of a double by an integer below 2^15 is
+//   never closer than 2^-68 relative to the midpoint of two doubles, nor is it one (n m would need 54 bits or more), so
+//   RN(q0 + r y) = RN(s / n).  No underflow: |s| >= 2^-149 or 0, so |s / n| >= 2^-164.  tests/test_div_by_count.py, wtemu_div_n_mismatches.
+WT_DEV double wt_div_n(double s, double n, double y) {
+    const double q0 = s * y;
+    const double r = __builtin_fma(-n, q0, s);
+    return __builtin_fma(r, y, q0);
+}
+
 // scan step 3: running sum / coverage of every position, breakpoint and emitted bytes, run values
 template <int OP>
 WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtDeltaLane &L,
@@ -705,11 +718,13 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
         for (int x = grp * WT_DELTA_GROUP; x < tid; x++) { bqa += d.ltqa[x]; bqb += d.ltqb[x]; }
     }
 #else
-    for (int x = 0; x < (tid >> 6); x++) { bv += d.gtv[x]; bc += d.gtc[x]; }   // waves before this one (wt_delta_scan_w1)
+    bv += (long long) wt_waves_before64((const unsigned long long *) d.gtv, 0, tid >> 6, tid & 63);     // waves before this one (wt_delta_scan_w1)
+    bc += (int32_t) wt_waves_before32((const uint32_t *) d.gtc, 0, tid >> 6, tid & 63);
     bv += L.wv;
     bc += L.wc;
     if (QQ) {
-        for (int x = 0; x < (tid >> 6); x++) { bqa += d.gtqa[x]; bqb += d.gtqb[x]; }
+        bqa += wt_waves_before64(d.gtqa, 0, tid >> 6, tid & 63);
+        bqb += wt_waves_before64(d.gtqb, 0, tid >> 6, tid & 63);
         bqa += L.wqa;
         bqb += L.wqb;
     }
@@ -722,6 +737,7 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
     const long long room = (long long) c.sh->emit_hi - ((long long) c.sh->w0 + p0);
     uint32_t em = 0, evmask = 0;
     if constexpr (!QQ) evmask = L.evmask;
+    const double dn = (double) N, yn = 1.0 / dn;            // (Mean: wt_div_n)
 #pragma unroll
     for (int k = 0; k < WT_DELTA_K; k++) {
         if constexpr (!QQ) {
@@ -729,7 +745,7 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
             const bool pred = strict ? (cov == N) : (cov > 0);       // multiplexer.c:120,125
             if (((evmask >> k) & 1u) && pred && k < room) em |= 1u << k;
             const double s = (double) (bv + L.pv[k]) * q;
-            out.res[k] = (OP == WT_OP_MEAN) ? s / N : s;
+            out.res[k] = (OP == WT_OP_MEAN) ? wt_div_n(s, dn, yn) : s;
         } else {
             // the lane's 8 positions once more (scan 1 kept only their totals): running sums from the lane's base on
             const uint32_t e = d.ev[p0 + k];
@@ -892,7 +908,7 @@ WT_DEV void wt_delta_scan3_mm(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_
     for (int x = 0; x < grp; x++) bc += d.gtc[x];
     for (int x = grp * WT_DELTA_GROUP; x < tid; x++) bc += d.ltc[x];
 #else
-    for (int x = 0; x < (tid >> 6); x++) bc += d.gtc[x];
+    bc += (int32_t) wt_waves_before32((const uint32_t *) d.gtc, 0, tid >> 6, tid & 63);
     bc += wc;
 #endif
     const int N = P.n_tracks;
@@ -1016,7 +1032,13 @@ WT_DEV void wt_delta_scan3_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const 
     for (int x = grp0; x < grp; x++) { bv += d.gtv[x]; bc += d.gtc[x]; bqa += d.gtqa[x]; bqb += d.gtqb[x]; }
     for (int x = grp * WT_DELTA_GROUP; x < tid; x++) { bv += d.ltv[x]; bc += d.ltc[x]; bqa += d.ltqa[x]; bqb += d.ltqb[x]; }
 #else
-    for (int x = s * (nts >> 6); x < (tid >> 6); x++) { bv += d.gtv[x]; bc += d.gtc[x]; bqa += d.gtqa[x]; bqb += d.gtqb[x]; }   // the set's waves before this one
+    {   // the set's waves before this one
+        const int w0_ = s * (nts >> 6), w1_ = tid >> 6, ln_ = tid & 63;
+        bv += (long long) wt_waves_before64((const unsigned long long *) d.gtv, w0_, w1_, ln_);
+        bc += (int32_t) wt_waves_before32((const uint32_t *) d.gtc, w0_, w1_, ln_);
+        bqa += wt_waves_before64(d.gtqa, w0_, w1_, ln_);
+        bqb += wt_waves_before64(d.gtqb, w0_, w1_, ln_);
+    }
     bv += L.wv; bc += L.wc; bqa += L.wqa; bqb += L.wqb;
 #endif
     const int o = s * P.W + (tid - s * nts) * WT_DELTA_K;
@@ -1165,22 +1187,11 @@ WT_DEV void wt_delta_nextw(const WtParams &P, WtCtx &c, int tid, int nt) {
 // bound this kernel (dropping ONE barrier took the 100-track mean from 1.69 to 1.48 ms).  The
 // LDS-only versions above are what the CPU emulator executes (it has no lane shuffles).
 // ---------------------------------------------------------------------------
+// (wave-wide inclusive scans: DPP, wt_core.h)
 WT_DEV unsigned wt_wave_scan_u32(unsigned v, int lane) {
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const unsigned o = (unsigned) __shfl_up((int) v, dd);
-        if (lane >= dd) v += o;
-    }
-    return v;
+    return wt_wave_scan32(v, 0u, [](uint32_t a, uint32_t b) { return a + b; });
 }
-WT_DEV long long wt_wave_scan_i64(long long v, int lane) {
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        const long long o = __shfl_up(v, dd);
-        if (lane >= dd) v += o;
-    }
-    return v;
-}
+WT_DEV long long wt_wave_scan_i64(long long v, int lane) { return (long long) wt_wave_scan_add64((unsigned long long) v); }
 
 // ranges: lookup + wave-local exclusive prefix; the wave totals go to gtc[wave]
 WT_DEV void wt_delta_ranges_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c0, int tid, int nt, long long row, int chrom) {
@@ -1198,7 +1209,7 @@ WT_DEV void wt_delta_ranges_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c
 WT_DEV void wt_delta_ranges_w2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
     const int wave = tid >> 6;
     uint32_t pfx = d.tpfx[tid];
-    for (int x = 0; x < wave; x++) pfx += (uint32_t) d.gtc[x];
+    pfx += wt_waves_before32((const uint32_t *) d.gtc, 0, wave, tid & 63);
     const uint32_t n = (uint32_t) d.ltc[tid];
     d.tpfx[tid] = pfx;
     d.tbase[tid] -= 4ll * (long long) pfx;
@@ -1261,15 +1272,56 @@ WT_DEV unsigned wt_delta_escan_wave(const WtParams &P, WtCtx &c, int lane) {
     const unsigned incl0 = wt_wave_scan_u32(v0, lane);
     if (lane < P.n_words) c.epfx[lane + 1] = incl0;
     if (lane == 0) c.epfx[0] = 0;
-    unsigned total = (unsigned) __shfl((int) incl0, 63);
+    unsigned total = wt_wave_last32(incl0);
     if (P.n_words > 64) {
         const unsigned v1 = lane + 64 < P.n_words ? (unsigned) wt_popc64(c.E[lane + 64]) : 0u;
         const unsigned incl1 = wt_wave_scan_u32(v1, lane) + total;
         if (lane + 64 < P.n_words) c.epfx[lane + 65] = incl1;
-        total = (unsigned) __shfl((int) incl1, 63);
+        total = wt_wave_last32(incl1);
     }
     return total;
 }
+
+// ---------------------------------------------------------------------------
+// Round 6: Sum / Mean publish their run count BEFORE the values are computed.  The look-back of a window waits for its
+// predecessors to PUBLISH (8-11 % of a window), and a count needs only the coverage scan: scan 3 is split into the
+// breakpoint / emitted bytes (wt_delta_scan3_cov) -- then wave 0 scans the counts and publishes -- and the values
+// (wt_delta_scan3_val: the conversions and Mean's division), which the other wavefronts compute meanwhile and wave 0 right after.
+// ---------------------------------------------------------------------------
+WT_DEV void wt_delta_scan3_cov(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtDeltaLane &L, int tid, int nt) {
+    int32_t bc = d.dsh->base_c;
+    bc += (int32_t) wt_waves_before32((const uint32_t *) d.gtc, 0, tid >> 6, tid & 63);
+    bc += L.wc;
+    const int N = P.n_tracks;
+    const bool strict = (P.flags & WT_STRICT_SET0) != 0;
+    const int p0 = tid * WT_DELTA_K;
+    const long long room = (long long) c.sh->emit_hi - ((long long) c.sh->w0 + p0);
+    const uint32_t evmask = L.evmask;
+    uint32_t em = 0;
+#pragma unroll
+    for (int k = 0; k < WT_DELTA_K; k++) {
+        const int32_t cov = bc + L.pc[k];
+        const bool pred = strict ? (cov == N) : (cov > 0);       // multiplexer.c:120,125
+        if (((evmask >> k) & 1u) && pred && k < room) em |= 1u << k;
+    }
+    ((uint8_t *) c.U)[tid] = (uint8_t) evmask;
+    ((uint8_t *) c.E)[tid] = (uint8_t) em;
+}
+template <int OP>
+WT_DEV void wt_delta_scan3_val(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtDeltaLane &L, WtLane<WT_DELTA_K> &out, int emin, int tid, int nt) {
+    long long bv = d.dsh->base_v;
+    bv += (long long) wt_waves_before64((const unsigned long long *) d.gtv, 0, tid >> 6, tid & 63);
+    bv += L.wv;
+    const int N = P.n_tracks;
+    const double q = __builtin_bit_cast(double, (uint64_t) (emin - 150 + 1023) << 52);
+    const double dn = (double) N, yn = 1.0 / dn;            // (Mean: wt_div_n)
+#pragma unroll
+    for (int k = 0; k < WT_DELTA_K; k++) {
+        const double s = (double) (bv + L.pv[k]) * q;
+        out.res[k] = (OP == WT_OP_MEAN) ? wt_div_n(s, dn, yn) : s;
+    }
+}
+
 #endif
 
 #endif  // WT_DELTA_H_

@@ -209,6 +209,9 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
 #ifndef WT_DELTA_SQ_BLOCK
 #define WT_DELTA_SQ_BLOCK WT_DELTA_SQ_T0   // workgroup of the launches that also accumulate squares (768: three wavefronts per SIMD, 168 registers; the scans: the first 512 lanes, see wt_make_delta_plan)
 #endif
+#ifndef WT_DELTA_EARLY_PUBLISH
+#define WT_DELTA_EARLY_PUBLISH 1
+#endif
 #ifndef WT_DELTA_BLOCK
 #define WT_DELTA_BLOCK 1024     // (launch bound; the plan's default, see wt_make_delta_plan)
 #endif
@@ -223,6 +226,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
     constexpr bool QQ = WT_DELTA_SQ(OP);
     constexpr bool TT = OP == WT_OP_TTEST;      // two sets per position (wt_delta_scan3_tt)
     constexpr bool MM = OP == WT_OP_MAX || OP == WT_OP_MIN;     // range updates of a segment tree (wt_delta_apply_mm)
+    constexpr bool EP = WT_DELTA_EARLY_PUBLISH && (OP == WT_OP_SUM || OP == WT_OP_MEAN);       // the run count is published before the values are computed (wt_delta_scan3_cov / _val)
     WtDeltaLane DL;
     WtDeltaLane2 DL2;
     (void) DL; (void) DL2;
@@ -359,6 +363,13 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             WT_MARK(107);
             wt_delta_scan3_mm<OP == WT_OP_MAX>(P, c, d, wc_mm, L, tid, nt);
             __syncthreads();
+        } else if constexpr (EP) {
+            // Sum / Mean: the bytes of the breakpoint / emitted bitmaps first ...
+            wt_delta_scan_w1<QQ>(P, c, d, DL, tid, nts);
+            __syncthreads();
+            WT_MARK(107);
+            wt_delta_scan3_cov(P, c, d, DL, tid, nts);
+            __syncthreads();
         } else {
             if (WT_SCAN_LANE) wt_delta_scan_w1<QQ>(P, c, d, DL, tid, nts);
             __syncthreads();
@@ -376,6 +387,8 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             WT_TICK(5);
             if (tid == 0) wt_lookback_publish(P, c, k, mine);
         }
+        // ... the count is out; now the values (wt_delta_scan3_val: nobody waits for them but this window's own staging)
+        if constexpr (EP) wt_delta_scan3_val<OP>(P, c, d, DL, L, scale, tid, nts);
         wt_delta_nextw(P, c, tid, nt);
         __syncthreads();
         WT_MARK(110);

@@ -187,7 +187,7 @@ WT_DEV void wt_walk_ranges3(WtDeltaCtx &d, int tid, int nt) {
 WT_DEV void wt_walk_ranges_w2(WtDeltaCtx &d, int tid, int nt) {
     const int wave = tid >> 6;
     uint32_t pfx = d.tpfx[tid];
-    for (int x = 0; x < wave; x++) pfx += (uint32_t) d.gtc[x];
+    pfx += wt_waves_before32((const uint32_t *) d.gtc, 0, wave, tid & 63);
     const uint32_t n = (uint32_t) d.ltc[tid];
     d.tpfx[tid] = pfx;
     d.tbase[tid] -= 4ll * (long long) pfx;
