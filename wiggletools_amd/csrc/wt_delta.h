@@ -641,6 +641,42 @@ WT_DEV void wt_delta_rezero(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid,
     }
 }
 
+// A lane's 8 consecutive accumulator entries in registers.  On the device as 16-byte LDS reads (ds_read_b128): entry by entry the lanes of
+// a wavefront are 32 or 64 bytes apart and eight of them meet in every bank -- 16 LDS cycles per 8-byte read instead of 2; the wide reads
+// see a quarter of that (round 6: the scans' strided reads were 4 000 of a window's LDS cycles, a tenth of a sparse window's time).
+// `p`: 16-byte aligned (the arrays' offsets are multiples of 16, a lane's first entry is a multiple of 8).
+#ifdef WT_EMU
+WT_DEV void wt_lds_load8(const uint32_t *p, uint32_t (&v)[WT_DELTA_K]) { for (int k = 0; k < WT_DELTA_K; k++) v[k] = p[k]; }
+WT_DEV void wt_lds_load8(const unsigned long long *p, unsigned long long (&v)[WT_DELTA_K]) { for (int k = 0; k < WT_DELTA_K; k++) v[k] = p[k]; }
+#else
+WT_DEV void wt_lds_load8(const uint32_t *p, uint32_t (&v)[WT_DELTA_K]) {
+    typedef uint32_t wt_u32x4 __attribute__((ext_vector_type(4)));
+    const wt_u32x4 a = ((const wt_u32x4 *) p)[0], b = ((const wt_u32x4 *) p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+WT_DEV void wt_lds_load8(const unsigned long long *p, unsigned long long (&v)[WT_DELTA_K]) {
+    typedef unsigned long long wt_u64x2 __attribute__((ext_vector_type(2)));
+    const wt_u64x2 a = ((const wt_u64x2 *) p)[0], b = ((const wt_u64x2 *) p)[1], c = ((const wt_u64x2 *) p)[2], e = ((const wt_u64x2 *) p)[3];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y; v[6] = e.x; v[7] = e.y;
+}
+#endif
+#ifdef WT_EMU
+WT_DEV void wt_lds_load4(const uint32_t *p, uint32_t (&v)[4]) { for (int k = 0; k < 4; k++) v[k] = p[k]; }
+WT_DEV void wt_lds_load2(const uint32_t *p, uint32_t (&v)[2]) { v[0] = p[0]; v[1] = p[1]; }
+#else
+WT_DEV void wt_lds_load4(const uint32_t *p, uint32_t (&v)[4]) {     // (16-byte aligned)
+    typedef uint32_t wt_u32x4 __attribute__((ext_vector_type(4)));
+    const wt_u32x4 a = *(const wt_u32x4 *) p;
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+WT_DEV void wt_lds_load2(const uint32_t *p, uint32_t (&v)[2]) {     // (8-byte aligned)
+    typedef uint32_t wt_u32x2 __attribute__((ext_vector_type(2)));
+    const wt_u32x2 a = *(const wt_u32x2 *) p;
+    v[0] = a.x; v[1] = a.y;
+}
+#endif
+WT_DEV void wt_lds_load8(const long long *p, long long (&v)[WT_DELTA_K]) { wt_lds_load8((const unsigned long long *) p, (unsigned long long (&)[WT_DELTA_K]) v); }
+
 // scan step 1: the lane's 8 positions
 template <bool QQ = false>
 WT_DEV void wt_delta_scan1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLane &L, int tid, int nt) {
@@ -648,10 +684,14 @@ WT_DEV void wt_delta_scan1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLa
     long long rv = 0;
     int32_t rc = 0;
     uint32_t evm = 0;
+    uint32_t e8[WT_DELTA_K];
+    long long a8[WT_DELTA_K];
+    wt_lds_load8(d.ev + p0, e8);
+    wt_lds_load8(d.acc + p0, a8);
 #pragma unroll
     for (int k = 0; k < WT_DELTA_K; k++) {
-        const uint32_t e = d.ev[p0 + k];
-        rv += d.acc[p0 + k];
+        const uint32_t e = e8[k];
+        rv += a8[k];
         rc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
         if constexpr (!QQ) { L.pv[k] = rv; L.pc[k] = rc; evm |= (e != 0u ? 1u : 0u) << k; }
     }
@@ -662,8 +702,11 @@ WT_DEV void wt_delta_scan1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDeltaLa
     d.ltc[tid] = rc;
     if constexpr (QQ) {
         unsigned long long ra = 0, rb = 0;
+        unsigned long long qa8[WT_DELTA_K], qb8[WT_DELTA_K];
+        wt_lds_load8(d.qa + p0, qa8);
+        wt_lds_load8(d.qb + p0, qb8);
 #pragma unroll
-        for (int k = 0; k < WT_DELTA_K; k++) { ra += d.qa[p0 + k]; rb += d.qb[p0 + k]; }
+        for (int k = 0; k < WT_DELTA_K; k++) { ra += qa8[k]; rb += qb8[k]; }
         L.tqa = ra; L.tqb = rb;
         d.ltqa[tid] = ra; d.ltqb[tid] = rb;
     }
@@ -738,6 +781,15 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
     uint32_t em = 0, evmask = 0;
     if constexpr (!QQ) evmask = L.evmask;
     const double dn = (double) N, yn = 1.0 / dn;            // (Mean: wt_div_n)
+    uint32_t e8[QQ ? WT_DELTA_K : 1];
+    long long a8[QQ ? WT_DELTA_K : 1];
+    unsigned long long qa8[QQ ? WT_DELTA_K : 1], qb8[QQ ? WT_DELTA_K : 1];
+    if constexpr (QQ) {
+        wt_lds_load8(d.ev + p0, (uint32_t (&)[WT_DELTA_K]) e8);
+        wt_lds_load8(d.acc + p0, (long long (&)[WT_DELTA_K]) a8);
+        wt_lds_load8(d.qa + p0, (unsigned long long (&)[WT_DELTA_K]) qa8);
+        wt_lds_load8(d.qb + p0, (unsigned long long (&)[WT_DELTA_K]) qb8);
+    }
 #pragma unroll
     for (int k = 0; k < WT_DELTA_K; k++) {
         if constexpr (!QQ) {
@@ -748,10 +800,10 @@ WT_DEV void wt_delta_scan3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtD
             out.res[k] = (OP == WT_OP_MEAN) ? wt_div_n(s, dn, yn) : s;
         } else {
             // the lane's 8 positions once more (scan 1 kept only their totals): running sums from the lane's base on
-            const uint32_t e = d.ev[p0 + k];
-            bv += d.acc[p0 + k];
+            const uint32_t e = e8[k];
+            bv += a8[k];
             bc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
-            bqa += d.qa[p0 + k]; bqb += d.qb[p0 + k];
+            bqa += qa8[k]; bqb += qb8[k];
             evmask |= (e != 0u ? 1u : 0u) << k;
             const int32_t cov = bc;
             const bool pred = strict ? (cov == N) : (cov > 0);       // multiplexer.c:120,125
@@ -882,9 +934,11 @@ WT_DEV void wt_delta_pass_mm(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid
 WT_DEV void wt_delta_scan1_mm(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_t &tc, int tid, int nt) {
     const int p0 = tid * WT_DELTA_K;
     int32_t rc = 0;
+    uint32_t e8[WT_DELTA_K];
+    wt_lds_load8(d.ev + p0, e8);
 #pragma unroll
     for (int k = 0; k < WT_DELTA_K; k++) {
-        const uint32_t e = d.ev[p0 + k];
+        const uint32_t e = e8[k];
         rc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
     }
     tc = rc;
@@ -922,15 +976,21 @@ WT_DEV void wt_delta_scan3_mm(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int32_
     uint32_t top = ISMAX ? 0u : 0xffffffffu;
     for (uint32_t n = ((uint32_t) p0 + W) >> 3; n >= 1u; n >>= 1) top = best(top, tree[n]);
     uint32_t em = 0, evmask = 0;
+    uint32_t e8[WT_DELTA_K];
+    wt_lds_load8(d.ev + p0, e8);
+    // the lane's 8 leaves, their 4 parents and 2 grandparents: consecutive nodes, read wide (wt_lds_load8: the lanes are 8 nodes apart)
+    uint32_t lf[WT_DELTA_K], par[4], gp[2];
+    wt_lds_load8(tree + W + (uint32_t) p0, lf);
+    wt_lds_load4(tree + ((W + (uint32_t) p0) >> 1), par);
+    wt_lds_load2(tree + ((W + (uint32_t) p0) >> 2), gp);
 #pragma unroll
     for (int k = 0; k < WT_DELTA_K; k++) {
-        const uint32_t e = d.ev[p0 + k];
+        const uint32_t e = e8[k];
         bc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
         evmask |= (e != 0u ? 1u : 0u) << k;
         const bool pred = strict ? (bc == N) : (bc > 0);            // multiplexer.c:120,125
         if (e != 0u && pred && k < room) em |= 1u << k;
-        const uint32_t leaf = (uint32_t) (p0 + k) + W;
-        const uint32_t key = best(best(tree[leaf], tree[leaf >> 1]), best(tree[leaf >> 2], top));
+        const uint32_t key = best(best(lf[k], par[k >> 1]), best(gp[k >> 2], top));
         double v = (double) wt_unkey32(key);
         // a track that is not in play enters with its default, 0 (reducers.c:141-152; track 0: the seed, :143-146)
         if (bc < N) v = ISMAX ? (v < 0.0 ? 0.0 : v) : (v > 0.0 ? 0.0 : v);
@@ -976,13 +1036,20 @@ WT_DEV void wt_delta_scan1_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, WtDelt
     long long rv = 0;
     int32_t rc = 0;
     unsigned long long ra = 0, rb = 0;
+    uint32_t e8[WT_DELTA_K];
+    long long a8[WT_DELTA_K];
+    unsigned long long qa8[WT_DELTA_K], qb8[WT_DELTA_K];
+    wt_lds_load8(d.ev + o, e8);
+    wt_lds_load8(d.acc + o, a8);
+    wt_lds_load8(d.qa + o, qa8);
+    wt_lds_load8(d.qb + o, qb8);
 #pragma unroll
     for (int k = 0; k < WT_DELTA_K; k++) {
-        const uint32_t e = d.ev[o + k];
-        rv += d.acc[o + k];
+        const uint32_t e = e8[k];
+        rv += a8[k];
         rc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
-        ra += d.qa[o + k];
-        rb += d.qb[o + k];
+        ra += qa8[k];
+        rb += qb8[k];
     }
     L.tv = rv; L.tc = rc; L.tqa = ra; L.tqb = rb;
     d.ltv[tid] = rv;
@@ -1044,12 +1111,19 @@ WT_DEV void wt_delta_scan3_tt(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const 
     const int o = s * P.W + (tid - s * nts) * WT_DELTA_K;
     const double q = __builtin_bit_cast(double, (uint64_t) (emin - 150 + 1023) << 52);      // the weight of one unit of the scaled mantissas
     double *sum = (double *) d.acc, *sumsq = (double *) d.qa;
+    uint32_t e8[WT_DELTA_K];
+    long long a8[WT_DELTA_K];
+    unsigned long long qa8[WT_DELTA_K], qb8[WT_DELTA_K];
+    wt_lds_load8(d.ev + o, e8);
+    wt_lds_load8(d.acc + o, a8);
+    wt_lds_load8(d.qa + o, qa8);
+    wt_lds_load8(d.qb + o, qb8);
 #pragma unroll
     for (int k = 0; k < WT_DELTA_K; k++) {
-        const uint32_t e = d.ev[o + k];
-        bv += d.acc[o + k];
+        const uint32_t e = e8[k];
+        bv += a8[k];
         bc += (int32_t) (e & 0xffffu) - (int32_t) (e >> 16);
-        bqa += d.qa[o + k]; bqb += d.qb[o + k];
+        bqa += qa8[k]; bqb += qb8[k];
         // exact integers: S and Q = (A << 40) + B (see WT_DELTA_QSHIFT); S * q is the reference's sum whenever that did not round
         const unsigned __int128 Q = ((unsigned __int128) bqa << WT_DELTA_QSHIFT) + (unsigned __int128) bqb;
         sum[o + k] = (double) bv * q;
@@ -1120,6 +1194,11 @@ WT_DEV void wt_delta_load_res_tt(const WtParams &P, const WtDeltaCtx &d, WtLane<
 // positions needs the bitmap walk (round 3: the copying lanes used to walk it for every run -- three
 // dependent LDS round trips per run, 8 runs per lane).
 #define WT_DELTA_FAR 0xffffu
+// Where run number r of the window is staged: one spare entry after every 32 (round 6).  A lane's runs are consecutive, so at r itself the
+// lanes of a wavefront store 8 entries apart where breakpoints are dense: eight lanes to a bank, 32 LDS cycles per 8-byte store instead
+// of 6, and the staging was a twentieth of a window.  With the spare entries lane i's k-th store goes to bank (8 i + i / 4 + k) mod 32:
+// no two lanes of a group meet, and the copy-out still reads consecutive entries.  (acc[] / ev[] are W + W / 32 entries: wt_make_delta_plan)
+#define WT_STAGE_AT(r) ((r) + ((r) >> 5))
 template <int OP>
 WT_DEV void wt_delta_stage(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtLane<WT_DELTA_K> &L, int tid, int nt) {
     const unsigned em = ((const uint8_t *) c.E)[tid];
@@ -1140,11 +1219,41 @@ WT_DEV void wt_delta_stage(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtL
         if (!((em >> k) & 1u)) continue;
         const unsigned higher = k + 1 < WT_DELTA_K ? um >> (k + 1) : 0u;
         const uint32_t fin_rel = higher ? (uint32_t) (p0 + k + 1 + wt_ctz64((uint64_t) higher)) : after_rel;
-        sv[idx] = L.res[k];
-        sp[idx] = (uint32_t) (p0 + k) | (fin_rel << 16);
+        sv[WT_STAGE_AT(idx)] = L.res[k];
+        sp[WT_STAGE_AT(idx)] = (uint32_t) (p0 + k) | (fin_rel << 16);
         idx++;
     }
 }
+
+#ifndef WT_EMU
+// Sum / Mean on the device (round 6): the lane's emitted byte, breakpoint byte and rank come in registers (wt_delta_scan3_cov); the first
+// lane of each of the window's WT_BAD_SUB sub-ranges leaves its rank in epfx[32 + j] for wt_delta_note_offset_ep.
+template <int OP>
+WT_DEV void wt_delta_stage_ep(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtLane<WT_DELTA_K> &L, unsigned em, unsigned um, unsigned idx, int tid, int nt) {
+    const int per = nt / WT_BAD_SUB;
+    if (c.sh->bad_slot >= 0 && tid % per == 0) c.epfx[32 + tid / per] = idx;
+    if (!em) return;
+    const int p0 = tid * WT_DELTA_K;
+    const int32_t after = wt_next_breakpoint(P, c, p0 + WT_DELTA_K - 1);
+    const int32_t w0 = c.sh->w0;
+    const uint32_t after_rel = after < c.sh->w1 ? (uint32_t) (after - w0) : WT_DELTA_FAR;
+    double *sv = (double *) d.acc;
+    uint32_t *sp = d.ev;
+#pragma unroll
+    for (int k = 0; k < WT_DELTA_K; k++) {
+        if (!((em >> k) & 1u)) continue;
+        const unsigned higher = k + 1 < WT_DELTA_K ? um >> (k + 1) : 0u;
+        const uint32_t fin_rel = higher ? (uint32_t) (p0 + k + 1 + wt_ctz64((uint64_t) higher)) : after_rel;
+        sv[WT_STAGE_AT(idx)] = L.res[k];
+        sp[WT_STAGE_AT(idx)] = (uint32_t) (p0 + k) | (fin_rel << 16);
+        idx++;
+    }
+}
+WT_DEV void wt_delta_note_offset_ep(const WtParams &P, WtCtx &c, int lane) {
+    if (c.sh->bad_slot >= 0 && P.bad_goff && lane < WT_BAD_SUB)
+        P.bad_goff[(long long) c.sh->bad_slot * WT_BAD_SUB + lane] = c.sh->goffset + (long long) c.epfx[32 + lane];
+}
+#endif
 
 WT_DEV void wt_delta_copy_out(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
     const int n = c.sh->n_emit;
@@ -1154,7 +1263,7 @@ WT_DEV void wt_delta_copy_out(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int ti
     const uint32_t *sp = d.ev;
     unsigned long long bp = 0;
     for (int i = tid; i < n; i += nt) {
-        const uint32_t pf = sp[i];
+        const uint32_t pf = sp[WT_STAGE_AT((unsigned) i)];
         const int32_t st = w0 + (int32_t) (pf & 0xffffu);
         const int32_t fin = (pf >> 16) == WT_DELTA_FAR ? far : w0 + (int32_t) (pf >> 16);
         bp += (unsigned long long) (fin - st);
@@ -1162,7 +1271,7 @@ WT_DEV void wt_delta_copy_out(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int ti
         if (o >= P.capacity) continue;
         P.o_start[o] = st;
         P.o_finish[o] = fin;
-        P.o_value[o] = sv[i];
+        P.o_value[o] = sv[WT_STAGE_AT((unsigned) i)];
     }
     bp = wt_wave_sum_u64(bp);
     if (bp && wt_wave_leader(tid & 63)) wt_lds_add64(&c.sh->bp_sum, bp);
@@ -1288,7 +1397,10 @@ WT_DEV unsigned wt_delta_escan_wave(const WtParams &P, WtCtx &c, int lane) {
 // breakpoint / emitted bytes (wt_delta_scan3_cov) -- then wave 0 scans the counts and publishes -- and the values
 // (wt_delta_scan3_val: the conversions and Mean's division), which the other wavefronts compute meanwhile and wave 0 right after.
 // ---------------------------------------------------------------------------
-WT_DEV void wt_delta_scan3_cov(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtDeltaLane &L, int tid, int nt) {
+// (`em`: the lane's emitted byte; returns the emitted runs of the wavefront's lanes before this one; the wavefront's total goes to
+//  epfx[wave] -- the run-count scan over the 64-bit words of E, wt_delta_escan_wave, is not needed: a lane's rank is the sum of the
+//  wavefronts before it, wt_waves_before32, and this)
+WT_DEV uint32_t wt_delta_scan3_cov(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtDeltaLane &L, uint32_t &em_out, int tid, int nt) {
     int32_t bc = d.dsh->base_c;
     bc += (int32_t) wt_waves_before32((const uint32_t *) d.gtc, 0, tid >> 6, tid & 63);
     bc += L.wc;
@@ -1306,6 +1418,11 @@ WT_DEV void wt_delta_scan3_cov(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const
     }
     ((uint8_t *) c.U)[tid] = (uint8_t) evmask;
     ((uint8_t *) c.E)[tid] = (uint8_t) em;
+    em_out = em;
+    const uint32_t cnt = (uint32_t) wt_popc32(em);
+    const uint32_t incl = wt_wave_scan_u32(cnt, tid & 63);
+    if ((tid & 63) == 63) c.epfx[tid >> 6] = incl;
+    return incl - cnt;
 }
 template <int OP>
 WT_DEV void wt_delta_scan3_val(const WtParams &P, WtCtx &c, WtDeltaCtx &d, const WtDeltaLane &L, WtLane<WT_DELTA_K> &out, int emin, int tid, int nt) {

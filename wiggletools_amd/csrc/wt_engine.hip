@@ -209,6 +209,9 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
 #ifndef WT_DELTA_SQ_BLOCK
 #define WT_DELTA_SQ_BLOCK WT_DELTA_SQ_T0   // workgroup of the launches that also accumulate squares (768: three wavefronts per SIMD, 168 registers; the scans: the first 512 lanes, see wt_make_delta_plan)
 #endif
+#ifndef WT_DELTA_ZERO_EARLY
+#define WT_DELTA_ZERO_EARLY 1      // the accumulators are zeroed beside lane 0's ticket + header chain (0: at the window's start, rounds 1-5): -2 % at every density
+#endif
 #ifndef WT_DELTA_EARLY_PUBLISH
 #define WT_DELTA_EARLY_PUBLISH 1
 #endif
@@ -231,6 +234,8 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
     WtDeltaLane2 DL2;
     (void) DL; (void) DL2;
     WtLane<WT_DELTA_K> L;
+    uint32_t ep_rank = 0, ep_em = 0;        // EP: the lane's first rank among the window's emitted runs, its emitted byte
+    (void) ep_rank; (void) ep_em;
     const int tid = threadIdx.x, nt = blockDim.x;
     // lanes of the scans and the staging (8 positions each): all of them -- or, with squares, the first 512 of 1024.  (Sum / Mean must not
     // see a run-time bound here: the guard alone cost wt_delta_kernel<mean> 31 more spilled registers and a quarter more HBM traffic.)
@@ -250,6 +255,11 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
         c.sh->ticket = k0;
         if (k0 < P.n_windows) wt_phase_header(P, c, k0);
     }
+#if WT_DELTA_ZERO_EARLY
+    // (experiment: the accumulators are zeroed beside lane 0's ticket + header chain, before the barrier that publishes the header)
+    if constexpr (MM) wt_delta_zero_mm<OP == WT_OP_MAX>(P, c, d, tid, nt);
+    else wt_delta_zero<QQ, TT>(P, c, d, tid, nt);
+#endif
     __syncthreads();
     for (;;) {
         WT_MARK(101);
@@ -258,8 +268,10 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
         if (k >= P.n_windows) break;
         const int nchunks = (P.n_tracks + nt - 1) / nt;
         auto ntr = [&](int ch) { const int r = P.n_tracks - ch * nt; return r < nt ? r : nt; };     // tracks of chunk ch
+#if !WT_DELTA_ZERO_EARLY
         if constexpr (MM) wt_delta_zero_mm<OP == WT_OP_MAX>(P, c, d, tid, nt);
         else wt_delta_zero<QQ, TT>(P, c, d, tid, nt);
+#endif
         WT_TICK(0);
         WT_MARK(102);
         int scale = 1;
@@ -368,7 +380,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             wt_delta_scan_w1<QQ>(P, c, d, DL, tid, nts);
             __syncthreads();
             WT_MARK(107);
-            wt_delta_scan3_cov(P, c, d, DL, tid, nts);
+            ep_rank = wt_delta_scan3_cov(P, c, d, DL, ep_em, tid, nts);
             __syncthreads();
         } else {
             if (WT_SCAN_LANE) wt_delta_scan_w1<QQ>(P, c, d, DL, tid, nts);
@@ -382,13 +394,22 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
         // wave 0: run-count scan and look-back back to back (it owns the counts); the last lanes
         // build the breakpoint jump table meanwhile
         unsigned long long mine = 0;
-        if (tid < 64) {
+        if constexpr (EP) {
+            // the wavefronts' run counts are in epfx[0 .. nwaves): this one's first rank, and -- wave 0 -- the window's count, published at once
+            const int lane_ = tid & 63;
+            if (tid < 64) {
+                mine = wt_waves_before32(c.epfx, 0, nt >> 6, lane_);
+                WT_TICK(5);
+                if (tid == 0) wt_lookback_publish(P, c, k, mine);
+            }
+            ep_rank += wt_waves_before32(c.epfx, 0, tid >> 6, lane_);
+            // ... the count is out; now the values (wt_delta_scan3_val: nobody waits for them but this window's own staging)
+            wt_delta_scan3_val<OP>(P, c, d, DL, L, scale, tid, nts);
+        } else if (tid < 64) {
             mine = wt_delta_escan_wave(P, c, tid);
             WT_TICK(5);
             if (tid == 0) wt_lookback_publish(P, c, k, mine);
         }
-        // ... the count is out; now the values (wt_delta_scan3_val: nobody waits for them but this window's own staging)
-        if constexpr (EP) wt_delta_scan3_val<OP>(P, c, d, DL, L, scale, tid, nts);
         wt_delta_nextw(P, c, tid, nt);
         __syncthreads();
         WT_MARK(110);
@@ -396,7 +417,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
         // (and the predecessors get that much longer to publish)
         if (tid < 64) {
             wt_lookback_complete(P, c, k, tid, mine);
-            wt_delta_note_offset(P, c, tid);                // (lane 0 set the offset in the look-back: same wave, LDS in order)
+            if constexpr (!EP) wt_delta_note_offset(P, c, tid);     // (lane 0 set the offset in the look-back: same wave, LDS in order)
         }
         WT_TICK(6);
         if constexpr (TT) {
@@ -407,8 +428,10 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             WT_TICK(2);             // (profile builds: the tail, less the look-back, in the slot of the exponent-range pass)
             if (tid < nts) wt_delta_load_res_tt(P, d, L, tid);
         }
-        if (WT_SCAN_LANE) wt_delta_stage<OP>(P, c, d, L, tid, nts);
+        if constexpr (EP) wt_delta_stage_ep<OP>(P, c, d, L, ep_em, DL.evmask, ep_rank, tid, nts);
+        else if (WT_SCAN_LANE) wt_delta_stage<OP>(P, c, d, L, tid, nts);
         __syncthreads();
+        if constexpr (EP) { if (tid < 64) wt_delta_note_offset_ep(P, c, tid); }
 #ifdef WT_PROFILE_TAIL
         WT_TICK(2);                 // (experiment: the tail of a window apart -- staging here, copy-out in "write", ticket + header in "zero")
 #endif
@@ -424,6 +447,10 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             c.sh->ticket = kn;
             if (kn < P.n_windows) wt_phase_header(P, c, kn);
         }
+#if WT_DELTA_ZERO_EARLY
+        if constexpr (MM) wt_delta_zero_mm<OP == WT_OP_MAX>(P, c, d, tid, nt);
+        else wt_delta_zero<QQ, TT>(P, c, d, tid, nt);
+#endif
         __syncthreads();
 #ifdef WT_PROFILE_TAIL
         WT_TICK(0);

@@ -133,11 +133,11 @@ static inline void wt_make_delta_plan(WtPlan &p, int n_tracks, bool squares = fa
     p.T = T; p.ppt = WT_DELTA_K; p.W = WT_DELTA_K * TS; p.n_words = p.W / 64;
     p.chunk_tracks = 0; p.n_chunks = 1;
     int o = 0;
-    p.off_acc = o;    o = wt_align16(o + ns * p.W * 8);
-    p.off_ev = o;     o = wt_align16(o + ns * p.W * 4);
+    p.off_acc = o;    o = wt_align16(o + (ns * p.W + p.W / 32) * 8);      // (+ W / 32: the staged runs' spare entries, WT_STAGE_AT)
+    p.off_ev = o;     o = wt_align16(o + (ns * p.W + p.W / 32) * 4);
     p.off_U = o;      o = wt_align16(o + p.n_words * 8);
     p.off_E = o;      o = wt_align16(o + p.n_words * 8);
-    p.off_epfx = o;   o = wt_align16(o + (p.n_words + 1) * 4);
+    p.off_epfx = o;   o = wt_align16(o + std::max(p.n_words + 1, 48) * 4);    // (device, Sum / Mean: [0, 16) the wavefronts' run counts, [32, 48) the sub-ranges' ranks)
     p.off_nextw = o;  o = wt_align16(o + p.n_words * 2);
     p.off_ltv = o;    o = wt_align16(o + ns * TS * 8);
     p.off_ltc = o;    o = wt_align16(o + std::max(T, ns * TS) * 4);     // (the tracks' run counts AND the scan lanes' totals)
