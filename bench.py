@@ -1147,7 +1147,7 @@ def main():
 
         def sub(name, ops_, N_, chroms_, mean_run_, f64=False, cpu=True, moments=False, values="k8"):
             try:
-                r = measure(ctx, name, ops_, N_, chroms_, mean_run_, args.sub_steps, 1, f64=f64, want_moments=moments, values=values)
+                r = measure(ctx, name, ops_, N_, chroms_, mean_run_, args.sub_steps, 2, f64=f64, want_moments=moments, values=values)
                 if cpu and not args.no_cpu_baseline:
                     # (one evaluation thread, a 6 s sample: the many-core figure of these configurations is in DESIGN.md 5
                     #  from `bench.py --config c3 / c4 / c5`, which still measures it; the default line spends its minutes
