@@ -95,6 +95,31 @@ def test_lane_inflate_equals_zlib(emu_lib):
         emu_lib.wtemu_inflate(bytes(bad), len(bad), out.ctypes.data, len(raw), int(is_raw))
 
 
+def test_lane_inflate_literal_in_front_of_a_match(emu_lib):
+    """Round 6: a step emits a leading literal and the symbol behind it (csrc/wt_inflate.h WT_INF_LEAD).  The cases where the literal
+    matters to what follows: a match at distance 1 .. 4 right behind it (its source IS the literal, or the partial dword it completes),
+    at every alignment of the output position, lengths across the 7-byte first put, runs of literals, a literal before the end of a
+    block, and output space that ends between the literal and the symbol behind it."""
+    cases = []
+    for pre in range(0, 9):
+        for period in (1, 2, 3, 4):
+            for rep in (3, 4, 7, 8, 9, 15, 16, 17, 40, 258, 259, 600):
+                unit = bytes([65 + k for k in range(period)])
+                head = bytes([200 + (k * 7) % 50 for k in range(pre)])
+                cases.append(head + unit + unit * rep + b"Z" + unit[:1] * 5 + b"qrs")
+    cases += [b"a", b"ab", b"abc", b"aaaa", b"abababab", bytes(range(256)) * 3, b"\0" * 1000 + b"\1" + b"\0" * 1000]
+    for i, raw in enumerate(cases):
+        for level, strategy in ((1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_RLE), (6, zlib.Z_FIXED)):
+            co = zlib.compressobj(level, zlib.DEFLATED, 15, 8, strategy)
+            comp = co.compress(raw) + co.flush()
+            out = np.zeros(len(raw) + 8, np.uint8)
+            got = emu_lib.wtemu_inflate(comp, len(comp), out.ctypes.data, len(raw), 0)
+            assert got == len(raw) and out[:len(raw)].tobytes() == raw, (i, level, strategy, got, len(raw))
+            for short in (1, 2, 3):     # no room for the last bytes: a clean error whichever symbol of a step hits the end
+                if len(raw) > short:
+                    assert emu_lib.wtemu_inflate(comp, len(comp), out.ctypes.data, len(raw) - short, 0) == -6, (i, level, short)
+
+
 def _device_vs_host(L, oracle, tmp_path, monkeypatch, must_be_device=True):
     # C1 of BASELINE.json through the device decoder: the reference's own fixtures (type 3 and type 2 sections)
     paths = [os.path.join(G, "fixedStep.bw"), os.path.join(G, "variableStep.bw")]

@@ -80,6 +80,16 @@
 #define WT_INF_RING_DIST(R) (4 * (R) - 4)  // matches up to this distance are served from a ring of R dwords
 #define WT_INF_COPY 8           // match bytes copied per step
 #define WT_INF_FAR 16           // bytes of a match beyond the ring fetched by one load (5 dwords)
+// the chains of compares: lengths below K1 are compared for by every wavefront, K1 .. K2 - 1 and K2 .. 14 behind wave-uniform tests on the
+// codes' longest words (literal / length code, distance code)
+#ifndef WT_INF_LK1
+#define WT_INF_LK1 12
+#define WT_INF_LK2 13
+#endif
+#ifndef WT_INF_DK1
+#define WT_INF_DK1 9
+#define WT_INF_DK2 11
+#endif
 #ifndef WT_INF_LEAD
 #define WT_INF_LEAD 1           // a literal in front of a symbol is emitted by the same step (round 6)
 #endif
@@ -649,13 +659,13 @@ WT_HD void wt_inf_step(WtInflateT<RING> &z, const WtInfMem &m) {
     // (acc1) and leaves through the same put as the bytes behind it.
     const uint32_t wA = wt_inf_bitrev15((uint32_t) win0 & 0x7FFFu);
     uint32_t pkA;
-    const int lenA = wt_inf_code<12, 13>(wA, z.llim, z.lpk, z.lmax, pkA);
+    const int lenA = wt_inf_code<WT_INF_LK1, WT_INF_LK2>(wA, z.llim, z.lpk, z.lmax, pkA);
     const uint32_t idxA = (uint32_t) (((int32_t) pkA >> 16) + (int32_t) (wA >> (15 - lenA)));
     const uint32_t s8A = wt_inf_perm_get(m, idxA < (uint32_t) WT_INF_PERM ? idxA : 0u);
     const uint64_t winB = win0 >> lenA;
     const uint32_t wB = wt_inf_bitrev15((uint32_t) winB & 0x7FFFu);
     uint32_t pkB;
-    const int lenB = wt_inf_code<12, 13>(wB, z.llim, z.lpk, z.lmax, pkB);
+    const int lenB = wt_inf_code<WT_INF_LK1, WT_INF_LK2>(wB, z.llim, z.lpk, z.lmax, pkB);
     const uint32_t idxB = (uint32_t) (((int32_t) pkB >> 16) + (int32_t) (wB >> (15 - lenB)));
     const uint32_t s8B = wt_inf_perm_get(m, idxB < (uint32_t) WT_INF_PERM ? idxB : 0u);
     const bool lead = dec && idxA < (pkA & 0xFFFFu) && wA < z.llim[15] && z.out_pos < z.out_cap;
@@ -672,7 +682,7 @@ WT_HD void wt_inf_step(WtInflateT<RING> &z, const WtInfMem &m) {
     const uint64_t win = win0;
     const uint32_t w1 = wt_inf_bitrev15((uint32_t) win & 0x7FFFu);
     uint32_t pk;
-    const int len1 = wt_inf_code<12, 13>(w1, z.llim, z.lpk, z.lmax, pk);
+    const int len1 = wt_inf_code<WT_INF_LK1, WT_INF_LK2>(w1, z.llim, z.lpk, z.lmax, pk);
     const uint32_t idx = (uint32_t) (((int32_t) pk >> 16) + (int32_t) (w1 >> (15 - len1)));
     const uint32_t s8 = wt_inf_perm_get(m, idx < (uint32_t) WT_INF_PERM ? idx : 0u);
     const bool lead = false;
@@ -688,7 +698,7 @@ WT_HD void wt_inf_step(WtInflateT<RING> &z, const WtInfMem &m) {
     // branch below) -- the table read and this chain overlap instead of following each other
     uint32_t w2 = wt_inf_bitrev15((uint32_t) a1 & 0x7FFFu);
     int32_t da;
-    int len2 = wt_inf_code<9, 11>(w2, z.dlim, z.dadj, z.dmax, da);
+    int len2 = wt_inf_code<WT_INF_DK1, WT_INF_DK2>(w2, z.dlim, z.dadj, z.dmax, da);
     // ---- the symbol read as a length symbol 257 + ls
     const uint32_t ls = s8 - 1u;
     const bool l_ext = ls >= 8u && ls < 28u;
@@ -701,7 +711,7 @@ WT_HD void wt_inf_step(WtInflateT<RING> &z, const WtInfMem &m) {
     if (dec && !is_lit && l_ext) {                  // a length with extra bits: the distance code starts behind them
         a2 = a1 >> e;
         w2 = wt_inf_bitrev15((uint32_t) a2 & 0x7FFFu);
-        len2 = wt_inf_code<9, 11>(w2, z.dlim, z.dadj, z.dmax, da);
+        len2 = wt_inf_code<WT_INF_DK1, WT_INF_DK2>(w2, z.dlim, z.dadj, z.dmax, da);
     }
     const uint32_t di = (uint32_t) (da + (int32_t) (w2 >> (15 - len2)));
     const uint32_t word = di / 6u, dsh = 5u * (di - 6u * word);
