@@ -1176,6 +1176,9 @@ def main():
         others["product"] = sub("product", ["product"], 100, [20], args.mean_run, cpu=False)
         others["mean_f64_values"] = sub("mean/f64", ["mean"], 100, [20], args.mean_run, f64=True, cpu=False)
         others["sum_500"] = sub("sum/500", ["sum"], 500, [20], args.mean_run, cpu=False)
+        # C5's reducer on values without ties (real float signal rarely ties; the generator's 800 levels tie at nearly every position):
+        # the library samples the values and takes the walking kernel here, the register columns there (csrc/wt_engine.hip wt_mwu_few_ties)
+        others["wilcoxon_full_mantissa"] = sub("wilcoxon/full mantissas", ["wilcoxon"], 100, [20], args.mean_run, cpu=False, values="fullm")
         if rank == 0:
             res["configs"] = subs
             res["c2_runs"] = runs
@@ -1194,7 +1197,7 @@ def main():
             put("c2_l200_hbm_frac", runs.get("l200"), "frac")
             put("c2_full_mantissa_hbm_frac", runs.get("full_mantissa"), "frac")
             put("c2_patched_hbm_frac", runs.get("full_mantissa_patched"), "frac")
-            for name in ("max", "product", "mean_f64_values", "sum_500"):
+            for name in ("max", "product", "mean_f64_values", "sum_500", "wilcoxon_full_mantissa"):
                 put("%s_hbm_frac" % name, others.get(name), "frac")
     if rank == 0:
         res["bench_seconds"] = time.perf_counter() - t_start

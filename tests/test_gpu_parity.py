@@ -810,6 +810,26 @@ def test_gpu_difference_array_every_run_crosses_a_window_edge(oracle, engine):
     ts.close()
 
 
+@pytest.mark.gpu
+def test_gpu_mwu_kernel_by_the_values(oracle, engine):
+    """Round 6: MWUReduction's kernel follows the VALUES (csrc/wt_engine.hip wt_mwu_few_ties: 4096 of them sampled once per track set).
+    Values that are nearly all distinct -- equal values at one position are rare -- walk (csrc/wt_mwalk.h, kernel 3: 28.5 against 35.8 ms
+    on chromosome 21); the generator's few levels stay on the register columns (kernel 0: 35.8 against 43.8 ms).  Either way the
+    oracle's bits."""
+    from wiggletools_amd.runlists import synth
+    rng = np.random.default_rng(77)
+    for distinct, want in ((True, 3), (False, 0)):
+        t = synth(60, [90000, 1500], mean_run=12.0, seed=3, gap_prob=0.05, dtype=np.float32, value_levels=800)
+        if distinct:
+            t.value[:] = rng.normal(0, 5, len(t.value)).astype(np.float32)
+        ts = engine.TrackSet.from_runlists(t)
+        got = ts.reduce_host("mwu", n_set0=25)
+        assert ts.stats()["kernel"] == want, (distinct, ts.stats())
+        exp = oracle.reduce(t.as_dict(), "mwu", n_set0=25)
+        assert_runs_equal(got, exp, 0.0, "distinct values %s" % distinct)
+        ts.close()
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_gpu_mwu_walk_paths(oracle, engine, seed, monkeypatch):
     """MWUReduction by walking (csrc/wt_mwalk.h) on the device: the default plan, short stretches, slots too few for the data

@@ -995,6 +995,7 @@ struct wtamd_trackset {
     size_t gscratch_bytes = 0;
     double *d_mwu_table = nullptr;              // MWUReduction's last step as a table (wt_mwu_make_table), for set sizes mwu_n1 / mwu_n2
     int mwu_n1 = -1, mwu_n2 = -1, mwu_kmax = 0;
+    int mwu_few_ties = -1;                      // MWUReduction's kernel by the data (wt_mwu_few_ties): -1 not looked at yet, 1 walk (wt_mwalk.h), 0 register columns
     std::vector<double *> mwu_retired;          // tables of earlier set sizes (freed with the track set)
     std::map<int, WtWindows> windows;           // keyed by W
     hipEvent_t ev_i0 = nullptr, ev_i1 = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
@@ -1433,18 +1434,41 @@ static double wt_events_per_bp(const wtamd_trackset *ts) {
     return span > 0 ? 1.25 * (double) ts->n_intervals / span : 0.0;
 }
 
+// MWUReduction has two kernels, and which one is faster is a matter of the VALUES (round 6; chromosome 21, 50 v 50): the register
+// columns of the bitmap kernel sort every position from scratch, 35.8 ms whatever the values are; the walking kernel (wt_mwalk.h)
+// keeps its state from position to position and pays for every group of equal values across the two sets -- 28.5 ms on
+// full-mantissa values (no position has one), 43.8 ms on the generator's 800 levels (nearly every position has one).  So the
+// track set's values are SAMPLED once (4096 of them, evenly strided over the value column; one strided copy and a stream
+// synchronisation per track set and index epoch): when nearly all of the sample's values are distinct, equal values at one position are
+// rare and the walk is taken.  Real coverage signal with its many exact zeros and small integers stays on the register columns.
+// WTAMD_MWALK=1 / 0: always / never.  Both kernels are bit-identical on every input (tests/test_gpu_parity.py::test_gpu_mwu_walk_paths).
+static bool wt_mwu_few_ties(wtamd_trackset *ts, hipStream_t stream) {
+    if (ts->mwu_few_ties >= 0) return ts->mwu_few_ties != 0;
+    ts->mwu_few_ties = 0;
+    if (hipStreamSynchronize(stream) != hipSuccess) { (void) hipGetLastError(); return false; }      // (the values may still be on their way on this stream)
+    const int64_t n = ts->n_intervals;
+    if (n < 1024 || ts->value_f64 || !ts->d_value) return false;      // (a small sample says little: the register columns)
+    const int64_t S = std::min<int64_t>(4096, n), stride = n / S;
+    std::vector<uint32_t> v((size_t) S);
+    if (hipMemcpy2D(v.data(), 4, ts->d_value, (size_t) stride * 4, 4, (size_t) S, hipMemcpyDeviceToHost) != hipSuccess) { (void) hipGetLastError(); return false; }
+    std::sort(v.begin(), v.end());
+    const int64_t distinct = (int64_t) (std::unique(v.begin(), v.end()) - v.begin());
+    ts->mwu_few_ties = distinct * 100 >= S * 97 ? 1 : 0;
+    return ts->mwu_few_ties != 0;
+}
+
 // The general (non difference-array) plan: MedianReduction over float tracks walks (wt_walk.h), everything else
 // -- and the median with WTAMD_NO_WALK=1, or when a Multiplexer tile is wanted -- takes the bitmap kernel.
-static bool wt_pick_plan(const wtamd_trackset *ts, int op, int n_set0, WtPlan &plan, std::string &err) {
+static bool wt_pick_plan(wtamd_trackset *ts, int op, int n_set0, WtPlan &plan, std::string &err, hipStream_t stream = nullptr) {
     if (op == WT_OP_MEDIAN && !ts->value_f64 && !getenv("WTAMD_NO_WALK"))
         if (const int nr = wt_regcol_slots(ts->n_tracks, op, ts->scratch_f32, n_set0))
             if (wt_make_walk_plan(plan, ts->n_tracks, nr, wt_events_per_bp(ts))) return true;
-    // MWUReduction by walking (wt_mwalk.h) is built, bit-exact on every path and NOT the default: measured on MI355X it needs
+    // MWUReduction by walking (wt_mwalk.h): when the values say so (wt_mwu_few_ties) -- on the generator's 800 levels it needs
     // 284 wave-wide VALU instructions per output run where the bitmap kernel's register columns need 253 (chromosome 21:
-    // 43.9 against 35.6 ms; profiles/r05_mwu_walk_vs_bitmap.json).  WTAMD_MWALK=1 selects it
+    // 43.9 against 35.6 ms; profiles/r05_mwu_walk_vs_bitmap.json)
     // (same domain as the register columns, wt_regcol_slots: float tracks, float-exact defaults, at most 64 per set).
-    static const bool mwalk = getenv("WTAMD_MWALK") && atoi(getenv("WTAMD_MWALK")) != 0;
-    if (op == WT_OP_MWU && mwalk && !ts->value_f64 && !getenv("WTAMD_NO_WALK"))
+    static const int mwalk = getenv("WTAMD_MWALK") ? (atoi(getenv("WTAMD_MWALK")) != 0 ? 1 : 0) : -1;      // (-1: by the data)
+    if (op == WT_OP_MWU && mwalk != 0 && !ts->value_f64 && !getenv("WTAMD_NO_WALK") && (mwalk == 1 || wt_mwu_few_ties(ts, stream)))
         if (const int nr = wt_regcol_slots(ts->n_tracks, op, ts->scratch_f32, n_set0))
             if (wt_make_walk_plan(plan, ts->n_tracks, nr, wt_events_per_bp(ts), 160 * 1024, n_set0)) return true;
     return wt_make_plan(ts->n_tracks, op, ts->scratch_f32, plan, err, 80 * 1024, 160 * 1024, n_set0);
@@ -1455,6 +1479,7 @@ int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
     // an explicit re-index means the run lists may have been rewritten in place (zero-copy track
     // sets): what was learnt about their values is void, the next Sum / Mean verifies again
     for (int q = 0; q < 3; q++) { ts->delta_verified_[q] = false; ts->delta_failed_[q] = false; ts->delta_n_bad_[q] = 0; }
+    ts->mwu_few_ties = -1;
     for (auto &kv : ts->windows) kv.second.indexed = false;     // every width's index describes the old data
     if (!ts->owns && !ts->pipe_mode) {
         // zero-copy track set rewritten in place: its runs may start earlier / end later than
@@ -1469,7 +1494,7 @@ int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
     std::string err;
     if (wt_wants_delta(ts, op)) wt_make_delta_plan_for(plan, ts->n_tracks, op);
     // (two-sample ops: the index only depends on the window width; the usual even split is assumed)
-    else if (!wt_pick_plan(ts, op, ts->n_tracks / 2, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
+    else if (!wt_pick_plan(ts, op, ts->n_tracks / 2, plan, err, (hipStream_t) stream)) return wt_fail(WTAMD_ERR_ARG, err);
     WtWindows *w = nullptr;
     int rc = wt_get_windows(ts, plan.W, &w, (hipStream_t) stream);
     if (rc != WTAMD_OK) return rc;
@@ -1690,7 +1715,7 @@ static int wt_reduce_impl(wtamd_trackset *ts, int op, uint32_t flags, int n_set0
         }
         ts->delta_failed_[dc] = true;
     }
-    if (!wt_pick_plan(ts, op, n_set0, plan, err)) return wt_fail(WTAMD_ERR_ARG, err);
+    if (!wt_pick_plan(ts, op, n_set0, plan, err, s)) return wt_fail(WTAMD_ERR_ARG, err);
     return wt_reduce_plan(ts, plan, op, flags, n_set0, runs, d_tile, d_inplay, n_runs, s);
 }
 

@@ -1207,7 +1207,7 @@ static int wt_pipe_submit_impl(wtamd_pipe *p, int value_is_f64, int32_t range_lo
     if (s.used_delta) {
         wt_make_delta_plan_for(plan, N, op);
         s.delta_W = plan.W;
-    } else if (!wt_pick_plan(ts, op, p->cfg.desc.n_set0, plan, err)) {
+    } else if (!wt_pick_plan(ts, op, p->cfg.desc.n_set0, plan, err, p->s_comp)) {
         return wt_fail(WTAMD_ERR_ARG, err);
     }
     rc = wt_reduce_plan(ts, plan, op, p->cfg.desc.flags, p->cfg.desc.n_set0, &runs, p->tile ? s.d_tile : nullptr,
