@@ -42,6 +42,9 @@
 #define WT_DELTA_U 4            // flat interval indices per lane and tile (round 2, with the prefetch really in flight: 4 beats 8 by 4 % at 100 tracks, loses 1 % at 500; round 1 measured the opposite with the prefetch serialised)
 #endif
 #define WT_DELTA_TILE (64 * WT_DELTA_U)
+#ifndef WT_DELTA_ONE_TILE
+#define WT_DELTA_ONE_TILE 1     // a wavefront whose only tile this is applies it without the next tile's loads in front (round 6: mean run 200 -5.5 %; 0: as before)
+#endif
 #define WT_DELTA_TF 2048        // tiles whose first track is tabulated (beyond: binary search)
 #define WT_MAX_DELTA_T 1024     // largest workgroup of the difference-array kernels (an 8192-bp window)
 #define WT_DELTA_SQ_T0 768      // workgroup (and launch bound) of the launches with squares: 12 wavefronts share the passes, the first 8 run the scans
@@ -563,6 +566,11 @@ WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale
         WtDeltaPend<DF || TT> pn;
         pn.mask = 0ull; pn.s = 0; pn.f = 0; pn.b = 0u; pn.d[0] = 0u;
         wt_delta_fetch<DF, TT>(P, d, nt, M, tb, lane, A, c0);
+#if WT_DELTA_ONE_TILE
+        // a wavefront with ONE tile (sparse windows: a tile per wavefront or fewer) applies it without a second set of loads in front
+        if (tb + step >= M) wt_delta_apply_tile<QQ, DF, TT>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
+        else
+#endif
         for (;;) {
             wt_delta_fetch<DF, TT>(P, d, nt, M, tb + step, lane, B, c0);    // (past the end: harmless re-reads of the last tile)
             wt_delta_apply_tile<QQ, DF, TT>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
@@ -913,6 +921,10 @@ WT_DEV void wt_delta_pass_mm(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid
             }
         };
         wt_delta_fetch<false>(P, d, nt, M, tb, lane, A);
+#if WT_DELTA_ONE_TILE
+        if (tb + step >= M) apply(A, tb);
+        else
+#endif
         for (;;) {
             wt_delta_fetch<false>(P, d, nt, M, tb + step, lane, B);    // (past the end: harmless re-reads of the last tile)
             apply(A, tb);
