@@ -13,6 +13,7 @@ cd $R
 if [ -z "$SKIP_TESTS" ]; then
   timeout 1500 python -m pytest tests -q -m gpu > $OUT/gpu_tests.log 2>&1
   tail -1 $OUT/gpu_tests.log
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | cut -c1-300 | tee $OUT/smoke.log
 fi
 cd /tmp && export TMPDIR=/tmp
 COMMON="--steps 2 --warmup 1 --no-cpu-baseline --no-e2e --no-sub"
@@ -101,6 +102,13 @@ ks.update(kernels)
 json.dump({"kernels": ks}, open(tp, "w"), indent=1)
 json.dump({"kernels": ks}, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 PY
+# the file leg's kernels (chromosome 1 x 100 files): the inflate kernel's average per batch
+if [ -z "$SKIP_BW" ]; then
+  rm -rf /tmp/p_bw
+  WTAMD_E2E_REPS=2 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bw -- python $R/tools/e2e_bw_only.py 248.9 100 > $OUT/bw_stats_run.log 2>&1
+  f=$(find /tmp/p_bw -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp "$f" $OUT/bw_kernel_stats.csv && head -4 $OUT/bw_kernel_stats.csv | cut -c1-160
+fi
 cd $R
 if [ -z "$SKIP_BENCH" ]; then
   (time python bench.py --full-record $OUT/bench_default_full.json) > $OUT/bench_default.json 2> $OUT/bench_default.err
