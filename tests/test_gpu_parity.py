@@ -768,6 +768,34 @@ def test_gpu_difference_array_more_tracks_than_lanes(oracle, engine, case, monke
     ts.close()
 
 
+@pytest.mark.parametrize("T", ["64", "128"])
+def test_gpu_difference_array_smallest_workgroups(oracle, engine, T, monkeypatch):
+    """The difference-array kernels on one and two wavefronts per workgroup (WTAMD_DELTA_T = 64 / 128: 512- / 1024-bp windows): round 6's
+    per-wavefront run counts and sub-range ranks (epfx[0 .. 16), epfx[32 .. 48): a 512-bp window has 9 words of its own) and the staging's
+    spare entries; with a NaN and an Inf in the data the reduction falls back as a whole; Sum / Mean / Max / Min against the oracle at tolerance 0."""
+    from wiggletools_amd.runlists import synth
+    monkeypatch.setenv("WTAMD_DELTA_T", T)
+    monkeypatch.setenv("WTAMD_DELTA_MIN_TRACKS", "1")
+    rng = np.random.default_rng(int(T))
+    for bad in (False, True):
+        t = synth(30, [40000, 700], mean_run=6.0, seed=int(T) + bad, gap_prob=0.05, dtype=np.float32, value_levels=800)
+        t.value[:] = (t.value - 30).astype(np.float32)
+        if bad:
+            t.value[11] = np.nan
+            t.value[len(t.value) // 2] = np.inf
+        ts = engine.TrackSet.from_runlists(t)
+        for op in ("sum", "mean", "max", "min"):
+            for flags in (0, 1):
+                got = ts.reduce_host(op, flags=flags)
+                st = ts.stats()
+                if not bad:
+                    assert st["kernel"] == 1 and st["window_bp"] == 8 * int(T) and st["patched_windows"] == 0, st
+                # (windows to patch: the general kernel's windows are wider than these, so the whole reduction is the general kernel's --
+                #  wt_launch_patch: "no general plan compatible with the difference-array windows"; the result is the oracle's either way)
+                assert_runs_equal(got, oracle.reduce(t.as_dict(), op, flags=flags), 0.0, "T %s op %s flags %d bad %s" % (T, op, flags, bad))
+        ts.close()
+
+
 def test_gpu_c2_shape_long_runs(oracle, engine):
     """BASELINE config C2's shape (mean, 100 float tracks, 2 % gaps, values k / 8) at MEAN RUN 200 bp: an 8192-bp window
     of the default plan holds ~40 runs per track instead of 512 -- per-window fixed costs, window-base runs spanning
