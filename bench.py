@@ -673,7 +673,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
 
     def one_pass(pass_no, record):
         hot_s = 0.0
-        idx_ms = red_ms = 0.0
+        idx_ms = red_ms = red_call_ms = 0.0
         for c in my_items(pass_no):
             t0 = time.perf_counter()
             seg, s, f, v = synthgen.device_tracks(seed, [chrom_lens[c]], N, mean_run, 0.02, 800, device, chrom_ids=[c])
@@ -703,13 +703,22 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
                 ev[1 + 2 * j].record()
                 ts.reduce(op, out, n_set0=n_set0, stream=stream, sync=False)
                 ev[2 + 2 * j].record()
+                # THE KERNEL'S duration: the library's own HIP events, recorded on the launch stream immediately before and after the
+                # launch (csrc/wt_engine.hip ev_r0 / ev_r1: behind the memsets of the look-back words, around the kernel and -- when
+                # windows are patched -- its patch kernels); reading them waits for this launch.  The events of THIS file around the
+                # whole call also see the three memsets and the host's way from the record to the launch (Python, ctypes, plan, four
+                # API calls) while the stream stands still: 0.1-0.3 ms per launch, 5-10 % of C2's kernels (round 6:
+                # tools/experiments/r6_launch_gap.sh -- rocprofv3's kernel durations agree with the library's events).
+                st_j = ts.stats()
+                red_ms += st_j["reduce_ms"]
+                if j == 0:
+                    idx_ms += st_j["index_ms"]
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             # ---- untimed bookkeeping ----
             hot_s += dt
             for j in range(len(ops)):
-                idx_ms += ev[2 * j].elapsed_time(ev[1 + 2 * j])
-                red_ms += ev[1 + 2 * j].elapsed_time(ev[2 + 2 * j])
+                red_call_ms += ev[1 + 2 * j].elapsed_time(ev[2 + 2 * j])
             if record:
                 n_runs = ts.reduce(ops[-1], out, n_set0=n_set0, stream=stream, sync=True)
                 st = ts.stats()
@@ -727,27 +736,27 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
                     ts2.close()
             ts.close()
             del ts, out, s, f, v
-        return hot_s, idx_ms, red_ms
+        return hot_s, idx_ms, red_ms, red_call_ms
 
     for w in range(max(warmup, 0)):
         one_pass(-1 - w, False)
 
-    pass_s, idx_tot, red_tot = [], 0.0, 0.0
+    pass_s, idx_tot, red_tot, red_call_tot = [], 0.0, 0.0, 0.0
     for k in range(steps):
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-        hs, im, rm = one_pass(k, k == steps - 1)
+        hs, im, rm, rcm = one_pass(k, k == steps - 1)
         t = torch.tensor([hs], dtype=torch.float64, device=ctx.cdev)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)        # a pass is over when the slowest rank is
             dist.barrier()
         pass_s.append(float(t.item()))
-        idx_tot += im; red_tot += rm
+        idx_tot += im; red_tot += rm; red_call_tot += rcm
     elapsed = float(sum(pass_s))
 
     # genome-wide scalars (RCCL over xGMI when world > 1): sums by all_reduce, Pearson by all_gather + ordered merge
-    vec = torch.tensor([agg["bp"], agg["auc"], agg["runs"], agg["intervals"], agg["windows"], idx_tot, red_tot, gen_s[0]],
+    vec = torch.tensor([agg["bp"], agg["auc"], agg["runs"], agg["intervals"], agg["windows"], idx_tot, red_tot, gen_s[0], red_call_tot],
                        dtype=torch.float64, device=ctx.cdev)
     mom = torch.zeros((len(GRCH38), 6), dtype=torch.float64, device=ctx.cdev)
     for c, m in moments.items():
@@ -769,7 +778,7 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
         want[list(chrom_ids)] = 1 if not replicas else world
         queue_check = {"every_chromosome_exactly_once": bool((cnt == want).all()), "chromosomes_per_rank": [int(g.sum().item()) for g in got],
                        "how": "tickets from a counter in the rendezvous store" if store is not None and not replicas else ("replicas" if replicas else "static deal")}
-    tot_bp, tot_auc, tot_runs, tot_int, tot_win, idx_all, red_all, gen_all = [float(x) for x in vec.tolist()]
+    tot_bp, tot_auc, tot_runs, tot_int, tot_win, idx_all, red_all, gen_all, red_call_all = [float(x) for x in vec.tolist()]
     pearson = None
     if moments or use_dist:
         from wiggletools_amd import shard
@@ -868,6 +877,8 @@ def measure(ctx, name, ops, N, chrom_ids, mean_run, steps, warmup, scale=1.0, n_
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes, "launch": "the %d launches of one pass (one per chromosome%s)" % (len(per_item) * len(ops) if world == 1 else int(len(chrom_ids) * len(ops)), ", per reducer" if len(ops) > 1 else ""),
                      "kernel_ms": kernel_ms_sum, "index_kernel_ms": idx_all / passes,
+                     "reduce_call_ms": red_call_all / passes,     # stream events around the whole reduce call: + memsets + the host's launch path
+                     "timing": "HIP events on the launch stream immediately around every launch (the library's, read here); reduce_call_ms: events around the whole call",
                      "frac_with_index": alg_bytes / ((kernel_ms_sum + idx_all / passes) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "tile_equivalent_GBs": tile_equiv, "note": note, "issue": issue},
         "auc_check": tot_auc, "pearson_tracks_0_1": pearson, "output_runs": tot_runs, "work_queue_check": queue_check,
