@@ -42,6 +42,9 @@
 #define WT_DELTA_U 4            // flat interval indices per lane and tile (round 2, with the prefetch really in flight: 4 beats 8 by 4 % at 100 tracks, loses 1 % at 500; round 1 measured the opposite with the prefetch serialised)
 #endif
 #define WT_DELTA_TILE (64 * WT_DELTA_U)
+#ifndef WT_DELTA_COPY2
+#define WT_DELTA_COPY2 1
+#endif
 #ifndef WT_DELTA_ONE_TILE
 #define WT_DELTA_ONE_TILE 1     // a wavefront whose only tile this is applies it without the next tile's loads in front (round 6: mean run 200 -5.5 %; 0: as before)
 #endif
@@ -1274,6 +1277,32 @@ WT_DEV void wt_delta_copy_out(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int ti
     const double *sv = (const double *) d.acc;
     const uint32_t *sp = d.ev;
     unsigned long long bp = 0;
+#if !defined(WT_EMU) && WT_DELTA_COPY2
+    // two consecutive runs per lane and trip: 8- and 16-byte stores (4- / 8-byte aligned: the unaligned access mode of global memory) --
+    // half the store instructions of a phase that is bound by issuing them (round 6)
+    struct __attribute__((packed, aligned(4))) I2 { int32_t x[2]; };
+    struct __attribute__((packed, aligned(8))) D2 { double x[2]; };
+    for (int i = 2 * tid; i < n; i += 2 * nt) {
+        const unsigned a0 = WT_STAGE_AT((unsigned) i);          // (run i + 1 is staged right behind: i is even)
+        const bool two = i + 1 < n;
+        const uint32_t pf0 = sp[a0], pf1 = two ? sp[a0 + 1] : 0u;
+        const double v0 = sv[a0], v1 = two ? sv[a0 + 1] : 0.0;
+        const int32_t st0 = w0 + (int32_t) (pf0 & 0xffffu), st1 = w0 + (int32_t) (pf1 & 0xffffu);
+        const int32_t fin0 = (pf0 >> 16) == WT_DELTA_FAR ? far : w0 + (int32_t) (pf0 >> 16);
+        const int32_t fin1 = (pf1 >> 16) == WT_DELTA_FAR ? far : w0 + (int32_t) (pf1 >> 16);
+        bp += (unsigned long long) (fin0 - st0) + (two ? (unsigned long long) (fin1 - st1) : 0ull);
+        const long long o = goff + i;
+        if (two && o + 1 < P.capacity) {
+            I2 s2, f2; D2 d2;
+            s2.x[0] = st0; s2.x[1] = st1; f2.x[0] = fin0; f2.x[1] = fin1; d2.x[0] = v0; d2.x[1] = v1;
+            *(I2 *) (P.o_start + o) = s2;
+            *(I2 *) (P.o_finish + o) = f2;
+            *(D2 *) (P.o_value + o) = d2;
+        } else if (o < P.capacity) {
+            P.o_start[o] = st0; P.o_finish[o] = fin0; P.o_value[o] = v0;
+        }
+    }
+#else
     for (int i = tid; i < n; i += nt) {
         const uint32_t pf = sp[WT_STAGE_AT((unsigned) i)];
         const int32_t st = w0 + (int32_t) (pf & 0xffffu);
@@ -1285,6 +1314,7 @@ WT_DEV void wt_delta_copy_out(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int ti
         P.o_finish[o] = fin;
         P.o_value[o] = sv[WT_STAGE_AT((unsigned) i)];
     }
+#endif
     bp = wt_wave_sum_u64(bp);
     if (bp && wt_wave_leader(tid & 63)) wt_lds_add64(&c.sh->bp_sum, bp);
 }
