@@ -973,6 +973,10 @@ struct WtWindows {
     int64_t cap_chrom = 0, cap_win = 0, cap_widx = 0, cap_bad = 0, cap_cidx = 0;
     bool tab_valid = false;             // tab / device tables describe the track set's current data
     int64_t *h_tab = nullptr;           // pinned staging of the per-chromosome tables (pipeline slots: asynchronous upload)
+    // round 6: cbase | cnwin | chi | cfirst | win_chrom live in ONE allocation (d_tabs) and travel in ONE copy -- a NEW track set's first
+    // index paid five hipMallocs and five blocking copies for them, 0.1 ms of host time per chromosome of a resident pass
+    char *d_tabs = nullptr;
+    int64_t cap_tabs = 0;               // bytes
 };
 
 struct wtamd_trackset {
@@ -1031,7 +1035,7 @@ static hipError_t wt_grow(T **p, int64_t *cap, int64_t need) {
 }
 
 static void wt_free_windows(WtWindows &w) {
-    (void) hipFree(w.d_cbase); (void) hipFree(w.d_cnwin); (void) hipFree(w.d_chi); (void) hipFree(w.d_win_chrom); (void) hipFree(w.d_cfirst);
+    (void) hipFree(w.d_tabs);          // (d_cbase, d_cnwin, d_chi, d_cfirst, d_win_chrom point into it)
     (void) hipFree(w.d_widx); (void) hipFree(w.d_cidx); (void) hipFree(w.d_status); (void) hipFree(w.d_bad_list); (void) hipFree(w.d_bad_goff);
     if (w.h_tab) (void) hipHostFree(w.h_tab);
     w = WtWindows();
@@ -1287,20 +1291,25 @@ static int wt_get_windows(wtamd_trackset *ts, int W, WtWindows **out, hipStream_
     const int64_t nc = ts->n_chrom > 0 ? ts->n_chrom : 1;
     const int64_t nwin = w.tab.n_windows > 0 ? w.tab.n_windows : 1;
     const int64_t nwidx = (w.tab.n_rows > 0 ? w.tab.n_rows : 1) * (int64_t) ts->n_tracks;
-    if (w.cap_chrom < nc) {
-        (void) hipFree(w.d_cbase); (void) hipFree(w.d_cnwin); (void) hipFree(w.d_chi); (void) hipFree(w.d_cfirst);
-        w.d_cbase = w.d_cnwin = w.d_chi = nullptr; w.d_cfirst = nullptr; w.cap_chrom = 0;
-        WT_HIP(hipMalloc(&w.d_cbase, sizeof(int32_t) * nc));
-        WT_HIP(hipMalloc(&w.d_cnwin, sizeof(int32_t) * nc));
-        WT_HIP(hipMalloc(&w.d_chi, sizeof(int32_t) * nc));
-        WT_HIP(hipMalloc(&w.d_cfirst, sizeof(int64_t) * (nc + 1)));
-        w.cap_chrom = nc;
-    }
-    if (w.cap_win < nwin) {
-        int64_t c1 = w.cap_win, c2 = w.cap_win;
-        WT_HIP(wt_grow(&w.d_win_chrom, &c1, nwin));
-        WT_HIP(wt_grow(&w.d_status, &c2, nwin));
-        w.cap_win = c1 < c2 ? c1 : c2;
+    // layout of the combined table allocation (8-byte aligned pieces)
+    auto up8 = [](int64_t x) { return (x + 7) & ~(int64_t) 7; };
+    if (w.cap_chrom < nc || w.cap_win < nwin || !w.d_tabs) {
+        // (growing: twice the old capacity at least, as wt_grow does -- a pipeline slot's batches creep up, and every hipFree waits for the device)
+        const int64_t cc = w.cap_chrom < nc ? std::max<int64_t>(nc, 2 * w.cap_chrom) : w.cap_chrom;
+        const int64_t cw = w.cap_win < nwin ? std::max<int64_t>(nwin, 2 * w.cap_win) : w.cap_win;
+        const int64_t o_cnwin = up8(4 * cc), o_chi = o_cnwin + up8(4 * cc), o_cfirst = o_chi + up8(4 * cc), o_win = o_cfirst + 8 * (cc + 1);
+        const int64_t total = o_win + up8(4 * cw);
+        (void) hipFree(w.d_tabs);
+        w.d_tabs = nullptr; w.cap_tabs = 0;
+        w.d_cbase = w.d_cnwin = w.d_chi = w.d_win_chrom = nullptr; w.d_cfirst = nullptr;
+        if (w.cap_win < cw) { (void) hipFree(w.d_status); w.d_status = nullptr; }      // (cleared before every launch: its own allocation)
+        w.cap_chrom = 0; w.cap_win = 0;
+        WT_HIP(hipMalloc((void **) &w.d_tabs, (size_t) total));
+        if (!w.d_status) WT_HIP(hipMalloc((void **) &w.d_status, sizeof(unsigned long long) * (size_t) cw));
+        w.cap_tabs = total;
+        w.d_cbase = (int32_t *) w.d_tabs; w.d_cnwin = (int32_t *) (w.d_tabs + o_cnwin); w.d_chi = (int32_t *) (w.d_tabs + o_chi);
+        w.d_cfirst = (int64_t *) (w.d_tabs + o_cfirst); w.d_win_chrom = (int32_t *) (w.d_tabs + o_win);
+        w.cap_chrom = cc; w.cap_win = cw;
     }
     WT_HIP(wt_grow(&w.d_widx, &w.cap_widx, nwidx));
     WT_HIP(wt_grow(&w.d_cidx, &w.cap_cidx, ((w.tab.n_rows > 0 ? w.tab.n_rows : 1) + WT_ISEARCH_ROWS - 1) / WT_ISEARCH_ROWS * (int64_t) ts->n_tracks));
@@ -1317,11 +1326,15 @@ static int wt_get_windows(wtamd_trackset *ts, int W, WtWindows **out, hipStream_
             WT_HIP(hipMemcpyAsync(w.d_cfirst, w.h_tab + 2, 2 * sizeof(int64_t), hipMemcpyHostToDevice, s));
             WT_HIP(hipMemsetAsync(w.d_win_chrom, 0, sizeof(int32_t) * (size_t) nwin, s));
         } else {
-            WT_HIP(hipMemcpy(w.d_cbase, w.tab.cbase.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
-            WT_HIP(hipMemcpy(w.d_cnwin, w.tab.c_nwin.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
-            WT_HIP(hipMemcpy(w.d_chi, w.tab.c_hi.data(), sizeof(int32_t) * ts->n_chrom, hipMemcpyHostToDevice));
-            WT_HIP(hipMemcpy(w.d_cfirst, w.tab.c_first_win.data(), sizeof(int64_t) * (ts->n_chrom + 1), hipMemcpyHostToDevice));
-            WT_HIP(hipMemcpy(w.d_win_chrom, w.tab.win_chrom.data(), sizeof(int32_t) * w.tab.n_windows, hipMemcpyHostToDevice));
+            // one (blocking) copy of the five tables, packed as they lie on the device
+            const int64_t used = ((char *) w.d_win_chrom - w.d_tabs) + (int64_t) sizeof(int32_t) * std::max<int64_t>(w.tab.n_windows, 0);
+            std::vector<char> pack((size_t) used, 0);
+            memcpy(pack.data() + ((char *) w.d_cbase - w.d_tabs), w.tab.cbase.data(), sizeof(int32_t) * ts->n_chrom);
+            memcpy(pack.data() + ((char *) w.d_cnwin - w.d_tabs), w.tab.c_nwin.data(), sizeof(int32_t) * ts->n_chrom);
+            memcpy(pack.data() + ((char *) w.d_chi - w.d_tabs), w.tab.c_hi.data(), sizeof(int32_t) * ts->n_chrom);
+            memcpy(pack.data() + ((char *) w.d_cfirst - w.d_tabs), w.tab.c_first_win.data(), sizeof(int64_t) * (ts->n_chrom + 1));
+            if (w.tab.n_windows > 0) memcpy(pack.data() + ((char *) w.d_win_chrom - w.d_tabs), w.tab.win_chrom.data(), sizeof(int32_t) * w.tab.n_windows);
+            WT_HIP(hipMemcpy(w.d_tabs, pack.data(), (size_t) used, hipMemcpyHostToDevice));
         }
     }
     w.tab_valid = true;
