@@ -520,6 +520,29 @@ def test_emu_delta_everybody_parks(oracle):
         emu.use_variant(None)
 
 
+def test_emu_delta_small_tiles(oracle):
+    """wt_delta.h with 2 runs per lane and tile (-DWT_DELTA_U=2: what the device takes for Sum / Mean launches whose windows hold few
+    tiles per wavefront, wt_launch_delta; the emulator's default build has 4): the tile -> track table, the fetch's walk across track
+    boundaries and the partial last tile at the other tile size -- Sum / Mean / Max / Var with zero and non-zero defaults, many tracks with few
+    runs each (a tile spans several tracks) and few tracks with many, against the oracle at tolerance 0 (1e-12 for Var)."""
+    from wiggletools_amd.runlists import RunLists, synth
+    emu.use_variant("u2", ["-DWT_DELTA_U=2"])
+    try:
+        a = synth(300, [30000, 900], mean_run=400, gap_prob=0.05, seed=91)         # ~75 runs per track and window: tiles span tracks
+        b = synth(12, [60000], mean_run=3, gap_prob=0.02, seed=92)                   # many tiles per track
+        b2 = RunLists(b.n_chrom, b.n_tracks, b.seg_off, b.start, b.finish, b.value, np.where(np.arange(b.n_tracks) % 2 == 0, 0.75, 0.0))
+        for case, name in ((a, "sparse"), (b, "dense"), (b2, "dense, defaults")):
+            for op in ("sum", "mean", "max", "var"):
+                if name.endswith("defaults") and op in ("max", "var"):
+                    continue
+                for T in (1024, 64):
+                    got, info = emu.reduce(case, op, delta_T=T)
+                    assert info["delta"] == 1, info
+                    assert_runs_equal(got, oracle.reduce(case.as_dict(), op), 1e-12 if op == "var" else 0.0, "u2 %s %s T %d" % (name, op, T))
+    finally:
+        emu.use_variant(None)
+
+
 def test_emu_delta_squares_workgroup_sizes(oracle, monkeypatch):
     """The launches with squares: the passes over the runs are shared by ALL the workgroup's wavefronts, the scans are run by
     the first W / 8 = 512 lanes -- 768 lanes by default (round 5), any multiple of 64 from 512 to 768 through

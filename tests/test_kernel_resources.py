@@ -53,8 +53,9 @@ def kernels():
     return k
 
 
-def _delta(kernels, op, df):
-    name = "_Z15wt_delta_kernelILi%dELb%dEEv8WtParams" % (op, 1 if df else 0)
+def _delta(kernels, op, df, u=4):
+    """wt_delta_kernel<op, df, u>: u = runs per lane and tile of the pass (round 6: Sum / Mean also exist with 2)."""
+    name = "_Z15wt_delta_kernelILi%dELb%dELi%dEEv8WtParams" % (op, 1 if df else 0, u)
     assert name in kernels, [n for n in kernels if "delta" in n]
     return kernels[name]
 
@@ -64,10 +65,11 @@ def test_sum_mean_difference_array_kernels_fit_their_registers(kernels):
     once per window by every lane, and that traffic reaches HBM)."""
     for op in (0, 2):
         for df in (False, True):
-            k = _delta(kernels, op, df)
-            assert k["max_wg"] == 1024 and k["vgpr"] <= 128, k
-            assert k["spill"] <= (8 if df else 6), (op, df, k)
-            assert k["scratch"] <= 64, (op, df, k)
+            for u in (4, 2):
+                k = _delta(kernels, op, df, u)
+                assert k["max_wg"] == 1024 and k["vgpr"] <= 128, k
+                assert k["spill"] <= (8 if df else 6), (op, df, u, k)
+                assert k["scratch"] <= 64, (op, df, u, k)
 
 
 def test_squares_difference_array_kernels_spill_nothing(kernels):

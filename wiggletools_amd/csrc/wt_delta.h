@@ -218,7 +218,7 @@ WT_DEV void wt_delta_ranges2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid
     d.gtc[tid] = sc;
 }
 
-WT_DEV void wt_delta_ranges3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+WT_DEV void wt_delta_ranges3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt, uint32_t tile_runs = WT_DELTA_TILE) {
     const int grp = tid / WT_DELTA_GROUP;
     uint32_t pfx = 0;
     for (int x = 0; x < grp; x++) pfx += (uint32_t) d.gtc[x];
@@ -229,7 +229,7 @@ WT_DEV void wt_delta_ranges3(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid
     if (tid == nt - 1) d.tpfx[nt] = pfx + n;
     // first track of every tile of WT_DELTA_TILE flat indices (the slices partition the flat
     // space, so every tile start lies in exactly one non-empty slice)
-    for (uint32_t b = (pfx + WT_DELTA_TILE - 1) / WT_DELTA_TILE; b * WT_DELTA_TILE < pfx + n && b < WT_DELTA_TF; b++)
+    for (uint32_t b = (pfx + tile_runs - 1) / tile_runs; b * tile_runs < pfx + n && b < WT_DELTA_TF; b++)
         d.tfirst[b] = (uint16_t) tid;
 }
 
@@ -244,11 +244,12 @@ WT_DEV int wt_delta_find(const uint32_t *tpfx, int nt, uint32_t jj, int i) {
 }
 
 // byte offsets (into a 4-byte column) of the lane's WT_DELTA_U flat indices of tile `tb` (-1: past the end)
-WT_DEV void wt_delta_tile(const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, long long (&g)[WT_DELTA_U]) {
-    const uint32_t tile = tb / WT_DELTA_TILE;
+template <int U = WT_DELTA_U>
+WT_DEV void wt_delta_tile(const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, long long (&g)[U]) {
+    const uint32_t tile = tb / (64u * U);
     int i = tile < WT_DELTA_TF ? (int) d.tfirst[tile] : wt_delta_find(d.tpfx, nt, tb, 0);
 #pragma unroll
-    for (int u = 0; u < WT_DELTA_U; u++) {
+    for (int u = 0; u < U; u++) {
         const uint32_t jj = tb + (uint32_t) lane + 64u * (uint32_t) u;
         g[u] = -1;
         if (jj < M) {
@@ -260,29 +261,30 @@ WT_DEV void wt_delta_tile(const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, 
 
 // pass 1: exponent range of every value the window may use.  The loads of the wave's next tile
 // are issued before the current one is consumed (the passes are latency-, not bandwidth-bound).
+template <int U = WT_DELTA_U>
 WT_DEV void wt_delta_pass1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
     const int wave = tid >> 6, lane = tid & 63, nwaves = nt >> 6;
     const uint32_t *val = (const uint32_t *) P.value;
     const uint32_t M = d.tpfx[nt];
-    const uint32_t step = (uint32_t) nwaves * WT_DELTA_TILE;
+    const uint32_t step = (uint32_t) nwaves * (64u * U);
     int emin = 255, emax = 0, bad = 0;
-    uint32_t cur[WT_DELTA_U], nxt[WT_DELTA_U];
-    uint32_t tb = (uint32_t) wave * WT_DELTA_TILE;
+    uint32_t cur[U], nxt[U];
+    uint32_t tb = (uint32_t) wave * (64u * U);
     if (tb < M) {
-        long long g[WT_DELTA_U];
-        wt_delta_tile(d, nt, M, tb, lane, g);
+        long long g[U];
+        wt_delta_tile<U>(d, nt, M, tb, lane, g);
 #pragma unroll
-        for (int u = 0; u < WT_DELTA_U; u++) cur[u] = g[u] >= 0 ? *(const uint32_t *) ((const char *) val + g[u]) : 0u;
+        for (int u = 0; u < U; u++) cur[u] = g[u] >= 0 ? *(const uint32_t *) ((const char *) val + g[u]) : 0u;
     }
     for (; tb < M; tb += step) {
         if (tb + step < M) {
-            long long g[WT_DELTA_U];
-            wt_delta_tile(d, nt, M, tb + step, lane, g);
+            long long g[U];
+            wt_delta_tile<U>(d, nt, M, tb + step, lane, g);
 #pragma unroll
-            for (int u = 0; u < WT_DELTA_U; u++) nxt[u] = g[u] >= 0 ? *(const uint32_t *) ((const char *) val + g[u]) : 0u;
+            for (int u = 0; u < U; u++) nxt[u] = g[u] >= 0 ? *(const uint32_t *) ((const char *) val + g[u]) : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < WT_DELTA_U; u++) {
+        for (int u = 0; u < U; u++) {
             const int e = (int) ((cur[u] >> 23) & 0xffu);
             if (e == 0xff) bad = 1;
             if ((cur[u] & 0x7fffffffu) != 0u) {
@@ -292,7 +294,7 @@ WT_DEV void wt_delta_pass1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, 
             }
         }
 #pragma unroll
-        for (int u = 0; u < WT_DELTA_U; u++) cur[u] = nxt[u];
+        for (int u = 0; u < U; u++) cur[u] = nxt[u];
     }
     if (emin <= emax) { wt_lds_min32(&d.dsh->emin, emin); wt_lds_max32(&d.dsh->emax, emax); }
     if (bad) wt_lds_max32(&d.dsh->bad, 1);
@@ -459,11 +461,11 @@ WT_DEV void wt_delta_apply_or_park(WtDeltaCtx &d, WtCtx &c, WtDeltaPend<DF || TT
 }
 
 // the lane's WT_DELTA_U intervals of one tile (same software pipeline as pass 1)
-template <bool DF>
+template <bool DF, int U = WT_DELTA_U>
 struct WtDeltaBatch {
-    int32_t s[WT_DELTA_U], f[WT_DELTA_U];
-    uint32_t b[WT_DELTA_U];
-    uint32_t d[DF ? WT_DELTA_U : 1];    // DF: bits of the interval's track's default
+    int32_t s[U], f[U];
+    uint32_t b[U];
+    uint32_t d[DF ? U : 1];    // DF: bits of the interval's track's default
 };
 
 // The loads are UNCONDITIONAL and always in range: a flat index past the end is clamped to the last
@@ -474,18 +476,18 @@ struct WtDeltaBatch {
 // The track of a flat index: tfirst[] gives the tile's first one; the lane keeps the end of its
 // current slice and the slice's byte offset in registers and only walks tpfx[] when an index crosses it.
 // (TT: B.d[] carries the run's position offset -- 0 / W by the set of its track, slot i of the chunk starting at track c0)
-template <bool DF, bool TT = false>
-WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, WtDeltaBatch<DF || TT> &B, int c0 = 0) {
-    const uint32_t last = (M - 1u) / WT_DELTA_TILE * WT_DELTA_TILE;
+template <bool DF, bool TT = false, int U = WT_DELTA_U>
+WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint32_t M, uint32_t tb, int lane, WtDeltaBatch<DF || TT, U> &B, int c0 = 0) {
+    const uint32_t last = (M - 1u) / (64u * U) * (64u * U);
     const uint32_t tbe = tb < last ? tb : last;
-    const uint32_t tile = tbe / WT_DELTA_TILE;
+    const uint32_t tile = tbe / (64u * U);
     int i = tile < WT_DELTA_TF ? (int) d.tfirst[tile] : wt_delta_find(d.tpfx, nt, tbe, 0);
     uint32_t hi = d.tpfx[i + 1];
     long long dl = d.tbase[i];
     uint32_t db = DF ? d.tdef[i] : 0u;
     if (TT) db = c0 + i >= P.n_set0 ? (uint32_t) P.W : 0u;
 #pragma unroll
-    for (int u = 0; u < WT_DELTA_U; u++) {
+    for (int u = 0; u < U; u++) {
         uint32_t jj = tbe + (uint32_t) lane + 64u * (uint32_t) u;
         jj = jj < M - 1u ? jj : M - 1u;
         if (jj >= hi) {
@@ -508,31 +510,31 @@ WT_DEV void wt_delta_fetch(const WtParams &P, const WtDeltaCtx &d, int nt, uint3
 // tools/experiments/r5_delta_merged_atomics.patch, the record DESIGN 4.1.)
 
 // every interval of the tile at flat index `tb`; only the window's last tile can be partial
-template <bool QQ = false, bool DF = false, bool TT = false>
-WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF || TT> &B, uint32_t tb, uint32_t M, int lane, int32_t w0,
+template <bool QQ = false, bool DF = false, bool TT = false, int U = WT_DELTA_U>
+WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF || TT, U> &B, uint32_t tb, uint32_t M, int lane, int32_t w0,
                                 uint32_t width, int scale, bool ok, int32_t &my_next, WtDeltaRange &R, WtDeltaPend<DF || TT> &pn) {
     // WT_DELTA_PARK: 1 = the launches with squares park (their long branch is twice as long and, at 500 tracks and 4096-bp
     // windows, every second wave row took it: -10 %); Sum / Mean do not (C2 the same to 1 % on a fast box, 4 % slower under
     // the profiler on a slow one: two more spilled registers and 5 % more HBM traffic); 2 = everybody parks; 0 = nobody.
     if constexpr (WT_DELTA_PARK == 2 || (WT_DELTA_PARK == 1 && QQ)) {
-        if (tb + WT_DELTA_TILE <= M) {
+        if (tb + (64u * U) <= M) {
 #pragma unroll
-            for (int u = 0; u < WT_DELTA_U; u++)
+            for (int u = 0; u < U; u++)
                 wt_delta_apply_or_park<QQ, DF, TT>(d, c, pn, lane, true, w0, width, B.s[u], B.f[u], B.b[u], (DF || TT) ? B.d[u] : 0u, scale, ok, my_next, R);
         } else {
 #pragma unroll
-            for (int u = 0; u < WT_DELTA_U; u++)
+            for (int u = 0; u < U; u++)
                 wt_delta_apply_or_park<QQ, DF, TT>(d, c, pn, lane, tb + (uint32_t) lane + 64u * (uint32_t) u < M, w0, width, B.s[u], B.f[u], B.b[u],
                                                (DF || TT) ? B.d[u] : 0u, scale, ok, my_next, R);
         }
     } else {
-        if (tb + WT_DELTA_TILE <= M) {
+        if (tb + (64u * U) <= M) {
 #pragma unroll
-            for (int u = 0; u < WT_DELTA_U; u++)
+            for (int u = 0; u < U; u++)
                 wt_delta_apply<QQ, DF, TT>(d, c, w0, width, B.s[u], B.f[u], B.b[u], (DF || TT) ? B.d[u] : 0u, scale, ok, my_next, R);
         } else {
 #pragma unroll
-            for (int u = 0; u < WT_DELTA_U; u++)
+            for (int u = 0; u < U; u++)
                 if (tb + (uint32_t) lane + 64u * (uint32_t) u < M)
                     wt_delta_apply<QQ, DF, TT>(d, c, w0, width, B.s[u], B.f[u], B.b[u], (DF || TT) ? B.d[u] : 0u, scale, ok, my_next, R);
         }
@@ -544,14 +546,14 @@ WT_DEV void wt_delta_apply_tile(WtDeltaCtx &d, WtCtx &c, const WtDeltaBatch<DF |
 // speculative single-pass flavour, see wt_delta_window_verdict); `stats`: count the intervals;
 // `ntr`: tracks of this chunk (DF: their defaults go to the window's base).
 // `c0`: first track of the chunk (TT: the set of a track is a matter of its number).
-template <bool QQ = false, bool DF = false, bool TT = false>
+template <bool QQ = false, bool DF = false, bool TT = false, int U = WT_DELTA_U>
 WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale, bool ok, bool collect, bool stats,
                            int tid, int nt, int ntr = 0, int c0 = 0) {
     const int wave = wt_uniform32(tid >> 6), lane = tid & 63, nwaves = nt >> 6;     // (uniform: the tile tests stay scalar)
     const uint32_t M = (uint32_t) wt_uniform32((int32_t) d.tpfx[nt]);
     const int32_t w0 = wt_uniform32(c.sh->w0);
     const uint32_t width = (uint32_t) (wt_uniform32(c.sh->w1) - w0);
-    const uint32_t step = (uint32_t) nwaves * WT_DELTA_TILE;
+    const uint32_t step = (uint32_t) nwaves * (64u * U);
     int32_t my_next = 0x7fffffff;
     WtDeltaRange R;
     R.kmax = 0u; R.kmin = 0xffffffffu;
@@ -561,26 +563,26 @@ WT_DEV void wt_delta_pass2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int scale
         dsum = wt_wave_sum_u64(dsum);
         if (dsum && wt_wave_leader(lane)) wt_lds_add64((unsigned long long *) &d.dsh->base_v, dsum);
     }
-    uint32_t tb = (uint32_t) wave * WT_DELTA_TILE;
+    uint32_t tb = (uint32_t) wave * (64u * U);
     if (tb < M) {
         // two register sets take turns (a `cur = nxt` copy is 12 moves per tile, and it put the wait for the
         // prefetched tile at the end of the iteration that issued it)
-        WtDeltaBatch<DF || TT> A, B;
+        WtDeltaBatch<DF || TT, U> A, B;
         WtDeltaPend<DF || TT> pn;
         pn.mask = 0ull; pn.s = 0; pn.f = 0; pn.b = 0u; pn.d[0] = 0u;
-        wt_delta_fetch<DF, TT>(P, d, nt, M, tb, lane, A, c0);
+        wt_delta_fetch<DF, TT, U>(P, d, nt, M, tb, lane, A, c0);
 #if WT_DELTA_ONE_TILE
         // a wavefront with ONE tile (sparse windows: a tile per wavefront or fewer) applies it without a second set of loads in front
-        if (tb + step >= M) wt_delta_apply_tile<QQ, DF, TT>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
+        if (tb + step >= M) wt_delta_apply_tile<QQ, DF, TT, U>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
         else
 #endif
         for (;;) {
-            wt_delta_fetch<DF, TT>(P, d, nt, M, tb + step, lane, B, c0);    // (past the end: harmless re-reads of the last tile)
-            wt_delta_apply_tile<QQ, DF, TT>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
+            wt_delta_fetch<DF, TT, U>(P, d, nt, M, tb + step, lane, B, c0);    // (past the end: harmless re-reads of the last tile)
+            wt_delta_apply_tile<QQ, DF, TT, U>(d, c, A, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
             tb += step;
             if (tb >= M) break;
-            wt_delta_fetch<DF, TT>(P, d, nt, M, tb + step, lane, A, c0);
-            wt_delta_apply_tile<QQ, DF, TT>(d, c, B, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
+            wt_delta_fetch<DF, TT, U>(P, d, nt, M, tb + step, lane, A, c0);
+            wt_delta_apply_tile<QQ, DF, TT, U>(d, c, B, tb, M, lane, w0, width, scale, ok, my_next, R, pn);
             tb += step;
             if (tb >= M) break;
         }
@@ -1357,7 +1359,7 @@ WT_DEV void wt_delta_ranges_w1(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int c
     wt_delta_ranges_w1(P, c, d, c0, tid, nt, c.sh->row, c.sh->chrom);
 }
 
-WT_DEV void wt_delta_ranges_w2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt) {
+WT_DEV void wt_delta_ranges_w2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int tid, int nt, uint32_t tile_runs = WT_DELTA_TILE) {
     const int wave = tid >> 6;
     uint32_t pfx = d.tpfx[tid];
     pfx += wt_waves_before32((const uint32_t *) d.gtc, 0, wave, tid & 63);
@@ -1365,7 +1367,7 @@ WT_DEV void wt_delta_ranges_w2(const WtParams &P, WtCtx &c, WtDeltaCtx &d, int t
     d.tpfx[tid] = pfx;
     d.tbase[tid] -= 4ll * (long long) pfx;
     if (tid == nt - 1) d.tpfx[nt] = pfx + n;
-    for (uint32_t b = (pfx + WT_DELTA_TILE - 1) / WT_DELTA_TILE; b * WT_DELTA_TILE < pfx + n && b < WT_DELTA_TF; b++)
+    for (uint32_t b = (pfx + tile_runs - 1) / tile_runs; b * tile_runs < pfx + n && b < WT_DELTA_TF; b++)
         d.tfirst[b] = (uint16_t) tid;
 }
 

@@ -220,7 +220,8 @@ __global__ void __launch_bounds__(NR > 0 ? 256 : WT_MAX_BLOCK, NR > 0 ? (NR > 64
 #define WT_DELTA_BLOCK 1024     // (launch bound; the plan's default, see wt_make_delta_plan)
 #endif
 // DF: some track's default is non-zero (Sum / Mean; P.delta_df)
-template <int OP, bool DF = false>
+// U: runs per lane and tile of the pass (round 6: 4, or 2 for launches whose windows hold few tiles per wavefront -- wt_launch_delta)
+template <int OP, bool DF = false, int U = WT_DELTA_U>
 __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA_BLOCK, WT_DELTA_SQ(OP) ? 3 : WT_DELTA_MIN_WAVES) wt_delta_kernel(const WtParams P) {
     extern __shared__ __attribute__((aligned(16))) char wt_lds[];
     WtCtx c;
@@ -281,7 +282,7 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             for (int ch = 0; ch < nchunks; ch++) {
                 wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
                 __syncthreads();
-                wt_delta_ranges_w2(P, c, d, tid, nt);
+                wt_delta_ranges_w2(P, c, d, tid, nt, 64u * U);
                 __syncthreads();
                 WT_TICK(1);
                 wt_delta_pass_mm<OP == WT_OP_MAX>(P, c, d, tid, nt);
@@ -294,10 +295,10 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             for (int ch = 0; ch < nchunks; ch++) {
                 wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
                 __syncthreads();
-                wt_delta_ranges_w2(P, c, d, tid, nt);
+                wt_delta_ranges_w2(P, c, d, tid, nt, 64u * U);
                 __syncthreads();
                 WT_TICK(1);
-                wt_delta_pass1(P, c, d, tid, nt);
+                wt_delta_pass1<U>(P, c, d, tid, nt);
                 __syncthreads();
                 WT_TICK(2);
             }
@@ -308,10 +309,10 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
                 if (nchunks > 1) {
                     wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
                     __syncthreads();
-                    wt_delta_ranges_w2(P, c, d, tid, nt);
+                    wt_delta_ranges_w2(P, c, d, tid, nt, 64u * U);
                     __syncthreads();
                 }
-                wt_delta_pass2<QQ, DF, TT>(P, c, d, scale, ok, false, true, tid, nt, ntr(ch), ch * nt);
+                wt_delta_pass2<QQ, DF, TT, U>(P, c, d, scale, ok, false, true, tid, nt, ntr(ch), ch * nt);
                 __syncthreads();
                 WT_TICK(3);
             }
@@ -321,10 +322,10 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
             for (int ch = 0; ch < nchunks; ch++) {
                 wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
                 __syncthreads();
-                wt_delta_ranges_w2(P, c, d, tid, nt);
+                wt_delta_ranges_w2(P, c, d, tid, nt, 64u * U);
                 __syncthreads();
                 WT_TICK(1);
-                wt_delta_pass2<QQ, DF, TT>(P, c, d, guess, true, true, true, tid, nt, ntr(ch), ch * nt);
+                wt_delta_pass2<QQ, DF, TT, U>(P, c, d, guess, true, true, true, tid, nt, ntr(ch), ch * nt);
                 __syncthreads();
                 WT_TICK(3);
             }
@@ -346,10 +347,10 @@ __global__ void __launch_bounds__(WT_DELTA_SQ(OP) ? WT_DELTA_SQ_BLOCK : WT_DELTA
                     if (nchunks > 1) {
                         wt_delta_ranges_w1(P, c, d, ch * nt, tid, nt);
                         __syncthreads();
-                        wt_delta_ranges_w2(P, c, d, tid, nt);
+                        wt_delta_ranges_w2(P, c, d, tid, nt, 64u * U);
                         __syncthreads();
                     }
-                    wt_delta_pass2<QQ, DF, TT>(P, c, d, lo, ok, false, false, tid, nt, ntr(ch), ch * nt);
+                    wt_delta_pass2<QQ, DF, TT, U>(P, c, d, lo, ok, false, false, tid, nt, ntr(ch), ch * nt);
                     __syncthreads();
                 }
                 scale = lo;
@@ -1521,6 +1522,7 @@ int wtamd_trackset_index(wtamd_trackset *ts, int op, void *stream) {
 struct WtLaunch {
     WtParams P;
     int T = 0, lds = 0, grid = 0;
+    bool small_tiles = false;           // difference-array Sum / Mean: the pass in 128-run tiles (wt_launch_delta)
     hipStream_t stream = nullptr;
     int num_cu = 256;
     char **gscratch = nullptr;
@@ -1584,7 +1586,11 @@ hipError_t wt_walk_launch(WtParams &P, int nr, int T, int lds, int num_cu, char 
 
 template <int OP, bool DF = false>
 static void wt_launch_delta(WtLaunch &L) {
-    auto kern = wt_delta_kernel<OP, DF>;
+    // Sum / Mean: 128-run tiles when a window holds fewer than 8 of the 256-run ones per wavefront (round 6: the last round of tiles
+    // leaves wavefronts idle -- mean run 64: 50 tiles over 16 wavefronts, -6.5 % with the small ones; mean run 200 -2.5 %; mean run 16,
+    // 12.5 per wavefront: +1 %, so the large ones stay there).  WTAMD_DELTA_U=2 / 4 forces one.
+    constexpr bool TWO = OP == WT_OP_SUM || OP == WT_OP_MEAN;
+    auto kern = (TWO && L.small_tiles) ? wt_delta_kernel<OP, DF, TWO ? 2 : WT_DELTA_U> : wt_delta_kernel<OP, DF, WT_DELTA_U>;
     // (the attribute and the occupancy query once per instantiation, device and launch shape: they are host calls of 50-150 us each,
     //  and they sat between the event that starts the reduction's clock and the launch -- round 6: the bench's events read 0.12-0.28 ms
     //  more per launch than rocprofv3's kernel durations)
@@ -1595,7 +1601,7 @@ static void wt_launch_delta(WtLaunch &L) {
     int per_cu = 0;
     {
         std::lock_guard<std::mutex> lk(mu);
-        auto it = known.find(std::make_tuple(dev, L.T, L.lds));
+        auto it = known.find(std::make_tuple(dev, L.T + (L.small_tiles ? 1 : 0), L.lds));
         if (it != known.end()) per_cu = it->second;
     }
     if (per_cu == 0) {
@@ -1607,7 +1613,7 @@ static void wt_launch_delta(WtLaunch &L) {
         if (L.err != hipSuccess) return;
         if (per_cu < 1) per_cu = 1;
         std::lock_guard<std::mutex> lk(mu);
-        known[std::make_tuple(dev, L.T, L.lds)] = per_cu;
+        known[std::make_tuple(dev, L.T + (L.small_tiles ? 1 : 0), L.lds)] = per_cu;
     }
     long long g = (long long) L.num_cu * per_cu;
     if (g > L.P.n_windows) g = L.P.n_windows;
@@ -1803,6 +1809,12 @@ static int wt_reduce_plan(wtamd_trackset *ts, const WtPlan &plan, int op, uint32
     WT_HIP(hipMemsetAsync(L.P.chrom_run_off, 0, sizeof(int64_t) * (ts->n_chrom + 1), s));
     if (w->tab.n_windows > 0 && ts->n_intervals > 0) {
         WT_HIP(hipMemsetAsync(w->d_status, 0, sizeof(unsigned long long) * w->tab.n_windows, s));
+        if (plan.delta) {
+            // (tiles of 256 runs per wavefront and window, on average)
+            static const int force_u = getenv("WTAMD_DELTA_U") ? atoi(getenv("WTAMD_DELTA_U")) : 0;
+            const double tiles_per_wave = (double) ts->n_intervals / (double) w->tab.n_windows / 256.0 / (double) std::max(1, L.T / 64);
+            L.small_tiles = force_u == 2 || (force_u != 4 && tiles_per_wave < 8.0);
+        }
         WT_HIP(hipEventRecord(ts->ev_r0, s));
         if (plan.delta) {
             switch (op) {
