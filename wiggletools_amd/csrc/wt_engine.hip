@@ -1586,10 +1586,12 @@ hipError_t wt_walk_launch(WtParams &P, int nr, int T, int lds, int num_cu, char 
 
 template <int OP, bool DF = false>
 static void wt_launch_delta(WtLaunch &L) {
-    // Sum / Mean: 128-run tiles when a window holds fewer than 8 of the 256-run ones per wavefront (round 6: the last round of tiles
+    // 128-run tiles when a window holds fewer than 8 of the 256-run ones per wavefront (round 6: the last round of tiles
     // leaves wavefronts idle -- mean run 64: 50 tiles over 16 wavefronts, -6.5 % with the small ones; mean run 200 -2.5 %; mean run 16,
     // 12.5 per wavefront: +1 %, so the large ones stay there).  WTAMD_DELTA_U=2 / 4 forces one.
-    constexpr bool TWO = OP == WT_OP_SUM || OP == WT_OP_MEAN;
+    // (the t-test's 2048-bp windows: 50 tiles over 12 wavefronts, -6 % with the small ones; the variance family measured +-0 at mean run 16
+    //  and +2.5 % at 200 with them and keeps the large ones; Max / Min have a pass of their own, wt_delta_pass_mm)
+    constexpr bool TWO = OP == WT_OP_SUM || OP == WT_OP_MEAN || OP == WT_OP_TTEST;
     auto kern = (TWO && L.small_tiles) ? wt_delta_kernel<OP, DF, TWO ? 2 : WT_DELTA_U> : wt_delta_kernel<OP, DF, WT_DELTA_U>;
     // (the attribute and the occupancy query once per instantiation, device and launch shape: they are host calls of 50-150 us each,
     //  and they sat between the event that starts the reduction's clock and the launch -- round 6: the bench's events read 0.12-0.28 ms
